@@ -1,0 +1,164 @@
+/*
+ * tsd_hip.h -- C ABI of the MI355X (gfx950) implementation of ohm_tsd_slam's per-scan hot path.
+ *
+ * This is the drop-in boundary: three device entry points (push / raycast / icp, plus the fused
+ * localize) that replace the three places where the reference's worker threads enter the vendored
+ * "obviously" library, with the TSD grid resident in HBM between calls.  Plain pointers and sizes
+ * only; no C++/torch types.  Host pointers unless the name ends in _dev.  Every call returns
+ * TSD_OK (0), a negative TSD_E* code (argument / HIP failure; text via tsd_last_error), or -- for the
+ * registration calls -- fills `state` with the reference's EnumIcpState.  Nothing throws.
+ *
+ * Citations `file:line` are relative to the reference tree (autonohm/ohm_tsd_slam, src/).
+ * A tsd_ctx serialises its work on one HIP stream; distinct contexts are independent (one grid per
+ * GPU for the multi-robot case).  Calls on one ctx must not be issued concurrently from two threads
+ * (the C++ facade in ohm_tsd_slam_amd/csrc/host serialises them with a mutex).
+ */
+#ifndef TSD_HIP_H
+#define TSD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSD_OK            0
+#define TSD_E_ARG        -1   /* bad argument (null pointer, size out of range) */
+#define TSD_E_HIP        -2   /* a HIP runtime call failed; see tsd_last_error */
+#define TSD_E_NODEVICE   -3   /* no usable gfx950 device */
+#define TSD_E_BOUNDS     -4   /* freeFootprint rectangle outside the grid (TsdGrid.cpp:617-622) */
+#define TSD_E_CAPACITY   -5   /* more beams / points than the kernels are built for */
+
+#define TSD_TILE_DIM     32   /* SlamNode.cpp:77 hard-codes LAYOUT_32x32 */
+#define TSD_TILE_PITCH   33   /* 32 cells + 1 halo (TsdGridPartition.cpp:97) */
+#define TSD_TILE_CELLS   1089
+#define TSD_MAX_BEAMS    4096 /* scan staged in LDS by the push kernel */
+#define TSD_MAX_ICP_POINTS 2048 /* model/scene resident in LDS in the ICP kernel */
+
+/* EnumIcpState (obvision/registration/icp/Icp.h:25-32) */
+#define TSD_ICP_PROCESSING     1
+#define TSD_ICP_NOTMATCHABLE   2
+#define TSD_ICP_MAXITERATIONS  3
+#define TSD_ICP_SUCCESS        5
+
+typedef struct tsd_ctx tsd_ctx;
+
+/* Work counters of one TsdGrid::push (TsdGrid.cpp:217-284); the terms of the algorithmic-bytes
+ * formula of DESIGN.md are computed from these. */
+typedef struct {
+  int64_t cells_updated;        /* addTsd calls that passed sd >= -maxTruncation */
+  int64_t cells_visited;        /* back-projected cells (1024 per UPDATE tile) */
+  int32_t tiles_total;
+  int32_t tiles_range_pass;     /* passed both range tests of isInRange */
+  int32_t tiles_update;         /* isInRange() == true */
+  int32_t tiles_new;            /* lazily initialised by this push */
+  int32_t tiles_new_from_empty; /* ... of which _initWeight > 0 */
+  int32_t tiles_emptied_init;   /* increaseEmptiness() on an initialised tile */
+  int32_t tiles_emptied_uninit; /* increaseEmptiness() on an uninitialised tile */
+} tsd_push_stats;
+
+/* Registration set-up as ThreadLocalize builds it (ThreadLocalize.cpp:211-225, 571-581) */
+typedef struct {
+  int    iterations;            /* icp_iterations: Icp max iterations == convergence counter */
+  double dist_filter_max;       /* DistanceFilter(maxdist, mindist, icp_iterations - 10) */
+  double dist_filter_min;
+  double min_x, max_x, min_y, max_y; /* OutOfBoundsFilter2D = TsdGrid::getMin/MaxX/Y */
+} tsd_icp_params;
+
+typedef struct {
+  double T[9];                  /* Icp::getFinalTransformation() 3x3 row-major */
+  double rms;                   /* ClosedFormEstimator2D "rms" = mean squared pair distance */
+  int32_t pairs;                /* pairs of the last step */
+  int32_t iterations;           /* steps executed */
+  int32_t state;                /* EnumIcpState */
+  int32_t n_model;              /* valid model points (ray-cast hits)  -- tsd_localize only */
+  int32_t n_scene;              /* valid scene points                  -- tsd_localize only */
+  int32_t reserved;
+} tsd_icp_result;
+
+/* ---- life cycle ------------------------------------------------------------------------------ */
+int      tsd_device_count(void);
+/* new TsdGrid(cellSize, LAYOUT_32x32, map_size) + setMaxTruncation(max_trunc)
+ * (SlamNode.cpp:77-78, TsdGrid.cpp:112-169, :206-215).  NULL on failure. */
+tsd_ctx* tsd_create(int device, int map_size_log2, double cell_size, double max_trunc);
+void     tsd_destroy(tsd_ctx* ctx);
+int      tsd_reset(tsd_ctx* ctx);                          /* TsdGrid::reset (TsdGrid.cpp:194-198) */
+int      tsd_sync(tsd_ctx* ctx);
+const char* tsd_last_error(const tsd_ctx* ctx);
+
+/* ---- geometry getters (TsdGrid.h getCellsX, getCellSize, getMaxTruncation, getMinX.., getMaxX..) -- */
+int    tsd_cells(const tsd_ctx* ctx);
+int    tsd_tiles(const tsd_ctx* ctx);
+double tsd_cell_size(const tsd_ctx* ctx);
+double tsd_max_truncation(const tsd_ctx* ctx);
+double tsd_min_x(const tsd_ctx* ctx);
+double tsd_max_x(const tsd_ctx* ctx);
+double tsd_min_y(const tsd_ctx* ctx);
+double tsd_max_y(const tsd_ctx* ctx);
+
+/* ---- map update ------------------------------------------------------------------------------ */
+/* TsdGrid::freeFootprint (TsdGrid.cpp:609-638) */
+int tsd_free_footprint(tsd_ctx* ctx, const double center[2], double width, double height);
+
+/* TsdGrid::push(SensorPolar2D*) (TsdGrid.cpp:217-284): isInRange classification incl. the
+ * increaseEmptiness side effect (TsdGridComponent.cpp:43-124), lazy tile init
+ * (TsdGridPartition.cpp:88-134), addTsd (TsdGridPartition.h:170-212), propagateBorders
+ * (TsdGrid.cpp:372-427).  `ranges`/`mask` are the sensor's PROCESSED data (after setStandardMask:
+ * > max_range -> +inf, no NaN).  Asynchronous unless `stats` is non-NULL (then it waits and fills). */
+int tsd_push(tsd_ctx* ctx, const double pose33[9], const double* ranges, const uint8_t* mask,
+             int beams, double ang_res, double phi_min, double max_range, double min_range,
+             double low_refl_range, tsd_push_stats* stats);
+
+/* ---- localisation ---------------------------------------------------------------------------- */
+/* RayCastPolar2D::calcCoordsFromCurrentViewMask (RayCastPolar2D.cpp:113-192).  rays_world_2xB is
+ * Sensor::getNormalizedRayMap(cellSize): row 0 = x, row 1 = y of every beam's world ray of length
+ * cellSize.  Outputs are in the sensor frame; only hit slots are written. */
+int tsd_raycast(tsd_ctx* ctx, const double pose33[9], const double* rays_world_2xB, int beams,
+                double min_range, double max_range, double* coords_2B, double* normals_2B,
+                uint8_t* mask_B, int* n_valid);
+
+/* Icp::reset + setModel + setScene + iterate + getFinalTransformation with the assigner/filter/
+ * estimator chain of ThreadLocalize, registration_mode 0 (ThreadLocalize.cpp:571-581;
+ * Icp.cpp:410-512; PairAssignment.cpp:38-84; ClosedFormEstimator2D.cpp:36-109).  `pose33` is the
+ * sensor pose handed to OutOfBoundsFilter2D::setPose. */
+int tsd_icp(tsd_ctx* ctx, const double* model_xy, int n_model, const double* scene_xy, int n_scene,
+            const double pose33[9], const tsd_icp_params* params, tsd_icp_result* result);
+
+/* Fused body of ThreadLocalize::eventLoop between setStandardMask and isRegistrationError
+ * (ThreadLocalize.cpp:353-377): ray cast -> dataToCartesianVectorMask -> maskMatrix compaction ->
+ * doRegistration, without leaving the device.  rays_local_2xB = Sensor::_raysLocal. */
+int tsd_localize(tsd_ctx* ctx, const double pose33[9], const double* rays_world_2xB,
+                 const double* rays_local_2xB, const double* ranges, const uint8_t* mask, int beams,
+                 double min_range, double max_range, const tsd_icp_params* params,
+                 tsd_icp_result* result);
+
+/* ---- map I/O --------------------------------------------------------------------------------- */
+/* Canonical dump / restore of the tile state: initialized[tiles], init_weight[tiles],
+ * tsd[tiles][1089], weight[tiles][1089] (uninitialised tiles read back NaN / 0).  Logical content of
+ * TsdGrid::storeGrid / file ctor (TsdGrid.cpp:25-110, 548-607) plus the halo. */
+int tsd_download_tiles(tsd_ctx* ctx, uint8_t* initialized, double* init_weight, double* tsd,
+                       double* weight);
+int tsd_upload_tiles(tsd_ctx* ctx, const uint8_t* initialized, const double* init_weight,
+                     const double* tsd, const double* weight);
+/* tile flags only (cheap) */
+int tsd_download_tile_state(tsd_ctx* ctx, uint8_t* initialized, double* init_weight);
+
+/* Occupancy map of ThreadGrid::eventLoop (ThreadGrid.cpp:72-118) built from
+ * RayCastAxisAligned2D::calcCoords (RayCastAxisAligned2D.cpp:13-105): int8 cells*cells,
+ * -1 unknown / 0 free / 100 occupied.  The map persists inside the ctx between calls like
+ * ThreadGrid::_occGridContent.  The _dev form writes to a device pointer (e.g. a torch tensor that is
+ * then max-all-reduced over RCCL). */
+int tsd_occupancy(tsd_ctx* ctx, int8_t* occ_host, int inflate, int inflate_factor, int* n_surface);
+int tsd_occupancy_dev(tsd_ctx* ctx, void* occ_dev, int inflate, int inflate_factor);
+
+/* ---- measurement ----------------------------------------------------------------------------- */
+/* Per-kernel HIP-event timing on the ctx stream.  Kernel names: "push_classify", "push_update",
+ * "push_halo", "raycast", "icp", "occupancy". */
+int tsd_profile_enable(tsd_ctx* ctx, int on);
+int tsd_profile_reset(tsd_ctx* ctx);
+int tsd_profile_get(tsd_ctx* ctx, const char* kernel, double* total_ms, int* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSD_HIP_H */

@@ -1,0 +1,287 @@
+"""ctypes binding of the C ABI in ``include/tsd_hip.h`` (``lib/libtsd_hip.so``).
+
+This is plumbing for the Python test / bench drivers; the product is the HIP library itself and the
+C++ facade in ``csrc/host``.  There is no CPU fall-back: importing works without a GPU (so the ABI can
+be checked), but every compute call needs a gfx950 device and raises :class:`TsdError` otherwise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtsd_hip.so")
+
+TILE_CELLS = 1089
+MAX_BEAMS = 4096
+MAX_ICP_POINTS = 2048
+
+ICP_STATE = {1: "PROCESSING", 2: "NOTMATCHABLE", 3: "MAXITERATIONS", 5: "SUCCESS"}
+
+
+class TsdError(RuntimeError):
+    pass
+
+
+class PushStats(C.Structure):
+    _fields_ = [
+        ("cells_updated", C.c_int64),
+        ("cells_visited", C.c_int64),
+        ("tiles_total", C.c_int32),
+        ("tiles_range_pass", C.c_int32),
+        ("tiles_update", C.c_int32),
+        ("tiles_new", C.c_int32),
+        ("tiles_new_from_empty", C.c_int32),
+        ("tiles_emptied_init", C.c_int32),
+        ("tiles_emptied_uninit", C.c_int32),
+    ]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class IcpParams(C.Structure):
+    _fields_ = [
+        ("iterations", C.c_int),
+        ("dist_filter_max", C.c_double),
+        ("dist_filter_min", C.c_double),
+        ("min_x", C.c_double),
+        ("max_x", C.c_double),
+        ("min_y", C.c_double),
+        ("max_y", C.c_double),
+    ]
+
+
+class IcpResult(C.Structure):
+    _fields_ = [
+        ("T", C.c_double * 9),
+        ("rms", C.c_double),
+        ("pairs", C.c_int32),
+        ("iterations", C.c_int32),
+        ("state", C.c_int32),
+        ("n_model", C.c_int32),
+        ("n_scene", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+# every symbol include/tsd_hip.h declares: name -> (restype, argtypes)
+_dp = C.POINTER(C.c_double)
+_u8p = C.POINTER(C.c_uint8)
+_i8p = C.POINTER(C.c_int8)
+_ip = C.POINTER(C.c_int)
+ABI = {
+    "tsd_device_count": (C.c_int, []),
+    "tsd_create": (C.c_void_p, [C.c_int, C.c_int, C.c_double, C.c_double]),
+    "tsd_destroy": (None, [C.c_void_p]),
+    "tsd_reset": (C.c_int, [C.c_void_p]),
+    "tsd_sync": (C.c_int, [C.c_void_p]),
+    "tsd_last_error": (C.c_char_p, [C.c_void_p]),
+    "tsd_cells": (C.c_int, [C.c_void_p]),
+    "tsd_tiles": (C.c_int, [C.c_void_p]),
+    "tsd_cell_size": (C.c_double, [C.c_void_p]),
+    "tsd_max_truncation": (C.c_double, [C.c_void_p]),
+    "tsd_min_x": (C.c_double, [C.c_void_p]),
+    "tsd_max_x": (C.c_double, [C.c_void_p]),
+    "tsd_min_y": (C.c_double, [C.c_void_p]),
+    "tsd_max_y": (C.c_double, [C.c_void_p]),
+    "tsd_free_footprint": (C.c_int, [C.c_void_p, _dp, C.c_double, C.c_double]),
+    "tsd_push": (C.c_int, [C.c_void_p, _dp, _dp, _u8p, C.c_int, C.c_double, C.c_double, C.c_double,
+                           C.c_double, C.c_double, C.POINTER(PushStats)]),
+    "tsd_raycast": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int, C.c_double, C.c_double, _dp, _dp, _u8p, _ip]),
+    "tsd_icp": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, C.c_int, _dp, C.POINTER(IcpParams),
+                          C.POINTER(IcpResult)]),
+    "tsd_localize": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _u8p, C.c_int, C.c_double, C.c_double,
+                               C.POINTER(IcpParams), C.POINTER(IcpResult)]),
+    "tsd_download_tiles": (C.c_int, [C.c_void_p, _u8p, _dp, _dp, _dp]),
+    "tsd_upload_tiles": (C.c_int, [C.c_void_p, _u8p, _dp, _dp, _dp]),
+    "tsd_download_tile_state": (C.c_int, [C.c_void_p, _u8p, _dp]),
+    "tsd_occupancy": (C.c_int, [C.c_void_p, _i8p, C.c_int, C.c_int, _ip]),
+    "tsd_occupancy_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "tsd_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "tsd_profile_reset": (C.c_int, [C.c_void_p]),
+    "tsd_profile_get": (C.c_int, [C.c_void_p, C.c_char_p, _dp, _ip]),
+}
+
+_lib = None
+
+
+def load_library(path: str | None = None):
+    """Load ``libtsd_hip.so`` and bind every ABI symbol.  Raises if the library is missing: the HIP
+    extension is the only implementation."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise TsdError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950); there is no CPU fall-back")
+    lib = C.CDLL(p)
+    for name, (res, args) in ABI.items():
+        fn = getattr(lib, name)     # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _u8(a):
+    return a.ctypes.data_as(_u8p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+@dataclass
+class IcpOut:
+    T: np.ndarray
+    rms: float
+    pairs: int
+    iterations: int
+    state: int
+    n_model: int = 0
+    n_scene: int = 0
+
+
+class TsdGridDevice:
+    """One TSD grid resident in the HBM of one GPU (``obvious::TsdGrid`` as constructed by
+    ``SlamNode::initialize``, SlamNode.cpp:77-78)."""
+
+    def __init__(self, map_size_log2: int, cell_size: float, max_trunc: float, device: int = 0):
+        self.lib = load_library()
+        if self.lib.tsd_device_count() <= 0:
+            raise TsdError("no HIP device visible: the TSD hot path only exists as gfx950 kernels")
+        self.h = self.lib.tsd_create(device, map_size_log2, cell_size, max_trunc)
+        if not self.h:
+            raise TsdError("tsd_create failed")
+        self.cells = self.lib.tsd_cells(self.h)
+        self.tiles = self.lib.tsd_tiles(self.h)
+        self.cell_size = self.lib.tsd_cell_size(self.h)
+        self.max_trunc = self.lib.tsd_max_truncation(self.h)
+        self.min_x, self.max_x = self.lib.tsd_min_x(self.h), self.lib.tsd_max_x(self.h)
+        self.min_y, self.max_y = self.lib.tsd_min_y(self.h), self.lib.tsd_max_y(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tsd_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise TsdError(f"{what} failed ({rc}): {self.lib.tsd_last_error(self.h).decode()}")
+
+    def reset(self):
+        self._check(self.lib.tsd_reset(self.h), "tsd_reset")
+
+    def sync(self):
+        self._check(self.lib.tsd_sync(self.h), "tsd_sync")
+
+    def free_footprint(self, center, width, height) -> bool:
+        c = _f64(center)
+        rc = self.lib.tsd_free_footprint(self.h, _d(c), float(width), float(height))
+        if rc == -4:
+            return False
+        self._check(rc, "tsd_free_footprint")
+        return True
+
+    def push(self, pose, ranges, mask, ang_res, phi_min, max_range, min_range, low_refl, want_stats=True):
+        pose = _f64(pose).reshape(9)
+        ranges = _f64(ranges)
+        mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        st = PushStats()
+        rc = self.lib.tsd_push(self.h, _d(pose), _d(ranges), _u8(mask), ranges.size, ang_res, phi_min,
+                               max_range, min_range, low_refl, C.byref(st) if want_stats else None)
+        self._check(rc, "tsd_push")
+        return st.as_dict() if want_stats else None
+
+    def raycast(self, pose, rays_world, min_range, max_range):
+        pose = _f64(pose).reshape(9)
+        rays = _f64(rays_world)
+        beams = rays.size // 2
+        coords = np.zeros(2 * beams)
+        normals = np.zeros(2 * beams)
+        mask = np.zeros(beams, dtype=np.uint8)
+        n = C.c_int(0)
+        rc = self.lib.tsd_raycast(self.h, _d(pose), _d(rays), beams, min_range, max_range, _d(coords),
+                                  _d(normals), _u8(mask), C.byref(n))
+        self._check(rc, "tsd_raycast")
+        return coords, normals, mask, n.value
+
+    def icp_params(self, iterations, dist_max, dist_min) -> IcpParams:
+        return IcpParams(iterations, dist_max, dist_min, self.min_x, self.max_x, self.min_y, self.max_y)
+
+    def icp(self, model_xy, scene_xy, pose, params: IcpParams) -> IcpOut:
+        m = _f64(model_xy).reshape(-1)
+        s = _f64(scene_xy).reshape(-1)
+        pose = _f64(pose).reshape(9)
+        r = IcpResult()
+        rc = self.lib.tsd_icp(self.h, _d(m), m.size // 2, _d(s), s.size // 2, _d(pose), C.byref(params), C.byref(r))
+        self._check(rc, "tsd_icp")
+        return IcpOut(np.array(r.T[:]).reshape(3, 3), r.rms, r.pairs, r.iterations, r.state)
+
+    def localize(self, pose, rays_world, rays_local, ranges, mask, min_range, max_range, params: IcpParams) -> IcpOut:
+        pose = _f64(pose).reshape(9)
+        rw, rl, rg = _f64(rays_world), _f64(rays_local), _f64(ranges)
+        mk = np.ascontiguousarray(mask, dtype=np.uint8)
+        r = IcpResult()
+        rc = self.lib.tsd_localize(self.h, _d(pose), _d(rw), _d(rl), _d(rg), _u8(mk), rg.size, min_range,
+                                   max_range, C.byref(params), C.byref(r))
+        self._check(rc, "tsd_localize")
+        return IcpOut(np.array(r.T[:]).reshape(3, 3), r.rms, r.pairs, r.iterations, r.state, r.n_model, r.n_scene)
+
+    def download_tile_state(self):
+        init = np.zeros(self.tiles, dtype=np.uint8)
+        iw = np.zeros(self.tiles)
+        self._check(self.lib.tsd_download_tile_state(self.h, _u8(init), _d(iw)), "tsd_download_tile_state")
+        return init, iw
+
+    def download_tiles(self):
+        init = np.zeros(self.tiles, dtype=np.uint8)
+        iw = np.zeros(self.tiles)
+        tsd = np.zeros((self.tiles, TILE_CELLS))
+        w = np.zeros((self.tiles, TILE_CELLS))
+        self._check(self.lib.tsd_download_tiles(self.h, _u8(init), _d(iw), _d(tsd), _d(w)), "tsd_download_tiles")
+        return init, iw, tsd, w
+
+    def upload_tiles(self, init, iw, tsd, w):
+        init = np.ascontiguousarray(init, dtype=np.uint8)
+        iw, tsd, w = _f64(iw), _f64(tsd), _f64(w)
+        self._check(self.lib.tsd_upload_tiles(self.h, _u8(init), _d(iw), _d(tsd), _d(w)), "tsd_upload_tiles")
+
+    def occupancy(self, inflate=False, inflate_factor=2):
+        occ = np.zeros(self.cells * self.cells, dtype=np.int8)
+        n = C.c_int(0)
+        rc = self.lib.tsd_occupancy(self.h, occ.ctypes.data_as(_i8p), int(inflate), inflate_factor, C.byref(n))
+        self._check(rc, "tsd_occupancy")
+        return occ.reshape(self.cells, self.cells), n.value
+
+    def occupancy_into(self, dev_ptr: int, inflate=False, inflate_factor=2):
+        self._check(self.lib.tsd_occupancy_dev(self.h, C.c_void_p(dev_ptr), int(inflate), inflate_factor),
+                    "tsd_occupancy_dev")
+
+    def profile(self, on=True):
+        self.lib.tsd_profile_enable(self.h, int(on))
+
+    def profile_reset(self):
+        self.lib.tsd_profile_reset(self.h)
+
+    def profile_get(self, kernel: str):
+        ms = C.c_double(0.0)
+        n = C.c_int(0)
+        self.lib.tsd_profile_get(self.h, kernel.encode(), C.byref(ms), C.byref(n))
+        return ms.value, n.value

@@ -1,0 +1,560 @@
+// capi.hip -- the extern "C" entry points of include/tsd_hip.h: context life cycle, staging of the
+// scan through a ring of pinned buffers, and the launch order of the kernels on the ctx stream.
+// No CPU fall-back exists: every compute entry point needs a gfx950 device and fails loudly without.
+#include "tsd_ctx.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <cstdio>
+#include <new>
+
+namespace tsd {
+
+int set_error(tsd_ctx* ctx, int code, const char* what, hipError_t e)
+{
+  if (ctx) {
+    char buf[512];
+    if (e != hipSuccess) snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+    else snprintf(buf, sizeof(buf), "%s", what);
+    ctx->err = buf;
+  }
+  return code;
+}
+
+ScopedKernelTimer::ScopedKernelTimer(tsd_ctx* c, const char* n) : ctx(c), name(n)
+{
+  if (!ctx->profile) return;
+  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+  hipEventRecord(a, ctx->stream);
+}
+ScopedKernelTimer::~ScopedKernelTimer()
+{
+  if (!ctx->profile || !a) return;
+  hipEventRecord(b, ctx->stream);
+  ctx->timers[name].pending.emplace_back(a, b);
+}
+void drain_timers(tsd_ctx* ctx)
+{
+  for (auto& kv : ctx->timers) {
+    for (auto& pr : kv.second.pending) {
+      float ms = 0.f;
+      if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+        kv.second.total_ms += (double)ms;
+        kv.second.launches++;
+      }
+      hipEventDestroy(pr.first);
+      hipEventDestroy(pr.second);
+    }
+    kv.second.pending.clear();
+  }
+}
+
+// obvious::Matrix::invert (gsl/Matrix.cpp:168-179): LU with partial pivoting, inverse by column solves
+void mat3_inv(const double A[9], double Ainv[9])
+{
+  double lu[9];
+  int perm[3] = {0, 1, 2};
+  std::memcpy(lu, A, sizeof(lu));
+  for (int j = 0; j < 3; j++) {
+    int piv = j;
+    double best = std::fabs(lu[3 * j + j]);
+    for (int i = j + 1; i < 3; i++)
+      if (std::fabs(lu[3 * i + j]) > best) { best = std::fabs(lu[3 * i + j]); piv = i; }
+    if (piv != j) {
+      for (int k = 0; k < 3; k++) std::swap(lu[3 * j + k], lu[3 * piv + k]);
+      std::swap(perm[j], perm[piv]);
+    }
+    for (int i = j + 1; i < 3; i++) {
+      lu[3 * i + j] = lu[3 * i + j] / lu[3 * j + j];
+      for (int k = j + 1; k < 3; k++) lu[3 * i + k] -= lu[3 * i + j] * lu[3 * j + k];
+    }
+  }
+  for (int c = 0; c < 3; c++) {
+    double x[3];
+    for (int i = 0; i < 3; i++) x[i] = (perm[i] == c) ? 1.0 : 0.0;
+    for (int i = 1; i < 3; i++)
+      for (int k = 0; k < i; k++) x[i] -= lu[3 * i + k] * x[k];
+    for (int i = 2; i >= 0; i--) {
+      for (int k = i + 1; k < 3; k++) x[i] -= lu[3 * i + k] * x[k];
+      x[i] = x[i] / lu[3 * i + i];
+    }
+    for (int i = 0; i < 3; i++) Ainv[3 * i + c] = x[i];
+  }
+}
+
+// next pinned staging slot; waits for the copy that last used it
+static char* stage_acquire(tsd_ctx* ctx, int* slot_out)
+{
+  const int s = ctx->slot;
+  ctx->slot = (ctx->slot + 1) % tsd_ctx::kSlots;
+  hipEventSynchronize(ctx->stage_ev[s]);
+  *slot_out = s;
+  return ctx->h_stage[s];
+}
+
+// DistanceFilter ctor as called from ThreadLocalize.cpp:212 (int -> unsigned conversion of
+// icp_iterations - 10; DistanceFilter.cpp:11-20)
+static double distance_filter_multiplier(double maxdist, double mindist, int icp_iterations)
+{
+  unsigned int iterations = (unsigned int)(icp_iterations - 10);
+  double it = (double)(iterations - 1);
+  if (iterations < 1) it = 1.0;
+  return std::pow((mindist / maxdist), 1.0 / it);
+}
+
+static void fill_icp_args(IcpArgs& a, const double pose33[9], const tsd_icp_params* p)
+{
+  for (int i = 0; i < 6; i++) a.P[i] = pose33[i];
+  a.min_x = p->min_x; a.max_x = p->max_x; a.min_y = p->min_y; a.max_y = p->max_y;
+  a.thr0 = p->dist_filter_max * p->dist_filter_max;
+  a.min_sqr = p->dist_filter_min * p->dist_filter_min;
+  a.multiplier = distance_filter_multiplier(p->dist_filter_max, p->dist_filter_min, p->iterations);
+  a.iterations = p->iterations;
+  a.n_model = a.n_scene = a.beams = 0;
+}
+
+static void fill_raycast_args(const tsd_ctx* ctx, RaycastArgs& a, const double pose33[9], int beams,
+                              double min_range, double max_range)
+{
+  double Pi[9];
+  mat3_inv(pose33, Pi);
+  for (int i = 0; i < 6; i++) a.Pi[i] = Pi[i];
+  a.trx = pose33[2]; a.try_ = pose33[5];
+  const GridDev& g = ctx->grid;
+  // TsdGrid::isInsideGrid (TsdGrid.h:342-347) -> RayCastPolar2D.cpp:128-146
+  if (a.trx > g.min_x && a.trx < g.max_x && a.try_ > g.min_y && a.try_ < g.max_y) {
+    a.gxmin = -10e9; a.gymin = -10e9; a.gxmax = 10e9; a.gymax = 10e9;
+  } else {
+    a.gxmin = 10e9; a.gymin = 10e9; a.gxmax = -10e9; a.gymax = -10e9;
+  }
+  a.idx_min = min_range / g.cs;
+  a.idx_max = max_range / g.cs;
+  a.beams = beams;
+}
+
+static void copy_icp_result(const IcpResultDev* h, tsd_icp_result* r)
+{
+  for (int i = 0; i < 9; i++) r->T[i] = h->T[i];
+  r->rms = h->rms; r->pairs = h->pairs; r->iterations = h->iterations; r->state = h->state;
+  r->n_model = h->n_model; r->n_scene = h->n_scene; r->reserved = h->reserved;
+}
+
+}  // namespace tsd
+
+using namespace tsd;
+
+extern "C" {
+
+int tsd_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+tsd_ctx* tsd_create(int device, int map_size_log2, double cell_size, double max_trunc)
+{
+  if (map_size_log2 < 5 || map_size_log2 > 15 || !(cell_size > 0.0)) return nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+    fprintf(stderr, "tsd_create: no usable HIP device (requested %d of %d); this library has no CPU path\n", device, ndev);
+    return nullptr;
+  }
+  if (hipSetDevice(device) != hipSuccess) return nullptr;
+  tsd_ctx* ctx = new (std::nothrow) tsd_ctx();
+  if (!ctx) return nullptr;
+  ctx->device = device;
+  ctx->map_log2 = map_size_log2;
+  GridDev& g = ctx->grid;
+  // TsdGrid::init (TsdGrid.cpp:112-169)
+  g.N = 1 << map_size_log2;
+  g.PX = g.N / TILE_DIM;
+  g.tiles = g.PX * g.PX;
+  g.cs = cell_size;
+  g.inv_cs = 1.0 / cell_size;
+  g.min_x = 0.0; g.max_x = ((double)g.N + 0.5) * cell_size;
+  g.min_y = 0.0; g.max_y = ((double)g.N + 0.5) * cell_size;
+  // setMaxTruncation (TsdGrid.cpp:206-215)
+  double val = max_trunc;
+  if (val < 2 * cell_size) val = 2 * cell_size;
+  g.max_trunc = val;
+
+  bool ok = true;
+  auto A = [&](hipError_t e) { if (e != hipSuccess) { if (ok) fprintf(stderr, "tsd_create: %s\n", hipGetErrorString(e)); ok = false; } };
+  A(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  const size_t T = (size_t)g.tiles;
+  A(hipMalloc(&g.flags, T));
+  A(hipMalloc(&g.init_weight, T * sizeof(double)));
+  A(hipMalloc(&g.tsd, T * TILE_STRIDE * sizeof(double)));
+  A(hipMalloc(&g.weight, T * TILE_STRIDE * sizeof(double)));
+  A(hipMalloc(&ctx->d_counters, 2 * sizeof(PushCounters)));
+  A(hipMalloc(&ctx->d_list, T * sizeof(uint32_t)));
+  ctx->dirty_cap = (int)(T < 65536 ? T : 65536);
+  A(hipMalloc(&ctx->d_dirty, (size_t)ctx->dirty_cap * sizeof(uint32_t)));
+  A(hipMalloc(&ctx->d_dirty_count, sizeof(int)));
+  A(hipHostMalloc(&ctx->h_dirty, ((size_t)ctx->dirty_cap + 1) * sizeof(uint32_t), hipHostMallocDefault));
+  A(hipHostMalloc(&ctx->h_counters, sizeof(PushCounters), hipHostMallocDefault));
+  ctx->stage_bytes = (size_t)TSD_MAX_BEAMS * (8 * 5 + 1) + 256;   // ranges + 2x rays(2) + mask
+  for (int s = 0; s < tsd_ctx::kSlots; s++) {
+    A(hipHostMalloc(&ctx->h_stage[s], ctx->stage_bytes, hipHostMallocDefault));
+    A(hipEventCreateWithFlags(&ctx->stage_ev[s], hipEventDisableTiming));
+  }
+  A(hipMalloc(&ctx->d_ranges, TSD_MAX_BEAMS * sizeof(double)));
+  A(hipMalloc(&ctx->d_mask, TSD_MAX_BEAMS));
+  A(hipMalloc(&ctx->d_rays, 2 * TSD_MAX_BEAMS * sizeof(double)));
+  A(hipMalloc(&ctx->d_rays_local, 2 * TSD_MAX_BEAMS * sizeof(double)));
+  A(hipMalloc(&ctx->d_coords, 2 * TSD_MAX_BEAMS * sizeof(double)));
+  A(hipMalloc(&ctx->d_normals, 2 * TSD_MAX_BEAMS * sizeof(double)));
+  A(hipMalloc(&ctx->d_mask_m, TSD_MAX_BEAMS));
+  A(hipMalloc(&ctx->d_model, 2 * TSD_MAX_ICP_POINTS * sizeof(double)));
+  A(hipMalloc(&ctx->d_scene, 2 * TSD_MAX_ICP_POINTS * sizeof(double)));
+  A(hipMalloc(&ctx->d_icp_res, sizeof(IcpResultDev)));
+  A(hipHostMalloc(&ctx->h_icp_res, sizeof(IcpResultDev), hipHostMallocDefault));
+  ctx->h_out_bytes = (size_t)TSD_MAX_BEAMS * (8 * 4 + 1) + 256;
+  A(hipHostMalloc(&ctx->h_out, ctx->h_out_bytes, hipHostMallocDefault));
+  A(hipMalloc(&ctx->d_occ, (size_t)g.N * g.N));
+  A(hipMalloc(&ctx->d_occ_count, sizeof(int)));
+  if (!ok) { tsd_destroy(ctx); return nullptr; }
+  if (tsd_reset(ctx) != TSD_OK) { fprintf(stderr, "tsd_create: %s\n", ctx->err.c_str()); tsd_destroy(ctx); return nullptr; }
+  return ctx;
+}
+
+void tsd_destroy(tsd_ctx* ctx)
+{
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  if (ctx->stream) hipStreamSynchronize(ctx->stream);
+  drain_timers(ctx);
+  GridDev& g = ctx->grid;
+  hipFree(g.flags); hipFree(g.init_weight); hipFree(g.tsd); hipFree(g.weight);
+  hipFree(ctx->d_counters); hipFree(ctx->d_list); hipFree(ctx->d_dirty); hipFree(ctx->d_dirty_count);
+  hipHostFree(ctx->h_dirty); hipHostFree(ctx->h_counters);
+  for (int s = 0; s < tsd_ctx::kSlots; s++) {
+    if (ctx->h_stage[s]) hipHostFree(ctx->h_stage[s]);
+    if (ctx->stage_ev[s]) hipEventDestroy(ctx->stage_ev[s]);
+  }
+  hipFree(ctx->d_ranges); hipFree(ctx->d_mask); hipFree(ctx->d_rays); hipFree(ctx->d_rays_local);
+  hipFree(ctx->d_coords); hipFree(ctx->d_normals); hipFree(ctx->d_mask_m); hipFree(ctx->d_model);
+  hipFree(ctx->d_scene); hipFree(ctx->d_icp_res); hipHostFree(ctx->h_icp_res); hipHostFree(ctx->h_out);
+  hipFree(ctx->d_occ); hipFree(ctx->d_occ_count);
+  if (ctx->stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int tsd_reset(tsd_ctx* ctx)
+{
+  if (!ctx) return TSD_E_ARG;
+  TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  GridDev& g = ctx->grid;
+  const size_t T = (size_t)g.tiles;
+  // cells are materialised lazily (flags == 0 means "no cell storage yet", TsdGridPartition.cpp:88)
+  TSD_HIP_CHECK(ctx, hipMemsetAsync(g.flags, 0, T, ctx->stream));
+  TSD_HIP_CHECK(ctx, hipMemsetAsync(g.init_weight, 0, T * sizeof(double), ctx->stream));
+  TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_counters, 0, 2 * sizeof(PushCounters), ctx->stream));
+  TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_dirty_count, 0, sizeof(int), ctx->stream));
+  TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_occ, 0xFF, (size_t)g.N * g.N, ctx->stream));   // -1 (ThreadGrid.cpp:27-28)
+  ctx->epoch = 0;
+  ctx->n_dirty = 0;
+  TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return TSD_OK;
+}
+
+int tsd_sync(tsd_ctx* ctx)
+{
+  if (!ctx) return TSD_E_ARG;
+  TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return TSD_OK;
+}
+
+const char* tsd_last_error(const tsd_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+int    tsd_cells(const tsd_ctx* ctx) { return ctx ? ctx->grid.N : 0; }
+int    tsd_tiles(const tsd_ctx* ctx) { return ctx ? ctx->grid.tiles : 0; }
+double tsd_cell_size(const tsd_ctx* ctx) { return ctx ? ctx->grid.cs : 0.0; }
+double tsd_max_truncation(const tsd_ctx* ctx) { return ctx ? ctx->grid.max_trunc : 0.0; }
+double tsd_min_x(const tsd_ctx* ctx) { return ctx ? ctx->grid.min_x : 0.0; }
+double tsd_max_x(const tsd_ctx* ctx) { return ctx ? ctx->grid.max_x : 0.0; }
+double tsd_min_y(const tsd_ctx* ctx) { return ctx ? ctx->grid.min_y : 0.0; }
+double tsd_max_y(const tsd_ctx* ctx) { return ctx ? ctx->grid.max_y : 0.0; }
+
+int tsd_free_footprint(tsd_ctx* ctx, const double center[2], double width, double height)
+{
+  if (!ctx || !center) return TSD_E_ARG;
+  TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const GridDev& g = ctx->grid;
+  // TsdGrid.cpp:611-622
+  const unsigned minX = static_cast<unsigned>((center[0] - width * 0.5) / g.cs + 0.5);
+  const unsigned maxX = static_cast<unsigned>((center[0] + width * 0.5) / g.cs + 0.5);
+  const unsigned minY = static_cast<unsigned>((center[1] - height * 0.5) / g.cs + 0.5);
+  const unsigned maxY = static_cast<unsigned>((center[1] + height * 0.5) / g.cs + 0.5);
+  const unsigned N = (unsigned)g.N;
+  if (minX > N || maxX > N || minY > N || maxY > N)
+    return set_error(ctx, TSD_E_BOUNDS, "freeFootprint: indices out of bounds", hipSuccess);
+  // cells == N would index past the last tile in the reference (undefined there); clamp
+  const unsigned cx1 = maxX > N ? N : maxX, cy1 = maxY > N ? N : maxY;
+  return launch_free_footprint(ctx, minX, cx1, minY, cy1);
+}
+
+int tsd_push(tsd_ctx* ctx, const double pose33[9], const double* ranges, const uint8_t* mask,
+             int beams, double ang_res, double phi_min, double max_range, double min_range,
+             double low_refl_range, tsd_push_stats* stats)
+{
+  if (!ctx || !pose33 || !ranges || !mask) return TSD_E_ARG;
+  if (beams < 1 || beams > TSD_MAX_BEAMS) return set_error(ctx, TSD_E_CAPACITY, "beams out of range", hipSuccess);
+  TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  PushArgs a;
+  double Pi[9];
+  mat3_inv(pose33, Pi);
+  for (int i = 0; i < 6; i++) a.Pi[i] = Pi[i];
+  a.trx = pose33[2]; a.try_ = pose33[5];                     // Sensor::getPosition (Sensor.cpp:114-118)
+  a.phi_min = phi_min; a.ang_res_inv = 1.0 / ang_res;
+  a.phi_lower = -0.5 * ang_res + phi_min;                    // SensorPolar2D.cpp:26-30
+  a.phi_upper = phi_min + (((double)beams) - 0.5) * ang_res;
+  a.max_range = max_range; a.min_range = min_range; a.low_refl = low_refl_range;
+  a.beams = beams; a.pad = 0;
+
+  int s;
+  char* h = stage_acquire(ctx, &s);
+  std::memcpy(h, ranges, (size_t)beams * sizeof(double));
+  std::memcpy(h + (size_t)TSD_MAX_BEAMS * 8, mask, (size_t)beams);
+  TSD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_ranges, h, (size_t)beams * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  TSD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_mask, h + (size_t)TSD_MAX_BEAMS * 8, (size_t)beams, hipMemcpyHostToDevice, ctx->stream));
+  TSD_HIP_CHECK(ctx, hipEventRecord(ctx->stage_ev[s], ctx->stream));
+
+  const uint32_t epoch = ctx->epoch;
+  int rc = launch_push(ctx, a);
+  if (rc != TSD_OK) return rc;
+  if (stats) {
+    TSD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters + (epoch & 1u), sizeof(PushCounters),
+                                      hipMemcpyDeviceToHost, ctx->stream));
+    TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const PushCounters& c = *ctx->h_counters;
+    stats->cells_updated = (int64_t)c.cells_updated;
+    stats->cells_visited = (int64_t)c.cells_visited;
+    stats->tiles_total = ctx->grid.tiles;
+    stats->tiles_range_pass = c.tiles_range_pass;
+    stats->tiles_update = c.tiles_update;
+    stats->tiles_new = c.tiles_new;
+    stats->tiles_new_from_empty = c.tiles_new_from_empty;
+    stats->tiles_emptied_init = c.tiles_emptied_init;
+    stats->tiles_emptied_uninit = c.tiles_emptied_uninit;
+  }
+  return TSD_OK;
+}
+
+int tsd_raycast(tsd_ctx* ctx, const double pose33[9], const double* rays_world_2xB, int beams,
+                double min_range, double max_range, double* coords_2B, double* normals_2B,
+                uint8_t* mask_B, int* n_valid)
+{
+  if (!ctx || !pose33 || !rays_world_2xB || !coords_2B || !normals_2B || !mask_B) return TSD_E_ARG;
+  if (beams < 1 || beams > TSD_MAX_BEAMS) return set_error(ctx, TSD_E_CAPACITY, "beams out of range", hipSuccess);
+  TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  RaycastArgs a;
+  fill_raycast_args(ctx, a, pose33, beams, min_range, max_range);
+  int s;
+  char* h = stage_acquire(ctx, &s);
+  std::memcpy(h, rays_world_2xB, (size_t)beams * 2 * sizeof(double));
+  TSD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_rays, h, (size_t)beams * 2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  TSD_HIP_CHECK(ctx, hipEventRecord(ctx->stage_ev[s], ctx->stream));
+  int rc = launch_raycast(ctx, a);
+  if (rc != TSD_OK) return rc;
+  const size_t nb = (size_t)beams;
+  char* o = ctx->h_out;
+  TSD_HIP_CHECK(ctx, hipMemcpyAsync(o, ctx->d_coords, nb * 16, hipMemcpyDeviceToHost, ctx->stream));
+  TSD_HIP_CHECK(ctx, hipMemcpyAsync(o + (size_t)TSD_MAX_BEAMS * 16, ctx->d_normals, nb * 16, hipMemcpyDeviceToHost, ctx->stream));
+  TSD_HIP_CHECK(ctx, hipMemcpyAsync(o + (size_t)TSD_MAX_BEAMS * 32, ctx->d_mask_m, nb, hipMemcpyDeviceToHost, ctx->stream));
+  TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  const double* hc = reinterpret_cast<const double*>(o);
+  const double* hn = reinterpret_cast<const double*>(o + (size_t)TSD_MAX_BEAMS * 16);
+  const uint8_t* hm = reinterpret_cast<const uint8_t*>(o + (size_t)TSD_MAX_BEAMS * 32);
+  int cnt = 0;
+  for (int b = 0; b < beams; b++) {
+    mask_B[b] = hm[b];
+    if (hm[b]) {   // only hit slots are written (RayCastPolar2D.cpp:171-178)
+      coords_2B[2 * b] = hc[2 * b]; coords_2B[2 * b + 1] = hc[2 * b + 1];
+      normals_2B[2 * b] = hn[2 * b]; normals_2B[2 * b + 1] = hn[2 * b + 1];
+      cnt++;
+    }
+  }
+  if (n_valid) *n_valid = cnt;
+  return TSD_OK;
+}
+
+int tsd_icp(tsd_ctx* ctx, const double* model_xy, int n_model, const double* scene_xy, int n_scene,
+            const double pose33[9], const tsd_icp_params* params, tsd_icp_result* result)
+{
+  if (!ctx || !pose33 || !params || !result || n_model < 0 || n_scene < 0) return TSD_E_ARG;
+  if ((n_model > 0 && !model_xy) || (n_scene > 0 && !scene_xy)) return TSD_E_ARG;
+  if (n_model > TSD_MAX_ICP_POINTS || n_scene > TSD_MAX_ICP_POINTS)
+    return set_error(ctx, TSD_E_CAPACITY, "icp points > TSD_MAX_ICP_POINTS", hipSuccess);
+  TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  IcpArgs a;
+  fill_icp_args(a, pose33, params);
+  a.n_model = n_model; a.n_scene = n_scene; a.beams = 0;
+  // model and scene share one staging slot (2 * 2048 * 16 B = 64 KB <= stage_bytes)
+  int s;
+  char* h = stage_acquire(ctx, &s);
+  const size_t mb = (size_t)n_model * 16, sb = (size_t)n_scene * 16;
+  if (mb + sb > ctx->stage_bytes) return set_error(ctx, TSD_E_CAPACITY, "icp staging", hipSuccess);
+  if (mb) std::memcpy(h, model_xy, mb);
+  if (sb) std::memcpy(h + mb, scene_xy, sb);
+  if (mb) TSD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_model, h, mb, hipMemcpyHostToDevice, ctx->stream));
+  if (sb) TSD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_scene, h + mb, sb, hipMemcpyHostToDevice, ctx->stream));
+  TSD_HIP_CHECK(ctx, hipEventRecord(ctx->stage_ev[s], ctx->stream));
+  int rc = launch_icp(ctx, a);
+  if (rc != TSD_OK) return rc;
+  TSD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_icp_res, ctx->d_icp_res, sizeof(IcpResultDev), hipMemcpyDeviceToHost, ctx->stream));
+  TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  copy_icp_result(ctx->h_icp_res, result);
+  return TSD_OK;
+}
+
+int tsd_localize(tsd_ctx* ctx, const double pose33[9], const double* rays_world_2xB,
+                 const double* rays_local_2xB, const double* ranges, const uint8_t* mask, int beams,
+                 double min_range, double max_range, const tsd_icp_params* params,
+                 tsd_icp_result* result)
+{
+  if (!ctx || !pose33 || !rays_world_2xB || !rays_local_2xB || !ranges || !mask || !params || !result) return TSD_E_ARG;
+  if (beams < 1 || beams > TSD_MAX_BEAMS || beams > TSD_MAX_ICP_POINTS)
+    return set_error(ctx, TSD_E_CAPACITY, "beams out of range for fused localize", hipSuccess);
+  TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const size_t nb = (size_t)beams;
+  int s;
+  char* h = stage_acquire(ctx, &s);
+  char* h_rw = h;                         // 2B doubles
+  char* h_rl = h + nb * 16;               // 2B doubles
+  char* h_r = h + nb * 32;                // B doubles
+  char* h_m = h + nb * 40;                // B bytes
+  std::memcpy(h_rw, rays_world_2xB, nb * 16);
+  std::memcpy(h_rl, rays_local_2xB, nb * 16);
+  std::memcpy(h_r, ranges, nb * 8);
+  std::memcpy(h_m, mask, nb);
+  TSD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_rays, h_rw, nb * 16, hipMemcpyHostToDevice, ctx->stream));
+  TSD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_rays_local, h_rl, nb * 16, hipMemcpyHostToDevice, ctx->stream));
+  TSD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_ranges, h_r, nb * 8, hipMemcpyHostToDevice, ctx->stream));
+  TSD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_mask, h_m, nb, hipMemcpyHostToDevice, ctx->stream));
+  TSD_HIP_CHECK(ctx, hipEventRecord(ctx->stage_ev[s], ctx->stream));
+
+  RaycastArgs ra;
+  fill_raycast_args(ctx, ra, pose33, beams, min_range, max_range);
+  int rc = launch_raycast(ctx, ra);
+  if (rc != TSD_OK) return rc;
+  IcpArgs ia;
+  fill_icp_args(ia, pose33, params);
+  ia.beams = beams;
+  rc = launch_icp(ctx, ia);
+  if (rc != TSD_OK) return rc;
+  TSD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_icp_res, ctx->d_icp_res, sizeof(IcpResultDev), hipMemcpyDeviceToHost, ctx->stream));
+  TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  copy_icp_result(ctx->h_icp_res, result);
+  return TSD_OK;
+}
+
+int tsd_download_tile_state(tsd_ctx* ctx, uint8_t* initialized, double* init_weight)
+{
+  if (!ctx || !initialized || !init_weight) return TSD_E_ARG;
+  TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  const size_t T = (size_t)ctx->grid.tiles;
+  TSD_HIP_CHECK(ctx, hipMemcpy(initialized, ctx->grid.flags, T, hipMemcpyDeviceToHost));
+  TSD_HIP_CHECK(ctx, hipMemcpy(init_weight, ctx->grid.init_weight, T * sizeof(double), hipMemcpyDeviceToHost));
+  return TSD_OK;
+}
+
+int tsd_download_tiles(tsd_ctx* ctx, uint8_t* initialized, double* init_weight, double* tsd_out,
+                       double* weight_out)
+{
+  if (!ctx || !initialized || !init_weight || !tsd_out || !weight_out) return TSD_E_ARG;
+  int rc = tsd_download_tile_state(ctx, initialized, init_weight);
+  if (rc != TSD_OK) return rc;
+  const GridDev& g = ctx->grid;
+  const double qnan = std::nan("");
+  for (int p = 0; p < g.tiles; p++) {
+    double* t = tsd_out + (size_t)p * TSD_TILE_CELLS;
+    double* w = weight_out + (size_t)p * TSD_TILE_CELLS;
+    if (initialized[p]) {
+      TSD_HIP_CHECK(ctx, hipMemcpy(t, g.tsd + (size_t)p * TILE_STRIDE, TSD_TILE_CELLS * sizeof(double), hipMemcpyDeviceToHost));
+      TSD_HIP_CHECK(ctx, hipMemcpy(w, g.weight + (size_t)p * TILE_STRIDE, TSD_TILE_CELLS * sizeof(double), hipMemcpyDeviceToHost));
+    } else {
+      for (int i = 0; i < TSD_TILE_CELLS; i++) { t[i] = qnan; w[i] = 0.0; }
+    }
+  }
+  return TSD_OK;
+}
+
+int tsd_upload_tiles(tsd_ctx* ctx, const uint8_t* initialized, const double* init_weight,
+                     const double* tsd_in, const double* weight_in)
+{
+  if (!ctx || !initialized || !init_weight || !tsd_in || !weight_in) return TSD_E_ARG;
+  TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  const GridDev& g = ctx->grid;
+  const size_t T = (size_t)g.tiles;
+  TSD_HIP_CHECK(ctx, hipMemcpy(g.flags, initialized, T, hipMemcpyHostToDevice));
+  TSD_HIP_CHECK(ctx, hipMemcpy(g.init_weight, init_weight, T * sizeof(double), hipMemcpyHostToDevice));
+  for (int p = 0; p < g.tiles; p++) {
+    if (!initialized[p]) continue;
+    TSD_HIP_CHECK(ctx, hipMemcpy(g.tsd + (size_t)p * TILE_STRIDE, tsd_in + (size_t)p * TSD_TILE_CELLS, TSD_TILE_CELLS * sizeof(double), hipMemcpyHostToDevice));
+    TSD_HIP_CHECK(ctx, hipMemcpy(g.weight + (size_t)p * TILE_STRIDE, weight_in + (size_t)p * TSD_TILE_CELLS, TSD_TILE_CELLS * sizeof(double), hipMemcpyHostToDevice));
+  }
+  return TSD_OK;
+}
+
+int tsd_occupancy_dev(tsd_ctx* ctx, void* occ_dev, int inflate, int inflate_factor)
+{
+  if (!ctx || !occ_dev) return TSD_E_ARG;
+  TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  int rc = launch_occupancy(ctx, static_cast<int8_t*>(occ_dev), inflate, inflate_factor);
+  if (rc != TSD_OK) return rc;
+  TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return TSD_OK;
+}
+
+int tsd_occupancy(tsd_ctx* ctx, int8_t* occ_host, int inflate, int inflate_factor, int* n_surface)
+{
+  if (!ctx || !occ_host) return TSD_E_ARG;
+  TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const size_t cells = (size_t)ctx->grid.N * ctx->grid.N;
+  int8_t* d_out = nullptr;
+  TSD_HIP_CHECK(ctx, hipMalloc(&d_out, cells));
+  int rc = launch_occupancy(ctx, d_out, inflate, inflate_factor);
+  if (rc == TSD_OK) {
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(occ_host, d_out, cells, hipMemcpyDeviceToHost);
+    int n = 0;
+    if (e == hipSuccess) e = hipMemcpy(&n, ctx->d_occ_count, sizeof(int), hipMemcpyDeviceToHost);
+    if (n_surface) *n_surface = n;
+    if (e != hipSuccess) rc = set_error(ctx, TSD_E_HIP, "tsd_occupancy copy", e);
+  }
+  hipFree(d_out);
+  return rc;
+}
+
+int tsd_profile_enable(tsd_ctx* ctx, int on)
+{
+  if (!ctx) return TSD_E_ARG;
+  ctx->profile = on != 0;
+  return TSD_OK;
+}
+
+int tsd_profile_reset(tsd_ctx* ctx)
+{
+  if (!ctx) return TSD_E_ARG;
+  hipStreamSynchronize(ctx->stream);
+  drain_timers(ctx);
+  ctx->timers.clear();
+  return TSD_OK;
+}
+
+int tsd_profile_get(tsd_ctx* ctx, const char* kernel, double* total_ms, int* launches)
+{
+  if (!ctx || !kernel) return TSD_E_ARG;
+  hipStreamSynchronize(ctx->stream);
+  drain_timers(ctx);
+  auto it = ctx->timers.find(kernel);
+  if (total_ms) *total_ms = (it == ctx->timers.end()) ? 0.0 : it->second.total_ms;
+  if (launches) *launches = (it == ctx->timers.end()) ? 0 : it->second.launches;
+  return TSD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,118 @@
+// occupancy_kernels.hip -- the occupancy map of ThreadGrid::eventLoop (ThreadGrid.cpp:72-118):
+// RayCastAxisAligned2D::calcCoords (RayCastAxisAligned2D.cpp:13-105) writes -1 / 0 per cell of every
+// non-border tile into a PERSISTENT char map (_occGridContent, initialised to -1, ThreadGrid.cpp:27)
+// and collects the sign changes along rows and columns; ThreadGrid then copies the map and marks the
+// rounded sign-change cells with 100 (+ optional inflation).
+//
+// The reference walks tiles serially (y outer, x inner) and each initialised tile also writes its
+// 1-cell halo, i.e. into the first row/column of its up/right neighbours, so for a cell at a tile's
+// first row/column the LAST writer in that serial order wins: own tile > left > down > diagonal.
+// k_occ_cells resolves that priority per cell (a gather, no write races); k_occ_mark does the
+// idempotent "100" marks.  Streams the whole grid once: HBM-bound (cells*8 B read, cells*2 B written).
+#include "tsd_ctx.hpp"
+
+namespace tsd {
+
+__device__ __forceinline__ bool tile_processed(int X, int Y, int PX)
+{
+  return X >= 1 && X <= PX - 2 && Y >= 1 && Y <= PX - 2;   // loops 1 .. partitions-2 (:25-27)
+}
+
+// value an initialised tile writes for its local cell (ly,lx), lx/ly in 0..32 (:41-47)
+__device__ __forceinline__ int8_t occ_from_tsd(const GridDev& g, int p, int ly, int lx)
+{
+  const double t = g.tsd[(size_t)p * TILE_STRIDE + ly * TILE_PITCH + lx];
+  return (t > 0.0) ? 0 : -1;
+}
+
+__global__ void __launch_bounds__(256)
+k_occ_cells(GridDev g, int8_t* __restrict__ content, int8_t* __restrict__ out)
+{
+  const int p = blockIdx.x;
+  const int PX = g.PX;
+  const int X = p % PX, Y = p / PX;
+  const bool own_proc = tile_processed(X, Y, PX);
+  const bool own_init = g.flags[p] != 0;
+  const bool own_empty = !own_init && g.init_weight[p] > 0.0;   // isEmpty(), TsdGridPartition.h:72
+  const bool left_w = X >= 1 && tile_processed(X - 1, Y, PX) && g.flags[p - 1];
+  const bool down_w = Y >= 1 && tile_processed(X, Y - 1, PX) && g.flags[p - PX];
+  const bool diag_w = X >= 1 && Y >= 1 && tile_processed(X - 1, Y - 1, PX) && g.flags[p - PX - 1];
+  for (int c = threadIdx.x; c < TILE_DIM * TILE_DIM; c += 256) {
+    const int lx = c & 31, ly = c >> 5;
+    const size_t gi = (size_t)(Y * TILE_DIM + ly) * g.N + (size_t)(X * TILE_DIM + lx);
+    int8_t v = content[gi];
+    if (own_proc && own_init) v = occ_from_tsd(g, p, ly, lx);
+    else if (own_proc && own_empty) v = 0;
+    else if (lx == 0 && left_w) v = occ_from_tsd(g, p - 1, ly, TILE_DIM);
+    else if (ly == 0 && down_w) v = occ_from_tsd(g, p - PX, TILE_DIM, lx);
+    else if (lx == 0 && ly == 0 && diag_w) v = occ_from_tsd(g, p - PX - 1, TILE_DIM, TILE_DIM);
+    content[gi] = v;
+    out[gi] = v;
+  }
+}
+
+__device__ __forceinline__ void occ_mark(const GridDev& g, int8_t* out, double x, double y, int inflate,
+                                         int factor)
+{
+  // ThreadGrid.cpp:96-117
+  const double ru = round(x / g.cs), rv = round(y / g.cs);
+  if (!(ru > 0.0 && ru < (double)g.N && rv > 0.0 && rv < (double)g.N)) return;
+  const unsigned u = (unsigned)ru, v = (unsigned)rv, N = (unsigned)g.N;
+  out[(size_t)v * N + u] = 100;
+  if (inflate) {
+    for (unsigned i = v - (unsigned)factor; i < v + (unsigned)factor; i++)
+      for (unsigned j = u - (unsigned)factor; j < u + (unsigned)factor; j++)
+        if ((size_t)i * N + j < (size_t)N * N) out[(size_t)i * N + j] = 100;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_occ_mark(GridDev g, int8_t* __restrict__ out, int* __restrict__ count, int inflate, int factor)
+{
+  const int p = blockIdx.x;
+  const int PX = g.PX;
+  const int X = p % PX, Y = p / PX;
+  if (!tile_processed(X, Y, PX) || !g.flags[p]) return;
+  const double* T = g.tsd + (size_t)p * TILE_STRIDE;
+  const double cs = g.cs;
+  int n = 0;
+  // row scans: py in 0..32, px in 1..32 (:38-60); column scans: px in 0..32, py in 1..32 (:62-80)
+  for (int c = threadIdx.x; c < 2 * TILE_PITCH * TILE_DIM; c += 256) {
+    const bool col = c >= TILE_PITCH * TILE_DIM;
+    const int cc = col ? c - TILE_PITCH * TILE_DIM : c;
+    const int a = cc / TILE_DIM;          // fixed index 0..32
+    const int b = cc % TILE_DIM + 1;      // running index 1..32
+    const int py = col ? b : a, px = col ? a : b;
+    const double prev = col ? T[(py - 1) * TILE_PITCH + px] : T[py * TILE_PITCH + px - 1];
+    const double cur = T[py * TILE_PITCH + px];
+    if ((prev > 0 && cur < 0) || (prev < 0 && cur > 0)) {
+      const double interp = prev / (prev - cur);
+      double x, y;
+      if (!col) {
+        x = px * cs + cs * (interp - 1.0) + (X * TILE_DIM) * cs;
+        y = py * cs + (Y * TILE_DIM) * cs;
+      } else {
+        x = px * cs + (X * TILE_DIM) * cs;
+        y = py * cs + cs * (interp - 1.0) + (Y * TILE_DIM) * cs;
+      }
+      occ_mark(g, out, x, y, inflate, factor);
+      n++;
+    }
+  }
+  n = wave_sum_i(n);
+  if ((threadIdx.x & 63) == 0 && n) atomicAdd(count, n);
+}
+
+int launch_occupancy(tsd_ctx* ctx, int8_t* d_out, int inflate, int inflate_factor)
+{
+  ScopedKernelTimer t(ctx, "occupancy");
+  TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_occ_count, 0, sizeof(int), ctx->stream));
+  hipLaunchKernelGGL(k_occ_cells, dim3(ctx->grid.tiles), dim3(256), 0, ctx->stream, ctx->grid,
+                     ctx->d_occ, d_out);
+  hipLaunchKernelGGL(k_occ_mark, dim3(ctx->grid.tiles), dim3(256), 0, ctx->stream, ctx->grid, d_out,
+                     ctx->d_occ_count, inflate, inflate_factor);
+  TSD_HIP_CHECK(ctx, hipGetLastError());
+  return TSD_OK;
+}
+
+}  // namespace tsd

@@ -1,0 +1,147 @@
+// tsd_ctx.hpp -- host-side state behind the opaque tsd_ctx of include/tsd_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <map>
+
+#include "tsd_device.hpp"
+#include "../../include/tsd_hip.h"
+
+namespace tsd {
+
+// device-resident counters of one push; two sets alternate by push epoch so that no memset node is
+// needed (the classify kernel of push e clears the set of push e+1).
+struct PushCounters {
+  unsigned long long cells_updated;
+  unsigned long long cells_visited;
+  int list_count;            // entries in the tile work list
+  int tiles_range_pass;
+  int tiles_update;
+  int tiles_new;
+  int tiles_new_from_empty;
+  int tiles_emptied_init;
+  int tiles_emptied_uninit;
+  int pad;
+};
+
+// scalar inputs of a push, passed by value as a kernel argument
+struct PushArgs {
+  double Pi[6];              // first two rows of pose^-1
+  double trx, try_;          // Sensor::getPosition
+  double phi_min, ang_res_inv, phi_lower, phi_upper;
+  double max_range, min_range, low_refl;
+  int beams;
+  int pad;
+};
+
+struct RaycastArgs {
+  double Pi[6];
+  double trx, try_;
+  double gxmin, gymin, gxmax, gymax;   // RayCastPolar2D::_xmin.. (RayCastPolar2D.cpp:128-146)
+  double idx_min, idx_max;             // _idxMin / _idxMax (:148-149)
+  int beams;
+  int pad;
+};
+
+struct IcpArgs {
+  double P[6];               // first two rows of the pre-registration sensor pose
+  double min_x, max_x, min_y, max_y;
+  double thr0, min_sqr, multiplier;    // DistanceFilter state (DistanceFilter.cpp:11-20)
+  int iterations;
+  int n_model, n_scene;      // direct mode
+  int beams;                 // fused mode (compaction from per-beam arrays) when > 0
+};
+
+struct IcpResultDev {
+  double T[9];
+  double rms;
+  int pairs, iterations, state, n_model, n_scene, reserved;
+};
+
+struct KernelTimer {
+  double total_ms = 0.0;
+  int launches = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+}  // namespace tsd
+
+struct tsd_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  tsd::GridDev grid{};
+  int map_log2 = 0;
+  std::string err;
+
+  // push state
+  uint32_t epoch = 0;
+  tsd::PushCounters* d_counters = nullptr;   // [2]
+  uint32_t* d_list = nullptr;                // [tiles] work list (bit 31 = emptied-initialised tile)
+  uint32_t* d_dirty = nullptr;               // tiles touched by freeFootprint since the last push
+  int* d_dirty_count = nullptr;
+  uint32_t* h_dirty = nullptr;               // pinned [dirty_cap + 1] (last word = count staging)
+  int dirty_cap = 0;
+  int n_dirty = 0;
+  tsd::PushCounters* h_counters = nullptr;   // pinned
+
+  // scan staging: ring of pinned slots + device buffers
+  static constexpr int kSlots = 8;
+  int slot = 0;
+  char* h_stage[kSlots] = {};
+  hipEvent_t stage_ev[kSlots] = {};
+  size_t stage_bytes = 0;
+  double* d_ranges = nullptr;    // [TSD_MAX_BEAMS]
+  uint8_t* d_mask = nullptr;     // [TSD_MAX_BEAMS]
+  double* d_rays = nullptr;      // [2*TSD_MAX_BEAMS] world rays
+  double* d_rays_local = nullptr;// [2*TSD_MAX_BEAMS]
+  double* d_coords = nullptr;    // [2*TSD_MAX_BEAMS]
+  double* d_normals = nullptr;   // [2*TSD_MAX_BEAMS]
+  uint8_t* d_mask_m = nullptr;   // [TSD_MAX_BEAMS]
+  double* d_model = nullptr;     // [2*TSD_MAX_ICP_POINTS]
+  double* d_scene = nullptr;     // [2*TSD_MAX_ICP_POINTS]
+  tsd::IcpResultDev* d_icp_res = nullptr;
+  tsd::IcpResultDev* h_icp_res = nullptr;    // pinned
+  char* h_out = nullptr;                     // pinned D2H staging (ray-cast outputs)
+  size_t h_out_bytes = 0;
+
+  // occupancy
+  int8_t* d_occ = nullptr;       // persistent map (ThreadGrid::_occGridContent)
+  int* d_occ_count = nullptr;
+
+  // profiling
+  bool profile = false;
+  std::map<std::string, tsd::KernelTimer> timers;
+};
+
+namespace tsd {
+
+int set_error(tsd_ctx* ctx, int code, const char* what, hipError_t e);
+#define TSD_HIP_CHECK(ctx, call)                                                     \
+  do {                                                                               \
+    hipError_t _e = (call);                                                          \
+    if (_e != hipSuccess) return tsd::set_error((ctx), TSD_E_HIP, #call, _e);        \
+  } while (0)
+
+// event-timed launch bracket
+struct ScopedKernelTimer {
+  tsd_ctx* ctx; const char* name; hipEvent_t a = nullptr, b = nullptr;
+  ScopedKernelTimer(tsd_ctx* c, const char* n);
+  ~ScopedKernelTimer();
+};
+void drain_timers(tsd_ctx* ctx);
+
+// per-file launchers
+int launch_push(tsd_ctx* ctx, const PushArgs& a);
+int launch_free_footprint(tsd_ctx* ctx, unsigned minX, unsigned maxX, unsigned minY, unsigned maxY);
+int launch_raycast(tsd_ctx* ctx, const RaycastArgs& a);
+int launch_icp(tsd_ctx* ctx, const IcpArgs& a);
+int launch_occupancy(tsd_ctx* ctx, int8_t* d_out, int inflate, int inflate_factor);
+size_t icp_lds_bytes();
+
+// pose helpers (host): textbook LU inverse with partial pivoting in the order of
+// gsl_linalg_LU_decomp / LU_invert as used by obvious::Matrix::invert (gsl/Matrix.cpp:168-179)
+void mat3_inv(const double A[9], double Ainv[9]);
+
+}  // namespace tsd

@@ -1,0 +1,166 @@
+/*
+ * tsd_oracle.h -- CPU restatement (plain C99 + OpenMP) of the ohm_tsd_slam per-scan hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this library.  The shipped path (ohm_tsd_slam_amd/) never
+ * links, imports or calls anything in oracle/.
+ *
+ * Pinning status (see oracle/README.md and DESIGN.md):
+ *   - ICP post-assignment chain (DistanceFilter, ReciprocalFilter, PairAssignment chain logic;
+ *     SURVEY row I4) is PINNED against the compiled reference (oracle/_ref, built from the three
+ *     GSL/FLANN-free reference translation units where they lie under /root/reference).
+ *   - every other row (S1-S3, P1-P6, R1-R2, I1-I3, I5-I6, L1) is "PARITY UNPINNED": the reference
+ *     ships no tests / golden vectors and the remaining translation units need GSL + FLANN, which
+ *     are absent from this image (and stand-ins are not allowed), so those rows are a line-by-line
+ *     restatement of the cited reference source only.
+ *
+ * All `file:line` citations are relative to /root/reference/src/.
+ */
+#ifndef TSD_ORACLE_H
+#define TSD_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORA_TILE_DIM   32            /* SlamNode.cpp:77 hard-codes LAYOUT_32x32 */
+#define ORA_TILE_PITCH 33            /* 32 + 1 halo, TsdGridPartition.cpp:97 */
+#define ORA_TILE_CELLS (33 * 33)
+
+typedef struct ora_grid ora_grid;
+
+typedef struct {
+  int64_t cells_updated;       /* addTsd calls that passed sd >= -maxTrunc (N_upd) */
+  int64_t cells_visited;       /* cells of UPDATE tiles that were back-projected */
+  int32_t tiles_total;
+  int32_t tiles_range_pass;    /* passed the two range tests of isInRange */
+  int32_t tiles_update;        /* isInRange returned true */
+  int32_t tiles_new;           /* lazily initialised this push */
+  int32_t tiles_new_from_empty;/* ... of which with initWeight > 0 (N_init_from_empty) */
+  int32_t tiles_emptied_init;  /* increaseEmptiness on an initialised tile (N_emptied_init) */
+  int32_t tiles_emptied_uninit;/* increaseEmptiness on an uninitialised tile */
+} ora_push_stats;
+
+typedef struct {
+  int    iterations;           /* icp_iterations: maxIterations == convCnt (ThreadLocalize.cpp:223-225) */
+  double dist_filter_max;      /* DistanceFilter maxdist */
+  double dist_filter_min;      /* DistanceFilter mindist */
+  double min_x, max_x, min_y, max_y; /* OutOfBoundsFilter2D bounds = TsdGrid::getMin/Max* */
+  int    nn_mode;              /* 0 = brute force (first minimum), 1 = kd-tree (exact) */
+} ora_icp_params;
+
+typedef struct {
+  double T[9];                 /* Icp::getFinalTransformation, 3x3 row-major */
+  double rms;                  /* mean SQUARED pair distance of the last estimating step */
+  int    pairs;                /* pairs of the last step */
+  int    iterations;           /* steps executed */
+  int    state;                /* EnumIcpState (Icp.h:25-32) */
+} ora_icp_result;
+
+/* ---- linear algebra helpers (restating the GSL call pattern) ---- */
+void ora_mat3_mul(const double A[9], const double B[9], double C[9]);
+void ora_mat3_inv(const double A[9], double Ainv[9]);
+
+/* ---- S1: scan ingest ---- */
+/* Sensor::setRealMeasurementData(vector<float>, 1.0f) + SensorPolar2D::setStandardMask */
+void ora_sensor_ingest_f32(const float* ranges, int n, double max_range, double ang_res,
+                           double* data_out, uint8_t* mask_out);
+/* Sensor::setRealMeasurementData(double*) + setStandardMask (ThreadMapping::queuePush path) */
+void ora_sensor_ingest_f64(const double* ranges, int n, double max_range, double ang_res,
+                           double* data_out, uint8_t* mask_out);
+/* ThreadLocalize::laserCallBack range clamp (ThreadLocalize.cpp:250-256) */
+void ora_laser_min_range_clamp(float* ranges, int n, double laser_min_range);
+
+/* ---- S2: back projection ---- */
+int  ora_backproject(const double pose_inv[9], double x, double y, double phi_min, double ang_res,
+                     int beams);
+
+/* ---- S3: ray maps ---- */
+void ora_rays_local(int beams, double phi_min, double ang_res, double* rays_2xB);
+void ora_rays_transform(const double T[9], double* rays_2xB, int beams);
+void ora_rays_rescale(double* rays_2xB, int beams, double norm_new, double norm_old);
+int  ora_scene_from_scan(const double* rays_local_2xB, const double* data, const uint8_t* mask,
+                         int beams, double* scene_2B, uint8_t* mask_s);
+
+/* ---- T0 / P3: grid ---- */
+ora_grid* ora_grid_create(int map_size_log2, double cell_size, double max_trunc_request);
+void      ora_grid_destroy(ora_grid* g);
+int       ora_grid_cells(const ora_grid* g);
+int       ora_grid_tiles(const ora_grid* g);
+double    ora_grid_max_trunc(const ora_grid* g);
+double    ora_grid_max_x(const ora_grid* g);
+int       ora_free_footprint(ora_grid* g, const double center[2], double width, double height);
+void      ora_grid_tile_state(const ora_grid* g, uint8_t* initialized, double* init_weight);
+/* copies 33*33 tsd and weight of one tile; returns 0 if the tile is not initialised */
+int       ora_grid_tile_cells(const ora_grid* g, int tile, double* tsd, double* weight);
+/* canonical dump of all tiles into caller arrays [tiles][1089] (uninitialised tiles -> NaN / 0) */
+void      ora_grid_dump(const ora_grid* g, uint8_t* initialized, double* init_weight,
+                        double* tsd, double* weight);
+void      ora_grid_load(ora_grid* g, const uint8_t* initialized, const double* init_weight,
+                        const double* tsd, const double* weight);
+
+/* ---- P1-P6: push ---- */
+void ora_push(ora_grid* g, const double pose[9], const double* data, const uint8_t* mask,
+              int beams, double ang_res, double phi_min, double max_range, double min_range,
+              double low_refl_range, int threads, ora_push_stats* stats);
+
+/* ---- R1-R2: ray cast ---- */
+int  ora_interpolate_bilinear(const ora_grid* g, double x, double y, double* tsd);
+int  ora_raycast(const ora_grid* g, const double pose[9], const double* rays_world_2xB, int beams,
+                 double min_range, double max_range, int threads, double* coords_2B,
+                 double* normals_2B, uint8_t* mask_B);
+
+/* ---- I1-I6: registration ---- */
+void ora_icp(const double* model_xy, int n_model, const double* scene_xy, int n_scene,
+             const double pose[9], const ora_icp_params* p, ora_icp_result* out,
+             double* trace_per_iter /* optional [iterations][4] = pairs, rms, thr_before, state */);
+/* pair chain of ONE ICP step for unit tests: returns number of pairs; thr is updated in place */
+int  ora_icp_pairs(const double* model_xy, int n_model, const double* scene_xy, int n_scene,
+                   const double pose[9], const ora_icp_params* p, double* thr_sqr,
+                   int* pair_model, int* pair_scene);
+double ora_distance_filter_multiplier(double maxdist, double mindist, int icp_iterations);
+
+/* ---- L1: gates ---- */
+double ora_calc_angle(const double T[9]);
+int    ora_is_registration_error(const double T[9], double trs_max, double sin_rot_max);
+int    ora_is_pose_change_significant(const double last_pose[9], const double cur_pose[9]);
+
+/* ---- N1: occupancy extraction (RayCastAxisAligned2D::calcCoords + ThreadGrid marking) ---- */
+/* content = persistent _occGridContent (caller initialises to -1 once, ThreadGrid.cpp:27-28);
+ * out = the published OccupancyGrid data (copy of content + 100 marks).  Returns #sign changes. */
+int  ora_occupancy(const ora_grid* g, int8_t* content, int8_t* out, int inflate, int inflate_factor);
+
+/* ---- whole-loop driver: ThreadLocalize::init + eventLoop body + ThreadMapping pushes ---- */
+typedef struct ora_slam ora_slam;
+typedef struct {
+  int    map_size_log2; double cell_size; int truncation_radius;
+  int    beams; double angle_min; double angle_increment;
+  double max_range, min_range, low_refl_range;
+  double x_offset, y_offset, local_offset_x, local_offset_y, local_offset_yaw;
+  double footprint_width, footprint_height, footprint_x_offset;
+  double laser_min_range;
+  int    icp_iterations; double dist_filter_max, dist_filter_min;
+  double reg_trs_max, reg_sin_rot_max;
+  int    nn_mode; int threads;
+} ora_slam_config;
+typedef struct {
+  double pose[9]; double T[9];
+  double rms; int pairs; int iterations; int icp_state;
+  int valid_model; int valid_scene;
+  int reg_error; int pushed; int no_model;
+  double t_raycast, t_icp, t_push;  /* seconds */
+} ora_scan_result;
+ora_slam* ora_slam_create(const ora_slam_config* cfg);
+void      ora_slam_destroy(ora_slam* s);
+ora_grid* ora_slam_grid(ora_slam* s);
+/* first call = ThreadLocalize::init (freeFootprint + initPush), later calls = eventLoop body with a
+ * synchronous push where the reference calls queuePush */
+void      ora_slam_process_scan(ora_slam* s, const float* ranges, ora_scan_result* out);
+void      ora_slam_last_push_stats(const ora_slam* s, ora_push_stats* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,98 @@
+"""Test-side closed loop around the HIP kernels: ThreadLocalize::init / eventLoop with the device calls
+of include/tsd_hip.h in place of RayCastPolar2D / Icp / TsdGrid::push, and the O(beams) host steps
+(scan ingest, ray maps, gates) taken from the oracle so that both sides see identical inputs.
+The product's own host side is the C++ facade (ohm_tsd_slam_amd/csrc/host), tested in test_facade*.py.
+"""
+import math
+
+import numpy as np
+
+from ohm_tsd_slam_amd import capi
+
+
+def slam_kwargs(gc, geo, **over):
+    kw = dict(
+        map_size_log2=gc.map_size_log2, cell_size=gc.cell_size, truncation_radius=gc.truncation_radius,
+        beams=geo.beams, angle_min=geo.angle_min, angle_increment=geo.angle_increment,
+        max_range=30.0, min_range=0.001, low_refl_range=2.0,
+        x_offset=0.0, y_offset=0.0, local_offset_x=0.37, local_offset_y=-0.21, local_offset_yaw=0.1,
+        footprint_width=1.0, footprint_height=1.0, footprint_x_offset=0.28,
+        laser_min_range=0.26, icp_iterations=30, dist_filter_max=0.4, dist_filter_min=0.02,
+        reg_trs_max=1.0, reg_sin_rot_max=0.5, nn_mode=0, threads=1,
+    )
+    kw.update(over)
+    return kw
+
+
+class HipSlam:
+    def __init__(self, oracle, fused=True, **kw):
+        self.o = oracle
+        self.kw = kw
+        self.fused = fused
+        self.grid = capi.TsdGridDevice(kw["map_size_log2"], kw["cell_size"], kw["truncation_radius"] * kw["cell_size"])
+        self.initialized = False
+        self.params = self.grid.icp_params(kw["icp_iterations"], kw["dist_filter_max"], kw["dist_filter_min"])
+
+    def process_scan(self, ranges_f32):
+        o, kw, g = self.o, self.kw, self.grid
+        r = np.array(ranges_f32, dtype=np.float32)
+        r[r < kw["laser_min_range"]] = 0.0
+        B, res, phi_min = kw["beams"], kw["angle_increment"], kw["angle_min"]
+        out = dict(pushed=0, reg_error=0, pairs=0, valid_model=0, no_model=0)
+        if not self.initialized:
+            W = g.cells * g.cell_size
+            phi = kw["local_offset_yaw"]
+            sx = W * 0.5 + kw["x_offset"] + kw["local_offset_x"]
+            sy = W * 0.5 + kw["y_offset"] + kw["local_offset_y"]
+            Tinit = np.array([[math.cos(phi), -math.sin(phi), sx], [math.sin(phi), math.cos(phi), sy], [0, 0, 1.0]])
+            self.rays_local = o.rays_local(B, phi_min, res)
+            self.rays = o.rays_transform(Tinit, self.rays_local)
+            self.ray_norm = 1.0
+            self.pose = o.mat3_mul(np.eye(3), Tinit)
+            self.data, self.mask = o.ingest_f32(r, kw["max_range"], res)
+            g.free_footprint([sx + kw["footprint_x_offset"], sy], kw["footprint_width"], kw["footprint_height"])
+            g.push(self.pose, self.data, self.mask, res, phi_min, kw["max_range"], kw["min_range"], kw["low_refl_range"])
+            self.initialized = True
+            self.last_pose = None
+            out.update(pose=self.pose.copy(), pushed=1)
+            return out
+        self.data, self.mask = o.ingest_f32(r, kw["max_range"], res)
+        if self.last_pose is None:
+            self.last_pose = self.pose.copy()
+        self.rays = o.rays_rescale(self.rays, g.cell_size, self.ray_norm)
+        self.ray_norm = g.cell_size
+        if self.fused:
+            res_icp = g.localize(self.pose, self.rays, self.rays_local, self.data, self.mask, kw["min_range"],
+                                 kw["max_range"], self.params)
+            out["valid_model"] = res_icp.n_model
+            if res_icp.n_model == 0:
+                out.update(pose=self.pose.copy(), no_model=1)
+                return out
+        else:
+            co, no, mo, cnt = g.raycast(self.pose, self.rays, kw["min_range"], kw["max_range"])
+            out["valid_model"] = cnt
+            if cnt == 0:
+                out.update(pose=self.pose.copy(), no_model=1)
+                return out
+            scene, ms, _ = o.scene_from_scan(self.rays_local, self.data, self.mask)
+            M = co.reshape(-1, 2)[mo.astype(bool)]
+            S = scene.reshape(-1, 2)[ms.astype(bool)]
+            res_icp = g.icp(M, S, self.pose, self.params)
+        T = res_icp.T
+        out["pairs"] = res_icp.pairs
+        out["T"] = T
+        Tf = o.f64(T).reshape(9)
+        if o.lib().ora_is_registration_error(o.d(Tf), kw["reg_trs_max"], kw["reg_sin_rot_max"]):
+            out.update(pose=self.pose.copy(), reg_error=1)
+            return out
+        self.rays = o.rays_transform(T, self.rays)
+        self.pose = o.mat3_mul(self.pose, T)
+        out["pose"] = self.pose.copy()
+        lp, cp = o.f64(self.last_pose).reshape(9), o.f64(self.pose).reshape(9)
+        if o.lib().ora_is_pose_change_significant(o.d(lp), o.d(cp)):
+            self.last_pose = self.pose.copy()
+            d2, m2 = o.ingest_f64(self.data, kw["max_range"], res)
+            g.push(self.pose, d2, m2, res, phi_min, kw["max_range"], kw["min_range"], kw["low_refl_range"],
+                   want_stats=False)
+            out["pushed"] = 1
+        return out

@@ -1,0 +1,247 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on identical seeded inputs.
+
+Bars (BASELINE.json north_star): tile flags / initWeight / hit masks / pair counts bit-exact; SDF and
+weight within 1e-5 (observed: 0 with fp64 storage); ICP pose within 1e-4 m / 1e-4 rad.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from ohm_tsd_slam_amd import capi, synth
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+TOL_CELL = 1e-5      # SDF / weight tolerance stated by north_star
+TOL_POSE_M = 1e-4
+TOL_POSE_RAD = 1e-4
+
+
+def make_pair(oracle, gc):
+    og = oracle.Grid(gc.map_size_log2, gc.cell_size, gc.max_trunc)
+    dg = capi.TsdGridDevice(gc.map_size_log2, gc.cell_size, gc.max_trunc)
+    return og, dg
+
+
+def push_both(oracle, og, dg, world, geo, k, ranges_f32=None, remask=False):
+    pose, (x, y, yaw) = H.sensor_pose(world, k)
+    r32 = world.scan(x, y, yaw, geo) if ranges_f32 is None else ranges_f32
+    data, mask = oracle.ingest_f32(r32, H.MAX_RANGE, geo.angle_increment)
+    if remask:
+        data, mask = oracle.ingest_f64(data, H.MAX_RANGE, geo.angle_increment)
+    so = og.push(pose, data, mask, geo.angle_increment, geo.angle_min, H.MAX_RANGE, H.MIN_RANGE, H.LOW_REFL)
+    sd = dg.push(pose, data, mask, geo.angle_increment, geo.angle_min, H.MAX_RANGE, H.MIN_RANGE, H.LOW_REFL)
+    return so, sd
+
+
+@pytest.mark.parametrize("scene,map_log2,cs,geo", [
+    ("room", 8, 0.1, synth.ScanGeometry.full_circle_360()),
+    ("room", 9, 0.05, synth.ScanGeometry.full_circle_360()),          # BASELINE cfg 1
+    ("pillars", 10, 0.05, synth.ScanGeometry.utm30lx()),
+])
+def test_push_matches_oracle(oracle, scene, map_log2, cs, geo):
+    gc = synth.GridConfig(map_log2, cs)
+    world = synth.World(scene, gc)
+    og, dg = make_pair(oracle, gc)
+    for k in range(6):
+        so, sd = push_both(oracle, og, dg, world, geo, k * 5)
+        assert so == sd, f"push {k}: stats differ\n oracle {so}\n hip    {sd}"
+        dt, dw = H.assert_grids_equal(og.dump(), dg.download_tiles(), TOL_CELL)
+    assert so["cells_updated"] > 0
+
+
+def test_push_special_readings(oracle):
+    """0.0, NaN, > max_range and +inf readings (Sensor.cpp:252-272, TsdGrid.cpp:266-271)."""
+    gc = synth.GridConfig(8, 0.1)
+    geo = synth.ScanGeometry.utm30lx()
+    world = synth.World("room", gc)
+    og, dg = make_pair(oracle, gc)
+    pose, (x, y, yaw) = H.sensor_pose(world, 0)
+    r = world.scan(x, y, yaw, geo).copy()
+    r[10:40] = 0.0
+    r[100:130] = np.nan
+    r[200:260] = 45.0
+    r[300:330] = np.inf
+    r[500] = 1.0      # depth discontinuity
+    for remask in (False, True):      # initPush path and queuePush re-mask path
+        so, sd = push_both(oracle, og, dg, world, geo, 0, ranges_f32=r, remask=remask)
+        assert so == sd
+        H.assert_grids_equal(og.dump(), dg.download_tiles(), TOL_CELL)
+
+
+def test_push_empties_and_reinit(oracle):
+    """Tiles that become EMPTY (increaseEmptiness on uninitialised and on initialised tiles) and tiles
+    later materialised from _initWeight > 0 (TsdGridComponent.cpp:104-121, TsdGridPartition.cpp:98-108)."""
+    gc = synth.GridConfig(9, 0.05)
+    geo = synth.ScanGeometry.full_circle_360()
+    world = synth.World("room", gc)
+    og, dg = make_pair(oracle, gc)
+    pose, (x, y, yaw) = H.sensor_pose(world, 0)
+    near = np.full(geo.beams, 2.0, dtype=np.float32)
+    far = np.full(geo.beams, 9.0, dtype=np.float32)
+    seen = {"emptied_init": 0, "emptied_uninit": 0, "new_from_empty": 0}
+    for r in (near, far, far, near, far, near):
+        so, sd = push_both(oracle, og, dg, world, geo, 0, ranges_f32=r)
+        assert so == sd
+        H.assert_grids_equal(og.dump(), dg.download_tiles(), TOL_CELL)
+        seen["emptied_init"] += so["tiles_emptied_init"]
+        seen["emptied_uninit"] += so["tiles_emptied_uninit"]
+        seen["new_from_empty"] += so["tiles_new_from_empty"]
+    assert all(v > 0 for v in seen.values()), seen
+
+
+def test_free_footprint_then_push(oracle):
+    gc = synth.GridConfig(8, 0.05)
+    geo = synth.ScanGeometry.full_circle_360()
+    world = synth.World("room", gc)
+    og, dg = make_pair(oracle, gc)
+    c = [world.start[0] + 0.28, world.start[1]]
+    assert og.free_footprint(c, 1.0, 1.0) and dg.free_footprint(c, 1.0, 1.0)
+    H.assert_grids_equal(og.dump(), dg.download_tiles(), 0.0)
+    so, sd = push_both(oracle, og, dg, world, geo, 0)
+    assert so == sd
+    H.assert_grids_equal(og.dump(), dg.download_tiles(), TOL_CELL)
+    # out of bounds rectangle is rejected by both (TsdGrid.cpp:617-622)
+    assert not og.free_footprint([1e4, 1e4], 1.0, 1.0)
+    assert not dg.free_footprint([1e4, 1e4], 1.0, 1.0)
+
+
+def build_map(oracle, gc, geo, world, pushes=4):
+    og, dg = make_pair(oracle, gc)
+    for k in range(pushes):
+        push_both(oracle, og, dg, world, geo, k * 3)
+    # identical grids on both sides from here on (upload the oracle's dump so that later comparisons
+    # isolate the kernel under test)
+    dg.upload_tiles(*og.dump())
+    return og, dg
+
+
+@pytest.mark.parametrize("scene,map_log2,cs,geo", [
+    ("room", 9, 0.05, synth.ScanGeometry.full_circle_360()),
+    ("pillars", 10, 0.05, synth.ScanGeometry.utm30lx()),
+])
+def test_raycast_matches_oracle(oracle, scene, map_log2, cs, geo):
+    gc = synth.GridConfig(map_log2, cs)
+    world = synth.World(scene, gc)
+    og, dg = build_map(oracle, gc, geo, world)
+    for k in (1, 4, 10):
+        pose, _ = H.sensor_pose(world, k)
+        rl, rw = H.world_rays(oracle, geo, pose, gc.cell_size)
+        co, no, mo, cnt_o = og.raycast(pose, rw, H.MIN_RANGE, H.MAX_RANGE)
+        cd, nd, md, cnt_d = dg.raycast(pose, rw, H.MIN_RANGE, H.MAX_RANGE)
+        assert np.array_equal(mo, md), f"hit masks differ at beams {np.nonzero(mo != md)[0][:10]}"
+        assert cnt_o == cnt_d and cnt_o > 0.5 * geo.beams
+        sel = np.repeat(mo.astype(bool), 2)
+        assert np.max(np.abs(co[sel] - cd[sel])) <= 1e-9
+        assert np.max(np.abs(no[sel] - nd[sel])) <= 1e-9
+
+
+def test_raycast_outside_and_empty(oracle):
+    """Sensor outside the grid and an empty map: no hits, no crash (RayCastPolar2D.cpp:137-146)."""
+    gc = synth.GridConfig(8, 0.05)
+    geo = synth.ScanGeometry.full_circle_360()
+    og, dg = make_pair(oracle, gc)
+    for pose in (synth.pose_matrix(-3.0, 2.0, 0.3), synth.pose_matrix(6.4, 6.4, 0.0)):
+        rl, rw = H.world_rays(oracle, geo, pose, gc.cell_size)
+        _, _, mo, cnt_o = og.raycast(pose, rw, H.MIN_RANGE, H.MAX_RANGE)
+        _, _, md, cnt_d = dg.raycast(pose, rw, H.MIN_RANGE, H.MAX_RANGE)
+        assert cnt_o == cnt_d == 0 and not md.any()
+
+
+def icp_inputs(oracle, gc, geo, world, k, og):
+    pose, (x, y, yaw) = H.sensor_pose(world, k)
+    rl, rw = H.world_rays(oracle, geo, pose, gc.cell_size)
+    co, no, mo, _ = og.raycast(pose, rw, H.MIN_RANGE, H.MAX_RANGE)
+    # scan taken from a slightly different true pose => non-trivial registration
+    r32 = world.scan(x + 0.05, y - 0.03, yaw + 0.015, geo)
+    data, mask = oracle.ingest_f32(r32, H.MAX_RANGE, geo.angle_increment)
+    scene, ms, _ = oracle.scene_from_scan(rl, data, mask)
+    M = co.reshape(-1, 2)[mo.astype(bool)]
+    S = scene.reshape(-1, 2)[ms.astype(bool)]
+    return pose, rl, rw, data, mask, M, S
+
+
+@pytest.mark.parametrize("iters", [30, 25, 10, 11, 5])
+def test_icp_matches_oracle(oracle, iters):
+    gc = synth.GridConfig(10, 0.05)
+    geo = synth.ScanGeometry.utm30lx()
+    world = synth.World("pillars", gc)
+    og, dg = build_map(oracle, gc, geo, world)
+    pose, rl, rw, data, mask, M, S = icp_inputs(oracle, gc, geo, world, 2, og)
+    bounds = (0.0, og.max_x, 0.0, og.max_x)
+    ro = oracle.icp(M, S, pose, iters, 0.4, 0.02, bounds, nn_mode=0)
+    rd = dg.icp(M, S, pose, dg.icp_params(iters, 0.4, 0.02))
+    assert (ro["pairs"], ro["iterations"], ro["state"]) == (rd.pairs, rd.iterations, rd.state)
+    d, a = H.pose_delta(ro["T"], rd.T)
+    assert d <= TOL_POSE_M and a <= TOL_POSE_RAD, (d, a)
+    assert abs(ro["rms"] - rd.rms) <= 1e-9
+    # the registration actually moved the scan
+    assert np.hypot(rd.T[0, 2], rd.T[1, 2]) > 0.02
+
+
+def test_icp_degenerate(oracle):
+    """<= 2 pairs: NOTMATCHABLE on the first step is reported as SUCCESS with T = I (Icp.cpp:489-505)."""
+    gc = synth.GridConfig(8, 0.05)
+    dg = capi.TsdGridDevice(gc.map_size_log2, gc.cell_size, gc.max_trunc)
+    og = oracle.Grid(gc.map_size_log2, gc.cell_size, gc.max_trunc)
+    M = np.array([[1.0, 1.0], [2.0, 2.0], [3.0, 1.5]])
+    S = M + 5.0     # farther than dist_filter_max
+    pose = synth.pose_matrix(6.0, 6.0, 0.0)
+    bounds = (0.0, og.max_x, 0.0, og.max_x)
+    ro = oracle.icp(M, S, pose, 30, 0.4, 0.02, bounds)
+    rd = dg.icp(M, S, pose, dg.icp_params(30, 0.4, 0.02))
+    assert (ro["pairs"], ro["iterations"], ro["state"]) == (rd.pairs, rd.iterations, rd.state) == (0, 1, 5)
+    assert np.array_equal(rd.T, np.eye(3))
+    # empty model / scene (Icp.cpp:467-471)
+    rd = dg.icp(np.zeros((0, 2)), S, pose, dg.icp_params(30, 0.4, 0.02))
+    assert rd.state == 2
+
+
+def test_localize_fused_matches_pieces(oracle):
+    """tsd_localize == tsd_raycast + host compaction + tsd_icp, and == the oracle chain."""
+    gc = synth.GridConfig(10, 0.05)
+    geo = synth.ScanGeometry.utm30lx()
+    world = synth.World("pillars", gc)
+    og, dg = build_map(oracle, gc, geo, world)
+    pose, rl, rw, data, mask, M, S = icp_inputs(oracle, gc, geo, world, 3, og)
+    bounds = (0.0, og.max_x, 0.0, og.max_x)
+    ro = oracle.icp(M, S, pose, 30, 0.4, 0.02, bounds)
+    p = dg.icp_params(30, 0.4, 0.02)
+    rf = dg.localize(pose, rw, rl, data, mask, H.MIN_RANGE, H.MAX_RANGE, p)
+    assert (rf.n_model, rf.n_scene) == (len(M), len(S))
+    assert (ro["pairs"], ro["iterations"], ro["state"]) == (rf.pairs, rf.iterations, rf.state)
+    d, a = H.pose_delta(ro["T"], rf.T)
+    assert d <= TOL_POSE_M and a <= TOL_POSE_RAD
+
+
+def test_closed_loop_trajectory(oracle):
+    """init -> [raycast -> ICP -> transform -> push] x K on both sides, poses compared every scan."""
+    gc = synth.GridConfig(9, 0.05)
+    geo = synth.ScanGeometry.full_circle_360()
+    world = synth.World("room", gc)
+    poses = synth.trajectory(world, 12)
+    scans = synth.scans_for(world, geo, poses)
+    from tests.slam_driver import HipSlam, slam_kwargs
+    kw = slam_kwargs(gc, geo)
+    so = oracle.Slam(**kw)
+    sh = HipSlam(oracle, **kw)
+    for k in range(len(scans)):
+        ro = so.process_scan(scans[k])
+        rh = sh.process_scan(scans[k])
+        Po = np.array(ro.pose[:]).reshape(3, 3)
+        d, a = H.pose_delta(Po, rh["pose"])
+        assert d <= TOL_POSE_M and a <= TOL_POSE_RAD, f"scan {k}: {d} {a}"
+        assert ro.pushed == rh["pushed"] and ro.reg_error == rh["reg_error"]
+        if k > 0:
+            assert ro.pairs == rh["pairs"] and ro.valid_model == rh["valid_model"]
+            # tracks ground truth
+            assert np.hypot(Po[0, 2] - poses[k, 0], Po[1, 2] - poses[k, 1]) < 0.15
+    oi, oiw, ot, ow = so.grid.dump()
+    gi, giw, gt, gw = sh.grid.download_tiles()
+    assert np.array_equal(oi, gi)
+    sel = oi.astype(bool)
+    m = ~np.isnan(ot[sel])
+    assert np.array_equal(np.isnan(ot[sel]), np.isnan(gt[sel]))
+    assert np.max(np.abs(ot[sel][m] - gt[sel][m])) <= TOL_CELL
+    assert np.max(np.abs(ow[sel] - gw[sel])) <= TOL_CELL
