@@ -83,6 +83,7 @@ int      tsd_device_count(void);
 tsd_ctx* tsd_create(int device, int map_size_log2, double cell_size, double max_trunc);
 void     tsd_destroy(tsd_ctx* ctx);
 int      tsd_reset(tsd_ctx* ctx);                          /* TsdGrid::reset (TsdGrid.cpp:194-198) */
+int      tsd_set_max_truncation(tsd_ctx* ctx, double val); /* TsdGrid::setMaxTruncation (:206-215) */
 int      tsd_sync(tsd_ctx* ctx);
 const char* tsd_last_error(const tsd_ctx* ctx);
 

@@ -78,6 +78,7 @@ ABI = {
     "tsd_create": (C.c_void_p, [C.c_int, C.c_int, C.c_double, C.c_double]),
     "tsd_destroy": (None, [C.c_void_p]),
     "tsd_reset": (C.c_int, [C.c_void_p]),
+    "tsd_set_max_truncation": (C.c_int, [C.c_void_p, C.c_double]),
     "tsd_sync": (C.c_int, [C.c_void_p]),
     "tsd_last_error": (C.c_char_p, [C.c_void_p]),
     "tsd_cells": (C.c_int, [C.c_void_p]),

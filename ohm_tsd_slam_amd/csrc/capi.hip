@@ -259,6 +259,15 @@ int tsd_reset(tsd_ctx* ctx)
   return TSD_OK;
 }
 
+int tsd_set_max_truncation(tsd_ctx* ctx, double val)
+{
+  if (!ctx) return TSD_E_ARG;
+  // TsdGrid::setMaxTruncation (TsdGrid.cpp:206-215): at least 2 x cell size
+  if (val < 2 * ctx->grid.cs) val = 2 * ctx->grid.cs;
+  ctx->grid.max_trunc = val;
+  return TSD_OK;
+}
+
 int tsd_sync(tsd_ctx* ctx)
 {
   if (!ctx) return TSD_E_ARG;

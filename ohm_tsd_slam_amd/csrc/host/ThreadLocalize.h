@@ -1,0 +1,97 @@
+// ThreadLocalize.h -- per-robot localisation worker; public surface of the reference's
+// ThreadLocalize (src/ThreadLocalize.h:73-104): same constructor, same laserCallBack entry point, same
+// parameters, topic and message content.  The arithmetic of eventLoop (ray cast, ICP) runs on the GPU
+// through obvious::TsdGrid::localize; scan ingest, gates and pose bookkeeping stay on the host.
+// registration_mode 0 (ICP only) is implemented; modes 1-3 are the reference's RANSAC-style
+// pre-registrations seeded with wall-clock time (out of scope) and fall back to 0 with a
+// warning, as the reference does for unknown modes (ThreadLocalize.cpp:188-190).
+#pragma once
+#include <deque>
+#include <memory>
+#include <string>
+
+#include "ThreadSLAM.h"
+#include "ros_shim.h"
+
+namespace ohm_tsd_slam
+{
+
+class ThreadMapping;
+
+namespace
+{
+  const double TRNS_MIN = 0.05;   // minimal pose change that triggers a push (ThreadLocalize.h:63-64)
+  const double ROT_MIN  = 0.03;
+}
+
+class ThreadLocalize: public ThreadSLAM
+{
+public:
+  ThreadLocalize(obvious::TsdGrid* grid, ThreadMapping* mapper, const std::shared_ptr<rclcpp::Node>& node,
+                 const std::string& robot_name, const double xOffset, const double yOffset);
+  virtual ~ThreadLocalize();
+
+  /** laser subscription callback (ThreadLocalize.cpp:248-276): first scan initialises synchronously,
+   *  later scans are queued for the localisation thread (newest wins) */
+  void laserCallBack(const std::shared_ptr<sensor_msgs::msg::LaserScan> scan);
+
+  // ---- additions for tests / benchmarks (not in the reference) ----
+  /** run the event-loop body on the caller's thread and push in stream order instead of handing
+   *  over to the two worker threads: the strict R -> I -> P order the parity tests need */
+  void setSynchronous(bool on) { _synchronous = on; }
+  struct ScanReport {
+    double pose[9]; double T[9]; double rms; int pairs; int iterations; int icpState;
+    int validModel; int validScene; bool regError; bool pushed; bool noModel; bool initialised;
+  };
+  ScanReport lastReport();
+  uint64_t processedScans();
+  /** nothing queued and nothing being processed */
+  bool idle();
+  std::shared_ptr<rclcpp::Publisher<geometry_msgs::msg::PoseStamped>> posePublisher() { return _posePub; }
+  obvious::SensorPolar2D* sensor() { return _sensor; }
+
+  // gates (static: also unit-tested against the oracle)
+  static double calcAngle(obvious::Matrix* T);                                               // :715-726
+  static bool isRegistrationError(obvious::Matrix* T, const double trnsMax, const double rotMax);   // :593-600
+  static bool isPoseChangeSignificant(obvious::Matrix* lastPose, obvious::Matrix* curPose);   // :728-736
+
+protected:
+  virtual void eventLoop(void);
+
+private:
+  void init(const sensor_msgs::msg::LaserScan& scan);
+  void processScan(const std::vector<float>& rangesIn, const builtin_interfaces::msg::Time& stamp);
+  void sendTransform(obvious::Matrix* T);
+  void sendNanTransform();
+
+  std::shared_ptr<rclcpp::Node> _node;
+  ThreadMapping& _mapper;
+  obvious::SensorPolar2D* _sensor;
+  bool _initialized;
+  bool _synchronous;
+  const double _gridWidth, _gridHeight, _gridOffSetX, _gridOffSetY, _xOffset, _yOffset;
+  std::string _robotName, _nameSpace;
+  std::string _tfMapFrameId, _tfOdomFrameId, _tfLaserFrameId, _tfFootprintFrameId;
+  double _trnsMax, _rotMax, _lasMinRange;
+  int _regMode;
+  bool _reverseScan;
+  tsd_icp_params _icpParams;
+  obvious::Matrix* _lastPose;
+  bool _haveLastPose;
+  builtin_interfaces::msg::Time _stampLaser, _stampLaserOld;
+
+  std::deque<std::shared_ptr<sensor_msgs::msg::LaserScan>> _laserData;
+  std::mutex _dataMutex;
+  bool _busy;
+
+  std::shared_ptr<rclcpp::Publisher<geometry_msgs::msg::PoseStamped>> _posePub;
+  std::unique_ptr<tf2_ros::TransformBroadcaster> _tfBroadcaster;
+  geometry_msgs::msg::PoseStamped _poseStamped;
+  geometry_msgs::msg::TransformStamped _tf;
+
+  std::mutex _reportMutex;
+  ScanReport _report;
+  uint64_t _processed;
+};
+
+} /* namespace ohm_tsd_slam */

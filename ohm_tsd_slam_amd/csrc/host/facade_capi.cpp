@@ -1,0 +1,243 @@
+// facade_capi.cpp -- a flat C surface over the C++ facade so that the Python test / bench drivers can
+// exercise ThreadLocalize / ThreadMapping exactly as SlamNode wires them (SlamNode.cpp:27-129): one
+// TsdGrid, one ThreadMapping, N ThreadLocalize sharing them, laser callbacks per robot.
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "ThreadLocalize.h"
+#include "ThreadMapping.h"
+
+using namespace ohm_tsd_slam;
+
+struct tsd_node
+{
+  std::shared_ptr<rclcpp::Node> node;
+  obvious::TsdGrid* grid = nullptr;
+  ThreadMapping* mapping = nullptr;
+  std::vector<ThreadLocalize*> localizers;
+  std::vector<uint64_t> submitted;
+  bool synchronous = false;
+};
+
+extern "C" {
+
+tsd_node* tsd_node_create(const char* node_name)
+{
+  tsd_node* n = new tsd_node();
+  n->node = std::make_shared<rclcpp::Node>(node_name ? node_name : "tsd_slam");
+  return n;
+}
+
+void tsd_node_set_double(tsd_node* n, const char* name, double v) { n->node->set_parameter(name, v); }
+void tsd_node_set_int(tsd_node* n, const char* name, int v) { n->node->set_parameter(name, v); }
+void tsd_node_set_bool(tsd_node* n, const char* name, int v) { n->node->set_parameter(name, v != 0); }
+void tsd_node_set_string(tsd_node* n, const char* name, const char* v) { n->node->set_parameter(name, std::string(v)); }
+
+// SlamNode::initialize (SlamNode.cpp:40-122): grid parameters, grid, mapping thread, localisers
+int tsd_node_initialize(tsd_node* n, int device)
+{
+  auto& node = n->node;
+  node->declare_parameter("robot_nbr", 1);
+  node->declare_parameter("x_off_factor", 0.5);
+  node->declare_parameter("y_off_factor", 0.5);
+  node->declare_parameter("x_offset", 0.0);
+  node->declare_parameter("y_offset", 0.0);
+  node->declare_parameter("map_size", 10);
+  node->declare_parameter("cellsize", 0.025);
+  node->declare_parameter("truncation_radius", 3);
+  node->declare_parameter("occ_grid_time_interval", 2.0);
+  node->declare_parameter("tf_map_frame", std::string("map"));
+  const unsigned robotNbr = (unsigned)node->get_parameter("robot_nbr").as_int();
+  const double xOffset = node->get_parameter("x_offset").as_double();
+  const double yOffset = node->get_parameter("y_offset").as_double();
+  unsigned octaveFactor = (unsigned)node->get_parameter("map_size").as_int();
+  const double cellSize = node->get_parameter("cellsize").as_double();
+  const double truncationRadius = (double)node->get_parameter("truncation_radius").as_int();
+  if(octaveFactor > 15)
+    octaveFactor = 10;   // "Unknown map size -> set to default" (SlamNode.cpp:71-75)
+
+  n->grid = new obvious::TsdGrid(cellSize, obvious::LAYOUT_32x32, static_cast<obvious::EnumTsdGridLayout>(octaveFactor), device);
+  if(!n->grid->valid())
+    return TSD_E_NODEVICE;
+  n->grid->setMaxTruncation(truncationRadius * cellSize);
+  n->mapping = new ThreadMapping(n->grid);
+  if(robotNbr == 1)
+  {
+    n->localizers.push_back(new ThreadLocalize(n->grid, n->mapping, node, "", xOffset, yOffset));
+  }
+  else
+  {
+    for(unsigned i = 0; i < robotNbr; i++)
+    {
+      const std::string key = "robot_" + std::to_string(i) + "/name";
+      node->declare_parameter(key, "robot_" + std::to_string(i));
+      const std::string robot_name = node->get_parameter(key).as_string();
+      n->localizers.push_back(new ThreadLocalize(n->grid, n->mapping, node, robot_name, xOffset, yOffset));
+    }
+  }
+  n->submitted.assign(n->localizers.size(), 0);
+  for(auto* l : n->localizers)
+    l->setSynchronous(n->synchronous);
+  return TSD_OK;
+}
+
+void tsd_node_set_synchronous(tsd_node* n, int on)
+{
+  n->synchronous = on != 0;
+  for(auto* l : n->localizers)
+    l->setSynchronous(n->synchronous);
+}
+
+int tsd_node_laser(tsd_node* n, int robot, const float* ranges, int count, double angle_min,
+                   double angle_increment, long long stamp_ns)
+{
+  if(!n || robot < 0 || robot >= (int)n->localizers.size())
+    return TSD_E_ARG;
+  auto scan = std::make_shared<sensor_msgs::msg::LaserScan>();
+  scan->ranges.assign(ranges, ranges + count);
+  scan->angle_min = (float)angle_min;
+  scan->angle_increment = (float)angle_increment;
+  scan->header.stamp.sec = (int32_t)(stamp_ns / 1000000000LL);
+  scan->header.stamp.nanosec = (uint32_t)(stamp_ns % 1000000000LL);
+  n->localizers[robot]->laserCallBack(scan);
+  return TSD_OK;
+}
+
+// asynchronous mode: wait until the localiser has nothing queued, the mapping queue is drained and
+// the device is idle.  Returns 0 when idle, 1 on timeout.
+int tsd_node_wait_idle(tsd_node* n, int timeout_ms)
+{
+  const auto t0 = std::chrono::steady_clock::now();
+  for(;;)
+  {
+    bool idle = true;
+    for(auto* l : n->localizers)
+      idle = idle && l->idle();
+    idle = idle && n->mapping->pending() == 0;
+    if(idle)
+    {
+      std::lock_guard<std::mutex> lk(n->grid->mutex());
+      tsd_sync(n->grid->context());
+      return 0;
+    }
+    if(std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(timeout_ms))
+      return 1;
+    std::this_thread::sleep_for(std::chrono::microseconds(200));
+  }
+}
+
+unsigned long long tsd_node_processed(tsd_node* n, int robot) { return n->localizers[robot]->processedScans(); }
+
+// report layout: pose[9], T[9], rms, pairs, iterations, icpState, validModel, validScene, regError,
+// pushed, noModel, initialised  (28 doubles)
+void tsd_node_report(tsd_node* n, int robot, double* out28)
+{
+  const ThreadLocalize::ScanReport r = n->localizers[robot]->lastReport();
+  std::memcpy(out28, r.pose, sizeof(r.pose));
+  std::memcpy(out28 + 9, r.T, sizeof(r.T));
+  out28[18] = r.rms; out28[19] = r.pairs; out28[20] = r.iterations; out28[21] = r.icpState;
+  out28[22] = r.validModel; out28[23] = r.validScene; out28[24] = r.regError; out28[25] = r.pushed;
+  out28[26] = r.noModel; out28[27] = r.initialised;
+}
+
+// last PoseStamped on <node>/<robot/>estimated_pose: x, y, z, qx, qy, qz, qw, publish count
+void tsd_node_pose_msg(tsd_node* n, int robot, double* out8)
+{
+  auto pub = n->localizers[robot]->posePublisher();
+  const auto m = pub->last();
+  out8[0] = m.pose.position.x; out8[1] = m.pose.position.y; out8[2] = m.pose.position.z;
+  out8[3] = m.pose.orientation.x; out8[4] = m.pose.orientation.y; out8[5] = m.pose.orientation.z;
+  out8[6] = m.pose.orientation.w; out8[7] = (double)pub->count();
+}
+
+const char* tsd_node_pose_topic(tsd_node* n, int robot)
+{
+  return n->localizers[robot]->posePublisher()->topic().c_str();
+}
+
+tsd_ctx* tsd_node_grid_ctx(tsd_node* n) { return n->grid ? n->grid->context() : nullptr; }
+
+// SlamNode::~SlamNode shutdown order (SlamNode.cpp:131-152): terminate + join every thread
+void tsd_node_destroy(tsd_node* n)
+{
+  if(!n)
+    return;
+  for(auto* l : n->localizers)
+  {
+    l->terminateThread();
+    while(!l->alive(1)) {}
+    delete l;
+  }
+  if(n->mapping)
+  {
+    n->mapping->terminateThread();
+    while(!n->mapping->alive(1)) {}
+    delete n->mapping;
+  }
+  delete n->grid;
+  delete n;
+}
+
+// host-only helpers for the CPU unit tests of the sensor model and gates ------------------------
+void tsd_host_sensor_ingest_f32(const float* ranges, int n, double ang_res, double phi_min, double max_range,
+                                double* data_out, unsigned char* mask_out, int remask)
+{
+  obvious::SensorPolar2D s((unsigned)n, ang_res, phi_min, max_range, 0.001, 2.0);
+  s.setRealMeasurementData(std::vector<float>(ranges, ranges + n));
+  s.setStandardMask();
+  if(remask)
+  {
+    std::unique_ptr<obvious::SensorPolar2D> c(s.copyForMapping());
+    std::memcpy(data_out, c->getRealMeasurementData(), sizeof(double) * (size_t)n);
+    std::memcpy(mask_out, c->maskBytes(), (size_t)n);
+    return;
+  }
+  std::memcpy(data_out, s.getRealMeasurementData(), sizeof(double) * (size_t)n);
+  std::memcpy(mask_out, s.maskBytes(), (size_t)n);
+}
+
+// pose after `transform(T1)` then `transform(T2)`, world rays scaled to `norm`, scene points
+void tsd_host_sensor_chain(int n, double ang_res, double phi_min, const double* T1, const double* T2, double norm,
+                           const float* ranges, double* pose_out, double* rays_out, double* rays_local_out,
+                           double* scene_out, unsigned char* scene_mask_out, int* valid_out)
+{
+  obvious::SensorPolar2D s((unsigned)n, ang_res, phi_min, 30.0, 0.001, 2.0);
+  obvious::Matrix A(3, 3, T1), B(3, 3, T2);
+  s.setRealMeasurementData(std::vector<float>(ranges, ranges + n));
+  s.setStandardMask();
+  s.transform(&A);
+  const double* r = s.getNormalizedRayMap(norm);
+  (void)r;
+  s.transform(&B);
+  r = s.getNormalizedRayMap(norm);
+  s.getTransformation().getData(pose_out);
+  std::memcpy(rays_out, r, sizeof(double) * 2 * (size_t)n);
+  std::memcpy(rays_local_out, s.getLocalRayMap(), sizeof(double) * 2 * (size_t)n);
+  std::vector<char> m((size_t)n);
+  *valid_out = (int)s.dataToCartesianVectorMask(scene_out, reinterpret_cast<bool*>(m.data()));
+  for(int i = 0; i < n; i++) scene_mask_out[i] = m[(size_t)i] ? 1 : 0;
+}
+
+double tsd_host_calc_angle(const double* T) { obvious::Matrix M(3, 3, T); return ThreadLocalize::calcAngle(&M); }
+int tsd_host_is_registration_error(const double* T, double trs, double rot)
+{
+  obvious::Matrix M(3, 3, T);
+  return ThreadLocalize::isRegistrationError(&M, trs, rot) ? 1 : 0;
+}
+int tsd_host_is_pose_change_significant(const double* last, const double* cur)
+{
+  obvious::Matrix A(3, 3, last), B(3, 3, cur);
+  return ThreadLocalize::isPoseChangeSignificant(&A, &B) ? 1 : 0;
+}
+void tsd_host_mat3_inv(const double* A, double* out) { obvious::Matrix M(3, 3, A); M.invert(); M.getData(out); }
+int tsd_host_backproject(const double* pose, double x, double y, int n, double ang_res, double phi_min)
+{
+  obvious::SensorPolar2D s((unsigned)n, ang_res, phi_min, 30.0, 0.001, 2.0);
+  s.setTransformation(obvious::Matrix(3, 3, pose));
+  double p[2] = {x, y};
+  return s.backProject(p);
+}
+
+}  // extern "C"

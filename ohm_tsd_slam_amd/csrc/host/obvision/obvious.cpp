@@ -1,0 +1,276 @@
+// obvious.cpp -- host-side sensor model and the device-grid handle (see obvious.h).
+#include "obvious.h"
+
+#include <algorithm>
+#include <cstdio>
+
+namespace obvious {
+
+// ---------------------------------------------------------------------------------------- Matrix
+Matrix::Matrix(unsigned rows, unsigned cols) : _rows(rows), _cols(cols)
+{
+  std::memset(_d, 0, sizeof(_d));
+}
+Matrix::Matrix(unsigned rows, unsigned cols, const double* data) : _rows(rows), _cols(cols)
+{
+  std::memset(_d, 0, sizeof(_d));
+  std::memcpy(_d, data, sizeof(double) * rows * cols);
+}
+void Matrix::setIdentity()
+{
+  for (unsigned r = 0; r < _rows; r++)
+    for (unsigned c = 0; c < _cols; c++) (*this)(r, c) = (r == c) ? 1.0 : 0.0;
+}
+void Matrix::setData(const double* array) { std::memcpy(_d, array, sizeof(double) * _rows * _cols); }
+void Matrix::getData(double* array) const { std::memcpy(array, _d, sizeof(double) * _rows * _cols); }
+
+// gsl_blas_dgemm(NoTrans, NoTrans, 1.0, A, B, 0.0, C): C[i][j] = sum_k A[i][k] B[k][j], k ascending
+Matrix Matrix::operator*(const Matrix& M) const
+{
+  Matrix R(_rows, M._cols);
+  for (unsigned i = 0; i < _rows; i++)
+    for (unsigned j = 0; j < M._cols; j++) {
+      double t = 0.0;
+      for (unsigned k = 0; k < _cols; k++) t += (*this)(i, k) * M(k, j);
+      R(i, j) = t;
+    }
+  return R;
+}
+
+// gsl_linalg_LU_decomp + gsl_linalg_LU_invert (gsl/Matrix.cpp:168-179): partial pivoting, inverse by
+// solving against the identity columns.  3x3 only (poses).
+void Matrix::invert()
+{
+  const unsigned n = _rows;
+  double lu[16];
+  int perm[4] = {0, 1, 2, 3};
+  for (unsigned i = 0; i < n; i++)
+    for (unsigned j = 0; j < n; j++) lu[n * i + j] = (*this)(i, j);
+  for (unsigned j = 0; j < n; j++) {
+    unsigned piv = j;
+    double best = std::fabs(lu[n * j + j]);
+    for (unsigned i = j + 1; i < n; i++)
+      if (std::fabs(lu[n * i + j]) > best) { best = std::fabs(lu[n * i + j]); piv = i; }
+    if (piv != j) {
+      for (unsigned k = 0; k < n; k++) std::swap(lu[n * j + k], lu[n * piv + k]);
+      std::swap(perm[j], perm[piv]);
+    }
+    for (unsigned i = j + 1; i < n; i++) {
+      lu[n * i + j] = lu[n * i + j] / lu[n * j + j];
+      for (unsigned k = j + 1; k < n; k++) lu[n * i + k] -= lu[n * i + j] * lu[n * j + k];
+    }
+  }
+  for (unsigned c = 0; c < n; c++) {
+    double x[4];
+    for (unsigned i = 0; i < n; i++) x[i] = (perm[i] == (int)c) ? 1.0 : 0.0;
+    for (unsigned i = 1; i < n; i++)
+      for (unsigned k = 0; k < i; k++) x[i] -= lu[n * i + k] * x[k];
+    for (int i = (int)n - 1; i >= 0; i--) {
+      for (unsigned k = (unsigned)i + 1; k < n; k++) x[i] -= lu[n * i + k] * x[k];
+      x[i] = x[i] / lu[n * i + i];
+    }
+    for (unsigned i = 0; i < n; i++) (*this)(i, c) = x[i];
+  }
+}
+
+// --------------------------------------------------------------------------------- SensorPolar2D
+SensorPolar2D::SensorPolar2D(unsigned int size, double angularRes, double phiMin, double maxRange,
+                             double minRange, double lowReflectivityRange)
+    : _size(size), _angularRes(angularRes), _phiMin(phiMin), _maxRange(maxRange), _minRange(minRange),
+      _lowReflectivityRange(lowReflectivityRange), _rayNorm(1.0), _T(3, 3), _data(size, 0.0),
+      _mask(size, 1), _rays(2 * size), _raysLocal(2 * size)
+{
+  _T.setIdentity();
+  _phiLowerBound = -0.5 * _angularRes + _phiMin;                       // SensorPolar2D.cpp:26
+  _phiUpperBound = _phiMin + (((double)size) - 0.5) * _angularRes;    // :30
+  for (unsigned int i = 0; i < _size; i++) {                          // :39-44
+    const double phi = _phiMin + ((double)i) * _angularRes;
+    _rays[i] = std::cos(phi);
+    _rays[_size + i] = std::sin(phi);
+  }
+  _raysLocal = _rays;
+}
+
+void SensorPolar2D::setRealMeasurementData(const std::vector<float>& data, float scale)
+{
+  const size_t n = std::min<size_t>(data.size(), _size);
+  for (size_t i = 0; i < n; i++) _data[i] = (double)(data[i] * scale);   // float multiply, then widen
+}
+
+void SensorPolar2D::setRealMeasurementData(const double* data, double scale)
+{
+  if (scale == 1.0) std::memcpy(_data.data(), data, _size * sizeof(*data));
+  else
+    for (unsigned int i = 0; i < _size; i++) _data[i] = data[i] * scale;
+}
+
+void SensorPolar2D::setStandardMask()
+{
+  resetMask();
+  maskZeroDepth();
+  maskInvalidDepth();
+  maskDepthDiscontinuity(3.0 * M_PI / 180.0);   // deg2rad(3.0), mathbase.h:175-178
+}
+
+void SensorPolar2D::resetMask() { std::fill(_mask.begin(), _mask.end(), 1); }
+
+void SensorPolar2D::maskZeroDepth()
+{
+  for (unsigned int i = 0; i < _size; i++) _mask[i] = _mask[i] && (_data[i] != 0.0);
+}
+
+void SensorPolar2D::maskInvalidDepth()
+{
+  for (unsigned int i = 0; i < _size; i++) {
+    if (_data[i] > _maxRange) _data[i] = INFINITY;
+    if (std::isnan(_data[i])) { _mask[i] = 0; _data[i] = INFINITY; }
+  }
+}
+
+void SensorPolar2D::maskDepthDiscontinuity(double thresh)
+{
+  const int radius = 1;
+  const double cosphi = std::cos(_angularRes), sinphi = std::sin(_angularRes);
+  for (int i = radius; i < ((int)_size) - radius; i++) {
+    double betamin = M_PI;
+    const double a = _data[i];
+    if (std::isinf(a)) continue;
+    for (int j = -radius; j <= radius; j++) {
+      const double b = _data[i + j];
+      if (std::isinf(b)) continue;
+      const double c = std::sqrt(a * a + b * b - 2 * a * b * cosphi);   // law of cosines
+      if (a > b) {
+        const double beta = std::asin(b / c * sinphi);                   // law of sines
+        if (beta < betamin) betamin = beta;
+      }
+    }
+    if (betamin < thresh) _mask[i] = 0;
+  }
+}
+
+void SensorPolar2D::transform(Matrix* T)
+{
+  // (*_rays) = R * (*_rays), R = T[0:2,0:2]
+  for (unsigned int i = 0; i < _size; i++) {
+    const double x = _rays[i], y = _rays[_size + i];
+    double nx = 0.0, ny = 0.0;
+    nx += (*T)(0, 0) * x; nx += (*T)(0, 1) * y;
+    ny += (*T)(1, 0) * x; ny += (*T)(1, 1) * y;
+    _rays[i] = nx; _rays[_size + i] = ny;
+  }
+  _T = _T * (*T);   // P' = P T
+}
+
+const double* SensorPolar2D::getNormalizedRayMap(double norm)
+{
+  if (norm != _rayNorm) {
+    for (unsigned int i = 0; i < _size; i++) {
+      _rays[i] *= (norm / _rayNorm);
+      _rays[_size + i] *= (norm / _rayNorm);
+    }
+    _rayNorm = norm;
+  }
+  return _rays.data();
+}
+
+unsigned int SensorPolar2D::dataToCartesianVectorMask(double* coords, bool* validityMask)
+{
+  unsigned int validPoints = 0;
+  for (unsigned int i = 0; i < _size; i++) {
+    if (!std::isinf(_data[i]) && _mask[i]) {
+      coords[2 * i] = _raysLocal[i] * _data[i];
+      coords[2 * i + 1] = _raysLocal[_size + i] * _data[i];
+      validPoints++;
+      validityMask[i] = true;
+    } else {
+      validityMask[i] = false;
+    }
+  }
+  return validPoints;
+}
+
+int SensorPolar2D::backProject(double data[2])
+{
+  Matrix PoseInv = _T;
+  PoseInv.invert();
+  double lx = 0.0, ly = 0.0;
+  lx += PoseInv(0, 0) * data[0]; lx += PoseInv(0, 1) * data[1]; lx += PoseInv(0, 2) * 1.0;
+  ly += PoseInv(1, 0) * data[0]; ly += PoseInv(1, 1) * data[1]; ly += PoseInv(1, 2) * 1.0;
+  const double phi = std::atan2(ly, lx);
+  if (phi <= _phiLowerBound) return -2;
+  if (phi >= _phiUpperBound) return -1;
+  return (int)std::round((phi - _phiMin) / _angularRes);
+}
+
+SensorPolar2D* SensorPolar2D::copyForMapping() const
+{
+  SensorPolar2D* c = new SensorPolar2D(_size, _angularRes, _phiMin, _maxRange, _minRange, _lowReflectivityRange);
+  c->_T = _T;
+  c->setRealMeasurementData(_data.data());
+  c->setStandardMask();     // a former NaN reading is +inf by now and becomes valid-infinite (Appendix B #20)
+  return c;
+}
+
+// --------------------------------------------------------------------------------------- TsdGrid
+TsdGrid::TsdGrid(double cellSize, EnumTsdGridLayout layoutPartition, EnumTsdGridLayout layoutGrid, int device)
+    : _ctx(nullptr), _initialPushAccomplished(false)
+{
+  if (layoutPartition != LAYOUT_32x32) {
+    std::fprintf(stderr, "TsdGrid: only LAYOUT_32x32 partitions are implemented (SlamNode.cpp:77)\n");
+    return;
+  }
+  // TsdGrid::init leaves _maxTruncation = 2 * cellSize until setMaxTruncation (TsdGrid.cpp:136)
+  _ctx = tsd_create(device, (int)layoutGrid, cellSize, 2.0 * cellSize);
+}
+
+TsdGrid::~TsdGrid()
+{
+  std::lock_guard<std::mutex> lk(_mutex);
+  tsd_destroy(_ctx);
+  _ctx = nullptr;
+}
+
+void TsdGrid::reset()
+{
+  std::lock_guard<std::mutex> lk(_mutex);
+  tsd_reset(_ctx);
+  _initialPushAccomplished = false;
+}
+
+void TsdGrid::setMaxTruncation(double val)
+{
+  std::lock_guard<std::mutex> lk(_mutex);
+  tsd_set_max_truncation(_ctx, val);
+}
+
+void TsdGrid::push(SensorPolar2D* sensor)
+{
+  double pose[9];
+  sensor->getTransformation().getData(pose);
+  std::lock_guard<std::mutex> lk(_mutex);
+  const int rc = tsd_push(_ctx, pose, sensor->getRealMeasurementData(), sensor->maskBytes(),
+                          (int)sensor->getRealMeasurementSize(), sensor->getAngularResolution(),
+                          sensor->getPhiMin(), sensor->getMaximumRange(), sensor->getMinimumRange(),
+                          sensor->getLowReflectivityRange(), nullptr);
+  if (rc != TSD_OK) std::fprintf(stderr, "TsdGrid::push failed (%d): %s\n", rc, tsd_last_error(_ctx));
+  _initialPushAccomplished = true;
+}
+
+bool TsdGrid::freeFootprint(const double centerCoords[2], double width, double height)
+{
+  std::lock_guard<std::mutex> lk(_mutex);
+  return tsd_free_footprint(_ctx, centerCoords, width, height) == TSD_OK;
+}
+
+int TsdGrid::localize(SensorPolar2D* sensor, const tsd_icp_params& params, tsd_icp_result* result)
+{
+  double pose[9];
+  sensor->getTransformation().getData(pose);
+  const double* rays = sensor->getNormalizedRayMap(getCellSize());   // RayCastPolar2D.cpp:122
+  std::lock_guard<std::mutex> lk(_mutex);
+  return tsd_localize(_ctx, pose, rays, sensor->getLocalRayMap(), sensor->getRealMeasurementData(),
+                      sensor->maskBytes(), (int)sensor->getRealMeasurementSize(),
+                      sensor->getMinimumRange(), sensor->getMaximumRange(), &params, result);
+}
+
+}  // namespace obvious

@@ -1,0 +1,135 @@
+// obvious.h -- host-side mirror of the vendored `obvious` types that appear in the public signatures
+// of ThreadSLAM / ThreadMapping / ThreadLocalize: Matrix (3x3 poses), SensorPolar2D (scan container
+// + sensor model, kept on the host as SURVEY 8(a) rows S1/S3 prescribe) and TsdGrid, whose storage and
+// arithmetic live on the GPU behind the C ABI of include/tsd_hip.h.
+//
+// Same names, argument meaning and error behaviour as the reference classes; citations are
+// file:line of autonohm/ohm_tsd_slam (src/).
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "tsd_hip.h"
+
+namespace obvious {
+
+// obvious::Matrix restricted to what the path needs (<= 4x4).  Products follow
+// gsl_blas_dgemm's k-ascending accumulation (gsl/Matrix.cpp:45-52,88-95), the inverse follows
+// gsl_linalg_LU_decomp + LU_invert (:168-179).
+class Matrix
+{
+public:
+  Matrix(unsigned rows = 3, unsigned cols = 3);
+  Matrix(unsigned rows, unsigned cols, const double* data);
+  double& operator()(unsigned r, unsigned c) { return _d[r * _cols + c]; }
+  double operator()(unsigned r, unsigned c) const { return _d[r * _cols + c]; }
+  unsigned getRows() const { return _rows; }
+  unsigned getCols() const { return _cols; }
+  void setIdentity();
+  void setData(const double* array);
+  void getData(double* array) const;
+  void invert();
+  Matrix operator*(const Matrix& M) const;
+  const double* data() const { return _d; }
+private:
+  unsigned _rows, _cols;
+  double _d[16];
+};
+
+// obvious::Sensor + obvious::SensorPolar2D (reconstruct/Sensor.{h,cpp}, grid/SensorPolar2D.{h,cpp})
+class SensorPolar2D
+{
+public:
+  SensorPolar2D(unsigned int size, double angularRes, double phiMin, double maxRange = INFINITY,
+                double minRange = 0.0, double lowReflectivityRange = INFINITY);
+  ~SensorPolar2D() = default;
+
+  void setRealMeasurementData(const std::vector<float>& data, float scale = 1.f);   // Sensor.cpp:136-145
+  void setRealMeasurementData(const double* data, double scale = 1.0);              // Sensor.cpp:125-134
+  double* getRealMeasurementData() { return _data.data(); }
+  bool* getRealMeasurementMask() { return reinterpret_cast<bool*>(_mask.data()); }
+  const uint8_t* maskBytes() const { return _mask.data(); }
+  unsigned int getRealMeasurementSize() const { return _size; }
+
+  void setStandardMask();                       // SensorPolar2D.cpp:59-65
+  void resetMask();                             // Sensor.cpp:246-250
+  void maskZeroDepth();                         // Sensor.cpp:252-256
+  void maskInvalidDepth();                      // Sensor.cpp:258-272
+  void maskDepthDiscontinuity(double thresh);   // SensorPolar2D.cpp:67-98
+
+  void transform(Matrix* T);                    // Sensor.cpp:50-60
+  Matrix getTransformation() const { return _T; }
+  void setTransformation(const Matrix& T) { _T = T; }
+  void getPosition(double* tr) const { tr[0] = _T(0, 2); tr[1] = _T(1, 2); }   // Sensor.cpp:114-118
+
+  double getMaximumRange() const { return _maxRange; }
+  double getMinimumRange() const { return _minRange; }
+  double getLowReflectivityRange() const { return _lowReflectivityRange; }
+  double getAngularResolution() const { return _angularRes; }
+  double getPhiMin() const { return _phiMin; }
+
+  const double* getNormalizedRayMap(double norm);   // Sensor.cpp:36-48; 2 x size, row-major
+  const double* getLocalRayMap() const { return _raysLocal.data(); }
+  unsigned int dataToCartesianVectorMask(double* coords, bool* validityMask);   // Sensor.cpp:168-190
+  int backProject(double data[2]);              // SensorPolar2D.cpp:100-115
+  /** the deep copy ThreadMapping::queuePush hands to the mapping thread (ThreadMapping.cpp:65-76):
+   *  same geometry and pose, the PROCESSED ranges, mask rebuilt by setStandardMask() */
+  SensorPolar2D* copyForMapping() const;
+
+private:
+  unsigned int _size;
+  double _angularRes, _phiMin, _phiLowerBound, _phiUpperBound;
+  double _maxRange, _minRange, _lowReflectivityRange;
+  double _rayNorm;
+  Matrix _T;
+  std::vector<double> _data;
+  std::vector<uint8_t> _mask;
+  std::vector<double> _rays, _raysLocal;
+};
+
+enum EnumTsdGridLayout { LAYOUT_1x1 = 0, LAYOUT_2x2 = 1, LAYOUT_4x4 = 2, LAYOUT_8x8 = 3, LAYOUT_16x16 = 4,
+  LAYOUT_32x32 = 5, LAYOUT_64x64 = 6, LAYOUT_128x128 = 7, LAYOUT_256x256 = 8, LAYOUT_512x512 = 9,
+  LAYOUT_1024x1024 = 10, LAYOUT_2048x2048 = 11, LAYOUT_4096x4096 = 12, LAYOUT_8192x8192 = 13,
+  LAYOUT_16384x16384 = 14, LAYOUT_36768x36768 = 15 };   // TsdGrid.h:11-26
+
+// obvious::TsdGrid: the handle of a grid that lives in HBM.  Only LAYOUT_32x32 partitions exist
+// (SlamNode.cpp:77 hard-codes it).  Every device call of this grid is serialised by mutex().
+class TsdGrid
+{
+public:
+  TsdGrid(double cellSize, EnumTsdGridLayout layoutPartition, EnumTsdGridLayout layoutGrid, int device = 0);
+  virtual ~TsdGrid();
+  TsdGrid(const TsdGrid&) = delete;
+  TsdGrid& operator=(const TsdGrid&) = delete;
+
+  bool valid() const { return _ctx != nullptr; }
+  void reset();                                         // TsdGrid.cpp:194-198
+  unsigned int getCellsX() const { return (unsigned)tsd_cells(_ctx); }
+  unsigned int getCellsY() const { return (unsigned)tsd_cells(_ctx); }
+  double getCellSize() const { return tsd_cell_size(_ctx); }
+  double getMinX() const { return tsd_min_x(_ctx); }
+  double getMaxX() const { return tsd_max_x(_ctx); }
+  double getMinY() const { return tsd_min_y(_ctx); }
+  double getMaxY() const { return tsd_max_y(_ctx); }
+  unsigned int getPartitionSize() const { return TSD_TILE_DIM; }
+  void setMaxTruncation(double val);                    // TsdGrid.cpp:206-215
+  double getMaxTruncation() const { return tsd_max_truncation(_ctx); }
+  virtual void push(SensorPolar2D* sensor);             // TsdGrid.cpp:217-284 (asynchronous on the stream)
+  bool containsData() const { return _initialPushAccomplished; }
+  virtual bool freeFootprint(const double centerCoords[2], double width, double height);   // TsdGrid.cpp:609-638
+
+  // ThreadLocalize's ray cast + registration, fused on the device (tsd_localize)
+  virtual int localize(SensorPolar2D* sensor, const tsd_icp_params& params, tsd_icp_result* result);
+
+  tsd_ctx* context() { return _ctx; }
+  std::mutex& mutex() { return _mutex; }
+protected:
+  tsd_ctx* _ctx;
+  std::mutex _mutex;
+  bool _initialPushAccomplished;
+};
+
+}  // namespace obvious

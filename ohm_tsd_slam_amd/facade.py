@@ -1,0 +1,171 @@
+"""ctypes driver of the C++ facade (``lib/libohm_tsd_slam.so``): ``ThreadLocalize`` / ``ThreadMapping``
+wired as ``SlamNode::initialize`` wires them (SlamNode.cpp:27-129), fed through ``laserCallBack``.
+Used by the tests and by ``bench.py``; the facade itself is C++ (``csrc/host``)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import capi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libohm_tsd_slam.so")
+
+_dp = C.POINTER(C.c_double)
+_fp = C.POINTER(C.c_float)
+_u8p = C.POINTER(C.c_uint8)
+_ip = C.POINTER(C.c_int)
+
+HOST_ABI = {
+    "tsd_node_create": (C.c_void_p, [C.c_char_p]),
+    "tsd_node_set_double": (None, [C.c_void_p, C.c_char_p, C.c_double]),
+    "tsd_node_set_int": (None, [C.c_void_p, C.c_char_p, C.c_int]),
+    "tsd_node_set_bool": (None, [C.c_void_p, C.c_char_p, C.c_int]),
+    "tsd_node_set_string": (None, [C.c_void_p, C.c_char_p, C.c_char_p]),
+    "tsd_node_initialize": (C.c_int, [C.c_void_p, C.c_int]),
+    "tsd_node_set_synchronous": (None, [C.c_void_p, C.c_int]),
+    "tsd_node_laser": (C.c_int, [C.c_void_p, C.c_int, _fp, C.c_int, C.c_double, C.c_double, C.c_longlong]),
+    "tsd_node_wait_idle": (C.c_int, [C.c_void_p, C.c_int]),
+    "tsd_node_processed": (C.c_ulonglong, [C.c_void_p, C.c_int]),
+    "tsd_node_report": (None, [C.c_void_p, C.c_int, _dp]),
+    "tsd_node_pose_msg": (None, [C.c_void_p, C.c_int, _dp]),
+    "tsd_node_pose_topic": (C.c_char_p, [C.c_void_p, C.c_int]),
+    "tsd_node_grid_ctx": (C.c_void_p, [C.c_void_p]),
+    "tsd_node_destroy": (None, [C.c_void_p]),
+    "tsd_host_sensor_ingest_f32": (None, [_fp, C.c_int, C.c_double, C.c_double, C.c_double, _dp, _u8p, C.c_int]),
+    "tsd_host_sensor_chain": (None, [C.c_int, C.c_double, C.c_double, _dp, _dp, C.c_double, _fp, _dp, _dp, _dp,
+                                     _dp, _u8p, _ip]),
+    "tsd_host_calc_angle": (C.c_double, [_dp]),
+    "tsd_host_is_registration_error": (C.c_int, [_dp, C.c_double, C.c_double]),
+    "tsd_host_is_pose_change_significant": (C.c_int, [_dp, _dp]),
+    "tsd_host_mat3_inv": (None, [_dp, _dp]),
+    "tsd_host_backproject": (C.c_int, [_dp, C.c_double, C.c_double, C.c_int, C.c_double, C.c_double]),
+}
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is None:
+        capi.load_library()   # dependency (resolved through rpath as well)
+        if not os.path.exists(LIB_PATH):
+            raise capi.TsdError(f"{LIB_PATH} not found: run __graft_entry__.build()")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in HOST_ABI.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+REPORT_FIELDS = ("rms", "pairs", "iterations", "icp_state", "valid_model", "valid_scene", "reg_error", "pushed",
+                 "no_model", "initialised")
+
+
+class SlamNode:
+    """``SlamNode`` wiring: parameters (SURVEY Appendix D names), one grid, one mapping thread, N
+    localisers.  ``synchronous=True`` runs the event-loop body inside ``laser()`` (strict
+    ray-cast -> ICP -> push order); otherwise the reference's threads/queues are used."""
+
+    def __init__(self, params: dict, device: int = 0, synchronous: bool = True, name: str = "tsd_slam"):
+        self.lib = load_library()
+        self.h = self.lib.tsd_node_create(name.encode())
+        for k, v in params.items():
+            kb = k.encode()
+            if isinstance(v, bool):
+                self.lib.tsd_node_set_bool(self.h, kb, int(v))
+            elif isinstance(v, int):
+                self.lib.tsd_node_set_int(self.h, kb, v)
+            elif isinstance(v, float):
+                self.lib.tsd_node_set_double(self.h, kb, v)
+            else:
+                self.lib.tsd_node_set_string(self.h, kb, str(v).encode())
+        self.lib.tsd_node_set_synchronous(self.h, int(synchronous))
+        rc = self.lib.tsd_node_initialize(self.h, device)
+        if rc != 0:
+            self.lib.tsd_node_destroy(self.h)
+            self.h = None
+            raise capi.TsdError(f"tsd_node_initialize failed ({rc}): no usable GPU; the hot path has no CPU fall-back")
+        self._stamp = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tsd_node_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_synchronous(self, on: bool):
+        self.lib.tsd_node_set_synchronous(self.h, int(on))
+
+    def laser(self, ranges_f32, angle_min, angle_increment, robot: int = 0, stamp_ns: int | None = None):
+        r = np.ascontiguousarray(ranges_f32, dtype=np.float32)
+        if stamp_ns is None:
+            self._stamp += 25_000_000
+            stamp_ns = self._stamp
+        rc = self.lib.tsd_node_laser(self.h, robot, r.ctypes.data_as(_fp), r.size, angle_min, angle_increment, stamp_ns)
+        if rc != 0:
+            raise capi.TsdError(f"tsd_node_laser failed ({rc})")
+
+    def wait_idle(self, timeout_ms: int = 10000) -> bool:
+        return self.lib.tsd_node_wait_idle(self.h, timeout_ms) == 0
+
+    def processed(self, robot: int = 0) -> int:
+        return int(self.lib.tsd_node_processed(self.h, robot))
+
+    def report(self, robot: int = 0) -> dict:
+        buf = np.zeros(28)
+        self.lib.tsd_node_report(self.h, robot, buf.ctypes.data_as(_dp))
+        out = {"pose": buf[:9].reshape(3, 3).copy(), "T": buf[9:18].reshape(3, 3).copy()}
+        out["rms"] = float(buf[18])
+        for i, k in enumerate(REPORT_FIELDS[1:]):
+            out[k] = int(buf[19 + i])
+        return out
+
+    def pose_msg(self, robot: int = 0) -> dict:
+        buf = np.zeros(8)
+        self.lib.tsd_node_pose_msg(self.h, robot, buf.ctypes.data_as(_dp))
+        return {"position": buf[:3].copy(), "orientation_xyzw": buf[3:7].copy(), "count": int(buf[7]),
+                "topic": self.lib.tsd_node_pose_topic(self.h, robot).decode()}
+
+    def grid(self) -> "GridView":
+        return GridView(self.lib.tsd_node_grid_ctx(self.h))
+
+
+class GridView(capi.TsdGridDevice):
+    """Non-owning view of the facade's grid context (for dumps / profiling through the tsd_* ABI)."""
+
+    def __init__(self, ctx):  # noqa: D401 - does not call the base constructor on purpose
+        self.lib = capi.load_library()
+        self.h = ctx
+        self.cells = self.lib.tsd_cells(ctx)
+        self.tiles = self.lib.tsd_tiles(ctx)
+        self.cell_size = self.lib.tsd_cell_size(ctx)
+        self.max_trunc = self.lib.tsd_max_truncation(ctx)
+        self.min_x, self.max_x = self.lib.tsd_min_x(ctx), self.lib.tsd_max_x(ctx)
+        self.min_y, self.max_y = self.lib.tsd_min_y(ctx), self.lib.tsd_max_y(ctx)
+
+    def close(self):
+        self.h = None
+
+
+def node_params(gc, geo=None, **over) -> dict:
+    """Parameter set of the measurement plan: single-laser.yaml values with
+    registration_mode 0 and the benchmark's grid size."""
+    p = {
+        "robot_nbr": 1, "map_size": gc.map_size_log2, "cellsize": float(gc.cell_size),
+        "truncation_radius": gc.truncation_radius, "x_offset": 0.0, "y_offset": 0.0,
+        "dist_filter_max": 0.4, "dist_filter_min": 0.02, "icp_iterations": 30,
+        "reg_trs_max": 1.0, "reg_sin_rot_max": 0.5, "laser_min_range": 0.26, "registration_mode": 0,
+        "tsd_slam/local_offset_x": 0.37, "tsd_slam/local_offset_y": -0.21, "tsd_slam/local_offset_yaw": 0.1,
+    }
+    p.update(over)
+    return p

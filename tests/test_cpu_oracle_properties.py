@@ -1,0 +1,211 @@
+"""Known-answer / property tests of the oracle itself (it is the checker of the GPU path, so it gets
+independent checks of its own): a vectorised NumPy re-derivation of one push, analytic ray-cast and ICP
+answers, idempotence / invariants of the tile state machine, and dump/load round trips."""
+import math
+
+import numpy as np
+import pytest
+
+from ohm_tsd_slam_amd import synth
+from oracle import pyoracle as O
+from tests import helpers as H
+
+
+def numpy_push_from_empty(gc, geo, pose, data, mask, max_range, low_refl):
+    """Independent NumPy restatement of the cell update of ONE push into an empty grid
+    (TsdGrid.cpp:237-274, TsdGridPartition.h:170-212) for every cell of the grid, ignoring tile
+    classification: returns tsd / weight the cell would get IF its tile is updated."""
+    N, cs, maxT = gc.cells, gc.cell_size, max(gc.max_trunc, 2 * gc.cell_size)
+    Pi = np.linalg.inv(pose)
+    idx = np.arange(N)
+    cx = ((idx + 0.5) * cs)[None, :].repeat(N, 0)
+    cy = ((idx + 0.5) * cs)[:, None].repeat(N, 1)
+    lx = Pi[0, 0] * cx + Pi[0, 1] * cy + Pi[0, 2]
+    ly = Pi[1, 0] * cx + Pi[1, 1] * cy + Pi[1, 2]
+    phi = np.arctan2(ly, lx)
+    lower = geo.angle_min - 0.5 * geo.angle_increment
+    upper = geo.angle_min + (geo.beams - 0.5) * geo.angle_increment
+    beam = np.round((phi - geo.angle_min) / geo.angle_increment).astype(int)
+    vis = (phi > lower) & (phi < upper)
+    beam = np.clip(beam, 0, geo.beams - 1)
+    dist = np.hypot(cx - pose[0, 2], cy - pose[1, 2])
+    r = data[beam]
+    ok = vis & (mask[beam] != 0)
+    sd = np.where(np.isinf(r), np.where(dist < low_refl, maxT, -np.inf), r - dist)
+    upd = ok & (sd >= -maxT)
+    tsd = np.where(upd, np.minimum(sd / maxT, 1.0), np.nan)
+    # partition weight from the tile centroid
+    tx = (idx // 32 * 32 + 16.5) * cs
+    dcen = np.hypot(tx[None, :] - pose[0, 2], tx[:, None] - pose[1, 2])
+    pw = ((max_range - np.minimum(dcen, max_range)) / max_range) ** 2
+    w = np.where(upd, 0.01 * pw, 0.0)
+    return tsd, w, upd
+
+
+@pytest.mark.parametrize("scene,map_log2,cs,geo", [
+    ("room", 8, 0.1, synth.ScanGeometry.full_circle_360()),
+    ("pillars", 9, 0.1, synth.ScanGeometry.utm30lx()),
+])
+def test_push_against_numpy_rederivation(scene, map_log2, cs, geo):
+    gc = synth.GridConfig(map_log2, cs)
+    world = synth.World(scene, gc)
+    pose, (x, y, yaw) = H.sensor_pose(world, 0)
+    data, mask = O.ingest_f32(world.scan(x, y, yaw, geo), 30.0, geo.angle_increment)
+    g = O.Grid(gc.map_size_log2, gc.cell_size, gc.max_trunc)
+    st = g.push(pose, data, mask, geo.angle_increment, geo.angle_min, 30.0, 0.001, 2.0)
+    init, iw, tsd, w = g.dump()
+    e_tsd, e_w, e_upd = numpy_push_from_empty(gc, geo, pose, data, mask, 30.0, 2.0)
+    PX = gc.cells // 32
+    n_upd = 0
+    for p in np.nonzero(init)[0]:
+        py, px = divmod(p, PX)
+        t = tsd[p].reshape(33, 33)[:32, :32]
+        ww = w[p].reshape(33, 33)[:32, :32]
+        et = e_tsd[py * 32:(py + 1) * 32, px * 32:(px + 1) * 32]
+        ew = e_w[py * 32:(py + 1) * 32, px * 32:(px + 1) * 32]
+        assert np.array_equal(np.isnan(t), np.isnan(et))
+        m = ~np.isnan(t)
+        assert np.allclose(t[m], et[m], rtol=0, atol=1e-12)
+        assert np.allclose(ww, ew, rtol=0, atol=1e-15)
+        n_upd += int(m.sum())
+    assert n_upd == st["cells_updated"] > 1000
+    # tiles the classifier skipped or emptied hold no surface: every cell the re-derivation puts within
+    # the truncation band of a finite reading lies in an initialised tile
+    near = e_upd & (np.abs(e_tsd) < 1.0)
+    tiles_of_near = np.unique((np.nonzero(near)[0] // 32) * PX + np.nonzero(near)[1] // 32)
+    assert init[tiles_of_near].all()
+
+
+def test_push_invariants():
+    gc = synth.GridConfig(9, 0.05)
+    geo = synth.ScanGeometry.full_circle_360()
+    world = synth.World("room", gc)
+    g = O.Grid(gc.map_size_log2, gc.cell_size, gc.max_trunc)
+    for k in range(25):
+        pose, (x, y, yaw) = H.sensor_pose(world, k)
+        data, mask = O.ingest_f32(world.scan(x, y, yaw, geo), 30.0, geo.angle_increment)
+        st = g.push(pose, data, mask, geo.angle_increment, geo.angle_min, 30.0, 0.001, 2.0)
+        assert st["tiles_update"] <= st["tiles_range_pass"] <= st["tiles_total"]
+        assert st["cells_updated"] <= st["cells_visited"] == 1024 * st["tiles_update"]
+    init, iw, tsd, w = g.dump()
+    sel = init.astype(bool)
+    assert (iw >= 0).all() and (iw <= 32).all()
+    assert (w[sel] >= 0).all() and (w[sel] <= 32).all()
+    t = tsd[sel]
+    assert np.nanmax(t) <= 1.0 and np.nanmin(t) >= -1.0
+    assert (w[sel][np.isnan(t)] == 0).all()          # NaN cells always carry weight 0
+    # halo consistency where both neighbours are initialised (TsdGrid.cpp:385-424)
+    PX = gc.cells // 32
+    checked = 0
+    for p in np.nonzero(init)[0]:
+        py, px = divmod(p, PX)
+        if px < PX - 1 and init[p + 1]:
+            a = tsd[p].reshape(33, 33)[:32, 32]
+            b = tsd[p + 1].reshape(33, 33)[:32, 0]
+            assert np.array_equal(a, b, equal_nan=True)
+            checked += 1
+        if py < PX - 1 and init[p + PX]:
+            a = tsd[p].reshape(33, 33)[32, :32]
+            b = tsd[p + PX].reshape(33, 33)[0, :32]
+            assert np.array_equal(a, b, equal_nan=True)
+    assert checked > 10
+
+
+def test_dump_load_roundtrip():
+    gc = synth.GridConfig(8, 0.1)
+    geo = synth.ScanGeometry.full_circle_360()
+    world = synth.World("room", gc)
+    g = O.Grid(gc.map_size_log2, gc.cell_size, gc.max_trunc)
+    pose, (x, y, yaw) = H.sensor_pose(world, 0)
+    data, mask = O.ingest_f32(world.scan(x, y, yaw, geo), 30.0, geo.angle_increment)
+    g.push(pose, data, mask, geo.angle_increment, geo.angle_min, 30.0, 0.001, 2.0)
+    d1 = g.dump()
+    g2 = O.Grid(gc.map_size_log2, gc.cell_size, gc.max_trunc)
+    g2.load(*d1)
+    d2 = g2.dump()
+    for a, b in zip(d1, d2):
+        assert np.array_equal(a, b, equal_nan=True)
+    s1 = g.push(pose, data, mask, geo.angle_increment, geo.angle_min, 30.0, 0.001, 2.0)
+    s2 = g2.push(pose, data, mask, geo.angle_increment, geo.angle_min, 30.0, 0.001, 2.0)
+    assert s1 == s2
+    for a, b in zip(g.dump(), g2.dump()):
+        assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_raycast_recovers_walls():
+    """After a few pushes of the box room, the ray-cast model points lie on the walls (within a cell)."""
+    gc = synth.GridConfig(9, 0.05)
+    geo = synth.ScanGeometry.full_circle_360()
+    world = synth.World("room", gc)
+    g = O.Grid(gc.map_size_log2, gc.cell_size, gc.max_trunc)
+    for k in range(3):
+        pose, (x, y, yaw) = H.sensor_pose(world, k)
+        data, mask = O.ingest_f32(world.scan(x, y, yaw, geo), 30.0, geo.angle_increment)
+        g.push(pose, data, mask, geo.angle_increment, geo.angle_min, 30.0, 0.001, 2.0)
+    pose, (x, y, yaw) = H.sensor_pose(world, 1)
+    rl, rw = H.world_rays(O, geo, pose, gc.cell_size)
+    coords, normals, m, n = g.raycast(pose, rw, 0.001, 30.0)
+    assert n > 0.9 * geo.beams
+    truth = world.scan(x, y, yaw, geo).astype(float)
+    pts = coords.reshape(-1, 2)[m.astype(bool)]
+    rng_model = np.hypot(pts[:, 0], pts[:, 1])          # sensor frame => range of the model point
+    assert np.max(np.abs(rng_model - truth[m.astype(bool)])) < 1.5 * gc.cell_size
+    nn = normals.reshape(-1, 2)[m.astype(bool)]
+    assert np.allclose(np.hypot(nn[:, 0], nn[:, 1]), 1.0, atol=1e-9)
+    # model points sit on their own beam: angle of the point == beam angle
+    ang = np.arctan2(pts[:, 1], pts[:, 0])
+    beam_ang = geo.angle_min + np.nonzero(m)[0] * geo.angle_increment
+    d = (ang - beam_ang + np.pi) % (2 * np.pi) - np.pi
+    assert np.max(np.abs(d)) < 1e-9
+
+
+@pytest.mark.parametrize("nn_mode", [0, 1])
+def test_icp_recovers_known_transform(nn_mode):
+    # well separated points (min spacing 0.3 m >> displacement): every nearest neighbour is the true
+    # correspondence from the first step, so the closed form must recover the transform exactly
+    rng = np.random.default_rng(42)
+    pts = []
+    while len(pts) < 300:
+        p = rng.uniform(2, 14, 2)
+        if all(np.hypot(*(p - q)) > 0.3 for q in pts):
+            pts.append(p)
+    model = np.array(pts)
+    th, tx, ty = 0.004, 0.03, -0.02
+    R = np.array([[math.cos(th), -math.sin(th)], [math.sin(th), math.cos(th)]])
+    scene = (model - np.array([tx, ty])) @ R      # scene = R^-1 (model - t)  =>  T maps scene -> model
+    pose = np.eye(3)
+    r = O.icp(model, scene, pose, 30, 0.4, 0.02, (0, 100, 0, 100), nn_mode=nn_mode, trace=True)
+    assert r["iterations"] == 30 and r["state"] == 3 and r["pairs"] == 300
+    T = r["T"]
+    assert abs(math.atan2(T[1, 0], T[0, 0]) - th) < 1e-12
+    assert abs(T[0, 2] - tx) < 1e-11 and abs(T[1, 2] - ty) < 1e-11
+    assert r["rms"] < 1e-20
+    tr = r["trace"]
+    assert (np.diff(tr[:, 2]) <= 0).all() and tr[-1, 2] >= 0.02 ** 2     # threshold schedule monotone, floored
+    assert tr[0, 1] > 1e-4 and tr[1, 1] < 1e-20                          # converged after the first step
+
+
+def test_icp_brute_force_equals_kdtree():
+    gc, geo, scene_name = synth.CONFIGS["cfg1"]
+    rng = np.random.default_rng(9)
+    model = rng.uniform(3, 9, (700, 2))
+    scene = model[rng.integers(0, 700, 500)] + rng.normal(0, 0.04, (500, 2))
+    a = O.icp(model, scene, np.eye(3), 30, 0.4, 0.02, (0, 100, 0, 100), nn_mode=0)
+    b = O.icp(model, scene, np.eye(3), 30, 0.4, 0.02, (0, 100, 0, 100), nn_mode=1)
+    assert a["pairs"] == b["pairs"] and np.array_equal(a["T"], b["T"]) and a["rms"] == b["rms"]
+
+
+def test_occupancy_values_and_persistence():
+    gc = synth.GridConfig(8, 0.1)
+    geo = synth.ScanGeometry.full_circle_360()
+    world = synth.World("room", gc)
+    g = O.Grid(gc.map_size_log2, gc.cell_size, gc.max_trunc)
+    content = np.full(gc.cells * gc.cells, -1, dtype=np.int8)
+    for k in range(3):
+        pose, (x, y, yaw) = H.sensor_pose(world, k)
+        data, mask = O.ingest_f32(world.scan(x, y, yaw, geo), 30.0, geo.angle_increment)
+        g.push(pose, data, mask, geo.angle_increment, geo.angle_min, 30.0, 0.001, 2.0)
+        out, n = g.occupancy(content)
+    assert set(np.unique(out)) <= {-1, 0, 100} and n > 50
+    assert (out == 100).sum() > 50 and (out == 0).sum() > 500
+    assert set(np.unique(content)) <= {-1, 0}           # the 100 marks never enter the persistent map

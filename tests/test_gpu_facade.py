@@ -1,0 +1,131 @@
+"""GPU tests of the C++ facade (ThreadLocalize / ThreadMapping over the C ABI): parity of the whole
+loop with the oracle, and the reference's threading contract (first scan initialises synchronously,
+newest scan wins, mapping queue drains, clean shutdown)."""
+import math
+import time
+
+import numpy as np
+import pytest
+
+from ohm_tsd_slam_amd import facade, synth
+from tests import helpers as H
+from tests.slam_driver import slam_kwargs
+
+pytestmark = pytest.mark.gpu
+
+
+def run_pair(oracle, gc, geo, scene, n, **over):
+    world = synth.World(scene, gc)
+    poses = synth.trajectory(world, n)
+    scans = synth.scans_for(world, geo, poses)
+    so = oracle.Slam(**slam_kwargs(gc, geo, **over))
+    node = facade.SlamNode(facade.node_params(gc, geo, **{k: v for k, v in over.items() if k in ("icp_iterations",)}),
+                           synchronous=True)
+    return world, poses, scans, so, node
+
+
+@pytest.mark.parametrize("cfg,n", [("cfg1", 15), ("cfg2", 8)])
+def test_facade_sync_loop_matches_oracle(oracle, cfg, n):
+    gc, geo, scene = synth.CONFIGS[cfg]
+    world, poses, scans, so, node = run_pair(oracle, gc, geo, scene, n)
+    pushes = 0
+    for k in range(n):
+        ro = so.process_scan(scans[k])
+        node.laser(scans[k], geo.angle_min, geo.angle_increment)
+        rh = node.report()
+        Po = np.array(ro.pose[:]).reshape(3, 3)
+        d, a = H.pose_delta(Po, rh["pose"])
+        assert d <= 1e-4 and a <= 1e-4, f"scan {k}: {d} m {a} rad"
+        assert bool(ro.pushed) == bool(rh["pushed"]) and bool(ro.reg_error) == bool(rh["reg_error"])
+        if k > 0:
+            assert (ro.pairs, ro.iterations, ro.icp_state) == (rh["pairs"], rh["iterations"], rh["icp_state"])
+            assert (ro.valid_model, ro.valid_scene) == (rh["valid_model"], rh["valid_scene"])
+            assert abs(ro.rms - rh["rms"]) <= 1e-9
+        pushes += rh["pushed"]
+    assert pushes >= n // 2
+    H.assert_grids_equal(so.grid.dump(), node.grid().download_tiles(), 1e-5)
+    # PoseStamped on <node>/estimated_pose: position = pose + grid offset, yaw quaternion
+    msg = node.pose_msg()
+    assert msg["topic"] == "tsd_slam/estimated_pose" and msg["count"] == n - 1
+    W = gc.cells * gc.cell_size
+    P = node.report()["pose"]
+    assert msg["position"][0] == P[0, 2] - 0.5 * W and msg["position"][1] == P[1, 2] - 0.5 * W
+    yaw = 2.0 * math.atan2(msg["orientation_xyzw"][2], msg["orientation_xyzw"][3])
+    assert abs(yaw - math.atan2(P[1, 0], P[0, 0])) < 1e-9
+    node.close()
+
+
+def test_facade_threads_contract(oracle):
+    gc, geo, scene = synth.CONFIGS["cfg1"]
+    world = synth.World(scene, gc)
+    poses = synth.trajectory(world, 40)
+    scans = synth.scans_for(world, geo, poses)
+    node = facade.SlamNode(facade.node_params(gc, geo), synchronous=False)
+    # first scan: init + synchronous initPush on the caller's thread (ThreadLocalize.cpp:257-267)
+    node.laser(scans[0], geo.angle_min, geo.angle_increment)
+    assert node.processed() == 1 and node.report()["pushed"] == 1 and node.report()["initialised"] == 1
+    init, _ = node.grid().download_tile_state()
+    assert init.sum() > 10
+    # a burst of scans: the localiser consumes the newest and drops the rest (:319-332)
+    for k in range(1, 30):
+        node.laser(scans[k], geo.angle_min, geo.angle_increment)
+    assert node.wait_idle(20000)
+    done = node.processed() - 1
+    assert 1 <= done <= 29
+    # the last processed scan is the newest one: pose is near the ground truth of scan 29, not scan 1
+    P = node.report()["pose"]
+    assert math.hypot(P[0, 2] - poses[29, 0], P[1, 2] - poses[29, 1]) < 0.3
+    # steady feeding (wait between scans): every scan is processed, map keeps growing
+    before = node.processed()
+    for k in range(30, 40):
+        node.laser(scans[k], geo.angle_min, geo.angle_increment)
+        assert node.wait_idle(20000)
+    assert node.processed() - before == 10
+    P = node.report()["pose"]
+    assert math.hypot(P[0, 2] - poses[39, 0], P[1, 2] - poses[39, 1]) < 0.3
+    t0 = time.time()
+    node.close()          # terminateThread + alive() polling + join, as SlamNode::~SlamNode
+    assert time.time() - t0 < 5.0
+
+
+def test_facade_registration_error_publishes_nan(oracle):
+    """A scan that cannot be registered within reg_trs_max -> NaN pose, pose unchanged, no push
+    (ThreadLocalize.cpp:381-387, 691-713)."""
+    gc, geo, scene = synth.CONFIGS["cfg1"]
+    world = synth.World(scene, gc)
+    poses = synth.trajectory(world, 3)
+    scans = synth.scans_for(world, geo, poses)
+    node = facade.SlamNode(facade.node_params(gc, geo, reg_trs_max=1e-4), synchronous=True)
+    node.laser(scans[0], geo.angle_min, geo.angle_increment)
+    p0 = node.report()["pose"].copy()
+    node.laser(scans[2], geo.angle_min, geo.angle_increment)
+    r = node.report()
+    assert r["reg_error"] == 1 and r["pushed"] == 0 and np.array_equal(r["pose"], p0)
+    assert np.isnan(node.pose_msg()["position"]).all()
+    node.close()
+
+
+def test_facade_multi_robot_shares_one_grid(oracle):
+    """robot_nbr = 2: two ThreadLocalize on ONE TsdGrid + ONE ThreadMapping (SlamNode.cpp:101-122);
+    only the first robot's init pushes (ThreadMapping::initialized gate, ThreadLocalize.cpp:506-507)."""
+    gc, geo, scene = synth.CONFIGS["cfg1"]
+    world = synth.World(scene, gc)
+    params = facade.node_params(gc, geo, robot_nbr=2)
+    params.update({"robot_0/name": "georg", "robot_1/name": "simon",
+                   "tsd_slam/georg/local_offset_x": 0.37, "tsd_slam/georg/local_offset_y": -0.21,
+                   "tsd_slam/georg/local_offset_yaw": 0.1,
+                   "tsd_slam/simon/local_offset_x": -0.7, "tsd_slam/simon/local_offset_y": 0.4})
+    node = facade.SlamNode(params, synchronous=True)
+    s0 = world.scan(world.start[0], world.start[1], 0.1, geo)
+    s1 = world.scan(world.cx - 0.7, world.cy + 0.4, 0.0, geo)
+    node.laser(s0, geo.angle_min, geo.angle_increment, robot=0)
+    node.laser(s1, geo.angle_min, geo.angle_increment, robot=1)
+    assert node.report(0)["pushed"] == 1 and node.report(1)["pushed"] == 0
+    assert node.pose_msg(0)["topic"] == "tsd_slam/georg/estimated_pose"
+    assert node.pose_msg(1)["topic"] == "tsd_slam/simon/estimated_pose"
+    for _ in range(3):
+        node.laser(s0, geo.angle_min, geo.angle_increment, robot=0)
+        node.laser(s1, geo.angle_min, geo.angle_increment, robot=1)
+    P1 = node.report(1)["pose"]
+    assert math.hypot(P1[0, 2] - (world.cx - 0.7), P1[1, 2] - (world.cy + 0.4)) < 0.1
+    node.close()

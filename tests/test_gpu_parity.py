@@ -81,7 +81,7 @@ def test_push_empties_and_reinit(oracle):
     near = np.full(geo.beams, 2.0, dtype=np.float32)
     far = np.full(geo.beams, 9.0, dtype=np.float32)
     seen = {"emptied_init": 0, "emptied_uninit": 0, "new_from_empty": 0}
-    for r in (near, far, far, near, far, near):
+    for r in (far, near, far, far, near, far):
         so, sd = push_both(oracle, og, dg, world, geo, 0, ranges_f32=r)
         assert so == sd
         H.assert_grids_equal(og.dump(), dg.download_tiles(), TOL_CELL)
