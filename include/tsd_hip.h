@@ -34,6 +34,7 @@ extern "C" {
 #define TSD_TILE_CELLS   1089
 #define TSD_MAX_BEAMS    4096 /* scan staged in LDS by the push kernel */
 #define TSD_MAX_ICP_POINTS 2048 /* model/scene resident in LDS in the ICP kernel */
+#define TSD_ICP_TRACE_MAX 256  /* iterations recorded by tsd_icp_trace */
 
 /* EnumIcpState (obvision/registration/icp/Icp.h:25-32) */
 #define TSD_ICP_PROCESSING     1
@@ -133,6 +134,11 @@ int tsd_localize(tsd_ctx* ctx, const double pose33[9], const double* rays_world_
                  double min_range, double max_range, const tsd_icp_params* params,
                  tsd_icp_result* result);
 
+/* Per-iteration record of the most recent tsd_icp / tsd_localize on this ctx (the role of
+ * Icp::activateTrace, Icp.cpp:60-70): out[4*i + {0,1,2,3}] = pairs, rms, DistanceFilter threshold
+ * before the step, state after loop control, for i < min(iterations, max_iters). */
+int tsd_icp_trace(tsd_ctx* ctx, double* out, int max_iters);
+
 /* ---- map I/O --------------------------------------------------------------------------------- */
 /* Canonical dump / restore of the tile state: initialized[tiles], init_weight[tiles],
  * tsd[tiles][1089], weight[tiles][1089] (uninitialised tiles read back NaN / 0).  Logical content of
@@ -156,8 +162,14 @@ int tsd_occupancy_dev(tsd_ctx* ctx, void* occ_dev, int inflate, int inflate_fact
 /* Per-kernel HIP-event timing on the ctx stream.  Kernel names: "push_classify", "push_update",
  * "push_halo", "raycast", "icp", "occupancy". */
 int tsd_profile_enable(tsd_ctx* ctx, int on);
+/* restrict timing to a comma separated list of kernel names, or "all" */
+int tsd_profile_select(tsd_ctx* ctx, const char* kernels_csv);
 int tsd_profile_reset(tsd_ctx* ctx);
 int tsd_profile_get(tsd_ctx* ctx, const char* kernel, double* total_ms, int* launches);
+
+/* Sum of the work counters of every push completed on this ctx since the last reset (the numerator of
+ * the algorithmic-bytes formula without a host sync per push).  Waits for pushes still in flight. */
+int tsd_push_stats_total(tsd_ctx* ctx, tsd_push_stats* total, int64_t* pushes, int reset);
 
 #ifdef __cplusplus
 }

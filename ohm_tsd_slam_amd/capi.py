@@ -97,13 +97,16 @@ ABI = {
                           C.POINTER(IcpResult)]),
     "tsd_localize": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _u8p, C.c_int, C.c_double, C.c_double,
                                C.POINTER(IcpParams), C.POINTER(IcpResult)]),
+    "tsd_icp_trace": (C.c_int, [C.c_void_p, _dp, C.c_int]),
     "tsd_download_tiles": (C.c_int, [C.c_void_p, _u8p, _dp, _dp, _dp]),
     "tsd_upload_tiles": (C.c_int, [C.c_void_p, _u8p, _dp, _dp, _dp]),
     "tsd_download_tile_state": (C.c_int, [C.c_void_p, _u8p, _dp]),
     "tsd_occupancy": (C.c_int, [C.c_void_p, _i8p, C.c_int, C.c_int, _ip]),
     "tsd_occupancy_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "tsd_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "tsd_profile_select": (C.c_int, [C.c_void_p, C.c_char_p]),
     "tsd_profile_reset": (C.c_int, [C.c_void_p]),
+    "tsd_push_stats_total": (C.c_int, [C.c_void_p, C.POINTER(PushStats), C.POINTER(C.c_int64), C.c_int]),
     "tsd_profile_get": (C.c_int, [C.c_void_p, C.c_char_p, _dp, _ip]),
 }
 
@@ -245,6 +248,11 @@ class TsdGridDevice:
         self._check(rc, "tsd_localize")
         return IcpOut(np.array(r.T[:]).reshape(3, 3), r.rms, r.pairs, r.iterations, r.state, r.n_model, r.n_scene)
 
+    def icp_trace(self, iterations):
+        tr = np.zeros((max(iterations, 1), 4))
+        self._check(self.lib.tsd_icp_trace(self.h, _d(tr), iterations), "tsd_icp_trace")
+        return tr[:iterations]
+
     def download_tile_state(self):
         init = np.zeros(self.tiles, dtype=np.uint8)
         iw = np.zeros(self.tiles)
@@ -275,8 +283,15 @@ class TsdGridDevice:
         self._check(self.lib.tsd_occupancy_dev(self.h, C.c_void_p(dev_ptr), int(inflate), inflate_factor),
                     "tsd_occupancy_dev")
 
-    def profile(self, on=True):
+    def profile(self, on=True, kernels="all"):
+        self.lib.tsd_profile_select(self.h, kernels.encode())
         self.lib.tsd_profile_enable(self.h, int(on))
+
+    def push_stats_total(self, reset=False):
+        st = PushStats()
+        n = C.c_int64(0)
+        self._check(self.lib.tsd_push_stats_total(self.h, C.byref(st), C.byref(n), int(reset)), "tsd_push_stats_total")
+        return st.as_dict(), n.value
 
     def profile_reset(self):
         self.lib.tsd_profile_reset(self.h)

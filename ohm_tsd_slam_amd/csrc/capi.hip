@@ -21,15 +21,34 @@ int set_error(tsd_ctx* ctx, int code, const char* what, hipError_t e)
   return code;
 }
 
+static const char* const kKernelNames[] = {"push_classify", "push_update", "push_halo", "raycast", "icp", "occupancy"};
+
+bool kernel_is_timed(const tsd_ctx* ctx, const char* name)
+{
+  if (!ctx->profile) return false;
+  for (unsigned i = 0; i < sizeof(kKernelNames) / sizeof(kKernelNames[0]); i++)
+    if (std::strcmp(kKernelNames[i], name) == 0) return (ctx->profile_mask >> i) & 1u;
+  return false;
+}
+
+static hipEvent_t pool_get(tsd_ctx* ctx)
+{
+  if (!ctx->event_pool.empty()) { hipEvent_t e = ctx->event_pool.back(); ctx->event_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+
 ScopedKernelTimer::ScopedKernelTimer(tsd_ctx* c, const char* n) : ctx(c), name(n)
 {
-  if (!ctx->profile) return;
-  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+  if (!kernel_is_timed(ctx, n)) return;
+  a = pool_get(ctx); b = pool_get(ctx);
+  if (!a || !b) { a = b = nullptr; return; }
   hipEventRecord(a, ctx->stream);
 }
 ScopedKernelTimer::~ScopedKernelTimer()
 {
-  if (!ctx->profile || !a) return;
+  if (!a) return;
   hipEventRecord(b, ctx->stream);
   ctx->timers[name].pending.emplace_back(a, b);
 }
@@ -42,10 +61,35 @@ void drain_timers(tsd_ctx* ctx)
         kv.second.total_ms += (double)ms;
         kv.second.launches++;
       }
-      hipEventDestroy(pr.first);
-      hipEventDestroy(pr.second);
+      ctx->event_pool.push_back(pr.first);     // recycled: no event creation in steady state
+      ctx->event_pool.push_back(pr.second);
     }
     kv.second.pending.clear();
+  }
+}
+
+static void add_counters(tsd_push_stats& t, const PushCounters& c)
+{
+  t.cells_updated += (int64_t)c.cells_updated;
+  t.cells_visited += (int64_t)c.cells_visited;
+  t.tiles_range_pass += c.tiles_range_pass;
+  t.tiles_update += c.tiles_update;
+  t.tiles_new += c.tiles_new;
+  t.tiles_new_from_empty += c.tiles_new_from_empty;
+  t.tiles_emptied_init += c.tiles_emptied_init;
+  t.tiles_emptied_uninit += c.tiles_emptied_uninit;
+}
+
+// fold finished ring slots into the running totals
+void harvest_push_stats(tsd_ctx* ctx, bool wait)
+{
+  for (int s = 0; s < tsd_ctx::kStatSlots; s++) {
+    if (!ctx->stat_pending[s]) continue;
+    if (wait) hipEventSynchronize(ctx->stat_ev[s]);
+    else if (hipEventQuery(ctx->stat_ev[s]) != hipSuccess) continue;
+    add_counters(ctx->stat_total, ctx->h_stat_ring[s]);
+    ctx->stat_pushes++;
+    ctx->stat_pending[s] = false;
   }
 }
 
@@ -194,6 +238,8 @@ tsd_ctx* tsd_create(int device, int map_size_log2, double cell_size, double max_
   A(hipMalloc(&ctx->d_dirty_count, sizeof(int)));
   A(hipHostMalloc(&ctx->h_dirty, ((size_t)ctx->dirty_cap + 1) * sizeof(uint32_t), hipHostMallocDefault));
   A(hipHostMalloc(&ctx->h_counters, sizeof(PushCounters), hipHostMallocDefault));
+  A(hipHostMalloc(&ctx->h_stat_ring, sizeof(PushCounters) * tsd_ctx::kStatSlots, hipHostMallocDefault));
+  for (int s = 0; s < tsd_ctx::kStatSlots; s++) A(hipEventCreateWithFlags(&ctx->stat_ev[s], hipEventDisableTiming));
   ctx->stage_bytes = (size_t)TSD_MAX_BEAMS * (8 * 5 + 1) + 256;   // ranges + 2x rays(2) + mask
   for (int s = 0; s < tsd_ctx::kSlots; s++) {
     A(hipHostMalloc(&ctx->h_stage[s], ctx->stage_bytes, hipHostMallocDefault));
@@ -209,6 +255,7 @@ tsd_ctx* tsd_create(int device, int map_size_log2, double cell_size, double max_
   A(hipMalloc(&ctx->d_model, 2 * TSD_MAX_ICP_POINTS * sizeof(double)));
   A(hipMalloc(&ctx->d_scene, 2 * TSD_MAX_ICP_POINTS * sizeof(double)));
   A(hipMalloc(&ctx->d_icp_res, sizeof(IcpResultDev)));
+  A(hipMalloc(&ctx->d_icp_trace, sizeof(double) * 4 * TSD_ICP_TRACE_MAX));
   A(hipHostMalloc(&ctx->h_icp_res, sizeof(IcpResultDev), hipHostMallocDefault));
   ctx->h_out_bytes = (size_t)TSD_MAX_BEAMS * (8 * 4 + 1) + 256;
   A(hipHostMalloc(&ctx->h_out, ctx->h_out_bytes, hipHostMallocDefault));
@@ -228,14 +275,16 @@ void tsd_destroy(tsd_ctx* ctx)
   GridDev& g = ctx->grid;
   hipFree(g.flags); hipFree(g.init_weight); hipFree(g.tsd); hipFree(g.weight);
   hipFree(ctx->d_counters); hipFree(ctx->d_list); hipFree(ctx->d_dirty); hipFree(ctx->d_dirty_count);
-  hipHostFree(ctx->h_dirty); hipHostFree(ctx->h_counters);
+  hipHostFree(ctx->h_dirty); hipHostFree(ctx->h_counters); hipHostFree(ctx->h_stat_ring);
+  for (int s = 0; s < tsd_ctx::kStatSlots; s++) if (ctx->stat_ev[s]) hipEventDestroy(ctx->stat_ev[s]);
+  for (hipEvent_t e : ctx->event_pool) hipEventDestroy(e);
   for (int s = 0; s < tsd_ctx::kSlots; s++) {
     if (ctx->h_stage[s]) hipHostFree(ctx->h_stage[s]);
     if (ctx->stage_ev[s]) hipEventDestroy(ctx->stage_ev[s]);
   }
   hipFree(ctx->d_ranges); hipFree(ctx->d_mask); hipFree(ctx->d_rays); hipFree(ctx->d_rays_local);
   hipFree(ctx->d_coords); hipFree(ctx->d_normals); hipFree(ctx->d_mask_m); hipFree(ctx->d_model);
-  hipFree(ctx->d_scene); hipFree(ctx->d_icp_res); hipHostFree(ctx->h_icp_res); hipHostFree(ctx->h_out);
+  hipFree(ctx->d_scene); hipFree(ctx->d_icp_res); hipFree(ctx->d_icp_trace); hipHostFree(ctx->h_icp_res); hipHostFree(ctx->h_out);
   hipFree(ctx->d_occ); hipFree(ctx->d_occ_count);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -333,6 +382,15 @@ int tsd_push(tsd_ctx* ctx, const double pose33[9], const double* ranges, const u
   const uint32_t epoch = ctx->epoch;
   int rc = launch_push(ctx, a);
   if (rc != TSD_OK) return rc;
+  {
+    // running totals for the roofline numerator: async copy of this push's counters into a ring slot
+    const int rs = (int)(epoch % tsd_ctx::kStatSlots);
+    if (ctx->stat_pending[rs]) { hipEventSynchronize(ctx->stat_ev[rs]); harvest_push_stats(ctx, false); }
+    TSD_HIP_CHECK(ctx, hipMemcpyAsync(&ctx->h_stat_ring[rs], ctx->d_counters + (epoch & 1u), sizeof(PushCounters),
+                                      hipMemcpyDeviceToHost, ctx->stream));
+    TSD_HIP_CHECK(ctx, hipEventRecord(ctx->stat_ev[rs], ctx->stream));
+    ctx->stat_pending[rs] = true;
+  }
   if (stats) {
     TSD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters + (epoch & 1u), sizeof(PushCounters),
                                       hipMemcpyDeviceToHost, ctx->stream));
@@ -459,6 +517,16 @@ int tsd_localize(tsd_ctx* ctx, const double pose33[9], const double* rays_world_
   return TSD_OK;
 }
 
+int tsd_icp_trace(tsd_ctx* ctx, double* out, int max_iters)
+{
+  if (!ctx || !out || max_iters < 0) return TSD_E_ARG;
+  TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  const int n = max_iters < TSD_ICP_TRACE_MAX ? max_iters : TSD_ICP_TRACE_MAX;
+  TSD_HIP_CHECK(ctx, hipMemcpy(out, ctx->d_icp_trace, sizeof(double) * 4 * (size_t)n, hipMemcpyDeviceToHost));
+  return TSD_OK;
+}
+
 int tsd_download_tile_state(tsd_ctx* ctx, uint8_t* initialized, double* init_weight)
 {
   if (!ctx || !initialized || !init_weight) return TSD_E_ARG;
@@ -543,6 +611,18 @@ int tsd_profile_enable(tsd_ctx* ctx, int on)
 {
   if (!ctx) return TSD_E_ARG;
   ctx->profile = on != 0;
+  if (ctx->profile && ctx->profile_mask == 0) ctx->profile_mask = ~0u;
+  return TSD_OK;
+}
+
+int tsd_profile_select(tsd_ctx* ctx, const char* kernels_csv)
+{
+  if (!ctx || !kernels_csv) return TSD_E_ARG;
+  unsigned mask = 0;
+  const std::string csv(kernels_csv);
+  for (unsigned i = 0; i < sizeof(kKernelNames) / sizeof(kKernelNames[0]); i++)
+    if (csv == "all" || ("," + csv + ",").find(std::string(",") + kKernelNames[i] + ",") != std::string::npos) mask |= 1u << i;
+  ctx->profile_mask = mask;
   return TSD_OK;
 }
 
@@ -563,6 +643,17 @@ int tsd_profile_get(tsd_ctx* ctx, const char* kernel, double* total_ms, int* lau
   auto it = ctx->timers.find(kernel);
   if (total_ms) *total_ms = (it == ctx->timers.end()) ? 0.0 : it->second.total_ms;
   if (launches) *launches = (it == ctx->timers.end()) ? 0 : it->second.launches;
+  return TSD_OK;
+}
+
+int tsd_push_stats_total(tsd_ctx* ctx, tsd_push_stats* total, int64_t* pushes, int reset)
+{
+  if (!ctx) return TSD_E_ARG;
+  TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  harvest_push_stats(ctx, true);
+  if (total) { *total = ctx->stat_total; total->tiles_total = ctx->grid.tiles; }
+  if (pushes) *pushes = ctx->stat_pushes;
+  if (reset) { ctx->stat_total = tsd_push_stats{}; ctx->stat_pushes = 0; }
   return TSD_OK;
 }
 

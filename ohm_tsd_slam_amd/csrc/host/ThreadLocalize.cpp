@@ -179,6 +179,7 @@ void ThreadLocalize::processScan(const std::vector<float>& ranges, const builtin
   ScanReport rep;
   std::memset(&rep, 0, sizeof(rep));
   rep.initialised = true;
+  rep.stampNs = (long long)stamp.sec * 1000000000LL + (long long)stamp.nanosec;
   _stampLaserOld = _stampLaser;
   _stampLaser = stamp;
 
@@ -298,6 +299,7 @@ void ThreadLocalize::init(const sensor_msgs::msg::LaserScan& scan)
     _sensor->getTransformation().getData(_report.pose);
     _report.T[0] = _report.T[4] = _report.T[8] = 1.0;
     _report.pushed = pushed; _report.initialised = true;
+    _report.stampNs = (long long)scan.header.stamp.sec * 1000000000LL + (long long)scan.header.stamp.nanosec;
     _processed++;
   }
   this->unblock();

@@ -42,6 +42,7 @@ public:
   struct ScanReport {
     double pose[9]; double T[9]; double rms; int pairs; int iterations; int icpState;
     int validModel; int validScene; bool regError; bool pushed; bool noModel; bool initialised;
+    long long stampNs;
   };
   ScanReport lastReport();
   uint64_t processedScans();

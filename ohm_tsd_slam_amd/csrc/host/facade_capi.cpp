@@ -131,7 +131,7 @@ int tsd_node_wait_idle(tsd_node* n, int timeout_ms)
 unsigned long long tsd_node_processed(tsd_node* n, int robot) { return n->localizers[robot]->processedScans(); }
 
 // report layout: pose[9], T[9], rms, pairs, iterations, icpState, validModel, validScene, regError,
-// pushed, noModel, initialised  (28 doubles)
+// pushed, noModel, initialised, stamp [ns]  (29 doubles)
 void tsd_node_report(tsd_node* n, int robot, double* out28)
 {
   const ThreadLocalize::ScanReport r = n->localizers[robot]->lastReport();
@@ -139,7 +139,7 @@ void tsd_node_report(tsd_node* n, int robot, double* out28)
   std::memcpy(out28 + 9, r.T, sizeof(r.T));
   out28[18] = r.rms; out28[19] = r.pairs; out28[20] = r.iterations; out28[21] = r.icpState;
   out28[22] = r.validModel; out28[23] = r.validScene; out28[24] = r.regError; out28[25] = r.pushed;
-  out28[26] = r.noModel; out28[27] = r.initialised;
+  out28[26] = r.noModel; out28[27] = r.initialised; out28[28] = (double)r.stampNs;
 }
 
 // last PoseStamped on <node>/<robot/>estimated_pose: x, y, z, qx, qy, qz, qw, publish count

@@ -93,7 +93,8 @@ __global__ void __launch_bounds__(ICP_THREADS)
 k_icp(IcpArgs a, int cap, const double* __restrict__ g_model, const double* __restrict__ g_scene,
       const double* __restrict__ g_coords, const uint8_t* __restrict__ g_mask_m,
       const double* __restrict__ g_rays_local, const double* __restrict__ g_ranges,
-      const uint8_t* __restrict__ g_mask, IcpResultDev* __restrict__ out)
+      const uint8_t* __restrict__ g_mask, IcpResultDev* __restrict__ out,
+      double* __restrict__ trace /* [TSD_ICP_TRACE_MAX][4] = pairs, rms, thr_before, state */)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   size_t off[12];
@@ -245,6 +246,7 @@ k_icp(IcpArgs a, int cap, const double* __restrict__ g_model, const double* __re
   const unsigned int max_it = (unsigned)a.iterations, conv_need = (unsigned)a.iterations;
 
   while (state == TSD_ICP_PROCESSING) {
+    const double thr_before = thr;
     // -- phase A: pre-filter + NN + distance filter (per scene point), reset reciprocal slots
     for (int k = tid; k < nM; k += ICP_THREADS) { L.best_bits[k] = ~0ull; L.best_i[k] = INT_MAX; }
     int my_k[PTS_PER_THREAD]; double my_d[PTS_PER_THREAD]; bool my_keep[PTS_PER_THREAD];
@@ -388,6 +390,10 @@ k_icp(IcpArgs a, int cap, const double* __restrict__ g_model, const double* __re
     if (rms <= 0.0 || conv_cnt >= conv_need) state = TSD_ICP_SUCCESS;
     else if (iter >= max_it) state = TSD_ICP_MAXITERATIONS;
     rms_prev = rms;
+    if (tid == 0 && iter <= TSD_ICP_TRACE_MAX) {
+      double* tr = trace + 4 * (iter - 1);
+      tr[0] = (double)pairs; tr[1] = rms; tr[2] = thr_before; tr[3] = (double)state;
+    }
     __syncthreads();
   }
 
@@ -424,7 +430,7 @@ int launch_icp(tsd_ctx* ctx, const IcpArgs& a)
   ScopedKernelTimer t(ctx, "icp");
   hipLaunchKernelGGL(k_icp, dim3(1), dim3(ICP_THREADS), lds, ctx->stream, a, cap, ctx->d_model,
                      ctx->d_scene, ctx->d_coords, ctx->d_mask_m, ctx->d_rays_local, ctx->d_ranges,
-                     ctx->d_mask, ctx->d_icp_res);
+                     ctx->d_mask, ctx->d_icp_res, ctx->d_icp_trace);
   TSD_HIP_CHECK(ctx, hipGetLastError());
   return TSD_OK;
 }

@@ -102,6 +102,7 @@ struct tsd_ctx {
   double* d_model = nullptr;     // [2*TSD_MAX_ICP_POINTS]
   double* d_scene = nullptr;     // [2*TSD_MAX_ICP_POINTS]
   tsd::IcpResultDev* d_icp_res = nullptr;
+  double* d_icp_trace = nullptr;            // [TSD_ICP_TRACE_MAX][4]
   tsd::IcpResultDev* h_icp_res = nullptr;    // pinned
   char* h_out = nullptr;                     // pinned D2H staging (ray-cast outputs)
   size_t h_out_bytes = 0;
@@ -110,9 +111,19 @@ struct tsd_ctx {
   int8_t* d_occ = nullptr;       // persistent map (ThreadGrid::_occGridContent)
   int* d_occ_count = nullptr;
 
-  // profiling
+  // cumulative push statistics: every push copies its counter set into a pinned ring slot
+  static constexpr int kStatSlots = 16;
+  tsd::PushCounters* h_stat_ring = nullptr;  // pinned [kStatSlots]
+  hipEvent_t stat_ev[kStatSlots] = {};
+  bool stat_pending[kStatSlots] = {};
+  tsd_push_stats stat_total{};
+  int64_t stat_pushes = 0;
+
+  // profiling: bit i of profile_mask times kernel i (names in capi.hip: kKernelNames)
+  unsigned profile_mask = 0;
   bool profile = false;
   std::map<std::string, tsd::KernelTimer> timers;
+  std::vector<hipEvent_t> event_pool;
 };
 
 namespace tsd {
@@ -131,6 +142,8 @@ struct ScopedKernelTimer {
   ~ScopedKernelTimer();
 };
 void drain_timers(tsd_ctx* ctx);
+bool kernel_is_timed(const tsd_ctx* ctx, const char* name);
+void harvest_push_stats(tsd_ctx* ctx, bool wait);
 
 // per-file launchers
 int launch_push(tsd_ctx* ctx, const PushArgs& a);

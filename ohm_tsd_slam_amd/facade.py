@@ -122,12 +122,13 @@ class SlamNode:
         return int(self.lib.tsd_node_processed(self.h, robot))
 
     def report(self, robot: int = 0) -> dict:
-        buf = np.zeros(28)
+        buf = np.zeros(29)
         self.lib.tsd_node_report(self.h, robot, buf.ctypes.data_as(_dp))
         out = {"pose": buf[:9].reshape(3, 3).copy(), "T": buf[9:18].reshape(3, 3).copy()}
         out["rms"] = float(buf[18])
         for i, k in enumerate(REPORT_FIELDS[1:]):
             out[k] = int(buf[19 + i])
+        out["stamp_ns"] = int(buf[28])
         return out
 
     def pose_msg(self, robot: int = 0) -> dict:
