@@ -233,6 +233,8 @@ tsd_ctx* tsd_create(int device, int map_size_log2, double cell_size, double max_
   A(hipMalloc(&g.weight, T * TILE_STRIDE * sizeof(double)));
   A(hipMalloc(&ctx->d_counters, 2 * sizeof(PushCounters)));
   A(hipMalloc(&ctx->d_list, T * sizeof(uint32_t)));
+  A(hipMalloc(&ctx->d_entry_upd, T * sizeof(uint32_t)));
+  A(hipMalloc(&ctx->d_block_stats, ((T + 255) / 256) * 8 * sizeof(int)));
   ctx->dirty_cap = (int)(T < 65536 ? T : 65536);
   A(hipMalloc(&ctx->d_dirty, (size_t)ctx->dirty_cap * sizeof(uint32_t)));
   A(hipMalloc(&ctx->d_dirty_count, sizeof(int)));
@@ -274,7 +276,7 @@ void tsd_destroy(tsd_ctx* ctx)
   drain_timers(ctx);
   GridDev& g = ctx->grid;
   hipFree(g.flags); hipFree(g.init_weight); hipFree(g.tsd); hipFree(g.weight);
-  hipFree(ctx->d_counters); hipFree(ctx->d_list); hipFree(ctx->d_dirty); hipFree(ctx->d_dirty_count);
+  hipFree(ctx->d_counters); hipFree(ctx->d_list); hipFree(ctx->d_entry_upd); hipFree(ctx->d_block_stats); hipFree(ctx->d_dirty); hipFree(ctx->d_dirty_count);
   hipHostFree(ctx->h_dirty); hipHostFree(ctx->h_counters); hipHostFree(ctx->h_stat_ring);
   for (int s = 0; s < tsd_ctx::kStatSlots; s++) if (ctx->stat_ev[s]) hipEventDestroy(ctx->stat_ev[s]);
   for (hipEvent_t e : ctx->event_pool) hipEventDestroy(e);

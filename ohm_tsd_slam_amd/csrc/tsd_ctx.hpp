@@ -79,6 +79,8 @@ struct tsd_ctx {
   uint32_t epoch = 0;
   tsd::PushCounters* d_counters = nullptr;   // [2]
   uint32_t* d_list = nullptr;                // [tiles] work list (bit 31 = emptied-initialised tile)
+  uint32_t* d_entry_upd = nullptr;           // [tiles] cells updated per list entry
+  int* d_block_stats = nullptr;              // [classify blocks][8] per-block tile statistics
   uint32_t* d_dirty = nullptr;               // tiles touched by freeFootprint since the last push
   int* d_dirty_count = nullptr;
   uint32_t* h_dirty = nullptr;               // pinned [dirty_cap + 1] (last word = count staging)
