@@ -12,12 +12,15 @@
 // (ThreadLocalize.cpp:738-755) from the ray-cast outputs.
 //
 // Nearest neighbour without a kd-tree, with identical filtered output: the reference finds the
-// exact NN and then DROPS the pair unless d2 <= thr <= dist_filter_max^2.  So only neighbours within
-// dist_filter_max matter.  Model points are counting-sorted into a uniform grid whose cell edge is
-// >= dist_filter_max; the NN of a scene point, if it is going to survive the distance filter, lies in
-// the 3x3 cells around it, which are three contiguous runs of the sorted arrays.  Pairs whose true NN
-// is farther than dist_filter_max are dropped here exactly as the filter would drop them.
-// Ties (equal d2) go to the lower original model index, like a first-minimum linear scan.
+// exact NN and then DROPS the pair unless d2 <= thr <= dist_filter_max^2, so only neighbours within
+// sqrt(thr) matter.  The model is sorted once per scan (bitonic sort in LDS) by (strip, x): strips are
+// horizontal bands of height h >= dist_filter_max, inside a strip points ascend in x.  A scene point
+// then only has to look at the window |dx| <= sqrt(limit) of its own strip and of the two neighbouring
+// strips, where limit = min(thr, best d2 so far).  From the second iteration on, the search starts at
+// the previous iteration's neighbour, which already bounds the window to a few centimetres, so a step
+// evaluates a handful of candidates per point instead of hundreds.  Everything within sqrt(thr) is
+// always visited, hence the result equals exact-NN + DistanceFilter.  Ties (equal d2) go to the lower
+// original model index, like a first-minimum linear scan.
 //
 // No dense contraction anywhere => no MFMA; fp64 VALU + LDS.  Latency-bound: reported as ms/iterate.
 #include "tsd_ctx.hpp"
@@ -27,39 +30,32 @@ namespace tsd {
 
 constexpr int ICP_THREADS = 1024;
 constexpr int ICP_WAVES = ICP_THREADS / 64;
-constexpr int GDIM = 64;
-constexpr int GCELLS = GDIM * GDIM;
+constexpr int MAX_STRIPS = 4096;
 constexpr int PTS_PER_THREAD = TSD_MAX_ICP_POINTS / ICP_THREADS;   // 2
+constexpr double QSCALE = 1048576.0;            // x quantisation of the sort key: 2^-20 m
+constexpr double QMARGIN = 4.0 / 1048576.0;     // window slack covering the quantisation disorder
 
 struct IcpLds {
-  double* msx; double* msy;        // model, grid-sorted
+  double* msx; double* msy;        // model, sorted by (strip, x)
   double* sx;  double* sy;         // scene (current estimate)
-  double* ux;  double* uy;         // model staging (aliases nn region)
+  double* ux;  double* uy;         // model staging (uy is reused as best_bits)
+  unsigned long long* keys;        // sort keys: strip << 52 | qx << 12 | original index
   unsigned long long* best_bits;   // per sorted model slot: min d2 (bit pattern) among its pairs
   int* morig;                      // original model index of a sorted slot
   int* best_i;                     // winning scene index per sorted model slot
-  int* key;                        // cell of unsorted model point (build only)
-  int* cell_end;                   // after the scatter: end offset of each cell
+  int* pos_of;                     // sorted slot of original model index
+  int* strip_start;                // [MAX_STRIPS + 2] first sorted slot of every strip
   double* red;                     // [ICP_WAVES][8] partials + [16] totals/broadcast
-  int* ired;                       // [ICP_WAVES*2 + 8]
+  int* ired;                       // [ICP_WAVES*2 + 16]
 };
 
-__host__ __device__ inline size_t icp_lds_layout(int cap, size_t off[12])
+__host__ __device__ inline int icp_pow2(int n) { int p = 64; while (p < n) p <<= 1; return p; }
+
+__host__ __device__ inline size_t icp_lds_bytes_for(int cap)
 {
-  size_t o = 0;
-  off[0] = o; o += sizeof(double) * cap;          // msx
-  off[1] = o; o += sizeof(double) * cap;          // msy
-  off[2] = o; o += sizeof(double) * cap;          // sx
-  off[3] = o; o += sizeof(double) * cap;          // sy
-  off[4] = o; o += sizeof(double) * cap;          // ux  (later unused)
-  off[5] = o; o += sizeof(double) * cap;          // uy / best_bits
-  off[6] = o; o += sizeof(int) * cap;             // morig
-  off[7] = o; o += sizeof(int) * cap;             // best_i
-  off[8] = o; o += sizeof(int) * cap;             // key
-  off[9] = o; o += sizeof(int) * (GCELLS + 16);   // cell_end
-  off[10] = o; o += sizeof(double) * (ICP_WAVES * 8 + 16);   // red
-  off[11] = o; o += sizeof(int) * (ICP_WAVES * 2 + 16);      // ired
-  return (o + 15) & ~(size_t)15;
+  return sizeof(double) * 6 * (size_t)cap + sizeof(unsigned long long) * (size_t)icp_pow2(cap) +
+         sizeof(int) * 3 * (size_t)cap + sizeof(int) * (MAX_STRIPS + 16) +
+         sizeof(double) * (ICP_WAVES * 8 + 16) + sizeof(int) * (ICP_WAVES * 2 + 16) + 64;
 }
 
 // sum of `nv` doubles held per thread -> totals in red[ICP_WAVES*8 .. +nv) (all threads may read them
@@ -97,25 +93,34 @@ k_icp(IcpArgs a, int cap, const double* __restrict__ g_model, const double* __re
       double* __restrict__ trace /* [TSD_ICP_TRACE_MAX][4] = pairs, rms, thr_before, state */)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  size_t off[12];
-  icp_lds_layout(cap, off);
   IcpLds L;
-  L.msx = reinterpret_cast<double*>(smem + off[0]);
-  L.msy = reinterpret_cast<double*>(smem + off[1]);
-  L.sx = reinterpret_cast<double*>(smem + off[2]);
-  L.sy = reinterpret_cast<double*>(smem + off[3]);
-  L.ux = reinterpret_cast<double*>(smem + off[4]);
-  L.uy = reinterpret_cast<double*>(smem + off[5]);
-  L.best_bits = reinterpret_cast<unsigned long long*>(smem + off[5]);
-  L.morig = reinterpret_cast<int*>(smem + off[6]);
-  L.best_i = reinterpret_cast<int*>(smem + off[7]);
-  L.key = reinterpret_cast<int*>(smem + off[8]);
-  L.cell_end = reinterpret_cast<int*>(smem + off[9]);
-  L.red = reinterpret_cast<double*>(smem + off[10]);
-  L.ired = reinterpret_cast<int*>(smem + off[11]);
+  {
+    char* p = smem;
+    const size_t cd = sizeof(double) * (size_t)cap, ci = sizeof(int) * (size_t)cap;
+    L.msx = reinterpret_cast<double*>(p); p += cd;
+    L.msy = reinterpret_cast<double*>(p); p += cd;
+    L.sx = reinterpret_cast<double*>(p); p += cd;
+    L.sy = reinterpret_cast<double*>(p); p += cd;
+    L.ux = reinterpret_cast<double*>(p); p += cd;
+    L.uy = reinterpret_cast<double*>(p); L.best_bits = reinterpret_cast<unsigned long long*>(p); p += cd;
+    L.keys = reinterpret_cast<unsigned long long*>(p); p += sizeof(unsigned long long) * (size_t)icp_pow2(cap);
+    L.red = reinterpret_cast<double*>(p); p += sizeof(double) * (ICP_WAVES * 8 + 16);
+    L.morig = reinterpret_cast<int*>(p); p += ci;
+    L.best_i = reinterpret_cast<int*>(p); p += ci;
+    L.pos_of = reinterpret_cast<int*>(p); p += ci;
+    L.strip_start = reinterpret_cast<int*>(p); p += sizeof(int) * (MAX_STRIPS + 16);
+    L.ired = reinterpret_cast<int*>(p);
+  }
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int nM = 0, nS = 0;
+#ifdef TSD_ICP_STAMPS   // diagnostic build: cycles per phase (thread 0), written behind the trace records
+  long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long st_t = clock64();
+#define STAMP(i) do { const long long now_ = clock64(); st_acc[i] += now_ - st_t; st_t = now_; } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
 
   // ---------------------------------------------------------------- inputs
   if (a.beams > 0) {
@@ -172,72 +177,78 @@ k_icp(IcpArgs a, int cap, const double* __restrict__ g_model, const double* __re
     return;
   }
 
-  // ---------------------------------------------------------------- search grid over the model
+  // ---------------------------------------------------------------- sort the model by (strip, x)
   double gminx, gminy, h;
+  int nstrips;
   {
-    double mn[2] = {__builtin_inf(), __builtin_inf()}, mxv[2] = {-__builtin_inf(), -__builtin_inf()};
+    double mn[2] = {__builtin_inf(), __builtin_inf()}, mxv = -__builtin_inf();
     for (int j = tid; j < nM; j += ICP_THREADS) {
       mn[0] = fmin(mn[0], L.ux[j]); mn[1] = fmin(mn[1], L.uy[j]);
-      mxv[0] = fmax(mxv[0], L.ux[j]); mxv[1] = fmax(mxv[1], L.uy[j]);
+      mxv = fmax(mxv, L.uy[j]);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       mn[0] = fmin(mn[0], __shfl_down(mn[0], o, 64)); mn[1] = fmin(mn[1], __shfl_down(mn[1], o, 64));
-      mxv[0] = fmax(mxv[0], __shfl_down(mxv[0], o, 64)); mxv[1] = fmax(mxv[1], __shfl_down(mxv[1], o, 64));
+      mxv = fmax(mxv, __shfl_down(mxv, o, 64));
     }
-    if (lane == 0) { L.red[wave * 8 + 0] = mn[0]; L.red[wave * 8 + 1] = mn[1]; L.red[wave * 8 + 2] = mxv[0]; L.red[wave * 8 + 3] = mxv[1]; }
+    if (lane == 0) { L.red[wave * 8 + 0] = mn[0]; L.red[wave * 8 + 1] = mn[1]; L.red[wave * 8 + 2] = mxv; }
     __syncthreads();
     gminx = L.red[0]; gminy = L.red[1];
-    double gmaxx = L.red[2], gmaxy = L.red[3];
+    double gmaxy = L.red[2];
     for (int w = 1; w < ICP_WAVES; w++) {
       gminx = fmin(gminx, L.red[w * 8 + 0]); gminy = fmin(gminy, L.red[w * 8 + 1]);
-      gmaxx = fmax(gmaxx, L.red[w * 8 + 2]); gmaxy = fmax(gmaxy, L.red[w * 8 + 3]);
+      gmaxy = fmax(gmaxy, L.red[w * 8 + 2]);
     }
-    const double ext = fmax(gmaxx - gminx, gmaxy - gminy);
-    h = fmax(sqrt(a.thr0) * (1.0 + 1e-9), ext / (double)GDIM * (1.0 + 1e-9));
+    // strip height >= sqrt(thr0) so that everything within the distance threshold of a point lies in
+    // its own strip or a direct neighbour; at most MAX_STRIPS - 2 strips
+    h = fmax(sqrt(a.thr0) * (1.0 + 1e-9), (gmaxy - gminy) / (double)(MAX_STRIPS - 2) * (1.0 + 1e-9));
     if (!(h > 0.0)) h = 1.0;
+    nstrips = (int)fmin(floor((gmaxy - gminy) / h) + 1.0, (double)(MAX_STRIPS - 1));
     __syncthreads();
   }
   const double inv_h = 1.0 / h;
-  for (int c = tid; c < GCELLS + 1; c += ICP_THREADS) L.cell_end[c] = 0;
-  __syncthreads();
-  for (int j = tid; j < nM; j += ICP_THREADS) {
-    int cx = (int)fmin(fmax(floor((L.ux[j] - gminx) * inv_h), 0.0), (double)(GDIM - 1));
-    int cy = (int)fmin(fmax(floor((L.uy[j] - gminy) * inv_h), 0.0), (double)(GDIM - 1));
-    const int c = cy * GDIM + cx;
-    L.key[j] = c;
-    atomicAdd(&L.cell_end[c], 1);
+  const int n2 = icp_pow2(nM);
+  for (int j = tid; j < n2; j += ICP_THREADS) {
+    unsigned long long key = ~0ull;
+    if (j < nM) {
+      const unsigned long long st = (unsigned long long)fmin(fmax(floor((L.uy[j] - gminy) * inv_h), 0.0), (double)(nstrips - 1));
+      const unsigned long long qx = (unsigned long long)fmin(fmax(floor((L.ux[j] - gminx) * QSCALE), 0.0), 1099511627775.0);
+      key = (st << 52) | (qx << 12) | (unsigned long long)j;
+    }
+    L.keys[j] = key;
   }
   __syncthreads();
-  {
-    // exclusive prefix sum over GCELLS counts, 4 per thread
-    const int c0 = tid * (GCELLS / ICP_THREADS);
-    int loc[GCELLS / ICP_THREADS];
-    int s = 0;
-#pragma unroll
-    for (int k = 0; k < GCELLS / ICP_THREADS; k++) { loc[k] = L.cell_end[c0 + k]; s += loc[k]; }
-    int incl = s;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
-    if (lane == 63) L.ired[wave] = incl;
-    __syncthreads();
-    int wbase = 0;
-    for (int w = 0; w < wave; w++) wbase += L.ired[w];
-    int run = wbase + incl - s;
-#pragma unroll
-    for (int k = 0; k < GCELLS / ICP_THREADS; k++) { L.cell_end[c0 + k] = run; run += loc[k]; }
-    __syncthreads();
+  // bitonic sort of the keys (unique: the original index is part of the key => deterministic order)
+  for (int k = 2; k <= n2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < (n2 >> 1); t += ICP_THREADS) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int l = i | j;
+        const unsigned long long ka = L.keys[i], kb = L.keys[l];
+        const bool asc = (i & k) == 0;
+        if ((ka > kb) == asc) { L.keys[i] = kb; L.keys[l] = ka; }
+      }
+      __syncthreads();
+    }
   }
-  // scatter: cell_end[c] starts as the cell's begin offset and ends as its end offset.  The slot a
-  // point lands in depends on atomic arrival order, so every order-sensitive loop below walks the
-  // ORIGINAL model index j and goes through pos_of[j]; results are then reproducible run to run.
-  for (int j = tid; j < nM; j += ICP_THREADS) {
-    const int pos = atomicAdd(&L.cell_end[L.key[j]], 1);
-    L.msx[pos] = L.ux[j]; L.msy[pos] = L.uy[j]; L.morig[pos] = j;
-    L.key[j] = pos;                                  // key[] becomes pos_of[]
+  for (int k = tid; k < nM; k += ICP_THREADS) {
+    const int j = (int)(L.keys[k] & 0xFFFull);
+    L.msx[k] = L.ux[j]; L.msy[k] = L.uy[j]; L.morig[k] = j;
+    L.pos_of[j] = k;
+  }
+  // first slot of every strip: lower bound of (strip << 52) in the sorted keys
+  for (int st = tid; st <= nstrips; st += ICP_THREADS) {
+    const unsigned long long target = (unsigned long long)st << 52;
+    int lo = 0, hi = nM;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (L.keys[mid] < target) lo = mid + 1; else hi = mid; }
+    L.strip_start[st] = lo;
   }
   __syncthreads();
-  const int* __restrict__ pos_of = L.key;
+  STAMP(0);
+  const int* __restrict__ pos_of = L.pos_of;
+  int hint[PTS_PER_THREAD];
+#pragma unroll
+  for (int q = 0; q < PTS_PER_THREAD; q++) hint[q] = -1;
 
   // ---------------------------------------------------------------- iterate
   double thr = a.thr0;                       // DistanceFilter::_distSqr after reset()
@@ -263,26 +274,65 @@ k_icp(IcpArgs a, int cap, const double* __restrict__ g_model, const double* __re
         wx += a.P[2]; wy += a.P[5];
         const bool pre = !(wx < a.min_x || wx > a.max_x || wy < a.min_y || wy > a.max_y);
         if (pre) {
-          const double fcx = fmin(fmax(floor((x - gminx) * inv_h), -2.0), (double)(GDIM + 1));
-          const double fcy = fmin(fmax(floor((y - gminy) * inv_h), -2.0), (double)(GDIM + 1));
-          const int cx = (int)fcx, cy = (int)fcy;
-          const int x0 = max(cx - 1, 0), x1 = min(cx + 1, GDIM - 1);
-          const int y0 = max(cy - 1, 0), y1 = min(cy + 1, GDIM - 1);
           double bd = __builtin_inf(); int bk = -1;
-          if (x0 <= x1) {
-            for (int r = y0; r <= y1; r++) {
-              const int cb = r * GDIM + x0, ce = r * GDIM + x1;
-              const int kb = (cb == 0) ? 0 : L.cell_end[cb - 1], ke = L.cell_end[ce];
-              for (int k = kb; k < ke; k++) {
-                const double dx = x - L.msx[k], dy = y - L.msy[k];
-                const double d = dx * dx + dy * dy;
-                if (d < bd) { bd = d; bk = k; }
-                else if (d == bd && bk >= 0 && L.morig[k] < L.morig[bk]) { bk = k; }
-              }
+          auto eval = [&](int k) {
+            const double dx = x - L.msx[k], dy = y - L.msy[k];
+            const double d = dx * dx + dy * dy;
+            if (d < bd) { bd = d; bk = k; }
+            else if (d == bd && bk >= 0 && L.morig[k] < L.morig[bk]) { bk = k; }
+          };
+          // window walk inside one strip [sb, se), starting at slot `pos` (first slot at/after x)
+          auto walk = [&](int sb, int se, int pos) {
+            for (int k = pos; k < se; k++) {
+              const double m = (L.msx[k] - x) - QMARGIN;
+              if (m > 0.0 && m * m > fmin(bd, thr)) break;
+              eval(k);
             }
+            for (int k = pos - 1; k >= sb; k--) {
+              const double m = (x - L.msx[k]) - QMARGIN;
+              if (m > 0.0 && m * m > fmin(bd, thr)) break;
+              eval(k);
+            }
+          };
+          const double fy = floor((y - gminy) * inv_h);
+          const int cy = (int)fmin(fmax(fy, -2.0), (double)(nstrips + 1));
+          // own strip first: start from last iteration's neighbour when it lives here, which already
+          // bounds the window to the current pair distance
+          const int hk = hint[q];
+          bool own_done = false;
+          if (hk >= 0) {
+            eval(hk);
+            if (cy >= 0 && cy < nstrips && hk >= L.strip_start[cy] && hk < L.strip_start[cy + 1] && bd <= thr) {
+              const int sb = L.strip_start[cy], se = L.strip_start[cy + 1];
+              for (int k = hk + 1; k < se; k++) {
+                const double m = (L.msx[k] - x) - QMARGIN;
+                if (m > 0.0 && m * m > fmin(bd, thr)) break;
+                eval(k);
+              }
+              for (int k = hk - 1; k >= sb; k--) {
+                const double m = (x - L.msx[k]) - QMARGIN;
+                if (m > 0.0 && m * m > fmin(bd, thr)) break;
+                eval(k);
+              }
+              own_done = true;
+            }
+          }
+#pragma unroll
+          for (int ds = 0; ds < 3; ds++) {
+            const int st = (ds == 0) ? cy : (ds == 1 ? cy - 1 : cy + 1);
+            if (st < 0 || st >= nstrips || (ds == 0 && own_done)) continue;
+            // distance from the point to the strip's band in y; skip bands out of reach
+            const double ylo = gminy + (double)st * h, yhi = gminy + (double)(st + 1) * h;
+            const double gap = fmax(fmax(ylo - y, y - yhi), 0.0) - 1e-9 * h;
+            if (gap > 0.0 && gap * gap > fmin(bd, thr)) continue;
+            const int sb = L.strip_start[st], se = L.strip_start[st + 1];
+            int lo = sb, hi = se;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (L.msx[mid] < x) lo = mid + 1; else hi = mid; }
+            walk(sb, se, lo);
           }
           my_k[q] = bk; my_d[q] = bd;
           my_keep[q] = (bk >= 0) && (bd <= thr);      // DistanceFilter::filter
+          hint[q] = bk;
         }
       }
     }
@@ -290,6 +340,7 @@ k_icp(IcpArgs a, int cap, const double* __restrict__ g_model, const double* __re
     thr *= a.multiplier;
     if (thr < a.min_sqr) thr = a.min_sqr;
     __syncthreads();
+    STAMP(1);
     // -- phase B/C: ReciprocalFilter = per model point keep the pair with the smallest d2
 #pragma unroll
     for (int q = 0; q < PTS_PER_THREAD; q++)
@@ -301,6 +352,7 @@ k_icp(IcpArgs a, int cap, const double* __restrict__ g_model, const double* __re
         atomicMin(&L.best_i[my_k[q]], tid + q * ICP_THREADS);
     __syncthreads();
 
+    STAMP(2);
     // -- phase D: ClosedFormEstimator2D::setPairs: centroids, "rms" (mean squared distance), count
     double v[6] = {0, 0, 0, 0, 0, 0};
     for (int j = tid; j < nM; j += ICP_THREADS) {
@@ -316,6 +368,7 @@ k_icp(IcpArgs a, int cap, const double* __restrict__ g_model, const double* __re
     }
     block_sum<6>(v, L.red, tid);
     pairs = (int)v[5];
+    STAMP(3);
 
     if (pairs > 2) {
       const double size_inv = 1.0 / (double)pairs;
@@ -354,6 +407,7 @@ k_icp(IcpArgs a, int cap, const double* __restrict__ g_model, const double* __re
         }
         __syncthreads();
       }
+      STAMP(4);
       const double co = L.red[ICP_WAVES * 8 + 0], si = L.red[ICP_WAVES * 8 + 1];
       const double dX = L.red[ICP_WAVES * 8 + 2], dY = L.red[ICP_WAVES * 8 + 3];
       // applyTransformation(sceneTmp): data * R^T (dgemm NoTrans,Trans), then + t (Icp.cpp:371-408)
@@ -390,6 +444,7 @@ k_icp(IcpArgs a, int cap, const double* __restrict__ g_model, const double* __re
     if (rms <= 0.0 || conv_cnt >= conv_need) state = TSD_ICP_SUCCESS;
     else if (iter >= max_it) state = TSD_ICP_MAXITERATIONS;
     rms_prev = rms;
+    STAMP(5);
     if (tid == 0 && iter <= TSD_ICP_TRACE_MAX) {
       double* tr = trace + 4 * (iter - 1);
       tr[0] = (double)pairs; tr[1] = rms; tr[2] = thr_before; tr[3] = (double)state;
@@ -397,6 +452,9 @@ k_icp(IcpArgs a, int cap, const double* __restrict__ g_model, const double* __re
     __syncthreads();
   }
 
+#ifdef TSD_ICP_STAMPS
+  if (tid == 0) for (int i = 0; i < 8; i++) trace[4 * TSD_ICP_TRACE_MAX - 8 + i] = (double)st_acc[i];
+#endif
   if (tid == 0) {
     // Icp::getFinalTransformation (Icp.cpp:528-546)
     out->T[0] = Tf[0]; out->T[1] = Tf[1]; out->T[2] = Tf[3];
@@ -419,8 +477,7 @@ int launch_icp(tsd_ctx* ctx, const IcpArgs& a)
   const int n = a.beams > 0 ? a.beams : (a.n_model > a.n_scene ? a.n_model : a.n_scene);
   if (n > TSD_MAX_ICP_POINTS) return set_error(ctx, TSD_E_CAPACITY, "icp points > TSD_MAX_ICP_POINTS", hipSuccess);
   const int cap = icp_cap_for(n);
-  size_t off[12];
-  const size_t lds = icp_lds_layout(cap, off);
+  const size_t lds = icp_lds_bytes_for(cap);
   static size_t configured = 0;
   if (lds > configured) {
     TSD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_icp),
@@ -435,10 +492,6 @@ int launch_icp(tsd_ctx* ctx, const IcpArgs& a)
   return TSD_OK;
 }
 
-size_t icp_lds_bytes()
-{
-  size_t off[12];
-  return icp_lds_layout(TSD_MAX_ICP_POINTS, off);
-}
+size_t icp_lds_bytes() { return icp_lds_bytes_for(TSD_MAX_ICP_POINTS); }
 
 }  // namespace tsd

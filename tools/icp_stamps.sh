@@ -1,0 +1,26 @@
+#!/bin/bash
+# diagnostic: rebuild icp_kernels with per-phase cycle stamps on the GPU box and print the phase shares
+cd $GRAFT_REPO_ROOT/ohm_tsd_slam_amd/csrc
+hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -I../../include -DTSD_ICP_STAMPS -c icp_kernels.hip -o ../lib/obj/icp_kernels.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libtsd_hip.so ../lib/obj/*.o
+cd $GRAFT_REPO_ROOT && python3 - <<'PY'
+import numpy as np, sys
+sys.path.insert(0, '.')
+from oracle import pyoracle as O
+from ohm_tsd_slam_amd import capi, synth
+from tests.test_gpu_parity import build_map, icp_inputs
+gc, geo, scene = synth.CONFIGS["cfg2"]
+world = synth.World(scene, gc)
+og, dg = build_map(O, gc, geo, world)
+pose, rl, rw, data, mask, M, S = icp_inputs(O, gc, geo, world, 5, og)
+p = dg.icp_params(30, 0.4, 0.02)
+for rep in range(3):
+    dg.profile(True, "icp"); dg.profile_reset()
+    rd = dg.icp(M, S, pose, p)
+    ms, n = dg.profile_get("icp")
+    tr = np.zeros((256, 4)); dg.lib.tsd_icp_trace(dg.h, tr.ctypes.data_as(capi._dp), 256)
+    st = tr.reshape(-1)[-8:]
+    names = ["setup(load+sort)", "A nn", "BC reciprocal", "D sums1", "F sums2+trig", "G transform+ctl"]
+    tot = st.sum()
+    print("kernel ms %.3f" % (ms / n), "cycles total %.0f" % tot, {nm: "%.1f%%" % (100 * c / tot) for nm, c in zip(names, st)}, "nM", len(M), "nS", len(S))
+PY
