@@ -92,12 +92,12 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", local_rank))
 
-    from ohm_tsd_slam_amd import facade, synth
+    from ohm_tsd_slam_amd import facade, multigpu, synth
     gc, geo, default_scene = synth.CONFIGS[args.config]
     scene = args.scene or default_scene
 
     # robot r starts 0.7 m further along -x (launch/multi_slam.launch:40); every rank owns one grid
-    off_x = 0.37 - 0.7 * rank
+    off_x = multigpu.robot_offset_x(rank)
     world = synth.World(scene, gc, start_xy=[0.5 * gc.width + off_x, 0.5 * gc.width - 0.21])
     K, W = args.steps, args.warmup
     poses = synth.trajectory(world, 1 + W + K)
@@ -107,15 +107,15 @@ def main():
     params["tsd_slam/local_offset_x"] = off_x
     node = facade.SlamNode(params, device=local_rank if world_size > 1 else 0, synchronous=True)
     grid = node.grid()
-    occ = None
+    merger = None
     if world_size > 1:
-        occ = torch.empty(gc.cells * gc.cells, dtype=torch.int8, device=f"cuda:{local_rank}")
+        merger = multigpu.OccupancyMerger(gc.cells, device=f"cuda:{local_rank}")
 
     def step(k):
         node.laser(scans[k], geo.angle_min, geo.angle_increment)
-        if dist is not None and k % MERGE_EVERY == 0:
-            grid.occupancy_into(occ.data_ptr())                       # extraction kernels, ctx stream
-            dist.all_reduce(occ, op=dist.ReduceOp.MAX, async_op=True)  # RCCL over xGMI, overlaps next scans
+        if merger is not None and k % MERGE_EVERY == 0:
+            merger.fill_from_grid(grid)     # occupancy extraction kernels on the ctx stream
+            merger.merge_async()            # RCCL max all-reduce over xGMI, overlaps the next scans
 
     node.laser(scans[0], geo.angle_min, geo.angle_increment)          # init: freeFootprint + initPush
     for k in range(1, 1 + W):
@@ -132,6 +132,7 @@ def main():
         step(k)
     grid.sync()
     if dist is not None:
+        merger.wait()
         torch.cuda.synchronize()
         dist.barrier()
     elapsed = time.perf_counter() - t0

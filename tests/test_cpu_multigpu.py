@@ -1,0 +1,96 @@
+"""The N > 1 path on CPU: two ranks (gloo, 127.0.0.1), one robot + one grid per rank, occupancy maps
+merged with the same ``OccupancyMerger`` that ``bench.py --gpus N`` uses over RCCL.  The per-rank maps
+come from the oracle here (no GPU in this suite); the merge semantics (element-wise max: occupied >
+free > unknown) are checked against numpy."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.distributed as dist  # noqa: E402
+import torch.multiprocessing as mp  # noqa: E402
+
+from ohm_tsd_slam_amd import multigpu, synth  # noqa: E402
+from tests import helpers as H  # noqa: E402
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rank_map(rank, n_scans=3):
+    """Occupancy map of robot `rank` after a few pushes (oracle = checker-side generator of test data)."""
+    from oracle import pyoracle as O
+    gc = synth.GridConfig(8, 0.05)
+    geo = synth.ScanGeometry.full_circle_360()
+    off = multigpu.robot_offset_x(rank)
+    world = synth.World("room", gc, start_xy=[0.5 * gc.width + off, 0.5 * gc.width - 0.21])
+    grid = O.Grid(gc.map_size_log2, gc.cell_size, gc.max_trunc)
+    for k in range(n_scans):
+        pose, (x, y, yaw) = H.sensor_pose(world, k)
+        data, mask = O.ingest_f32(world.scan(x, y, yaw, geo), H.MAX_RANGE, geo.angle_increment)
+        grid.push(pose, data, mask, geo.angle_increment, geo.angle_min, H.MAX_RANGE, H.MIN_RANGE, H.LOW_REFL)
+    content = np.full(gc.cells * gc.cells, -1, dtype=np.int8)
+    occ, _ = grid.occupancy(content)
+    return gc, occ.reshape(-1)
+
+
+def _worker(rank, world_size, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        gc, mine = _rank_map(rank)
+        merger = multigpu.OccupancyMerger(gc.cells)
+        assert merger.active
+        merger.fill_from_host(mine)
+        merger.merge_async()                       # would overlap the next scans on a GPU
+        merged = merger.merged().numpy().reshape(-1).copy()
+        # second round: maps only grow, merging again is idempotent
+        merger.fill_from_host(merged)
+        merger.merge_async()
+        again = merger.merged().numpy().reshape(-1).copy()
+        q.put((rank, mine, merged, bool(np.array_equal(again, merged))))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_occupancy_merge_two_ranks_gloo():
+    ws = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, ws, port, q)) for r in range(ws)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in range(ws)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    maps = [r[1] for r in res]
+    want = np.maximum(maps[0], maps[1])
+    assert set(np.unique(want)).issubset({-1, 0, 100})
+    assert (maps[0] != maps[1]).any(), "the two robots must see different maps for the test to mean anything"
+    for r in res:
+        assert np.array_equal(r[2], want), f"rank {r[0]}: merged map != element-wise max"
+        assert r[3], "merge is not idempotent"
+    # occupied wins over free wins over unknown
+    both = (maps[0] == 100) | (maps[1] == 100)
+    assert np.array_equal(want == 100, both)
+    assert np.array_equal(want == -1, (maps[0] == -1) & (maps[1] == -1))
+
+
+def test_single_rank_is_a_no_op():
+    merger = multigpu.OccupancyMerger(8)
+    assert not merger.active
+    merger.fill_from_host(np.arange(64, dtype=np.int8) % 3 - 1)
+    assert merger.merge_async() is None
+    assert merger.merged().shape == (8, 8)
+    assert multigpu.merge_bytes_per_rank(4096, 1) == 0.0
+    assert multigpu.merge_bytes_per_rank(4096, 8) == 2 * 7 / 8 * 4096 * 4096
+    assert multigpu.robot_offset_x(0) == 0.37 and abs(multigpu.robot_offset_x(1) + 0.33) < 1e-12
