@@ -3,10 +3,14 @@
 // No CPU fall-back exists: every compute entry point needs a gfx950 device and fails loudly without.
 #include "tsd_ctx.hpp"
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <cstdio>
 #include <new>
+#include <numeric>
+#include <vector>
 
 namespace tsd {
 
@@ -155,6 +159,7 @@ static void fill_icp_args(IcpArgs& a, const double pose33[9], const tsd_icp_para
   a.multiplier = distance_filter_multiplier(p->dist_filter_max, p->dist_filter_min, p->iterations);
   a.iterations = p->iterations;
   a.n_model = a.n_scene = a.beams = 0;
+  a.ccw = 1; a.pad = 0;
 }
 
 static void fill_raycast_args(const tsd_ctx* ctx, RaycastArgs& a, const double pose33[9], int beams,
@@ -242,7 +247,7 @@ tsd_ctx* tsd_create(int device, int map_size_log2, double cell_size, double max_
   A(hipHostMalloc(&ctx->h_counters, sizeof(PushCounters), hipHostMallocDefault));
   A(hipHostMalloc(&ctx->h_stat_ring, sizeof(PushCounters) * tsd_ctx::kStatSlots, hipHostMallocDefault));
   for (int s = 0; s < tsd_ctx::kStatSlots; s++) A(hipEventCreateWithFlags(&ctx->stat_ev[s], hipEventDisableTiming));
-  ctx->stage_bytes = (size_t)TSD_MAX_BEAMS * (8 * 5 + 1) + 256;   // ranges + 2x rays(2) + mask
+  ctx->stage_bytes = (size_t)TSD_MAX_BEAMS * (8 * 5 + 1) + 256;   // ranges + 2x rays(2) + mask; >= icp staging (80 KB)
   for (int s = 0; s < tsd_ctx::kSlots; s++) {
     A(hipHostMalloc(&ctx->h_stage[s], ctx->stage_bytes, hipHostMallocDefault));
     A(hipEventCreateWithFlags(&ctx->stage_ev[s], hipEventDisableTiming));
@@ -256,6 +261,9 @@ tsd_ctx* tsd_create(int device, int map_size_log2, double cell_size, double max_
   A(hipMalloc(&ctx->d_mask_m, TSD_MAX_BEAMS));
   A(hipMalloc(&ctx->d_model, 2 * TSD_MAX_ICP_POINTS * sizeof(double)));
   A(hipMalloc(&ctx->d_scene, 2 * TSD_MAX_ICP_POINTS * sizeof(double)));
+  A(hipMalloc(&ctx->d_morig, TSD_MAX_ICP_POINTS * sizeof(int)));
+  A(hipMalloc(&ctx->d_start, TSD_MAX_ICP_POINTS * sizeof(int)));
+  if (const char* e = std::getenv("TSD_ICP_SHAPE")) ctx->icp_shape = std::atoi(e);
   A(hipMalloc(&ctx->d_icp_res, sizeof(IcpResultDev)));
   A(hipMalloc(&ctx->d_icp_trace, sizeof(double) * 4 * TSD_ICP_TRACE_MAX));
   A(hipHostMalloc(&ctx->h_icp_res, sizeof(IcpResultDev), hipHostMallocDefault));
@@ -286,7 +294,7 @@ void tsd_destroy(tsd_ctx* ctx)
   }
   hipFree(ctx->d_ranges); hipFree(ctx->d_mask); hipFree(ctx->d_rays); hipFree(ctx->d_rays_local);
   hipFree(ctx->d_coords); hipFree(ctx->d_normals); hipFree(ctx->d_mask_m); hipFree(ctx->d_model);
-  hipFree(ctx->d_scene); hipFree(ctx->d_icp_res); hipFree(ctx->d_icp_trace); hipHostFree(ctx->h_icp_res); hipHostFree(ctx->h_out);
+  hipFree(ctx->d_scene); hipFree(ctx->d_morig); hipFree(ctx->d_start); hipFree(ctx->d_icp_res); hipFree(ctx->d_icp_trace); hipHostFree(ctx->h_icp_res); hipHostFree(ctx->h_out);
   hipFree(ctx->d_occ); hipFree(ctx->d_occ_count);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -460,15 +468,36 @@ int tsd_icp(tsd_ctx* ctx, const double* model_xy, int n_model, const double* sce
   IcpArgs a;
   fill_icp_args(a, pose33, params);
   a.n_model = n_model; a.n_scene = n_scene; a.beams = 0;
-  // model and scene share one staging slot (2 * 2048 * 16 B = 64 KB <= stage_bytes)
+  // The kernel's exact nearest-neighbour walk wants the model in angular order about the origin of the
+  // sensor frame (what the ray-cast emits by construction).  Arbitrary callers get it sorted here; the
+  // original indices travel along for the lowest-index tie rule, and every scene point gets the slot
+  // where its own direction falls as first search position.  Ordering only: no arithmetic on the data.
+  std::vector<int> order((size_t)n_model), start((size_t)n_scene);
+  std::vector<double> ang((size_t)n_model);
+  for (int j = 0; j < n_model; j++) ang[(size_t)j] = std::atan2(model_xy[2 * j + 1], model_xy[2 * j]);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return ang[(size_t)x] < ang[(size_t)y]; });
+  std::vector<double> sorted_ang((size_t)n_model);
+  for (int k = 0; k < n_model; k++) sorted_ang[(size_t)k] = ang[(size_t)order[(size_t)k]];
+  for (int i = 0; i < n_scene; i++) {
+    const double t = std::atan2(scene_xy[2 * i + 1], scene_xy[2 * i]);
+    int k = (int)(std::lower_bound(sorted_ang.begin(), sorted_ang.end(), t) - sorted_ang.begin());
+    start[(size_t)i] = (n_model > 0 && k >= n_model) ? 0 : k;
+  }
+  // model, scene, permutation and start slots share one staging slot (2 * 2048 * (16 + 4) B = 80 KB)
   int s;
   char* h = stage_acquire(ctx, &s);
-  const size_t mb = (size_t)n_model * 16, sb = (size_t)n_scene * 16;
-  if (mb + sb > ctx->stage_bytes) return set_error(ctx, TSD_E_CAPACITY, "icp staging", hipSuccess);
-  if (mb) std::memcpy(h, model_xy, mb);
+  const size_t mb = (size_t)n_model * 16, sb = (size_t)n_scene * 16, ob = (size_t)n_model * 4, tb = (size_t)n_scene * 4;
+  if (mb + sb + ob + tb > ctx->stage_bytes) return set_error(ctx, TSD_E_CAPACITY, "icp staging", hipSuccess);
+  double* hm = reinterpret_cast<double*>(h);
+  for (int k = 0; k < n_model; k++) { const int j = order[(size_t)k]; hm[2 * k] = model_xy[2 * j]; hm[2 * k + 1] = model_xy[2 * j + 1]; }
   if (sb) std::memcpy(h + mb, scene_xy, sb);
+  if (ob) std::memcpy(h + mb + sb, order.data(), ob);
+  if (tb) std::memcpy(h + mb + sb + ob, start.data(), tb);
   if (mb) TSD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_model, h, mb, hipMemcpyHostToDevice, ctx->stream));
   if (sb) TSD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_scene, h + mb, sb, hipMemcpyHostToDevice, ctx->stream));
+  if (ob) TSD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_morig, h + mb + sb, ob, hipMemcpyHostToDevice, ctx->stream));
+  if (tb) TSD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_start, h + mb + sb + ob, tb, hipMemcpyHostToDevice, ctx->stream));
   TSD_HIP_CHECK(ctx, hipEventRecord(ctx->stage_ev[s], ctx->stream));
   int rc = launch_icp(ctx, a);
   if (rc != TSD_OK) return rc;
@@ -511,6 +540,8 @@ int tsd_localize(tsd_ctx* ctx, const double pose33[9], const double* rays_world_
   IcpArgs ia;
   fill_icp_args(ia, pose33, params);
   ia.beams = beams;
+  // beam order is counter-clockwise when consecutive local rays turn left (positive angle increment)
+  ia.ccw = (beams < 2) || (rays_local_2xB[0] * rays_local_2xB[nb + 1] - rays_local_2xB[nb] * rays_local_2xB[1] >= 0.0);
   rc = launch_icp(ctx, ia);
   if (rc != TSD_OK) return rc;
   TSD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_icp_res, ctx->d_icp_res, sizeof(IcpResultDev), hipMemcpyDeviceToHost, ctx->stream));

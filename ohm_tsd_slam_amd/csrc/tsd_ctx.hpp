@@ -52,6 +52,8 @@ struct IcpArgs {
   int iterations;
   int n_model, n_scene;      // direct mode
   int beams;                 // fused mode (compaction from per-beam arrays) when > 0
+  int ccw;                   // model slots ascend counter-clockwise about the sensor (1) or clockwise (0)
+  int pad;
 };
 
 struct IcpResultDev {
@@ -103,6 +105,9 @@ struct tsd_ctx {
   uint8_t* d_mask_m = nullptr;   // [TSD_MAX_BEAMS]
   double* d_model = nullptr;     // [2*TSD_MAX_ICP_POINTS]
   double* d_scene = nullptr;     // [2*TSD_MAX_ICP_POINTS]
+  int* d_morig = nullptr;        // [TSD_MAX_ICP_POINTS] original index of every angle-sorted model point
+  int* d_start = nullptr;        // [TSD_MAX_ICP_POINTS] first search slot of every scene point
+  int icp_shape = 0;             // 0 = default workgroup shape (env TSD_ICP_SHAPE for experiments)
   tsd::IcpResultDev* d_icp_res = nullptr;
   double* d_icp_trace = nullptr;            // [TSD_ICP_TRACE_MAX][4]
   tsd::IcpResultDev* h_icp_res = nullptr;    // pinned

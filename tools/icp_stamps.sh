@@ -1,10 +1,10 @@
 #!/bin/bash
 # diagnostic: rebuild icp_kernels with per-phase cycle stamps on the GPU box and print the phase shares
 cd $GRAFT_REPO_ROOT/ohm_tsd_slam_amd/csrc
-hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -I../../include -DTSD_ICP_STAMPS -c icp_kernels.hip -o ../lib/obj/icp_kernels.o
+hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -I../../include -DTSD_ICP_STAMPS $TSD_EXTRA -c icp_kernels.hip -o ../lib/obj/icp_kernels.o
 hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libtsd_hip.so ../lib/obj/*.o
 cd $GRAFT_REPO_ROOT && python3 - <<'PY'
-import numpy as np, sys
+import numpy as np, sys, os
 sys.path.insert(0, '.')
 from oracle import pyoracle as O
 from ohm_tsd_slam_amd import capi, synth
@@ -20,7 +20,11 @@ for rep in range(3):
     ms, n = dg.profile_get("icp")
     tr = np.zeros((256, 4)); dg.lib.tsd_icp_trace(dg.h, tr.ctypes.data_as(capi._dp), 256)
     st = tr.reshape(-1)[-8:]
-    names = ["setup(load+sort)", "A nn", "BC reciprocal", "D sums1", "F sums2+trig", "G transform+ctl"]
-    tot = st.sum()
-    print("kernel ms %.3f" % (ms / n), "cycles total %.0f" % tot, {nm: "%.1f%%" % (100 * c / tot) for nm, c in zip(names, st)}, "nM", len(M), "nS", len(S))
+    names = ["setup", "A nn", "BC reciprocal", "D sums1", "F sums2+trig", "G transform+ctl"]
+    tot = st[:6].sum()
+    print("phase A cycles per step:", np.diff(np.concatenate([[0], tr[:30, 2]])).astype(int).tolist())
+    print("searched points per step:", np.diff(np.concatenate([[0], tr[:30, 1]])).astype(int).tolist())
+    print("searched points total %d, of which whole-wave searches %d" % (st[6], st[7]))
+    print("shape", os.environ.get("TSD_ICP_SHAPE", "0"), "kernel ms %.3f" % (ms / n), "cycles total %.0f" % tot,
+          {nm: "%.0f" % (c / 30) for nm, c in zip(names, st[:6])}, "nM", len(M), "nS", len(S), "pairs", rd.pairs)
 PY
