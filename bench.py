@@ -31,6 +31,29 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 MERGE_EVERY = 50             # occupancy merge period in scans (cfg 4/5)
+CALIB_DOUBLES = 8 << 20      # k_calib_rmw: 2 arrays x 8 Mi doubles -> 128 MiB read + 128 MiB written per launch
+
+
+def pmc_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (profiles/*_pmc.json, newest
+    tag; collected with tools/profile_bench.sh on this same command in separate --pmc passes).  FETCH_SIZE /
+    WRITE_SIZE are KB; they are scaled by the factors the calibration kernel of the same run gives for this
+    8 B/lane access shape (known bytes / reported bytes).  None when no summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), key=os.path.getmtime)
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    k = d["kernels"].get("tsd::" + kernel)
+    if not k or k.get("FETCH_SIZE_KB") is None or k.get("WRITE_SIZE_KB") is None:
+        return None, None
+    fr = fw = 1.0
+    cal = d["kernels"].get("tsd::k_calib_rmw")
+    if cal and cal.get("FETCH_SIZE_KB") and cal.get("WRITE_SIZE_KB"):
+        known = 16.0 * CALIB_DOUBLES
+        fr = known / (cal["FETCH_SIZE_KB"] * 1024.0)
+        fw = known / (cal["WRITE_SIZE_KB"] * 1024.0)
+    return (k["FETCH_SIZE_KB"] * fr + k["WRITE_SIZE_KB"] * fw) * 1024.0, os.path.basename(files[-1])
 
 
 def algorithmic_bytes(st: dict, pushes: int, beams: int) -> float:
@@ -77,7 +100,9 @@ def main():
     ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3"])
     ap.add_argument("--scene", default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-scans", type=int, default=100)
+    ap.add_argument("--cpu-scans", type=int, default=30)
+    ap.add_argument("--calibrate", action="store_true",
+                    help="also launch the PMC calibration kernel (known byte count; used by tools/profile_bench.sh)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -159,12 +184,15 @@ def main():
         ms, n = grid.profile_get(name)
         stages[name] = ms / n if n else None
     grid.profile(False)
+    if args.calibrate:
+        grid.calibrate_rmw(CALIB_DOUBLES, 3)
 
     if rank == 0:
         bytes_total = algorithmic_bytes(st, pushes, geo.beams)
         bytes_per_launch = bytes_total / max(pushes, 1)
         upd_avg_ms = upd_ms / max(upd_launches, 1)
         achieved = bytes_per_launch / (upd_avg_ms * 1e-3) / 1e9 if upd_avg_ms > 0 else 0.0
+        traffic, traffic_src = pmc_traffic("k_push_update") if args.config == "cfg2" and scene == default_scene else (None, None)
         out = {
             "metric": "scans/sec + ms/ICP-iterate, 4096^2 TSD grid, 1081-beam scan" if args.config == "cfg2"
                       else f"scans/sec + ms/ICP-iterate, {gc.cells}^2 TSD grid, {geo.beams}-beam scan",
@@ -181,7 +209,7 @@ def main():
             "tiles_updated_per_push": st["tiles_update"] / max(pushes, 1),
             "tracking_error_m": track_err,
             "roofline": {"kernel": "k_push_update", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": upd_avg_ms,
                          "launches": upd_launches},
         }

@@ -167,6 +167,11 @@ int tsd_profile_select(tsd_ctx* ctx, const char* kernels_csv);
 int tsd_profile_reset(tsd_ctx* ctx);
 int tsd_profile_get(tsd_ctx* ctx, const char* kernel, double* total_ms, int* launches);
 
+/* Counter calibration for profiles/: `reps` launches of k_calib_rmw, a read-modify-write of two arrays
+ * of n_doubles fp64 values with the push kernel's 8-byte-per-lane access shape (known traffic: 16 B read
+ * + 16 B written per element and launch).  Allocates and frees its own scratch. */
+int tsd_calibrate_rmw(tsd_ctx* ctx, int64_t n_doubles, int reps);
+
 /* Sum of the work counters of every push completed on this ctx since the last reset (the numerator of
  * the algorithmic-bytes formula without a host sync per push).  Waits for pushes still in flight. */
 int tsd_push_stats_total(tsd_ctx* ctx, tsd_push_stats* total, int64_t* pushes, int reset);

@@ -103,6 +103,7 @@ ABI = {
     "tsd_download_tile_state": (C.c_int, [C.c_void_p, _u8p, _dp]),
     "tsd_occupancy": (C.c_int, [C.c_void_p, _i8p, C.c_int, C.c_int, _ip]),
     "tsd_occupancy_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "tsd_calibrate_rmw": (C.c_int, [C.c_void_p, C.c_int64, C.c_int]),
     "tsd_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "tsd_profile_select": (C.c_int, [C.c_void_p, C.c_char_p]),
     "tsd_profile_reset": (C.c_int, [C.c_void_p]),
@@ -282,6 +283,9 @@ class TsdGridDevice:
     def occupancy_into(self, dev_ptr: int, inflate=False, inflate_factor=2):
         self._check(self.lib.tsd_occupancy_dev(self.h, C.c_void_p(dev_ptr), int(inflate), inflate_factor),
                     "tsd_occupancy_dev")
+
+    def calibrate_rmw(self, n_doubles: int, reps: int = 3):
+        self._check(self.lib.tsd_calibrate_rmw(self.h, n_doubles, reps), "tsd_calibrate_rmw")
 
     def profile(self, on=True, kernels="all"):
         self.lib.tsd_profile_select(self.h, kernels.encode())

@@ -640,6 +640,23 @@ int tsd_occupancy(tsd_ctx* ctx, int8_t* occ_host, int inflate, int inflate_facto
   return rc;
 }
 
+int tsd_calibrate_rmw(tsd_ctx* ctx, int64_t n_doubles, int reps)
+{
+  if (!ctx || n_doubles <= 0 || reps <= 0) return TSD_E_ARG;
+  TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  double *t = nullptr, *w = nullptr;
+  TSD_HIP_CHECK(ctx, hipMalloc(&t, (size_t)n_doubles * sizeof(double)));
+  hipError_t e = hipMalloc(&w, (size_t)n_doubles * sizeof(double));
+  if (e != hipSuccess) { hipFree(t); return set_error(ctx, TSD_E_HIP, "tsd_calibrate_rmw", e); }
+  hipMemsetAsync(t, 0, (size_t)n_doubles * sizeof(double), ctx->stream);
+  hipMemsetAsync(w, 0, (size_t)n_doubles * sizeof(double), ctx->stream);
+  int rc = TSD_OK;
+  for (int r = 0; r < reps && rc == TSD_OK; r++) rc = launch_calibrate(ctx, t, w, (size_t)n_doubles);
+  hipStreamSynchronize(ctx->stream);
+  hipFree(t); hipFree(w);
+  return rc;
+}
+
 int tsd_profile_enable(tsd_ctx* ctx, int on)
 {
   if (!ctx) return TSD_E_ARG;

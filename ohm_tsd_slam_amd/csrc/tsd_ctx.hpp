@@ -157,6 +157,7 @@ int launch_push(tsd_ctx* ctx, const PushArgs& a);
 int launch_free_footprint(tsd_ctx* ctx, unsigned minX, unsigned maxX, unsigned minY, unsigned maxY);
 int launch_raycast(tsd_ctx* ctx, const RaycastArgs& a);
 int launch_icp(tsd_ctx* ctx, const IcpArgs& a);
+int launch_calibrate(tsd_ctx* ctx, double* t, double* w, size_t n);
 int launch_occupancy(tsd_ctx* ctx, int8_t* d_out, int inflate, int inflate_factor);
 size_t icp_lds_bytes();
 
