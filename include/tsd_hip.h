@@ -134,6 +134,47 @@ int tsd_localize(tsd_ctx* ctx, const double pose33[9], const double* rays_world_
                  double min_range, double max_range, const tsd_icp_params* params,
                  tsd_icp_result* result);
 
+/* ---- fused scan: ThreadLocalize::eventLoop + ThreadMapping push without a host round trip ------------ */
+/* Device-resident mirror of one robot's obvious::SensorPolar2D (pose, world / local ray maps) and of
+ * ThreadLocalize's pose bookkeeping (_lastPose).  Several sensors may share one grid context
+ * (multi-robot mode, SlamNode.cpp:101-122). */
+typedef struct tsd_sensor tsd_sensor;
+
+/* gates of ThreadLocalize: isRegistrationError(T, reg_trs_max, reg_sin_rot_max) (ThreadLocalize.cpp:593-600)
+ * and isPoseChangeSignificant (:728-736) with TRNS_MIN / ROT_MIN (ThreadLocalize.h:63-64) */
+typedef struct {
+  double reg_trs_max, reg_sin_rot_max;
+  double trs_min, rot_min;
+} tsd_gate_params;
+
+typedef struct {
+  tsd_icp_result icp;           /* as tsd_localize */
+  double pose[9];               /* sensor pose after this scan (unchanged on reg_error / no_model) */
+  int32_t reg_error;            /* isRegistrationError: pose kept, caller publishes the NaN pose */
+  int32_t pushed;               /* isPoseChangeSignificant: the scan was integrated into the grid */
+  int32_t no_model;             /* ray cast found no model points: scan skipped (ThreadLocalize.cpp:354-358) */
+  int32_t reserved;
+} tsd_scan_result;
+
+/* new SensorPolar2D(beams, ang_res, phi_min, max_range, min_range, low_refl_range) (ThreadLocalize.cpp:498) */
+tsd_sensor* tsd_sensor_create(tsd_ctx* ctx, int beams, double ang_res, double phi_min, double max_range,
+                              double min_range, double low_refl_range);
+void tsd_sensor_destroy(tsd_sensor* s);
+/* Upload the sensor state after ThreadLocalize::init (pose, Sensor::getNormalizedRayMap(cellSize), local
+ * rays); forgets _lastPose. */
+int tsd_sensor_set_pose(tsd_sensor* s, const double pose33[9], const double* rays_world_2xB,
+                        const double* rays_local_2xB);
+/* One scan: ray cast -> registration -> isRegistrationError -> Sensor::transform ->
+ * isPoseChangeSignificant -> TsdGrid::push, all in stream order on the device (the body of
+ * ThreadLocalize::eventLoop, ThreadLocalize.cpp:353-406, plus ThreadMapping::eventLoop's push,
+ * ThreadMapping.cpp:51-56).  `ranges` / `mask` are the processed scan (setStandardMask), `mask_push` is
+ * the mask of the copy ThreadMapping::queuePush makes (ThreadMapping.cpp:65-76; NULL = same mask).
+ * Returns as soon as the result record is there (the device writes it to pinned host memory right
+ * after the gates); the push of this scan may still be running and is ordered before anything enqueued
+ * later on this context.  tsd_sync() waits for it. */
+int tsd_scan(tsd_sensor* s, const double* ranges, const uint8_t* mask, const uint8_t* mask_push,
+             const tsd_icp_params* params, const tsd_gate_params* gates, tsd_scan_result* result);
+
 /* Per-iteration record of the most recent tsd_icp / tsd_localize on this ctx (the role of
  * Icp::activateTrace, Icp.cpp:60-70): out[4*i + {0,1,2,3}] = pairs, rms, DistanceFilter threshold
  * before the step, state after loop control, for i < min(iterations, max_iters). */
@@ -160,9 +201,10 @@ int tsd_occupancy_dev(tsd_ctx* ctx, void* occ_dev, int inflate, int inflate_fact
 
 /* ---- measurement ----------------------------------------------------------------------------- */
 /* Per-kernel HIP-event timing on the ctx stream.  Kernel names: "push_classify", "push_update",
- * "push_halo", "raycast", "icp", "occupancy". */
+ * "push_halo", "raycast", "icp", "scan_post", "occupancy". */
 int tsd_profile_enable(tsd_ctx* ctx, int on);
-/* restrict timing to a comma separated list of kernel names, or "all" */
+/* restrict timing to a comma separated list of kernel names, or "all"; a "/n" suffix times every n-th
+ * launch only (two event records cost ~13 us of stream time per timed launch) */
 int tsd_profile_select(tsd_ctx* ctx, const char* kernels_csv);
 int tsd_profile_reset(tsd_ctx* ctx);
 int tsd_profile_get(tsd_ctx* ctx, const char* kernel, double* total_ms, int* launches);

@@ -68,6 +68,16 @@ class IcpResult(C.Structure):
     ]
 
 
+class GateParams(C.Structure):
+    _fields_ = [("reg_trs_max", C.c_double), ("reg_sin_rot_max", C.c_double),
+                ("trs_min", C.c_double), ("rot_min", C.c_double)]
+
+
+class ScanResult(C.Structure):
+    _fields_ = [("icp", IcpResult), ("pose", C.c_double * 9), ("reg_error", C.c_int32), ("pushed", C.c_int32),
+                ("no_model", C.c_int32), ("reserved", C.c_int32)]
+
+
 # every symbol include/tsd_hip.h declares: name -> (restype, argtypes)
 _dp = C.POINTER(C.c_double)
 _u8p = C.POINTER(C.c_uint8)
@@ -97,6 +107,11 @@ ABI = {
                           C.POINTER(IcpResult)]),
     "tsd_localize": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _u8p, C.c_int, C.c_double, C.c_double,
                                C.POINTER(IcpParams), C.POINTER(IcpResult)]),
+    "tsd_sensor_create": (C.c_void_p, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "tsd_sensor_destroy": (None, [C.c_void_p]),
+    "tsd_sensor_set_pose": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),
+    "tsd_scan": (C.c_int, [C.c_void_p, _dp, _u8p, _u8p, C.POINTER(IcpParams), C.POINTER(GateParams),
+                           C.POINTER(ScanResult)]),
     "tsd_icp_trace": (C.c_int, [C.c_void_p, _dp, C.c_int]),
     "tsd_download_tiles": (C.c_int, [C.c_void_p, _u8p, _dp, _dp, _dp]),
     "tsd_upload_tiles": (C.c_int, [C.c_void_p, _u8p, _dp, _dp, _dp]),
@@ -305,3 +320,39 @@ class TsdGridDevice:
         n = C.c_int(0)
         self.lib.tsd_profile_get(self.h, kernel.encode(), C.byref(ms), C.byref(n))
         return ms.value, n.value
+
+
+class TsdSensorDevice:
+    """Device-resident ``SensorPolar2D`` + pose bookkeeping of one robot on a grid (fused scan path)."""
+
+    def __init__(self, grid: TsdGridDevice, beams, ang_res, phi_min, max_range, min_range, low_refl):
+        self.grid = grid
+        self.lib = grid.lib
+        self.h = self.lib.tsd_sensor_create(grid.h, beams, ang_res, phi_min, max_range, min_range, low_refl)
+        if not self.h:
+            raise TsdError("tsd_sensor_create failed")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tsd_sensor_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_pose(self, pose, rays_world, rays_local):
+        pose, rw, rl = _f64(pose).reshape(9), _f64(rays_world), _f64(rays_local)
+        self.grid._check(self.lib.tsd_sensor_set_pose(self.h, _d(pose), _d(rw), _d(rl)), "tsd_sensor_set_pose")
+
+    def scan(self, ranges, mask, mask_push, params: IcpParams, gates: GateParams) -> ScanResult:
+        rg = _f64(ranges)
+        mk = np.ascontiguousarray(mask, dtype=np.uint8)
+        mp = np.ascontiguousarray(mask_push, dtype=np.uint8) if mask_push is not None else None
+        r = ScanResult()
+        rc = self.lib.tsd_scan(self.h, _d(rg), _u8(mk), _u8(mp) if mp is not None else None, C.byref(params),
+                               C.byref(gates), C.byref(r))
+        self.grid._check(rc, "tsd_scan")
+        return r

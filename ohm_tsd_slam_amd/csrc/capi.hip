@@ -25,7 +25,7 @@ int set_error(tsd_ctx* ctx, int code, const char* what, hipError_t e)
   return code;
 }
 
-static const char* const kKernelNames[] = {"push_classify", "push_update", "push_halo", "raycast", "icp", "occupancy"};
+static const char* const kKernelNames[] = {"push_classify", "push_update", "push_halo", "raycast", "icp", "occupancy", "scan_post"};
 
 bool kernel_is_timed(const tsd_ctx* ctx, const char* name)
 {
@@ -46,6 +46,7 @@ static hipEvent_t pool_get(tsd_ctx* ctx)
 ScopedKernelTimer::ScopedKernelTimer(tsd_ctx* c, const char* n) : ctx(c), name(n)
 {
   if (!kernel_is_timed(ctx, n)) return;
+  if (ctx->profile_every > 1 && (ctx->profile_tick++ % ctx->profile_every) != 0) return;
   a = pool_get(ctx); b = pool_get(ctx);
   if (!a || !b) { a = b = nullptr; return; }
   hipEventRecord(a, ctx->stream);
@@ -69,31 +70,6 @@ void drain_timers(tsd_ctx* ctx)
       ctx->event_pool.push_back(pr.second);
     }
     kv.second.pending.clear();
-  }
-}
-
-static void add_counters(tsd_push_stats& t, const PushCounters& c)
-{
-  t.cells_updated += (int64_t)c.cells_updated;
-  t.cells_visited += (int64_t)c.cells_visited;
-  t.tiles_range_pass += c.tiles_range_pass;
-  t.tiles_update += c.tiles_update;
-  t.tiles_new += c.tiles_new;
-  t.tiles_new_from_empty += c.tiles_new_from_empty;
-  t.tiles_emptied_init += c.tiles_emptied_init;
-  t.tiles_emptied_uninit += c.tiles_emptied_uninit;
-}
-
-// fold finished ring slots into the running totals
-void harvest_push_stats(tsd_ctx* ctx, bool wait)
-{
-  for (int s = 0; s < tsd_ctx::kStatSlots; s++) {
-    if (!ctx->stat_pending[s]) continue;
-    if (wait) hipEventSynchronize(ctx->stat_ev[s]);
-    else if (hipEventQuery(ctx->stat_ev[s]) != hipSuccess) continue;
-    add_counters(ctx->stat_total, ctx->h_stat_ring[s]);
-    ctx->stat_pushes++;
-    ctx->stat_pending[s] = false;
   }
 }
 
@@ -245,8 +221,7 @@ tsd_ctx* tsd_create(int device, int map_size_log2, double cell_size, double max_
   A(hipMalloc(&ctx->d_dirty_count, sizeof(int)));
   A(hipHostMalloc(&ctx->h_dirty, ((size_t)ctx->dirty_cap + 1) * sizeof(uint32_t), hipHostMallocDefault));
   A(hipHostMalloc(&ctx->h_counters, sizeof(PushCounters), hipHostMallocDefault));
-  A(hipHostMalloc(&ctx->h_stat_ring, sizeof(PushCounters) * tsd_ctx::kStatSlots, hipHostMallocDefault));
-  for (int s = 0; s < tsd_ctx::kStatSlots; s++) A(hipEventCreateWithFlags(&ctx->stat_ev[s], hipEventDisableTiming));
+  A(hipMalloc(&ctx->d_stat_total, 2 * sizeof(PushCounters)));
   ctx->stage_bytes = (size_t)TSD_MAX_BEAMS * (8 * 5 + 1) + 256;   // ranges + 2x rays(2) + mask; >= icp staging (80 KB)
   for (int s = 0; s < tsd_ctx::kSlots; s++) {
     A(hipHostMalloc(&ctx->h_stage[s], ctx->stage_bytes, hipHostMallocDefault));
@@ -285,8 +260,7 @@ void tsd_destroy(tsd_ctx* ctx)
   GridDev& g = ctx->grid;
   hipFree(g.flags); hipFree(g.init_weight); hipFree(g.tsd); hipFree(g.weight);
   hipFree(ctx->d_counters); hipFree(ctx->d_list); hipFree(ctx->d_entry_upd); hipFree(ctx->d_block_stats); hipFree(ctx->d_dirty); hipFree(ctx->d_dirty_count);
-  hipHostFree(ctx->h_dirty); hipHostFree(ctx->h_counters); hipHostFree(ctx->h_stat_ring);
-  for (int s = 0; s < tsd_ctx::kStatSlots; s++) if (ctx->stat_ev[s]) hipEventDestroy(ctx->stat_ev[s]);
+  hipHostFree(ctx->h_dirty); hipHostFree(ctx->h_counters); hipFree(ctx->d_stat_total);
   for (hipEvent_t e : ctx->event_pool) hipEventDestroy(e);
   for (int s = 0; s < tsd_ctx::kSlots; s++) {
     if (ctx->h_stage[s]) hipHostFree(ctx->h_stage[s]);
@@ -310,6 +284,7 @@ int tsd_reset(tsd_ctx* ctx)
   TSD_HIP_CHECK(ctx, hipMemsetAsync(g.flags, 0, T, ctx->stream));
   TSD_HIP_CHECK(ctx, hipMemsetAsync(g.init_weight, 0, T * sizeof(double), ctx->stream));
   TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_counters, 0, 2 * sizeof(PushCounters), ctx->stream));
+  TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_stat_total, 0, 2 * sizeof(PushCounters), ctx->stream));
   TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_dirty_count, 0, sizeof(int), ctx->stream));
   TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_occ, 0xFF, (size_t)g.N * g.N, ctx->stream));   // -1 (ThreadGrid.cpp:27-28)
   ctx->epoch = 0;
@@ -379,7 +354,7 @@ int tsd_push(tsd_ctx* ctx, const double pose33[9], const double* ranges, const u
   a.phi_lower = -0.5 * ang_res + phi_min;                    // SensorPolar2D.cpp:26-30
   a.phi_upper = phi_min + (((double)beams) - 0.5) * ang_res;
   a.max_range = max_range; a.min_range = min_range; a.low_refl = low_refl_range;
-  a.beams = beams; a.pad = 0;
+  a.beams = beams; a.enabled = 1;
 
   int s;
   char* h = stage_acquire(ctx, &s);
@@ -392,15 +367,6 @@ int tsd_push(tsd_ctx* ctx, const double pose33[9], const double* ranges, const u
   const uint32_t epoch = ctx->epoch;
   int rc = launch_push(ctx, a);
   if (rc != TSD_OK) return rc;
-  {
-    // running totals for the roofline numerator: async copy of this push's counters into a ring slot
-    const int rs = (int)(epoch % tsd_ctx::kStatSlots);
-    if (ctx->stat_pending[rs]) { hipEventSynchronize(ctx->stat_ev[rs]); harvest_push_stats(ctx, false); }
-    TSD_HIP_CHECK(ctx, hipMemcpyAsync(&ctx->h_stat_ring[rs], ctx->d_counters + (epoch & 1u), sizeof(PushCounters),
-                                      hipMemcpyDeviceToHost, ctx->stream));
-    TSD_HIP_CHECK(ctx, hipEventRecord(ctx->stat_ev[rs], ctx->stream));
-    ctx->stat_pending[rs] = true;
-  }
   if (stats) {
     TSD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters + (epoch & 1u), sizeof(PushCounters),
                                       hipMemcpyDeviceToHost, ctx->stream));
@@ -669,7 +635,14 @@ int tsd_profile_select(tsd_ctx* ctx, const char* kernels_csv)
 {
   if (!ctx || !kernels_csv) return TSD_E_ARG;
   unsigned mask = 0;
-  const std::string csv(kernels_csv);
+  std::string csv(kernels_csv);
+  ctx->profile_every = 1; ctx->profile_tick = 0;
+  const size_t slash = csv.find('/');          // "names/n": time every n-th launch only
+  if (slash != std::string::npos) {
+    const int n = std::atoi(csv.c_str() + slash + 1);
+    ctx->profile_every = n > 1 ? (unsigned)n : 1u;
+    csv = csv.substr(0, slash);
+  }
   for (unsigned i = 0; i < sizeof(kKernelNames) / sizeof(kKernelNames[0]); i++)
     if (csv == "all" || ("," + csv + ",").find(std::string(",") + kKernelNames[i] + ",") != std::string::npos) mask |= 1u << i;
   ctx->profile_mask = mask;
@@ -700,10 +673,153 @@ int tsd_push_stats_total(tsd_ctx* ctx, tsd_push_stats* total, int64_t* pushes, i
 {
   if (!ctx) return TSD_E_ARG;
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  harvest_push_stats(ctx, true);
-  if (total) { *total = ctx->stat_total; total->tiles_total = ctx->grid.tiles; }
-  if (pushes) *pushes = ctx->stat_pushes;
-  if (reset) { ctx->stat_total = tsd_push_stats{}; ctx->stat_pushes = 0; }
+  PushCounters h[2];
+  TSD_HIP_CHECK(ctx, hipMemcpyAsync(h, ctx->d_stat_total, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  if (reset) TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_stat_total, 0, sizeof(h), ctx->stream));
+  TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (total) {
+    total->cells_updated = (int64_t)h[0].cells_updated; total->cells_visited = (int64_t)h[0].cells_visited;
+    total->tiles_total = ctx->grid.tiles;
+    total->tiles_range_pass = h[0].tiles_range_pass; total->tiles_update = h[0].tiles_update;
+    total->tiles_new = h[0].tiles_new; total->tiles_new_from_empty = h[0].tiles_new_from_empty;
+    total->tiles_emptied_init = h[0].tiles_emptied_init; total->tiles_emptied_uninit = h[0].tiles_emptied_uninit;
+  }
+  if (pushes) *pushes = h[1].list_count;
+  return TSD_OK;
+}
+
+// ---------------------------------------------------------------------------------- fused scan path
+tsd_sensor* tsd_sensor_create(tsd_ctx* ctx, int beams, double ang_res, double phi_min, double max_range,
+                              double min_range, double low_refl_range)
+{
+  if (!ctx || beams < 1 || beams > TSD_MAX_BEAMS || beams > TSD_MAX_ICP_POINTS) return nullptr;
+  if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+  tsd_sensor* s = new (std::nothrow) tsd_sensor();
+  if (!s) return nullptr;
+  s->ctx = ctx; s->beams = beams; s->ang_res = ang_res; s->phi_min = phi_min;
+  s->max_range = max_range; s->min_range = min_range; s->low_refl = low_refl_range;
+  bool ok = true;
+  auto A = [&](hipError_t e) { if (e != hipSuccess) ok = false; };
+  const size_t nb = (size_t)beams;
+  A(hipMalloc(&s->d_state, sizeof(SensorDev)));
+  A(hipMalloc(&s->d_rays, nb * 16));
+  A(hipMalloc(&s->d_rays_local, nb * 16));
+  A(hipMalloc(&s->d_scan, nb * 10 + 64));
+  // the scan result is written by the kernel straight into coherent pinned host memory
+  A(hipHostMalloc(&s->h_result, sizeof(ScanResultDev), hipHostMallocMapped | hipHostMallocCoherent));
+  if (ok) { std::memset(s->h_result, 0, sizeof(ScanResultDev)); A(hipHostGetDevicePointer((void**)&s->d_result, s->h_result, 0)); }
+  if (!ok) { tsd_sensor_destroy(s); return nullptr; }
+  return s;
+}
+
+void tsd_sensor_destroy(tsd_sensor* s)
+{
+  if (!s) return;
+  if (s->ctx) { hipSetDevice(s->ctx->device); hipStreamSynchronize(s->ctx->stream); }
+  hipFree(s->d_state); hipFree(s->d_rays); hipFree(s->d_rays_local); hipFree(s->d_scan);
+  hipHostFree(s->h_result);
+  delete s;
+}
+
+int tsd_sensor_set_pose(tsd_sensor* s, const double pose33[9], const double* rays_world_2xB,
+                        const double* rays_local_2xB)
+{
+  if (!s || !pose33 || !rays_world_2xB || !rays_local_2xB) return TSD_E_ARG;
+  tsd_ctx* ctx = s->ctx;
+  TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const size_t nb = (size_t)s->beams;
+  SensorDev st;
+  std::memset(&st, 0, sizeof(st));
+  for (int i = 0; i < 9; i++) st.pose[i] = pose33[i];
+  st.have_last_pose = 0;
+  // constant parts of the kernel arguments (the pose dependent parts are derived on the device)
+  st.rc.idx_min = s->min_range / ctx->grid.cs;
+  st.rc.idx_max = s->max_range / ctx->grid.cs;
+  st.rc.beams = s->beams;
+  st.push.phi_min = s->phi_min; st.push.ang_res_inv = 1.0 / s->ang_res;
+  st.push.phi_lower = -0.5 * s->ang_res + s->phi_min;                    // SensorPolar2D.cpp:26-30
+  st.push.phi_upper = s->phi_min + (((double)s->beams) - 0.5) * s->ang_res;
+  st.push.max_range = s->max_range; st.push.min_range = s->min_range; st.push.low_refl = s->low_refl;
+  st.push.beams = s->beams; st.push.enabled = 0;
+  s->ccw = (s->beams < 2) || (rays_local_2xB[0] * rays_local_2xB[nb + 1] - rays_local_2xB[nb] * rays_local_2xB[1] >= 0.0);
+  int slot;
+  char* h = stage_acquire(ctx, &slot);
+  if (nb * 32 + sizeof(SensorDev) > ctx->stage_bytes) return set_error(ctx, TSD_E_CAPACITY, "sensor staging", hipSuccess);
+  std::memcpy(h, rays_world_2xB, nb * 16);
+  std::memcpy(h + nb * 16, rays_local_2xB, nb * 16);
+  std::memcpy(h + nb * 32, &st, sizeof(SensorDev));
+  TSD_HIP_CHECK(ctx, hipMemcpyAsync(s->d_rays, h, nb * 16, hipMemcpyHostToDevice, ctx->stream));
+  TSD_HIP_CHECK(ctx, hipMemcpyAsync(s->d_rays_local, h + nb * 16, nb * 16, hipMemcpyHostToDevice, ctx->stream));
+  TSD_HIP_CHECK(ctx, hipMemcpyAsync(s->d_state, h + nb * 32, sizeof(SensorDev), hipMemcpyHostToDevice, ctx->stream));
+  TSD_HIP_CHECK(ctx, hipEventRecord(ctx->stage_ev[slot], ctx->stream));
+  int rc = launch_scan_prepare(ctx, s->d_state);
+  if (rc != TSD_OK) return rc;
+  s->posed = true;
+  return TSD_OK;
+}
+
+int tsd_scan(tsd_sensor* s, const double* ranges, const uint8_t* mask, const uint8_t* mask_push,
+             const tsd_icp_params* params, const tsd_gate_params* gates, tsd_scan_result* result)
+{
+  if (!s || !ranges || !mask || !params || !gates || !result) return TSD_E_ARG;
+  tsd_ctx* ctx = s->ctx;
+  if (!s->posed) return set_error(ctx, TSD_E_ARG, "tsd_scan before tsd_sensor_set_pose", hipSuccess);
+  TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const size_t nb = (size_t)s->beams;
+  // one H2D: ranges | mask | mask_push
+  int slot;
+  char* h = stage_acquire(ctx, &slot);
+  std::memcpy(h, ranges, nb * 8);
+  std::memcpy(h + nb * 8, mask, nb);
+  std::memcpy(h + nb * 9, mask_push ? mask_push : mask, nb);
+  TSD_HIP_CHECK(ctx, hipMemcpyAsync(s->d_scan, h, nb * 10, hipMemcpyHostToDevice, ctx->stream));
+  TSD_HIP_CHECK(ctx, hipEventRecord(ctx->stage_ev[slot], ctx->stream));
+  const double* d_ranges = reinterpret_cast<const double*>(s->d_scan);
+  const uint8_t* d_mask = reinterpret_cast<const uint8_t*>(s->d_scan + nb * 8);
+  const uint8_t* d_mask_push = reinterpret_cast<const uint8_t*>(s->d_scan + nb * 9);
+
+  RaycastArgs ra;
+  std::memset(&ra, 0, sizeof(ra));
+  ra.beams = s->beams;                                   // grid size of the launch; the rest is read on the device
+  int rc = launch_raycast(ctx, ra, &s->d_state->rc, s->d_rays);
+  if (rc != TSD_OK) return rc;
+  IcpArgs ia;
+  const double ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  fill_icp_args(ia, ident, params);
+  ia.beams = s->beams; ia.ccw = s->ccw ? 1 : 0;
+  rc = launch_icp(ctx, ia, s->d_state->icpP, s->d_rays_local, d_ranges, d_mask);
+  if (rc != TSD_OK) return rc;
+  GateArgs ga{gates->reg_trs_max, gates->reg_sin_rot_max, gates->trs_min, gates->rot_min};
+  const unsigned long long seq = ++s->seq;
+  rc = launch_scan_post(ctx, s->d_state, s->d_rays, s->beams, ga, s->d_result, seq);
+  if (rc != TSD_OK) return rc;
+  PushArgs pa;
+  std::memset(&pa, 0, sizeof(pa));
+  pa.beams = s->beams;                                   // LDS size of the launch
+  rc = launch_push(ctx, pa, &s->d_state->push, d_ranges, d_mask_push);
+  if (rc != TSD_OK) return rc;
+  // The result is known once k_scan_post has run; the push kernels behind it only touch the grid, and
+  // whatever the caller enqueues next is ordered behind them on the stream.  So the host does not wait for
+  // the stream: it polls the sequence number and prepares the next scan while the push is still running.
+  {
+    volatile unsigned long long* vseq = &s->h_result->seq;
+    unsigned long long spins = 0;
+    while (__atomic_load_n(vseq, __ATOMIC_ACQUIRE) != seq) {
+      if (++spins > 2000000ull) {          // ~ a second: something is wrong, fall back to a real wait
+        TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (__atomic_load_n(vseq, __ATOMIC_ACQUIRE) != seq)
+          return set_error(ctx, TSD_E_HIP, "tsd_scan: result record never arrived", hipSuccess);
+        break;
+      }
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
+  }
+  copy_icp_result(&s->h_result->icp, &result->icp);
+  for (int i = 0; i < 9; i++) result->pose[i] = s->h_result->pose[i];
+  result->reg_error = s->h_result->reg_error; result->pushed = s->h_result->pushed;
+  result->no_model = s->h_result->no_model; result->reserved = 0;
   return TSD_OK;
 }
 

@@ -42,6 +42,7 @@ ThreadLocalize::ThreadLocalize(obvious::TsdGrid* grid, ThreadMapping* mapper, co
     _sensor(nullptr),
     _initialized(false),
     _synchronous(false),
+    _fused(true),
     _gridWidth(grid->getCellsX() * grid->getCellSize()),
     _gridHeight(grid->getCellsY() * grid->getCellSize()),
     _gridOffSetX(-(grid->getCellsX() * grid->getCellSize() * 0.5 + xOffset)),
@@ -192,6 +193,12 @@ void ThreadLocalize::processScan(const std::vector<float>& ranges, const builtin
     _haveLastPose = true;
   }
 
+  if(_fused && _sensor->deviceHandle())
+  {
+    processScanFused(rep);
+    return;
+  }
+
   // reconstruction + registration on the device (ThreadLocalize.cpp:353-377)
   tsd_icp_result res;
   std::memset(&res, 0, sizeof(res));
@@ -247,6 +254,60 @@ void ThreadLocalize::processScan(const std::vector<float>& ranges, const builtin
   _report = rep; _processed++;
 }
 
+// The event-loop body with the device doing everything between scan ingest and pose publication
+// (tsd_scan): ray cast, registration, isRegistrationError, Sensor::transform, isPoseChangeSignificant and
+// the push that the mapping thread would do, in stream order.  The host sensor is kept as a mirror.
+void ThreadLocalize::processScanFused(ScanReport& rep)
+{
+  // mask of the copy ThreadMapping::queuePush would make (ThreadMapping.cpp:65-76, Appendix B #20)
+  std::vector<uint8_t> maskPush;
+  _sensor->maskForMapping(maskPush);
+  tsd_gate_params gates = {_trnsMax, _rotMax, TRNS_MIN, ROT_MIN};
+  tsd_scan_result sr;
+  std::memset(&sr, 0, sizeof(sr));
+  const int rc = _grid.scan(_sensor, maskPush.data(), _icpParams, gates, &sr);
+  _sensor->getTransformation().getData(rep.pose);
+  if(rc != TSD_OK)
+  {
+    std::fprintf(stderr, "Localizer(%s) device error %d\n", _nameSpace.c_str(), rc);
+    std::lock_guard<std::mutex> lk(_reportMutex);
+    _report = rep; _processed++;
+    return;
+  }
+  rep.validModel = sr.icp.n_model; rep.validScene = sr.icp.n_scene;
+  if(sr.no_model)
+  {
+    rep.noModel = true;
+    std::lock_guard<std::mutex> lk(_reportMutex);
+    _report = rep; _processed++;
+    return;
+  }
+  obvious::Matrix T(3, 3, sr.icp.T);
+  std::memcpy(rep.T, sr.icp.T, sizeof(rep.T));
+  rep.rms = sr.icp.rms; rep.pairs = sr.icp.pairs; rep.iterations = sr.icp.iterations; rep.icpState = sr.icp.state;
+  if(sr.reg_error)
+  {
+    rep.regError = true;
+    sendNanTransform();
+  }
+  else
+  {
+    _sensor->transform(&T);                          // host mirror: same arithmetic as the device
+    obvious::Matrix devPose(3, 3, sr.pose);
+    _sensor->setTransformation(devPose);             // the device pose is the authoritative one
+    obvious::Matrix curPose = _sensor->getTransformation();
+    curPose.getData(rep.pose);
+    sendTransform(&curPose);
+    if(sr.pushed)
+    {
+      *_lastPose = curPose;
+      rep.pushed = true;
+    }
+  }
+  std::lock_guard<std::mutex> lk(_reportMutex);
+  _report = rep; _processed++;
+}
+
 void ThreadLocalize::init(const sensor_msgs::msg::LaserScan& scan)
 {
   // per-robot parameters (ThreadLocalize.cpp:424-442)
@@ -292,6 +353,8 @@ void ThreadLocalize::init(const sensor_msgs::msg::LaserScan& scan)
     _mapper.initPush(_sensor);
     pushed = true;
   }
+  if(_fused && _grid.attachSensor(_sensor) != TSD_OK)
+    std::fprintf(stderr, "Localizer (%s): no device sensor, using the unfused path\n", _nameSpace.c_str());
   _initialized = true;
   {
     std::lock_guard<std::mutex> lk(_reportMutex);

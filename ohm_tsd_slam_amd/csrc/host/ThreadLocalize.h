@@ -39,6 +39,9 @@ public:
   /** run the event-loop body on the caller's thread and push in stream order instead of handing
    *  over to the two worker threads: the strict R -> I -> P order the parity tests need */
   void setSynchronous(bool on) { _synchronous = on; }
+  /** fused scan path (default): sensor state on the device, gates + push decided there in stream
+   *  order (tsd_scan).  Off: tsd_localize, host gates, ThreadMapping::queuePush as in the reference. */
+  void setFused(bool on) { _fused = on; }
   struct ScanReport {
     double pose[9]; double T[9]; double rms; int pairs; int iterations; int icpState;
     int validModel; int validScene; bool regError; bool pushed; bool noModel; bool initialised;
@@ -62,6 +65,7 @@ protected:
 private:
   void init(const sensor_msgs::msg::LaserScan& scan);
   void processScan(const std::vector<float>& rangesIn, const builtin_interfaces::msg::Time& stamp);
+  void processScanFused(ScanReport& rep);
   void sendTransform(obvious::Matrix* T);
   void sendNanTransform();
 
@@ -70,6 +74,7 @@ private:
   obvious::SensorPolar2D* _sensor;
   bool _initialized;
   bool _synchronous;
+  bool _fused;
   const double _gridWidth, _gridHeight, _gridOffSetX, _gridOffSetY, _xOffset, _yOffset;
   std::string _robotName, _nameSpace;
   std::string _tfMapFrameId, _tfOdomFrameId, _tfLaserFrameId, _tfFootprintFrameId;

@@ -19,6 +19,7 @@ struct tsd_node
   std::vector<ThreadLocalize*> localizers;
   std::vector<uint64_t> submitted;
   bool synchronous = false;
+  bool fused = true;
 };
 
 extern "C" {
@@ -79,8 +80,19 @@ int tsd_node_initialize(tsd_node* n, int device)
   }
   n->submitted.assign(n->localizers.size(), 0);
   for(auto* l : n->localizers)
+  {
     l->setSynchronous(n->synchronous);
+    l->setFused(n->fused);
+  }
   return TSD_OK;
+}
+
+// before the first scan: choose the fused device scan (default) or the reference's three-call flow
+void tsd_node_set_fused(tsd_node* n, int on)
+{
+  n->fused = on != 0;
+  for(auto* l : n->localizers)
+    l->setFused(n->fused);
 }
 
 void tsd_node_set_synchronous(tsd_node* n, int on)
@@ -187,6 +199,14 @@ void tsd_host_sensor_ingest_f32(const float* ranges, int n, double ang_res, doub
   obvious::SensorPolar2D s((unsigned)n, ang_res, phi_min, max_range, 0.001, 2.0);
   s.setRealMeasurementData(std::vector<float>(ranges, ranges + n));
   s.setStandardMask();
+  if(remask == 2)   // the shortcut the fused scan path uses
+  {
+    std::vector<uint8_t> m;
+    s.maskForMapping(m);
+    std::memcpy(data_out, s.getRealMeasurementData(), sizeof(double) * (size_t)n);
+    std::memcpy(mask_out, m.data(), (size_t)n);
+    return;
+  }
   if(remask)
   {
     std::unique_ptr<obvious::SensorPolar2D> c(s.copyForMapping());

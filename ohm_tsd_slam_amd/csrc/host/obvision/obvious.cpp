@@ -121,30 +121,48 @@ void SensorPolar2D::maskZeroDepth()
 
 void SensorPolar2D::maskInvalidDepth()
 {
+  _nanBeams.clear();
   for (unsigned int i = 0; i < _size; i++) {
     if (_data[i] > _maxRange) _data[i] = INFINITY;
-    if (std::isnan(_data[i])) { _mask[i] = 0; _data[i] = INFINITY; }
+    if (std::isnan(_data[i])) { _mask[i] = 0; _data[i] = INFINITY; _nanBeams.push_back(i); }
   }
+}
+
+// The mask ThreadMapping::queuePush's copy ends up with (ThreadMapping.cpp:65-76): setStandardMask() is
+// run again on the PROCESSED ranges.  Zero and over-range readings and every depth discontinuity come
+// out as before (same data); only a former NaN reading, +inf by now, is no longer masked (Appendix B #20).
+// copyForMapping() does the two passes literally; this is its result without the second pass.
+void SensorPolar2D::maskForMapping(std::vector<uint8_t>& out) const
+{
+  out = _mask;
+  for (unsigned int i : _nanBeams) out[i] = 1;
 }
 
 void SensorPolar2D::maskDepthDiscontinuity(double thresh)
 {
+  // Reference loop (SensorPolar2D.cpp:67-98): betamin = min over the neighbours j in {-1,0,+1} with a > b
+  // of asin(b / c * sin(res)), c = sqrt(a^2 + b^2 - 2ab cos(res)); mask if betamin < thresh.  Only j = -1
+  // and j = +1 can have a > b, and min(asin) < thresh <=> some asin(v) < thresh.  asin is monotone, so v is
+  // first compared with sin(thresh) widened by 1e-12: outside that band the libm call cannot change the
+  // decision and is skipped (this loop is the whole per-scan host cost of the ingest).
   const int radius = 1;
   const double cosphi = std::cos(_angularRes), sinphi = std::sin(_angularRes);
+  const double sv = std::sin(thresh), svLo = sv * (1.0 - 1e-12), svHi = sv * (1.0 + 1e-12);
+  const bool fastOk = thresh > 0.0 && thresh < 1.5;
   for (int i = radius; i < ((int)_size) - radius; i++) {
-    double betamin = M_PI;
     const double a = _data[i];
     if (std::isinf(a)) continue;
-    for (int j = -radius; j <= radius; j++) {
+    bool hit = false;
+    for (int j = -radius; j <= radius && !hit; j += 2) {
       const double b = _data[i + j];
-      if (std::isinf(b)) continue;
+      if (std::isinf(b) || !(a > b)) continue;
       const double c = std::sqrt(a * a + b * b - 2 * a * b * cosphi);   // law of cosines
-      if (a > b) {
-        const double beta = std::asin(b / c * sinphi);                   // law of sines
-        if (beta < betamin) betamin = beta;
-      }
+      const double v = b / c * sinphi;                                   // law of sines
+      if (fastOk && v < svLo && v >= 0.0) hit = true;
+      else if (fastOk && v > svHi) hit = false;
+      else hit = std::asin(v) < thresh;
     }
-    if (betamin < thresh) _mask[i] = 0;
+    if (hit) _mask[i] = 0;
   }
 }
 
@@ -204,9 +222,12 @@ int SensorPolar2D::backProject(double data[2])
 
 SensorPolar2D* SensorPolar2D::copyForMapping() const
 {
-  SensorPolar2D* c = new SensorPolar2D(_size, _angularRes, _phiMin, _maxRange, _minRange, _lowReflectivityRange);
-  c->_T = _T;
-  c->setRealMeasurementData(_data.data());
+  // same geometry, pose and PROCESSED ranges (the reference constructs a fresh sensor and copies them;
+  // cloning skips recomputing the 2 x size ray table, which costs more than the masking itself)
+  SensorPolar2D* c = new SensorPolar2D(*this);
+  c->_dev = nullptr;        // the device twin stays with the original
+  c->_rays = c->_raysLocal; // a fresh sensor's rays: untransformed, norm 1 (unused by push)
+  c->_rayNorm = 1.0;
   c->setStandardMask();     // a former NaN reading is +inf by now and becomes valid-infinite (Appendix B #20)
   return c;
 }
@@ -271,6 +292,32 @@ int TsdGrid::localize(SensorPolar2D* sensor, const tsd_icp_params& params, tsd_i
   return tsd_localize(_ctx, pose, rays, sensor->getLocalRayMap(), sensor->getRealMeasurementData(),
                       sensor->maskBytes(), (int)sensor->getRealMeasurementSize(),
                       sensor->getMinimumRange(), sensor->getMaximumRange(), &params, result);
+}
+
+int TsdGrid::attachSensor(SensorPolar2D* sensor)
+{
+  double pose[9];
+  sensor->getTransformation().getData(pose);
+  const double* rays = sensor->getNormalizedRayMap(getCellSize());   // RayCastPolar2D.cpp:122
+  std::lock_guard<std::mutex> lk(_mutex);
+  if (!sensor->deviceHandle()) {
+    tsd_sensor* h = tsd_sensor_create(_ctx, (int)sensor->getRealMeasurementSize(), sensor->getAngularResolution(),
+                                      sensor->getPhiMin(), sensor->getMaximumRange(), sensor->getMinimumRange(),
+                                      sensor->getLowReflectivityRange());
+    if (!h) return TSD_E_HIP;
+    sensor->setDeviceHandle(h);
+  }
+  return tsd_sensor_set_pose(sensor->deviceHandle(), pose, rays, sensor->getLocalRayMap());
+}
+
+int TsdGrid::scan(SensorPolar2D* sensor, const uint8_t* maskPush, const tsd_icp_params& params,
+                  const tsd_gate_params& gates, tsd_scan_result* result)
+{
+  std::lock_guard<std::mutex> lk(_mutex);
+  const int rc = tsd_scan(sensor->deviceHandle(), sensor->getRealMeasurementData(), sensor->maskBytes(), maskPush,
+                          &params, &gates, result);
+  if (rc == TSD_OK && result->pushed) _initialPushAccomplished = true;
+  return rc;
 }
 
 }  // namespace obvious

@@ -45,8 +45,6 @@ class SensorPolar2D
 public:
   SensorPolar2D(unsigned int size, double angularRes, double phiMin, double maxRange = INFINITY,
                 double minRange = 0.0, double lowReflectivityRange = INFINITY);
-  ~SensorPolar2D() = default;
-
   void setRealMeasurementData(const std::vector<float>& data, float scale = 1.f);   // Sensor.cpp:136-145
   void setRealMeasurementData(const double* data, double scale = 1.0);              // Sensor.cpp:125-134
   double* getRealMeasurementData() { return _data.data(); }
@@ -78,8 +76,18 @@ public:
   /** the deep copy ThreadMapping::queuePush hands to the mapping thread (ThreadMapping.cpp:65-76):
    *  same geometry and pose, the PROCESSED ranges, mask rebuilt by setStandardMask() */
   SensorPolar2D* copyForMapping() const;
+  /** mask of that copy without building it */
+  void maskForMapping(std::vector<uint8_t>& out) const;
+
+  // device-resident twin of this sensor on a grid context (fused scan path); owned by the sensor
+  tsd_sensor* deviceHandle() const { return _dev; }
+  void setDeviceHandle(tsd_sensor* h) { _dev = h; }
+  ~SensorPolar2D() { if (_dev) tsd_sensor_destroy(_dev); }
+  SensorPolar2D(const SensorPolar2D&) = default;
+  SensorPolar2D& operator=(const SensorPolar2D&) = delete;
 
 private:
+  tsd_sensor* _dev = nullptr;
   unsigned int _size;
   double _angularRes, _phiMin, _phiLowerBound, _phiUpperBound;
   double _maxRange, _minRange, _lowReflectivityRange;
@@ -87,6 +95,7 @@ private:
   Matrix _T;
   std::vector<double> _data;
   std::vector<uint8_t> _mask;
+  std::vector<unsigned int> _nanBeams;   // readings that were NaN when the mask was built
   std::vector<double> _rays, _raysLocal;
 };
 
@@ -123,6 +132,12 @@ public:
 
   // ThreadLocalize's ray cast + registration, fused on the device (tsd_localize)
   virtual int localize(SensorPolar2D* sensor, const tsd_icp_params& params, tsd_icp_result* result);
+
+  // fused scan path: the sensor's pose / ray maps live on the device next to the grid, one call runs
+  // ray cast -> registration -> gates -> Sensor::transform -> push in stream order (tsd_scan)
+  virtual int attachSensor(SensorPolar2D* sensor);
+  virtual int scan(SensorPolar2D* sensor, const uint8_t* maskPush, const tsd_icp_params& params,
+                   const tsd_gate_params& gates, tsd_scan_result* result);
 
   tsd_ctx* context() { return _ctx; }
   std::mutex& mutex() { return _mutex; }

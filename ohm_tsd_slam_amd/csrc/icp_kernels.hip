@@ -249,7 +249,7 @@ __device__ __forceinline__ NnResult wave_search(const IcpLds& L, int nM, double 
 
 template <int R, int MAXT>
 __global__ void __launch_bounds__(MAXT)
-k_icp(IcpArgs a, int cap, const double* __restrict__ g_model, const double* __restrict__ g_scene,
+k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __restrict__ g_model, const double* __restrict__ g_scene,
       const int* __restrict__ g_morig, const int* __restrict__ g_start,
       const double* __restrict__ g_coords, const uint8_t* __restrict__ g_mask_m,
       const double* __restrict__ g_rays_local, const double* __restrict__ g_ranges,
@@ -279,6 +279,10 @@ k_icp(IcpArgs a, int cap, const double* __restrict__ g_model, const double* __re
     L.ired = reinterpret_cast<int*>(p);
   }
 
+  if (P_dev) {   // fused scan: the pre-registration sensor pose lives on the device
+#pragma unroll
+    for (int i = 0; i < 6; i++) a.P[i] = P_dev[i];
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int T = blockDim.x, W = T >> 6;
   int nM = 0, nS = 0;
@@ -663,7 +667,8 @@ static int icp_cap_for(int n)
 // workgroup shape: R scene points per thread, T threads.  One CU runs the whole registration and is
 // issue bound, so few waves (per-wave reduction / control cost paid once per SIMD) win.
 template <int R, int MAXT>
-static int launch_icp_shape(tsd_ctx* ctx, const IcpArgs& a, int n, int cap, size_t lds)
+static int launch_icp_shape(tsd_ctx* ctx, const IcpArgs& a, int n, int cap, size_t lds, const double* P_dev,
+                            const double* d_rays_local, const double* d_ranges, const uint8_t* d_mask)
 {
   int T = ((n + R - 1) / R + 63) & ~63;
   if (T < 64) T = 64;
@@ -675,14 +680,16 @@ static int launch_icp_shape(tsd_ctx* ctx, const IcpArgs& a, int n, int cap, size
     configured = lds;
   }
   ScopedKernelTimer t(ctx, "icp");
-  hipLaunchKernelGGL((k_icp<R, MAXT>), dim3(1), dim3(T), lds, ctx->stream, a, cap, ctx->d_model, ctx->d_scene,
-                     ctx->d_morig, ctx->d_start, ctx->d_coords, ctx->d_mask_m, ctx->d_rays_local,
-                     ctx->d_ranges, ctx->d_mask, ctx->d_icp_res, ctx->d_icp_trace);
+  hipLaunchKernelGGL((k_icp<R, MAXT>), dim3(1), dim3(T), lds, ctx->stream, a, P_dev, cap, ctx->d_model, ctx->d_scene,
+                     ctx->d_morig, ctx->d_start, ctx->d_coords, ctx->d_mask_m,
+                     d_rays_local ? d_rays_local : ctx->d_rays_local, d_ranges ? d_ranges : ctx->d_ranges,
+                     d_mask ? d_mask : ctx->d_mask, ctx->d_icp_res, ctx->d_icp_trace);
   TSD_HIP_CHECK(ctx, hipGetLastError());
   return TSD_OK;
 }
 
-int launch_icp(tsd_ctx* ctx, const IcpArgs& a)
+int launch_icp(tsd_ctx* ctx, const IcpArgs& a, const double* P_dev, const double* d_rays_local,
+               const double* d_ranges, const uint8_t* d_mask)
 {
   const int n = a.beams > 0 ? a.beams : (a.n_model > a.n_scene ? a.n_model : a.n_scene);
   if (n > TSD_MAX_ICP_POINTS) return set_error(ctx, TSD_E_CAPACITY, "icp points > TSD_MAX_ICP_POINTS", hipSuccess);
@@ -690,13 +697,13 @@ int launch_icp(tsd_ctx* ctx, const IcpArgs& a)
   const size_t lds = icp_lds_bytes_for(cap);
   const int nthr = a.beams > 0 ? a.beams : a.n_scene;     // scene points decide the thread count
   switch (ctx->icp_shape) {      // TSD_ICP_SHAPE: experiments only
-    case 2: return launch_icp_shape<2, 576>(ctx, a, nthr, cap, lds);
-    case 5: return launch_icp_shape<5, 256>(ctx, a, nthr, cap, lds);
-    case 8: return launch_icp_shape<8, 256>(ctx, a, nthr, cap, lds);
+    case 2: return launch_icp_shape<2, 576>(ctx, a, nthr, cap, lds, P_dev, d_rays_local, d_ranges, d_mask);
+    case 5: return launch_icp_shape<5, 256>(ctx, a, nthr, cap, lds, P_dev, d_rays_local, d_ranges, d_mask);
+    case 8: return launch_icp_shape<8, 256>(ctx, a, nthr, cap, lds, P_dev, d_rays_local, d_ranges, d_mask);
     default: break;
   }
-  if (nthr <= 3 * 512) return launch_icp_shape<3, 512>(ctx, a, nthr, cap, lds);
-  return launch_icp_shape<8, 256>(ctx, a, nthr, cap, lds);
+  if (nthr <= 3 * 512) return launch_icp_shape<3, 512>(ctx, a, nthr, cap, lds, P_dev, d_rays_local, d_ranges, d_mask);
+  return launch_icp_shape<8, 256>(ctx, a, nthr, cap, lds, P_dev, d_rays_local, d_ranges, d_mask);
 }
 
 size_t icp_lds_bytes() { return icp_lds_bytes_for(TSD_MAX_ICP_POINTS); }

@@ -41,11 +41,13 @@ __device__ __forceinline__ void tile_geometry(const GridDev& g, int p, double e[
 }
 
 __global__ void __launch_bounds__(256)
-k_push_classify(GridDev g, PushArgs a, const double* __restrict__ ranges,
+k_push_classify(GridDev g, PushArgs a_val, const PushArgs* __restrict__ a_dev,
+                const double* __restrict__ ranges,
                 const uint8_t* __restrict__ mask, PushCounters* __restrict__ ctr,
                 PushCounters* __restrict__ ctr_next, uint32_t* __restrict__ list,
                 int* __restrict__ block_stats)
 {
+  const PushArgs a = a_dev ? *a_dev : a_val;
   const int lane = threadIdx.x & 63;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p == 0) {   // clear the other epoch's counter set (consumed before this push was enqueued)
@@ -54,7 +56,8 @@ k_push_classify(GridDev g, PushArgs a, const double* __restrict__ ranges,
     ctr_next->tiles_new_from_empty = 0; ctr_next->tiles_emptied_init = 0;
     ctr_next->tiles_emptied_uninit = 0;
   }
-  const bool valid = p < g.tiles;
+  // a push gated off on the device (fused scan): no tile is classified, the work list stays empty
+  const bool valid = p < g.tiles && a.enabled;
 
   bool range_pass = false, need_scan = false, all_vis = true;
   int lo = 0, hi = -1;
@@ -196,10 +199,12 @@ __device__ __forceinline__ bool add_tsd(double& tsd, double& weight, double sd, 
 }
 
 __global__ void __launch_bounds__(UPDATE_BLOCK)
-k_push_update(GridDev g, PushArgs a, const double* __restrict__ ranges,
+k_push_update(GridDev g, PushArgs a_val, const PushArgs* __restrict__ a_dev,
+              const double* __restrict__ ranges,
               const uint8_t* __restrict__ mask, PushCounters* __restrict__ ctr,
               const uint32_t* __restrict__ list, uint32_t* __restrict__ entry_upd)
 {
+  const PushArgs a = a_dev ? *a_dev : a_val;
   // all LDS in the dynamic region (16-byte aligned carve): [0,16) block counter, ranges, mask
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned long long& s_upd = *reinterpret_cast<unsigned long long*>(smem);
@@ -337,7 +342,8 @@ __device__ __forceinline__ void copy_corner(const GridDev& g, int dst, int src, 
 __global__ void __launch_bounds__(256)
 k_push_halo(GridDev g, const uint32_t* __restrict__ list, const int* __restrict__ count_ptr,
             PushCounters* __restrict__ ctr, const int* __restrict__ block_stats, int n_stat_blocks,
-            const uint32_t* __restrict__ entry_upd)
+            const uint32_t* __restrict__ entry_upd, PushCounters* __restrict__ total,
+            const PushArgs* __restrict__ a_dev)
 {
   const int count = *count_ptr;
   if (ctr != nullptr && blockIdx.x == gridDim.x - 1) {
@@ -364,6 +370,15 @@ k_push_halo(GridDev g, const uint32_t* __restrict__ list, const int* __restrict_
       ctr->tiles_new_from_empty = (int)s_tot[4]; ctr->tiles_emptied_init = (int)s_tot[5];
       ctr->tiles_emptied_uninit = (int)s_tot[6];
       ctr->cells_visited = 1024ull * s_tot[2];     // every UPDATE tile back-projects its 32x32 cells
+      if (total != nullptr && (a_dev == nullptr || a_dev->enabled)) {
+        // running totals of every push on this grid (read back on demand: tsd_push_stats_total)
+        total[0].cells_updated += s_tot[0];
+        total[0].cells_visited += 1024ull * s_tot[2];
+        total[0].tiles_range_pass += (int)s_tot[1]; total[0].tiles_update += (int)s_tot[2];
+        total[0].tiles_new += (int)s_tot[3]; total[0].tiles_new_from_empty += (int)s_tot[4];
+        total[0].tiles_emptied_init += (int)s_tot[5]; total[0].tiles_emptied_uninit += (int)s_tot[6];
+        total[1].list_count += 1;                  // pushes
+      }
     }
   }
   const int lane = threadIdx.x & 63;
@@ -458,8 +473,10 @@ int launch_free_footprint(tsd_ctx* ctx, unsigned minX, unsigned maxX, unsigned m
   return TSD_OK;
 }
 
-int launch_push(tsd_ctx* ctx, const PushArgs& a)
+int launch_push(tsd_ctx* ctx, const PushArgs& a, const PushArgs* a_dev, const double* d_ranges, const uint8_t* d_mask)
 {
+  if (!d_ranges) d_ranges = ctx->d_ranges;
+  if (!d_mask) d_mask = ctx->d_mask;
   const GridDev& g = ctx->grid;
   PushCounters* ctr = ctx->d_counters + (ctx->epoch & 1u);
   PushCounters* ctr_next = ctx->d_counters + ((ctx->epoch + 1u) & 1u);
@@ -468,29 +485,30 @@ int launch_push(tsd_ctx* ctx, const PushArgs& a)
     ScopedKernelTimer t(ctx, "push_classify");
     const int blocks = (g.tiles + 255) / 256;
     const size_t lds = (size_t)((a.beams + 1) & ~1) * sizeof(double) + (size_t)((a.beams + 15) & ~15);
-    hipLaunchKernelGGL(k_push_classify, dim3(blocks), dim3(256), lds, ctx->stream, g, a, ctx->d_ranges,
-                       ctx->d_mask, ctr, ctr_next, ctx->d_list, ctx->d_block_stats);
+    hipLaunchKernelGGL(k_push_classify, dim3(blocks), dim3(256), lds, ctx->stream, g, a, a_dev, d_ranges,
+                       d_mask, ctr, ctr_next, ctx->d_list, ctx->d_block_stats);
   }
   TSD_HIP_CHECK(ctx, hipGetLastError());
   {
     ScopedKernelTimer t(ctx, "push_update");
     const size_t lds = 16 + (size_t)((a.beams + 1) & ~1) * sizeof(double) + (size_t)((a.beams + 15) & ~15);
     const int blocks = g.tiles < 2048 ? g.tiles : 2048;
-    hipLaunchKernelGGL(k_push_update, dim3(blocks), dim3(UPDATE_BLOCK), lds, ctx->stream, g, a,
-                       ctx->d_ranges, ctx->d_mask, ctr, ctx->d_list, ctx->d_entry_upd);
+    hipLaunchKernelGGL(k_push_update, dim3(blocks), dim3(UPDATE_BLOCK), lds, ctx->stream, g, a, a_dev,
+                       d_ranges, d_mask, ctr, ctx->d_list, ctx->d_entry_upd);
   }
   TSD_HIP_CHECK(ctx, hipGetLastError());
   {
     ScopedKernelTimer t(ctx, "push_halo");
     const int blocks = g.tiles / 4 < 512 ? (g.tiles + 3) / 4 : 512;
     hipLaunchKernelGGL(k_push_halo, dim3(blocks), dim3(256), 0, ctx->stream, g, ctx->d_list,
-                       &ctr->list_count, ctr, ctx->d_block_stats, (g.tiles + 255) / 256, ctx->d_entry_upd);
+                       &ctr->list_count, ctr, ctx->d_block_stats, (g.tiles + 255) / 256, ctx->d_entry_upd,
+                       ctx->d_stat_total, a_dev);
     if (ctx->n_dirty > 0) {
       // tiles written by freeFootprint since the previous push: same refresh over the list that
       // launch_free_footprint left in d_dirty / d_dirty_count
       hipLaunchKernelGGL(k_push_halo, dim3((ctx->n_dirty + 3) / 4), dim3(256), 0, ctx->stream, g,
                          ctx->d_dirty, ctx->d_dirty_count, (PushCounters*)nullptr, (const int*)nullptr, 0,
-                         (const uint32_t*)nullptr);
+                         (const uint32_t*)nullptr, (PushCounters*)nullptr, (const PushArgs*)nullptr);
       hipMemsetAsync(ctx->d_dirty_count, 0, sizeof(int), ctx->stream);
       ctx->n_dirty = 0;
     }

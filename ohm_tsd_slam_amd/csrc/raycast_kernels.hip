@@ -16,9 +16,10 @@
 namespace tsd {
 
 __global__ void __launch_bounds__(64)
-k_raycast(GridDev g, RaycastArgs a, const double* __restrict__ rays, double* __restrict__ coords,
-          double* __restrict__ normals, uint8_t* __restrict__ mask)
+k_raycast(GridDev g, RaycastArgs a_val, const RaycastArgs* __restrict__ a_dev, const double* __restrict__ rays,
+          double* __restrict__ coords, double* __restrict__ normals, uint8_t* __restrict__ mask)
 {
+  const RaycastArgs a = a_dev ? *a_dev : a_val;
   const int beam = blockIdx.x;
   const int lane = threadIdx.x;
   if (beam >= a.beams) return;
@@ -149,10 +150,10 @@ k_raycast(GridDev g, RaycastArgs a, const double* __restrict__ rays, double* __r
   }
 }
 
-int launch_raycast(tsd_ctx* ctx, const RaycastArgs& a)
+int launch_raycast(tsd_ctx* ctx, const RaycastArgs& a, const RaycastArgs* a_dev, const double* d_rays)
 {
   ScopedKernelTimer t(ctx, "raycast");
-  hipLaunchKernelGGL(k_raycast, dim3(a.beams), dim3(64), 0, ctx->stream, ctx->grid, a, ctx->d_rays,
+  hipLaunchKernelGGL(k_raycast, dim3(a.beams), dim3(64), 0, ctx->stream, ctx->grid, a, a_dev, d_rays ? d_rays : ctx->d_rays,
                      ctx->d_coords, ctx->d_normals, ctx->d_mask_m);
   TSD_HIP_CHECK(ctx, hipGetLastError());
   return TSD_OK;

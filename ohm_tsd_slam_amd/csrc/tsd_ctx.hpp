@@ -33,7 +33,7 @@ struct PushArgs {
   double phi_min, ang_res_inv, phi_lower, phi_upper;
   double max_range, min_range, low_refl;
   int beams;
-  int pad;
+  int enabled;               // 0: this push was gated off on the device (fused scan): every kernel is a no-op
 };
 
 struct RaycastArgs {
@@ -60,6 +60,30 @@ struct IcpResultDev {
   double T[9];
   double rms;
   int pairs, iterations, state, n_model, n_scene, reserved;
+};
+
+// what one fused scan reports (layout of tsd_scan_result in include/tsd_hip.h)
+struct ScanResultDev {
+  IcpResultDev icp;
+  double pose[9];
+  int reg_error, pushed, no_model, reserved;
+  unsigned long long seq;    // written last, system scope: the host spins on it instead of a stream sync
+};
+
+// gates of ThreadLocalize (ThreadLocalize.cpp:593-600, :728-736; ThreadLocalize.h:63-64)
+struct GateArgs {
+  double reg_trs_max, reg_sin_rot_max, trs_min, rot_min;
+};
+
+// device-resident SensorPolar2D + ThreadLocalize pose bookkeeping of one robot (fused scan path)
+struct SensorDev {
+  double pose[9];            // Sensor::_T
+  double last_pose[9];       // ThreadLocalize::_lastPose
+  int have_last_pose;
+  int pad;
+  RaycastArgs rc;            // arguments of the NEXT ray cast / registration, derived from `pose`
+  double icpP[6];
+  PushArgs push;             // arguments of this scan's push (enabled = gate result)
 };
 
 struct KernelTimer {
@@ -118,19 +142,32 @@ struct tsd_ctx {
   int8_t* d_occ = nullptr;       // persistent map (ThreadGrid::_occGridContent)
   int* d_occ_count = nullptr;
 
-  // cumulative push statistics: every push copies its counter set into a pinned ring slot
-  static constexpr int kStatSlots = 16;
-  tsd::PushCounters* h_stat_ring = nullptr;  // pinned [kStatSlots]
-  hipEvent_t stat_ev[kStatSlots] = {};
-  bool stat_pending[kStatSlots] = {};
-  tsd_push_stats stat_total{};
-  int64_t stat_pushes = 0;
+  // cumulative push statistics, accumulated on the device by k_push_halo (no per-push read-back)
+  tsd::PushCounters* d_stat_total = nullptr; // [2]: [0] sums, [1].list_count = pushes
 
   // profiling: bit i of profile_mask times kernel i (names in capi.hip: kKernelNames)
   unsigned profile_mask = 0;
+  unsigned profile_every = 1;   // time every n-th launch of a selected kernel ("name/n" in tsd_profile_select)
+  unsigned profile_tick = 0;
   bool profile = false;
   std::map<std::string, tsd::KernelTimer> timers;
   std::vector<hipEvent_t> event_pool;
+};
+
+// device-resident sensor of one robot (tsd_sensor_* / tsd_scan in include/tsd_hip.h)
+struct tsd_sensor {
+  tsd_ctx* ctx = nullptr;
+  int beams = 0;
+  double ang_res = 0, phi_min = 0, max_range = 0, min_range = 0, low_refl = 0;
+  bool ccw = true;
+  bool posed = false;
+  tsd::SensorDev* d_state = nullptr;
+  double* d_rays = nullptr;        // [2*beams] world rays, normalised to the cell size
+  double* d_rays_local = nullptr;  // [2*beams]
+  char* d_scan = nullptr;          // ranges[beams] | mask[beams] | mask_push[beams]
+  tsd::ScanResultDev* h_result = nullptr;   // pinned, coherent, written by k_scan_post directly
+  tsd::ScanResultDev* d_result = nullptr;   // device address of h_result
+  unsigned long long seq = 0;
 };
 
 namespace tsd {
@@ -150,13 +187,18 @@ struct ScopedKernelTimer {
 };
 void drain_timers(tsd_ctx* ctx);
 bool kernel_is_timed(const tsd_ctx* ctx, const char* name);
-void harvest_push_stats(tsd_ctx* ctx, bool wait);
 
-// per-file launchers
-int launch_push(tsd_ctx* ctx, const PushArgs& a);
+// per-file launchers.  The *_dev pointers are the fused scan path: the kernels then read their pose
+// dependent arguments from the device-resident sensor state instead of the by-value copy.
+int launch_push(tsd_ctx* ctx, const PushArgs& a, const PushArgs* a_dev = nullptr, const double* d_ranges = nullptr,
+                const uint8_t* d_mask = nullptr);
 int launch_free_footprint(tsd_ctx* ctx, unsigned minX, unsigned maxX, unsigned minY, unsigned maxY);
-int launch_raycast(tsd_ctx* ctx, const RaycastArgs& a);
-int launch_icp(tsd_ctx* ctx, const IcpArgs& a);
+int launch_raycast(tsd_ctx* ctx, const RaycastArgs& a, const RaycastArgs* a_dev = nullptr, const double* d_rays = nullptr);
+int launch_icp(tsd_ctx* ctx, const IcpArgs& a, const double* P_dev = nullptr, const double* d_rays_local = nullptr,
+               const double* d_ranges = nullptr, const uint8_t* d_mask = nullptr);
+int launch_scan_prepare(tsd_ctx* ctx, SensorDev* st);
+int launch_scan_post(tsd_ctx* ctx, SensorDev* st, double* d_rays, int beams, const GateArgs& gates,
+                     ScanResultDev* d_out, unsigned long long seq);
 int launch_calibrate(tsd_ctx* ctx, double* t, double* w, size_t n);
 int launch_occupancy(tsd_ctx* ctx, int8_t* d_out, int inflate, int inflate_factor);
 size_t icp_lds_bytes();

@@ -26,6 +26,7 @@ HOST_ABI = {
     "tsd_node_set_string": (None, [C.c_void_p, C.c_char_p, C.c_char_p]),
     "tsd_node_initialize": (C.c_int, [C.c_void_p, C.c_int]),
     "tsd_node_set_synchronous": (None, [C.c_void_p, C.c_int]),
+    "tsd_node_set_fused": (None, [C.c_void_p, C.c_int]),
     "tsd_node_laser": (C.c_int, [C.c_void_p, C.c_int, _fp, C.c_int, C.c_double, C.c_double, C.c_longlong]),
     "tsd_node_wait_idle": (C.c_int, [C.c_void_p, C.c_int]),
     "tsd_node_processed": (C.c_ulonglong, [C.c_void_p, C.c_int]),
@@ -71,7 +72,8 @@ class SlamNode:
     localisers.  ``synchronous=True`` runs the event-loop body inside ``laser()`` (strict
     ray-cast -> ICP -> push order); otherwise the reference's threads/queues are used."""
 
-    def __init__(self, params: dict, device: int = 0, synchronous: bool = True, name: str = "tsd_slam"):
+    def __init__(self, params: dict, device: int = 0, synchronous: bool = True, name: str = "tsd_slam",
+                 fused: bool = True):
         self.lib = load_library()
         self.h = self.lib.tsd_node_create(name.encode())
         for k, v in params.items():
@@ -85,6 +87,7 @@ class SlamNode:
             else:
                 self.lib.tsd_node_set_string(self.h, kb, str(v).encode())
         self.lib.tsd_node_set_synchronous(self.h, int(synchronous))
+        self.lib.tsd_node_set_fused(self.h, int(fused))
         rc = self.lib.tsd_node_initialize(self.h, device)
         if rc != 0:
             self.lib.tsd_node_destroy(self.h)

@@ -96,3 +96,29 @@ class HipSlam:
                    want_stats=False)
             out["pushed"] = 1
         return out
+
+
+class HipSlamFused(HipSlam):
+    """The same closed loop through tsd_scan: sensor state, gates, Sensor::transform and the push
+    decision live on the device; the host only ingests the scan and reads the result."""
+
+    def process_scan(self, ranges_f32):
+        o, kw, g = self.o, self.kw, self.grid
+        if not self.initialized:
+            out = super().process_scan(ranges_f32)
+            self.rays = o.rays_rescale(self.rays, g.cell_size, self.ray_norm)
+            self.ray_norm = g.cell_size
+            self.sensor = capi.TsdSensorDevice(g, kw["beams"], kw["angle_increment"], kw["angle_min"], kw["max_range"],
+                                               kw["min_range"], kw["low_refl_range"])
+            self.sensor.set_pose(self.pose, self.rays, self.rays_local)
+            self.gates = capi.GateParams(kw["reg_trs_max"], kw["reg_sin_rot_max"], 0.05, 0.03)
+            return out
+        r = np.array(ranges_f32, dtype=np.float32)
+        r[r < kw["laser_min_range"]] = 0.0
+        res = kw["angle_increment"]
+        data, mask = o.ingest_f32(r, kw["max_range"], res)
+        _, mask_push = o.ingest_f64(data, kw["max_range"], res)
+        sr = self.sensor.scan(data, mask, mask_push, self.params, self.gates)
+        self.pose = np.array(sr.pose[:]).reshape(3, 3)
+        return dict(pose=self.pose.copy(), pushed=int(sr.pushed), reg_error=int(sr.reg_error), pairs=int(sr.icp.pairs),
+                    valid_model=int(sr.icp.n_model), no_model=int(sr.no_model), T=np.array(sr.icp.T[:]).reshape(3, 3))

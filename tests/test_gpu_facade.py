@@ -14,7 +14,7 @@ from tests.slam_driver import slam_kwargs
 pytestmark = pytest.mark.gpu
 
 
-def run_pair(oracle, gc, geo, scene, n, **over):
+def run_pair(oracle, gc, geo, scene, n, fused=True, **over):
     world = synth.World(scene, gc)
     poses = synth.trajectory(world, n)
     scans = synth.scans_for(world, geo, poses)
@@ -23,14 +23,16 @@ def run_pair(oracle, gc, geo, scene, n, **over):
     geo_msg = synth.ScanGeometry(geo.beams, float(np.float32(geo.angle_min)), float(np.float32(geo.angle_increment)))
     so = oracle.Slam(**slam_kwargs(gc, geo_msg, **over))
     node = facade.SlamNode(facade.node_params(gc, geo, **{k: v for k, v in over.items() if k in ("icp_iterations",)}),
-                           synchronous=True)
+                           synchronous=True, fused=fused)
     return world, poses, scans, so, node
 
 
-@pytest.mark.parametrize("cfg,n", [("cfg1", 15), ("cfg2", 8)])
-def test_facade_sync_loop_matches_oracle(oracle, cfg, n):
+@pytest.mark.parametrize("cfg,n,fused", [("cfg1", 15, True), ("cfg1", 15, False), ("cfg2", 8, True), ("cfg2", 8, False)])
+def test_facade_sync_loop_matches_oracle(oracle, cfg, n, fused):
+    """fused: tsd_scan (gates, Sensor::transform and the push decided on the device in stream order);
+    unfused: tsd_localize + host gates + tsd_push, the reference's call structure."""
     gc, geo, scene = synth.CONFIGS[cfg]
-    world, poses, scans, so, node = run_pair(oracle, gc, geo, scene, n)
+    world, poses, scans, so, node = run_pair(oracle, gc, geo, scene, n, fused=fused)
     pushes = 0
     for k in range(n):
         ro = so.process_scan(scans[k])
@@ -58,12 +60,13 @@ def test_facade_sync_loop_matches_oracle(oracle, cfg, n):
     node.close()
 
 
-def test_facade_threads_contract(oracle):
+@pytest.mark.parametrize("fused", [True, False])
+def test_facade_threads_contract(oracle, fused):
     gc, geo, scene = synth.CONFIGS["cfg1"]
     world = synth.World(scene, gc)
     poses = synth.trajectory(world, 40)
     scans = synth.scans_for(world, geo, poses)
-    node = facade.SlamNode(facade.node_params(gc, geo), synchronous=False)
+    node = facade.SlamNode(facade.node_params(gc, geo), synchronous=False, fused=fused)
     # first scan: init + synchronous initPush on the caller's thread (ThreadLocalize.cpp:257-267)
     node.laser(scans[0], geo.angle_min, geo.angle_increment)
     assert node.processed() == 1 and node.report()["pushed"] == 1 and node.report()["initialised"] == 1
@@ -88,20 +91,25 @@ def test_facade_threads_contract(oracle):
     assert time.time() - t0 < 5.0
 
 
-def test_facade_registration_error_publishes_nan(oracle):
+@pytest.mark.parametrize("fused", [True, False])
+def test_facade_registration_error_publishes_nan(oracle, fused):
     """A scan that cannot be registered within reg_trs_max -> NaN pose, pose unchanged, no push
     (ThreadLocalize.cpp:381-387, 691-713)."""
     gc, geo, scene = synth.CONFIGS["cfg1"]
     world = synth.World(scene, gc)
     poses = synth.trajectory(world, 3)
     scans = synth.scans_for(world, geo, poses)
-    node = facade.SlamNode(facade.node_params(gc, geo, reg_trs_max=1e-4), synchronous=True)
+    node = facade.SlamNode(facade.node_params(gc, geo, reg_trs_max=1e-4), synchronous=True, fused=fused)
     node.laser(scans[0], geo.angle_min, geo.angle_increment)
     p0 = node.report()["pose"].copy()
+    init0, _ = node.grid().download_tile_state()
     node.laser(scans[2], geo.angle_min, geo.angle_increment)
     r = node.report()
     assert r["reg_error"] == 1 and r["pushed"] == 0 and np.array_equal(r["pose"], p0)
     assert np.isnan(node.pose_msg()["position"]).all()
+    # the gated-off push left the grid alone, and the next good scan is still registered from p0
+    init1, _ = node.grid().download_tile_state()
+    assert np.array_equal(init0, init1)
     node.close()
 
 

@@ -215,17 +215,19 @@ def test_localize_fused_matches_pieces(oracle):
     assert d <= TOL_POSE_M and a <= TOL_POSE_RAD
 
 
-def test_closed_loop_trajectory(oracle):
-    """init -> [raycast -> ICP -> transform -> push] x K on both sides, poses compared every scan."""
+@pytest.mark.parametrize("fused", [False, True])
+def test_closed_loop_trajectory(oracle, fused):
+    """init -> [raycast -> ICP -> transform -> push] x K on both sides, poses compared every scan.
+    fused = tsd_scan (one call per scan, gates and pose bookkeeping on the device)."""
     gc = synth.GridConfig(9, 0.05)
     geo = synth.ScanGeometry.full_circle_360()
     world = synth.World("room", gc)
     poses = synth.trajectory(world, 12)
     scans = synth.scans_for(world, geo, poses)
-    from tests.slam_driver import HipSlam, slam_kwargs
+    from tests.slam_driver import HipSlam, HipSlamFused, slam_kwargs
     kw = slam_kwargs(gc, geo)
     so = oracle.Slam(**kw)
-    sh = HipSlam(oracle, **kw)
+    sh = (HipSlamFused if fused else HipSlam)(oracle, **kw)
     for k in range(len(scans)):
         ro = so.process_scan(scans[k])
         rh = sh.process_scan(scans[k])
