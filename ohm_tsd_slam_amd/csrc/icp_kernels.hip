@@ -56,8 +56,10 @@ struct IcpLds {
   double* res_d;                   // [lcap] results: squared distance to the nearest neighbour
   double* res_lb;                  // [lcap]          lower bound (distance) to every other model point
   int* res_k;                      // [lcap]          neighbour slot (-1: unresolved)
-  double* red;                     // [ICP_MAXW][8] wave partials (first pass)
-  double* red2;                    // [ICP_MAXW][2] wave partials (second pass)
+  int* res_k2;                     // [lcap]          runner-up slot
+  double* red;                     // [2][ICP_MAXW][16] wave partials of the pair sums, per-wave broadcast rows
+  double* cst;                     // [16] IcpArgs scalars (kept out of the scalar register file)
+  double* tr;                      // [T][NSUMP] transpose buffer of the pair sums (aliases the work list)
   int* ired;                       // [64] counters
   // setup only (alias the work list)
   double2* stage_s;                // compacted scene
@@ -65,13 +67,19 @@ struct IcpLds {
 };
 
 __host__ __device__ inline int icp_list_cap(int cap) { return cap < 1024 ? cap : 1024; }
-__host__ __device__ inline size_t icp_lds_bytes_for(int cap)
+// bytes of the region shared by the work list (44 B per entry), the setup staging and the transpose buffer
+__host__ __device__ inline size_t icp_region_bytes(int cap, int threads)
 {
-  const size_t lc = (size_t)icp_list_cap(cap);
+  size_t b = 44u * (size_t)icp_list_cap(cap);
+  const size_t tr = (size_t)threads * 9u * sizeof(double);
+  if (tr > b) b = tr;
+  return (b + 15u) & ~(size_t)15u;
+}
+__host__ __device__ inline size_t icp_lds_bytes_for(int cap, int threads)
+{
   // the staging (cap double2 + cap int) aliases the list + result arrays: 40 * lc >= 20 * cap
   return sizeof(double2) * 2 * (size_t)cap + sizeof(unsigned long long) * (size_t)cap + sizeof(int) * 2 * (size_t)cap +
-         (sizeof(double2) + sizeof(int) + 2 * sizeof(double) + sizeof(int)) * lc +
-         sizeof(double) * (ICP_MAXW * 8 + ICP_MAXW * 2) + sizeof(int) * 64 + 64;
+         icp_region_bytes(cap, threads) + sizeof(double) * (2 * ICP_MAXW * 16 + 16) + sizeof(int) * 64 + 64;
 }
 
 // ---- wave reductions: DPP row shifts inside the 16-lane rows, then the four row results through
@@ -113,7 +121,23 @@ __device__ __forceinline__ double wave_min(double v)
   return fmin(fmin(read_lane(v, 15), read_lane(v, 31)), fmin(read_lane(v, 47), read_lane(v, 63)));
 }
 
-struct NnResult { double best, lbsq; int bk; bool resolved; };
+// best = squared distance to the nearest slot bk, bk2 = runner-up slot, lbsq = squared lower bound on the
+// distance to every slot other than those two
+struct NnResult { double best, lbsq; int bk, bk2; bool resolved; };
+
+// running three smallest squared distances (the two smallest with their slots)
+struct Top3 { double b1, b2, b3; int k1, k2; };
+__device__ __forceinline__ void top3_insert(Top3& t, double d, int k)
+{
+  if (d < t.b1) { t.b3 = t.b2; t.b2 = t.b1; t.k2 = t.k1; t.b1 = d; t.k1 = k; }
+  else if (d < t.b2) { t.b3 = t.b2; t.b2 = d; t.k2 = k; }
+  else if (d < t.b3) t.b3 = d;
+}
+// exact tie between the two nearest: the lower original model index is the neighbour
+__device__ __forceinline__ void top3_tiebreak(const IcpLds& L, Top3& t)
+{
+  if (t.k2 >= 0 && t.k1 >= 0 && t.b2 == t.b1 && L.morig[t.k2] < L.morig[t.k1]) { const int k = t.k1; t.k1 = t.k2; t.k2 = k; }
+}
 
 // separation bound of model slot with unit direction u for the point (x, y): squared lower bound on the
 // distance from (x, y) to ANY point at that angular separation or more; `cr` returns the side.
@@ -130,49 +154,36 @@ __device__ __forceinline__ NnResult window_search(const IcpLds& L, int nM, doubl
                                                   double thr, double sgn)
 {
   NnResult r;
-  r.best = __builtin_inf(); r.lbsq = 0.0; r.bk = -1; r.resolved = false;
+  r.best = __builtin_inf(); r.lbsq = 0.0; r.bk = -1; r.bk2 = -1; r.resolved = false;
   if (nM <= 2 * HW + 1) return r;
-  int kk[2 * HW + 1];
+  int k0 = c - HW;
+  if (k0 < 0) k0 += nM;
   double2 m[2 * HW + 1];
+  int kk[2 * HW + 1];
 #pragma unroll
   for (int j = 0; j < 2 * HW + 1; j++) {
-    int k = c + j - HW;
-    if (k < 0) k += nM;
+    int k = k0 + j;
     if (k >= nM) k -= nM;
     kk[j] = k;
     m[j] = L.mxy[k];
   }
   const double2 ulo = L.uxy[kk[0]], uhi = L.uxy[kk[2 * HW]];
-  double best = __builtin_inf(), second = __builtin_inf();
-  int bj = 0;
-  bool tie = false;
+  Top3 t;
+  t.b1 = t.b2 = t.b3 = __builtin_inf(); t.k1 = t.k2 = -1;
 #pragma unroll
   for (int j = 0; j < 2 * HW + 1; j++) {
     const double dx = x - m[j].x, dy = y - m[j].y;
-    const double d = dx * dx + dy * dy;
-    tie = tie || (d == best);
-    if (d < best) { second = best; best = d; bj = j; tie = false; }
-    else if (d < second) second = d;
+    top3_insert(t, dx * dx + dy * dy, kk[j]);
   }
-  int bk = kk[0];
-#pragma unroll
-  for (int j = 1; j < 2 * HW + 1; j++) if (bj == j) bk = kk[j];
-  if (tie) {                                         // exact tie: lowest original index (rare)
-    second = best;
-#pragma unroll
-    for (int j = 0; j < 2 * HW + 1; j++) {
-      const double dx = x - m[j].x, dy = y - m[j].y;
-      if (dx * dx + dy * dy == best && L.morig[kk[j]] < L.morig[bk]) bk = kk[j];
-    }
-  }
+  top3_tiebreak(L, t);
   const double rs2 = x * x + y * y;
   double crl, crh;
   const double l2lo = sep_bound(x, y, rs2, ulo, crl), l2hi = sep_bound(x, y, rs2, uhi, crh);
   // the low end must lie clockwise of s (in slot order) and the high end counter-clockwise
   const double lbo = fmin(crl * sgn <= 0.0 ? l2lo : 0.0, crh * sgn >= 0.0 ? l2hi : 0.0);
-  r.best = best; r.bk = bk;
-  r.lbsq = fmin(second, lbo);
-  r.resolved = lbo > fmin(best, thr);
+  r.best = t.b1; r.bk = t.k1; r.bk2 = t.k2;
+  r.lbsq = fmin(t.b3, lbo);
+  r.resolved = lbo > fmin(t.b1, thr);
   return r;
 }
 
@@ -182,10 +193,10 @@ __device__ __forceinline__ NnResult wave_search(const IcpLds& L, int nM, double 
                                                 double thr, double sgn, int lane)
 {
   const double rs2 = x * x + y * y;
-  double best = __builtin_inf(), second = __builtin_inf();
+  Top3 t;
+  t.b1 = t.b2 = t.b3 = __builtin_inf(); t.k1 = t.k2 = -1;
   double l2u = __builtin_inf(), l2d = __builtin_inf();
   bool up_done = false, dn_done = false;
-  int bk = -1;
   int lo = 0, hi = -1;                               // visited offsets relative to `start` (empty)
   int cnt = nM < 64 ? nM : 64;
   int w0 = -(cnt / 2);
@@ -204,11 +215,15 @@ __device__ __forceinline__ NnResult wave_search(const IcpLds& L, int nM, double 
       d = dx * dx + dy * dy;
       l2 = sep_bound(x, y, rs2, u, cr);
     }
-    const double wmin = wave_min(d);
-    const unsigned long long eq = __ballot(act && d == wmin);
-    if (eq) {
+    // the three smallest of this window (exact ties: lowest original index first), merged into the run
+    double dd = d;
+#pragma unroll
+    for (int rnk = 0; rnk < 3; rnk++) {
+      const double wmin = wave_min(dd);
+      const unsigned long long eq = __ballot(act && dd == wmin);
+      if (!eq) break;
       int wl = __ffsll((long long)eq) - 1;
-      if (__popcll(eq) > 1) {                        // exact tie inside the window: lowest original index
+      if (__popcll(eq) > 1) {
         int bo = INT_MAX;
         unsigned long long e = eq;
         while (e) {
@@ -217,15 +232,11 @@ __device__ __forceinline__ NnResult wave_search(const IcpLds& L, int nM, double 
           if (mo < bo) { bo = mo; wl = l; }
         }
       }
-      const int wk = __builtin_amdgcn_readlane(k, wl);
-      const double wsec = wave_min(lane == wl ? __builtin_inf() : d);
-      if (wmin < best) { second = fmin(best, wsec); best = wmin; bk = wk; }
-      else {
-        second = fmin(second, wmin);
-        if (wmin == best && bk >= 0 && L.morig[wk] < L.morig[bk]) bk = wk;
-      }
+      top3_insert(t, wmin, __builtin_amdgcn_readlane(k, wl));
+      if (lane == wl) dd = __builtin_inf();
     }
-    const double limit = fmin(best, thr);
+    top3_tiebreak(L, t);
+    const double limit = fmin(t.b1, thr);
     const bool sc = act && l2 > limit;
     const unsigned long long bu = __ballot(sc && o >= 0 && cr * sgn >= 0.0);
     const unsigned long long bdn = __ballot(sc && o < 0 && cr * sgn <= 0.0);
@@ -236,15 +247,59 @@ __device__ __forceinline__ NnResult wave_search(const IcpLds& L, int nM, double 
     const int total = hi - lo + 1;
     if ((up_done && dn_done) || total >= nM) {
       NnResult r;
-      r.best = best; r.bk = bk; r.resolved = true;
-      r.lbsq = (total >= nM) ? second : fmin(second, fmin(l2u, l2d));
-      if (nM <= 1) r.lbsq = __builtin_inf();
+      r.best = t.b1; r.bk = t.k1; r.bk2 = t.k2 >= 0 ? t.k2 : t.k1; r.resolved = true;
+      r.lbsq = (total >= nM) ? t.b3 : fmin(t.b3, fmin(l2u, l2d));
       return r;
     }
     const int remaining = nM - total;
     cnt = remaining < 64 ? remaining : 64;
     w0 = !up_done ? hi + 1 : lo - cnt;
   }
+}
+
+
+constexpr int NSUM = 9;      // pair sums of one step: sum mx, my, sx, sy, d2 and the four centred products
+constexpr int NSUMP = 9;     // row pitch of the transpose buffer (doubles); odd => conflict-free columns
+
+// Sums over the whole workgroup of NSUM doubles per thread (+ one wave-uniform integer per wave).
+// Every lane writes its row into an LDS transpose buffer; lane l of a wave then adds 16 rows of column
+// l/4 (4 lanes per column), two DPP shifts finish the column, the wave partials meet in LDS.  ~80
+// instructions for nine values where nine shuffle trees cost ~200; fixed order => deterministic.
+template <int MAXW>
+__device__ __forceinline__ void block_totals(const IcpLds& L, const double (&v)[NSUM], int cnt, double (&tot)[NSUM],
+                                             int& cnt_total, int tid, int lane, int wave, int W)
+{
+  double* row = L.tr + (size_t)tid * NSUMP;
+#pragma unroll
+  for (int k = 0; k < NSUM; k++) row[k] = v[k];
+  // (same wave wrote the rows it reads: LDS executes a wave's accesses in order)
+  const int col = lane >> 2, part = lane & 3;
+  double acc = 0.0;
+  if (col < NSUM) {
+    const double* base = L.tr + ((size_t)wave * 64 + part) * NSUMP + col;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc += base[(size_t)(4 * i) * NSUMP];
+  }
+  acc += dpp_shr0<0x111>(acc);     // row_shr:1
+  acc += dpp_shr0<0x112>(acc);     // row_shr:2  -> lane 4*col + 3 holds the column total of this wave
+  if (part == 3 && col < NSUM) L.red[wave * 16 + col] = acc;
+  if (lane == 0) L.red[wave * 16 + NSUM] = (double)cnt;      // the pair count rides along (exact in fp64)
+  __syncthreads();
+  double t = 0.0;
+  if (lane <= NSUM) {
+    double x[MAXW];
+#pragma unroll
+    for (int w = 0; w < MAXW; w++) x[w] = (w < W) ? L.red[w * 16 + lane] : 0.0;   // independent reads in flight
+#pragma unroll
+    for (int w = 0; w < MAXW; w++) t += x[w];
+  }
+  // broadcast through LDS (a wave's LDS accesses execute in order): the totals stay in vector registers,
+  // which this kernel has plenty of, instead of 20 scalar registers it has not
+  double* bc = L.red + (ICP_MAXW + wave) * 16;
+  if (lane <= NSUM) bc[lane] = t;
+#pragma unroll
+  for (int k = 0; k < NSUM; k++) tot[k] = bc[k];
+  cnt_total = (int)bc[NSUM];
 }
 
 template <int R, int MAXT>
@@ -269,11 +324,14 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
     L.res_lb = reinterpret_cast<double*>(p); p += sizeof(double) * (size_t)lcap;
     L.list_k = reinterpret_cast<int*>(p); p += sizeof(int) * (size_t)lcap;
     L.res_k = reinterpret_cast<int*>(p); p += sizeof(int) * (size_t)lcap;
+    L.res_k2 = reinterpret_cast<int*>(p);
+    p = reinterpret_cast<char*>(L.list_xy) + icp_region_bytes(cap, (int)blockDim.x);
     // staging view of the same 40*lcap bytes: cap double2 then cap int (40*lcap >= 20*cap)
     L.start = reinterpret_cast<int*>(reinterpret_cast<char*>(L.stage_s) + sizeof(double2) * (size_t)cap);
     L.slotD = reinterpret_cast<unsigned long long*>(p); p += sizeof(unsigned long long) * (size_t)cap;
-    L.red = reinterpret_cast<double*>(p); p += sizeof(double) * ICP_MAXW * 8;
-    L.red2 = reinterpret_cast<double*>(p); p += sizeof(double) * ICP_MAXW * 2;
+    L.red = reinterpret_cast<double*>(p); p += sizeof(double) * 2 * ICP_MAXW * 16;
+    L.cst = reinterpret_cast<double*>(p); p += sizeof(double) * 16;
+    L.tr = reinterpret_cast<double*>(L.list_xy);     // T * 72 B <= 40 * lcap B (checked by the launcher)
     L.slotI = reinterpret_cast<int*>(p); p += sizeof(int) * (size_t)cap;
     L.morig = reinterpret_cast<int*>(p); p += sizeof(int) * (size_t)cap;
     L.ired = reinterpret_cast<int*>(p);
@@ -337,7 +395,13 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
     }
     __syncthreads();
   }
-  if (tid == 0) { L.ired[IR_CNT] = 0; L.ired[IR_RMAX] = 0; }
+  if (tid == 0) {
+    L.ired[IR_CNT] = 0; L.ired[IR_RMAX] = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) L.cst[i] = a.P[i];
+    L.cst[6] = a.min_x; L.cst[7] = a.max_x; L.cst[8] = a.min_y; L.cst[9] = a.max_y;
+    L.cst[10] = a.multiplier; L.cst[11] = a.min_sqr;
+  }
 
   double Tf[6] = {1, 0, 0, 0, 1, 0};   // rows 0,1 of _Tfinal4x4: [r00 r01 tx ; r10 r11 ty]
   double rms = 0.0;
@@ -355,24 +419,24 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
   }
 
   // every thread takes its scene points into registers; unit directions of the model
-  double sx[R], sy[R], lb[R], r0[R];
-  int hint[R];
+  double sx[R], sy[R], lb[R];
+  int hint[R], hint2[R];
   bool have[R];
   float rmaxf = 0.f;
 #pragma unroll
   for (int q = 0; q < R; q++) {
     const int i = tid + q * T;
     have[q] = i < nS;
-    sx[q] = 0.0; sy[q] = 0.0; hint[q] = 0; lb[q] = -1.0; r0[q] = 0.0;
+    sx[q] = 0.0; sy[q] = 0.0; hint[q] = 0; hint2[q] = 0; lb[q] = -1.0;
     if (have[q]) {
       const double2 s = L.stage_s[i];
       sx[q] = s.x; sy[q] = s.y;
       // |s| rounded up: fp32 is plenty for a bound
       const float rf = sqrtf((float)(s.x * s.x + s.y * s.y) * 1.000001f) * 1.000001f;
-      r0[q] = (double)rf;
       rmaxf = fmaxf(rmaxf, rf);
       int h = L.start[i];
       hint[q] = h < 0 ? 0 : (h >= nM ? nM - 1 : h);
+      hint2[q] = hint[q];
     }
   }
   for (int k = tid; k < nM; k += T) {
@@ -399,7 +463,9 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
   unsigned int conv_cnt = 0;
   const unsigned int max_it = (unsigned)a.iterations, conv_need = (unsigned)a.iterations;
   // rows of the pose's rotation block are unit vectors up to rounding: |R_p s| <= pnorm |s| per axis
-  const double pnorm = fmax(sqrt(a.P[0] * a.P[0] + a.P[1] * a.P[1]), sqrt(a.P[3] * a.P[3] + a.P[4] * a.P[4])) * (1.0 + 1e-9);
+  const double pnorm = fmax(sqrt(L.cst[0] * L.cst[0] + L.cst[1] * L.cst[1]), sqrt(L.cst[3] * L.cst[3] + L.cst[4] * L.cst[4])) * (1.0 + 1e-9);
+
+  double c0[4] = {0.0, 0.0, 0.0, 0.0};       // centring point of the pair sums: last step's centroids
 
   while (state == TSD_ICP_PROCESSING) {
     const double thr_before = thr;
@@ -407,37 +473,47 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
     // -- phase A: pre-filter + exact NN + distance filter (per scene point)
     // OutOfBoundsFilter2D: when even a disc of the largest possible scene radius around the sensor
     // lies inside the bounds nothing can be filtered and the per-point transform is skipped.
-    const double tcum = sqrt(Tf[2] * Tf[2] + Tf[5] * Tf[5]) * (1.0 + 1e-9);
+    const double tcum = (double)(sqrtf((float)(Tf[2] * Tf[2] + Tf[5] * Tf[5]) * 1.000001f) * 1.000001f);
     const double reach = (scene_rmax + tcum) * pnorm * (1.0 + 1e-6) + 1e-6;
-    const bool all_in = (a.P[2] - reach > a.min_x) && (a.P[2] + reach < a.max_x) &&
-                        (a.P[5] - reach > a.min_y) && (a.P[5] + reach < a.max_y);
+    const double Ptx = L.cst[2], Pty = L.cst[5];
+    const bool all_in = (Ptx - reach > L.cst[6]) && (Ptx + reach < L.cst[7]) &&
+                        (Pty - reach > L.cst[8]) && (Pty + reach < L.cst[9]);
     double bd[R]; bool keep[R], need[R];
     int ent[R];
+    {
+      double2 mh[R], mh2[R];
 #pragma unroll
-    for (int q = 0; q < R; q++) {
-      keep[q] = false; need[q] = false; bd[q] = __builtin_inf(); ent[q] = -1;
-      if (have[q]) {
+      for (int q = 0; q < R; q++) { mh[q] = L.mxy[hint[q]]; mh2[q] = L.mxy[hint2[q]]; }   // all reads in flight
+#pragma unroll
+      for (int q = 0; q < R; q++) {
         const double x = sx[q], y = sy[q];
-        bool pre = true;
+        bool pre = have[q];
         if (!all_in) {
           // S.transform(P): (0 + x*R00) + y*R01, then + t (gsl/Matrix.cpp:403-432)
           double wx = 0.0, wy = 0.0;
-          wx += x * a.P[0]; wx += y * a.P[1];
-          wy += x * a.P[3]; wy += y * a.P[4];
-          wx += a.P[2]; wy += a.P[5];
-          pre = !(wx < a.min_x || wx > a.max_x || wy < a.min_y || wy > a.max_y);
+          wx += x * L.cst[0]; wx += y * L.cst[1];
+          wy += x * L.cst[3]; wy += y * L.cst[4];
+          wx += L.cst[2]; wy += L.cst[5];
+          pre = pre && !(wx < L.cst[6] || wx > L.cst[7] || wy < L.cst[8] || wy > L.cst[9]);
         }
-        if (pre) {
-          const double2 m = L.mxy[hint[q]];
-          const double dx = x - m.x, dy = y - m.y;
-          const double d = dx * dx + dy * dy;
-          const double lbq = lb[q];
-          const double lb2 = lbq * lbq;
-          bd[q] = d;
-          if (lbq > 0.0 && d < lb2) keep[q] = d <= thr;                 // neighbour unchanged
-          else if (lbq > 0.0 && d > thr && lb2 > thr) { }               // no pair whoever it is
-          else need[q] = true;
-        }
+        // the nearer of the last neighbour and its runner-up is the exact neighbour as long as it beats
+        // the bound on everything else (a point hovering between two model points never searches)
+        const double dx1 = x - mh[q].x, dy1 = y - mh[q].y, dx2 = x - mh2[q].x, dy2 = y - mh2[q].y;
+        const double d1 = dx1 * dx1 + dy1 * dy1, d2 = dx2 * dx2 + dy2 * dy2;
+        bool swp = d2 < d1;
+        if (d2 == d1 && hint2[q] != hint[q]) swp = L.morig[hint2[q]] < L.morig[hint[q]];   // exact tie (rare)
+        const double d = swp ? d2 : d1;
+        const int kn = swp ? hint2[q] : hint[q], ko = swp ? hint[q] : hint2[q];
+        hint[q] = kn; hint2[q] = ko;
+        const double lbq = lb[q];
+        const double lb2 = lbq * lbq;
+        const bool known = lbq > 0.0;
+        const bool same = known && d < lb2;                       // neighbour proven
+        const bool drop = known && d > thr && lb2 > thr;          // no pair whoever it is
+        bd[q] = pre ? d : __builtin_inf();
+        keep[q] = pre && same && d <= thr;
+        need[q] = pre && !same && !drop;
+        ent[q] = -1;
       }
     }
     // work list of the points that need a search
@@ -445,6 +521,7 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
     for (int q = 0; q < R; q++)
       if (need[q]) ent[q] = atomicAdd(&L.ired[IR_CNT], 1);
     __syncthreads();
+    STAMP(0);
     const int n_need = L.ired[IR_CNT];
     for (int base = 0; base < n_need; base += lcap) {       // one pass unless more than lcap points search
       const int n = (n_need - base) < lcap ? (n_need - base) : lcap;
@@ -458,15 +535,20 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
       for (int e0 = wave * 64; e0 < n; e0 += T) {
         const int e = e0 + lane;
         bool unresolved = false;
+#ifdef TSD_ICP_STAMPS
+        const long long ws0 = clock64();
+#endif
         if (e < n) {
           const double2 s = L.list_xy[e];
           const NnResult r = window_search(L, nM, s.x, s.y, L.list_k[e], thr, sgn);
-          if (r.resolved) { L.res_d[e] = r.best; L.res_k[e] = r.bk; L.res_lb[e] = sqrt(r.lbsq) * SLACK; }
+          if (r.resolved) { L.res_d[e] = r.best; L.res_k[e] = r.bk; L.res_k2[e] = r.bk2; L.res_lb[e] = sqrt(r.lbsq) * SLACK; }
           else unresolved = true;
         }
         unsigned long long todo = __ballot(unresolved);
 #ifdef TSD_ICP_STAMPS
         if (lane == 0) { atomicAdd(&L.ired[IR_DBG + 1], __popcll(todo)); }
+        if (tid == 0) { L.ired[IR_DBG + 2] += (int)(clock64() - ws0); L.ired[IR_DBG + 3] += 1; }
+        const long long ws1 = clock64();
 #endif
         while (todo) {
           const int src = __ffsll((long long)todo) - 1;
@@ -474,8 +556,11 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
           const int es = e0 + src;
           const double2 s = L.list_xy[es];
           const NnResult r = wave_search(L, nM, s.x, s.y, L.list_k[es], thr, sgn, lane);
-          if (lane == 0) { L.res_d[es] = r.best; L.res_k[es] = r.bk; L.res_lb[es] = sqrt(r.lbsq) * SLACK; }
+          if (lane == 0) { L.res_d[es] = r.best; L.res_k[es] = r.bk; L.res_k2[es] = r.bk2; L.res_lb[es] = sqrt(r.lbsq) * SLACK; }
         }
+#ifdef TSD_ICP_STAMPS
+        if (tid == 0) { L.ired[IR_DBG + 4] += (int)(clock64() - ws1); }
+#endif
       }
       __syncthreads();
 #pragma unroll
@@ -483,7 +568,7 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
         if (need[q] && ent[q] >= base && ent[q] < base + lcap) {
           const int e = ent[q] - base;
           const int k = L.res_k[e];
-          if (k >= 0) { bd[q] = L.res_d[e]; hint[q] = k; lb[q] = L.res_lb[e]; keep[q] = bd[q] <= thr; }   // DistanceFilter::filter
+          if (k >= 0) { bd[q] = L.res_d[e]; hint[q] = k; hint2[q] = L.res_k2[e]; lb[q] = L.res_lb[e]; keep[q] = bd[q] <= thr; }   // DistanceFilter::filter
           else { bd[q] = __builtin_inf(); lb[q] = -1.0; }                                                // non-finite input point
         }
       if (base + lcap < n_need) __syncthreads();
@@ -492,8 +577,8 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
     if (tid == 0) L.ired[IR_DBG] += n_need;
 #endif
     // threshold schedule (DistanceFilter.cpp:62-63)
-    thr *= a.multiplier;
-    if (thr < a.min_sqr) thr = a.min_sqr;
+    thr *= L.cst[10];
+    if (thr < L.cst[11]) thr = L.cst[11];
     STAMP(1);
 
     // -- phase B/C: ReciprocalFilter = per model point keep the pair with the smallest d2
@@ -501,78 +586,79 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
     for (int q = 0; q < R; q++)
       if (keep[q]) atomicMin(&L.slotD[hint[q]], (unsigned long long)__double_as_longlong(bd[q]));
     __syncthreads();
+    {
+      unsigned long long sd[R];
 #pragma unroll
-    for (int q = 0; q < R; q++)
-      if (keep[q] && L.slotD[hint[q]] == (unsigned long long)__double_as_longlong(bd[q]))
-        atomicMin(&L.slotI[hint[q]], tid + q * T);
+      for (int q = 0; q < R; q++) sd[q] = L.slotD[hint[q]];
+#pragma unroll
+      for (int q = 0; q < R; q++)
+        if (keep[q] && sd[q] == (unsigned long long)__double_as_longlong(bd[q]))
+          atomicMin(&L.slotI[hint[q]], tid + q * T);
+    }
     __syncthreads();
     STAMP(2);
 
-    // -- phase D: ClosedFormEstimator2D::setPairs: centroids, "rms" (mean squared distance), count
-    double v[5] = {0, 0, 0, 0, 0};
-    double wmx[R], wmy[R];
+    // -- phase D/F: ClosedFormEstimator2D::setPairs + estimateTransformation in ONE pass over the pairs.
+    // The reference centres the pairs on their centroids (two passes).  Centring on the previous
+    // step's centroids c0 instead and correcting, sum (a-ca)(b-cb) = sum (a-c0a)(b-c0b) - n (ca-c0a)(cb-c0b),
+    // is the same quantity with the same conditioning (c0 is within millimetres of c); the very first
+    // step has no c0 and runs the pass twice, i.e. the reference's two passes.
     bool win[R];
+    double2 mw[R];
     int cnt = 0;
+    {
+      int si_[R];
 #pragma unroll
-    for (int q = 0; q < R; q++) {
-      win[q] = keep[q] && L.slotI[hint[q]] == tid + q * T;
-      wmx[q] = 0.0; wmy[q] = 0.0;
-      if (win[q]) {
-        const double2 m = L.mxy[hint[q]];
-        wmx[q] = m.x; wmy[q] = m.y;
-        v[0] += m.x; v[1] += m.y; v[2] += sx[q]; v[3] += sy[q];
-        const double dx = sx[q] - m.x, dy = sy[q] - m.y;
-        v[4] += dx * dx + dy * dy;
+      for (int q = 0; q < R; q++) { si_[q] = L.slotI[hint[q]]; mw[q] = L.mxy[hint[q]]; }
+#pragma unroll
+      for (int q = 0; q < R; q++) {
+        win[q] = keep[q] && si_[q] == tid + q * T;
+        cnt += __popcll(__ballot(win[q]));
       }
-      cnt += __popcll(__ballot(win[q]));
     }
+    double tot[NSUM];
+    for (int pass = (iter == 0 ? 0 : 1); pass < 2; pass++) {
+      double v[NSUM];
 #pragma unroll
-    for (int k = 0; k < 5; k++) v[k] = wave_total(v[k]);
-    if (lane == 0) {
+      for (int k = 0; k < NSUM; k++) v[k] = 0.0;
 #pragma unroll
-      for (int k = 0; k < 5; k++) L.red[wave * 8 + k] = v[k];
-      L.ired[wave] = cnt;
+      for (int q = 0; q < R; q++) {
+        if (win[q]) {
+          const double2 m = mw[q];
+          v[0] += m.x; v[1] += m.y; v[2] += sx[q]; v[3] += sy[q];
+          const double dx = sx[q] - m.x, dy = sy[q] - m.y;
+          v[4] += dx * dx + dy * dy;
+          const double xF = m.x - c0[0], yF = m.y - c0[1], xS = sx[q] - c0[2], yS = sy[q] - c0[3];
+          v[5] += yF * xS; v[6] += xF * yS; v[7] += xF * xS; v[8] += yF * yS;
+        }
+      }
+      STAMP(3);
+      block_totals<MAXT / 64>(L, v, cnt, tot, pairs, tid, lane, wave, W);
+      STAMP(4);
+      if (pass == 0) {                     // first step only: centroids first, then the centred pass
+        if (pairs > 0) {
+          const double inv0 = 1.0 / (double)pairs;
+          c0[0] = tot[0] * inv0; c0[1] = tot[1] * inv0; c0[2] = tot[2] * inv0; c0[3] = tot[3] * inv0;
+        }
+        __syncthreads();                   // the wave partials are rewritten by the second pass
+      }
     }
-    __syncthreads();
     // everybody is past the winner test: give the touched slots back, clear the work list counter
 #pragma unroll
     for (int q = 0; q < R; q++)
       if (keep[q]) { L.slotD[hint[q]] = ~0ull; L.slotI[hint[q]] = INT_MAX; }
     if (tid == 0) L.ired[IR_CNT] = 0;
-    {
-      double t[5] = {0, 0, 0, 0, 0};
-      int c = 0;
-      for (int w = 0; w < W; w++) {
-#pragma unroll
-        for (int k = 0; k < 5; k++) t[k] += L.red[w * 8 + k];
-        c += L.ired[w];
-      }
-#pragma unroll
-      for (int k = 0; k < 5; k++) v[k] = t[k];
-      pairs = c;
-    }
     STAMP(3);
 
     if (pairs > 2) {
-      const double size_inv = 1.0 / (double)pairs;
-      rms = v[4] * size_inv;
-      const double cmx = v[0] * size_inv, cmy = v[1] * size_inv, csx = v[2] * size_inv, csy = v[3] * size_inv;
-      // -- phase F: estimateTransformation: nominator / denominator over centred pairs
-      double nom = 0.0, den = 0.0;
-#pragma unroll
-      for (int q = 0; q < R; q++) {
-        if (win[q]) {
-          const double xF = wmx[q] - cmx, yF = wmy[q] - cmy;
-          const double xS = sx[q] - csx, yS = sy[q] - csy;
-          nom += yF * xS - xF * yS;
-          den += xF * xS + yF * yS;
-        }
-      }
-      nom = wave_total(nom); den = wave_total(den);
-      if (lane == 0) { L.red2[wave * 2] = nom; L.red2[wave * 2 + 1] = den; }
-      __syncthreads();
-      nom = 0.0; den = 0.0;
-      for (int w = 0; w < W; w++) { nom += L.red2[w * 2]; den += L.red2[w * 2 + 1]; }
+      const double np = (double)pairs;
+      const double size_inv = 1.0 / np;
+      rms = tot[4] * size_inv;
+      const double cmx = tot[0] * size_inv, cmy = tot[1] * size_inv, csx = tot[2] * size_inv, csy = tot[3] * size_inv;
+      const double emx = cmx - c0[0], emy = cmy - c0[1], esx = csx - c0[2], esy = csy - c0[3];
+      const double nom = (tot[5] - np * (emy * esx)) - (tot[6] - np * (emx * esy));
+      const double den = (tot[7] - np * (emx * esx)) + (tot[8] - np * (emy * esy));
+      c0[0] = cmx; c0[1] = cmy; c0[2] = csx; c0[3] = csy;
       // every wave evaluates the closed form itself (wave-uniform inputs): no broadcast barrier
       double co, si;
 #ifdef TSD_ICP_EXACT_TRIG
@@ -582,30 +668,27 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
       // from the reference's atan2 -> cos/sin by rounding only (DESIGN.md "ICP", tolerance 1e-4)
       {
         const double h2 = nom * nom + den * den;
-        if (h2 > 0.0) { const double inv = 1.0 / sqrt(h2); co = den * inv; si = nom * inv; }
+        if (h2 > 0.0) { const double inv = rsqrt(h2); co = den * inv; si = nom * inv; }
         else { co = signbit(den) ? -1.0 : 1.0; si = 0.0; }
       }
 #endif
       const double dX = (cmx - (co * csx - si * csy));
       const double dY = (cmy - (co * csy + si * csx));
       STAMP(4);
-      // How far can this step move a point?  |R s - s| = chord * |s| and |s| <= r0 + |t_cum|, so
-      // disp <= chord * (r0 + tcum) + |t_step|: it eats into the neighbour bounds of tier 0.
-      const float chordf = sqrtf((float)((1.0 - co) * (1.0 - co) + si * si) * 1.000001f) * 1.000001f;
-      const float tstepf = sqrtf((float)(dX * dX + dY * dY) * 1.000001f) * 1.000001f;
-      const double chord = (double)chordf;
-      const double dfix = chord * tcum + (double)tstepf;
-      // applyTransformation(sceneTmp): data * R^T (dgemm NoTrans,Trans), then + t (Icp.cpp:371-408)
+      // applyTransformation(sceneTmp): data * R^T (dgemm NoTrans,Trans), then + t (Icp.cpp:371-408).
+      // The distance each point moves (rounded up, fp32 is plenty for a bound) eats into its neighbour
+      // bound of tier 0.
 #pragma unroll
       for (int q = 0; q < R; q++) {
-        if (have[q]) {
-          const double x = sx[q], y = sy[q];
-          double nx = 0.0, ny = 0.0;
-          nx += x * co; nx += y * (-si);
-          ny += x * si; ny += y * co;
-          sx[q] = nx + dX; sy[q] = ny + dY;
-          lb[q] = lb[q] - (chord * r0[q] + dfix);
-        }
+        const double x = sx[q], y = sy[q];
+        double nx = 0.0, ny = 0.0;
+        nx += x * co; nx += y * (-si);
+        ny += x * si; ny += y * co;
+        nx = nx + dX; ny = ny + dY;
+        const double ex = nx - x, ey = ny - y;
+        const float disp = sqrtf((float)(ex * ex + ey * ey) * 1.000001f) * 1.000001f;
+        lb[q] = lb[q] - (double)disp;
+        sx[q] = nx; sy[q] = ny;
       }
       {
         // Tfinal = Tlast * Tfinal (Icp.cpp:452): the 4x4 product restricted to its non-trivial entries
@@ -644,6 +727,8 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
   __syncthreads();
   if (tid == 0) {
     st_acc[6] = L.ired[IR_DBG]; st_acc[7] = L.ired[IR_DBG + 1];     // searched points / wave searches
+    printf("wave0: window rounds %d cycles %d (avg %d), tier2 cycles %d\n", L.ired[IR_DBG + 3], L.ired[IR_DBG + 2],
+           L.ired[IR_DBG + 2] / (L.ired[IR_DBG + 3] > 0 ? L.ired[IR_DBG + 3] : 1), L.ired[IR_DBG + 4]);
     for (int i = 0; i < 8; i++) trace[4 * TSD_ICP_TRACE_MAX - 8 + i] = (double)st_acc[i];
   }
 #endif
@@ -667,12 +752,13 @@ static int icp_cap_for(int n)
 // workgroup shape: R scene points per thread, T threads.  One CU runs the whole registration and is
 // issue bound, so few waves (per-wave reduction / control cost paid once per SIMD) win.
 template <int R, int MAXT>
-static int launch_icp_shape(tsd_ctx* ctx, const IcpArgs& a, int n, int cap, size_t lds, const double* P_dev,
+static int launch_icp_shape(tsd_ctx* ctx, const IcpArgs& a, int n, int cap, const double* P_dev,
                             const double* d_rays_local, const double* d_ranges, const uint8_t* d_mask)
 {
   int T = ((n + R - 1) / R + 63) & ~63;
   if (T < 64) T = 64;
   if (T > MAXT) return set_error(ctx, TSD_E_CAPACITY, "icp workgroup shape", hipSuccess);
+  const size_t lds = icp_lds_bytes_for(cap, T);
   static size_t configured = 0;
   if (lds > configured) {
     TSD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_icp<R, MAXT>),
@@ -694,18 +780,17 @@ int launch_icp(tsd_ctx* ctx, const IcpArgs& a, const double* P_dev, const double
   const int n = a.beams > 0 ? a.beams : (a.n_model > a.n_scene ? a.n_model : a.n_scene);
   if (n > TSD_MAX_ICP_POINTS) return set_error(ctx, TSD_E_CAPACITY, "icp points > TSD_MAX_ICP_POINTS", hipSuccess);
   const int cap = icp_cap_for(n);
-  const size_t lds = icp_lds_bytes_for(cap);
   const int nthr = a.beams > 0 ? a.beams : a.n_scene;     // scene points decide the thread count
   switch (ctx->icp_shape) {      // TSD_ICP_SHAPE: experiments only
-    case 2: return launch_icp_shape<2, 576>(ctx, a, nthr, cap, lds, P_dev, d_rays_local, d_ranges, d_mask);
-    case 5: return launch_icp_shape<5, 256>(ctx, a, nthr, cap, lds, P_dev, d_rays_local, d_ranges, d_mask);
-    case 8: return launch_icp_shape<8, 256>(ctx, a, nthr, cap, lds, P_dev, d_rays_local, d_ranges, d_mask);
+    case 2: return launch_icp_shape<2, 576>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask);
+    case 5: return launch_icp_shape<5, 256>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask);
+    case 8: return launch_icp_shape<8, 256>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask);
     default: break;
   }
-  if (nthr <= 3 * 512) return launch_icp_shape<3, 512>(ctx, a, nthr, cap, lds, P_dev, d_rays_local, d_ranges, d_mask);
-  return launch_icp_shape<8, 256>(ctx, a, nthr, cap, lds, P_dev, d_rays_local, d_ranges, d_mask);
+  if (nthr <= 3 * 512) return launch_icp_shape<3, 512>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask);
+  return launch_icp_shape<8, 256>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask);
 }
 
-size_t icp_lds_bytes() { return icp_lds_bytes_for(TSD_MAX_ICP_POINTS); }
+size_t icp_lds_bytes() { return icp_lds_bytes_for(TSD_MAX_ICP_POINTS, 256); }
 
 }  // namespace tsd

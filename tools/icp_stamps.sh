@@ -20,7 +20,7 @@ for rep in range(3):
     ms, n = dg.profile_get("icp")
     tr = np.zeros((256, 4)); dg.lib.tsd_icp_trace(dg.h, tr.ctypes.data_as(capi._dp), 256)
     st = tr.reshape(-1)[-8:]
-    names = ["setup", "A nn", "BC reciprocal", "D sums1", "F sums2+trig", "G transform+ctl"]
+    names = ["setup+tier0", "A list", "BC reciprocal", "D sums1", "F sums2+trig", "G transform+ctl"]
     tot = st[:6].sum()
     print("phase A cycles per step:", np.diff(np.concatenate([[0], tr[:30, 2]])).astype(int).tolist())
     print("searched points per step:", np.diff(np.concatenate([[0], tr[:30, 1]])).astype(int).tolist())
