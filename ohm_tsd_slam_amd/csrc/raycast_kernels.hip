@@ -3,26 +3,171 @@
 //
 // One 64-lane wavefront per beam.  The reference marches a beam one cell at a time with
 // `position += ray` (REPEATED fp64 addition, :246-247) and looks for the first sign change of the
-// bilinearly interpolated TSD.  The event at step k only depends on the samples of steps k-1 and k,
-// so 64 consecutive steps are sampled by the 64 lanes at once and the first event is found with a
-// ballot.  To stay bit-identical with the reference's accumulated rounding, the positions themselves
-// are produced by the same chain of additions, run redundantly (wave-uniform) by all lanes; each
-// lane keeps the value of its own step.  The coarse 32-cell skip loop (:225-236) is handled the same
-// way.  The four normal look-ups of TsdGrid::interpolateNormal (TsdGrid.cpp:517-546) run on 4 lanes.
+// bilinearly interpolated TSD.  The event at step k only depends on the samples of steps k-1 and k, so
+// a round samples 64 x RC_S consecutive steps at once (each lane RC_S of them, all their loads in
+// flight together) and finds the first event with a ballot.
+//
+// The positions must carry the reference's accumulated rounding bit for bit.  A serial chain of 1200
+// dependent additions per beam would cost more than everything else, so it is evaluated in closed
+// form: while a coordinate p stays inside one binade [2^e, 2^(e+1)) every representable value is a
+// multiple of u = ulp, and fl(p + r) = p + rhat with rhat = r rounded to a multiple of u (the rounding
+// of each addition is the same constant unless r/u ends in exactly .5, where ties-to-even alternates).
+// A beam crosses at most a handful of binades, so per coordinate a short table of segments
+// (first step, anchor value, rhat) is built once per beam -- the crossing step itself is a genuine fp64
+// addition -- and step k is fma(k - n0, rhat, anchor), exact because the result is representable.  The
+// loop counter `i += 1.0` of the reference (it decides how many steps run) goes through the same
+// machinery.  Beams that hit the .5 case or need more than RC_MAXSEG segments (coordinates within a few
+// ulps of zero) take the serial chain instead (slow path of the kernel, same results).
+//
+// The coarse 32-cell skip loop (:225-236) samples one position per lane; the four normal look-ups of
+// TsdGrid::interpolateNormal (TsdGrid.cpp:517-546) run on 4 lanes.
 //
 // Latency-bound gather (L2 / Infinity-Cache resident tiles): reported as time, not as a roofline.
 #include "tsd_ctx.hpp"
 
 namespace tsd {
 
+constexpr int RC_S = 4;            // steps per lane and round (256 steps per round)
+constexpr int RC_MAXSEG = 16;
+
+struct RcSeg { double anchor, rhat; int n0, pad; };
+struct __attribute__((aligned(8))) Cell2 { double a, b; };      // two neighbouring cells of a tile row
+
+// exponent field of a positive normal double, -1 otherwise
+__device__ __forceinline__ int binade_of(double p)
+{
+  const unsigned long long b = (unsigned long long)__double_as_longlong(p);
+  const int ef = (int)((b >> 52) & 0x7ffu);
+  if ((b >> 63) != 0ull || ef == 0 || ef == 0x7ff) return -1;
+  return ef;
+}
+
+__device__ __forceinline__ double pow2_from_field(int ef)      // 2^(ef - 1023) for a normal exponent field
+{
+  return __longlong_as_double((long long)ef << 52);
+}
+
+// Segment table of the chain v_0 = p0, v_{n+1} = fl(v_n + r) for n < N.  Wave-uniform; every lane
+// computes it, lane 0 stores it.  Returns false if the closed form is not applicable.
+__device__ bool build_segments(double p0, double r, int N, RcSeg* seg, int& nseg, int lane)
+{
+  nseg = 0;
+  int n = 0;
+  double p = p0;
+  while (n <= N) {
+    if (nseg >= RC_MAXSEG) return false;
+    const int ef = binade_of(p);
+    double rhat = 0.0;
+    long long M = 0;                       // steps n+1 .. n+M stay in the binade and follow the closed form
+    if (ef > 53 && ef < 0x7fe) {
+      const double lo = pow2_from_field(ef), hi = pow2_from_field(ef + 1);
+      const double u = pow2_from_field(ef - 52), uinv = pow2_from_field(2046 - (ef - 52));   // ulp and 1/ulp
+      const double q = r * uinv;                         // r / ulp, exact (power-of-two scaling)
+      const double rq = rint(q);
+      if (fabs(q - rq) == 0.5) return false;             // ties-to-even would alternate: serial chain
+      rhat = rq * u;
+      // common case: the rest of the beam stays inside this binade (fma is exact for in-binade values)
+      const double pend = fma((double)(N - n), rhat, p);
+      if ((rhat >= 0.0 && pend < hi) || (rhat < 0.0 && pend > lo)) {
+        if (lane == 0) { seg[nseg].anchor = p; seg[nseg].rhat = rhat; seg[nseg].n0 = n; seg[nseg].pad = 0; }
+        nseg++;
+        return true;
+      }
+      if (rhat > 0.0) {
+        // values strictly below 2^(e+1) were rounded on this binade's grid.  The estimate uses the
+        // hardware reciprocal; the two loops make the count exact whatever its error.
+        double t = floor((hi - p) * __builtin_amdgcn_rcp(rhat));
+        if (!(t < 4.0e9)) t = 4.0e9;
+        if (!(t >= 0.0)) t = 0.0;
+        M = (long long)t;
+        while (M > 0 && !(fma((double)M, rhat, p) < hi)) M--;
+        while (M < 4000000000ll && fma((double)(M + 1), rhat, p) < hi) M++;
+      } else if (rhat < 0.0) {
+        // going down, a value that lands exactly on 2^e may have been rounded on the finer grid below:
+        // stay strictly above it
+        double t = floor((p - lo) * __builtin_amdgcn_rcp(-rhat));
+        if (!(t < 4.0e9)) t = 4.0e9;
+        if (!(t >= 0.0)) t = 0.0;
+        M = (long long)t;
+        while (M > 0 && !(fma((double)M, rhat, p) > lo)) M--;
+        while (M < 4000000000ll && fma((double)(M + 1), rhat, p) > lo) M++;
+      } else {
+        M = 4000000000ll;
+      }
+    }
+    if (lane == 0) { seg[nseg].anchor = p; seg[nseg].rhat = rhat; seg[nseg].n0 = n; seg[nseg].pad = 0; }
+    nseg++;
+    if ((long long)n + M >= (long long)N) break;
+    const double pm = fma((double)M, rhat, p);           // last value of the segment (exact)
+    p = pm + r;                                          // the crossing step is a genuine addition
+    n += (int)M + 1;
+  }
+  return true;
+}
+
+// A loop counter i_0 = p0, i += step with step a small power of two (1.0 or 32.0) and 0 <= i < 2^40: the
+// step is a multiple of every ulp in range, so inside a binade i_n = anchor + m * step exactly and only the
+// crossings round.  One pass over the (at most ~14) binades, in registers: returns the number of
+// iterations n = 0, 1, ... with i_n <= limit (or < limit when `strict`) and the value i_k of iteration k.
+__device__ __forceinline__ int counter_chain(double p0, double step, double inv_step, double limit, bool strict,
+                                             int k, double& value_k, bool& ok)
+{
+  int count = 0, n = 0;
+  double p = p0;
+  value_k = p0;
+  ok = true;
+  for (int it = 0; it < 64; it++) {
+    const int ef = binade_of(p);
+    double M = 0.0;                                        // iterations n+1 .. n+M stay in the binade
+    if (ef > 0 && ef < 1023 + 40) {
+      if (pow2_from_field(ef > 52 ? ef - 52 : 1) > step) { ok = false; return 0; }   // (no grid is that large)
+      const double hi = pow2_from_field(ef + 1);
+      M = fmax(ceil((hi - p) * inv_step) - 1.0, 0.0);      // p + m*step < hi, all exact
+    }
+    const int Mi = (int)fmin(M, 1.0e9);
+    if (k >= n && k <= n + Mi) value_k = fma((double)(k - n), step, p);
+    const bool in = strict ? (p < limit) : (p <= limit);
+    if (!in) break;                                        // count == n: every earlier iteration passed
+    // last m in [0, M] with p + m*step inside the limit: estimate, then make it exact (fma is exact here)
+    double mm = fmin(floor((limit - p) * inv_step), M);
+    if (!(mm >= 0.0)) mm = 0.0;
+    if (strict) {
+      while (mm > 0.0 && !(fma(mm, step, p) < limit)) mm -= 1.0;
+      while (mm < M && fma(mm + 1.0, step, p) < limit) mm += 1.0;
+    } else {
+      while (mm > 0.0 && !(fma(mm, step, p) <= limit)) mm -= 1.0;
+      while (mm < M && fma(mm + 1.0, step, p) <= limit) mm += 1.0;
+    }
+    if (mm < M) { count = n + (int)mm + 1; break; }        // the limit falls inside this binade
+    count = n + Mi + 1;
+    p = fma(M, step, p) + step;                            // the crossing step is a genuine addition
+    n += Mi + 1;
+  }
+  return count;
+}
+
+__device__ __forceinline__ double seg_value(const RcSeg* seg, int nseg, int k)
+{
+  int s = 0;
+  for (int j = 1; j < nseg; j++) if (seg[j].n0 <= k) s = j;
+  return fma((double)(k - seg[s].n0), seg[s].rhat, seg[s].anchor);
+}
+
 __global__ void __launch_bounds__(64)
 k_raycast(GridDev g, RaycastArgs a_val, const RaycastArgs* __restrict__ a_dev, const double* __restrict__ rays,
-          double* __restrict__ coords, double* __restrict__ normals, uint8_t* __restrict__ mask)
+          double* __restrict__ coords, double* __restrict__ normals, uint8_t* __restrict__ mask, double* dbg)
 {
+#ifdef TSD_RC_STAMPS   // diagnostic build: cycles per phase summed over beams into dbg[0..7], max beam total in dbg[8]
+  long long st_t = clock64(); const long long st_begin = st_t;
+#define RSTAMP(i) do { const long long now_ = clock64(); if (threadIdx.x == 0 && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 128) dbg[(blockIdx.x >> 3) * 8 + i] = (double)(now_ - st_t); st_t = now_; } while (0)
+#else
+#define RSTAMP(i) do {} while (0)
+#endif
   const RaycastArgs a = a_dev ? *a_dev : a_val;
   const int beam = blockIdx.x;
   const int lane = threadIdx.x;
   if (beam >= a.beams) return;
+  __shared__ RcSeg s_segx[RC_MAXSEG], s_segy[RC_MAXSEG];
   const double rx = rays[beam], ry = rays[a.beams + beam];
   const double trx = a.trx, try_ = a.try_;
   const double cs = g.cs;
@@ -44,15 +189,24 @@ k_raycast(GridDev g, RaycastArgs a_val, const RaycastArgs* __restrict__ a_dev, c
 
   // coarse traversal: for(i = idxMin; i < idxMax; i += 32) { if tile usable: break; else idxMin = i; }
   {
-    double i_run = idxMin;          // wave-uniform loop variable of the reference
+    double i_run = idxMin;          // wave-uniform loop variable of the reference (serial fall-back only)
+    bool cclosed = true;
     bool done = false;
-    while (!done) {
+    for (int cbase = 0; !done; cbase += 64) {
       double my_i = 0.0; bool my_act = false;
+      if (cclosed) {
+        bool okc;
+        const int cnt = counter_chain(idxMin, 32.0, 1.0 / 32.0, idxMax, true, cbase + lane, my_i, okc);
+        my_act = cbase + lane < cnt;
+        cclosed = __ballot(!okc) == 0ull;
+      }
+      if (!cclosed) {
 #pragma unroll 8
-      for (int s = 0; s < 64; s++) {
-        const bool act = i_run < idxMax;
-        if (lane == s) { my_i = i_run; my_act = act; }
-        i_run += 32.0;
+        for (int s = 0; s < 64; s++) {
+          const bool act = i_run < idxMax;
+          if (lane == s) { my_i = i_run; my_act = act; }
+          i_run += 32.0;
+        }
       }
       bool ok = false;
       if (my_act) {
@@ -74,52 +228,160 @@ k_raycast(GridDev g, RaycastArgs a_val, const RaycastArgs* __restrict__ a_dev, c
     }
   }
 
-  // fine march
-  double px = trx + idxMin * rx, py = try_ + idxMin * ry;   // wave-uniform running position
+  RSTAMP(0);
+  // fine march: position_0 = tr + idxMin * ray; for (i = idxMin; i <= idxMax; i += 1.0) { position += ray; ... }
+  const double px0 = trx + idxMin * rx, py0 = try_ + idxMin * ry;
+  const int cap = (int)fmin(fmax(idxMax - idxMin, 0.0), 1.0e6) + 2;     // more than the loop can run
+  int nsx = 0, nsy = 0;
+  // iterations of `for (i = idxMin; i <= idxMax; i += 1.0)`: the accumulated rounding of i is below 1e-9,
+  // so unless idxMax - idxMin is that close to an integer the count is floor(idxMax - idxMin) + 1; only
+  // then the exact chain decides
+  int nsteps_i; bool oki = true;
+  {
+    const double dspan = idxMax - idxMin, fl_ = floor(dspan), fr = dspan - fl_;
+    if (fr > 1e-9 && fr < 1.0 - 1e-9 && dspan < 1.0e9) nsteps_i = (int)fl_ + 1;
+    else { double dummy; nsteps_i = counter_chain(idxMin, 1.0, 1.0, idxMax, false, -1, dummy, oki); }
+  }
+  bool closed = oki;
+  closed = closed && build_segments(px0, rx, cap, s_segx, nsx, lane);
+  closed = closed && build_segments(py0, ry, cap, s_segy, nsy, lane);
+  __syncthreads();
+  RSTAMP(1);
+  const int nsteps = closed ? nsteps_i : 0;
+  RSTAMP(2);
+
   double carry;                                             // sample of the previous step (NaN = none)
   {
     double t0;
-    carry = (interpolate_bilinear(g, px, py, t0) == INTERP_SUCCESS) ? t0 : __builtin_nan("");
+    carry = (interpolate_bilinear(g, px0, py0, t0) == INTERP_SUCCESS) ? t0 : __builtin_nan("");
   }
-  double i_run = idxMin;
-  bool found = false;
+  bool found = false, ended = false;
   double hit_x = 0.0, hit_y = 0.0;
-  for (;;) {
-    double mx = 0.0, my = 0.0; bool my_act = false;
-#pragma unroll 8
-    for (int s = 0; s < 64; s++) {
-      const bool act = i_run <= idxMax;
-      px += rx; py += ry;
-      if (lane == s) { mx = px; my = py; my_act = act; }
-      i_run += 1.0;
-    }
-    double cur = __builtin_nan("");
-    if (my_act) {
-      double t;
-      if (interpolate_bilinear(g, mx, my, t) == INTERP_SUCCESS) cur = t;
-    }
-    double prev = __shfl_up(cur, 1, 64);
-    if (lane == 0) prev = carry;
-    const bool hit = my_act && (prev > 0 && cur < 0);
-    const bool miss = my_act && !hit && (prev < 0 && cur > 0);
-    const unsigned long long m_hit = __ballot(hit), m_miss = __ballot(miss);
-    const unsigned long long m_ev = m_hit | m_miss;
-    if (m_ev) {
-      const int f = __ffsll((long long)m_ev) - 1;
-      if ((m_hit >> f) & 1ull) {
-        // interp = tsd_prev / (tsd_prev - tsd); c = position + ray * (interp - 1)
-        const double interp = prev / (prev - cur);
-        const double cx = mx + rx * (interp - 1.0);
-        const double cy = my + ry * (interp - 1.0);
-        hit_x = __shfl(cx, f, 64);
-        hit_y = __shfl(cy, f, 64);
-        found = true;
+  RSTAMP(3);
+
+  if (closed) {
+    // the first two segments of each coordinate in registers (nearly every beam has at most two)
+    const RcSeg x0 = s_segx[0], x1 = s_segx[nsx > 1 ? 1 : 0], y0 = s_segy[0], y1 = s_segy[nsy > 1 ? 1 : 0];
+    const int x1n = nsx > 1 ? x1.n0 : 0x7fffffff, y1n = nsy > 1 ? y1.n0 : 0x7fffffff;
+    auto posx = [&](int k) {
+      if (nsx > 2) return seg_value(s_segx, nsx, k);
+      return k >= x1n ? fma((double)(k - x1n), x1.rhat, x1.anchor) : fma((double)k, x0.rhat, x0.anchor);
+    };
+    auto posy = [&](int k) {
+      if (nsy > 2) return seg_value(s_segy, nsy, k);
+      return k >= y1n ? fma((double)(k - y1n), y1.rhat, y1.anchor) : fma((double)k, y0.rhat, y0.anchor);
+    };
+    for (int base = 1; base <= nsteps && !found; base += 64 * RC_S) {
+      // sub-round j covers the 64 consecutive steps base + 64 j + lane (one per lane, so that a load
+      // instruction touches 64 neighbouring cells along the ray); every position by the closed form
+      double qx[RC_S], qy[RC_S], v[RC_S];
+      bool act[RC_S];
+      int st[RC_S]; size_t off[RC_S]; int tp[RC_S]; double wx[RC_S], wy[RC_S];
+#pragma unroll
+      for (int j = 0; j < RC_S; j++) {
+        const int k = base + 64 * j + lane;
+        qx[j] = posx(k); qy[j] = posy(k);
+        act[j] = k <= nsteps;
+        int p = 0, lx = 0, ly = 0; double dx = 0.0, dy = 0.0;
+        const bool inside = act[j] && coord2cell(g, qx[j], qy[j], p, lx, ly, dx, dy);
+        st[j] = inside ? INTERP_SUCCESS : INTERP_INVALIDINDEX;
+        tp[j] = inside ? p : 0;
+        off[j] = (size_t)tp[j] * TILE_STRIDE + (size_t)(inside ? ly * TILE_PITCH + lx : 0);
+        wx[j] = fabs((qx[j] - dx) * g.inv_cs);
+        wy[j] = fabs((qy[j] - dy) * g.inv_cs);
       }
-      break;
+      // the tile storage exists for every tile (only `flags` says whether it holds data), so the cell
+      // reads need not wait for the flag; each row pair is one 16-byte read
+      uint8_t fl[RC_S]; Cell2 r0[RC_S], r1[RC_S];
+#pragma unroll
+      for (int j = 0; j < RC_S; j++) {
+        fl[j] = g.flags[tp[j]];
+        const double* t = g.tsd + off[j];
+        r0[j] = *reinterpret_cast<const Cell2*>(t);
+        r1[j] = *reinterpret_cast<const Cell2*>(t + TILE_PITCH);
+      }
+#pragma unroll
+      for (int j = 0; j < RC_S; j++) {
+        double r = __builtin_nan("");
+        if (st[j] == INTERP_SUCCESS && fl[j]) {
+          r = r0[j].a * (1. - wy[j]) * (1. - wx[j]) + r1[j].a * wy[j] * (1. - wx[j])
+            + r0[j].b * (1. - wy[j]) * wx[j] + r1[j].b * wy[j] * wx[j];   // NaN stays NaN = "not SUCCESS"
+        }
+        v[j] = r;
+      }
+      // events in step order, sub-round by sub-round
+#pragma unroll
+      for (int j = 0; j < RC_S; j++) {
+        if (found) break;
+        const double cur = v[j];
+        double prev = __shfl_up(cur, 1, 64);
+        if (lane == 0) prev = carry;
+        const bool hit = act[j] && (prev > 0 && cur < 0);
+        const bool miss = act[j] && !hit && (prev < 0 && cur > 0);
+        const unsigned long long m_hit = __ballot(hit), m_miss = __ballot(miss);
+        const unsigned long long m_ev = m_hit | m_miss;
+        if (m_ev) {
+          const int f = __ffsll((long long)m_ev) - 1;
+          if ((m_hit >> f) & 1ull) {
+            // interp = tsd_prev / (tsd_prev - tsd); c = position + ray * (interp - 1)
+            const double interp = prev / (prev - cur);
+            const double cx = qx[j] + rx * (interp - 1.0);
+            const double cy = qy[j] + ry * (interp - 1.0);
+            hit_x = __shfl(cx, f, 64);
+            hit_y = __shfl(cy, f, 64);
+            found = true;
+          }
+          ended = true;
+          break;
+        }
+        carry = __shfl(cur, 63, 64);
+      }
+      if (ended) break;
     }
-    if (__ballot(my_act) != ~0ull) break;       // i > idxMax reached inside this round
-    carry = __shfl(cur, 63, 64);
+  } else {
+    // serial chain (rare): 64 steps per round, positions by the reference's own additions
+    double px = px0, py = py0;
+    double i_run = idxMin;
+    for (;;) {
+      double mx = 0.0, my = 0.0; bool my_act = false;
+#pragma unroll 8
+      for (int s = 0; s < 64; s++) {
+        const bool act = i_run <= idxMax;
+        px += rx; py += ry;
+        if (lane == s) { mx = px; my = py; my_act = act; }
+        i_run += 1.0;
+      }
+      double cur = __builtin_nan("");
+      if (my_act) {
+        double t;
+        if (interpolate_bilinear(g, mx, my, t) == INTERP_SUCCESS) cur = t;
+      }
+      double prev = __shfl_up(cur, 1, 64);
+      if (lane == 0) prev = carry;
+      const bool hit = my_act && (prev > 0 && cur < 0);
+      const bool miss = my_act && !hit && (prev < 0 && cur > 0);
+      const unsigned long long m_hit = __ballot(hit), m_miss = __ballot(miss);
+      const unsigned long long m_ev = m_hit | m_miss;
+      if (m_ev) {
+        const int f = __ffsll((long long)m_ev) - 1;
+        if ((m_hit >> f) & 1ull) {
+          const double interp = prev / (prev - cur);
+          const double cx = mx + rx * (interp - 1.0);
+          const double cy = my + ry * (interp - 1.0);
+          hit_x = __shfl(cx, f, 64);
+          hit_y = __shfl(cy, f, 64);
+          found = true;
+        }
+        break;
+      }
+      if (__ballot(my_act) != ~0ull) break;       // i > idxMax reached inside this round
+      carry = __shfl(cur, 63, 64);
+    }
   }
+  RSTAMP(4);
+#ifdef TSD_RC_STAMPS
+  if (lane == 0 && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 128) dbg[(blockIdx.x >> 3) * 8 + 6] = closed ? 0.0 : 1.0;
+#endif
   if (!found) { if (lane == 0) mask[beam] = 0; return; }
 
   // TsdGrid::interpolateNormal: lanes 0..3 sample (x+cs,y) (x-cs,y) (x,y+cs) (x,y-cs)
@@ -148,13 +410,17 @@ k_raycast(GridDev g, RaycastArgs a_val, const RaycastArgs* __restrict__ a_dev, c
     normals[2 * beam] = n0; normals[2 * beam + 1] = n1;
     mask[beam] = 1;
   }
+  RSTAMP(5);
+#ifdef TSD_RC_STAMPS
+  if (lane == 0 && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 128) dbg[(blockIdx.x >> 3) * 8 + 7] = (double)(clock64() - st_begin);
+#endif
 }
 
 int launch_raycast(tsd_ctx* ctx, const RaycastArgs& a, const RaycastArgs* a_dev, const double* d_rays)
 {
   ScopedKernelTimer t(ctx, "raycast");
   hipLaunchKernelGGL(k_raycast, dim3(a.beams), dim3(64), 0, ctx->stream, ctx->grid, a, a_dev, d_rays ? d_rays : ctx->d_rays,
-                     ctx->d_coords, ctx->d_normals, ctx->d_mask_m);
+                     ctx->d_coords, ctx->d_normals, ctx->d_mask_m, ctx->d_icp_trace);
   TSD_HIP_CHECK(ctx, hipGetLastError());
   return TSD_OK;
 }
