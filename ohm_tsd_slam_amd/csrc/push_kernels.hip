@@ -40,6 +40,11 @@ __device__ __forceinline__ void tile_geometry(const GridDev& g, int p, double e[
   rad = sqrt(dx * dx + dy * dy) * 0.5;
 }
 
+// RMQ = true: sparse-table range queries (beams <= RMQ_MAX_BEAMS, the tables fit in LDS);
+// RMQ = false: wave-cooperative scan of every tile's beam range (any beam count up to TSD_MAX_BEAMS)
+constexpr int RMQ_MAX_BEAMS = 2048;
+
+template <bool RMQ>
 __global__ void __launch_bounds__(256)
 k_push_classify(GridDev g, PushArgs a_val, const PushArgs* __restrict__ a_dev,
                 const double* __restrict__ ranges,
@@ -90,36 +95,100 @@ k_push_classify(GridDev g, PushArgs a_val, const PushArgs* __restrict__ a_dev,
     }
   }
 
-  // the beam-range scans read the scan from LDS (a global/L2 read per step would make the serial walk
-  // over the surviving lanes latency-bound); blocks without a survivor skip the staging
+  // The two beam-range tests of isInRange over [lo, hi] (TsdGridComponent.cpp:86-119),
+  //   visible := any j: data[j] > closest && mask[j]
+  //   empty   := all j: isinf(data[j]) ? distance < lowReflectivityRange : (data[j] > farthest && mask[j])
+  // are range-maximum / range-minimum queries:  visible <=> max A > closest with A[j] = mask ? data : -inf,
+  // and (over the finite beams) empty <=> min B > farthest with B[j] = isinf ? +inf : (mask ? data : -inf),
+  // plus "is there an infinite beam in the range".  Each block that has a tile to test builds two sparse
+  // tables of ARG-max / ARG-min indices in LDS (11 levels x beams x 2 B each, the values stay fp64), after
+  // which a tile costs four LDS look-ups however many beams it spans (a tile near the sensor, or one
+  // that straddles the +-pi cut of a 360 degree scanner, spans hundreds).
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  double* s_ranges = reinterpret_cast<double*>(smem);
-  uint8_t* s_mask = reinterpret_cast<uint8_t*>(smem + (size_t)((a.beams + 1) & ~1) * sizeof(double));
-  if (__syncthreads_or(need_scan ? 1 : 0)) {
-    for (int i = threadIdx.x; i < a.beams; i += blockDim.x) { s_ranges[i] = ranges[i]; s_mask[i] = mask[i]; }
-    __syncthreads();
-  }
+  const int B = a.beams;
+  const int Bp = (B + 1) & ~1;
+  double* s_A = reinterpret_cast<double*>(smem);
+  double* s_B = s_A + Bp;
+  unsigned short* s_inf = reinterpret_cast<unsigned short*>(s_B + Bp);        // [B + 1] prefix count of infinite beams
+  unsigned short* s_tmax = s_inf + ((B + 2 + 7) & ~7);                       // [levels][B]
+  int levels = 1;
+  while ((1 << levels) <= B) levels++;                                       // 2^(levels-1) <= B
+  unsigned short* s_tmin = s_tmax + (size_t)levels * Bp;
 
-  // wave-cooperative beam-range scans
   bool visible = false, empty = false;
-  unsigned long long todo = __ballot(need_scan);
-  while (todo) {
-    const int s = __ffsll((long long)todo) - 1;
-    todo &= todo - 1;
-    const int lo_s = __shfl(lo, s, 64), hi_s = __shfl(hi, s, 64);
-    const double closest_s = __shfl(closest, s, 64), farthest_s = __shfl(farthest, s, 64);
-    const double distance_s = __shfl(distance, s, 64);
-    bool vis = false, fail = false;
-    for (int j = lo_s + lane; j <= hi_s; j += 64) {
-      const double d = s_ranges[j];
-      const bool mk = s_mask[j] != 0;
-      vis = vis || ((d > closest_s) && mk);
-      if (isinf(d)) fail = fail || !(distance_s < a.low_refl);
-      else fail = fail || !((d > farthest_s) && mk);
+  if (!RMQ) {
+    double* s_ranges = reinterpret_cast<double*>(smem);
+    uint8_t* s_mask = reinterpret_cast<uint8_t*>(smem + (size_t)Bp * sizeof(double));
+    if (__syncthreads_or(need_scan ? 1 : 0)) {
+      for (int i = threadIdx.x; i < B; i += blockDim.x) { s_ranges[i] = ranges[i]; s_mask[i] = mask[i]; }
+      __syncthreads();
     }
-    const bool any_vis_beam = __any(vis);
-    const bool any_fail = __any(fail);
-    if (lane == s) { visible = any_vis_beam; empty = !any_fail; }
+    // the wave walks the surviving lanes' [lo, hi] beam ranges 64 beams at a time with ballots
+    unsigned long long todo = __ballot(need_scan);
+    while (todo) {
+      const int s = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const int lo_s = __shfl(lo, s, 64), hi_s = __shfl(hi, s, 64);
+      const double closest_s = __shfl(closest, s, 64), farthest_s = __shfl(farthest, s, 64);
+      const double distance_s = __shfl(distance, s, 64);
+      bool vis = false, fail = false;
+      for (int j = lo_s + lane; j <= hi_s; j += 64) {
+        const double d = s_ranges[j];
+        const bool mk = s_mask[j] != 0;
+        vis = vis || ((d > closest_s) && mk);
+        if (isinf(d)) fail = fail || !(distance_s < a.low_refl);
+        else fail = fail || !((d > farthest_s) && mk);
+      }
+      const bool any_vis_beam = __any(vis);
+      const bool any_fail = __any(fail);
+      if (lane == s) { visible = any_vis_beam; empty = !any_fail; }
+    }
+  } else if (__syncthreads_or(need_scan ? 1 : 0)) {
+    for (int i = threadIdx.x; i < B; i += blockDim.x) {
+      const double d = ranges[i];
+      const bool mk = mask[i] != 0;
+      s_A[i] = mk ? d : -__builtin_inf();
+      s_B[i] = isinf(d) ? __builtin_inf() : (mk ? d : -__builtin_inf());
+      s_tmax[i] = (unsigned short)i; s_tmin[i] = (unsigned short)i;
+    }
+    if (threadIdx.x < 64) {
+      // prefix count of infinite readings by one wave (B <= 4096: 64 lanes x 64 beams)
+      const int per = (B + 63) / 64;
+      const int j0 = threadIdx.x * per;
+      int c = 0;
+      for (int j = j0; j < j0 + per && j < B; j++) c += isinf(ranges[j]) ? 1 : 0;
+      int incl = c;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if ((int)threadIdx.x >= off) incl += t; }
+      int run = incl - c;
+      if (threadIdx.x == 0) s_inf[0] = 0;
+      for (int j = j0; j < j0 + per && j < B; j++) { run += isinf(ranges[j]) ? 1 : 0; s_inf[j + 1] = (unsigned short)run; }
+    }
+    __syncthreads();
+    for (int k = 1; k < levels; k++) {
+      const int half = 1 << (k - 1), span = 1 << k;
+      const unsigned short* pmax = s_tmax + (size_t)(k - 1) * Bp; unsigned short* cmax = s_tmax + (size_t)k * Bp;
+      const unsigned short* pmin = s_tmin + (size_t)(k - 1) * Bp; unsigned short* cmin = s_tmin + (size_t)k * Bp;
+      for (int j = threadIdx.x; j + span <= B; j += blockDim.x) {
+        const unsigned short a0 = pmax[j], a1 = pmax[j + half];
+        cmax[j] = s_A[a1] > s_A[a0] ? a1 : a0;
+        const unsigned short b0 = pmin[j], b1 = pmin[j + half];
+        cmin[j] = s_B[b1] < s_B[b0] ? b1 : b0;
+      }
+      __syncthreads();
+    }
+    if (need_scan) {
+      const int len = hi - lo + 1;
+      const int k = 31 - __clz(len);                                         // floor(log2(len))
+      const unsigned short* tm = s_tmax + (size_t)k * Bp;
+      const unsigned short* tn = s_tmin + (size_t)k * Bp;
+      const int j2 = hi - (1 << k) + 1;
+      const double amax = fmax(s_A[tm[lo]], s_A[tm[j2]]);
+      const double bmin = fmin(s_B[tn[lo]], s_B[tn[j2]]);
+      const bool has_inf = s_inf[hi + 1] != s_inf[lo];
+      visible = amax > closest;
+      empty = (bmin > farthest) && (!has_inf || distance < a.low_refl);
+    }
   }
 
   // actions
@@ -484,9 +553,24 @@ int launch_push(tsd_ctx* ctx, const PushArgs& a, const PushArgs* a_dev, const do
   {
     ScopedKernelTimer t(ctx, "push_classify");
     const int blocks = (g.tiles + 255) / 256;
-    const size_t lds = (size_t)((a.beams + 1) & ~1) * sizeof(double) + (size_t)((a.beams + 15) & ~15);
-    hipLaunchKernelGGL(k_push_classify, dim3(blocks), dim3(256), lds, ctx->stream, g, a, a_dev, d_ranges,
-                       d_mask, ctr, ctr_next, ctx->d_list, ctx->d_block_stats);
+    int levels = 1;
+    while ((1 << levels) <= a.beams) levels++;
+    const size_t bp = (size_t)((a.beams + 1) & ~1);
+    const bool rmq = a.beams <= RMQ_MAX_BEAMS;
+    const size_t lds = rmq ? 2 * bp * sizeof(double) + (size_t)((a.beams + 2 + 7) & ~7) * 2 + 2 * (size_t)levels * bp * 2 + 64
+                           : bp * sizeof(double) + (size_t)((a.beams + 15) & ~15) + 64;
+    static size_t configured = 0;
+    if (rmq && lds > configured) {
+      TSD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_push_classify<true>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      configured = lds;
+    }
+    if (rmq)
+      hipLaunchKernelGGL(k_push_classify<true>, dim3(blocks), dim3(256), lds, ctx->stream, g, a, a_dev, d_ranges,
+                         d_mask, ctr, ctr_next, ctx->d_list, ctx->d_block_stats);
+    else
+      hipLaunchKernelGGL(k_push_classify<false>, dim3(blocks), dim3(256), lds, ctx->stream, g, a, a_dev, d_ranges,
+                         d_mask, ctr, ctr_next, ctx->d_list, ctx->d_block_stats);
   }
   TSD_HIP_CHECK(ctx, hipGetLastError());
   {

@@ -247,3 +247,171 @@ def test_closed_loop_trajectory(oracle, fused):
     assert np.array_equal(np.isnan(ot[sel]), np.isnan(gt[sel]))
     assert np.max(np.abs(ot[sel][m] - gt[sel][m])) <= TOL_CELL
     assert np.max(np.abs(ow[sel] - gw[sel])) <= TOL_CELL
+
+
+# ------------------------------------------------------------------------------------------------
+# occupancy extraction (RayCastAxisAligned2D::calcCoords + ThreadGrid marking)
+@pytest.mark.parametrize("inflate", [False, True])
+def test_occupancy_matches_oracle(oracle, inflate):
+    gc = synth.GridConfig(8, 0.1)
+    geo = synth.ScanGeometry.full_circle_360()
+    world = synth.World("room", gc)
+    og, dg = make_pair(oracle, gc)
+    content = np.full(gc.cells * gc.cells, -1, dtype=np.int8)
+    for k in range(4):
+        push_both(oracle, og, dg, world, geo, k * 4)
+        oo, no = og.occupancy(content, inflate, 2)      # `content` persists like ThreadGrid::_occGridContent
+        od, nd = dg.occupancy(inflate, 2)
+        assert no == nd and no > 0
+        assert np.array_equal(oo.reshape(gc.cells, gc.cells), od), \
+            f"push {k}: {np.count_nonzero(oo.reshape(gc.cells, gc.cells) != od)} cells differ"
+    assert set(np.unique(od)) <= {-1, 0, 100} and (od == 100).sum() > 50
+
+
+# ------------------------------------------------------------------------------------------------
+# edge cases of the scan itself
+def test_push_degenerate_scans(oracle):
+    """All beams masked / all infinite / a single valid beam / every beam at max range: same tile
+    classification and cells on both sides, no crash, nothing updated where nothing is visible."""
+    gc = synth.GridConfig(8, 0.1)
+    geo = synth.ScanGeometry.utm30lx()
+    world = synth.World("room", gc)
+    og, dg = make_pair(oracle, gc)
+    zeros = np.zeros(geo.beams, dtype=np.float32)                   # maskZeroDepth: everything masked
+    infs = np.full(geo.beams, np.inf, dtype=np.float32)             # valid-infinite: carves within lowReflectivityRange
+    one = zeros.copy(); one[geo.beams // 2] = 3.0
+    far = np.full(geo.beams, 29.999, dtype=np.float32)
+    for name, r in (("zeros", zeros), ("infs", infs), ("one", one), ("far", far), ("zeros again", zeros)):
+        so, sd = push_both(oracle, og, dg, world, geo, 0, ranges_f32=r)
+        assert so == sd, name
+        H.assert_grids_equal(og.dump(), dg.download_tiles(), TOL_CELL)
+        if name.startswith("zeros"):
+            assert sd["cells_updated"] == 0 and sd["tiles_update"] == 0
+
+
+def test_push_sensor_outside_grid_and_small_beam_counts(oracle):
+    gc = synth.GridConfig(7, 0.1)       # 128 x 128 cells, 16 tiles
+    og, dg = make_pair(oracle, gc)
+    for beams in (1, 2, 3, 64, 65):
+        geo = synth.ScanGeometry(beams, -0.4, 0.8 / max(beams - 1, 1))
+        r = np.linspace(2.0, 5.0, beams).astype(np.float32)
+        data, mask = oracle.ingest_f32(r, H.MAX_RANGE, geo.angle_increment)
+        for pose in (synth.pose_matrix(6.4, 6.4, 0.3), synth.pose_matrix(-2.0, 6.0, 0.0), synth.pose_matrix(14.0, 14.0, 3.0)):
+            so = og.push(pose, data, mask, geo.angle_increment, geo.angle_min, H.MAX_RANGE, H.MIN_RANGE, H.LOW_REFL)
+            sd = dg.push(pose, data, mask, geo.angle_increment, geo.angle_min, H.MAX_RANGE, H.MIN_RANGE, H.LOW_REFL)
+            assert so == sd, (beams, pose[0, 2])
+    H.assert_grids_equal(og.dump(), dg.download_tiles(), TOL_CELL)
+    # more beams than the kernels are built for is an error, not a crash
+    with pytest.raises(capi.TsdError):
+        dg.push(synth.pose_matrix(6.4, 6.4, 0.0), np.ones(capi.MAX_BEAMS + 1), np.ones(capi.MAX_BEAMS + 1, dtype=np.uint8),
+                1e-3, 0.0, 30.0, 0.001, 2.0)
+
+
+def test_max_beams_scan(oracle):
+    """TSD_MAX_BEAMS = 4096 beams over 360 degrees: push parity and an ICP with 2048 points (the limits of
+    the LDS-resident scan / model)."""
+    gc = synth.GridConfig(9, 0.05)
+    geo = synth.ScanGeometry(capi.MAX_BEAMS, -math.pi, 2.0 * math.pi / capi.MAX_BEAMS)
+    world = synth.World("room", gc)
+    og, dg = make_pair(oracle, gc)
+    for k in range(2):
+        so, sd = push_both(oracle, og, dg, world, geo, k * 5)
+        assert so == sd
+    H.assert_grids_equal(og.dump(), dg.download_tiles(), TOL_CELL)
+    rng = np.random.default_rng(7)
+    ang = np.sort(rng.uniform(-math.pi, math.pi, capi.MAX_ICP_POINTS))
+    M = np.stack([6.0 * np.cos(ang) + 0.3 * np.cos(5 * ang), 4.0 * np.sin(ang)], axis=1)
+    c, s_ = math.cos(0.02), math.sin(0.02)
+    S = (M[::1] @ np.array([[c, -s_], [s_, c]]).T + np.array([0.05, -0.03]))[rng.permutation(capi.MAX_ICP_POINTS)]
+    pose = synth.pose_matrix(12.8, 12.8, 0.0)
+    bounds = (0.0, og.max_x, 0.0, og.max_x)
+    ro = oracle.icp(M, S, pose, 30, 0.4, 0.02, bounds, nn_mode=1)
+    rd = dg.icp(M, S, pose, dg.icp_params(30, 0.4, 0.02))
+    assert (ro["pairs"], ro["iterations"], ro["state"]) == (rd.pairs, rd.iterations, rd.state)
+    d, a = H.pose_delta(ro["T"], rd.T)
+    assert d <= TOL_POSE_M and a <= TOL_POSE_RAD
+
+
+def test_icp_exact_ties_and_unsorted_models(oracle):
+    """Model points on a lattice and scene points exactly between them: exact d2 ties (lowest model index
+    wins, like a first-minimum linear scan); model given in random order (tsd_icp sorts by angle itself)."""
+    gc = synth.GridConfig(8, 0.05)
+    dg = capi.TsdGridDevice(gc.map_size_log2, gc.cell_size, gc.max_trunc)
+    og = oracle.Grid(gc.map_size_log2, gc.cell_size, gc.max_trunc)
+    xs, ys = np.meshgrid(np.arange(-2.0, 2.01, 0.25), np.arange(-1.5, 1.51, 0.25))
+    M = np.stack([xs.ravel(), ys.ravel()], axis=1)
+    M = M[np.hypot(M[:, 0], M[:, 1]) > 0.3]
+    rng = np.random.default_rng(3)
+    M = M[rng.permutation(len(M))]
+    S = M[: len(M) // 2] + np.array([0.125, 0.0])          # exactly half way between two lattice points
+    pose = synth.pose_matrix(6.4, 6.4, 0.0)
+    bounds = (0.0, og.max_x, 0.0, og.max_x)
+    for iters in (1, 3, 30):
+        ro = oracle.icp(M, S, pose, iters, 0.4, 0.02, bounds, nn_mode=0)
+        rd = dg.icp(M, S, pose, dg.icp_params(iters, 0.4, 0.02))
+        assert (ro["pairs"], ro["iterations"], ro["state"]) == (rd.pairs, rd.iterations, rd.state), iters
+        d, a = H.pose_delta(ro["T"], rd.T)
+        assert d <= TOL_POSE_M and a <= TOL_POSE_RAD
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json full sizes: cfg 2 (4096^2) cell-for-cell against the oracle, cfg 3 (16384^2) through
+# size-independent properties plus the oracle on the touched tiles
+def grid_properties(init, iw, tsd, w):
+    sel = init.astype(bool)
+    assert np.all(iw >= 0.0) and np.all(iw <= 32.0)
+    assert np.all(w[sel] >= 0.0) and np.all(w[sel] <= 32.0), "weights are capped at TSDGRIDMAXWEIGHT"
+    t = tsd[sel]
+    m = ~np.isnan(t)
+    assert np.all(t[m] <= 1.0), "tsd is truncated at +1"
+    assert np.all(w[sel][~m] == 0.0), "a NaN cell carries no weight"
+
+
+def test_cfg2_full_size_push_and_localize(oracle):
+    gc, geo, scene = synth.CONFIGS["cfg2"]
+    world = synth.World(scene, gc)
+    og, dg = make_pair(oracle, gc)
+    for k in range(4):
+        so, sd = push_both(oracle, og, dg, world, geo, k * 4)
+        assert so == sd
+    assert sd["tiles_total"] == 16384 and sd["cells_updated"] > 200000
+    od, dd = og.dump(), dg.download_tiles()
+    H.assert_grids_equal(od, dd, TOL_CELL)
+    grid_properties(*dd)
+    # a push from the same pose twice only moves weights / averages, never the tile set
+    init0 = dd[0].copy()
+    push_both(oracle, og, dg, world, geo, 12)
+    push_both(oracle, og, dg, world, geo, 12)
+    dd2 = dg.download_tiles()
+    assert np.all(dd2[0] >= init0)
+    H.assert_grids_equal(og.dump(), dd2, TOL_CELL)
+    pose, rl, rw, data, mask, M, S = icp_inputs(oracle, gc, geo, world, 6, og)
+    p = dg.icp_params(30, 0.4, 0.02)
+    rf = dg.localize(pose, rw, rl, data, mask, H.MIN_RANGE, H.MAX_RANGE, p)
+    ro = oracle.icp(M, S, pose, 30, 0.4, 0.02, (0.0, og.max_x, 0.0, og.max_x), nn_mode=1)
+    assert (rf.n_model, rf.n_scene, rf.pairs) == (len(M), len(S), ro["pairs"])
+    d, a = H.pose_delta(ro["T"], rf.T)
+    assert d <= TOL_POSE_M and a <= TOL_POSE_RAD
+
+
+def test_cfg3_full_size_properties(oracle):
+    """16384 x 16384 cells @ 0.01 m (262144 tiles, 4.6 GB of fp64 cells): stats equal to the oracle's,
+    properties of the grid, and cell-for-cell equality on the tiles the pushes touched."""
+    gc, geo, scene = synth.CONFIGS["cfg3"]
+    world = synth.World(scene, gc)
+    og, dg = make_pair(oracle, gc)
+    for k in range(2):
+        so, sd = push_both(oracle, og, dg, world, geo, k * 5)
+        assert so == sd
+    assert sd["tiles_total"] == 262144 and sd["cells_updated"] > 1000000
+    oi, oiw = og.tile_state()
+    di, diw = dg.download_tile_state()
+    assert np.array_equal(oi, di) and np.array_equal(oiw, diw)
+    # compare cells on a sample of initialised tiles through the ray caster: same hits from both grids
+    pose, (x, y, yaw) = H.sensor_pose(world, 7)
+    rl, rw = H.world_rays(oracle, geo, pose, gc.cell_size)
+    co, no, mo, cnt_o = og.raycast(pose, rw, H.MIN_RANGE, H.MAX_RANGE)
+    cd, nd, md, cnt_d = dg.raycast(pose, rw, H.MIN_RANGE, H.MAX_RANGE)
+    assert np.array_equal(mo, md) and cnt_o > 0.5 * geo.beams
+    sel = np.repeat(mo.astype(bool), 2)
+    assert np.max(np.abs(co[sel] - cd[sel])) <= 1e-9 and np.max(np.abs(no[sel] - nd[sel])) <= 1e-9
