@@ -415,3 +415,61 @@ def test_cfg3_full_size_properties(oracle):
     assert np.array_equal(mo, md) and cnt_o > 0.5 * geo.beams
     sel = np.repeat(mo.astype(bool), 2)
     assert np.max(np.abs(co[sel] - cd[sel])) <= 1e-9 and np.max(np.abs(no[sel] - nd[sel])) <= 1e-9
+
+
+# ------------------------------------------------------------------------------------------------
+# committed golden vectors (tests/golden/oracle_*.npz): the HIP path against numbers fixed at commit
+# time, without calling the oracle
+def test_golden_push_raycast_icp_fixture():
+    import os
+    f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_push_raycast_icp.npz"))
+    dg = capi.TsdGridDevice(int(f["map_size_log2"]), float(f["cell_size"]), float(f["max_trunc"]))
+    res, phi = float(f["angle_increment"]), float(f["angle_min"])
+    from ohm_tsd_slam_amd import facade
+    import ctypes as C
+    HL = facade.load_library()
+    for k in range(len(f["push_poses"])):
+        r = np.ascontiguousarray(f["push_scans"][k], dtype=np.float32)
+        data = np.zeros(r.size); mask = np.zeros(r.size, dtype=np.uint8)
+        HL.tsd_host_sensor_ingest_f32(r.ctypes.data_as(C.POINTER(C.c_float)), r.size, res, phi, H.MAX_RANGE,
+                                      data.ctypes.data_as(C.POINTER(C.c_double)), mask.ctypes.data_as(C.POINTER(C.c_uint8)), 0)
+        st = dg.push(f["push_poses"][k], data, mask, res, phi, H.MAX_RANGE, H.MIN_RANGE, H.LOW_REFL)
+        assert [st[n] for n in sorted(st)] == list(f["push_stats"][k])
+    H.assert_grids_equal((f["init"], f["init_weight"], f["tsd"], f["weight"]), dg.download_tiles(), TOL_CELL)
+    cd, nd, md, cnt = dg.raycast(f["rc_pose"], f["rc_rays_world"], H.MIN_RANGE, H.MAX_RANGE)
+    assert np.array_equal(md, f["rc_mask"])
+    sel = np.repeat(md.astype(bool), 2)
+    assert np.max(np.abs(cd[sel] - f["rc_coords"][sel])) <= 1e-9 and np.max(np.abs(nd[sel] - f["rc_normals"][sel])) <= 1e-9
+    p = dg.icp_params(30, 0.4, 0.02)
+    rd = dg.icp(f["icp_model"], f["icp_scene"], f["rc_pose"], p)
+    assert (rd.pairs, rd.iterations, rd.state) == (int(f["icp_pairs"]), int(f["icp_iterations"]), int(f["icp_state"]))
+    d, a = H.pose_delta(f["icp_T"], rd.T)
+    assert d <= TOL_POSE_M and a <= TOL_POSE_RAD
+    tr = dg.icp_trace(rd.iterations)
+    assert np.array_equal(tr[:, 0], f["icp_trace"][:, 0]), "pairs per step"
+    assert np.max(np.abs(tr[:, 1] - f["icp_trace"][:, 1])) <= 1e-9, "mean squared distance per step"
+    # fused localize on the same inputs
+    rf = dg.localize(f["rc_pose"], f["rc_rays_world"], f["rc_rays_local"], f["icp_ranges"], f["icp_mask"], H.MIN_RANGE,
+                     H.MAX_RANGE, p)
+    assert (rf.pairs, rf.n_model, rf.n_scene) == (int(f["icp_pairs"]), len(f["icp_model"]), len(f["icp_scene"]))
+
+
+def test_golden_trajectory_fixture():
+    import os
+    f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_trajectory.npz"))
+    from ohm_tsd_slam_amd import facade
+    gc = synth.GridConfig(int(f["map_size_log2"]), float(f["cell_size"]))
+    geo = synth.ScanGeometry.full_circle_360()
+    # the facade receives angle_min / angle_increment as float32 like a LaserScan; the fixture was made with
+    # the double geometry, so poses are compared at the tolerance, flags and counts exactly
+    node = facade.SlamNode(facade.node_params(gc, geo), synchronous=True)
+    for k in range(len(f["scans"])):
+        node.laser(f["scans"][k], geo.angle_min, geo.angle_increment)
+        rep = node.report()
+        row = f["rows"][k]
+        d, a = H.pose_delta(row[:9].reshape(3, 3), rep["pose"])
+        assert d <= TOL_POSE_M and a <= TOL_POSE_RAD, f"scan {k}"
+        assert (int(row[11]), int(row[12])) == (rep["pushed"], rep["reg_error"])
+    init, _ = node.grid().download_tile_state()
+    assert np.array_equal(init, f["init"])
+    node.close()
