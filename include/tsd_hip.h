@@ -201,7 +201,7 @@ int tsd_occupancy_dev(tsd_ctx* ctx, void* occ_dev, int inflate, int inflate_fact
 
 /* ---- measurement ----------------------------------------------------------------------------- */
 /* Per-kernel HIP-event timing on the ctx stream.  Kernel names: "push_classify", "push_update",
- * "push_halo", "raycast", "icp", "scan_post", "occupancy". */
+ * "push_halo", "raycast", "icp", "occupancy". */
 int tsd_profile_enable(tsd_ctx* ctx, int on);
 /* restrict timing to a comma separated list of kernel names, or "all"; a "/n" suffix times every n-th
  * launch only (two event records cost ~13 us of stream time per timed launch) */

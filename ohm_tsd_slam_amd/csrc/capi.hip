@@ -25,7 +25,7 @@ int set_error(tsd_ctx* ctx, int code, const char* what, hipError_t e)
   return code;
 }
 
-static const char* const kKernelNames[] = {"push_classify", "push_update", "push_halo", "raycast", "icp", "occupancy", "scan_post"};
+static const char* const kKernelNames[] = {"push_classify", "push_update", "push_halo", "raycast", "icp", "occupancy"};
 
 bool kernel_is_timed(const tsd_ctx* ctx, const char* name)
 {
@@ -787,11 +787,14 @@ int tsd_scan(tsd_sensor* s, const double* ranges, const uint8_t* mask, const uin
   const double ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   fill_icp_args(ia, ident, params);
   ia.beams = s->beams; ia.ccw = s->ccw ? 1 : 0;
-  rc = launch_icp(ctx, ia, s->d_state->icpP, s->d_rays_local, d_ranges, d_mask);
-  if (rc != TSD_OK) return rc;
-  GateArgs ga{gates->reg_trs_max, gates->reg_sin_rot_max, gates->trs_min, gates->rot_min};
+  // the gates, Sensor::transform and the push decision run as the epilogue of the registration kernel
   const unsigned long long seq = ++s->seq;
-  rc = launch_scan_post(ctx, s->d_state, s->d_rays, s->beams, ga, s->d_result, seq);
+  ScanPostArgs sp;
+  std::memset(&sp, 0, sizeof(sp));
+  sp.st = s->d_state; sp.rays = s->d_rays; sp.out = s->d_result; sp.seq = seq; sp.beams = s->beams;
+  sp.gmin_x = ctx->grid.min_x; sp.gmax_x = ctx->grid.max_x; sp.gmin_y = ctx->grid.min_y; sp.gmax_y = ctx->grid.max_y;
+  sp.gates = GateArgs{gates->reg_trs_max, gates->reg_sin_rot_max, gates->trs_min, gates->rot_min};
+  rc = launch_icp(ctx, ia, s->d_state->icpP, s->d_rays_local, d_ranges, d_mask, &sp);
   if (rc != TSD_OK) return rc;
   PushArgs pa;
   std::memset(&pa, 0, sizeof(pa));

@@ -32,15 +32,16 @@
 //           whole wave: 64 consecutive slots per step with a DPP minimum, widened until proven.
 //
 // No dense contraction anywhere => no MFMA; fp64 VALU + LDS.  Latency-bound: reported as ms/iterate.
-#include "tsd_ctx.hpp"
+#include "scan_device.hpp"
 #include <climits>
+#include <cstring>
 
 namespace tsd {
 
 constexpr int ICP_MAXW = 16;                    // waves per workgroup at most
 constexpr double SLACK = 1.0 - 1e-9;            // conservative factor on every pruning bound
 constexpr int HW = 6;                           // tier-1 window: k-6 .. k+6
-constexpr int IR_CNT = 32, IR_RMAX = 33;   // words of IcpLds::ired
+constexpr int IR_CNT = 32, IR_RMAX = 33, IR_CNT2 = 34;   // words of IcpLds::ired
 #ifdef TSD_ICP_STAMPS
 constexpr int IR_DBG = 40;
 #endif
@@ -57,6 +58,7 @@ struct IcpLds {
   double* res_lb;                  // [lcap]          lower bound (distance) to every other model point
   int* res_k;                      // [lcap]          neighbour slot (-1: unresolved)
   int* res_k2;                     // [lcap]          runner-up slot
+  int* list2;                      // [lcap] entries the window could not prove (tier 2 work list)
   double* red;                     // [2][ICP_MAXW][16] wave partials of the pair sums, per-wave broadcast rows
   double* cst;                     // [16] IcpArgs scalars (kept out of the scalar register file)
   double* tr;                      // [T][NSUMP] transpose buffer of the pair sums (aliases the work list)
@@ -67,10 +69,10 @@ struct IcpLds {
 };
 
 __host__ __device__ inline int icp_list_cap(int cap) { return cap < 1024 ? cap : 1024; }
-// bytes of the region shared by the work list (44 B per entry), the setup staging and the transpose buffer
+// bytes of the region shared by the work list (48 B per entry), the setup staging and the transpose buffer
 __host__ __device__ inline size_t icp_region_bytes(int cap, int threads)
 {
-  size_t b = 44u * (size_t)icp_list_cap(cap);
+  size_t b = 48u * (size_t)icp_list_cap(cap);
   const size_t tr = (size_t)threads * 9u * sizeof(double);
   if (tr > b) b = tr;
   return (b + 15u) & ~(size_t)15u;
@@ -215,8 +217,10 @@ __device__ __forceinline__ NnResult wave_search(const IcpLds& L, int nM, double 
       d = dx * dx + dy * dy;
       l2 = sep_bound(x, y, rs2, u, cr);
     }
-    // the three smallest of this window (exact ties: lowest original index first), merged into the run
+    // the three smallest of this window (exact ties: lowest original index first), merged into the run.
+    // While nothing lies within the filter distance only the bound matters: one rank, entered three times.
     double dd = d;
+    const bool far_so_far = t.b1 > thr;
 #pragma unroll
     for (int rnk = 0; rnk < 3; rnk++) {
       const double wmin = wave_min(dd);
@@ -232,11 +236,15 @@ __device__ __forceinline__ NnResult wave_search(const IcpLds& L, int nM, double 
           if (mo < bo) { bo = mo; wl = l; }
         }
       }
-      top3_insert(t, wmin, __builtin_amdgcn_readlane(k, wl));
+      const int wk = __builtin_amdgcn_readlane(k, wl);
+      top3_insert(t, wmin, wk);
+      if (rnk == 0 && far_so_far && wmin > thr) { top3_insert(t, wmin, wk); top3_insert(t, wmin, wk); break; }
       if (lane == wl) dd = __builtin_inf();
     }
     top3_tiebreak(L, t);
-    const double limit = fmin(t.b1, thr);
+    // the walk runs on until the bound exceeds 4x what exactness needs: the extra slots (evaluated 64 at a
+    // time anyway) buy a bound that survives the following steps
+    const double limit = 4.0 * fmin(t.b1, thr);
     const bool sc = act && l2 > limit;
     const unsigned long long bu = __ballot(sc && o >= 0 && cr * sgn >= 0.0);
     const unsigned long long bdn = __ballot(sc && o < 0 && cr * sgn <= 0.0);
@@ -309,7 +317,7 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
       const double* __restrict__ g_coords, const uint8_t* __restrict__ g_mask_m,
       const double* __restrict__ g_rays_local, const double* __restrict__ g_ranges,
       const uint8_t* __restrict__ g_mask, IcpResultDev* __restrict__ out,
-      double* __restrict__ trace /* [TSD_ICP_TRACE_MAX][4] = pairs, rms, thr_before, state */)
+      double* __restrict__ trace /* [TSD_ICP_TRACE_MAX][4] = pairs, rms, thr_before, state */, ScanPostArgs post)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   IcpLds L;
@@ -324,7 +332,8 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
     L.res_lb = reinterpret_cast<double*>(p); p += sizeof(double) * (size_t)lcap;
     L.list_k = reinterpret_cast<int*>(p); p += sizeof(int) * (size_t)lcap;
     L.res_k = reinterpret_cast<int*>(p); p += sizeof(int) * (size_t)lcap;
-    L.res_k2 = reinterpret_cast<int*>(p);
+    L.res_k2 = reinterpret_cast<int*>(p); p += sizeof(int) * (size_t)lcap;
+    L.list2 = reinterpret_cast<int*>(p);
     p = reinterpret_cast<char*>(L.list_xy) + icp_region_bytes(cap, (int)blockDim.x);
     // staging view of the same 40*lcap bytes: cap double2 then cap int (40*lcap >= 20*cap)
     L.start = reinterpret_cast<int*>(reinterpret_cast<char*>(L.stage_s) + sizeof(double2) * (size_t)cap);
@@ -396,7 +405,7 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
     __syncthreads();
   }
   if (tid == 0) {
-    L.ired[IR_CNT] = 0; L.ired[IR_RMAX] = 0;
+    L.ired[IR_CNT] = 0; L.ired[IR_RMAX] = 0; L.ired[IR_CNT2] = 0;
 #pragma unroll
     for (int i = 0; i < 6; i++) L.cst[i] = a.P[i];
     L.cst[6] = a.min_x; L.cst[7] = a.max_x; L.cst[8] = a.min_y; L.cst[9] = a.max_y;
@@ -410,11 +419,12 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
 
   if (nM == 0 || nS == 0 || nM > cap || nS > cap) {
     // Icp::iterate early-out (Icp.cpp:467-471); ThreadLocalize never gets here with nM == 0
-    if (tid == 0) {
-      for (int i = 0; i < 9; i++) out->T[i] = (i % 4 == 0) ? 1.0 : 0.0;
-      out->rms = 0.0; out->pairs = 0; out->iterations = 0; out->state = TSD_ICP_NOTMATCHABLE;
-      out->n_model = nM; out->n_scene = nS; out->reserved = (nM > cap || nS > cap) ? TSD_E_CAPACITY : 0;
-    }
+    IcpResultDev r;
+    for (int i = 0; i < 9; i++) r.T[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    r.rms = 0.0; r.pairs = 0; r.iterations = 0; r.state = TSD_ICP_NOTMATCHABLE;
+    r.n_model = nM; r.n_scene = nS; r.reserved = (nM > cap || nS > cap) ? TSD_E_CAPACITY : 0;
+    if (tid == 0) *out = r;
+    if (post.st) scan_post_body(post, r.T, r, post.gmin_x, post.gmax_x, post.gmin_y, post.gmax_y);
     return;
   }
 
@@ -534,35 +544,26 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
       __syncthreads();
       for (int e0 = wave * 64; e0 < n; e0 += T) {
         const int e = e0 + lane;
-        bool unresolved = false;
-#ifdef TSD_ICP_STAMPS
-        const long long ws0 = clock64();
-#endif
         if (e < n) {
           const double2 s = L.list_xy[e];
           const NnResult r = window_search(L, nM, s.x, s.y, L.list_k[e], thr, sgn);
           if (r.resolved) { L.res_d[e] = r.best; L.res_k[e] = r.bk; L.res_k2[e] = r.bk2; L.res_lb[e] = sqrt(r.lbsq) * SLACK; }
-          else unresolved = true;
+          else L.list2[atomicAdd(&L.ired[IR_CNT2], 1)] = e;      // tier 2, shared out over all waves below
         }
-        unsigned long long todo = __ballot(unresolved);
-#ifdef TSD_ICP_STAMPS
-        if (lane == 0) { atomicAdd(&L.ired[IR_DBG + 1], __popcll(todo)); }
-        if (tid == 0) { L.ired[IR_DBG + 2] += (int)(clock64() - ws0); L.ired[IR_DBG + 3] += 1; }
-        const long long ws1 = clock64();
-#endif
-        while (todo) {
-          const int src = __ffsll((long long)todo) - 1;
-          todo &= todo - 1;
-          const int es = e0 + src;
-          const double2 s = L.list_xy[es];
-          const NnResult r = wave_search(L, nM, s.x, s.y, L.list_k[es], thr, sgn, lane);
-          if (lane == 0) { L.res_d[es] = r.best; L.res_k[es] = r.bk; L.res_k2[es] = r.bk2; L.res_lb[es] = sqrt(r.lbsq) * SLACK; }
-        }
-#ifdef TSD_ICP_STAMPS
-        if (tid == 0) { L.ired[IR_DBG + 4] += (int)(clock64() - ws1); }
-#endif
       }
       __syncthreads();
+      const int n2 = L.ired[IR_CNT2];
+#ifdef TSD_ICP_STAMPS
+      if (tid == 0) L.ired[IR_DBG + 1] += n2;
+#endif
+      for (int i = wave; i < n2; i += W) {
+        const int es = L.list2[i];
+        const double2 s = L.list_xy[es];
+        const NnResult r = wave_search(L, nM, s.x, s.y, L.list_k[es], thr, sgn, lane);
+        if (lane == 0) { L.res_d[es] = r.best; L.res_k[es] = r.bk; L.res_k2[es] = r.bk2; L.res_lb[es] = sqrt(r.lbsq) * SLACK; }
+      }
+      __syncthreads();
+      if (tid == 0) L.ired[IR_CNT2] = 0;
 #pragma unroll
       for (int q = 0; q < R; q++)
         if (need[q] && ent[q] >= base && ent[q] < base + lcap) {
@@ -732,13 +733,17 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
     for (int i = 0; i < 8; i++) trace[4 * TSD_ICP_TRACE_MAX - 8 + i] = (double)st_acc[i];
   }
 #endif
-  if (tid == 0) {
+  {
     // Icp::getFinalTransformation (Icp.cpp:528-546)
-    out->T[0] = Tf[0]; out->T[1] = Tf[1]; out->T[2] = Tf[2];
-    out->T[3] = Tf[3]; out->T[4] = Tf[4]; out->T[5] = Tf[5];
-    out->T[6] = 0.0; out->T[7] = 0.0; out->T[8] = 1.0;
-    out->rms = rms; out->pairs = pairs; out->iterations = (int)iter; out->state = state;
-    out->n_model = nM; out->n_scene = nS; out->reserved = 0;
+    IcpResultDev r;
+    r.T[0] = Tf[0]; r.T[1] = Tf[1]; r.T[2] = Tf[2];
+    r.T[3] = Tf[3]; r.T[4] = Tf[4]; r.T[5] = Tf[5];
+    r.T[6] = 0.0; r.T[7] = 0.0; r.T[8] = 1.0;
+    r.rms = rms; r.pairs = pairs; r.iterations = (int)iter; r.state = state;
+    r.n_model = nM; r.n_scene = nS; r.reserved = 0;
+    if (tid == 0) *out = r;
+    // fused scan: gates, Sensor::transform, push / next-scan arguments, result record for the host
+    if (post.st) scan_post_body(post, r.T, r, post.gmin_x, post.gmax_x, post.gmin_y, post.gmax_y);
   }
 }
 
@@ -753,7 +758,8 @@ static int icp_cap_for(int n)
 // issue bound, so few waves (per-wave reduction / control cost paid once per SIMD) win.
 template <int R, int MAXT>
 static int launch_icp_shape(tsd_ctx* ctx, const IcpArgs& a, int n, int cap, const double* P_dev,
-                            const double* d_rays_local, const double* d_ranges, const uint8_t* d_mask)
+                            const double* d_rays_local, const double* d_ranges, const uint8_t* d_mask,
+                            const ScanPostArgs& post)
 {
   int T = ((n + R - 1) / R + 63) & ~63;
   if (T < 64) T = 64;
@@ -769,26 +775,29 @@ static int launch_icp_shape(tsd_ctx* ctx, const IcpArgs& a, int n, int cap, cons
   hipLaunchKernelGGL((k_icp<R, MAXT>), dim3(1), dim3(T), lds, ctx->stream, a, P_dev, cap, ctx->d_model, ctx->d_scene,
                      ctx->d_morig, ctx->d_start, ctx->d_coords, ctx->d_mask_m,
                      d_rays_local ? d_rays_local : ctx->d_rays_local, d_ranges ? d_ranges : ctx->d_ranges,
-                     d_mask ? d_mask : ctx->d_mask, ctx->d_icp_res, ctx->d_icp_trace);
+                     d_mask ? d_mask : ctx->d_mask, ctx->d_icp_res, ctx->d_icp_trace, post);
   TSD_HIP_CHECK(ctx, hipGetLastError());
   return TSD_OK;
 }
 
 int launch_icp(tsd_ctx* ctx, const IcpArgs& a, const double* P_dev, const double* d_rays_local,
-               const double* d_ranges, const uint8_t* d_mask)
+               const double* d_ranges, const uint8_t* d_mask, const ScanPostArgs* post_in)
 {
+  ScanPostArgs post;
+  std::memset(&post, 0, sizeof(post));
+  if (post_in) post = *post_in;
   const int n = a.beams > 0 ? a.beams : (a.n_model > a.n_scene ? a.n_model : a.n_scene);
   if (n > TSD_MAX_ICP_POINTS) return set_error(ctx, TSD_E_CAPACITY, "icp points > TSD_MAX_ICP_POINTS", hipSuccess);
   const int cap = icp_cap_for(n);
   const int nthr = a.beams > 0 ? a.beams : a.n_scene;     // scene points decide the thread count
   switch (ctx->icp_shape) {      // TSD_ICP_SHAPE: experiments only
-    case 2: return launch_icp_shape<2, 576>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask);
-    case 5: return launch_icp_shape<5, 256>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask);
-    case 8: return launch_icp_shape<8, 256>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask);
+    case 2: return launch_icp_shape<2, 576>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post);
+    case 5: return launch_icp_shape<5, 256>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post);
+    case 8: return launch_icp_shape<8, 256>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post);
     default: break;
   }
-  if (nthr <= 3 * 512) return launch_icp_shape<3, 512>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask);
-  return launch_icp_shape<8, 256>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask);
+  if (nthr <= 3 * 512) return launch_icp_shape<3, 512>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post);
+  return launch_icp_shape<8, 256>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post);
 }
 
 size_t icp_lds_bytes() { return icp_lds_bytes_for(TSD_MAX_ICP_POINTS, 256); }

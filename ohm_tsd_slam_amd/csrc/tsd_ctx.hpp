@@ -86,6 +86,18 @@ struct SensorDev {
   PushArgs push;             // arguments of this scan's push (enabled = gate result)
 };
 
+// fused scan path: what k_icp's epilogue needs (st == nullptr: plain registration)
+struct ScanPostArgs {
+  SensorDev* st;
+  double* rays;              // world ray map of the sensor, turned in place
+  ScanResultDev* out;        // coherent host memory
+  unsigned long long seq;
+  GateArgs gates;
+  double gmin_x, gmax_x, gmin_y, gmax_y;   // TsdGrid::getMin/Max* (RayCastPolar2D's isInsideGrid)
+  int beams;
+  int pad;
+};
+
 struct KernelTimer {
   double total_ms = 0.0;
   int launches = 0;
@@ -195,10 +207,9 @@ int launch_push(tsd_ctx* ctx, const PushArgs& a, const PushArgs* a_dev = nullptr
 int launch_free_footprint(tsd_ctx* ctx, unsigned minX, unsigned maxX, unsigned minY, unsigned maxY);
 int launch_raycast(tsd_ctx* ctx, const RaycastArgs& a, const RaycastArgs* a_dev = nullptr, const double* d_rays = nullptr);
 int launch_icp(tsd_ctx* ctx, const IcpArgs& a, const double* P_dev = nullptr, const double* d_rays_local = nullptr,
-               const double* d_ranges = nullptr, const uint8_t* d_mask = nullptr);
+               const double* d_ranges = nullptr, const uint8_t* d_mask = nullptr, const ScanPostArgs* post = nullptr);
 int launch_scan_prepare(tsd_ctx* ctx, SensorDev* st);
-int launch_scan_post(tsd_ctx* ctx, SensorDev* st, double* d_rays, int beams, const GateArgs& gates,
-                     ScanResultDev* d_out, unsigned long long seq);
+
 int launch_calibrate(tsd_ctx* ctx, double* t, double* w, size_t n);
 int launch_occupancy(tsd_ctx* ctx, int8_t* d_out, int inflate, int inflate_factor);
 size_t icp_lds_bytes();
