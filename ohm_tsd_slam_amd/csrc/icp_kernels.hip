@@ -41,6 +41,11 @@ namespace tsd {
 constexpr int ICP_MAXW = 16;                    // waves per workgroup at most
 constexpr double SLACK = 1.0 - 1e-9;            // conservative factor on every pruning bound
 constexpr int HW = 6;                           // tier-1 window: k-6 .. k+6
+#ifndef TSD_ICP_REFRESH_A
+#define TSD_ICP_REFRESH_A 6
+#define TSD_ICP_REFRESH_B 12
+#endif
+constexpr unsigned REFRESH_A = TSD_ICP_REFRESH_A, REFRESH_B = TSD_ICP_REFRESH_B;   // steps with a scheduled bound renewal
 constexpr int IR_CNT = 32, IR_RMAX = 33, IR_CNT2 = 34;   // words of IcpLds::ired
 #ifdef TSD_ICP_STAMPS
 constexpr int IR_DBG = 40;
@@ -244,7 +249,8 @@ __device__ __forceinline__ NnResult wave_search(const IcpLds& L, int nM, double 
     top3_tiebreak(L, t);
     // the walk runs on until the bound exceeds 4x what exactness needs: the extra slots (evaluated 64 at a
     // time anyway) buy a bound that survives the following steps
-    const double limit = 4.0 * fmin(t.b1, thr);
+    // (a point with nothing within the filter distance only has to stay dropped: 1.5x is plenty)
+    const double limit = (t.b1 > thr ? 1.5 : 4.0) * fmin(t.b1, thr);
     const bool sc = act && l2 > limit;
     const unsigned long long bu = __ballot(sc && o >= 0 && cr * sgn >= 0.0);
     const unsigned long long bdn = __ballot(sc && o < 0 && cr * sgn <= 0.0);
@@ -490,6 +496,7 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
                         (Pty - reach > L.cst[8]) && (Pty + reach < L.cst[9]);
     double bd[R]; bool keep[R], need[R];
     int ent[R];
+    const bool refresh = (iter == REFRESH_A) || (iter == REFRESH_B);
     {
       double2 mh[R], mh2[R];
 #pragma unroll
@@ -522,7 +529,11 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
         const bool drop = known && d > thr && lb2 > thr;          // no pair whoever it is
         bd[q] = pre ? d : __builtin_inf();
         keep[q] = pre && same && d <= thr;
-        need[q] = pre && !same && !drop;
+        // Bounds only ever decay, and a point whose slack runs out costs a work-list pass however few such
+        // points there are in that step.  Two scheduled passes renew every bound with less than 2x slack
+        // in distance while the steps are still large, instead of a trickle of passes later.
+        const bool weak = refresh && pre && known && !drop && lb2 < 4.0 * d;
+        need[q] = (pre && !same && !drop) || weak;
         ent[q] = -1;
       }
     }
@@ -720,6 +731,7 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
 #ifdef TSD_ICP_STAMPS
       tr[2] = (double)st_acc[1];        // cumulative phase-A cycles      (diagnostic build only)
       tr[1] = (double)L.ired[IR_DBG];   // cumulative searched points
+      tr[3] = (double)L.ired[IR_DBG + 1];   // cumulative whole-wave searches
 #endif
     }
   }

@@ -23,6 +23,7 @@ for rep in range(3):
     names = ["setup+tier0", "A list", "BC reciprocal", "D sums1", "F sums2+trig", "G transform+ctl"]
     tot = st[:6].sum()
     print("phase A cycles per step:", np.diff(np.concatenate([[0], tr[:30, 2]])).astype(int).tolist())
+    print("whole-wave searches per step:", np.diff(np.concatenate([[0], tr[:30, 3]])).astype(int).tolist())
     print("searched points per step:", np.diff(np.concatenate([[0], tr[:30, 1]])).astype(int).tolist())
     print("searched points total %d, of which whole-wave searches %d" % (st[6], st[7]))
     print("shape", os.environ.get("TSD_ICP_SHAPE", "0"), "kernel ms %.3f" % (ms / n), "cycles total %.0f" % tot,
