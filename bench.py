@@ -60,7 +60,8 @@ def algorithmic_bytes(st: dict, pushes: int, beams: int) -> float:
     """Bytes one push MUST move, fp64 SoA storage (DESIGN.md "Roofline"): per updated cell tsd+weight
     read+write = 32 B; an emptied initialised tile RMWs 1089 cells; a tile materialised from
     _initWeight > 0 writes 1024 cells; the scan (8 B range + 1 B mask per beam) is read once; every tile
-    that passes the range cull reads/writes 16 B of tile state."""
+    that passes the range cull reads/writes 16 B of tile state.  k_push_tiles (classification + update of
+    every tile, one workgroup per tile) is the kernel that moves these bytes."""
     return (32.0 * st["cells_updated"] + 32.0 * 1089 * st["tiles_emptied_init"]
             + 16.0 * 1024 * st["tiles_new_from_empty"] + 16.0 * st["tiles_range_pass"] + 9.0 * beams * pushes)
 
@@ -180,7 +181,7 @@ def main():
         node.laser(s, geo.angle_min, geo.angle_increment)
     grid.sync()
     stages = {}
-    for name in ("raycast", "icp", "push_classify", "push_update", "push_halo"):
+    for name in ("raycast", "icp", "push_update", "push_halo"):
         ms, n = grid.profile_get(name)
         stages[name] = ms / n if n else None
     grid.profile(False)
@@ -192,7 +193,7 @@ def main():
         bytes_per_launch = bytes_total / max(pushes, 1)
         upd_avg_ms = upd_ms / max(upd_launches, 1)
         achieved = bytes_per_launch / (upd_avg_ms * 1e-3) / 1e9 if upd_avg_ms > 0 else 0.0
-        traffic, traffic_src = pmc_traffic("k_push_update") if args.config == "cfg2" and scene == default_scene else (None, None)
+        traffic, traffic_src = pmc_traffic("k_push_tiles") if args.config == "cfg2" and scene == default_scene else (None, None)
         out = {
             "metric": "scans/sec + ms/ICP-iterate, 4096^2 TSD grid, 1081-beam scan" if args.config == "cfg2"
                       else f"scans/sec + ms/ICP-iterate, {gc.cells}^2 TSD grid, {geo.beams}-beam scan",
@@ -208,7 +209,7 @@ def main():
             "pushes_in_timed_region": pushes, "cells_updated_per_push": st["cells_updated"] / max(pushes, 1),
             "tiles_updated_per_push": st["tiles_update"] / max(pushes, 1),
             "tracking_error_m": track_err,
-            "roofline": {"kernel": "k_push_update", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"kernel": "k_push_tiles", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": upd_avg_ms,
                          "launches": upd_launches},

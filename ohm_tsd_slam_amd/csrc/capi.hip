@@ -25,7 +25,7 @@ int set_error(tsd_ctx* ctx, int code, const char* what, hipError_t e)
   return code;
 }
 
-static const char* const kKernelNames[] = {"push_classify", "push_update", "push_halo", "raycast", "icp", "occupancy"};
+static const char* const kKernelNames[] = {"push_update", "push_halo", "raycast", "icp", "occupancy"};
 
 bool kernel_is_timed(const tsd_ctx* ctx, const char* name)
 {
@@ -164,6 +164,55 @@ static void copy_icp_result(const IcpResultDev* h, tsd_icp_result* r)
   r->n_model = h->n_model; r->n_scene = h->n_scene; r->reserved = h->reserved;
 }
 
+// Statistics of the pushes: every tile keeps a record of the last push (k_push_tiles) and running totals
+// (k_push_halo); they are summed on the host when somebody asks -- tests and the end of a benchmark.
+static void fill_stats(tsd_ctx* ctx, const unsigned long long t[7], tsd_push_stats* out)
+{
+  out->cells_updated = (int64_t)t[0];
+  out->cells_visited = 1024ll * (int64_t)t[2];     // every UPDATE tile back-projects its 32x32 cells
+  out->tiles_total = ctx->grid.tiles;
+  out->tiles_range_pass = (int32_t)t[1]; out->tiles_update = (int32_t)t[2]; out->tiles_new = (int32_t)t[3];
+  out->tiles_new_from_empty = (int32_t)t[4]; out->tiles_emptied_init = (int32_t)t[5];
+  out->tiles_emptied_uninit = (int32_t)t[6];
+}
+
+static int read_last_push_stats(tsd_ctx* ctx, tsd_push_stats* out)
+{
+  const size_t T = (size_t)ctx->grid.tiles;
+  std::vector<uint32_t> rec(T);
+  TSD_HIP_CHECK(ctx, hipMemcpyAsync(rec.data(), ctx->d_tile_rec, T * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  unsigned long long t[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (size_t p = 0; p < T; p++) {
+    const uint32_t r = rec[p];
+    if (!r) continue;
+    t[0] += r >> 8;
+    for (int k = 1; k < 7; k++) t[k] += (r >> (k - 1)) & 1u;
+  }
+  fill_stats(ctx, t, out);
+  return TSD_OK;
+}
+
+static int read_total_stats(tsd_ctx* ctx, tsd_push_stats* out, int64_t* pushes, bool reset)
+{
+  const size_t T = (size_t)ctx->grid.tiles;
+  std::vector<uint32_t> tot(T * 8);
+  unsigned long long np = 0;
+  TSD_HIP_CHECK(ctx, hipMemcpyAsync(tot.data(), ctx->d_tile_totals, T * 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  TSD_HIP_CHECK(ctx, hipMemcpyAsync(&np, ctx->d_pushes, sizeof(np), hipMemcpyDeviceToHost, ctx->stream));
+  if (reset) {
+    TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_tile_totals, 0, T * 8 * sizeof(uint32_t), ctx->stream));
+    TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_pushes, 0, sizeof(np), ctx->stream));
+  }
+  TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  unsigned long long t[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (size_t p = 0; p < T; p++)
+    for (int k = 0; k < 7; k++) t[k] += tot[p * 8 + k];
+  if (out) fill_stats(ctx, t, out);
+  if (pushes) *pushes = (int64_t)np;
+  return TSD_OK;
+}
+
 }  // namespace tsd
 
 using namespace tsd;
@@ -212,16 +261,13 @@ tsd_ctx* tsd_create(int device, int map_size_log2, double cell_size, double max_
   A(hipMalloc(&g.init_weight, T * sizeof(double)));
   A(hipMalloc(&g.tsd, T * TILE_STRIDE * sizeof(double)));
   A(hipMalloc(&g.weight, T * TILE_STRIDE * sizeof(double)));
-  A(hipMalloc(&ctx->d_counters, 2 * sizeof(PushCounters)));
-  A(hipMalloc(&ctx->d_list, T * sizeof(uint32_t)));
-  A(hipMalloc(&ctx->d_entry_upd, T * sizeof(uint32_t)));
-  A(hipMalloc(&ctx->d_block_stats, ((T + 255) / 256) * 8 * sizeof(int)));
-  ctx->dirty_cap = (int)(T < 65536 ? T : 65536);
-  A(hipMalloc(&ctx->d_dirty, (size_t)ctx->dirty_cap * sizeof(uint32_t)));
-  A(hipMalloc(&ctx->d_dirty_count, sizeof(int)));
-  A(hipHostMalloc(&ctx->h_dirty, ((size_t)ctx->dirty_cap + 1) * sizeof(uint32_t), hipHostMallocDefault));
-  A(hipHostMalloc(&ctx->h_counters, sizeof(PushCounters), hipHostMallocDefault));
-  A(hipMalloc(&ctx->d_stat_total, 2 * sizeof(PushCounters)));
+  A(hipMalloc(&ctx->d_rmq, push_rmq_bytes(TSD_MAX_BEAMS)));
+  A(hipMalloc(&ctx->d_tile_rec, T * sizeof(uint32_t)));
+  A(hipMalloc(&ctx->d_dirty, T));
+  A(hipMalloc(&ctx->d_tile_totals, T * 8 * sizeof(uint32_t)));
+  A(hipMalloc(&ctx->d_pushes, sizeof(unsigned long long)));
+  A(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+  A(hipEventCreateWithFlags(&ctx->ev_tables, hipEventDisableTiming));
   ctx->stage_bytes = (size_t)TSD_MAX_BEAMS * (8 * 5 + 1) + 256;   // ranges + 2x rays(2) + mask; >= icp staging (80 KB)
   for (int s = 0; s < tsd_ctx::kSlots; s++) {
     A(hipHostMalloc(&ctx->h_stage[s], ctx->stage_bytes, hipHostMallocDefault));
@@ -259,8 +305,10 @@ void tsd_destroy(tsd_ctx* ctx)
   drain_timers(ctx);
   GridDev& g = ctx->grid;
   hipFree(g.flags); hipFree(g.init_weight); hipFree(g.tsd); hipFree(g.weight);
-  hipFree(ctx->d_counters); hipFree(ctx->d_list); hipFree(ctx->d_entry_upd); hipFree(ctx->d_block_stats); hipFree(ctx->d_dirty); hipFree(ctx->d_dirty_count);
-  hipHostFree(ctx->h_dirty); hipHostFree(ctx->h_counters); hipFree(ctx->d_stat_total);
+  if (ctx->stream2) hipStreamSynchronize(ctx->stream2);
+  hipFree(ctx->d_rmq); hipFree(ctx->d_tile_rec); hipFree(ctx->d_dirty); hipFree(ctx->d_tile_totals); hipFree(ctx->d_pushes);
+  if (ctx->ev_tables) hipEventDestroy(ctx->ev_tables);
+  if (ctx->stream2) hipStreamDestroy(ctx->stream2);
   for (hipEvent_t e : ctx->event_pool) hipEventDestroy(e);
   for (int s = 0; s < tsd_ctx::kSlots; s++) {
     if (ctx->h_stage[s]) hipHostFree(ctx->h_stage[s]);
@@ -283,12 +331,11 @@ int tsd_reset(tsd_ctx* ctx)
   // cells are materialised lazily (flags == 0 means "no cell storage yet", TsdGridPartition.cpp:88)
   TSD_HIP_CHECK(ctx, hipMemsetAsync(g.flags, 0, T, ctx->stream));
   TSD_HIP_CHECK(ctx, hipMemsetAsync(g.init_weight, 0, T * sizeof(double), ctx->stream));
-  TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_counters, 0, 2 * sizeof(PushCounters), ctx->stream));
-  TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_stat_total, 0, 2 * sizeof(PushCounters), ctx->stream));
-  TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_dirty_count, 0, sizeof(int), ctx->stream));
+  TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_dirty, 0, T, ctx->stream));
+  TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_tile_rec, 0, T * sizeof(uint32_t), ctx->stream));
+  TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_tile_totals, 0, T * 8 * sizeof(uint32_t), ctx->stream));
+  TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_pushes, 0, sizeof(unsigned long long), ctx->stream));
   TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_occ, 0xFF, (size_t)g.N * g.N, ctx->stream));   // -1 (ThreadGrid.cpp:27-28)
-  ctx->epoch = 0;
-  ctx->n_dirty = 0;
   TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return TSD_OK;
 }
@@ -364,23 +411,13 @@ int tsd_push(tsd_ctx* ctx, const double pose33[9], const double* ranges, const u
   TSD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_mask, h + (size_t)TSD_MAX_BEAMS * 8, (size_t)beams, hipMemcpyHostToDevice, ctx->stream));
   TSD_HIP_CHECK(ctx, hipEventRecord(ctx->stage_ev[s], ctx->stream));
 
-  const uint32_t epoch = ctx->epoch;
-  int rc = launch_push(ctx, a);
+  int rc = launch_push_tables(ctx, ctx->stream, beams, nullptr, nullptr);
+  if (rc != TSD_OK) return rc;
+  rc = launch_push(ctx, a);
   if (rc != TSD_OK) return rc;
   if (stats) {
-    TSD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters + (epoch & 1u), sizeof(PushCounters),
-                                      hipMemcpyDeviceToHost, ctx->stream));
-    TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    const PushCounters& c = *ctx->h_counters;
-    stats->cells_updated = (int64_t)c.cells_updated;
-    stats->cells_visited = (int64_t)c.cells_visited;
-    stats->tiles_total = ctx->grid.tiles;
-    stats->tiles_range_pass = c.tiles_range_pass;
-    stats->tiles_update = c.tiles_update;
-    stats->tiles_new = c.tiles_new;
-    stats->tiles_new_from_empty = c.tiles_new_from_empty;
-    stats->tiles_emptied_init = c.tiles_emptied_init;
-    stats->tiles_emptied_uninit = c.tiles_emptied_uninit;
+    rc = read_last_push_stats(ctx, stats);
+    if (rc != TSD_OK) return rc;
   }
   return TSD_OK;
 }
@@ -673,19 +710,7 @@ int tsd_push_stats_total(tsd_ctx* ctx, tsd_push_stats* total, int64_t* pushes, i
 {
   if (!ctx) return TSD_E_ARG;
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  PushCounters h[2];
-  TSD_HIP_CHECK(ctx, hipMemcpyAsync(h, ctx->d_stat_total, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-  if (reset) TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_stat_total, 0, sizeof(h), ctx->stream));
-  TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  if (total) {
-    total->cells_updated = (int64_t)h[0].cells_updated; total->cells_visited = (int64_t)h[0].cells_visited;
-    total->tiles_total = ctx->grid.tiles;
-    total->tiles_range_pass = h[0].tiles_range_pass; total->tiles_update = h[0].tiles_update;
-    total->tiles_new = h[0].tiles_new; total->tiles_new_from_empty = h[0].tiles_new_from_empty;
-    total->tiles_emptied_init = h[0].tiles_emptied_init; total->tiles_emptied_uninit = h[0].tiles_emptied_uninit;
-  }
-  if (pushes) *pushes = h[1].list_count;
-  return TSD_OK;
+  return read_total_stats(ctx, total, pushes, reset != 0);
 }
 
 // ---------------------------------------------------------------------------------- fused scan path
@@ -778,10 +803,17 @@ int tsd_scan(tsd_sensor* s, const double* ranges, const uint8_t* mask, const uin
   const uint8_t* d_mask = reinterpret_cast<const uint8_t*>(s->d_scan + nb * 8);
   const uint8_t* d_mask_push = reinterpret_cast<const uint8_t*>(s->d_scan + nb * 9);
 
+  // the range-query tables of this scan's push only depend on the scan: built on the side stream while the
+  // ray cast and the registration run (the previous push finished before this scan's copy could start)
+  TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->stage_ev[slot], 0));
+  int rc = launch_push_tables(ctx, ctx->stream2, s->beams, d_ranges, d_mask_push);
+  if (rc != TSD_OK) return rc;
+  TSD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_tables, ctx->stream2));
+
   RaycastArgs ra;
   std::memset(&ra, 0, sizeof(ra));
   ra.beams = s->beams;                                   // grid size of the launch; the rest is read on the device
-  int rc = launch_raycast(ctx, ra, &s->d_state->rc, s->d_rays);
+  rc = launch_raycast(ctx, ra, &s->d_state->rc, s->d_rays);
   if (rc != TSD_OK) return rc;
   IcpArgs ia;
   const double ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -799,6 +831,7 @@ int tsd_scan(tsd_sensor* s, const double* ranges, const uint8_t* mask, const uin
   PushArgs pa;
   std::memset(&pa, 0, sizeof(pa));
   pa.beams = s->beams;                                   // LDS size of the launch
+  TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_tables, 0));
   rc = launch_push(ctx, pa, &s->d_state->push, d_ranges, d_mask_push);
   if (rc != TSD_OK) return rc;
   // The result is known once k_scan_post has run; the push kernels behind it only touch the grid, and

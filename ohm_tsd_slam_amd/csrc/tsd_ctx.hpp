@@ -11,21 +11,6 @@
 
 namespace tsd {
 
-// device-resident counters of one push; two sets alternate by push epoch so that no memset node is
-// needed (the classify kernel of push e clears the set of push e+1).
-struct PushCounters {
-  unsigned long long cells_updated;
-  unsigned long long cells_visited;
-  int list_count;            // entries in the tile work list
-  int tiles_range_pass;
-  int tiles_update;
-  int tiles_new;
-  int tiles_new_from_empty;
-  int tiles_emptied_init;
-  int tiles_emptied_uninit;
-  int pad;
-};
-
 // scalar inputs of a push, passed by value as a kernel argument
 struct PushArgs {
   double Pi[6];              // first two rows of pose^-1
@@ -114,17 +99,13 @@ struct tsd_ctx {
   std::string err;
 
   // push state
-  uint32_t epoch = 0;
-  tsd::PushCounters* d_counters = nullptr;   // [2]
-  uint32_t* d_list = nullptr;                // [tiles] work list (bit 31 = emptied-initialised tile)
-  uint32_t* d_entry_upd = nullptr;           // [tiles] cells updated per list entry
-  int* d_block_stats = nullptr;              // [classify blocks][8] per-block tile statistics
-  uint32_t* d_dirty = nullptr;               // tiles touched by freeFootprint since the last push
-  int* d_dirty_count = nullptr;
-  uint32_t* h_dirty = nullptr;               // pinned [dirty_cap + 1] (last word = count staging)
-  int dirty_cap = 0;
-  int n_dirty = 0;
-  tsd::PushCounters* h_counters = nullptr;   // pinned
+  char* d_rmq = nullptr;                     // range-query tables of the current scan (k_push_tables)
+  uint32_t* d_tile_rec = nullptr;            // [tiles] what the last push did to every tile
+  uint8_t* d_dirty = nullptr;                // [tiles] written by freeFootprint since the last push
+  uint32_t* d_tile_totals = nullptr;         // [tiles][8] records summed over the pushes since the last reset
+  unsigned long long* d_pushes = nullptr;    // [1] pushes since the last reset
+  hipStream_t stream2 = nullptr;             // side stream: the tables are built while ray cast / ICP run
+  hipEvent_t ev_tables = nullptr;
 
   // scan staging: ring of pinned slots + device buffers
   static constexpr int kSlots = 8;
@@ -154,8 +135,6 @@ struct tsd_ctx {
   int8_t* d_occ = nullptr;       // persistent map (ThreadGrid::_occGridContent)
   int* d_occ_count = nullptr;
 
-  // cumulative push statistics, accumulated on the device by k_push_halo (no per-push read-back)
-  tsd::PushCounters* d_stat_total = nullptr; // [2]: [0] sums, [1].list_count = pushes
 
   // profiling: bit i of profile_mask times kernel i (names in capi.hip: kKernelNames)
   unsigned profile_mask = 0;
@@ -204,6 +183,8 @@ bool kernel_is_timed(const tsd_ctx* ctx, const char* name);
 // dependent arguments from the device-resident sensor state instead of the by-value copy.
 int launch_push(tsd_ctx* ctx, const PushArgs& a, const PushArgs* a_dev = nullptr, const double* d_ranges = nullptr,
                 const uint8_t* d_mask = nullptr);
+int launch_push_tables(tsd_ctx* ctx, hipStream_t stream, int beams, const double* d_ranges, const uint8_t* d_mask);
+size_t push_rmq_bytes(int beams);
 int launch_free_footprint(tsd_ctx* ctx, unsigned minX, unsigned maxX, unsigned minY, unsigned maxY);
 int launch_raycast(tsd_ctx* ctx, const RaycastArgs& a, const RaycastArgs* a_dev = nullptr, const double* d_rays = nullptr);
 int launch_icp(tsd_ctx* ctx, const IcpArgs& a, const double* P_dev = nullptr, const double* d_rays_local = nullptr,
