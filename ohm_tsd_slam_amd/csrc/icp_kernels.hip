@@ -46,7 +46,7 @@ constexpr int HW = 6;                           // tier-1 window: k-6 .. k+6
 #define TSD_ICP_REFRESH_B 12
 #endif
 constexpr unsigned REFRESH_A = TSD_ICP_REFRESH_A, REFRESH_B = TSD_ICP_REFRESH_B;   // steps with a scheduled bound renewal
-constexpr int IR_CNT = 32, IR_RMAX = 33, IR_CNT2 = 34;   // words of IcpLds::ired
+constexpr int IR_CNT = 32, IR_RMAX = 33, IR_CNT2 = 34, IR_TIE = 35;   // words of IcpLds::ired
 #ifdef TSD_ICP_STAMPS
 constexpr int IR_DBG = 40;
 #endif
@@ -88,6 +88,9 @@ __host__ __device__ inline size_t icp_lds_bytes_for(int cap, int threads)
   return sizeof(double2) * 2 * (size_t)cap + sizeof(unsigned long long) * (size_t)cap + sizeof(int) * 2 * (size_t)cap +
          icp_region_bytes(cap, threads) + sizeof(double) * (2 * ICP_MAXW * 16 + 16) + sizeof(int) * 64 + 64;
 }
+
+// a wave-uniform value the compiler must keep in a vector register
+__device__ __forceinline__ double vreg(double x) { asm volatile("" : "+v"(x)); return x; }
 
 // ---- wave reductions: DPP row shifts inside the 16-lane rows, then the four row results through
 // SGPRs.  Fixed order => deterministic.  (v_add_f64 has no DPP form: two 32-bit DPP moves + add.)
@@ -156,41 +159,58 @@ __device__ __forceinline__ double sep_bound(double x, double y, double rs2, doub
   return valid_u ? (dt > 0.0 ? cr * cr : rs2) * SLACK : 0.0;
 }
 
-// tier 1: the 2*HW+1 slots around `c`, one lane per point, all LDS reads issued together
+// tier 1: the 2*HW+1 slots around `c`, one lane per point, all LDS reads of a round issued together.  When
+// the two ends cannot bound what lies outside, the arc grows by another 2*HW+1 slots on its weaker side (the
+// neighbour of a scan that turned against the prediction sits the same number of slots away for every
+// point), up to WIN_ROUNDS times; only then the point goes to the whole-wave search.
+constexpr int WIN = 2 * HW + 1;
+constexpr int WIN_ROUNDS = 6;
+__device__ __forceinline__ int wrap_slot(int k, int nM)
+{
+  k += (k < 0) ? nM : 0;
+  k -= (k >= nM) ? nM : 0;
+  return k;
+}
 __device__ __forceinline__ NnResult window_search(const IcpLds& L, int nM, double x, double y, int c,
                                                   double thr, double sgn)
 {
   NnResult r;
   r.best = __builtin_inf(); r.lbsq = 0.0; r.bk = -1; r.bk2 = -1; r.resolved = false;
-  if (nM <= 2 * HW + 1) return r;
-  int k0 = c - HW;
-  if (k0 < 0) k0 += nM;
-  double2 m[2 * HW + 1];
-  int kk[2 * HW + 1];
-#pragma unroll
-  for (int j = 0; j < 2 * HW + 1; j++) {
-    int k = k0 + j;
-    if (k >= nM) k -= nM;
-    kk[j] = k;
-    m[j] = L.mxy[k];
-  }
-  const double2 ulo = L.uxy[kk[0]], uhi = L.uxy[kk[2 * HW]];
+  if (nM <= WIN) return r;
   Top3 t;
   t.b1 = t.b2 = t.b3 = __builtin_inf(); t.k1 = t.k2 = -1;
+  const double rs2 = x * x + y * y;
+  int lo = c - HW, hi = c + HW;                 // visited arc, unwrapped slot numbers
+  double blo = 0.0, bhi = 0.0;                  // bounds on everything below lo / above hi
+  int b = lo;                                   // first slot of the round
+  int side = 0;                                 // 0: first round (both ends), -1: grew downwards, +1: upwards
+  for (int round = 0;; round++) {
+    double2 m[WIN];
+    int kk[WIN];
 #pragma unroll
-  for (int j = 0; j < 2 * HW + 1; j++) {
-    const double dx = x - m[j].x, dy = y - m[j].y;
-    top3_insert(t, dx * dx + dy * dy, kk[j]);
+    for (int j = 0; j < WIN; j++) {
+      kk[j] = wrap_slot(b + j, nM);
+      m[j] = L.mxy[kk[j]];
+    }
+    const double2 ulo = L.uxy[kk[0]], uhi = L.uxy[kk[WIN - 1]];
+#pragma unroll
+    for (int j = 0; j < WIN; j++) {
+      const double dx = x - m[j].x, dy = y - m[j].y;
+      top3_insert(t, dx * dx + dy * dy, kk[j]);
+    }
+    // the low end must lie clockwise of s (in slot order) and the high end counter-clockwise
+    double cr;
+    if (side <= 0) { const double l2 = sep_bound(x, y, rs2, ulo, cr); blo = cr * sgn <= 0.0 ? l2 : 0.0; }
+    if (side >= 0) { const double l2 = sep_bound(x, y, rs2, uhi, cr); bhi = cr * sgn >= 0.0 ? l2 : 0.0; }
+    const double lbo = fmin(blo, bhi);
+    if (lbo > fmin(t.b1, thr)) { r.resolved = true; break; }
+    if (round == WIN_ROUNDS || hi - lo + 1 + WIN > nM) break;
+    if (blo <= bhi) { side = -1; lo -= WIN; b = lo; }
+    else { side = 1; b = hi + 1; hi += WIN; }
   }
   top3_tiebreak(L, t);
-  const double rs2 = x * x + y * y;
-  double crl, crh;
-  const double l2lo = sep_bound(x, y, rs2, ulo, crl), l2hi = sep_bound(x, y, rs2, uhi, crh);
-  // the low end must lie clockwise of s (in slot order) and the high end counter-clockwise
-  const double lbo = fmin(crl * sgn <= 0.0 ? l2lo : 0.0, crh * sgn >= 0.0 ? l2hi : 0.0);
   r.best = t.b1; r.bk = t.k1; r.bk2 = t.k2;
-  r.lbsq = fmin(t.b3, lbo);
-  r.resolved = lbo > fmin(t.b1, thr);
+  r.lbsq = fmin(t.b3, fmin(blo, bhi));
   return r;
 }
 
@@ -411,11 +431,7 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
     __syncthreads();
   }
   if (tid == 0) {
-    L.ired[IR_CNT] = 0; L.ired[IR_RMAX] = 0; L.ired[IR_CNT2] = 0;
-#pragma unroll
-    for (int i = 0; i < 6; i++) L.cst[i] = a.P[i];
-    L.cst[6] = a.min_x; L.cst[7] = a.max_x; L.cst[8] = a.min_y; L.cst[9] = a.max_y;
-    L.cst[10] = a.multiplier; L.cst[11] = a.min_sqr;
+    L.ired[IR_CNT] = 0; L.ired[IR_RMAX] = 0; L.ired[IR_CNT2] = 0; L.ired[IR_TIE] = 0;
   }
 
   double Tf[6] = {1, 0, 0, 0, 1, 0};   // rows 0,1 of _Tfinal4x4: [r00 r01 tx ; r10 r11 ty]
@@ -448,7 +464,7 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
       const double2 s = L.stage_s[i];
       sx[q] = s.x; sy[q] = s.y;
       // |s| rounded up: fp32 is plenty for a bound
-      const float rf = sqrtf((float)(s.x * s.x + s.y * s.y) * 1.000001f) * 1.000001f;
+      const float rf = __builtin_amdgcn_sqrtf((float)(s.x * s.x + s.y * s.y) * 1.000001f) * 1.000001f;
       rmaxf = fmaxf(rmaxf, rf);
       int h = L.start[i];
       hint[q] = h < 0 ? 0 : (h >= nM ? nM - 1 : h);
@@ -473,15 +489,22 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
   STAMP(0);
 
   // ---------------------------------------------------------------- iterate
+  // loop-invariant scalars: vector registers (the scalar file is the scarce one in this kernel)
+  const double P00 = vreg(a.P[0]), P01 = vreg(a.P[1]), P02 = vreg(a.P[2]), P10 = vreg(a.P[3]), P11 = vreg(a.P[4]), P12 = vreg(a.P[5]);
+  const double bmin_x = vreg(a.min_x), bmax_x = vreg(a.max_x), bmin_y = vreg(a.min_y), bmax_y = vreg(a.max_y);
+  const double thr_mult = vreg(a.multiplier), thr_min = vreg(a.min_sqr);
   const double sgn = a.ccw ? 1.0 : -1.0;     // +1: slots ascend counter-clockwise
   double thr = a.thr0;                       // DistanceFilter::_distSqr after reset()
   double rms_prev = 10e12;
   unsigned int conv_cnt = 0;
   const unsigned int max_it = (unsigned)a.iterations, conv_need = (unsigned)a.iterations;
   // rows of the pose's rotation block are unit vectors up to rounding: |R_p s| <= pnorm |s| per axis
-  const double pnorm = fmax(sqrt(L.cst[0] * L.cst[0] + L.cst[1] * L.cst[1]), sqrt(L.cst[3] * L.cst[3] + L.cst[4] * L.cst[4])) * (1.0 + 1e-9);
+  const double pnorm = fmax(sqrt(P00 * P00 + P01 * P01), sqrt(P10 * P10 + P11 * P11)) * (1.0 + 1e-9);
 
   double c0[4] = {0.0, 0.0, 0.0, 0.0};       // centring point of the pair sums: last step's centroids
+
+  int Rn = 0;                                // register slots of this wave that hold scene points (wave-uniform)
+  for (int q = 0; q < R; q++) Rn += (q * T + wave * 64 < nS) ? 1 : 0;
 
   while (state == TSD_ICP_PROCESSING) {
     const double thr_before = thr;
@@ -489,13 +512,13 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
     // -- phase A: pre-filter + exact NN + distance filter (per scene point)
     // OutOfBoundsFilter2D: when even a disc of the largest possible scene radius around the sensor
     // lies inside the bounds nothing can be filtered and the per-point transform is skipped.
-    const double tcum = (double)(sqrtf((float)(Tf[2] * Tf[2] + Tf[5] * Tf[5]) * 1.000001f) * 1.000001f);
+    const double tcum = (double)(__builtin_amdgcn_sqrtf((float)(Tf[2] * Tf[2] + Tf[5] * Tf[5]) * 1.000001f) * 1.000001f);
     const double reach = (scene_rmax + tcum) * pnorm * (1.0 + 1e-6) + 1e-6;
-    const double Ptx = L.cst[2], Pty = L.cst[5];
-    const bool all_in = (Ptx - reach > L.cst[6]) && (Ptx + reach < L.cst[7]) &&
-                        (Pty - reach > L.cst[8]) && (Pty + reach < L.cst[9]);
+    const bool all_in = (int)(P02 - reach > bmin_x) & (int)(P02 + reach < bmax_x) &
+                        (int)(P12 - reach > bmin_y) & (int)(P12 + reach < bmax_y);
     double bd[R]; bool keep[R], need[R];
     int ent[R];
+    double2 mw[R];                            // the neighbour's coordinates
     const bool refresh = (iter == REFRESH_A) || (iter == REFRESH_B);
     {
       double2 mh[R], mh2[R];
@@ -503,15 +526,17 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
       for (int q = 0; q < R; q++) { mh[q] = L.mxy[hint[q]]; mh2[q] = L.mxy[hint2[q]]; }   // all reads in flight
 #pragma unroll
       for (int q = 0; q < R; q++) {
+        bd[q] = __builtin_inf(); keep[q] = false; need[q] = false; ent[q] = -1; mw[q] = mh[q];
+        if (q >= Rn) continue;                  // (wave-uniform) no scene point in this register slot
         const double x = sx[q], y = sy[q];
         bool pre = have[q];
         if (!all_in) {
           // S.transform(P): (0 + x*R00) + y*R01, then + t (gsl/Matrix.cpp:403-432)
           double wx = 0.0, wy = 0.0;
-          wx += x * L.cst[0]; wx += y * L.cst[1];
-          wy += x * L.cst[3]; wy += y * L.cst[4];
-          wx += L.cst[2]; wy += L.cst[5];
-          pre = pre && !(wx < L.cst[6] || wx > L.cst[7] || wy < L.cst[8] || wy > L.cst[9]);
+          wx += x * P00; wx += y * P01;
+          wy += x * P10; wy += y * P11;
+          wx += P02; wy += P12;
+          pre = pre & !((int)(wx < bmin_x) | (int)(wx > bmax_x) | (int)(wy < bmin_y) | (int)(wy > bmax_y));
         }
         // the nearer of the last neighbour and its runner-up is the exact neighbour as long as it beats
         // the bound on everything else (a point hovering between two model points never searches)
@@ -521,93 +546,137 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
         if (d2 == d1 && hint2[q] != hint[q]) swp = L.morig[hint2[q]] < L.morig[hint[q]];   // exact tie (rare)
         const double d = swp ? d2 : d1;
         const int kn = swp ? hint2[q] : hint[q], ko = swp ? hint[q] : hint2[q];
+        mw[q] = swp ? mh2[q] : mh[q];
         hint[q] = kn; hint2[q] = ko;
         const double lbq = lb[q];
         const double lb2 = lbq * lbq;
         const bool known = lbq > 0.0;
-        const bool same = known && d < lb2;                       // neighbour proven
-        const bool drop = known && d > thr && lb2 > thr;          // no pair whoever it is
+        const bool same = known & (d < lb2);                       // neighbour proven
+        const bool drop = known & (d > thr) & (lb2 > thr);          // no pair whoever it is
         bd[q] = pre ? d : __builtin_inf();
-        keep[q] = pre && same && d <= thr;
+        keep[q] = pre & same & (d <= thr);
         // Bounds only ever decay, and a point whose slack runs out costs a work-list pass however few such
         // points there are in that step.  Two scheduled passes renew every bound with less than 2x slack
         // in distance while the steps are still large, instead of a trickle of passes later.
-        const bool weak = refresh && pre && known && !drop && lb2 < 4.0 * d;
-        need[q] = (pre && !same && !drop) || weak;
+        const bool weak = refresh & pre & known & !drop & (lb2 < 4.0 * d);
+        need[q] = (pre & !same & !drop) | weak;
+        keep[q] = keep[q] & !need[q];
         ent[q] = -1;
       }
     }
-    // work list of the points that need a search
+    // -- ReciprocalFilter, first half: per model slot the smallest d2 (LDS atomic min on the bit pattern).
+    // Pairs settled by tier 0 go in right away; two scene points with the SAME d2 to one slot are the only
+    // case that needs the index round below, and the later of the two sees its own value come back.
+    bool tie = false;
 #pragma unroll
-    for (int q = 0; q < R; q++)
-      if (need[q]) ent[q] = atomicAdd(&L.ired[IR_CNT], 1);
+    for (int q = 0; q < R; q++) {
+      if (keep[q]) {
+        const unsigned long long mine = (unsigned long long)__double_as_longlong(bd[q]);
+        tie |= atomicMin(&L.slotD[hint[q]], mine) == mine;
+      }
+      // work list of the points that need a search (an entry beyond the list capacity waits for its pass)
+      if (need[q]) {
+        ent[q] = atomicAdd(&L.ired[IR_CNT], 1);
+        if (ent[q] < lcap) { L.list_xy[ent[q]] = make_double2(sx[q], sy[q]); L.list_k[ent[q]] = hint[q]; }
+      }
+    }
+    if (tie) L.ired[IR_TIE] = 1;
     __syncthreads();
     STAMP(0);
     const int n_need = L.ired[IR_CNT];
-    for (int base = 0; base < n_need; base += lcap) {       // one pass unless more than lcap points search
-      const int n = (n_need - base) < lcap ? (n_need - base) : lcap;
+    if (n_need > 0) {
+      tie = false;
+      for (int base = 0; base < n_need; base += lcap) {       // one pass unless more than lcap points search
+        const int n = (n_need - base) < lcap ? (n_need - base) : lcap;
+        if (base > 0) {
 #pragma unroll
-      for (int q = 0; q < R; q++)
-        if (need[q] && ent[q] >= base && ent[q] < base + lcap) {
-          L.list_xy[ent[q] - base] = make_double2(sx[q], sy[q]);
-          L.list_k[ent[q] - base] = hint[q];
+          for (int q = 0; q < R; q++)
+            if (need[q] && ent[q] >= base && ent[q] < base + lcap) {
+              L.list_xy[ent[q] - base] = make_double2(sx[q], sy[q]);
+              L.list_k[ent[q] - base] = hint[q];
+            }
+          __syncthreads();
         }
-      __syncthreads();
-      for (int e0 = wave * 64; e0 < n; e0 += T) {
-        const int e = e0 + lane;
-        if (e < n) {
-          const double2 s = L.list_xy[e];
-          const NnResult r = window_search(L, nM, s.x, s.y, L.list_k[e], thr, sgn);
-          if (r.resolved) { L.res_d[e] = r.best; L.res_k[e] = r.bk; L.res_k2[e] = r.bk2; L.res_lb[e] = sqrt(r.lbsq) * SLACK; }
-          else L.list2[atomicAdd(&L.ired[IR_CNT2], 1)] = e;      // tier 2, shared out over all waves below
+        for (int e0 = wave * 64; e0 < n; e0 += T) {
+          const int e = e0 + lane;
+          if (e < n) {
+            const double2 s = L.list_xy[e];
+            const NnResult r = window_search(L, nM, s.x, s.y, L.list_k[e], thr, sgn);
+            if (r.resolved) { L.res_d[e] = r.best; L.res_k[e] = r.bk; L.res_k2[e] = r.bk2; L.res_lb[e] = sqrt(r.lbsq) * SLACK; }
+            else L.list2[atomicAdd(&L.ired[IR_CNT2], 1)] = e;      // tier 2, shared out over all waves below
+          }
         }
-      }
-      __syncthreads();
-      const int n2 = L.ired[IR_CNT2];
+        __syncthreads();
+        const int n2 = L.ired[IR_CNT2];
 #ifdef TSD_ICP_STAMPS
-      if (tid == 0) L.ired[IR_DBG + 1] += n2;
+        if (tid == 0) L.ired[IR_DBG + 1] += n2;
 #endif
-      for (int i = wave; i < n2; i += W) {
-        const int es = L.list2[i];
-        const double2 s = L.list_xy[es];
-        const NnResult r = wave_search(L, nM, s.x, s.y, L.list_k[es], thr, sgn, lane);
-        if (lane == 0) { L.res_d[es] = r.best; L.res_k[es] = r.bk; L.res_k2[es] = r.bk2; L.res_lb[es] = sqrt(r.lbsq) * SLACK; }
-      }
-      __syncthreads();
-      if (tid == 0) L.ired[IR_CNT2] = 0;
-#pragma unroll
-      for (int q = 0; q < R; q++)
-        if (need[q] && ent[q] >= base && ent[q] < base + lcap) {
-          const int e = ent[q] - base;
-          const int k = L.res_k[e];
-          if (k >= 0) { bd[q] = L.res_d[e]; hint[q] = k; hint2[q] = L.res_k2[e]; lb[q] = L.res_lb[e]; keep[q] = bd[q] <= thr; }   // DistanceFilter::filter
-          else { bd[q] = __builtin_inf(); lb[q] = -1.0; }                                                // non-finite input point
+        if (n2 > 0) {
+          for (int i = wave; i < n2; i += W) {
+            const int es = L.list2[i];
+            const double2 s = L.list_xy[es];
+            const NnResult r = wave_search(L, nM, s.x, s.y, L.list_k[es], thr, sgn, lane);
+            if (lane == 0) { L.res_d[es] = r.best; L.res_k[es] = r.bk; L.res_k2[es] = r.bk2; L.res_lb[es] = sqrt(r.lbsq) * SLACK; }
+          }
+          __syncthreads();
+          if (tid == 0) L.ired[IR_CNT2] = 0;
         }
-      if (base + lcap < n_need) __syncthreads();
+#pragma unroll
+        for (int q = 0; q < R; q++)
+          if (need[q] && ent[q] >= base && ent[q] < base + lcap) {
+            const int e = ent[q] - base;
+            const int k = L.res_k[e];
+            if (k >= 0) {
+              bd[q] = L.res_d[e]; hint[q] = k; hint2[q] = L.res_k2[e]; lb[q] = L.res_lb[e];
+              mw[q] = L.mxy[k];
+              keep[q] = bd[q] <= thr;                                  // DistanceFilter::filter
+              if (keep[q]) {
+                const unsigned long long mine = (unsigned long long)__double_as_longlong(bd[q]);
+                tie |= atomicMin(&L.slotD[k], mine) == mine;
+              }
+            } else { bd[q] = __builtin_inf(); lb[q] = -1.0; }          // non-finite input point
+          }
+        if (base + lcap < n_need) __syncthreads();
+      }
+      if (tie) L.ired[IR_TIE] = 1;
+      __syncthreads();
     }
 #ifdef TSD_ICP_STAMPS
     if (tid == 0) L.ired[IR_DBG] += n_need;
 #endif
     // threshold schedule (DistanceFilter.cpp:62-63)
-    thr *= L.cst[10];
-    if (thr < L.cst[11]) thr = L.cst[11];
+    thr *= thr_mult;
+    if (thr < thr_min) thr = thr_min;
     STAMP(1);
 
-    // -- phase B/C: ReciprocalFilter = per model point keep the pair with the smallest d2
-#pragma unroll
-    for (int q = 0; q < R; q++)
-      if (keep[q]) atomicMin(&L.slotD[hint[q]], (unsigned long long)__double_as_longlong(bd[q]));
-    __syncthreads();
+    // -- ReciprocalFilter, second half: the pair whose d2 stands in its slot wins
+    bool win[R];
+    int cnt = 0;
     {
       unsigned long long sd[R];
 #pragma unroll
       for (int q = 0; q < R; q++) sd[q] = L.slotD[hint[q]];
 #pragma unroll
-      for (int q = 0; q < R; q++)
-        if (keep[q] && sd[q] == (unsigned long long)__double_as_longlong(bd[q]))
-          atomicMin(&L.slotI[hint[q]], tid + q * T);
+      for (int q = 0; q < R; q++) win[q] = keep[q] & (sd[q] == (unsigned long long)__double_as_longlong(bd[q]));
     }
-    __syncthreads();
+    if (L.ired[IR_TIE]) {
+      // equal d2 somewhere: the lowest scene index of the candidates wins its slot
+#pragma unroll
+      for (int q = 0; q < R; q++)
+        if (win[q]) atomicMin(&L.slotI[hint[q]], tid + q * T);
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < R; q++) {
+        if (win[q]) { win[q] = L.slotI[hint[q]] == tid + q * T; }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < R; q++)
+        if (keep[q]) L.slotI[hint[q]] = INT_MAX;
+      if (tid == 0) L.ired[IR_TIE] = 0;
+    }
+#pragma unroll
+    for (int q = 0; q < R; q++) cnt += __popcll(__ballot(win[q]));
     STAMP(2);
 
     // -- phase D/F: ClosedFormEstimator2D::setPairs + estimateTransformation in ONE pass over the pairs.
@@ -615,19 +684,6 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
     // step's centroids c0 instead and correcting, sum (a-ca)(b-cb) = sum (a-c0a)(b-c0b) - n (ca-c0a)(cb-c0b),
     // is the same quantity with the same conditioning (c0 is within millimetres of c); the very first
     // step has no c0 and runs the pass twice, i.e. the reference's two passes.
-    bool win[R];
-    double2 mw[R];
-    int cnt = 0;
-    {
-      int si_[R];
-#pragma unroll
-      for (int q = 0; q < R; q++) { si_[q] = L.slotI[hint[q]]; mw[q] = L.mxy[hint[q]]; }
-#pragma unroll
-      for (int q = 0; q < R; q++) {
-        win[q] = keep[q] && si_[q] == tid + q * T;
-        cnt += __popcll(__ballot(win[q]));
-      }
-    }
     double tot[NSUM];
     for (int pass = (iter == 0 ? 0 : 1); pass < 2; pass++) {
       double v[NSUM];
@@ -658,7 +714,7 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
     // everybody is past the winner test: give the touched slots back, clear the work list counter
 #pragma unroll
     for (int q = 0; q < R; q++)
-      if (keep[q]) { L.slotD[hint[q]] = ~0ull; L.slotI[hint[q]] = INT_MAX; }
+      if (keep[q]) L.slotD[hint[q]] = ~0ull;
     if (tid == 0) L.ired[IR_CNT] = 0;
     STAMP(3);
 
@@ -692,13 +748,14 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
       // bound of tier 0.
 #pragma unroll
       for (int q = 0; q < R; q++) {
+        if (q >= Rn) continue;
         const double x = sx[q], y = sy[q];
         double nx = 0.0, ny = 0.0;
         nx += x * co; nx += y * (-si);
         ny += x * si; ny += y * co;
         nx = nx + dX; ny = ny + dY;
         const double ex = nx - x, ey = ny - y;
-        const float disp = sqrtf((float)(ex * ex + ey * ey) * 1.000001f) * 1.000001f;
+        const float disp = __builtin_amdgcn_sqrtf((float)(ex * ex + ey * ey) * 1.000001f) * 1.000001f;
         lb[q] = lb[q] - (double)disp;
         sx[q] = nx; sy[q] = ny;
       }
@@ -740,8 +797,6 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
   __syncthreads();
   if (tid == 0) {
     st_acc[6] = L.ired[IR_DBG]; st_acc[7] = L.ired[IR_DBG + 1];     // searched points / wave searches
-    printf("wave0: window rounds %d cycles %d (avg %d), tier2 cycles %d\n", L.ired[IR_DBG + 3], L.ired[IR_DBG + 2],
-           L.ired[IR_DBG + 2] / (L.ired[IR_DBG + 3] > 0 ? L.ired[IR_DBG + 3] : 1), L.ired[IR_DBG + 4]);
     for (int i = 0; i < 8; i++) trace[4 * TSD_ICP_TRACE_MAX - 8 + i] = (double)st_acc[i];
   }
 #endif
@@ -771,10 +826,11 @@ static int icp_cap_for(int n)
 template <int R, int MAXT>
 static int launch_icp_shape(tsd_ctx* ctx, const IcpArgs& a, int n, int cap, const double* P_dev,
                             const double* d_rays_local, const double* d_ranges, const uint8_t* d_mask,
-                            const ScanPostArgs& post)
+                            const ScanPostArgs& post, int force_T = 0)
 {
   int T = ((n + R - 1) / R + 63) & ~63;
   if (T < 64) T = 64;
+  if (force_T > T) T = force_T;
   if (T > MAXT) return set_error(ctx, TSD_E_CAPACITY, "icp workgroup shape", hipSuccess);
   const size_t lds = icp_lds_bytes_for(cap, T);
   static size_t configured = 0;
@@ -804,6 +860,7 @@ int launch_icp(tsd_ctx* ctx, const IcpArgs& a, const double* P_dev, const double
   const int nthr = a.beams > 0 ? a.beams : a.n_scene;     // scene points decide the thread count
   switch (ctx->icp_shape) {      // TSD_ICP_SHAPE: experiments only
     case 2: return launch_icp_shape<2, 576>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post);
+    case 3: return launch_icp_shape<3, 512>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post, 512);
     case 5: return launch_icp_shape<5, 256>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post);
     case 8: return launch_icp_shape<8, 256>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post);
     default: break;
