@@ -41,6 +41,7 @@ namespace tsd {
 constexpr int ICP_MAXW = 16;                    // waves per workgroup at most
 constexpr double SLACK = 1.0 - 1e-9;            // conservative factor on every pruning bound
 constexpr int HW = 6;                           // tier-1 window: k-6 .. k+6
+constexpr int ICP_PAD = 96;                     // wrapped copies of the model at both ends of its LDS array
 #ifndef TSD_ICP_REFRESH_A
 #define TSD_ICP_REFRESH_A 6
 #define TSD_ICP_REFRESH_B 12
@@ -51,7 +52,12 @@ constexpr int IR_CNT = 32, IR_RMAX = 33, IR_CNT2 = 34, IR_TIE = 35;   // words o
 constexpr int IR_DBG = 40;
 #endif
 
+// what the kernel needs again only after the last step (and the trace pointer, once per step by one
+// thread): parked in LDS so that it does not sit in scalar registers through the loop
+struct IcpTail { IcpResultDev* out; double* trace; ScanPostArgs post; };
+
 struct IcpLds {
+  IcpTail* tail;
   double2* mxy;                    // model (angular order)
   double2* uxy;                    // unit direction of every model point (0,0 for a point at the origin)
   unsigned long long* slotD;       // [cap] reciprocal filter: min d2 (bit pattern) per model slot
@@ -85,8 +91,9 @@ __host__ __device__ inline size_t icp_region_bytes(int cap, int threads)
 __host__ __device__ inline size_t icp_lds_bytes_for(int cap, int threads)
 {
   // the staging (cap double2 + cap int) aliases the list + result arrays: 40 * lc >= 20 * cap
-  return sizeof(double2) * 2 * (size_t)cap + sizeof(unsigned long long) * (size_t)cap + sizeof(int) * 2 * (size_t)cap +
-         icp_region_bytes(cap, threads) + sizeof(double) * (2 * ICP_MAXW * 16 + 16) + sizeof(int) * 64 + 64;
+  return sizeof(double2) * 2 * (size_t)cap + sizeof(double2) * 2 * ICP_PAD + sizeof(unsigned long long) * (size_t)cap + sizeof(int) * 2 * (size_t)cap +
+         icp_region_bytes(cap, threads) + sizeof(double) * (2 * ICP_MAXW * 16 + 16) + ((sizeof(IcpTail) + 15) & ~(size_t)15) +
+         sizeof(int) * 64 + 64;
 }
 
 // a wave-uniform value the compiler must keep in a vector register
@@ -135,6 +142,12 @@ __device__ __forceinline__ double wave_min(double v)
 // distance to every slot other than those two
 struct NnResult { double best, lbsq; int bk, bk2; bool resolved; };
 
+// lower bound (distance) from its square: fp32 square root rounded down by more than its error
+__device__ __forceinline__ double lb_from_sq(double lbsq)
+{
+  return (double)__builtin_amdgcn_sqrtf((float)lbsq) * (1.0 - 1e-6);
+}
+
 // running three smallest squared distances (the two smallest with their slots)
 struct Top3 { double b1, b2, b3; int k1, k2; };
 __device__ __forceinline__ void top3_insert(Top3& t, double d, int k)
@@ -163,13 +176,26 @@ __device__ __forceinline__ double sep_bound(double x, double y, double rs2, doub
 // the two ends cannot bound what lies outside, the arc grows by another 2*HW+1 slots on its weaker side (the
 // neighbour of a scan that turned against the prediction sits the same number of slots away for every
 // point), up to WIN_ROUNDS times; only then the point goes to the whole-wave search.
+//
+// Instruction diet (this is the hot loop of the first steps): the model array carries ICP_PAD wrapped
+// copies at both ends, so a round is 13 reads at constant offsets from one address; the running three
+// smallest distances carry their slot offset in the low 8 mantissa bits, so the insertion is five
+// v_min/v_max_f64 and no index bookkeeping.  Packed order equals true order unless the upper 56 bits
+// agree; the two nearest are therefore re-evaluated exactly at the end (ties: lower original index) and
+// a third candidate in the same 256-ulp bucket sends the point to the exact whole-wave search.
 constexpr int WIN = 2 * HW + 1;
 constexpr int WIN_ROUNDS = 6;
+constexpr int INLINE_MAX = 6;                   // points a wave resolves on the spot instead of listing them
+static_assert(ICP_PAD >= HW + WIN_ROUNDS * WIN, "padding must cover the widest window");
 __device__ __forceinline__ int wrap_slot(int k, int nM)
 {
   k += (k < 0) ? nM : 0;
   k -= (k >= nM) ? nM : 0;
   return k;
+}
+__device__ __forceinline__ double pack_code(double d, int code)
+{
+  return __hiloint2double(__double2hiint(d), (__double2loint(d) & ~0xFF) | code);
 }
 __device__ __forceinline__ NnResult window_search(const IcpLds& L, int nM, double x, double y, int c,
                                                   double thr, double sgn)
@@ -177,40 +203,53 @@ __device__ __forceinline__ NnResult window_search(const IcpLds& L, int nM, doubl
   NnResult r;
   r.best = __builtin_inf(); r.lbsq = 0.0; r.bk = -1; r.bk2 = -1; r.resolved = false;
   if (nM <= WIN) return r;
-  Top3 t;
-  t.b1 = t.b2 = t.b3 = __builtin_inf(); t.k1 = t.k2 = -1;
+  double b1 = __builtin_inf(), b2 = __builtin_inf(), b3 = __builtin_inf();   // packed (offset + 128 in the low byte)
   const double rs2 = x * x + y * y;
-  int lo = c - HW, hi = c + HW;                 // visited arc, unwrapped slot numbers
+  int lo = -HW, hi = HW;                        // visited arc, offsets relative to c
   double blo = 0.0, bhi = 0.0;                  // bounds on everything below lo / above hi
-  int b = lo;                                   // first slot of the round
+  int b = lo;                                   // first offset of the round
   int side = 0;                                 // 0: first round (both ends), -1: grew downwards, +1: upwards
+  bool proven = false;
   for (int round = 0;; round++) {
+    const double2* base = L.mxy + (c + b);      // padded: c + b + j stays inside [-ICP_PAD, nM + ICP_PAD)
     double2 m[WIN];
-    int kk[WIN];
 #pragma unroll
-    for (int j = 0; j < WIN; j++) {
-      kk[j] = wrap_slot(b + j, nM);
-      m[j] = L.mxy[kk[j]];
-    }
-    const double2 ulo = L.uxy[kk[0]], uhi = L.uxy[kk[WIN - 1]];
+    for (int j = 0; j < WIN; j++) m[j] = base[j];
+    const double2 ulo = L.uxy[wrap_slot(c + b, nM)], uhi = L.uxy[wrap_slot(c + b + WIN - 1, nM)];
+    const int code0 = b + 128;
 #pragma unroll
     for (int j = 0; j < WIN; j++) {
       const double dx = x - m[j].x, dy = y - m[j].y;
-      top3_insert(t, dx * dx + dy * dy, kk[j]);
+      const double d = pack_code(dx * dx + dy * dy, code0 + j);
+      const double h1 = fmax(b1, d); b1 = fmin(b1, d);
+      const double h2 = fmax(b2, h1); b2 = fmin(b2, h1);
+      b3 = fmin(b3, h2);
     }
     // the low end must lie clockwise of s (in slot order) and the high end counter-clockwise
     double cr;
     if (side <= 0) { const double l2 = sep_bound(x, y, rs2, ulo, cr); blo = cr * sgn <= 0.0 ? l2 : 0.0; }
     if (side >= 0) { const double l2 = sep_bound(x, y, rs2, uhi, cr); bhi = cr * sgn >= 0.0 ? l2 : 0.0; }
-    const double lbo = fmin(blo, bhi);
-    if (lbo > fmin(t.b1, thr)) { r.resolved = true; break; }
+    // (b1 packed differs from the true distance by < 256 ulp; SLACK in the bounds covers that)
+    if (fmin(blo, bhi) > fmin(b1, thr)) { proven = true; break; }
     if (round == WIN_ROUNDS || hi - lo + 1 + WIN > nM) break;
     if (blo <= bhi) { side = -1; lo -= WIN; b = lo; }
     else { side = 1; b = hi + 1; hi += WIN; }
   }
-  top3_tiebreak(L, t);
-  r.best = t.b1; r.bk = t.k1; r.bk2 = t.k2;
-  r.lbsq = fmin(t.b3, fmin(blo, bhi));
+  if (!(b1 < __builtin_inf())) return r;        // no finite distance at all (non-finite point): tier 2 sorts it out
+  // unpack the two nearest and evaluate them exactly
+  const int o1 = (__double2loint(b1) & 0xFF) - 128, o2 = (__double2loint(b2) & 0xFF) - 128;
+  int k1 = wrap_slot(c + o1, nM), k2 = wrap_slot(c + o2, nM);
+  const double2 m1 = L.mxy[k1], m2 = L.mxy[k2];
+  double d1, d2;
+  { const double dx = x - m1.x, dy = y - m1.y; d1 = dx * dx + dy * dy; }
+  { const double dx = x - m2.x, dy = y - m2.y; d2 = dx * dx + dy * dy; }
+  if (d2 < d1 || (d2 == d1 && L.morig[k2] < L.morig[k1])) { const int t = k1; k1 = k2; k2 = t; d1 = d2; }
+  // third candidate in the same bucket as the nearest: order unknown here
+  const double b3c = pack_code(b3, 0);
+  const bool crowded = !(b3c > pack_code(b1, 0));
+  r.best = d1; r.bk = k1; r.bk2 = k2;
+  r.lbsq = fmin(b3c, fmin(blo, bhi));
+  r.resolved = proven && !crowded && !isnan(d1);
   return r;
 }
 
@@ -350,7 +389,7 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
   const int lcap = icp_list_cap(cap);
   {
     char* p = smem;
-    L.mxy = reinterpret_cast<double2*>(p); p += sizeof(double2) * (size_t)cap;
+    L.mxy = reinterpret_cast<double2*>(p) + ICP_PAD; p += sizeof(double2) * (size_t)(cap + 2 * ICP_PAD);
     L.uxy = reinterpret_cast<double2*>(p); p += sizeof(double2) * (size_t)cap;
     L.list_xy = reinterpret_cast<double2*>(p); L.stage_s = reinterpret_cast<double2*>(p);
     p += sizeof(double2) * (size_t)lcap;
@@ -366,6 +405,7 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
     L.slotD = reinterpret_cast<unsigned long long*>(p); p += sizeof(unsigned long long) * (size_t)cap;
     L.red = reinterpret_cast<double*>(p); p += sizeof(double) * 2 * ICP_MAXW * 16;
     L.cst = reinterpret_cast<double*>(p); p += sizeof(double) * 16;
+    L.tail = reinterpret_cast<IcpTail*>(p); p += (sizeof(IcpTail) + 15) & ~(size_t)15;
     L.tr = reinterpret_cast<double*>(L.list_xy);     // T * 72 B <= 40 * lcap B (checked by the launcher)
     L.slotI = reinterpret_cast<int*>(p); p += sizeof(int) * (size_t)cap;
     L.morig = reinterpret_cast<int*>(p); p += sizeof(int) * (size_t)cap;
@@ -386,42 +426,66 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
 #else
 #define STAMP(i) do {} while (0)
 #endif
+#ifdef TSD_ICP_STAMPS_SETUP   // diagnostic: the setup phase split up instead of the loop phases
+#undef STAMP
+#define STAMP(i) do {} while (0)
+#define SSTAMP(i) do { const long long now_ = clock64(); st_acc[i] += now_ - st_t; st_t = now_; } while (0)
+#else
+#define SSTAMP(i) do {} while (0)
+#endif
 
   // ---------------------------------------------------------------- inputs
   if (a.beams > 0) {
     // fused mode: maskMatrix compaction of the ray-cast model and of the scan's cartesian points.
     // Model points stay in beam order = angular order about the sensor.
-    int baseM = 0, baseS = 0;
-    for (int b0 = 0; b0 < a.beams; b0 += T) {
-      const int b = b0 + tid;
-      bool fm = false, fs = false;
-      double r = 0.0;
-      if (b < a.beams) {
-        fm = g_mask_m[b] != 0;
-        r = g_ranges[b];
-        fs = !isinf(r) && (g_mask[b] != 0);
-      }
-      const unsigned long long bm = __ballot(fm), bs = __ballot(fs);
-      const unsigned long long lt = (1ull << lane) - 1ull;
-      if (lane == 0) { L.ired[wave * 2] = __popcll(bm); L.ired[wave * 2 + 1] = __popcll(bs); }
-      __syncthreads();
-      int offM = baseM, offS = baseS, totM = 0, totS = 0;
+    // Every global read of the kernel is issued here, unconditionally and at once (one memory latency
+    // instead of one per dependent step); the launcher guarantees beams <= R * T.
+    bool fm[R], fs[R];
+    double rr[R], lx[R], ly[R];
+    double2 cm[R];
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+      const int b = q * T + tid;
+      const int bc = b < a.beams ? b : 0;
+      const uint8_t mm = g_mask_m[bc], ms = g_mask[bc];
+      rr[q] = g_ranges[bc];
+      cm[q] = *reinterpret_cast<const double2*>(g_coords + 2 * (size_t)bc);
+      lx[q] = g_rays_local[bc]; ly[q] = g_rays_local[a.beams + bc];
+      fm[q] = (b < a.beams) && mm != 0;
+      fs[q] = (b < a.beams) && !isinf(rr[q]) && ms != 0;
+    }
+    SSTAMP(0);
+    int* cnts = reinterpret_cast<int*>(L.red);           // [R][W][2] (the reduction rows are idle during setup)
+    unsigned long long bm[R], bs[R];
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+      bm[q] = __ballot(fm[q]); bs[q] = __ballot(fs[q]);
+      if (lane == 0) { cnts[(q * W + wave) * 2] = __popcll(bm[q]); cnts[(q * W + wave) * 2 + 1] = __popcll(bs[q]); }
+    }
+    __syncthreads();
+    SSTAMP(1);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int runM = 0, runS = 0;
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+      int offM = 0, offS = 0;
       for (int w = 0; w < W; w++) {
-        const int cm = L.ired[w * 2], cs_ = L.ired[w * 2 + 1];
-        if (w < wave) { offM += cm; offS += cs_; }
-        totM += cm; totS += cs_;
+        const int c_m = cnts[(q * W + w) * 2], c_s = cnts[(q * W + w) * 2 + 1];
+        if (w == wave) { offM = runM; offS = runS; }
+        runM += c_m; runS += c_s;
       }
-      offM += __popcll(bm & lt); offS += __popcll(bs & lt);
-      if (fm && offM < cap) { L.mxy[offM] = make_double2(g_coords[2 * b], g_coords[2 * b + 1]); L.morig[offM] = offM; }
-      if (fs && offS < cap) {
+      offM += __popcll(bm[q] & lt); offS += __popcll(bs[q] & lt);
+      if (fm[q] && offM < cap) { L.mxy[offM] = cm[q]; L.morig[offM] = offM; }
+      if (fs[q] && offS < cap) {
         // coords = raysLocal(j,i) * data[i] (Sensor.cpp:176-179)
-        L.stage_s[offS] = make_double2(g_rays_local[b] * r, g_rays_local[a.beams + b] * r);
+        L.stage_s[offS] = make_double2(lx[q] * rr[q], ly[q] * rr[q]);
         L.start[offS] = offM;      // model slot of the same beam (or of the next hit beam)
       }
-      baseM += totM; baseS += totS;
-      __syncthreads();
     }
-    nM = baseM; nS = baseS;
+    nM = runM; nS = runS;
+    if (a.beams > R * T) nM = cap + 1;                   // (not reachable through launch_icp)
+    __syncthreads();
+    SSTAMP(2);
   } else {
     nM = a.n_model; nS = a.n_scene;
     if (nM <= cap && nS <= cap) {
@@ -431,6 +495,7 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
     __syncthreads();
   }
   if (tid == 0) {
+    L.tail->out = out; L.tail->trace = trace; L.tail->post = post;
     L.ired[IR_CNT] = 0; L.ired[IR_RMAX] = 0; L.ired[IR_CNT2] = 0; L.ired[IR_TIE] = 0;
   }
 
@@ -471,22 +536,29 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
       hint2[q] = hint[q];
     }
   }
+  SSTAMP(3);
   for (int k = tid; k < nM; k += T) {
     const double2 m = L.mxy[k];
     const double r2 = m.x * m.x + m.y * m.y;
     double2 u = make_double2(0.0, 0.0);
-    if (r2 > 0.0) { const double inv = 1.0 / sqrt(r2); u.x = m.x * inv; u.y = m.y * inv; }
+    if (r2 > 0.0) { const double inv = rsqrt(r2); u.x = m.x * inv; u.y = m.y * inv; }   // |u| = 1 within 1e-15: SLACK covers it
     L.uxy[k] = u;
+  }
+  for (int i = tid; i < ICP_PAD; i += T) {        // wrapped copies at both ends (window_search)
+    L.mxy[nM + i] = L.mxy[i % nM];
+    L.mxy[-1 - i] = L.mxy[nM - 1 - (i % nM)];
   }
   for (int k = tid; k < cap; k += T) { L.slotD[k] = ~0ull; L.slotI[k] = INT_MAX; }
 #ifdef TSD_ICP_STAMPS
   if (tid == 0) for (int i = 0; i < 8; i++) L.ired[IR_DBG + i] = 0;
 #endif
+  SSTAMP(4);
   __syncthreads();                     // staging consumed (it aliases the work list); counters zeroed
   if (rmaxf > 0.f) atomicMax(&L.ired[IR_RMAX], __float_as_int(rmaxf));   // positive floats order like ints
   __syncthreads();
   const double scene_rmax = (double)__int_as_float(L.ired[IR_RMAX]);
-  STAMP(0);
+  STAMP(6);
+  SSTAMP(5);
 
   // ---------------------------------------------------------------- iterate
   // loop-invariant scalars: vector registers (the scalar file is the scarce one in this kernel)
@@ -564,6 +636,44 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
         ent[q] = -1;
       }
     }
+    // A wave with only a few points to search resolves them on the spot (one lane-per-point window each):
+    // no list, no barrier.  The dense work list pays off when many lanes of a wave would idle otherwise.
+    {
+      int wneed = 0;
+#pragma unroll
+      for (int q = 0; q < R; q++) wneed += __popcll(__ballot(need[q]));
+      if (wneed > 0 && wneed <= INLINE_MAX) {
+        bool tolist[R];
+#pragma unroll
+        for (int q = 0; q < R; q++) tolist[q] = false;
+        for (int pass = 0; pass < R; pass++) {
+          int sel = -1;
+#pragma unroll
+          for (int q = R - 1; q >= 0; q--) if (need[q]) sel = q;
+          if (!__ballot(sel >= 0)) break;
+          double x = 0.0, y = 0.0; int hk = 0;
+#pragma unroll
+          for (int q = 0; q < R; q++) if (sel == q) { x = sx[q]; y = sy[q]; hk = hint[q]; }
+          if (sel >= 0) {
+            const NnResult r = window_search(L, nM, x, y, hk, thr, sgn);
+            const double2 mk = L.mxy[r.bk >= 0 ? r.bk : 0];
+            const double lbn = lb_from_sq(r.lbsq);
+#pragma unroll
+            for (int q = 0; q < R; q++)
+              if (sel == q) {
+                need[q] = false;
+                if (r.resolved) { bd[q] = r.best; hint[q] = r.bk; hint2[q] = r.bk2; lb[q] = lbn; mw[q] = mk; keep[q] = r.best <= thr; }
+                else tolist[q] = true;
+              }
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < R; q++) need[q] = tolist[q];
+#ifdef TSD_ICP_STAMPS
+        if (lane == 0) atomicAdd(&L.ired[IR_DBG + 2], wneed);
+#endif
+      }
+    }
     // -- ReciprocalFilter, first half: per model slot the smallest d2 (LDS atomic min on the bit pattern).
     // Pairs settled by tier 0 go in right away; two scene points with the SAME d2 to one slot are the only
     // case that needs the index round below, and the later of the two sees its own value come back.
@@ -602,7 +712,7 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
           if (e < n) {
             const double2 s = L.list_xy[e];
             const NnResult r = window_search(L, nM, s.x, s.y, L.list_k[e], thr, sgn);
-            if (r.resolved) { L.res_d[e] = r.best; L.res_k[e] = r.bk; L.res_k2[e] = r.bk2; L.res_lb[e] = sqrt(r.lbsq) * SLACK; }
+            if (r.resolved) { L.res_d[e] = r.best; L.res_k[e] = r.bk; L.res_k2[e] = r.bk2; L.res_lb[e] = lb_from_sq(r.lbsq); }
             else L.list2[atomicAdd(&L.ired[IR_CNT2], 1)] = e;      // tier 2, shared out over all waves below
           }
         }
@@ -616,7 +726,7 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
             const int es = L.list2[i];
             const double2 s = L.list_xy[es];
             const NnResult r = wave_search(L, nM, s.x, s.y, L.list_k[es], thr, sgn, lane);
-            if (lane == 0) { L.res_d[es] = r.best; L.res_k[es] = r.bk; L.res_k2[es] = r.bk2; L.res_lb[es] = sqrt(r.lbsq) * SLACK; }
+            if (lane == 0) { L.res_d[es] = r.best; L.res_k[es] = r.bk; L.res_k2[es] = r.bk2; L.res_lb[es] = lb_from_sq(r.lbsq); }
           }
           __syncthreads();
           if (tid == 0) L.ired[IR_CNT2] = 0;
@@ -783,7 +893,7 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
     rms_prev = rms;
     STAMP(5);
     if (tid == 0 && iter <= TSD_ICP_TRACE_MAX) {
-      double* tr = trace + 4 * (iter - 1);
+      double* tr = L.tail->trace + 4 * (iter - 1);
       tr[0] = (double)pairs; tr[1] = rms; tr[2] = thr_before; tr[3] = (double)state;
 #ifdef TSD_ICP_STAMPS
       tr[2] = (double)st_acc[1];        // cumulative phase-A cycles      (diagnostic build only)
@@ -796,8 +906,8 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
 #ifdef TSD_ICP_STAMPS
   __syncthreads();
   if (tid == 0) {
-    st_acc[6] = L.ired[IR_DBG]; st_acc[7] = L.ired[IR_DBG + 1];     // searched points / wave searches
-    for (int i = 0; i < 8; i++) trace[4 * TSD_ICP_TRACE_MAX - 8 + i] = (double)st_acc[i];
+    st_acc[7] = L.ired[IR_DBG + 1];     // setup cycles / wave searches
+    for (int i = 0; i < 8; i++) L.tail->trace[4 * TSD_ICP_TRACE_MAX - 8 + i] = (double)st_acc[i];
   }
 #endif
   {
@@ -808,9 +918,10 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
     r.T[6] = 0.0; r.T[7] = 0.0; r.T[8] = 1.0;
     r.rms = rms; r.pairs = pairs; r.iterations = (int)iter; r.state = state;
     r.n_model = nM; r.n_scene = nS; r.reserved = 0;
-    if (tid == 0) *out = r;
+    const IcpTail tl = *L.tail;
+    if (tid == 0) *tl.out = r;
     // fused scan: gates, Sensor::transform, push / next-scan arguments, result record for the host
-    if (post.st) scan_post_body(post, r.T, r, post.gmin_x, post.gmax_x, post.gmin_y, post.gmax_y);
+    if (tl.post.st) scan_post_body(tl.post, r.T, r, tl.post.gmin_x, tl.post.gmax_x, tl.post.gmin_y, tl.post.gmax_y);
   }
 }
 

@@ -14,7 +14,8 @@ poses = synth.trajectory(world, N)
 scans = synth.scans_for(world, geo, poses)
 node = facade.SlamNode(facade.node_params(gc, geo), device=0, synchronous=True)
 grid = node.grid()
-names = ["setup+tier0", "A search", "BC reciprocal", "D sums1", "F sums2+trig", "G transform+ctl"]
+import os
+names = ["setup+tier0", "A search", "BC reciprocal", "D sums1", "F sums2+trig", "G transform+ctl"] if "SETUP" not in os.environ.get("TSD_EXTRA", "") else ["s0 loads", "s1 ballot+bar", "s2 compaction", "s3 take regs", "s4 unit+pads", "s5 rmax"]
 acc = np.zeros(8); cnt = 0
 grid.profile(True, "icp"); grid.profile_reset()
 for k in range(N):
@@ -29,6 +30,6 @@ for k in range(N):
         print("   searched/step:", np.diff(np.concatenate([[0], tr[:30, 1]])).astype(int).tolist(), "wave searches", int(st[7]))
 ms, n = grid.profile_get("icp")
 print("avg over %d scans: kernel ms %.3f, cycles total %.0f" % (cnt, ms / max(n, 1), acc[:6].sum() / cnt),
-      {nm: "%.0f" % (c / cnt / 30) for nm, c in zip(names, acc[:6])}, "searched pts %.0f wave searches %.1f" % (acc[6] / cnt, acc[7] / cnt))
+      {nm: "%.0f" % (c / cnt / 30) for nm, c in zip(names, acc[:6])}, "setup cycles %.0f wave searches %.1f" % (acc[6] / cnt, acc[7] / cnt))
 node.close()
 PY
