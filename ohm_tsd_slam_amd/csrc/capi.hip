@@ -197,19 +197,20 @@ static int read_total_stats(tsd_ctx* ctx, tsd_push_stats* out, int64_t* pushes, 
 {
   const size_t T = (size_t)ctx->grid.tiles;
   std::vector<uint32_t> tot(T * 8);
-  unsigned long long np = 0;
+  unsigned long long np[2] = {0, 0};
   TSD_HIP_CHECK(ctx, hipMemcpyAsync(tot.data(), ctx->d_tile_totals, T * 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-  TSD_HIP_CHECK(ctx, hipMemcpyAsync(&np, ctx->d_pushes, sizeof(np), hipMemcpyDeviceToHost, ctx->stream));
+  TSD_HIP_CHECK(ctx, hipMemcpyAsync(np, ctx->d_pushes, sizeof(np), hipMemcpyDeviceToHost, ctx->stream));
   if (reset) {
     TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_tile_totals, 0, T * 8 * sizeof(uint32_t), ctx->stream));
     TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_pushes, 0, sizeof(np), ctx->stream));
   }
   TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (np[1] != 0) return set_error(ctx, TSD_E_HIP, "push launch window missed the sensor position", hipSuccess);
   unsigned long long t[7] = {0, 0, 0, 0, 0, 0, 0};
   for (size_t p = 0; p < T; p++)
     for (int k = 0; k < 7; k++) t[k] += tot[p * 8 + k];
   if (out) fill_stats(ctx, t, out);
-  if (pushes) *pushes = (int64_t)np;
+  if (pushes) *pushes = (int64_t)np[0];
   return TSD_OK;
 }
 
@@ -265,7 +266,7 @@ tsd_ctx* tsd_create(int device, int map_size_log2, double cell_size, double max_
   A(hipMalloc(&ctx->d_tile_rec, T * sizeof(uint32_t)));
   A(hipMalloc(&ctx->d_dirty, T));
   A(hipMalloc(&ctx->d_tile_totals, T * 8 * sizeof(uint32_t)));
-  A(hipMalloc(&ctx->d_pushes, sizeof(unsigned long long)));
+  A(hipMalloc(&ctx->d_pushes, 2 * sizeof(unsigned long long)));
   A(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
   A(hipEventCreateWithFlags(&ctx->ev_tables, hipEventDisableTiming));
   ctx->stage_bytes = (size_t)TSD_MAX_BEAMS * (8 * 5 + 1) + 256;   // ranges + 2x rays(2) + mask; >= icp staging (80 KB)
@@ -334,7 +335,8 @@ int tsd_reset(tsd_ctx* ctx)
   TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_dirty, 0, T, ctx->stream));
   TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_tile_rec, 0, T * sizeof(uint32_t), ctx->stream));
   TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_tile_totals, 0, T * 8 * sizeof(uint32_t), ctx->stream));
-  TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_pushes, 0, sizeof(unsigned long long), ctx->stream));
+  TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_pushes, 0, 2 * sizeof(unsigned long long), ctx->stream));
+  ctx->box_prev = TileBox{}; ctx->box_dirty = TileBox{};
   TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_occ, 0xFF, (size_t)g.N * g.N, ctx->stream));   // -1 (ThreadGrid.cpp:27-28)
   TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return TSD_OK;
@@ -413,7 +415,7 @@ int tsd_push(tsd_ctx* ctx, const double pose33[9], const double* ranges, const u
 
   int rc = launch_push_tables(ctx, ctx->stream, beams, nullptr, nullptr);
   if (rc != TSD_OK) return rc;
-  rc = launch_push(ctx, a);
+  rc = launch_push(ctx, a, a.trx, a.try_, 0.0);
   if (rc != TSD_OK) return rc;
   if (stats) {
     rc = read_last_push_stats(ctx, stats);
@@ -756,6 +758,7 @@ int tsd_sensor_set_pose(tsd_sensor* s, const double pose33[9], const double* ray
   SensorDev st;
   std::memset(&st, 0, sizeof(st));
   for (int i = 0; i < 9; i++) st.pose[i] = pose33[i];
+  s->pos[0] = pose33[2]; s->pos[1] = pose33[5];
   st.have_last_pose = 0;
   // constant parts of the kernel arguments (the pose dependent parts are derived on the device)
   st.rc.idx_min = s->min_range / ctx->grid.cs;
@@ -831,8 +834,10 @@ int tsd_scan(tsd_sensor* s, const double* ranges, const uint8_t* mask, const uin
   PushArgs pa;
   std::memset(&pa, 0, sizeof(pa));
   pa.beams = s->beams;                                   // LDS size of the launch
+  pa.max_range = s->max_range;                           // tile window of the launch (the rest is read on the device)
   TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_tables, 0));
-  rc = launch_push(ctx, pa, &s->d_state->push, d_ranges, d_mask_push);
+  // the registration moves the sensor by at most the gate (a larger step is rejected: pose unchanged)
+  rc = launch_push(ctx, pa, s->pos[0], s->pos[1], gates->reg_trs_max, &s->d_state->push, d_ranges, d_mask_push);
   if (rc != TSD_OK) return rc;
   // The result is known once k_scan_post has run; the push kernels behind it only touch the grid, and
   // whatever the caller enqueues next is ordered behind them on the stream.  So the host does not wait for
@@ -854,6 +859,7 @@ int tsd_scan(tsd_sensor* s, const double* ranges, const uint8_t* mask, const uin
   }
   copy_icp_result(&s->h_result->icp, &result->icp);
   for (int i = 0; i < 9; i++) result->pose[i] = s->h_result->pose[i];
+  s->pos[0] = result->pose[2]; s->pos[1] = result->pose[5];
   result->reg_error = s->h_result->reg_error; result->pushed = s->h_result->pushed;
   result->no_model = s->h_result->no_model; result->reserved = 0;
   return TSD_OK;

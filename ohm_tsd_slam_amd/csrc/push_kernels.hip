@@ -161,10 +161,12 @@ __device__ __forceinline__ bool add_tsd(double& tsd, double& weight, double sd, 
 
 __global__ void __launch_bounds__(UPDATE_BLOCK)
 k_push_tiles(GridDev g, PushArgs a_val, const PushArgs* __restrict__ a_dev, const double* __restrict__ ranges,
-             const uint8_t* __restrict__ mask, const char* __restrict__ rmq_buf, uint32_t* __restrict__ tile_rec)
+             const uint8_t* __restrict__ mask, const char* __restrict__ rmq_buf, uint32_t* __restrict__ tile_rec,
+             int tx0, int ty0)
 {
   const PushArgs a = a_dev ? *a_dev : a_val;
-  const int p = blockIdx.x;
+  // the launch covers the tile window the scan can reach (launch_push); tiles outside fail the range cull
+  const int p = (ty0 + (int)blockIdx.y) * g.PX + tx0 + (int)blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
   if (!a.enabled) { if (tid == 0) tile_rec[p] = 0u; return; }   // push gated off on the device (fused scan)
 
@@ -355,13 +357,19 @@ constexpr int TOT_FIELDS = 8;   // cells updated, range pass, update, new, new f
 __global__ void __launch_bounds__(256)
 k_push_halo(GridDev g, const uint32_t* __restrict__ tile_rec, uint8_t* __restrict__ dirty,
             uint32_t* __restrict__ tile_totals /* [tiles][TOT_FIELDS] */, unsigned long long* __restrict__ pushes,
-            const PushArgs* __restrict__ a_dev)
+            PushArgs a_val, const PushArgs* __restrict__ a_dev, int tx0, int ty0, int ntx, int nty, double cx, double cy, double slack)
 {
   const int lane = threadIdx.x & 63;
-  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (p >= g.tiles) return;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= ntx * nty) return;
+  const int p = (ty0 + t / ntx) * g.PX + tx0 + t % ntx;
   if (a_dev != nullptr && !a_dev->enabled) return;            // push gated off on the device: nothing happened
-  if (p == 0 && lane == 0) pushes[0] += 1ull;
+  if (t == 0 && lane == 0) {
+    pushes[0] += 1ull;
+    // the window was laid around (cx, cy) +- slack by the host: a sensor outside of that is a host-side bug
+    const double sx = a_dev ? a_dev->trx : a_val.trx, sy = a_dev ? a_dev->try_ : a_val.try_;
+    if (!(fabs(sx - cx) <= slack && fabs(sy - cy) <= slack)) pushes[1] += 1ull;
+  }
   const uint32_t rec = tile_rec[p];
   const bool was_dirty = dirty[p] != 0;                       // written by freeFootprint since the last push
   if (rec == 0u && !was_dirty) return;
@@ -443,6 +451,8 @@ int launch_free_footprint(tsd_ctx* ctx, unsigned minX, unsigned maxX, unsigned m
   hipLaunchKernelGGL(k_free_footprint, dim3(ntx * nty), dim3(256), 0, ctx->stream, ctx->grid, minX,
                      maxX, minY, maxY, tx0, ty0, ntx, ctx->d_dirty);
   TSD_HIP_CHECK(ctx, hipGetLastError());
+  TileBox b; b.x0 = (int)tx0; b.y0 = (int)ty0; b.x1 = (int)tx1; b.y1 = (int)ty1;
+  ctx->box_dirty.add(b);             // the next push refreshes the halos there
   return TSD_OK;
 }
 
@@ -465,22 +475,45 @@ int launch_push_tables(tsd_ctx* ctx, hipStream_t stream, int beams, const double
 }
 
 // the tables of this scan must already be in ctx->d_rmq (launch_push_tables, ordered before this)
-int launch_push(tsd_ctx* ctx, const PushArgs& a, const PushArgs* a_dev, const double* d_ranges, const uint8_t* d_mask)
+int launch_push(tsd_ctx* ctx, const PushArgs& a, double cx, double cy, double slack, const PushArgs* a_dev,
+                const double* d_ranges, const uint8_t* d_mask)
 {
   const GridDev& g = ctx->grid;
   if (!d_ranges) d_ranges = ctx->d_ranges;
   if (!d_mask) d_mask = ctx->d_mask;
+  // Tile window: a tile passes the range cull of isInRange only if its centre is within
+  // max_range + radius + max_trunc of the sensor (TsdGridComponent.cpp:52-60); the sensor is within `slack`
+  // of (cx, cy).  The window also covers the previous push (its records are rewritten) and whatever
+  // freeFootprint touched since.  sensor max_range comes from the by-value args or the attached sensor.
+  TileBox box;
+  {
+    const double tile = TILE_DIM * g.cs;
+    const double reach = a.max_range + 0.75 * tile + g.max_trunc + slack + g.cs;      // radius = sqrt(2)/2 tile < 0.75 tile
+    const double last = (double)(g.PX - 1);
+    const double fx0 = floor((cx - reach) / tile) - 1.0, fy0 = floor((cy - reach) / tile) - 1.0;
+    const double fx1 = floor((cx + reach) / tile) + 1.0, fy1 = floor((cy + reach) / tile) + 1.0;
+    if (!(reach < 1e300) || !(fx0 == fx0)) { box.x0 = 0; box.y0 = 0; box.x1 = g.PX - 1; box.y1 = g.PX - 1; }
+    else {
+      box.x0 = (int)fmax(0.0, fmin(last, fx0)); box.y0 = (int)fmax(0.0, fmin(last, fy0));
+      box.x1 = (int)fmax(0.0, fmin(last, fx1)); box.y1 = (int)fmax(0.0, fmin(last, fy1));
+    }
+  }
+  const TileBox cur = box;
+  box.add(ctx->box_prev);
+  box.add(ctx->box_dirty);
+  ctx->box_prev = cur; ctx->box_dirty = TileBox{};
+  const int ntx = box.x1 - box.x0 + 1, nty = box.y1 - box.y0 + 1;
   {
     ScopedKernelTimer t(ctx, "push_update");
     const size_t lds = 16 + (size_t)((a.beams + 1) & ~1) * sizeof(double) + (size_t)((a.beams + 15) & ~15);
-    hipLaunchKernelGGL(k_push_tiles, dim3(g.tiles), dim3(UPDATE_BLOCK), lds, ctx->stream, g, a, a_dev, d_ranges,
-                       d_mask, ctx->d_rmq, ctx->d_tile_rec);
+    hipLaunchKernelGGL(k_push_tiles, dim3(ntx, nty), dim3(UPDATE_BLOCK), lds, ctx->stream, g, a, a_dev, d_ranges,
+                       d_mask, ctx->d_rmq, ctx->d_tile_rec, box.x0, box.y0);
   }
   TSD_HIP_CHECK(ctx, hipGetLastError());
   {
     ScopedKernelTimer t(ctx, "push_halo");
-    hipLaunchKernelGGL(k_push_halo, dim3((g.tiles + 3) / 4), dim3(256), 0, ctx->stream, g, ctx->d_tile_rec, ctx->d_dirty,
-                       ctx->d_tile_totals, ctx->d_pushes, a_dev);
+    hipLaunchKernelGGL(k_push_halo, dim3((ntx * nty + 3) / 4), dim3(256), 0, ctx->stream, g, ctx->d_tile_rec, ctx->d_dirty,
+                       ctx->d_tile_totals, ctx->d_pushes, a, a_dev, box.x0, box.y0, ntx, nty, cx, cy, slack + g.cs);
   }
   TSD_HIP_CHECK(ctx, hipGetLastError());
   return TSD_OK;

@@ -83,6 +83,18 @@ struct ScanPostArgs {
   int pad;
 };
 
+// inclusive tile rectangle (empty when x1 < x0)
+struct TileBox {
+  int x0 = 0, y0 = 0, x1 = -1, y1 = -1;
+  bool empty() const { return x1 < x0 || y1 < y0; }
+  void add(const TileBox& o)
+  {
+    if (o.empty()) return;
+    if (empty()) { *this = o; return; }
+    if (o.x0 < x0) x0 = o.x0; if (o.y0 < y0) y0 = o.y0; if (o.x1 > x1) x1 = o.x1; if (o.y1 > y1) y1 = o.y1;
+  }
+};
+
 struct KernelTimer {
   double total_ms = 0.0;
   int launches = 0;
@@ -103,7 +115,9 @@ struct tsd_ctx {
   uint32_t* d_tile_rec = nullptr;            // [tiles] what the last push did to every tile
   uint8_t* d_dirty = nullptr;                // [tiles] written by freeFootprint since the last push
   uint32_t* d_tile_totals = nullptr;         // [tiles][8] records summed over the pushes since the last reset
-  unsigned long long* d_pushes = nullptr;    // [1] pushes since the last reset
+  unsigned long long* d_pushes = nullptr;    // [2] pushes since the last reset, pushes whose launch window missed the sensor
+  // tile window of the push launches: what the last push covered and what freeFootprint dirtied since
+  tsd::TileBox box_prev{}, box_dirty{};
   hipStream_t stream2 = nullptr;             // side stream: the tables are built while ray cast / ICP run
   hipEvent_t ev_tables = nullptr;
 
@@ -159,6 +173,7 @@ struct tsd_sensor {
   tsd::ScanResultDev* h_result = nullptr;   // pinned, coherent, written by k_scan_post directly
   tsd::ScanResultDev* d_result = nullptr;   // device address of h_result
   unsigned long long seq = 0;
+  double pos[2] = {0, 0};          // host mirror of the sensor position (window of the push launches)
 };
 
 namespace tsd {
@@ -181,8 +196,9 @@ bool kernel_is_timed(const tsd_ctx* ctx, const char* name);
 
 // per-file launchers.  The *_dev pointers are the fused scan path: the kernels then read their pose
 // dependent arguments from the device-resident sensor state instead of the by-value copy.
-int launch_push(tsd_ctx* ctx, const PushArgs& a, const PushArgs* a_dev = nullptr, const double* d_ranges = nullptr,
-                const uint8_t* d_mask = nullptr);
+// (cx, cy) is where the host knows the sensor to be and `slack` how far the device-side pose may be from it
+int launch_push(tsd_ctx* ctx, const PushArgs& a, double cx, double cy, double slack, const PushArgs* a_dev = nullptr,
+                const double* d_ranges = nullptr, const uint8_t* d_mask = nullptr);
 int launch_push_tables(tsd_ctx* ctx, hipStream_t stream, int beams, const double* d_ranges, const uint8_t* d_mask);
 size_t push_rmq_bytes(int beams);
 int launch_free_footprint(tsd_ctx* ctx, unsigned minX, unsigned maxX, unsigned minY, unsigned maxY);
