@@ -181,7 +181,7 @@ def main():
         node.laser(s, geo.angle_min, geo.angle_increment)
     grid.sync()
     stages = {}
-    for name in ("raycast", "icp", "push_update", "push_halo"):
+    for name in ("raycast", "icp", "push_classify", "push_update", "push_halo"):
         ms, n = grid.profile_get(name)
         stages[name] = ms / n if n else None
     grid.profile(False)
@@ -193,7 +193,7 @@ def main():
         bytes_per_launch = bytes_total / max(pushes, 1)
         upd_avg_ms = upd_ms / max(upd_launches, 1)
         achieved = bytes_per_launch / (upd_avg_ms * 1e-3) / 1e9 if upd_avg_ms > 0 else 0.0
-        traffic, traffic_src = pmc_traffic("k_push_tiles") if args.config == "cfg2" and scene == default_scene else (None, None)
+        traffic, traffic_src = pmc_traffic("k_push_update") if args.config == "cfg2" and scene == default_scene else (None, None)
         out = {
             "metric": "scans/sec + ms/ICP-iterate, 4096^2 TSD grid, 1081-beam scan" if args.config == "cfg2"
                       else f"scans/sec + ms/ICP-iterate, {gc.cells}^2 TSD grid, {geo.beams}-beam scan",
@@ -209,7 +209,7 @@ def main():
             "pushes_in_timed_region": pushes, "cells_updated_per_push": st["cells_updated"] / max(pushes, 1),
             "tiles_updated_per_push": st["tiles_update"] / max(pushes, 1),
             "tracking_error_m": track_err,
-            "roofline": {"kernel": "k_push_tiles", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"kernel": "k_push_update", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": upd_avg_ms,
                          "launches": upd_launches},

@@ -25,7 +25,7 @@ int set_error(tsd_ctx* ctx, int code, const char* what, hipError_t e)
   return code;
 }
 
-static const char* const kKernelNames[] = {"push_update", "push_halo", "raycast", "icp", "occupancy"};
+static const char* const kKernelNames[] = {"push_classify", "push_update", "push_halo", "raycast", "icp", "occupancy"};
 
 bool kernel_is_timed(const tsd_ctx* ctx, const char* name)
 {
@@ -267,6 +267,8 @@ tsd_ctx* tsd_create(int device, int map_size_log2, double cell_size, double max_
   A(hipMalloc(&ctx->d_dirty, T));
   A(hipMalloc(&ctx->d_tile_totals, T * 8 * sizeof(uint32_t)));
   A(hipMalloc(&ctx->d_pushes, 2 * sizeof(unsigned long long)));
+  A(hipMalloc(&ctx->d_list, T * sizeof(uint32_t)));
+  A(hipMalloc(&ctx->d_list_cnt, 2 * sizeof(unsigned int)));
   A(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
   A(hipEventCreateWithFlags(&ctx->ev_tables, hipEventDisableTiming));
   ctx->stage_bytes = (size_t)TSD_MAX_BEAMS * (8 * 5 + 1) + 256;   // ranges + 2x rays(2) + mask; >= icp staging (80 KB)
@@ -307,7 +309,7 @@ void tsd_destroy(tsd_ctx* ctx)
   GridDev& g = ctx->grid;
   hipFree(g.flags); hipFree(g.init_weight); hipFree(g.tsd); hipFree(g.weight);
   if (ctx->stream2) hipStreamSynchronize(ctx->stream2);
-  hipFree(ctx->d_rmq); hipFree(ctx->d_tile_rec); hipFree(ctx->d_dirty); hipFree(ctx->d_tile_totals); hipFree(ctx->d_pushes);
+  hipFree(ctx->d_rmq); hipFree(ctx->d_tile_rec); hipFree(ctx->d_dirty); hipFree(ctx->d_tile_totals); hipFree(ctx->d_pushes); hipFree(ctx->d_list); hipFree(ctx->d_list_cnt);
   if (ctx->ev_tables) hipEventDestroy(ctx->ev_tables);
   if (ctx->stream2) hipStreamDestroy(ctx->stream2);
   for (hipEvent_t e : ctx->event_pool) hipEventDestroy(e);
@@ -337,6 +339,7 @@ int tsd_reset(tsd_ctx* ctx)
   TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_tile_totals, 0, T * 8 * sizeof(uint32_t), ctx->stream));
   TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_pushes, 0, 2 * sizeof(unsigned long long), ctx->stream));
   ctx->box_prev = TileBox{}; ctx->box_dirty = TileBox{};
+  TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_list_cnt, 0, 2 * sizeof(unsigned int), ctx->stream));
   TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_occ, 0xFF, (size_t)g.N * g.N, ctx->stream));   // -1 (ThreadGrid.cpp:27-28)
   TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return TSD_OK;

@@ -159,80 +159,124 @@ __device__ __forceinline__ bool add_tsd(double& tsd, double& weight, double sd, 
   return false;
 }
 
-__global__ void __launch_bounds__(UPDATE_BLOCK)
-k_push_tiles(GridDev g, PushArgs a_val, const PushArgs* __restrict__ a_dev, const double* __restrict__ ranges,
-             const uint8_t* __restrict__ mask, const char* __restrict__ rmq_buf, uint32_t* __restrict__ tile_rec,
-             int tx0, int ty0)
+// ---- work list of one push: tiles that need a workgroup (UPDATE, increaseEmptiness of a materialised tile)
+// or only their halos refreshed (freeFootprint marks).  Entry = tile | kind << 28.
+constexpr uint32_t KIND_UPDATE = 1u, KIND_EMPTY = 2u, KIND_HALO = 3u;
+constexpr int KIND_SHIFT = 28;
+constexpr int TOT_FIELDS = 8;   // cells updated, range pass, update, new, new from empty, emptied init, emptied uninit, -
+
+// isInRange for every tile of the launch window, one LANE per tile (TsdGridComponent.cpp:43-124: range cull,
+// four corner back-projections, the two beam-range tests as O(1) table look-ups).  Tiles that need work go
+// to the list (one atomic per wave); increaseEmptiness of a tile that was never materialised is done here
+// (TsdGridPartition.cpp:157-162).  Every tile of the window gets its record.
+__global__ void __launch_bounds__(64)
+k_push_classify(GridDev g, PushArgs a_val, const PushArgs* __restrict__ a_dev, const char* __restrict__ rmq_buf,
+                uint32_t* __restrict__ tile_rec, const uint8_t* __restrict__ dirty, uint32_t* __restrict__ tile_totals,
+                uint32_t* __restrict__ list, unsigned int* __restrict__ list_cnt /* [2] */, int parity,
+                int tx0, int ty0, int ntx, int nty)
 {
   const PushArgs a = a_dev ? *a_dev : a_val;
-  // the launch covers the tile window the scan can reach (launch_push); tiles outside fail the range cull
-  const int p = (ty0 + (int)blockIdx.y) * g.PX + tx0 + (int)blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63;
-  if (!a.enabled) { if (tid == 0) tile_rec[p] = 0u; return; }   // push gated off on the device (fused scan)
-
-  // ---- isInRange, evaluated by every wave for itself (TsdGridComponent.cpp:43-124) ----
-  double e[4][2], cx, cy, rad;
-  tile_geometry(g, p, e, cx, cy, rad);
-  // euklideanDistance<obfloat>(pos, _centroid, 2) (mathbase.h:369-378)
-  double sqr = 0.0;
-  { const double t0 = a.trx - cx; sqr += t0 * t0; const double t1 = a.try_ - cy; sqr += t1 * t1; }
-  const double distance = sqrt(sqr);
-  const double closest = distance - rad - g.max_trunc;
-  const double farthest = distance + rad + g.max_trunc;
-  if (closest > a.max_range || farthest < a.min_range) { if (tid == 0) tile_rec[p] = 0u; return; }
-
-  // Past the range cull (a quarter of the tiles): wave 0 does the corner back-projections (one corner per
-  // lane) and the range queries, the other waves wait for its verdict instead of repeating them.
-  __shared__ int s_verdict[2];                                 // action (0 skip, 1 empty, 2 update), all_vis
-  uint32_t rec = REC_RANGE_PASS;
-  if (tid < 64) {
-    int idx = 0;
-    {
-      const int c = lane & 3;
-      const double ex = (c & 1) ? e[1][0] : e[0][0], ey = (c & 2) ? e[2][1] : e[0][1];
-      idx = backproject(a.Pi, ex, ey, a.phi_min, a.ang_res_inv, a.phi_lower, a.phi_upper);
-    }
-    bool all_vis = true, any_vis = false;
-    int lo = 0, hi = 0;
+  const int lane = threadIdx.x;
+  const int t = blockIdx.x * 64 + lane;
+  if (t == 0) list_cnt[parity ^ 1] = 0u;                    // the next push's counter (nobody uses it now)
+  const bool in_window = t < ntx * nty;
+  const int p = in_window ? (ty0 + t / ntx) * g.PX + tx0 + t % ntx : 0;
+  uint32_t rec = 0u, kind = 0u;
+  if (in_window && a.enabled) {
+    double e[4][2], cx, cy, rad;
+    tile_geometry(g, p, e, cx, cy, rad);
+    // euklideanDistance<obfloat>(pos, _centroid, 2) (mathbase.h:369-378)
+    double sqr = 0.0;
+    { const double t0 = a.trx - cx; sqr += t0 * t0; const double t1 = a.try_ - cy; sqr += t1 * t1; }
+    const double distance = sqrt(sqr);
+    const double closest = distance - rad - g.max_trunc;
+    const double farthest = distance + rad + g.max_trunc;
+    if (!(closest > a.max_range || farthest < a.min_range)) {
+      rec = REC_RANGE_PASS;
+      bool all_vis = true, any_vis = false;
+      int lo = 0, hi = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      int ik = __shfl(idx, k, 64);
-      if (ik == -1) { ik = a.beams - 1; all_vis = false; }
-      else if (ik == -2) { ik = 0; all_vis = false; }
-      else any_vis = true;
-      // minmaxArray<int> (mathbase.h:55-64)
-      if (k == 0) { lo = ik; hi = ik; }
-      else { if (lo > ik) lo = ik; else if (hi < ik) hi = ik; }
+      for (int k = 0; k < 4; k++) {
+        const double ex = (k & 1) ? e[1][0] : e[0][0], ey = (k & 2) ? e[2][1] : e[0][1];
+        int ik = backproject(a.Pi, ex, ey, a.phi_min, a.ang_res_inv, a.phi_lower, a.phi_upper);
+        if (ik == -1) { ik = a.beams - 1; all_vis = false; }
+        else if (ik == -2) { ik = 0; all_vis = false; }
+        else any_vis = true;
+        // minmaxArray<int> (mathbase.h:55-64)
+        if (k == 0) { lo = ik; hi = ik; }
+        else { if (lo > ik) lo = ik; else if (hi < ik) hi = ik; }
+      }
+      int action = 0;
+      if (any_vis) {
+        const RmqView rv = rmq_view(const_cast<char*>(rmq_buf), a.beams);
+        const int len = hi - lo + 1;
+        const int k = 31 - __clz(len);                                         // floor(log2(len))
+        const unsigned short* tm = rv.tmax + (size_t)k * rv.Bp;
+        const unsigned short* tn = rv.tmin + (size_t)k * rv.Bp;
+        const int j2 = hi - (1 << k) + 1;
+        const unsigned short i0 = tm[lo], i1 = tm[j2], i2 = tn[lo], i3 = tn[j2];
+        const unsigned short n0 = rv.inf[lo], n1 = rv.inf[hi + 1];
+        const double amax = fmax(rv.A[i0], rv.A[i1]);
+        const double bmin = fmin(rv.Bv[i2], rv.Bv[i3]);
+        const bool has_inf = n1 != n0;
+        const bool visible = amax > closest;
+        const bool empty = (bmin > farthest) && (!has_inf || distance < a.low_refl);
+        if (visible) action = (all_vis && empty) ? 1 : 2;
+      }
+      if (action == 2) kind = KIND_UPDATE;
+      else if (action == 1) {
+        // TsdGridPartition::increaseEmptiness (TsdGridPartition.cpp:136-164), isInRange then returns false
+        if (g.flags[p]) kind = KIND_EMPTY;
+        else {
+          double v = g.init_weight[p] + 1.0; v = fmin(v, MAX_WEIGHT); g.init_weight[p] = v;
+          rec |= REC_EMPTIED_UNINIT;
+          tile_totals[(size_t)p * TOT_FIELDS + 6] += 1u;
+        }
+      }
+      tile_totals[(size_t)p * TOT_FIELDS + 1] += 1u;         // (this lane owns the tile: no atomics)
     }
-    int action = 0;
-    if (any_vis) {
-      const RmqView rv = rmq_view(const_cast<char*>(rmq_buf), a.beams);
-      const int len = hi - lo + 1;
-      const int k = 31 - __clz(len);                                         // floor(log2(len))
-      const unsigned short* tm = rv.tmax + (size_t)k * rv.Bp;
-      const unsigned short* tn = rv.tmin + (size_t)k * rv.Bp;
-      const int j2 = hi - (1 << k) + 1;
-      const double amax = fmax(rv.A[tm[lo]], rv.A[tm[j2]]);
-      const double bmin = fmin(rv.Bv[tn[lo]], rv.Bv[tn[j2]]);
-      const bool has_inf = rv.inf[hi + 1] != rv.inf[lo];
-      const bool visible = amax > closest;
-      const bool empty = (bmin > farthest) && (!has_inf || distance < a.low_refl);
-      if (visible) action = (all_vis && empty) ? 1 : 2;
-    }
-    if (tid == 0) { s_verdict[0] = action; s_verdict[1] = all_vis ? 1 : 0; }
+    if (kind == 0u && dirty[p] != 0) kind = KIND_HALO;       // written by freeFootprint since the last push
   }
-  __syncthreads();
-  const int action = s_verdict[0];
-  if (action == 0) { if (tid == 0) tile_rec[p] = rec; return; }
+  if (in_window && (kind == 0u || kind == KIND_HALO)) tile_rec[p] = rec;   // UPDATE / EMPTY: the workgroup writes the final record
+  const unsigned long long listed = __ballot(kind != 0u);
+  if (listed) {
+    unsigned int base = 0;
+    if (lane == 0) base = atomicAdd(&list_cnt[parity], (unsigned int)__popcll(listed));
+    base = __shfl(base, 0, 64);
+    if (kind != 0u) list[base + __popcll(listed & ((1ull << lane) - 1ull))] = (uint32_t)p | (kind << KIND_SHIFT);
+  }
+}
 
-  double* __restrict__ T = g.tsd + (size_t)p * TILE_STRIDE;
-  double* __restrict__ W = g.weight + (size_t)p * TILE_STRIDE;
-  const bool initialised = g.flags[p] != 0;
-  const double iw = g.init_weight[p];
+// One workgroup per listed tile (TsdGrid.cpp:237-274): scan staged in LDS, 4 cells per thread, row-major =>
+// coalesced 8-byte RMW; lazy TsdGridPartition::init (TsdGridPartition.cpp:88-134) folded in (a fresh tile's
+// old value is known, so it is written once, halo included).  KIND_EMPTY: increaseEmptiness over the 33x33
+// cells.  The workgroup leaves the tile's record and adds it to the tile's running totals.
+__global__ void __launch_bounds__(UPDATE_BLOCK)
+k_push_update(GridDev g, PushArgs a_val, const PushArgs* __restrict__ a_dev, const double* __restrict__ ranges,
+              const uint8_t* __restrict__ mask, uint32_t* __restrict__ tile_rec, uint32_t* __restrict__ tile_totals,
+              const uint32_t* __restrict__ list, const unsigned int* __restrict__ list_cnt, int parity)
+{
+  const unsigned int n_list = list_cnt[parity];
+  if (blockIdx.x >= n_list) return;
+  const PushArgs a = a_dev ? *a_dev : a_val;
+  const int tid = threadIdx.x, lane = tid & 63;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned int* s_upd = reinterpret_cast<unsigned int*>(smem);             // [4] cells updated per wave
+  double* s_ranges = reinterpret_cast<double*>(smem + 16);
+  uint8_t* s_mask = reinterpret_cast<uint8_t*>(smem + 16 + (size_t)((a.beams + 1) & ~1) * sizeof(double));
+  bool staged = false;
 
-  if (action == 1) {
-    // TsdGridPartition::increaseEmptiness (TsdGridPartition.cpp:136-164), isInRange then returns false
-    if (initialised) {
+  for (unsigned int li = blockIdx.x; li < n_list; li += gridDim.x) {
+    const uint32_t entry = list[li];
+    const uint32_t kind = entry >> KIND_SHIFT;
+    const int p = (int)(entry & ((1u << KIND_SHIFT) - 1u));
+    if (kind == KIND_HALO) continue;
+
+    double* __restrict__ T = g.tsd + (size_t)p * TILE_STRIDE;
+    double* __restrict__ W = g.weight + (size_t)p * TILE_STRIDE;
+    uint32_t rec = REC_RANGE_PASS;
+
+    if (kind == KIND_EMPTY) {
       // all 33x33 cells, halo included; the average uses the NEW weight
       for (int i = tid; i < TILE_CELLS; i += UPDATE_BLOCK) {
         double t = T[i], w = W[i];
@@ -241,88 +285,102 @@ k_push_tiles(GridDev g, PushArgs a_val, const PushArgs* __restrict__ a_dev, cons
         T[i] = t; W[i] = w;
       }
       rec |= REC_EMPTIED_INIT;
-    } else {
-      if (tid == 0) { double v = iw + 1.0; v = fmin(v, MAX_WEIGHT); g.init_weight[p] = v; }
-      rec |= REC_EMPTIED_UNINIT;
+      if (tid == 0) { tile_rec[p] = rec; tile_totals[(size_t)p * TOT_FIELDS + 5] += 1u; }
+      continue;
     }
-    if (tid == 0) tile_rec[p] = rec;
-    return;
-  }
 
-  // ---- UPDATE (TsdGrid.cpp:237-274) ----
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  unsigned int* s_upd = reinterpret_cast<unsigned int*>(smem);             // [4] cells updated per wave
-  double* s_ranges = reinterpret_cast<double*>(smem + 16);
-  uint8_t* s_mask = reinterpret_cast<uint8_t*>(smem + 16 + (size_t)((a.beams + 1) & ~1) * sizeof(double));
-  for (int i = tid; i < a.beams; i += UPDATE_BLOCK) { s_ranges[i] = ranges[i]; s_mask[i] = mask[i]; }
-  __syncthreads();
+    // ---- UPDATE ----
+    const bool initialised = g.flags[p] != 0;
+    const double iw = g.init_weight[p];
+    if (!staged) {
+      for (int i = tid; i < a.beams; i += UPDATE_BLOCK) { s_ranges[i] = ranges[i]; s_mask[i] = mask[i]; }
+      staged = true;
+    }
+    __syncthreads();               // scan staged; s_upd of a previous tile consumed
 
-  const bool fresh = !initialised;
-  rec |= REC_UPDATE;
-  if (fresh) rec |= REC_NEW | (iw > 0.0 ? REC_NEW_FROM_EMPTY : 0u);
-  // TsdGridPartition::init values (TsdGridPartition.cpp:98-120)
-  const double t_init = (iw > 0.0) ? 1.0 : __builtin_nan("");
-  const double w_init = iw;
-  const double max_trunc = g.max_trunc;
-  const double inv_max_trunc = 1.0 / max_trunc;
-  const double eps = -g.cs / 2.0;
-  // partition weight (TsdGrid.cpp:239-243)
-  double dist_c = sqrt((cx - a.trx) * (cx - a.trx) + (cy - a.try_) * (cy - a.try_));
-  if (dist_c > a.max_range) dist_c = a.max_range;
-  double pw = (a.max_range - dist_c) / a.max_range;
-  pw *= pw;
+    double e[4][2], cx, cy, rad;
+    tile_geometry(g, p, e, cx, cy, rad);
+    const bool fresh = !initialised;
+    rec |= REC_UPDATE;
+    if (fresh) rec |= REC_NEW | (iw > 0.0 ? REC_NEW_FROM_EMPTY : 0u);
+    // TsdGridPartition::init values (TsdGridPartition.cpp:98-120)
+    const double t_init = (iw > 0.0) ? 1.0 : __builtin_nan("");
+    const double w_init = iw;
+    const double max_trunc = g.max_trunc;
+    const double inv_max_trunc = 1.0 / max_trunc;
+    const double eps = -g.cs / 2.0;
+    // partition weight (TsdGrid.cpp:239-243)
+    double dist_c = sqrt((cx - a.trx) * (cx - a.trx) + (cy - a.try_) * (cy - a.try_));
+    if (dist_c > a.max_range) dist_c = a.max_range;
+    double pw = (a.max_range - dist_c) / a.max_range;
+    pw *= pw;
 
-  const unsigned x0 = (unsigned)(p % g.PX) * TILE_DIM, y0 = (unsigned)(p / g.PX) * TILE_DIM;
-  unsigned int n_upd = 0;
+    const unsigned x0 = (unsigned)(p % g.PX) * TILE_DIM, y0 = (unsigned)(p / g.PX) * TILE_DIM;
+    unsigned int n_upd = 0;
 #pragma unroll
-  for (int k = 0; k < (TILE_DIM * TILE_DIM) / UPDATE_BLOCK; k++) {
-    const int c = tid + UPDATE_BLOCK * k;
-    const unsigned ix = (unsigned)c & 31u, iy = (unsigned)c >> 5;
-    const double ccx = ((double)(x0 + ix) + 0.5) * g.cs;   // TsdGridPartition.cpp:127-128
-    const double ccy = ((double)(y0 + iy) + 0.5) * g.cs;
-    const int ci = (int)(iy * TILE_PITCH + ix);
-    const int index = backproject(a.Pi, ccx, ccy, a.phi_min, a.ang_res_inv, a.phi_lower, a.phi_upper);
-    bool touched = false;
-    double t = t_init, w = w_init;
-    if (index >= 0 && s_mask[index]) {
-      const double r = s_ranges[index];
-      const double dist = sqrt((ccx - a.trx) * (ccx - a.trx) + (ccy - a.try_) * (ccy - a.try_));
-      // the cell is only read when addTsd will update it (sd >= -maxTruncation): cells behind the
-      // surface cost no HBM traffic
-      double sd = 0.0; bool cand = false;
-      if (!isinf(r)) { sd = r - dist; cand = true; }
-      else if (dist < a.low_refl) { sd = max_trunc; cand = true; }
-      if (cand && sd >= -max_trunc) {
-        if (!fresh) { t = T[ci]; w = W[ci]; }
-        touched = add_tsd(t, w, sd, pw, max_trunc, inv_max_trunc, eps);
+    for (int k = 0; k < (TILE_DIM * TILE_DIM) / UPDATE_BLOCK; k++) {
+      const int c = tid + UPDATE_BLOCK * k;
+      const unsigned ix = (unsigned)c & 31u, iy = (unsigned)c >> 5;
+      const double ccx = ((double)(x0 + ix) + 0.5) * g.cs;   // TsdGridPartition.cpp:127-128
+      const double ccy = ((double)(y0 + iy) + 0.5) * g.cs;
+      const int ci = (int)(iy * TILE_PITCH + ix);
+#ifdef TSD_EXP_FAST_BP   // timing experiment only (inexact)
+      int index;
+      {
+        double lx = 0.0, ly = 0.0;
+        lx += a.Pi[0] * ccx; lx += a.Pi[1] * ccy; lx += a.Pi[2] * 1.0;
+        ly += a.Pi[3] * ccx; ly += a.Pi[4] * ccy; ly += a.Pi[5] * 1.0;
+        const float phi = atan2f((float)ly, (float)lx);
+        index = (phi <= (float)a.phi_lower) ? -2 : (phi >= (float)a.phi_upper ? -1 : (int)rintf((phi - (float)a.phi_min) * (float)a.ang_res_inv));
+      }
+#else
+      const int index = backproject(a.Pi, ccx, ccy, a.phi_min, a.ang_res_inv, a.phi_lower, a.phi_upper);
+#endif
+      bool touched = false;
+      double t = t_init, w = w_init;
+      if (index >= 0 && s_mask[index]) {
+        const double r = s_ranges[index];
+        const double dist = sqrt((ccx - a.trx) * (ccx - a.trx) + (ccy - a.try_) * (ccy - a.try_));
+        // the cell is only read when addTsd will update it (sd >= -maxTruncation): cells behind the
+        // surface cost no HBM traffic
+        double sd = 0.0; bool cand = false;
+        if (!isinf(r)) { sd = r - dist; cand = true; }
+        else if (dist < a.low_refl) { sd = max_trunc; cand = true; }
+        if (cand && sd >= -max_trunc) {
+          if (!fresh) { t = T[ci]; w = W[ci]; }
+          touched = add_tsd(t, w, sd, pw, max_trunc, inv_max_trunc, eps);
+        }
+      }
+      if (touched) n_upd++;
+      if (touched || fresh) { T[ci] = t; W[ci] = w; }
+    }
+    if (fresh) {
+      // halo cells of a freshly materialised tile keep the init value until k_push_halo
+      for (int h = tid; h < 2 * TILE_DIM + 1; h += UPDATE_BLOCK) {
+        if (h < TILE_DIM) {
+          T[h * TILE_PITCH + TILE_DIM] = t_init; W[h * TILE_PITCH + TILE_DIM] = w_init;       // column 32
+        } else {
+          const int i = h - TILE_DIM;                                                          // row 32, 0..32
+          T[TILE_DIM * TILE_PITCH + i] = t_init; W[TILE_DIM * TILE_PITCH + i] = w_init;
+        }
       }
     }
-    if (touched) n_upd++;
-    if (touched || fresh) { T[ci] = t; W[ci] = w; }
-  }
-  if (fresh) {
-    // halo cells of a freshly materialised tile keep the init value until k_push_halo
-    for (int h = tid; h < 2 * TILE_DIM + 1; h += UPDATE_BLOCK) {
-      if (h < TILE_DIM) {
-        T[h * TILE_PITCH + TILE_DIM] = t_init; W[h * TILE_PITCH + TILE_DIM] = w_init;       // column 32
-      } else {
-        const int i = h - TILE_DIM;                                                          // row 32, 0..32
-        T[TILE_DIM * TILE_PITCH + i] = t_init; W[TILE_DIM * TILE_PITCH + i] = w_init;
-      }
+    const unsigned wu = (unsigned)wave_sum_i((int)n_upd);
+    if (lane == 0) s_upd[tid >> 6] = wu;
+    __syncthreads();               // every thread is done with the cells (and has read `initialised`)
+    if (tid == 0) {
+      unsigned cells = 0;
+      for (int w = 0; w < UPDATE_BLOCK / 64; w++) cells += s_upd[w];
+      tile_rec[p] = rec | (cells << REC_CELLS_SHIFT);
+      uint32_t* tot = tile_totals + (size_t)p * TOT_FIELDS;
+      tot[0] += cells; tot[2] += 1u;
+      if (fresh) { tot[3] += 1u; if (iw > 0.0) tot[4] += 1u; }
+      if (fresh) g.flags[p] = 1;   // publish the tile
     }
-  }
-  const unsigned wu = (unsigned)wave_sum_i((int)n_upd);
-  if (lane == 0) s_upd[tid >> 6] = wu;
-  __syncthreads();               // every thread is done with the cells (and has read `initialised`)
-  if (tid == 0) {
-    unsigned cells = 0;
-    for (int w = 0; w < UPDATE_BLOCK / 64; w++) cells += s_upd[w];
-    tile_rec[p] = rec | (cells << REC_CELLS_SHIFT);
-    if (fresh) g.flags[p] = 1;   // publish the tile
   }
 }
 
-// TsdGrid::propagateBorders (TsdGrid.cpp:372-427), incremental form.  One wave per touched tile.
+// TsdGrid::propagateBorders (TsdGrid.cpp:372-427), incremental form.  One wave per listed tile.
 __device__ __forceinline__ void copy_col(const GridDev& g, int dst, int src, int lane)
 {
   if (lane < TILE_DIM) {
@@ -349,48 +407,46 @@ __device__ __forceinline__ void copy_corner(const GridDev& g, int dst, int src, 
   }
 }
 
-// One wave per tile (four tiles per workgroup): a tile the push touched (or freeFootprint marked) gets the
-// halos around it refreshed; every tile with a record adds it to its running totals (the host sums them
-// when somebody asks, tsd_push_stats_total).  No list, no atomics.
-constexpr int TOT_FIELDS = 8;   // cells updated, range pass, update, new, new from empty, emptied init, emptied uninit, -
-
+// One wave per listed tile: the tile's own halo from R/U/UR and the halos of L/D/DL that mirror its first
+// column/row/cell.  Equal to the reference's full sweep by induction (untouched pairs are already consistent).
 __global__ void __launch_bounds__(256)
-k_push_halo(GridDev g, const uint32_t* __restrict__ tile_rec, uint8_t* __restrict__ dirty,
-            uint32_t* __restrict__ tile_totals /* [tiles][TOT_FIELDS] */, unsigned long long* __restrict__ pushes,
-            PushArgs a_val, const PushArgs* __restrict__ a_dev, int tx0, int ty0, int ntx, int nty, double cx, double cy, double slack)
+k_push_halo(GridDev g, uint8_t* __restrict__ dirty, unsigned long long* __restrict__ pushes,
+            PushArgs a_val, const PushArgs* __restrict__ a_dev, const uint32_t* __restrict__ list,
+            const unsigned int* __restrict__ list_cnt, int parity, double cx, double cy, double slack)
 {
   const int lane = threadIdx.x & 63;
-  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (t >= ntx * nty) return;
-  const int p = (ty0 + t / ntx) * g.PX + tx0 + t % ntx;
-  if (a_dev != nullptr && !a_dev->enabled) return;            // push gated off on the device: nothing happened
-  if (t == 0 && lane == 0) {
-    pushes[0] += 1ull;
-    // the window was laid around (cx, cy) +- slack by the host: a sensor outside of that is a host-side bug
-    const double sx = a_dev ? a_dev->trx : a_val.trx, sy = a_dev ? a_dev->try_ : a_val.try_;
-    if (!(fabs(sx - cx) <= slack && fabs(sy - cy) <= slack)) pushes[1] += 1ull;
+  const unsigned int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wv == 0 && lane == 0) {
+    const bool enabled = a_dev ? a_dev->enabled != 0 : a_val.enabled != 0;
+    if (enabled) {
+      pushes[0] += 1ull;
+      // the window was laid around (cx, cy) +- slack by the host: a sensor outside of that is a host-side bug
+      const double sx = a_dev ? a_dev->trx : a_val.trx, sy = a_dev ? a_dev->try_ : a_val.try_;
+      if (!(fabs(sx - cx) <= slack && fabs(sy - cy) <= slack)) pushes[1] += 1ull;
+    }
   }
-  const uint32_t rec = tile_rec[p];
-  const bool was_dirty = dirty[p] != 0;                       // written by freeFootprint since the last push
-  if (rec == 0u && !was_dirty) return;
-  if (lane < 7 && rec != 0u) {
-    const uint32_t add = lane == 0 ? (rec >> REC_CELLS_SHIFT) : ((rec >> (lane - 1)) & 1u);
-    if (add) tile_totals[(size_t)p * TOT_FIELDS + lane] += add;
-  }
-  if (was_dirty && lane == 0) dirty[p] = 0;
-  if (!((rec & (REC_UPDATE | REC_EMPTIED_INIT)) != 0u || was_dirty)) return;
-  if (!g.flags[p]) return;
+  const unsigned int n_list = list_cnt[parity];
   const int PX = g.PX;
-  const int px = p % PX, py = p / PX;
-  const bool hasR = px < PX - 1, hasU = py < PX - 1, hasL = px > 0, hasD = py > 0;
-  // (a) own halo from right / up / up-right
-  if (hasR && g.flags[p + 1]) copy_col(g, p, p + 1, lane);
-  if (hasU && g.flags[p + PX]) copy_row(g, p, p + PX, lane);
-  if (hasR && hasU && g.flags[p + PX + 1]) copy_corner(g, p, p + PX + 1, lane);
-  // (b)-(d) neighbours whose halo mirrors this tile
-  if (hasL && g.flags[p - 1]) copy_col(g, p - 1, p, lane);
-  if (hasD && g.flags[p - PX]) copy_row(g, p - PX, p, lane);
-  if (hasL && hasD && g.flags[p - PX - 1]) copy_corner(g, p - PX - 1, p, lane);
+  for (unsigned int li = wv; li < n_list; li += gridDim.x * 4) {
+    const uint32_t entry = list[li];
+    const int p = (int)(entry & ((1u << KIND_SHIFT) - 1u));
+    if (lane == 0 && dirty[p] != 0) dirty[p] = 0;
+    const int px = p % PX, py = p / PX;
+    const bool hasR = px < PX - 1, hasU = py < PX - 1, hasL = px > 0, hasD = py > 0;
+    // all nine flags in flight at once
+    const uint8_t f0 = g.flags[p];
+    const uint8_t fR = hasR ? g.flags[p + 1] : 0, fU = hasU ? g.flags[p + PX] : 0, fUR = (hasR && hasU) ? g.flags[p + PX + 1] : 0;
+    const uint8_t fL = hasL ? g.flags[p - 1] : 0, fD = hasD ? g.flags[p - PX] : 0, fDL = (hasL && hasD) ? g.flags[p - PX - 1] : 0;
+    if (!f0) continue;
+    // (a) own halo from right / up / up-right
+    if (fR) copy_col(g, p, p + 1, lane);
+    if (fU) copy_row(g, p, p + PX, lane);
+    if (fUR) copy_corner(g, p, p + PX + 1, lane);
+    // (b)-(d) neighbours whose halo mirrors this tile
+    if (fL) copy_col(g, p - 1, p, lane);
+    if (fD) copy_row(g, p - PX, p, lane);
+    if (fDL) copy_corner(g, p - PX - 1, p, lane);
+  }
 }
 
 // TsdGrid::freeFootprint (TsdGrid.cpp:609-638): lazily initialise touched tiles, set tsd = 1.0
@@ -503,17 +559,28 @@ int launch_push(tsd_ctx* ctx, const PushArgs& a, double cx, double cy, double sl
   box.add(ctx->box_dirty);
   ctx->box_prev = cur; ctx->box_dirty = TileBox{};
   const int ntx = box.x1 - box.x0 + 1, nty = box.y1 - box.y0 + 1;
+  const int parity = (int)(ctx->push_parity & 1u);
+  ctx->push_parity++;
+  const int n_window = ntx * nty;
+  {
+    ScopedKernelTimer t(ctx, "push_classify");
+    hipLaunchKernelGGL(k_push_classify, dim3((n_window + 63) / 64), dim3(64), 0, ctx->stream, g, a, a_dev, ctx->d_rmq,
+                       ctx->d_tile_rec, ctx->d_dirty, ctx->d_tile_totals, ctx->d_list, ctx->d_list_cnt, parity,
+                       box.x0, box.y0, ntx, nty);
+  }
+  TSD_HIP_CHECK(ctx, hipGetLastError());
+  const int n_groups = n_window < 2048 ? n_window : 2048;      // resident at once; a longer list is looped over
   {
     ScopedKernelTimer t(ctx, "push_update");
     const size_t lds = 16 + (size_t)((a.beams + 1) & ~1) * sizeof(double) + (size_t)((a.beams + 15) & ~15);
-    hipLaunchKernelGGL(k_push_tiles, dim3(ntx, nty), dim3(UPDATE_BLOCK), lds, ctx->stream, g, a, a_dev, d_ranges,
-                       d_mask, ctx->d_rmq, ctx->d_tile_rec, box.x0, box.y0);
+    hipLaunchKernelGGL(k_push_update, dim3(n_groups), dim3(UPDATE_BLOCK), lds, ctx->stream, g, a, a_dev, d_ranges, d_mask,
+                       ctx->d_tile_rec, ctx->d_tile_totals, ctx->d_list, ctx->d_list_cnt, parity);
   }
   TSD_HIP_CHECK(ctx, hipGetLastError());
   {
     ScopedKernelTimer t(ctx, "push_halo");
-    hipLaunchKernelGGL(k_push_halo, dim3((ntx * nty + 3) / 4), dim3(256), 0, ctx->stream, g, ctx->d_tile_rec, ctx->d_dirty,
-                       ctx->d_tile_totals, ctx->d_pushes, a, a_dev, box.x0, box.y0, ntx, nty, cx, cy, slack + g.cs);
+    hipLaunchKernelGGL(k_push_halo, dim3((n_groups + 3) / 4), dim3(256), 0, ctx->stream, g, ctx->d_dirty, ctx->d_pushes,
+                       a, a_dev, ctx->d_list, ctx->d_list_cnt, parity, cx, cy, slack + g.cs);
   }
   TSD_HIP_CHECK(ctx, hipGetLastError());
   return TSD_OK;

@@ -118,6 +118,9 @@ struct tsd_ctx {
   unsigned long long* d_pushes = nullptr;    // [2] pushes since the last reset, pushes whose launch window missed the sensor
   // tile window of the push launches: what the last push covered and what freeFootprint dirtied since
   tsd::TileBox box_prev{}, box_dirty{};
+  uint32_t* d_list = nullptr;               // [tiles] work list of the current push (tile | kind << 28)
+  unsigned int* d_list_cnt = nullptr;       // [2] its length, by push parity
+  unsigned int push_parity = 0;
   hipStream_t stream2 = nullptr;             // side stream: the tables are built while ray cast / ICP run
   hipEvent_t ev_tables = nullptr;
 
