@@ -43,18 +43,18 @@ static hipEvent_t pool_get(tsd_ctx* ctx)
   return e;
 }
 
-ScopedKernelTimer::ScopedKernelTimer(tsd_ctx* c, const char* n) : ctx(c), name(n)
+ScopedKernelTimer::ScopedKernelTimer(tsd_ctx* c, const char* n, bool around_) : ctx(c), name(n), around(around_)
 {
   if (!kernel_is_timed(ctx, n)) return;
   if (ctx->profile_every > 1 && (ctx->profile_tick++ % ctx->profile_every) != 0) return;
   a = pool_get(ctx); b = pool_get(ctx);
   if (!a || !b) { a = b = nullptr; return; }
-  hipEventRecord(a, ctx->stream);
+  if (around) hipEventRecord(a, ctx->stream);
 }
 ScopedKernelTimer::~ScopedKernelTimer()
 {
   if (!a) return;
-  hipEventRecord(b, ctx->stream);
+  if (around) hipEventRecord(b, ctx->stream);
   ctx->timers[name].pending.emplace_back(a, b);
 }
 void drain_timers(tsd_ctx* ctx)
@@ -262,12 +262,16 @@ tsd_ctx* tsd_create(int device, int map_size_log2, double cell_size, double max_
   A(hipMalloc(&g.init_weight, T * sizeof(double)));
   A(hipMalloc(&g.tsd, T * TILE_STRIDE * sizeof(double)));
   A(hipMalloc(&g.weight, T * TILE_STRIDE * sizeof(double)));
-  A(hipMalloc(&ctx->d_rmq, push_rmq_bytes(TSD_MAX_BEAMS)));
+  A(hipMalloc(&ctx->d_rmq2[0], push_rmq_bytes(TSD_MAX_BEAMS)));
+  A(hipMalloc(&ctx->d_rmq2[1], push_rmq_bytes(TSD_MAX_BEAMS)));
+  ctx->d_rmq = ctx->d_rmq2[0];
+  A(hipEventCreateWithFlags(&ctx->ev_h2d, hipEventDisableTiming));
   A(hipMalloc(&ctx->d_tile_rec, T * sizeof(uint32_t)));
   A(hipMalloc(&ctx->d_dirty, T));
   A(hipMalloc(&ctx->d_tile_totals, T * 8 * sizeof(uint32_t)));
   A(hipMalloc(&ctx->d_pushes, 2 * sizeof(unsigned long long)));
   A(hipMalloc(&ctx->d_list, T * sizeof(uint32_t)));
+  A(hipMalloc(&ctx->d_list_win, T * sizeof(uint32_t)));
   A(hipMalloc(&ctx->d_list_cnt, 2 * sizeof(unsigned int)));
   A(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
   A(hipEventCreateWithFlags(&ctx->ev_tables, hipEventDisableTiming));
@@ -309,8 +313,9 @@ void tsd_destroy(tsd_ctx* ctx)
   GridDev& g = ctx->grid;
   hipFree(g.flags); hipFree(g.init_weight); hipFree(g.tsd); hipFree(g.weight);
   if (ctx->stream2) hipStreamSynchronize(ctx->stream2);
-  hipFree(ctx->d_rmq); hipFree(ctx->d_tile_rec); hipFree(ctx->d_dirty); hipFree(ctx->d_tile_totals); hipFree(ctx->d_pushes); hipFree(ctx->d_list); hipFree(ctx->d_list_cnt);
+  hipFree(ctx->d_rmq2[0]); hipFree(ctx->d_rmq2[1]); hipFree(ctx->d_tile_rec); hipFree(ctx->d_dirty); hipFree(ctx->d_tile_totals); hipFree(ctx->d_pushes); hipFree(ctx->d_list); hipFree(ctx->d_list_win); hipFree(ctx->d_list_cnt);
   if (ctx->ev_tables) hipEventDestroy(ctx->ev_tables);
+  if (ctx->ev_h2d) hipEventDestroy(ctx->ev_h2d);
   if (ctx->stream2) hipStreamDestroy(ctx->stream2);
   for (hipEvent_t e : ctx->event_pool) hipEventDestroy(e);
   for (int s = 0; s < tsd_ctx::kSlots; s++) {
@@ -416,7 +421,7 @@ int tsd_push(tsd_ctx* ctx, const double pose33[9], const double* ranges, const u
   TSD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_mask, h + (size_t)TSD_MAX_BEAMS * 8, (size_t)beams, hipMemcpyHostToDevice, ctx->stream));
   TSD_HIP_CHECK(ctx, hipEventRecord(ctx->stage_ev[s], ctx->stream));
 
-  int rc = launch_push_tables(ctx, ctx->stream, beams, nullptr, nullptr);
+  int rc = launch_push_tables(ctx, ctx->stream, beams, nullptr, nullptr, phi_min, ang_res);
   if (rc != TSD_OK) return rc;
   rc = launch_push(ctx, a, a.trx, a.try_, 0.0);
   if (rc != TSD_OK) return rc;
@@ -734,7 +739,8 @@ tsd_sensor* tsd_sensor_create(tsd_ctx* ctx, int beams, double ang_res, double ph
   A(hipMalloc(&s->d_state, sizeof(SensorDev)));
   A(hipMalloc(&s->d_rays, nb * 16));
   A(hipMalloc(&s->d_rays_local, nb * 16));
-  A(hipMalloc(&s->d_scan, nb * 10 + 64));
+  A(hipMalloc(&s->d_scan2[0], nb * 10 + 64));
+  A(hipMalloc(&s->d_scan2[1], nb * 10 + 64));
   // the scan result is written by the kernel straight into coherent pinned host memory
   A(hipHostMalloc(&s->h_result, sizeof(ScanResultDev), hipHostMallocMapped | hipHostMallocCoherent));
   if (ok) { std::memset(s->h_result, 0, sizeof(ScanResultDev)); A(hipHostGetDevicePointer((void**)&s->d_result, s->h_result, 0)); }
@@ -745,8 +751,8 @@ tsd_sensor* tsd_sensor_create(tsd_ctx* ctx, int beams, double ang_res, double ph
 void tsd_sensor_destroy(tsd_sensor* s)
 {
   if (!s) return;
-  if (s->ctx) { hipSetDevice(s->ctx->device); hipStreamSynchronize(s->ctx->stream); }
-  hipFree(s->d_state); hipFree(s->d_rays); hipFree(s->d_rays_local); hipFree(s->d_scan);
+  if (s->ctx) { hipSetDevice(s->ctx->device); hipStreamSynchronize(s->ctx->stream2); hipStreamSynchronize(s->ctx->stream); }
+  hipFree(s->d_state); hipFree(s->d_rays); hipFree(s->d_rays_local); hipFree(s->d_scan2[0]); hipFree(s->d_scan2[1]);
   hipHostFree(s->h_result);
   delete s;
 }
@@ -797,22 +803,23 @@ int tsd_scan(tsd_sensor* s, const double* ranges, const uint8_t* mask, const uin
   if (!s->posed) return set_error(ctx, TSD_E_ARG, "tsd_scan before tsd_sensor_set_pose", hipSuccess);
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const size_t nb = (size_t)s->beams;
-  // one H2D: ranges | mask | mask_push
+  // One H2D: ranges | mask | mask_push, on the side stream into the buffer the previous scan does not use: the
+  // copy and the range-query tables of this scan's push (which only depend on the scan) run while the previous
+  // push and this scan's ray cast are still busy on the main stream.
   int slot;
   char* h = stage_acquire(ctx, &slot);
   std::memcpy(h, ranges, nb * 8);
   std::memcpy(h + nb * 8, mask, nb);
   std::memcpy(h + nb * 9, mask_push ? mask_push : mask, nb);
-  TSD_HIP_CHECK(ctx, hipMemcpyAsync(s->d_scan, h, nb * 10, hipMemcpyHostToDevice, ctx->stream));
-  TSD_HIP_CHECK(ctx, hipEventRecord(ctx->stage_ev[slot], ctx->stream));
-  const double* d_ranges = reinterpret_cast<const double*>(s->d_scan);
-  const uint8_t* d_mask = reinterpret_cast<const uint8_t*>(s->d_scan + nb * 8);
-  const uint8_t* d_mask_push = reinterpret_cast<const uint8_t*>(s->d_scan + nb * 9);
-
-  // the range-query tables of this scan's push only depend on the scan: built on the side stream while the
-  // ray cast and the registration run (the previous push finished before this scan's copy could start)
-  TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->stage_ev[slot], 0));
-  int rc = launch_push_tables(ctx, ctx->stream2, s->beams, d_ranges, d_mask_push);
+  char* d_scan = s->d_scan2[s->scan_slot];
+  s->scan_slot ^= 1;
+  TSD_HIP_CHECK(ctx, hipMemcpyAsync(d_scan, h, nb * 10, hipMemcpyHostToDevice, ctx->stream2));
+  TSD_HIP_CHECK(ctx, hipEventRecord(ctx->stage_ev[slot], ctx->stream2));
+  TSD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_h2d, ctx->stream2));
+  const double* d_ranges = reinterpret_cast<const double*>(d_scan);
+  const uint8_t* d_mask = reinterpret_cast<const uint8_t*>(d_scan + nb * 8);
+  const uint8_t* d_mask_push = reinterpret_cast<const uint8_t*>(d_scan + nb * 9);
+  int rc = launch_push_tables(ctx, ctx->stream2, s->beams, d_ranges, d_mask_push, s->phi_min, s->ang_res);
   if (rc != TSD_OK) return rc;
   TSD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_tables, ctx->stream2));
 
@@ -832,6 +839,7 @@ int tsd_scan(tsd_sensor* s, const double* ranges, const uint8_t* mask, const uin
   sp.st = s->d_state; sp.rays = s->d_rays; sp.out = s->d_result; sp.seq = seq; sp.beams = s->beams;
   sp.gmin_x = ctx->grid.min_x; sp.gmax_x = ctx->grid.max_x; sp.gmin_y = ctx->grid.min_y; sp.gmax_y = ctx->grid.max_y;
   sp.gates = GateArgs{gates->reg_trs_max, gates->reg_sin_rot_max, gates->trs_min, gates->rot_min};
+  TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_h2d, 0));       // the ray cast did not need the scan
   rc = launch_icp(ctx, ia, s->d_state->icpP, s->d_rays_local, d_ranges, d_mask, &sp);
   if (rc != TSD_OK) return rc;
   PushArgs pa;

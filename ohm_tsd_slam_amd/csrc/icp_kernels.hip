@@ -951,7 +951,7 @@ static int launch_icp_shape(tsd_ctx* ctx, const IcpArgs& a, int n, int cap, cons
     configured = lds;
   }
   ScopedKernelTimer t(ctx, "icp");
-  hipLaunchKernelGGL((k_icp<R, MAXT>), dim3(1), dim3(T), lds, ctx->stream, a, P_dev, cap, ctx->d_model, ctx->d_scene,
+  hipExtLaunchKernelGGL((k_icp<R, MAXT>), dim3(1), dim3(T), lds, ctx->stream, t.a, t.b, 0, a, P_dev, cap, ctx->d_model, ctx->d_scene,
                      ctx->d_morig, ctx->d_start, ctx->d_coords, ctx->d_mask_m,
                      d_rays_local ? d_rays_local : ctx->d_rays_local, d_ranges ? d_ranges : ctx->d_ranges,
                      d_mask ? d_mask : ctx->d_mask, ctx->d_icp_res, ctx->d_icp_trace, post);

@@ -105,7 +105,7 @@ k_occ_mark(GridDev g, int8_t* __restrict__ out, int* __restrict__ count, int inf
 
 int launch_occupancy(tsd_ctx* ctx, int8_t* d_out, int inflate, int inflate_factor)
 {
-  ScopedKernelTimer t(ctx, "occupancy");
+  ScopedKernelTimer t(ctx, "occupancy", true);
   TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_occ_count, 0, sizeof(int), ctx->stream));
   hipLaunchKernelGGL(k_occ_cells, dim3(ctx->grid.tiles), dim3(256), 0, ctx->stream, ctx->grid,
                      ctx->d_occ, d_out);

@@ -21,6 +21,7 @@
 //
 // HBM-bound integer/fp64 work: no MFMA.  Roofline accounting in DESIGN.md.
 #include "tsd_ctx.hpp"
+#include <climits>
 
 namespace tsd {
 
@@ -45,6 +46,7 @@ struct RmqView {
   const unsigned short* inf;        // [B + 1]
   const unsigned short* tmax;       // [levels][Bp]
   const unsigned short* tmin;
+  const double2* bdir;              // [B + 1] unit vectors of the beam boundaries phi_min + (j - 0.5) * res (fast_index)
   int Bp, levels;
 };
 
@@ -52,7 +54,8 @@ __host__ __device__ inline int rmq_levels(int beams) { int l = 1; while ((1 << l
 __host__ __device__ inline size_t rmq_bytes(int beams)
 {
   const size_t bp = (size_t)((beams + 3) & ~3);
-  return 2 * bp * sizeof(double) + ((size_t)(beams + 1 + 7) & ~(size_t)7) * 2 + 2 * (size_t)rmq_levels(beams) * bp * 2 + 64;
+  return 2 * bp * sizeof(double) + ((size_t)(beams + 1 + 7) & ~(size_t)7) * 2 + 2 * (size_t)rmq_levels(beams) * bp * 2 + 64 +
+         ((size_t)beams + 2) * sizeof(double2);
 }
 __host__ __device__ inline RmqView rmq_view(char* buf, int beams)
 {
@@ -65,11 +68,14 @@ __host__ __device__ inline RmqView rmq_view(char* buf, int beams)
   v.inf = inf;
   unsigned short* tmax = inf + ((size_t)(beams + 1 + 7) & ~(size_t)7);
   v.tmax = tmax; v.tmin = tmax + (size_t)v.levels * bp;
+  const size_t used = 2 * bp * sizeof(double) + ((size_t)(beams + 1 + 7) & ~(size_t)7) * 2 + 2 * (size_t)v.levels * bp * 2;
+  v.bdir = reinterpret_cast<const double2*>(buf + ((used + 15) & ~(size_t)15));
   return v;
 }
 
 __global__ void __launch_bounds__(1024)
-k_push_tables(const double* __restrict__ ranges, const uint8_t* __restrict__ mask, int B, char* __restrict__ buf)
+k_push_tables(const double* __restrict__ ranges, const uint8_t* __restrict__ mask, int B, char* __restrict__ buf,
+              double phi_min, double ang_res)
 {
   // LDS: values (2 x Bp doubles) + two levels of both index tables (ping-pong); each finished level is
   // streamed to global memory, so 4096 beams need 96 KB whatever the number of levels
@@ -83,6 +89,13 @@ k_push_tables(const double* __restrict__ ranges, const uint8_t* __restrict__ mas
   unsigned short* ginf = const_cast<unsigned short*>(gv.inf);
   unsigned short* gmax = const_cast<unsigned short*>(gv.tmax); unsigned short* gmin = const_cast<unsigned short*>(gv.tmin);
   const int tid = threadIdx.x, T = blockDim.x;
+  {
+    double2* gb = const_cast<double2*>(gv.bdir);
+    for (int j = tid; j <= B; j += T) {
+      const double beta = phi_min + ((double)j - 0.5) * ang_res;
+      gb[j] = make_double2(cos(beta), sin(beta));
+    }
+  }
   for (int i = tid; i < B; i += T) {
     const double d = ranges[i];
     const bool mk = mask[i] != 0;
@@ -163,6 +176,7 @@ __device__ __forceinline__ bool add_tsd(double& tsd, double& weight, double sd, 
 // or only their halos refreshed (freeFootprint marks).  Entry = tile | kind << 28.
 constexpr uint32_t KIND_UPDATE = 1u, KIND_EMPTY = 2u, KIND_HALO = 3u;
 constexpr int KIND_SHIFT = 28;
+constexpr int FAST_MAX_BEAMS = 2048;   // above that the scan alone fills the workgroup's LDS share: exact index only
 constexpr int TOT_FIELDS = 8;   // cells updated, range pass, update, new, new from empty, emptied init, emptied uninit, -
 
 // isInRange for every tile of the launch window, one LANE per tile (TsdGridComponent.cpp:43-124: range cull,
@@ -172,8 +186,8 @@ constexpr int TOT_FIELDS = 8;   // cells updated, range pass, update, new, new f
 __global__ void __launch_bounds__(64)
 k_push_classify(GridDev g, PushArgs a_val, const PushArgs* __restrict__ a_dev, const char* __restrict__ rmq_buf,
                 uint32_t* __restrict__ tile_rec, const uint8_t* __restrict__ dirty, uint32_t* __restrict__ tile_totals,
-                uint32_t* __restrict__ list, unsigned int* __restrict__ list_cnt /* [2] */, int parity,
-                int tx0, int ty0, int ntx, int nty)
+                uint32_t* __restrict__ list, uint32_t* __restrict__ list_win, unsigned int* __restrict__ list_cnt /* [2] */,
+                int parity, int tx0, int ty0, int ntx, int nty)
 {
   const PushArgs a = a_dev ? *a_dev : a_val;
   const int lane = threadIdx.x;
@@ -182,6 +196,7 @@ k_push_classify(GridDev g, PushArgs a_val, const PushArgs* __restrict__ a_dev, c
   const bool in_window = t < ntx * nty;
   const int p = in_window ? (ty0 + t / ntx) * g.PX + tx0 + t % ntx : 0;
   uint32_t rec = 0u, kind = 0u;
+  uint32_t win = (uint32_t)(a.beams - 1) << 16;              // beams the cells of the tile can project to: lo | hi << 16
   if (in_window && a.enabled) {
     double e[4][2], cx, cy, rad;
     tile_geometry(g, p, e, cx, cy, rad);
@@ -223,6 +238,10 @@ k_push_classify(GridDev g, PushArgs a_val, const PushArgs* __restrict__ a_dev, c
         const bool empty = (bmin > farthest) && (!has_inf || distance < a.low_refl);
         if (visible) action = (all_vis && empty) ? 1 : 2;
       }
+      // The cell centres of a tile lie inside the quadrilateral of the four corner points; seen from a sensor
+      // well outside of it the extreme angles are those of corners, so every cell projects into [lo, hi]
+      // (corners outside the field of view were mapped to its ends above).
+      if (distance > 3.0 * rad) win = (uint32_t)lo | ((uint32_t)hi << 16);
       if (action == 2) kind = KIND_UPDATE;
       else if (action == 1) {
         // TsdGridPartition::increaseEmptiness (TsdGridPartition.cpp:136-164), isInRange then returns false
@@ -243,31 +262,129 @@ k_push_classify(GridDev g, PushArgs a_val, const PushArgs* __restrict__ a_dev, c
     unsigned int base = 0;
     if (lane == 0) base = atomicAdd(&list_cnt[parity], (unsigned int)__popcll(listed));
     base = __shfl(base, 0, 64);
-    if (kind != 0u) list[base + __popcll(listed & ((1ull << lane) - 1ull))] = (uint32_t)p | (kind << KIND_SHIFT);
+    if (kind != 0u) {
+      const unsigned int slot = base + __popcll(listed & ((1ull << lane) - 1ull));
+      list[slot] = (uint32_t)p | (kind << KIND_SHIFT);
+      list_win[slot] = win;
+    }
   }
+}
+
+// Beam index of a cell without the fp64 atan2 (SensorPolar2D::backProject, SensorPolar2D.cpp:117-135, decides
+// round((atan2(ly, lx) - phi_min) / res) and the two bound checks).  A fp32 estimate of the angle names a
+// candidate beam j; two fp64 cross products against the boundary directions of that beam (table in LDS) prove
+// that the angle lies strictly inside [phi_min + (j - 0.5) res, phi_min + (j + 0.5) res] with a margin far
+// above the rounding of either formulation, in which case the reference's atan2 + round gives j as well.
+// Anything closer than the margin to a boundary (or to the ends of the field of view) returns FAST_UNSURE
+// and is decided by the exact formulation.  ~45 instructions instead of ~125.
+constexpr int FAST_UNSURE = INT_MIN;
+__device__ __forceinline__ float atan2_estimate(float y, float x)      // |error| < 2e-6 rad
+{
+  const float ax = fabsf(x), ay = fabsf(y);
+  const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+  const float t = mn * __builtin_amdgcn_rcpf(mx);
+  const float t2 = t * t;
+  // minimax odd polynomial of atan on [0, 1] (Abramowitz-Stegun 4.4.49 class, 6 terms)
+  float r = -0.0117212f;
+  r = fmaf(r, t2, 0.05265332f);
+  r = fmaf(r, t2, -0.11643287f);
+  r = fmaf(r, t2, 0.19354346f);
+  r = fmaf(r, t2, -0.33262347f);
+  r = fmaf(r, t2, 0.99997726f);
+  r *= t;
+  r = ay > ax ? 1.57079637f - r : r;
+  r = x < 0.f ? 3.14159274f - r : r;
+  return y < 0.f ? -r : r;
+}
+__device__ __forceinline__ int fast_index(double lx, double ly, const double2* __restrict__ s_bdir, int beams,
+                                          float phi_min_f, float inv_res_f, int wlo, int whi)
+{
+  const float th = atan2_estimate((float)ly, (float)lx);
+  const float u = (th - phi_min_f) * inv_res_f;             // beam coordinate, good to ~1e-3
+  const float m = 0.02f;
+  if (u < -0.5f - m || u > (float)beams - 0.5f + m) return -1;           // outside the field of view for sure
+  if (!(u > -0.5f + m && u < (float)beams - 0.5f - m)) return FAST_UNSURE;
+  const int j = (int)rintf(u);
+  if (j < wlo || j > whi) return FAST_UNSURE;                // boundaries j, j + 1 are staged for wlo <= j <= whi
+  const double2 b0 = s_bdir[j], b1 = s_bdir[j + 1];
+  const double c0 = b0.x * ly - b0.y * lx;                  // sin(angle - boundary j) * |l|
+  const double c1 = b1.x * ly - b1.y * lx;
+  const double tol = (fabs(lx) + fabs(ly)) * 1e-11;
+  return (c0 > tol && c1 < -tol) ? j : FAST_UNSURE;
 }
 
 // One workgroup per listed tile (TsdGrid.cpp:237-274): scan staged in LDS, 4 cells per thread, row-major =>
 // coalesced 8-byte RMW; lazy TsdGridPartition::init (TsdGridPartition.cpp:88-134) folded in (a fresh tile's
 // old value is known, so it is written once, halo included).  KIND_EMPTY: increaseEmptiness over the 33x33
 // cells.  The workgroup leaves the tile's record and adds it to the tile's running totals.
-__global__ void __launch_bounds__(UPDATE_BLOCK)
+__global__ void __launch_bounds__(UPDATE_BLOCK, 4)      // 4 waves per SIMD = four workgroups per CU: the listed tiles of a usual push are resident at once
 k_push_update(GridDev g, PushArgs a_val, const PushArgs* __restrict__ a_dev, const double* __restrict__ ranges,
               const uint8_t* __restrict__ mask, uint32_t* __restrict__ tile_rec, uint32_t* __restrict__ tile_totals,
-              const uint32_t* __restrict__ list, const unsigned int* __restrict__ list_cnt, int parity)
+              const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_win,
+              const unsigned int* __restrict__ list_cnt, int parity, const double2* __restrict__ bdir, double* __restrict__ dbg)
 {
+#ifdef TSD_PUSH_STAMPS   // diagnostic: 100 MHz wall clock at the phases of every 8th listed tile (thread 0)
+#define PSTAMP(i) do { if (threadIdx.x == 0 && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 128) dbg[(blockIdx.x >> 3) * 8 + (i)] = (double)wall_clock64(); } while (0)
+#else
+#define PSTAMP(i) do {} while (0)
+#endif
+  PSTAMP(0);
+  // the list length, this workgroup's first entry (read speculatively) and the arguments arrive together
   const unsigned int n_list = list_cnt[parity];
-  if (blockIdx.x >= n_list) return;
+  const uint32_t first = list[blockIdx.x];
+  const uint32_t first_win = list_win[blockIdx.x];
   const PushArgs a = a_dev ? *a_dev : a_val;
+  if (blockIdx.x >= n_list) return;
+  PSTAMP(1);
   const int tid = threadIdx.x, lane = tid & 63;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned int* s_upd = reinterpret_cast<unsigned int*>(smem);             // [4] cells updated per wave
   double* s_ranges = reinterpret_cast<double*>(smem + 16);
   uint8_t* s_mask = reinterpret_cast<uint8_t*>(smem + 16 + (size_t)((a.beams + 1) & ~1) * sizeof(double));
-  bool staged = false;
+  double2* s_bdir = reinterpret_cast<double2*>(smem + 16 + (size_t)((a.beams + 1) & ~1) * sizeof(double) + (size_t)((a.beams + 15) & ~15));
+  const bool fast = bdir != nullptr;                     // boundary table staged (launch_push: beams <= FAST_MAX_BEAMS)
+  const float phi_min_f = (float)a.phi_min, inv_res_f = (float)a.ang_res_inv;
+  // The scan (and the boundary table) is staged once per workgroup, together with the first tile's state:
+  // only the beams the tile can project to when the workgroup has a single tile (the usual case), all of
+  // them when it will loop over several.  Reads outside the staged window go to global memory.
+  const int p_first = (int)(first & ((1u << KIND_SHIFT) - 1u));
+  const uint8_t flag_first = g.flags[p_first];
+  const double iw_first = g.init_weight[p_first];
+  int wlo = 0, whi = a.beams - 1;
+  if (n_list <= gridDim.x) {
+    wlo = (int)(first_win & 0xFFFFu) - 1; whi = (int)(first_win >> 16) + 1;
+    if (wlo < 0) wlo = 0;
+    if (whi > a.beams - 1) whi = a.beams - 1;
+  }
+  if (a.beams <= FAST_MAX_BEAMS) {
+    // every read issued before the first LDS write: one memory latency for the whole staging
+    constexpr int NR = FAST_MAX_BEAMS / 2 / UPDATE_BLOCK, NM = FAST_MAX_BEAMS / UPDATE_BLOCK, NB = NM + 1;
+    const int p0 = wlo >> 1, p1 = whi >> 1;                    // pairs of ranges
+    const double2* r2 = reinterpret_cast<const double2*>(ranges);
+    double2 rr[NR]; uint8_t mm[NM]; double2 bb[NB];
+#pragma unroll
+    for (int i = 0; i < NR; i++) { const int j = p0 + tid + i * UPDATE_BLOCK; rr[i] = j <= p1 ? r2[j] : make_double2(0.0, 0.0); }
+#pragma unroll
+    for (int i = 0; i < NM; i++) { const int j = wlo + tid + i * UPDATE_BLOCK; mm[i] = j <= whi ? mask[j] : (uint8_t)0; }
+    if (fast) {
+#pragma unroll
+      for (int i = 0; i < NB; i++) { const int j = wlo + tid + i * UPDATE_BLOCK; bb[i] = j <= whi + 1 ? bdir[j] : make_double2(0.0, 0.0); }
+    }
+    double2* s_r2 = reinterpret_cast<double2*>(s_ranges);
+#pragma unroll
+    for (int i = 0; i < NR; i++) { const int j = p0 + tid + i * UPDATE_BLOCK; if (j <= p1) s_r2[j] = rr[i]; }
+#pragma unroll
+    for (int i = 0; i < NM; i++) { const int j = wlo + tid + i * UPDATE_BLOCK; if (j <= whi) s_mask[j] = mm[i]; }
+    if (fast) {
+#pragma unroll
+      for (int i = 0; i < NB; i++) { const int j = wlo + tid + i * UPDATE_BLOCK; if (j <= whi + 1) s_bdir[j] = bb[i]; }
+    }
+  } else {
+    for (int i = tid; i < a.beams; i += UPDATE_BLOCK) { s_ranges[i] = ranges[i]; s_mask[i] = mask[i]; }
+  }
 
   for (unsigned int li = blockIdx.x; li < n_list; li += gridDim.x) {
-    const uint32_t entry = list[li];
+    const uint32_t entry = (li == blockIdx.x) ? first : list[li];
     const uint32_t kind = entry >> KIND_SHIFT;
     const int p = (int)(entry & ((1u << KIND_SHIFT) - 1u));
     if (kind == KIND_HALO) continue;
@@ -290,13 +407,10 @@ k_push_update(GridDev g, PushArgs a_val, const PushArgs* __restrict__ a_dev, con
     }
 
     // ---- UPDATE ----
-    const bool initialised = g.flags[p] != 0;
-    const double iw = g.init_weight[p];
-    if (!staged) {
-      for (int i = tid; i < a.beams; i += UPDATE_BLOCK) { s_ranges[i] = ranges[i]; s_mask[i] = mask[i]; }
-      staged = true;
-    }
+    const bool initialised = (li == blockIdx.x ? flag_first : g.flags[p]) != 0;
+    const double iw = li == blockIdx.x ? iw_first : g.init_weight[p];
     __syncthreads();               // scan staged; s_upd of a previous tile consumed
+    PSTAMP(2);
 
     double e[4][2], cx, cy, rad;
     tile_geometry(g, p, e, cx, cy, rad);
@@ -317,42 +431,66 @@ k_push_update(GridDev g, PushArgs a_val, const PushArgs* __restrict__ a_dev, con
 
     const unsigned x0 = (unsigned)(p % g.PX) * TILE_DIM, y0 = (unsigned)(p / g.PX) * TILE_DIM;
     unsigned int n_upd = 0;
-#pragma unroll
-    for (int k = 0; k < (TILE_DIM * TILE_DIM) / UPDATE_BLOCK; k++) {
+    // Three passes over the thread's four cells so that their reads are in flight together: (1) beam index,
+    // signed distance and whether addTsd will touch the cell (sd >= -maxTruncation: cells behind the surface
+    // cost no HBM traffic), (2) the reads, (3) addTsd and the writes.
+    constexpr int CPT = (TILE_DIM * TILE_DIM) / UPDATE_BLOCK;
+    int cidx[CPT], bidx[CPT]; double sdv[CPT]; bool hit[CPT];
+    // (1a) beam indices: a rolled loop, so that the exact fallback exists once in the code and the register
+    // budget stays at four workgroups per CU
+#pragma unroll 1
+    for (int k = 0; k < CPT; k++) {
       const int c = tid + UPDATE_BLOCK * k;
       const unsigned ix = (unsigned)c & 31u, iy = (unsigned)c >> 5;
       const double ccx = ((double)(x0 + ix) + 0.5) * g.cs;   // TsdGridPartition.cpp:127-128
       const double ccy = ((double)(y0 + iy) + 0.5) * g.cs;
-      const int ci = (int)(iy * TILE_PITCH + ix);
-#ifdef TSD_EXP_FAST_BP   // timing experiment only (inexact)
-      int index;
-      {
-        double lx = 0.0, ly = 0.0;
-        lx += a.Pi[0] * ccx; lx += a.Pi[1] * ccy; lx += a.Pi[2] * 1.0;
-        ly += a.Pi[3] * ccx; ly += a.Pi[4] * ccy; ly += a.Pi[5] * 1.0;
-        const float phi = atan2f((float)ly, (float)lx);
-        index = (phi <= (float)a.phi_lower) ? -2 : (phi >= (float)a.phi_upper ? -1 : (int)rintf((phi - (float)a.phi_min) * (float)a.ang_res_inv));
-      }
-#else
-      const int index = backproject(a.Pi, ccx, ccy, a.phi_min, a.ang_res_inv, a.phi_lower, a.phi_upper);
-#endif
-      bool touched = false;
-      double t = t_init, w = w_init;
-      if (index >= 0 && s_mask[index]) {
-        const double r = s_ranges[index];
+      // SensorPolar2D::backProject: PoseInv * (x,y,1)^T through dgemm(NoTrans,Trans) = ((0 + a*x) + b*y) + c*1
+      double lx = 0.0, ly = 0.0;
+      lx += a.Pi[0] * ccx; lx += a.Pi[1] * ccy; lx += a.Pi[2] * 1.0;
+      ly += a.Pi[3] * ccx; ly += a.Pi[4] * ccy; ly += a.Pi[5] * 1.0;
+      int index = fast ? fast_index(lx, ly, s_bdir, a.beams, phi_min_f, inv_res_f, wlo, whi) : FAST_UNSURE;
+      if (index == FAST_UNSURE) index = backproject(a.Pi, ccx, ccy, a.phi_min, a.ang_res_inv, a.phi_lower, a.phi_upper);
+#pragma unroll
+      for (int j = 0; j < CPT; j++) if (j == k) bidx[j] = index;
+    }
+    // (1b) signed distances
+#pragma unroll
+    for (int k = 0; k < CPT; k++) {
+      const int c = tid + UPDATE_BLOCK * k;
+      const unsigned ix = (unsigned)c & 31u, iy = (unsigned)c >> 5;
+      const double ccx = ((double)(x0 + ix) + 0.5) * g.cs;
+      const double ccy = ((double)(y0 + iy) + 0.5) * g.cs;
+      cidx[k] = (int)(iy * TILE_PITCH + ix);
+      const int index = bidx[k];
+      hit[k] = false; sdv[k] = 0.0;
+      const bool staged_beam = index >= wlo && index <= whi;
+      if (index >= 0 && (staged_beam ? s_mask[index] : mask[index])) {
+        const double r = staged_beam ? s_ranges[index] : ranges[index];
         const double dist = sqrt((ccx - a.trx) * (ccx - a.trx) + (ccy - a.try_) * (ccy - a.try_));
-        // the cell is only read when addTsd will update it (sd >= -maxTruncation): cells behind the
-        // surface cost no HBM traffic
         double sd = 0.0; bool cand = false;
         if (!isinf(r)) { sd = r - dist; cand = true; }
         else if (dist < a.low_refl) { sd = max_trunc; cand = true; }
-        if (cand && sd >= -max_trunc) {
-          if (!fresh) { t = T[ci]; w = W[ci]; }
-          touched = add_tsd(t, w, sd, pw, max_trunc, inv_max_trunc, eps);
-        }
+        hit[k] = cand && sd >= -max_trunc;
+        sdv[k] = sd;
       }
+    }
+    PSTAMP(3);
+    double tv[CPT], wv[CPT];
+#pragma unroll
+    for (int k = 0; k < CPT; k++) {
+      tv[k] = t_init; wv[k] = w_init;
+      if (hit[k] && !fresh) { tv[k] = T[cidx[k]]; wv[k] = W[cidx[k]]; }
+    }
+#ifdef TSD_PUSH_STAMPS
+    if (tv[0] == 123.456) dbg[1023] = wv[0] + tv[1] + tv[2] + tv[3];    // (wait for the reads)
+#endif
+    PSTAMP(4);
+#pragma unroll
+    for (int k = 0; k < CPT; k++) {
+      bool touched = false;
+      if (hit[k]) touched = add_tsd(tv[k], wv[k], sdv[k], pw, max_trunc, inv_max_trunc, eps);
       if (touched) n_upd++;
-      if (touched || fresh) { T[ci] = t; W[ci] = w; }
+      if (touched || fresh) { T[cidx[k]] = tv[k]; W[cidx[k]] = wv[k]; }
     }
     if (fresh) {
       // halo cells of a freshly materialised tile keep the init value until k_push_halo
@@ -365,9 +503,11 @@ k_push_update(GridDev g, PushArgs a_val, const PushArgs* __restrict__ a_dev, con
         }
       }
     }
+    PSTAMP(5);
     const unsigned wu = (unsigned)wave_sum_i((int)n_upd);
     if (lane == 0) s_upd[tid >> 6] = wu;
     __syncthreads();               // every thread is done with the cells (and has read `initialised`)
+    PSTAMP(6);
     if (tid == 0) {
       unsigned cells = 0;
       for (int w = 0; w < UPDATE_BLOCK / 64; w++) cells += s_upd[w];
@@ -426,9 +566,10 @@ k_push_halo(GridDev g, uint8_t* __restrict__ dirty, unsigned long long* __restri
     }
   }
   const unsigned int n_list = list_cnt[parity];
+  const uint32_t first = list[wv];                            // speculative: arrives with the list length
   const int PX = g.PX;
   for (unsigned int li = wv; li < n_list; li += gridDim.x * 4) {
-    const uint32_t entry = list[li];
+    const uint32_t entry = (li == wv) ? first : list[li];
     const int p = (int)(entry & ((1u << KIND_SHIFT) - 1u));
     if (lane == 0 && dirty[p] != 0) dirty[p] = 0;
     const int px = p % PX, py = p / PX;
@@ -514,7 +655,8 @@ int launch_free_footprint(tsd_ctx* ctx, unsigned minX, unsigned maxX, unsigned m
 
 size_t push_rmq_bytes(int beams) { return rmq_bytes(beams); }
 
-int launch_push_tables(tsd_ctx* ctx, hipStream_t stream, int beams, const double* d_ranges, const uint8_t* d_mask)
+int launch_push_tables(tsd_ctx* ctx, hipStream_t stream, int beams, const double* d_ranges, const uint8_t* d_mask,
+                       double phi_min, double ang_res)
 {
   const size_t bp = (size_t)((beams + 3) & ~3);
   const size_t lds = 2 * bp * sizeof(double) + 4 * bp * 2 + 64;
@@ -524,8 +666,10 @@ int launch_push_tables(tsd_ctx* ctx, hipStream_t stream, int beams, const double
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     configured = lds;
   }
+  ctx->rmq_slot ^= 1;                                    // the push that may still be running keeps its tables
+  ctx->d_rmq = ctx->d_rmq2[ctx->rmq_slot];
   hipLaunchKernelGGL(k_push_tables, dim3(1), dim3(1024), lds, stream, d_ranges ? d_ranges : ctx->d_ranges,
-                     d_mask ? d_mask : ctx->d_mask, beams, ctx->d_rmq);
+                     d_mask ? d_mask : ctx->d_mask, beams, ctx->d_rmq, phi_min, ang_res);
   TSD_HIP_CHECK(ctx, hipGetLastError());
   return TSD_OK;
 }
@@ -564,22 +708,26 @@ int launch_push(tsd_ctx* ctx, const PushArgs& a, double cx, double cy, double sl
   const int n_window = ntx * nty;
   {
     ScopedKernelTimer t(ctx, "push_classify");
-    hipLaunchKernelGGL(k_push_classify, dim3((n_window + 63) / 64), dim3(64), 0, ctx->stream, g, a, a_dev, ctx->d_rmq,
-                       ctx->d_tile_rec, ctx->d_dirty, ctx->d_tile_totals, ctx->d_list, ctx->d_list_cnt, parity,
+    hipExtLaunchKernelGGL(k_push_classify, dim3((n_window + 63) / 64), dim3(64), 0, ctx->stream, t.a, t.b, 0, g, a, a_dev, ctx->d_rmq,
+                       ctx->d_tile_rec, ctx->d_dirty, ctx->d_tile_totals, ctx->d_list, ctx->d_list_win, ctx->d_list_cnt, parity,
                        box.x0, box.y0, ntx, nty);
   }
   TSD_HIP_CHECK(ctx, hipGetLastError());
   const int n_groups = n_window < 2048 ? n_window : 2048;      // resident at once; a longer list is looped over
   {
     ScopedKernelTimer t(ctx, "push_update");
-    const size_t lds = 16 + (size_t)((a.beams + 1) & ~1) * sizeof(double) + (size_t)((a.beams + 15) & ~15);
-    hipLaunchKernelGGL(k_push_update, dim3(n_groups), dim3(UPDATE_BLOCK), lds, ctx->stream, g, a, a_dev, d_ranges, d_mask,
-                       ctx->d_tile_rec, ctx->d_tile_totals, ctx->d_list, ctx->d_list_cnt, parity);
+    const bool fast = a.beams <= FAST_MAX_BEAMS;           // the boundary table shares LDS with the scan
+    const size_t lds = 16 + (size_t)((a.beams + 1) & ~1) * sizeof(double) + (size_t)((a.beams + 15) & ~15) +
+                       (fast ? ((size_t)a.beams + 1) * sizeof(double2) : 0);
+    const double2* bdir = fast ? rmq_view(ctx->d_rmq, a.beams).bdir : nullptr;
+    hipExtLaunchKernelGGL(k_push_update, dim3(n_groups), dim3(UPDATE_BLOCK), lds, ctx->stream, t.a, t.b, 0, g, a, a_dev, d_ranges, d_mask,
+                       ctx->d_tile_rec, ctx->d_tile_totals, ctx->d_list, ctx->d_list_win, ctx->d_list_cnt, parity, bdir,
+                       ctx->d_icp_trace);
   }
   TSD_HIP_CHECK(ctx, hipGetLastError());
   {
     ScopedKernelTimer t(ctx, "push_halo");
-    hipLaunchKernelGGL(k_push_halo, dim3((n_groups + 3) / 4), dim3(256), 0, ctx->stream, g, ctx->d_dirty, ctx->d_pushes,
+    hipExtLaunchKernelGGL(k_push_halo, dim3((n_groups + 3) / 4), dim3(256), 0, ctx->stream, t.a, t.b, 0, g, ctx->d_dirty, ctx->d_pushes,
                        a, a_dev, ctx->d_list, ctx->d_list_cnt, parity, cx, cy, slack + g.cs);
   }
   TSD_HIP_CHECK(ctx, hipGetLastError());

@@ -1,6 +1,7 @@
 // tsd_ctx.hpp -- host-side state behind the opaque tsd_ctx of include/tsd_hip.h.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <string>
 #include <vector>
@@ -111,7 +112,10 @@ struct tsd_ctx {
   std::string err;
 
   // push state
-  char* d_rmq = nullptr;                     // range-query tables of the current scan (k_push_tables)
+  char* d_rmq = nullptr;                     // range-query tables of the current scan (k_push_tables): one of d_rmq2
+  char* d_rmq2[2] = {nullptr, nullptr};      // (the next scan's tables are built while the current push still reads its own)
+  int rmq_slot = 0;
+  hipEvent_t ev_h2d = nullptr;               // fused scan: the scan's copy (side stream) is complete
   uint32_t* d_tile_rec = nullptr;            // [tiles] what the last push did to every tile
   uint8_t* d_dirty = nullptr;                // [tiles] written by freeFootprint since the last push
   uint32_t* d_tile_totals = nullptr;         // [tiles][8] records summed over the pushes since the last reset
@@ -119,6 +123,7 @@ struct tsd_ctx {
   // tile window of the push launches: what the last push covered and what freeFootprint dirtied since
   tsd::TileBox box_prev{}, box_dirty{};
   uint32_t* d_list = nullptr;               // [tiles] work list of the current push (tile | kind << 28)
+  uint32_t* d_list_win = nullptr;           // [tiles] beams a listed tile can project to (lo | hi << 16)
   unsigned int* d_list_cnt = nullptr;       // [2] its length, by push parity
   unsigned int push_parity = 0;
   hipStream_t stream2 = nullptr;             // side stream: the tables are built while ray cast / ICP run
@@ -172,7 +177,8 @@ struct tsd_sensor {
   tsd::SensorDev* d_state = nullptr;
   double* d_rays = nullptr;        // [2*beams] world rays, normalised to the cell size
   double* d_rays_local = nullptr;  // [2*beams]
-  char* d_scan = nullptr;          // ranges[beams] | mask[beams] | mask_push[beams]
+  char* d_scan2[2] = {nullptr, nullptr};   // ranges[beams] | mask[beams] | mask_push[beams], alternating between scans
+  int scan_slot = 0;
   tsd::ScanResultDev* h_result = nullptr;   // pinned, coherent, written by k_scan_post directly
   tsd::ScanResultDev* d_result = nullptr;   // device address of h_result
   unsigned long long seq = 0;
@@ -188,10 +194,12 @@ int set_error(tsd_ctx* ctx, int code, const char* what, hipError_t e);
     if (_e != hipSuccess) return tsd::set_error((ctx), TSD_E_HIP, #call, _e);        \
   } while (0)
 
-// event-timed launch bracket
+// Event-timed launch.  Default: the two events are handed to hipExtLaunchKernelGGL, which stamps them with the
+// dispatch's own begin / end (the duration rocprofv3 reports, free of the gaps between stream operations).
+// around = true brackets whatever the scope enqueues with hipEventRecord (several operations).
 struct ScopedKernelTimer {
-  tsd_ctx* ctx; const char* name; hipEvent_t a = nullptr, b = nullptr;
-  ScopedKernelTimer(tsd_ctx* c, const char* n);
+  tsd_ctx* ctx; const char* name; hipEvent_t a = nullptr, b = nullptr; bool around;
+  ScopedKernelTimer(tsd_ctx* c, const char* n, bool around_ = false);
   ~ScopedKernelTimer();
 };
 void drain_timers(tsd_ctx* ctx);
@@ -202,7 +210,8 @@ bool kernel_is_timed(const tsd_ctx* ctx, const char* name);
 // (cx, cy) is where the host knows the sensor to be and `slack` how far the device-side pose may be from it
 int launch_push(tsd_ctx* ctx, const PushArgs& a, double cx, double cy, double slack, const PushArgs* a_dev = nullptr,
                 const double* d_ranges = nullptr, const uint8_t* d_mask = nullptr);
-int launch_push_tables(tsd_ctx* ctx, hipStream_t stream, int beams, const double* d_ranges, const uint8_t* d_mask);
+int launch_push_tables(tsd_ctx* ctx, hipStream_t stream, int beams, const double* d_ranges, const uint8_t* d_mask,
+                       double phi_min, double ang_res);
 size_t push_rmq_bytes(int beams);
 int launch_free_footprint(tsd_ctx* ctx, unsigned minX, unsigned maxX, unsigned minY, unsigned maxY);
 int launch_raycast(tsd_ctx* ctx, const RaycastArgs& a, const RaycastArgs* a_dev = nullptr, const double* d_rays = nullptr);
