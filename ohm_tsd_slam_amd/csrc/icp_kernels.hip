@@ -41,6 +41,7 @@ namespace tsd {
 constexpr int ICP_MAXW = 16;                    // waves per workgroup at most
 constexpr double SLACK = 1.0 - 1e-9;            // conservative factor on every pruning bound
 constexpr int HW = 6;                           // tier-1 window: k-6 .. k+6
+constexpr int ICP_RL = 2;                       // register slots every wave fills before the lone waves take more
 constexpr int ICP_PAD = 96;                     // wrapped copies of the model at both ends of its LDS array
 #ifndef TSD_ICP_REFRESH_A
 #define TSD_ICP_REFRESH_A 6
@@ -520,9 +521,29 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
   int hint[R], hint2[R];
   bool have[R];
   float rmaxf = 0.f;
+  // Scene points -> register slots.  Waves i and i + 4 of a workgroup share a SIMD (tools/exp/hwid.hip), so with
+  // a wave count that is no multiple of four some waves have a SIMD to themselves: they take the slots beyond
+  // the first ICP_RL of every wave, which evens out the instruction issue per SIMD.  blk = 64-point group.
+  int pid[R];
+  {
+    const int rr = W & 3;
+    const bool asym = R >= 5 && W > 4 && rr != 0;        // (needs the register slots: experimental shape 7 only)
+    int nH = 0, hrank = 0;
+    for (int w = 0; w < W; w++) {
+      const bool hv = !asym || (w & 3) >= rr;
+      if (hv && w < wave) hrank++;
+      if (hv) nH++;
+    }
+    const bool heavy = !asym || (wave & 3) >= rr;
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+      const int blk = q < ICP_RL ? q * W + wave : (heavy ? ICP_RL * W + (q - ICP_RL) * nH + hrank : (1 << 20));
+      pid[q] = blk * 64 + lane;
+    }
+  }
 #pragma unroll
   for (int q = 0; q < R; q++) {
-    const int i = tid + q * T;
+    const int i = pid[q];
     have[q] = i < nS;
     sx[q] = 0.0; sy[q] = 0.0; hint[q] = 0; hint2[q] = 0; lb[q] = -1.0;
     if (have[q]) {
@@ -576,7 +597,7 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
   double c0[4] = {0.0, 0.0, 0.0, 0.0};       // centring point of the pair sums: last step's centroids
 
   int Rn = 0;                                // register slots of this wave that hold scene points (wave-uniform)
-  for (int q = 0; q < R; q++) Rn += (q * T + wave * 64 < nS) ? 1 : 0;
+  for (int q = 0; q < R; q++) Rn += (pid[q] - lane < nS) ? 1 : 0;
 
   while (state == TSD_ICP_PROCESSING) {
     const double thr_before = thr;
@@ -773,11 +794,11 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
       // equal d2 somewhere: the lowest scene index of the candidates wins its slot
 #pragma unroll
       for (int q = 0; q < R; q++)
-        if (win[q]) atomicMin(&L.slotI[hint[q]], tid + q * T);
+        if (win[q]) atomicMin(&L.slotI[hint[q]], pid[q]);
       __syncthreads();
 #pragma unroll
       for (int q = 0; q < R; q++) {
-        if (win[q]) { win[q] = L.slotI[hint[q]] == tid + q * T; }
+        if (win[q]) { win[q] = L.slotI[hint[q]] == pid[q]; }
       }
       __syncthreads();
 #pragma unroll
@@ -972,6 +993,10 @@ int launch_icp(tsd_ctx* ctx, const IcpArgs& a, const double* P_dev, const double
   switch (ctx->icp_shape) {      // TSD_ICP_SHAPE: experiments only
     case 2: return launch_icp_shape<2, 576>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post);
     case 3: return launch_icp_shape<3, 512>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post, 512);
+    // six waves: four share two SIMDs and hold two 64-point groups each, the two lone waves hold up to five
+    // (evens out the issue load per SIMD, but five register slots spill: slower than the default as measured)
+    case 7: if (nthr <= 64 * (ICP_RL * 6 + (5 - ICP_RL) * 2)) return launch_icp_shape<5, 512>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post, 384);
+            break;
     case 5: return launch_icp_shape<5, 256>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post);
     case 8: return launch_icp_shape<8, 256>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post);
     default: break;

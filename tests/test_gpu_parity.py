@@ -107,6 +107,54 @@ def test_free_footprint_then_push(oracle):
     assert not dg.free_footprint([1e4, 1e4], 1.0, 1.0)
 
 
+def test_push_launch_window_follows_the_sensor(oracle):
+    """The push kernels are launched over the tile window the scan can reach (union with the previous window and
+    with freeFootprint marks): jumps across the map, a footprint freed far away from the sensor and a push with a
+    longer range must leave the same grid and the same statistics as the reference's sweep over all tiles."""
+    gc = synth.GridConfig(10, 0.05)                      # 51.2 m, 32 x 32 tiles
+    geo = synth.ScanGeometry.utm30lx()
+    world = synth.World("pillars", gc)
+    og, dg = make_pair(oracle, gc)
+    w = gc.width
+    stops = [(0.2 * w, 0.25 * w, 0.3, 4.0), (0.8 * w, 0.7 * w, 2.0, 4.0), (0.8 * w, 0.7 * w, 2.1, 4.0),
+             (0.15 * w, 0.85 * w, -1.0, 3.0), (0.5 * w, 0.5 * w, 0.0, 30.0), (0.21 * w, 0.26 * w, 0.35, 4.0)]
+    total = None
+    for n, (x, y, yaw, max_range) in enumerate(stops):
+        if n == 2:      # far from every window so far
+            c = [0.3 * w, 0.6 * w]
+            assert og.free_footprint(c, 1.5, 1.0) and dg.free_footprint(c, 1.5, 1.0)
+        pose = synth.pose_matrix(x, y, yaw)
+        r32 = np.minimum(world.scan(x, y, yaw, geo), np.float32(max_range + 1.0))
+        data, mask = oracle.ingest_f32(r32, max_range, geo.angle_increment)
+        so = og.push(pose, data, mask, geo.angle_increment, geo.angle_min, max_range, H.MIN_RANGE, H.LOW_REFL)
+        sd = dg.push(pose, data, mask, geo.angle_increment, geo.angle_min, max_range, H.MIN_RANGE, H.LOW_REFL)
+        assert so == sd, f"stop {n}: stats differ\n oracle {so}\n hip    {sd}"
+        H.assert_grids_equal(og.dump(), dg.download_tiles(), TOL_CELL)
+        total = dict(so) if total is None else {k: total[k] + v for k, v in so.items()}
+    st, pushes = dg.push_stats_total()
+    assert pushes == len(stops)
+    total.pop("tiles_total")                            # a property of the grid, not a sum over pushes
+    assert {k: st[k] for k in total} == total
+
+
+def test_push_beam_index_without_atan2_is_exact(oracle):
+    """k_push_update names the beam of a cell from a fp32 angle estimate proven by two fp64 cross products and falls
+    back to the reference's atan2 + round near a beam boundary: every rotation of the sensor, axis-aligned ones
+    included (cells exactly on boundaries), must give the reference's grid."""
+    gc = synth.GridConfig(8, 0.05)
+    world = synth.World("room", gc)
+    for geo in (synth.ScanGeometry.utm30lx(), synth.ScanGeometry.full_circle_360()):
+        og, dg = make_pair(oracle, gc)
+        x, y = world.start[0], world.start[1]
+        for yaw in (0.0, math.pi / 2, math.pi, -math.pi / 2, math.pi / 4, 0.5 * geo.angle_increment, 1.2345, -2.9):
+            pose = synth.pose_matrix(x + 0.025, y + 0.025, yaw)      # the sensor sits exactly on a cell centre
+            data, mask = oracle.ingest_f32(world.scan(x + 0.025, y + 0.025, yaw, geo), H.MAX_RANGE, geo.angle_increment)
+            so = og.push(pose, data, mask, geo.angle_increment, geo.angle_min, H.MAX_RANGE, H.MIN_RANGE, H.LOW_REFL)
+            sd = dg.push(pose, data, mask, geo.angle_increment, geo.angle_min, H.MAX_RANGE, H.MIN_RANGE, H.LOW_REFL)
+            assert so == sd, f"yaw {yaw}: {so} != {sd}"
+            H.assert_grids_equal(og.dump(), dg.download_tiles(), TOL_CELL)
+
+
 def build_map(oracle, gc, geo, world, pushes=4):
     og, dg = make_pair(oracle, gc)
     for k in range(pushes):
