@@ -2,22 +2,21 @@
 //
 //   k_push_tables   (one workgroup, off the critical path in the fused scan) range-query tables of the
 //                   scan: the two beam-range tests of TsdGridComponent::isInRange become O(1) look-ups.
-//   k_push_tiles    ONE 256-thread workgroup PER TILE, the reference's `#pragma omp for` over all
-//                   partitions (TsdGrid.cpp:228-277) taken literally: every wave classifies the tile
-//                   (isInRange, TsdGridComponent.cpp:43-124: range cull, four corner back-projections on
-//                   four lanes, range queries) -- redundantly, so the workgroup needs no barrier to agree
-//                   -- and most workgroups exit within a microsecond.  An UPDATE tile is then written by
-//                   its workgroup: scan staged in LDS, 4 cells per thread, row-major => coalesced 8-byte
-//                   RMW; lazy TsdGridPartition::init (TsdGridPartition.cpp:88-134) folded in (a fresh
-//                   tile's old value is known, so it is written once, halo included).  An EMPTY tile
-//                   gets TsdGridPartition::increaseEmptiness (TsdGridPartition.cpp:136-164).  No work
-//                   list, no atomics: every tile leaves a 4-byte record (what happened, cells updated).
+//   k_push_classify isInRange for every tile of the launch window, one LANE per tile (range cull, four corner
+//                   back-projections, table look-ups): the reference's `#pragma omp for` over all partitions
+//                   (TsdGrid.cpp:228-277) without its load imbalance.  Tiles that need a workgroup go to a
+//                   work list (one atomic per wave) with the beam interval their cells can project to.
+//   k_push_update   one 256-thread workgroup per listed tile: scan window staged in LDS, 4 cells per thread,
+//                   row-major => coalesced 8-byte RMW; beam index from a fp32 estimate proven by two fp64
+//                   cross products (exact atan2 fallback); lazy TsdGridPartition::init
+//                   (TsdGridPartition.cpp:88-134) folded in; TsdGridPartition::increaseEmptiness
+//                   (TsdGridPartition.cpp:136-164) for EMPTY tiles.  No same-address atomics: every tile
+//                   leaves a 4-byte record (what happened, cells updated) and running totals.
 //   k_push_halo     TsdGrid::propagateBorders (TsdGrid.cpp:372-427) restricted to what can have
-//                   changed: for every touched tile (record, or freeFootprint's dirty mark) refresh its
+//                   changed: for every listed tile (touched, or freeFootprint's dirty mark) refresh its
 //                   own halo from R/U/UR and the halos of L/D/DL that mirror its first column/row/cell.
 //                   Equal to the reference's full sweep by induction (untouched pairs are already
-//                   consistent).  One wave per tile; it also adds the tile's record to the tile's running
-//                   totals (the host sums records / totals when somebody asks).
+//                   consistent).  One wave per tile.
 //
 // HBM-bound integer/fp64 work: no MFMA.  Roofline accounting in DESIGN.md.
 #include "tsd_ctx.hpp"
