@@ -192,6 +192,12 @@ k_raycast(GridDev g, RaycastArgs a_val, const RaycastArgs* __restrict__ a_dev, c
     double i_run = idxMin;          // wave-uniform loop variable of the reference (serial fall-back only)
     bool cclosed = true;
     bool done = false;
+    {
+      // the usual case: the first sample (i = idxMin, no counter arithmetic needed) already lies in a tile with
+      // data -- the sensor stands in mapped space -- and the loop breaks at once, idxMin unchanged
+      int p, lx, ly; double dx, dy;
+      if (coord2cell(g, trx + idxMin * rx, try_ + idxMin * ry, p, lx, ly, dx, dy) && g.flags[p] != 0) done = true;
+    }
     for (int cbase = 0; !done; cbase += 64) {
       double my_i = 0.0; bool my_act = false;
       if (cclosed) {
@@ -210,9 +216,9 @@ k_raycast(GridDev g, RaycastArgs a_val, const RaycastArgs* __restrict__ a_dev, c
       }
       bool ok = false;
       if (my_act) {
-        double tmp;
-        const int rv = interpolate_bilinear(g, trx + my_i * rx, try_ + my_i * ry, tmp);
-        ok = (rv != INTERP_EMPTYPARTITION && rv != INTERP_INVALIDINDEX);
+        // interpolateBilinear's EMPTYPARTITION / INVALIDINDEX verdicts only need the cell index and the tile flag
+        int p, lx, ly; double dx, dy;
+        ok = coord2cell(g, trx + my_i * rx, try_ + my_i * ry, p, lx, ly, dx, dy) && g.flags[p] != 0;
       }
       const unsigned long long m_act = __ballot(my_act);
       const unsigned long long m_ok = __ballot(ok);
@@ -243,18 +249,36 @@ k_raycast(GridDev g, RaycastArgs a_val, const RaycastArgs* __restrict__ a_dev, c
     else { double dummy; nsteps_i = counter_chain(idxMin, 1.0, 1.0, idxMax, false, -1, dummy, oki); }
   }
   bool closed = oki;
-  closed = closed && build_segments(px0, rx, cap, s_segx, nsx, lane);
-  closed = closed && build_segments(py0, ry, cap, s_segy, nsy, lane);
+  {
+    // the x table by lanes 0..31, the y table by lanes 32..63, at the same time
+    const bool yh = lane >= 32;
+    int ns = 0;
+    const bool okh = build_segments(yh ? py0 : px0, yh ? ry : rx, cap, yh ? s_segy : s_segx, ns, lane & 31);
+    nsx = __shfl(ns, 0, 64); nsy = __shfl(ns, 32, 64);
+    closed = closed && (__ballot(!okh) == 0ull);
+  }
   __syncthreads();
   RSTAMP(1);
   const int nsteps = closed ? nsteps_i : 0;
   RSTAMP(2);
 
-  double carry;                                             // sample of the previous step (NaN = none)
-  {
-    double t0;
-    carry = (interpolate_bilinear(g, px0, py0, t0) == INTERP_SUCCESS) ? t0 : __builtin_nan("");
-  }
+  // sample of step 0 ("the previous step" of step 1; NaN = none): its reads go out now and are consumed
+  // once the first round's reads are in flight too
+  int c_p = 0, c_lx = 0, c_ly = 0; double c_dx = 0.0, c_dy = 0.0;
+  const bool c_in = coord2cell(g, px0, py0, c_p, c_lx, c_ly, c_dx, c_dy);
+  const size_t c_off = c_in ? (size_t)c_p * TILE_STRIDE + (size_t)(c_ly * TILE_PITCH + c_lx) : 0;
+  const uint8_t c_fl = g.flags[c_in ? c_p : 0];
+  const Cell2 c_r0 = *reinterpret_cast<const Cell2*>(g.tsd + c_off);
+  const Cell2 c_r1 = *reinterpret_cast<const Cell2*>(g.tsd + c_off + TILE_PITCH);
+  auto first_sample = [&]() {
+    double r = __builtin_nan("");
+    if (c_in && c_fl) {
+      const double wx = fabs((px0 - c_dx) * g.inv_cs), wy = fabs((py0 - c_dy) * g.inv_cs);
+      r = c_r0.a * (1. - wy) * (1. - wx) + c_r1.a * wy * (1. - wx) + c_r0.b * (1. - wy) * wx + c_r1.b * wy * wx;
+    }
+    return r;                                               // NaN stays NaN = "not SUCCESS"
+  };
+  double carry = 0.0;
   bool found = false, ended = false;
   double hit_x = 0.0, hit_y = 0.0;
   RSTAMP(3);
@@ -300,6 +324,7 @@ k_raycast(GridDev g, RaycastArgs a_val, const RaycastArgs* __restrict__ a_dev, c
         r0[j] = *reinterpret_cast<const Cell2*>(t);
         r1[j] = *reinterpret_cast<const Cell2*>(t + TILE_PITCH);
       }
+      if (base == 1) carry = first_sample();
 #pragma unroll
       for (int j = 0; j < RC_S; j++) {
         double r = __builtin_nan("");
@@ -340,6 +365,7 @@ k_raycast(GridDev g, RaycastArgs a_val, const RaycastArgs* __restrict__ a_dev, c
     }
   } else {
     // serial chain (rare): 64 steps per round, positions by the reference's own additions
+    carry = first_sample();
     double px = px0, py = py0;
     double i_run = idxMin;
     for (;;) {
@@ -391,7 +417,20 @@ k_raycast(GridDev g, RaycastArgs a_val, const RaycastArgs* __restrict__ a_dev, c
   else if (lane == 2) sy = hit_y + cs;
   else if (lane == 3) sy = hit_y - cs;
   double v = 0.0; bool okn = true;
-  if (lane < 4) okn = interpolate_bilinear(g, sx, sy, v) == INTERP_SUCCESS;
+  if (lane < 4) {
+    // interpolateBilinear with the cell reads issued together with the flag read (the tile storage exists for
+    // every tile; only `flags` says whether it holds data)
+    int p, lx, ly; double dx, dy;
+    okn = coord2cell(g, sx, sy, p, lx, ly, dx, dy);
+    if (okn) {
+      const uint8_t f = g.flags[p];
+      const double* t = g.tsd + (size_t)p * TILE_STRIDE + ly * TILE_PITCH + lx;
+      const Cell2 r0 = *reinterpret_cast<const Cell2*>(t), r1 = *reinterpret_cast<const Cell2*>(t + TILE_PITCH);
+      const double wx = fabs((sx - dx) * g.inv_cs), wy = fabs((sy - dy) * g.inv_cs);
+      v = r0.a * (1. - wy) * (1. - wx) + r1.a * wy * (1. - wx) + r0.b * (1. - wy) * wx + r1.b * wy * wx;
+      okn = f != 0 && !isnan(v);
+    }
+  }
   const bool all_ok = __ballot(!okn) == 0ull;
   const double v0 = __shfl(v, 0, 64), v1 = __shfl(v, 1, 64), v2 = __shfl(v, 2, 64), v3 = __shfl(v, 3, 64);
   if (lane == 0) {
