@@ -60,8 +60,8 @@ def algorithmic_bytes(st: dict, pushes: int, beams: int) -> float:
     """Bytes one push MUST move, fp64 SoA storage (DESIGN.md "Roofline"): per updated cell tsd+weight
     read+write = 32 B; an emptied initialised tile RMWs 1089 cells; a tile materialised from
     _initWeight > 0 writes 1024 cells; the scan (8 B range + 1 B mask per beam) is read once; every tile
-    that passes the range cull reads/writes 16 B of tile state.  k_push_tiles (classification + update of
-    every tile, one workgroup per tile) is the kernel that moves these bytes."""
+    that passes the range cull reads/writes 16 B of tile state.  k_push_update (one workgroup per listed tile)
+    moves all of these bytes but the tile state of the tiles k_push_classify rejects."""
     return (32.0 * st["cells_updated"] + 32.0 * 1089 * st["tiles_emptied_init"]
             + 16.0 * 1024 * st["tiles_new_from_empty"] + 16.0 * st["tiles_range_pass"] + 9.0 * beams * pushes)
 

@@ -355,7 +355,16 @@ k_push_update(GridDev g, PushArgs a_val, const PushArgs* __restrict__ a_dev, con
     if (wlo < 0) wlo = 0;
     if (whi > a.beams - 1) whi = a.beams - 1;
   }
-  if (a.beams <= FAST_MAX_BEAMS) {
+  if (whi - wlo + 2 <= UPDATE_BLOCK) {
+    // the usual tile, seen from outside: a few dozen beams, at most one element of each array per thread
+    const int j = wlo + tid;
+    const bool in_r = j <= whi, in_b = fast && j <= whi + 1;
+    const double rj = in_r ? ranges[j] : 0.0;
+    const uint8_t mj = in_r ? mask[j] : (uint8_t)0;
+    const double2 bj = in_b ? bdir[j] : make_double2(0.0, 0.0);
+    if (in_r) { s_ranges[j] = rj; s_mask[j] = mj; }
+    if (in_b) s_bdir[j] = bj;
+  } else if (a.beams <= FAST_MAX_BEAMS) {
     // every read issued before the first LDS write: one memory latency for the whole staging
     constexpr int NR = FAST_MAX_BEAMS / 2 / UPDATE_BLOCK, NM = FAST_MAX_BEAMS / UPDATE_BLOCK, NB = NM + 1;
     const int p0 = wlo >> 1, p1 = whi >> 1;                    // pairs of ranges
