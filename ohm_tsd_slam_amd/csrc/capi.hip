@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <cstdio>
 #include <new>
@@ -212,6 +213,16 @@ static int read_total_stats(tsd_ctx* ctx, tsd_push_stats* out, int64_t* pushes, 
   if (out) fill_stats(ctx, t, out);
   if (pushes) *pushes = (int64_t)np[0];
   return TSD_OK;
+}
+
+// true once `ev` has completed; polls for at most ~`us` microseconds
+static bool host_saw_event(hipEvent_t ev, int us)
+{
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    if (hipEventQuery(ev) == hipSuccess) return true;
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(us)) return false;
+  }
 }
 
 }  // namespace tsd
@@ -839,14 +850,17 @@ int tsd_scan(tsd_sensor* s, const double* ranges, const uint8_t* mask, const uin
   sp.st = s->d_state; sp.rays = s->d_rays; sp.out = s->d_result; sp.seq = seq; sp.beams = s->beams;
   sp.gmin_x = ctx->grid.min_x; sp.gmax_x = ctx->grid.max_x; sp.gmin_y = ctx->grid.min_y; sp.gmax_y = ctx->grid.max_y;
   sp.gates = GateArgs{gates->reg_trs_max, gates->reg_sin_rot_max, gates->trs_min, gates->rot_min};
-  TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_h2d, 0));       // the ray cast did not need the scan
+  // The ray cast did not need the scan, the registration does.  The copy is short and the ray cast long, so the
+  // host waits for the copy itself (a few microseconds, the device is busy meanwhile) instead of putting a
+  // cross-stream barrier between the two kernels; the barrier is the fall-back.
+  if (!host_saw_event(ctx->ev_h2d, 40)) TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_h2d, 0));
   rc = launch_icp(ctx, ia, s->d_state->icpP, s->d_rays_local, d_ranges, d_mask, &sp);
   if (rc != TSD_OK) return rc;
   PushArgs pa;
   std::memset(&pa, 0, sizeof(pa));
   pa.beams = s->beams;                                   // LDS size of the launch
   pa.max_range = s->max_range;                           // tile window of the launch (the rest is read on the device)
-  TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_tables, 0));
+  if (!host_saw_event(ctx->ev_tables, 60)) TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_tables, 0));
   // the registration moves the sensor by at most the gate (a larger step is rejected: pose unchanged)
   rc = launch_push(ctx, pa, s->pos[0], s->pos[1], gates->reg_trs_max, &s->d_state->push, d_ranges, d_mask_push);
   if (rc != TSD_OK) return rc;
