@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--scene", default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scans", type=int, default=30)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and run the occupancy merge even with one rank (checks the "
+                         "multi-GPU plumbing on a single GPU; tests/test_gpu_multigpu_plumbing.py)")
     ap.add_argument("--calibrate", action="store_true",
                     help="also launch the PMC calibration kernel (known byte count; used by tools/profile_bench.sh)")
     args = ap.parse_args()
@@ -112,7 +115,8 @@ def main():
     n_gpus = args.gpus
     dist = None
     torch = None
-    if world_size > 1:
+    use_dist = world_size > 1 or args.force_dist
+    if use_dist:
         import torch  # plumbing only: device tensors for the collective + torch.distributed (RCCL)
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -131,17 +135,17 @@ def main():
 
     params = facade.node_params(gc, geo)
     params["tsd_slam/local_offset_x"] = off_x
-    node = facade.SlamNode(params, device=local_rank if world_size > 1 else 0, synchronous=True)
+    node = facade.SlamNode(params, device=local_rank if use_dist else 0, synchronous=True)
     grid = node.grid()
     merger = None
-    if world_size > 1:
+    if use_dist:
         merger = multigpu.OccupancyMerger(gc.cells, device=f"cuda:{local_rank}")
 
     def step(k):
         node.laser(scans[k], geo.angle_min, geo.angle_increment)
         if merger is not None and k % MERGE_EVERY == 0:
             merger.fill_from_grid(grid)     # occupancy extraction kernels on the ctx stream
-            merger.merge_async()            # RCCL max all-reduce over xGMI, overlaps the next scans
+            merger.merge_async(force=args.force_dist)   # RCCL max all-reduce over xGMI, overlaps the next scans
 
     node.laser(scans[0], geo.angle_min, geo.angle_increment)          # init: freeFootprint + initPush
     for k in range(1, 1 + W):

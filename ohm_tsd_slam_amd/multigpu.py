@@ -65,9 +65,10 @@ class OccupancyMerger:
         t = self._torch.as_tensor(occ_int8, dtype=self._torch.int8).reshape(-1)
         self.buffer.copy_(t)
 
-    def merge_async(self):
+    def merge_async(self, force: bool = False):
+        """``force`` issues the collective even in a one-rank group (plumbing check on a single GPU)."""
         self.wait()
-        if self.active:
+        if self.active or (force and self._dist.is_initialized()):
             self._work = self._dist.all_reduce(self.buffer, op=self._dist.ReduceOp.MAX, group=self.group, async_op=True)
         return self._work
 
