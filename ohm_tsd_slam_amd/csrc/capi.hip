@@ -273,6 +273,7 @@ tsd_ctx* tsd_create(int device, int map_size_log2, double cell_size, double max_
   A(hipMalloc(&g.init_weight, T * sizeof(double)));
   A(hipMalloc(&g.tsd, T * TILE_STRIDE * sizeof(double)));
   A(hipMalloc(&g.weight, T * TILE_STRIDE * sizeof(double)));
+  A(hipMalloc(&g.negmask, T * sizeof(unsigned long long)));
   A(hipMalloc(&ctx->d_rmq2[0], push_rmq_bytes(TSD_MAX_BEAMS)));
   A(hipMalloc(&ctx->d_rmq2[1], push_rmq_bytes(TSD_MAX_BEAMS)));
   ctx->d_rmq = ctx->d_rmq2[0];
@@ -322,7 +323,7 @@ void tsd_destroy(tsd_ctx* ctx)
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   drain_timers(ctx);
   GridDev& g = ctx->grid;
-  hipFree(g.flags); hipFree(g.init_weight); hipFree(g.tsd); hipFree(g.weight);
+  hipFree(g.flags); hipFree(g.init_weight); hipFree(g.tsd); hipFree(g.weight); hipFree(g.negmask);
   if (ctx->stream2) hipStreamSynchronize(ctx->stream2);
   hipFree(ctx->d_rmq2[0]); hipFree(ctx->d_rmq2[1]); hipFree(ctx->d_tile_rec); hipFree(ctx->d_dirty); hipFree(ctx->d_tile_totals); hipFree(ctx->d_pushes); hipFree(ctx->d_list); hipFree(ctx->d_list_win); hipFree(ctx->d_list_cnt);
   if (ctx->ev_tables) hipEventDestroy(ctx->ev_tables);
@@ -351,6 +352,7 @@ int tsd_reset(tsd_ctx* ctx)
   TSD_HIP_CHECK(ctx, hipMemsetAsync(g.flags, 0, T, ctx->stream));
   TSD_HIP_CHECK(ctx, hipMemsetAsync(g.init_weight, 0, T * sizeof(double), ctx->stream));
   TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_dirty, 0, T, ctx->stream));
+  TSD_HIP_CHECK(ctx, hipMemsetAsync(g.negmask, 0, T * sizeof(unsigned long long), ctx->stream));
   TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_tile_rec, 0, T * sizeof(uint32_t), ctx->stream));
   TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_tile_totals, 0, T * 8 * sizeof(uint32_t), ctx->stream));
   TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_pushes, 0, 2 * sizeof(unsigned long long), ctx->stream));
@@ -631,6 +633,9 @@ int tsd_upload_tiles(tsd_ctx* ctx, const uint8_t* initialized, const double* ini
     TSD_HIP_CHECK(ctx, hipMemcpy(g.tsd + (size_t)p * TILE_STRIDE, tsd_in + (size_t)p * TSD_TILE_CELLS, TSD_TILE_CELLS * sizeof(double), hipMemcpyHostToDevice));
     TSD_HIP_CHECK(ctx, hipMemcpy(g.weight + (size_t)p * TILE_STRIDE, weight_in + (size_t)p * TSD_TILE_CELLS, TSD_TILE_CELLS * sizeof(double), hipMemcpyHostToDevice));
   }
+  int rc = launch_neg_scan(ctx);          // which tiles can show a sign change to the ray cast
+  if (rc != TSD_OK) return rc;
+  TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return TSD_OK;
 }
 

@@ -338,6 +338,8 @@ k_push_update(GridDev g, PushArgs a_val, const PushArgs* __restrict__ a_dev, con
   const int tid = threadIdx.x, lane = tid & 63;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned int* s_upd = reinterpret_cast<unsigned int*>(smem);             // [4] cells updated per wave
+  __shared__ unsigned long long s_neg_store;
+  unsigned long long* s_neg = &s_neg_store;                               // groups of the tile that received a negative value
   double* s_ranges = reinterpret_cast<double*>(smem + 16);
   uint8_t* s_mask = reinterpret_cast<uint8_t*>(smem + 16 + (size_t)((a.beams + 1) & ~1) * sizeof(double));
   double2* s_bdir = reinterpret_cast<double2*>(smem + 16 + (size_t)((a.beams + 1) & ~1) * sizeof(double) + (size_t)((a.beams + 15) & ~15));
@@ -417,6 +419,7 @@ k_push_update(GridDev g, PushArgs a_val, const PushArgs* __restrict__ a_dev, con
     // ---- UPDATE ----
     const bool initialised = (li == blockIdx.x ? flag_first : g.flags[p]) != 0;
     const double iw = li == blockIdx.x ? iw_first : g.init_weight[p];
+    if (tid == 0) *s_neg = 0ull;
     __syncthreads();               // scan staged; s_upd of a previous tile consumed
     PSTAMP(2);
 
@@ -493,13 +496,16 @@ k_push_update(GridDev g, PushArgs a_val, const PushArgs* __restrict__ a_dev, con
     if (tv[0] == 123.456) dbg[1023] = wv[0] + tv[1] + tv[2] + tv[3];    // (wait for the reads)
 #endif
     PSTAMP(4);
+    unsigned long long wrote_neg = 0ull;
 #pragma unroll
     for (int k = 0; k < CPT; k++) {
       bool touched = false;
       if (hit[k]) touched = add_tsd(tv[k], wv[k], sdv[k], pw, max_trunc, inv_max_trunc, eps);
       if (touched) n_upd++;
+      if (touched && tv[k] < 0.0) wrote_neg |= neg_bit((unsigned)cidx[k] % TILE_PITCH, (unsigned)cidx[k] / TILE_PITCH);
       if (touched || fresh) { T[cidx[k]] = tv[k]; W[cidx[k]] = wv[k]; }
     }
+    if (wrote_neg) atomicOr(s_neg, wrote_neg);                      // (LDS; folded into the tile's mask below)
     if (fresh) {
       // halo cells of a freshly materialised tile keep the init value until k_push_halo
       for (int h = tid; h < 2 * TILE_DIM + 1; h += UPDATE_BLOCK) {
@@ -520,6 +526,8 @@ k_push_update(GridDev g, PushArgs a_val, const PushArgs* __restrict__ a_dev, con
       unsigned cells = 0;
       for (int w = 0; w < UPDATE_BLOCK / 64; w++) cells += s_upd[w];
       tile_rec[p] = rec | (cells << REC_CELLS_SHIFT);
+      const unsigned long long nm = *s_neg;
+      if (nm) g.negmask[p] |= nm;    // (this workgroup owns the tile)
       uint32_t* tot = tile_totals + (size_t)p * TOT_FIELDS;
       tot[0] += cells; tot[2] += 1u;
       if (fresh) { tot[3] += 1u; if (iw > 0.0) tot[4] += 1u; }
@@ -647,6 +655,33 @@ int launch_calibrate(tsd_ctx* ctx, double* t, double* w, size_t n)
 }
 
 // ------------------------------------------------------------------------------------------------
+// exact `negmask` of a grid whose cells were written by the host (tsd_upload_tiles): one workgroup per tile;
+// a negative halo cell is charged to the tile that owns the cell (uploaded halos may be stale)
+__global__ void __launch_bounds__(256)
+k_neg_scan(GridDev g)
+{
+  const int p = blockIdx.x;
+  if (!g.flags[p]) return;
+  const int PX = g.PX, px = p % PX, py = p / PX;
+  const double* T = g.tsd + (size_t)p * TILE_STRIDE;
+  for (int i = threadIdx.x; i < TILE_CELLS; i += 256) {
+    if (!(T[i] < 0.0)) continue;
+    const unsigned ix = (unsigned)i % TILE_PITCH, iy = (unsigned)i / TILE_PITCH;
+    const int qx = px + (ix == TILE_DIM ? 1 : 0), qy = py + (iy == TILE_DIM ? 1 : 0);
+    if (qx >= PX || qy >= PX) continue;                        // (no tile owns the outermost halo)
+    atomicOr(&g.negmask[qy * PX + qx], neg_bit(ix & 31u, iy & 31u));
+  }
+}
+
+int launch_neg_scan(tsd_ctx* ctx)
+{
+  const GridDev& g = ctx->grid;
+  TSD_HIP_CHECK(ctx, hipMemsetAsync(g.negmask, 0, (size_t)g.tiles * sizeof(unsigned long long), ctx->stream));
+  hipLaunchKernelGGL(k_neg_scan, dim3(g.tiles), dim3(256), 0, ctx->stream, g);
+  TSD_HIP_CHECK(ctx, hipGetLastError());
+  return TSD_OK;
+}
+
 int launch_free_footprint(tsd_ctx* ctx, unsigned minX, unsigned maxX, unsigned minY, unsigned maxY)
 {
   if (maxX <= minX || maxY <= minY) return TSD_OK;

@@ -29,6 +29,7 @@ namespace tsd {
 
 constexpr int RC_S = 4;            // steps per lane and round (256 steps per round)
 constexpr int RC_MAXSEG = 16;
+constexpr int RC_BLK = 15;         // steps per block of the fine march (one group of 16 lanes; < one tile)
 
 struct RcSeg { double anchor, rhat; int n0, pad; };
 struct __attribute__((aligned(8))) Cell2 { double a, b; };      // two neighbouring cells of a tile row
@@ -48,12 +49,13 @@ __device__ __forceinline__ double pow2_from_field(int ef)      // 2^(ef - 1023) 
 }
 
 // Segment table of the chain v_0 = p0, v_{n+1} = fl(v_n + r) for n < N.  Wave-uniform; every lane
-// computes it, lane 0 stores it.  Returns false if the closed form is not applicable.
+// computes it, lane 0 stores it.  Returns false if the closed form is not applicable (more than RC_MAXSEG segments).
 __device__ bool build_segments(double p0, double r, int N, RcSeg* seg, int& nseg, int lane)
 {
   nseg = 0;
   int n = 0;
   double p = p0;
+  int even_ef = -2;                        // binade in which p / ulp is known to be even (tie case below)
   while (n <= N) {
     if (nseg >= RC_MAXSEG) return false;
     const int ef = binade_of(p);
@@ -63,8 +65,19 @@ __device__ bool build_segments(double p0, double r, int N, RcSeg* seg, int& nseg
       const double lo = pow2_from_field(ef), hi = pow2_from_field(ef + 1);
       const double u = pow2_from_field(ef - 52), uinv = pow2_from_field(2046 - (ef - 52));   // ulp and 1/ulp
       const double q = r * uinv;                         // r / ulp, exact (power-of-two scaling)
-      const double rq = rint(q);
-      if (fabs(q - rq) == 0.5) return false;             // ties-to-even would alternate: serial chain
+      const double rq = rint(q);                         // (half-way cases go to the even integer)
+      if (fabs(q - rq) == 0.5 && even_ef != ef) {
+        // r / ulp ends in exactly .5 (one beam coordinate in ~2000): every addition is a tie and goes to the EVEN
+        // multiple of ulp.  From an even p / ulp the chain therefore adds the even one of floor(q), floor(q) + 1,
+        // which is rint(q), every time and stays even; from an odd one the first sum lands one ulp off that
+        // pattern and is even afterwards.  So: one genuine addition, then the closed form with rint(q) * ulp.
+        if (lane == 0) { seg[nseg].anchor = p; seg[nseg].rhat = 0.0; seg[nseg].n0 = n; seg[nseg].pad = 0; }
+        nseg++;
+        p = p + r;
+        n += 1;
+        if (binade_of(p) == ef) even_ef = ef;
+        continue;
+      }
       rhat = rq * u;
       // common case: the rest of the beam stays inside this binade (fma is exact for in-binade values)
       const double pend = fma((double)(N - n), rhat, p);
@@ -163,11 +176,15 @@ k_raycast(GridDev g, RaycastArgs a_val, const RaycastArgs* __restrict__ a_dev, c
 #else
 #define RSTAMP(i) do {} while (0)
 #endif
+#ifdef TSD_RC_STAMPS2
+  const long long st2_begin = clock64();
+#endif
   const RaycastArgs a = a_dev ? *a_dev : a_val;
   const int beam = blockIdx.x;
   const int lane = threadIdx.x;
   if (beam >= a.beams) return;
   __shared__ RcSeg s_segx[RC_MAXSEG], s_segy[RC_MAXSEG];
+  __shared__ int s_blk[64];                                  // blocks of the current chunk that can hold an event
   const double rx = rays[beam], ry = rays[a.beams + beam];
   const double trx = a.trx, try_ = a.try_;
   const double cs = g.cs;
@@ -260,28 +277,11 @@ k_raycast(GridDev g, RaycastArgs a_val, const RaycastArgs* __restrict__ a_dev, c
   __syncthreads();
   RSTAMP(1);
   const int nsteps = closed ? nsteps_i : 0;
-  RSTAMP(2);
 
-  // sample of step 0 ("the previous step" of step 1; NaN = none): its reads go out now and are consumed
-  // once the first round's reads are in flight too
-  int c_p = 0, c_lx = 0, c_ly = 0; double c_dx = 0.0, c_dy = 0.0;
-  const bool c_in = coord2cell(g, px0, py0, c_p, c_lx, c_ly, c_dx, c_dy);
-  const size_t c_off = c_in ? (size_t)c_p * TILE_STRIDE + (size_t)(c_ly * TILE_PITCH + c_lx) : 0;
-  const uint8_t c_fl = g.flags[c_in ? c_p : 0];
-  const Cell2 c_r0 = *reinterpret_cast<const Cell2*>(g.tsd + c_off);
-  const Cell2 c_r1 = *reinterpret_cast<const Cell2*>(g.tsd + c_off + TILE_PITCH);
-  auto first_sample = [&]() {
-    double r = __builtin_nan("");
-    if (c_in && c_fl) {
-      const double wx = fabs((px0 - c_dx) * g.inv_cs), wy = fabs((py0 - c_dy) * g.inv_cs);
-      r = c_r0.a * (1. - wy) * (1. - wx) + c_r1.a * wy * (1. - wx) + c_r0.b * (1. - wy) * wx + c_r1.b * wy * wx;
-    }
-    return r;                                               // NaN stays NaN = "not SUCCESS"
-  };
-  double carry = 0.0;
+
   bool found = false, ended = false;
   double hit_x = 0.0, hit_y = 0.0;
-  RSTAMP(3);
+
 
   if (closed) {
     // the first two segments of each coordinate in registers (nearly every beam has at most two)
@@ -295,77 +295,139 @@ k_raycast(GridDev g, RaycastArgs a_val, const RaycastArgs* __restrict__ a_dev, c
       if (nsy > 2) return seg_value(s_segy, nsy, k);
       return k >= y1n ? fma((double)(k - y1n), y1.rhat, y1.anchor) : fma((double)k, y0.rhat, y0.anchor);
     };
-    for (int base = 1; base <= nsteps && !found; base += 64 * RC_S) {
-      // sub-round j covers the 64 consecutive steps base + 64 j + lane (one per lane, so that a load
-      // instruction touches 64 neighbouring cells along the ray); every position by the closed form
-      double qx[RC_S], qy[RC_S], v[RC_S];
-      bool act[RC_S];
-      int st[RC_S]; size_t off[RC_S]; int tp[RC_S]; double wx[RC_S], wy[RC_S];
+    // The reference samples every step; an event at step k (hit: prev > 0 > cur, miss: prev < 0 < cur) needs a
+    // negative sample, i.e. a negative cell among the four a sample interpolates.  GridDev::negmask says for
+    // every 4x4-cell group of every tile whether it has ever held a negative value (a halo cell is a copy of the
+    // owning neighbour's cell, so the owner's bit stands for it).  The march looks at the path in blocks of
+    // RC_BLK steps: the cells the samples of a block can touch lie in the box spanned by the block's first and
+    // last sample (the path is monotone) plus one cell; when no group under that box has its bit set the block
+    // cannot hold an event and is not sampled.  The others are sampled in order and the first event wins --
+    // exactly what the full march finds.  Free space costs a few mask reads per block.
+    // A group of 16 lanes takes one block: its first lane samples the step before the block ("prev" of the
+    // block's first step), the others the block's RC_BLK steps.
+    auto block_may_hold_event = [&](int k_first, int k_last) {
+      int p0, lx0, ly0, p1, lx1, ly1; double dx, dy;
+      if (!coord2cell(g, posx(k_first), posy(k_first), p0, lx0, ly0, dx, dy)) return true;
+      if (!coord2cell(g, posx(k_last), posy(k_last), p1, lx1, ly1, dx, dy)) return true;
+      const int PX = g.PX;
+      const int xs = (p0 % PX) * TILE_DIM + lx0, ys = (p0 / PX) * TILE_DIM + ly0;
+      const int xe = (p1 % PX) * TILE_DIM + lx1, ye = (p1 / PX) * TILE_DIM + ly1;
+      const int xa = xs < xe ? xs : xe, ya = ys < ye ? ys : ye;
+      int xb = (xs < xe ? xe : xs) + 1, yb = (ys < ye ? ye : ys) + 1;      // + the second column / row of the footprint
+      if (xb > g.N - 1) xb = g.N - 1;
+      if (yb > g.N - 1) yb = g.N - 1;
+      const int txa = xa >> 5, txb = xb >> 5, tya = ya >> 5, tyb = yb >> 5;   // at most 2 x 2 tiles (RC_BLK + 2 <= 32)
+      bool any = false;
 #pragma unroll
-      for (int j = 0; j < RC_S; j++) {
-        const int k = base + 64 * j + lane;
-        qx[j] = posx(k); qy[j] = posy(k);
-        act[j] = k <= nsteps;
-        int p = 0, lx = 0, ly = 0; double dx = 0.0, dy = 0.0;
-        const bool inside = act[j] && coord2cell(g, qx[j], qy[j], p, lx, ly, dx, dy);
-        st[j] = inside ? INTERP_SUCCESS : INTERP_INVALIDINDEX;
-        tp[j] = inside ? p : 0;
-        off[j] = (size_t)tp[j] * TILE_STRIDE + (size_t)(inside ? ly * TILE_PITCH + lx : 0);
-        wx[j] = fabs((qx[j] - dx) * g.inv_cs);
-        wy[j] = fabs((qy[j] - dy) * g.inv_cs);
-      }
-      // the tile storage exists for every tile (only `flags` says whether it holds data), so the cell
-      // reads need not wait for the flag; each row pair is one 16-byte read
-      uint8_t fl[RC_S]; Cell2 r0[RC_S], r1[RC_S];
+      for (int iy = 0; iy < 2; iy++) {
 #pragma unroll
-      for (int j = 0; j < RC_S; j++) {
-        fl[j] = g.flags[tp[j]];
-        const double* t = g.tsd + off[j];
-        r0[j] = *reinterpret_cast<const Cell2*>(t);
-        r1[j] = *reinterpret_cast<const Cell2*>(t + TILE_PITCH);
-      }
-      if (base == 1) carry = first_sample();
-#pragma unroll
-      for (int j = 0; j < RC_S; j++) {
-        double r = __builtin_nan("");
-        if (st[j] == INTERP_SUCCESS && fl[j]) {
-          r = r0[j].a * (1. - wy[j]) * (1. - wx[j]) + r1[j].a * wy[j] * (1. - wx[j])
-            + r0[j].b * (1. - wy[j]) * wx[j] + r1[j].b * wy[j] * wx[j];   // NaN stays NaN = "not SUCCESS"
+        for (int ix = 0; ix < 2; ix++) {
+          const int tx = ix ? txb : txa, ty = iy ? tyb : tya;
+          if ((ix && txb == txa) || (iy && tyb == tya)) continue;
+          const int cx0 = (xa > tx * TILE_DIM ? xa : tx * TILE_DIM) - tx * TILE_DIM;
+          const int cx1 = (xb < tx * TILE_DIM + 31 ? xb : tx * TILE_DIM + 31) - tx * TILE_DIM;
+          const int cy0 = (ya > ty * TILE_DIM ? ya : ty * TILE_DIM) - ty * TILE_DIM;
+          const int cy1 = (yb < ty * TILE_DIM + 31 ? yb : ty * TILE_DIM + 31) - ty * TILE_DIM;
+          any |= (g.negmask[ty * PX + tx] & neg_rect(cx0 >> 2, cx1 >> 2, cy0 >> 2, cy1 >> 2)) != 0ull;
         }
-        v[j] = r;
       }
-      // events in step order, sub-round by sub-round
+      return any;
+    };
+    const int nblk = (nsteps + RC_BLK - 1) / RC_BLK;
+#ifdef TSD_RC_STAMPS
+    int dbg_cand = 0, dbg_blocks = 0;
+#endif
+    for (int chunk = 0; chunk * 64 < nblk && !found && !ended; chunk++) {
+      // which of this chunk's 64 blocks can hold an event
+      const int bq = chunk * 64 + lane;
+      bool cand = false;
+      if (bq < nblk) {
+        const int k0 = bq * RC_BLK, k1 = k0 + RC_BLK < nsteps ? k0 + RC_BLK : nsteps;
+        cand = block_may_hold_event(k0, k1);
+      }
+      const unsigned long long m_cand = __ballot(cand);
+      const int n_cand = __popcll(m_cand);
+#ifdef TSD_RC_STAMPS
+      dbg_cand += n_cand; dbg_blocks += (nblk - chunk * 64 < 64 ? nblk - chunk * 64 : 64);
+#endif
+      if (cand) s_blk[__popcll(m_cand & ((1ull << lane) - 1ull))] = bq;
+      __syncthreads();
+      for (int r0 = 0; r0 < n_cand && !found && !ended; r0 += 4 * RC_S) {
+        double qx[RC_S], qy[RC_S], v[RC_S];
+        bool act[RC_S];
+        int st[RC_S]; size_t off[RC_S]; int tp[RC_S]; double wx[RC_S], wy[RC_S];
 #pragma unroll
-      for (int j = 0; j < RC_S; j++) {
-        if (found) break;
-        const double cur = v[j];
-        double prev = __shfl_up(cur, 1, 64);
-        if (lane == 0) prev = carry;
-        const bool hit = act[j] && (prev > 0 && cur < 0);
-        const bool miss = act[j] && !hit && (prev < 0 && cur > 0);
-        const unsigned long long m_hit = __ballot(hit), m_miss = __ballot(miss);
-        const unsigned long long m_ev = m_hit | m_miss;
-        if (m_ev) {
-          const int f = __ffsll((long long)m_ev) - 1;
-          if ((m_hit >> f) & 1ull) {
-            // interp = tsd_prev / (tsd_prev - tsd); c = position + ray * (interp - 1)
-            const double interp = prev / (prev - cur);
-            const double cx = qx[j] + rx * (interp - 1.0);
-            const double cy = qy[j] + ry * (interp - 1.0);
-            hit_x = __shfl(cx, f, 64);
-            hit_y = __shfl(cy, f, 64);
-            found = true;
+        for (int j = 0; j < RC_S; j++) {
+          const int li = r0 + 4 * j + (lane >> 4);
+          const int blk = li < n_cand ? s_blk[li] : -1;
+          const int k = blk * RC_BLK + (lane & 15);             // lane 0 of the group: the step before the block
+          qx[j] = posx(k < 0 ? 0 : k); qy[j] = posy(k < 0 ? 0 : k);
+          act[j] = blk >= 0 && k <= nsteps;
+          int p = 0, lx = 0, ly = 0; double dx = 0.0, dy = 0.0;
+          const bool inside = act[j] && coord2cell(g, qx[j], qy[j], p, lx, ly, dx, dy);
+          st[j] = inside ? INTERP_SUCCESS : INTERP_INVALIDINDEX;
+          tp[j] = inside ? p : 0;
+          off[j] = (size_t)tp[j] * TILE_STRIDE + (size_t)(inside ? ly * TILE_PITCH + lx : 0);
+          wx[j] = fabs((qx[j] - dx) * g.inv_cs);
+          wy[j] = fabs((qy[j] - dy) * g.inv_cs);
+        }
+        // the tile storage exists for every tile (only `flags` says whether it holds data), so the cell
+        // reads need not wait for the flag; each row pair is one 16-byte read
+        uint8_t fl[RC_S]; Cell2 r0v[RC_S], r1v[RC_S];
+#pragma unroll
+        for (int j = 0; j < RC_S; j++) {
+          fl[j] = g.flags[tp[j]];
+          const double* t = g.tsd + off[j];
+          r0v[j] = *reinterpret_cast<const Cell2*>(t);
+          r1v[j] = *reinterpret_cast<const Cell2*>(t + TILE_PITCH);
+        }
+#pragma unroll
+        for (int j = 0; j < RC_S; j++) {
+          double r = __builtin_nan("");
+          if (st[j] == INTERP_SUCCESS && fl[j]) {
+            r = r0v[j].a * (1. - wy[j]) * (1. - wx[j]) + r1v[j].a * wy[j] * (1. - wx[j])
+              + r0v[j].b * (1. - wy[j]) * wx[j] + r1v[j].b * wy[j] * wx[j];   // NaN stays NaN = "not SUCCESS"
           }
-          ended = true;
-          break;
+          v[j] = r;
         }
-        carry = __shfl(cur, 63, 64);
+        // events in step order: groups hold ascending blocks, lanes ascending steps
+#pragma unroll
+        for (int j = 0; j < RC_S; j++) {
+          if (found || ended) break;
+          const double cur = v[j];
+          const double prev = __shfl_up(cur, 1, 64);
+          const bool is_step = act[j] && (lane & 15) != 0;      // (the group's first lane only supplies `prev`)
+          const bool hit = is_step && (prev > 0 && cur < 0);
+          const bool miss = is_step && !hit && (prev < 0 && cur > 0);
+          const unsigned long long m_hit = __ballot(hit), m_miss = __ballot(miss);
+          const unsigned long long m_ev = m_hit | m_miss;
+          if (m_ev) {
+            const int f = __ffsll((long long)m_ev) - 1;
+            if ((m_hit >> f) & 1ull) {
+              // interp = tsd_prev / (tsd_prev - tsd); c = position + ray * (interp - 1)
+              const double interp = prev / (prev - cur);
+              const double cx = qx[j] + rx * (interp - 1.0);
+              const double cy = qy[j] + ry * (interp - 1.0);
+              hit_x = __shfl(cx, f, 64);
+              hit_y = __shfl(cy, f, 64);
+              found = true;
+            }
+            ended = true;
+          }
+        }
       }
-      if (ended) break;
+      __syncthreads();                                         // the block list is rewritten by the next chunk
     }
+#ifdef TSD_RC_STAMPS
+    if (threadIdx.x == 0 && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 128) { dbg[(blockIdx.x >> 3) * 8 + 2] = dbg_cand; dbg[(blockIdx.x >> 3) * 8 + 3] = dbg_blocks; }
+#endif
   } else {
     // serial chain (rare): 64 steps per round, positions by the reference's own additions
-    carry = first_sample();
+    double carry;                                           // sample of the previous step (NaN = none)
+    {
+      double t0;
+      carry = (interpolate_bilinear(g, px0, py0, t0) == INTERP_SUCCESS) ? t0 : __builtin_nan("");
+    }
     double px = px0, py = py0;
     double i_run = idxMin;
     for (;;) {
@@ -407,6 +469,9 @@ k_raycast(GridDev g, RaycastArgs a_val, const RaycastArgs* __restrict__ a_dev, c
   RSTAMP(4);
 #ifdef TSD_RC_STAMPS
   if (lane == 0 && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 128) dbg[(blockIdx.x >> 3) * 8 + 6] = closed ? 0.0 : 1.0;
+#endif
+#ifdef TSD_RC_STAMPS2    // diagnostic: every beam's cycles (negative: serial chain) -- dbg[beam % 1024]
+  if (lane == 0) dbg[beam & 1023] = (closed ? 1.0 : -1.0) * (double)(clock64() - st2_begin);
 #endif
   if (!found) { if (lane == 0) mask[beam] = 0; return; }
 

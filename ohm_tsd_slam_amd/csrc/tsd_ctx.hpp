@@ -214,6 +214,7 @@ int launch_push_tables(tsd_ctx* ctx, hipStream_t stream, int beams, const double
                        double phi_min, double ang_res);
 size_t push_rmq_bytes(int beams);
 int launch_free_footprint(tsd_ctx* ctx, unsigned minX, unsigned maxX, unsigned minY, unsigned maxY);
+int launch_neg_scan(tsd_ctx* ctx);
 int launch_raycast(tsd_ctx* ctx, const RaycastArgs& a, const RaycastArgs* a_dev = nullptr, const double* d_rays = nullptr);
 int launch_icp(tsd_ctx* ctx, const IcpArgs& a, const double* P_dev = nullptr, const double* d_rays_local = nullptr,
                const double* d_ranges = nullptr, const uint8_t* d_mask = nullptr, const ScanPostArgs* post = nullptr);

@@ -30,7 +30,23 @@ struct GridDev {
   double*  init_weight;
   double*  tsd;
   double*  weight;
+  unsigned long long* negmask;   // [tiles] bit gy*8+gx: the 4x4-cell group (gx, gy) of the tile has (ever) held a negative tsd
 };
+
+// `negmask` bookkeeping (k_raycast skips the steps that cannot see a sign change): which 4x4-cell groups of a tile
+// have ever held a negative value.  Sticky and conservative: never cleared by a push.  A halo cell is a copy of
+// the owning neighbour's interior cell, so the owner's bit covers it.
+__device__ __forceinline__ unsigned long long neg_bit(unsigned ix, unsigned iy)     // interior cell (ix, iy), 0..31
+{
+  return 1ull << ((iy >> 2) * 8u + (ix >> 2));
+}
+// groups gx0..gx1 x gy0..gy1 (0..7) of a tile as a mask
+__device__ __forceinline__ unsigned long long neg_rect(int gx0, int gx1, int gy0, int gy1)
+{
+  const unsigned long long cols = (unsigned long long)(((1u << (gx1 + 1)) - (1u << gx0)) & 0xFFu) * 0x0101010101010101ull;
+  const unsigned long long rows = (~0ull >> (8 * (7 - gy1))) & (~0ull << (8 * gy0));
+  return cols & rows;
+}
 
 enum : int { INTERP_SUCCESS = 0, INTERP_INVALIDINDEX = 1, INTERP_EMPTYPARTITION = 2, INTERP_ISNAN = 3 };
 
