@@ -358,6 +358,8 @@ k_raycast(GridDev g, RaycastArgs a_val, const RaycastArgs* __restrict__ a_dev, c
         int st[RC_S]; size_t off[RC_S]; int tp[RC_S]; double wx[RC_S], wy[RC_S];
 #pragma unroll
         for (int j = 0; j < RC_S; j++) {
+          act[j] = false; st[j] = INTERP_INVALIDINDEX; tp[j] = 0; off[j] = 0; qx[j] = 0.0; qy[j] = 0.0; wx[j] = 0.0; wy[j] = 0.0;
+          if (r0 + 4 * j >= n_cand) continue;                   // (wave-uniform) no block left for this sub-round
           const int li = r0 + 4 * j + (lane >> 4);
           const int blk = li < n_cand ? s_blk[li] : -1;
           const int k = blk * RC_BLK + (lane & 15);             // lane 0 of the group: the step before the block
@@ -376,6 +378,8 @@ k_raycast(GridDev g, RaycastArgs a_val, const RaycastArgs* __restrict__ a_dev, c
         uint8_t fl[RC_S]; Cell2 r0v[RC_S], r1v[RC_S];
 #pragma unroll
         for (int j = 0; j < RC_S; j++) {
+          fl[j] = 0; r0v[j].a = r0v[j].b = r1v[j].a = r1v[j].b = 0.0;
+          if (r0 + 4 * j >= n_cand) continue;
           fl[j] = g.flags[tp[j]];
           const double* t = g.tsd + off[j];
           r0v[j] = *reinterpret_cast<const Cell2*>(t);
@@ -384,7 +388,7 @@ k_raycast(GridDev g, RaycastArgs a_val, const RaycastArgs* __restrict__ a_dev, c
 #pragma unroll
         for (int j = 0; j < RC_S; j++) {
           double r = __builtin_nan("");
-          if (st[j] == INTERP_SUCCESS && fl[j]) {
+          if (r0 + 4 * j < n_cand && st[j] == INTERP_SUCCESS && fl[j]) {
             r = r0v[j].a * (1. - wy[j]) * (1. - wx[j]) + r1v[j].a * wy[j] * (1. - wx[j])
               + r0v[j].b * (1. - wy[j]) * wx[j] + r1v[j].b * wy[j] * wx[j];   // NaN stays NaN = "not SUCCESS"
           }
@@ -393,7 +397,7 @@ k_raycast(GridDev g, RaycastArgs a_val, const RaycastArgs* __restrict__ a_dev, c
         // events in step order: groups hold ascending blocks, lanes ascending steps
 #pragma unroll
         for (int j = 0; j < RC_S; j++) {
-          if (found || ended) break;
+          if (found || ended || r0 + 4 * j >= n_cand) break;
           const double cur = v[j];
           const double prev = __shfl_up(cur, 1, 64);
           const bool is_step = act[j] && (lane & 15) != 0;      // (the group's first lane only supplies `prev`)
