@@ -186,6 +186,8 @@ __device__ __forceinline__ double sep_bound(double x, double y, double rs2, doub
 // a third candidate in the same 256-ulp bucket sends the point to the exact whole-wave search.
 constexpr int WIN = 2 * HW + 1;
 constexpr int WIN_ROUNDS = 6;
+constexpr double WIN_REACH = 0.03;               // sin^2 of ~10 degrees: about the widest arc the window grows to at 0.25 degree per slot
+constexpr int LIST_PAST_WINDOW = 1 << 30;         // work-list entry: the tier-1 window was already tried (in place)
 constexpr int INLINE_MAX = 6;                   // points a wave resolves on the spot instead of listing them
 static_assert(ICP_PAD >= HW + WIN_ROUNDS * WIN, "padding must cover the widest window");
 __device__ __forceinline__ int wrap_slot(int k, int nM)
@@ -233,6 +235,9 @@ __device__ __forceinline__ NnResult window_search(const IcpLds& L, int nM, doubl
     // (b1 packed differs from the true distance by < 256 ulp; SLACK in the bounds covers that)
     if (fmin(blo, bhi) > fmin(b1, thr)) { proven = true; break; }
     if (round == WIN_ROUNDS || hi - lo + 1 + WIN > nM) break;
+    // the arc can grow to +-(HW + WIN_ROUNDS * WIN) slots; what needs a wider separation than a scan's beams
+    // have over that many slots goes to tier 2 right away (something far from the whole model)
+    if (fmin(b1, thr) > WIN_REACH * rs2) break;
     if (blo <= bhi) { side = -1; lo -= WIN; b = lo; }
     else { side = 1; b = hi + 1; hi += WIN; }
   }
@@ -254,6 +259,45 @@ __device__ __forceinline__ NnResult window_search(const IcpLds& L, int nM, doubl
   return r;
 }
 
+// Every slot of the model for one point, by the whole wave: each lane keeps the three smallest distances of its
+// slots (slot number in the low 11 mantissa bits, five v_min/max_f64 per slot), three wave minima merge them.
+// The two nearest are re-evaluated exactly (ties: lower original index); false if the third shares their
+// 2048-ulp bucket (the caller then finishes the exact walk).  lbsq = the third smallest distance: a bound on
+// every other slot.
+__device__ __forceinline__ bool sweep_all(const IcpLds& L, int nM, double x, double y, int lane, NnResult& r)
+{
+  const double inf = __builtin_inf();
+  double b1 = inf, b2 = inf, b3 = inf;
+  for (int k = lane; k < nM; k += 64) {
+    const double2 m = L.mxy[k];
+    const double dx = x - m.x, dy = y - m.y;
+    const double dd = dx * dx + dy * dy;
+    const double d = __hiloint2double(__double2hiint(dd), (__double2loint(dd) & ~0x7FF) | k);
+    const double h1 = fmax(b1, d); b1 = fmin(b1, d);
+    const double h2 = fmax(b2, h1); b2 = fmin(b2, h1);
+    b3 = fmin(b3, h2);
+  }
+  double g[3];
+#pragma unroll
+  for (int rnk = 0; rnk < 3; rnk++) {
+    const double wmin = wave_min(b1);
+    g[rnk] = wmin;
+    if (b1 == wmin && wmin < inf) { b1 = b2; b2 = b3; b3 = inf; }       // (packed values are unique: one lane pops)
+  }
+  if (!(g[0] < inf)) return false;
+  int k1 = __double2loint(g[0]) & 0x7FF, k2 = g[1] < inf ? (__double2loint(g[1]) & 0x7FF) : k1;
+  const double2 m1 = L.mxy[k1], m2 = L.mxy[k2];
+  double d1, d2;
+  { const double dx = x - m1.x, dy = y - m1.y; d1 = dx * dx + dy * dy; }
+  { const double dx = x - m2.x, dy = y - m2.y; d2 = dx * dx + dy * dy; }
+  if (d2 < d1 || (d2 == d1 && L.morig[k2] < L.morig[k1])) { const int t = k1; k1 = k2; k2 = t; d1 = d2; }
+  const double c0 = __hiloint2double(__double2hiint(g[0]), __double2loint(g[0]) & ~0x7FF);
+  const double c2 = g[2] < inf ? __hiloint2double(__double2hiint(g[2]), __double2loint(g[2]) & ~0x7FF) : inf;
+  if (!(c2 > c0)) return false;
+  r.best = d1; r.bk = k1; r.bk2 = k2; r.lbsq = c2; r.resolved = true;
+  return !isnan(d1);
+}
+
 // tier 2: the same proof by the whole wave for one point (x, y, start wave-uniform): 64 consecutive
 // slots per step, widened towards the side that is not yet bounded.
 __device__ __forceinline__ NnResult wave_search(const IcpLds& L, int nM, double x, double y, int start,
@@ -267,7 +311,21 @@ __device__ __forceinline__ NnResult wave_search(const IcpLds& L, int nM, double 
   int lo = 0, hi = -1;                               // visited offsets relative to `start` (empty)
   int cnt = nM < 64 ? nM : 64;
   int w0 = -(cnt / 2);
+  // What tier 1 could not prove within +-84 slots of the hint is far from the model (something the map does not
+  // hold yet).  One step of the walk below costs ~700 instructions (three ranked wave minima) and such a point
+  // needs several, while sweeping ALL slots costs ~400: sweep first, walk only if the sweep cannot rank.
+  if (nM <= (1 << 11)) {
+#ifdef TSD_ICP_STAMPS
+    if (lane == 0) atomicAdd(&L.ired[IR_DBG + 4], 1);
+#endif
+    NnResult r;
+    if (sweep_all(L, nM, x, y, lane, r)) return r;
+    // (three candidates in one 2048-ulp bucket, or a non-finite point: the exact walk sorts it out)
+  }
   for (;;) {
+#ifdef TSD_ICP_STAMPS
+    if (lane == 0) atomicAdd(&L.ired[IR_DBG + 3], 1);
+#endif
     const int o = w0 + lane;
     const bool act = lane < cnt;
     int k = start + o;
@@ -657,6 +715,9 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
         ent[q] = -1;
       }
     }
+    bool past_window[R];                       // the window was already tried in place and could not prove the point
+#pragma unroll
+    for (int q = 0; q < R; q++) past_window[q] = false;
     // A wave with only a few points to search resolves them on the spot (one lane-per-point window each):
     // no list, no barrier.  The dense work list pays off when many lanes of a wave would idle otherwise.
     {
@@ -689,7 +750,7 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
           }
         }
 #pragma unroll
-        for (int q = 0; q < R; q++) need[q] = tolist[q];
+        for (int q = 0; q < R; q++) { need[q] = tolist[q]; past_window[q] = tolist[q]; }
 #ifdef TSD_ICP_STAMPS
         if (lane == 0) atomicAdd(&L.ired[IR_DBG + 2], wneed);
 #endif
@@ -708,7 +769,7 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
       // work list of the points that need a search (an entry beyond the list capacity waits for its pass)
       if (need[q]) {
         ent[q] = atomicAdd(&L.ired[IR_CNT], 1);
-        if (ent[q] < lcap) { L.list_xy[ent[q]] = make_double2(sx[q], sy[q]); L.list_k[ent[q]] = hint[q]; }
+        if (ent[q] < lcap) { L.list_xy[ent[q]] = make_double2(sx[q], sy[q]); L.list_k[ent[q]] = hint[q] | (past_window[q] ? LIST_PAST_WINDOW : 0); }
       }
     }
     if (tie) L.ired[IR_TIE] = 1;
@@ -724,7 +785,7 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
           for (int q = 0; q < R; q++)
             if (need[q] && ent[q] >= base && ent[q] < base + lcap) {
               L.list_xy[ent[q] - base] = make_double2(sx[q], sy[q]);
-              L.list_k[ent[q] - base] = hint[q];
+              L.list_k[ent[q] - base] = hint[q] | (past_window[q] ? LIST_PAST_WINDOW : 0);
             }
           __syncthreads();
         }
@@ -732,7 +793,9 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
           const int e = e0 + lane;
           if (e < n) {
             const double2 s = L.list_xy[e];
-            const NnResult r = window_search(L, nM, s.x, s.y, L.list_k[e], thr, sgn);
+            const int lk = L.list_k[e];
+            NnResult r; r.resolved = false;
+            if (!(lk & LIST_PAST_WINDOW)) r = window_search(L, nM, s.x, s.y, lk, thr, sgn);
             if (r.resolved) { L.res_d[e] = r.best; L.res_k[e] = r.bk; L.res_k2[e] = r.bk2; L.res_lb[e] = lb_from_sq(r.lbsq); }
             else L.list2[atomicAdd(&L.ired[IR_CNT2], 1)] = e;      // tier 2, shared out over all waves below
           }
@@ -742,15 +805,21 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
 #ifdef TSD_ICP_STAMPS
         if (tid == 0) L.ired[IR_DBG + 1] += n2;
 #endif
+#ifdef TSD_ICP_STAMPS
+        const long long t2_begin = clock64();
+#endif
         if (n2 > 0) {
           for (int i = wave; i < n2; i += W) {
             const int es = L.list2[i];
             const double2 s = L.list_xy[es];
-            const NnResult r = wave_search(L, nM, s.x, s.y, L.list_k[es], thr, sgn, lane);
+            const NnResult r = wave_search(L, nM, s.x, s.y, L.list_k[es] & ~LIST_PAST_WINDOW, thr, sgn, lane);
             if (lane == 0) { L.res_d[es] = r.best; L.res_k[es] = r.bk; L.res_k2[es] = r.bk2; L.res_lb[es] = lb_from_sq(r.lbsq); }
           }
           __syncthreads();
           if (tid == 0) L.ired[IR_CNT2] = 0;
+#ifdef TSD_ICP_STAMPS
+          if (tid == 0) L.ired[IR_DBG + 5] += (int)((clock64() - t2_begin) >> 4);
+#endif
         }
 #pragma unroll
         for (int q = 0; q < R; q++)
@@ -928,6 +997,7 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
   __syncthreads();
   if (tid == 0) {
     st_acc[7] = L.ired[IR_DBG + 1];     // setup cycles / wave searches
+    printf("ICPDBG wave searches %d walk steps %d sweeps %d tier2 cycles %d inline pts %d\n", L.ired[IR_DBG + 1], L.ired[IR_DBG + 3], L.ired[IR_DBG + 4], L.ired[IR_DBG + 5] << 4, L.ired[IR_DBG + 2]);
     for (int i = 0; i < 8; i++) L.tail->trace[4 * TSD_ICP_TRACE_MAX - 8 + i] = (double)st_acc[i];
   }
 #endif
