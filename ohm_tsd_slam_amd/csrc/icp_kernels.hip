@@ -1060,14 +1060,17 @@ int launch_icp(tsd_ctx* ctx, const IcpArgs& a, const double* P_dev, const double
   if (n > TSD_MAX_ICP_POINTS) return set_error(ctx, TSD_E_CAPACITY, "icp points > TSD_MAX_ICP_POINTS", hipSuccess);
   const int cap = icp_cap_for(n);
   const int nthr = a.beams > 0 ? a.beams : a.n_scene;     // scene points decide the thread count
-  switch (ctx->icp_shape) {      // TSD_ICP_SHAPE: experiments only
-    case 2: return launch_icp_shape<2, 576>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post);
-    case 3: return launch_icp_shape<3, 512>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post, 512);
+  switch (ctx->icp_shape) {      // TSD_ICP_SHAPE: experiments only (a shape that cannot hold the points falls through)
+    case 2: if (nthr <= 2 * 576) return launch_icp_shape<2, 576>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post);
+            break;
+    case 3: if (nthr <= 3 * 512) return launch_icp_shape<3, 512>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post, 512);
+            break;
     // six waves: four share two SIMDs and hold two 64-point groups each, the two lone waves hold up to five
     // (evens out the issue load per SIMD, but five register slots spill: slower than the default as measured)
     case 7: if (nthr <= 64 * (ICP_RL * 6 + (5 - ICP_RL) * 2)) return launch_icp_shape<5, 512>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post, 384);
             break;
-    case 5: return launch_icp_shape<5, 256>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post);
+    case 5: if (nthr <= 5 * 256) return launch_icp_shape<5, 256>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post);
+            break;
     case 8: return launch_icp_shape<8, 256>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post);
     default: break;
   }
