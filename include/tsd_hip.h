@@ -59,8 +59,13 @@ typedef struct {
 } tsd_push_stats;
 
 /* Registration set-up as ThreadLocalize builds it (ThreadLocalize.cpp:211-225, 571-581) */
+/* estimator of Icp::step: the one the node constructs (ThreadLocalize.cpp:214) or the reference's other one */
+#define TSD_ESTIMATOR_CLOSED_FORM   0  /* ClosedFormEstimator2D (ClosedFormEstimator2D.cpp:36-109), point to point */
+#define TSD_ESTIMATOR_POINT_TO_LINE 1  /* PointToLine2DEstimator (PointToLineEstimator2D.cpp:52-157), needs model normals */
+
 typedef struct {
   int    iterations;            /* icp_iterations: Icp max iterations == convergence counter */
+  int    estimator;             /* TSD_ESTIMATOR_*; occupies what used to be padding: set it (0 = the node's choice) */
   double dist_filter_max;       /* DistanceFilter(maxdist, mindist, icp_iterations - 10) */
   double dist_filter_min;
   double min_x, max_x, min_y, max_y; /* OutOfBoundsFilter2D = TsdGrid::getMin/MaxX/Y */
@@ -68,7 +73,7 @@ typedef struct {
 
 typedef struct {
   double T[9];                  /* Icp::getFinalTransformation() 3x3 row-major */
-  double rms;                   /* ClosedFormEstimator2D "rms" = mean squared pair distance */
+  double rms;                   /* estimator's "rms": mean squared pair distance (closed form) or mean |n.(s - m)| (point to line) */
   int32_t pairs;                /* pairs of the last step */
   int32_t iterations;           /* steps executed */
   int32_t state;                /* EnumIcpState */
@@ -125,6 +130,11 @@ int tsd_raycast(tsd_ctx* ctx, const double pose33[9], const double* rays_world_2
  * sensor pose handed to OutOfBoundsFilter2D::setPose. */
 int tsd_icp(tsd_ctx* ctx, const double* model_xy, int n_model, const double* scene_xy, int n_scene,
             const double pose33[9], const tsd_icp_params* params, tsd_icp_result* result);
+/* The same with the model normals Icp::setModel(coords, normals) takes (Icp.cpp:150-203); required by
+ * TSD_ESTIMATOR_POINT_TO_LINE, ignored by the closed form.  tsd_localize / tsd_scan use the ray cast's normals. */
+int tsd_icp_normals(tsd_ctx* ctx, const double* model_xy, const double* model_normals_xy, int n_model,
+                    const double* scene_xy, int n_scene, const double pose33[9], const tsd_icp_params* params,
+                    tsd_icp_result* result);
 
 /* Fused body of ThreadLocalize::eventLoop between setStandardMask and isRegistrationError
  * (ThreadLocalize.cpp:353-377): ray cast -> dataToCartesianVectorMask -> maskMatrix compaction ->

@@ -46,6 +46,7 @@ class PushStats(C.Structure):
 class IcpParams(C.Structure):
     _fields_ = [
         ("iterations", C.c_int),
+        ("estimator", C.c_int),          # 0 ClosedFormEstimator2D (the node's), 1 PointToLine2DEstimator
         ("dist_filter_max", C.c_double),
         ("dist_filter_min", C.c_double),
         ("min_x", C.c_double),
@@ -105,6 +106,8 @@ ABI = {
     "tsd_raycast": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int, C.c_double, C.c_double, _dp, _dp, _u8p, _ip]),
     "tsd_icp": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, C.c_int, _dp, C.POINTER(IcpParams),
                           C.POINTER(IcpResult)]),
+    "tsd_icp_normals": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int, _dp, C.c_int, _dp, C.POINTER(IcpParams),
+                                  C.POINTER(IcpResult)]),
     "tsd_localize": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _u8p, C.c_int, C.c_double, C.c_double,
                                C.POINTER(IcpParams), C.POINTER(IcpResult)]),
     "tsd_sensor_create": (C.c_void_p, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]),
@@ -242,15 +245,21 @@ class TsdGridDevice:
         self._check(rc, "tsd_raycast")
         return coords, normals, mask, n.value
 
-    def icp_params(self, iterations, dist_max, dist_min) -> IcpParams:
-        return IcpParams(iterations, dist_max, dist_min, self.min_x, self.max_x, self.min_y, self.max_y)
+    def icp_params(self, iterations, dist_max, dist_min, estimator: int = 0) -> IcpParams:
+        return IcpParams(iterations, estimator, dist_max, dist_min, self.min_x, self.max_x, self.min_y, self.max_y)
 
-    def icp(self, model_xy, scene_xy, pose, params: IcpParams) -> IcpOut:
+    def icp(self, model_xy, scene_xy, pose, params: IcpParams, model_normals_xy=None) -> IcpOut:
         m = _f64(model_xy).reshape(-1)
         s = _f64(scene_xy).reshape(-1)
         pose = _f64(pose).reshape(9)
         r = IcpResult()
-        rc = self.lib.tsd_icp(self.h, _d(m), m.size // 2, _d(s), s.size // 2, _d(pose), C.byref(params), C.byref(r))
+        if model_normals_xy is None:
+            rc = self.lib.tsd_icp(self.h, _d(m), m.size // 2, _d(s), s.size // 2, _d(pose), C.byref(params), C.byref(r))
+        else:
+            nrm = _f64(model_normals_xy).reshape(-1)
+            assert nrm.size == m.size
+            rc = self.lib.tsd_icp_normals(self.h, _d(m), _d(nrm), m.size // 2, _d(s), s.size // 2, _d(pose),
+                                          C.byref(params), C.byref(r))
         self._check(rc, "tsd_icp")
         return IcpOut(np.array(r.T[:]).reshape(3, 3), r.rms, r.pairs, r.iterations, r.state)
 

@@ -136,7 +136,7 @@ static void fill_icp_args(IcpArgs& a, const double pose33[9], const tsd_icp_para
   a.multiplier = distance_filter_multiplier(p->dist_filter_max, p->dist_filter_min, p->iterations);
   a.iterations = p->iterations;
   a.n_model = a.n_scene = a.beams = 0;
-  a.ccw = 1; a.pad = 0;
+  a.ccw = 1; a.estimator = p->estimator;
 }
 
 static void fill_raycast_args(const tsd_ctx* ctx, RaycastArgs& a, const double pose33[9], int beams,
@@ -298,6 +298,7 @@ tsd_ctx* tsd_create(int device, int map_size_log2, double cell_size, double max_
   A(hipMalloc(&ctx->d_rays_local, 2 * TSD_MAX_BEAMS * sizeof(double)));
   A(hipMalloc(&ctx->d_coords, 2 * TSD_MAX_BEAMS * sizeof(double)));
   A(hipMalloc(&ctx->d_normals, 2 * TSD_MAX_BEAMS * sizeof(double)));
+  A(hipMalloc(&ctx->d_mnormals, 2 * TSD_MAX_ICP_POINTS * sizeof(double)));
   A(hipMalloc(&ctx->d_mask_m, TSD_MAX_BEAMS));
   A(hipMalloc(&ctx->d_model, 2 * TSD_MAX_ICP_POINTS * sizeof(double)));
   A(hipMalloc(&ctx->d_scene, 2 * TSD_MAX_ICP_POINTS * sizeof(double)));
@@ -335,7 +336,7 @@ void tsd_destroy(tsd_ctx* ctx)
     if (ctx->stage_ev[s]) hipEventDestroy(ctx->stage_ev[s]);
   }
   hipFree(ctx->d_ranges); hipFree(ctx->d_mask); hipFree(ctx->d_rays); hipFree(ctx->d_rays_local);
-  hipFree(ctx->d_coords); hipFree(ctx->d_normals); hipFree(ctx->d_mask_m); hipFree(ctx->d_model);
+  hipFree(ctx->d_coords); hipFree(ctx->d_normals); hipFree(ctx->d_mnormals); hipFree(ctx->d_mask_m); hipFree(ctx->d_model);
   hipFree(ctx->d_scene); hipFree(ctx->d_morig); hipFree(ctx->d_start); hipFree(ctx->d_icp_res); hipFree(ctx->d_icp_trace); hipHostFree(ctx->h_icp_res); hipHostFree(ctx->h_out);
   hipFree(ctx->d_occ); hipFree(ctx->d_occ_count);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -486,7 +487,18 @@ int tsd_raycast(tsd_ctx* ctx, const double pose33[9], const double* rays_world_2
 int tsd_icp(tsd_ctx* ctx, const double* model_xy, int n_model, const double* scene_xy, int n_scene,
             const double pose33[9], const tsd_icp_params* params, tsd_icp_result* result)
 {
+  return tsd_icp_normals(ctx, model_xy, nullptr, n_model, scene_xy, n_scene, pose33, params, result);
+}
+
+int tsd_icp_normals(tsd_ctx* ctx, const double* model_xy, const double* model_normals_xy, int n_model,
+                    const double* scene_xy, int n_scene, const double pose33[9], const tsd_icp_params* params,
+                    tsd_icp_result* result)
+{
   if (!ctx || !pose33 || !params || !result || n_model < 0 || n_scene < 0) return TSD_E_ARG;
+  if (params->estimator != TSD_ESTIMATOR_CLOSED_FORM && params->estimator != TSD_ESTIMATOR_POINT_TO_LINE)
+    return set_error(ctx, TSD_E_ARG, "tsd_icp_params.estimator", hipSuccess);
+  if (params->estimator == TSD_ESTIMATOR_POINT_TO_LINE && n_model > 0 && !model_normals_xy)
+    return set_error(ctx, TSD_E_ARG, "the point-to-line estimator needs the model normals (tsd_icp_normals)", hipSuccess);
   if ((n_model > 0 && !model_xy) || (n_scene > 0 && !scene_xy)) return TSD_E_ARG;
   if (n_model > TSD_MAX_ICP_POINTS || n_scene > TSD_MAX_ICP_POINTS)
     return set_error(ctx, TSD_E_CAPACITY, "icp points > TSD_MAX_ICP_POINTS", hipSuccess);
@@ -514,7 +526,8 @@ int tsd_icp(tsd_ctx* ctx, const double* model_xy, int n_model, const double* sce
   int s;
   char* h = stage_acquire(ctx, &s);
   const size_t mb = (size_t)n_model * 16, sb = (size_t)n_scene * 16, ob = (size_t)n_model * 4, tb = (size_t)n_scene * 4;
-  if (mb + sb + ob + tb > ctx->stage_bytes) return set_error(ctx, TSD_E_CAPACITY, "icp staging", hipSuccess);
+  const size_t nb = (params->estimator == TSD_ESTIMATOR_POINT_TO_LINE) ? mb : 0;
+  if (mb + sb + ob + tb + nb > ctx->stage_bytes) return set_error(ctx, TSD_E_CAPACITY, "icp staging", hipSuccess);
   double* hm = reinterpret_cast<double*>(h);
   for (int k = 0; k < n_model; k++) { const int j = order[(size_t)k]; hm[2 * k] = model_xy[2 * j]; hm[2 * k + 1] = model_xy[2 * j + 1]; }
   if (sb) std::memcpy(h + mb, scene_xy, sb);
@@ -524,6 +537,12 @@ int tsd_icp(tsd_ctx* ctx, const double* model_xy, int n_model, const double* sce
   if (sb) TSD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_scene, h + mb, sb, hipMemcpyHostToDevice, ctx->stream));
   if (ob) TSD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_morig, h + mb + sb, ob, hipMemcpyHostToDevice, ctx->stream));
   if (tb) TSD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_start, h + mb + sb + ob, tb, hipMemcpyHostToDevice, ctx->stream));
+  if (nb) {
+    double* hn = reinterpret_cast<double*>(h + mb + sb + ob + ((tb + 7) & ~(size_t)7));
+    if (mb + sb + ob + ((tb + 7) & ~(size_t)7) + nb > ctx->stage_bytes) return set_error(ctx, TSD_E_CAPACITY, "icp staging", hipSuccess);
+    for (int k = 0; k < n_model; k++) { const int j = order[(size_t)k]; hn[2 * k] = model_normals_xy[2 * j]; hn[2 * k + 1] = model_normals_xy[2 * j + 1]; }
+    TSD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_mnormals, hn, nb, hipMemcpyHostToDevice, ctx->stream));
+  }
   TSD_HIP_CHECK(ctx, hipEventRecord(ctx->stage_ev[s], ctx->stream));
   int rc = launch_icp(ctx, a);
   if (rc != TSD_OK) return rc;

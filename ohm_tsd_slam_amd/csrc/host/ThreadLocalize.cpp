@@ -89,6 +89,10 @@ ThreadLocalize::ThreadLocalize(obvious::TsdGrid* grid, ThreadMapping* mapper, co
   // ICP set-up (ThreadLocalize.cpp:211-225): DistanceFilter(max, min, icpIterations - 10), bounds filter
   // over the grid extent, maxRMS 0, max iterations == convergence counter == icpIterations
   _icpParams.iterations      = icpIterations;
+  // The node constructs ClosedFormEstimator2D (ThreadLocalize.cpp:214); "icp_estimator" = 1 selects the reference's
+  // other estimator, PointToLine2DEstimator, on the ray cast's normals (an addition: the reference has no such key)
+  _icpParams.estimator       = (int)param(node, _robotName + "icp_estimator", 0).as_int() == 1
+                                   ? TSD_ESTIMATOR_POINT_TO_LINE : TSD_ESTIMATOR_CLOSED_FORM;
   _icpParams.dist_filter_max = distFilterMax;
   _icpParams.dist_filter_min = distFilterMin;
   _icpParams.min_x = grid->getMinX();

@@ -61,6 +61,7 @@ struct IcpLds {
   IcpTail* tail;
   double2* mxy;                    // model (angular order)
   double2* uxy;                    // unit direction of every model point (0,0 for a point at the origin)
+  double2* nxy;                    // model normals (point-to-line estimator only; nullptr otherwise)
   unsigned long long* slotD;       // [cap] reciprocal filter: min d2 (bit pattern) per model slot
   int* slotI;                      // [cap] winning scene index per model slot
   int* morig;                      // original model index of a slot (tie-breaking)
@@ -85,16 +86,16 @@ __host__ __device__ inline int icp_list_cap(int cap) { return cap < 1024 ? cap :
 __host__ __device__ inline size_t icp_region_bytes(int cap, int threads)
 {
   size_t b = 48u * (size_t)icp_list_cap(cap);
-  const size_t tr = (size_t)threads * 9u * sizeof(double);
+  const size_t tr = (size_t)threads * 11u * sizeof(double);      // nsum_pitch(NSUM_PTL): the wider of the two
   if (tr > b) b = tr;
   return (b + 15u) & ~(size_t)15u;
 }
-__host__ __device__ inline size_t icp_lds_bytes_for(int cap, int threads)
+__host__ __device__ inline size_t icp_lds_bytes_for(int cap, int threads, bool normals = false)
 {
   // the staging (cap double2 + cap int) aliases the list + result arrays: 40 * lc >= 20 * cap
   return sizeof(double2) * 2 * (size_t)cap + sizeof(double2) * 2 * ICP_PAD + sizeof(unsigned long long) * (size_t)cap + sizeof(int) * 2 * (size_t)cap +
          icp_region_bytes(cap, threads) + sizeof(double) * (2 * ICP_MAXW * 16 + 16) + ((sizeof(IcpTail) + 15) & ~(size_t)15) +
-         sizeof(int) * 64 + 64;
+         sizeof(int) * 64 + 64 + (normals ? sizeof(double2) * (size_t)cap : 0);
 }
 
 // a wave-uniform value the compiler must keep in a vector register
@@ -390,17 +391,21 @@ __device__ __forceinline__ NnResult wave_search(const IcpLds& L, int nM, double 
 }
 
 
-constexpr int NSUM = 9;      // pair sums of one step: sum mx, my, sx, sy, d2 and the four centred products
-constexpr int NSUMP = 9;     // row pitch of the transpose buffer (doubles); odd => conflict-free columns
+// pair sums of one step.  Closed form: sum mx, my, sx, sy, d2 and the four centred products (9); point to line:
+// the six entries of A, the three of b, sum |n.(s - m)| (10).  The row pitch of the transpose buffer is the
+// next odd number (conflict-free columns).
+constexpr int NSUM_CF = 9, NSUM_PTL = 10;
+__host__ __device__ constexpr int nsum_pitch(int ns) { return ns | 1; }
 
 // Sums over the whole workgroup of NSUM doubles per thread (+ one wave-uniform integer per wave).
 // Every lane writes its row into an LDS transpose buffer; lane l of a wave then adds 16 rows of column
 // l/4 (4 lanes per column), two DPP shifts finish the column, the wave partials meet in LDS.  ~80
 // instructions for nine values where nine shuffle trees cost ~200; fixed order => deterministic.
-template <int MAXW>
+template <int MAXW, int NSUM>
 __device__ __forceinline__ void block_totals(const IcpLds& L, const double (&v)[NSUM], int cnt, double (&tot)[NSUM],
                                              int& cnt_total, int tid, int lane, int wave, int W)
 {
+  constexpr int NSUMP = nsum_pitch(NSUM);
   double* row = L.tr + (size_t)tid * NSUMP;
 #pragma unroll
   for (int k = 0; k < NSUM; k++) row[k] = v[k];
@@ -434,14 +439,15 @@ __device__ __forceinline__ void block_totals(const IcpLds& L, const double (&v)[
   cnt_total = (int)bc[NSUM];
 }
 
-template <int R, int MAXT>
+template <int R, int MAXT, bool PTL>
 __global__ void __launch_bounds__(MAXT)
 k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __restrict__ g_model, const double* __restrict__ g_scene,
       const int* __restrict__ g_morig, const int* __restrict__ g_start,
       const double* __restrict__ g_coords, const uint8_t* __restrict__ g_mask_m,
       const double* __restrict__ g_rays_local, const double* __restrict__ g_ranges,
       const uint8_t* __restrict__ g_mask, IcpResultDev* __restrict__ out,
-      double* __restrict__ trace /* [TSD_ICP_TRACE_MAX][4] = pairs, rms, thr_before, state */, ScanPostArgs post)
+      double* __restrict__ trace /* [TSD_ICP_TRACE_MAX][4] = pairs, rms, thr_before, state */, ScanPostArgs post,
+      const double* __restrict__ g_mnormals /* direct mode */, const double* __restrict__ g_normals /* fused: ray cast */)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   IcpLds L;
@@ -468,7 +474,9 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
     L.tr = reinterpret_cast<double*>(L.list_xy);     // T * 72 B <= 40 * lcap B (checked by the launcher)
     L.slotI = reinterpret_cast<int*>(p); p += sizeof(int) * (size_t)cap;
     L.morig = reinterpret_cast<int*>(p); p += sizeof(int) * (size_t)cap;
-    L.ired = reinterpret_cast<int*>(p);
+    L.ired = reinterpret_cast<int*>(p); p += sizeof(int) * 64;
+    p = reinterpret_cast<char*>(((uintptr_t)p + 15) & ~(uintptr_t)15);
+    L.nxy = PTL ? reinterpret_cast<double2*>(p) : nullptr;
   }
 
   if (P_dev) {   // fused scan: the pre-registration sensor pose lives on the device
@@ -501,7 +509,7 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
     // instead of one per dependent step); the launcher guarantees beams <= R * T.
     bool fm[R], fs[R];
     double rr[R], lx[R], ly[R];
-    double2 cm[R];
+    double2 cm[R], nn[R];
 #pragma unroll
     for (int q = 0; q < R; q++) {
       const int b = q * T + tid;
@@ -510,6 +518,7 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
       rr[q] = g_ranges[bc];
       cm[q] = *reinterpret_cast<const double2*>(g_coords + 2 * (size_t)bc);
       lx[q] = g_rays_local[bc]; ly[q] = g_rays_local[a.beams + bc];
+      nn[q] = L.nxy ? *reinterpret_cast<const double2*>(g_normals + 2 * (size_t)bc) : make_double2(0.0, 0.0);
       fm[q] = (b < a.beams) && mm != 0;
       fs[q] = (b < a.beams) && !isinf(rr[q]) && ms != 0;
     }
@@ -534,7 +543,7 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
         runM += c_m; runS += c_s;
       }
       offM += __popcll(bm[q] & lt); offS += __popcll(bs[q] & lt);
-      if (fm[q] && offM < cap) { L.mxy[offM] = cm[q]; L.morig[offM] = offM; }
+      if (fm[q] && offM < cap) { L.mxy[offM] = cm[q]; L.morig[offM] = offM; if (L.nxy) L.nxy[offM] = nn[q]; }
       if (fs[q] && offS < cap) {
         // coords = raysLocal(j,i) * data[i] (Sensor.cpp:176-179)
         L.stage_s[offS] = make_double2(lx[q] * rr[q], ly[q] * rr[q]);
@@ -549,6 +558,7 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
     nM = a.n_model; nS = a.n_scene;
     if (nM <= cap && nS <= cap) {
       for (int j = tid; j < nM; j += T) { L.mxy[j] = make_double2(g_model[2 * j], g_model[2 * j + 1]); L.morig[j] = g_morig[j]; }
+      if (L.nxy) for (int j = tid; j < nM; j += T) L.nxy[j] = make_double2(g_mnormals[2 * j], g_mnormals[2 * j + 1]);
       for (int i = tid; i < nS; i += T) { L.stage_s[i] = make_double2(g_scene[2 * i], g_scene[2 * i + 1]); L.start[i] = g_start[i]; }
     }
     __syncthreads();
@@ -884,24 +894,47 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
     // step's centroids c0 instead and correcting, sum (a-ca)(b-cb) = sum (a-c0a)(b-c0b) - n (ca-c0a)(cb-c0b),
     // is the same quantity with the same conditioning (c0 is within millimetres of c); the very first
     // step has no c0 and runs the pass twice, i.e. the reference's two passes.
+    constexpr int NSUM = PTL ? NSUM_PTL : NSUM_CF;
+    constexpr bool ptl = PTL;                           // PointToLine2DEstimator instead of ClosedFormEstimator2D
     double tot[NSUM];
-    for (int pass = (iter == 0 ? 0 : 1); pass < 2; pass++) {
+    for (int pass = ((iter == 0 && !ptl) ? 0 : 1); pass < 2; pass++) {
       double v[NSUM];
 #pragma unroll
       for (int k = 0; k < NSUM; k++) v[k] = 0.0;
+      if constexpr (!PTL) {
 #pragma unroll
-      for (int q = 0; q < R; q++) {
-        if (win[q]) {
-          const double2 m = mw[q];
-          v[0] += m.x; v[1] += m.y; v[2] += sx[q]; v[3] += sy[q];
-          const double dx = sx[q] - m.x, dy = sy[q] - m.y;
-          v[4] += dx * dx + dy * dy;
-          const double xF = m.x - c0[0], yF = m.y - c0[1], xS = sx[q] - c0[2], yS = sy[q] - c0[3];
-          v[5] += yF * xS; v[6] += xF * yS; v[7] += xF * xS; v[8] += yF * yS;
+        for (int q = 0; q < R; q++) {
+          if (win[q]) {
+            const double2 m = mw[q];
+            v[0] += m.x; v[1] += m.y; v[2] += sx[q]; v[3] += sy[q];
+            const double dx = sx[q] - m.x, dy = sy[q] - m.y;
+            v[4] += dx * dx + dy * dy;
+            const double xF = m.x - c0[0], yF = m.y - c0[1], xS = sx[q] - c0[2], yS = sy[q] - c0[3];
+            v[5] += yF * xS; v[6] += xF * yS; v[7] += xF * xS; v[8] += yF * yS;
+          }
+        }
+      } else {
+        // PointToLine2DEstimator::setPairs + estimateTransformation (PointToLineEstimator2D.cpp:52-132): per pair
+        // a_z = p_x n_y - p_y n_x, A += (a_z, n_x, n_y)(a_z, n_x, n_y)^T, b -= (a_z, n_x, n_y) ((p - q).n),
+        // "rms" += |(p - q).n|, with p the scene point, q the model point, n the model normal
+        double2 nw[R];
+#pragma unroll
+        for (int q = 0; q < R; q++) nw[q] = L.nxy[hint[q]];
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+          if (win[q]) {
+            const double2 m = mw[q], n = nw[q];
+            const double az = sx[q] * n.y - sy[q] * n.x;
+            const double tmp = (sx[q] - m.x) * n.x + (sy[q] - m.y) * n.y;
+            v[0] += az * az; v[1] += az * n.x; v[2] += az * n.y;
+            v[3] += n.x * n.x; v[4] += n.x * n.y; v[5] += n.y * n.y;
+            v[6] -= az * tmp; v[7] -= n.x * tmp; v[8] -= n.y * tmp;
+            v[NSUM - 1] += fabs(tmp);
+          }
         }
       }
       STAMP(3);
-      block_totals<MAXT / 64>(L, v, cnt, tot, pairs, tid, lane, wave, W);
+      block_totals<MAXT / 64, NSUM>(L, v, cnt, tot, pairs, tid, lane, wave, W);
       STAMP(4);
       if (pass == 0) {                     // first step only: centroids first, then the centred pass
         if (pairs > 0) {
@@ -919,29 +952,40 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
     STAMP(3);
 
     if (pairs > 2) {
-      const double np = (double)pairs;
-      const double size_inv = 1.0 / np;
-      rms = tot[4] * size_inv;
-      const double cmx = tot[0] * size_inv, cmy = tot[1] * size_inv, csx = tot[2] * size_inv, csy = tot[3] * size_inv;
-      const double emx = cmx - c0[0], emy = cmy - c0[1], esx = csx - c0[2], esy = csy - c0[3];
-      const double nom = (tot[5] - np * (emy * esx)) - (tot[6] - np * (emx * esy));
-      const double den = (tot[7] - np * (emx * esx)) + (tot[8] - np * (emy * esy));
-      c0[0] = cmx; c0[1] = cmy; c0[2] = csx; c0[3] = csy;
-      // every wave evaluates the closed form itself (wave-uniform inputs): no broadcast barrier
-      double co, si;
+      double co, si, dX, dY;
+      if constexpr (PTL) {
+        // PointToLine2DEstimator: Matrix::solve = gsl_linalg_LU_decomp + LU_solve (gsl/Matrix.cpp:343-355);
+        // psi = x[0] (cos, sin by libm like the reference), t = (x[1], x[2]); "rms" = mean |n.(p - q)|
+        rms = tot[NSUM - 1] / (double)pairs;
+        const double A[9] = {tot[0], tot[1], tot[2], tot[1], tot[3], tot[4], tot[2], tot[4], tot[5]};
+        const double bb[3] = {tot[6], tot[7], tot[8]};
+        double xs[3];
+        d_lu3_solve(A, bb, xs);
+        co = cos(xs[0]); si = sin(xs[0]); dX = xs[1]; dY = xs[2];
+      } else {
+        const double np = (double)pairs;
+        const double size_inv = 1.0 / np;
+        rms = tot[4] * size_inv;
+        const double cmx = tot[0] * size_inv, cmy = tot[1] * size_inv, csx = tot[2] * size_inv, csy = tot[3] * size_inv;
+        const double emx = cmx - c0[0], emy = cmy - c0[1], esx = csx - c0[2], esy = csy - c0[3];
+        const double nom = (tot[5] - np * (emy * esx)) - (tot[6] - np * (emx * esy));
+        const double den = (tot[7] - np * (emx * esx)) + (tot[8] - np * (emy * esy));
+        c0[0] = cmx; c0[1] = cmy; c0[2] = csx; c0[3] = csy;
+        // every wave evaluates the closed form itself (wave-uniform inputs): no broadcast barrier
 #ifdef TSD_ICP_EXACT_TRIG
-      { const double th_ = atan2(nom, den); co = cos(th_); si = sin(th_); }
+        { const double th_ = atan2(nom, den); co = cos(th_); si = sin(th_); }
 #else
-      // cos(atan2(n, d)) = d / hypot, sin = n / hypot: same angle without three libm calls; differs
-      // from the reference's atan2 -> cos/sin by rounding only (DESIGN.md "ICP", tolerance 1e-4)
-      {
-        const double h2 = nom * nom + den * den;
-        if (h2 > 0.0) { const double inv = rsqrt(h2); co = den * inv; si = nom * inv; }
-        else { co = signbit(den) ? -1.0 : 1.0; si = 0.0; }
-      }
+        // cos(atan2(n, d)) = d / hypot, sin = n / hypot: same angle without three libm calls; differs
+        // from the reference's atan2 -> cos/sin by rounding only (DESIGN.md "ICP", tolerance 1e-4)
+        {
+          const double h2 = nom * nom + den * den;
+          if (h2 > 0.0) { const double inv = rsqrt(h2); co = den * inv; si = nom * inv; }
+          else { co = signbit(den) ? -1.0 : 1.0; si = 0.0; }
+        }
 #endif
-      const double dX = (cmx - (co * csx - si * csy));
-      const double dY = (cmy - (co * csy + si * csx));
+        dX = (cmx - (co * csx - si * csy));
+        dY = (cmy - (co * csy + si * csx));
+      }
       STAMP(4);
       // applyTransformation(sceneTmp): data * R^T (dgemm NoTrans,Trans), then + t (Icp.cpp:371-408).
       // The distance each point moves (rounded up, fp32 is plenty for a bound) eats into its neighbour
@@ -1025,8 +1069,8 @@ static int icp_cap_for(int n)
 
 // workgroup shape: R scene points per thread, T threads.  One CU runs the whole registration and is
 // issue bound, so few waves (per-wave reduction / control cost paid once per SIMD) win.
-template <int R, int MAXT>
-static int launch_icp_shape(tsd_ctx* ctx, const IcpArgs& a, int n, int cap, const double* P_dev,
+template <int R, int MAXT, bool PTL>
+static int launch_icp_shape_est(tsd_ctx* ctx, const IcpArgs& a, int n, int cap, const double* P_dev,
                             const double* d_rays_local, const double* d_ranges, const uint8_t* d_mask,
                             const ScanPostArgs& post, int force_T = 0)
 {
@@ -1034,20 +1078,33 @@ static int launch_icp_shape(tsd_ctx* ctx, const IcpArgs& a, int n, int cap, cons
   if (T < 64) T = 64;
   if (force_T > T) T = force_T;
   if (T > MAXT) return set_error(ctx, TSD_E_CAPACITY, "icp workgroup shape", hipSuccess);
-  const size_t lds = icp_lds_bytes_for(cap, T);
+  const bool ptl = a.estimator == TSD_ESTIMATOR_POINT_TO_LINE;
+  const size_t lds = icp_lds_bytes_for(cap, T, ptl);
+  if (lds > 160u * 1024u) return set_error(ctx, TSD_E_CAPACITY, "registration does not fit the LDS of one CU (point-to-line: model normals too)", hipSuccess);
   static size_t configured = 0;
   if (lds > configured) {
-    TSD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_icp<R, MAXT>),
+    TSD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_icp<R, MAXT, PTL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     configured = lds;
   }
   ScopedKernelTimer t(ctx, "icp");
-  hipExtLaunchKernelGGL((k_icp<R, MAXT>), dim3(1), dim3(T), lds, ctx->stream, t.a, t.b, 0, a, P_dev, cap, ctx->d_model, ctx->d_scene,
+  hipExtLaunchKernelGGL((k_icp<R, MAXT, PTL>), dim3(1), dim3(T), lds, ctx->stream, t.a, t.b, 0, a, P_dev, cap, ctx->d_model, ctx->d_scene,
                      ctx->d_morig, ctx->d_start, ctx->d_coords, ctx->d_mask_m,
                      d_rays_local ? d_rays_local : ctx->d_rays_local, d_ranges ? d_ranges : ctx->d_ranges,
-                     d_mask ? d_mask : ctx->d_mask, ctx->d_icp_res, ctx->d_icp_trace, post);
+                     d_mask ? d_mask : ctx->d_mask, ctx->d_icp_res, ctx->d_icp_trace, post, ctx->d_mnormals, ctx->d_normals);
   TSD_HIP_CHECK(ctx, hipGetLastError());
   return TSD_OK;
+}
+
+template <int R, int MAXT>
+static int launch_icp_shape(tsd_ctx* ctx, const IcpArgs& a, int n, int cap, const double* P_dev,
+                            const double* d_rays_local, const double* d_ranges, const uint8_t* d_mask,
+                            const ScanPostArgs& post, int force_T = 0)
+{
+  // the estimator is a compile-time choice: the node's closed form does not pay for the other one's tenth sum
+  if (a.estimator == TSD_ESTIMATOR_POINT_TO_LINE)
+    return launch_icp_shape_est<R, MAXT, true>(ctx, a, n, cap, P_dev, d_rays_local, d_ranges, d_mask, post, force_T);
+  return launch_icp_shape_est<R, MAXT, false>(ctx, a, n, cap, P_dev, d_rays_local, d_ranges, d_mask, post, force_T);
 }
 
 int launch_icp(tsd_ctx* ctx, const IcpArgs& a, const double* P_dev, const double* d_rays_local,
@@ -1056,6 +1113,8 @@ int launch_icp(tsd_ctx* ctx, const IcpArgs& a, const double* P_dev, const double
   ScanPostArgs post;
   std::memset(&post, 0, sizeof(post));
   if (post_in) post = *post_in;
+  if (a.estimator != TSD_ESTIMATOR_CLOSED_FORM && a.estimator != TSD_ESTIMATOR_POINT_TO_LINE)
+    return set_error(ctx, TSD_E_ARG, "tsd_icp_params.estimator", hipSuccess);
   const int n = a.beams > 0 ? a.beams : (a.n_model > a.n_scene ? a.n_model : a.n_scene);
   if (n > TSD_MAX_ICP_POINTS) return set_error(ctx, TSD_E_CAPACITY, "icp points > TSD_MAX_ICP_POINTS", hipSuccess);
   const int cap = icp_cap_for(n);

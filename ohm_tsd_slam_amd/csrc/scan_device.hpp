@@ -57,6 +57,36 @@ __device__ inline void d_mat3_inv(const double A[9], double Ainv[9])
   }
 }
 
+// obvious::Matrix::solve (gsl/Matrix.cpp:343-355): gsl_linalg_LU_decomp (partial pivoting, first maximum) then
+// gsl_linalg_LU_solve (x = P b, unit-lower forward substitution, upper back substitution); 3 x 3
+__device__ inline void d_lu3_solve(const double A[9], const double b[3], double x[3])
+{
+  double lu[9];
+  int perm[3] = {0, 1, 2};
+  for (int i = 0; i < 9; i++) lu[i] = A[i];
+  for (int j = 0; j < 3; j++) {
+    int piv = j;
+    double best = fabs(lu[3 * j + j]);
+    for (int i = j + 1; i < 3; i++)
+      if (fabs(lu[3 * i + j]) > best) { best = fabs(lu[3 * i + j]); piv = i; }
+    if (piv != j) {
+      for (int k = 0; k < 3; k++) { const double t = lu[3 * j + k]; lu[3 * j + k] = lu[3 * piv + k]; lu[3 * piv + k] = t; }
+      const int t = perm[j]; perm[j] = perm[piv]; perm[piv] = t;
+    }
+    for (int i = j + 1; i < 3; i++) {
+      lu[3 * i + j] = lu[3 * i + j] / lu[3 * j + j];
+      for (int k = j + 1; k < 3; k++) lu[3 * i + k] -= lu[3 * i + j] * lu[3 * j + k];
+    }
+  }
+  for (int i = 0; i < 3; i++) x[i] = b[perm[i]];
+  for (int i = 1; i < 3; i++)
+    for (int k = 0; k < i; k++) x[i] -= lu[3 * i + k] * x[k];
+  for (int i = 2; i >= 0; i--) {
+    for (int k = i + 1; k < 3; k++) x[i] -= lu[3 * i + k] * x[k];
+    x[i] = x[i] / lu[3 * i + i];
+  }
+}
+
 // ThreadLocalize::calcAngle (ThreadLocalize.cpp:715-726)
 __device__ __forceinline__ double d_calc_angle(const double T[9])
 {

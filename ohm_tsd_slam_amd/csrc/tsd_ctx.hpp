@@ -39,7 +39,7 @@ struct IcpArgs {
   int n_model, n_scene;      // direct mode
   int beams;                 // fused mode (compaction from per-beam arrays) when > 0
   int ccw;                   // model slots ascend counter-clockwise about the sensor (1) or clockwise (0)
-  int pad;
+  int estimator;             // TSD_ESTIMATOR_*
 };
 
 struct IcpResultDev {
@@ -141,6 +141,7 @@ struct tsd_ctx {
   double* d_rays_local = nullptr;// [2*TSD_MAX_BEAMS]
   double* d_coords = nullptr;    // [2*TSD_MAX_BEAMS]
   double* d_normals = nullptr;   // [2*TSD_MAX_BEAMS]
+  double* d_mnormals = nullptr;  // [2*TSD_MAX_ICP_POINTS] model normals of tsd_icp_normals, in the model's slot order
   uint8_t* d_mask_m = nullptr;   // [TSD_MAX_BEAMS]
   double* d_model = nullptr;     // [2*TSD_MAX_ICP_POINTS]
   double* d_scene = nullptr;     // [2*TSD_MAX_ICP_POINTS]

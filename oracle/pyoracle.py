@@ -110,6 +110,8 @@ def lib():
         L.ora_raycast.restype = C.c_int
         L.ora_interpolate_bilinear.argtypes = [C.c_void_p, C.c_double, C.c_double, _dp]
         L.ora_icp.argtypes = [_dp, C.c_int, _dp, C.c_int, _dp, C.POINTER(IcpParams), C.POINTER(IcpResult), _dp]
+        L.ora_icp_point_to_line.argtypes = [_dp, _dp, C.c_int, _dp, C.c_int, _dp, C.POINTER(IcpParams), C.POINTER(IcpResult), _dp]
+        L.ora_icp_point_to_line.restype = None
         L.ora_icp_pairs.argtypes = [_dp, C.c_int, _dp, C.c_int, _dp, C.POINTER(IcpParams), _dp, _ip, _ip]
         L.ora_icp_pairs.restype = C.c_int
         L.ora_distance_filter_multiplier.argtypes = [C.c_double, C.c_double, C.c_int]
@@ -318,13 +320,20 @@ def mat3_mul(A, B):
     return out.reshape(3, 3)
 
 
-def icp(model_xy, scene_xy, pose, iterations, dist_max, dist_min, bounds, nn_mode=0, trace=False):
+def icp(model_xy, scene_xy, pose, iterations, dist_max, dist_min, bounds, nn_mode=0, trace=False, model_normals_xy=None):
+    """model_normals_xy given: PointToLine2DEstimator instead of the node's ClosedFormEstimator2D."""
     m, s = f64(model_xy).reshape(-1), f64(scene_xy).reshape(-1)
     pose = f64(pose).reshape(9)
     p = IcpParams(iterations, dist_max, dist_min, bounds[0], bounds[1], bounds[2], bounds[3], nn_mode)
     r = IcpResult()
     tr = np.zeros((max(iterations, 1), 4)) if trace else None
-    lib().ora_icp(d(m), m.size // 2, d(s), s.size // 2, d(pose), C.byref(p), C.byref(r), d(tr) if trace else None)
+    if model_normals_xy is None:
+        lib().ora_icp(d(m), m.size // 2, d(s), s.size // 2, d(pose), C.byref(p), C.byref(r), d(tr) if trace else None)
+    else:
+        nrm = f64(model_normals_xy).reshape(-1)
+        assert nrm.size == m.size
+        lib().ora_icp_point_to_line(d(m), d(nrm), m.size // 2, d(s), s.size // 2, d(pose), C.byref(p), C.byref(r),
+                                    d(tr) if trace else None)
     out = {"T": np.array(r.T[:]).reshape(3, 3), "rms": r.rms, "pairs": r.pairs, "iterations": r.iterations,
            "state": r.state}
     if trace:

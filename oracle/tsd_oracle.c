@@ -911,10 +911,41 @@ int ora_icp_pairs(const double* model, int n_model, const double* scene, int n_s
   return n;
 }
 
-/* Icp::iterate (Icp.cpp:464-512) driving Icp::step (:410-462) with ClosedFormEstimator2D
- * (ClosedFormEstimator2D.cpp:36-109), Tinit = identity (registration_mode 0). */
-void ora_icp(const double* model, int n_model, const double* scene_in, int n_scene,
-             const double pose[9], const ora_icp_params* p, ora_icp_result* out, double* trace)
+/* obvious::Matrix::solve (gsl/Matrix.cpp:343-355): gsl_linalg_LU_decomp (partial pivoting, first maximum) +
+ * gsl_linalg_LU_solve (x = P b, unit-lower forward substitution, upper back substitution); 3 x 3 */
+static void lu3_solve(const double A[9], const double b[3], double x[3])
+{
+  double lu[9];
+  int perm[3] = {0, 1, 2};
+  memcpy(lu, A, sizeof(lu));
+  for (int j = 0; j < 3; j++) {
+    int piv = j;
+    double best = fabs(lu[3 * j + j]);
+    for (int i = j + 1; i < 3; i++)
+      if (fabs(lu[3 * i + j]) > best) { best = fabs(lu[3 * i + j]); piv = i; }
+    if (piv != j) {
+      for (int k = 0; k < 3; k++) { double t = lu[3 * j + k]; lu[3 * j + k] = lu[3 * piv + k]; lu[3 * piv + k] = t; }
+      int t = perm[j]; perm[j] = perm[piv]; perm[piv] = t;
+    }
+    for (int i = j + 1; i < 3; i++) {
+      lu[3 * i + j] = lu[3 * i + j] / lu[3 * j + j];
+      for (int k = j + 1; k < 3; k++) lu[3 * i + k] -= lu[3 * i + j] * lu[3 * j + k];
+    }
+  }
+  for (int i = 0; i < 3; i++) x[i] = b[perm[i]];
+  for (int i = 1; i < 3; i++)
+    for (int k = 0; k < i; k++) x[i] -= lu[3 * i + k] * x[k];
+  for (int i = 2; i >= 0; i--) {
+    for (int k = i + 1; k < 3; k++) x[i] -= lu[3 * i + k] * x[k];
+    x[i] = x[i] / lu[3 * i + i];
+  }
+}
+
+/* Icp::iterate (Icp.cpp:464-512) driving Icp::step (:410-462), Tinit = identity (registration_mode 0), with
+ * ClosedFormEstimator2D (ClosedFormEstimator2D.cpp:36-109) when `normals` is NULL -- what the node constructs
+ * (ThreadLocalize.cpp:214) -- or PointToLine2DEstimator (PointToLineEstimator2D.cpp:52-157) on the model normals. */
+static void icp_impl(const double* model, const double* normals, int n_model, const double* scene_in, int n_scene,
+                     const double pose[9], const ora_icp_params* p, ora_icp_result* out, double* trace)
 {
   enum { PROCESSING = 1, NOTMATCHABLE = 2, MAXITERATIONS = 3, SUCCESS = 5 };
   double Tf[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};   /* _Tfinal4x4->setIdentity() */
@@ -945,6 +976,36 @@ void ora_icp(const double* model, int n_model, const double* scene_in, int n_sce
     /* ---- step ---- */
     pairs = determine_pairs(&c, sc, n_scene);
     if (pairs > 2) {
+      double co, si, dX, dY;
+      if (normals) {
+        /* PointToLine2DEstimator::setPairs: rms = mean |(scene - model) . normal| (:52-77) */
+        rms = 0.0;
+        for (int i = 0; i < pairs; i++) {
+          const double* pm = model + 2 * c.pm[i];
+          const double* ps = sc + 2 * c.ps[i];
+          const double* pn = normals + 2 * c.pm[i];
+          double v0 = ps[0] - pm[0], v1 = ps[1] - pm[1];
+          rms += fabs(v0 * pn[0] + v1 * pn[1]);
+        }
+        rms /= (double)pairs;
+        /* estimateTransformation (:89-157): 3x3 normal equations over (a_z, n_x, n_y), LU solve */
+        double A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+        for (int i = 0; i < pairs; i++) {
+          const double* q = model + 2 * c.pm[i];
+          const double* pp = sc + 2 * c.ps[i];
+          const double* n = normals + 2 * c.pm[i];
+          const double az = pp[0] * n[1] - pp[1] * n[0];
+          A[0] += az * az;   A[1] += az * n[0];   A[2] += az * n[1];
+          A[3] += az * n[0]; A[4] += n[0] * n[0]; A[5] += n[0] * n[1];
+          A[6] += az * n[1]; A[7] += n[1] * n[0]; A[8] += n[1] * n[1];
+          const double pq0 = pp[0] - q[0], pq1 = pp[1] - q[1];
+          const double tmp = pq0 * n[0] + pq1 * n[1];
+          b[0] -= az * tmp; b[1] -= n[0] * tmp; b[2] -= n[1] * tmp;
+        }
+        double x[3];
+        lu3_solve(A, b, x);
+        co = cos(x[0]); si = sin(x[0]); dX = x[1]; dY = x[2];
+      } else {
       /* ClosedFormEstimator2D::setPairs */
       double cm[2] = {0, 0}, cs_[2] = {0, 0};
       rms = 0.0;
@@ -966,9 +1027,10 @@ void ora_icp(const double* model, int n_model, const double* scene_in, int n_sce
         den += xF * xS + yF * yS;
       }
       const double th = atan2(nom, den);
-      const double co = cos(th), si = sin(th);
-      const double dX = (cm[0] - (co * cs_[0] - si * cs_[1]));
-      const double dY = (cm[1] - (co * cs_[1] + si * cs_[0]));
+      co = cos(th); si = sin(th);
+      dX = (cm[0] - (co * cs_[0] - si * cs_[1]));
+      dY = (cm[1] - (co * cs_[1] + si * cs_[0]));
+      }
       double Tl[16] = {co, -si, 0, dX, si, co, 0, dY, 0, 0, 1, 0, 0, 0, 0, 1};
       /* applyTransformation: Matrix::multiply(R, data) = data * R^T via dgemm(NoTrans,Trans)
        * (gsl/Matrix.cpp:489-497), then translation */
@@ -1010,6 +1072,19 @@ void ora_icp(const double* model, int n_model, const double* scene_in, int n_sce
   out->rms = rms; out->pairs = pairs; out->iterations = (int)iter; out->state = state;
   icp_ctx_free(&c);
   free(sc);
+}
+
+void ora_icp(const double* model, int n_model, const double* scene_in, int n_scene,
+             const double pose[9], const ora_icp_params* p, ora_icp_result* out, double* trace)
+{
+  icp_impl(model, NULL, n_model, scene_in, n_scene, pose, p, out, trace);
+}
+
+/* the same registration with PointToLine2DEstimator on the model normals Icp::setModel(coords, normals) takes */
+void ora_icp_point_to_line(const double* model, const double* normals, int n_model, const double* scene_in, int n_scene,
+                           const double pose[9], const ora_icp_params* p, ora_icp_result* out, double* trace)
+{
+  icp_impl(model, normals, n_model, scene_in, n_scene, pose, p, out, trace);
 }
 
 /* ------------------------------------------------------------------------------------------- */

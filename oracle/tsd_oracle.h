@@ -116,6 +116,10 @@ int  ora_raycast(const ora_grid* g, const double pose[9], const double* rays_wor
 void ora_icp(const double* model_xy, int n_model, const double* scene_xy, int n_scene,
              const double pose[9], const ora_icp_params* p, ora_icp_result* out,
              double* trace_per_iter /* optional [iterations][4] = pairs, rms, thr_before, state */);
+/* ... with PointToLine2DEstimator (PointToLineEstimator2D.cpp:52-157) on the model normals */
+void ora_icp_point_to_line(const double* model_xy, const double* model_normals_xy, int n_model, const double* scene_xy,
+                           int n_scene, const double pose33[9], const ora_icp_params* p, ora_icp_result* out,
+                           double* trace);
 /* pair chain of ONE ICP step for unit tests: returns number of pairs; thr is updated in place */
 int  ora_icp_pairs(const double* model_xy, int n_model, const double* scene_xy, int n_scene,
                    const double pose[9], const ora_icp_params* p, double* thr_sqr,

@@ -28,7 +28,8 @@ def test_header_symbols_are_exported(hip_lib):
 
 def test_struct_layouts_match_header():
     assert C.sizeof(capi.PushStats) == 8 + 8 + 7 * 4 + 4      # padded to 8
-    assert C.sizeof(capi.IcpParams) == 8 + 6 * 8
+    assert C.sizeof(capi.IcpParams) == 8 + 6 * 8               # iterations + estimator share the first 8 bytes
+    assert capi.IcpParams.estimator.offset == 4 and capi.IcpParams.dist_filter_max.offset == 8
     assert C.sizeof(capi.IcpResult) == 9 * 8 + 8 + 6 * 4
 
 

@@ -185,6 +185,31 @@ def test_icp_recovers_known_transform(nn_mode):
     assert tr[0, 1] > 1e-4 and tr[1, 1] < 1e-20                          # converged after the first step
 
 
+def test_icp_point_to_line_estimator():
+    """PointToLine2DEstimator (PointToLineEstimator2D.cpp:52-157), the reference's other estimator: on two
+    perpendicular walls with exact normals the linearised point-to-line step recovers a small rigid motion to
+    rounding once the pairs are right, sliding along a wall is free (the closed form keeps a residual there), and
+    its "rms" is the mean |n.(s - m)|, not a mean square."""
+    xs = np.linspace(-3.0, 3.0, 200)
+    model = np.concatenate([np.stack([xs, np.full_like(xs, 2.0)], 1), np.stack([np.full_like(xs, 3.0), 0.6 * xs], 1)])
+    normals = np.concatenate([np.tile([0.0, -1.0], (200, 1)), np.tile([-1.0, 0.0], (200, 1))])
+    th = 0.02
+    R = np.array([[math.cos(th), -math.sin(th)], [math.sin(th), math.cos(th)]])
+    scene = model @ R.T + np.array([0.03, -0.02])
+    pose = np.array([[1.0, 0, 10.0], [0, 1.0, 10.0], [0, 0, 1.0]])
+    b = (0.0, 25.6, 0.0, 25.6)
+    cf = O.icp(model, scene, pose, 30, 0.4, 0.02, b)
+    pl = O.icp(model, scene, pose, 30, 0.4, 0.02, b, model_normals_xy=normals, trace=True)
+    assert pl["state"] == 3 and pl["iterations"] == 30 and pl["pairs"] >= 398
+    assert abs(math.asin(pl["T"][1, 0]) + th) < 1e-12            # T maps the scene back onto the model
+    assert pl["rms"] < 1e-12 and cf["rms"] > 1e-6
+    # first step: mean distance to the wall lines of the displaced scene, a few centimetres
+    assert 0.01 < pl["trace"][0, 1] < 0.1
+    # exact normals and correct pairs: every scene point ends up on its wall line
+    moved = scene @ pl["T"][:2, :2].T + pl["T"][:2, 2]
+    assert np.abs(moved[:200, 1] - 2.0).max() < 1e-9 and np.abs(moved[200:, 0] - 3.0).max() < 1e-9
+
+
 def test_icp_brute_force_equals_kdtree():
     gc, geo, scene_name = synth.CONFIGS["cfg1"]
     rng = np.random.default_rng(9)

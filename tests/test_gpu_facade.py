@@ -137,3 +137,30 @@ def test_facade_multi_robot_shares_one_grid(oracle):
     P1 = node.report(1)["pose"]
     assert math.hypot(P1[0, 2] - (world.cx - 0.7), P1[1, 2] - (world.cy + 0.4)) < 0.1
     node.close()
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_facade_point_to_line_estimator_tracks(oracle, fused):
+    """`icp_estimator` = 1 (an addition: the reference node has no such key) runs the loop with
+    PointToLine2DEstimator on the ray cast's normals; it has to track the synthetic trajectory like the closed form."""
+    gc, geo, scene = synth.CONFIGS["cfg1"]
+    world = synth.World(scene, gc)
+    n = 25
+    poses = synth.trajectory(world, n)
+    scans = synth.scans_for(world, geo, poses)
+    out = {}
+    for est in (0, 1):
+        node = facade.SlamNode(facade.node_params(gc, geo, **{"icp_estimator": est}), synchronous=True, fused=fused)
+        rms = []
+        for k in range(n):
+            node.laser(scans[k], geo.angle_min, geo.angle_increment)
+            rh = node.report()
+            if k > 0:
+                assert rh["pairs"] > 100 and not rh["reg_error"]
+                rms.append(rh["rms"])
+        err = math.hypot(rh["pose"][0, 2] - poses[-1, 0], rh["pose"][1, 2] - poses[-1, 1])
+        out[est] = (err, float(np.mean(rms)))
+        node.close()
+    assert out[0][0] < 0.15 and out[1][0] < 0.15, out
+    # the two estimators report different error measures (mean squared distance vs mean |n.(s - m)|)
+    assert out[0][1] != out[1][1]

@@ -228,6 +228,52 @@ def test_icp_matches_oracle(oracle, iters):
     assert np.hypot(rd.T[0, 2], rd.T[1, 2]) > 0.02
 
 
+@pytest.mark.parametrize("iters", [30, 11])
+def test_icp_point_to_line_matches_oracle(oracle, iters):
+    """PointToLine2DEstimator (PointToLineEstimator2D.cpp:52-157) on the ray cast's normals, the
+    estimator north_star names; the node itself constructs the closed form.  Direct call and fused localize."""
+    gc = synth.GridConfig(10, 0.05)
+    geo = synth.ScanGeometry.utm30lx()
+    world = synth.World("pillars", gc)
+    og, dg = build_map(oracle, gc, geo, world)
+    pose, (x, y, yaw) = H.sensor_pose(world, 2)
+    rl, rw = H.world_rays(oracle, geo, pose, gc.cell_size)
+    co, no, mo, _ = og.raycast(pose, rw, H.MIN_RANGE, H.MAX_RANGE)
+    data, mask = oracle.ingest_f32(world.scan(x + 0.05, y - 0.03, yaw + 0.015, geo), H.MAX_RANGE, geo.angle_increment)
+    scene, ms, _ = oracle.scene_from_scan(rl, data, mask)
+    M = co.reshape(-1, 2)[mo.astype(bool)]
+    N = no.reshape(-1, 2)[mo.astype(bool)]
+    S = scene.reshape(-1, 2)[ms.astype(bool)]
+    bounds = (0.0, og.max_x, 0.0, og.max_x)
+    ro = oracle.icp(M, S, pose, iters, 0.4, 0.02, bounds, nn_mode=0, model_normals_xy=N)
+    rc = oracle.icp(M, S, pose, iters, 0.4, 0.02, bounds, nn_mode=0)
+    p = dg.icp_params(iters, 0.4, 0.02, estimator=1)
+    rd = dg.icp(M, S, pose, p, model_normals_xy=N)
+    assert (ro["pairs"], ro["iterations"], ro["state"]) == (rd.pairs, rd.iterations, rd.state)
+    d, a = H.pose_delta(ro["T"], rd.T)
+    assert d <= TOL_POSE_M and a <= TOL_POSE_RAD, (d, a)
+    assert abs(ro["rms"] - rd.rms) <= 1e-9
+    # a different estimator, not the closed form under another name: its "rms" is a mean distance, not a mean square
+    assert abs(ro["rms"] - rc["rms"]) > 1e-6 and np.hypot(rd.T[0, 2], rd.T[1, 2]) > 0.02
+    # the unsorted / shuffled model takes its normals along
+    perm = np.random.default_rng(5).permutation(len(M))
+    rs = dg.icp(M[perm], S, pose, p, model_normals_xy=N[perm])
+    assert (rs.pairs, rs.iterations, rs.state) == (rd.pairs, rd.iterations, rd.state)
+    d, a = H.pose_delta(rs.T, rd.T)
+    assert d <= 1e-9 and a <= 1e-9
+    # fused: ray cast -> compaction -> registration on the device, normals included
+    rf = dg.localize(pose, rw, rl, data, mask, H.MIN_RANGE, H.MAX_RANGE, p)
+    assert (rf.n_model, rf.n_scene) == (len(M), len(S))
+    assert (ro["pairs"], ro["iterations"], ro["state"]) == (rf.pairs, rf.iterations, rf.state)
+    d, a = H.pose_delta(ro["T"], rf.T)
+    assert d <= TOL_POSE_M and a <= TOL_POSE_RAD
+    # the estimator needs normals and a known id
+    with pytest.raises(capi.TsdError):
+        dg.icp(M, S, pose, p)
+    with pytest.raises(capi.TsdError):
+        dg.icp(M, S, pose, dg.icp_params(iters, 0.4, 0.02, estimator=7))
+
+
 def test_icp_degenerate(oracle):
     """<= 2 pairs: NOTMATCHABLE on the first step is reported as SUCCESS with T = I (Icp.cpp:489-505)."""
     gc = synth.GridConfig(8, 0.05)
