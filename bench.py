@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--scene", default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scans", type=int, default=30)
+    ap.add_argument("--estimator", type=int, default=0, choices=[0, 1],
+                    help="0: ClosedFormEstimator2D, what the node constructs (the bench line); 1: PointToLine2DEstimator")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the occupancy merge even with one rank (checks the "
                          "multi-GPU plumbing on a single GPU; tests/test_gpu_multigpu_plumbing.py)")
@@ -135,6 +137,8 @@ def main():
 
     params = facade.node_params(gc, geo)
     params["tsd_slam/local_offset_x"] = off_x
+    if args.estimator:
+        params["icp_estimator"] = args.estimator
     node = facade.SlamNode(params, device=local_rank if use_dist else 0, synchronous=True)
     grid = node.grid()
     merger = None
@@ -205,7 +209,8 @@ def main():
             "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.config}: {gc.cells}x{gc.cells} cells @ {gc.cell_size} m, {geo.beams} beams, "
-                                   f"scene '{scene}', icp_iterations 30, one robot + one grid per GPU",
+                                   f"scene '{scene}', icp_iterations 30, one robot + one grid per GPU"
+                                   + (", point-to-line estimator" if args.estimator else ""),
                        "robots": world_size, "occupancy_merge_every": MERGE_EVERY if world_size > 1 else None},
             "ms_icp_iterate": stages["icp"], "ms_icp_per_iteration": (stages["icp"] / 30.0) if stages["icp"] else None,
             "ms_raycast": stages["raycast"],
