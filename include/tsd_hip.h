@@ -208,6 +208,9 @@ int tsd_download_tile_state(tsd_ctx* ctx, uint8_t* initialized, double* init_wei
  * then max-all-reduced over RCCL). */
 int tsd_occupancy(tsd_ctx* ctx, int8_t* occ_host, int inflate, int inflate_factor, int* n_surface);
 int tsd_occupancy_dev(tsd_ctx* ctx, void* occ_dev, int inflate, int inflate_factor);
+/* TsdGrid::grid2ColorImage(image, width, height) (TsdGrid.cpp:429-488): RGB8, rgb[3 * (h * width + w)], the debug
+ * image ThreadGrid publishes with every occupancy map (ThreadGrid.cpp:119-131).  Host buffer of 3*width*height. */
+int tsd_color_image(tsd_ctx* ctx, uint8_t* rgb_host, unsigned int width, unsigned int height);
 
 /* ---- measurement ----------------------------------------------------------------------------- */
 /* Per-kernel HIP-event timing on the ctx stream.  Kernel names: "push_classify", "push_update",

@@ -116,6 +116,7 @@ ABI = {
     "tsd_scan": (C.c_int, [C.c_void_p, _dp, _u8p, _u8p, C.POINTER(IcpParams), C.POINTER(GateParams),
                            C.POINTER(ScanResult)]),
     "tsd_icp_trace": (C.c_int, [C.c_void_p, _dp, C.c_int]),
+    "tsd_color_image": (C.c_int, [C.c_void_p, _u8p, C.c_uint, C.c_uint]),
     "tsd_download_tiles": (C.c_int, [C.c_void_p, _u8p, _dp, _dp, _dp]),
     "tsd_upload_tiles": (C.c_int, [C.c_void_p, _u8p, _dp, _dp, _dp]),
     "tsd_download_tile_state": (C.c_int, [C.c_void_p, _u8p, _dp]),
@@ -314,6 +315,14 @@ class TsdGridDevice:
     def profile(self, on=True, kernels="all"):
         self.lib.tsd_profile_select(self.h, kernels.encode())
         self.lib.tsd_profile_enable(self.h, int(on))
+
+    def color_image(self, width=None, height=None):
+        """TsdGrid::grid2ColorImage: (height, width, 3) uint8."""
+        width = self.cells if width is None else width
+        height = self.cells if height is None else height
+        img = np.zeros((height, width, 3), dtype=np.uint8)
+        self._check(self.lib.tsd_color_image(self.h, img.ctypes.data_as(_u8p), width, height), "tsd_color_image")
+        return img
 
     def push_stats_total(self, reset=False):
         st = PushStats()

@@ -668,6 +668,30 @@ int tsd_occupancy_dev(tsd_ctx* ctx, void* occ_dev, int inflate, int inflate_fact
   return TSD_OK;
 }
 
+int tsd_color_image(tsd_ctx* ctx, uint8_t* rgb_host, unsigned int width, unsigned int height)
+{
+  if (!ctx || !rgb_host || width == 0 || height == 0) return TSD_E_ARG;
+  TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  // px / py exactly as the reference accumulates them (TsdGrid.cpp:433-486): start at 0, += step per pixel
+  std::vector<double> pq((size_t)width + height);
+  const double stepW = ctx->grid.max_x / (double)width, stepH = ctx->grid.max_y / (double)height;
+  { double v = 0.0; for (unsigned w = 0; w < width; w++) { pq[w] = v; v += stepW; } }
+  { double v = 0.0; for (unsigned h = 0; h < height; h++) { pq[(size_t)width + h] = v; v += stepH; } }
+  double* d_pq = nullptr; uint8_t* d_img = nullptr;
+  const size_t img_bytes = (size_t)3 * width * height;
+  TSD_HIP_CHECK(ctx, hipMalloc(&d_pq, pq.size() * sizeof(double)));
+  hipError_t e = hipMalloc(&d_img, img_bytes);
+  if (e != hipSuccess) { hipFree(d_pq); return set_error(ctx, TSD_E_HIP, "hipMalloc(image)", e); }
+  int rc = TSD_OK;
+  e = hipMemcpyAsync(d_pq, pq.data(), pq.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) rc = launch_color_image(ctx, d_pq, d_pq + width, width, height, d_img);
+  if (e == hipSuccess && rc == TSD_OK) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess && rc == TSD_OK) e = hipMemcpy(rgb_host, d_img, img_bytes, hipMemcpyDeviceToHost);
+  hipFree(d_pq); hipFree(d_img);
+  if (e != hipSuccess) return set_error(ctx, TSD_E_HIP, "tsd_color_image", e);
+  return rc;
+}
+
 int tsd_occupancy(tsd_ctx* ctx, int8_t* occ_host, int inflate, int inflate_factor, int* n_surface)
 {
   if (!ctx || !occ_host) return TSD_E_ARG;

@@ -103,6 +103,41 @@ k_occ_mark(GridDev g, int8_t* __restrict__ out, int* __restrict__ count, int inf
   if ((threadIdx.x & 63) == 0 && n) atomicAdd(count, n);
 }
 
+// TsdGrid::grid2ColorImage (TsdGrid.cpp:429-488), what ThreadGrid publishes next to the occupancy map
+// (ThreadGrid.cpp:125).  The reference walks the image with px += stepW / py += stepH (repeated fp64 addition):
+// the two coordinate tables are built that way on the host and a pixel is then one coord2Cell + one cell read.
+// One thread per pixel, 3 bytes out; streams the touched cells once.
+__global__ void __launch_bounds__(256)
+k_color_image(GridDev g, const double* __restrict__ pxs, const double* __restrict__ pys, unsigned width,
+              unsigned height, uint8_t* __restrict__ image)
+{
+  const unsigned w = blockIdx.x * 256u + threadIdx.x, h = blockIdx.y;
+  if (w >= width || h >= height) return;
+  int p, lx, ly; double dx, dy;
+  double t = __builtin_nan("");
+  bool is_empty = false;
+  if (coord2cell(g, pxs[w], pys[h], p, lx, ly, dx, dy)) {
+    const bool init = g.flags[p] != 0;
+    if (init) t = g.tsd[(size_t)p * TILE_STRIDE + ly * TILE_PITCH + lx];
+    is_empty = !init && g.init_weight[p] > 0.0;                 // isEmpty(), TsdGridPartition.h:72
+  }
+  uint8_t r, gch, b;
+  if (t > 0.0) { r = (uint8_t)(t * 255.0); gch = 255; b = (uint8_t)(t * 255.0); }
+  else if (t < 0.0) { r = (uint8_t)((1.0 + t) * 255.0); gch = 0; b = 0; }
+  else if (is_empty) { r = 255; gch = 255; b = 255; }
+  else { r = 0; gch = 0; b = 0; }
+  uint8_t* o = image + 3 * ((size_t)h * width + w);
+  o[0] = r; o[1] = gch; o[2] = b;
+}
+
+int launch_color_image(tsd_ctx* ctx, const double* d_px, const double* d_py, unsigned width, unsigned height, uint8_t* d_image)
+{
+  hipLaunchKernelGGL(k_color_image, dim3((width + 255) / 256, height), dim3(256), 0, ctx->stream, ctx->grid, d_px, d_py,
+                     width, height, d_image);
+  TSD_HIP_CHECK(ctx, hipGetLastError());
+  return TSD_OK;
+}
+
 int launch_occupancy(tsd_ctx* ctx, int8_t* d_out, int inflate, int inflate_factor)
 {
   ScopedKernelTimer t(ctx, "occupancy", true);

@@ -223,6 +223,7 @@ int launch_scan_prepare(tsd_ctx* ctx, SensorDev* st);
 
 int launch_calibrate(tsd_ctx* ctx, double* t, double* w, size_t n);
 int launch_occupancy(tsd_ctx* ctx, int8_t* d_out, int inflate, int inflate_factor);
+int launch_color_image(tsd_ctx* ctx, const double* d_px, const double* d_py, unsigned width, unsigned height, uint8_t* d_image);
 size_t icp_lds_bytes();
 
 // pose helpers (host): textbook LU inverse with partial pivoting in the order of

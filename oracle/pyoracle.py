@@ -134,6 +134,8 @@ def lib():
         L.ora_is_pose_change_significant.argtypes = [_dp, _dp]
         L.ora_occupancy.argtypes = [C.c_void_p, _i8p, _i8p, C.c_int, C.c_int]
         L.ora_occupancy.restype = C.c_int
+        L.ora_grid_color_image.argtypes = [C.c_void_p, C.POINTER(C.c_ubyte), C.c_uint, C.c_uint]
+        L.ora_grid_color_image.restype = None
         L.ora_slam_create.restype = C.c_void_p
         L.ora_slam_create.argtypes = [C.POINTER(SlamConfig)]
         L.ora_slam_destroy.argtypes = [C.c_void_p]
@@ -254,6 +256,15 @@ class Grid:
         v = C.c_double(0.0)
         st = self.L.ora_interpolate_bilinear(self.h, x, y, C.byref(v))
         return st, v.value
+
+    def color_image(self, width=None, height=None):
+        """TsdGrid::grid2ColorImage: (height, width, 3) uint8."""
+        n = self.cells
+        width = n if width is None else width
+        height = n if height is None else height
+        img = np.zeros((height, width, 3), dtype=np.uint8)
+        self.L.ora_grid_color_image(self.h, img.ctypes.data_as(C.POINTER(C.c_ubyte)), width, height)
+        return img
 
     def occupancy(self, content, inflate=False, factor=2):
         out = np.zeros_like(content)

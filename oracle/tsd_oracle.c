@@ -1087,6 +1087,36 @@ void ora_icp_point_to_line(const double* model, const double* normals, int n_mod
   icp_impl(model, normals, n_model, scene_in, n_scene, pose, p, out, trace);
 }
 
+/* TsdGrid::grid2ColorImage (TsdGrid.cpp:429-488), what ThreadGrid publishes next to the occupancy map
+ * (ThreadGrid.cpp:125): rgb[3 * (h * width + w)].  px / py by REPEATED addition of the step like the reference. */
+void ora_grid_color_image(const ora_grid* g, unsigned char* image, unsigned int width, unsigned int height)
+{
+  const double stepW = g->max_x / (double)width;
+  const double stepH = g->max_y / (double)height;
+  double py = 0.0;
+  size_t i = 0;
+  for (unsigned int h = 0; h < height; h++) {
+    double px = 0.0;
+    for (unsigned int w = 0; w < width; w++, i++) {
+      int p, x, y; double dx, dy;
+      double tsd = NAN;
+      int is_empty = 0;
+      if (coord2cell(g, px, py, &p, &x, &y, &dx, &dy)) {
+        if (g->init[p]) tsd = g->tsd[p][y * PT + x];
+        is_empty = !g->init[p] && g->init_weight[p] > 0.0;     /* isEmpty(), TsdGridPartition.h:72 */
+      }
+      unsigned char rgb[3];
+      if (tsd > 0.0) { rgb[0] = (unsigned char)(tsd * 255.0); rgb[1] = 255; rgb[2] = (unsigned char)(tsd * 255.0); }
+      else if (tsd < 0.0) { rgb[0] = (unsigned char)((1.0 + tsd) * 255.0); rgb[1] = 0; rgb[2] = 0; }
+      else if (is_empty) { rgb[0] = 255; rgb[1] = 255; rgb[2] = 255; }
+      else { rgb[0] = 0; rgb[1] = 0; rgb[2] = 0; }
+      memcpy(image + 3 * i, rgb, 3);
+      px += stepW;
+    }
+    py += stepH;
+  }
+}
+
 /* ------------------------------------------------------------------------------------------- */
 /* L1: gates                                                                                     */
 /* ------------------------------------------------------------------------------------------- */

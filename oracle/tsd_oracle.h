@@ -135,6 +135,8 @@ int    ora_is_pose_change_significant(const double last_pose[9], const double cu
 /* content = persistent _occGridContent (caller initialises to -1 once, ThreadGrid.cpp:27-28);
  * out = the published OccupancyGrid data (copy of content + 100 marks).  Returns #sign changes. */
 int  ora_occupancy(const ora_grid* g, int8_t* content, int8_t* out, int inflate, int inflate_factor);
+/* TsdGrid::grid2ColorImage (TsdGrid.cpp:429-488): rgb[3 * width * height] */
+void ora_grid_color_image(const ora_grid* g, unsigned char* image, unsigned int width, unsigned int height);
 
 /* ---- whole-loop driver: ThreadLocalize::init + eventLoop body + ThreadMapping pushes ---- */
 typedef struct ora_slam ora_slam;

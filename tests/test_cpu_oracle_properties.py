@@ -220,6 +220,30 @@ def test_icp_brute_force_equals_kdtree():
     assert a["pairs"] == b["pairs"] and np.array_equal(a["T"], b["T"]) and a["rms"] == b["rms"]
 
 
+def test_color_image_colours():
+    """grid2ColorImage (TsdGrid.cpp:429-488): green channel 255 with r = b = tsd * 255 in front of a surface, red
+    (1 + tsd) * 255 behind it, white for tiles that are empty-with-weight, black for unseen space; pixel (w, h)
+    shows the cell coord2Cell finds for the accumulated coordinate."""
+    gc = synth.GridConfig(8, 0.1)
+    geo = synth.ScanGeometry.full_circle_360()
+    world = synth.World("room", gc)
+    g = O.Grid(gc.map_size_log2, gc.cell_size, gc.max_trunc)
+    pose = synth.pose_matrix(world.start[0], world.start[1], 0.1)
+    far = np.full(geo.beams, 9.0, dtype=np.float32)
+    for r32 in (world.scan(world.start[0], world.start[1], 0.1, geo), far):
+        data, mask = O.ingest_f32(r32, 30.0, geo.angle_increment)
+        g.push(pose, data, mask, geo.angle_increment, geo.angle_min, 30.0, 0.001, 2.0)
+    img = g.color_image()
+    assert img.shape == (gc.cells, gc.cells, 3) and img.dtype == np.uint8
+    green = img[..., 1] == 255
+    assert green.any() and (img[green][:, 0] == img[green][:, 2]).all()
+    red = (img[..., 1] == 0) & (img[..., 0] > 0)
+    assert red.any() and (img[red][:, 2] == 0).all()
+    assert (img.sum(axis=2) == 0).any()
+    small = g.color_image(64, 48)
+    assert small.shape == (48, 64, 3) and small.any()
+
+
 def test_occupancy_values_and_persistence():
     gc = synth.GridConfig(8, 0.1)
     geo = synth.ScanGeometry.full_circle_360()

@@ -364,6 +364,26 @@ def test_occupancy_matches_oracle(oracle, inflate):
 
 # ------------------------------------------------------------------------------------------------
 # edge cases of the scan itself
+def test_color_image_matches_oracle(oracle):
+    """TsdGrid::grid2ColorImage (TsdGrid.cpp:429-488), the RGB image ThreadGrid publishes with the occupancy map:
+    byte for byte, at the grid's own size and at an arbitrary one (px / py accumulate by repeated addition)."""
+    gc = synth.GridConfig(9, 0.05)
+    geo = synth.ScanGeometry.full_circle_360()
+    world = synth.World("room", gc)
+    og, dg = make_pair(oracle, gc)
+    near = np.full(geo.beams, 2.0, dtype=np.float32)
+    for k, r in enumerate((None, None, near, None)):          # content, empty-with-weight and untouched tiles
+        push_both(oracle, og, dg, world, geo, 4 * k, ranges_f32=r)
+    for (w, h) in ((gc.cells, gc.cells), (300, 200), (1000, 37)):
+        io = og.color_image(w, h)
+        ih = dg.color_image(w, h)
+        assert io.shape == ih.shape == (h, w, 3)
+        assert np.array_equal(io, ih), f"{w}x{h}: {np.argwhere(io != ih)[:5]}"
+    full = dg.color_image()
+    assert (full[..., 1] == 255).any() and ((full[..., 1] == 0) & (full[..., 0] > 0)).any()      # free (green), behind the surface (red)
+    assert (full.sum(axis=2) == 0).any()                                                     # unseen (black)
+
+
 def test_push_degenerate_scans(oracle):
     """All beams masked / all infinite / a single valid beam / every beam at max range: same tile
     classification and cells on both sides, no crash, nothing updated where nothing is visible."""
