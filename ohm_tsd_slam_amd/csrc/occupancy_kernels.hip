@@ -25,6 +25,9 @@ __device__ __forceinline__ int8_t occ_from_tsd(const GridDev& g, int p, int ly, 
   return (t > 0.0) ? 0 : -1;
 }
 
+// One workgroup per tile, one thread per 4 consecutive cells of a row: the map is read and written 4 bytes per
+// lane (16-byte aligned rows), the tile's cells 32 bytes per lane.  A tile nobody writes (most of the grid) only
+// forwards the persistent map to the output.
 __global__ void __launch_bounds__(256)
 k_occ_cells(GridDev g, int8_t* __restrict__ content, int8_t* __restrict__ out)
 {
@@ -37,18 +40,35 @@ k_occ_cells(GridDev g, int8_t* __restrict__ content, int8_t* __restrict__ out)
   const bool left_w = X >= 1 && tile_processed(X - 1, Y, PX) && g.flags[p - 1];
   const bool down_w = Y >= 1 && tile_processed(X, Y - 1, PX) && g.flags[p - PX];
   const bool diag_w = X >= 1 && Y >= 1 && tile_processed(X - 1, Y - 1, PX) && g.flags[p - PX - 1];
-  for (int c = threadIdx.x; c < TILE_DIM * TILE_DIM; c += 256) {
-    const int lx = c & 31, ly = c >> 5;
-    const size_t gi = (size_t)(Y * TILE_DIM + ly) * g.N + (size_t)(X * TILE_DIM + lx);
-    int8_t v = content[gi];
-    if (own_proc && own_init) v = occ_from_tsd(g, p, ly, lx);
-    else if (own_proc && own_empty) v = 0;
-    else if (lx == 0 && left_w) v = occ_from_tsd(g, p - 1, ly, TILE_DIM);
-    else if (ly == 0 && down_w) v = occ_from_tsd(g, p - PX, TILE_DIM, lx);
-    else if (lx == 0 && ly == 0 && diag_w) v = occ_from_tsd(g, p - PX - 1, TILE_DIM, TILE_DIM);
-    content[gi] = v;
-    out[gi] = v;
+  const int lx0 = (threadIdx.x & 7) * 4, ly = threadIdx.x >> 3;
+  const size_t gi = (size_t)(Y * TILE_DIM + ly) * g.N + (size_t)(X * TILE_DIM + lx0);
+  uint32_t* c4 = reinterpret_cast<uint32_t*>(content + gi);
+  uint32_t* o4 = reinterpret_cast<uint32_t*>(out + gi);
+  if (own_proc && own_init) {
+    const double* t = g.tsd + (size_t)p * TILE_STRIDE + ly * TILE_PITCH + lx0;
+    const double t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
+    const uint32_t v = (t0 > 0.0 ? 0u : 0xFFu) | (t1 > 0.0 ? 0u : 0xFF00u) | (t2 > 0.0 ? 0u : 0xFF0000u) | (t3 > 0.0 ? 0u : 0xFF000000u);
+    *c4 = v; *o4 = v;
+    return;
   }
+  if (own_proc && own_empty) { *c4 = 0u; *o4 = 0u; return; }
+  uint32_t v = *c4;
+  // a neighbour's halo lands in this tile's first column / row / corner cell (the last writer of the reference's
+  // serial order wins: left > down > diagonal)
+  bool changed = false;
+  if (lx0 == 0 && left_w) { v = (v & ~0xFFu) | (uint8_t)occ_from_tsd(g, p - 1, ly, TILE_DIM); changed = true; }
+  else if (lx0 == 0 && ly == 0 && down_w) { }       // (handled with the rest of row 0 below)
+  if (ly == 0 && down_w) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (lx0 + k == 0 && left_w) continue;                                        // left neighbour wins the corner cell
+      v = (v & ~(0xFFu << (8 * k))) | ((uint32_t)(uint8_t)occ_from_tsd(g, p - PX, TILE_DIM, lx0 + k) << (8 * k));
+    }
+    changed = true;
+  }
+  if (lx0 == 0 && ly == 0 && !left_w && !down_w && diag_w) { v = (v & ~0xFFu) | (uint8_t)occ_from_tsd(g, p - PX - 1, TILE_DIM, TILE_DIM); changed = true; }
+  if (changed) *c4 = v;
+  *o4 = v;
 }
 
 __device__ __forceinline__ void occ_mark(const GridDev& g, int8_t* out, double x, double y, int inflate,
@@ -73,7 +93,13 @@ k_occ_mark(GridDev g, int8_t* __restrict__ out, int* __restrict__ count, int inf
   const int PX = g.PX;
   const int X = p % PX, Y = p / PX;
   if (!tile_processed(X, Y, PX) || !g.flags[p]) return;
-  const double* T = g.tsd + (size_t)p * TILE_STRIDE;
+  // the tile (33 x 33 doubles) through LDS: every cell is looked at by up to four scan positions
+  __shared__ double T[TILE_CELLS];
+  {
+    const double* Tg = g.tsd + (size_t)p * TILE_STRIDE;
+    for (int i = threadIdx.x; i < TILE_CELLS; i += 256) T[i] = Tg[i];
+  }
+  __syncthreads();
   const double cs = g.cs;
   int n = 0;
   // row scans: py in 0..32, px in 1..32 (:38-60); column scans: px in 0..32, py in 1..32 (:62-80)
