@@ -481,6 +481,21 @@ def grid_properties(init, iw, tsd, w):
     assert np.all(w[sel][~m] == 0.0), "a NaN cell carries no weight"
 
 
+def test_push_comb_scene(oracle):
+    """BASELINE's bandwidth-stress scene: ranges alternate 5 m / 25 m every 8 beams, so nearly every tile within
+    25 m is seen by some beam and hidden from its neighbours -- the range-maximum / range-minimum tables of
+    isInRange and the beam windows of the update kernel at their worst."""
+    gc = synth.GridConfig(11, 0.025)                     # 51.2 m: the 25 m beams stay inside
+    geo = synth.ScanGeometry.utm30lx()
+    world = synth.World("comb", gc)
+    og, dg = make_pair(oracle, gc)
+    for k in range(3):
+        so, sd = push_both(oracle, og, dg, world, geo, 7 * k)
+        assert so == sd, f"push {k}: stats differ\n oracle {so}\n hip    {sd}"
+        H.assert_grids_equal(og.dump(), dg.download_tiles(), TOL_CELL)
+    assert sd["tiles_update"] > 1000 and sd["cells_updated"] > 400000
+
+
 def test_cfg2_full_size_push_and_localize(oracle):
     gc, geo, scene = synth.CONFIGS["cfg2"]
     world = synth.World(scene, gc)
