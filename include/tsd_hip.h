@@ -200,6 +200,12 @@ int tsd_upload_tiles(tsd_ctx* ctx, const uint8_t* initialized, const double* ini
                      const double* tsd, const double* weight);
 /* tile flags only (cheap) */
 int tsd_download_tile_state(tsd_ctx* ctx, uint8_t* initialized, double* init_weight);
+/* TsdGrid::storeGrid(path) (TsdGrid.cpp:548-607) and the file constructor TsdGrid(path, FILE_SOURCE) (:25-110): the
+ * reference's text format (one value per line, 6 significant digits; per tile its identifier and, for content
+ * tiles, tsd and weight of the 32 x 32 interior cells).  Loading replaces the grid's content; the file's layout and
+ * cell size must be the context's (TSD_E_ARG otherwise), its maxTruncation is taken over. */
+int tsd_store_grid_text(tsd_ctx* ctx, const char* path);
+int tsd_load_grid_text(tsd_ctx* ctx, const char* path);
 
 /* Occupancy map of ThreadGrid::eventLoop (ThreadGrid.cpp:72-118) built from
  * RayCastAxisAligned2D::calcCoords (RayCastAxisAligned2D.cpp:13-105): int8 cells*cells,

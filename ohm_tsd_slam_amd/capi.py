@@ -117,6 +117,8 @@ ABI = {
                            C.POINTER(ScanResult)]),
     "tsd_icp_trace": (C.c_int, [C.c_void_p, _dp, C.c_int]),
     "tsd_color_image": (C.c_int, [C.c_void_p, _u8p, C.c_uint, C.c_uint]),
+    "tsd_store_grid_text": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "tsd_load_grid_text": (C.c_int, [C.c_void_p, C.c_char_p]),
     "tsd_download_tiles": (C.c_int, [C.c_void_p, _u8p, _dp, _dp, _dp]),
     "tsd_upload_tiles": (C.c_int, [C.c_void_p, _u8p, _dp, _dp, _dp]),
     "tsd_download_tile_state": (C.c_int, [C.c_void_p, _u8p, _dp]),
@@ -315,6 +317,14 @@ class TsdGridDevice:
     def profile(self, on=True, kernels="all"):
         self.lib.tsd_profile_select(self.h, kernels.encode())
         self.lib.tsd_profile_enable(self.h, int(on))
+
+    def store_text(self, path):
+        """TsdGrid::storeGrid: the reference's text format."""
+        self._check(self.lib.tsd_store_grid_text(self.h, str(path).encode()), "tsd_store_grid_text")
+
+    def load_text(self, path):
+        """TsdGrid(file): replaces the grid's content by a stored file of the same layout."""
+        self._check(self.lib.tsd_load_grid_text(self.h, str(path).encode()), "tsd_load_grid_text")
 
     def color_image(self, width=None, height=None):
         """TsdGrid::grid2ColorImage: (height, width, 3) uint8."""

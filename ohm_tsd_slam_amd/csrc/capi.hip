@@ -658,6 +658,95 @@ int tsd_upload_tiles(tsd_ctx* ctx, const uint8_t* initialized, const double* ini
   return TSD_OK;
 }
 
+int tsd_store_grid_text(tsd_ctx* ctx, const char* path)
+{
+  if (!ctx || !path || !path[0]) return TSD_E_ARG;
+  const GridDev& g = ctx->grid;
+  const size_t T = (size_t)g.tiles;
+  std::vector<uint8_t> init(T);
+  std::vector<double> iw(T), tsd(T * TSD_TILE_CELLS), w(T * TSD_TILE_CELLS);
+  int rc = tsd_download_tiles(ctx, init.data(), iw.data(), tsd.data(), w.data());
+  if (rc != TSD_OK) return rc;
+  std::FILE* f = std::fopen(path, "w");
+  if (!f) return set_error(ctx, TSD_E_ARG, "tsd_store_grid_text: cannot open the file", hipSuccess);
+  int map_log2 = 0;
+  while ((1 << map_log2) < g.N) map_log2++;
+  // "%g" is the default ostream format of the reference's `outFile << value`
+  std::fprintf(f, "%g\n%d\n%d\n%g\n", g.cs, 5 /* LAYOUT_32x32 */, map_log2, g.max_trunc);
+  for (size_t p = 0; p < T; p++) {
+    if (init[p]) {
+      std::fprintf(f, "2\n");
+      for (int py = 0; py < TILE_DIM; py++)
+        for (int px = 0; px < TILE_DIM; px++) {
+          const size_t i = p * TSD_TILE_CELLS + (size_t)(py * TILE_PITCH + px);
+          std::fprintf(f, "%g\n%g\n", tsd[i], w[i]);
+        }
+    } else if (iw[p] > 0.0) {            // isEmpty()
+      std::fprintf(f, "1\n%g\n", iw[p]);
+    } else {
+      std::fprintf(f, "0\n");
+    }
+  }
+  std::fclose(f);
+  return TSD_OK;
+}
+
+// getDoubleLine / getIntLine (obcore/base/tools.cpp:190-215)
+static double text_double_line(std::FILE* f)
+{
+  char line[1024];
+  if (!std::fgets(line, sizeof(line), f) || line[0] == '\n' || line[0] == 0) return std::nan("");
+  return std::strtod(line, nullptr);
+}
+static int text_int_line(std::FILE* f)
+{
+  char line[1024];
+  if (!std::fgets(line, sizeof(line), f) || line[0] == '\n' || line[0] == 0) return 0;
+  return std::atoi(line);
+}
+
+int tsd_load_grid_text(tsd_ctx* ctx, const char* path)
+{
+  if (!ctx || !path || !path[0]) return TSD_E_ARG;
+  std::FILE* f = std::fopen(path, "r");
+  if (!f) return set_error(ctx, TSD_E_ARG, "tsd_load_grid_text: cannot open the file", hipSuccess);
+  const GridDev& g = ctx->grid;
+  const double cell_size = text_double_line(f);
+  const int layout_part = text_int_line(f), layout_grid = text_int_line(f);
+  const double max_trunc = text_double_line(f);
+  int map_log2 = 0;
+  while ((1 << map_log2) < g.N) map_log2++;
+  if (layout_part != 5 || layout_grid != map_log2 || !(std::fabs(cell_size - g.cs) <= 1e-5 * g.cs)) {
+    std::fclose(f);
+    return set_error(ctx, TSD_E_ARG, "tsd_load_grid_text: the file's layout / cell size is not this grid's", hipSuccess);
+  }
+  const size_t T = (size_t)g.tiles;
+  std::vector<uint8_t> init(T, 0);
+  std::vector<double> iw(T, 0.0), tsd(T * TSD_TILE_CELLS), w(T * TSD_TILE_CELLS, 0.0);
+  for (size_t p = 0; p < T; p++) {
+    const int id = text_int_line(f);
+    if (id == 0) continue;
+    if (id == 1) { iw[p] = std::fmin(text_double_line(f), 32.0 /* TSDGRIDMAXWEIGHT */); continue; }
+    if (id != 2) { std::fclose(f); return set_error(ctx, TSD_E_ARG, "tsd_load_grid_text: unknown tile identifier", hipSuccess); }
+    // curPart->init(maxTruncation) on a fresh partition (_initWeight 0): every cell NaN / 0, halo included; then the
+    // interior cells from the file
+    init[p] = 1;
+    for (int i = 0; i < TSD_TILE_CELLS; i++) tsd[p * TSD_TILE_CELLS + (size_t)i] = std::nan("");
+    for (int py = 0; py < TILE_DIM; py++)
+      for (int px = 0; px < TILE_DIM; px++) {
+        const size_t i = p * TSD_TILE_CELLS + (size_t)(py * TILE_PITCH + px);
+        tsd[i] = text_double_line(f);
+        w[i] = text_double_line(f);
+      }
+  }
+  std::fclose(f);
+  int rc = tsd_reset(ctx);
+  if (rc != TSD_OK) return rc;
+  rc = tsd_set_max_truncation(ctx, max_trunc);
+  if (rc != TSD_OK) return rc;
+  return tsd_upload_tiles(ctx, init.data(), iw.data(), tsd.data(), w.data());
+}
+
 int tsd_occupancy_dev(tsd_ctx* ctx, void* occ_dev, int inflate, int inflate_factor)
 {
   if (!ctx || !occ_dev) return TSD_E_ARG;

@@ -136,6 +136,10 @@ def lib():
         L.ora_occupancy.restype = C.c_int
         L.ora_grid_color_image.argtypes = [C.c_void_p, C.POINTER(C.c_ubyte), C.c_uint, C.c_uint]
         L.ora_grid_color_image.restype = None
+        L.ora_grid_store_text.argtypes = [C.c_void_p, C.c_char_p]
+        L.ora_grid_store_text.restype = C.c_int
+        L.ora_grid_load_text.argtypes = [C.c_char_p]
+        L.ora_grid_load_text.restype = C.c_void_p
         L.ora_slam_create.restype = C.c_void_p
         L.ora_slam_create.argtypes = [C.POINTER(SlamConfig)]
         L.ora_slam_destroy.argtypes = [C.c_void_p]
@@ -208,6 +212,20 @@ class Grid:
             self.close()
         except Exception:
             pass
+
+    def store_text(self, path) -> bool:
+        """TsdGrid::storeGrid: the reference's text format."""
+        return bool(self.L.ora_grid_store_text(self.h, str(path).encode()))
+
+    @classmethod
+    def load_text(cls, path, cell_size):
+        """TsdGrid(file, FILE_SOURCE): a new grid from a stored file (None if the file is not one)."""
+        h = lib().ora_grid_load_text(str(path).encode())
+        if not h:
+            return None
+        g = cls(0, cell_size, 0.0, handle=h)
+        g.own = True
+        return g
 
     def free_footprint(self, center, w, h):
         c = f64(center)

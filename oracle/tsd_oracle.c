@@ -358,6 +358,75 @@ void ora_grid_load(ora_grid* g, const uint8_t* initialized, const double* init_w
   }
 }
 
+/* TsdGrid::storeGrid (TsdGrid.cpp:548-607): text, one value per line in the default ostream format (6 significant
+ * digits == "%g"): cellSize, partition layout, grid layout, maxTruncation, then per tile (y outer, x inner) its
+ * identifier 0 uninitialised / 1 empty (+ initWeight) / 2 content (+ tsd, weight of the 32 x 32 interior cells,
+ * row-major; the halo is not stored). */
+int ora_grid_store_text(const ora_grid* g, const char* path)
+{
+  if (!path || !path[0]) return 0;
+  FILE* f = fopen(path, "w");
+  if (!f) return 0;
+  fprintf(f, "%g\n%d\n%d\n%g\n", g->cs, 5 /* LAYOUT_32x32 */, g->map_log2, g->max_trunc);
+  for (int p = 0; p < g->tiles; p++) {
+    if (g->init[p]) {
+      fprintf(f, "2\n");
+      for (int py = 0; py < D; py++)
+        for (int px = 0; px < D; px++) fprintf(f, "%g\n%g\n", g->tsd[p][py * PT + px], g->weight[p][py * PT + px]);
+    } else if (g->init_weight[p] > 0.0) {        /* isEmpty() */
+      fprintf(f, "1\n%g\n", g->init_weight[p]);
+    } else {
+      fprintf(f, "0\n");
+    }
+  }
+  fclose(f);
+  return 1;
+}
+
+/* getDoubleLine / getIntLine (obcore/base/tools.cpp:190-215) */
+static double text_double_line(FILE* f)
+{
+  char line[1024];
+  if (!fgets(line, sizeof(line), f) || line[0] == '\n' || line[0] == 0) return NAN;
+  return strtod(line, NULL);
+}
+static int text_int_line(FILE* f)
+{
+  char line[1024];
+  if (!fgets(line, sizeof(line), f) || line[0] == '\n' || line[0] == 0) return 0;
+  return atoi(line);
+}
+
+/* TsdGrid(const std::string&, FILE_SOURCE) (TsdGrid.cpp:25-110): a new grid from such a file.  A content tile is
+ * init()-ed (halo included) and its interior overwritten; the halo keeps the init value until the next push. */
+ora_grid* ora_grid_load_text(const char* path)
+{
+  FILE* f = fopen(path, "r");
+  if (!f) return NULL;
+  const double cell_size = text_double_line(f);
+  const int layout_part = text_int_line(f);
+  const int layout_grid = text_int_line(f);
+  if (layout_grid < 0 || layout_part != 5 || layout_grid > 15) { fclose(f); return NULL; }
+  const double max_trunc = text_double_line(f);
+  ora_grid* g = ora_grid_create(layout_grid, cell_size, max_trunc);
+  for (int p = 0; p < g->tiles; p++) {
+    const int id = text_int_line(f);
+    if (id == 0) continue;
+    if (id == 1) {
+      g->init_weight[p] = fmin(text_double_line(f), TSDGRIDMAXWEIGHT);
+    } else if (id == 2) {
+      tile_init(g, p);
+      for (int py = 0; py < D; py++)
+        for (int px = 0; px < D; px++) {
+          g->tsd[p][py * PT + px] = text_double_line(f);
+          g->weight[p][py * PT + px] = text_double_line(f);
+        }
+    } else { fclose(f); ora_grid_destroy(g); return NULL; }
+  }
+  fclose(f);
+  return g;
+}
+
 /* ------------------------------------------------------------------------------------------- */
 /* P1-P6: push                                                                                   */
 /* ------------------------------------------------------------------------------------------- */

@@ -100,6 +100,9 @@ void      ora_grid_dump(const ora_grid* g, uint8_t* initialized, double* init_we
                         double* tsd, double* weight);
 void      ora_grid_load(ora_grid* g, const uint8_t* initialized, const double* init_weight,
                         const double* tsd, const double* weight);
+/* TsdGrid::storeGrid (TsdGrid.cpp:548-607) / TsdGrid(file) (:25-110): the reference's text format */
+int       ora_grid_store_text(const ora_grid* g, const char* path);
+ora_grid* ora_grid_load_text(const char* path);
 
 /* ---- P1-P6: push ---- */
 void ora_push(ora_grid* g, const double pose[9], const double* data, const uint8_t* mask,

@@ -244,6 +244,40 @@ def test_color_image_colours():
     assert small.shape == (48, 64, 3) and small.any()
 
 
+def test_text_grid_file_roundtrip(tmp_path):
+    """TsdGrid::storeGrid / TsdGrid(file) (TsdGrid.cpp:548-607, :25-110): header, tile identifiers, 6-digit values,
+    halo not stored."""
+    gc = synth.GridConfig(8, 0.1)
+    geo = synth.ScanGeometry.full_circle_360()
+    world = synth.World("room", gc)
+    g = O.Grid(gc.map_size_log2, gc.cell_size, gc.max_trunc)
+    pose = synth.pose_matrix(world.start[0], world.start[1], 0.1)
+    far = np.full(geo.beams, 9.0, dtype=np.float32)
+    for r32 in (world.scan(world.start[0], world.start[1], 0.1, geo), far):
+        data, mask = O.ingest_f32(r32, 30.0, geo.angle_increment)
+        g.push(pose, data, mask, geo.angle_increment, geo.angle_min, 30.0, 0.001, 2.0)
+    path = tmp_path / "a.grid"
+    assert g.store_text(path)
+    lines = path.read_text().split("\n")
+    assert lines[:4] == ["0.1", "5", "8", "0.3"]
+    flags, iw, tsd, w = g.dump()
+    n_content, n_empty = int(flags.sum()), int(((flags == 0) & (iw > 0)).sum())
+    assert len(lines) - 1 == 4 + g.tiles + n_empty + n_content * 2 * 32 * 32
+    g2 = O.Grid.load_text(path, gc.cell_size)
+    f2, iw2, tsd2, w2 = g2.dump()
+    un = flags == 0                                           # (a content tile's _initWeight is not in the file)
+    assert np.array_equal(flags, f2) and np.allclose(iw[un], iw2[un], rtol=1e-5)
+    a = tsd.reshape(-1, 33, 33)[flags.astype(bool)][:, :32, :32]
+    b = tsd2.reshape(-1, 33, 33)[flags.astype(bool)][:, :32, :32]
+    m = ~np.isnan(a)
+    assert np.array_equal(np.isnan(b), ~m) and np.allclose(a[m], b[m], rtol=1e-5, atol=1e-12)
+    assert np.isnan(tsd2.reshape(-1, 33, 33)[flags.astype(bool)][:, 32, :]).all()
+    path2 = tmp_path / "b.grid"
+    g2.store_text(path2)
+    assert path2.read_bytes() == path.read_bytes()            # storing what was loaded reproduces the file
+    assert O.Grid.load_text(tmp_path / "missing.grid", gc.cell_size) is None
+
+
 def test_occupancy_values_and_persistence():
     gc = synth.GridConfig(8, 0.1)
     geo = synth.ScanGeometry.full_circle_360()

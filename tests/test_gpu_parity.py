@@ -384,6 +384,56 @@ def test_color_image_matches_oracle(oracle):
     assert (full.sum(axis=2) == 0).any()                                                     # unseen (black)
 
 
+def test_text_grid_file_matches_oracle(oracle, tmp_path):
+    """SURVEY 8(f) N2: TsdGrid::storeGrid / TsdGrid(file) (TsdGrid.cpp:548-607, :25-110), the reference's text format:
+    the file written from the device grid is byte-identical to the oracle's, loading it gives the same grid on both
+    sides (interior cells at the file's 6 digits, halos at their init value until the next push), and the ray cast /
+    the next push on the loaded grids agree."""
+    gc = synth.GridConfig(8, 0.05)
+    geo = synth.ScanGeometry.full_circle_360()
+    world = synth.World("room", gc)
+    og, dg = make_pair(oracle, gc)
+    near = np.full(geo.beams, 2.0, dtype=np.float32)
+    for k, r in enumerate((None, near, None)):                # content tiles, empty-with-weight tiles, untouched tiles
+        push_both(oracle, og, dg, world, geo, 3 * k, ranges_f32=r)
+    fo, fh = tmp_path / "oracle.grid", tmp_path / "hip.grid"
+    assert og.store_text(fo)
+    dg.store_text(fh)
+    bo, bh = fo.read_bytes(), fh.read_bytes()
+    assert bo == bh and len(bo) > 1000
+    head = bo.split(b"\n")[:4]
+    assert head == [b"0.05", b"5", b"8", b"0.15"]
+    # load into fresh grids
+    og2 = oracle.Grid.load_text(fo, gc.cell_size)
+    dg2 = capi.TsdGridDevice(gc.map_size_log2, gc.cell_size, gc.max_trunc)
+    dg2.load_text(fh)
+    d_o, d_h = og2.dump(), dg2.download_tiles()
+    H.assert_grids_equal(d_o, d_h, 0.0)
+    flags, iw, tsd, w = d_h
+    f0 = og.dump()
+    un = flags == 0                                           # (a content tile's _initWeight is not in the file)
+    assert np.array_equal(flags, f0[0]) and np.allclose(iw[un], f0[1][un], rtol=1e-5) and (iw[~un] == 0).all()
+    t = tsd.reshape(-1, 33, 33)[flags.astype(bool)]
+    t0 = f0[2].reshape(-1, 33, 33)[flags.astype(bool)]
+    assert np.isnan(t[:, 32, :]).all() and np.isnan(t[:, :, 32]).all()          # the halo is not stored
+    both = ~np.isnan(t0[:, :32, :32])
+    assert np.array_equal(np.isnan(t[:, :32, :32]), ~both)
+    assert np.allclose(t[:, :32, :32][both], t0[:, :32, :32][both], rtol=1e-5, atol=1e-12)
+    # the loaded grids behave alike: ray cast and the next push
+    pose, _ = H.sensor_pose(world, 2)
+    rl, rw = H.world_rays(oracle, geo, pose, gc.cell_size)
+    co, no, mo, cnt_o = og2.raycast(pose, rw, H.MIN_RANGE, H.MAX_RANGE)
+    cd, nd, md, cnt_d = dg2.raycast(pose, rw, H.MIN_RANGE, H.MAX_RANGE)
+    assert cnt_o == cnt_d and np.array_equal(mo, md)
+    so, sd = push_both(oracle, og2, dg2, world, geo, 9)
+    assert so == sd
+    H.assert_grids_equal(og2.dump(), dg2.download_tiles(), TOL_CELL)
+    # a file of another layout is refused
+    other = capi.TsdGridDevice(9, gc.cell_size, gc.max_trunc)
+    with pytest.raises(capi.TsdError):
+        other.load_text(fh)
+
+
 def test_push_degenerate_scans(oracle):
     """All beams masked / all infinite / a single valid beam / every beam at max range: same tile
     classification and cells on both sides, no crash, nothing updated where nothing is visible."""
