@@ -345,6 +345,7 @@ void tsd_destroy(tsd_ctx* ctx)
 
 int tsd_reset(tsd_ctx* ctx)
 {
+  if (ctx) ctx->epoch++;                  // (invalidates ray casts enqueued ahead of their scan)
   if (!ctx) return TSD_E_ARG;
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   GridDev& g = ctx->grid;
@@ -366,6 +367,7 @@ int tsd_reset(tsd_ctx* ctx)
 
 int tsd_set_max_truncation(tsd_ctx* ctx, double val)
 {
+  if (ctx) ctx->epoch++;                  // (invalidates ray casts enqueued ahead of their scan)
   if (!ctx) return TSD_E_ARG;
   // TsdGrid::setMaxTruncation (TsdGrid.cpp:206-215): at least 2 x cell size
   if (val < 2 * ctx->grid.cs) val = 2 * ctx->grid.cs;
@@ -393,6 +395,7 @@ double tsd_max_y(const tsd_ctx* ctx) { return ctx ? ctx->grid.max_y : 0.0; }
 
 int tsd_free_footprint(tsd_ctx* ctx, const double center[2], double width, double height)
 {
+  if (ctx) ctx->epoch++;                  // (invalidates ray casts enqueued ahead of their scan)
   if (!ctx || !center) return TSD_E_ARG;
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const GridDev& g = ctx->grid;
@@ -413,6 +416,7 @@ int tsd_push(tsd_ctx* ctx, const double pose33[9], const double* ranges, const u
              int beams, double ang_res, double phi_min, double max_range, double min_range,
              double low_refl_range, tsd_push_stats* stats)
 {
+  if (ctx) ctx->epoch++;                  // (invalidates ray casts enqueued ahead of their scan)
   if (!ctx || !pose33 || !ranges || !mask) return TSD_E_ARG;
   if (beams < 1 || beams > TSD_MAX_BEAMS) return set_error(ctx, TSD_E_CAPACITY, "beams out of range", hipSuccess);
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -450,6 +454,7 @@ int tsd_raycast(tsd_ctx* ctx, const double pose33[9], const double* rays_world_2
                 double min_range, double max_range, double* coords_2B, double* normals_2B,
                 uint8_t* mask_B, int* n_valid)
 {
+  if (ctx) ctx->epoch++;                  // (invalidates ray casts enqueued ahead of their scan)
   if (!ctx || !pose33 || !rays_world_2xB || !coords_2B || !normals_2B || !mask_B) return TSD_E_ARG;
   if (beams < 1 || beams > TSD_MAX_BEAMS) return set_error(ctx, TSD_E_CAPACITY, "beams out of range", hipSuccess);
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -494,6 +499,7 @@ int tsd_icp_normals(tsd_ctx* ctx, const double* model_xy, const double* model_no
                     const double* scene_xy, int n_scene, const double pose33[9], const tsd_icp_params* params,
                     tsd_icp_result* result)
 {
+  if (ctx) ctx->epoch++;                  // (invalidates ray casts enqueued ahead of their scan)
   if (!ctx || !pose33 || !params || !result || n_model < 0 || n_scene < 0) return TSD_E_ARG;
   if (params->estimator != TSD_ESTIMATOR_CLOSED_FORM && params->estimator != TSD_ESTIMATOR_POINT_TO_LINE)
     return set_error(ctx, TSD_E_ARG, "tsd_icp_params.estimator", hipSuccess);
@@ -557,6 +563,7 @@ int tsd_localize(tsd_ctx* ctx, const double pose33[9], const double* rays_world_
                  double min_range, double max_range, const tsd_icp_params* params,
                  tsd_icp_result* result)
 {
+  if (ctx) ctx->epoch++;                  // (invalidates ray casts enqueued ahead of their scan)
   if (!ctx || !pose33 || !rays_world_2xB || !rays_local_2xB || !ranges || !mask || !params || !result) return TSD_E_ARG;
   if (beams < 1 || beams > TSD_MAX_BEAMS || beams > TSD_MAX_ICP_POINTS)
     return set_error(ctx, TSD_E_CAPACITY, "beams out of range for fused localize", hipSuccess);
@@ -640,6 +647,7 @@ int tsd_download_tiles(tsd_ctx* ctx, uint8_t* initialized, double* init_weight, 
 int tsd_upload_tiles(tsd_ctx* ctx, const uint8_t* initialized, const double* init_weight,
                      const double* tsd_in, const double* weight_in)
 {
+  if (ctx) ctx->epoch++;                  // (invalidates ray casts enqueued ahead of their scan)
   if (!ctx || !initialized || !init_weight || !tsd_in || !weight_in) return TSD_E_ARG;
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -908,6 +916,7 @@ void tsd_sensor_destroy(tsd_sensor* s)
 int tsd_sensor_set_pose(tsd_sensor* s, const double pose33[9], const double* rays_world_2xB,
                         const double* rays_local_2xB)
 {
+  if (s && s->ctx) s->ctx->epoch++;
   if (!s || !pose33 || !rays_world_2xB || !rays_local_2xB) return TSD_E_ARG;
   tsd_ctx* ctx = s->ctx;
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -971,11 +980,17 @@ int tsd_scan(tsd_sensor* s, const double* ranges, const uint8_t* mask, const uin
   if (rc != TSD_OK) return rc;
   TSD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_tables, ctx->stream2));
 
+  // The ray cast needs nothing from the scan (its pose arguments were left on the device by the previous
+  // registration), so the previous tsd_scan enqueued it right behind its push; it is launched here only if
+  // something touched the grid, the sensor or the context's ray-cast outputs since.
   RaycastArgs ra;
   std::memset(&ra, 0, sizeof(ra));
   ra.beams = s->beams;                                   // grid size of the launch; the rest is read on the device
-  rc = launch_raycast(ctx, ra, &s->d_state->rc, s->d_rays);
-  if (rc != TSD_OK) return rc;
+  if (!(s->rc_pending && s->rc_epoch == ctx->epoch)) {
+    rc = launch_raycast(ctx, ra, &s->d_state->rc, s->d_rays);
+    if (rc != TSD_OK) return rc;
+  }
+  s->rc_pending = false;
   IcpArgs ia;
   const double ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   fill_icp_args(ia, ident, params);
@@ -1001,6 +1016,12 @@ int tsd_scan(tsd_sensor* s, const double* ranges, const uint8_t* mask, const uin
   // the registration moves the sensor by at most the gate (a larger step is rejected: pose unchanged)
   rc = launch_push(ctx, pa, s->pos[0], s->pos[1], gates->reg_trs_max, &s->d_state->push, d_ranges, d_mask_push);
   if (rc != TSD_OK) return rc;
+  ctx->epoch++;                                          // the grid changes
+  // the next scan's ray cast, right behind the push (see above): the host's work on the next scan no longer sits
+  // between this push and that ray cast
+  rc = launch_raycast(ctx, ra, &s->d_state->rc, s->d_rays);
+  if (rc != TSD_OK) return rc;
+  s->rc_pending = true; s->rc_epoch = ctx->epoch;
   // The result is known once k_scan_post has run; the push kernels behind it only touch the grid, and
   // whatever the caller enqueues next is ordered behind them on the stream.  So the host does not wait for
   // the stream: it polls the sequence number and prepares the next scan while the push is still running.

@@ -126,6 +126,7 @@ struct tsd_ctx {
   uint32_t* d_list_win = nullptr;           // [tiles] beams a listed tile can project to (lo | hi << 16)
   unsigned int* d_list_cnt = nullptr;       // [2] its length, by push parity
   unsigned int push_parity = 0;
+  unsigned long long epoch = 0;             // bumped by everything that changes the grid, a sensor pose or the ctx's ray-cast outputs
   hipStream_t stream2 = nullptr;             // side stream: the tables are built while ray cast / ICP run
   hipEvent_t ev_tables = nullptr;
 
@@ -184,6 +185,8 @@ struct tsd_sensor {
   tsd::ScanResultDev* d_result = nullptr;   // device address of h_result
   unsigned long long seq = 0;
   double pos[2] = {0, 0};          // host mirror of the sensor position (window of the push launches)
+  bool rc_pending = false;         // the next scan's ray cast was enqueued behind this scan's push ...
+  unsigned long long rc_epoch = 0; // ... when the context was in this state
 };
 
 namespace tsd {

@@ -434,6 +434,43 @@ def test_text_grid_file_matches_oracle(oracle, tmp_path):
         other.load_text(fh)
 
 
+def test_fused_scan_with_host_calls_in_between(oracle):
+    """tsd_scan enqueues the NEXT scan's ray cast right behind its push.  Whatever touches the grid, the sensor or
+    the context's ray-cast outputs in between (another push, a freed footprint, a new sensor pose, an unfused ray
+    cast, a map upload) must make the next tsd_scan cast again: the loop with such calls interleaved has to equal
+    the same loop run through the unfused calls."""
+    from tests.slam_driver import HipSlam, HipSlamFused, slam_kwargs
+    gc = synth.GridConfig(9, 0.05)
+    geo = synth.ScanGeometry.full_circle_360()
+    world = synth.World("room", gc)
+    poses = synth.trajectory(world, 10)
+    scans = synth.scans_for(world, geo, poses)
+    kw = slam_kwargs(gc, geo)
+    a, b = HipSlamFused(oracle, **kw), HipSlam(oracle, fused=False, **kw)
+
+    def meddle(s, k):
+        g = s.grid
+        if k == 2:      # an extra push from somewhere else (e.g. a second sensor's mapping thread)
+            pose = synth.pose_matrix(world.start[0] - 1.0, world.start[1] + 0.5, 1.0)
+            data, mask = oracle.ingest_f32(world.scan(world.start[0] - 1.0, world.start[1] + 0.5, 1.0, geo), H.MAX_RANGE, geo.angle_increment)
+            g.push(pose, data, mask, geo.angle_increment, geo.angle_min, H.MAX_RANGE, H.MIN_RANGE, H.LOW_REFL)
+        elif k == 4:
+            g.free_footprint([world.start[0] + 2.0, world.start[1] - 1.0], 0.6, 0.6)
+        elif k == 5:    # an unfused ray cast overwrites the context's model buffers
+            rl, rw = H.world_rays(oracle, geo, synth.pose_matrix(world.start[0], world.start[1], 0.7), gc.cell_size)
+            g.raycast(synth.pose_matrix(world.start[0], world.start[1], 0.7), rw, H.MIN_RANGE, H.MAX_RANGE)
+        elif k == 7:    # the map is replaced by itself through the host
+            g.upload_tiles(*g.download_tiles())
+
+    for k in range(len(scans)):
+        ra, rb = a.process_scan(scans[k]), b.process_scan(scans[k])
+        d, ang = H.pose_delta(ra["pose"], rb["pose"])
+        assert d <= 1e-9 and ang <= 1e-9, f"scan {k}: {d} {ang}"
+        assert ra["pushed"] == rb["pushed"] and ra["pairs"] == rb["pairs"] and ra["valid_model"] == rb["valid_model"]
+        meddle(a, k); meddle(b, k)
+    H.assert_grids_equal(a.grid.download_tiles(), b.grid.download_tiles(), 0.0)
+
+
 def test_push_degenerate_scans(oracle):
     """All beams masked / all infinite / a single valid beam / every beam at max range: same tile
     classification and cells on both sides, no crash, nothing updated where nothing is visible."""
