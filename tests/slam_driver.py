@@ -33,7 +33,9 @@ class HipSlam:
         self.initialized = False
         self.params = self.grid.icp_params(kw["icp_iterations"], kw["dist_filter_max"], kw["dist_filter_min"])
 
-    def process_scan(self, ranges_f32):
+    def process_scan(self, ranges_f32, T_override=None):
+        """T_override: the registration result the STATE is advanced with (the oracle's, in the re-synced long runs:
+        out["T"] stays the device's own result, which is what gets compared); None = the device's."""
         o, kw, g = self.o, self.kw, self.grid
         r = np.array(ranges_f32, dtype=np.float32)
         r[r < kw["laser_min_range"]] = 0.0
@@ -79,8 +81,9 @@ class HipSlam:
             S = scene.reshape(-1, 2)[ms.astype(bool)]
             res_icp = g.icp(M, S, self.pose, self.params)
         T = res_icp.T
-        out["pairs"] = res_icp.pairs
-        out["T"] = T
+        out.update(pairs=res_icp.pairs, T=T, iterations=res_icp.iterations, icp_state=res_icp.state, rms=res_icp.rms)
+        if T_override is not None:
+            T = np.array(T_override, dtype=np.float64).reshape(3, 3)
         Tf = o.f64(T).reshape(9)
         if o.lib().ora_is_registration_error(o.d(Tf), kw["reg_trs_max"], kw["reg_sin_rot_max"]):
             out.update(pose=self.pose.copy(), reg_error=1)

@@ -1,0 +1,140 @@
+"""GPU parity on the workloads `bench.py` actually times (VERDICT r1 "next round" item 1):
+
+  * cfg2 / pillars over the bench's whole length (1 init + 5 warm-up + 200 timed scans), HIP and oracle side by
+    side.  RE-SYNCED run: both sides advance their state with the oracle's registration result, so every scan is
+    registered on identical inputs -- pairs / iterations / state / point counts exact, pose <= 1e-4 (north_star),
+    grids cell-for-cell equal at check points.  FREE-RUNNING run (the facade's fused tsd_scan, which is what
+    bench.py drives): its own results feed back through the map; the divergence from the oracle is reported
+    (gpurun_out/free_run_divergence.json) and bounded.
+  * cfg3 / "comb" at full size (16384^2): the bandwidth-stress scene of SURVEY 8(d).
+  * N1 (occupancy + colour image) at cfg2 size: the gridOffset quirk of RayCastAxisAligned2D.cpp:35,92 depends on
+    the number of tiles per side.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from ohm_tsd_slam_amd import capi, facade, synth
+from tests import helpers as H
+from tests.slam_driver import HipSlam, slam_kwargs
+
+pytestmark = pytest.mark.gpu
+
+BENCH_SCANS = 1 + 5 + 200      # bench.py defaults: init + warm-up + timed
+
+
+def _threads():
+    return max(1, min(32, os.cpu_count() or 1))
+
+
+def test_cfg2_pillars_bench_length(oracle):
+    gc, geo, scene = synth.CONFIGS["cfg2"]
+    n = BENCH_SCANS
+    world = synth.World(scene, gc)
+    poses = synth.trajectory(world, n)
+    scans = synth.scans_for(world, geo, poses)
+    geo_msg = synth.ScanGeometry(geo.beams, float(np.float32(geo.angle_min)), float(np.float32(geo.angle_increment)))
+    kw = slam_kwargs(gc, geo_msg, nn_mode=1, threads=_threads())
+    so = oracle.Slam(**kw)
+    sh = HipSlam(oracle, fused=True, **kw)                       # re-synced: state advanced with the oracle's T
+    node = facade.SlamNode(facade.node_params(gc, geo), synchronous=True, fused=True)   # free-running (bench path)
+    worst_sync = (0.0, 0.0)
+    worst_cell = 0.0
+    free = dict(max_pos=0.0, max_yaw=0.0, first_pair_flip=None, per_scan=[])
+    pushes = 0
+    for k in range(n):
+        ro = so.process_scan(scans[k])
+        To = np.array(ro.T[:]).reshape(3, 3)
+        Po = np.array(ro.pose[:]).reshape(3, 3)
+        rh = sh.process_scan(scans[k], T_override=To if k > 0 else None)
+        if k > 0:
+            assert not ro.no_model and not rh["no_model"], f"scan {k}"
+            assert (ro.pairs, ro.iterations, ro.icp_state, ro.valid_model) == \
+                   (rh["pairs"], rh["iterations"], rh["icp_state"], rh["valid_model"]), f"scan {k}"
+            assert abs(ro.rms - rh["rms"]) <= 1e-9, f"scan {k}"
+            d, a = H.pose_delta(To, rh["T"])                    # the registration itself, on identical inputs
+            assert d <= 1e-4 and a <= 1e-4, f"scan {k}: T differs by {d} m {a} rad"
+            worst_sync = (max(worst_sync[0], d), max(worst_sync[1], a))
+            assert bool(ro.pushed) == bool(rh["pushed"]) and bool(ro.reg_error) == bool(rh["reg_error"])
+            assert np.max(np.abs(Po - rh["pose"])) <= 1e-12, f"scan {k}: re-synced state drifted"
+        pushes += int(ro.pushed)
+        if k in (60, 130, n - 1):                                # cell-for-cell: identical poses => identical grids
+            dt, dw = H.assert_grids_equal(so.grid.dump(), sh.grid.download_tiles(), 1e-9)
+            worst_cell = max(worst_cell, dt, dw)
+        # free-running facade
+        node.laser(scans[k], geo.angle_min, geo.angle_increment)
+        rf = node.report()
+        d, a = H.pose_delta(Po, rf["pose"])
+        free["max_pos"] = max(free["max_pos"], d); free["max_yaw"] = max(free["max_yaw"], a)
+        if k > 0 and free["first_pair_flip"] is None and rf["pairs"] != ro.pairs:
+            free["first_pair_flip"] = k
+        if free["first_pair_flip"] is None:
+            assert d <= 1e-6 and a <= 1e-6, f"free run, scan {k}: {d} m {a} rad before any pair decision flipped"
+        free["per_scan"].append([k, d, a, int(rf.get("pairs", 0)), int(ro.pairs)])
+    assert pushes >= 200
+    # free-running: a flipped pair decision gives a transient difference that the registration contracts again
+    assert free["max_pos"] <= 5e-3 and free["max_yaw"] <= 5e-3, free
+    eo = math.hypot(Po[0, 2] - poses[-1, 0], Po[1, 2] - poses[-1, 1])
+    free.update(scans=n, resynced_max_T_diff_m=worst_sync[0], resynced_max_T_diff_rad=worst_sync[1],
+                oracle_tracking_error_m=eo, resynced_max_cell_diff=worst_cell)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "free_run_divergence.json"), "w") as f:
+        json.dump(free, f)
+    print("cfg2 x %d scans: re-synced max |dT| %.2e m %.2e rad; free-running max |dpose| %.2e m %.2e rad, first pair flip %s"
+          % (n, worst_sync[0], worst_sync[1], free["max_pos"], free["max_yaw"], free["first_pair_flip"]))
+    node.close()
+
+
+def test_cfg3_comb_full_size(oracle):
+    """16384^2 @ 0.01 m, scene "comb" (the bandwidth stress): push statistics, tile states and the
+    ray cast's hit mask equal to the oracle's."""
+    gc, geo, _ = synth.CONFIGS["cfg3"]
+    world = synth.World("comb", gc)
+    og = oracle.Grid(gc.map_size_log2, gc.cell_size, gc.max_trunc)
+    dg = capi.TsdGridDevice(gc.map_size_log2, gc.cell_size, gc.max_trunc)
+    for k in range(3):
+        pose, (x, y, yaw) = H.sensor_pose(world, 5 * k)
+        r32 = world.scan(x, y, yaw, geo)
+        data, mask = oracle.ingest_f32(r32, H.MAX_RANGE, geo.angle_increment)
+        so = og.push(pose, data, mask, geo.angle_increment, geo.angle_min, H.MAX_RANGE, H.MIN_RANGE, H.LOW_REFL, threads=_threads())
+        sd = dg.push(pose, data, mask, geo.angle_increment, geo.angle_min, H.MAX_RANGE, H.MIN_RANGE, H.LOW_REFL)
+        assert so == sd, f"push {k}: stats differ\n oracle {so}\n hip    {sd}"
+    assert sd["tiles_total"] == 262144 and sd["tiles_update"] > 8000 and sd["cells_updated"] > 3000000
+    assert int(mask.sum()) == 947                                  # 947 of 1081 beams stay valid
+    oi, oiw = og.tile_state()
+    di, diw = dg.download_tile_state()
+    assert np.array_equal(oi, di) and np.array_equal(oiw, diw)
+    pose, _ = H.sensor_pose(world, 7)
+    rl, rw = H.world_rays(oracle, geo, pose, gc.cell_size)
+    co, no, mo, cnt_o = og.raycast(pose, rw, H.MIN_RANGE, H.MAX_RANGE, threads=_threads())
+    cd, nd, md, cnt_d = dg.raycast(pose, rw, H.MIN_RANGE, H.MAX_RANGE)
+    assert np.array_equal(mo, md) and cnt_o == cnt_d and cnt_o > 0.5 * geo.beams
+    sel = np.repeat(mo.astype(bool), 2)
+    assert np.max(np.abs(co[sel] - cd[sel])) <= 1e-9 and np.max(np.abs(no[sel] - nd[sel])) <= 1e-9
+
+
+def test_occupancy_and_colour_image_at_cfg2_size(oracle):
+    gc, geo, scene = synth.CONFIGS["cfg2"]
+    world = synth.World(scene, gc)
+    og = oracle.Grid(gc.map_size_log2, gc.cell_size, gc.max_trunc)
+    dg = capi.TsdGridDevice(gc.map_size_log2, gc.cell_size, gc.max_trunc)
+    content = np.full(gc.cells * gc.cells, -1, dtype=np.int8)
+    near = np.full(geo.beams, 2.0, dtype=np.float32)
+    for k, r in enumerate((None, near, None)):                 # content, emptied and untouched tiles
+        pose, (x, y, yaw) = H.sensor_pose(world, 6 * k)
+        r32 = world.scan(x, y, yaw, geo) if r is None else r
+        data, mask = oracle.ingest_f32(r32, H.MAX_RANGE, geo.angle_increment)
+        og.push(pose, data, mask, geo.angle_increment, geo.angle_min, H.MAX_RANGE, H.MIN_RANGE, H.LOW_REFL, threads=_threads())
+        dg.push(pose, data, mask, geo.angle_increment, geo.angle_min, H.MAX_RANGE, H.MIN_RANGE, H.LOW_REFL, want_stats=False)
+        oo, no = og.occupancy(content, False, 2)               # `content` persists like ThreadGrid::_occGridContent
+        od, nd = dg.occupancy(False, 2)
+        assert no == nd and no > 0
+        assert np.array_equal(oo.reshape(gc.cells, gc.cells), od), \
+            f"push {k}: {np.count_nonzero(oo.reshape(gc.cells, gc.cells) != od)} cells differ"
+    assert (od == 100).sum() > 1000 and (od == 0).sum() > 100000
+    for (w, h) in ((gc.cells, gc.cells), (1000, 777)):
+        assert np.array_equal(og.color_image(w, h), dg.color_image(w, h))
