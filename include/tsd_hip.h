@@ -198,6 +198,22 @@ int tsd_download_tiles(tsd_ctx* ctx, uint8_t* initialized, double* init_weight, 
                        double* weight);
 int tsd_upload_tiles(tsd_ctx* ctx, const uint8_t* initialized, const double* init_weight,
                      const double* tsd, const double* weight);
+/* Digest of that canonical dump without moving it: an order-free 64-bit hash over (tile flag, initWeight, the bit
+ * patterns of every cell's tsd and weight of the initialised tiles, halo included; NaN and -0.0 canonicalised), the
+ * number of non-NaN cells and the sums of tsd / weight over them (per tile, then in tile order).  The hash of the
+ * oracle's dump is computed by the same rule (oracle/tsd_oracle.c: ora_grid_digest); tests/golden pins it for
+ * BASELINE configs 1-3. */
+typedef struct {
+  uint64_t hash;
+  int64_t  cells_valid;
+  int32_t  tiles_initialized;
+  int32_t  reserved;
+  double   sum_tsd, sum_weight;
+} tsd_grid_digest_t;
+int tsd_grid_digest(tsd_ctx* ctx, tsd_grid_digest_t* out);
+/* bits per stored cell value of this build: 64 (fp64 like the reference, cells bit-identical to the oracle's) or 32
+ * (libtsd_hip_q32.so: fixed point, 8 bytes per cell; within n * 2^-27 of the fp64 result after n pushes) */
+int tsd_storage_bits(void);
 /* tile flags only (cheap) */
 int tsd_download_tile_state(tsd_ctx* ctx, uint8_t* initialized, double* init_weight);
 /* TsdGrid::storeGrid(path) (TsdGrid.cpp:548-607) and the file constructor TsdGrid(path, FILE_SOURCE) (:25-110): the

@@ -14,6 +14,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtsd_hip.so")
+# the same library built with 32-bit fixed-point cell storage (-DTSD_STORAGE_Q32, csrc/tsd_device.hpp)
+LIB_PATH_Q32 = os.path.join(_HERE, "lib", "libtsd_hip_q32.so")
 
 TILE_CELLS = 1089
 MAX_BEAMS = 4096
@@ -69,6 +71,16 @@ class IcpResult(C.Structure):
     ]
 
 
+class GridDigest(C.Structure):
+    """tsd_grid_digest_t"""
+    _fields_ = [("hash", C.c_uint64), ("cells_valid", C.c_int64), ("tiles_initialized", C.c_int32),
+                ("reserved", C.c_int32), ("sum_tsd", C.c_double), ("sum_weight", C.c_double)]
+
+    def as_dict(self):
+        return dict(hash=int(self.hash), cells_valid=int(self.cells_valid), tiles_initialized=int(self.tiles_initialized),
+                    sum_tsd=float(self.sum_tsd), sum_weight=float(self.sum_weight))
+
+
 class GateParams(C.Structure):
     _fields_ = [("reg_trs_max", C.c_double), ("reg_sin_rot_max", C.c_double),
                 ("trs_min", C.c_double), ("rot_min", C.c_double)]
@@ -122,6 +134,8 @@ ABI = {
     "tsd_download_tiles": (C.c_int, [C.c_void_p, _u8p, _dp, _dp, _dp]),
     "tsd_upload_tiles": (C.c_int, [C.c_void_p, _u8p, _dp, _dp, _dp]),
     "tsd_download_tile_state": (C.c_int, [C.c_void_p, _u8p, _dp]),
+    "tsd_grid_digest": (C.c_int, [C.c_void_p, C.POINTER(GridDigest)]),
+    "tsd_storage_bits": (C.c_int, []),
     "tsd_occupancy": (C.c_int, [C.c_void_p, _i8p, C.c_int, C.c_int, _ip]),
     "tsd_occupancy_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "tsd_calibrate_rmw": (C.c_int, [C.c_void_p, C.c_int64, C.c_int]),
@@ -182,8 +196,10 @@ class TsdGridDevice:
     """One TSD grid resident in the HBM of one GPU (``obvious::TsdGrid`` as constructed by
     ``SlamNode::initialize``, SlamNode.cpp:77-78)."""
 
-    def __init__(self, map_size_log2: int, cell_size: float, max_trunc: float, device: int = 0):
-        self.lib = load_library()
+    def __init__(self, map_size_log2: int, cell_size: float, max_trunc: float, device: int = 0, storage: str = "f64"):
+        """storage: "f64" (the reference's cells, lib/libtsd_hip.so) or "q32" (8 bytes per cell, lib/libtsd_hip_q32.so)"""
+        self.lib = load_library() if storage == "f64" else load_library(LIB_PATH_Q32)
+        assert self.lib.tsd_storage_bits() == (64 if storage == "f64" else 32)
         if self.lib.tsd_device_count() <= 0:
             raise TsdError("no HIP device visible: the TSD hot path only exists as gfx950 kernels")
         self.h = self.lib.tsd_create(device, map_size_log2, cell_size, max_trunc)
@@ -299,6 +315,11 @@ class TsdGridDevice:
         init = np.ascontiguousarray(init, dtype=np.uint8)
         iw, tsd, w = _f64(iw), _f64(tsd), _f64(w)
         self._check(self.lib.tsd_upload_tiles(self.h, _u8(init), _d(iw), _d(tsd), _d(w)), "tsd_upload_tiles")
+
+    def digest(self) -> dict:
+        d = GridDigest()
+        self._check(self.lib.tsd_grid_digest(self.h, C.byref(d)), "tsd_grid_digest")
+        return d.as_dict()
 
     def occupancy(self, inflate=False, inflate_factor=2):
         occ = np.zeros(self.cells * self.cells, dtype=np.int8)

@@ -47,7 +47,7 @@ static hipEvent_t pool_get(tsd_ctx* ctx)
 ScopedKernelTimer::ScopedKernelTimer(tsd_ctx* c, const char* n, bool around_) : ctx(c), name(n), around(around_)
 {
   if (!kernel_is_timed(ctx, n)) return;
-  if (ctx->profile_every > 1 && (ctx->profile_tick++ % ctx->profile_every) != 0) return;
+  if (ctx->profile_every > 1 && (ctx->timers[n].tick++ % ctx->profile_every) != 0) return;   // every n-th launch of THIS kernel
   a = pool_get(ctx); b = pool_get(ctx);
   if (!a || !b) { a = b = nullptr; return; }
   if (around) hipEventRecord(a, ctx->stream);
@@ -271,8 +271,8 @@ tsd_ctx* tsd_create(int device, int map_size_log2, double cell_size, double max_
   const size_t T = (size_t)g.tiles;
   A(hipMalloc(&g.flags, T));
   A(hipMalloc(&g.init_weight, T * sizeof(double)));
-  A(hipMalloc(&g.tsd, T * TILE_STRIDE * sizeof(double)));
-  A(hipMalloc(&g.weight, T * TILE_STRIDE * sizeof(double)));
+  A(hipMalloc(&g.tsd, T * TILE_STRIDE * sizeof(tsd_cell_t)));
+  A(hipMalloc(&g.weight, T * TILE_STRIDE * sizeof(w_cell_t)));
   A(hipMalloc(&g.negmask, T * sizeof(unsigned long long)));
   A(hipMalloc(&ctx->d_rmq2[0], push_rmq_bytes(TSD_MAX_BEAMS)));
   A(hipMalloc(&ctx->d_rmq2[1], push_rmq_bytes(TSD_MAX_BEAMS)));
@@ -623,6 +623,9 @@ int tsd_download_tile_state(tsd_ctx* ctx, uint8_t* initialized, double* init_wei
   return TSD_OK;
 }
 
+// tiles per chunk of the canonical tile I/O: 2 x 4096 x 1089 doubles = 71 MB of device staging
+static constexpr int kIoChunk = 4096;
+
 int tsd_download_tiles(tsd_ctx* ctx, uint8_t* initialized, double* init_weight, double* tsd_out,
                        double* weight_out)
 {
@@ -631,17 +634,31 @@ int tsd_download_tiles(tsd_ctx* ctx, uint8_t* initialized, double* init_weight, 
   if (rc != TSD_OK) return rc;
   const GridDev& g = ctx->grid;
   const double qnan = std::nan("");
-  for (int p = 0; p < g.tiles; p++) {
-    double* t = tsd_out + (size_t)p * TSD_TILE_CELLS;
-    double* w = weight_out + (size_t)p * TSD_TILE_CELLS;
-    if (initialized[p]) {
-      TSD_HIP_CHECK(ctx, hipMemcpy(t, g.tsd + (size_t)p * TILE_STRIDE, TSD_TILE_CELLS * sizeof(double), hipMemcpyDeviceToHost));
-      TSD_HIP_CHECK(ctx, hipMemcpy(w, g.weight + (size_t)p * TILE_STRIDE, TSD_TILE_CELLS * sizeof(double), hipMemcpyDeviceToHost));
-    } else {
-      for (int i = 0; i < TSD_TILE_CELLS; i++) { t[i] = qnan; w[i] = 0.0; }
+  const int chunk = g.tiles < kIoChunk ? g.tiles : kIoChunk;
+  double* d_t = nullptr; double* d_w = nullptr;
+  const size_t cb = (size_t)chunk * TSD_TILE_CELLS * sizeof(double);
+  TSD_HIP_CHECK(ctx, hipMalloc(&d_t, cb));
+  hipError_t e = hipMalloc(&d_w, cb);
+  if (e != hipSuccess) { hipFree(d_t); return set_error(ctx, TSD_E_HIP, "tsd_download_tiles staging", e); }
+  for (int t0 = 0; t0 < g.tiles && rc == TSD_OK; t0 += chunk) {
+    const int n = g.tiles - t0 < chunk ? g.tiles - t0 : chunk;
+    bool any = false;
+    for (int p = t0; p < t0 + n; p++) any |= initialized[p] != 0;
+    double* t = tsd_out + (size_t)t0 * TSD_TILE_CELLS;
+    double* w = weight_out + (size_t)t0 * TSD_TILE_CELLS;
+    if (!any) {                                    // most of a big grid: nothing to fetch
+      for (size_t i = 0; i < (size_t)n * TSD_TILE_CELLS; i++) { t[i] = qnan; w[i] = 0.0; }
+      continue;
     }
+    rc = launch_export_tiles(ctx, t0, n, d_t, d_w);
+    if (rc != TSD_OK) break;
+    e = hipMemcpyAsync(t, d_t, (size_t)n * TSD_TILE_CELLS * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(w, d_w, (size_t)n * TSD_TILE_CELLS * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = set_error(ctx, TSD_E_HIP, "tsd_download_tiles copy", e);
   }
-  return TSD_OK;
+  hipFree(d_t); hipFree(d_w);
+  return rc;
 }
 
 int tsd_upload_tiles(tsd_ctx* ctx, const uint8_t* initialized, const double* init_weight,
@@ -655,16 +672,62 @@ int tsd_upload_tiles(tsd_ctx* ctx, const uint8_t* initialized, const double* ini
   const size_t T = (size_t)g.tiles;
   TSD_HIP_CHECK(ctx, hipMemcpy(g.flags, initialized, T, hipMemcpyHostToDevice));
   TSD_HIP_CHECK(ctx, hipMemcpy(g.init_weight, init_weight, T * sizeof(double), hipMemcpyHostToDevice));
-  for (int p = 0; p < g.tiles; p++) {
-    if (!initialized[p]) continue;
-    TSD_HIP_CHECK(ctx, hipMemcpy(g.tsd + (size_t)p * TILE_STRIDE, tsd_in + (size_t)p * TSD_TILE_CELLS, TSD_TILE_CELLS * sizeof(double), hipMemcpyHostToDevice));
-    TSD_HIP_CHECK(ctx, hipMemcpy(g.weight + (size_t)p * TILE_STRIDE, weight_in + (size_t)p * TSD_TILE_CELLS, TSD_TILE_CELLS * sizeof(double), hipMemcpyHostToDevice));
+  const int chunk = g.tiles < kIoChunk ? g.tiles : kIoChunk;
+  double* d_t = nullptr; double* d_w = nullptr;
+  const size_t cb = (size_t)chunk * TSD_TILE_CELLS * sizeof(double);
+  TSD_HIP_CHECK(ctx, hipMalloc(&d_t, cb));
+  hipError_t e = hipMalloc(&d_w, cb);
+  if (e != hipSuccess) { hipFree(d_t); return set_error(ctx, TSD_E_HIP, "tsd_upload_tiles staging", e); }
+  int rc = TSD_OK;
+  for (int t0 = 0; t0 < g.tiles && rc == TSD_OK; t0 += chunk) {
+    const int n = g.tiles - t0 < chunk ? g.tiles - t0 : chunk;
+    bool any = false;
+    for (int p = t0; p < t0 + n; p++) any |= initialized[p] != 0;
+    if (!any) continue;
+    e = hipMemcpyAsync(d_t, tsd_in + (size_t)t0 * TSD_TILE_CELLS, (size_t)n * TSD_TILE_CELLS * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_w, weight_in + (size_t)t0 * TSD_TILE_CELLS, (size_t)n * TSD_TILE_CELLS * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) { rc = set_error(ctx, TSD_E_HIP, "tsd_upload_tiles copy", e); break; }
+    rc = launch_import_tiles(ctx, t0, n, d_t, d_w);
+    if (rc == TSD_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = set_error(ctx, TSD_E_HIP, "tsd_upload_tiles sync", hipGetLastError());
   }
-  int rc = launch_neg_scan(ctx);          // which tiles can show a sign change to the ray cast
+  hipFree(d_t); hipFree(d_w);
+  if (rc != TSD_OK) return rc;
+  rc = launch_neg_scan(ctx);              // which tiles can show a sign change to the ray cast
   if (rc != TSD_OK) return rc;
   TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return TSD_OK;
 }
+
+int tsd_grid_digest(tsd_ctx* ctx, tsd_grid_digest_t* out)
+{
+  if (!ctx || !out) return TSD_E_ARG;
+  TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const size_t T = (size_t)ctx->grid.tiles;
+  unsigned long long* d_o = nullptr; double* d_s = nullptr;
+  TSD_HIP_CHECK(ctx, hipMalloc(&d_o, T * 2 * sizeof(unsigned long long)));
+  hipError_t e = hipMalloc(&d_s, T * 2 * sizeof(double));
+  if (e != hipSuccess) { hipFree(d_o); return set_error(ctx, TSD_E_HIP, "tsd_grid_digest", e); }
+  int rc = launch_grid_digest(ctx, d_o, d_s);
+  std::vector<unsigned long long> ho(T * 2); std::vector<double> hs(T * 2); std::vector<uint8_t> fl(T);
+  if (rc == TSD_OK) {
+    e = hipMemcpyAsync(ho.data(), d_o, T * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(hs.data(), d_s, T * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(fl.data(), ctx->grid.flags, T, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = set_error(ctx, TSD_E_HIP, "tsd_grid_digest copy", e);
+  }
+  hipFree(d_o); hipFree(d_s);
+  if (rc != TSD_OK) return rc;
+  out->hash = 0; out->cells_valid = 0; out->tiles_initialized = 0; out->sum_tsd = 0.0; out->sum_weight = 0.0;
+  for (size_t p = 0; p < T; p++) {          // tile order: the sums are reproducible
+    out->hash += ho[2 * p]; out->cells_valid += (int64_t)ho[2 * p + 1];
+    out->sum_tsd += hs[2 * p]; out->sum_weight += hs[2 * p + 1];
+    out->tiles_initialized += fl[p] ? 1 : 0;
+  }
+  return TSD_OK;
+}
+
+int tsd_storage_bits(void) { return (int)(8 * sizeof(tsd_cell_t)); }
 
 int tsd_store_grid_text(tsd_ctx* ctx, const char* path)
 {
@@ -839,7 +902,7 @@ int tsd_profile_select(tsd_ctx* ctx, const char* kernels_csv)
   if (!ctx || !kernels_csv) return TSD_E_ARG;
   unsigned mask = 0;
   std::string csv(kernels_csv);
-  ctx->profile_every = 1; ctx->profile_tick = 0;
+  ctx->profile_every = 1;
   const size_t slash = csv.find('/');          // "names/n": time every n-th launch only
   if (slash != std::string::npos) {
     const int n = std::atoi(csv.c_str() + slash + 1);

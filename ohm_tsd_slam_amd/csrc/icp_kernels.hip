@@ -1081,11 +1081,14 @@ static int launch_icp_shape_est(tsd_ctx* ctx, const IcpArgs& a, int n, int cap, 
   const bool ptl = a.estimator == TSD_ESTIMATOR_POINT_TO_LINE;
   const size_t lds = icp_lds_bytes_for(cap, T, ptl);
   if (lds > 160u * 1024u) return set_error(ctx, TSD_E_CAPACITY, "registration does not fit the LDS of one CU (point-to-line: model normals too)", hipSuccess);
-  static size_t configured = 0;
-  if (lds > configured) {
-    TSD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_icp<R, MAXT, PTL>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = lds;
+  {
+    // the attribute is per device: remembered per context (and kernel instantiation), not per process
+    size_t& configured = ctx->lds_configured[reinterpret_cast<const void*>(k_icp<R, MAXT, PTL>)];
+    if (lds > configured) {
+      TSD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_icp<R, MAXT, PTL>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      configured = lds;
+    }
   }
   ScopedKernelTimer t(ctx, "icp");
   hipExtLaunchKernelGGL((k_icp<R, MAXT, PTL>), dim3(1), dim3(T), lds, ctx->stream, t.a, t.b, 0, a, P_dev, cap, ctx->d_model, ctx->d_scene,

@@ -21,7 +21,7 @@ __device__ __forceinline__ bool tile_processed(int X, int Y, int PX)
 // value an initialised tile writes for its local cell (ly,lx), lx/ly in 0..32 (:41-47)
 __device__ __forceinline__ int8_t occ_from_tsd(const GridDev& g, int p, int ly, int lx)
 {
-  const double t = g.tsd[(size_t)p * TILE_STRIDE + ly * TILE_PITCH + lx];
+  const double t = ld_tsd(g.tsd + (size_t)p * TILE_STRIDE + cell_off(lx, ly));
   return (t > 0.0) ? 0 : -1;
 }
 
@@ -45,8 +45,8 @@ k_occ_cells(GridDev g, int8_t* __restrict__ content, int8_t* __restrict__ out)
   uint32_t* c4 = reinterpret_cast<uint32_t*>(content + gi);
   uint32_t* o4 = reinterpret_cast<uint32_t*>(out + gi);
   if (own_proc && own_init) {
-    const double* t = g.tsd + (size_t)p * TILE_STRIDE + ly * TILE_PITCH + lx0;
-    const double t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
+    const tsd_cell_t* t = g.tsd + (size_t)p * TILE_STRIDE + ly * TILE_DIM + lx0;     // interior row, 4 cells
+    const double t0 = ld_tsd(t), t1 = ld_tsd(t + 1), t2 = ld_tsd(t + 2), t3 = ld_tsd(t + 3);
     const uint32_t v = (t0 > 0.0 ? 0u : 0xFFu) | (t1 > 0.0 ? 0u : 0xFF00u) | (t2 > 0.0 ? 0u : 0xFF0000u) | (t3 > 0.0 ? 0u : 0xFF000000u);
     *c4 = v; *o4 = v;
     return;
@@ -96,8 +96,8 @@ k_occ_mark(GridDev g, int8_t* __restrict__ out, int* __restrict__ count, int inf
   // the tile (33 x 33 doubles) through LDS: every cell is looked at by up to four scan positions
   __shared__ double T[TILE_CELLS];
   {
-    const double* Tg = g.tsd + (size_t)p * TILE_STRIDE;
-    for (int i = threadIdx.x; i < TILE_CELLS; i += 256) T[i] = Tg[i];
+    const tsd_cell_t* Tg = g.tsd + (size_t)p * TILE_STRIDE;
+    for (int i = threadIdx.x; i < TILE_CELLS; i += 256) T[canonical_of_off(i)] = ld_tsd(Tg + i);   // LDS copy in the 33 x 33 form
   }
   __syncthreads();
   const double cs = g.cs;
@@ -144,7 +144,7 @@ k_color_image(GridDev g, const double* __restrict__ pxs, const double* __restric
   bool is_empty = false;
   if (coord2cell(g, pxs[w], pys[h], p, lx, ly, dx, dy)) {
     const bool init = g.flags[p] != 0;
-    if (init) t = g.tsd[(size_t)p * TILE_STRIDE + ly * TILE_PITCH + lx];
+    if (init) t = ld_tsd(g.tsd + (size_t)p * TILE_STRIDE + cell_off(lx, ly));
     is_empty = !init && g.init_weight[p] > 0.0;                 // isEmpty(), TsdGridPartition.h:72
   }
   uint8_t r, gch, b;

@@ -399,17 +399,17 @@ k_push_update(GridDev g, PushArgs a_val, const PushArgs* __restrict__ a_dev, con
     const int p = (int)(entry & ((1u << KIND_SHIFT) - 1u));
     if (kind == KIND_HALO) continue;
 
-    double* __restrict__ T = g.tsd + (size_t)p * TILE_STRIDE;
-    double* __restrict__ W = g.weight + (size_t)p * TILE_STRIDE;
+    tsd_cell_t* __restrict__ T = g.tsd + (size_t)p * TILE_STRIDE;
+    w_cell_t* __restrict__ W = g.weight + (size_t)p * TILE_STRIDE;
     uint32_t rec = REC_RANGE_PASS;
 
     if (kind == KIND_EMPTY) {
       // all 33x33 cells, halo included; the average uses the NEW weight
-      for (int i = tid; i < TILE_CELLS; i += UPDATE_BLOCK) {
-        double t = T[i], w = W[i];
+      for (int i = tid; i < TILE_CELLS; i += UPDATE_BLOCK) {      // (interior, halo column, halo row: offsets 0..1088)
+        double t = ld_tsd(T + i), w = ld_w(W + i);
         if (isnan(t)) { w += 1.0; t = 1.0; }
         else { w = fmin(w + 1, MAX_WEIGHT); t = (t * (w - 1.0) + 1.0) / w; }
-        T[i] = t; W[i] = w;
+        st_tsd(T + i, t); st_w(W + i, w);
       }
       rec |= REC_EMPTIED_INIT;
       if (tid == 0) { tile_rec[p] = rec; tile_totals[(size_t)p * TOT_FIELDS + 5] += 1u; }
@@ -471,7 +471,7 @@ k_push_update(GridDev g, PushArgs a_val, const PushArgs* __restrict__ a_dev, con
       const unsigned ix = (unsigned)c & 31u, iy = (unsigned)c >> 5;
       const double ccx = ((double)(x0 + ix) + 0.5) * g.cs;
       const double ccy = ((double)(y0 + iy) + 0.5) * g.cs;
-      cidx[k] = (int)(iy * TILE_PITCH + ix);
+      cidx[k] = c;                                           // interior offset iy * 32 + ix
       const int index = bidx[k];
       hit[k] = false; sdv[k] = 0.0;
       const bool staged_beam = index >= wlo && index <= whi;
@@ -490,7 +490,7 @@ k_push_update(GridDev g, PushArgs a_val, const PushArgs* __restrict__ a_dev, con
 #pragma unroll
     for (int k = 0; k < CPT; k++) {
       tv[k] = t_init; wv[k] = w_init;
-      if (hit[k] && !fresh) { tv[k] = T[cidx[k]]; wv[k] = W[cidx[k]]; }
+      if (hit[k] && !fresh) { tv[k] = ld_tsd(T + cidx[k]); wv[k] = ld_w(W + cidx[k]); }
     }
 #ifdef TSD_PUSH_STAMPS
     if (tv[0] == 123.456) dbg[1023] = wv[0] + tv[1] + tv[2] + tv[3];    // (wait for the reads)
@@ -502,19 +502,14 @@ k_push_update(GridDev g, PushArgs a_val, const PushArgs* __restrict__ a_dev, con
       bool touched = false;
       if (hit[k]) touched = add_tsd(tv[k], wv[k], sdv[k], pw, max_trunc, inv_max_trunc, eps);
       if (touched) n_upd++;
-      if (touched && tv[k] < 0.0) wrote_neg |= neg_bit((unsigned)cidx[k] % TILE_PITCH, (unsigned)cidx[k] / TILE_PITCH);
-      if (touched || fresh) { T[cidx[k]] = tv[k]; W[cidx[k]] = wv[k]; }
+      if (touched && tv[k] < 0.0) wrote_neg |= neg_bit((unsigned)cidx[k] & 31u, (unsigned)cidx[k] >> 5);
+      if (touched || fresh) { st_tsd(T + cidx[k], tv[k]); st_w(W + cidx[k], wv[k]); }
     }
     if (wrote_neg) atomicOr(s_neg, wrote_neg);                      // (LDS; folded into the tile's mask below)
     if (fresh) {
       // halo cells of a freshly materialised tile keep the init value until k_push_halo
-      for (int h = tid; h < 2 * TILE_DIM + 1; h += UPDATE_BLOCK) {
-        if (h < TILE_DIM) {
-          T[h * TILE_PITCH + TILE_DIM] = t_init; W[h * TILE_PITCH + TILE_DIM] = w_init;       // column 32
-        } else {
-          const int i = h - TILE_DIM;                                                          // row 32, 0..32
-          T[TILE_DIM * TILE_PITCH + i] = t_init; W[TILE_DIM * TILE_PITCH + i] = w_init;
-        }
+      for (int h = tid; h < 2 * TILE_DIM + 1; h += UPDATE_BLOCK) {      // the halo strip: column 32, then row 32
+        st_tsd(T + HALO_COL + h, t_init); st_w(W + HALO_COL + h, w_init);
       }
     }
     PSTAMP(5);
@@ -540,8 +535,8 @@ k_push_update(GridDev g, PushArgs a_val, const PushArgs* __restrict__ a_dev, con
 __device__ __forceinline__ void copy_col(const GridDev& g, int dst, int src, int lane)
 {
   if (lane < TILE_DIM) {
-    const size_t d = (size_t)dst * TILE_STRIDE + lane * TILE_PITCH + TILE_DIM;
-    const size_t s = (size_t)src * TILE_STRIDE + lane * TILE_PITCH;
+    const size_t d = (size_t)dst * TILE_STRIDE + HALO_COL + lane;
+    const size_t s = (size_t)src * TILE_STRIDE + lane * TILE_DIM;
     g.tsd[d] = g.tsd[s]; g.weight[d] = g.weight[s];
   }
 }
@@ -549,7 +544,7 @@ __device__ __forceinline__ void copy_row(const GridDev& g, int dst, int src, int
 {
   if (lane >= TILE_DIM) {
     const int i = lane - TILE_DIM;
-    const size_t d = (size_t)dst * TILE_STRIDE + TILE_DIM * TILE_PITCH + i;
+    const size_t d = (size_t)dst * TILE_STRIDE + HALO_ROW + i;
     const size_t s = (size_t)src * TILE_STRIDE + i;
     g.tsd[d] = g.tsd[s]; g.weight[d] = g.weight[s];
   }
@@ -557,7 +552,7 @@ __device__ __forceinline__ void copy_row(const GridDev& g, int dst, int src, int
 __device__ __forceinline__ void copy_corner(const GridDev& g, int dst, int src, int lane)
 {
   if (lane == 0) {
-    const size_t d = (size_t)dst * TILE_STRIDE + TILE_DIM * TILE_PITCH + TILE_DIM;
+    const size_t d = (size_t)dst * TILE_STRIDE + HALO_ROW + TILE_DIM;
     const size_t s = (size_t)src * TILE_STRIDE;
     g.tsd[d] = g.tsd[s]; g.weight[d] = g.weight[s];
   }
@@ -615,17 +610,18 @@ k_free_footprint(GridDev g, unsigned minX, unsigned maxX, unsigned minY, unsigne
   const unsigned tx = tx0 + blockIdx.x % ntx, ty = ty0 + blockIdx.x / ntx;
   const int p = (int)(ty * (unsigned)g.PX + tx);
   const int tid = threadIdx.x;
-  double* T = g.tsd + (size_t)p * TILE_STRIDE;
-  double* W = g.weight + (size_t)p * TILE_STRIDE;
+  tsd_cell_t* T = g.tsd + (size_t)p * TILE_STRIDE;
+  w_cell_t* W = g.weight + (size_t)p * TILE_STRIDE;
   const bool fresh = g.flags[p] == 0;
   const double iw = g.init_weight[p];
   const double t_init = (iw > 0.0) ? 1.0 : __builtin_nan("");
   for (int i = tid; i < TILE_CELLS; i += 256) {
-    const unsigned lx = (unsigned)(i % TILE_PITCH), ly = (unsigned)(i / TILE_PITCH);
+    const int can = canonical_of_off(i);                       // i is the device offset
+    const unsigned lx = (unsigned)(can % TILE_PITCH), ly = (unsigned)(can / TILE_PITCH);
     const unsigned col = tx * TILE_DIM + lx, row = ty * TILE_DIM + ly;
     const bool inside = lx < TILE_DIM && ly < TILE_DIM && col >= minX && col < maxX && row >= minY && row < maxY;
-    if (inside) { T[i] = 1.0; if (fresh) W[i] = iw; }
-    else if (fresh) { T[i] = t_init; W[i] = iw; }
+    if (inside) { st_tsd(T + i, 1.0); if (fresh) st_w(W + i, iw); }
+    else if (fresh) { st_tsd(T + i, t_init); st_w(W + i, iw); }
   }
   __syncthreads();            // every thread has read `fresh`
   if (tid == 0) {
@@ -663,14 +659,116 @@ k_neg_scan(GridDev g)
   const int p = blockIdx.x;
   if (!g.flags[p]) return;
   const int PX = g.PX, px = p % PX, py = p / PX;
-  const double* T = g.tsd + (size_t)p * TILE_STRIDE;
+  const tsd_cell_t* T = g.tsd + (size_t)p * TILE_STRIDE;
   for (int i = threadIdx.x; i < TILE_CELLS; i += 256) {
-    if (!(T[i] < 0.0)) continue;
-    const unsigned ix = (unsigned)i % TILE_PITCH, iy = (unsigned)i / TILE_PITCH;
+    if (!(ld_tsd(T + i) < 0.0)) continue;
+    const int can = canonical_of_off(i);
+    const unsigned ix = (unsigned)can % TILE_PITCH, iy = (unsigned)can / TILE_PITCH;
     const int qx = px + (ix == TILE_DIM ? 1 : 0), qy = py + (iy == TILE_DIM ? 1 : 0);
     if (qx >= PX || qy >= PX) continue;                        // (no tile owns the outermost halo)
     atomicOr(&g.negmask[qy * PX + qx], neg_bit(ix & 31u, iy & 31u));
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Canonical tile I/O (tsd_download_tiles / tsd_upload_tiles): the C ABI and the oracle speak 33 x 33 row-major fp64
+// tiles (TsdGridPartition::_grid); the device layout (interior + halo strip, fp64 or Q32 cells) is converted here.
+// One workgroup per tile of the chunk [t0, t0 + n).
+__global__ void __launch_bounds__(256)
+k_export_tiles(GridDev g, int t0, double* __restrict__ out_t, double* __restrict__ out_w)
+{
+  const int p = t0 + blockIdx.x;
+  const bool init = g.flags[p] != 0;
+  const tsd_cell_t* T = g.tsd + (size_t)p * TILE_STRIDE;
+  const w_cell_t* W = g.weight + (size_t)p * TILE_STRIDE;
+  double* ot = out_t + (size_t)blockIdx.x * TILE_CELLS;
+  double* ow = out_w + (size_t)blockIdx.x * TILE_CELLS;
+  for (int i = threadIdx.x; i < TILE_CELLS; i += 256) {
+    const int can = canonical_of_off(i);
+    ot[can] = init ? ld_tsd(T + i) : __builtin_nan("");      // uninitialised tiles read back NaN / 0
+    ow[can] = init ? ld_w(W + i) : 0.0;
+  }
+}
+__global__ void __launch_bounds__(256)
+k_import_tiles(GridDev g, int t0, const double* __restrict__ in_t, const double* __restrict__ in_w)
+{
+  const int p = t0 + blockIdx.x;
+  if (!g.flags[p]) return;
+  tsd_cell_t* T = g.tsd + (size_t)p * TILE_STRIDE;
+  w_cell_t* W = g.weight + (size_t)p * TILE_STRIDE;
+  const double* it = in_t + (size_t)blockIdx.x * TILE_CELLS;
+  const double* iw = in_w + (size_t)blockIdx.x * TILE_CELLS;
+  for (int i = threadIdx.x; i < TILE_CELLS; i += 256) {
+    const int can = canonical_of_off(i);
+    st_tsd(T + i, it[can]); st_w(W + i, iw[can]);
+  }
+}
+int launch_export_tiles(tsd_ctx* ctx, int t0, int n, double* d_t, double* d_w)
+{
+  hipLaunchKernelGGL(k_export_tiles, dim3(n), dim3(256), 0, ctx->stream, ctx->grid, t0, d_t, d_w);
+  TSD_HIP_CHECK(ctx, hipGetLastError());
+  return TSD_OK;
+}
+int launch_import_tiles(tsd_ctx* ctx, int t0, int n, const double* d_t, const double* d_w)
+{
+  hipLaunchKernelGGL(k_import_tiles, dim3(n), dim3(256), 0, ctx->stream, ctx->grid, t0, d_t, d_w);
+  TSD_HIP_CHECK(ctx, hipGetLastError());
+  return TSD_OK;
+}
+
+// Digest of the canonical dump (tsd_grid_digest): an order-free 64-bit hash of (tile flag, initWeight, every cell's
+// tsd and weight bit patterns, NaN and -0.0 canonicalised) plus sums over the valid cells -- what the cfg 1-3 golden
+// fixtures pin without shipping a 4.6 GB dump.  One workgroup per tile; out[p] = {hash, n_valid} as
+// u64, sums[p] = {sum tsd, sum weight}; the host adds the per-tile records in tile order.
+__device__ __forceinline__ unsigned long long digest_mix(unsigned long long k, unsigned long long a, unsigned long long b)
+{
+  unsigned long long x = k * 0x9E3779B97F4A7C15ull + a;
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+  x += b;
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+  return x;
+}
+__device__ __forceinline__ unsigned long long digest_bits(double v)
+{
+  if (isnan(v)) return 0x7FF8000000000000ull;
+  return (unsigned long long)__double_as_longlong(v + 0.0);      // -0.0 -> +0.0
+}
+__global__ void __launch_bounds__(256)
+k_grid_digest(GridDev g, unsigned long long* __restrict__ out, double* __restrict__ sums)
+{
+  const int p = blockIdx.x;
+  const bool init = g.flags[p] != 0;
+  const tsd_cell_t* T = g.tsd + (size_t)p * TILE_STRIDE;
+  const w_cell_t* W = g.weight + (size_t)p * TILE_STRIDE;
+  unsigned long long h = 0ull, nv = 0ull; double st = 0.0, sw = 0.0;
+  if (init) {
+    for (int i = threadIdx.x; i < TILE_CELLS; i += 256) {
+      const double t = ld_tsd(T + i), w = ld_w(W + i);
+      h += digest_mix((unsigned long long)p * 2048ull + 1ull + (unsigned long long)canonical_of_off(i), digest_bits(t), digest_bits(w));
+      if (!isnan(t)) { nv++; st += t; sw += w; }
+    }
+  }
+  __shared__ unsigned long long s_h[256], s_n[256]; __shared__ double s_t[256], s_w[256];
+  s_h[threadIdx.x] = h; s_n[threadIdx.x] = nv; s_t[threadIdx.x] = st; s_w[threadIdx.x] = sw;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) {
+      s_h[threadIdx.x] += s_h[threadIdx.x + k]; s_n[threadIdx.x] += s_n[threadIdx.x + k];
+      s_t[threadIdx.x] += s_t[threadIdx.x + k]; s_w[threadIdx.x] += s_w[threadIdx.x + k];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[2 * p] = s_h[0] + digest_mix((unsigned long long)p * 2048ull, init ? 1ull : 0ull, digest_bits(g.init_weight[p]));
+    out[2 * p + 1] = s_n[0];
+    sums[2 * p] = s_t[0]; sums[2 * p + 1] = s_w[0];
+  }
+}
+int launch_grid_digest(tsd_ctx* ctx, unsigned long long* d_out, double* d_sums)
+{
+  hipLaunchKernelGGL(k_grid_digest, dim3(ctx->grid.tiles), dim3(256), 0, ctx->stream, ctx->grid, d_out, d_sums);
+  TSD_HIP_CHECK(ctx, hipGetLastError());
+  return TSD_OK;
 }
 
 int launch_neg_scan(tsd_ctx* ctx)
@@ -703,11 +801,10 @@ int launch_push_tables(tsd_ctx* ctx, hipStream_t stream, int beams, const double
 {
   const size_t bp = (size_t)((beams + 3) & ~3);
   const size_t lds = 2 * bp * sizeof(double) + 4 * bp * 2 + 64;
-  static size_t configured = 0;
-  if (lds > configured) {
+  if (lds > ctx->tables_lds_configured) {     // the attribute is per device: remembered per context, not per process
     TSD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_push_tables),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = lds;
+    ctx->tables_lds_configured = lds;
   }
   ctx->rmq_slot ^= 1;                                    // the push that may still be running keeps its tables
   ctx->d_rmq = ctx->d_rmq2[ctx->rmq_slot];

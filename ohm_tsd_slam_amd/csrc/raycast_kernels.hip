@@ -32,7 +32,6 @@ constexpr int RC_MAXSEG = 16;
 constexpr int RC_BLK = 15;         // steps per block of the fine march (one group of 16 lanes; < one tile)
 
 struct RcSeg { double anchor, rhat; int n0, pad; };
-struct __attribute__((aligned(8))) Cell2 { double a, b; };      // two neighbouring cells of a tile row
 
 // exponent field of a positive normal double, -1 otherwise
 __device__ __forceinline__ int binade_of(double p)
@@ -355,10 +354,10 @@ k_raycast(GridDev g, RaycastArgs a_val, const RaycastArgs* __restrict__ a_dev, c
       for (int r0 = 0; r0 < n_cand && !found && !ended; r0 += 4 * RC_S) {
         double qx[RC_S], qy[RC_S], v[RC_S];
         bool act[RC_S];
-        int st[RC_S]; size_t off[RC_S]; int tp[RC_S]; double wx[RC_S], wy[RC_S];
+        int st[RC_S]; int lxy[RC_S]; int tp[RC_S]; double wx[RC_S], wy[RC_S];
 #pragma unroll
         for (int j = 0; j < RC_S; j++) {
-          act[j] = false; st[j] = INTERP_INVALIDINDEX; tp[j] = 0; off[j] = 0; qx[j] = 0.0; qy[j] = 0.0; wx[j] = 0.0; wy[j] = 0.0;
+          act[j] = false; st[j] = INTERP_INVALIDINDEX; tp[j] = 0; lxy[j] = 0; qx[j] = 0.0; qy[j] = 0.0; wx[j] = 0.0; wy[j] = 0.0;
           if (r0 + 4 * j >= n_cand) continue;                   // (wave-uniform) no block left for this sub-round
           const int li = r0 + 4 * j + (lane >> 4);
           const int blk = li < n_cand ? s_blk[li] : -1;
@@ -369,28 +368,26 @@ k_raycast(GridDev g, RaycastArgs a_val, const RaycastArgs* __restrict__ a_dev, c
           const bool inside = act[j] && coord2cell(g, qx[j], qy[j], p, lx, ly, dx, dy);
           st[j] = inside ? INTERP_SUCCESS : INTERP_INVALIDINDEX;
           tp[j] = inside ? p : 0;
-          off[j] = (size_t)tp[j] * TILE_STRIDE + (size_t)(inside ? ly * TILE_PITCH + lx : 0);
+          lxy[j] = inside ? (lx | (ly << 8)) : 0;
           wx[j] = fabs((qx[j] - dx) * g.inv_cs);
           wy[j] = fabs((qy[j] - dy) * g.inv_cs);
         }
         // the tile storage exists for every tile (only `flags` says whether it holds data), so the cell
-        // reads need not wait for the flag; each row pair is one 16-byte read
-        uint8_t fl[RC_S]; Cell2 r0v[RC_S], r1v[RC_S];
+        // reads need not wait for the flag
+        uint8_t fl[RC_S]; Quad qv[RC_S];
 #pragma unroll
         for (int j = 0; j < RC_S; j++) {
-          fl[j] = 0; r0v[j].a = r0v[j].b = r1v[j].a = r1v[j].b = 0.0;
+          fl[j] = 0; qv[j].t00 = qv[j].t01 = qv[j].t10 = qv[j].t11 = 0.0;
           if (r0 + 4 * j >= n_cand) continue;
           fl[j] = g.flags[tp[j]];
-          const double* t = g.tsd + off[j];
-          r0v[j] = *reinterpret_cast<const Cell2*>(t);
-          r1v[j] = *reinterpret_cast<const Cell2*>(t + TILE_PITCH);
+          qv[j] = load_quad(g.tsd + (size_t)tp[j] * TILE_STRIDE, lxy[j] & 0xFF, lxy[j] >> 8);
         }
 #pragma unroll
         for (int j = 0; j < RC_S; j++) {
           double r = __builtin_nan("");
           if (r0 + 4 * j < n_cand && st[j] == INTERP_SUCCESS && fl[j]) {
-            r = r0v[j].a * (1. - wy[j]) * (1. - wx[j]) + r1v[j].a * wy[j] * (1. - wx[j])
-              + r0v[j].b * (1. - wy[j]) * wx[j] + r1v[j].b * wy[j] * wx[j];   // NaN stays NaN = "not SUCCESS"
+            r = qv[j].t00 * (1. - wy[j]) * (1. - wx[j]) + qv[j].t10 * wy[j] * (1. - wx[j])
+              + qv[j].t01 * (1. - wy[j]) * wx[j] + qv[j].t11 * wy[j] * wx[j];   // NaN stays NaN = "not SUCCESS"
           }
           v[j] = r;
         }
@@ -493,10 +490,9 @@ k_raycast(GridDev g, RaycastArgs a_val, const RaycastArgs* __restrict__ a_dev, c
     okn = coord2cell(g, sx, sy, p, lx, ly, dx, dy);
     if (okn) {
       const uint8_t f = g.flags[p];
-      const double* t = g.tsd + (size_t)p * TILE_STRIDE + ly * TILE_PITCH + lx;
-      const Cell2 r0 = *reinterpret_cast<const Cell2*>(t), r1 = *reinterpret_cast<const Cell2*>(t + TILE_PITCH);
+      const Quad q = load_quad(g.tsd + (size_t)p * TILE_STRIDE, lx, ly);
       const double wx = fabs((sx - dx) * g.inv_cs), wy = fabs((sy - dy) * g.inv_cs);
-      v = r0.a * (1. - wy) * (1. - wx) + r1.a * wy * (1. - wx) + r0.b * (1. - wy) * wx + r1.b * wy * wx;
+      v = q.t00 * (1. - wy) * (1. - wx) + q.t10 * wy * (1. - wx) + q.t01 * (1. - wy) * wx + q.t11 * wy * wx;
       okn = f != 0 && !isnan(v);
     }
   }

@@ -99,6 +99,7 @@ struct TileBox {
 struct KernelTimer {
   double total_ms = 0.0;
   int launches = 0;
+  unsigned tick = 0;         // launches seen (sampling: every profile_every-th one is timed)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
 };
 
@@ -115,6 +116,8 @@ struct tsd_ctx {
   char* d_rmq = nullptr;                     // range-query tables of the current scan (k_push_tables): one of d_rmq2
   char* d_rmq2[2] = {nullptr, nullptr};      // (the next scan's tables are built while the current push still reads its own)
   int rmq_slot = 0;
+  size_t tables_lds_configured = 0;          // dynamic LDS k_push_tables was configured for on this context's device
+  std::map<const void*, size_t> lds_configured;   // the same for the k_icp instantiations
   hipEvent_t ev_h2d = nullptr;               // fused scan: the scan's copy (side stream) is complete
   uint32_t* d_tile_rec = nullptr;            // [tiles] what the last push did to every tile
   uint8_t* d_dirty = nullptr;                // [tiles] written by freeFootprint since the last push
@@ -163,7 +166,6 @@ struct tsd_ctx {
   // profiling: bit i of profile_mask times kernel i (names in capi.hip: kKernelNames)
   unsigned profile_mask = 0;
   unsigned profile_every = 1;   // time every n-th launch of a selected kernel ("name/n" in tsd_profile_select)
-  unsigned profile_tick = 0;
   bool profile = false;
   std::map<std::string, tsd::KernelTimer> timers;
   std::vector<hipEvent_t> event_pool;
@@ -219,6 +221,9 @@ int launch_push_tables(tsd_ctx* ctx, hipStream_t stream, int beams, const double
 size_t push_rmq_bytes(int beams);
 int launch_free_footprint(tsd_ctx* ctx, unsigned minX, unsigned maxX, unsigned minY, unsigned maxY);
 int launch_neg_scan(tsd_ctx* ctx);
+int launch_export_tiles(tsd_ctx* ctx, int t0, int n, double* d_t, double* d_w);
+int launch_import_tiles(tsd_ctx* ctx, int t0, int n, const double* d_t, const double* d_w);
+int launch_grid_digest(tsd_ctx* ctx, unsigned long long* d_out, double* d_sums);
 int launch_raycast(tsd_ctx* ctx, const RaycastArgs& a, const RaycastArgs* a_dev = nullptr, const double* d_rays = nullptr);
 int launch_icp(tsd_ctx* ctx, const IcpArgs& a, const double* P_dev = nullptr, const double* d_rays_local = nullptr,
                const double* d_ranges = nullptr, const uint8_t* d_mask = nullptr, const ScanPostArgs* post = nullptr);

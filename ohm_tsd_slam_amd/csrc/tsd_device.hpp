@@ -1,11 +1,26 @@
 // tsd_device.hpp -- device-side view of the TSD grid and the small fp64 helpers every kernel shares.
 //
 // Data layout in HBM (DESIGN.md "Data layout"): tile-major structure-of-arrays.  Tile p = py*PX + px
-// (row-major like TsdGrid::_partitions[0][p], TsdGrid.cpp:234) owns TILE_STRIDE doubles in `tsd` and
-// in `weight`; the first 33*33 of them are the row-major 33x33 cells (32x32 interior + the duplicated
-// 1-cell halo of TsdGridPartition.cpp:97), the rest is padding to a 64-byte line.  `flags[p]` is
-// TsdGridPartition::_initialized, `init_weight[p]` is _initWeight.  All arithmetic is fp64 in the
+// (row-major like TsdGrid::_partitions[0][p], TsdGrid.cpp:234) owns TILE_STRIDE cells in `tsd` and in
+// `weight`, laid out so that everything a push streams is whole 128-byte lines:
+//     [0, 1024)      the 32 x 32 interior, row-major (cell (ix, iy) at iy * 32 + ix): a row is 256 contiguous
+//                    bytes (fp64) on a 128-byte boundary, a tile starts on a 128-byte boundary
+//     [1024, 1056)   halo column  (ix == 32, iy = 0..31)   } the duplicated 1-cell halo of
+//     [1056, 1089)   halo row     (iy == 32, ix = 0..32)   } TsdGridPartition.cpp:97, kept with its stale-halo semantics
+//     [1089, 1120)   padding
+// (round 1 kept the reference's 33-cell row pitch: every 256-byte interior row then straddled five 64-byte
+// segments instead of four and the update kernel moved 1.4-1.5 x its algorithmic bytes.)
+// `flags[p]` is TsdGridPartition::_initialized, `init_weight[p]` is _initWeight.  All arithmetic is fp64 in the
 // reference's operation order; translation units are compiled with -ffp-contract=off.
+//
+// Cell storage is a compile-time choice:
+//   default            fp64 like the reference (obfloat == double): cells bit-identical to the oracle's
+//   -DTSD_STORAGE_Q32  32-bit fixed point, 8 bytes per cell instead of 16: tsd as signed Q1.30 (NaN = INT32_MIN),
+//                      weight as unsigned Q6.26 (0 .. 32).  Arithmetic stays fp64; a store rounds to the nearest
+//                      grid value, so after n pushes a cell is within n * 2^-31 (tsd) / n * 2^-27 (weight) of the
+//                      fp64 result whatever the data -- north_star's 1e-5 holds for > 1000 pushes by construction.
+//                      (fp32 cells do not give that: a weight near 10 has an ulp of 9.5e-7 and the rounding errors of
+//                      1000 additions random-walk to ~1e-5; tests/test_cpu_oracle_properties.py shows it.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -13,10 +28,45 @@
 namespace tsd {
 
 constexpr int TILE_DIM    = 32;
-constexpr int TILE_PITCH  = 33;
+constexpr int TILE_PITCH  = 33;            // of the CANONICAL 33 x 33 dump (C ABI, oracle); not the device layout
 constexpr int TILE_CELLS  = 33 * 33;
-constexpr int TILE_STRIDE = 1096;          // 1089 rounded up to a multiple of 8 doubles (64 B)
+constexpr int TILE_INTERIOR = TILE_DIM * TILE_DIM;
+constexpr int HALO_COL    = TILE_INTERIOR;              // + iy
+constexpr int HALO_ROW    = TILE_INTERIOR + TILE_DIM;   // + ix (0..32)
+constexpr int TILE_STRIDE = 1120;          // 1089 rounded up to whole 128-byte lines for 4-byte and 8-byte cells
 constexpr double MAX_WEIGHT = 32.0;        // TSDGRIDMAXWEIGHT, reconstruct_defs.h:4
+
+// device offset of cell (ix, iy), 0..32 each, inside its tile
+__host__ __device__ __forceinline__ int cell_off(int ix, int iy)
+{
+  return iy < TILE_DIM ? (ix < TILE_DIM ? iy * TILE_DIM + ix : HALO_COL + iy) : HALO_ROW + ix;
+}
+// device offset -> canonical index iy * 33 + ix
+__host__ __device__ __forceinline__ int canonical_of_off(int off)
+{
+  if (off < TILE_INTERIOR) return (off >> 5) * TILE_PITCH + (off & 31);
+  if (off < HALO_ROW) return (off - HALO_COL) * TILE_PITCH + TILE_DIM;
+  return TILE_DIM * TILE_PITCH + (off - HALO_ROW);
+}
+
+#ifdef TSD_STORAGE_Q32
+using tsd_cell_t = int32_t;
+using w_cell_t   = uint32_t;
+constexpr bool STORAGE_EXACT = false;
+constexpr int32_t Q_NAN = INT32_MIN;
+__device__ __forceinline__ double ld_tsd(const tsd_cell_t* p) { const int32_t q = *p; return q == Q_NAN ? __builtin_nan("") : ldexp((double)q, -30); }
+__device__ __forceinline__ void st_tsd(tsd_cell_t* p, double v) { *p = isnan(v) ? Q_NAN : (int32_t)rint(ldexp(v, 30)); }
+__device__ __forceinline__ double ld_w(const w_cell_t* p) { return ldexp((double)*p, -26); }
+__device__ __forceinline__ void st_w(w_cell_t* p, double v) { *p = (uint32_t)rint(ldexp(v, 26)); }
+#else
+using tsd_cell_t = double;
+using w_cell_t   = double;
+constexpr bool STORAGE_EXACT = true;
+__device__ __forceinline__ double ld_tsd(const tsd_cell_t* p) { return *p; }
+__device__ __forceinline__ void st_tsd(tsd_cell_t* p, double v) { *p = v; }
+__device__ __forceinline__ double ld_w(const w_cell_t* p) { return *p; }
+__device__ __forceinline__ void st_w(w_cell_t* p, double v) { *p = v; }
+#endif
 
 struct GridDev {
   int N;            // cells per side
@@ -28,8 +78,8 @@ struct GridDev {
   double min_x, max_x, min_y, max_y;
   uint8_t* flags;
   double*  init_weight;
-  double*  tsd;
-  double*  weight;
+  tsd_cell_t* tsd;
+  w_cell_t*   weight;
   unsigned long long* negmask;   // [tiles] bit gy*8+gx: the 4x4-cell group (gx, gy) of the tile has (ever) held a negative tsd
 };
 
@@ -92,14 +142,25 @@ __device__ __forceinline__ int interpolate_bilinear(const GridDev& g, double x, 
   if (!g.flags[p]) return INTERP_EMPTYPARTITION;
   const double wx = fabs((x - dx) * g.inv_cs);
   const double wy = fabs((y - dy) * g.inv_cs);
-  const double* t = g.tsd + (size_t)p * TILE_STRIDE + ly * TILE_PITCH + lx;
-  const double t00 = t[0], t01 = t[1], t10 = t[TILE_PITCH], t11 = t[TILE_PITCH + 1];
+  const tsd_cell_t* t = g.tsd + (size_t)p * TILE_STRIDE;
+  const double t00 = ld_tsd(t + cell_off(lx, ly)), t01 = ld_tsd(t + cell_off(lx + 1, ly));
+  const double t10 = ld_tsd(t + cell_off(lx, ly + 1)), t11 = ld_tsd(t + cell_off(lx + 1, ly + 1));
   tsd = t00 * (1. - wy) * (1. - wx)
       + t10 * wy * (1. - wx)
       + t01 * (1. - wy) * wx
       + t11 * wy * wx;
   if (isnan(tsd)) return INTERP_ISNAN;
   return INTERP_SUCCESS;
+}
+
+// the four cells a bilinear look-up at anchor (lx, ly) touches, reads issued together (the halo strip when lx / ly == 31)
+struct Quad { double t00, t01, t10, t11; };
+__device__ __forceinline__ Quad load_quad(const tsd_cell_t* __restrict__ tile, int lx, int ly)
+{
+  Quad q;
+  q.t00 = ld_tsd(tile + cell_off(lx, ly));     q.t01 = ld_tsd(tile + cell_off(lx + 1, ly));
+  q.t10 = ld_tsd(tile + cell_off(lx, ly + 1)); q.t11 = ld_tsd(tile + cell_off(lx + 1, ly + 1));
+  return q;
 }
 
 // 64-lane sum (all lanes receive lane 0's total is NOT guaranteed: result valid in lane 0)

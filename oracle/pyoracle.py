@@ -104,6 +104,8 @@ def lib():
         L.ora_grid_dump.argtypes = [C.c_void_p, _u8p, _dp, _dp, _dp]
         L.ora_grid_load.argtypes = [C.c_void_p, _u8p, _dp, _dp, _dp]
         L.ora_grid_tile_state.argtypes = [C.c_void_p, _u8p, _dp]
+        L.ora_grid_digest.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int64), C.POINTER(C.c_int32), _dp, _dp]
+        L.ora_grid_digest.restype = None
         L.ora_push.argtypes = [C.c_void_p, _dp, _dp, _u8p, C.c_int, C.c_double, C.c_double, C.c_double,
                                C.c_double, C.c_double, C.c_int, C.POINTER(PushStats)]
         L.ora_raycast.argtypes = [C.c_void_p, _dp, _dp, C.c_int, C.c_double, C.c_double, C.c_int, _dp, _dp, _u8p]
@@ -258,6 +260,13 @@ class Grid:
         w = np.zeros((self.tiles, TILE_CELLS))
         self.L.ora_grid_dump(self.h, u8(init), d(iw), d(tsd), d(w))
         return init, iw, tsd, w
+
+    def digest(self) -> dict:
+        h, nv, ni = C.c_uint64(), C.c_int64(), C.c_int32()
+        st, sw = C.c_double(), C.c_double()
+        self.L.ora_grid_digest(self.h, C.byref(h), C.byref(nv), C.byref(ni), C.byref(st), C.byref(sw))
+        return dict(hash=int(h.value), cells_valid=int(nv.value), tiles_initialized=int(ni.value),
+                    sum_tsd=float(st.value), sum_weight=float(sw.value))
 
     def load(self, init, iw, tsd, w):
         init = np.ascontiguousarray(init, dtype=np.uint8)

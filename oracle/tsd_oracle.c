@@ -343,6 +343,44 @@ void ora_grid_dump(const ora_grid* g, uint8_t* initialized, double* init_weight,
   }
 }
 
+/* Digest of the canonical dump (the rule of include/tsd_hip.h: tsd_grid_digest): order-free 64-bit hash of
+ * (tile flag, initWeight, bit patterns of tsd / weight of every cell of the initialised tiles; NaN and -0.0
+ * canonicalised), count of non-NaN cells, sums over them per tile then in tile order.  Test infrastructure: lets the
+ * cfg 1-3 fixtures pin whole grids without shipping the dumps. */
+static uint64_t digest_mix(uint64_t k, uint64_t a, uint64_t b)
+{
+  uint64_t x = k * 0x9E3779B97F4A7C15ull + a;
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+  x += b;
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+  return x;
+}
+static uint64_t digest_bits(double v)
+{
+  if (isnan(v)) return 0x7FF8000000000000ull;
+  v = v + 0.0;
+  uint64_t u; memcpy(&u, &v, 8);
+  return u;
+}
+void ora_grid_digest(const ora_grid* g, uint64_t* hash, int64_t* cells_valid, int32_t* tiles_initialized,
+                     double* sum_tsd, double* sum_weight)
+{
+  uint64_t h = 0; int64_t nv = 0; int32_t ni = 0; double st = 0.0, sw = 0.0;
+  for (int p = 0; p < g->tiles; p++) {
+    h += digest_mix((uint64_t)p * 2048ull, g->init[p] ? 1ull : 0ull, digest_bits(g->init_weight[p]));
+    if (!g->init[p]) continue;
+    ni++;
+    double tt = 0.0, tw = 0.0;
+    for (int i = 0; i < TC; i++) {
+      const double t = g->tsd[p][i], w = g->weight[p][i];
+      h += digest_mix((uint64_t)p * 2048ull + 1ull + (uint64_t)i, digest_bits(t), digest_bits(w));
+      if (!isnan(t)) { nv++; tt += t; tw += w; }
+    }
+    st += tt; sw += tw;
+  }
+  *hash = h; *cells_valid = nv; *tiles_initialized = ni; *sum_tsd = st; *sum_weight = sw;
+}
+
 void ora_grid_load(ora_grid* g, const uint8_t* initialized, const double* init_weight,
                    const double* tsd, const double* weight)
 {

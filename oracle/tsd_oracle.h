@@ -100,6 +100,9 @@ void      ora_grid_dump(const ora_grid* g, uint8_t* initialized, double* init_we
                         double* tsd, double* weight);
 void      ora_grid_load(ora_grid* g, const uint8_t* initialized, const double* init_weight,
                         const double* tsd, const double* weight);
+/* digest of that dump by the rule of include/tsd_hip.h (tsd_grid_digest) */
+void      ora_grid_digest(const ora_grid* g, uint64_t* hash, int64_t* cells_valid, int32_t* tiles_initialized,
+                          double* sum_tsd, double* sum_weight);
 /* TsdGrid::storeGrid (TsdGrid.cpp:548-607) / TsdGrid(file) (:25-110): the reference's text format */
 int       ora_grid_store_text(const ora_grid* g, const char* path);
 ora_grid* ora_grid_load_text(const char* path);

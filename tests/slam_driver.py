@@ -25,11 +25,12 @@ def slam_kwargs(gc, geo, **over):
 
 
 class HipSlam:
-    def __init__(self, oracle, fused=True, **kw):
+    def __init__(self, oracle, fused=True, storage="f64", **kw):
         self.o = oracle
         self.kw = kw
         self.fused = fused
-        self.grid = capi.TsdGridDevice(kw["map_size_log2"], kw["cell_size"], kw["truncation_radius"] * kw["cell_size"])
+        self.grid = capi.TsdGridDevice(kw["map_size_log2"], kw["cell_size"], kw["truncation_radius"] * kw["cell_size"],
+                                       storage=storage)
         self.initialized = False
         self.params = self.grid.icp_params(kw["icp_iterations"], kw["dist_filter_max"], kw["dist_filter_min"])
 
