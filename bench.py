@@ -1,18 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- scans/s of the per-scan hot path (ray cast -> ICP -> TSD push) on MI355X.
 
-One "step" = one synthetic 1081-beam scan through ThreadLocalize's event-loop body and
-ThreadMapping's push on a 4096x4096-cell TSD grid (BASELINE.json configs[1]): scan
-ingest on the host, tsd_localize (ray-cast kernel + persistent ICP kernel) and tsd_push (classify /
-update / halo kernels) on the GPU, pose read-back included.  The grid stays resident in HBM.
+One "step" = one synthetic 1081-beam scan through ThreadLocalize's event-loop body and ThreadMapping's push
+on a 4096x4096-cell TSD grid (BASELINE.json configs[1]): scan ingest on the host, the fused
+tsd_scan (ray-cast kernel + persistent ICP kernel + gates + classify / update / halo push kernels) on the
+GPU, pose read-back included.  The grid stays resident in HBM.  `value` is a SINGLE-STREAM LATENCY CHAIN:
+one robot's scans are strictly sequential (the next ray cast needs this push), so it is 1 / (time of one scan).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg3|cfg1] [--scene ...]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg1|cfg2|cfg3] [--scene room|pillars|comb]
+                  [--mode slam|push] [--storage f64|q32] [--robots R]
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): one robot + one grid per GPU (the
-multi-robot case, BASELINE configs[3]/[4]); every 50 scans the ranks merge their int8 occupancy maps
-with an RCCL max all-reduce.  Weak scaling: `value` = scans of all ranks / max-over-ranks time.
+  --mode push   (default for --scene comb, whose ranges do not depend on the pose, so there is nothing to localise
+                against): a step = one TsdGrid::push from the ground-truth pose (tables + classify + update + halo).
+                This is the HBM-bound leg SURVEY 8(d) prices against the roofline (cfg3 / comb = bandwidth stress).
+  --storage q32 (push mode) the 8-byte-per-cell build, lib/libtsd_hip_q32.so.
+  --robots R    R robots on ONE grid in one process (the reference's own multi-robot mode, SlamNode.cpp:101-122),
+                one feeder thread per robot; value = all robots' scans / wall time.
 
-Prints ONE JSON line on rank 0.
+N > 1 (launched by torch.distributed.run, one rank per GPU): one robot + one grid per GPU (BASELINE configs[3]/[4]);
+every 50 scans the ranks merge their int8 occupancy maps with an RCCL max all-reduce.  Weak scaling: `value` =
+scans of all ranks / max-over-ranks time.
+
+Prints ONE JSON line on rank 0.  Stage times (`stages_ms`, `ms_icp_iterate`, ...) and the roofline kernel's
+duration come from HIP events on every n-th dispatch of each kernel INSIDE the timed region.
 """
 from __future__ import annotations
 
@@ -21,6 +31,7 @@ import json
 import math
 import os
 import sys
+import threading
 import time
 
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")     # CPU baseline: no active spinning
@@ -32,18 +43,24 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 MERGE_EVERY = 50             # occupancy merge period in scans (cfg 4/5)
 CALIB_DOUBLES = 8 << 20      # k_calib_rmw: 2 arrays x 8 Mi doubles -> 128 MiB read + 128 MiB written per launch
+PROFILE_TAG = "r2"           # profiles/<tag>_<workload>_pmc.json: the committed rocprofv3 PMC summary of this round
+STAGES = ("raycast", "icp", "push_classify", "push_update", "push_halo")
 
 
-def pmc_traffic(kernel: str):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (profiles/*_pmc.json, newest
-    tag; collected with tools/profile_bench.sh on this same command in separate --pmc passes).  FETCH_SIZE /
-    WRITE_SIZE are KB; they are scaled by the factors the calibration kernel of the same run gives for this
-    8 B/lane access shape (known bytes / reported bytes).  None when no summary is committed."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), key=os.path.getmtime)
-    if not files:
+def workload_key(cfg: str, scene: str, mode: str, storage: str) -> str:
+    return f"{cfg}_{scene}" + ("_push" if mode == "push" else "") + ("_q32" if storage == "q32" else "")
+
+
+def pmc_traffic(kernel: str, key: str):
+    """HBM bytes per launch of `kernel` from the rocprofv3 PMC summary committed for THIS workload under
+    profiles/<PROFILE_TAG>_<workload>_pmc.json (tools/profile_bench.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes
+    of this same command).  FETCH_SIZE / WRITE_SIZE are KB; they are scaled by the factors the calibration kernel of
+    the same run gives for this access shape (known bytes / reported bytes; MI355X_MICROARCH.md HBM section: FETCH_SIZE
+    tallies 128-byte requests at 64 bytes).  None when no summary is committed for the workload."""
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_{key}_pmc.json")
+    if not os.path.exists(path):
         return None, None
-    d = json.load(open(files[-1]))
+    d = json.load(open(path))
     k = d["kernels"].get("tsd::" + kernel)
     if not k or k.get("FETCH_SIZE_KB") is None or k.get("WRITE_SIZE_KB") is None:
         return None, None
@@ -53,44 +70,103 @@ def pmc_traffic(kernel: str):
         known = 16.0 * CALIB_DOUBLES
         fr = known / (cal["FETCH_SIZE_KB"] * 1024.0)
         fw = known / (cal["WRITE_SIZE_KB"] * 1024.0)
-    return (k["FETCH_SIZE_KB"] * fr + k["WRITE_SIZE_KB"] * fw) * 1024.0, os.path.basename(files[-1])
+    return (k["FETCH_SIZE_KB"] * fr + k["WRITE_SIZE_KB"] * fw) * 1024.0, os.path.basename(path)
 
 
-def algorithmic_bytes(st: dict, pushes: int, beams: int) -> float:
-    """Bytes one push MUST move, fp64 SoA storage (DESIGN.md "Roofline"): per updated cell tsd+weight
-    read+write = 32 B; an emptied initialised tile RMWs 1089 cells; a tile materialised from
-    _initWeight > 0 writes 1024 cells; the scan (8 B range + 1 B mask per beam) is read once; every tile
-    that passes the range cull reads/writes 16 B of tile state.  k_push_update (one workgroup per listed tile)
-    moves all of these bytes but the tile state of the tiles k_push_classify rejects."""
-    return (32.0 * st["cells_updated"] + 32.0 * 1089 * st["tiles_emptied_init"]
-            + 16.0 * 1024 * st["tiles_new_from_empty"] + 16.0 * st["tiles_range_pass"] + 9.0 * beams * pushes)
+def algorithmic_bytes(st: dict, pushes: int, beams: int, cell_bytes: int = 16) -> float:
+    """Bytes one push MUST move (DESIGN.md "Roofline"; SURVEY 8(d)'s formula with `cell_bytes` = bytes of one cell's
+    (tsd, weight): 16 for the reference's fp64 cells, 8 for the Q32 build): per updated cell tsd+weight read+write; an
+    emptied initialised tile RMWs 1089 cells; a tile materialised from _initWeight > 0 writes 1024 cells; the scan
+    (8 B range + 1 B mask per beam) is read once; every tile that passes the range cull reads/writes 16 B of tile
+    state.  k_push_update (one workgroup per listed tile) moves all of these bytes but the tile state of the tiles
+    k_push_classify rejects."""
+    return (2.0 * cell_bytes * st["cells_updated"] + 2.0 * cell_bytes * 1089 * st["tiles_emptied_init"]
+            + 1.0 * cell_bytes * 1024 * st["tiles_new_from_empty"] + 16.0 * st["tiles_range_pass"] + 9.0 * beams * pushes)
 
 
-def cpu_baseline(cfg_name: str, scene: str, n_scans: int):
-    """The oracle (CPU restatement, OpenMP over tiles / beams like the reference, kd-tree NN like FLANN)
-    timed on this box's host cores on the same synthetic workload."""
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def cpu_info():
+    model, phys = "unknown", set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    logical = len(os.sched_getaffinity(0))
+    physical = min(len(phys), logical) if phys else logical
+    return model, max(physical, 1), logical
+
+
+def cpu_baseline(cfg_name: str, scene: str, mode: str, n_scans: int):
+    """The oracle (oracle/tsd_oracle.c: CPU restatement, OpenMP over tiles / beams like the reference, kd-tree NN like
+    FLANN) timed on this box's host cores on the same synthetic workload: a thread sweep {1, 16, 64, physical cores},
+    OMP_WAIT_POLICY=passive.  `value` = the best of the sweep, `cores` = its thread count; the 1-thread figure has its
+    own key (SURVEY 8(d) "CPU baseline")."""
     from oracle import pyoracle as O
     from ohm_tsd_slam_amd import synth
     from tests.slam_driver import slam_kwargs
+    from tests import helpers as H
     gc, geo, _ = synth.CONFIGS[cfg_name]
     world = synth.World(scene, gc)
     poses = synth.trajectory(world, n_scans + 1)
     scans = synth.scans_for(world, geo, poses)
-    cores = len(os.sched_getaffinity(0))
-    slam = O.Slam(**slam_kwargs(gc, geo, nn_mode=1, threads=cores))
-    slam.process_scan(scans[0])
-    t_rc = t_icp = t_push = 0.0
-    t0 = time.perf_counter()
-    for k in range(1, n_scans + 1):
-        r = slam.process_scan(scans[k])
-        t_rc += r.t_raycast; t_icp += r.t_icp; t_push += r.t_push
-    dt = time.perf_counter() - t0
-    return {
-        "value": n_scans / dt, "unit": "scans/s", "cores": cores, "kind": "port",
-        "sample": f"{n_scans} scans of {cfg_name}/{scene} after the init push; oracle/tsd_oracle.c, "
-                  f"OpenMP {cores} threads, kd-tree NN, OMP_WAIT_POLICY=passive",
-        "ms_raycast": 1e3 * t_rc / n_scans, "ms_icp": 1e3 * t_icp / n_scans, "ms_push": 1e3 * t_push / n_scans,
-    }
+    model, physical, logical = cpu_info()
+    sweep = sorted({t for t in (1, 16, 64, physical) if t <= logical})
+    results = {}
+    for thr in sweep:
+        if mode == "push":
+            og = O.Grid(gc.map_size_log2, gc.cell_size, gc.max_trunc)
+            t_total = 0.0
+            for k in range(n_scans + 1):
+                pose = synth.pose_matrix(*poses[k])
+                data, mask = O.ingest_f32(scans[k], 30.0, geo.angle_increment)
+                t0 = time.perf_counter()
+                og.push(pose, data, mask, geo.angle_increment, geo.angle_min, 30.0, 0.001, 2.0, threads=thr)
+                if k > 0:
+                    t_total += time.perf_counter() - t0
+            results[thr] = dict(scans_per_s=n_scans / t_total, ms_push=1e3 * t_total / n_scans)
+            og.close()
+        else:
+            slam = O.Slam(**slam_kwargs(gc, geo, nn_mode=1, threads=thr))
+            slam.process_scan(scans[0])
+            t_rc = t_icp = t_push = 0.0
+            t0 = time.perf_counter()
+            for k in range(1, n_scans + 1):
+                r = slam.process_scan(scans[k])
+                t_rc += r.t_raycast; t_icp += r.t_icp; t_push += r.t_push
+            dt = time.perf_counter() - t0
+            results[thr] = dict(scans_per_s=n_scans / dt, ms_raycast=1e3 * t_rc / n_scans, ms_icp=1e3 * t_icp / n_scans,
+                                ms_push=1e3 * t_push / n_scans)
+            slam.close()
+    best = max(results, key=lambda t: results[t]["scans_per_s"])
+    out = {"value": results[best]["scans_per_s"], "unit": "scans/s", "cores": best, "kind": "port",
+           "sample": f"{n_scans} {'pushes' if mode == 'push' else 'scans'} of {cfg_name}/{scene} after the init push per "
+                     f"thread count; oracle/tsd_oracle.c, OpenMP, kd-tree NN, OMP_WAIT_POLICY=passive",
+           "cpu_model": model, "physical_cores": physical, "logical_cpus": logical,
+           "value_1thread": results[1]["scans_per_s"] if 1 in results else None,
+           "threads_sweep": {str(t): results[t] for t in sweep}}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ timing helpers
+def stage_table(grid, steps):
+    """Mean dispatch duration of every stage kernel from the events sampled in the timed region, and its share of a
+    step (launches per step x mean duration)."""
+    out = {}
+    for name in STAGES:
+        ms, n = grid.profile_get(name)
+        out[name] = (ms / n) if n else None
+    return out
 
 
 def main():
@@ -100,8 +176,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3"])
     ap.add_argument("--scene", default=None)
+    ap.add_argument("--mode", default=None, choices=["slam", "push"])
+    ap.add_argument("--storage", default="f64", choices=["f64", "q32"])
+    ap.add_argument("--robots", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-scans", type=int, default=30)
+    ap.add_argument("--cpu-scans", type=int, default=10)
+    ap.add_argument("--sample-every", type=int, default=0, help="time every n-th dispatch of each kernel (0 = auto)")
     ap.add_argument("--estimator", type=int, default=0, choices=[0, 1],
                     help="0: ClosedFormEstimator2D, what the node constructs (the bench line); 1: PointToLine2DEstimator")
     ap.add_argument("--force-dist", action="store_true",
@@ -109,61 +189,184 @@ def main():
                          "multi-GPU plumbing on a single GPU; tests/test_gpu_multigpu_plumbing.py)")
     ap.add_argument("--calibrate", action="store_true",
                     help="also launch the PMC calibration kernel (known byte count; used by tools/profile_bench.sh)")
+    ap.add_argument("--occupancy", type=int, default=0, help="also run the occupancy extraction (row N1) this many times "
+                                                           "after the timed region (profiling)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
-    n_gpus = args.gpus
+    if world_size > 1 and args.gpus != world_size:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_size}; reporting n_gpus={world_size}", file=sys.stderr)
+    n_gpus = world_size if world_size > 1 else args.gpus
     dist = None
     torch = None
     use_dist = world_size > 1 or args.force_dist
     if use_dist:
-        import torch  # plumbing only: device tensors for the collective + torch.distributed (RCCL)
+        import torch  # plumbing only: process group (RCCL) and the barrier / max-over-ranks of the contract
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", local_rank))
 
-    from ohm_tsd_slam_amd import facade, multigpu, synth
+    from ohm_tsd_slam_amd import capi, facade, multigpu, synth
     gc, geo, default_scene = synth.CONFIGS[args.config]
     scene = args.scene or default_scene
-
-    # robot r starts 0.7 m further along -x (launch/multi_slam.launch:40); every rank owns one grid
-    off_x = multigpu.robot_offset_x(rank)
-    world = synth.World(scene, gc, start_xy=[0.5 * gc.width + off_x, 0.5 * gc.width - 0.21])
+    mode = args.mode or ("push" if scene == "comb" else "slam")
+    if args.storage == "q32" and mode != "push":
+        ap.error("--storage q32 is measured in --mode push (the C++ facade links the fp64 library)")
     K, W = args.steps, args.warmup
+    every = args.sample_every or (8 if K >= 80 else 4)
+    device = local_rank if use_dist else 0
+    cell_bytes = 8 if args.storage == "q32" else 16
+
+    if mode == "push":
+        out = run_push(args, gc, geo, scene, K, W, every, device, capi, synth)
+    else:
+        out = run_slam(args, gc, geo, scene, K, W, every, device, rank, local_rank, world_size, use_dist, dist, torch,
+                       facade, multigpu, synth)
+    if rank == 0:
+        st, pushes, upd_ms, upd_launches = out.pop("_stats")
+        bytes_per_launch = algorithmic_bytes(st, pushes, geo.beams, cell_bytes) / max(pushes, 1)
+        upd_avg_ms = upd_ms / max(upd_launches, 1)
+        achieved = bytes_per_launch / (upd_avg_ms * 1e-3) / 1e9 if upd_avg_ms > 0 else 0.0
+        key = workload_key(args.config, scene, mode, args.storage)
+        traffic, traffic_src = pmc_traffic("k_push_update", key)
+        line = {
+            "metric": "scans/sec + ms/ICP-iterate, 4096^2 TSD grid, 1081-beam scan" if args.config == "cfg2"
+                      else f"scans/sec + ms/ICP-iterate, {gc.cells}^2 TSD grid, {geo.beams}-beam scan",
+            "value": out.pop("value"), "unit": "scans/s", "n_gpus": n_gpus, "steps": K, "warmup": W,
+            "ms_per_step": out.pop("ms_per_step"), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+        }
+        line.update(out)
+        line["roofline"] = {"kernel": "k_push_update", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                            "algorithmic_bytes_per_launch": bytes_per_launch, "cell_bytes": cell_bytes,
+                            "avg_launch_ms": upd_avg_ms, "launches": upd_launches,
+                            "timing": f"HIP events on every {every}th dispatch, inside the timed region"}
+        if not args.no_cpu_baseline and world_size == 1 and args.robots == 1:
+            line["cpu_baseline"] = cpu_baseline(args.config, scene, mode, min(args.cpu_scans, K))
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_push(args, gc, geo, scene, K, W, every, device, capi, synth):
+    """Push-only steps: TsdGrid::push from the ground-truth pose, host scan in, nothing read back."""
+    from ohm_tsd_slam_amd import facade
+    world = synth.World(scene, gc)
     poses = synth.trajectory(world, 1 + W + K)
     scans = synth.scans_for(world, geo, poses)
+    grid = capi.TsdGridDevice(gc.map_size_log2, gc.cell_size, gc.max_trunc, device=device, storage=args.storage)
+    lib = facade.load_library()
+    import ctypes as C
+    items = []
+    for k in range(len(scans)):          # the product's own host ingest (Sensor::setRealMeasurementData + setStandardMask)
+        data = np.zeros(geo.beams); mask = np.zeros(geo.beams, dtype=np.uint8)
+        r = np.ascontiguousarray(scans[k], dtype=np.float32)
+        lib.tsd_host_sensor_ingest_f32(r.ctypes.data_as(C.POINTER(C.c_float)), geo.beams, geo.angle_increment, geo.angle_min, 30.0,
+                                       data.ctypes.data_as(C.POINTER(C.c_double)), mask.ctypes.data_as(C.POINTER(C.c_uint8)), 0)
+        items.append((synth.pose_matrix(*poses[k]), data, mask))
 
+    def step(k):
+        pose, data, mask = items[k]
+        grid.push(pose, data, mask, geo.angle_increment, geo.angle_min, 30.0, 0.001, 2.0, want_stats=False)
+
+    for k in range(0, 1 + W):
+        step(k)
+    grid.sync()
+    grid.push_stats_total(reset=True)
+    grid.profile(True, kernels=f"push_classify,push_update,push_halo/{every}")
+    grid.profile_reset()
+    t0 = time.perf_counter()
+    for k in range(1 + W, 1 + W + K):
+        step(k)
+    grid.sync()
+    elapsed = time.perf_counter() - t0
+    upd_ms, upd_launches = grid.profile_get("push_update")
+    stages = stage_table(grid, K)
+    st, pushes = grid.push_stats_total()
+    grid.profile(False)
+    if args.calibrate:
+        grid.calibrate_rmw(CALIB_DOUBLES, 3)
+    for _ in range(args.occupancy):
+        grid.occupancy(False, 2)
+    out = {
+        "value": K / elapsed, "ms_per_step": 1e3 * elapsed / K,
+        "config": {"workload": f"{args.config}: {gc.cells}x{gc.cells} cells @ {gc.cell_size} m, {geo.beams} beams, scene "
+                               f"'{scene}', PUSH ONLY (TsdGrid::push from the ground-truth pose; no localisation), "
+                               f"cell storage {args.storage}", "robots": 1, "mode": "push", "storage": args.storage},
+        "stages_ms": {k: v for k, v in stages.items() if k.startswith("push")},
+        "ms_push_kernels": sum(v for k, v in stages.items() if k.startswith("push") and v is not None),
+        "pushes_in_timed_region": pushes, "cells_updated_per_push": st["cells_updated"] / max(pushes, 1),
+        "cells_visited_per_push": st["cells_visited"] / max(pushes, 1),
+        "tiles_updated_per_push": st["tiles_update"] / max(pushes, 1),
+        "_stats": (st, pushes, upd_ms, upd_launches),
+    }
+    grid.close()
+    return out
+
+
+def run_slam(args, gc, geo, scene, K, W, every, device, rank, local_rank, world_size, use_dist, dist, torch, facade, multigpu, synth):
+    R = args.robots
+    # robot r starts 0.7 m further along -x (launch/multi_slam.launch:40).  Ranks own one grid each (--gpus N);
+    # --robots R puts R robots on this rank's ONE grid (the reference's own multi-robot mode)
+    worlds, poses, scans = [], [], []
+    for r in range(R):
+        off_x = multigpu.robot_offset_x(rank * R + r)
+        w = synth.World(scene, gc, start_xy=[0.5 * gc.width + off_x, 0.5 * gc.width - 0.21 - (0.9 * r if R > 1 else 0.0)])
+        p = synth.trajectory(w, 1 + W + K)
+        worlds.append(w); poses.append(p); scans.append(synth.scans_for(w, geo, p))
     params = facade.node_params(gc, geo)
-    params["tsd_slam/local_offset_x"] = off_x
+    if R == 1:
+        params["tsd_slam/local_offset_x"] = multigpu.robot_offset_x(rank)
+    else:
+        params["robot_nbr"] = R
+        for r in range(R):
+            params[f"robot_{r}/name"] = f"robot{r}"
+            params[f"tsd_slam/robot{r}/local_offset_x"] = multigpu.robot_offset_x(rank * R + r)
+            params[f"tsd_slam/robot{r}/local_offset_y"] = -0.21 - 0.9 * r
     if args.estimator:
         params["icp_estimator"] = args.estimator
-    node = facade.SlamNode(params, device=local_rank if use_dist else 0, synchronous=True)
+    node = facade.SlamNode(params, device=device, synchronous=True)
     grid = node.grid()
     merger = None
     if use_dist:
         merger = multigpu.OccupancyMerger(gc.cells, device=f"cuda:{local_rank}")
 
-    def step(k):
-        node.laser(scans[k], geo.angle_min, geo.angle_increment)
-        if merger is not None and k % MERGE_EVERY == 0:
+    def step(k, r=0):
+        node.laser(scans[r][k], geo.angle_min, geo.angle_increment, robot=r)
+        if merger is not None and r == 0 and k % MERGE_EVERY == 0:
             merger.fill_from_grid(grid)     # occupancy extraction kernels on the ctx stream
             merger.merge_async(force=args.force_dist)   # RCCL max all-reduce over xGMI, overlaps the next scans
 
-    node.laser(scans[0], geo.angle_min, geo.angle_increment)          # init: freeFootprint + initPush
-    for k in range(1, 1 + W):
-        step(k)
+    def run_range(k0, k1):
+        if R == 1:
+            for k in range(k0, k1):
+                step(k)
+            return
+        # one feeder thread per robot: laser() runs the event-loop body on the calling thread (synchronous facade) and
+        # releases the GIL inside the C++ call, so the robots' scans overlap on the device like the reference's N
+        # ThreadLocalize workers do
+        ts = [threading.Thread(target=lambda rr=r: [step(k, rr) for k in range(k0, k1)]) for r in range(R)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+
+    for r in range(R):
+        node.laser(scans[r][0], geo.angle_min, geo.angle_increment, robot=r)          # init: freeFootprint + initPush
+    run_range(1, 1 + W)
     grid.sync()
     grid.push_stats_total(reset=True)
-    grid.profile(True, kernels="push_update/4")      # HIP events on the ctx stream around every 4th launch
+    grid.profile(True, kernels=f"all/{every}")      # HIP events on every n-th dispatch of each kernel
     grid.profile_reset()
     if dist is not None:
         torch.cuda.synchronize()
         dist.barrier()
     t0 = time.perf_counter()
-    for k in range(1 + W, 1 + W + K):
-        step(k)
+    run_range(1 + W, 1 + W + K)
     grid.sync()
     if dist is not None:
         merger.wait()
@@ -171,65 +374,47 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     upd_ms, upd_launches = grid.profile_get("push_update")
+    stages = stage_table(grid, K)
     st, pushes = grid.push_stats_total()
-    final = node.report()
-    track_err = math.hypot(final["pose"][0, 2] - poses[-1, 0], final["pose"][1, 2] - poses[-1, 1])
+    grid.profile(False)
+    errs = []
+    for r in range(R):
+        final = node.report(robot=r)
+        errs.append(math.hypot(final["pose"][0, 2] - poses[r][-1, 0], final["pose"][1, 2] - poses[r][-1, 1]))
 
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-
-    # per-stage breakdown: a short extra pass with every kernel timed (not part of `value`)
-    grid.profile(True, kernels="all")
-    grid.profile_reset()
-    extra = min(20, K)
-    more = synth.scans_for(world, geo, synth.trajectory(world, 1 + W + K + extra)[-extra:])
-    for s in more:
-        node.laser(s, geo.angle_min, geo.angle_increment)
-    grid.sync()
-    stages = {}
-    for name in ("raycast", "icp", "push_classify", "push_update", "push_halo"):
-        ms, n = grid.profile_get(name)
-        stages[name] = ms / n if n else None
-    grid.profile(False)
     if args.calibrate:
         grid.calibrate_rmw(CALIB_DOUBLES, 3)
+    for _ in range(args.occupancy):
+        grid.occupancy(False, 2)
 
-    if rank == 0:
-        bytes_total = algorithmic_bytes(st, pushes, geo.beams)
-        bytes_per_launch = bytes_total / max(pushes, 1)
-        upd_avg_ms = upd_ms / max(upd_launches, 1)
-        achieved = bytes_per_launch / (upd_avg_ms * 1e-3) / 1e9 if upd_avg_ms > 0 else 0.0
-        traffic, traffic_src = pmc_traffic("k_push_update") if args.config == "cfg2" and scene == default_scene else (None, None)
-        out = {
-            "metric": "scans/sec + ms/ICP-iterate, 4096^2 TSD grid, 1081-beam scan" if args.config == "cfg2"
-                      else f"scans/sec + ms/ICP-iterate, {gc.cells}^2 TSD grid, {geo.beams}-beam scan",
-            "value": world_size * K / elapsed, "unit": "scans/s", "n_gpus": n_gpus, "steps": K, "warmup": W,
-            "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {gc.cells}x{gc.cells} cells @ {gc.cell_size} m, {geo.beams} beams, "
-                                   f"scene '{scene}', icp_iterations 30, one robot + one grid per GPU"
-                                   + (", point-to-line estimator" if args.estimator else ""),
-                       "robots": world_size, "occupancy_merge_every": MERGE_EVERY if world_size > 1 else None},
-            "ms_icp_iterate": stages["icp"], "ms_icp_per_iteration": (stages["icp"] / 30.0) if stages["icp"] else None,
-            "ms_raycast": stages["raycast"],
-            "ms_push_kernels": sum(v for k, v in stages.items() if k.startswith("push") and v is not None),
-            "pushes_in_timed_region": pushes, "cells_updated_per_push": st["cells_updated"] / max(pushes, 1),
-            "tiles_updated_per_push": st["tiles_update"] / max(pushes, 1),
-            "tracking_error_m": track_err,
-            "roofline": {"kernel": "k_push_update", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": upd_avg_ms,
-                         "launches": upd_launches},
-        }
-        if not args.no_cpu_baseline and world_size == 1:
-            out["cpu_baseline"] = cpu_baseline(args.config, scene, min(args.cpu_scans, K))
-        print(json.dumps(out), flush=True)
+    pushes_per_step = pushes / max(K * R, 1)
+    stage_sum = sum(v * (pushes_per_step if k.startswith("push") else 1.0) for k, v in stages.items() if v is not None)
+    out = {
+        "value": world_size * R * K / elapsed, "ms_per_step": 1e3 * elapsed / K,
+        "config": {"workload": f"{args.config}: {gc.cells}x{gc.cells} cells @ {gc.cell_size} m, {geo.beams} beams, "
+                               f"scene '{scene}', icp_iterations 30, "
+                               + (f"{R} robots on one grid per GPU" if R > 1 else "one robot + one grid per GPU")
+                               + (", point-to-line estimator" if args.estimator else ""),
+                   "robots": world_size * R, "robots_per_grid": R, "mode": "slam", "storage": "f64",
+                   "occupancy_merge_every": MERGE_EVERY if world_size > 1 else None,
+                   "note": "single-stream latency chain per robot: a scan's ray cast needs the previous scan's push"},
+        "ms_icp_iterate": stages["icp"], "ms_icp_per_iteration": (stages["icp"] / 30.0) if stages["icp"] else None,
+        "ms_raycast": stages["raycast"],
+        "ms_push_kernels": sum(v for k, v in stages.items() if k.startswith("push") and v is not None),
+        "stages_ms": stages, "stages_sum_ms_per_scan": stage_sum,
+        "stage_timing": f"HIP events on every {every}th dispatch of each kernel, inside the timed region",
+        "pushes_in_timed_region": pushes, "cells_updated_per_push": st["cells_updated"] / max(pushes, 1),
+        "cells_visited_per_push": st["cells_visited"] / max(pushes, 1),
+        "tiles_updated_per_push": st["tiles_update"] / max(pushes, 1),
+        "tracking_error_m": max(errs),
+        "_stats": (st, pushes, upd_ms, upd_launches),
+    }
     node.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    return out
 
 
 if __name__ == "__main__":

@@ -13,9 +13,15 @@ from dataclasses import dataclass
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtsd_hip.so")
+# TSD_LIB_DIR: developer override used by tools/*_stamps*.sh, which build INSTRUMENTED variants of the kernels into
+# lib/diag/ so that the product libraries under lib/ are never replaced by a build without parity checks
+LIB_DIR = os.environ.get("TSD_LIB_DIR") or os.path.join(_HERE, "lib")
+if os.environ.get("TSD_LIB_DIR"):
+    import sys as _sys
+    print(f"ohm_tsd_slam_amd: using the libraries under TSD_LIB_DIR={LIB_DIR} (diagnostic build)", file=_sys.stderr)
+LIB_PATH = os.path.join(LIB_DIR, "libtsd_hip.so")
 # the same library built with 32-bit fixed-point cell storage (-DTSD_STORAGE_Q32, csrc/tsd_device.hpp)
-LIB_PATH_Q32 = os.path.join(_HERE, "lib", "libtsd_hip_q32.so")
+LIB_PATH_Q32 = os.path.join(LIB_DIR, "libtsd_hip_q32.so")
 
 TILE_CELLS = 1089
 MAX_BEAMS = 4096

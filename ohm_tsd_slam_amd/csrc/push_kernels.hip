@@ -531,35 +531,13 @@ k_push_update(GridDev g, PushArgs a_val, const PushArgs* __restrict__ a_dev, con
   }
 }
 
-// TsdGrid::propagateBorders (TsdGrid.cpp:372-427), incremental form.  One wave per listed tile.
-__device__ __forceinline__ void copy_col(const GridDev& g, int dst, int src, int lane)
-{
-  if (lane < TILE_DIM) {
-    const size_t d = (size_t)dst * TILE_STRIDE + HALO_COL + lane;
-    const size_t s = (size_t)src * TILE_STRIDE + lane * TILE_DIM;
-    g.tsd[d] = g.tsd[s]; g.weight[d] = g.weight[s];
-  }
-}
-__device__ __forceinline__ void copy_row(const GridDev& g, int dst, int src, int lane)
-{
-  if (lane >= TILE_DIM) {
-    const int i = lane - TILE_DIM;
-    const size_t d = (size_t)dst * TILE_STRIDE + HALO_ROW + i;
-    const size_t s = (size_t)src * TILE_STRIDE + i;
-    g.tsd[d] = g.tsd[s]; g.weight[d] = g.weight[s];
-  }
-}
-__device__ __forceinline__ void copy_corner(const GridDev& g, int dst, int src, int lane)
-{
-  if (lane == 0) {
-    const size_t d = (size_t)dst * TILE_STRIDE + HALO_ROW + TILE_DIM;
-    const size_t s = (size_t)src * TILE_STRIDE;
-    g.tsd[d] = g.tsd[s]; g.weight[d] = g.weight[s];
-  }
-}
-
+// TsdGrid::propagateBorders (TsdGrid.cpp:372-427), incremental form.
 // One wave per listed tile: the tile's own halo from R/U/UR and the halos of L/D/DL that mirror its first
 // column/row/cell.  Equal to the reference's full sweep by induction (untouched pairs are already consistent).
+// Every lane has up to three copy jobs (source cell -> destination cell, tsd and weight); all loads of a tile are
+// issued before the first store, so a tile costs one memory round trip after its flags (round 1 ran the six copies
+// one after the other: 40 us of latency chain at cfg3 / comb).  Lanes 0..31: the two column copies; lanes 32..63:
+// the two row copies; lane 0 / lane 32: the corner cells.
 __global__ void __launch_bounds__(256)
 k_push_halo(GridDev g, uint8_t* __restrict__ dirty, unsigned long long* __restrict__ pushes,
             PushArgs a_val, const PushArgs* __restrict__ a_dev, const uint32_t* __restrict__ list,
@@ -579,6 +557,8 @@ k_push_halo(GridDev g, uint8_t* __restrict__ dirty, unsigned long long* __restri
   const unsigned int n_list = list_cnt[parity];
   const uint32_t first = list[wv];                            // speculative: arrives with the list length
   const int PX = g.PX;
+  const bool colhalf = lane < TILE_DIM;
+  const int i = lane & 31;
   for (unsigned int li = wv; li < n_list; li += gridDim.x * 4) {
     const uint32_t entry = (li == wv) ? first : list[li];
     const int p = (int)(entry & ((1u << KIND_SHIFT) - 1u));
@@ -590,14 +570,24 @@ k_push_halo(GridDev g, uint8_t* __restrict__ dirty, unsigned long long* __restri
     const uint8_t fR = hasR ? g.flags[p + 1] : 0, fU = hasU ? g.flags[p + PX] : 0, fUR = (hasR && hasU) ? g.flags[p + PX + 1] : 0;
     const uint8_t fL = hasL ? g.flags[p - 1] : 0, fD = hasD ? g.flags[p - PX] : 0, fDL = (hasL && hasD) ? g.flags[p - PX - 1] : 0;
     if (!f0) continue;
-    // (a) own halo from right / up / up-right
-    if (fR) copy_col(g, p, p + 1, lane);
-    if (fU) copy_row(g, p, p + PX, lane);
-    if (fUR) copy_corner(g, p, p + PX + 1, lane);
-    // (b)-(d) neighbours whose halo mirrors this tile
-    if (fL) copy_col(g, p - 1, p, lane);
-    if (fD) copy_row(g, p - PX, p, lane);
-    if (fDL) copy_corner(g, p - PX - 1, p, lane);
+    const size_t own = (size_t)p * TILE_STRIDE;
+    // job 0: own halo from the right / upper neighbour; job 1: the left / lower neighbour's halo from this tile;
+    // job 2 (lanes 0 and 32 only): the corner cells
+    size_t src[3], dst[3]; bool on[3];
+    if (colhalf) {
+      on[0] = fR != 0;  src[0] = (size_t)(p + 1) * TILE_STRIDE + (size_t)i * TILE_DIM;  dst[0] = own + HALO_COL + i;
+      on[1] = fL != 0;  src[1] = own + (size_t)i * TILE_DIM;                           dst[1] = (size_t)(p - 1) * TILE_STRIDE + HALO_COL + i;
+      on[2] = lane == 0 && fUR != 0; src[2] = (size_t)(p + PX + 1) * TILE_STRIDE;      dst[2] = own + HALO_ROW + TILE_DIM;
+    } else {
+      on[0] = fU != 0;  src[0] = (size_t)(p + PX) * TILE_STRIDE + i;                   dst[0] = own + HALO_ROW + i;
+      on[1] = fD != 0;  src[1] = own + i;                                              dst[1] = (size_t)(p - PX) * TILE_STRIDE + HALO_ROW + i;
+      on[2] = lane == 32 && fDL != 0; src[2] = own;                                    dst[2] = (size_t)(p - PX - 1) * TILE_STRIDE + HALO_ROW + TILE_DIM;
+    }
+    tsd_cell_t tv[3]; w_cell_t wv_[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { tv[k] = tsd_cell_t(); wv_[k] = w_cell_t(); if (on[k]) { tv[k] = g.tsd[src[k]]; wv_[k] = g.weight[src[k]]; } }
+#pragma unroll
+    for (int k = 0; k < 3; k++) if (on[k]) { g.tsd[dst[k]] = tv[k]; g.weight[dst[k]] = wv_[k]; }
   }
 }
 
@@ -867,7 +857,8 @@ int launch_push(tsd_ctx* ctx, const PushArgs& a, double cx, double cy, double sl
   TSD_HIP_CHECK(ctx, hipGetLastError());
   {
     ScopedKernelTimer t(ctx, "push_halo");
-    hipExtLaunchKernelGGL(k_push_halo, dim3((n_groups + 3) / 4), dim3(256), 0, ctx->stream, t.a, t.b, 0, g, ctx->d_dirty, ctx->d_pushes,
+    const int n_waves = n_window < 4096 ? n_window : 4096;        // one wave per listed tile; a longer list is looped over
+    hipExtLaunchKernelGGL(k_push_halo, dim3((n_waves + 3) / 4), dim3(256), 0, ctx->stream, t.a, t.b, 0, g, ctx->d_dirty, ctx->d_pushes,
                        a, a_dev, ctx->d_list, ctx->d_list_cnt, parity, cx, cy, slack + g.cs);
   }
   TSD_HIP_CHECK(ctx, hipGetLastError());

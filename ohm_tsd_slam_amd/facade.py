@@ -11,7 +11,7 @@ import numpy as np
 from . import capi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libohm_tsd_slam.so")
+LIB_PATH = os.path.join(capi.LIB_DIR, "libohm_tsd_slam.so")
 
 _dp = C.POINTER(C.c_double)
 _fp = C.POINTER(C.c_float)

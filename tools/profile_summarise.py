@@ -9,7 +9,7 @@ import collections, csv, glob, json, os, shutil, sys
 tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out")
-dst = os.path.join(root, "profiles")
+dst = os.path.join(root, "gpurun_out", "profiles_new") if os.environ.get("GRAFT_REPO_ROOT") else os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 
 
@@ -62,4 +62,5 @@ if cal:
     if cal.get("WRITE_SIZE_KB"):
         cal["write_factor_known_over_reported"] = known_kb / cal["WRITE_SIZE_KB"]
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1)
-print(json.dumps(out, indent=1)[:3000])
+want = ("tsd::k_push_update", "tsd::k_calib_rmw", "tsd::k_occ_cells", "tsd::k_occ_mark", "tsd::k_push_classify", "tsd::k_push_halo")
+print(json.dumps({k: v for k, v in out["kernels"].items() if k in want}, indent=1)[:3000])

@@ -1,8 +1,7 @@
 #!/bin/bash
 # diagnostic: phase timeline (100 MHz wall clock) of sampled workgroups of k_push_update inside the bench loop
-cd $GRAFT_REPO_ROOT/ohm_tsd_slam_amd/csrc
-hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -I../../include -DTSD_PUSH_STAMPS $TSD_EXTRA -c push_kernels.hip -o ../lib/obj/push_kernels.o
-hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libtsd_hip.so ../lib/obj/*.o
+$GRAFT_REPO_ROOT/tools/diag_build.sh push_kernels -DTSD_PUSH_STAMPS $TSD_EXTRA
+export TSD_LIB_DIR=$GRAFT_REPO_ROOT/ohm_tsd_slam_amd/lib/diag
 cd $GRAFT_REPO_ROOT && python3 - <<'PY'
 import numpy as np, sys
 sys.path.insert(0, '.')

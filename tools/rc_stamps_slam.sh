@@ -1,8 +1,7 @@
 #!/bin/bash
 # diagnostic: per-phase cycle stamps of k_raycast inside the closed SLAM loop of bench.py (cfg2)
-cd $GRAFT_REPO_ROOT/ohm_tsd_slam_amd/csrc
-hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -I../../include -DTSD_RC_STAMPS -c raycast_kernels.hip -o ../lib/obj/raycast_kernels.o
-hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libtsd_hip.so ../lib/obj/*.o
+$GRAFT_REPO_ROOT/tools/diag_build.sh raycast_kernels -DTSD_RC_STAMPS
+export TSD_LIB_DIR=$GRAFT_REPO_ROOT/ohm_tsd_slam_amd/lib/diag
 cd $GRAFT_REPO_ROOT && python3 - <<'PY'
 import numpy as np, sys
 sys.path.insert(0, '.')
