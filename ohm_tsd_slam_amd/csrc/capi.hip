@@ -284,6 +284,8 @@ tsd_ctx* tsd_create(int device, int map_size_log2, double cell_size, double max_
   A(hipMalloc(&ctx->d_pushes, 2 * sizeof(unsigned long long)));
   A(hipMalloc(&ctx->d_list, T * sizeof(uint32_t)));
   A(hipMalloc(&ctx->d_list_win, T * sizeof(uint32_t)));
+  A(hipMalloc(&ctx->d_list_pw, T * sizeof(double)));
+  A(hipMalloc(&ctx->d_push_args, sizeof(PushArgs)));
   A(hipMalloc(&ctx->d_list_cnt, 2 * sizeof(unsigned int)));
   A(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
   A(hipEventCreateWithFlags(&ctx->ev_tables, hipEventDisableTiming));
@@ -326,7 +328,7 @@ void tsd_destroy(tsd_ctx* ctx)
   GridDev& g = ctx->grid;
   hipFree(g.flags); hipFree(g.init_weight); hipFree(g.tsd); hipFree(g.weight); hipFree(g.negmask);
   if (ctx->stream2) hipStreamSynchronize(ctx->stream2);
-  hipFree(ctx->d_rmq2[0]); hipFree(ctx->d_rmq2[1]); hipFree(ctx->d_tile_rec); hipFree(ctx->d_dirty); hipFree(ctx->d_tile_totals); hipFree(ctx->d_pushes); hipFree(ctx->d_list); hipFree(ctx->d_list_win); hipFree(ctx->d_list_cnt);
+  hipFree(ctx->d_rmq2[0]); hipFree(ctx->d_rmq2[1]); hipFree(ctx->d_tile_rec); hipFree(ctx->d_dirty); hipFree(ctx->d_tile_totals); hipFree(ctx->d_pushes); hipFree(ctx->d_list); hipFree(ctx->d_list_win); hipFree(ctx->d_list_pw); hipFree(ctx->d_push_args); hipFree(ctx->d_list_cnt);
   if (ctx->ev_tables) hipEventDestroy(ctx->ev_tables);
   if (ctx->ev_h2d) hipEventDestroy(ctx->ev_h2d);
   if (ctx->stream2) hipStreamDestroy(ctx->stream2);
@@ -435,13 +437,15 @@ int tsd_push(tsd_ctx* ctx, const double pose33[9], const double* ranges, const u
   char* h = stage_acquire(ctx, &s);
   std::memcpy(h, ranges, (size_t)beams * sizeof(double));
   std::memcpy(h + (size_t)TSD_MAX_BEAMS * 8, mask, (size_t)beams);
+  std::memcpy(h + (size_t)TSD_MAX_BEAMS * 9, &a, sizeof(a));        // the kernels read their arguments from device memory
   TSD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_ranges, h, (size_t)beams * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   TSD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_mask, h + (size_t)TSD_MAX_BEAMS * 8, (size_t)beams, hipMemcpyHostToDevice, ctx->stream));
+  TSD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_push_args, h + (size_t)TSD_MAX_BEAMS * 9, sizeof(a), hipMemcpyHostToDevice, ctx->stream));
   TSD_HIP_CHECK(ctx, hipEventRecord(ctx->stage_ev[s], ctx->stream));
 
   int rc = launch_push_tables(ctx, ctx->stream, beams, nullptr, nullptr, phi_min, ang_res);
   if (rc != TSD_OK) return rc;
-  rc = launch_push(ctx, a, a.trx, a.try_, 0.0);
+  rc = launch_push(ctx, a, a.trx, a.try_, 0.0, ctx->d_push_args);
   if (rc != TSD_OK) return rc;
   if (stats) {
     rc = read_last_push_stats(ctx, stats);

@@ -31,7 +31,8 @@ constexpr int UPDATE_BLOCK = TSD_UPDATE_BLOCK;     // threads of the per-tile wo
 
 // ---- per-tile record written by k_push_tiles -------------------------------------------------------
 constexpr uint32_t REC_RANGE_PASS = 1u, REC_UPDATE = 2u, REC_NEW = 4u, REC_NEW_FROM_EMPTY = 8u,
-                   REC_EMPTIED_INIT = 16u, REC_EMPTIED_UNINIT = 32u;
+                   REC_EMPTIED_INIT = 16u, REC_EMPTIED_UNINIT = 32u,
+                   REC_LISTED = 64u;      // on this push's work list (k_push_halo: the tile refreshes its own halo itself)
 constexpr int REC_CELLS_SHIFT = 8;
 
 // ---- range-query tables of one scan (global memory, built by k_push_tables) ---------------------------
@@ -183,18 +184,19 @@ constexpr int TOT_FIELDS = 8;   // cells updated, range pass, update, new, new f
 // to the list (one atomic per wave); increaseEmptiness of a tile that was never materialised is done here
 // (TsdGridPartition.cpp:157-162).  Every tile of the window gets its record.
 __global__ void __launch_bounds__(64)
-k_push_classify(GridDev g, PushArgs a_val, const PushArgs* __restrict__ a_dev, const char* __restrict__ rmq_buf,
+k_push_classify(GridDev g, const PushArgs* __restrict__ a_dev, const char* __restrict__ rmq_buf,
                 uint32_t* __restrict__ tile_rec, const uint8_t* __restrict__ dirty, uint32_t* __restrict__ tile_totals,
-                uint32_t* __restrict__ list, uint32_t* __restrict__ list_win, unsigned int* __restrict__ list_cnt /* [2] */,
-                int parity, int tx0, int ty0, int ntx, int nty)
+                uint32_t* __restrict__ list, uint32_t* __restrict__ list_win, double* __restrict__ list_pw,
+                unsigned int* __restrict__ list_cnt /* [2] */, int parity, int tx0, int ty0, int ntx, int nty)
 {
-  const PushArgs a = a_dev ? *a_dev : a_val;
+  const PushArgs a = *a_dev;
   const int lane = threadIdx.x;
   const int t = blockIdx.x * 64 + lane;
   if (t == 0) list_cnt[parity ^ 1] = 0u;                    // the next push's counter (nobody uses it now)
   const bool in_window = t < ntx * nty;
   const int p = in_window ? (ty0 + t / ntx) * g.PX + tx0 + t % ntx : 0;
   uint32_t rec = 0u, kind = 0u;
+  double pw = 0.0;
   uint32_t win = (uint32_t)(a.beams - 1) << 16;              // beams the cells of the tile can project to: lo | hi << 16
   if (in_window && a.enabled) {
     double e[4][2], cx, cy, rad;
@@ -241,7 +243,16 @@ k_push_classify(GridDev g, PushArgs a_val, const PushArgs* __restrict__ a_dev, c
       // well outside of it the extreme angles are those of corners, so every cell projects into [lo, hi]
       // (corners outside the field of view were mapped to its ends above).
       if (distance > 3.0 * rad) win = (uint32_t)lo | ((uint32_t)hi << 16);
-      if (action == 2) kind = KIND_UPDATE;
+      if (action == 2) {
+        kind = KIND_UPDATE;
+        // partition weight (TsdGrid.cpp:239-243): ((maxRange - min(distance to the centroid, maxRange)) / maxRange)^2.
+        // `distance` above is that distance bit for bit ((a - b)^2 == (b - a)^2, 0.0 + x == x), so the per-tile
+        // square root and division are done once here instead of by every thread of the update workgroup.
+        double dc = distance;
+        if (dc > a.max_range) dc = a.max_range;
+        pw = (a.max_range - dc) / a.max_range;
+        pw *= pw;
+      }
       else if (action == 1) {
         // TsdGridPartition::increaseEmptiness (TsdGridPartition.cpp:136-164), isInRange then returns false
         if (g.flags[p]) kind = KIND_EMPTY;
@@ -253,7 +264,7 @@ k_push_classify(GridDev g, PushArgs a_val, const PushArgs* __restrict__ a_dev, c
       }
       tile_totals[(size_t)p * TOT_FIELDS + 1] += 1u;         // (this lane owns the tile: no atomics)
     }
-    if (kind == 0u && dirty[p] != 0) kind = KIND_HALO;       // written by freeFootprint since the last push
+    if (kind == 0u && dirty[p] != 0) { kind = KIND_HALO; rec |= REC_LISTED; }       // written by freeFootprint since the last push
   }
   if (in_window && (kind == 0u || kind == KIND_HALO)) tile_rec[p] = rec;   // UPDATE / EMPTY: the workgroup writes the final record
   const unsigned long long listed = __ballot(kind != 0u);
@@ -265,6 +276,7 @@ k_push_classify(GridDev g, PushArgs a_val, const PushArgs* __restrict__ a_dev, c
       const unsigned int slot = base + __popcll(listed & ((1ull << lane) - 1ull));
       list[slot] = (uint32_t)p | (kind << KIND_SHIFT);
       list_win[slot] = win;
+      list_pw[slot] = pw;
     }
   }
 }
@@ -317,9 +329,9 @@ __device__ __forceinline__ int fast_index(double lx, double ly, const double2* _
 // old value is known, so it is written once, halo included).  KIND_EMPTY: increaseEmptiness over the 33x33
 // cells.  The workgroup leaves the tile's record and adds it to the tile's running totals.
 __global__ void __launch_bounds__(UPDATE_BLOCK, 4)      // 4 waves per SIMD = four workgroups per CU: the listed tiles of a usual push are resident at once
-k_push_update(GridDev g, PushArgs a_val, const PushArgs* __restrict__ a_dev, const double* __restrict__ ranges,
+k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __restrict__ ranges,
               const uint8_t* __restrict__ mask, uint32_t* __restrict__ tile_rec, uint32_t* __restrict__ tile_totals,
-              const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_win,
+              const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_win, const double* __restrict__ list_pw,
               const unsigned int* __restrict__ list_cnt, int parity, const double2* __restrict__ bdir, double* __restrict__ dbg)
 {
 #ifdef TSD_PUSH_STAMPS   // diagnostic: 100 MHz wall clock at the phases of every 8th listed tile (thread 0)
@@ -332,7 +344,8 @@ k_push_update(GridDev g, PushArgs a_val, const PushArgs* __restrict__ a_dev, con
   const unsigned int n_list = list_cnt[parity];
   const uint32_t first = list[blockIdx.x];
   const uint32_t first_win = list_win[blockIdx.x];
-  const PushArgs a = a_dev ? *a_dev : a_val;
+  const double first_pw = list_pw[blockIdx.x];
+  const PushArgs a = *a_dev;
   if (blockIdx.x >= n_list) return;
   PSTAMP(1);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -411,7 +424,7 @@ k_push_update(GridDev g, PushArgs a_val, const PushArgs* __restrict__ a_dev, con
         else { w = fmin(w + 1, MAX_WEIGHT); t = (t * (w - 1.0) + 1.0) / w; }
         st_tsd(T + i, t); st_w(W + i, w);
       }
-      rec |= REC_EMPTIED_INIT;
+      rec |= REC_EMPTIED_INIT | REC_LISTED;
       if (tid == 0) { tile_rec[p] = rec; tile_totals[(size_t)p * TOT_FIELDS + 5] += 1u; }
       continue;
     }
@@ -423,10 +436,8 @@ k_push_update(GridDev g, PushArgs a_val, const PushArgs* __restrict__ a_dev, con
     __syncthreads();               // scan staged; s_upd of a previous tile consumed
     PSTAMP(2);
 
-    double e[4][2], cx, cy, rad;
-    tile_geometry(g, p, e, cx, cy, rad);
     const bool fresh = !initialised;
-    rec |= REC_UPDATE;
+    rec |= REC_UPDATE | REC_LISTED;
     if (fresh) rec |= REC_NEW | (iw > 0.0 ? REC_NEW_FROM_EMPTY : 0u);
     // TsdGridPartition::init values (TsdGridPartition.cpp:98-120)
     const double t_init = (iw > 0.0) ? 1.0 : __builtin_nan("");
@@ -434,11 +445,8 @@ k_push_update(GridDev g, PushArgs a_val, const PushArgs* __restrict__ a_dev, con
     const double max_trunc = g.max_trunc;
     const double inv_max_trunc = 1.0 / max_trunc;
     const double eps = -g.cs / 2.0;
-    // partition weight (TsdGrid.cpp:239-243)
-    double dist_c = sqrt((cx - a.trx) * (cx - a.trx) + (cy - a.try_) * (cy - a.try_));
-    if (dist_c > a.max_range) dist_c = a.max_range;
-    double pw = (a.max_range - dist_c) / a.max_range;
-    pw *= pw;
+    // partition weight (TsdGrid.cpp:239-243): evaluated once per tile by k_push_classify
+    const double pw = (li == blockIdx.x) ? first_pw : list_pw[li];
 
     const unsigned x0 = (unsigned)(p % g.PX) * TILE_DIM, y0 = (unsigned)(p / g.PX) * TILE_DIM;
     unsigned int n_upd = 0;
@@ -474,9 +482,16 @@ k_push_update(GridDev g, PushArgs a_val, const PushArgs* __restrict__ a_dev, con
       cidx[k] = c;                                           // interior offset iy * 32 + ix
       const int index = bidx[k];
       hit[k] = false; sdv[k] = 0.0;
+      // mask and range of the beam from LDS, both at once (a select between an LDS and a global pointer would turn
+      // into a flat load with a full wait per cell); a beam outside the staged window -- possible only through
+      // rounding at the window's ends -- is fetched from global memory by the lanes concerned
       const bool staged_beam = index >= wlo && index <= whi;
-      if (index >= 0 && (staged_beam ? s_mask[index] : mask[index])) {
-        const double r = staged_beam ? s_ranges[index] : ranges[index];
+      const int il = index < wlo ? wlo : (index > whi ? whi : index);
+      unsigned mk = s_mask[il];
+      double r = s_ranges[il];
+      asm volatile("" : "+v"(mk), "+v"(r));      // (keeps the two LDS reads LDS reads: no pointer select)
+      if (__builtin_expect(index >= 0 && !staged_beam, 0)) { mk = mask[index]; r = ranges[index]; }
+      if (index >= 0 && mk) {
         const double dist = sqrt((ccx - a.trx) * (ccx - a.trx) + (ccy - a.try_) * (ccy - a.try_));
         double sd = 0.0; bool cand = false;
         if (!isinf(r)) { sd = r - dist; cand = true; }
@@ -540,17 +555,17 @@ k_push_update(GridDev g, PushArgs a_val, const PushArgs* __restrict__ a_dev, con
 // the two row copies; lane 0 / lane 32: the corner cells.
 __global__ void __launch_bounds__(256)
 k_push_halo(GridDev g, uint8_t* __restrict__ dirty, unsigned long long* __restrict__ pushes,
-            PushArgs a_val, const PushArgs* __restrict__ a_dev, const uint32_t* __restrict__ list,
+            const PushArgs* __restrict__ a_dev, const uint32_t* __restrict__ list, const uint32_t* __restrict__ tile_rec,
             const unsigned int* __restrict__ list_cnt, int parity, double cx, double cy, double slack)
 {
   const int lane = threadIdx.x & 63;
   const unsigned int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (wv == 0 && lane == 0) {
-    const bool enabled = a_dev ? a_dev->enabled != 0 : a_val.enabled != 0;
+    const bool enabled = a_dev->enabled != 0;
     if (enabled) {
       pushes[0] += 1ull;
       // the window was laid around (cx, cy) +- slack by the host: a sensor outside of that is a host-side bug
-      const double sx = a_dev ? a_dev->trx : a_val.trx, sy = a_dev ? a_dev->try_ : a_val.try_;
+      const double sx = a_dev->trx, sy = a_dev->try_;
       if (!(fabs(sx - cx) <= slack && fabs(sy - cy) <= slack)) pushes[1] += 1ull;
     }
   }
@@ -568,8 +583,15 @@ k_push_halo(GridDev g, uint8_t* __restrict__ dirty, unsigned long long* __restri
     // all nine flags in flight at once
     const uint8_t f0 = g.flags[p];
     const uint8_t fR = hasR ? g.flags[p + 1] : 0, fU = hasU ? g.flags[p + PX] : 0, fUR = (hasR && hasU) ? g.flags[p + PX + 1] : 0;
-    const uint8_t fL = hasL ? g.flags[p - 1] : 0, fD = hasD ? g.flags[p - PX] : 0, fDL = (hasL && hasD) ? g.flags[p - PX - 1] : 0;
+    uint8_t fL = hasL ? g.flags[p - 1] : 0, fD = hasD ? g.flags[p - PX] : 0, fDL = (hasL && hasD) ? g.flags[p - PX - 1] : 0;
+    // a left / lower / diagonal neighbour that is on this push's list refreshes its own halo from this tile itself
+    // (its job 0 / corner job is the very same copy): skipping the mirror job halves the column gathers where the
+    // listed tiles are dense.  Records outside this push's window are never "listed" (see launch_push).
+    const uint32_t rL = hasL ? tile_rec[p - 1] : 0u, rD = hasD ? tile_rec[p - PX] : 0u, rDL = (hasL && hasD) ? tile_rec[p - PX - 1] : 0u;
     if (!f0) continue;
+    if (rL & REC_LISTED) fL = 0;
+    if (rD & REC_LISTED) fD = 0;
+    if (rDL & REC_LISTED) fDL = 0;
     const size_t own = (size_t)p * TILE_STRIDE;
     // job 0: own halo from the right / upper neighbour; job 1: the left / lower neighbour's halo from this tile;
     // job 2 (lanes 0 and 32 only): the corner cells
@@ -809,6 +831,7 @@ int launch_push(tsd_ctx* ctx, const PushArgs& a, double cx, double cy, double sl
                 const double* d_ranges, const uint8_t* d_mask)
 {
   const GridDev& g = ctx->grid;
+  if (!a_dev) return set_error(ctx, TSD_E_ARG, "launch_push: the arguments must be on the device", hipSuccess);
   if (!d_ranges) d_ranges = ctx->d_ranges;
   if (!d_mask) d_mask = ctx->d_mask;
   // Tile window: a tile passes the range cull of isInRange only if its centre is within
@@ -838,8 +861,8 @@ int launch_push(tsd_ctx* ctx, const PushArgs& a, double cx, double cy, double sl
   const int n_window = ntx * nty;
   {
     ScopedKernelTimer t(ctx, "push_classify");
-    hipExtLaunchKernelGGL(k_push_classify, dim3((n_window + 63) / 64), dim3(64), 0, ctx->stream, t.a, t.b, 0, g, a, a_dev, ctx->d_rmq,
-                       ctx->d_tile_rec, ctx->d_dirty, ctx->d_tile_totals, ctx->d_list, ctx->d_list_win, ctx->d_list_cnt, parity,
+    hipExtLaunchKernelGGL(k_push_classify, dim3((n_window + 63) / 64), dim3(64), 0, ctx->stream, t.a, t.b, 0, g, a_dev, ctx->d_rmq,
+                       ctx->d_tile_rec, ctx->d_dirty, ctx->d_tile_totals, ctx->d_list, ctx->d_list_win, ctx->d_list_pw, ctx->d_list_cnt, parity,
                        box.x0, box.y0, ntx, nty);
   }
   TSD_HIP_CHECK(ctx, hipGetLastError());
@@ -850,8 +873,8 @@ int launch_push(tsd_ctx* ctx, const PushArgs& a, double cx, double cy, double sl
     const size_t lds = 16 + (size_t)((a.beams + 1) & ~1) * sizeof(double) + (size_t)((a.beams + 15) & ~15) +
                        (fast ? ((size_t)a.beams + 1) * sizeof(double2) : 0);
     const double2* bdir = fast ? rmq_view(ctx->d_rmq, a.beams).bdir : nullptr;
-    hipExtLaunchKernelGGL(k_push_update, dim3(n_groups), dim3(UPDATE_BLOCK), lds, ctx->stream, t.a, t.b, 0, g, a, a_dev, d_ranges, d_mask,
-                       ctx->d_tile_rec, ctx->d_tile_totals, ctx->d_list, ctx->d_list_win, ctx->d_list_cnt, parity, bdir,
+    hipExtLaunchKernelGGL(k_push_update, dim3(n_groups), dim3(UPDATE_BLOCK), lds, ctx->stream, t.a, t.b, 0, g, a_dev, d_ranges, d_mask,
+                       ctx->d_tile_rec, ctx->d_tile_totals, ctx->d_list, ctx->d_list_win, ctx->d_list_pw, ctx->d_list_cnt, parity, bdir,
                        ctx->d_icp_trace);
   }
   TSD_HIP_CHECK(ctx, hipGetLastError());
@@ -859,7 +882,7 @@ int launch_push(tsd_ctx* ctx, const PushArgs& a, double cx, double cy, double sl
     ScopedKernelTimer t(ctx, "push_halo");
     const int n_waves = n_window < 4096 ? n_window : 4096;        // one wave per listed tile; a longer list is looped over
     hipExtLaunchKernelGGL(k_push_halo, dim3((n_waves + 3) / 4), dim3(256), 0, ctx->stream, t.a, t.b, 0, g, ctx->d_dirty, ctx->d_pushes,
-                       a, a_dev, ctx->d_list, ctx->d_list_cnt, parity, cx, cy, slack + g.cs);
+                       a_dev, ctx->d_list, ctx->d_tile_rec, ctx->d_list_cnt, parity, cx, cy, slack + g.cs);
   }
   TSD_HIP_CHECK(ctx, hipGetLastError());
   return TSD_OK;

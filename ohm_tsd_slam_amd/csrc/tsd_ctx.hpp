@@ -127,6 +127,8 @@ struct tsd_ctx {
   tsd::TileBox box_prev{}, box_dirty{};
   uint32_t* d_list = nullptr;               // [tiles] work list of the current push (tile | kind << 28)
   uint32_t* d_list_win = nullptr;           // [tiles] beams a listed tile can project to (lo | hi << 16)
+  double* d_list_pw = nullptr;              // [tiles] partition weight of a listed UPDATE tile (TsdGrid.cpp:239-243)
+  tsd::PushArgs* d_push_args = nullptr;     // arguments of an unfused tsd_push (the fused scan keeps them in the sensor state)
   unsigned int* d_list_cnt = nullptr;       // [2] its length, by push parity
   unsigned int push_parity = 0;
   unsigned long long epoch = 0;             // bumped by everything that changes the grid, a sensor pose or the ctx's ray-cast outputs
