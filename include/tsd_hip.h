@@ -69,6 +69,12 @@ typedef struct {
   double dist_filter_max;       /* DistanceFilter(maxdist, mindist, icp_iterations - 10) */
   double dist_filter_min;
   double min_x, max_x, min_y, max_y; /* OutOfBoundsFilter2D = TsdGrid::getMin/MaxX/Y */
+  /* Tinit of Icp::iterate(rms, pairs, iterations, Tinit) (Icp.cpp:464-486): the pre-registration result in
+   * registration_mode 1-3 (ThreadLocalize.cpp:531-569, :580), 3x3 row-major.  Used by tsd_icp / tsd_icp_normals when
+   * use_t_init != 0 (0 = the identity of registration_mode 0); the fused calls always start from the identity. */
+  double t_init[9];
+  int    use_t_init;
+  int    reserved;
 } tsd_icp_params;
 
 typedef struct {
@@ -92,6 +98,10 @@ int      tsd_reset(tsd_ctx* ctx);                          /* TsdGrid::reset (Ts
 int      tsd_set_max_truncation(tsd_ctx* ctx, double val); /* TsdGrid::setMaxTruncation (:206-215) */
 int      tsd_sync(tsd_ctx* ctx);
 const char* tsd_last_error(const tsd_ctx* ctx);
+
+/* sizeof() of a public struct of this header by name ("tsd_push_stats", "tsd_icp_params", ...; 0 if unknown): lets a
+ * binding (ctypes, cgo, JNI) check its mirror of the layout at load time */
+int      tsd_abi_sizeof(const char* struct_name);
 
 /* ---- geometry getters (TsdGrid.h getCellsX, getCellSize, getMaxTruncation, getMinX.., getMaxX..) -- */
 int    tsd_cells(const tsd_ctx* ctx);
@@ -143,6 +153,38 @@ int tsd_localize(tsd_ctx* ctx, const double pose33[9], const double* rays_world_
                  const double* rays_local_2xB, const double* ranges, const uint8_t* mask, int beams,
                  double min_range, double max_range, const tsd_icp_params* params,
                  tsd_icp_result* result);
+
+/* ---- pre-registration (registration_mode 3) ------------------------------------------------------------- */
+/* obvious::TSD_PDFMatching(grid, trials, epsThresh, sizeControlSet, zrand) (TSD_PDFMatching.cpp:6-26; ThreadLocalize.cpp:193)
+ * and the arguments of its match() that are not point sets (ThreadLocalize.cpp:559) */
+typedef struct {
+  int    trials;                /* "trials" (ThreadLocalize.cpp:105), default 100 */
+  int    size_control_set;      /* "sizeControlSet" (:106), default 140 */
+  double eps_thresh;            /* "epsThresh" (:107); only sets _scaleDistance, which match() never reads */
+  double zrand;                 /* "zrand" (:112): clipped probability of a control point without a valid look-up */
+  double phi_max;               /* deg2rad("ransac_phi_max"), capped at pi/2 inside (TSD_PDFMatching.cpp:163) */
+  double ang_res;               /* sensor->getAngularResolution() */
+} tsd_tsdpdf_params;
+typedef struct {
+  double T[9];                  /* TBest, 3x3 row-major (identity when nothing scored above 0) */
+  double probability;           /* bestProb */
+  int32_t idx_model, idx_scene; /* the winning pair (beam indices), -1 if none */
+  int32_t candidates;           /* (trial, i) pairs scored */
+  int32_t valid_model, valid_scene, control_points;   /* idxMValid.size(), idxSValid.size(), Control->getCols() */
+  int32_t reserved;
+} tsd_tsdpdf_result;
+/* obvious::TSD_PDFMatching::match(TSensor, M, maskM, NULL, S, maskS, phiMax, transMax, resolution)
+ * (TSD_PDFMatching.cpp:31-294).  model / scene are beam-indexed (beams x 2, row-major) with their masks, exactly what
+ * ThreadLocalize builds from _modelCoords / _scene (ThreadLocalize.cpp:367-369).  The reference draws from rand() in
+ * three places; here the raw rand() values are inputs: draws_subsample[beams] (RandomMatching::subsampleMask,
+ * RandomMatching.cpp:176-189: one per beam, consumed only when 180 / validScenePoints < 0.99), draws_control
+ * [size_control_set] (RandomMatching::pickControlSet, :65), draws_trials[trials] (TSD_PDFMatching.cpp:190-194).  Trials
+ * are evaluated in trial order (the reference's OpenMP loop leaves the order to the scheduler): the first candidate
+ * that reaches the best probability wins.  Scoring runs on the device against the grid in HBM. */
+int tsd_tsdpdf_match(tsd_ctx* ctx, const double pose33[9], const double* model_xy_2B, const uint8_t* mask_m,
+                     const double* scene_xy_2B, const uint8_t* mask_s, int beams, const tsd_tsdpdf_params* params,
+                     const int* draws_subsample, const int* draws_control, const int* draws_trials,
+                     tsd_tsdpdf_result* result);
 
 /* ---- fused scan: ThreadLocalize::eventLoop + ThreadMapping push without a host round trip ------------ */
 /* Device-resident mirror of one robot's obvious::SensorPolar2D (pose, world / local ray maps) and of
@@ -236,7 +278,7 @@ int tsd_color_image(tsd_ctx* ctx, uint8_t* rgb_host, unsigned int width, unsigne
 
 /* ---- measurement ----------------------------------------------------------------------------- */
 /* Per-kernel HIP-event timing on the ctx stream.  Kernel names: "push_classify", "push_update",
- * "push_halo", "raycast", "icp", "occupancy". */
+ * "push_halo", "raycast", "icp", "occupancy", "tsdpdf". */
 int tsd_profile_enable(tsd_ctx* ctx, int on);
 /* restrict timing to a comma separated list of kernel names, or "all"; a "/n" suffix times every n-th
  * launch only (two event records cost ~13 us of stream time per timed launch) */

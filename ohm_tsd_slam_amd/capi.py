@@ -61,7 +61,23 @@ class IcpParams(C.Structure):
         ("max_x", C.c_double),
         ("min_y", C.c_double),
         ("max_y", C.c_double),
+        ("t_init", C.c_double * 9),      # Tinit of Icp::iterate (pre-registration result), used when use_t_init != 0
+        ("use_t_init", C.c_int),
+        ("reserved", C.c_int),
     ]
+
+
+class TsdPdfParams(C.Structure):
+    """tsd_tsdpdf_params"""
+    _fields_ = [("trials", C.c_int), ("size_control_set", C.c_int), ("eps_thresh", C.c_double), ("zrand", C.c_double),
+                ("phi_max", C.c_double), ("ang_res", C.c_double)]
+
+
+class TsdPdfResult(C.Structure):
+    """tsd_tsdpdf_result"""
+    _fields_ = [("T", C.c_double * 9), ("probability", C.c_double), ("idx_model", C.c_int32), ("idx_scene", C.c_int32),
+                ("candidates", C.c_int32), ("valid_model", C.c_int32), ("valid_scene", C.c_int32), ("control_points", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class IcpResult(C.Structure):
@@ -134,6 +150,8 @@ ABI = {
     "tsd_scan": (C.c_int, [C.c_void_p, _dp, _u8p, _u8p, C.POINTER(IcpParams), C.POINTER(GateParams),
                            C.POINTER(ScanResult)]),
     "tsd_icp_trace": (C.c_int, [C.c_void_p, _dp, C.c_int]),
+    "tsd_tsdpdf_match": (C.c_int, [C.c_void_p, _dp, _dp, _u8p, _dp, _u8p, C.c_int, C.POINTER(TsdPdfParams), _ip, _ip, _ip,
+                                   C.POINTER(TsdPdfResult)]),
     "tsd_color_image": (C.c_int, [C.c_void_p, _u8p, C.c_uint, C.c_uint]),
     "tsd_store_grid_text": (C.c_int, [C.c_void_p, C.c_char_p]),
     "tsd_load_grid_text": (C.c_int, [C.c_void_p, C.c_char_p]),
@@ -142,6 +160,7 @@ ABI = {
     "tsd_download_tile_state": (C.c_int, [C.c_void_p, _u8p, _dp]),
     "tsd_grid_digest": (C.c_int, [C.c_void_p, C.POINTER(GridDigest)]),
     "tsd_storage_bits": (C.c_int, []),
+    "tsd_abi_sizeof": (C.c_int, [C.c_char_p]),
     "tsd_occupancy": (C.c_int, [C.c_void_p, _i8p, C.c_int, C.c_int, _ip]),
     "tsd_occupancy_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "tsd_calibrate_rmw": (C.c_int, [C.c_void_p, C.c_int64, C.c_int]),
@@ -170,6 +189,12 @@ def load_library(path: str | None = None):
         fn = getattr(lib, name)     # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    # the ctypes mirrors of the public structs must have the library's layout
+    for cname, mirror in (("tsd_push_stats", PushStats), ("tsd_icp_params", IcpParams), ("tsd_icp_result", IcpResult),
+                          ("tsd_gate_params", GateParams), ("tsd_scan_result", ScanResult), ("tsd_grid_digest_t", GridDigest),
+                          ("tsd_tsdpdf_params", TsdPdfParams), ("tsd_tsdpdf_result", TsdPdfResult)):
+        if lib.tsd_abi_sizeof(cname.encode()) != C.sizeof(mirror):
+            raise TsdError(f"ABI mismatch: sizeof({cname}) = {lib.tsd_abi_sizeof(cname.encode())} in {p}, {C.sizeof(mirror)} in capi.py")
     if path is None:
         _lib = lib
     return lib
@@ -270,8 +295,28 @@ class TsdGridDevice:
         self._check(rc, "tsd_raycast")
         return coords, normals, mask, n.value
 
-    def icp_params(self, iterations, dist_max, dist_min, estimator: int = 0) -> IcpParams:
-        return IcpParams(iterations, estimator, dist_max, dist_min, self.min_x, self.max_x, self.min_y, self.max_y)
+    def icp_params(self, iterations, dist_max, dist_min, estimator: int = 0, t_init=None) -> IcpParams:
+        p = IcpParams(iterations, estimator, dist_max, dist_min, self.min_x, self.max_x, self.min_y, self.max_y)
+        if t_init is not None:
+            p.t_init = (C.c_double * 9)(*_f64(t_init).reshape(9))
+            p.use_t_init = 1
+        return p
+
+    def tsdpdf_match(self, pose, model_xy, mask_m, scene_xy, mask_s, trials, size_control_set, zrand, phi_max, ang_res,
+                     draws_sub, draws_ctrl, draws_trials, eps_thresh=0.15) -> dict:
+        """obvious::TSD_PDFMatching::match with the rand() draws as inputs (tsd_tsdpdf_match)"""
+        M, S = _f64(model_xy).reshape(-1), _f64(scene_xy).reshape(-1)
+        n = M.size // 2
+        mM, mS = np.ascontiguousarray(mask_m, dtype=np.uint8), np.ascontiguousarray(mask_s, dtype=np.uint8)
+        ds, dc, dt = (np.ascontiguousarray(x, dtype=np.int32) for x in (draws_sub, draws_ctrl, draws_trials))
+        assert ds.size >= n and dc.size >= size_control_set and dt.size >= trials
+        prm = TsdPdfParams(trials, size_control_set, eps_thresh, zrand, phi_max, ang_res)
+        r = TsdPdfResult()
+        rc = self.lib.tsd_tsdpdf_match(self.h, _d(_f64(pose).reshape(9)), _d(M), _u8(mM), _d(S), _u8(mS), n, C.byref(prm),
+                                       ds.ctypes.data_as(_ip), dc.ctypes.data_as(_ip), dt.ctypes.data_as(_ip), C.byref(r))
+        self._check(rc, "tsd_tsdpdf_match")
+        return dict(T=np.array(r.T[:]).reshape(3, 3), prob=r.probability, idx=r.idx_model, i=r.idx_scene,
+                    candidates=r.candidates, valid_model=r.valid_model, valid_scene=r.valid_scene, control=r.control_points)
 
     def icp(self, model_xy, scene_xy, pose, params: IcpParams, model_normals_xy=None) -> IcpOut:
         m = _f64(model_xy).reshape(-1)

@@ -26,7 +26,7 @@ int set_error(tsd_ctx* ctx, int code, const char* what, hipError_t e)
   return code;
 }
 
-static const char* const kKernelNames[] = {"push_classify", "push_update", "push_halo", "raycast", "icp", "occupancy"};
+static const char* const kKernelNames[] = {"push_classify", "push_update", "push_halo", "raycast", "icp", "occupancy", "tsdpdf"};
 
 bool kernel_is_timed(const tsd_ctx* ctx, const char* name)
 {
@@ -137,6 +137,9 @@ static void fill_icp_args(IcpArgs& a, const double pose33[9], const tsd_icp_para
   a.iterations = p->iterations;
   a.n_model = a.n_scene = a.beams = 0;
   a.ccw = 1; a.estimator = p->estimator;
+  // Tinit of Icp::iterate (rows 0, 1 of the 3x3): the identity unless the caller hands a pre-registration result over
+  const double I6[6] = {1, 0, 0, 0, 1, 0};
+  for (int i = 0; i < 6; i++) a.Tinit[i] = p->use_t_init ? p->t_init[i] : I6[i];
 }
 
 static void fill_raycast_args(const tsd_ctx* ctx, RaycastArgs& a, const double pose33[9], int beams,
@@ -341,6 +344,8 @@ void tsd_destroy(tsd_ctx* ctx)
   hipFree(ctx->d_coords); hipFree(ctx->d_normals); hipFree(ctx->d_mnormals); hipFree(ctx->d_mask_m); hipFree(ctx->d_model);
   hipFree(ctx->d_scene); hipFree(ctx->d_morig); hipFree(ctx->d_start); hipFree(ctx->d_icp_res); hipFree(ctx->d_icp_trace); hipHostFree(ctx->h_icp_res); hipHostFree(ctx->h_out);
   hipFree(ctx->d_occ); hipFree(ctx->d_occ_count);
+  if (ctx->d_pdf) hipFree(ctx->d_pdf);
+  if (ctx->h_pdf) hipHostFree(ctx->h_pdf);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -528,7 +533,10 @@ int tsd_icp_normals(tsd_ctx* ctx, const double* model_xy, const double* model_no
   std::vector<double> sorted_ang((size_t)n_model);
   for (int k = 0; k < n_model; k++) sorted_ang[(size_t)k] = ang[(size_t)order[(size_t)k]];
   for (int i = 0; i < n_scene; i++) {
-    const double t = std::atan2(scene_xy[2 * i + 1], scene_xy[2 * i]);
+    // (search hint only: where the point's direction falls after Tinit)
+    const double hx = a.Tinit[0] * scene_xy[2 * i] + a.Tinit[1] * scene_xy[2 * i + 1] + a.Tinit[2];
+    const double hy = a.Tinit[3] * scene_xy[2 * i] + a.Tinit[4] * scene_xy[2 * i + 1] + a.Tinit[5];
+    const double t = std::atan2(hy, hx);
     int k = (int)(std::lower_bound(sorted_ang.begin(), sorted_ang.end(), t) - sorted_ang.begin());
     start[(size_t)i] = (n_model > 0 && k >= n_model) ? 0 : k;
   }
@@ -732,6 +740,16 @@ int tsd_grid_digest(tsd_ctx* ctx, tsd_grid_digest_t* out)
 }
 
 int tsd_storage_bits(void) { return (int)(8 * sizeof(tsd_cell_t)); }
+
+int tsd_abi_sizeof(const char* n)
+{
+  if (!n) return 0;
+#define TSD_SZ(T) if (std::strcmp(n, #T) == 0) return (int)sizeof(T)
+  TSD_SZ(tsd_push_stats); TSD_SZ(tsd_icp_params); TSD_SZ(tsd_icp_result); TSD_SZ(tsd_gate_params); TSD_SZ(tsd_scan_result);
+  TSD_SZ(tsd_grid_digest_t); TSD_SZ(tsd_tsdpdf_params); TSD_SZ(tsd_tsdpdf_result);
+#undef TSD_SZ
+  return 0;
+}
 
 int tsd_store_grid_text(tsd_ctx* ctx, const char* path)
 {

@@ -63,31 +63,46 @@ ThreadLocalize::ThreadLocalize(obvious::TsdGrid* grid, ThreadMapping* mapper, co
   _nameSpace = node_name + _robotName;
   const std::string poseTopic = _nameSpace + "estimated_pose";
 
-  // parameters: names and defaults of SlamNode.cpp:40-58 / ThreadLocalize.cpp:86-129 (Appendix D)
-  const double distFilterMax = param(node, _robotName + "dist_filter_max", 1.0).as_double();
-  const double distFilterMin = param(node, _robotName + "dist_filter_min", 0.1).as_double();
-  const int icpIterations    = (int)param(node, _robotName + "icp_iterations", 25).as_int();
-  _tfLaserFrameId     = param(node, _robotName + "tf_laser_frame", std::string("laser")).as_string();
-  _tfMapFrameId       = param(node, "tf_map_frame", std::string("map")).as_string();
-  _tfOdomFrameId      = param(node, _robotName + "tf_odom_frame", std::string("odom")).as_string();
-  _tfFootprintFrameId = param(node, _robotName + "tf_footprint_frame", std::string("base_footprint")).as_string();
-  _trnsMax     = param(node, "reg_trs_max", 0.25).as_double();
-  _rotMax      = param(node, "reg_sin_rot_max", 0.17).as_double();
-  (void)param(node, "max_velocity_lin", 1.5);
-  (void)param(node, "max_velocity_rot", 2.0 * M_PI);
-  (void)param(node, "ude_odom_rescue", false);
-  (void)param(node, "wait_for_odom_tf", 1.0);
-  _lasMinRange = param(node, "laser_min_range", 0.0).as_double();
-  _regMode     = (int)param(node, _robotName + "registration_mode", 0).as_int();
-  if(_regMode != 0)
+  // parameters: names, types and defaults of ThreadLocalize.cpp:86-129 (Appendix D)
+  declareParameters(node, _robotName);
+  const double distFilterMax = node->get_parameter(_robotName + "dist_filter_max").as_double();
+  const double distFilterMin = node->get_parameter(_robotName + "dist_filter_min").as_double();
+  const int icpIterations    = (int)node->get_parameter(_robotName + "icp_iterations").as_int();
+  _tfLaserFrameId     = node->get_parameter(_robotName + "tf_laser_frame").as_string();
+  _tfMapFrameId       = param(node, "tf_map_frame", std::string("map")).as_string();     // declared by SlamNode (SlamNode.cpp:58)
+  _tfOdomFrameId      = node->get_parameter(_robotName + "tf_odom_frame").as_string();
+  _tfFootprintFrameId = node->get_parameter(_robotName + "tf_footprint_frame").as_string();
+  _trnsMax     = node->get_parameter("reg_trs_max").as_double();
+  _rotMax      = node->get_parameter("reg_sin_rot_max").as_double();
+  _lasMinRange = node->get_parameter("laser_min_range").as_double();
+  _regMode     = (int)node->get_parameter(_robotName + "registration_mode").as_int();
+  _ranPhiMax   = node->get_parameter(_robotName + "ransac_phi_max").as_double();
+  _preMatcher.reset();
+  switch(_regMode)
   {
-    std::fprintf(stderr, "Localizer(%s): registration mode %d (wall-clock seeded RANSAC pre-registration) is not part of "
-                         "the GPU hot path; using default = ICP.\n", _nameSpace.c_str(), _regMode);
+  case 0:   // ICP: no instance needed
+    break;
+  case 3:   // TSD (ThreadLocalize.cpp:193): TSD_PDFMatching(_grid, trials, epsThresh, sizeControlSet, zrand)
+    _preMatcher.reset(new obvious::TSD_PDFMatching(*grid, (unsigned)node->get_parameter("trials").as_int(),
+                                                   node->get_parameter("epsThresh").as_double(),
+                                                   (unsigned)node->get_parameter("sizeControlSet").as_int(),
+                                                   node->get_parameter("zrand").as_double()));
+    _preMatcher->setSeed((long)param(node, _robotName + "tsdpdf_seed", -1).as_int());   // addition: reproducible draws for tests
+    break;
+  case 1:   // EXP: RandomNormalMatching
+  case 2:   // PDF: PDFMatching
+    std::fprintf(stderr, "Localizer(%s): registration mode %d (RandomNormalMatching / PDFMatching pre-registration) is not part of "
+                         "the GPU hot path (SURVEY 2: out of scope); using default = ICP.\n", _nameSpace.c_str(), _regMode);
+    _regMode = 0;
+    break;
+  default:  // ThreadLocalize.cpp:188-190
+    std::fprintf(stderr, "Localizer(%s): Unknown registration mode %d use default = ICP.\n", _nameSpace.c_str(), _regMode);
     _regMode = 0;
   }
 
   // ICP set-up (ThreadLocalize.cpp:211-225): DistanceFilter(max, min, icpIterations - 10), bounds filter
   // over the grid extent, maxRMS 0, max iterations == convergence counter == icpIterations
+  std::memset(&_icpParams, 0, sizeof(_icpParams));
   _icpParams.iterations      = icpIterations;
   // The node constructs ClosedFormEstimator2D (ThreadLocalize.cpp:214); "icp_estimator" = 1 selects the reference's
   // other estimator, PointToLine2DEstimator, on the ray cast's normals (an addition: the reference has no such key)
@@ -116,6 +131,59 @@ ThreadLocalize::~ThreadLocalize()
   delete _sensor;
   delete _lastPose;
   _laserData.clear();
+}
+
+// ThreadLocalize.cpp:86-129: every parameter the reference's constructor declares, with its type and default
+// (tests/test_cpu_abi_and_host.py diffs this set against a table transcribed from those lines)
+void ThreadLocalize::declareParameters(const std::shared_ptr<rclcpp::Node>& node, const std::string& robotName)
+{
+  (void)param(node, robotName + "dist_filter_max", 1.0);          // DIST_FILT_MAX (ThreadLocalize.h:66)
+  (void)param(node, robotName + "dist_filter_min", 0.1);          // DIST_FILT_MIN (:65)
+  (void)param(node, robotName + "icp_iterations", 25);            // ICP_ITERATIONS (:58)
+  (void)param(node, robotName + "tf_laser_frame", robotName + "laser");
+  (void)param(node, robotName + "tf_odom_frame", robotName + "odom");
+  (void)param(node, robotName + "tf_footprint_frame", robotName + "base_footprint");
+  (void)param(node, "reg_trs_max", 0.25);                         // TRNS_THRESH
+  (void)param(node, "reg_sin_rot_max", 0.17);                     // ROT_THRESH
+  (void)param(node, "max_velocity_lin", 1.5);                     // TRNS_VEL_MAX
+  (void)param(node, "max_velocity_rot", 2.0 * M_PI);              // ROT_VEL_MAX
+  (void)param(node, "ude_odom_rescue", false);
+  (void)param(node, "wait_for_odom_tf", 1.0);
+  (void)param(node, "laser_min_range", 0.0);
+  (void)param(node, "trials", 100);
+  (void)param(node, "sizeControlSet", 140);
+  (void)param(node, "epsThresh", 0.15);
+  (void)param(node, "zhit", 0.45);
+  (void)param(node, "zphi", 0.0);
+  (void)param(node, "zshort", 0.25);
+  (void)param(node, "zmax", 0.05);
+  (void)param(node, "zrand", 0.25);
+  (void)param(node, "percentagePointsInC", 0.9);
+  (void)param(node, "rangemax", 20.0);
+  (void)param(node, "sigphi", M_PI / 180.0 * 3);
+  (void)param(node, "sighit", 0.2);
+  (void)param(node, "lamshort", 0.08);
+  (void)param(node, "maxAngleDiff", 3.0);
+  (void)param(node, "maxAnglePenalty", 0.5);
+  (void)param(node, robotName + "ransac_trials", 50);             // RANSAC_TRIALS
+  (void)param(node, robotName + "ransac_eps_thresh", 0.15);       // RANSAC_EPS_THRESH
+  (void)param(node, robotName + "ransac_ctrlset_size", 180);      // RANSAC_CTRL_SET_SIZE
+  (void)param(node, robotName + "ransac_phi_max", 30.0);
+  (void)param(node, robotName + "registration_mode", 0);          // ICP
+}
+
+// ThreadLocalize::init (ThreadLocalize.cpp:424-432): the per-robot parameters declared with the first scan
+void ThreadLocalize::declareInitParameters(const std::shared_ptr<rclcpp::Node>& node, const std::string& nameSpace)
+{
+  (void)param(node, nameSpace + "local_offset_x", 0.0);
+  (void)param(node, nameSpace + "local_offset_y", 0.0);
+  (void)param(node, nameSpace + "local_offset_yaw", 0.0);
+  (void)param(node, nameSpace + "max_range", 30.0);
+  (void)param(node, nameSpace + "min_range", 0.001);
+  (void)param(node, nameSpace + "low_reflectivity_range", 2.0);
+  (void)param(node, nameSpace + "footprint_width", 1.0);
+  (void)param(node, nameSpace + "footprint_height", 1.0);
+  (void)param(node, nameSpace + "footprint_x_offset", 0.28);
 }
 
 void ThreadLocalize::laserCallBack(const std::shared_ptr<sensor_msgs::msg::LaserScan> scan)
@@ -197,6 +265,11 @@ void ThreadLocalize::processScan(const std::vector<float>& ranges, const builtin
     _haveLastPose = true;
   }
 
+  if(_regMode == 3 && _preMatcher)
+  {
+    processScanPreRegistered(rep);
+    return;
+  }
   if(_fused && _sensor->deviceHandle())
   {
     processScanFused(rep);
@@ -224,12 +297,71 @@ void ThreadLocalize::processScan(const std::vector<float>& ranges, const builtin
     _report = rep; _processed++;
     return;
   }
+  finishScan(rep, res);
+}
+
+// registration_mode 3 (ThreadLocalize.cpp:353-406 with doRegistration's case TSD, :557-567): ray cast, the TSD_PDF
+// pre-registration on the beam-indexed model / scene, then Icp::iterate with its result as Tinit.  The unfused call
+// structure of the reference: the pre-registration's host part sits between the ray cast and the registration.
+void ThreadLocalize::processScanPreRegistered(ScanReport& rep)
+{
+  const unsigned int n = _sensor->getRealMeasurementSize();
+  if(_modelCoords.size() != 2 * (size_t)n)      // first call: buffers (ThreadLocalize.cpp:342-350)
+  {
+    _modelCoords.assign(2 * (size_t)n, 0.0); _modelNormals.assign(2 * (size_t)n, 0.0); _scene.assign(2 * (size_t)n, 0.0);
+    _maskM.assign(n, 0); _maskS.assign(n, 0);
+  }
+  bool* maskM = reinterpret_cast<bool*>(_maskM.data());
+  bool* maskS = reinterpret_cast<bool*>(_maskS.data());
+  unsigned int validModelPoints = 0;
+  const int rcR = _grid.raycast(_sensor, _modelCoords.data(), _modelNormals.data(), maskM, &validModelPoints);
+  _sensor->getTransformation().getData(rep.pose);
+  rep.validModel = (int)validModelPoints;
+  if(rcR != TSD_OK || validModelPoints == 0)
+  {
+    if(rcR != TSD_OK) std::fprintf(stderr, "Localizer(%s) device error %d\n", _nameSpace.c_str(), rcR);
+    rep.noModel = rcR == TSD_OK;
+    std::lock_guard<std::mutex> lk(_reportMutex);
+    _report = rep; _processed++;
+    return;
+  }
+  const unsigned int validScenePoints = _sensor->dataToCartesianVectorMask(_scene.data(), maskS);
+  rep.validScene = (int)validScenePoints;
+  // maskMatrix (ThreadLocalize.cpp:738-755)
+  std::vector<double> Mvalid(2 * (size_t)validModelPoints), Svalid(2 * (size_t)validScenePoints);
+  {
+    size_t c = 0;
+    for(unsigned int i = 0; i < n; i++) if(maskM[i]) { Mvalid[c++] = _modelCoords[2 * i]; Mvalid[c++] = _modelCoords[2 * i + 1]; }
+    c = 0;
+    for(unsigned int i = 0; i < n; i++) if(maskS[i]) { Svalid[c++] = _scene[2 * i]; Svalid[c++] = _scene[2 * i + 1]; }
+  }
+  // doRegistration, case TSD: T = _TSD_PDFMatcher->match(sensor->getTransformation(), M, _maskM, NULL, S, _maskS,
+  //                                                      deg2rad(_ranPhiMax), _trnsMax, sensor->getAngularResolution())
+  obvious::Matrix Tpre = _preMatcher->match(_sensor->getTransformation(), _modelCoords.data(), maskM, nullptr, _scene.data(), maskS,
+                                            n, _ranPhiMax * M_PI / 180.0, _trnsMax, _sensor->getAngularResolution());
+  tsd_icp_params p = _icpParams;
+  Tpre.getData(p.t_init);
+  p.use_t_init = 1;
+  tsd_icp_result res;
+  std::memset(&res, 0, sizeof(res));
+  const int rc = _grid.icp(Mvalid.data(), validModelPoints, Svalid.data(), validScenePoints, _sensor->getTransformation(), p, &res);
+  if(rc != TSD_OK)
+  {
+    std::fprintf(stderr, "Localizer(%s) device error %d\n", _nameSpace.c_str(), rc);
+    std::lock_guard<std::mutex> lk(_reportMutex);
+    _report = rep; _processed++;
+    return;
+  }
+  finishScan(rep, res);
+}
+
+// what follows the registration (ThreadLocalize.cpp:381-406): gate, Sensor::transform, pose / tf, push decision
+void ThreadLocalize::finishScan(ScanReport& rep, const tsd_icp_result& res)
+{
   obvious::Matrix T(3, 3, res.T);
   std::memcpy(rep.T, res.T, sizeof(rep.T));
   rep.rms = res.rms; rep.pairs = res.pairs; rep.iterations = res.iterations; rep.icpState = res.state;
-
-  const bool regErrorT = isRegistrationError(&T, _trnsMax, _rotMax);
-  if(regErrorT)
+  if(isRegistrationError(&T, _trnsMax, _rotMax))
   {
     rep.regError = true;
     sendNanTransform();
@@ -315,15 +447,16 @@ void ThreadLocalize::processScanFused(ScanReport& rep)
 void ThreadLocalize::init(const sensor_msgs::msg::LaserScan& scan)
 {
   // per-robot parameters (ThreadLocalize.cpp:424-442)
-  const double localXoffset   = param(_node, _nameSpace + "local_offset_x", 0.0).as_double();
-  const double localYoffset   = param(_node, _nameSpace + "local_offset_y", 0.0).as_double();
-  const double localYawOffset = param(_node, _nameSpace + "local_offset_yaw", 0.0).as_double();
-  const double maxRange       = param(_node, _nameSpace + "max_range", 30.0).as_double();
-  const double minRange       = param(_node, _nameSpace + "min_range", 0.001).as_double();
-  const double lowReflectivityRange = param(_node, _nameSpace + "low_reflectivity_range", 2.0).as_double();
-  const double footPrintWidth   = param(_node, _nameSpace + "footprint_width", 1.0).as_double();
-  const double footPrintHeight  = param(_node, _nameSpace + "footprint_height", 1.0).as_double();
-  const double footPrintXoffset = param(_node, _nameSpace + "footprint_x_offset", 0.28).as_double();
+  declareInitParameters(_node, _nameSpace);
+  const double localXoffset   = _node->get_parameter(_nameSpace + "local_offset_x").as_double();
+  const double localYoffset   = _node->get_parameter(_nameSpace + "local_offset_y").as_double();
+  const double localYawOffset = _node->get_parameter(_nameSpace + "local_offset_yaw").as_double();
+  const double maxRange       = _node->get_parameter(_nameSpace + "max_range").as_double();
+  const double minRange       = _node->get_parameter(_nameSpace + "min_range").as_double();
+  const double lowReflectivityRange = _node->get_parameter(_nameSpace + "low_reflectivity_range").as_double();
+  const double footPrintWidth   = _node->get_parameter(_nameSpace + "footprint_width").as_double();
+  const double footPrintHeight  = _node->get_parameter(_nameSpace + "footprint_height").as_double();
+  const double footPrintXoffset = _node->get_parameter(_nameSpace + "footprint_x_offset").as_double();
 
   const double phi    = localYawOffset;
   const double startX = _gridWidth * 0.5 + _xOffset + localXoffset;

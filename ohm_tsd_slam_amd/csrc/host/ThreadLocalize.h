@@ -2,9 +2,9 @@
 // ThreadLocalize (src/ThreadLocalize.h:73-104): same constructor, same laserCallBack entry point, same
 // parameters, topic and message content.  The arithmetic of eventLoop (ray cast, ICP) runs on the GPU
 // through obvious::TsdGrid::localize; scan ingest, gates and pose bookkeeping stay on the host.
-// registration_mode 0 (ICP only) is implemented; modes 1-3 are the reference's RANSAC-style
-// pre-registrations seeded with wall-clock time (out of scope) and fall back to 0 with a
-// warning, as the reference does for unknown modes (ThreadLocalize.cpp:188-190).
+// registration_mode 0 (ICP only) and 3 (TSD_PDF pre-registration + ICP, what config/single-laser.yaml ships) are
+// implemented; modes 1 / 2 (RandomNormalMatching / PDFMatching, SURVEY 2: out of scope) fall back to 0 with a warning,
+// as the reference does for unknown modes (ThreadLocalize.cpp:188-190).
 #pragma once
 #include <deque>
 #include <memory>
@@ -54,6 +54,10 @@ public:
   std::shared_ptr<rclcpp::Publisher<geometry_msgs::msg::PoseStamped>> posePublisher() { return _posePub; }
   obvious::SensorPolar2D* sensor() { return _sensor; }
 
+  // every parameter the reference declares in the constructor (ThreadLocalize.cpp:86-129) / in init (:424-432)
+  static void declareParameters(const std::shared_ptr<rclcpp::Node>& node, const std::string& robotName);
+  static void declareInitParameters(const std::shared_ptr<rclcpp::Node>& node, const std::string& nameSpace);
+
   // gates (static: also unit-tested against the oracle)
   static double calcAngle(obvious::Matrix* T);                                               // :715-726
   static bool isRegistrationError(obvious::Matrix* T, const double trnsMax, const double rotMax);   // :593-600
@@ -66,6 +70,8 @@ private:
   void init(const sensor_msgs::msg::LaserScan& scan);
   void processScan(const std::vector<float>& rangesIn, const builtin_interfaces::msg::Time& stamp);
   void processScanFused(ScanReport& rep);
+  void processScanPreRegistered(ScanReport& rep);
+  void finishScan(ScanReport& rep, const tsd_icp_result& res);
   void sendTransform(obvious::Matrix* T);
   void sendNanTransform();
 
@@ -80,6 +86,10 @@ private:
   std::string _tfMapFrameId, _tfOdomFrameId, _tfLaserFrameId, _tfFootprintFrameId;
   double _trnsMax, _rotMax, _lasMinRange;
   int _regMode;
+  double _ranPhiMax;
+  std::unique_ptr<obvious::TSD_PDFMatching> _preMatcher;      // _TSD_PDFMatcher (ThreadLocalize.h)
+  std::vector<double> _modelCoords, _modelNormals, _scene;     // beam-indexed buffers of the event loop (:342-350)
+  std::vector<uint8_t> _maskM, _maskS;
   bool _reverseScan;
   tsd_icp_params _icpParams;
   obvious::Matrix* _lastPose;

@@ -1,6 +1,7 @@
 // facade_capi.cpp -- a flat C surface over the C++ facade so that the Python test / bench drivers can
 // exercise ThreadLocalize / ThreadMapping exactly as SlamNode wires them (SlamNode.cpp:27-129): one
 // TsdGrid, one ThreadMapping, N ThreadLocalize sharing them, laser callbacks per robot.
+#include <cstdio>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -36,10 +37,9 @@ void tsd_node_set_int(tsd_node* n, const char* name, int v) { n->node->set_param
 void tsd_node_set_bool(tsd_node* n, const char* name, int v) { n->node->set_parameter(name, v != 0); }
 void tsd_node_set_string(tsd_node* n, const char* name, const char* v) { n->node->set_parameter(name, std::string(v)); }
 
-// SlamNode::initialize (SlamNode.cpp:40-122): grid parameters, grid, mapping thread, localisers
-int tsd_node_initialize(tsd_node* n, int device)
+// the parameters SlamNode::initialize declares (SlamNode.cpp:40-58)
+static void declare_node_parameters(const std::shared_ptr<rclcpp::Node>& node)
 {
-  auto& node = n->node;
   node->declare_parameter("robot_nbr", 1);
   node->declare_parameter("x_off_factor", 0.5);
   node->declare_parameter("y_off_factor", 0.5);
@@ -50,6 +50,59 @@ int tsd_node_initialize(tsd_node* n, int device)
   node->declare_parameter("truncation_radius", 3);
   node->declare_parameter("occ_grid_time_interval", 2.0);
   node->declare_parameter("tf_map_frame", std::string("map"));
+  // ThreadGrid's (ThreadGrid.cpp:42-47): the occupancy thread itself is out of scope, its extraction kernels (row N1) take
+  // these as arguments; declared so that the shipped YAMLs (config/single-laser.yaml) load as they are
+  node->declare_parameter("pub_tsd_color_map", true);
+  node->declare_parameter("object_inflation_factor", 2);
+  node->declare_parameter("use_object_inflation", false);
+}
+
+#if !OHM_TSD_SLAM_HAVE_ROS
+// Parameter surface without a device (CPU test): what SlamNode::initialize, every ThreadLocalize constructor and
+// every ThreadLocalize::init would declare, as "name|type|default" lines.  Returns the bytes needed.
+int tsd_node_declared_parameters(tsd_node* n, char* buf, int cap)
+{
+  auto& node = n->node;
+  declare_node_parameters(node);
+  const unsigned robotNbr = (unsigned)node->get_parameter("robot_nbr").as_int();
+  const std::string node_name = std::string(node->get_name()) + "/";
+  for(unsigned i = 0; i < robotNbr; i++)
+  {
+    std::string robot = "";
+    if(robotNbr > 1)
+    {
+      const std::string key = "robot_" + std::to_string(i) + "/name";
+      node->declare_parameter(key, "robot_" + std::to_string(i));
+      robot = node->get_parameter(key).as_string();
+      if(robot.size() > 0 && robot.back() != '/') robot += "/";
+    }
+    ThreadLocalize::declareParameters(node, robot);
+    ThreadLocalize::declareInitParameters(node, node_name + robot);
+  }
+  std::string out;
+  for(const auto& kv : node->declared_parameters())
+  {
+    const auto& v = kv.second.value();
+    char num[64];
+    if(std::holds_alternative<bool>(v)) out += kv.first + "|bool|" + (std::get<bool>(v) ? "true" : "false") + "\n";
+    else if(std::holds_alternative<int64_t>(v)) out += kv.first + "|int|" + std::to_string(std::get<int64_t>(v)) + "\n";
+    else if(std::holds_alternative<double>(v)) { std::snprintf(num, sizeof(num), "%.17g", std::get<double>(v)); out += kv.first + "|double|" + num + "\n"; }
+    else out += kv.first + "|string|" + std::get<std::string>(v) + "\n";
+  }
+  if(buf && cap > 0)
+  {
+    std::strncpy(buf, out.c_str(), (size_t)cap - 1);
+    buf[cap - 1] = 0;
+  }
+  return (int)out.size() + 1;
+}
+#endif
+
+// SlamNode::initialize (SlamNode.cpp:40-122): grid parameters, grid, mapping thread, localisers
+int tsd_node_initialize(tsd_node* n, int device)
+{
+  auto& node = n->node;
+  declare_node_parameters(node);
   const unsigned robotNbr = (unsigned)node->get_parameter("robot_nbr").as_int();
   const double xOffset = node->get_parameter("x_offset").as_double();
   const double yOffset = node->get_parameter("y_offset").as_double();

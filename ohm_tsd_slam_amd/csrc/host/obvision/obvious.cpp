@@ -1,5 +1,7 @@
 // obvious.cpp -- host-side sensor model and the device-grid handle (see obvious.h).
 #include "obvious.h"
+#include <cstdlib>
+#include <ctime>
 
 #include <algorithm>
 #include <cstdio>
@@ -294,6 +296,28 @@ int TsdGrid::localize(SensorPolar2D* sensor, const tsd_icp_params& params, tsd_i
                       sensor->getMinimumRange(), sensor->getMaximumRange(), &params, result);
 }
 
+int TsdGrid::raycast(SensorPolar2D* sensor, double* coords, double* normals, bool* mask, unsigned int* validPoints)
+{
+  double pose[9];
+  sensor->getTransformation().getData(pose);
+  const double* rays = sensor->getNormalizedRayMap(getCellSize());   // RayCastPolar2D.cpp:122
+  int n = 0;
+  std::lock_guard<std::mutex> lk(_mutex);
+  const int rc = tsd_raycast(_ctx, pose, rays, (int)sensor->getRealMeasurementSize(), sensor->getMinimumRange(),
+                             sensor->getMaximumRange(), coords, normals, reinterpret_cast<uint8_t*>(mask), &n);
+  if (validPoints) *validPoints = (unsigned)n;
+  return rc;
+}
+
+int TsdGrid::icp(const double* modelValid, unsigned nModel, const double* sceneValid, unsigned nScene, const Matrix& sensorPose,
+                 const tsd_icp_params& params, tsd_icp_result* result)
+{
+  double pose[9];
+  sensorPose.getData(pose);
+  std::lock_guard<std::mutex> lk(_mutex);
+  return tsd_icp(_ctx, modelValid, (int)nModel, sceneValid, (int)nScene, pose, &params, result);
+}
+
 int TsdGrid::attachSensor(SensorPolar2D* sensor)
 {
   double pose[9];
@@ -318,6 +342,46 @@ int TsdGrid::scan(SensorPolar2D* sensor, const uint8_t* maskPush, const tsd_icp_
                           &params, &gates, result);
   if (rc == TSD_OK && result->pushed) _initialPushAccomplished = true;
   return rc;
+}
+
+// --------------------------------------------------------------------------------------- TSD_PDFMatching
+TSD_PDFMatching::TSD_PDFMatching(TsdGrid& grid, unsigned int trials, double epsThresh, unsigned int sizeControlSet, double zrand)
+    : _grid(grid), _trials(trials), _sizeControlSet(sizeControlSet), _epsThresh(epsThresh), _zrand(zrand), _seed(-1), _calls(0)
+{
+  std::memset(&_last, 0, sizeof(_last));
+}
+
+Matrix TSD_PDFMatching::match(Matrix TSensor, const double* M, const bool* maskM, const double* /*NM*/, const double* S,
+                              const bool* maskS, unsigned int points, double phiMax, const double /*transMax*/,
+                              const double resolution)
+{
+  Matrix TBest(3, 3);
+  TBest.setIdentity();
+  // the three rand() streams, in the reference's call order
+  if (_seed >= 0) std::srand((unsigned)(_seed + (long)_calls));
+  _calls++;
+  std::vector<int> dSub(points), dCtrl(_sizeControlSet > 0 ? _sizeControlSet : 1), dTrials(_trials > 0 ? _trials : 1);
+  for (auto& v : dSub) v = std::rand();                      // RandomMatching::subsampleMask (RandomMatching.cpp:183)
+  for (auto& v : dCtrl) v = std::rand();                     // RandomMatching::pickControlSet (:65)
+  if (_seed < 0) std::srand((unsigned)time(NULL));           // TSD_PDFMatching.cpp:184
+  for (auto& v : dTrials) v = std::rand();                   // TSD_PDFMatching.cpp:190
+  tsd_tsdpdf_params prm;
+  prm.trials = (int)_trials; prm.size_control_set = (int)_sizeControlSet; prm.eps_thresh = _epsThresh; prm.zrand = _zrand;
+  prm.phi_max = phiMax; prm.ang_res = resolution;
+  double pose[9];
+  TSensor.getData(pose);
+  int rc;
+  {
+    std::lock_guard<std::mutex> lk(_grid.mutex());
+    rc = tsd_tsdpdf_match(_grid.context(), pose, M, reinterpret_cast<const uint8_t*>(maskM), S,
+                          reinterpret_cast<const uint8_t*>(maskS), (int)points, &prm, dSub.data(), dCtrl.data(), dTrials.data(), &_last);
+  }
+  if (rc != TSD_OK) {
+    std::fprintf(stderr, "TSD_PDFMatching::match failed (%d): %s\n", rc, tsd_last_error(_grid.context()));
+    return TBest;
+  }
+  TBest.setData(_last.T);
+  return TBest;
 }
 
 }  // namespace obvious

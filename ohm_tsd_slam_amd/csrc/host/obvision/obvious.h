@@ -133,6 +133,12 @@ public:
   // ThreadLocalize's ray cast + registration, fused on the device (tsd_localize)
   virtual int localize(SensorPolar2D* sensor, const tsd_icp_params& params, tsd_icp_result* result);
 
+  // the two halves of localize() as separate calls (registration_mode 1-3 runs a pre-registration between them,
+  // ThreadLocalize.cpp:353-377, :531-581): RayCastPolar2D::calcCoordsFromCurrentViewMask and Icp::iterate with Tinit
+  virtual int raycast(SensorPolar2D* sensor, double* coords, double* normals, bool* mask, unsigned int* validPoints);
+  virtual int icp(const double* modelValid, unsigned nModel, const double* sceneValid, unsigned nScene, const Matrix& sensorPose,
+                  const tsd_icp_params& params, tsd_icp_result* result);
+
   // fused scan path: the sensor's pose / ray maps live on the device next to the grid, one call runs
   // ray cast -> registration -> gates -> Sensor::transform -> push in stream order (tsd_scan)
   virtual int attachSensor(SensorPolar2D* sensor);
@@ -145,6 +151,33 @@ protected:
   tsd_ctx* _ctx;
   std::mutex _mutex;
   bool _initialPushAccomplished;
+};
+
+// obvious::TSD_PDFMatching (registration/ransacMatching/TSD_PDFMatching.{h,cpp}) on obvious::RandomMatching: the
+// pre-registration of registration_mode 3.  Same constructor and match() signature as the reference; the scoring of
+// the candidates runs on the device (tsd_tsdpdf_match), the three rand() streams are drawn here, where the reference
+// draws them (RandomMatching.cpp:65, :183; TSD_PDFMatching.cpp:190).
+class TSD_PDFMatching
+{
+public:
+  TSD_PDFMatching(TsdGrid& grid, unsigned int trials = 50, double epsThresh = 0.15, unsigned int sizeControlSet = 140,
+                  double zrand = 0.05);
+  virtual ~TSD_PDFMatching() {}
+  /** NM (model normals) is accepted for signature compatibility; ThreadLocalize passes NULL and the normals come from
+   *  the PCA of RandomMatching::calcNormals, as in the reference's call (ThreadLocalize.cpp:559) */
+  Matrix match(Matrix TSensor, const double* M, const bool* maskM, const double* NM, const double* S, const bool* maskS,
+               unsigned int points, double phiMax = M_PI / 4.0, const double transMax = 1.5, const double resolution = 0.0);
+  /** addition (tests): >= 0 makes the draws reproducible -- srand(seed + number of calls so far) before drawing; the
+   *  default -1 keeps the reference's behaviour (srand(time(NULL)) before the trial picks, TSD_PDFMatching.cpp:184) */
+  void setSeed(long seed) { _seed = seed; }
+  const tsd_tsdpdf_result& lastResult() const { return _last; }
+private:
+  TsdGrid& _grid;
+  unsigned int _trials, _sizeControlSet;
+  double _epsThresh, _zrand;
+  long _seed;
+  unsigned long _calls;
+  tsd_tsdpdf_result _last;
 };
 
 }  // namespace obvious

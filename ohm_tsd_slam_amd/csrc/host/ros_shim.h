@@ -66,6 +66,7 @@ public:
   int64_t as_int() const { return std::holds_alternative<int64_t>(_v) ? std::get<int64_t>(_v) : (int64_t)std::get<double>(_v); }
   double as_double() const { return std::holds_alternative<double>(_v) ? std::get<double>(_v) : (double)std::get<int64_t>(_v); }
   std::string as_string() const { return std::get<std::string>(_v); }
+  const Value& value() const { return _v; }
 private:
   Value _v;
 };
@@ -95,9 +96,12 @@ public:
   template <class T>
   void declare_parameter(const std::string& name, const T& def) {
     std::lock_guard<std::mutex> lk(_mx);
+    if (!_declared.count(name)) _declared[name] = Parameter(to_value(def));     // what the code declares (name, type, default)
     if (_params.count(name)) return;
     _params[name] = Parameter(to_value(def));
   }
+  /** every declare_parameter() so far with its DECLARED default (an earlier set_parameter does not show here) */
+  std::map<std::string, Parameter> declared_parameters() const { std::lock_guard<std::mutex> lk(_mx); return _declared; }
   bool has_parameter(const std::string& name) const { std::lock_guard<std::mutex> lk(_mx); return _params.count(name) != 0; }
   Parameter get_parameter(const std::string& name) const {
     std::lock_guard<std::mutex> lk(_mx);
@@ -122,7 +126,7 @@ private:
   std::string _name;
   std::shared_ptr<Clock> _clock = std::make_shared<Clock>();
   mutable std::mutex _mx;
-  std::map<std::string, Parameter> _params;
+  std::map<std::string, Parameter> _params, _declared;
 };
 
 }  // namespace rclcpp

@@ -559,7 +559,14 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
     if (nM <= cap && nS <= cap) {
       for (int j = tid; j < nM; j += T) { L.mxy[j] = make_double2(g_model[2 * j], g_model[2 * j + 1]); L.morig[j] = g_morig[j]; }
       if (L.nxy) for (int j = tid; j < nM; j += T) L.nxy[j] = make_double2(g_mnormals[2 * j], g_mnormals[2 * j + 1]);
-      for (int i = tid; i < nS; i += T) { L.stage_s[i] = make_double2(g_scene[2 * i], g_scene[2 * i + 1]); L.start[i] = g_start[i]; }
+      // applyTransformation(_sceneTmp, Tinit) (Icp.cpp:481-486, :371-408): (0 + x*R00) + y*R01, then + t; Tinit is the
+      // identity unless a pre-registration ran (x*1 + y*0 + 0 == x exactly, so mode 0 is unchanged)
+      for (int i = tid; i < nS; i += T) {
+        const double x = g_scene[2 * i], y = g_scene[2 * i + 1];
+        double nx = 0.0, ny = 0.0;
+        nx += x * a.Tinit[0]; nx += y * a.Tinit[1]; ny += x * a.Tinit[3]; ny += y * a.Tinit[4];
+        L.stage_s[i] = make_double2(nx + a.Tinit[2], ny + a.Tinit[5]); L.start[i] = g_start[i];
+      }
     }
     __syncthreads();
   }
@@ -568,7 +575,8 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
     L.ired[IR_CNT] = 0; L.ired[IR_RMAX] = 0; L.ired[IR_CNT2] = 0; L.ired[IR_TIE] = 0;
   }
 
-  double Tf[6] = {1, 0, 0, 0, 1, 0};   // rows 0,1 of _Tfinal4x4: [r00 r01 tx ; r10 r11 ty]
+  // rows 0,1 of _Tfinal4x4: [r00 r01 tx ; r10 r11 ty]; (*_Tfinal4x4) = (*Tinit) * I (Icp.cpp:485)
+  double Tf[6] = {a.Tinit[0], a.Tinit[1], a.Tinit[2], a.Tinit[3], a.Tinit[4], a.Tinit[5]};
   double rms = 0.0;
   int pairs = 0, state = TSD_ICP_PROCESSING;
   unsigned int iter = 0;

@@ -40,6 +40,7 @@ struct IcpArgs {
   int beams;                 // fused mode (compaction from per-beam arrays) when > 0
   int ccw;                   // model slots ascend counter-clockwise about the sensor (1) or clockwise (0)
   int estimator;             // TSD_ESTIMATOR_*
+  double Tinit[6];           // rows 0, 1 of Icp::iterate's Tinit (identity in registration_mode 0; direct mode only)
 };
 
 struct IcpResultDev {
@@ -159,6 +160,9 @@ struct tsd_ctx {
   tsd::IcpResultDev* h_icp_res = nullptr;    // pinned
   char* h_out = nullptr;                     // pinned D2H staging (ray-cast outputs)
   size_t h_out_bytes = 0;
+
+  // TSD_PDF pre-registration (tsdpdf.hip): one device + one pinned staging buffer, grown on demand
+  char* d_pdf = nullptr; char* h_pdf = nullptr; size_t pdf_bytes = 0;
 
   // occupancy
   int8_t* d_occ = nullptr;       // persistent map (ThreadGrid::_occGridContent)

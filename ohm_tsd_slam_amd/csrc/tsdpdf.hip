@@ -1,0 +1,325 @@
+// tsdpdf.hip -- SURVEY 8(f) row N3: the TSD_PDF pre-registration ThreadLocalize runs before the ICP in
+// registration_mode 3 (ThreadLocalize.cpp:557-567; config/single-laser.yaml:28 ships this mode):
+// obvious::TSD_PDFMatching::match (registration/ransacMatching/TSD_PDFMatching.cpp:31-294) on top of
+// obvious::RandomMatching (RandomMatching.cpp:41-189).
+//
+// What it computes.  For `trials` randomly picked model points m_idx (ray-cast hits with a PCA normal) and every
+// scene point s_i within +-span beams of idx that has a normal: the rigid motion T(idx, i) that turns s_i's normal
+// onto m_idx's and moves s_i onto m_idx; a control set of <= sizeControlSet scene points is carried through
+// TSensor * T into the map and scored with the product of 1 - (1 - zrand) |tsd| over the control points (zrand where
+// the bilinear look-up fails); the candidate with the highest product wins.
+//
+// Where the work goes.  Normals (a 2 x 2 PCA over <= 10 neighbours per point), masks, the control set and the
+// candidate list are O(beams) host work, serial in the reference too.  The scoring -- candidates x control points
+// bilinear look-ups into the TSD grid -- is the data-parallel part and runs here on the device: one lane per
+// candidate, the control set in LDS, the look-ups of a candidate issued in batches and multiplied IN THE REFERENCE'S
+// ORDER (s = 0 .. C-1), because the winner is an arg-max over floating-point products; then one workgroup reduces
+// to the first candidate (in the reference's serial trial / i order) that reaches the maximum, which is what the
+// strict `>` of TSD_PDFMatching.cpp:264 gives a serial run.
+//
+// Randomness.  The reference draws from rand() in RandomMatching::subsampleMask, RandomMatching::pickControlSet and
+// for the trial pick (after srand(time(NULL)), inside an OpenMP loop): not reproducible.  The C ABI takes the three
+// streams of raw rand() values as inputs; the C++ facade (csrc/host/obvision) draws them with rand() where the
+// reference does.  With given draws the result is a function of the inputs and is parity-tested against the oracle's
+// restatement (PARITY UNPINNED: the reference's translation unit needs GSL and cannot be compiled in this image).
+#include "tsd_ctx.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace tsd {
+
+struct PdfCandidate { int idx, i; double phi; };
+struct PdfResult { double T[9]; double prob; int idx, i, candidates, pad; };
+
+constexpr int PDF_MAX_CONTROL = 1024;      // control points held in LDS (16 KB)
+constexpr int PDF_BATCH = 8;               // look-ups of one candidate in flight together
+
+// one lane per candidate: probability of the control set under T(idx, i)
+__global__ void __launch_bounds__(256)
+k_pdf_score(GridDev g, const double* __restrict__ pose /* 9 */, const double* __restrict__ M, const double* __restrict__ S,
+            const double2* __restrict__ control, int n_control, const PdfCandidate* __restrict__ cand, int n_cand,
+            double zrand, double* __restrict__ prob_out)
+{
+  __shared__ double2 s_c[PDF_MAX_CONTROL];
+  for (int k = threadIdx.x; k < n_control; k += blockDim.x) s_c[k] = control[k];
+  __syncthreads();
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_cand) return;
+  const PdfCandidate cd = cand[c];
+  // T = MatrixFactory::TransformationMatrix33(phi, 0, 0) + translation (TSD_PDFMatching.cpp:217-223)
+  const double co = cos(cd.phi), si = sin(cd.phi);
+  const double sx = S[2 * cd.i], sy = S[2 * cd.i + 1];
+  const double T02 = M[2 * cd.idx] - (co * sx + (-si) * sy);
+  const double T12 = M[2 * cd.idx + 1] - (si * sx + co * sy);
+  // TMap = TSensor * T (3 x 3 dgemm: k ascending from 0.0)
+  const double T[9] = {co, -si, T02, si, co, T12, 0.0, 0.0, 1.0};
+  double TM[6];
+#pragma unroll
+  for (int r = 0; r < 2; r++)
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      double t = 0.0;
+      t += pose[3 * r] * T[q]; t += pose[3 * r + 1] * T[3 + q]; t += pose[3 * r + 2] * T[6 + q];
+      TM[3 * r + q] = t;
+    }
+  double prob = 1.0;
+  for (int s0 = 0; s0 < n_control; s0 += PDF_BATCH) {
+    double f[PDF_BATCH];
+#pragma unroll
+    for (int b = 0; b < PDF_BATCH; b++) {
+      f[b] = 1.0;
+      const int s = s0 + b;
+      if (s < n_control) {
+        const double2 cp = s_c[s];
+        // STemp = TMap * Control, Control column = (x, y, 1)
+        double cx = 0.0, cy = 0.0;
+        cx += TM[0] * cp.x; cx += TM[1] * cp.y; cx += TM[2] * 1.0;
+        cy += TM[3] * cp.x; cy += TM[4] * cp.y; cy += TM[5] * 1.0;
+        double tsd;
+        // !interpolateBilinear(...) <=> INTERPOLATE_SUCCESS (TsdGrid.h:28): clipped probability, else zrand (:244-254)
+        f[b] = (interpolate_bilinear(g, cx, cy, tsd) == INTERP_SUCCESS) ? (1.0 - (1.0 - zrand) * fabs(tsd)) : zrand;
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < PDF_BATCH; b++) if (s0 + b < n_control) prob *= f[b];      // the reference's order
+  }
+  prob_out[c] = prob;
+}
+
+// first candidate (list order = the reference's serial trial / i order) that reaches the maximum; bestProb starts at
+// 0.0 and is replaced on `>` only (TSD_PDFMatching.cpp:188,264)
+__global__ void __launch_bounds__(1024)
+k_pdf_argmax(const double* __restrict__ prob, const PdfCandidate* __restrict__ cand, int n_cand, const double* __restrict__ M,
+             const double* __restrict__ S, PdfResult* __restrict__ out)
+{
+  __shared__ double s_p[1024];
+  __shared__ int s_k[1024];
+  double bp = 0.0; int bk = -1;
+  for (int c = threadIdx.x; c < n_cand; c += 1024) {      // ascending c per thread: `>` keeps the earliest
+    const double p = prob[c];
+    if (p > bp) { bp = p; bk = c; }
+  }
+  s_p[threadIdx.x] = bp; s_k[threadIdx.x] = bk;
+  __syncthreads();
+  for (int h = 512; h > 0; h >>= 1) {
+    if ((int)threadIdx.x < h) {
+      const double p2 = s_p[threadIdx.x + h]; const int k2 = s_k[threadIdx.x + h];
+      const double p1 = s_p[threadIdx.x]; const int k1 = s_k[threadIdx.x];
+      const bool take = k2 >= 0 && (p2 > p1 || (p2 == p1 && (k1 < 0 || k2 < k1)));
+      if (take) { s_p[threadIdx.x] = p2; s_k[threadIdx.x] = k2; }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    PdfResult r;
+    for (int i = 0; i < 9; i++) r.T[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    r.prob = 0.0; r.idx = -1; r.i = -1; r.candidates = n_cand; r.pad = 0;
+    const int k = s_k[0];
+    if (k >= 0 && s_p[0] > 0.0) {
+      const PdfCandidate cd = cand[k];
+      const double co = cos(cd.phi), si = sin(cd.phi);
+      const double sx = S[2 * cd.i], sy = S[2 * cd.i + 1];
+      r.T[0] = co; r.T[1] = -si; r.T[3] = si; r.T[4] = co;
+      r.T[2] = M[2 * cd.idx] - (co * sx + (-si) * sy);
+      r.T[5] = M[2 * cd.idx + 1] - (si * sx + co * sy);
+      r.prob = s_p[0]; r.idx = cd.idx; r.i = cd.i;
+    }
+    *out = r;
+  }
+}
+
+// ---- host side: RandomMatching's O(beams) preparation ------------------------------------------------------
+
+// Matrix::pcaAnalysis for n x 2 points (obcore/math/linalg/gsl/Matrix.cpp:227-327): centroid (gsl_stats_mean: running
+// mean in long double), M^T M, its eigenvectors (gsl_linalg_SV_decomp_jacobi of a symmetric 2 x 2 matrix = its
+// eigen-decomposition; column signs are free and nothing below depends on them), extents along both axes.
+static void pca2_axes(const double* pts, int n, double axes[2][4])
+{
+  double cent[2];
+  for (int j = 0; j < 2; j++) {
+    long double mean = 0.0L;
+    for (int i = 0; i < n; i++) mean += ((long double)pts[2 * i + j] - mean) / (long double)(i + 1);
+    cent[j] = (double)mean;
+  }
+  std::vector<double> mc(2 * (size_t)n);
+  for (int i = 0; i < n; i++) { mc[2 * i] = pts[2 * i] + (-cent[0]); mc[2 * i + 1] = pts[2 * i + 1] + (-cent[1]); }
+  double a = 0.0, b = 0.0, c = 0.0;
+  for (int i = 0; i < n; i++) { a += mc[2 * i] * mc[2 * i]; b += mc[2 * i] * mc[2 * i + 1]; c += mc[2 * i + 1] * mc[2 * i + 1]; }
+  const double th = 0.5 * std::atan2(2.0 * b, a - c);
+  const double V[2][2] = {{std::cos(th), -std::sin(th)}, {std::sin(th), std::cos(th)}};
+  double mx[2], mn[2];
+  for (int i = 0; i < 2; i++) {
+    mx[i] = -INFINITY; mn[i] = INFINITY;
+    for (int r = 0; r < n; r++) {
+      double pr = 0.0;
+      pr += V[0][i] * mc[2 * r]; pr += V[1][i] * mc[2 * r + 1];
+      mx[i] = std::max(mx[i], pr); mn[i] = std::min(mn[i], pr);
+    }
+  }
+  for (int i = 0; i < 2; i++) {
+    const double ext = mx[i] - mn[i];
+    const double align = ext > 1e-6 ? (mx[i] + mn[i]) / 2.0 : 0.0;
+    for (int j = 0; j < 2; j++) cent[j] += V[j][i] * align;
+  }
+  for (int i = 0; i < 2; i++) {
+    const double ext = mx[i] - mn[i];
+    for (int j = 0; j < 2; j++) {
+      const double e = V[j][i] * ext / 2.0;
+      axes[i][2 * j] = cent[j] - e; axes[i][2 * j + 1] = cent[j] + e;
+    }
+  }
+}
+
+// RandomMatching::calcNormals (RandomMatching.cpp:82-153)
+static void calc_normals(const double* M, int points, std::vector<double>& N, const uint8_t* mask_in, std::vector<uint8_t>& mask_out, int sr)
+{
+  for (int i = 0; i < sr && i < points; i++) mask_out[i] = 0;
+  for (int i = std::max(points - sr, 0); i < points; i++) mask_out[i] = 0;
+  std::vector<double> A(2 * (size_t)(2 * sr + 1));
+  for (int i = sr; i < points - sr; i++) {
+    if (!mask_in[i]) continue;
+    unsigned cnt = 0;
+    for (int j = -sr; j < sr; j++) if (mask_in[i + j]) cnt++;
+    if (cnt > 3) {
+      cnt = 0;
+      for (int j = -sr; j < sr; j++) if (mask_in[i + j]) { A[2 * cnt] = M[2 * (i + j)]; A[2 * cnt + 1] = M[2 * (i + j) + 1]; cnt++; }
+      double ax[2][4];
+      pca2_axes(A.data(), (int)cnt, ax);
+      const double xLong = ax[0][1] - ax[0][0], yLong = ax[0][3] - ax[0][2];
+      const double xShort = ax[1][1] - ax[1][0], yShort = ax[1][3] - ax[1][2];
+      const double lenLongSqr = xLong * xLong + yLong * yLong, lenShortSqr = xShort * xShort + yShort * yShort;
+      // main axis needs to be twice as long as the second one
+      if (lenShortSqr > 1e-6 && (lenLongSqr / lenShortSqr) < 4.0) { mask_out[i] = 0; continue; }
+      const double len = std::sqrt(lenShortSqr);
+      if ((M[2 * i] * xShort + M[2 * i + 1] * yShort) < 0.0) { N[2 * i] = xShort / len; N[2 * i + 1] = yShort / len; }
+      else { N[2 * i] = -xShort / len; N[2 * i + 1] = -yShort / len; }
+    } else mask_out[i] = 0;
+  }
+}
+
+}  // namespace tsd
+
+using namespace tsd;
+
+extern "C" int tsd_tsdpdf_match(tsd_ctx* ctx, const double pose33[9], const double* model_xy_2B, const uint8_t* mask_m,
+                                const double* scene_xy_2B, const uint8_t* mask_s, int beams, const tsd_tsdpdf_params* prm,
+                                const int* draws_subsample, const int* draws_control, const int* draws_trials,
+                                tsd_tsdpdf_result* result)
+{
+  if (!ctx || !pose33 || !model_xy_2B || !mask_m || !scene_xy_2B || !mask_s || !prm || !draws_subsample || !draws_control ||
+      !draws_trials || !result)
+    return TSD_E_ARG;
+  if (beams < 1 || beams > TSD_MAX_BEAMS || prm->size_control_set < 0 || prm->size_control_set > PDF_MAX_CONTROL || prm->trials < 0)
+    return set_error(ctx, TSD_E_CAPACITY, "tsd_tsdpdf_match: beams / control set out of range", hipSuccess);
+  TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const int n = beams;
+  const int SR = 10 / 2;                                   // _pcaSearchRange / 2 (TSD_PDFMatching.cpp:18)
+  for (int i = 0; i < 9; i++) result->T[i] = (i % 4 == 0) ? 1.0 : 0.0;     // TBest.setIdentity()
+  result->probability = 0.0; result->idx_model = -1; result->idx_scene = -1; result->candidates = 0;
+  result->valid_model = 0; result->valid_scene = 0; result->control_points = 0; result->reserved = 0;
+  if (n < 3) return TSD_OK;                                // "Model and scene contain too less points" (:53-57)
+  const double* M = model_xy_2B; const double* S = scene_xy_2B;
+
+  // ---- model (:63-77)
+  std::vector<double> NM(2 * (size_t)n, 0.0), NS(2 * (size_t)n, 0.0), phiM((size_t)n), phiS((size_t)n);
+  std::vector<uint8_t> mMp(mask_m, mask_m + n), mSp(mask_s, mask_s + n);
+  calc_normals(M, n, NM, mask_m, mMp, SR);
+  for (int i = 0; i < n; i++) phiM[i] = mMp[i] ? std::atan2(NM[2 * i + 1], NM[2 * i]) : -1e6;     // calcPhi (:155-174)
+  std::vector<int> idxM, idxS;
+  for (int i = SR; i < n - SR; i++) if (mMp[i]) idxM.push_back(i);                                // extractSamples (:41-50)
+  // ---- scene (:81-102)
+  unsigned valid = 0;
+  for (int i = 0; i < n; i++) if (mSp[i]) valid++;
+  double probability = 180.0 / (double)valid;
+  if (probability < 0.99) {                                // subsampleMask (RandomMatching.cpp:176-189)
+    if (probability > 1.0) probability = 1.0;
+    if (probability < 0.0) probability = 0.0;
+    const int thresh = (int)(1000.0 - probability * 1000.0 + 0.5);
+    for (int i = 0; i < n; i++) if ((draws_subsample[i] % 1000) < thresh) mSp[i] = 0;
+  }
+  calc_normals(S, n, NS, mask_s, mSp, SR);
+  for (int i = 0; i < n; i++) phiS[i] = mSp[i] ? std::atan2(NS[2 * i + 1], NS[2 * i]) : -1e6;
+  for (int i = SR; i < n - SR; i++) if (mSp[i]) idxS.push_back(i);
+  // ---- control set (:106-118, RandomMatching::pickControlSet :52-80)
+  int nC = prm->size_control_set;
+  if ((int)idxS.size() < nC) nC = (int)idxS.size();
+  std::vector<double> control(2 * (size_t)std::max(nC, 1));
+  {
+    std::vector<int> tmp = idxS;
+    for (int k = 0; k < nC; k++) {
+      const unsigned r = (unsigned)draws_control[k] % (unsigned)tmp.size();
+      const int idx = tmp[r];
+      tmp.erase(tmp.begin() + r);
+      control[2 * k] = S[2 * idx]; control[2 * k + 1] = S[2 * idx + 1];
+    }
+  }
+  result->valid_model = (int)idxM.size(); result->valid_scene = (int)idxS.size(); result->control_points = nC;
+  if (idxS.size() < 3 || idxM.size() < 3) return TSD_OK;   // "Too less valid points" (:129-139): identity
+  int trials = prm->trials;
+  if ((int)idxM.size() < trials) trials = (int)idxM.size();
+  double phi_max = std::min(prm->phi_max, M_PI * 0.5);
+  if (!(prm->ang_res > 1e-6)) return set_error(ctx, TSD_E_ARG, "tsd_tsdpdf_match: resolution not properly set", hipSuccess);   // :171-175
+  int span = (int)std::floor(phi_max / prm->ang_res);
+  if (span > n) span = n;
+  // ---- candidates in the reference's serial order (:185-215)
+  std::vector<PdfCandidate> cand;
+  {
+    std::vector<int> tmp = idxM;
+    for (int trial = 0; trial < trials; trial++) {
+      const int r = (int)((unsigned)draws_trials[trial] % (unsigned)tmp.size());
+      const int idx = tmp[r];
+      tmp.erase(tmp.begin() + r);
+      const int iMin = std::max(idx - span, SR), iMax = std::min(idx + span, n - SR);
+      for (int i = iMin; i < iMax; i++) {
+        if (!mSp[i]) continue;
+        double phi = phiM[idx] - phiS[i];
+        if (phi > M_PI) phi -= 2.0 * M_PI;
+        else if (phi < -M_PI) phi += 2.0 * M_PI;
+        if (std::fabs(phi) < phi_max) cand.push_back(PdfCandidate{idx, i, phi});
+      }
+    }
+  }
+  result->candidates = (int)cand.size();
+  if (cand.empty()) return TSD_OK;
+
+  // ---- device: score + arg-max
+  const size_t bM = (size_t)n * 16, bC = (size_t)nC * 16, bK = cand.size() * sizeof(PdfCandidate), bP = 9 * sizeof(double);
+  const size_t off_S = bM, off_C = 2 * bM, off_K = off_C + ((bC + 15) & ~(size_t)15), off_P = off_K + ((bK + 15) & ~(size_t)15);
+  const size_t off_prob = off_P + 80, off_res = off_prob + cand.size() * sizeof(double);
+  const size_t total = off_res + sizeof(PdfResult);
+  if (total > ctx->pdf_bytes) {
+    if (ctx->d_pdf) hipFree(ctx->d_pdf);
+    if (ctx->h_pdf) hipHostFree(ctx->h_pdf);
+    ctx->d_pdf = nullptr; ctx->h_pdf = nullptr; ctx->pdf_bytes = 0;
+    const size_t want = total * 2;
+    TSD_HIP_CHECK(ctx, hipMalloc(&ctx->d_pdf, want));
+    TSD_HIP_CHECK(ctx, hipHostMalloc(&ctx->h_pdf, want, hipHostMallocDefault));
+    ctx->pdf_bytes = want;
+  }
+  TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));          // (the pinned buffer of a previous call is free)
+  char* h = ctx->h_pdf; char* d = ctx->d_pdf;
+  std::memcpy(h, M, bM); std::memcpy(h + off_S, S, bM); std::memcpy(h + off_C, control.data(), bC);
+  std::memcpy(h + off_K, cand.data(), bK); std::memcpy(h + off_P, pose33, bP);
+  TSD_HIP_CHECK(ctx, hipMemcpyAsync(d, h, off_prob, hipMemcpyHostToDevice, ctx->stream));
+  {
+    ScopedKernelTimer t(ctx, "tsdpdf", true);
+    const int nc = (int)cand.size();
+    hipLaunchKernelGGL(k_pdf_score, dim3((nc + 255) / 256), dim3(256), 0, ctx->stream, ctx->grid, reinterpret_cast<const double*>(d + off_P),
+                       reinterpret_cast<const double*>(d), reinterpret_cast<const double*>(d + off_S),
+                       reinterpret_cast<const double2*>(d + off_C), nC, reinterpret_cast<const PdfCandidate*>(d + off_K), nc,
+                       prm->zrand, reinterpret_cast<double*>(d + off_prob));
+    hipLaunchKernelGGL(k_pdf_argmax, dim3(1), dim3(1024), 0, ctx->stream, reinterpret_cast<const double*>(d + off_prob),
+                       reinterpret_cast<const PdfCandidate*>(d + off_K), nc, reinterpret_cast<const double*>(d),
+                       reinterpret_cast<const double*>(d + off_S), reinterpret_cast<PdfResult*>(d + off_res));
+  }
+  TSD_HIP_CHECK(ctx, hipGetLastError());
+  TSD_HIP_CHECK(ctx, hipMemcpyAsync(h + off_res, d + off_res, sizeof(PdfResult), hipMemcpyDeviceToHost, ctx->stream));
+  TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  const PdfResult* r = reinterpret_cast<const PdfResult*>(h + off_res);
+  std::memcpy(result->T, r->T, sizeof(r->T));
+  result->probability = r->prob; result->idx_model = r->idx; result->idx_scene = r->i;
+  return TSD_OK;
+}

@@ -25,6 +25,7 @@ HOST_ABI = {
     "tsd_node_set_bool": (None, [C.c_void_p, C.c_char_p, C.c_int]),
     "tsd_node_set_string": (None, [C.c_void_p, C.c_char_p, C.c_char_p]),
     "tsd_node_initialize": (C.c_int, [C.c_void_p, C.c_int]),
+    "tsd_node_declared_parameters": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "tsd_node_set_synchronous": (None, [C.c_void_p, C.c_int]),
     "tsd_node_set_fused": (None, [C.c_void_p, C.c_int]),
     "tsd_node_laser": (C.c_int, [C.c_void_p, C.c_int, _fp, C.c_int, C.c_double, C.c_double, C.c_longlong]),
@@ -65,6 +66,32 @@ def load_library():
 
 REPORT_FIELDS = ("rms", "pairs", "iterations", "icp_state", "valid_model", "valid_scene", "reg_error", "pushed",
                  "no_model", "initialised")
+
+
+def declared_parameters(params: dict | None = None, name: str = "tsd_slam") -> dict:
+    """(type, declared default) of every parameter the facade declares for a node configured with `params` -- SlamNode,
+    the ThreadLocalize constructors and ThreadLocalize::init -- without touching a device."""
+    lib = load_library()
+    h = lib.tsd_node_create(name.encode())
+    for k, v in (params or {}).items():
+        kb = k.encode()
+        if isinstance(v, bool):
+            lib.tsd_node_set_bool(h, kb, int(v))
+        elif isinstance(v, int):
+            lib.tsd_node_set_int(h, kb, v)
+        elif isinstance(v, float):
+            lib.tsd_node_set_double(h, kb, v)
+        else:
+            lib.tsd_node_set_string(h, kb, str(v).encode())
+    need = lib.tsd_node_declared_parameters(h, None, 0)
+    buf = C.create_string_buffer(need)
+    lib.tsd_node_declared_parameters(h, buf, need)
+    lib.tsd_node_destroy(h)
+    out = {}
+    for line in buf.value.decode().splitlines():
+        k, t, v = line.split("|", 2)
+        out[k] = (t, {"bool": lambda x: x == "true", "int": int, "double": float, "string": str}[t](v))
+    return out
 
 
 class SlamNode:

@@ -60,6 +60,8 @@ class SlamConfig(C.Structure):
         ("icp_iterations", C.c_int), ("dist_filter_max", C.c_double), ("dist_filter_min", C.c_double),
         ("reg_trs_max", C.c_double), ("reg_sin_rot_max", C.c_double),
         ("nn_mode", C.c_int), ("threads", C.c_int),
+        ("registration_mode", C.c_int), ("trials", C.c_int), ("size_control_set", C.c_int), ("zrand", C.c_double),
+        ("ransac_phi_max", C.c_double),
     ]
 
 
@@ -149,6 +151,15 @@ def lib():
         L.ora_slam_grid.argtypes = [C.c_void_p]
         L.ora_slam_process_scan.argtypes = [C.c_void_p, _fp, C.POINTER(ScanResult)]
         L.ora_slam_last_push_stats.argtypes = [C.c_void_p, C.POINTER(PushStats)]
+        L.ora_slam_set_draws.argtypes = [C.c_void_p, _ip, _ip, _ip]
+        L.ora_slam_set_draws.restype = None
+        L.ora_slam_last_prereg.argtypes = [C.c_void_p, _dp, _dp, _ip, _ip]
+        L.ora_slam_last_prereg.restype = None
+        L.ora_tsdpdf_match.argtypes = [C.c_void_p, _dp, _dp, _u8p, _dp, _u8p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                                       C.c_double, _ip, _ip, _ip, _dp, _dp, _ip, _ip, _ip]
+        L.ora_tsdpdf_match.restype = C.c_int
+        L.ora_icp_init.argtypes = [_dp, C.c_int, _dp, C.c_int, _dp, C.POINTER(IcpParams), _dp, C.POINTER(IcpResult), _dp]
+        L.ora_icp_init.restype = None
         _lib = L
     return _lib
 
@@ -379,6 +390,31 @@ def icp(model_xy, scene_xy, pose, iterations, dist_max, dist_min, bounds, nn_mod
     return out
 
 
+def tsdpdf_match(grid, pose, M, maskM, S, maskS, trials, size_control_set, zrand, phi_max, resolution, draws_sub, draws_ctrl,
+                 draws_trials):
+    """TSD_PDFMatching::match with the rand() draws as inputs -> dict(T, prob, idx, i, candidates, rc)"""
+    M, S = f64(M).reshape(-1), f64(S).reshape(-1)
+    n = M.size // 2
+    mM, mS = np.ascontiguousarray(maskM, dtype=np.uint8), np.ascontiguousarray(maskS, dtype=np.uint8)
+    ds = np.ascontiguousarray(draws_sub, dtype=np.int32); dc = np.ascontiguousarray(draws_ctrl, dtype=np.int32)
+    dt = np.ascontiguousarray(draws_trials, dtype=np.int32)
+    assert ds.size >= n and dc.size >= size_control_set and dt.size >= trials
+    T = np.zeros(9); prob = C.c_double(); idx = C.c_int(); ii = C.c_int(); cand = C.c_int()
+    rc = lib().ora_tsdpdf_match(grid.h, d(f64(pose).reshape(9)), d(M), u8(mM), d(S), u8(mS), n, trials, size_control_set, zrand,
+                                phi_max, resolution, ds.ctypes.data_as(_ip), dc.ctypes.data_as(_ip), dt.ctypes.data_as(_ip),
+                                d(T), C.byref(prob), C.byref(idx), C.byref(ii), C.byref(cand))
+    return dict(T=T.reshape(3, 3), prob=prob.value, idx=idx.value, i=ii.value, candidates=cand.value, rc=rc)
+
+
+def icp_init(model_xy, scene_xy, pose, iterations, dist_max, dist_min, bounds, T_init, nn_mode=0):
+    m, s = f64(model_xy).reshape(-1), f64(scene_xy).reshape(-1)
+    p = IcpParams(iterations, dist_max, dist_min, bounds[0], bounds[1], bounds[2], bounds[3], nn_mode)
+    r = IcpResult()
+    lib().ora_icp_init(d(m), m.size // 2, d(s), s.size // 2, d(f64(pose).reshape(9)), C.byref(p), d(f64(T_init).reshape(9)),
+                       C.byref(r), None)
+    return dict(T=np.array(r.T[:]).reshape(3, 3), rms=r.rms, pairs=r.pairs, iterations=r.iterations, state=r.state)
+
+
 def icp_pairs(model_xy, scene_xy, pose, iterations, dist_max, dist_min, bounds, thr_sqr, nn_mode=0):
     m, s = f64(model_xy).reshape(-1), f64(scene_xy).reshape(-1)
     pose = f64(pose).reshape(9)
@@ -416,6 +452,15 @@ class Slam:
         out = ScanResult()
         self.L.ora_slam_process_scan(self.h, r.ctypes.data_as(_fp), C.byref(out))
         return out
+
+    def set_draws(self, sub, ctrl, trials):
+        a = [np.ascontiguousarray(x, dtype=np.int32) for x in (sub, ctrl, trials)]
+        self.L.ora_slam_set_draws(self.h, *[x.ctypes.data_as(_ip) for x in a])
+
+    def last_prereg(self):
+        T = np.zeros(9); prob = C.c_double(); idx = C.c_int(); ii = C.c_int()
+        self.L.ora_slam_last_prereg(self.h, d(T), C.byref(prob), C.byref(idx), C.byref(ii))
+        return dict(T=T.reshape(3, 3), prob=prob.value, idx=idx.value, i=ii.value)
 
     def last_push_stats(self):
         st = PushStats()

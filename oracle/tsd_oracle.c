@@ -1052,7 +1052,7 @@ static void lu3_solve(const double A[9], const double b[3], double x[3])
  * ClosedFormEstimator2D (ClosedFormEstimator2D.cpp:36-109) when `normals` is NULL -- what the node constructs
  * (ThreadLocalize.cpp:214) -- or PointToLine2DEstimator (PointToLineEstimator2D.cpp:52-157) on the model normals. */
 static void icp_impl(const double* model, const double* normals, int n_model, const double* scene_in, int n_scene,
-                     const double pose[9], const ora_icp_params* p, ora_icp_result* out, double* trace)
+                     const double pose[9], const ora_icp_params* p, ora_icp_result* out, double* trace, const double* Tinit33)
 {
   enum { PROCESSING = 1, NOTMATCHABLE = 2, MAXITERATIONS = 3, SUCCESS = 5 };
   double Tf[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};   /* _Tfinal4x4->setIdentity() */
@@ -1063,13 +1063,18 @@ static void icp_impl(const double* model, const double* normals, int n_model, co
     return;
   }
   double* sc = (double*)malloc(sizeof(double) * 2 * (size_t)n_scene);
-  /* applyTransformation(sceneTmp, Tinit = I) (Icp.cpp:481-486, :371-408): (0 + x*1) + y*0, then + 0 */
+  /* applyTransformation(sceneTmp, Tinit) (Icp.cpp:481-486, :371-408): (0 + x*R00) + y*R01, then + t.  Tinit is the
+   * identity in registration_mode 0 and the pre-registration's result otherwise (ThreadLocalize.cpp:531-569) */
+  const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  const double* Ti = Tinit33 ? Tinit33 : I3;
   for (int i = 0; i < n_scene; i++) {
     double x = scene_in[2 * i], y = scene_in[2 * i + 1];
     double nx = 0.0, ny = 0.0;
-    nx += x * 1.0; nx += y * 0.0; ny += x * 0.0; ny += y * 1.0;
-    sc[2 * i] = nx + 0.0; sc[2 * i + 1] = ny + 0.0;
+    nx += x * Ti[0]; nx += y * Ti[1]; ny += x * Ti[3]; ny += y * Ti[4];
+    sc[2 * i] = nx + Ti[2]; sc[2 * i + 1] = ny + Ti[5];
   }
+  /* (*_Tfinal4x4) = (*Tinit) * (*_Tfinal4x4) with _Tfinal4x4 == I (Icp.cpp:485) */
+  Tf[0] = Ti[0]; Tf[1] = Ti[1]; Tf[3] = Ti[2]; Tf[4] = Ti[3]; Tf[5] = Ti[4]; Tf[7] = Ti[5];
   icp_ctx c;
   icp_ctx_init(&c, model, n_model, n_scene, pose, p);
 
@@ -1184,14 +1189,214 @@ static void icp_impl(const double* model, const double* normals, int n_model, co
 void ora_icp(const double* model, int n_model, const double* scene_in, int n_scene,
              const double pose[9], const ora_icp_params* p, ora_icp_result* out, double* trace)
 {
-  icp_impl(model, NULL, n_model, scene_in, n_scene, pose, p, out, trace);
+  icp_impl(model, NULL, n_model, scene_in, n_scene, pose, p, out, trace, NULL);
+}
+
+/* Icp::iterate with a pre-registration result as Tinit (registration_mode 1-3, ThreadLocalize.cpp:580) */
+void ora_icp_init(const double* model, int n_model, const double* scene_in, int n_scene, const double pose[9],
+                  const ora_icp_params* p, const double Tinit33[9], ora_icp_result* out, double* trace)
+{
+  icp_impl(model, NULL, n_model, scene_in, n_scene, pose, p, out, trace, Tinit33);
 }
 
 /* the same registration with PointToLine2DEstimator on the model normals Icp::setModel(coords, normals) takes */
 void ora_icp_point_to_line(const double* model, const double* normals, int n_model, const double* scene_in, int n_scene,
                            const double pose[9], const ora_icp_params* p, ora_icp_result* out, double* trace)
 {
-  icp_impl(model, normals, n_model, scene_in, n_scene, pose, p, out, trace);
+  icp_impl(model, normals, n_model, scene_in, n_scene, pose, p, out, trace, NULL);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Row N3: TSD_PDFMatching::match (registration/ransacMatching/TSD_PDFMatching.cpp:31-294), the pre-registration
+ * ThreadLocalize runs in registration_mode 3 (ThreadLocalize.cpp:557-567) -- what config/single-laser.yaml ships.
+ * The reference draws from rand() in three places: RandomMatching::subsampleMask (RandomMatching.cpp:176-189),
+ * RandomMatching::pickControlSet (:65) and the trial pick (TSD_PDFMatching.cpp:190-194), the last one after
+ * srand(time(NULL)) and inside an OpenMP loop.  Here the draws are INPUTS (the raw rand() values, in the order
+ * of a serial run), and the trials run in trial order, so the result is a function of its arguments:
+ * "first candidate that reaches the best probability wins", which is what the strict `>` of :264 gives a serial
+ * run.  PARITY UNPINNED: the translation unit needs GSL (Matrix, pcaAnalysis) and cannot be compiled here.
+ *
+ * Matrix::pcaAnalysis (obcore/math/linalg/gsl/Matrix.cpp:227-327) for n x 2 input: centroid by gsl_stats_mean
+ * (running mean in long double, GSL 2.7.1 statistics/mean_source.c), M^T M by dgemm, gsl_linalg_SV_decomp_jacobi of
+ * the symmetric 2 x 2 product (restated as its closed-form eigen-decomposition: the same V up to the sign of a
+ * column and rounding, and every use below is invariant to the sign), extents along the two axes. */
+static void pca2_axes(const double* pts, int n, double axes[2][4])
+{
+  double cent[2];
+  for (int j = 0; j < 2; j++) {
+    long double mean = 0.0L;
+    for (int i = 0; i < n; i++) mean += ((long double)pts[2 * i + j] - mean) / (long double)(i + 1);
+    cent[j] = (double)mean;
+  }
+  double* Mc = (double*)malloc(sizeof(double) * 2 * (size_t)n);
+  for (int i = 0; i < n; i++) { Mc[2 * i] = pts[2 * i] + (-cent[0]); Mc[2 * i + 1] = pts[2 * i + 1] + (-cent[1]); }
+  double a = 0.0, b = 0.0, c = 0.0;
+  for (int i = 0; i < n; i++) { a += Mc[2 * i] * Mc[2 * i]; b += Mc[2 * i] * Mc[2 * i + 1]; c += Mc[2 * i + 1] * Mc[2 * i + 1]; }
+  /* eigenvectors of [[a b][b c]], major axis first */
+  const double th = 0.5 * atan2(2.0 * b, a - c);
+  const double V[2][2] = {{cos(th), -sin(th)}, {sin(th), cos(th)}};          /* V[j][i]: component j of eigenvector i */
+  double mx[2], mn[2];
+  for (int i = 0; i < 2; i++) {
+    mx[i] = -INFINITY; mn[i] = INFINITY;
+    for (int r = 0; r < n; r++) {
+      double pr = 0.0;
+      pr += V[0][i] * Mc[2 * r]; pr += V[1][i] * Mc[2 * r + 1];               /* P = V^T M^T */
+      if (pr > mx[i]) mx[i] = pr;
+      if (pr < mn[i]) mn[i] = pr;
+    }
+  }
+  for (int i = 0; i < 2; i++) {
+    const double ext = mx[i] - mn[i];
+    double align = 0.0;
+    if (ext > 1e-6) align = (mx[i] + mn[i]) / 2.0;
+    for (int j = 0; j < 2; j++) cent[j] += V[j][i] * align;
+  }
+  for (int i = 0; i < 2; i++) {
+    const double ext = mx[i] - mn[i];
+    for (int j = 0; j < 2; j++) {
+      const double e = V[j][i] * ext / 2.0;
+      axes[i][2 * j] = cent[j] - e; axes[i][2 * j + 1] = cent[j] + e;
+    }
+  }
+  free(Mc);
+}
+
+/* RandomMatching::calcNormals (RandomMatching.cpp:82-153) */
+static void rm_calc_normals(const double* M, int points, double* N, const uint8_t* mask_in, uint8_t* mask_out, int sr)
+{
+  for (int i = 0; i < sr && i < points; i++) mask_out[i] = 0;
+  for (int i = points - sr; i < points; i++) if (i >= 0) mask_out[i] = 0;
+  double* A = (double*)malloc(sizeof(double) * 2 * (size_t)(2 * sr + 1));
+  for (int i = sr; i < points - sr; i++) {
+    if (!mask_in[i]) continue;
+    unsigned cnt = 0;
+    for (int j = -sr; j < sr; j++) if (mask_in[i + j]) cnt++;
+    if (cnt > 3) {
+      cnt = 0;
+      for (int j = -sr; j < sr; j++) if (mask_in[i + j]) { A[2 * cnt] = M[2 * (i + j)]; A[2 * cnt + 1] = M[2 * (i + j) + 1]; cnt++; }
+      double ax[2][4];
+      pca2_axes(A, (int)cnt, ax);
+      const double xLong = ax[0][1] - ax[0][0], yLong = ax[0][3] - ax[0][2];
+      const double xShort = ax[1][1] - ax[1][0], yShort = ax[1][3] - ax[1][2];
+      const double lenLongSqr = xLong * xLong + yLong * yLong, lenShortSqr = xShort * xShort + yShort * yShort;
+      if (lenShortSqr > 1e-6 && (lenLongSqr / lenShortSqr) < 4.0) { mask_out[i] = 0; continue; }
+      const double len = sqrt(lenShortSqr);
+      if ((M[2 * i] * xShort + M[2 * i + 1] * yShort) < 0.0) { N[2 * i] = xShort / len; N[2 * i + 1] = yShort / len; }
+      else { N[2 * i] = -xShort / len; N[2 * i + 1] = -yShort / len; }
+    } else mask_out[i] = 0;
+  }
+  free(A);
+}
+
+int ora_tsdpdf_match(const ora_grid* g, const double pose[9], const double* M, const uint8_t* maskM, const double* S,
+                     const uint8_t* maskS, int n, int trials_cfg, int size_control_set, double zrand, double phi_max,
+                     double resolution, const int* draws_subsample, const int* draws_control, const int* draws_trials,
+                     double T_out[9], double* best_prob_out, int* best_idx_out, int* best_i_out, int* candidates_out)
+{
+  const int SR = 10 / 2;                                               /* _pcaSearchRange / 2 */
+  for (int i = 0; i < 9; i++) T_out[i] = (i % 4 == 0) ? 1.0 : 0.0;     /* TBest.setIdentity() */
+  if (best_prob_out) *best_prob_out = 0.0;
+  if (best_idx_out) *best_idx_out = -1;
+  if (best_i_out) *best_i_out = -1;
+  if (candidates_out) *candidates_out = 0;
+  if (n < 3) return 1;
+  double* NM = (double*)calloc(2 * (size_t)n, sizeof(double));
+  double* NS = (double*)calloc(2 * (size_t)n, sizeof(double));
+  double* phiM = (double*)malloc(sizeof(double) * (size_t)n);
+  double* phiS = (double*)malloc(sizeof(double) * (size_t)n);
+  uint8_t* mMp = (uint8_t*)malloc((size_t)n);
+  uint8_t* mSp = (uint8_t*)malloc((size_t)n);
+  int* idxM = (int*)malloc(sizeof(int) * (size_t)n);
+  int* idxS = (int*)malloc(sizeof(int) * (size_t)n);
+  int* tmp = (int*)malloc(sizeof(int) * (size_t)n);
+  int nMv = 0, nSv = 0, rc = 0;
+  /* model (:63-77) */
+  memcpy(mMp, maskM, (size_t)n);
+  rm_calc_normals(M, n, NM, maskM, mMp, SR);
+  for (int i = 0; i < n; i++) phiM[i] = mMp[i] ? atan2(NM[2 * i + 1], NM[2 * i]) : -1e6;      /* calcPhi */
+  for (int i = SR; i < n - SR; i++) if (mMp[i]) idxM[nMv++] = i;                              /* extractSamples */
+  /* scene (:81-102) */
+  memcpy(mSp, maskS, (size_t)n);
+  unsigned valid = 0;
+  for (int i = 0; i < n; i++) if (mSp[i]) valid++;
+  double probability = 180.0 / (double)valid;
+  if (probability < 0.99) {                                            /* subsampleMask (RandomMatching.cpp:176-189) */
+    if (probability > 1.0) probability = 1.0;
+    if (probability < 0.0) probability = 0.0;
+    const int thresh = (int)(1000.0 - probability * 1000.0 + 0.5);
+    for (int i = 0; i < n; i++) if ((draws_subsample[i] % 1000) < thresh) mSp[i] = 0;
+  }
+  rm_calc_normals(S, n, NS, maskS, mSp, SR);
+  for (int i = 0; i < n; i++) phiS[i] = mSp[i] ? atan2(NS[2 * i + 1], NS[2 * i]) : -1e6;
+  for (int i = SR; i < n - SR; i++) if (mSp[i]) idxS[nSv++] = i;
+  /* control set (:106-118, RandomMatching::pickControlSet) */
+  int nC = size_control_set;
+  if (nSv < nC) nC = nSv;
+  double* C = (double*)malloc(sizeof(double) * 2 * (size_t)(nC > 0 ? nC : 1));
+  {
+    int nt = nSv;
+    memcpy(tmp, idxS, sizeof(int) * (size_t)nSv);
+    for (int k = 0; k < nC; k++) {
+      const unsigned r = (unsigned)draws_control[k] % (unsigned)nt;
+      const int idx = tmp[r];
+      memmove(tmp + r, tmp + r + 1, sizeof(int) * (size_t)(nt - (int)r - 1)); nt--;
+      C[2 * k] = S[2 * idx]; C[2 * k + 1] = S[2 * idx + 1];
+    }
+  }
+  if (nSv < 3 || nMv < 3) { rc = 1; goto done; }                         /* :129-139 */
+  {
+    int trials = trials_cfg;
+    if (nMv < trials) trials = nMv;
+    if (phi_max > M_PI * 0.5) phi_max = M_PI * 0.5;                      /* min(phiMax, pi/2) */
+    int span;
+    if (resolution > 1e-6) { span = (int)floor(phi_max / resolution); if (span > n) span = n; }
+    else { rc = 2; goto done; }
+    double best = 0.0;
+    int nt = nMv, cand = 0;
+    memcpy(tmp, idxM, sizeof(int) * (size_t)nMv);
+    for (int trial = 0; trial < trials; trial++) {
+      const int r = (int)((unsigned)draws_trials[trial] % (unsigned)nt);
+      const int idx = tmp[r];
+      memmove(tmp + r, tmp + r + 1, sizeof(int) * (size_t)(nt - r - 1)); nt--;
+      const int iMin = (idx - span > SR) ? idx - span : SR;
+      const int iMax = (idx + span < n - SR) ? idx + span : n - SR;
+      for (int i = iMin; i < iMax; i++) {
+        if (!mSp[i]) continue;
+        double phi = phiM[idx] - phiS[i];
+        if (phi > M_PI) phi -= 2.0 * M_PI; else if (phi < -M_PI) phi += 2.0 * M_PI;
+        if (!(fabs(phi) < phi_max)) continue;
+        cand++;
+        /* T = TransformationMatrix33(phi, 0, 0) + translation (:217-223) */
+        double T[9] = {cos(phi), -sin(phi), 0, sin(phi), cos(phi), 0, 0, 0, 1};
+        const double sx = S[2 * i], sy = S[2 * i + 1];
+        T[2] = M[2 * idx] - (T[0] * sx + T[1] * sy);
+        T[5] = M[2 * idx + 1] - (T[3] * sx + T[4] * sy);
+        double TMap[9];
+        ora_mat3_mul(pose, T, TMap);                                     /* TSensor * T (dgemm) */
+        double prob = 1.0;
+        for (int s = 0; s < nC; s++) {
+          /* STemp = TMap * Control, Control = [x; y; 1] (dgemm: k ascending from 0.0) */
+          double cx = 0.0, cy = 0.0;
+          cx += TMap[0] * C[2 * s]; cx += TMap[1] * C[2 * s + 1]; cx += TMap[2] * 1.0;
+          cy += TMap[3] * C[2 * s]; cy += TMap[4] * C[2 * s + 1]; cy += TMap[5] * 1.0;
+          double tsd;
+          if (ora_interpolate_bilinear(g, cx, cy, &tsd) == 0) prob *= (1.0 - (1.0 - zrand) * fabs(tsd));
+          else prob *= zrand;
+        }
+        if (prob > best) {
+          memcpy(T_out, T, sizeof(T));
+          best = prob;
+          if (best_idx_out) *best_idx_out = idx;
+          if (best_i_out) *best_i_out = i;
+        }
+      }
+    }
+    if (best_prob_out) *best_prob_out = best;
+    if (candidates_out) *candidates_out = cand;
+  }
+done:
+  free(NM); free(NS); free(phiM); free(phiS); free(mMp); free(mSp); free(idxM); free(idxS); free(tmp); free(C);
+  return rc;
 }
 
 /* TsdGrid::grid2ColorImage (TsdGrid.cpp:429-488), what ThreadGrid publishes next to the occupancy map
@@ -1355,6 +1560,9 @@ struct ora_slam {
   double* model; double* normals; uint8_t* mask_m; double* scene; uint8_t* mask_s;
   int have_last_pose;
   ora_push_stats last_stats;
+  /* registration_mode 3: the rand() draws of the next scan's TSD_PDFMatching::match (caller-supplied) */
+  int* draws_sub; int* draws_ctrl; int* draws_trials;
+  double pre_T[9]; double pre_prob; int pre_idx, pre_i;
 };
 
 ora_slam* ora_slam_create(const ora_slam_config* cfg)
@@ -1387,6 +1595,22 @@ void ora_slam_destroy(ora_slam* s)
 }
 
 ora_grid* ora_slam_grid(ora_slam* s) { return s->grid; }
+void ora_slam_set_draws(ora_slam* s, const int* sub, const int* ctrl, const int* trials)
+{
+  const size_t B = (size_t)s->beams;
+  if (!s->draws_sub) {
+    s->draws_sub = (int*)malloc(B * sizeof(int));
+    s->draws_ctrl = (int*)malloc((size_t)(s->cfg.size_control_set > 0 ? s->cfg.size_control_set : 1) * sizeof(int));
+    s->draws_trials = (int*)malloc((size_t)(s->cfg.trials > 0 ? s->cfg.trials : 1) * sizeof(int));
+  }
+  memcpy(s->draws_sub, sub, B * sizeof(int));
+  memcpy(s->draws_ctrl, ctrl, (size_t)s->cfg.size_control_set * sizeof(int));
+  memcpy(s->draws_trials, trials, (size_t)s->cfg.trials * sizeof(int));
+}
+void ora_slam_last_prereg(const ora_slam* s, double T[9], double* prob, int* idx, int* i)
+{
+  memcpy(T, s->pre_T, sizeof(s->pre_T)); *prob = s->pre_prob; *idx = s->pre_idx; *i = s->pre_i;
+}
 void ora_slam_last_push_stats(const ora_slam* s, ora_push_stats* out) { *out = s->last_stats; }
 
 static void reverse_f32(float* a, int n)
@@ -1467,6 +1691,13 @@ void ora_slam_process_scan(ora_slam* s, const float* ranges_in, ora_scan_result*
   ip.nn_mode = cfg->nn_mode;
   ora_icp_result r;
   t0 = now_s();
+  if (cfg->registration_mode == 3 && s->draws_sub) {
+    /* doRegistration case TSD (ThreadLocalize.cpp:557-567): M, S keep the ray model (beam-indexed, masks) */
+    ora_tsdpdf_match(s->grid, s->pose, s->model, s->mask_m, s->scene, s->mask_s, B, cfg->trials, cfg->size_control_set,
+                     cfg->zrand, cfg->ransac_phi_max * M_PI / 180.0 /* deg2rad(_ranPhiMax) */, s->ang_res,
+                     s->draws_sub, s->draws_ctrl, s->draws_trials, s->pre_T, &s->pre_prob, &s->pre_idx, &s->pre_i, NULL);
+    ora_icp_init(Mv, nm, Sv, ns, s->pose, &ip, s->pre_T, &r, NULL);
+  } else
   ora_icp(Mv, nm, Sv, ns, s->pose, &ip, &r, NULL);
   out->t_icp = now_s() - t0;
   free(Mv); free(Sv);

@@ -156,6 +156,8 @@ typedef struct {
   int    icp_iterations; double dist_filter_max, dist_filter_min;
   double reg_trs_max, reg_sin_rot_max;
   int    nn_mode; int threads;
+  /* registration_mode 3 (TSD_PDF pre-registration): ThreadLocalize.cpp:105-128 */
+  int    registration_mode; int trials; int size_control_set; double zrand; double ransac_phi_max /* degrees */;
 } ora_slam_config;
 typedef struct {
   double pose[9]; double T[9];
@@ -171,6 +173,20 @@ ora_grid* ora_slam_grid(ora_slam* s);
  * synchronous push where the reference calls queuePush */
 void      ora_slam_process_scan(ora_slam* s, const float* ranges, ora_scan_result* out);
 void      ora_slam_last_push_stats(const ora_slam* s, ora_push_stats* out);
+/* registration_mode 3: the raw rand() values the next scan's TSD_PDFMatching::match consumes (subsampleMask: beams
+ * values; pickControlSet: size_control_set; trial picks: trials), and what the last pre-registration found */
+void      ora_slam_set_draws(ora_slam* s, const int* sub, const int* ctrl, const int* trials);
+void      ora_slam_last_prereg(const ora_slam* s, double T[9], double* prob, int* idx, int* i);
+
+/* ---- N3: TSD_PDFMatching::match (TSD_PDFMatching.cpp:31-294) with the three rand() streams as inputs.  M / S are
+ * beam-indexed (n x 2) with their masks, like ThreadLocalize hands them over.  Returns 0, or 1 when the reference
+ * returns the identity early (too few points). */
+int ora_tsdpdf_match(const ora_grid* g, const double pose[9], const double* M, const uint8_t* maskM, const double* S,
+                     const uint8_t* maskS, int n, int trials, int size_control_set, double zrand, double phi_max,
+                     double resolution, const int* draws_subsample, const int* draws_control, const int* draws_trials,
+                     double T_out[9], double* best_prob, int* best_idx, int* best_i, int* candidates);
+void ora_icp_init(const double* model, int n_model, const double* scene_in, int n_scene, const double pose[9],
+                  const ora_icp_params* p, const double Tinit33[9], ora_icp_result* out, double* trace);
 
 #ifdef __cplusplus
 }

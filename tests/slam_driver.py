@@ -19,6 +19,7 @@ def slam_kwargs(gc, geo, **over):
         footprint_width=1.0, footprint_height=1.0, footprint_x_offset=0.28,
         laser_min_range=0.26, icp_iterations=30, dist_filter_max=0.4, dist_filter_min=0.02,
         reg_trs_max=1.0, reg_sin_rot_max=0.5, nn_mode=0, threads=1,
+        registration_mode=0, trials=100, size_control_set=140, zrand=0.25, ransac_phi_max=30.0,
     )
     kw.update(over)
     return kw

@@ -2,6 +2,7 @@
 GPU), the product fails loudly without a device, and the C++ host logic of the facade (sensor model,
 pose algebra, gates) equals the oracle bit for bit."""
 import ctypes as C
+import math
 import os
 import re
 
@@ -28,9 +29,15 @@ def test_header_symbols_are_exported(hip_lib):
 
 def test_struct_layouts_match_header():
     assert C.sizeof(capi.PushStats) == 8 + 8 + 7 * 4 + 4      # padded to 8
-    assert C.sizeof(capi.IcpParams) == 8 + 6 * 8               # iterations + estimator share the first 8 bytes
+    assert C.sizeof(capi.IcpParams) == 8 + 6 * 8 + 9 * 8 + 8  # iterations + estimator share the first 8 bytes; t_init + flag
     assert capi.IcpParams.estimator.offset == 4 and capi.IcpParams.dist_filter_max.offset == 8
     assert C.sizeof(capi.IcpResult) == 9 * 8 + 8 + 6 * 4
+    lib = capi.load_library()                                  # (load_library itself refuses a size mismatch)
+    for cname, mirror in (("tsd_push_stats", capi.PushStats), ("tsd_icp_params", capi.IcpParams), ("tsd_scan_result", capi.ScanResult),
+                          ("tsd_tsdpdf_params", capi.TsdPdfParams), ("tsd_tsdpdf_result", capi.TsdPdfResult),
+                          ("tsd_grid_digest_t", capi.GridDigest)):
+        assert lib.tsd_abi_sizeof(cname.encode()) == C.sizeof(mirror), cname
+    assert lib.tsd_abi_sizeof(b"no_such_struct") == 0
 
 
 @pytest.mark.skipif(capi.load_library().tsd_device_count() > 0, reason="a GPU is present")
@@ -143,3 +150,78 @@ def test_host_backproject_equals_oracle():
         assert a == b
         n_valid += a >= 0
     assert 1000 < n_valid < 2000      # both in-view and out-of-view (-1 / -2) cases were hit
+
+
+# ---- parameter surface: names, types and defaults the facade declares, against a table transcribed
+# ---- from the reference's declare_parameter calls
+def _reference_parameter_table(robot=""):
+    """SlamNode.cpp:40-58, ThreadLocalize.cpp:86-129 (constructor) and :424-432 (init); `robot` = _robotName incl. '/'"""
+    pi = math.pi
+    node = {                                             # SlamNode.cpp:40-58
+        "robot_nbr": ("int", 1), "x_off_factor": ("double", 0.5), "y_off_factor": ("double", 0.5),
+        "x_offset": ("double", 0.0), "y_offset": ("double", 0.0), "map_size": ("int", 10), "cellsize": ("double", 0.025),
+        "truncation_radius": ("int", 3), "occ_grid_time_interval": ("double", 2.0), "tf_map_frame": ("string", "map"),
+    }
+    ctor = {                                             # ThreadLocalize.cpp:86-129 (constants ThreadLocalize.h:58-70)
+        robot + "dist_filter_max": ("double", 1.0), robot + "dist_filter_min": ("double", 0.1),
+        robot + "icp_iterations": ("int", 25),
+        robot + "tf_laser_frame": ("string", robot + "laser"), robot + "tf_odom_frame": ("string", robot + "odom"),
+        robot + "tf_footprint_frame": ("string", robot + "base_footprint"),
+        "reg_trs_max": ("double", 0.25), "reg_sin_rot_max": ("double", 0.17), "max_velocity_lin": ("double", 1.5),
+        "max_velocity_rot": ("double", 2 * pi), "ude_odom_rescue": ("bool", False), "wait_for_odom_tf": ("double", 1.0),
+        "laser_min_range": ("double", 0.0), "trials": ("int", 100), "sizeControlSet": ("int", 140),
+        "epsThresh": ("double", 0.15), "zhit": ("double", 0.45), "zphi": ("double", 0.0), "zshort": ("double", 0.25),
+        "zmax": ("double", 0.05), "zrand": ("double", 0.25), "percentagePointsInC": ("double", 0.9),
+        "rangemax": ("double", 20.0), "sigphi": ("double", pi / 180.0 * 3), "sighit": ("double", 0.2),
+        "lamshort": ("double", 0.08), "maxAngleDiff": ("double", 3.0), "maxAnglePenalty": ("double", 0.5),
+        robot + "ransac_trials": ("int", 50), robot + "ransac_eps_thresh": ("double", 0.15),
+        robot + "ransac_ctrlset_size": ("int", 180), robot + "ransac_phi_max": ("double", 30.0),
+        robot + "registration_mode": ("int", 0),
+    }
+    ns = "tsd_slam/" + robot
+    init = {                                             # ThreadLocalize.cpp:424-432
+        ns + "local_offset_x": ("double", 0.0), ns + "local_offset_y": ("double", 0.0), ns + "local_offset_yaw": ("double", 0.0),
+        ns + "max_range": ("double", 30.0), ns + "min_range": ("double", 0.001), ns + "low_reflectivity_range": ("double", 2.0),
+        ns + "footprint_width": ("double", 1.0), ns + "footprint_height": ("double", 1.0), ns + "footprint_x_offset": ("double", 0.28),
+    }
+    return node, ctor, init
+
+
+def test_declared_parameters_equal_the_references():
+    # the facade's own additions (documented in INTEGRATION.md), everything else must be the reference's
+    additions = {"icp_estimator", "tsdpdf_seed", "pub_tsd_color_map", "object_inflation_factor", "use_object_inflation"}   # (the last three: ThreadGrid.cpp:42-47)
+    got = facade.declared_parameters()
+    node, ctor, init = _reference_parameter_table("")
+    want = {**node, **ctor, **init}
+    assert {k for k in got if k.split("/")[-1] not in additions} == set(want), set(got) ^ set(want)
+    for k, (t, v) in want.items():
+        assert got[k][0] == t, (k, got[k], t)
+        assert got[k][1] == v or (t == "double" and abs(got[k][1] - v) <= 1e-15), (k, got[k], v)
+    # multi-robot: per-robot prefixes (SlamNode.cpp:101-122), tf frames default to <robot>/laser ... (ThreadLocalize.cpp:90-92)
+    got = facade.declared_parameters({"robot_nbr": 2, "robot_0/name": "georg", "robot_1/name": "simon"})
+    for r in ("georg/", "simon/"):
+        _, ctor, init = _reference_parameter_table(r)
+        for k, (t, v) in {**ctor, **init}.items():
+            assert k in got and got[k][0] == t and got[k][1] == v, (k, got.get(k), (t, v))
+    assert got["georg/tf_laser_frame"] == ("string", "georg/laser")
+
+
+def test_shipped_single_laser_yaml_loads():
+    """config/single-laser.yaml of the reference (values transcribed: registration_mode 3, map_size 10, ...): every key is a
+    declared parameter of the right type, so the shipped YAML loads without touching an undeclared parameter."""
+    yaml_values = {     # /root/reference/config/single-laser.yaml (ros__parameters), transcribed key by key
+        "cellsize": 0.025, "epsThresh": 0.15, "lamshort": 0.08, "laser_min_range": 0.26, "map_size": 10, "maxAngleDiff": 1.5,
+        "maxAnglePenalty": 0.5, "max_velocity_lin": 1.0, "max_velocity_rot": 6.283185307179586, "object_inflation_factor": 1,
+        "occ_grid_time_interval": 2.0, "percentagePointsInC": 0.6, "pub_tsd_color_map": True, "rangemax": 30.0,
+        "reg_sin_rot_max": 0.5, "reg_trs_max": 1.0, "robot_nbr": 1, "sighit": 0.1, "sigphi": 0.05235987755982989,
+        "sizeControlSet": 360, "dist_filter_max": 0.4, "dist_filter_min": 0.02, "icp_iterations": 30, "ransac_phi_max": 45.0,
+        "registration_mode": 3, "ransac_ctrlset_size": 180, "ransac_eps_thresh": 0.15, "ransac_trials": 50,
+        "tf_laser_frame": "laser", "tf_map_frame": "map", "tf_odom_frame": "odom", "trials": 100, "truncation_radius": 3,
+        "ude_odom_rescue": False, "use_object_inflation": False, "wait_for_odom_tf": 1.0, "x_off_factor": 0.5, "x_offset": 0.0,
+        "y_off_factor": 0.5, "y_offset": 0.0, "zrand": 0.05, "zhit": 0.2, "zphi": 0.2, "zshort": 0.2, "zmax": 0.2,
+    }   # (use_sim_time is rclcpp's own parameter)
+    got = facade.declared_parameters(yaml_values)
+    for k, v in yaml_values.items():
+        assert k in got, k
+        t = "bool" if isinstance(v, bool) else "int" if isinstance(v, int) else "string" if isinstance(v, str) else "double"
+        assert got[k][0] == t, (k, got[k], t)

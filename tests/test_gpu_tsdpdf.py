@@ -1,0 +1,138 @@
+"""GPU tests of SURVEY 8(f) row N3: the TSD_PDF pre-registration (registration_mode 3; TSD_PDFMatching.cpp:31-294) and
+Icp::iterate with its result as Tinit (ThreadLocalize.cpp:557-581).  The reference's three rand() streams are inputs
+here (fixed draw arrays), so the HIP result is compared with the oracle's restatement for identical draws: the same
+winning (model, scene) pair, candidates and point counts exact, T / probability to rounding (the device's cos / sin
+and the product of 140-360 factors differ from libm's in the last bits).  PARITY UNPINNED like the other GSL-bound rows.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from ohm_tsd_slam_amd import capi, facade, synth
+from tests import helpers as H
+from tests.slam_driver import slam_kwargs
+
+pytestmark = pytest.mark.gpu
+
+
+def _map_and_scan(oracle, gc, geo, scene, k_pose, k_scan, dyaw=0.0, pushes=4):
+    world = synth.World(scene, gc)
+    og = oracle.Grid(gc.map_size_log2, gc.cell_size, gc.max_trunc)
+    dg = capi.TsdGridDevice(gc.map_size_log2, gc.cell_size, gc.max_trunc)
+    for k in range(pushes):
+        pose, (x, y, yaw) = H.sensor_pose(world, k)
+        data, mask = oracle.ingest_f32(world.scan(x, y, yaw, geo), H.MAX_RANGE, geo.angle_increment)
+        og.push(pose, data, mask, geo.angle_increment, geo.angle_min, H.MAX_RANGE, H.MIN_RANGE, H.LOW_REFL)
+        dg.push(pose, data, mask, geo.angle_increment, geo.angle_min, H.MAX_RANGE, H.MIN_RANGE, H.LOW_REFL, want_stats=False)
+    pose, _ = H.sensor_pose(world, k_pose)                        # where the robot believes it is
+    _, (x, y, yaw) = H.sensor_pose(world, k_scan)                 # where the scan is really taken
+    rl, rw = H.world_rays(oracle, geo, pose, gc.cell_size)
+    co, no, mo, cnt = og.raycast(pose, rw, H.MIN_RANGE, H.MAX_RANGE)
+    data, mask = oracle.ingest_f32(world.scan(x, y, yaw + dyaw, geo), H.MAX_RANGE, geo.angle_increment)
+    sc, ms, ns = oracle.scene_from_scan(rl, data, mask)
+    Ttrue = np.linalg.inv(pose) @ synth.pose_matrix(x, y, yaw + dyaw)
+    return og, dg, pose, co, mo, sc, ms, Ttrue
+
+
+@pytest.mark.parametrize("cfg,scene,ctrl,zrand,seed", [
+    ("cfg1", "room", 140, 0.25, 1), ("cfg2", "pillars", 140, 0.25, 2), ("cfg2", "pillars", 360, 0.05, 3),   # defaults / shipped YAML
+])
+def test_tsdpdf_match_matches_oracle(oracle, cfg, scene, ctrl, zrand, seed):
+    gc, geo, _ = synth.CONFIGS[cfg]
+    og, dg, pose, co, mo, sc, ms, Ttrue = _map_and_scan(oracle, gc, geo, scene, 3, 8, dyaw=0.05)
+    rng = np.random.default_rng(seed)
+    trials = 100
+    ds, dc, dt = (rng.integers(0, 2 ** 31 - 1, n) for n in (geo.beams, ctrl, trials))
+    phi_max = math.radians(30.0)
+    ro = oracle.tsdpdf_match(og, pose, co, mo, sc, ms, trials, ctrl, zrand, phi_max, geo.angle_increment, ds, dc, dt)
+    rh = dg.tsdpdf_match(pose, co, mo, sc, ms, trials, ctrl, zrand, phi_max, geo.angle_increment, ds, dc, dt)
+    assert ro["rc"] == 0 and ro["candidates"] > 200
+    assert (rh["candidates"], rh["idx"], rh["i"]) == (ro["candidates"], ro["idx"], ro["i"]), (ro, rh)
+    assert abs(rh["prob"] - ro["prob"]) <= 1e-9 * ro["prob"]
+    assert np.max(np.abs(rh["T"] - ro["T"])) <= 1e-12
+    # and it is a sensible pre-registration: close to the true motion between the believed and the real pose
+    d, a = H.pose_delta(Ttrue, rh["T"])
+    assert d < 0.15 and a < 0.05, (d, a)
+
+
+def test_tsdpdf_degenerate_inputs(oracle):
+    """too few valid points -> identity (TSD_PDFMatching.cpp:53-57, :129-139); all-false masks; tiny control set"""
+    gc, geo, _ = synth.CONFIGS["cfg1"]
+    og, dg, pose, co, mo, sc, ms, _ = _map_and_scan(oracle, gc, geo, "room", 2, 3)
+    rng = np.random.default_rng(5)
+    ds, dc, dt = (rng.integers(0, 2 ** 31 - 1, n) for n in (geo.beams, 140, 100))
+    z = np.zeros_like(mo)
+    for (mm, msk) in ((z, ms), (mo, z)):
+        rh = dg.tsdpdf_match(pose, co, mm, sc, msk, 100, 140, 0.25, 0.5, geo.angle_increment, ds, dc, dt)
+        ro = oracle.tsdpdf_match(og, pose, co, mm, sc, msk, 100, 140, 0.25, 0.5, geo.angle_increment, ds, dc, dt)
+        assert np.array_equal(rh["T"], np.eye(3)) and np.array_equal(ro["T"], np.eye(3)) and rh["idx"] == -1
+    rh = dg.tsdpdf_match(pose, co, mo, sc, ms, 5, 3, 0.25, 0.5, geo.angle_increment, ds, dc, dt)
+    ro = oracle.tsdpdf_match(og, pose, co, mo, sc, ms, 5, 3, 0.25, 0.5, geo.angle_increment, ds, dc, dt)
+    assert (rh["candidates"], rh["idx"], rh["i"]) == (ro["candidates"], ro["idx"], ro["i"])
+    assert np.max(np.abs(rh["T"] - ro["T"])) <= 1e-12
+
+
+@pytest.mark.parametrize("iters", [30, 11])
+def test_icp_with_t_init_matches_oracle(oracle, iters):
+    gc, geo, scene = synth.CONFIGS["cfg2"]
+    og, dg, pose, co, mo, sc, ms, Ttrue = _map_and_scan(oracle, gc, geo, scene, 3, 8, dyaw=0.05)
+    M = co.reshape(-1, 2)[mo.astype(bool)]
+    S = sc.reshape(-1, 2)[ms.astype(bool)]
+    Tinit = synth.pose_matrix(0.28, -0.03, 0.09)                   # a rough pre-registration
+    ro = oracle.icp_init(M, S, pose, iters, 0.4, 0.02, (0.0, og.max_x, 0.0, og.max_x), Tinit, nn_mode=1)
+    rh = dg.icp(M, S, pose, dg.icp_params(iters, 0.4, 0.02, t_init=Tinit))
+    assert (rh.pairs, rh.iterations, rh.state) == (ro["pairs"], ro["iterations"], ro["state"])
+    d, a = H.pose_delta(ro["T"], rh.T)
+    assert d <= 1e-9 and a <= 1e-9 and abs(rh.rms - ro["rms"]) <= 1e-9
+    d, a = H.pose_delta(Ttrue, rh.T)
+    assert d < 0.05 and a < 0.02                                   # Tfinal includes Tinit (Icp.cpp:485)
+    # without Tinit the same call starts from the identity
+    r0 = dg.icp(M, S, pose, dg.icp_params(iters, 0.4, 0.02))
+    o0 = oracle.icp(M, S, pose, iters, 0.4, 0.02, (0.0, og.max_x, 0.0, og.max_x), nn_mode=1)
+    assert (r0.pairs, r0.iterations) == (o0["pairs"], o0["iterations"])
+
+
+def _libc_draws(seed, n_sub, n_ctrl, n_trials):
+    """what obvious::TSD_PDFMatching::match of the facade draws for `tsdpdf_seed` >= 0: srand(seed + call), then rand()"""
+    libc = C.CDLL(None)
+    libc.srand(C.c_uint(seed))
+    return ([libc.rand() for _ in range(n_sub)], [libc.rand() for _ in range(n_ctrl)], [libc.rand() for _ in range(n_trials)])
+
+
+@pytest.mark.parametrize("cfg,n", [("cfg1", 12), ("cfg2", 10)])
+def test_facade_registration_mode_3_matches_oracle(oracle, cfg, n):
+    """config/single-laser.yaml's mode: ThreadLocalize with the TSD_PDF pre-registration in front of the ICP, the whole
+    closed loop against the oracle's SLAM loop in the same mode, both fed the same rand() draws."""
+    gc, geo, scene = synth.CONFIGS[cfg]
+    world = synth.World(scene, gc)
+    poses = synth.trajectory(world, n)
+    scans = synth.scans_for(world, geo, poses)
+    geo_msg = synth.ScanGeometry(geo.beams, float(np.float32(geo.angle_min)), float(np.float32(geo.angle_increment)))
+    trials, ctrl, zrand, phimax, seed = 100, 140, 0.25, 30.0, 4711
+    so = oracle.Slam(**slam_kwargs(gc, geo_msg, registration_mode=3, trials=trials, size_control_set=ctrl, zrand=zrand,
+                                   ransac_phi_max=phimax))
+    params = facade.node_params(gc, geo)
+    params.update({"registration_mode": 3, "trials": trials, "sizeControlSet": ctrl, "zrand": zrand, "ransac_phi_max": phimax,
+                   "tsdpdf_seed": seed})
+    node = facade.SlamNode(params, synchronous=True)
+    pushes = 0
+    for k in range(n):
+        if k > 0:
+            so.set_draws(*_libc_draws(seed + (k - 1), geo.beams, ctrl, trials))
+        ro = so.process_scan(scans[k])
+        node.laser(scans[k], geo.angle_min, geo.angle_increment)
+        rh = node.report()
+        d, a = H.pose_delta(np.array(ro.pose[:]).reshape(3, 3), rh["pose"])
+        assert d <= 1e-4 and a <= 1e-4, f"scan {k}: {d} m {a} rad"
+        if k > 0:
+            assert (ro.pairs, ro.iterations, ro.icp_state) == (rh["pairs"], rh["iterations"], rh["icp_state"]), f"scan {k}"
+            assert (ro.valid_model, ro.valid_scene) == (rh["valid_model"], rh["valid_scene"])
+            assert bool(ro.pushed) == bool(rh["pushed"]) and bool(ro.reg_error) == bool(rh["reg_error"])
+        pushes += rh["pushed"]
+    assert pushes >= n // 2
+    H.assert_grids_equal(so.grid.dump(), node.grid().download_tiles(), 1e-5)
+    e = math.hypot(rh["pose"][0, 2] - poses[-1, 0], rh["pose"][1, 2] - poses[-1, 1])
+    assert e < 0.1, f"tracking error {e} m"
+    node.close()
