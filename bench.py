@@ -333,13 +333,16 @@ def run_slam(args, gc, geo, scene, K, W, every, device, rank, local_rank, world_
     grid = node.grid()
     merger = None
     if use_dist:
-        merger = multigpu.OccupancyMerger(gc.cells, device=f"cuda:{local_rank}")
+        # the merge itself is the C ABI of include/tsd_comm.h (extraction kernels + ncclAllReduce(int8, max) on the grid's
+        # stream); torch.distributed only carries the communicator's unique id to the ranks
+        ids = [multigpu.NativeOccupancyMerger.new_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        merger = multigpu.NativeOccupancyMerger(grid, world_size, rank, ids[0])
 
     def step(k, r=0):
         node.laser(scans[r][k], geo.angle_min, geo.angle_increment, robot=r)
         if merger is not None and r == 0 and k % MERGE_EVERY == 0:
-            merger.fill_from_grid(grid)     # occupancy extraction kernels on the ctx stream
-            merger.merge_async(force=args.force_dist)   # RCCL max all-reduce over xGMI, overlaps the next scans
+            merger.merge_async()            # extraction kernels + RCCL max all-reduce over xGMI, in stream order, no wait
 
     def run_range(k0, k1):
         if R == 1:
@@ -413,6 +416,8 @@ def run_slam(args, gc, geo, scene, K, W, every, device, rank, local_rank, world_
         "tracking_error_m": max(errs),
         "_stats": (st, pushes, upd_ms, upd_launches),
     }
+    if merger is not None:
+        merger.close()        # (the communicator refers to the grid context: it goes first)
     node.close()
     return out
 

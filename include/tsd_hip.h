@@ -97,6 +97,8 @@ void     tsd_destroy(tsd_ctx* ctx);
 int      tsd_reset(tsd_ctx* ctx);                          /* TsdGrid::reset (TsdGrid.cpp:194-198) */
 int      tsd_set_max_truncation(tsd_ctx* ctx, double val); /* TsdGrid::setMaxTruncation (:206-215) */
 int      tsd_sync(tsd_ctx* ctx);
+int      tsd_device(const tsd_ctx* ctx);                   /* HIP device ordinal of the context */
+void*    tsd_stream(tsd_ctx* ctx);                         /* its hipStream_t: work a host enqueues there is ordered with the grid's */
 const char* tsd_last_error(const tsd_ctx* ctx);
 
 /* sizeof() of a public struct of this header by name ("tsd_push_stats", "tsd_icp_params", ...; 0 if unknown): lets a
@@ -272,6 +274,9 @@ int tsd_load_grid_text(tsd_ctx* ctx, const char* path);
  * then max-all-reduced over RCCL). */
 int tsd_occupancy(tsd_ctx* ctx, int8_t* occ_host, int inflate, int inflate_factor, int* n_surface);
 int tsd_occupancy_dev(tsd_ctx* ctx, void* occ_dev, int inflate, int inflate_factor);
+/* the same without the final wait: the extraction kernels are only enqueued on the context's stream (what the RCCL
+ * merge of include/tsd_comm.h puts its all-reduce behind) */
+int tsd_occupancy_dev_async(tsd_ctx* ctx, void* occ_dev, int inflate, int inflate_factor);
 /* TsdGrid::grid2ColorImage(image, width, height) (TsdGrid.cpp:429-488): RGB8, rgb[3 * (h * width + w)], the debug
  * image ThreadGrid publishes with every occupancy map (ThreadGrid.cpp:119-131).  Host buffer of 3*width*height. */
 int tsd_color_image(tsd_ctx* ctx, uint8_t* rgb_host, unsigned int width, unsigned int height);

@@ -125,6 +125,8 @@ ABI = {
     "tsd_reset": (C.c_int, [C.c_void_p]),
     "tsd_set_max_truncation": (C.c_int, [C.c_void_p, C.c_double]),
     "tsd_sync": (C.c_int, [C.c_void_p]),
+    "tsd_device": (C.c_int, [C.c_void_p]),
+    "tsd_stream": (C.c_void_p, [C.c_void_p]),
     "tsd_last_error": (C.c_char_p, [C.c_void_p]),
     "tsd_cells": (C.c_int, [C.c_void_p]),
     "tsd_tiles": (C.c_int, [C.c_void_p]),
@@ -163,6 +165,7 @@ ABI = {
     "tsd_abi_sizeof": (C.c_int, [C.c_char_p]),
     "tsd_occupancy": (C.c_int, [C.c_void_p, _i8p, C.c_int, C.c_int, _ip]),
     "tsd_occupancy_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "tsd_occupancy_dev_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "tsd_calibrate_rmw": (C.c_int, [C.c_void_p, C.c_int64, C.c_int]),
     "tsd_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "tsd_profile_select": (C.c_int, [C.c_void_p, C.c_char_p]),

@@ -224,6 +224,7 @@ static bool host_saw_event(hipEvent_t ev, int us)
   const auto t0 = std::chrono::steady_clock::now();
   for (;;) {
     if (hipEventQuery(ev) == hipSuccess) return true;
+    (void)hipGetLastError();                 // hipErrorNotReady is sticky as "last error": do not leave it for other libraries
     if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(us)) return false;
   }
 }
@@ -390,6 +391,8 @@ int tsd_sync(tsd_ctx* ctx)
 }
 
 const char* tsd_last_error(const tsd_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+int   tsd_device(const tsd_ctx* ctx) { return ctx ? ctx->device : -1; }
+void* tsd_stream(tsd_ctx* ctx) { return ctx ? static_cast<void*>(ctx->stream) : nullptr; }
 
 int    tsd_cells(const tsd_ctx* ctx) { return ctx ? ctx->grid.N : 0; }
 int    tsd_tiles(const tsd_ctx* ctx) { return ctx ? ctx->grid.tiles : 0; }
@@ -840,11 +843,16 @@ int tsd_load_grid_text(tsd_ctx* ctx, const char* path)
   return tsd_upload_tiles(ctx, init.data(), iw.data(), tsd.data(), w.data());
 }
 
-int tsd_occupancy_dev(tsd_ctx* ctx, void* occ_dev, int inflate, int inflate_factor)
+int tsd_occupancy_dev_async(tsd_ctx* ctx, void* occ_dev, int inflate, int inflate_factor)
 {
   if (!ctx || !occ_dev) return TSD_E_ARG;
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  int rc = launch_occupancy(ctx, static_cast<int8_t*>(occ_dev), inflate, inflate_factor);
+  return launch_occupancy(ctx, static_cast<int8_t*>(occ_dev), inflate, inflate_factor);
+}
+
+int tsd_occupancy_dev(tsd_ctx* ctx, void* occ_dev, int inflate, int inflate_factor)
+{
+  int rc = tsd_occupancy_dev_async(ctx, occ_dev, inflate, inflate_factor);
   if (rc != TSD_OK) return rc;
   TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return TSD_OK;

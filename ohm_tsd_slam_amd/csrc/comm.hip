@@ -1,0 +1,141 @@
+// comm.hip -- lib/libtsd_comm.so: the occupancy-map merge of the multi-grid case on RCCL (include/tsd_comm.h).
+// Uses only the public C ABI of libtsd_hip.so (tsd_stream, tsd_occupancy_dev_async) plus RCCL.  The extraction kernels
+// run on the context's stream (ordered behind the pushes already enqueued); ncclAllReduce(int8, max) runs on the
+// communicator's own stream behind an event, so the scans that follow on the context's stream overlap the collective
+// (xGMI ring: ~0.2 ms for 16 MiB on 8 GPUs); the next extraction waits for the previous collective through a second
+// event.  No hipStreamSynchronize anywhere but in tsd_comm_occupancy_wait.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/tsd_comm.h"
+
+struct tsd_comm {
+  tsd_ctx* ctx = nullptr;
+  ncclComm_t comm = nullptr;
+  int world = 1, rank = 0, device = 0;
+  size_t cells2 = 0;
+  int8_t* d_map = nullptr;
+  hipStream_t cstream = nullptr;       // the collective's stream
+  hipEvent_t ev_extracted = nullptr;   // map written by the extraction kernels (context stream)
+  hipEvent_t ev_reduced = nullptr;     // all-reduce finished with the map (collective stream)
+  bool reduced_pending = false;
+  std::string err;
+};
+
+static int fail(tsd_comm* c, const char* what, const char* detail)
+{
+  if (c) c->err = std::string(what) + ": " + (detail ? detail : "");
+  return TSD_E_HIP;
+}
+
+extern "C" {
+
+int tsd_comm_unique_id(char id_out[TSD_COMM_ID_BYTES])
+{
+  if (!id_out) return TSD_E_ARG;
+  ncclUniqueId id;
+  const ncclResult_t r = ncclGetUniqueId(&id);
+  if (r != ncclSuccess) { std::fprintf(stderr, "tsd_comm_unique_id: %s\n", ncclGetErrorString(r)); return TSD_E_HIP; }
+  static_assert(sizeof(id.internal) == TSD_COMM_ID_BYTES, "NCCL_UNIQUE_ID_BYTES");
+  std::memcpy(id_out, id.internal, TSD_COMM_ID_BYTES);
+  return TSD_OK;
+}
+
+tsd_comm* tsd_comm_create(tsd_ctx* ctx, int world_size, int rank, const char id_in[TSD_COMM_ID_BYTES])
+{
+  if (!ctx || !id_in || world_size < 1 || rank < 0 || rank >= world_size) return nullptr;
+  tsd_comm* c = new (std::nothrow) tsd_comm();
+  if (!c) return nullptr;
+  c->ctx = ctx; c->world = world_size; c->rank = rank; c->device = tsd_device(ctx);
+  c->cells2 = (size_t)tsd_cells(ctx) * (size_t)tsd_cells(ctx);
+  if (hipSetDevice(c->device) != hipSuccess || hipMalloc(&c->d_map, c->cells2) != hipSuccess) {
+    std::fprintf(stderr, "tsd_comm_create: no device memory for the map\n");
+    delete c; return nullptr;
+  }
+  hipMemset(c->d_map, 0xFF, c->cells2);           // -1 = unknown
+  if (hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_extracted, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_reduced, hipEventDisableTiming) != hipSuccess) {
+    std::fprintf(stderr, "tsd_comm_create: stream / events\n");
+    hipFree(c->d_map); delete c; return nullptr;
+  }
+  ncclUniqueId id;
+  std::memcpy(id.internal, id_in, TSD_COMM_ID_BYTES);
+  (void)hipGetLastError();      // RCCL reads the thread's sticky last error: an earlier hipErrorNotReady is not its business
+  const ncclResult_t r = ncclCommInitRank(&c->comm, world_size, id, rank);
+  if (r != ncclSuccess) {
+    std::fprintf(stderr, "tsd_comm_create: ncclCommInitRank: %s\n", ncclGetErrorString(r));
+    hipFree(c->d_map); delete c; return nullptr;
+  }
+  return c;
+}
+
+void tsd_comm_destroy(tsd_comm* c)
+{
+  if (!c) return;
+  hipSetDevice(c->device);
+  if (c->ctx) tsd_sync(c->ctx);
+  if (c->cstream) hipStreamSynchronize(c->cstream);
+  if (c->comm) ncclCommDestroy(c->comm);
+  if (c->ev_extracted) hipEventDestroy(c->ev_extracted);
+  if (c->ev_reduced) hipEventDestroy(c->ev_reduced);
+  if (c->cstream) hipStreamDestroy(c->cstream);
+  if (c->d_map) hipFree(c->d_map);
+  delete c;
+}
+
+int tsd_comm_world_size(const tsd_comm* c) { return c ? c->world : 0; }
+int tsd_comm_rank(const tsd_comm* c) { return c ? c->rank : -1; }
+const char* tsd_comm_last_error(const tsd_comm* c) { return c ? c->err.c_str() : "null comm"; }
+void* tsd_comm_map_dev(tsd_comm* c) { return c ? c->d_map : nullptr; }
+
+int tsd_comm_allreduce_map(tsd_comm* c)
+{
+  if (!c) return TSD_E_ARG;
+  if (hipSetDevice(c->device) != hipSuccess) return fail(c, "hipSetDevice", "");
+  hipStream_t stream = static_cast<hipStream_t>(tsd_stream(c->ctx));
+  // the map is complete once everything enqueued on the context's stream so far has run
+  if (hipEventRecord(c->ev_extracted, stream) != hipSuccess || hipStreamWaitEvent(c->cstream, c->ev_extracted, 0) != hipSuccess)
+    return fail(c, "event hand-over to the collective stream", "");
+  (void)hipGetLastError();
+  // -1 unknown < 0 free < 100 occupied: the signed maximum is "occupied wins over free wins over unknown"
+  const ncclResult_t r = ncclAllReduce(c->d_map, c->d_map, c->cells2, ncclInt8, ncclMax, c->comm, c->cstream);
+  if (r != ncclSuccess) return fail(c, "ncclAllReduce", ncclGetErrorString(r));
+  if (hipEventRecord(c->ev_reduced, c->cstream) != hipSuccess) return fail(c, "hipEventRecord", "");
+  c->reduced_pending = true;
+  return TSD_OK;
+}
+
+int tsd_comm_occupancy_allreduce(tsd_comm* c, int inflate, int inflate_factor)
+{
+  if (!c) return TSD_E_ARG;
+  if (hipSetDevice(c->device) != hipSuccess) return fail(c, "hipSetDevice", "");
+  if (c->reduced_pending) {       // the previous collective still owns the map: the extraction waits for it on the device
+    if (hipStreamWaitEvent(static_cast<hipStream_t>(tsd_stream(c->ctx)), c->ev_reduced, 0) != hipSuccess) return fail(c, "hipStreamWaitEvent", "");
+    c->reduced_pending = false;
+  }
+  const int rc = tsd_occupancy_dev_async(c->ctx, c->d_map, inflate, inflate_factor);     // extraction kernels, stream order
+  if (rc != TSD_OK) { c->err = tsd_last_error(c->ctx); return rc; }
+  return tsd_comm_allreduce_map(c);
+}
+
+int tsd_comm_occupancy_wait(tsd_comm* c, int8_t* merged_host)
+{
+  if (!c) return TSD_E_ARG;
+  if (hipSetDevice(c->device) != hipSuccess) return fail(c, "hipSetDevice", "");
+  hipStream_t stream = c->cstream;
+  if (merged_host) {
+    const hipError_t e = hipMemcpyAsync(merged_host, c->d_map, c->cells2, hipMemcpyDeviceToHost, stream);
+    if (e != hipSuccess) return fail(c, "hipMemcpyAsync", hipGetErrorString(e));
+  }
+  const hipError_t e = hipStreamSynchronize(stream);
+  if (e != hipSuccess) return fail(c, "hipStreamSynchronize", hipGetErrorString(e));
+  return TSD_OK;
+}
+
+}  // extern "C"

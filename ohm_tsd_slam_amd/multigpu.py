@@ -11,14 +11,104 @@ shared occupancy map is the element-wise maximum of the per-rank int8 maps (all 
 grid geometry, their start poses differ by ``local_offset_*``): occupied (100) wins over free (0) wins
 over unknown (-1), which is what writing all robots' scans into one grid converges to.
 
-``torch`` is plumbing here (device buffer + process group), not the compute path: the per-rank map is
-produced by the HIP kernels behind ``tsd_occupancy_dev``.
+The collective itself lives behind the C ABI (``include/tsd_comm.h``, ``lib/libtsd_comm.so``): extraction kernels and
+``ncclAllReduce(int8, max)`` enqueued on the grid context's own stream, so a C++ host can merge without Python or
+torch.  :class:`NativeOccupancyMerger` is the thin ctypes caller ``bench.py`` uses; ``torch.distributed`` is only the
+launcher's process group (rank / world size, the 128-byte unique id travels through it, barrier and max-over-ranks of
+the bench contract).  :class:`OccupancyMerger` is the same merge over ``torch.distributed`` tensors, kept for the gloo
+CPU tests of the semantics (world_size 2 without a GPU).
 """
 from __future__ import annotations
 
 import os
 
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
 UNKNOWN, FREE, OCCUPIED = -1, 0, 100
+COMM_LIB_PATH = os.path.join(capi.LIB_DIR, "libtsd_comm.so")
+COMM_ID_BYTES = 128
+
+COMM_ABI = {
+    "tsd_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "tsd_comm_create": (C.c_void_p, [C.c_void_p, C.c_int, C.c_int, C.c_char_p]),
+    "tsd_comm_destroy": (None, [C.c_void_p]),
+    "tsd_comm_world_size": (C.c_int, [C.c_void_p]),
+    "tsd_comm_rank": (C.c_int, [C.c_void_p]),
+    "tsd_comm_last_error": (C.c_char_p, [C.c_void_p]),
+    "tsd_comm_occupancy_allreduce": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "tsd_comm_allreduce_map": (C.c_int, [C.c_void_p]),
+    "tsd_comm_occupancy_wait": (C.c_int, [C.c_void_p, C.POINTER(C.c_int8)]),
+    "tsd_comm_map_dev": (C.c_void_p, [C.c_void_p]),
+}
+_comm_lib = None
+
+
+def load_comm_library():
+    """``lib/libtsd_comm.so`` (links librccl + libtsd_hip); every symbol of include/tsd_comm.h is bound."""
+    global _comm_lib
+    if _comm_lib is None:
+        capi.load_library()
+        if not os.path.exists(COMM_LIB_PATH):
+            raise capi.TsdError(f"{COMM_LIB_PATH} not found: run __graft_entry__.build()")
+        lib = C.CDLL(COMM_LIB_PATH)
+        for name, (res, args) in COMM_ABI.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _comm_lib = lib
+    return _comm_lib
+
+
+class NativeOccupancyMerger:
+    """The RCCL merge through the C ABI: one communicator per grid context, ``merge_async`` enqueues the extraction
+    kernels and ``ncclAllReduce(int8, max)`` on the context's stream (nothing waits), ``wait`` synchronises.
+    ``unique_id`` comes from rank 0 (``NativeOccupancyMerger.new_id()``) and is handed to every rank by the launcher."""
+
+    @staticmethod
+    def new_id() -> bytes:
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        if load_comm_library().tsd_comm_unique_id(buf) != 0:
+            raise capi.TsdError("tsd_comm_unique_id failed")
+        return buf.raw
+
+    def __init__(self, grid, world_size: int, rank: int, unique_id: bytes):
+        self.lib = load_comm_library()
+        self.grid = grid
+        self.cells = grid.cells
+        assert len(unique_id) == COMM_ID_BYTES
+        self.h = self.lib.tsd_comm_create(grid.h, world_size, rank, unique_id)
+        if not self.h:
+            raise capi.TsdError("tsd_comm_create failed (RCCL communicator)")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tsd_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise capi.TsdError(f"{what} failed ({rc}): {self.lib.tsd_comm_last_error(self.h).decode()}")
+
+    def merge_async(self, inflate: bool = False, inflate_factor: int = 2):
+        self._check(self.lib.tsd_comm_occupancy_allreduce(self.h, int(inflate), inflate_factor), "tsd_comm_occupancy_allreduce")
+
+    def wait(self):
+        self._check(self.lib.tsd_comm_occupancy_wait(self.h, None), "tsd_comm_occupancy_wait")
+
+    def merged(self) -> np.ndarray:
+        out = np.empty(self.cells * self.cells, dtype=np.int8)
+        self._check(self.lib.tsd_comm_occupancy_wait(self.h, out.ctypes.data_as(C.POINTER(C.c_int8))), "tsd_comm_occupancy_wait")
+        return out.reshape(self.cells, self.cells)
 
 
 def env_rank():

@@ -27,6 +27,21 @@ def test_header_symbols_are_exported(hip_lib):
         assert hasattr(hip_lib, name), f"{name} declared in include/tsd_hip.h but not exported"
 
 
+def test_comm_header_symbols_are_exported():
+    """include/tsd_comm.h (the RCCL occupancy merge behind the C ABI, lib/libtsd_comm.so): loads without a GPU, exports
+    every declared symbol; no collective is issued here."""
+    from ohm_tsd_slam_amd import multigpu
+    lib = multigpu.load_comm_library()
+    hdr = open(os.path.join(ROOT, "include", "tsd_comm.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(tsd_comm_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(multigpu.COMM_ABI.keys()), declared ^ set(multigpu.COMM_ABI.keys())
+    for name in declared:
+        assert hasattr(lib, name)
+    src = open(os.path.join(ROOT, "ohm_tsd_slam_amd", "csrc", "comm.hip")).read()
+    assert "ncclAllReduce(" in src and "ncclInt8" in src and "ncclMax" in src and "hipStreamSynchronize" in src.split("tsd_comm_occupancy_wait")[-1]
+
+
 def test_struct_layouts_match_header():
     assert C.sizeof(capi.PushStats) == 8 + 8 + 7 * 4 + 4      # padded to 8
     assert C.sizeof(capi.IcpParams) == 8 + 6 * 8 + 9 * 8 + 8  # iterations + estimator share the first 8 bytes; t_init + flag

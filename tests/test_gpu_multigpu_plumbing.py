@@ -27,3 +27,13 @@ def test_bench_distributed_plumbing_one_rank():
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["steps"] == 60 and d["scaling"] == "weak"
     assert d["value"] > 100.0 and d["tracking_error_m"] < 0.5
+
+
+def test_native_rccl_merge_one_rank():
+    """include/tsd_comm.h on one GPU, in a FRESH interpreter (tests/comm_check.py): a process that has both this image's
+    ROCm runtime and the HIP / RCCL copies bundled with the torch wheel mapped -- as a pytest process that collected the
+    gloo tests has -- mixes RCCL and HIP builds, which is no property of the library under test (a C++ host has no torch)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "tests.comm_check"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    assert "comm_check ok" in out.stdout
