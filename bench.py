@@ -312,12 +312,16 @@ def run_slam(args, gc, geo, scene, K, W, every, device, rank, local_rank, world_
     R = args.robots
     # robot r starts 0.7 m further along -x (launch/multi_slam.launch:40).  Ranks own one grid each (--gpus N);
     # --robots R puts R robots on this rank's ONE grid (the reference's own multi-robot mode)
-    worlds, poses, scans = [], [], []
+    # ONE world for all robots of a grid; robots beyond the first start on pillar-free lanes next to it
+    world = synth.World(scene, gc, start_xy=[0.5 * gc.width + multigpu.robot_offset_x(rank), 0.5 * gc.width - 0.21])
+    # (several robots: 3 m legs back and forth, so that enough pillar-free lanes exist among the 200 pillars)
+    leg = 50 if R > 1 else None
+    lanes = synth.free_lanes(world, R, 0.06 * leg, clearance=0.6) if R > 1 else [(float(world.start[0]), float(world.start[1]))]
+    poses, scans = [], []
     for r in range(R):
-        off_x = multigpu.robot_offset_x(rank * R + r)
-        w = synth.World(scene, gc, start_xy=[0.5 * gc.width + off_x, 0.5 * gc.width - 0.21 - (0.9 * r if R > 1 else 0.0)])
-        p = synth.trajectory(w, 1 + W + K)
-        worlds.append(w); poses.append(p); scans.append(synth.scans_for(w, geo, p))
+        p = synth.trajectory(world, 1 + W + K, leg=leg)
+        p[:, 1] += lanes[r][1] - world.start[1]
+        poses.append(p); scans.append(synth.scans_for(world, geo, p))
     params = facade.node_params(gc, geo)
     if R == 1:
         params["tsd_slam/local_offset_x"] = multigpu.robot_offset_x(rank)
@@ -325,8 +329,12 @@ def run_slam(args, gc, geo, scene, K, W, every, device, rank, local_rank, world_
         params["robot_nbr"] = R
         for r in range(R):
             params[f"robot_{r}/name"] = f"robot{r}"
-            params[f"tsd_slam/robot{r}/local_offset_x"] = multigpu.robot_offset_x(rank * R + r)
-            params[f"tsd_slam/robot{r}/local_offset_y"] = -0.21 - 0.9 * r
+            params[f"tsd_slam/robot{r}/local_offset_x"] = lanes[r][0] - 0.5 * gc.width
+            params[f"tsd_slam/robot{r}/local_offset_y"] = lanes[r][1] - 0.5 * gc.width
+            params[f"tsd_slam/robot{r}/local_offset_yaw"] = 0.1
+            # the ICP keys are per robot in multi-robot mode (ThreadLocalize.cpp:86-88: _robotName + "dist_filter_max" ...)
+            params.update({f"robot{r}/dist_filter_max": 0.4, f"robot{r}/dist_filter_min": 0.02, f"robot{r}/icp_iterations": 30,
+                           f"robot{r}/registration_mode": 0})
     if args.estimator:
         params["icp_estimator"] = args.estimator
     node = facade.SlamNode(params, device=device, synchronous=True)

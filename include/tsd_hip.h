@@ -229,6 +229,21 @@ int tsd_sensor_set_pose(tsd_sensor* s, const double pose33[9], const double* ray
 int tsd_scan(tsd_sensor* s, const double* ranges, const uint8_t* mask, const uint8_t* mask_push,
              const tsd_icp_params* params, const tsd_gate_params* gates, tsd_scan_result* result);
 
+/* The same scan in two halves for several robots on ONE grid (the reference's multi-robot mode, SlamNode.cpp:101-122),
+ * one calling thread per SENSOR.  tsd_scan_begin enqueues copy, tables, ray cast and registration (+ gates,
+ * Sensor::transform) on the sensor's own stream and buffers; tsd_scan_wait blocks the calling thread until the result
+ * record is there; tsd_scan_finish (which waits itself if need be) enqueues the push on the grid's stream and returns
+ * the result.  Registrations of different robots overlap (each occupies one compute unit and does not touch the grid); a
+ * ray cast waits for the grid writes enqueued before it and a push for the ray casts enqueued before it, in the order
+ * the calls reach their short, internally locked ordered sections -- pushes are serialised, like the reference's single
+ * ThreadMapping does, and no ray cast ever sees a half-written tile.  These calls may be issued concurrently for
+ * different sensors of one grid; one scan per sensor in flight.  For calls issued in turn the results are those of
+ * tsd_scan. */
+int tsd_scan_begin(tsd_sensor* s, const double* ranges, const uint8_t* mask, const uint8_t* mask_push,
+                   const tsd_icp_params* params, const tsd_gate_params* gates);
+int tsd_scan_wait(tsd_sensor* s);
+int tsd_scan_finish(tsd_sensor* s, tsd_scan_result* result);
+
 /* Per-iteration record of the most recent tsd_icp / tsd_localize on this ctx (the role of
  * Icp::activateTrace, Icp.cpp:60-70): out[4*i + {0,1,2,3}] = pairs, rms, DistanceFilter threshold
  * before the step, state after loop control, for i < min(iterations, max_iters). */

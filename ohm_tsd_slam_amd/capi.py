@@ -151,6 +151,9 @@ ABI = {
     "tsd_sensor_set_pose": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),
     "tsd_scan": (C.c_int, [C.c_void_p, _dp, _u8p, _u8p, C.POINTER(IcpParams), C.POINTER(GateParams),
                            C.POINTER(ScanResult)]),
+    "tsd_scan_begin": (C.c_int, [C.c_void_p, _dp, _u8p, _u8p, C.POINTER(IcpParams), C.POINTER(GateParams)]),
+    "tsd_scan_wait": (C.c_int, [C.c_void_p]),
+    "tsd_scan_finish": (C.c_int, [C.c_void_p, C.POINTER(ScanResult)]),
     "tsd_icp_trace": (C.c_int, [C.c_void_p, _dp, C.c_int]),
     "tsd_tsdpdf_match": (C.c_int, [C.c_void_p, _dp, _dp, _u8p, _dp, _u8p, C.c_int, C.POINTER(TsdPdfParams), _ip, _ip, _ip,
                                    C.POINTER(TsdPdfResult)]),

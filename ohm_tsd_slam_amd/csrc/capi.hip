@@ -15,6 +15,8 @@
 
 namespace tsd {
 
+thread_local const LaunchTarget* g_launch_target = nullptr;
+
 int set_error(tsd_ctx* ctx, int code, const char* what, hipError_t e)
 {
   if (ctx) {
@@ -47,6 +49,7 @@ static hipEvent_t pool_get(tsd_ctx* ctx)
 ScopedKernelTimer::ScopedKernelTimer(tsd_ctx* c, const char* n, bool around_) : ctx(c), name(n), around(around_)
 {
   if (!kernel_is_timed(ctx, n)) return;
+  std::lock_guard<std::mutex> lk(ctx->misc_mutex);
   if (ctx->profile_every > 1 && (ctx->timers[n].tick++ % ctx->profile_every) != 0) return;   // every n-th launch of THIS kernel
   a = pool_get(ctx); b = pool_get(ctx);
   if (!a || !b) { a = b = nullptr; return; }
@@ -56,10 +59,12 @@ ScopedKernelTimer::~ScopedKernelTimer()
 {
   if (!a) return;
   if (around) hipEventRecord(b, ctx->stream);
+  std::lock_guard<std::mutex> lk(ctx->misc_mutex);
   ctx->timers[name].pending.emplace_back(a, b);
 }
 void drain_timers(tsd_ctx* ctx)
 {
+  std::lock_guard<std::mutex> lk(ctx->misc_mutex);
   for (auto& kv : ctx->timers) {
     for (auto& pr : kv.second.pending) {
       float ms = 0.f;
@@ -229,6 +234,26 @@ static bool host_saw_event(hipEvent_t ev, int us)
   }
 }
 
+// every grid WRITE enqueued on the context's stream goes behind the ray casts the concurrent multi-robot path has in
+// flight on the sensors' own streams (no-op without such sensors)
+static int wait_for_readers(tsd_ctx* ctx)
+{
+  // (caller holds ctx->order_mutex.)  Ray casts ticketed after the last grid write that waited are the ones to wait
+  // for: earlier ones are ordered through that write already.  A sensor whose thread has taken its ticket but not yet
+  // issued the event record (a few microseconds) is waited for on the host.
+  for (tsd_sensor* t : ctx->sensors) {
+    if (!t->rc_event_valid || t->rc_ticket <= ctx->last_push_ticket) continue;
+    while (!__atomic_load_n(&t->rc_recorded, __ATOMIC_ACQUIRE)) {
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
+    TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, t->ev_rc_done, 0));
+  }
+  ctx->last_push_ticket = ctx->ticket;
+  return TSD_OK;
+}
+
 }  // namespace tsd
 
 using namespace tsd;
@@ -318,6 +343,7 @@ tsd_ctx* tsd_create(int device, int map_size_log2, double cell_size, double max_
   A(hipHostMalloc(&ctx->h_out, ctx->h_out_bytes, hipHostMallocDefault));
   A(hipMalloc(&ctx->d_occ, (size_t)g.N * g.N));
   A(hipMalloc(&ctx->d_occ_count, sizeof(int)));
+  A(hipEventCreateWithFlags(&ctx->ev_grid, hipEventDisableTiming));
   if (!ok) { tsd_destroy(ctx); return nullptr; }
   if (tsd_reset(ctx) != TSD_OK) { fprintf(stderr, "tsd_create: %s\n", ctx->err.c_str()); tsd_destroy(ctx); return nullptr; }
   return ctx;
@@ -335,6 +361,7 @@ void tsd_destroy(tsd_ctx* ctx)
   hipFree(ctx->d_rmq2[0]); hipFree(ctx->d_rmq2[1]); hipFree(ctx->d_tile_rec); hipFree(ctx->d_dirty); hipFree(ctx->d_tile_totals); hipFree(ctx->d_pushes); hipFree(ctx->d_list); hipFree(ctx->d_list_win); hipFree(ctx->d_list_pw); hipFree(ctx->d_push_args); hipFree(ctx->d_list_cnt);
   if (ctx->ev_tables) hipEventDestroy(ctx->ev_tables);
   if (ctx->ev_h2d) hipEventDestroy(ctx->ev_h2d);
+  if (ctx->ev_grid) hipEventDestroy(ctx->ev_grid);
   if (ctx->stream2) hipStreamDestroy(ctx->stream2);
   for (hipEvent_t e : ctx->event_pool) hipEventDestroy(e);
   for (int s = 0; s < tsd_ctx::kSlots; s++) {
@@ -356,6 +383,8 @@ int tsd_reset(tsd_ctx* ctx)
   if (ctx) ctx->epoch++;                  // (invalidates ray casts enqueued ahead of their scan)
   if (!ctx) return TSD_E_ARG;
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  std::lock_guard<std::mutex> lk_order(ctx->order_mutex);
+  if (int rcw = wait_for_readers(ctx)) return rcw;
   GridDev& g = ctx->grid;
   const size_t T = (size_t)g.tiles;
   // cells are materialised lazily (flags == 0 means "no cell storage yet", TsdGridPartition.cpp:88)
@@ -417,6 +446,8 @@ int tsd_free_footprint(tsd_ctx* ctx, const double center[2], double width, doubl
   const unsigned N = (unsigned)g.N;
   if (minX > N || maxX > N || minY > N || maxY > N)
     return set_error(ctx, TSD_E_BOUNDS, "freeFootprint: indices out of bounds", hipSuccess);
+  std::lock_guard<std::mutex> lk_order(ctx->order_mutex);
+  if (int rcw = wait_for_readers(ctx)) return rcw;
   // cells == N would index past the last tile in the reference (undefined there); clamp
   const unsigned cx1 = maxX > N ? N : maxX, cy1 = maxY > N ? N : maxY;
   return launch_free_footprint(ctx, minX, cx1, minY, cy1);
@@ -451,7 +482,10 @@ int tsd_push(tsd_ctx* ctx, const double pose33[9], const double* ranges, const u
   TSD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_push_args, h + (size_t)TSD_MAX_BEAMS * 9, sizeof(a), hipMemcpyHostToDevice, ctx->stream));
   TSD_HIP_CHECK(ctx, hipEventRecord(ctx->stage_ev[s], ctx->stream));
 
-  int rc = launch_push_tables(ctx, ctx->stream, beams, nullptr, nullptr, phi_min, ang_res);
+  std::lock_guard<std::mutex> lk_order(ctx->order_mutex);
+  int rc = wait_for_readers(ctx);
+  if (rc != TSD_OK) return rc;
+  rc = launch_push_tables(ctx, ctx->stream, beams, nullptr, nullptr, phi_min, ang_res);
   if (rc != TSD_OK) return rc;
   rc = launch_push(ctx, a, a.trx, a.try_, 0.0, ctx->d_push_args);
   if (rc != TSD_OK) return rc;
@@ -682,6 +716,8 @@ int tsd_upload_tiles(tsd_ctx* ctx, const uint8_t* initialized, const double* ini
   if (ctx) ctx->epoch++;                  // (invalidates ray casts enqueued ahead of their scan)
   if (!ctx || !initialized || !init_weight || !tsd_in || !weight_in) return TSD_E_ARG;
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  std::lock_guard<std::mutex> lk_order(ctx->order_mutex);
+  if (int rcw = wait_for_readers(ctx)) return rcw;
   TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   const GridDev& g = ctx->grid;
   const size_t T = (size_t)g.tiles;
@@ -994,13 +1030,25 @@ tsd_sensor* tsd_sensor_create(tsd_ctx* ctx, int beams, double ang_res, double ph
   A(hipHostMalloc(&s->h_result, sizeof(ScanResultDev), hipHostMallocMapped | hipHostMallocCoherent));
   if (ok) { std::memset(s->h_result, 0, sizeof(ScanResultDev)); A(hipHostGetDevicePointer((void**)&s->d_result, s->h_result, 0)); }
   if (!ok) { tsd_sensor_destroy(s); return nullptr; }
+  ctx->sensors.push_back(s);
   return s;
 }
 
 void tsd_sensor_destroy(tsd_sensor* s)
 {
   if (!s) return;
-  if (s->ctx) { hipSetDevice(s->ctx->device); hipStreamSynchronize(s->ctx->stream2); hipStreamSynchronize(s->ctx->stream); }
+  if (s->ctx) {
+    hipSetDevice(s->ctx->device); hipStreamSynchronize(s->ctx->stream2); hipStreamSynchronize(s->ctx->stream);
+    auto& v = s->ctx->sensors;
+    v.erase(std::remove(v.begin(), v.end(), s), v.end());
+  }
+  if (s->stream) hipStreamSynchronize(s->stream);
+  for (hipEvent_t e : {s->ev_rc_done, s->ev_icp_done}) if (e) hipEventDestroy(e);
+  if (s->stream) hipStreamDestroy(s->stream);
+  hipFree(s->d_coords); hipFree(s->d_normals); hipFree(s->d_mask_m); hipFree(s->d_icp_res); hipFree(s->d_icp_trace);
+  hipFree(s->d_rmq2[0]); hipFree(s->d_rmq2[1]);
+  if (s->h_stage2[0]) hipHostFree(s->h_stage2[0]);
+  if (s->h_stage2[1]) hipHostFree(s->h_stage2[1]);
   hipFree(s->d_state); hipFree(s->d_rays); hipFree(s->d_rays_local); hipFree(s->d_scan2[0]); hipFree(s->d_scan2[1]);
   hipHostFree(s->h_result);
   delete s;
@@ -1132,6 +1180,162 @@ int tsd_scan(tsd_sensor* s, const double* ranges, const uint8_t* mask, const uin
       __builtin_ia32_pause();
 #endif
     }
+  }
+  copy_icp_result(&s->h_result->icp, &result->icp);
+  for (int i = 0; i < 9; i++) result->pose[i] = s->h_result->pose[i];
+  s->pos[0] = result->pose[2]; s->pos[1] = result->pose[5];
+  result->reg_error = s->h_result->reg_error; result->pushed = s->h_result->pushed;
+  result->no_model = s->h_result->no_model; result->reserved = 0;
+  return TSD_OK;
+}
+
+
+// ------------------------------------------------------------------ concurrent multi-robot scans (one shared grid)
+// The reference's multi-robot mode is N ThreadLocalize workers on ONE TsdGrid (SlamNode.cpp:101-122).  With tsd_scan
+// every robot's whole scan sits on the grid's one stream, so N robots run their 0.17 ms registrations -- which do not
+// touch the grid at all and occupy ONE compute unit each -- back to back while 255 CUs idle.  Here a scan is split:
+//   tsd_scan_begin   from the robot's own thread: copy, tables, ray cast and registration (+ gates, Sensor::transform)
+//                    on the SENSOR's own stream into the sensor's own buffers
+//   tsd_scan_wait    the thread waits for the result record (written right after the registration)
+//   tsd_scan_finish  the push on the GRID stream (pushes of all robots are serialised there, like the reference's one
+//                    ThreadMapping serialises them)
+// Ordering is by events, in the order the calls reach two short sections locked by ctx->order_mutex: a ray cast waits
+// for every grid write enqueued before it, a push for every ray cast ticketed since the last grid write; registrations
+// overlap freely.  The push is enqueued only once its registration has finished: events order by ENQUEUE time, so a
+// push enqueued ahead of time would pull every later ray cast of every robot behind its own registration.
+static int sensor_conc_init(tsd_sensor* s)
+{
+  if (s->conc_ready) return TSD_OK;
+  tsd_ctx* ctx = s->ctx;
+  const size_t nb = (size_t)s->beams;
+  bool ok = true;
+  auto A = [&](hipError_t e) { if (e != hipSuccess) ok = false; };
+  A(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  for (hipEvent_t* e : {&s->ev_rc_done, &s->ev_icp_done}) A(hipEventCreateWithFlags(e, hipEventDisableTiming));
+  A(hipMalloc(&s->d_coords, nb * 16)); A(hipMalloc(&s->d_normals, nb * 16)); A(hipMalloc(&s->d_mask_m, nb));
+  A(hipMalloc(&s->d_icp_res, sizeof(IcpResultDev))); A(hipMalloc(&s->d_icp_trace, sizeof(double) * 4 * TSD_ICP_TRACE_MAX));
+  A(hipMalloc(&s->d_rmq2[0], push_rmq_bytes(s->beams))); A(hipMalloc(&s->d_rmq2[1], push_rmq_bytes(s->beams)));
+  A(hipHostMalloc(&s->h_stage2[0], nb * 10 + 64, hipHostMallocDefault)); A(hipHostMalloc(&s->h_stage2[1], nb * 10 + 64, hipHostMallocDefault));
+  if (!ok) return set_error(ctx, TSD_E_HIP, "tsd_scan_begin: per-sensor streams / buffers", hipGetLastError());
+  s->conc_ready = true;
+  return TSD_OK;
+}
+
+int tsd_scan_begin(tsd_sensor* s, const double* ranges, const uint8_t* mask, const uint8_t* mask_push,
+                   const tsd_icp_params* params, const tsd_gate_params* gates)
+{
+  if (!s || !ranges || !mask || !params || !gates) return TSD_E_ARG;
+  tsd_ctx* ctx = s->ctx;
+  if (!s->posed) return set_error(ctx, TSD_E_ARG, "tsd_scan_begin before tsd_sensor_set_pose", hipSuccess);
+  if (s->inflight) return set_error(ctx, TSD_E_ARG, "tsd_scan_begin: the previous scan of this sensor was not finished", hipSuccess);
+  TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  int rc = sensor_conc_init(s);
+  if (rc != TSD_OK) return rc;
+  const size_t nb = (size_t)s->beams;
+  // the scan: ranges | mask | mask_push through the sensor's own pinned buffer (the buffer two scans back is free: its
+  // copy was waited for by that scan's registration)
+  char* h = s->h_stage2[s->scan_slot];
+  char* d_scan = s->d_scan2[s->scan_slot];
+  s->scan_slot ^= 1;
+  std::memcpy(h, ranges, nb * 8);
+  std::memcpy(h + nb * 8, mask, nb);
+  std::memcpy(h + nb * 9, mask_push ? mask_push : mask, nb);
+  // (copy and tables on the sensor's ONE stream, ahead of the ray cast: every further stream is one more candidate for
+  // sharing a hardware queue with another robot's 0.17 ms registration -- HIP multiplexes streams onto a few in-order
+  // hardware queues, GPU_MAX_HW_QUEUES -- and 17 us ahead of a 190 us chain is the cheaper price)
+  TSD_HIP_CHECK(ctx, hipMemcpyAsync(d_scan, h, nb * 10, hipMemcpyHostToDevice, s->stream));
+  const double* d_ranges = reinterpret_cast<const double*>(d_scan);
+  const uint8_t* d_mask = reinterpret_cast<const uint8_t*>(d_scan + nb * 8);
+  const uint8_t* d_mask_push = reinterpret_cast<const uint8_t*>(d_scan + nb * 9);
+  s->rmq_slot ^= 1;                         // (the previous push of this sensor may still read its tables)
+  LaunchTarget tg;
+  tg.stream = s->stream; tg.coords = s->d_coords; tg.normals = s->d_normals; tg.mask_m = s->d_mask_m;
+  tg.icp_res = s->d_icp_res; tg.trace = s->d_icp_trace; tg.rmq = s->d_rmq2[s->rmq_slot];
+  TargetScope scope(ctx, &tg);
+  rc = launch_push_tables(ctx, s->stream, s->beams, d_ranges, d_mask_push, s->phi_min, s->ang_res);
+  if (rc != TSD_OK) return rc;
+  {
+    // ORDERED SECTION (the only part of begin that other robots' threads wait for): the ray cast reads the grid, so it
+    // goes behind every grid write enqueued so far, and takes its place in the order for the writes that follow
+    std::lock_guard<std::mutex> lk(ctx->order_mutex);
+    TSD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_grid, ctx->stream));
+    TSD_HIP_CHECK(ctx, hipStreamWaitEvent(s->stream, ctx->ev_grid, 0));
+    __atomic_store_n(&s->rc_recorded, 0, __ATOMIC_RELEASE);
+    s->rc_ticket = ++ctx->ticket;
+    s->rc_event_valid = true;
+  }
+  RaycastArgs ra;
+  std::memset(&ra, 0, sizeof(ra));
+  ra.beams = s->beams;
+  rc = launch_raycast(ctx, ra, &s->d_state->rc, s->d_rays);
+  const hipError_t e_rc = hipEventRecord(s->ev_rc_done, s->stream);
+  __atomic_store_n(&s->rc_recorded, 1, __ATOMIC_RELEASE);      // (always: a writer may be spinning on it)
+  if (rc != TSD_OK) return rc;
+  if (e_rc != hipSuccess) return set_error(ctx, TSD_E_HIP, "hipEventRecord(ev_rc_done)", e_rc);
+  s->rc_pending = false;
+  IcpArgs ia;
+  const double ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  fill_icp_args(ia, ident, params);
+  ia.beams = s->beams; ia.ccw = s->ccw ? 1 : 0;
+  const unsigned long long seq = ++s->seq;
+  ScanPostArgs sp;
+  std::memset(&sp, 0, sizeof(sp));
+  sp.st = s->d_state; sp.rays = s->d_rays; sp.out = s->d_result; sp.seq = seq; sp.beams = s->beams;
+  sp.gmin_x = ctx->grid.min_x; sp.gmax_x = ctx->grid.max_x; sp.gmin_y = ctx->grid.min_y; sp.gmax_y = ctx->grid.max_y;
+  sp.gates = GateArgs{gates->reg_trs_max, gates->reg_sin_rot_max, gates->trs_min, gates->rot_min};
+  rc = launch_icp(ctx, ia, s->d_state->icpP, s->d_rays_local, d_ranges, d_mask, &sp);
+  if (rc != TSD_OK) return rc;
+  TSD_HIP_CHECK(ctx, hipEventRecord(s->ev_icp_done, s->stream));
+  s->conc_gates = *gates; s->conc_ranges = d_ranges; s->conc_mask_push = d_mask_push;
+  s->inflight = true;
+  return TSD_OK;
+}
+
+int tsd_scan_wait(tsd_sensor* s)
+{
+  if (!s || !s->inflight) return TSD_E_ARG;
+  volatile unsigned long long* vseq = &s->h_result->seq;
+  unsigned long long spins = 0;
+  while (__atomic_load_n(vseq, __ATOMIC_ACQUIRE) != s->seq) {
+    if (++spins > 4000000ull) {            // something is wrong: a real wait on the sensor's stream
+      if (hipStreamSynchronize(s->stream) != hipSuccess || __atomic_load_n(vseq, __ATOMIC_ACQUIRE) != s->seq) return TSD_E_HIP;
+      break;
+    }
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+  return TSD_OK;
+}
+
+int tsd_scan_finish(tsd_sensor* s, tsd_scan_result* result)
+{
+  if (!s || !result || !s->inflight) return TSD_E_ARG;
+  tsd_ctx* ctx = s->ctx;
+  TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  int rc = tsd_scan_wait(s);
+  if (rc != TSD_OK) return set_error(ctx, TSD_E_HIP, "tsd_scan_finish: result record never arrived", hipSuccess);
+  s->inflight = false;
+  {
+    // ORDERED SECTION: the push on the grid stream -- enqueued only now, when the registration has finished, so it
+    // never sits on the grid stream waiting for it while other robots' pushes and ray casts queue up behind (events
+    // order by ENQUEUE time: a push enqueued early would pull every later ray cast of every robot behind its own
+    // registration and serialise the robots; measured: 3.7 k scans/s for any N).  Behind the ray casts ticketed since
+    // the last grid write.
+    std::lock_guard<std::mutex> lk_order(ctx->order_mutex);
+    TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, s->ev_icp_done, 0));
+    if (int rcw = wait_for_readers(ctx)) return rcw;
+    PushArgs pa;
+    std::memset(&pa, 0, sizeof(pa));
+    pa.beams = s->beams;
+    pa.max_range = s->max_range;
+    LaunchTarget tg;
+    tg.rmq = s->d_rmq2[s->rmq_slot];
+    TargetScope scope(ctx, &tg);
+    // the registration moves the sensor by at most the gate (a larger step is rejected: pose unchanged)
+    rc = launch_push(ctx, pa, s->pos[0], s->pos[1], s->conc_gates.reg_trs_max, &s->d_state->push, s->conc_ranges, s->conc_mask_push);
+    if (rc != TSD_OK) return rc;
+    ctx->epoch++;
   }
   copy_icp_result(&s->h_result->icp, &result->icp);
   for (int i = 0; i < 9; i++) result->pose[i] = s->h_result->pose[i];

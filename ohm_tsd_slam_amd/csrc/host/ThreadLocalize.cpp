@@ -43,6 +43,7 @@ ThreadLocalize::ThreadLocalize(obvious::TsdGrid* grid, ThreadMapping* mapper, co
     _initialized(false),
     _synchronous(false),
     _fused(true),
+    _concurrent(false),
     _gridWidth(grid->getCellsX() * grid->getCellSize()),
     _gridHeight(grid->getCellsY() * grid->getCellSize()),
     _gridOffSetX(-(grid->getCellsX() * grid->getCellSize() * 0.5 + xOffset)),
@@ -401,7 +402,9 @@ void ThreadLocalize::processScanFused(ScanReport& rep)
   tsd_gate_params gates = {_trnsMax, _rotMax, TRNS_MIN, ROT_MIN};
   tsd_scan_result sr;
   std::memset(&sr, 0, sizeof(sr));
-  const int rc = _grid.scan(_sensor, maskPush.data(), _icpParams, gates, &sr);
+  // several robots on one grid: split scan, so that the robots' registrations overlap on the device
+  const int rc = _concurrent ? _grid.scanConcurrent(_sensor, maskPush.data(), _icpParams, gates, &sr)
+                             : _grid.scan(_sensor, maskPush.data(), _icpParams, gates, &sr);
   _sensor->getTransformation().getData(rep.pose);
   if(rc != TSD_OK)
   {

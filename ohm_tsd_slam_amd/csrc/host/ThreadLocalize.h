@@ -42,6 +42,9 @@ public:
   /** fused scan path (default): sensor state on the device, gates + push decided there in stream
    *  order (tsd_scan).  Off: tsd_localize, host gates, ThreadMapping::queuePush as in the reference. */
   void setFused(bool on) { _fused = on; }
+  /** this grid is shared with other localisers (SlamNode's multi-robot mode): use the split scan of the fused path
+   *  (tsd_scan_begin / _wait / _finish) so that the robots' registrations overlap on the device */
+  void setConcurrent(bool on) { _concurrent = on; }
   struct ScanReport {
     double pose[9]; double T[9]; double rms; int pairs; int iterations; int icpState;
     int validModel; int validScene; bool regError; bool pushed; bool noModel; bool initialised;
@@ -81,6 +84,7 @@ private:
   bool _initialized;
   bool _synchronous;
   bool _fused;
+  bool _concurrent;
   const double _gridWidth, _gridHeight, _gridOffSetX, _gridOffSetY, _xOffset, _yOffset;
   std::string _robotName, _nameSpace;
   std::string _tfMapFrameId, _tfOdomFrameId, _tfLaserFrameId, _tfFootprintFrameId;

@@ -2,6 +2,7 @@
 // exercise ThreadLocalize / ThreadMapping exactly as SlamNode wires them (SlamNode.cpp:27-129): one
 // TsdGrid, one ThreadMapping, N ThreadLocalize sharing them, laser callbacks per robot.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -136,6 +137,7 @@ int tsd_node_initialize(tsd_node* n, int device)
   {
     l->setSynchronous(n->synchronous);
     l->setFused(n->fused);
+    l->setConcurrent(n->localizers.size() > 1 && !std::getenv("TSD_NO_CONCURRENT"));   // (env: A/B switch for tests / measurements)
   }
   return TSD_OK;
 }

@@ -344,6 +344,18 @@ int TsdGrid::scan(SensorPolar2D* sensor, const uint8_t* maskPush, const tsd_icp_
   return rc;
 }
 
+int TsdGrid::scanConcurrent(SensorPolar2D* sensor, const uint8_t* maskPush, const tsd_icp_params& params,
+                            const tsd_gate_params& gates, tsd_scan_result* result)
+{
+  // both halves run on this robot's thread without the facade's grid mutex: the C ABI orders the robots' ray casts and
+  // pushes internally (ctx->order_mutex) and the sensor's private stream is this thread's alone
+  int rc = tsd_scan_begin(sensor->deviceHandle(), sensor->getRealMeasurementData(), sensor->maskBytes(), maskPush, &params, &gates);
+  if (rc != TSD_OK) return rc;
+  rc = tsd_scan_finish(sensor->deviceHandle(), result);     // waits for the registration (other robots run meanwhile), then the push
+  if (rc == TSD_OK && result->pushed) _initialPushAccomplished = true;
+  return rc;
+}
+
 // --------------------------------------------------------------------------------------- TSD_PDFMatching
 TSD_PDFMatching::TSD_PDFMatching(TsdGrid& grid, unsigned int trials, double epsThresh, unsigned int sizeControlSet, double zrand)
     : _grid(grid), _trials(trials), _sizeControlSet(sizeControlSet), _epsThresh(epsThresh), _zrand(zrand), _seed(-1), _calls(0)

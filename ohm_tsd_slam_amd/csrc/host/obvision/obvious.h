@@ -145,6 +145,11 @@ public:
   virtual int scan(SensorPolar2D* sensor, const uint8_t* maskPush, const tsd_icp_params& params,
                    const tsd_gate_params& gates, tsd_scan_result* result);
 
+  // the same scan in two halves for several robots on this one grid (tsd_scan_begin / _wait / _finish): the mutex is
+  // held for the two enqueue steps only, the wait in between is lock-free, so the robots' registrations overlap
+  virtual int scanConcurrent(SensorPolar2D* sensor, const uint8_t* maskPush, const tsd_icp_params& params,
+                             const tsd_gate_params& gates, tsd_scan_result* result);
+
   tsd_ctx* context() { return _ctx; }
   std::mutex& mutex() { return _mutex; }
 protected:

@@ -1091,6 +1091,7 @@ static int launch_icp_shape_est(tsd_ctx* ctx, const IcpArgs& a, int n, int cap, 
   if (lds > 160u * 1024u) return set_error(ctx, TSD_E_CAPACITY, "registration does not fit the LDS of one CU (point-to-line: model normals too)", hipSuccess);
   {
     // the attribute is per device: remembered per context (and kernel instantiation), not per process
+    std::lock_guard<std::mutex> lk_misc(ctx->misc_mutex);
     size_t& configured = ctx->lds_configured[reinterpret_cast<const void*>(k_icp<R, MAXT, PTL>)];
     if (lds > configured) {
       TSD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_icp<R, MAXT, PTL>),
@@ -1099,10 +1100,12 @@ static int launch_icp_shape_est(tsd_ctx* ctx, const IcpArgs& a, int n, int cap, 
     }
   }
   ScopedKernelTimer t(ctx, "icp");
-  hipExtLaunchKernelGGL((k_icp<R, MAXT, PTL>), dim3(1), dim3(T), lds, ctx->stream, t.a, t.b, 0, a, P_dev, cap, ctx->d_model, ctx->d_scene,
-                     ctx->d_morig, ctx->d_start, ctx->d_coords, ctx->d_mask_m,
+  const LaunchTarget* tg = launch_target();       // concurrent multi-robot path: the sensor's own stream and buffers
+  hipExtLaunchKernelGGL((k_icp<R, MAXT, PTL>), dim3(1), dim3(T), lds, launch_stream(ctx), t.a, t.b, 0, a, P_dev, cap, ctx->d_model, ctx->d_scene,
+                     ctx->d_morig, ctx->d_start, tg && tg->coords ? tg->coords : ctx->d_coords, tg && tg->mask_m ? tg->mask_m : ctx->d_mask_m,
                      d_rays_local ? d_rays_local : ctx->d_rays_local, d_ranges ? d_ranges : ctx->d_ranges,
-                     d_mask ? d_mask : ctx->d_mask, ctx->d_icp_res, ctx->d_icp_trace, post, ctx->d_mnormals, ctx->d_normals);
+                     d_mask ? d_mask : ctx->d_mask, tg && tg->icp_res ? tg->icp_res : ctx->d_icp_res,
+                     tg && tg->trace ? tg->trace : ctx->d_icp_trace, post, ctx->d_mnormals, tg && tg->normals ? tg->normals : ctx->d_normals);
   TSD_HIP_CHECK(ctx, hipGetLastError());
   return TSD_OK;
 }

@@ -813,15 +813,21 @@ int launch_push_tables(tsd_ctx* ctx, hipStream_t stream, int beams, const double
 {
   const size_t bp = (size_t)((beams + 3) & ~3);
   const size_t lds = 2 * bp * sizeof(double) + 4 * bp * 2 + 64;
+  std::lock_guard<std::mutex> lk_misc(ctx->misc_mutex);
   if (lds > ctx->tables_lds_configured) {     // the attribute is per device: remembered per context, not per process
     TSD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_push_tables),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ctx->tables_lds_configured = lds;
   }
-  ctx->rmq_slot ^= 1;                                    // the push that may still be running keeps its tables
-  ctx->d_rmq = ctx->d_rmq2[ctx->rmq_slot];
+  char* rmq;
+  if (launch_target() && launch_target()->rmq) rmq = launch_target()->rmq;       // concurrent multi-robot path: the sensor's own (double) buffer
+  else {
+    ctx->rmq_slot ^= 1;                                  // the push that may still be running keeps its tables
+    ctx->d_rmq = ctx->d_rmq2[ctx->rmq_slot];
+    rmq = ctx->d_rmq;
+  }
   hipLaunchKernelGGL(k_push_tables, dim3(1), dim3(1024), lds, stream, d_ranges ? d_ranges : ctx->d_ranges,
-                     d_mask ? d_mask : ctx->d_mask, beams, ctx->d_rmq, phi_min, ang_res);
+                     d_mask ? d_mask : ctx->d_mask, beams, rmq, phi_min, ang_res);
   TSD_HIP_CHECK(ctx, hipGetLastError());
   return TSD_OK;
 }
@@ -832,6 +838,7 @@ int launch_push(tsd_ctx* ctx, const PushArgs& a, double cx, double cy, double sl
 {
   const GridDev& g = ctx->grid;
   if (!a_dev) return set_error(ctx, TSD_E_ARG, "launch_push: the arguments must be on the device", hipSuccess);
+  char* const rmq = (launch_target() && launch_target()->rmq) ? launch_target()->rmq : ctx->d_rmq;
   if (!d_ranges) d_ranges = ctx->d_ranges;
   if (!d_mask) d_mask = ctx->d_mask;
   // Tile window: a tile passes the range cull of isInRange only if its centre is within
@@ -861,7 +868,7 @@ int launch_push(tsd_ctx* ctx, const PushArgs& a, double cx, double cy, double sl
   const int n_window = ntx * nty;
   {
     ScopedKernelTimer t(ctx, "push_classify");
-    hipExtLaunchKernelGGL(k_push_classify, dim3((n_window + 63) / 64), dim3(64), 0, ctx->stream, t.a, t.b, 0, g, a_dev, ctx->d_rmq,
+    hipExtLaunchKernelGGL(k_push_classify, dim3((n_window + 63) / 64), dim3(64), 0, ctx->stream, t.a, t.b, 0, g, a_dev, rmq,
                        ctx->d_tile_rec, ctx->d_dirty, ctx->d_tile_totals, ctx->d_list, ctx->d_list_win, ctx->d_list_pw, ctx->d_list_cnt, parity,
                        box.x0, box.y0, ntx, nty);
   }
@@ -872,7 +879,7 @@ int launch_push(tsd_ctx* ctx, const PushArgs& a, double cx, double cy, double sl
     const bool fast = a.beams <= FAST_MAX_BEAMS;           // the boundary table shares LDS with the scan
     const size_t lds = 16 + (size_t)((a.beams + 1) & ~1) * sizeof(double) + (size_t)((a.beams + 15) & ~15) +
                        (fast ? ((size_t)a.beams + 1) * sizeof(double2) : 0);
-    const double2* bdir = fast ? rmq_view(ctx->d_rmq, a.beams).bdir : nullptr;
+    const double2* bdir = fast ? rmq_view(rmq, a.beams).bdir : nullptr;
     hipExtLaunchKernelGGL(k_push_update, dim3(n_groups), dim3(UPDATE_BLOCK), lds, ctx->stream, t.a, t.b, 0, g, a_dev, d_ranges, d_mask,
                        ctx->d_tile_rec, ctx->d_tile_totals, ctx->d_list, ctx->d_list_win, ctx->d_list_pw, ctx->d_list_cnt, parity, bdir,
                        ctx->d_icp_trace);

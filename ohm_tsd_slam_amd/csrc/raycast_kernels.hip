@@ -523,8 +523,10 @@ k_raycast(GridDev g, RaycastArgs a_val, const RaycastArgs* __restrict__ a_dev, c
 int launch_raycast(tsd_ctx* ctx, const RaycastArgs& a, const RaycastArgs* a_dev, const double* d_rays)
 {
   ScopedKernelTimer t(ctx, "raycast");
-  hipExtLaunchKernelGGL(k_raycast, dim3(a.beams), dim3(64), 0, ctx->stream, t.a, t.b, 0, ctx->grid, a, a_dev, d_rays ? d_rays : ctx->d_rays,
-                     ctx->d_coords, ctx->d_normals, ctx->d_mask_m, ctx->d_icp_trace);
+  const LaunchTarget* tg = launch_target();       // concurrent multi-robot path: the sensor's own stream and output buffers
+  hipExtLaunchKernelGGL(k_raycast, dim3(a.beams), dim3(64), 0, launch_stream(ctx), t.a, t.b, 0, ctx->grid, a, a_dev, d_rays ? d_rays : ctx->d_rays,
+                     tg && tg->coords ? tg->coords : ctx->d_coords, tg && tg->normals ? tg->normals : ctx->d_normals,
+                     tg && tg->mask_m ? tg->mask_m : ctx->d_mask_m, ctx->d_icp_trace);
   TSD_HIP_CHECK(ctx, hipGetLastError());
   return TSD_OK;
 }

@@ -6,6 +6,7 @@
 #include <string>
 #include <vector>
 #include <map>
+#include <mutex>
 
 #include "tsd_device.hpp"
 #include "../../include/tsd_hip.h"
@@ -97,6 +98,16 @@ struct TileBox {
   }
 };
 
+// Where a ray cast / registration of the concurrent multi-robot path runs and writes (tsd_scan_begin / _finish): the
+// sensor's own stream and output buffers instead of the context's.  Set for the duration of the launches by the entry
+// point (calls on one context are serialised by the caller), nullptr otherwise.
+struct LaunchTarget {
+  hipStream_t stream = nullptr;                                       // ray cast + registration
+  double* coords = nullptr; double* normals = nullptr; uint8_t* mask_m = nullptr;   // ray-cast outputs
+  IcpResultDev* icp_res = nullptr; double* trace = nullptr;
+  char* rmq = nullptr;                                                // range-query tables of the scan's push
+};
+
 struct KernelTimer {
   double total_ms = 0.0;
   int launches = 0;
@@ -106,9 +117,16 @@ struct KernelTimer {
 
 }  // namespace tsd
 
+struct tsd_sensor;
 struct tsd_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  std::mutex order_mutex;                    // the ordered sections of the concurrent multi-robot path and every grid-writing entry point
+  std::mutex misc_mutex;                     // timers / per-kernel attribute cache: touched by launches that run outside the caller's lock
+  unsigned long long ticket = 0;             // order of the ray casts / pushes of the concurrent multi-robot path
+  unsigned long long last_push_ticket = 0;
+  std::vector<tsd_sensor*> sensors;          // device sensors attached to this grid (multi-robot mode, SlamNode.cpp:101-122)
+  hipEvent_t ev_grid = nullptr;              // "every grid write enqueued so far is done" (recorded on `stream` by tsd_scan_begin)
   tsd::GridDev grid{};
   int map_log2 = 0;
   std::string err;
@@ -195,11 +213,36 @@ struct tsd_sensor {
   double pos[2] = {0, 0};          // host mirror of the sensor position (window of the push launches)
   bool rc_pending = false;         // the next scan's ray cast was enqueued behind this scan's push ...
   unsigned long long rc_epoch = 0; // ... when the context was in this state
+
+  // concurrent multi-robot path (tsd_scan_begin / tsd_scan_wait / tsd_scan_finish): ray cast + registration on the
+  // sensor's own stream into its own buffers, created on first use
+  bool conc_ready = false;
+  hipStream_t stream = nullptr;      // ONE stream per sensor: streams are multiplexed onto a few in-order hardware queues
+  hipEvent_t ev_rc_done = nullptr, ev_icp_done = nullptr;
+  bool rc_event_valid = false;     // ev_rc_done has been recorded at least once
+  unsigned long long rc_ticket = 0;            // ticket of the sensor's most recent ray cast ...
+  volatile int rc_recorded = 1;                // ... whose ev_rc_done record has been issued (by the sensor's own thread)
+  double* d_coords = nullptr; double* d_normals = nullptr; uint8_t* d_mask_m = nullptr;
+  tsd::IcpResultDev* d_icp_res = nullptr; double* d_icp_trace = nullptr;
+  char* d_rmq2[2] = {nullptr, nullptr}; int rmq_slot = 0;
+  char* h_stage2[2] = {nullptr, nullptr};   // pinned staging of the scan, alternating
+  bool inflight = false;           // begin() without finish()
+  tsd_gate_params conc_gates{};
+  const double* conc_ranges = nullptr; const uint8_t* conc_mask_push = nullptr;
 };
 
 namespace tsd {
 
 int set_error(tsd_ctx* ctx, int code, const char* what, hipError_t e);
+// launch target of the entry point that is enqueueing on THIS thread (the sensors' private streams are driven by their
+// own threads, outside the caller's grid lock)
+extern thread_local const LaunchTarget* g_launch_target;
+inline const LaunchTarget* launch_target() { return g_launch_target; }
+inline hipStream_t launch_stream(const tsd_ctx* c) { return (g_launch_target && g_launch_target->stream) ? g_launch_target->stream : c->stream; }
+struct TargetScope {
+  TargetScope(tsd_ctx*, const LaunchTarget* t) { g_launch_target = t; }
+  ~TargetScope() { g_launch_target = nullptr; }
+};
 #define TSD_HIP_CHECK(ctx, call)                                                     \
   do {                                                                               \
     hipError_t _e = (call);                                                          \

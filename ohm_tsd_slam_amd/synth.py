@@ -131,6 +131,31 @@ def trajectory(world: World, n: int, step_x=0.06, step_yaw=0.01, yaw0=0.1, leg=N
     return np.stack([world.start[0] + step_x * tri, world.start[1] + 0.0 * k, yaw0 + step_yaw * k], axis=1)
 
 
+def free_lanes(world: World, n: int, length: float, spacing: float = 0.9, clearance: float = 0.9):
+    """Start points of `n` robots in ONE world (the reference's multi-robot mode: N localisers, one grid): robot 0 starts
+    at the world's own start, the others on lanes parallel to x at multiples of `spacing` in y, nearest first, keeping
+    the lanes whose corridor [x0 - 1, x0 + length + 1] x [y - clearance, y + clearance] holds no pillar."""
+    x0, y0 = float(world.start[0]), float(world.start[1])
+    out = [(x0, y0)]
+    k = 1
+    while len(out) < n and k < 200:
+        for sgn in (-1.0, 1.0):
+            y = y0 + sgn * spacing * k
+            if abs(y - world.cy) > world.hy - 2.0 and world.hy > 0:
+                continue
+            ok = True
+            for (cx, cy, r) in world.circles:
+                if (x0 - 1.0 - r) <= cx <= (x0 + length + 1.0 + r) and abs(cy - y) <= clearance + r:
+                    ok = False
+                    break
+            if ok and len(out) < n:
+                out.append((x0, y))
+        k += 1
+    if len(out) < n:
+        raise ValueError("not enough free lanes in this world")
+    return out
+
+
 def scans_for(world: World, geo: ScanGeometry, poses: np.ndarray) -> np.ndarray:
     return np.stack([world.scan(p[0], p[1], p[2], geo) for p in poses])
 

@@ -147,6 +147,8 @@ def lib():
         L.ora_slam_create.restype = C.c_void_p
         L.ora_slam_create.argtypes = [C.POINTER(SlamConfig)]
         L.ora_slam_destroy.argtypes = [C.c_void_p]
+        L.ora_slam_create_shared.restype = C.c_void_p
+        L.ora_slam_create_shared.argtypes = [C.POINTER(SlamConfig), C.c_void_p]
         L.ora_slam_grid.restype = C.c_void_p
         L.ora_slam_grid.argtypes = [C.c_void_p]
         L.ora_slam_process_scan.argtypes = [C.c_void_p, _fp, C.POINTER(ScanResult)]
@@ -430,10 +432,15 @@ def icp_pairs(model_xy, scene_xy, pose, iterations, dist_max, dist_min, bounds, 
 class Slam:
     """ThreadLocalize::init + eventLoop body + synchronous ThreadMapping pushes on the CPU."""
 
-    def __init__(self, **kw):
+    def __init__(self, shared_with=None, **kw):
+        """shared_with: another Slam whose grid this localiser works on (multi-robot mode, SlamNode.cpp:101-122)"""
         self.L = lib()
         self.cfg = SlamConfig(**kw)
-        self.h = self.L.ora_slam_create(C.byref(self.cfg))
+        self._first = shared_with          # (keeps the grid's owner alive)
+        if shared_with is None:
+            self.h = self.L.ora_slam_create(C.byref(self.cfg))
+        else:
+            self.h = self.L.ora_slam_create_shared(C.byref(self.cfg), shared_with.h)
         self.grid = Grid(kw["map_size_log2"], kw["cell_size"], 0.0, handle=self.L.ora_slam_grid(self.h))
 
     def close(self):

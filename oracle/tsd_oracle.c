@@ -1563,6 +1563,7 @@ struct ora_slam {
   /* registration_mode 3: the rand() draws of the next scan's TSD_PDFMatching::match (caller-supplied) */
   int* draws_sub; int* draws_ctrl; int* draws_trials;
   double pre_T[9]; double pre_prob; int pre_idx, pre_i;
+  int owns_grid, skip_init_push;      /* multi-robot mode: several localisers on ONE grid (SlamNode.cpp:101-122) */
 };
 
 ora_slam* ora_slam_create(const ora_slam_config* cfg)
@@ -1571,6 +1572,7 @@ ora_slam* ora_slam_create(const ora_slam_config* cfg)
   s->cfg = *cfg;
   /* SlamNode::initialize (SlamNode.cpp:77-78) */
   s->grid = ora_grid_create(cfg->map_size_log2, cfg->cell_size, (double)cfg->truncation_radius * cfg->cell_size);
+  s->owns_grid = 1;
   s->beams = cfg->beams;
   size_t B = (size_t)cfg->beams;
   s->rays = (double*)malloc(2 * B * sizeof(double));
@@ -1588,13 +1590,23 @@ ora_slam* ora_slam_create(const ora_slam_config* cfg)
 void ora_slam_destroy(ora_slam* s)
 {
   if (!s) return;
-  ora_grid_destroy(s->grid);
+  if (s->owns_grid) ora_grid_destroy(s->grid);
+  free(s->draws_sub); free(s->draws_ctrl); free(s->draws_trials);
   free(s->rays); free(s->rays_local); free(s->data); free(s->mask);
   free(s->model); free(s->normals); free(s->mask_m); free(s->scene); free(s->mask_s);
   free(s);
 }
 
 ora_grid* ora_slam_grid(ora_slam* s) { return s->grid; }
+/* a further localiser on the grid of `first` (SlamNode.cpp:101-122: N ThreadLocalize, one TsdGrid, one ThreadMapping):
+ * its init frees its footprint but does not push (the mapper is initialised by then, ThreadLocalize.cpp:506-507) */
+ora_slam* ora_slam_create_shared(const ora_slam_config* cfg, ora_slam* first)
+{
+  ora_slam* s = ora_slam_create(cfg);
+  ora_grid_destroy(s->grid);
+  s->grid = first->grid; s->owns_grid = 0; s->skip_init_push = 1;
+  return s;
+}
 void ora_slam_set_draws(ora_slam* s, const int* sub, const int* ctrl, const int* trials)
 {
   const size_t B = (size_t)s->beams;
@@ -1650,10 +1662,12 @@ void ora_slam_process_scan(ora_slam* s, const float* ranges_in, ora_scan_result*
     double t[2] = {startX + cfg->footprint_x_offset, startY};
     ora_free_footprint(s->grid, t, cfg->footprint_width, cfg->footprint_height);
     double t0 = now_s();
-    ora_push(s->grid, s->pose, s->data, s->mask, B, s->ang_res, s->phi_min, cfg->max_range,
-             cfg->min_range, cfg->low_refl_range, cfg->threads, &s->last_stats);   /* initPush */
+    if (!s->skip_init_push) {            /* if(!_mapper.initialized()) _mapper.initPush(_sensor) (ThreadLocalize.cpp:506-507) */
+      ora_push(s->grid, s->pose, s->data, s->mask, B, s->ang_res, s->phi_min, cfg->max_range,
+               cfg->min_range, cfg->low_refl_range, cfg->threads, &s->last_stats);   /* initPush */
+      out->pushed = 1;
+    }
     out->t_push = now_s() - t0;
-    out->pushed = 1;
     s->initialized = 1;
     memcpy(out->pose, s->pose, sizeof(s->pose));
     double Id[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};

@@ -167,6 +167,8 @@ typedef struct {
   double t_raycast, t_icp, t_push;  /* seconds */
 } ora_scan_result;
 ora_slam* ora_slam_create(const ora_slam_config* cfg);
+/* a further localiser on the grid of `first` (the reference's multi-robot mode, SlamNode.cpp:101-122) */
+ora_slam* ora_slam_create_shared(const ora_slam_config* cfg, ora_slam* first);
 void      ora_slam_destroy(ora_slam* s);
 ora_grid* ora_slam_grid(ora_slam* s);
 /* first call = ThreadLocalize::init (freeFootprint + initPush), later calls = eventLoop body with a

@@ -139,6 +139,84 @@ def test_facade_multi_robot_shares_one_grid(oracle):
     node.close()
 
 
+def _two_robot_setup(oracle, cfg, n):
+    gc, geo, scene = synth.CONFIGS[cfg]
+    offs = [(0.37, -0.21, 0.1), (-0.7, 0.4, 0.0)]
+    geo_msg = synth.ScanGeometry(geo.beams, float(np.float32(geo.angle_min)), float(np.float32(geo.angle_increment)))
+    worlds, scans = [], []
+    for (ox, oy, yaw) in offs:
+        w = synth.World(scene, gc, start_xy=[0.5 * gc.width + ox, 0.5 * gc.width + oy])
+        worlds.append(w)
+        scans.append(synth.scans_for(w, geo, synth.trajectory(w, n, yaw0=yaw)))
+    so0 = oracle.Slam(**slam_kwargs(gc, geo_msg, local_offset_x=offs[0][0], local_offset_y=offs[0][1], local_offset_yaw=offs[0][2]))
+    so1 = oracle.Slam(shared_with=so0, **slam_kwargs(gc, geo_msg, local_offset_x=offs[1][0], local_offset_y=offs[1][1],
+                                                       local_offset_yaw=offs[1][2]))
+    params = facade.node_params(gc, geo, robot_nbr=2)
+    params.update({"robot_0/name": "georg", "robot_1/name": "simon"})
+    for name, (ox, oy, yaw) in zip(("georg", "simon"), offs):
+        params.update({f"tsd_slam/{name}/local_offset_x": ox, f"tsd_slam/{name}/local_offset_y": oy,
+                       f"tsd_slam/{name}/local_offset_yaw": yaw,
+                       # the ICP keys are per robot in multi-robot mode (ThreadLocalize.cpp:86-88: _robotName + ...)
+                       f"{name}/dist_filter_max": 0.4, f"{name}/dist_filter_min": 0.02, f"{name}/icp_iterations": 30})
+    params = {k: v for k, v in params.items() if not k.startswith("tsd_slam/local_offset")}
+    node = facade.SlamNode(params, synchronous=True)
+    return gc, geo, scans, (so0, so1), node
+
+
+@pytest.mark.parametrize("cfg,n", [("cfg1", 12), ("cfg2", 8)])
+def test_facade_two_robots_one_grid_match_oracle(oracle, cfg, n):
+    """The shared-grid multi-robot loop against the oracle's: two localisers on ONE grid, scans fed in turn
+    (robot 0 scan k, robot 1 scan k, ...).  The facade uses the split scan (tsd_scan_begin / _wait / _finish: ray cast +
+    registration on the sensor's own stream, push on the grid's); fed in turn its results are those of the serial loop."""
+    gc, geo, scans, sos, node = _two_robot_setup(oracle, cfg, n)
+    for k in range(n):
+        for r in (0, 1):
+            ro = sos[r].process_scan(scans[r][k])
+            node.laser(scans[r][k], geo.angle_min, geo.angle_increment, robot=r)
+            rh = node.report(r)
+            d, a = H.pose_delta(np.array(ro.pose[:]).reshape(3, 3), rh["pose"])
+            assert d <= 1e-4 and a <= 1e-4, f"scan {k} robot {r}: {d} m {a} rad"
+            assert bool(ro.pushed) == bool(rh["pushed"]), f"scan {k} robot {r}"
+            if k > 0:
+                assert (ro.pairs, ro.iterations, ro.icp_state) == (rh["pairs"], rh["iterations"], rh["icp_state"]), f"scan {k} robot {r}"
+                assert (ro.valid_model, ro.valid_scene) == (rh["valid_model"], rh["valid_scene"])
+    H.assert_grids_equal(sos[0].grid.dump(), node.grid().download_tiles(), 1e-5)
+    node.close()
+
+
+def test_facade_two_robots_concurrently(oracle):
+    """The same two robots fed from two threads at once (what bench.py --robots does): every scan is processed, both
+    robots keep tracking, the grid stays consistent (properties; the interleaving is the scheduler's, like the reference's)."""
+    import threading
+    n = 40
+    gc, geo, scans, sos, node = _two_robot_setup(oracle, "cfg2", n)
+    for r in (0, 1):
+        node.laser(scans[r][0], geo.angle_min, geo.angle_increment, robot=r)
+    errs = []
+
+    def feed(r):
+        try:
+            for k in range(1, n):
+                node.laser(scans[r][k], geo.angle_min, geo.angle_increment, robot=r)
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+    ts = [threading.Thread(target=feed, args=(r,)) for r in (0, 1)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert not errs, errs
+    node.grid().sync()
+    for r, (ox, oy) in enumerate(((0.37, -0.21), (-0.7, 0.4))):
+        assert node.processed(r) == n
+        P = node.report(r)["pose"]
+        truth_x = 0.5 * gc.width + ox + 0.06 * (n - 1)
+        assert math.hypot(P[0, 2] - truth_x, P[1, 2] - (0.5 * gc.width + oy)) < 0.15, (r, P)
+    init, iw, tsd, w = node.grid().download_tiles()
+    sel = init.astype(bool)
+    assert sel.sum() > 500 and np.all(w[sel] >= 0.0) and np.all(w[sel] <= 32.0)
+    t = tsd[sel]; m = ~np.isnan(t)
+    assert np.all(t[m] <= 1.0) and np.all(t[m] >= -1.0)
+    node.close()
+
+
 @pytest.mark.parametrize("fused", [True, False])
 def test_facade_point_to_line_estimator_tracks(oracle, fused):
     """`icp_estimator` = 1 (an addition: the reference node has no such key) runs the loop with
