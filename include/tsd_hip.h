@@ -35,6 +35,7 @@ extern "C" {
 #define TSD_MAX_BEAMS    4096 /* scan staged in LDS by the push kernel */
 #define TSD_MAX_ICP_POINTS 2048 /* model/scene resident in LDS in the ICP kernel */
 #define TSD_ICP_TRACE_MAX 256  /* iterations recorded by tsd_icp_trace */
+#define TSD_ICP_TRACE_STRIDE 8 /* doubles per recorded iteration */
 
 /* EnumIcpState (obvision/registration/icp/Icp.h:25-32) */
 #define TSD_ICP_PROCESSING     1
@@ -245,8 +246,9 @@ int tsd_scan_wait(tsd_sensor* s);
 int tsd_scan_finish(tsd_sensor* s, tsd_scan_result* result);
 
 /* Per-iteration record of the most recent tsd_icp / tsd_localize on this ctx (the role of
- * Icp::activateTrace, Icp.cpp:60-70): out[4*i + {0,1,2,3}] = pairs, rms, DistanceFilter threshold
- * before the step, state after loop control, for i < min(iterations, max_iters). */
+ * Icp::activateTrace, Icp.cpp:60-70): out[TSD_ICP_TRACE_STRIDE * i + {0..7}] = pairs, rms, DistanceFilter threshold
+ * before the step, state after loop control, and the step's Tlast = [[c, -s, tx], [s, c, ty]] as c, s, tx, ty (NaN
+ * when the step had too few pairs to estimate), for i < min(iterations, max_iters). */
 int tsd_icp_trace(tsd_ctx* ctx, double* out, int max_iters);
 
 /* ---- map I/O --------------------------------------------------------------------------------- */

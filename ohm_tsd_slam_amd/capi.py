@@ -350,7 +350,8 @@ class TsdGridDevice:
         return IcpOut(np.array(r.T[:]).reshape(3, 3), r.rms, r.pairs, r.iterations, r.state, r.n_model, r.n_scene)
 
     def icp_trace(self, iterations):
-        tr = np.zeros((max(iterations, 1), 4))
+        """per iteration: pairs, rms, DistanceFilter threshold before the step, state, Tlast as (c, s, tx, ty)"""
+        tr = np.zeros((max(iterations, 1), 8))
         self._check(self.lib.tsd_icp_trace(self.h, _d(tr), iterations), "tsd_icp_trace")
         return tr[:iterations]
 

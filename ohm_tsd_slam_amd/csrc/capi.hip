@@ -337,7 +337,7 @@ tsd_ctx* tsd_create(int device, int map_size_log2, double cell_size, double max_
   A(hipMalloc(&ctx->d_start, TSD_MAX_ICP_POINTS * sizeof(int)));
   if (const char* e = std::getenv("TSD_ICP_SHAPE")) ctx->icp_shape = std::atoi(e);
   A(hipMalloc(&ctx->d_icp_res, sizeof(IcpResultDev)));
-  A(hipMalloc(&ctx->d_icp_trace, sizeof(double) * 4 * TSD_ICP_TRACE_MAX));
+  A(hipMalloc(&ctx->d_icp_trace, sizeof(double) * TSD_ICP_TRACE_STRIDE * TSD_ICP_TRACE_MAX));
   A(hipHostMalloc(&ctx->h_icp_res, sizeof(IcpResultDev), hipHostMallocDefault));
   ctx->h_out_bytes = (size_t)TSD_MAX_BEAMS * (8 * 4 + 1) + 256;
   A(hipHostMalloc(&ctx->h_out, ctx->h_out_bytes, hipHostMallocDefault));
@@ -657,7 +657,7 @@ int tsd_icp_trace(tsd_ctx* ctx, double* out, int max_iters)
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   const int n = max_iters < TSD_ICP_TRACE_MAX ? max_iters : TSD_ICP_TRACE_MAX;
-  TSD_HIP_CHECK(ctx, hipMemcpy(out, ctx->d_icp_trace, sizeof(double) * 4 * (size_t)n, hipMemcpyDeviceToHost));
+  TSD_HIP_CHECK(ctx, hipMemcpy(out, ctx->d_icp_trace, sizeof(double) * TSD_ICP_TRACE_STRIDE * (size_t)n, hipMemcpyDeviceToHost));
   return TSD_OK;
 }
 
@@ -1213,7 +1213,7 @@ static int sensor_conc_init(tsd_sensor* s)
   A(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   for (hipEvent_t* e : {&s->ev_rc_done, &s->ev_icp_done}) A(hipEventCreateWithFlags(e, hipEventDisableTiming));
   A(hipMalloc(&s->d_coords, nb * 16)); A(hipMalloc(&s->d_normals, nb * 16)); A(hipMalloc(&s->d_mask_m, nb));
-  A(hipMalloc(&s->d_icp_res, sizeof(IcpResultDev))); A(hipMalloc(&s->d_icp_trace, sizeof(double) * 4 * TSD_ICP_TRACE_MAX));
+  A(hipMalloc(&s->d_icp_res, sizeof(IcpResultDev))); A(hipMalloc(&s->d_icp_trace, sizeof(double) * TSD_ICP_TRACE_STRIDE * TSD_ICP_TRACE_MAX));
   A(hipMalloc(&s->d_rmq2[0], push_rmq_bytes(s->beams))); A(hipMalloc(&s->d_rmq2[1], push_rmq_bytes(s->beams)));
   A(hipHostMalloc(&s->h_stage2[0], nb * 10 + 64, hipHostMallocDefault)); A(hipHostMalloc(&s->h_stage2[1], nb * 10 + 64, hipHostMallocDefault));
   if (!ok) return set_error(ctx, TSD_E_HIP, "tsd_scan_begin: per-sensor streams / buffers", hipGetLastError());

@@ -446,7 +446,7 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
       const double* __restrict__ g_coords, const uint8_t* __restrict__ g_mask_m,
       const double* __restrict__ g_rays_local, const double* __restrict__ g_ranges,
       const uint8_t* __restrict__ g_mask, IcpResultDev* __restrict__ out,
-      double* __restrict__ trace /* [TSD_ICP_TRACE_MAX][4] = pairs, rms, thr_before, state */, ScanPostArgs post,
+      double* __restrict__ trace /* [TSD_ICP_TRACE_MAX][TSD_ICP_TRACE_STRIDE] = pairs, rms, thr_before, state, Tlast (co, si, dX, dY) */, ScanPostArgs post,
       const double* __restrict__ g_mnormals /* direct mode */, const double* __restrict__ g_normals /* fused: ray cast */)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -959,8 +959,8 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
     if (tid == 0) L.ired[IR_CNT] = 0;
     STAMP(3);
 
+    double co = __builtin_nan(""), si = __builtin_nan(""), dX = __builtin_nan(""), dY = __builtin_nan("");   // Tlast of this step (trace)
     if (pairs > 2) {
-      double co, si, dX, dY;
       if constexpr (PTL) {
         // PointToLine2DEstimator: Matrix::solve = gsl_linalg_LU_decomp + LU_solve (gsl/Matrix.cpp:343-355);
         // psi = x[0] (cos, sin by libm like the reference), t = (x[1], x[2]); "rms" = mean |n.(p - q)|
@@ -1035,8 +1035,9 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
     rms_prev = rms;
     STAMP(5);
     if (tid == 0 && iter <= TSD_ICP_TRACE_MAX) {
-      double* tr = L.tail->trace + 4 * (iter - 1);
+      double* tr = L.tail->trace + TSD_ICP_TRACE_STRIDE * (iter - 1);
       tr[0] = (double)pairs; tr[1] = rms; tr[2] = thr_before; tr[3] = (double)state;
+      tr[4] = co; tr[5] = si; tr[6] = dX; tr[7] = dY;          // Tlast = [[co, -si, dX], [si, co, dY]] (NaN: no estimate this step)
 #ifdef TSD_ICP_STAMPS
       tr[2] = (double)st_acc[1];        // cumulative phase-A cycles      (diagnostic build only)
       tr[1] = (double)L.ired[IR_DBG];   // cumulative searched points
@@ -1050,7 +1051,7 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
   if (tid == 0) {
     st_acc[7] = L.ired[IR_DBG + 1];     // setup cycles / wave searches
     printf("ICPDBG wave searches %d walk steps %d sweeps %d tier2 cycles %d inline pts %d\n", L.ired[IR_DBG + 1], L.ired[IR_DBG + 3], L.ired[IR_DBG + 4], L.ired[IR_DBG + 5] << 4, L.ired[IR_DBG + 2]);
-    for (int i = 0; i < 8; i++) L.tail->trace[4 * TSD_ICP_TRACE_MAX - 8 + i] = (double)st_acc[i];
+    for (int i = 0; i < 8; i++) L.tail->trace[TSD_ICP_TRACE_STRIDE * TSD_ICP_TRACE_MAX - 8 + i] = (double)st_acc[i];
   }
 #endif
   {

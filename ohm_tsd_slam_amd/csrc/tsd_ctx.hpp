@@ -174,7 +174,7 @@ struct tsd_ctx {
   int* d_start = nullptr;        // [TSD_MAX_ICP_POINTS] first search slot of every scene point
   int icp_shape = 0;             // 0 = default workgroup shape (env TSD_ICP_SHAPE for experiments)
   tsd::IcpResultDev* d_icp_res = nullptr;
-  double* d_icp_trace = nullptr;            // [TSD_ICP_TRACE_MAX][4]
+  double* d_icp_trace = nullptr;            // [TSD_ICP_TRACE_MAX][TSD_ICP_TRACE_STRIDE]
   tsd::IcpResultDev* h_icp_res = nullptr;    // pinned
   char* h_out = nullptr;                     // pinned D2H staging (ray-cast outputs)
   size_t h_out_bytes = 0;

@@ -142,6 +142,8 @@ def lib():
         L.ora_grid_color_image.restype = None
         L.ora_grid_store_text.argtypes = [C.c_void_p, C.c_char_p]
         L.ora_grid_store_text.restype = C.c_int
+        L.ora_text_lines.argtypes = [C.c_char_p, _ip, C.c_int, _dp]
+        L.ora_text_lines.restype = C.c_int
         L.ora_grid_load_text.argtypes = [C.c_char_p]
         L.ora_grid_load_text.restype = C.c_void_p
         L.ora_slam_create.restype = C.c_void_p
@@ -189,6 +191,8 @@ def ref():
         R.ref_norm2.argtypes = [_dp]
         R.ref_deg2rad.argtypes = [C.c_double]
         R.ref_deg2rad.restype = C.c_double
+        R.ref_text_lines.argtypes = [C.c_char_p, _ip, C.c_int, _dp]
+        R.ref_text_lines.restype = None
         _ref = R
     return _ref
 
@@ -377,7 +381,7 @@ def icp(model_xy, scene_xy, pose, iterations, dist_max, dist_min, bounds, nn_mod
     pose = f64(pose).reshape(9)
     p = IcpParams(iterations, dist_max, dist_min, bounds[0], bounds[1], bounds[2], bounds[3], nn_mode)
     r = IcpResult()
-    tr = np.zeros((max(iterations, 1), 4)) if trace else None
+    tr = np.zeros((max(iterations, 1), 8)) if trace else None       # pairs, rms, thr, state, Tlast (c, s, tx, ty)
     if model_normals_xy is None:
         lib().ora_icp(d(m), m.size // 2, d(s), s.size // 2, d(pose), C.byref(p), C.byref(r), d(tr) if trace else None)
     else:

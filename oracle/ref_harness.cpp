@@ -5,6 +5,7 @@
  *     /root/reference/src/obvision/registration/icp/assign/filter/DistanceFilter.cpp
  *     /root/reference/src/obvision/registration/icp/assign/filter/ReciprocalFilter.cpp
  *     /root/reference/src/obcore/math/mathbase.h            (header-only templates)
+ *     /root/reference/src/obcore/base/tools.cpp             (getDoubleLine / getIntLine of the grid text format)
  * They are compiled where they lie (oracle/Makefile target `_ref`), never copied; the output
  * oracle/_ref/libtsd_ref.so is git-ignored.  Everything else on the hot path needs GSL / FLANN
  * (absent here, and stand-ins are not allowed), so only the ICP post-assignment chain
@@ -18,6 +19,9 @@
 #include "obvision/registration/icp/assign/filter/DistanceFilter.h"
 #include "obvision/registration/icp/assign/filter/ReciprocalFilter.h"
 #include "obcore/math/mathbase.h"
+#include "obcore/base/tools.h"
+
+#include <sstream>
 
 #include <cmath>
 #include <cstring>
@@ -139,3 +143,12 @@ void   ref_norm2(double* n) { obvious::norm2<double>(n); }
 double ref_deg2rad(double d) { return obvious::deg2rad(d); }
 
 } // extern "C"
+
+/* obvious::getDoubleLine / getIntLine (obcore/base/tools.cpp:190-215), the line readers of TsdGrid's file constructor
+ * (TsdGrid.cpp:25-110): `text` is read line by line, line i as a double (kinds[i] == 0) or as an int (1). */
+extern "C" void ref_text_lines(const char* text, const int* kinds, int n, double* out)
+{
+  std::istringstream in(text);
+  for(int i = 0; i < n; i++)
+    out[i] = kinds[i] ? (double)obvious::getIntLine(in) : obvious::getDoubleLine(in);
+}

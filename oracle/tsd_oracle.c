@@ -435,6 +435,17 @@ static int text_int_line(FILE* f)
   return atoi(line);
 }
 
+/* the two line readers on a file, line i as a double (kinds[i] == 0) or an int (1): pinned against the compiled
+ * obcore/base/tools.cpp in oracle/_ref (tests/test_cpu_oracle_ref.py) */
+int ora_text_lines(const char* path, const int* kinds, int n, double* out)
+{
+  FILE* f = fopen(path, "r");
+  if (!f) return 0;
+  for (int i = 0; i < n; i++) out[i] = kinds[i] ? (double)text_int_line(f) : text_double_line(f);
+  fclose(f);
+  return 1;
+}
+
 /* TsdGrid(const std::string&, FILE_SOURCE) (TsdGrid.cpp:25-110): a new grid from such a file.  A content tile is
  * init()-ed (halo included) and its interior overwritten; the halo keeps the init value until the next push. */
 ora_grid* ora_grid_load_text(const char* path)
@@ -1087,6 +1098,7 @@ static void icp_impl(const double* model, const double* normals, int n_model, co
     const double thr_before = c.thr;
     /* ---- step ---- */
     pairs = determine_pairs(&c, sc, n_scene);
+    double tl_co = NAN, tl_si = NAN, tl_dx = NAN, tl_dy = NAN;        /* Tlast of this step (trace) */
     if (pairs > 2) {
       double co, si, dX, dY;
       if (normals) {
@@ -1144,6 +1156,7 @@ static void icp_impl(const double* model, const double* normals, int n_model, co
       dY = (cm[1] - (co * cs_[1] + si * cs_[0]));
       }
       double Tl[16] = {co, -si, 0, dX, si, co, 0, dY, 0, 0, 1, 0, 0, 0, 0, 1};
+      tl_co = co; tl_si = si; tl_dx = dX; tl_dy = dY;
       /* applyTransformation: Matrix::multiply(R, data) = data * R^T via dgemm(NoTrans,Trans)
        * (gsl/Matrix.cpp:489-497), then translation */
       for (int i = 0; i < n_scene; i++) {
@@ -1173,8 +1186,9 @@ static void icp_impl(const double* model, const double* normals, int n_model, co
     else if (iter >= max_it) state = MAXITERATIONS;
     rms_prev = rms;
     if (trace) {
-      trace[4 * (iter - 1) + 0] = (double)pairs; trace[4 * (iter - 1) + 1] = rms;
-      trace[4 * (iter - 1) + 2] = thr_before; trace[4 * (iter - 1) + 3] = (double)state;
+      double* tr = trace + 8 * (iter - 1);       /* layout of include/tsd_hip.h: tsd_icp_trace */
+      tr[0] = (double)pairs; tr[1] = rms; tr[2] = thr_before; tr[3] = (double)state;
+      tr[4] = tl_co; tr[5] = tl_si; tr[6] = tl_dx; tr[7] = tl_dy;
     }
   }
   /* getFinalTransformation (Icp.cpp:528-546) */

@@ -100,6 +100,8 @@ void      ora_grid_dump(const ora_grid* g, uint8_t* initialized, double* init_we
                         double* tsd, double* weight);
 void      ora_grid_load(ora_grid* g, const uint8_t* initialized, const double* init_weight,
                         const double* tsd, const double* weight);
+/* getDoubleLine / getIntLine of the grid text format (obcore/base/tools.cpp:190-215) applied to the lines of a file */
+int       ora_text_lines(const char* path, const int* kinds, int n, double* out);
 /* digest of that dump by the rule of include/tsd_hip.h (tsd_grid_digest) */
 void      ora_grid_digest(const ora_grid* g, uint64_t* hash, int64_t* cells_valid, int32_t* tiles_initialized,
                           double* sum_tsd, double* sum_weight);

@@ -78,9 +78,72 @@ def trajectory():
                         cell_size=gc.cell_size, scans=scans, rows=np.array(rows), init=init, grid_summary=summary)
 
 
+DIGEST_KEYS = ("hash", "cells_valid", "tiles_initialized", "sum_tsd", "sum_weight")
+
+
+def baseline_configs():
+    """SURVEY 8(c) "golden vectors to commit": for BASELINE configs 1-3 (and cfg3 / comb) per push the work counters and
+    the digest of the whole grid (64-bit hash of the canonical dump, valid cells, sum tsd, sum weight: tsd_grid_digest /
+    ora_grid_digest), a ray cast, a registration with its per-iteration (pairs, rms, threshold, state, Tlast), and a
+    short closed loop (per-scan pose, pairs, pushed) -- everything the GPU box needs to check the HIP path at FULL size
+    without the oracle.  Inputs are the raw float32 scans (the ingest is part of what is pinned)."""
+    out = {}
+    threads = min(8, os.cpu_count() or 1)
+    for tag, cfg, scene, n_push in (("cfg1", "cfg1", "room", 4), ("cfg2", "cfg2", "pillars", 4), ("cfg3", "cfg3", "pillars", 3),
+                                    ("cfg3comb", "cfg3", "comb", 3)):
+        gc, geo, _ = synth.CONFIGS[cfg]
+        world = synth.World(scene, gc)
+        g = O.Grid(gc.map_size_log2, gc.cell_size, gc.max_trunc)
+        poses, scans, stats, digs = [], [], [], []
+        for k in range(n_push):
+            pose, (x, y, yaw) = H.sensor_pose(world, 5 * k)
+            r = world.scan(x, y, yaw, geo)
+            data, mask = O.ingest_f32(r, H.MAX_RANGE, geo.angle_increment)
+            st = g.push(pose, data, mask, geo.angle_increment, geo.angle_min, H.MAX_RANGE, H.MIN_RANGE, H.LOW_REFL, threads=threads)
+            d = g.digest()
+            poses.append(pose); scans.append(r); stats.append([st[k_] for k_ in sorted(st)])
+            digs.append([np.uint64(d["hash"]), d["cells_valid"], d["tiles_initialized"]]); out[f"{tag}_sums_{k}"] = np.array([d["sum_tsd"], d["sum_weight"]])
+        out[f"{tag}_push_poses"] = np.array(poses); out[f"{tag}_push_scans"] = np.array(scans)
+        out[f"{tag}_push_stats"] = np.array(stats); out[f"{tag}_stat_names"] = np.array(sorted(st))
+        out[f"{tag}_digest_hash"] = np.array([d[0] for d in digs], dtype=np.uint64)
+        out[f"{tag}_digest_counts"] = np.array([[d[1], d[2]] for d in digs], dtype=np.int64)
+        # ray cast + registration from a pose between the pushes
+        pose, (x, y, yaw) = H.sensor_pose(world, 7)
+        rl, rw = H.world_rays(O, geo, pose, gc.cell_size)
+        co, no, mo, cnt = g.raycast(pose, rw, H.MIN_RANGE, H.MAX_RANGE, threads=threads)
+        out[f"{tag}_rc_pose"] = pose; out[f"{tag}_rc_rays_world"] = rw; out[f"{tag}_rc_rays_local"] = rl
+        out[f"{tag}_rc_mask"] = mo; out[f"{tag}_rc_coords"] = co; out[f"{tag}_rc_normals"] = no
+        if scene != "comb":
+            r32 = world.scan(x + 0.04, y - 0.02, yaw + 0.01, geo)
+            data, mask = O.ingest_f32(r32, H.MAX_RANGE, geo.angle_increment)
+            sc, ms, _ = O.scene_from_scan(rl, data, mask)
+            M = co.reshape(-1, 2)[mo.astype(bool)]
+            S = sc.reshape(-1, 2)[ms.astype(bool)]
+            icp = O.icp(M, S, pose, 30, 0.4, 0.02, (0.0, g.max_x, 0.0, g.max_x), nn_mode=1, trace=True)
+            out[f"{tag}_icp_scan"] = r32; out[f"{tag}_icp_T"] = icp["T"]; out[f"{tag}_icp_trace"] = icp["trace"]
+            out[f"{tag}_icp_counts"] = np.array([icp["pairs"], icp["iterations"], icp["state"], len(M), len(S)])
+            # closed loop through the SLAM loop (a LaserScan carries angle_min / angle_increment as float32)
+            geo_msg = synth.ScanGeometry(geo.beams, float(np.float32(geo.angle_min)), float(np.float32(geo.angle_increment)))
+            n = 8
+            tposes = synth.trajectory(world, n)
+            tscans = synth.scans_for(world, geo, tposes)
+            slam = O.Slam(**slam_kwargs(gc, geo_msg, nn_mode=1, threads=threads))
+            rows = []
+            for k in range(n):
+                rr = slam.process_scan(tscans[k])
+                rows.append(list(rr.pose[:]) + [rr.pairs, rr.iterations, rr.icp_state, rr.valid_model, rr.valid_scene, rr.pushed, rr.reg_error, rr.rms])
+            dd = slam.grid.digest()
+            out[f"{tag}_traj_scans"] = tscans; out[f"{tag}_traj_rows"] = np.array(rows)
+            out[f"{tag}_traj_grid"] = np.array([dd["cells_valid"], dd["tiles_initialized"], dd["sum_tsd"], dd["sum_weight"]])
+            slam.close()
+        g.close()
+    np.savez_compressed(os.path.join(HERE, "oracle_baseline_configs.npz"), **out)
+
+
 if __name__ == "__main__":
     O.build()
     push_raycast_icp()
     trajectory()
-    for f in ("oracle_push_raycast_icp.npz", "oracle_trajectory.npz"):
+    baseline_configs()
+    for f in ("oracle_push_raycast_icp.npz", "oracle_trajectory.npz", "oracle_baseline_configs.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

@@ -292,3 +292,156 @@ def test_occupancy_values_and_persistence():
     assert set(np.unique(out)) <= {-1, 0, 100} and n > 50
     assert (out == 100).sum() > 50 and (out == 0).sum() > 500
     assert set(np.unique(content)) <= {-1, 0}           # the 100 marks never enter the persistent map
+
+
+# ------------------------------------------------------------------------------------------------
+# independent second derivations (numpy / plain Python from SURVEY Appendix A, written against the canonical 33 x 33
+# dump, not against oracle/tsd_oracle.c): ray march and both estimators, as the push already has one above
+def _np_bilinear(gc, dump, x, y):
+    """TsdGrid::interpolateBilinear + coord2Cell (Appendix A.5) -> (status, tsd); status 0 success, 1 invalid index,
+    2 empty partition, 3 nan"""
+    init, _, tsd, _ = dump
+    cs, N, PX = gc.cell_size, gc.cells, gc.cells // 32
+    inv = 1.0 / cs
+    xi, yi = math.floor(x * inv), math.floor(y * inv)
+    dx, dy = (xi + 0.5) * cs, (yi + 0.5) * cs
+    if x < dx:
+        xi -= 1; dx -= cs
+    if y < dy:
+        yi -= 1; dy -= cs
+    if xi >= N or xi < 0 or yi >= N or yi < 0:
+        return 1, 0.0
+    p = (yi // 32) * PX + xi // 32
+    if not init[p]:
+        return 2, 0.0
+    lx, ly = xi % 32, yi % 32
+    wx, wy = abs((x - dx) * inv), abs((y - dy) * inv)
+    t = tsd[p].reshape(33, 33)
+    v = t[ly, lx] * (1. - wy) * (1. - wx) + t[ly + 1, lx] * wy * (1. - wx) + t[ly, lx + 1] * (1. - wy) * wx + t[ly + 1, lx + 1] * wy * wx
+    return (3, v) if math.isnan(v) else (0, float(v))
+
+
+def _np_raycast_beam(gc, dump, tr, ray, min_range, max_range):
+    """RayCastPolar2D::rayCastFromCurrentView (Appendix A.5) for one beam -> (hit, cx, cy)"""
+    cs, N = gc.cell_size, gc.cells
+    maxc = (N + 0.5) * cs
+    inside = 0 < tr[0] < maxc and 0 < tr[1] < maxc
+    gmin, gmax = (-10e9, 10e9) if inside else (10e9, -10e9)
+    lim = (N - 1) * cs
+    xmin = (((0.0 if ray[0] > 0 else lim) - tr[0]) / ray[0]) if abs(ray[0]) > 10e-6 else gmin
+    ymin = (((0.0 if ray[1] > 0 else lim) - tr[1]) / ray[1]) if abs(ray[1]) > 10e-6 else gmin
+    xmax = (((lim if ray[0] > 0 else 0.0) - tr[0]) / ray[0]) if abs(ray[0]) > 10e-6 else gmax
+    ymax = (((lim if ray[1] > 0 else 0.0) - tr[1]) / ray[1]) if abs(ray[1]) > 10e-6 else gmax
+    imin = max(max(xmin, ymin), 0.0)
+    imax = min(xmax, ymax)
+    imin = max(imin, min_range / cs)
+    imax = min(imax, max_range / cs)
+    if imin >= imax:
+        return False, 0.0, 0.0
+    i = imin
+    while i < imax:                                  # coarse skip over empty / outside partitions, 32 cells at a time
+        st, _ = _np_bilinear(gc, dump, tr[0] + i * ray[0], tr[1] + i * ray[1])
+        if st not in (2, 1):
+            break
+        imin = i
+        i += 32.0
+    px, py = tr[0] + imin * ray[0], tr[1] + imin * ray[1]
+    st, v = _np_bilinear(gc, dump, px, py)
+    prev = v if st == 0 else float("nan")
+    i = imin
+    while i <= imax:
+        px += ray[0]; py += ray[1]                   # repeated addition
+        st, v = _np_bilinear(gc, dump, px, py)
+        if st != 0:
+            prev = float("nan")
+        else:
+            if prev > 0 and v < 0:
+                interp = prev / (prev - v)
+                return True, px + ray[0] * (interp - 1.0), py + ray[1] * (interp - 1.0)
+            if prev < 0 and v > 0:
+                return False, 0.0, 0.0
+            prev = v
+        i += 1.0
+    return False, 0.0, 0.0
+
+
+def test_raycast_against_python_rederivation():
+    gc = synth.GridConfig(8, 0.1)
+    geo = synth.ScanGeometry(181, math.radians(-90.0), math.radians(1.0))
+    world = synth.World("room", gc)
+    g = O.Grid(gc.map_size_log2, gc.cell_size, gc.max_trunc)
+    for k in range(3):
+        pose, (x, y, yaw) = H.sensor_pose(world, 4 * k)
+        data, mask = O.ingest_f32(world.scan(x, y, yaw, geo), 30.0, geo.angle_increment)
+        g.push(pose, data, mask, geo.angle_increment, geo.angle_min, 30.0, 0.001, 2.0)
+    dump = g.dump()
+    pose, _ = H.sensor_pose(world, 5)
+    rl, rw = H.world_rays(O, geo, pose, gc.cell_size)
+    co, no, mo, cnt = g.raycast(pose, rw, 0.001, 30.0)
+    Pi = np.linalg.inv(pose)
+    hits = 0
+    for b in range(geo.beams):
+        hit, cx, cy = _np_raycast_beam(gc, dump, (pose[0, 2], pose[1, 2]), (rw[b], rw[geo.beams + b]), 0.001, 30.0)
+        if hit:
+            # interpolateNormal (4 look-ups at +-cellSize, all must succeed) decides whether the hit is reported
+            vals = [_np_bilinear(gc, dump, cx + dx, cy + dy) for dx, dy in ((gc.cell_size, 0), (-gc.cell_size, 0), (0, gc.cell_size), (0, -gc.cell_size))]
+            if any(st != 0 for st, _ in vals):
+                hit = False
+            else:
+                n = np.array([vals[0][1] - vals[1][1], vals[2][1] - vals[3][1]])
+                ln = math.sqrt(n[0] * n[0] + n[1] * n[1])
+                if abs(ln) > 10e-6:
+                    n = n / ln
+        assert bool(mo[b]) == hit, f"beam {b}"
+        if hit:
+            hits += 1
+            m = Pi @ np.array([cx, cy, 1.0])
+            nn = Pi[:2, :2] @ n
+            assert abs(m[0] - co[2 * b]) <= 1e-12 and abs(m[1] - co[2 * b + 1]) <= 1e-12, f"beam {b}"
+            assert abs(nn[0] - no[2 * b]) <= 1e-12 and abs(nn[1] - no[2 * b + 1]) <= 1e-12, f"beam {b}"
+    assert hits == cnt and hits > 0.8 * geo.beams
+
+
+def test_estimators_against_numpy_rederivation():
+    """Both estimators from the pair list of a step (ora_icp_pairs) by numpy: ClosedFormEstimator2D (Appendix A.6) and
+    PointToLine2DEstimator (normal equations by np.linalg.solve), against Tlast of the oracle's first iteration (trace)."""
+    gc = synth.GridConfig(9, 0.05)
+    geo = synth.ScanGeometry.full_circle_360()
+    world = synth.World("room", gc)
+    g = O.Grid(gc.map_size_log2, gc.cell_size, gc.max_trunc)
+    for k in range(3):
+        pose, (x, y, yaw) = H.sensor_pose(world, k)
+        data, mask = O.ingest_f32(world.scan(x, y, yaw, geo), 30.0, geo.angle_increment)
+        g.push(pose, data, mask, geo.angle_increment, geo.angle_min, 30.0, 0.001, 2.0)
+    pose, (x, y, yaw) = H.sensor_pose(world, 1)
+    rl, rw = H.world_rays(O, geo, pose, gc.cell_size)
+    co, no, mo, cnt = g.raycast(pose, rw, 0.001, 30.0)
+    data, mask = O.ingest_f32(world.scan(x + 0.05, y - 0.03, yaw + 0.012, geo), 30.0, geo.angle_increment)
+    sc, ms, _ = O.scene_from_scan(rl, data, mask)
+    M = co.reshape(-1, 2)[mo.astype(bool)]; Nn = no.reshape(-1, 2)[mo.astype(bool)]
+    S = sc.reshape(-1, 2)[ms.astype(bool)]
+    b = (0.0, g.max_x, 0.0, g.max_x)
+    pm, ps, _ = O.icp_pairs(M, S, pose, 30, 0.4, 0.02, b, 0.4 ** 2)
+    assert len(pm) > 100
+    m, s = M[pm], S[ps]
+    # closed form
+    cm, csn = m.mean(0), s.mean(0)
+    mse = np.mean(np.sum((s - m) ** 2, 1))
+    mc, scn = m - cm, s - csn
+    th = math.atan2(np.sum(mc[:, 1] * scn[:, 0] - mc[:, 0] * scn[:, 1]), np.sum(mc[:, 0] * scn[:, 0] + mc[:, 1] * scn[:, 1]))
+    c, si = math.cos(th), math.sin(th)
+    t = cm - np.array([c * csn[0] - si * csn[1], c * csn[1] + si * csn[0]])
+    r = O.icp(M, S, pose, 30, 0.4, 0.02, b, trace=True)
+    tl = r["trace"][0]
+    assert int(tl[0]) == len(pm) and abs(tl[1] - mse) <= 1e-15
+    assert np.max(np.abs(tl[4:8] - np.array([c, si, t[0], t[1]]))) <= 1e-13
+    # point to line: A x = b over (a_z, n_x, n_y), x = (psi, tx, ty); rms = mean |n.(s - m)|
+    n = Nn[pm]
+    az = s[:, 0] * n[:, 1] - s[:, 1] * n[:, 0]
+    J = np.stack([az, n[:, 0], n[:, 1]], 1)
+    resid = np.sum((s - m) * n, 1)
+    xsol = np.linalg.solve(J.T @ J, -(J.T @ resid))
+    rp = O.icp(M, S, pose, 30, 0.4, 0.02, b, model_normals_xy=Nn, trace=True)
+    tlp = rp["trace"][0]
+    assert int(tlp[0]) == len(pm) and abs(tlp[1] - np.mean(np.abs(resid))) <= 1e-15
+    assert np.max(np.abs(tlp[4:8] - np.array([math.cos(xsol[0]), math.sin(xsol[0]), xsol[1], xsol[2]]))) <= 1e-11

@@ -139,3 +139,22 @@ def test_golden_chain_fixture():
         for k in range(calls):
             assert np.array_equal(z[f"pm_{case}_{k}"], ora[k][0]), (case, k)
             assert np.array_equal(z[f"ps_{case}_{k}"], ora[k][1]), (case, k)
+
+
+def test_text_line_readers_match_compiled_reference(tmp_path):
+    """getDoubleLine / getIntLine (obcore/base/tools.cpp:190-215, compiled from the reference in oracle/_ref) against the
+    oracle's restatement: the readers of TsdGrid's text file constructor (row N2).  Numbers as storeGrid writes them
+    (%g), empty lines (-> NaN / 0), garbage, signs, exponents, inf / nan, leading blanks, CR LF."""
+    if not O.ref_available():
+        pytest.skip("oracle/_ref not built (no /root/reference in this environment)")
+    lines = ["0.025", "5", "12", "0.075", "2", "1", "-1", "nan", "inf", "-inf", "", "1e-05", "3.14159e+10", "  42", "42abc", "abc",
+             "7.9", "-0.0", "0x10", "1,5", "\r", "12\r", " ", "+3", "1e400", "4.9e-324", "00012", "2147483647", "-2147483648"]
+    text = "\n".join(lines) + "\n"
+    path = tmp_path / "lines.txt"
+    path.write_bytes(text.encode())
+    for kinds in ([0] * len(lines), [1] * len(lines), [i % 2 for i in range(len(lines))]):
+        k = np.array(kinds, dtype=np.int32)
+        want, got = np.zeros(len(lines)), np.zeros(len(lines))
+        O.ref().ref_text_lines(text.encode(), k.ctypes.data_as(O._ip), len(lines), O.d(want))
+        assert O.lib().ora_text_lines(str(path).encode(), k.ctypes.data_as(O._ip), len(lines), O.d(got)) == 1
+        assert np.array_equal(want, got, equal_nan=True), [(l, w, g) for l, w, g in zip(lines, want, got) if not (w == g or (w != w and g != g))]

@@ -757,3 +757,69 @@ def test_golden_trajectory_fixture():
     init, _ = node.grid().download_tile_state()
     assert np.array_equal(init, f["init"])
     node.close()
+
+
+@pytest.mark.parametrize("tag,cfg,scene", [("cfg1", "cfg1", "room"), ("cfg2", "cfg2", "pillars"), ("cfg3", "cfg3", "pillars"),
+                                           ("cfg3comb", "cfg3", "comb")])
+def test_golden_baseline_config_fixture(tag, cfg, scene):
+    """tests/golden/oracle_baseline_configs.npz, checked WITHOUT the oracle: BASELINE configs 1-3 (+ cfg3 /
+    comb) at full size.  Per push the work counters and the digest of the whole grid -- the 64-bit hash of the canonical
+    dump is bit-exact or it is not equal; ray cast; registration per iteration (pairs, rms, threshold, state, Tlast);
+    closed loop through the C++ facade (per-scan pose, counts, push decisions, final grid sums)."""
+    import ctypes as C
+    import os
+    from ohm_tsd_slam_amd import facade
+    f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_baseline_configs.npz"))
+    gc, geo, _ = synth.CONFIGS[cfg]
+    HL = facade.load_library()
+
+    def ingest(r32):
+        r = np.ascontiguousarray(r32, dtype=np.float32)
+        data = np.zeros(r.size); mask = np.zeros(r.size, dtype=np.uint8)
+        HL.tsd_host_sensor_ingest_f32(r.ctypes.data_as(C.POINTER(C.c_float)), r.size, geo.angle_increment, geo.angle_min, H.MAX_RANGE,
+                                      data.ctypes.data_as(C.POINTER(C.c_double)), mask.ctypes.data_as(C.POINTER(C.c_uint8)), 0)
+        return data, mask
+
+    dg = capi.TsdGridDevice(gc.map_size_log2, gc.cell_size, gc.max_trunc)
+    for k in range(len(f[f"{tag}_push_poses"])):
+        data, mask = ingest(f[f"{tag}_push_scans"][k])
+        st = dg.push(f[f"{tag}_push_poses"][k], data, mask, geo.angle_increment, geo.angle_min, H.MAX_RANGE, H.MIN_RANGE, H.LOW_REFL)
+        assert [st[n] for n in sorted(st)] == list(f[f"{tag}_push_stats"][k]), f"push {k}"
+        d = dg.digest()
+        assert np.uint64(d["hash"]) == f[f"{tag}_digest_hash"][k], f"push {k}: the grid is not bit-identical to the fixture's"
+        assert [d["cells_valid"], d["tiles_initialized"]] == list(f[f"{tag}_digest_counts"][k])
+        so = f[f"{tag}_sums_{k}"]
+        assert abs(d["sum_tsd"] - so[0]) <= 1e-9 * max(1.0, abs(so[0])) and abs(d["sum_weight"] - so[1]) <= 1e-9 * max(1.0, abs(so[1]))
+    cd, nd, md, cnt = dg.raycast(f[f"{tag}_rc_pose"], f[f"{tag}_rc_rays_world"], H.MIN_RANGE, H.MAX_RANGE)
+    assert np.array_equal(md, f[f"{tag}_rc_mask"])
+    sel = np.repeat(md.astype(bool), 2)
+    assert np.max(np.abs(cd[sel] - f[f"{tag}_rc_coords"][sel])) <= 1e-9 and np.max(np.abs(nd[sel] - f[f"{tag}_rc_normals"][sel])) <= 1e-9
+    if scene == "comb":
+        return
+    data, mask = ingest(f[f"{tag}_icp_scan"])
+    p = dg.icp_params(30, 0.4, 0.02)
+    rf = dg.localize(f[f"{tag}_rc_pose"], f[f"{tag}_rc_rays_world"], f[f"{tag}_rc_rays_local"], data, mask, H.MIN_RANGE, H.MAX_RANGE, p)
+    want = f[f"{tag}_icp_counts"]
+    assert [rf.pairs, rf.iterations, rf.state, rf.n_model, rf.n_scene] == list(want)
+    d, a = H.pose_delta(f[f"{tag}_icp_T"], rf.T)
+    assert d <= 1e-9 and a <= 1e-9
+    tr, to = dg.icp_trace(rf.iterations), f[f"{tag}_icp_trace"]
+    assert np.array_equal(tr[:, 0], to[:, 0]) and np.array_equal(tr[:, 3], to[:, 3]), "pairs / state per iteration"
+    assert np.max(np.abs(tr[:, 1] - to[:, 1])) <= 1e-9 and np.max(np.abs(tr[:, 2] - to[:, 2])) <= 1e-15, "rms / threshold per iteration"
+    assert np.max(np.abs(tr[:, 4:8] - to[:, 4:8])) <= 1e-9, "Tlast per iteration"
+    # closed loop through the facade
+    node = facade.SlamNode(facade.node_params(gc, geo), synchronous=True)
+    rows = f[f"{tag}_traj_rows"]
+    for k in range(len(rows)):
+        node.laser(f[f"{tag}_traj_scans"][k], geo.angle_min, geo.angle_increment)
+        rep = node.report()
+        d, a = H.pose_delta(rows[k][:9].reshape(3, 3), rep["pose"])
+        assert d <= TOL_POSE_M and a <= TOL_POSE_RAD, f"scan {k}"
+        if k > 0:
+            assert [int(x) for x in rows[k][9:14]] == [rep["pairs"], rep["iterations"], rep["icp_state"], rep["valid_model"], rep["valid_scene"]], f"scan {k}"
+        assert (int(rows[k][14]), int(rows[k][15])) == (rep["pushed"], rep["reg_error"])
+    dd = node.grid().digest()
+    tg = f[f"{tag}_traj_grid"]
+    assert [dd["cells_valid"], dd["tiles_initialized"]] == [int(tg[0]), int(tg[1])]
+    assert abs(dd["sum_tsd"] - tg[2]) <= 1e-6 * max(1.0, abs(tg[2])) and abs(dd["sum_weight"] - tg[3]) <= 1e-6 * max(1.0, abs(tg[3]))
+    node.close()

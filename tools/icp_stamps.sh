@@ -17,7 +17,7 @@ for rep in range(3):
     dg.profile(True, "icp"); dg.profile_reset()
     rd = dg.icp(M, S, pose, p)
     ms, n = dg.profile_get("icp")
-    tr = np.zeros((256, 4)); dg.lib.tsd_icp_trace(dg.h, tr.ctypes.data_as(capi._dp), 256)
+    tr = np.zeros((256, 8)); dg.lib.tsd_icp_trace(dg.h, tr.ctypes.data_as(capi._dp), 256)
     st = tr.reshape(-1)[-8:]
     names = ["setup+tier0", "A list", "BC reciprocal", "D sums1", "F sums2+trig", "G transform+ctl"]
     tot = st[:6].sum()

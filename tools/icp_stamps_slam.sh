@@ -21,7 +21,7 @@ for k in range(N):
     node.laser(scans[k], geo.angle_min, geo.angle_increment)
     if k < 10: continue
     grid.sync()
-    tr = np.zeros((256, 4)); grid.lib.tsd_icp_trace(grid.h, tr.ctypes.data_as(capi._dp), 256)
+    tr = np.zeros((256, 8)); grid.lib.tsd_icp_trace(grid.h, tr.ctypes.data_as(capi._dp), 256)
     st = tr.reshape(-1)[-8:]
     acc += st; cnt += 1
     worst.append((st[:6].sum() + st[6], k, np.diff(np.concatenate([[0], tr[:30, 2]])).astype(int).tolist(),

@@ -17,7 +17,7 @@ for k in range(N):
     node.laser(scans[k], geo.angle_min, geo.angle_increment)
     grid.sync()
     if k in (20, 30, 39):
-        tr = np.zeros((256, 4)); grid.lib.tsd_icp_trace(grid.h, tr.ctypes.data_as(capi._dp), 256)
+        tr = np.zeros((256, 8)); grid.lib.tsd_icp_trace(grid.h, tr.ctypes.data_as(capi._dp), 256)
         st = tr.reshape(128, 8)
         st = st[st[:, 1] > 0]
         t0 = st[:, 0].min()

@@ -21,7 +21,7 @@ for rep in range(2):
     # zero the debug buffer through a dummy icp trace read is not possible; accept accumulation across reps
     cd, nd, md, cnt = dg.raycast(pose, rw, H.MIN_RANGE, H.MAX_RANGE)
     ms, n = dg.profile_get("raycast")
-    tr = np.zeros((256, 4)); dg.lib.tsd_icp_trace(dg.h, tr.ctypes.data_as(capi._dp), 256)
+    tr = np.zeros((256, 8)); dg.lib.tsd_icp_trace(dg.h, tr.ctypes.data_as(capi._dp), 256)
     d = tr.reshape(128, 8)
     names = ["clip+coarse", "segments", "cand blocks", "blocks looked at", "march", "normal", "serial", "total"]
     print("kernel us %.1f hits %d" % (1e3 * ms / max(n, 1), cnt), "avg cycles over 128 sampled beams:",

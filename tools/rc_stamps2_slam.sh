@@ -20,7 +20,7 @@ for k in range(N):
     grid.sync()
     if k % 6 == 5:
         ms, n = grid.profile_get("raycast")
-        tr = np.zeros((256, 4)); grid.lib.tsd_icp_trace(grid.h, tr.ctypes.data_as(capi._dp), 256)
+        tr = np.zeros((256, 8)); grid.lib.tsd_icp_trace(grid.h, tr.ctypes.data_as(capi._dp), 256)
         d = tr.reshape(-1)
         c = np.abs(d[d != 0])
         print("scan %d kernel %.1f us; beams: median %.0f p90 %.0f p99 %.0f max %.0f cycles (%.1f us); serial-chain beams %d" %

@@ -19,7 +19,7 @@ for k in range(N):
     node.laser(scans[k], geo.angle_min, geo.angle_increment)
     if k in (10, 60, 119):
         grid.sync()
-        tr = np.zeros((256, 4)); grid.lib.tsd_icp_trace(grid.h, tr.ctypes.data_as(capi._dp), 256)
+        tr = np.zeros((256, 8)); grid.lib.tsd_icp_trace(grid.h, tr.ctypes.data_as(capi._dp), 256)
         d = tr.reshape(128, 8)
         print("scan", k, {nm: "%.0f" % d[:, i].mean() for i, nm in enumerate(names)}, "max total %.0f" % d[:, 7].max(),
               "max cand %d" % d[:, 2].max())
