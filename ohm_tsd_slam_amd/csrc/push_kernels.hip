@@ -150,6 +150,36 @@ __device__ __forceinline__ void tile_geometry(const GridDev& g, int p, double e[
   rad = sqrt(dx * dx + dy * dy) * 0.5;
 }
 
+// ---- correctly rounded fp64 square root and quotient for operands in the NORMAL range -----------------------
+// The compiler's expansions of sqrt() / operator/ (v_rsq_f64 / v_rcp_f64 seed + Goldschmidt / Newton steps + one
+// correction step, which is what makes them correctly rounded) wrap that core in scaling for tiny / huge operands
+// (v_div_scale, v_ldexp, v_cmp_class, v_div_fixup).  Cell distances (1e-3 .. 1e3 m, squared) and the running
+// average's operands (|numerator| <= 33, 1e-6 < denominator <= 33) never need the scaling, so the core alone gives
+// bit-identical results with two thirds of the instructions.  (tests: every cell of every push bit-identical to the
+// oracle's libm sqrt and IEEE division -- the grid digests of tests/golden pin exactly that.)
+__device__ __forceinline__ double sqrt_normal(double x)
+{
+  // AMDGPU's f64 sqrt lowering without the 2^+-256 scaling and the zero / inf pass-through
+  const double y = __builtin_amdgcn_rsq(x);
+  const double g0 = x * y, h0 = 0.5 * y;
+  const double r0 = __builtin_fma(-h0, g0, 0.5);
+  const double g1 = __builtin_fma(g0, r0, g0), h1 = __builtin_fma(h0, r0, h0);
+  const double d0 = __builtin_fma(-g1, g1, x);
+  const double g2 = __builtin_fma(d0, h1, g1);
+  const double d1 = __builtin_fma(-g2, g2, x);
+  return __builtin_fma(d1, h1, g2);
+}
+__device__ __forceinline__ double div_normal(double n, double d)
+{
+  // AMDGPU's f64 division lowering without v_div_scale / v_div_fixup: reciprocal seed, two Newton steps, quotient,
+  // one residual correction (the step v_div_fmas performs)
+  double r = __builtin_amdgcn_rcp(d);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  const double q = n * r;
+  return __builtin_fma(__builtin_fma(-d, q, n), r, q);
+}
+
 // TsdGridPartition::addTsd (TsdGridPartition.h:170-212); the `fabs(sd) < _eps` branch is dead because
 // _eps = -cellSize/2 (TsdGridPartition.cpp:95) and is kept only as a comparison against eps.
 __device__ __forceinline__ bool add_tsd(double& tsd, double& weight, double sd, double part_weight,
@@ -164,7 +194,7 @@ __device__ __forceinline__ bool add_tsd(double& tsd, double& weight, double sd, 
       tsd = v;
       weight += w;
     } else {
-      tsd = (tsd * weight + v * w) / (weight + w);
+      tsd = div_normal(tsd * weight + v * w, weight + w);
       weight = fmin(weight + w, MAX_WEIGHT);
     }
     return true;
@@ -176,7 +206,8 @@ __device__ __forceinline__ bool add_tsd(double& tsd, double& weight, double sd, 
 // or only their halos refreshed (freeFootprint marks).  Entry = tile | kind << 28.
 constexpr uint32_t KIND_UPDATE = 1u, KIND_EMPTY = 2u, KIND_HALO = 3u;
 constexpr int KIND_SHIFT = 28;
-constexpr int FAST_MAX_BEAMS = 2048;   // above that the scan alone fills the workgroup's LDS share: exact index only
+constexpr uint32_t LIST_TILE_MASK = (1u << 20) - 1u;   // tile index (<= 2^20 tiles at map_size 15)
+constexpr uint32_t LIST_FAR = 1u << 27;          // entry flag: the sensor is further than 3 circumradii from the tile centre
 constexpr int TOT_FIELDS = 8;   // cells updated, range pass, update, new, new from empty, emptied init, emptied uninit, -
 
 // isInRange for every tile of the launch window, one LANE per tile (TsdGridComponent.cpp:43-124: range cull,
@@ -195,7 +226,7 @@ k_push_classify(GridDev g, const PushArgs* __restrict__ a_dev, const char* __res
   if (t == 0) list_cnt[parity ^ 1] = 0u;                    // the next push's counter (nobody uses it now)
   const bool in_window = t < ntx * nty;
   const int p = in_window ? (ty0 + t / ntx) * g.PX + tx0 + t % ntx : 0;
-  uint32_t rec = 0u, kind = 0u;
+  uint32_t rec = 0u, kind = 0u, far_flag = 0u;
   double pw = 0.0;
   uint32_t win = (uint32_t)(a.beams - 1) << 16;              // beams the cells of the tile can project to: lo | hi << 16
   if (in_window && a.enabled) {
@@ -242,7 +273,7 @@ k_push_classify(GridDev g, const PushArgs* __restrict__ a_dev, const char* __res
       // The cell centres of a tile lie inside the quadrilateral of the four corner points; seen from a sensor
       // well outside of it the extreme angles are those of corners, so every cell projects into [lo, hi]
       // (corners outside the field of view were mapped to its ends above).
-      if (distance > 3.0 * rad) win = (uint32_t)lo | ((uint32_t)hi << 16);
+      if (distance > 3.0 * rad) { win = (uint32_t)lo | ((uint32_t)hi << 16); far_flag = LIST_FAR; }
       if (action == 2) {
         kind = KIND_UPDATE;
         // partition weight (TsdGrid.cpp:239-243): ((maxRange - min(distance to the centroid, maxRange)) / maxRange)^2.
@@ -274,21 +305,29 @@ k_push_classify(GridDev g, const PushArgs* __restrict__ a_dev, const char* __res
     base = __shfl(base, 0, 64);
     if (kind != 0u) {
       const unsigned int slot = base + __popcll(listed & ((1ull << lane) - 1ull));
-      list[slot] = (uint32_t)p | (kind << KIND_SHIFT);
+      list[slot] = (uint32_t)p | far_flag | (kind << KIND_SHIFT);
       list_win[slot] = win;
       list_pw[slot] = pw;
     }
   }
 }
 
-// Beam index of a cell without the fp64 atan2 (SensorPolar2D::backProject, SensorPolar2D.cpp:117-135, decides
-// round((atan2(ly, lx) - phi_min) / res) and the two bound checks).  A fp32 estimate of the angle names a
-// candidate beam j; two fp64 cross products against the boundary directions of that beam (table in LDS) prove
-// that the angle lies strictly inside [phi_min + (j - 0.5) res, phi_min + (j + 0.5) res] with a margin far
-// above the rounding of either formulation, in which case the reference's atan2 + round gives j as well.
-// Anything closer than the margin to a boundary (or to the ends of the field of view) returns FAST_UNSURE
-// and is decided by the exact formulation.  ~45 instructions instead of ~125.
-constexpr int FAST_UNSURE = INT_MIN;
+// ---- beam index of a cell without the fp64 atan2 ------------------------------------------------------------
+// SensorPolar2D::backProject (SensorPolar2D.cpp:117-135) decides round((atan2(ly, lx) - phi_min) / res) and the two
+// bound checks from fp64 values.  The kernel ESTIMATES the beam coordinate u = (angle - phi_min) / res in fp32:
+//   far tiles (sensor further than 3 circumradii from the tile centre -- all but a handful): the cell's angle is the
+//       tile centre's plus a small delta, |delta| < 0.34 rad, and delta = atan(cross / dot) by a four-term series;
+//       ~17 fp32 instructions
+//   near tiles: a six-term minimax arctangent over the full circle; ~30
+// Every source of error (fp32 coordinates relative to the tile centre, v_rcp_f32, the series truncation t^9 / 9, the
+// fp32 product with 1 / res at u <= 4096) stays below 4e-3 beams -- measured on the device over all BASELINE scenes by
+// the -DTSD_PUSH_VERIFY_INDEX build: max |u_est - u_exact| = see profiles/ -- so an estimate further than 0.02 beams
+// from a rounding boundary (j +- 0.5), from the ends of the field of view and from the +-pi cut of atan2 names the
+// reference's beam with a margin of 5x.  The other cells (4-5 %) are not decided by the estimate at all: they go to
+// a queue in LDS and get the exact fp64 formulation, densely (one lane per queued cell), instead of dragging their
+// whole wave through it.
+constexpr int IDX_UNSURE = INT_MIN;
+constexpr float IDX_MARGIN = 0.02f;
 __device__ __forceinline__ float atan2_estimate(float y, float x)      // |error| < 2e-6 rad
 {
   const float ax = fabsf(x), ay = fabsf(y);
@@ -307,32 +346,39 @@ __device__ __forceinline__ float atan2_estimate(float y, float x)      // |error
   r = x < 0.f ? 3.14159274f - r : r;
   return y < 0.f ? -r : r;
 }
-__device__ __forceinline__ int fast_index(double lx, double ly, const double2* __restrict__ s_bdir, int beams,
-                                          float phi_min_f, float inv_res_f, int wlo, int whi)
+// beam index from the estimated angle `th` (radians, possibly outside (-pi, pi] by the small delta)
+__device__ __forceinline__ int index_from_angle(float th, float phi_min_f, float inv_res_f, int beams)
 {
-  const float th = atan2_estimate((float)ly, (float)lx);
-  const float u = (th - phi_min_f) * inv_res_f;             // beam coordinate, good to ~1e-3
-  const float m = 0.02f;
-  if (u < -0.5f - m || u > (float)beams - 0.5f + m) return -1;           // outside the field of view for sure
-  if (!(u > -0.5f + m && u < (float)beams - 0.5f - m)) return FAST_UNSURE;
-  const int j = (int)rintf(u);
-  if (j < wlo || j > whi) return FAST_UNSURE;                // boundaries j, j + 1 are staged for wlo <= j <= whi
-  const double2 b0 = s_bdir[j], b1 = s_bdir[j + 1];
-  const double c0 = b0.x * ly - b0.y * lx;                  // sin(angle - boundary j) * |l|
-  const double c1 = b1.x * ly - b1.y * lx;
-  const double tol = (fabs(lx) + fabs(ly)) * 1e-11;
-  return (c0 > tol && c1 < -tol) ? j : FAST_UNSURE;
+  const float PI_F = 3.14159274f;
+  if (th > PI_F) th -= 2.0f * PI_F;                        // the reference's atan2 lives in (-pi, pi]
+  else if (th <= -PI_F) th += 2.0f * PI_F;
+  if (fabsf(th) > PI_F - 1e-3f) return IDX_UNSURE;         // at the cut the two branches are 2 pi apart: exact path
+  const float u = (th - phi_min_f) * inv_res_f;            // beam coordinate
+  if (u < -0.5f - IDX_MARGIN || u > (float)beams - 0.5f + IDX_MARGIN) return -1;     // outside the field of view for sure
+  if (!(u > -0.5f + IDX_MARGIN && u < (float)beams - 0.5f - IDX_MARGIN)) return IDX_UNSURE;
+  const float j = rintf(u);
+  if (fabsf(u - j) > 0.5f - IDX_MARGIN) return IDX_UNSURE;
+  return (int)j;
 }
 
-// One workgroup per listed tile (TsdGrid.cpp:237-274): scan staged in LDS, 4 cells per thread, row-major =>
+
+// One workgroup per listed tile (TsdGrid.cpp:237-274): scan window staged in LDS, 4 cells per thread, row-major =>
 // coalesced 8-byte RMW; lazy TsdGridPartition::init (TsdGridPartition.cpp:88-134) folded in (a fresh tile's
 // old value is known, so it is written once, halo included).  KIND_EMPTY: increaseEmptiness over the 33x33
 // cells.  The workgroup leaves the tile's record and adds it to the tile's running totals.
+//
+// Instruction diet (the kernel is issue bound once the pushes are large: cfg3 / comb visits 10 M cells):
+//   pass A  beam index of every cell from the fp32 estimate above; undecided cells queue up in LDS
+//   drain   the queued cells, one lane each: the exact fp64 atan2 formulation
+//   pass B  mask / range of the beam from LDS; an fp32 test throws out the cells that lie behind the surface by more
+//           than the truncation for sure (|l|^2 against (range + maxTruncation)^2 with a 1e-5 margin, fp32 being good
+//           to 6e-7 here) -- a wave whose cells are all such skips the exact distance altogether -- then the exact
+//           IEEE distance / signed distance for the rest, the reads of the cells addTsd will touch, addTsd, the writes.
 __global__ void __launch_bounds__(UPDATE_BLOCK, 4)      // 4 waves per SIMD = four workgroups per CU: the listed tiles of a usual push are resident at once
 k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __restrict__ ranges,
               const uint8_t* __restrict__ mask, uint32_t* __restrict__ tile_rec, uint32_t* __restrict__ tile_totals,
               const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_win, const double* __restrict__ list_pw,
-              const unsigned int* __restrict__ list_cnt, int parity, const double2* __restrict__ bdir, double* __restrict__ dbg)
+              const unsigned int* __restrict__ list_cnt, int parity, double* __restrict__ dbg)
 {
 #ifdef TSD_PUSH_STAMPS   // diagnostic: 100 MHz wall clock at the phases of every 8th listed tile (thread 0)
 #define PSTAMP(i) do { if (threadIdx.x == 0 && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 128) dbg[(blockIdx.x >> 3) * 8 + (i)] = (double)wall_clock64(); } while (0)
@@ -353,15 +399,16 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
   unsigned int* s_upd = reinterpret_cast<unsigned int*>(smem);             // [4] cells updated per wave
   __shared__ unsigned long long s_neg_store;
   unsigned long long* s_neg = &s_neg_store;                               // groups of the tile that received a negative value
+  __shared__ unsigned int s_qn;                                           // cells queued for the exact beam index
+  __shared__ unsigned short s_queue[TILE_INTERIOR];
+  __shared__ short s_idx[TILE_INTERIOR];                                  // their exact index (-1 / -2: outside the field of view)
   double* s_ranges = reinterpret_cast<double*>(smem + 16);
   uint8_t* s_mask = reinterpret_cast<uint8_t*>(smem + 16 + (size_t)((a.beams + 1) & ~1) * sizeof(double));
-  double2* s_bdir = reinterpret_cast<double2*>(smem + 16 + (size_t)((a.beams + 1) & ~1) * sizeof(double) + (size_t)((a.beams + 15) & ~15));
-  const bool fast = bdir != nullptr;                     // boundary table staged (launch_push: beams <= FAST_MAX_BEAMS)
   const float phi_min_f = (float)a.phi_min, inv_res_f = (float)a.ang_res_inv;
-  // The scan (and the boundary table) is staged once per workgroup, together with the first tile's state:
-  // only the beams the tile can project to when the workgroup has a single tile (the usual case), all of
-  // them when it will loop over several.  Reads outside the staged window go to global memory.
-  const int p_first = (int)(first & ((1u << KIND_SHIFT) - 1u));
+  // The scan is staged once per workgroup, together with the first tile's state: only the beams the tile can project
+  // to when the workgroup has a single tile (the usual case), all of them when it will loop over several.  Reads
+  // outside the staged window go to global memory.
+  const int p_first = (int)(first & LIST_TILE_MASK);
   const uint8_t flag_first = g.flags[p_first];
   const double iw_first = g.init_weight[p_first];
   int wlo = 0, whi = a.beams - 1;
@@ -370,47 +417,50 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
     if (wlo < 0) wlo = 0;
     if (whi > a.beams - 1) whi = a.beams - 1;
   }
-  if (whi - wlo + 2 <= UPDATE_BLOCK) {
+  if (whi - wlo + 1 <= UPDATE_BLOCK) {
     // the usual tile, seen from outside: a few dozen beams, at most one element of each array per thread
     const int j = wlo + tid;
-    const bool in_r = j <= whi, in_b = fast && j <= whi + 1;
+    const bool in_r = j <= whi;
     const double rj = in_r ? ranges[j] : 0.0;
     const uint8_t mj = in_r ? mask[j] : (uint8_t)0;
-    const double2 bj = in_b ? bdir[j] : make_double2(0.0, 0.0);
     if (in_r) { s_ranges[j] = rj; s_mask[j] = mj; }
-    if (in_b) s_bdir[j] = bj;
-  } else if (a.beams <= FAST_MAX_BEAMS) {
+  } else if (a.beams <= 2048) {
     // every read issued before the first LDS write: one memory latency for the whole staging
-    constexpr int NR = FAST_MAX_BEAMS / 2 / UPDATE_BLOCK, NM = FAST_MAX_BEAMS / UPDATE_BLOCK, NB = NM + 1;
+    constexpr int NR = 2048 / 2 / UPDATE_BLOCK, NM = 2048 / UPDATE_BLOCK;
     const int p0 = wlo >> 1, p1 = whi >> 1;                    // pairs of ranges
     const double2* r2 = reinterpret_cast<const double2*>(ranges);
-    double2 rr[NR]; uint8_t mm[NM]; double2 bb[NB];
+    double2 rr[NR]; uint8_t mm[NM];
 #pragma unroll
     for (int i = 0; i < NR; i++) { const int j = p0 + tid + i * UPDATE_BLOCK; rr[i] = j <= p1 ? r2[j] : make_double2(0.0, 0.0); }
 #pragma unroll
     for (int i = 0; i < NM; i++) { const int j = wlo + tid + i * UPDATE_BLOCK; mm[i] = j <= whi ? mask[j] : (uint8_t)0; }
-    if (fast) {
-#pragma unroll
-      for (int i = 0; i < NB; i++) { const int j = wlo + tid + i * UPDATE_BLOCK; bb[i] = j <= whi + 1 ? bdir[j] : make_double2(0.0, 0.0); }
-    }
     double2* s_r2 = reinterpret_cast<double2*>(s_ranges);
 #pragma unroll
     for (int i = 0; i < NR; i++) { const int j = p0 + tid + i * UPDATE_BLOCK; if (j <= p1) s_r2[j] = rr[i]; }
 #pragma unroll
     for (int i = 0; i < NM; i++) { const int j = wlo + tid + i * UPDATE_BLOCK; if (j <= whi) s_mask[j] = mm[i]; }
-    if (fast) {
-#pragma unroll
-      for (int i = 0; i < NB; i++) { const int j = wlo + tid + i * UPDATE_BLOCK; if (j <= whi + 1) s_bdir[j] = bb[i]; }
-    }
   } else {
     for (int i = tid; i < a.beams; i += UPDATE_BLOCK) { s_ranges[i] = ranges[i]; s_mask[i] = mask[i]; }
   }
 
+  // Software pipeline over the workgroup's tiles (a large push gives every workgroup a dozen): the list entry of the
+  // NEXT tile is requested at the top of an iteration and its tile state after pass A, so an iteration's only
+  // dependent trip to memory is the read of the cells it updates.
+  uint32_t nx_entry = first; double nx_pw = first_pw; uint8_t nx_flag = flag_first; double nx_iw = iw_first;
   for (unsigned int li = blockIdx.x; li < n_list; li += gridDim.x) {
-    const uint32_t entry = (li == blockIdx.x) ? first : list[li];
+    const uint32_t entry = nx_entry;
+    const double pw = nx_pw;
+    const bool initialised = nx_flag != 0;
+    const double iw = nx_iw;
+    const unsigned int li_n = li + gridDim.x;
+    const bool has_next = li_n < n_list;
+    if (has_next) { nx_entry = list[li_n]; nx_pw = list_pw[li_n]; }
     const uint32_t kind = entry >> KIND_SHIFT;
-    const int p = (int)(entry & ((1u << KIND_SHIFT) - 1u));
-    if (kind == KIND_HALO) continue;
+    const int p = (int)(entry & LIST_TILE_MASK);
+    if (kind == KIND_HALO) {
+      if (has_next) { const int pn = (int)(nx_entry & LIST_TILE_MASK); nx_flag = g.flags[pn]; nx_iw = g.init_weight[pn]; }
+      continue;
+    }
 
     tsd_cell_t* __restrict__ T = g.tsd + (size_t)p * TILE_STRIDE;
     w_cell_t* __restrict__ W = g.weight + (size_t)p * TILE_STRIDE;
@@ -425,15 +475,14 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
         st_tsd(T + i, t); st_w(W + i, w);
       }
       rec |= REC_EMPTIED_INIT | REC_LISTED;
-      if (tid == 0) { tile_rec[p] = rec; tile_totals[(size_t)p * TOT_FIELDS + 5] += 1u; }
+      if (tid == 0) { tile_rec[p] = rec; atomicAdd(&tile_totals[(size_t)p * TOT_FIELDS + 5], 1u); }
+      if (has_next) { const int pn = (int)(nx_entry & LIST_TILE_MASK); nx_flag = g.flags[pn]; nx_iw = g.init_weight[pn]; }
       continue;
     }
 
     // ---- UPDATE ----
-    const bool initialised = (li == blockIdx.x ? flag_first : g.flags[p]) != 0;
-    const double iw = li == blockIdx.x ? iw_first : g.init_weight[p];
-    if (tid == 0) *s_neg = 0ull;
-    __syncthreads();               // scan staged; s_upd of a previous tile consumed
+    if (tid == 0) { *s_neg = 0ull; s_qn = 0u; }
+    __syncthreads();               // scan staged; s_upd / queue of a previous tile consumed
     PSTAMP(2);
 
     const bool fresh = !initialised;
@@ -445,43 +494,107 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
     const double max_trunc = g.max_trunc;
     const double inv_max_trunc = 1.0 / max_trunc;
     const double eps = -g.cs / 2.0;
-    // partition weight (TsdGrid.cpp:239-243): evaluated once per tile by k_push_classify
-    const double pw = (li == blockIdx.x) ? first_pw : list_pw[li];
+    // (partition weight `pw`, TsdGrid.cpp:239-243: evaluated once per tile by k_push_classify)
 
     const unsigned x0 = (unsigned)(p % g.PX) * TILE_DIM, y0 = (unsigned)(p / g.PX) * TILE_DIM;
     unsigned int n_upd = 0;
-    // Three passes over the thread's four cells so that their reads are in flight together: (1) beam index,
-    // signed distance and whether addTsd will touch the cell (sd >= -maxTruncation: cells behind the surface
-    // cost no HBM traffic), (2) the reads, (3) addTsd and the writes.
     constexpr int CPT = (TILE_DIM * TILE_DIM) / UPDATE_BLOCK;
-    int cidx[CPT], bidx[CPT]; double sdv[CPT]; bool hit[CPT];
-    // (1a) beam indices: a rolled loop, so that the exact fallback exists once in the code and the register
-    // budget stays at four workgroups per CU
-#pragma unroll 1
-    for (int k = 0; k < CPT; k++) {
-      const int c = tid + UPDATE_BLOCK * k;
-      const unsigned ix = (unsigned)c & 31u, iy = (unsigned)c >> 5;
-      const double ccx = ((double)(x0 + ix) + 0.5) * g.cs;   // TsdGridPartition.cpp:127-128
-      const double ccy = ((double)(y0 + iy) + 0.5) * g.cs;
-      // SensorPolar2D::backProject: PoseInv * (x,y,1)^T through dgemm(NoTrans,Trans) = ((0 + a*x) + b*y) + c*1
-      double lx = 0.0, ly = 0.0;
-      lx += a.Pi[0] * ccx; lx += a.Pi[1] * ccy; lx += a.Pi[2] * 1.0;
-      ly += a.Pi[3] * ccx; ly += a.Pi[4] * ccy; ly += a.Pi[5] * 1.0;
-      int index = fast ? fast_index(lx, ly, s_bdir, a.beams, phi_min_f, inv_res_f, wlo, whi) : FAST_UNSURE;
-      if (index == FAST_UNSURE) index = backproject(a.Pi, ccx, ccy, a.phi_min, a.ang_res_inv, a.phi_lower, a.phi_upper);
+    int bidx[CPT]; float d2f[CPT];
+    // Cell k of this thread: (ix, iy0 + 8 k).  A wave covers a 32 x 2 strip of cells per k: two 256-byte rows per
+    // access.  (Measured alternative, -DTSD_UPDATE_BLOCKS: 16 x 4 blocks -- four 128-byte segments per access -- so that
+    // fewer waves straddle the edge of the region addTsd touches: 25 % SLOWER at cfg3 / comb, 111 vs 89 us; the access
+    // shape outweighs the divergence.)
+#ifndef TSD_UPDATE_BLOCKS
+    const unsigned ix = (unsigned)tid & 31u, iy0 = (unsigned)tid >> 5;
+#else
+    const unsigned ix = (((unsigned)tid >> 6) & 1u) * 16u + ((unsigned)tid & 15u);
+    const unsigned iy0 = ((unsigned)tid >> 7) * 4u + (((unsigned)tid >> 4) & 3u);
+#endif
+    const int c0 = (int)(iy0 * 32u + ix);                                  // offset of cell k: c0 + 256 k
+
+    // ---- pass A: beam index of every cell from the fp32 estimate (sensor frame relative to the tile centre)
+    {
+      // tile centre = corner of the four middle cells; l_c = PoseInv * (centre, 1) in fp64 once, the cells relative
+      // to it in fp32: l = l_c + (PoseInv's rotation * cellSize) * (cell offset in cells), exact small offsets
+      const double ccx_c = (double)(x0 + 16u) * g.cs, ccy_c = (double)(y0 + 16u) * g.cs;
+      const double lcx = a.Pi[0] * ccx_c + a.Pi[1] * ccy_c + a.Pi[2], lcy = a.Pi[3] * ccx_c + a.Pi[4] * ccy_c + a.Pi[5];
+      const float lcxf = (float)lcx, lcyf = (float)lcy;
+      const float axx = (float)(a.Pi[0] * g.cs), axy = (float)(a.Pi[1] * g.cs), ayx = (float)(a.Pi[3] * g.cs), ayy = (float)(a.Pi[4] * g.cs);
+      const bool far = (entry & LIST_FAR) != 0u;
+      const float th_c = atan2_estimate(lcyf, lcxf);
+      const float dxc = (float)ix - 15.5f;
+      const float bx = fmaf(axx, dxc, lcxf), by = fmaf(ayx, dxc, lcyf);
 #pragma unroll
-      for (int j = 0; j < CPT; j++) if (j == k) bidx[j] = index;
+      for (int k = 0; k < CPT; k++) {
+        const float dyc = (float)(iy0 + 8u * (unsigned)k) - 15.5f;
+        const float lxf = fmaf(axy, dyc, bx), lyf = fmaf(ayy, dyc, by);
+        d2f[k] = fmaf(lxf, lxf, lyf * lyf);
+        float th;
+        if (far) {
+          // angle relative to the tile centre: tan(delta) = cross / dot, |delta| < 0.34 rad; atan by its series
+          const float cr = lcxf * lyf - lcyf * lxf, dt = fmaf(lcxf, lxf, lcyf * lyf);
+          const float t = cr * __builtin_amdgcn_rcpf(dt);
+          const float t2 = t * t;
+          float r = fmaf(t2, -0.142857143f, 0.2f);
+          r = fmaf(r, t2, -0.333333333f);
+          r = fmaf(r, t2, 1.0f);
+          th = fmaf(r, t, th_c);
+        } else {
+          th = atan2_estimate(lyf, lxf);
+        }
+        bidx[k] = index_from_angle(th, phi_min_f, inv_res_f, a.beams);
+      }
+#ifdef TSD_PUSH_VERIFY_INDEX   // diagnostic build: every decided cell against the exact formulation
+#pragma unroll
+      for (int k = 0; k < CPT; k++) {
+        const double ccx = ((double)(x0 + ix) + 0.5) * g.cs, ccy = ((double)(y0 + iy0 + 8u * (unsigned)k) + 0.5) * g.cs;
+        const int ex = backproject(a.Pi, ccx, ccy, a.phi_min, a.ang_res_inv, a.phi_lower, a.phi_upper);
+        if (bidx[k] != IDX_UNSURE && (bidx[k] < 0 ? ex >= 0 : ex != bidx[k])) atomicAdd(reinterpret_cast<unsigned long long*>(dbg + 1000), 1ull);
+        if (bidx[k] == IDX_UNSURE) atomicAdd(reinterpret_cast<unsigned long long*>(dbg + 1001), 1ull);
+        atomicAdd(reinterpret_cast<unsigned long long*>(dbg + 1002), 1ull);
+      }
+#endif
+      // undecided cells -> queue (one LDS atomic per wave and k)
+#pragma unroll
+      for (int k = 0; k < CPT; k++) {
+        const bool un = bidx[k] == IDX_UNSURE;
+        const unsigned long long m = __ballot(un);
+        if (m) {
+          unsigned int base = 0;
+          if (lane == 0) base = atomicAdd(&s_qn, (unsigned int)__popcll(m));
+          base = __shfl(base, 0, 64);
+          if (un) s_queue[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(c0 + UPDATE_BLOCK * k);
+        }
+      }
     }
-    // (1b) signed distances
+    if (has_next) { const int pn = (int)(nx_entry & LIST_TILE_MASK); nx_flag = g.flags[pn]; nx_iw = g.init_weight[pn]; }   // (next tile's state: in flight during the rest)
+    __syncthreads();
+    // ---- drain: the exact formulation (SensorPolar2D::backProject: fp64 atan2, bound checks, round) for the queued cells
+    {
+      const unsigned int nq = s_qn;
+      for (unsigned int q = (unsigned)tid; q < nq; q += UPDATE_BLOCK) {
+        const unsigned c = s_queue[q];
+        const double ccx = ((double)(x0 + (c & 31u)) + 0.5) * g.cs;   // TsdGridPartition.cpp:127-128
+        const double ccy = ((double)(y0 + (c >> 5)) + 0.5) * g.cs;
+        s_idx[c] = (short)backproject(a.Pi, ccx, ccy, a.phi_min, a.ang_res_inv, a.phi_lower, a.phi_upper);
+      }
+    }
+    __syncthreads();
+    PSTAMP(3);
+
+    // ---- pass B: signed distance and whether addTsd will touch the cell (sd >= -maxTruncation: cells behind the
+    // surface cost no HBM traffic)
+    double sdv[CPT]; bool hit[CPT], cnd[CPT]; double rng[CPT];
+    const double ccx = ((double)(x0 + ix) + 0.5) * g.cs;
+    const double dxw = ccx - a.trx, dxw2 = dxw * dxw;
+    const float low2f = (float)(a.low_refl * a.low_refl) * 1.00001f;
+    const float mtf = (float)max_trunc;
+    // (B1) candidates: valid beam, and not behind the surface by more than the truncation for sure
 #pragma unroll
     for (int k = 0; k < CPT; k++) {
-      const int c = tid + UPDATE_BLOCK * k;
-      const unsigned ix = (unsigned)c & 31u, iy = (unsigned)c >> 5;
-      const double ccx = ((double)(x0 + ix) + 0.5) * g.cs;
-      const double ccy = ((double)(y0 + iy) + 0.5) * g.cs;
-      cidx[k] = c;                                           // interior offset iy * 32 + ix
-      const int index = bidx[k];
-      hit[k] = false; sdv[k] = 0.0;
+      const int c = c0 + UPDATE_BLOCK * k;
+      int index = bidx[k];
+      if (index == IDX_UNSURE) index = s_idx[c];
       // mask and range of the beam from LDS, both at once (a select between an LDS and a global pointer would turn
       // into a flat load with a full wait per cell); a beam outside the staged window -- possible only through
       // rounding at the window's ends -- is fetched from global memory by the lanes concerned
@@ -491,21 +604,37 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
       double r = s_ranges[il];
       asm volatile("" : "+v"(mk), "+v"(r));      // (keeps the two LDS reads LDS reads: no pointer select)
       if (__builtin_expect(index >= 0 && !staged_beam, 0)) { mk = mask[index]; r = ranges[index]; }
-      if (index >= 0 && mk) {
-        const double dist = sqrt((ccx - a.trx) * (ccx - a.trx) + (ccy - a.try_) * (ccy - a.try_));
-        double sd = 0.0; bool cand = false;
-        if (!isinf(r)) { sd = r - dist; cand = true; }
-        else if (dist < a.low_refl) { sd = max_trunc; cand = true; }
-        hit[k] = cand && sd >= -max_trunc;
-        sdv[k] = sd;
+      bool cand = index >= 0 && mk != 0u;
+      if (cand) {
+        const float rf = (float)r + mtf;
+        const float lim2 = isinf(r) ? low2f : rf * rf * 1.00001f;
+        cand = !(d2f[k] > lim2);
       }
+      cnd[k] = cand; rng[k] = r;
     }
-    PSTAMP(3);
+    // (B2) the cells' reads go out now -- candidates are the updated cells plus a sliver at the truncation boundary --
+    // and are in flight during the exact distances
     double tv[CPT], wv[CPT];
 #pragma unroll
     for (int k = 0; k < CPT; k++) {
       tv[k] = t_init; wv[k] = w_init;
-      if (hit[k] && !fresh) { tv[k] = ld_tsd(T + cidx[k]); wv[k] = ld_w(W + cidx[k]); }
+      if (cnd[k] && !fresh) { tv[k] = ld_tsd(T + c0 + UPDATE_BLOCK * k); wv[k] = ld_w(W + c0 + UPDATE_BLOCK * k); }
+    }
+    // (B3) exact signed distance of the candidates
+#pragma unroll
+    for (int k = 0; k < CPT; k++) {
+      hit[k] = false; sdv[k] = 0.0;
+      if (cnd[k]) {
+        const double r = rng[k];
+        const double ccy = ((double)(y0 + iy0 + 8u * (unsigned)k) + 0.5) * g.cs;
+        const double dyw = ccy - a.try_;
+        const double dist = sqrt_normal(dxw2 + dyw * dyw);        // (ccx - trx)^2 + (ccy - try)^2, then the IEEE root
+        double sd = 0.0; bool ok = false;
+        if (!isinf(r)) { sd = r - dist; ok = true; }
+        else if (dist < a.low_refl) { sd = max_trunc; ok = true; }
+        hit[k] = ok && sd >= -max_trunc;
+        sdv[k] = sd;
+      }
     }
 #ifdef TSD_PUSH_STAMPS
     if (tv[0] == 123.456) dbg[1023] = wv[0] + tv[1] + tv[2] + tv[3];    // (wait for the reads)
@@ -514,11 +643,12 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
     unsigned long long wrote_neg = 0ull;
 #pragma unroll
     for (int k = 0; k < CPT; k++) {
+      const int c = c0 + UPDATE_BLOCK * k;
       bool touched = false;
       if (hit[k]) touched = add_tsd(tv[k], wv[k], sdv[k], pw, max_trunc, inv_max_trunc, eps);
       if (touched) n_upd++;
-      if (touched && tv[k] < 0.0) wrote_neg |= neg_bit((unsigned)cidx[k] & 31u, (unsigned)cidx[k] >> 5);
-      if (touched || fresh) { st_tsd(T + cidx[k], tv[k]); st_w(W + cidx[k], wv[k]); }
+      if (touched && tv[k] < 0.0) wrote_neg |= neg_bit((unsigned)c & 31u, (unsigned)c >> 5);
+      if (touched || fresh) { st_tsd(T + c, tv[k]); st_w(W + c, wv[k]); }
     }
     if (wrote_neg) atomicOr(s_neg, wrote_neg);                      // (LDS; folded into the tile's mask below)
     if (fresh) {
@@ -536,11 +666,14 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
       unsigned cells = 0;
       for (int w = 0; w < UPDATE_BLOCK / 64; w++) cells += s_upd[w];
       tile_rec[p] = rec | (cells << REC_CELLS_SHIFT);
+      // The tile's running totals and mask: NO-RETURN atomics (fire and forget; every tile has its own words, so
+      // nothing contends).  As read-add-write they were four dependent trips to memory by thread 0 at the end of every
+      // tile, with the rest of the workgroup waiting for it at the next tile's first barrier.
       const unsigned long long nm = *s_neg;
-      if (nm) g.negmask[p] |= nm;    // (this workgroup owns the tile)
+      if (nm) atomicOr(&g.negmask[p], nm);
       uint32_t* tot = tile_totals + (size_t)p * TOT_FIELDS;
-      tot[0] += cells; tot[2] += 1u;
-      if (fresh) { tot[3] += 1u; if (iw > 0.0) tot[4] += 1u; }
+      atomicAdd(&tot[0], cells); atomicAdd(&tot[2], 1u);
+      if (fresh) { atomicAdd(&tot[3], 1u); if (iw > 0.0) atomicAdd(&tot[4], 1u); }
       if (fresh) g.flags[p] = 1;   // publish the tile
     }
   }
@@ -576,7 +709,7 @@ k_push_halo(GridDev g, uint8_t* __restrict__ dirty, unsigned long long* __restri
   const int i = lane & 31;
   for (unsigned int li = wv; li < n_list; li += gridDim.x * 4) {
     const uint32_t entry = (li == wv) ? first : list[li];
-    const int p = (int)(entry & ((1u << KIND_SHIFT) - 1u));
+    const int p = (int)(entry & LIST_TILE_MASK);
     if (lane == 0 && dirty[p] != 0) dirty[p] = 0;
     const int px = p % PX, py = p / PX;
     const bool hasR = px < PX - 1, hasU = py < PX - 1, hasL = px > 0, hasD = py > 0;
@@ -876,12 +1009,9 @@ int launch_push(tsd_ctx* ctx, const PushArgs& a, double cx, double cy, double sl
   const int n_groups = n_window < 2048 ? n_window : 2048;      // resident at once; a longer list is looped over
   {
     ScopedKernelTimer t(ctx, "push_update");
-    const bool fast = a.beams <= FAST_MAX_BEAMS;           // the boundary table shares LDS with the scan
-    const size_t lds = 16 + (size_t)((a.beams + 1) & ~1) * sizeof(double) + (size_t)((a.beams + 15) & ~15) +
-                       (fast ? ((size_t)a.beams + 1) * sizeof(double2) : 0);
-    const double2* bdir = fast ? rmq_view(rmq, a.beams).bdir : nullptr;
+    const size_t lds = 16 + (size_t)((a.beams + 1) & ~1) * sizeof(double) + (size_t)((a.beams + 15) & ~15);
     hipExtLaunchKernelGGL(k_push_update, dim3(n_groups), dim3(UPDATE_BLOCK), lds, ctx->stream, t.a, t.b, 0, g, a_dev, d_ranges, d_mask,
-                       ctx->d_tile_rec, ctx->d_tile_totals, ctx->d_list, ctx->d_list_win, ctx->d_list_pw, ctx->d_list_cnt, parity, bdir,
+                       ctx->d_tile_rec, ctx->d_tile_totals, ctx->d_list, ctx->d_list_win, ctx->d_list_pw, ctx->d_list_cnt, parity,
                        ctx->d_icp_trace);
   }
   TSD_HIP_CHECK(ctx, hipGetLastError());
