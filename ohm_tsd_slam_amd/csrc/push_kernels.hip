@@ -374,7 +374,13 @@ __device__ __forceinline__ int index_from_angle(float th, float phi_min_f, float
 //           than the truncation for sure (|l|^2 against (range + maxTruncation)^2 with a 1e-5 margin, fp32 being good
 //           to 6e-7 here) -- a wave whose cells are all such skips the exact distance altogether -- then the exact
 //           IEEE distance / signed distance for the rest, the reads of the cells addTsd will touch, addTsd, the writes.
-__global__ void __launch_bounds__(UPDATE_BLOCK, 4)      // 4 waves per SIMD = four workgroups per CU: the listed tiles of a usual push are resident at once
+#ifndef TSD_UPDATE_WPS
+#define TSD_UPDATE_WPS 4
+#endif
+#ifndef TSD_UPDATE_BATCH
+#define TSD_UPDATE_BATCH 2
+#endif
+__global__ void __launch_bounds__(UPDATE_BLOCK, TSD_UPDATE_WPS)      // 4 waves per SIMD = four workgroups per CU: the listed tiles of a usual push are resident at once
 k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __restrict__ ranges,
               const uint8_t* __restrict__ mask, uint32_t* __restrict__ tile_rec, uint32_t* __restrict__ tile_totals,
               const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_win, const double* __restrict__ list_pw,
@@ -584,17 +590,20 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
 
     // ---- pass B: signed distance and whether addTsd will touch the cell (sd >= -maxTruncation: cells behind the
     // surface cost no HBM traffic)
-    double sdv[CPT]; bool hit[CPT], cnd[CPT]; double rng[CPT];
+    unsigned cnd = 0u;                                           // bit k: cell k is a candidate
     const double ccx = ((double)(x0 + ix) + 0.5) * g.cs;
     const double dxw = ccx - a.trx, dxw2 = dxw * dxw;
     const float low2f = (float)(a.low_refl * a.low_refl) * 1.00001f;
     const float mtf = (float)max_trunc;
-    // (B1) candidates: valid beam, and not behind the surface by more than the truncation for sure
+    // (B1) candidates: valid beam, and not behind the surface by more than the truncation for sure.  (Registers are
+    // tight at four workgroups per CU -- a spilled dword costs scratch traffic per tile -- so the range is looked up
+    // again in B3 instead of being kept.)
 #pragma unroll
     for (int k = 0; k < CPT; k++) {
       const int c = c0 + UPDATE_BLOCK * k;
       int index = bidx[k];
       if (index == IDX_UNSURE) index = s_idx[c];
+      bidx[k] = index;
       // mask and range of the beam from LDS, both at once (a select between an LDS and a global pointer would turn
       // into a flat load with a full wait per cell); a beam outside the staged window -- possible only through
       // rounding at the window's ends -- is fetched from global memory by the lanes concerned
@@ -610,46 +619,58 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
         const float lim2 = isinf(r) ? low2f : rf * rf * 1.00001f;
         cand = !(d2f[k] > lim2);
       }
-      cnd[k] = cand; rng[k] = r;
+      cnd |= cand ? (1u << k) : 0u;
     }
-    // (B2) the cells' reads go out now -- candidates are the updated cells plus a sliver at the truncation boundary --
-    // and are in flight during the exact distances
-    double tv[CPT], wv[CPT];
+    // (B2-B4) in two halves of two cells (a rolled loop: half the registers of doing all four at once, which is what keeps
+    // the kernel at four workgroups per CU without scratch spills): the candidates' reads go out -- candidates are the
+    // updated cells plus a sliver at the truncation boundary -- and are in flight during the exact distances; then
+    // addTsd and the writes
+    unsigned long long wrote_neg = 0ull;
+    constexpr int HB = TSD_UPDATE_BATCH;          // cells per batch: 2 (default) or 4
+#pragma unroll 1
+    for (int h = 0; h < CPT / HB; h++) {
+      int idx2[HB];
+      if constexpr (HB == 2) { idx2[0] = h ? bidx[2] : bidx[0]; idx2[1] = h ? bidx[3] : bidx[1]; }
+      else { for (int j = 0; j < HB; j++) idx2[j] = bidx[j]; }
+      const unsigned cn2 = cnd >> (HB * h);
+      double tv[HB], wv[HB], sdv[HB]; bool hit[HB];
 #pragma unroll
-    for (int k = 0; k < CPT; k++) {
-      tv[k] = t_init; wv[k] = w_init;
-      if (cnd[k] && !fresh) { tv[k] = ld_tsd(T + c0 + UPDATE_BLOCK * k); wv[k] = ld_w(W + c0 + UPDATE_BLOCK * k); }
-    }
-    // (B3) exact signed distance of the candidates
+      for (int j = 0; j < HB; j++) {
+        const int c = c0 + UPDATE_BLOCK * (HB * h + j);
+        tv[j] = t_init; wv[j] = w_init;
+        if (((cn2 >> j) & 1u) && !fresh) { tv[j] = ld_tsd(T + c); wv[j] = ld_w(W + c); }
+      }
 #pragma unroll
-    for (int k = 0; k < CPT; k++) {
-      hit[k] = false; sdv[k] = 0.0;
-      if (cnd[k]) {
-        const double r = rng[k];
-        const double ccy = ((double)(y0 + iy0 + 8u * (unsigned)k) + 0.5) * g.cs;
-        const double dyw = ccy - a.try_;
-        const double dist = sqrt_normal(dxw2 + dyw * dyw);        // (ccx - trx)^2 + (ccy - try)^2, then the IEEE root
-        double sd = 0.0; bool ok = false;
-        if (!isinf(r)) { sd = r - dist; ok = true; }
-        else if (dist < a.low_refl) { sd = max_trunc; ok = true; }
-        hit[k] = ok && sd >= -max_trunc;
-        sdv[k] = sd;
+      for (int j = 0; j < HB; j++) {
+        hit[j] = false; sdv[j] = 0.0;
+        if ((cn2 >> j) & 1u) {
+          const int index = idx2[j];
+          const bool staged_beam = index >= wlo && index <= whi;
+          const int il = index < wlo ? wlo : (index > whi ? whi : index);
+          double r = s_ranges[il];
+          asm volatile("" : "+v"(r));
+          if (__builtin_expect(!staged_beam, 0)) r = ranges[index];
+          const double ccy = ((double)(y0 + iy0 + 8u * (unsigned)(HB * h + j)) + 0.5) * g.cs;
+          const double dyw = ccy - a.try_;
+          const double dist = sqrt_normal(dxw2 + dyw * dyw);        // (ccx - trx)^2 + (ccy - try)^2, then the IEEE root
+          double sd = 0.0; bool ok = false;
+          if (!isinf(r)) { sd = r - dist; ok = true; }
+          else if (dist < a.low_refl) { sd = max_trunc; ok = true; }
+          hit[j] = ok && sd >= -max_trunc;
+          sdv[j] = sd;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < HB; j++) {
+        const int c = c0 + UPDATE_BLOCK * (HB * h + j);
+        bool touched = false;
+        if (hit[j]) touched = add_tsd(tv[j], wv[j], sdv[j], pw, max_trunc, inv_max_trunc, eps);
+        if (touched) n_upd++;
+        if (touched && tv[j] < 0.0) wrote_neg |= neg_bit((unsigned)c & 31u, (unsigned)c >> 5);
+        if (touched || fresh) { st_tsd(T + c, tv[j]); st_w(W + c, wv[j]); }
       }
     }
-#ifdef TSD_PUSH_STAMPS
-    if (tv[0] == 123.456) dbg[1023] = wv[0] + tv[1] + tv[2] + tv[3];    // (wait for the reads)
-#endif
     PSTAMP(4);
-    unsigned long long wrote_neg = 0ull;
-#pragma unroll
-    for (int k = 0; k < CPT; k++) {
-      const int c = c0 + UPDATE_BLOCK * k;
-      bool touched = false;
-      if (hit[k]) touched = add_tsd(tv[k], wv[k], sdv[k], pw, max_trunc, inv_max_trunc, eps);
-      if (touched) n_upd++;
-      if (touched && tv[k] < 0.0) wrote_neg |= neg_bit((unsigned)c & 31u, (unsigned)c >> 5);
-      if (touched || fresh) { st_tsd(T + c, tv[k]); st_w(W + c, wv[k]); }
-    }
     if (wrote_neg) atomicOr(s_neg, wrote_neg);                      // (LDS; folded into the tile's mask below)
     if (fresh) {
       // halo cells of a freshly materialised tile keep the init value until k_push_halo
@@ -670,10 +691,16 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
       // nothing contends).  As read-add-write they were four dependent trips to memory by thread 0 at the end of every
       // tile, with the rest of the workgroup waiting for it at the next tile's first barrier.
       const unsigned long long nm = *s_neg;
-      if (nm) atomicOr(&g.negmask[p], nm);
       uint32_t* tot = tile_totals + (size_t)p * TOT_FIELDS;
+#ifndef TSD_RMW_RECORDS
+      if (nm) atomicOr(&g.negmask[p], nm);
       atomicAdd(&tot[0], cells); atomicAdd(&tot[2], 1u);
       if (fresh) { atomicAdd(&tot[3], 1u); if (iw > 0.0) atomicAdd(&tot[4], 1u); }
+#else
+      if (nm) g.negmask[p] |= nm;
+      tot[0] += cells; tot[2] += 1u;
+      if (fresh) { tot[3] += 1u; if (iw > 0.0) tot[4] += 1u; }
+#endif
       if (fresh) g.flags[p] = 1;   // publish the tile
     }
   }
