@@ -225,6 +225,10 @@ const char* tsd_node_pose_topic(tsd_node* n, int robot)
 }
 
 tsd_ctx* tsd_node_grid_ctx(tsd_node* n) { return n->grid ? n->grid->context() : nullptr; }
+// the facade's grid mutex (obvious::TsdGrid::mutex()): whoever talks to the context through the raw tsd_* ABI while the
+// node's worker threads may be running takes it around each call, like the facade's own classes do
+void tsd_node_grid_lock(tsd_node* n) { if(n && n->grid) n->grid->mutex().lock(); }
+void tsd_node_grid_unlock(tsd_node* n) { if(n && n->grid) n->grid->mutex().unlock(); }
 
 // SlamNode::~SlamNode shutdown order (SlamNode.cpp:131-152): terminate + join every thread
 void tsd_node_destroy(tsd_node* n)

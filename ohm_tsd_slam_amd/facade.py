@@ -35,6 +35,8 @@ HOST_ABI = {
     "tsd_node_pose_msg": (None, [C.c_void_p, C.c_int, _dp]),
     "tsd_node_pose_topic": (C.c_char_p, [C.c_void_p, C.c_int]),
     "tsd_node_grid_ctx": (C.c_void_p, [C.c_void_p]),
+    "tsd_node_grid_lock": (None, [C.c_void_p]),
+    "tsd_node_grid_unlock": (None, [C.c_void_p]),
     "tsd_node_destroy": (None, [C.c_void_p]),
     "tsd_host_sensor_ingest_f32": (None, [_fp, C.c_int, C.c_double, C.c_double, C.c_double, _dp, _u8p, C.c_int]),
     "tsd_host_sensor_chain": (None, [C.c_int, C.c_double, C.c_double, _dp, _dp, C.c_double, _fp, _dp, _dp, _dp,
@@ -168,21 +170,42 @@ class SlamNode:
                 "topic": self.lib.tsd_node_pose_topic(self.h, robot).decode()}
 
     def grid(self) -> "GridView":
-        return GridView(self.lib.tsd_node_grid_ctx(self.h))
+        return GridView(self.lib.tsd_node_grid_ctx(self.h), self)
 
 
 class GridView(capi.TsdGridDevice):
-    """Non-owning view of the facade's grid context (for dumps / profiling through the tsd_* ABI)."""
+    """Non-owning view of the facade's grid context (for dumps / profiling through the tsd_* ABI).  Every device call
+    made through it takes the facade's grid mutex (obvious::TsdGrid::mutex()), like the facade's own classes do: the
+    node's localise / mapping threads may be enqueueing on the same context."""
 
-    def __init__(self, ctx):  # noqa: D401 - does not call the base constructor on purpose
+    _LOCKED = ("reset", "sync", "free_footprint", "push", "raycast", "icp", "localize", "icp_trace", "download_tile_state",
+               "download_tiles", "upload_tiles", "digest", "occupancy", "occupancy_into", "calibrate_rmw", "profile", "store_text",
+               "load_text", "color_image", "push_stats_total", "profile_reset", "profile_get", "tsdpdf_match")
+
+    def __init__(self, ctx, node=None):  # noqa: D401 - does not call the base constructor on purpose
         self.lib = capi.load_library()
         self.h = ctx
+        self._node = node
         self.cells = self.lib.tsd_cells(ctx)
         self.tiles = self.lib.tsd_tiles(ctx)
         self.cell_size = self.lib.tsd_cell_size(ctx)
         self.max_trunc = self.lib.tsd_max_truncation(ctx)
         self.min_x, self.max_x = self.lib.tsd_min_x(ctx), self.lib.tsd_max_x(ctx)
         self.min_y, self.max_y = self.lib.tsd_min_y(ctx), self.lib.tsd_max_y(ctx)
+
+    def __getattribute__(self, name):
+        attr = object.__getattribute__(self, name)
+        if name in GridView._LOCKED and callable(attr):
+            node = object.__getattribute__(self, "_node")
+            if node is not None and getattr(node, "h", None):
+                def locked(*a, **k):
+                    node.lib.tsd_node_grid_lock(node.h)
+                    try:
+                        return attr(*a, **k)
+                    finally:
+                        node.lib.tsd_node_grid_unlock(node.h)
+                return locked
+        return attr
 
     def close(self):
         self.h = None
