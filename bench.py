@@ -179,6 +179,7 @@ def main():
     ap.add_argument("--mode", default=None, choices=["slam", "push"])
     ap.add_argument("--storage", default="f64", choices=["f64", "q32"])
     ap.add_argument("--robots", type=int, default=1)
+    ap.add_argument("--python-feeders", action="store_true", help="--robots: Python feeder threads instead of tsd_node_play")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scans", type=int, default=10)
     ap.add_argument("--sample-every", type=int, default=0, help="time every n-th dispatch of each kernel (0 = auto)")
@@ -322,6 +323,7 @@ def run_slam(args, gc, geo, scene, K, W, every, device, rank, local_rank, world_
         p = synth.trajectory(world, 1 + W + K, leg=leg)
         p[:, 1] += lanes[r][1] - world.start[1]
         poses.append(p); scans.append(synth.scans_for(world, geo, p))
+    scans32 = [np.ascontiguousarray(np.stack(sc), dtype=np.float32) for sc in scans]
     params = facade.node_params(gc, geo)
     if R == 1:
         params["tsd_slam/local_offset_x"] = multigpu.robot_offset_x(rank)
@@ -357,9 +359,12 @@ def run_slam(args, gc, geo, scene, K, W, every, device, rank, local_rank, world_
             for k in range(k0, k1):
                 step(k)
             return
-        # one feeder thread per robot: laser() runs the event-loop body on the calling thread (synchronous facade) and
-        # releases the GIL inside the C++ call, so the robots' scans overlap on the device like the reference's N
-        # ThreadLocalize workers do
+        # one publisher thread per robot, like `rosbag play` feeding the reference node: laserCallBack runs the event-loop
+        # body on the publisher's thread (synchronous facade), so the robots' scans overlap on the device like the reference's
+        # N ThreadLocalize workers do.  Native threads (tsd_node_play) unless --python-feeders.
+        if not args.python_feeders:
+            node.play(scans32, k0, k1 - k0, geo.angle_min, geo.angle_increment)
+            return
         ts = [threading.Thread(target=lambda rr=r: [step(k, rr) for k in range(k0, k1)]) for r in range(R)]
         for t in ts:
             t.start()
@@ -376,6 +381,7 @@ def run_slam(args, gc, geo, scene, K, W, every, device, rank, local_rank, world_
     if dist is not None:
         torch.cuda.synchronize()
         dist.barrier()
+    b0 = node.batch_stats()
     t0 = time.perf_counter()
     run_range(1 + W, 1 + W + K)
     grid.sync()
@@ -386,6 +392,8 @@ def run_slam(args, gc, geo, scene, K, W, every, device, rank, local_rank, world_
     elapsed = time.perf_counter() - t0
     upd_ms, upd_launches = grid.profile_get("push_update")
     stages = stage_table(grid, K)
+    b1 = node.batch_stats()
+    bstats = (b1[0] - b0[0], b1[1] - b0[1])
     st, pushes = grid.push_stats_total()
     grid.profile(False)
     errs = []
@@ -412,7 +420,9 @@ def run_slam(args, gc, geo, scene, K, W, every, device, rank, local_rank, world_
                                + (", point-to-line estimator" if args.estimator else ""),
                    "robots": world_size * R, "robots_per_grid": R, "mode": "slam", "storage": "f64",
                    "occupancy_merge_every": MERGE_EVERY if world_size > 1 else None,
-                   "note": "single-stream latency chain per robot: a scan's ray cast needs the previous scan's push"},
+                   "note": "single-stream latency chain per robot: a scan's ray cast needs the previous scan's push"
+                           if R == 1 else "robots' scans batched by the facade's dispatcher (tsd_batch_*), two batch slots in turn",
+                   "scans_per_batch": (bstats[1] / max(bstats[0], 1)) if R > 1 else None},
         "ms_icp_iterate": stages["icp"], "ms_icp_per_iteration": (stages["icp"] / 30.0) if stages["icp"] else None,
         "ms_raycast": stages["raycast"],
         "ms_push_kernels": sum(v for k, v in stages.items() if k.startswith("push") and v is not None),

@@ -245,6 +245,31 @@ int tsd_scan_begin(tsd_sensor* s, const double* ranges, const uint8_t* mask, con
 int tsd_scan_wait(tsd_sensor* s);
 int tsd_scan_finish(tsd_sensor* s, tsd_scan_result* result);
 
+/* Batched form for several robots on ONE grid: the robots that have a scan pending are registered by ONE launch of each kernel
+ * (tables: workgroup = scan; ray cast: block row = sensor; registration: workgroup = robot, one compute unit each) on the
+ * batch's own stream, their pushes follow one after the other on the grid's stream.  All ray casts of a batch read the same
+ * grid state, the pushes are applied in the order of the batch -- one of the interleavings the reference's N ThreadLocalize
+ * workers and its single ThreadMapping can produce (SlamNode.cpp:101-122, ThreadMapping.cpp:47-75).  A caller keeps two or
+ * three batches and uses them in turn: while one registers, the other's pushes run.
+ *   tsd_batch_begin    copy, tables, ray casts, registrations (+ gates, Sensor::transform) of n sensors; returns at once
+ *   tsd_batch_push     enqueue the n pushes (gated on the device); may be called BEFORE the registrations have finished: ray
+ *                      casts enqueued later wait for these pushes, ray casts enqueued earlier do not
+ *   tsd_batch_poll     1 when every result record of the batch has arrived, 0 otherwise (never blocks)
+ *   tsd_batch_results  waits for the records, enqueues the pushes unless tsd_batch_push did, fills results[0..n), frees the slot
+ * The sensors of a batch must be distinct, attached to the batch's grid and without a scan in flight; one estimator per batch. */
+#define TSD_BATCH_MAX_SCANS 64
+typedef struct tsd_batch tsd_batch;
+tsd_batch* tsd_batch_create(tsd_ctx* ctx, int max_scans);
+void tsd_batch_destroy(tsd_batch* b);
+int tsd_batch_capacity(const tsd_batch* b);
+int tsd_batch_inflight(const tsd_batch* b);      /* scans begun and not yet collected */
+int tsd_batch_begin(tsd_batch* b, int n, tsd_sensor* const* sensors, const double* const* ranges, const uint8_t* const* mask,
+                    const uint8_t* const* mask_push /* NULL or per-scan NULL: = mask */, const tsd_icp_params* params /* [n] */,
+                    const tsd_gate_params* gates /* [n] */);
+int tsd_batch_push(tsd_batch* b);
+int tsd_batch_poll(tsd_batch* b);
+int tsd_batch_results(tsd_batch* b, tsd_scan_result* results /* [n] */);
+
 /* Per-iteration record of the most recent tsd_icp / tsd_localize on this ctx (the role of
  * Icp::activateTrace, Icp.cpp:60-70): out[TSD_ICP_TRACE_STRIDE * i + {0..7}] = pairs, rms, DistanceFilter threshold
  * before the step, state after loop control, and the step's Tlast = [[c, -s, tx], [s, c, ty]] as c, s, tx, ty (NaN

@@ -154,6 +154,15 @@ ABI = {
     "tsd_scan_begin": (C.c_int, [C.c_void_p, _dp, _u8p, _u8p, C.POINTER(IcpParams), C.POINTER(GateParams)]),
     "tsd_scan_wait": (C.c_int, [C.c_void_p]),
     "tsd_scan_finish": (C.c_int, [C.c_void_p, C.POINTER(ScanResult)]),
+    "tsd_batch_create": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "tsd_batch_destroy": (None, [C.c_void_p]),
+    "tsd_batch_capacity": (C.c_int, [C.c_void_p]),
+    "tsd_batch_inflight": (C.c_int, [C.c_void_p]),
+    "tsd_batch_begin": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(_dp), C.POINTER(_u8p), C.POINTER(_u8p),
+                                  C.POINTER(IcpParams), C.POINTER(GateParams)]),
+    "tsd_batch_push": (C.c_int, [C.c_void_p]),
+    "tsd_batch_poll": (C.c_int, [C.c_void_p]),
+    "tsd_batch_results": (C.c_int, [C.c_void_p, C.POINTER(ScanResult)]),
     "tsd_icp_trace": (C.c_int, [C.c_void_p, _dp, C.c_int]),
     "tsd_tsdpdf_match": (C.c_int, [C.c_void_p, _dp, _dp, _u8p, _dp, _u8p, C.c_int, C.POINTER(TsdPdfParams), _ip, _ip, _ip,
                                    C.POINTER(TsdPdfResult)]),
@@ -463,3 +472,58 @@ class TsdSensorDevice:
                                C.byref(gates), C.byref(r))
         self.grid._check(rc, "tsd_scan")
         return r
+
+
+class TsdBatch:
+    """One batch slot of the multi-robot path (``tsd_batch_*``): the scans of several sensors on one grid registered by one
+    launch of each kernel, their pushes applied in the order of the batch."""
+
+    def __init__(self, grid: TsdGridDevice, max_scans: int):
+        self.grid = grid
+        self.lib = grid.lib
+        self.h = self.lib.tsd_batch_create(grid.h, max_scans)
+        if not self.h:
+            raise TsdError("tsd_batch_create failed")
+        self._keep = None
+        self.n = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tsd_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def begin(self, sensors, ranges, masks, masks_push, params, gates):
+        """``params`` / ``gates``: one IcpParams / GateParams for all scans, or a list with one per scan."""
+        n = len(sensors)
+        rg = [_f64(r) for r in ranges]
+        mk = [np.ascontiguousarray(m, dtype=np.uint8) for m in masks]
+        mp = [np.ascontiguousarray(m, dtype=np.uint8) if m is not None else None for m in (masks_push or [None] * n)]
+        hs = (C.c_void_p * n)(*[s.h for s in sensors])
+        rp = (_dp * n)(*[_d(r) for r in rg])
+        mkp = (_u8p * n)(*[_u8(m) for m in mk])
+        mpp = (_u8p * n)(*[_u8(m) if m is not None else C.cast(None, _u8p) for m in mp])
+        pl = params if isinstance(params, (list, tuple)) else [params] * n
+        gl = gates if isinstance(gates, (list, tuple)) else [gates] * n
+        pa = (IcpParams * n)(*pl)
+        ga = (GateParams * n)(*gl)
+        self._keep = (rg, mk, mp)
+        self.grid._check(self.lib.tsd_batch_begin(self.h, n, hs, rp, mkp, mpp, pa, ga), "tsd_batch_begin")
+        self.n = n
+
+    def push(self):
+        self.grid._check(self.lib.tsd_batch_push(self.h), "tsd_batch_push")
+
+    def poll(self) -> bool:
+        return self.lib.tsd_batch_poll(self.h) == 1
+
+    def results(self):
+        out = (ScanResult * self.n)()
+        self.grid._check(self.lib.tsd_batch_results(self.h, out), "tsd_batch_results")
+        self._keep = None
+        return list(out)

@@ -4,6 +4,7 @@
 #include "tsd_ctx.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <chrono>
@@ -234,6 +235,25 @@ static bool host_saw_event(hipEvent_t ev, int us)
   }
 }
 
+// TSD_CONC_TIMING=1: host time spent inside the split-scan calls (wall clock, summed over all threads), printed by
+// tsd_destroy.  Diagnostic only.
+struct ConcTiming {
+  std::atomic<unsigned long long> ns[8];
+  std::atomic<unsigned long long> n;
+  bool on;
+  ConcTiming() : on(getenv("TSD_CONC_TIMING") != nullptr) { for (auto& v : ns) v = 0; n = 0; }
+};
+static ConcTiming g_conc_timing;
+static inline unsigned long long now_ns()
+{
+  return (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+struct ConcLap {
+  unsigned long long t;
+  ConcLap() : t(g_conc_timing.on ? now_ns() : 0) {}
+  void lap(int i) { if (g_conc_timing.on) { const unsigned long long u = now_ns(); g_conc_timing.ns[i] += u - t; t = u; } }
+};
+
 // every grid WRITE enqueued on the context's stream goes behind the ray casts the concurrent multi-robot path has in
 // flight on the sensors' own streams (no-op without such sensors)
 static int wait_for_readers(tsd_ctx* ctx)
@@ -249,6 +269,10 @@ static int wait_for_readers(tsd_ctx* ctx)
 #endif
     }
     TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, t->ev_rc_done, 0));
+  }
+  for (tsd_batch* bt : ctx->batches) {       // (their records are issued inside the ordered section: nothing to spin on)
+    if (!bt->rc_event_valid || bt->rc_ticket <= ctx->last_push_ticket) continue;
+    TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, bt->ev_rc_done, 0));
   }
   ctx->last_push_ticket = ctx->ticket;
   return TSD_OK;
@@ -352,7 +376,17 @@ tsd_ctx* tsd_create(int device, int map_size_log2, double cell_size, double max_
 void tsd_destroy(tsd_ctx* ctx)
 {
   if (!ctx) return;
+  if (g_conc_timing.on && g_conc_timing.n) {
+    const double n = (double)g_conc_timing.n;
+    static const char* names[8] = {"begin:copy+tables", "begin:lock", "begin:ordered", "begin:raycast+icp", "wait", "finish:lock", "finish:push", "finish:result"};
+    fprintf(stderr, "TSD_CONC_TIMING scans %.0f; host us per scan:", n);
+    for (int i = 0; i < 8; i++) fprintf(stderr, " %s %.1f", names[i], 1e-3 * (double)g_conc_timing.ns[i] / n);
+    fprintf(stderr, "\n");
+  }
   hipSetDevice(ctx->device);
+  // sensors and batch slots that outlive their grid are detached: their own destroy calls then only free what is theirs
+  for (tsd_batch* bt : ctx->batches) { if (bt->stream) hipStreamSynchronize(bt->stream); bt->ctx = nullptr; }
+  for (tsd_sensor* sn : ctx->sensors) { if (sn->stream) hipStreamSynchronize(sn->stream); sn->ctx = nullptr; }
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   drain_timers(ctx);
   GridDev& g = ctx->grid;
@@ -1058,7 +1092,7 @@ int tsd_sensor_set_pose(tsd_sensor* s, const double pose33[9], const double* ray
                         const double* rays_local_2xB)
 {
   if (s && s->ctx) s->ctx->epoch++;
-  if (!s || !pose33 || !rays_world_2xB || !rays_local_2xB) return TSD_E_ARG;
+  if (!s || !s->ctx || !pose33 || !rays_world_2xB || !rays_local_2xB) return TSD_E_ARG;
   tsd_ctx* ctx = s->ctx;
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const size_t nb = (size_t)s->beams;
@@ -1096,7 +1130,7 @@ int tsd_sensor_set_pose(tsd_sensor* s, const double pose33[9], const double* ray
 int tsd_scan(tsd_sensor* s, const double* ranges, const uint8_t* mask, const uint8_t* mask_push,
              const tsd_icp_params* params, const tsd_gate_params* gates, tsd_scan_result* result)
 {
-  if (!s || !ranges || !mask || !params || !gates || !result) return TSD_E_ARG;
+  if (!s || !s->ctx || !ranges || !mask || !params || !gates || !result) return TSD_E_ARG;
   tsd_ctx* ctx = s->ctx;
   if (!s->posed) return set_error(ctx, TSD_E_ARG, "tsd_scan before tsd_sensor_set_pose", hipSuccess);
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -1203,15 +1237,18 @@ int tsd_scan(tsd_sensor* s, const double* ranges, const uint8_t* mask, const uin
 // for every grid write enqueued before it, a push for every ray cast ticketed since the last grid write; registrations
 // overlap freely.  The push is enqueued only once its registration has finished: events order by ENQUEUE time, so a
 // push enqueued ahead of time would pull every later ray cast of every robot behind its own registration.
-static int sensor_conc_init(tsd_sensor* s)
+static int sensor_conc_init(tsd_sensor* s, bool own_stream = true)
 {
-  if (s->conc_ready) return TSD_OK;
   tsd_ctx* ctx = s->ctx;
-  const size_t nb = (size_t)s->beams;
   bool ok = true;
   auto A = [&](hipError_t e) { if (e != hipSuccess) ok = false; };
-  A(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-  for (hipEvent_t* e : {&s->ev_rc_done, &s->ev_icp_done}) A(hipEventCreateWithFlags(e, hipEventDisableTiming));
+  if (own_stream && !s->stream) {            // (a sensor that only ever runs in batches uses the batch's stream and events)
+    A(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    for (hipEvent_t* e : {&s->ev_rc_done, &s->ev_icp_done}) A(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    if (!ok) return set_error(ctx, TSD_E_HIP, "tsd_scan_begin: per-sensor stream", hipGetLastError());
+  }
+  if (s->conc_ready) return TSD_OK;
+  const size_t nb = (size_t)s->beams;
   A(hipMalloc(&s->d_coords, nb * 16)); A(hipMalloc(&s->d_normals, nb * 16)); A(hipMalloc(&s->d_mask_m, nb));
   A(hipMalloc(&s->d_icp_res, sizeof(IcpResultDev))); A(hipMalloc(&s->d_icp_trace, sizeof(double) * TSD_ICP_TRACE_STRIDE * TSD_ICP_TRACE_MAX));
   A(hipMalloc(&s->d_rmq2[0], push_rmq_bytes(s->beams))); A(hipMalloc(&s->d_rmq2[1], push_rmq_bytes(s->beams)));
@@ -1224,7 +1261,7 @@ static int sensor_conc_init(tsd_sensor* s)
 int tsd_scan_begin(tsd_sensor* s, const double* ranges, const uint8_t* mask, const uint8_t* mask_push,
                    const tsd_icp_params* params, const tsd_gate_params* gates)
 {
-  if (!s || !ranges || !mask || !params || !gates) return TSD_E_ARG;
+  if (!s || !s->ctx || !ranges || !mask || !params || !gates) return TSD_E_ARG;
   tsd_ctx* ctx = s->ctx;
   if (!s->posed) return set_error(ctx, TSD_E_ARG, "tsd_scan_begin before tsd_sensor_set_pose", hipSuccess);
   if (s->inflight) return set_error(ctx, TSD_E_ARG, "tsd_scan_begin: the previous scan of this sensor was not finished", hipSuccess);
@@ -1232,6 +1269,7 @@ int tsd_scan_begin(tsd_sensor* s, const double* ranges, const uint8_t* mask, con
   int rc = sensor_conc_init(s);
   if (rc != TSD_OK) return rc;
   const size_t nb = (size_t)s->beams;
+  ConcLap lap;
   // the scan: ranges | mask | mask_push through the sensor's own pinned buffer (the buffer two scans back is free: its
   // copy was waited for by that scan's registration)
   char* h = s->h_stage2[s->scan_slot];
@@ -1254,15 +1292,18 @@ int tsd_scan_begin(tsd_sensor* s, const double* ranges, const uint8_t* mask, con
   TargetScope scope(ctx, &tg);
   rc = launch_push_tables(ctx, s->stream, s->beams, d_ranges, d_mask_push, s->phi_min, s->ang_res);
   if (rc != TSD_OK) return rc;
+  lap.lap(0);
   {
     // ORDERED SECTION (the only part of begin that other robots' threads wait for): the ray cast reads the grid, so it
     // goes behind every grid write enqueued so far, and takes its place in the order for the writes that follow
     std::lock_guard<std::mutex> lk(ctx->order_mutex);
+    lap.lap(1);
     TSD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_grid, ctx->stream));
     TSD_HIP_CHECK(ctx, hipStreamWaitEvent(s->stream, ctx->ev_grid, 0));
     __atomic_store_n(&s->rc_recorded, 0, __ATOMIC_RELEASE);
     s->rc_ticket = ++ctx->ticket;
     s->rc_event_valid = true;
+    lap.lap(2);
   }
   RaycastArgs ra;
   std::memset(&ra, 0, sizeof(ra));
@@ -1288,6 +1329,7 @@ int tsd_scan_begin(tsd_sensor* s, const double* ranges, const uint8_t* mask, con
   TSD_HIP_CHECK(ctx, hipEventRecord(s->ev_icp_done, s->stream));
   s->conc_gates = *gates; s->conc_ranges = d_ranges; s->conc_mask_push = d_mask_push;
   s->inflight = true;
+  lap.lap(3);
   return TSD_OK;
 }
 
@@ -1310,12 +1352,14 @@ int tsd_scan_wait(tsd_sensor* s)
 
 int tsd_scan_finish(tsd_sensor* s, tsd_scan_result* result)
 {
-  if (!s || !result || !s->inflight) return TSD_E_ARG;
+  if (!s || !s->ctx || !result || !s->inflight) return TSD_E_ARG;
   tsd_ctx* ctx = s->ctx;
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  ConcLap lap;
   int rc = tsd_scan_wait(s);
   if (rc != TSD_OK) return set_error(ctx, TSD_E_HIP, "tsd_scan_finish: result record never arrived", hipSuccess);
   s->inflight = false;
+  lap.lap(4);
   {
     // ORDERED SECTION: the push on the grid stream -- enqueued only now, when the registration has finished, so it
     // never sits on the grid stream waiting for it while other robots' pushes and ray casts queue up behind (events
@@ -1323,6 +1367,7 @@ int tsd_scan_finish(tsd_sensor* s, tsd_scan_result* result)
     // registration and serialise the robots; measured: 3.7 k scans/s for any N).  Behind the ray casts ticketed since
     // the last grid write.
     std::lock_guard<std::mutex> lk_order(ctx->order_mutex);
+    lap.lap(5);
     TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, s->ev_icp_done, 0));
     if (int rcw = wait_for_readers(ctx)) return rcw;
     PushArgs pa;
@@ -1336,12 +1381,227 @@ int tsd_scan_finish(tsd_sensor* s, tsd_scan_result* result)
     rc = launch_push(ctx, pa, s->pos[0], s->pos[1], s->conc_gates.reg_trs_max, &s->d_state->push, s->conc_ranges, s->conc_mask_push);
     if (rc != TSD_OK) return rc;
     ctx->epoch++;
+    lap.lap(6);
   }
   copy_icp_result(&s->h_result->icp, &result->icp);
   for (int i = 0; i < 9; i++) result->pose[i] = s->h_result->pose[i];
   s->pos[0] = result->pose[2]; s->pos[1] = result->pose[5];
   result->reg_error = s->h_result->reg_error; result->pushed = s->h_result->pushed;
   result->no_model = s->h_result->no_model; result->reserved = 0;
+  lap.lap(7); g_conc_timing.n++;
+  return TSD_OK;
+}
+
+// ------------------------------------------------------------------ batched multi-robot scans (one shared grid)
+// The split scan above gives every robot its own stream; HIP multiplexes streams onto a few in-order hardware queues, so with
+// more than two or three robots a 0.17 ms registration blocks whatever shares its queue (measured: the time from begin to the
+// result record grows from 0.19 ms at two robots to 0.8 ms at eight while the host calls stay at 0.1 ms per scan).  A batch
+// does the robots that have a scan pending in ONE launch of each kernel on the batch's own stream -- tables (workgroup =
+// scan), ray casts (block row = sensor), registrations (workgroup = robot, one compute unit each) -- and their pushes one
+// after the other on the grid's stream.  Two or three batch slots used in turn keep the device busy with three or four streams
+// in total: while one batch registers, the other one's pushes run.  All ray casts of a batch see the same grid state, the
+// pushes follow in the order of the batch: one of the interleavings the reference's N ThreadLocalize + one ThreadMapping
+// threads can produce.  tsd_batch_push may be called before the registrations have finished (the pushes are gated on the
+// device like tsd_scan's); a ray cast enqueued later waits for it, one enqueued earlier does not.
+static inline size_t align64(size_t v) { return (v + 63u) & ~(size_t)63u; }
+
+tsd_batch* tsd_batch_create(tsd_ctx* ctx, int max_scans)
+{
+  if (!ctx || max_scans < 1 || max_scans > TSD_BATCH_MAX_SCANS) return nullptr;
+  if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+  tsd_batch* b = new (std::nothrow) tsd_batch();
+  if (!b) return nullptr;
+  b->ctx = ctx; b->max_scans = max_scans;
+  b->head_bytes = align64((size_t)max_scans * sizeof(IcpBatchEntry)) + align64((size_t)max_scans * sizeof(RaycastBatchEntry)) +
+                  align64((size_t)max_scans * sizeof(TablesBatchEntry));
+  b->scan_bytes = align64((size_t)TSD_MAX_BEAMS * 10);
+  const size_t bytes = b->head_bytes + (size_t)max_scans * b->scan_bytes;
+  bool ok = true;
+  auto A = [&](hipError_t e) { if (e != hipSuccess) ok = false; };
+  A(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+  for (hipEvent_t* e : {&b->ev_rc_done, &b->ev_icp_done}) A(hipEventCreateWithFlags(e, hipEventDisableTiming));
+  A(hipHostMalloc(&b->h_stage, bytes, hipHostMallocDefault));
+  A(hipMalloc(&b->d_stage2[0], bytes)); A(hipMalloc(&b->d_stage2[1], bytes));
+  if (!ok) { set_error(ctx, TSD_E_HIP, "tsd_batch_create", hipGetLastError()); tsd_batch_destroy(b); return nullptr; }
+  std::lock_guard<std::mutex> lk(ctx->order_mutex);
+  ctx->batches.push_back(b);
+  return b;
+}
+
+void tsd_batch_destroy(tsd_batch* b)
+{
+  if (!b) return;
+  if (b->ctx) {
+    hipSetDevice(b->ctx->device);
+    if (b->stream) hipStreamSynchronize(b->stream);
+    hipStreamSynchronize(b->ctx->stream);
+    std::lock_guard<std::mutex> lk(b->ctx->order_mutex);
+    auto& v = b->ctx->batches;
+    v.erase(std::remove(v.begin(), v.end(), b), v.end());
+  }
+  for (tsd_sensor* s : b->sensors) if (s) s->inflight = false;
+  for (hipEvent_t e : {b->ev_rc_done, b->ev_icp_done}) if (e) hipEventDestroy(e);
+  if (b->stream) hipStreamDestroy(b->stream);
+  if (b->h_stage) hipHostFree(b->h_stage);
+  hipFree(b->d_stage2[0]); hipFree(b->d_stage2[1]);
+  delete b;
+}
+
+int tsd_batch_capacity(const tsd_batch* b) { return b ? b->max_scans : 0; }
+int tsd_batch_inflight(const tsd_batch* b) { return b ? b->n : 0; }
+
+int tsd_batch_begin(tsd_batch* b, int n, tsd_sensor* const* sensors, const double* const* ranges, const uint8_t* const* mask,
+                    const uint8_t* const* mask_push, const tsd_icp_params* params, const tsd_gate_params* gates)
+{
+  if (!b || !b->ctx || n < 1 || !sensors || !ranges || !mask || !params || !gates) return TSD_E_ARG;
+  tsd_ctx* ctx = b->ctx;
+  if (n > b->max_scans) return set_error(ctx, TSD_E_CAPACITY, "tsd_batch_begin: more scans than the batch was created for", hipSuccess);
+  if (b->n) return set_error(ctx, TSD_E_ARG, "tsd_batch_begin: the previous batch of this slot was not collected (tsd_batch_results)", hipSuccess);
+  for (int i = 0; i < n; i++) {
+    tsd_sensor* s = sensors[i];
+    if (!s || s->ctx != ctx || !ranges[i] || !mask[i]) return set_error(ctx, TSD_E_ARG, "tsd_batch_begin: sensor / scan", hipSuccess);
+    if (!s->posed) return set_error(ctx, TSD_E_ARG, "tsd_batch_begin before tsd_sensor_set_pose", hipSuccess);
+    if (s->inflight) return set_error(ctx, TSD_E_ARG, "tsd_batch_begin: a sensor has a scan in flight already", hipSuccess);
+    for (int j = 0; j < i; j++) if (sensors[j] == s) return set_error(ctx, TSD_E_ARG, "tsd_batch_begin: a sensor appears twice", hipSuccess);
+  }
+  TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  for (int i = 0; i < n; i++) if (int rc = sensor_conc_init(sensors[i], false)) return rc;
+
+  // staging: [registration entries | ray-cast entries | tables entries | scan 0 | scan 1 ...], one copy for all of it, into the
+  // device buffer the previous batch of this slot does not use (its pushes may still be reading their scans)
+  b->stage_slot ^= 1;
+  char* const d_base = b->d_stage2[b->stage_slot];
+  char* const h_base = b->h_stage;
+  IcpBatchEntry* h_icp = reinterpret_cast<IcpBatchEntry*>(h_base);
+  const size_t off_rc = align64((size_t)b->max_scans * sizeof(IcpBatchEntry));
+  const size_t off_tb = off_rc + align64((size_t)b->max_scans * sizeof(RaycastBatchEntry));
+  RaycastBatchEntry* h_rc = reinterpret_cast<RaycastBatchEntry*>(h_base + off_rc);
+  TablesBatchEntry* h_tb = reinterpret_cast<TablesBatchEntry*>(h_base + off_tb);
+  b->sensors.assign(sensors, sensors + n);
+  b->seqs.resize((size_t)n); b->gates.assign(gates, gates + n); b->scan_off.resize((size_t)n);
+  size_t off = b->head_bytes;
+  int max_beams = 0;
+  const double ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  for (int i = 0; i < n; i++) {
+    tsd_sensor* s = sensors[i];
+    const size_t nb = (size_t)s->beams;
+    if (s->beams > max_beams) max_beams = s->beams;
+    char* h = h_base + off;
+    std::memcpy(h, ranges[i], nb * 8);
+    std::memcpy(h + nb * 8, mask[i], nb);
+    std::memcpy(h + nb * 9, (mask_push && mask_push[i]) ? mask_push[i] : mask[i], nb);
+    const double* d_ranges = reinterpret_cast<const double*>(d_base + off);
+    const uint8_t* d_mask = reinterpret_cast<const uint8_t*>(d_base + off + nb * 8);
+    const uint8_t* d_mask_push = reinterpret_cast<const uint8_t*>(d_base + off + nb * 9);
+    b->scan_off[(size_t)i] = off;
+    off += align64(nb * 10);
+    s->rmq_slot ^= 1;                       // (the previous push of this sensor may still read its tables)
+    h_tb[i] = TablesBatchEntry{d_ranges, d_mask_push, s->d_rmq2[s->rmq_slot], s->phi_min, s->ang_res, s->beams, 0};
+    h_rc[i] = RaycastBatchEntry{&s->d_state->rc, s->d_rays, s->d_coords, s->d_normals, s->d_mask_m};
+    IcpBatchEntry& e = h_icp[i];
+    std::memset(&e, 0, sizeof(e));
+    fill_icp_args(e.a, ident, &params[i]);
+    e.a.beams = s->beams; e.a.ccw = s->ccw ? 1 : 0;
+    e.P_dev = s->d_state->icpP; e.coords = s->d_coords; e.mask_m = s->d_mask_m; e.rays_local = s->d_rays_local;
+    e.ranges = d_ranges; e.mask = d_mask; e.out = s->d_icp_res; e.trace = s->d_icp_trace; e.normals = s->d_normals;
+    const unsigned long long seq = ++s->seq;
+    b->seqs[(size_t)i] = seq;
+    e.post.st = s->d_state; e.post.rays = s->d_rays; e.post.out = s->d_result; e.post.seq = seq; e.post.beams = s->beams;
+    e.post.gmin_x = ctx->grid.min_x; e.post.gmax_x = ctx->grid.max_x; e.post.gmin_y = ctx->grid.min_y; e.post.gmax_y = ctx->grid.max_y;
+    e.post.gates = GateArgs{gates[i].reg_trs_max, gates[i].reg_sin_rot_max, gates[i].trs_min, gates[i].rot_min};
+  }
+  TSD_HIP_CHECK(ctx, hipMemcpyAsync(d_base, h_base, off, hipMemcpyHostToDevice, b->stream));
+  b->d_stage_cur = d_base;
+  int rc = launch_push_tables_batch(ctx, b->stream, reinterpret_cast<const TablesBatchEntry*>(d_base + off_tb), n, max_beams);
+  if (rc != TSD_OK) return rc;
+  {
+    // ORDERED SECTION: the ray casts read the grid, so they go behind every grid write enqueued so far and take their place in
+    // the order for the writes that follow
+    std::lock_guard<std::mutex> lk(ctx->order_mutex);
+    TSD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_grid, ctx->stream));
+    TSD_HIP_CHECK(ctx, hipStreamWaitEvent(b->stream, ctx->ev_grid, 0));
+    rc = launch_raycast_batch(ctx, b->stream, reinterpret_cast<const RaycastBatchEntry*>(d_base + off_rc), n, max_beams);
+    if (rc != TSD_OK) return rc;
+    TSD_HIP_CHECK(ctx, hipEventRecord(b->ev_rc_done, b->stream));
+    b->rc_ticket = ++ctx->ticket;
+    b->rc_event_valid = true;
+  }
+  rc = launch_icp_batch(ctx, b->stream, h_icp, reinterpret_cast<const IcpBatchEntry*>(d_base), n);
+  if (rc != TSD_OK) return rc;
+  TSD_HIP_CHECK(ctx, hipEventRecord(b->ev_icp_done, b->stream));
+  for (int i = 0; i < n; i++) { sensors[i]->inflight = true; sensors[i]->rc_pending = false; }
+  b->n = n; b->push_enqueued = false;
+  return TSD_OK;
+}
+
+int tsd_batch_push(tsd_batch* b)
+{
+  if (!b || !b->ctx) return TSD_E_ARG;
+  if (!b->n || b->push_enqueued) return TSD_OK;
+  tsd_ctx* ctx = b->ctx;
+  TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  std::lock_guard<std::mutex> lk_order(ctx->order_mutex);
+  TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, b->ev_icp_done, 0));
+  if (int rcw = wait_for_readers(ctx)) return rcw;
+  for (int i = 0; i < b->n; i++) {
+    tsd_sensor* s = b->sensors[(size_t)i];
+    const size_t nb = (size_t)s->beams;
+    PushArgs pa;
+    std::memset(&pa, 0, sizeof(pa));
+    pa.beams = s->beams;
+    pa.max_range = s->max_range;
+    LaunchTarget tg;
+    tg.rmq = s->d_rmq2[s->rmq_slot];
+    TargetScope scope(ctx, &tg);
+    const char* d_scan = b->d_stage_cur + b->scan_off[(size_t)i];
+    // the registration moves the sensor by at most the gate (a larger step is rejected: pose unchanged); s->pos is the
+    // position after the previous scan, which the host has seen
+    int rc = launch_push(ctx, pa, s->pos[0], s->pos[1], b->gates[(size_t)i].reg_trs_max, &s->d_state->push,
+                         reinterpret_cast<const double*>(d_scan), reinterpret_cast<const uint8_t*>(d_scan + nb * 9));
+    if (rc != TSD_OK) return rc;
+  }
+  ctx->epoch++;
+  b->push_enqueued = true;
+  return TSD_OK;
+}
+
+int tsd_batch_poll(tsd_batch* b)
+{
+  if (!b) return TSD_E_ARG;
+  for (int i = 0; i < b->n; i++)
+    if (__atomic_load_n(&b->sensors[(size_t)i]->h_result->seq, __ATOMIC_ACQUIRE) != b->seqs[(size_t)i]) return 0;
+  return 1;
+}
+
+int tsd_batch_results(tsd_batch* b, tsd_scan_result* results)
+{
+  if (!b || !b->ctx || !results) return TSD_E_ARG;
+  tsd_ctx* ctx = b->ctx;
+  if (!b->n) return set_error(ctx, TSD_E_ARG, "tsd_batch_results without tsd_batch_begin", hipSuccess);
+  unsigned long long spins = 0;
+  while (tsd_batch_poll(b) != 1) {
+    if (++spins > 4000000ull) {              // something is wrong: a real wait on the batch's stream
+      if (hipStreamSynchronize(b->stream) != hipSuccess || tsd_batch_poll(b) != 1)
+        return set_error(ctx, TSD_E_HIP, "tsd_batch_results: result records never arrived", hipSuccess);
+      break;
+    }
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+  int rc = tsd_batch_push(b);               // (no-op when the caller enqueued the pushes ahead of the results)
+  if (rc != TSD_OK) return rc;
+  for (int i = 0; i < b->n; i++) {
+    tsd_sensor* s = b->sensors[(size_t)i];
+    tsd_scan_result* r = &results[i];
+    copy_icp_result(&s->h_result->icp, &r->icp);
+    for (int k = 0; k < 9; k++) r->pose[k] = s->h_result->pose[k];
+    s->pos[0] = r->pose[2]; s->pos[1] = r->pose[5];
+    r->reg_error = s->h_result->reg_error; r->pushed = s->h_result->pushed;
+    r->no_model = s->h_result->no_model; r->reserved = 0;
+    s->inflight = false;
+  }
+  b->n = 0;
   return TSD_OK;
 }
 

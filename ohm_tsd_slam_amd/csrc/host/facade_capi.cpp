@@ -1,11 +1,14 @@
 // facade_capi.cpp -- a flat C surface over the C++ facade so that the Python test / bench drivers can
 // exercise ThreadLocalize / ThreadMapping exactly as SlamNode wires them (SlamNode.cpp:27-129): one
 // TsdGrid, one ThreadMapping, N ThreadLocalize sharing them, laser callbacks per robot.
+#include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "ThreadLocalize.h"
@@ -133,6 +136,13 @@ int tsd_node_initialize(tsd_node* n, int device)
     }
   }
   n->submitted.assign(n->localizers.size(), 0);
+  // several robots on one grid: their scans go through the grid's dispatcher as batched launches (TSD_NO_BATCH: the split
+  // scan on one stream per robot instead; TSD_BATCH_SLOTS: batch slots used in turn, default 2 -- A/B switches for measurements)
+  if(n->localizers.size() > 1 && !std::getenv("TSD_NO_CONCURRENT") && !std::getenv("TSD_NO_BATCH"))
+  {
+    const char* e = std::getenv("TSD_BATCH_SLOTS");
+    n->grid->enableBatchedScans((int)n->localizers.size(), e ? std::atoi(e) : 2);
+  }
   for(auto* l : n->localizers)
   {
     l->setSynchronous(n->synchronous);
@@ -170,6 +180,38 @@ int tsd_node_laser(tsd_node* n, int robot, const float* ranges, int count, doubl
   scan->header.stamp.nanosec = (uint32_t)(stamp_ns % 1000000000LL);
   n->localizers[robot]->laserCallBack(scan);
   return TSD_OK;
+}
+
+// Replay of recorded scans, the way `rosbag play` feeds the reference node: one publisher thread per robot, each handing
+// its robot's scans to laserCallBack in order (synchronous facade: the callback returns when the scan has been processed, so
+// every robot runs as fast as the node lets it and the robots' scans overlap).  scans[r] = n_scans x count floats.
+int tsd_node_play(tsd_node* n, int robots, const float* const* scans, int first, int n_scans, int count, double angle_min,
+                  double angle_increment, long long stamp0_ns, long long stamp_step_ns)
+{
+  if(!n || robots < 1 || robots > (int)n->localizers.size() || !scans || n_scans < 0 || first < 0)
+    return TSD_E_ARG;
+  std::vector<std::thread> pubs;
+  std::atomic<int> failed{0};
+  for(int r = 0; r < robots; r++)
+    pubs.emplace_back([&, r] {
+      for(int k = first; k < first + n_scans; k++)
+        if(tsd_node_laser(n, r, scans[r] + (size_t)k * (size_t)count, count, angle_min, angle_increment,
+                          stamp0_ns + (long long)k * stamp_step_ns) != TSD_OK)
+          failed++;
+    });
+  for(auto& t : pubs)
+    t.join();
+  return failed ? TSD_E_ARG : TSD_OK;
+}
+
+// multi-robot dispatcher: batches begun and scans they carried (0, 0 without a dispatcher)
+void tsd_node_batch_stats(tsd_node* n, unsigned long long* batches, unsigned long long* scans)
+{
+  obvious::ScanBatcher::Stats st;
+  if(n && n->grid && n->grid->batcher())
+    st = n->grid->batcher()->stats();
+  if(batches) *batches = st.batches;
+  if(scans) *scans = st.scans;
 }
 
 // asynchronous mode: wait until the localiser has nothing queued, the mapping queue is drained and

@@ -4,6 +4,7 @@
 #include <ctime>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 
 namespace obvious {
@@ -248,6 +249,7 @@ TsdGrid::TsdGrid(double cellSize, EnumTsdGridLayout layoutPartition, EnumTsdGrid
 
 TsdGrid::~TsdGrid()
 {
+  _batcher.reset();                    // (stops the dispatcher thread and frees its batch slots while the context still exists)
   std::lock_guard<std::mutex> lk(_mutex);
   tsd_destroy(_ctx);
   _ctx = nullptr;
@@ -344,9 +346,19 @@ int TsdGrid::scan(SensorPolar2D* sensor, const uint8_t* maskPush, const tsd_icp_
   return rc;
 }
 
+void TsdGrid::enableBatchedScans(int robots, int slots)
+{
+  if (!_batcher && _ctx && robots > 1) _batcher.reset(new ScanBatcher(_ctx, robots, slots));
+}
+
 int TsdGrid::scanConcurrent(SensorPolar2D* sensor, const uint8_t* maskPush, const tsd_icp_params& params,
                             const tsd_gate_params& gates, tsd_scan_result* result)
 {
+  if (_batcher) {
+    const int rc = _batcher->scan(sensor->deviceHandle(), sensor->getRealMeasurementData(), sensor->maskBytes(), maskPush, params, gates, result);
+    if (rc == TSD_OK && result->pushed) _initialPushAccomplished = true;
+    return rc;
+  }
   // both halves run on this robot's thread without the facade's grid mutex: the C ABI orders the robots' ray casts and
   // pushes internally (ctx->order_mutex) and the sensor's private stream is this thread's alone
   int rc = tsd_scan_begin(sensor->deviceHandle(), sensor->getRealMeasurementData(), sensor->maskBytes(), maskPush, &params, &gates);
@@ -354,6 +366,183 @@ int TsdGrid::scanConcurrent(SensorPolar2D* sensor, const uint8_t* maskPush, cons
   rc = tsd_scan_finish(sensor->deviceHandle(), result);     // waits for the registration (other robots run meanwhile), then the push
   if (rc == TSD_OK && result->pushed) _initialPushAccomplished = true;
   return rc;
+}
+
+// --------------------------------------------------------------------------------------- ScanBatcher
+static inline long long steady_ns()
+{
+  return (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+static inline void cpu_relax()
+{
+#if defined(__x86_64__)
+  __builtin_ia32_pause();
+#endif
+}
+
+ScanBatcher::ScanBatcher(tsd_ctx* ctx, int robots, int slots) : _ctx(ctx), _stop(false)
+{
+  if (slots < 1) slots = 1;
+  if (slots > robots) slots = robots;
+  _cap = (robots + slots - 1) / slots;
+  // how long a batch waits for the other robots that are about to hand their next scan in (those whose previous scan came in
+  // less than 2 ms ago); robots scanning at sensor rate never make anybody wait
+  const char* e = std::getenv("TSD_BATCH_LINGER_US");
+  _lingerNs = 1000ll * (e ? std::atol(e) : 120);
+  _slots.resize((size_t)slots);
+  for (auto& sl : _slots) sl.b = tsd_batch_create(ctx, _cap);
+  _thread = std::thread([this] { run(); });
+}
+
+ScanBatcher::~ScanBatcher()
+{
+  {
+    std::lock_guard<std::mutex> lk(_m);
+    _stop = true;
+  }
+  _cvWork.notify_all();
+  if (_thread.joinable()) _thread.join();
+  for (auto& sl : _slots) tsd_batch_destroy(sl.b);
+}
+
+ScanBatcher::Stats ScanBatcher::stats()
+{
+  std::lock_guard<std::mutex> lk(_m);
+  return _stats;
+}
+
+int ScanBatcher::scan(tsd_sensor* s, const double* ranges, const uint8_t* mask, const uint8_t* maskPush, const tsd_icp_params& params,
+                      const tsd_gate_params& gates, tsd_scan_result* result)
+{
+  Request r;
+  r.s = s; r.ranges = ranges; r.mask = mask; r.maskPush = maskPush; r.params = params; r.gates = gates; r.result = result;
+  r.t_submit = steady_ns();
+  {
+    std::lock_guard<std::mutex> lk(_m);
+    if (_stop) return TSD_E_ARG;
+    _pending.push_back(&r);
+    bool known = false;
+    for (auto& ls : _lastSubmit) if (ls.first == s) { ls.second = r.t_submit; known = true; }
+    if (!known) _lastSubmit.emplace_back(s, r.t_submit);
+  }
+  _cvWork.notify_one();
+  // a round of batched registrations takes ~0.4 ms: spin for a few of those before sleeping (the wake-up of a sleeping
+  // thread costs 50 us and more, and a robot that comes back late misses its batch)
+  const long long t_spin_end = r.t_submit + 2000000;
+  while (!r.done.load(std::memory_order_acquire)) {
+    if (steady_ns() > t_spin_end) {
+      std::unique_lock<std::mutex> lk(_m);
+      _cvDone.wait(lk, [&] { return r.done.load(std::memory_order_acquire) != 0; });
+      break;
+    }
+    cpu_relax();
+  }
+  return r.rc;
+}
+
+void ScanBatcher::complete(Request* r, int rc)
+{
+  r->rc = rc;
+  r->done.store(1, std::memory_order_release);      // (the request lives on its thread's stack: not touched after this)
+}
+
+void ScanBatcher::run()
+{
+  std::vector<tsd_sensor*> sensors; std::vector<const double*> ranges; std::vector<const uint8_t*> mask, maskPush;
+  std::vector<tsd_icp_params> params; std::vector<tsd_gate_params> gates; std::vector<tsd_scan_result> results;
+  long long t_last_free = 0;                           // when the latest batch was handed out
+  unsigned long long begun = 0;                        // batches begun so far; the oldest batch in flight is collected first
+  std::vector<size_t> by_age(_slots.size());
+  for (;;) {
+    bool progress = false;
+    // 1. batches whose result records have arrived: enqueue their pushes (unless that happened already), hand the results out
+    for (size_t k = 0; k < _slots.size(); k++) by_age[k] = k;
+    std::sort(by_age.begin(), by_age.end(), [&](size_t x, size_t y) { return _slots[x].order < _slots[y].order; });
+    for (size_t k = 0; k < _slots.size(); k++) {
+      Slot& sl = _slots[by_age[k]];
+      if (sl.reqs.empty() || tsd_batch_poll(sl.b) != 1) continue;
+      results.resize(sl.reqs.size());
+      const int rc = tsd_batch_results(sl.b, results.data());
+      {
+        std::lock_guard<std::mutex> lk(_m);           // (pairs with the sleepers' predicate check)
+        for (size_t i = 0; i < sl.reqs.size(); i++) {
+          if (rc == TSD_OK) *sl.reqs[i]->result = results[i];
+          complete(sl.reqs[i], rc);
+        }
+        sl.reqs.clear();
+      }
+      _cvDone.notify_all();
+      t_last_free = steady_ns();
+      progress = true;
+    }
+    // 2. a free slot and scans pending: begin a batch
+    Slot* free_slot = nullptr;
+    size_t free_idx = 0;
+    for (size_t k = 0; k < _slots.size() && !free_slot; k++) if (_slots[k].reqs.empty()) { free_slot = &_slots[k]; free_idx = k; }
+    bool any_inflight = false;
+    for (auto& sl : _slots) any_inflight = any_inflight || !sl.reqs.empty();
+    if (free_slot) {
+      std::unique_lock<std::mutex> lk(_m);
+      if (_stop && _pending.empty() && !any_inflight) return;
+      if (_pending.empty() && !any_inflight) {         // idle: sleep until a scan comes in
+        _cvWork.wait(lk, [&] { return _stop || !_pending.empty(); });
+        if (_stop && _pending.empty()) return;
+      }
+      if (!_pending.empty()) {
+        const long long now = steady_ns();
+        // (a batch that has just been handed out brings its robots back within the linger time: count it from then, or the
+        // scans that were waiting for the slot leave without them and the batches stay small for good)
+        const long long since = std::max(_pending.front()->t_submit, t_last_free);
+        bool go = (int)_pending.size() >= _cap || now - since > _lingerNs;
+        if (!go) {
+          // robots that are about to come back: their previous scan came in less than 2 ms ago and they are neither pending
+          // nor in flight.  Nobody like that: no reason to wait.
+          int expected = 0;
+          for (auto& ls : _lastSubmit) {
+            if (now - ls.second > 2000000) continue;
+            bool busy = false;
+            for (Request* r : _pending) busy = busy || r->s == ls.first;
+            for (auto& sl : _slots) for (Request* r : sl.reqs) busy = busy || r->s == ls.first;
+            if (!busy) expected++;
+          }
+          go = expected == 0;
+        }
+        if (go) {
+          const size_t n = std::min(_pending.size(), (size_t)_cap);
+          free_slot->reqs.assign(_pending.begin(), _pending.begin() + (long)n);
+          _pending.erase(_pending.begin(), _pending.begin() + (long)n);
+          _stats.batches++; _stats.scans += n;
+        }
+      }
+      lk.unlock();
+      if (!free_slot->reqs.empty()) {
+        const size_t n = free_slot->reqs.size();
+        sensors.resize(n); ranges.resize(n); mask.resize(n); maskPush.resize(n); params.resize(n); gates.resize(n);
+        for (size_t i = 0; i < n; i++) {
+          Request* r = free_slot->reqs[i];
+          sensors[i] = r->s; ranges[i] = r->ranges; mask[i] = r->mask; maskPush[i] = r->maskPush; params[i] = r->params; gates[i] = r->gates;
+        }
+        const int rc = tsd_batch_begin(free_slot->b, (int)n, sensors.data(), ranges.data(), mask.data(), maskPush.data(), params.data(), gates.data());
+        if (rc != TSD_OK) {
+          {
+            std::lock_guard<std::mutex> lk2(_m);
+            for (Request* r : free_slot->reqs) complete(r, rc);
+            free_slot->reqs.clear();
+          }
+          _cvDone.notify_all();
+        } else {
+          // the other slots' pushes go right behind this begin: this batch's ray casts do not wait for them
+          free_slot->order = ++begun;
+          for (size_t k = 0; k < _slots.size(); k++) {
+            const size_t j = by_age[k];
+            if (j != free_idx && !_slots[j].reqs.empty()) tsd_batch_push(_slots[j].b);
+          }
+        }
+        progress = true;
+      }
+    }
+    if (!progress) cpu_relax();
+  }
 }
 
 // --------------------------------------------------------------------------------------- TSD_PDFMatching

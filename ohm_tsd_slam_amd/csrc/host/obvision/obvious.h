@@ -9,7 +9,12 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <memory>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "tsd_hip.h"
@@ -104,6 +109,45 @@ enum EnumTsdGridLayout { LAYOUT_1x1 = 0, LAYOUT_2x2 = 1, LAYOUT_4x4 = 2, LAYOUT_
   LAYOUT_1024x1024 = 10, LAYOUT_2048x2048 = 11, LAYOUT_4096x4096 = 12, LAYOUT_8192x8192 = 13,
   LAYOUT_16384x16384 = 14, LAYOUT_36768x36768 = 15 };   // TsdGrid.h:11-26
 
+// Dispatcher of the multi-robot mode (addition; the reference runs N ThreadLocalize workers against one TsdGrid and lets the
+// scheduler interleave them, SlamNode.cpp:101-122).  The robots' threads hand their scans in and block; ONE dispatcher thread
+// groups the scans that are pending into batches (tsd_batch_*: one launch of each kernel for all robots of the batch) and
+// uses two batch slots in turn, so that one batch registers while the other one's pushes run.  The pushes of a slot are
+// enqueued right behind the NEXT begin of the other slot (or when the slot's results have been seen, whichever comes
+// first): the other slot's ray casts then do not wait for them, and the slot's own next ray casts do.
+class ScanBatcher
+{
+public:
+  ScanBatcher(tsd_ctx* ctx, int robots, int slots);
+  ~ScanBatcher();
+  /** blocking: returns when the registration of this scan has finished (its push is enqueued in stream order) */
+  int scan(tsd_sensor* s, const double* ranges, const uint8_t* mask, const uint8_t* maskPush, const tsd_icp_params& params,
+           const tsd_gate_params& gates, tsd_scan_result* result);
+  struct Stats { unsigned long long batches = 0, scans = 0; };
+  Stats stats();
+private:
+  struct Request {
+    tsd_sensor* s; const double* ranges; const uint8_t* mask; const uint8_t* maskPush;
+    tsd_icp_params params; tsd_gate_params gates; tsd_scan_result* result;
+    int rc = 0; std::atomic<int> done{0};
+    long long t_submit = 0;
+  };
+  struct Slot { tsd_batch* b = nullptr; std::vector<Request*> reqs; unsigned long long order = 0; };
+  void run();
+  void complete(Request* r, int rc);
+  tsd_ctx* _ctx;
+  int _cap;
+  long long _lingerNs;
+  std::vector<Slot> _slots;
+  std::deque<Request*> _pending;
+  std::vector<std::pair<tsd_sensor*, long long>> _lastSubmit;    // per sensor: when its latest scan came in
+  std::mutex _m;
+  std::condition_variable _cvWork, _cvDone;
+  bool _stop;
+  Stats _stats;
+  std::thread _thread;
+};
+
 // obvious::TsdGrid: the handle of a grid that lives in HBM.  Only LAYOUT_32x32 partitions exist
 // (SlamNode.cpp:77 hard-codes it).  Every device call of this grid is serialised by mutex().
 class TsdGrid
@@ -150,10 +194,15 @@ public:
   virtual int scanConcurrent(SensorPolar2D* sensor, const uint8_t* maskPush, const tsd_icp_params& params,
                              const tsd_gate_params& gates, tsd_scan_result* result);
 
+  /** multi-robot mode: route scanConcurrent through a ScanBatcher (batched launches, `slots` batch slots used in turn) */
+  void enableBatchedScans(int robots, int slots = 2);
+  ScanBatcher* batcher() { return _batcher.get(); }
+
   tsd_ctx* context() { return _ctx; }
   std::mutex& mutex() { return _mutex; }
 protected:
   tsd_ctx* _ctx;
+  std::unique_ptr<ScanBatcher> _batcher;
   std::mutex _mutex;
   bool _initialPushAccomplished;
 };

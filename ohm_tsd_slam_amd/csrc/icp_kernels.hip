@@ -439,14 +439,16 @@ __device__ __forceinline__ void block_totals(const IcpLds& L, const double (&v)[
   cnt_total = (int)bc[NSUM];
 }
 
+// the whole registration of one workgroup; k_icp (one registration per launch) and k_icp_batch (workgroup x = registration x
+// of a batch) are thin wrappers
 template <int R, int MAXT, bool PTL>
-__global__ void __launch_bounds__(MAXT)
-k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __restrict__ g_model, const double* __restrict__ g_scene,
+__device__ __forceinline__ void
+icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __restrict__ g_model, const double* __restrict__ g_scene,
       const int* __restrict__ g_morig, const int* __restrict__ g_start,
       const double* __restrict__ g_coords, const uint8_t* __restrict__ g_mask_m,
       const double* __restrict__ g_rays_local, const double* __restrict__ g_ranges,
       const uint8_t* __restrict__ g_mask, IcpResultDev* __restrict__ out,
-      double* __restrict__ trace /* [TSD_ICP_TRACE_MAX][TSD_ICP_TRACE_STRIDE] = pairs, rms, thr_before, state, Tlast (co, si, dX, dY) */, ScanPostArgs post,
+      double* __restrict__ trace /* [TSD_ICP_TRACE_MAX][TSD_ICP_TRACE_STRIDE] = pairs, rms, thr_before, state, Tlast (co, si, dX, dY) */, const ScanPostArgs& post,
       const double* __restrict__ g_mnormals /* direct mode */, const double* __restrict__ g_normals /* fused: ray cast */)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1069,6 +1071,30 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
   }
 }
 
+template <int R, int MAXT, bool PTL>
+__global__ void __launch_bounds__(MAXT)
+k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __restrict__ g_model, const double* __restrict__ g_scene,
+      const int* __restrict__ g_morig, const int* __restrict__ g_start,
+      const double* __restrict__ g_coords, const uint8_t* __restrict__ g_mask_m,
+      const double* __restrict__ g_rays_local, const double* __restrict__ g_ranges,
+      const uint8_t* __restrict__ g_mask, IcpResultDev* __restrict__ out, double* __restrict__ trace, ScanPostArgs post,
+      const double* __restrict__ g_mnormals, const double* __restrict__ g_normals)
+{
+  icp_workgroup<R, MAXT, PTL>(a, P_dev, cap, g_model, g_scene, g_morig, g_start, g_coords, g_mask_m, g_rays_local, g_ranges, g_mask, out, trace,
+                              post, g_mnormals, g_normals);
+}
+
+// the registrations of a batch of robots in ONE launch (tsd_batch_begin): workgroup x = entry x, fused mode only (model and
+// scene come from the ray cast's / the scan's per-beam arrays); each registration still runs on one compute unit
+template <int R, int MAXT, bool PTL>
+__global__ void __launch_bounds__(MAXT)
+k_icp_batch(const IcpBatchEntry* __restrict__ entries, int cap)
+{
+  const IcpBatchEntry& e = entries[blockIdx.x];
+  icp_workgroup<R, MAXT, PTL>(e.a, e.P_dev, cap, nullptr, nullptr, nullptr, nullptr, e.coords, e.mask_m, e.rays_local, e.ranges, e.mask, e.out,
+                              e.trace, e.post, nullptr, e.normals);
+}
+
 static int icp_cap_for(int n)
 {
   int cap = (n + 63) & ~63;
@@ -1150,6 +1176,50 @@ int launch_icp(tsd_ctx* ctx, const IcpArgs& a, const double* P_dev, const double
   }
   if (nthr <= 3 * 512) return launch_icp_shape<3, 512>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post);
   return launch_icp_shape<8, 256>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post);
+}
+
+template <int R, int MAXT, bool PTL>
+static int launch_icp_batch_shape(tsd_ctx* ctx, hipStream_t stream, const IcpBatchEntry* d_entries, int n, int nthr, int cap)
+{
+  int T = ((nthr + R - 1) / R + 63) & ~63;
+  if (T < 64) T = 64;
+  if (T > MAXT) return set_error(ctx, TSD_E_CAPACITY, "icp workgroup shape", hipSuccess);
+  const size_t lds = icp_lds_bytes_for(cap, T, PTL);
+  if (lds > 160u * 1024u) return set_error(ctx, TSD_E_CAPACITY, "registration does not fit the LDS of one CU", hipSuccess);
+  {
+    std::lock_guard<std::mutex> lk_misc(ctx->misc_mutex);
+    size_t& configured = ctx->lds_configured[reinterpret_cast<const void*>(k_icp_batch<R, MAXT, PTL>)];
+    if (lds > configured) {
+      TSD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_icp_batch<R, MAXT, PTL>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      configured = lds;
+    }
+  }
+  ScopedKernelTimer t(ctx, "icp");
+  hipExtLaunchKernelGGL((k_icp_batch<R, MAXT, PTL>), dim3(n), dim3(T), lds, stream, t.a, t.b, 0, d_entries, cap);
+  TSD_HIP_CHECK(ctx, hipGetLastError());
+  return TSD_OK;
+}
+
+// every registration of a batch runs in the same workgroup shape (the widest sensor decides) and with the same estimator
+int launch_icp_batch(tsd_ctx* ctx, hipStream_t stream, const IcpBatchEntry* host, const IcpBatchEntry* d_entries, int n)
+{
+  if (n < 1) return TSD_OK;
+  int beams = 0;
+  for (int i = 0; i < n; i++) {
+    if (host[i].a.estimator != host[0].a.estimator) return set_error(ctx, TSD_E_ARG, "tsd_batch_begin: one estimator per batch", hipSuccess);
+    if (host[i].a.beams < 1) return set_error(ctx, TSD_E_ARG, "tsd_batch_begin: fused registrations only", hipSuccess);
+    if (host[i].a.beams > beams) beams = host[i].a.beams;
+  }
+  if (beams > TSD_MAX_ICP_POINTS) return set_error(ctx, TSD_E_CAPACITY, "icp points > TSD_MAX_ICP_POINTS", hipSuccess);
+  const int cap = icp_cap_for(beams);
+  const bool ptl = host[0].a.estimator == TSD_ESTIMATOR_POINT_TO_LINE;
+  if (host[0].a.estimator != TSD_ESTIMATOR_CLOSED_FORM && !ptl) return set_error(ctx, TSD_E_ARG, "tsd_icp_params.estimator", hipSuccess);
+  if (beams <= 3 * 512)
+    return ptl ? launch_icp_batch_shape<3, 512, true>(ctx, stream, d_entries, n, beams, cap)
+               : launch_icp_batch_shape<3, 512, false>(ctx, stream, d_entries, n, beams, cap);
+  return ptl ? launch_icp_batch_shape<8, 256, true>(ctx, stream, d_entries, n, beams, cap)
+             : launch_icp_batch_shape<8, 256, false>(ctx, stream, d_entries, n, beams, cap);
 }
 
 size_t icp_lds_bytes() { return icp_lds_bytes_for(TSD_MAX_ICP_POINTS, 256); }

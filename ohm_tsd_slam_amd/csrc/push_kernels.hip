@@ -73,9 +73,9 @@ __host__ __device__ inline RmqView rmq_view(char* buf, int beams)
   return v;
 }
 
-__global__ void __launch_bounds__(1024)
-k_push_tables(const double* __restrict__ ranges, const uint8_t* __restrict__ mask, int B, char* __restrict__ buf,
-              double phi_min, double ang_res)
+__device__ __forceinline__ void
+push_tables_body(const double* __restrict__ ranges, const uint8_t* __restrict__ mask, int B, char* __restrict__ buf,
+                 double phi_min, double ang_res)
 {
   // LDS: values (2 x Bp doubles) + two levels of both index tables (ping-pong); each finished level is
   // streamed to global memory, so 4096 beams need 96 KB whatever the number of levels
@@ -133,6 +133,21 @@ k_push_tables(const double* __restrict__ ranges, const uint8_t* __restrict__ mas
     }
     __syncthreads();
   }
+}
+
+__global__ void __launch_bounds__(1024)
+k_push_tables(const double* __restrict__ ranges, const uint8_t* __restrict__ mask, int B, char* __restrict__ buf,
+              double phi_min, double ang_res)
+{
+  push_tables_body(ranges, mask, B, buf, phi_min, ang_res);
+}
+
+// the tables of a batch of scans in ONE launch (tsd_batch_begin): workgroup x builds the tables of scan x
+__global__ void __launch_bounds__(1024)
+k_push_tables_batch(const TablesBatchEntry* __restrict__ entries)
+{
+  const TablesBatchEntry e = entries[blockIdx.x];
+  push_tables_body(e.ranges, e.mask, e.beams, e.rmq, e.phi_min, e.ang_res);
 }
 
 // TsdGridPartition ctor geometry (TsdGridPartition.cpp:48-70)
@@ -988,6 +1003,24 @@ int launch_push_tables(tsd_ctx* ctx, hipStream_t stream, int beams, const double
   }
   hipLaunchKernelGGL(k_push_tables, dim3(1), dim3(1024), lds, stream, d_ranges ? d_ranges : ctx->d_ranges,
                      d_mask ? d_mask : ctx->d_mask, beams, rmq, phi_min, ang_res);
+  TSD_HIP_CHECK(ctx, hipGetLastError());
+  return TSD_OK;
+}
+
+int launch_push_tables_batch(tsd_ctx* ctx, hipStream_t stream, const TablesBatchEntry* d_entries, int n, int max_beams)
+{
+  const size_t bp = (size_t)((max_beams + 3) & ~3);
+  const size_t lds = 2 * bp * sizeof(double) + 4 * bp * 2 + 64;
+  {
+    std::lock_guard<std::mutex> lk_misc(ctx->misc_mutex);
+    size_t& configured = ctx->lds_configured[reinterpret_cast<const void*>(k_push_tables_batch)];
+    if (lds > configured) {
+      TSD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_push_tables_batch),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      configured = lds;
+    }
+  }
+  hipLaunchKernelGGL(k_push_tables_batch, dim3(n), dim3(1024), lds, stream, d_entries);
   TSD_HIP_CHECK(ctx, hipGetLastError());
   return TSD_OK;
 }

@@ -165,9 +165,10 @@ __device__ __forceinline__ double seg_value(const RcSeg* seg, int nseg, int k)
   return fma((double)(k - seg[s].n0), seg[s].rhat, seg[s].anchor);
 }
 
-__global__ void __launch_bounds__(64)
-k_raycast(GridDev g, RaycastArgs a_val, const RaycastArgs* __restrict__ a_dev, const double* __restrict__ rays,
-          double* __restrict__ coords, double* __restrict__ normals, uint8_t* __restrict__ mask, double* dbg)
+// one wave = one beam; shared by k_raycast (one sensor per launch) and k_raycast_batch (block row y = sensor y of a batch)
+__device__ __forceinline__ void
+raycast_beam(const GridDev& g, const RaycastArgs& a_val, const RaycastArgs* __restrict__ a_dev, const double* __restrict__ rays,
+             double* __restrict__ coords, double* __restrict__ normals, uint8_t* __restrict__ mask, double* dbg)
 {
 #ifdef TSD_RC_STAMPS   // diagnostic build: cycles per phase summed over beams into dbg[0..7], max beam total in dbg[8]
   long long st_t = clock64(); const long long st_begin = st_t;
@@ -518,6 +519,31 @@ k_raycast(GridDev g, RaycastArgs a_val, const RaycastArgs* __restrict__ a_dev, c
 #ifdef TSD_RC_STAMPS
   if (lane == 0 && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 128) dbg[(blockIdx.x >> 3) * 8 + 7] = (double)(clock64() - st_begin);
 #endif
+}
+
+__global__ void __launch_bounds__(64)
+k_raycast(GridDev g, RaycastArgs a_val, const RaycastArgs* __restrict__ a_dev, const double* __restrict__ rays,
+          double* __restrict__ coords, double* __restrict__ normals, uint8_t* __restrict__ mask, double* dbg)
+{
+  raycast_beam(g, a_val, a_dev, rays, coords, normals, mask, dbg);
+}
+
+// the ray casts of a batch of sensors on one grid in ONE launch (tsd_batch_begin): blockIdx.y picks the sensor
+__global__ void __launch_bounds__(64)
+k_raycast_batch(GridDev g, const RaycastBatchEntry* __restrict__ entries, double* dbg)
+{
+  const RaycastBatchEntry e = entries[blockIdx.y];
+  RaycastArgs none;
+  none.beams = 0;
+  raycast_beam(g, none, e.a_dev, e.rays, e.coords, e.normals, e.mask, dbg);
+}
+
+int launch_raycast_batch(tsd_ctx* ctx, hipStream_t stream, const RaycastBatchEntry* d_entries, int n, int max_beams)
+{
+  ScopedKernelTimer t(ctx, "raycast");
+  hipExtLaunchKernelGGL(k_raycast_batch, dim3(max_beams, n), dim3(64), 0, stream, t.a, t.b, 0, ctx->grid, d_entries, ctx->d_icp_trace);
+  TSD_HIP_CHECK(ctx, hipGetLastError());
+  return TSD_OK;
 }
 
 int launch_raycast(tsd_ctx* ctx, const RaycastArgs& a, const RaycastArgs* a_dev, const double* d_rays)

@@ -108,6 +108,24 @@ struct LaunchTarget {
   char* rmq = nullptr;                                                // range-query tables of the scan's push
 };
 
+// ---- batched scans (tsd_batch_*): one launch of each kernel for the robots of a batch; block (.., y) of the batched ray cast /
+// block x of the batched registration and tables kernels read their arguments from entry y / x of these device arrays
+struct RaycastBatchEntry {
+  const RaycastArgs* a_dev; const double* rays;
+  double* coords; double* normals; uint8_t* mask;
+};
+struct TablesBatchEntry {
+  const double* ranges; const uint8_t* mask; char* rmq;
+  double phi_min, ang_res;
+  int beams, pad;
+};
+struct IcpBatchEntry {
+  IcpArgs a;
+  const double* P_dev; const double* coords; const uint8_t* mask_m; const double* rays_local; const double* ranges;
+  const uint8_t* mask; IcpResultDev* out; double* trace; const double* normals;
+  ScanPostArgs post;
+};
+
 struct KernelTimer {
   double total_ms = 0.0;
   int launches = 0;
@@ -126,6 +144,7 @@ struct tsd_ctx {
   unsigned long long ticket = 0;             // order of the ray casts / pushes of the concurrent multi-robot path
   unsigned long long last_push_ticket = 0;
   std::vector<tsd_sensor*> sensors;          // device sensors attached to this grid (multi-robot mode, SlamNode.cpp:101-122)
+  std::vector<struct tsd_batch*> batches;    // batch slots of the multi-robot path (their ray casts are grid readers too)
   hipEvent_t ev_grid = nullptr;              // "every grid write enqueued so far is done" (recorded on `stream` by tsd_scan_begin)
   tsd::GridDev grid{};
   int map_log2 = 0;
@@ -231,6 +250,28 @@ struct tsd_sensor {
   const double* conc_ranges = nullptr; const uint8_t* conc_mask_push = nullptr;
 };
 
+// one batch slot of the multi-robot path (tsd_batch_* in include/tsd_hip.h): its own stream, events and staging
+struct tsd_batch {
+  tsd_ctx* ctx = nullptr;
+  int max_scans = 0;
+  size_t scan_bytes = 0;             // bytes of one scan (ranges | mask | mask_push) in the staging buffers, 64-byte aligned
+  size_t head_bytes = 0;             // bytes of the three entry arrays in front of the scans
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_rc_done = nullptr, ev_icp_done = nullptr;
+  bool rc_event_valid = false;
+  unsigned long long rc_ticket = 0;
+  char* h_stage = nullptr;           // pinned: entries + scans of the batch being enqueued
+  char* d_stage2[2] = {nullptr, nullptr};   // device copies, alternating (the pushes of the previous batch still read theirs)
+  int stage_slot = 0;
+  int n = 0;                         // scans of the batch in flight (0: free)
+  bool push_enqueued = false;
+  std::vector<tsd_sensor*> sensors;
+  std::vector<unsigned long long> seqs;
+  std::vector<tsd_gate_params> gates;
+  std::vector<size_t> scan_off;      // offset of scan i in d_stage2[slot of the batch]
+  char* d_stage_cur = nullptr;
+};
+
 namespace tsd {
 
 int set_error(tsd_ctx* ctx, int code, const char* what, hipError_t e);
@@ -277,6 +318,10 @@ int launch_raycast(tsd_ctx* ctx, const RaycastArgs& a, const RaycastArgs* a_dev 
 int launch_icp(tsd_ctx* ctx, const IcpArgs& a, const double* P_dev = nullptr, const double* d_rays_local = nullptr,
                const double* d_ranges = nullptr, const uint8_t* d_mask = nullptr, const ScanPostArgs* post = nullptr);
 int launch_scan_prepare(tsd_ctx* ctx, SensorDev* st);
+// batched launches on `stream`; the entry arrays live in device memory, `host` is the host copy they were staged from
+int launch_raycast_batch(tsd_ctx* ctx, hipStream_t stream, const RaycastBatchEntry* d_entries, int n, int max_beams);
+int launch_push_tables_batch(tsd_ctx* ctx, hipStream_t stream, const TablesBatchEntry* d_entries, int n, int max_beams);
+int launch_icp_batch(tsd_ctx* ctx, hipStream_t stream, const IcpBatchEntry* host, const IcpBatchEntry* d_entries, int n);
 
 int launch_calibrate(tsd_ctx* ctx, double* t, double* w, size_t n);
 int launch_occupancy(tsd_ctx* ctx, int8_t* d_out, int inflate, int inflate_factor);

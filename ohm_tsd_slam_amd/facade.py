@@ -34,6 +34,8 @@ HOST_ABI = {
     "tsd_node_report": (None, [C.c_void_p, C.c_int, _dp]),
     "tsd_node_pose_msg": (None, [C.c_void_p, C.c_int, _dp]),
     "tsd_node_pose_topic": (C.c_char_p, [C.c_void_p, C.c_int]),
+    "tsd_node_play": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(_fp), C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_longlong, C.c_longlong]),
+    "tsd_node_batch_stats": (None, [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "tsd_node_grid_ctx": (C.c_void_p, [C.c_void_p]),
     "tsd_node_grid_lock": (None, [C.c_void_p]),
     "tsd_node_grid_unlock": (None, [C.c_void_p]),
@@ -146,6 +148,22 @@ class SlamNode:
         rc = self.lib.tsd_node_laser(self.h, robot, r.ctypes.data_as(_fp), r.size, angle_min, angle_increment, stamp_ns)
         if rc != 0:
             raise capi.TsdError(f"tsd_node_laser failed ({rc})")
+
+    def play(self, scans, first: int, count: int, angle_min, angle_increment):
+        """Replay scans[r][first:first+count] of every robot r from one native publisher thread per robot (`rosbag play`):
+        ``scans`` = list (one per robot) of C-contiguous float32 arrays [n_scans, beams]."""
+        arrs = [np.ascontiguousarray(s, dtype=np.float32) for s in scans]
+        ptrs = (_fp * len(arrs))(*[a.ctypes.data_as(_fp) for a in arrs])
+        rc = self.lib.tsd_node_play(self.h, len(arrs), ptrs, first, count, arrs[0].shape[1], angle_min, angle_increment,
+                                    self._stamp + 25_000_000, 25_000_000)
+        self._stamp += 25_000_000 * (first + count)
+        if rc != 0:
+            raise capi.TsdError(f"tsd_node_play failed ({rc})")
+
+    def batch_stats(self):
+        b, s = C.c_ulonglong(0), C.c_ulonglong(0)
+        self.lib.tsd_node_batch_stats(self.h, C.byref(b), C.byref(s))
+        return int(b.value), int(s.value)
 
     def wait_idle(self, timeout_ms: int = 10000) -> bool:
         return self.lib.tsd_node_wait_idle(self.h, timeout_ms) == 0

@@ -217,6 +217,47 @@ def test_facade_two_robots_concurrently(oracle):
     node.close()
 
 
+def test_facade_four_robots_replayed_through_the_dispatcher(oracle):
+    """Four robots on one grid fed by the native replay (one publisher thread per robot, what bench.py --robots does): the
+    facade's dispatcher groups their scans into batches (tsd_batch_*).  Every scan is processed, the scans travel in batches
+    of more than one, every robot keeps tracking, the grid stays consistent."""
+    n, R = 40, 4
+    gc, geo, scene = synth.CONFIGS["cfg2"]
+    world = synth.World(scene, gc, start_xy=[0.5 * gc.width + 0.37, 0.5 * gc.width - 0.21])
+    lanes = synth.free_lanes(world, R, 0.06 * 50, clearance=0.6)
+    poses, scans = [], []
+    for r in range(R):
+        p = synth.trajectory(world, n, leg=50)
+        p[:, 1] += lanes[r][1] - world.start[1]
+        poses.append(p); scans.append(np.stack(synth.scans_for(world, geo, p)).astype(np.float32))
+    params = facade.node_params(gc, geo, robot_nbr=R)
+    for r in range(R):
+        params.update({f"robot_{r}/name": f"robot{r}", f"tsd_slam/robot{r}/local_offset_x": lanes[r][0] - 0.5 * gc.width,
+                       f"tsd_slam/robot{r}/local_offset_y": lanes[r][1] - 0.5 * gc.width, f"tsd_slam/robot{r}/local_offset_yaw": 0.1,
+                       f"robot{r}/dist_filter_max": 0.4, f"robot{r}/dist_filter_min": 0.02, f"robot{r}/icp_iterations": 30,
+                       f"robot{r}/registration_mode": 0})
+    params = {k: v for k, v in params.items() if not k.startswith("tsd_slam/local_offset")}
+    node = facade.SlamNode(params, synchronous=True)
+    for r in range(R):
+        node.laser(scans[r][0], geo.angle_min, geo.angle_increment, robot=r)
+    b0 = node.batch_stats()
+    node.play(scans, 1, n - 1, geo.angle_min, geo.angle_increment)
+    node.grid().sync()
+    batches, carried = (x - y for x, y in zip(node.batch_stats(), b0))
+    assert carried == R * (n - 1)
+    assert batches < carried, "the robots' scans never shared a batch"
+    for r in range(R):
+        assert node.processed(r) == n
+        P = node.report(r)["pose"]
+        assert math.hypot(P[0, 2] - poses[r][-1, 0], P[1, 2] - poses[r][-1, 1]) < 0.15, (r, P, poses[r][-1])
+    init, iw, tsd, w = node.grid().download_tiles()
+    sel = init.astype(bool)
+    assert sel.sum() > 500 and np.all(w[sel] >= 0.0) and np.all(w[sel] <= 32.0)
+    t = tsd[sel]; m = ~np.isnan(t)
+    assert np.all(t[m] <= 1.0) and np.all(t[m] >= -1.0)
+    node.close()
+
+
 @pytest.mark.parametrize("fused", [True, False])
 def test_facade_point_to_line_estimator_tracks(oracle, fused):
     """`icp_estimator` = 1 (an addition: the reference node has no such key) runs the loop with
