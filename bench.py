@@ -15,7 +15,8 @@ one robot's scans are strictly sequential (the next ray cast needs this push), s
                 This is the HBM-bound leg SURVEY 8(d) prices against the roofline (cfg3 / comb = bandwidth stress).
   --storage q32 (push mode) the 8-byte-per-cell build, lib/libtsd_hip_q32.so.
   --robots R    R robots on ONE grid in one process (the reference's own multi-robot mode, SlamNode.cpp:101-122),
-                one feeder thread per robot; value = all robots' scans / wall time.
+                scans replayed by one native publisher thread per robot (tsd_node_play; --python-feeders: Python
+                threads); the facade's dispatcher batches the robots' scans (tsd_batch_*); value = all robots' scans / wall time.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): one robot + one grid per GPU (BASELINE configs[3]/[4]);
 every 50 scans the ranks merge their int8 occupancy maps with an RCCL max all-reduce.  Weak scaling: `value` =
@@ -216,7 +217,8 @@ def main():
     if args.storage == "q32" and mode != "push":
         ap.error("--storage q32 is measured in --mode push (the C++ facade links the fp64 library)")
     K, W = args.steps, args.warmup
-    every = args.sample_every or (8 if K >= 80 else 4)
+    # (several robots: many more dispatches per step, and every sampled one costs the chain of dependent launches ~10 us)
+    every = args.sample_every or (32 if args.robots > 1 else (8 if K >= 80 else 4))
     device = local_rank if use_dist else 0
     cell_bytes = 8 if args.storage == "q32" else 16
 

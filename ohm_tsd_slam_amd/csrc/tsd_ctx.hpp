@@ -144,7 +144,7 @@ struct tsd_ctx {
   unsigned long long ticket = 0;             // order of the ray casts / pushes of the concurrent multi-robot path
   unsigned long long last_push_ticket = 0;
   std::vector<tsd_sensor*> sensors;          // device sensors attached to this grid (multi-robot mode, SlamNode.cpp:101-122)
-  std::vector<struct tsd_batch*> batches;    // batch slots of the multi-robot path (their ray casts are grid readers too)
+  std::vector<struct tsd_batch*> batches;    // batch slots of the multi-robot path
   hipEvent_t ev_grid = nullptr;              // "every grid write enqueued so far is done" (recorded on `stream` by tsd_scan_begin)
   tsd::GridDev grid{};
   int map_log2 = 0;
@@ -257,9 +257,7 @@ struct tsd_batch {
   size_t scan_bytes = 0;             // bytes of one scan (ranges | mask | mask_push) in the staging buffers, 64-byte aligned
   size_t head_bytes = 0;             // bytes of the three entry arrays in front of the scans
   hipStream_t stream = nullptr;
-  hipEvent_t ev_rc_done = nullptr, ev_icp_done = nullptr;
-  bool rc_event_valid = false;
-  unsigned long long rc_ticket = 0;
+  hipEvent_t ev_rc_done = nullptr, ev_icp_done = nullptr, ev_copy_done = nullptr;
   char* h_stage = nullptr;           // pinned: entries + scans of the batch being enqueued
   char* d_stage2[2] = {nullptr, nullptr};   // device copies, alternating (the pushes of the previous batch still read theirs)
   int stage_slot = 0;
