@@ -49,6 +49,21 @@ constexpr int ICP_PAD = 96;                     // wrapped copies of the model a
 #endif
 constexpr unsigned REFRESH_A = TSD_ICP_REFRESH_A, REFRESH_B = TSD_ICP_REFRESH_B;   // steps with a scheduled bound renewal
 constexpr int IR_CNT = 32, IR_RMAX = 33, IR_CNT2 = 34, IR_TIE = 35;   // words of IcpLds::ired
+// -DTSD_ICP_ABLATE=<bits>: timing experiments that switch parts of a step off (the RESULTS are wrong; tools/icp_ablate.sh):
+//   1 no searches (a point that fails tier 0 is dropped)   2 no in-place window searches (everything through the work list)
+//   4 no closed form (identity step)   8 no cross-wave reduction (a thread's own sums stand in for the totals)
+//   16 no reciprocal filter (every kept pair wins)   32 no tier-0 runner-up
+#ifndef TSD_ICP_ABLATE
+#define TSD_ICP_ABLATE 0
+#endif
+constexpr int ABL = TSD_ICP_ABLATE;
+// -DTSD_ICP_DUP=<bits>: timing experiments that run a part of every step TWICE with the same outcome (results unchanged), so the
+// time difference is that part's cost in place:  1 cross-wave reduction   2 closed form   4 transform + bound update (second
+// time on copies)   8 an extra workgroup barrier
+#ifndef TSD_ICP_DUP
+#define TSD_ICP_DUP 0
+#endif
+constexpr int DUP = TSD_ICP_DUP;
 #ifdef TSD_ICP_STAMPS
 constexpr int IR_DBG = 40;
 #endif
@@ -189,7 +204,10 @@ constexpr int WIN = 2 * HW + 1;
 constexpr int WIN_ROUNDS = 6;
 constexpr double WIN_REACH = 0.03;               // sin^2 of ~10 degrees: about the widest arc the window grows to at 0.25 degree per slot
 constexpr int LIST_PAST_WINDOW = 1 << 30;         // work-list entry: the tier-1 window was already tried (in place)
-constexpr int INLINE_MAX = 6;                   // points a wave resolves on the spot instead of listing them
+#ifndef TSD_ICP_INLINE_MAX
+#define TSD_ICP_INLINE_MAX 0
+#endif
+constexpr int INLINE_MAX = TSD_ICP_INLINE_MAX;  // points a wave resolves on the spot instead of listing them
 static_assert(ICP_PAD >= HW + WIN_ROUNDS * WIN, "padding must cover the widest window");
 __device__ __forceinline__ int wrap_slot(int k, int nM)
 {
@@ -713,7 +731,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
         // the bound on everything else (a point hovering between two model points never searches)
         const double dx1 = x - mh[q].x, dy1 = y - mh[q].y, dx2 = x - mh2[q].x, dy2 = y - mh2[q].y;
         const double d1 = dx1 * dx1 + dy1 * dy1, d2 = dx2 * dx2 + dy2 * dy2;
-        bool swp = d2 < d1;
+        bool swp = (ABL & 32) ? false : d2 < d1;
         if (d2 == d1 && hint2[q] != hint[q]) swp = L.morig[hint2[q]] < L.morig[hint[q]];   // exact tie (rare)
         const double d = swp ? d2 : d1;
         const int kn = swp ? hint2[q] : hint[q], ko = swp ? hint[q] : hint2[q];
@@ -731,6 +749,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
         // in distance while the steps are still large, instead of a trickle of passes later.
         const bool weak = refresh & pre & known & !drop & (lb2 < 4.0 * d);
         need[q] = (pre & !same & !drop) | weak;
+        if constexpr ((ABL & 1) != 0) need[q] = false;
         keep[q] = keep[q] & !need[q];
         ent[q] = -1;
       }
@@ -744,7 +763,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
       int wneed = 0;
 #pragma unroll
       for (int q = 0; q < R; q++) wneed += __popcll(__ballot(need[q]));
-      if (wneed > 0 && wneed <= INLINE_MAX) {
+      if (wneed > 0 && wneed <= ((ABL & 2) ? 0 : INLINE_MAX)) {
         bool tolist[R];
 #pragma unroll
         for (int q = 0; q < R; q++) tolist[q] = false;
@@ -782,7 +801,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     bool tie = false;
 #pragma unroll
     for (int q = 0; q < R; q++) {
-      if (keep[q]) {
+      if (keep[q] && !(ABL & 16)) {
         const unsigned long long mine = (unsigned long long)__double_as_longlong(bd[q]);
         tie |= atomicMin(&L.slotD[hint[q]], mine) == mine;
       }
@@ -878,6 +897,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
       for (int q = 0; q < R; q++) sd[q] = L.slotD[hint[q]];
 #pragma unroll
       for (int q = 0; q < R; q++) win[q] = keep[q] & (sd[q] == (unsigned long long)__double_as_longlong(bd[q]));
+      if constexpr ((ABL & 16) != 0) { for (int q = 0; q < R; q++) win[q] = keep[q]; }
     }
     if (L.ired[IR_TIE]) {
       // equal d2 somewhere: the lowest scene index of the candidates wins its slot
@@ -944,7 +964,16 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
         }
       }
       STAMP(3);
-      block_totals<MAXT / 64, NSUM>(L, v, cnt, tot, pairs, tid, lane, wave, W);
+      if constexpr ((ABL & 8) != 0) { for (int k = 0; k < NSUM; k++) tot[k] = v[k] * 300.0; pairs = 300; }
+      else block_totals<MAXT / 64, NSUM>(L, v, cnt, tot, pairs, tid, lane, wave, W);
+      if constexpr ((DUP & 1) != 0) {
+        __syncthreads();
+        double v2[NSUM];
+#pragma unroll
+        for (int k = 0; k < NSUM; k++) v2[k] = vreg(v[k]);
+        block_totals<MAXT / 64, NSUM>(L, v2, cnt, tot, pairs, tid, lane, wave, W);
+      }
+      if constexpr ((DUP & 8) != 0) __syncthreads();
       STAMP(4);
       if (pass == 0) {                     // first step only: centroids first, then the centred pass
         if (pairs > 0) {
@@ -974,7 +1003,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
         co = cos(xs[0]); si = sin(xs[0]); dX = xs[1]; dY = xs[2];
       } else {
         const double np = (double)pairs;
-        const double size_inv = 1.0 / np;
+        const double size_inv = (ABL & 4) ? 0.0033 : 1.0 / np;
         rms = tot[4] * size_inv;
         const double cmx = tot[0] * size_inv, cmy = tot[1] * size_inv, csx = tot[2] * size_inv, csy = tot[3] * size_inv;
         const double emx = cmx - c0[0], emy = cmy - c0[1], esx = csx - c0[2], esy = csy - c0[3];
@@ -989,12 +1018,28 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
         // from the reference's atan2 -> cos/sin by rounding only (DESIGN.md "ICP", tolerance 1e-4)
         {
           const double h2 = nom * nom + den * den;
-          if (h2 > 0.0) { const double inv = rsqrt(h2); co = den * inv; si = nom * inv; }
+          if constexpr ((ABL & 4) != 0) { co = 1.0 - 1e-12 * h2; si = 1e-9 * h2; }
+          else if (h2 > 0.0) { const double inv = rsqrt(h2); co = den * inv; si = nom * inv; }
           else { co = signbit(den) ? -1.0 : 1.0; si = 0.0; }
         }
 #endif
         dX = (cmx - (co * csx - si * csy));
         dY = (cmy - (co * csy + si * csx));
+        if constexpr ((DUP & 2) != 0) {
+          // the same closed form again, on inputs the compiler cannot recognise, chained behind the first result
+          const double z = vreg(0.0) * co;
+          const double np2 = vreg(np) + z;
+          const double sinv = 1.0 / np2;
+          const double m0 = vreg(tot[0]) * sinv, m1 = vreg(tot[1]) * sinv, m2 = vreg(tot[2]) * sinv, m3 = vreg(tot[3]) * sinv;
+          const double e0 = m0 - vreg(emx + m0 - emx - m0 + c0[0] * 0.0), e1 = m1 - vreg(0.0), e2 = m2 - vreg(0.0), e3 = m3 - vreg(0.0);
+          const double nom2 = (vreg(tot[5]) - np2 * (e1 * e2)) - (vreg(tot[6]) - np2 * (e0 * e3));
+          const double den2 = (vreg(tot[7]) - np2 * (e0 * e2)) + (vreg(tot[8]) - np2 * (e1 * e3));
+          const double h22 = nom2 * nom2 + den2 * den2;
+          double co2 = 1.0, si2 = 0.0;
+          if (h22 > 0.0) { const double inv2 = rsqrt(h22); co2 = den2 * inv2; si2 = nom2 * inv2; }
+          const double dX2 = (m0 - (co2 * m2 - si2 * m3)), dY2 = (m1 - (co2 * m3 + si2 * m2));
+          dX += 0.0 * (dX2 + dY2);      // (0 * finite = 0: keeps the chain alive without changing the value)
+        }
       }
       STAMP(4);
       // applyTransformation(sceneTmp): data * R^T (dgemm NoTrans,Trans), then + t (Icp.cpp:371-408).
@@ -1012,6 +1057,16 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
         const float disp = __builtin_amdgcn_sqrtf((float)(ex * ex + ey * ey) * 1.000001f) * 1.000001f;
         lb[q] = lb[q] - (double)disp;
         sx[q] = nx; sy[q] = ny;
+        if constexpr ((DUP & 4) != 0) {
+          const double x2 = vreg(nx), y2 = vreg(ny);
+          double mx = 0.0, my = 0.0;
+          mx += x2 * co; mx += y2 * (-si);
+          my += x2 * si; my += y2 * co;
+          mx = mx + dX; my = my + dY;
+          const double fx = mx - x2, fy = my - y2;
+          const float disp2 = __builtin_amdgcn_sqrtf((float)(fx * fx + fy * fy) * 1.000001f) * 1.000001f;
+          lb[q] = lb[q] - 0.0 * (double)disp2;
+        }
       }
       {
         // Tfinal = Tlast * Tfinal (Icp.cpp:452): the 4x4 product restricted to its non-trivial entries
@@ -1036,7 +1091,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     else if (iter >= max_it) state = TSD_ICP_MAXITERATIONS;
     rms_prev = rms;
     STAMP(5);
-    if (tid == 0 && iter <= TSD_ICP_TRACE_MAX) {
+    if (tid == 0 && iter <= TSD_ICP_TRACE_MAX && !(ABL & 64)) {
       double* tr = L.tail->trace + TSD_ICP_TRACE_STRIDE * (iter - 1);
       tr[0] = (double)pairs; tr[1] = rms; tr[2] = thr_before; tr[3] = (double)state;
       tr[4] = co; tr[5] = si; tr[6] = dX; tr[7] = dY;          // Tlast = [[co, -si, dX], [si, co, dY]] (NaN: no estimate this step)
@@ -1174,7 +1229,7 @@ int launch_icp(tsd_ctx* ctx, const IcpArgs& a, const double* P_dev, const double
     case 8: return launch_icp_shape<8, 256>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post);
     default: break;
   }
-  if (nthr <= 3 * 512) return launch_icp_shape<3, 512>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post);
+  if (nthr <= 3 * 512) return launch_icp_shape<3, 512>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post, ctx->icp_shape >= 64 ? ctx->icp_shape : 0);
   return launch_icp_shape<8, 256>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post);
 }
 

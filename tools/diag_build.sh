@@ -7,11 +7,12 @@ set -e
 root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 tu=$1; shift
 lib=$root/ohm_tsd_slam_amd/lib
-mkdir -p $lib/diag/obj
+diag=${DIAG_DIR:-diag}            # DIAG_DIR=diag_<name>: several variants side by side
+mkdir -p $lib/$diag/obj
 cd $root/ohm_tsd_slam_amd/csrc
-hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -I../../include "$@" -c $tu.hip -o $lib/diag/obj/$tu.o
+hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -I../../include "$@" -c $tu.hip -o $lib/$diag/obj/$tu.o
 objs=""
-for o in $lib/obj/*.o; do b=$(basename $o); if [ "$b" = "$tu.o" ]; then objs="$objs $lib/diag/obj/$tu.o"; else objs="$objs $o"; fi; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o $lib/diag/libtsd_hip.so $objs
-cp $lib/libohm_tsd_slam.so $lib/diag/
-echo "diag library: $lib/diag (TSD_LIB_DIR)"
+for o in $lib/obj/*.o; do b=$(basename $o); if [ "$b" = "$tu.o" ]; then objs="$objs $lib/$diag/obj/$tu.o"; else objs="$objs $o"; fi; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o $lib/$diag/libtsd_hip.so $objs
+cp $lib/libohm_tsd_slam.so $lib/$diag/
+echo "diag library: $lib/$diag (TSD_LIB_DIR)"
