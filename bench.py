@@ -180,7 +180,7 @@ def main():
     ap.add_argument("--mode", default=None, choices=["slam", "push"])
     ap.add_argument("--storage", default="f64", choices=["f64", "q32"])
     ap.add_argument("--robots", type=int, default=1)
-    ap.add_argument("--python-feeders", action="store_true", help="--robots: Python feeder threads instead of tsd_node_play")
+    ap.add_argument("--python-feeders", action="store_true", help="--robots: Python feeder threads instead of the native replay tsd_node_play")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scans", type=int, default=10)
     ap.add_argument("--sample-every", type=int, default=0, help="time every n-th dispatch of each kernel (0 = auto)")
