@@ -223,6 +223,9 @@ constexpr uint32_t KIND_UPDATE = 1u, KIND_EMPTY = 2u, KIND_HALO = 3u;
 constexpr int KIND_SHIFT = 28;
 constexpr uint32_t LIST_TILE_MASK = (1u << 20) - 1u;   // tile index (<= 2^20 tiles at map_size 15)
 constexpr uint32_t LIST_FAR = 1u << 27;          // entry flag: the sensor is further than 3 circumradii from the tile centre
+constexpr uint32_t LIST_INTERIOR = 1u << 26;     // far tile whose four corners all project to valid beams 1 .. beams-2 within the angular
+                                                 // diameter of a far tile: every cell's beam is valid, inside [lo, hi], and no cell is near
+                                                 // an end of the field of view or the +-pi cut (k_push_update skips those tests)
 constexpr int TOT_FIELDS = 8;   // cells updated, range pass, update, new, new from empty, emptied init, emptied uninit, -
 
 // isInRange for every tile of the launch window, one LANE per tile (TsdGridComponent.cpp:43-124: range cull,
@@ -288,7 +291,12 @@ k_push_classify(GridDev g, const PushArgs* __restrict__ a_dev, const char* __res
       // The cell centres of a tile lie inside the quadrilateral of the four corner points; seen from a sensor
       // well outside of it the extreme angles are those of corners, so every cell projects into [lo, hi]
       // (corners outside the field of view were mapped to its ends above).
-      if (distance > 3.0 * rad) { win = (uint32_t)lo | ((uint32_t)hi << 16); far_flag = LIST_FAR; }
+      if (distance > 3.0 * rad) {
+        win = (uint32_t)lo | ((uint32_t)hi << 16); far_flag = LIST_FAR;
+        // angular diameter of a far tile < 2 asin(1/3) = 0.68 rad; a tile that straddles the cut of a full-circle sensor has its
+        // corner indices at both ends of the scan instead
+        if (all_vis && lo >= 1 && hi <= a.beams - 2 && (double)(hi - lo) <= 0.7 * a.ang_res_inv + 2.0) far_flag |= LIST_INTERIOR;
+      }
       if (action == 2) {
         kind = KIND_UPDATE;
         // partition weight (TsdGrid.cpp:239-243): ((maxRange - min(distance to the centroid, maxRange)) / maxRange)^2.
@@ -363,15 +371,21 @@ __device__ __forceinline__ float atan2_estimate(float y, float x)      // |error
   return y < 0.f ? -r : r;
 }
 // beam index from the estimated angle `th` (radians, possibly outside (-pi, pi] by the small delta)
-__device__ __forceinline__ int index_from_angle(float th, float phi_min_f, float inv_res_f, int beams)
+// interior (wave-uniform, LIST_INTERIOR): the tile lies inside the field of view by a beam and away from the cut, the angle is
+// continuous over it -- only the distance to a rounding boundary is left to test
+__device__ __forceinline__ int index_from_angle(float th, float phi_min_f, float inv_res_f, int beams, bool interior = false)
 {
   const float PI_F = 3.14159274f;
-  if (th > PI_F) th -= 2.0f * PI_F;                        // the reference's atan2 lives in (-pi, pi]
-  else if (th <= -PI_F) th += 2.0f * PI_F;
-  if (fabsf(th) > PI_F - 1e-3f) return IDX_UNSURE;         // at the cut the two branches are 2 pi apart: exact path
+  if (!interior) {
+    if (th > PI_F) th -= 2.0f * PI_F;                        // the reference's atan2 lives in (-pi, pi]
+    else if (th <= -PI_F) th += 2.0f * PI_F;
+    if (fabsf(th) > PI_F - 1e-3f) return IDX_UNSURE;         // at the cut the two branches are 2 pi apart: exact path
+  }
   const float u = (th - phi_min_f) * inv_res_f;            // beam coordinate
-  if (u < -0.5f - IDX_MARGIN || u > (float)beams - 0.5f + IDX_MARGIN) return -1;     // outside the field of view for sure
-  if (!(u > -0.5f + IDX_MARGIN && u < (float)beams - 0.5f - IDX_MARGIN)) return IDX_UNSURE;
+  if (!interior) {
+    if (u < -0.5f - IDX_MARGIN || u > (float)beams - 0.5f + IDX_MARGIN) return -1;     // outside the field of view for sure
+    if (!(u > -0.5f + IDX_MARGIN && u < (float)beams - 0.5f - IDX_MARGIN)) return IDX_UNSURE;
+  }
   const float j = rintf(u);
   if (fabsf(u - j) > 0.5f - IDX_MARGIN) return IDX_UNSURE;
   return (int)j;
@@ -543,6 +557,7 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
       const float lcxf = (float)lcx, lcyf = (float)lcy;
       const float axx = (float)(a.Pi[0] * g.cs), axy = (float)(a.Pi[1] * g.cs), ayx = (float)(a.Pi[3] * g.cs), ayy = (float)(a.Pi[4] * g.cs);
       const bool far = (entry & LIST_FAR) != 0u;
+      const bool interior = (entry & LIST_INTERIOR) != 0u;
       const float th_c = atan2_estimate(lcyf, lcxf);
       const float dxc = (float)ix - 15.5f;
       const float bx = fmaf(axx, dxc, lcxf), by = fmaf(ayx, dxc, lcyf);
@@ -564,7 +579,7 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
         } else {
           th = atan2_estimate(lyf, lxf);
         }
-        bidx[k] = index_from_angle(th, phi_min_f, inv_res_f, a.beams);
+        bidx[k] = index_from_angle(th, phi_min_f, inv_res_f, a.beams, interior);
       }
 #ifdef TSD_PUSH_VERIFY_INDEX   // diagnostic build: every decided cell against the exact formulation
 #pragma unroll
