@@ -394,6 +394,7 @@ def run_slam(args, gc, geo, scene, K, W, every, device, rank, local_rank, world_
     elapsed = time.perf_counter() - t0
     upd_ms, upd_launches = grid.profile_get("push_update")
     stages = stage_table(grid, K)
+    icp_min, icp_max, icp_std = grid.profile_spread("icp")
     b1 = node.batch_stats()
     bstats = (b1[0] - b0[0], b1[1] - b0[1])
     st, pushes = grid.push_stats_total()
@@ -426,6 +427,7 @@ def run_slam(args, gc, geo, scene, K, W, every, device, rank, local_rank, world_
                            if R == 1 else "robots' scans batched by the facade's dispatcher (tsd_batch_*), two batch slots in turn",
                    "scans_per_batch": (bstats[1] / max(bstats[0], 1)) if R > 1 else None},
         "ms_icp_iterate": stages["icp"], "ms_icp_per_iteration": (stages["icp"] / 30.0) if stages["icp"] else None,
+        "ms_icp_iterate_spread": {"min": icp_min, "max": icp_max, "std": icp_std, "of": "the sampled dispatches"},
         "ms_raycast": stages["raycast"],
         "ms_push_kernels": sum(v for k, v in stages.items() if k.startswith("push") and v is not None),
         "stages_ms": stages, "stages_sum_ms_per_scan": stage_sum,

@@ -184,6 +184,7 @@ ABI = {
     "tsd_profile_reset": (C.c_int, [C.c_void_p]),
     "tsd_push_stats_total": (C.c_int, [C.c_void_p, C.POINTER(PushStats), C.POINTER(C.c_int64), C.c_int]),
     "tsd_profile_get": (C.c_int, [C.c_void_p, C.c_char_p, _dp, _ip]),
+    "tsd_profile_get_spread": (C.c_int, [C.c_void_p, C.c_char_p, _dp, _dp, _dp]),
 }
 
 _lib = None
@@ -430,6 +431,12 @@ class TsdGridDevice:
 
     def profile_reset(self):
         self.lib.tsd_profile_reset(self.h)
+
+    def profile_spread(self, kernel: str):
+        """(min, max, std) in ms of the timed dispatches of one kernel since the last reset"""
+        mn, mx, sd = C.c_double(0.0), C.c_double(0.0), C.c_double(0.0)
+        self.lib.tsd_profile_get_spread(self.h, kernel.encode(), C.byref(mn), C.byref(mx), C.byref(sd))
+        return mn.value, mx.value, sd.value
 
     def profile_get(self, kernel: str):
         ms = C.c_double(0.0)

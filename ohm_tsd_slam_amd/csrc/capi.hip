@@ -71,6 +71,9 @@ void drain_timers(tsd_ctx* ctx)
       float ms = 0.f;
       if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
         kv.second.total_ms += (double)ms;
+        kv.second.sum_sq += (double)ms * (double)ms;
+        if ((double)ms < kv.second.min_ms) kv.second.min_ms = (double)ms;
+        if ((double)ms > kv.second.max_ms) kv.second.max_ms = (double)ms;
         kv.second.launches++;
       }
       ctx->event_pool.push_back(pr.first);     // recycled: no event creation in steady state
@@ -1029,6 +1032,24 @@ int tsd_profile_get(tsd_ctx* ctx, const char* kernel, double* total_ms, int* lau
   auto it = ctx->timers.find(kernel);
   if (total_ms) *total_ms = (it == ctx->timers.end()) ? 0.0 : it->second.total_ms;
   if (launches) *launches = (it == ctx->timers.end()) ? 0 : it->second.launches;
+  return TSD_OK;
+}
+
+int tsd_profile_get_spread(tsd_ctx* ctx, const char* kernel, double* min_ms, double* max_ms, double* std_ms)
+{
+  if (!ctx || !kernel) return TSD_E_ARG;
+  hipStreamSynchronize(ctx->stream);
+  drain_timers(ctx);
+  std::lock_guard<std::mutex> lk(ctx->misc_mutex);
+  auto it = ctx->timers.find(kernel);
+  const bool have = it != ctx->timers.end() && it->second.launches > 0;
+  const double n = have ? (double)it->second.launches : 1.0;
+  const double mean = have ? it->second.total_ms / n : 0.0;
+  double var = have ? it->second.sum_sq / n - mean * mean : 0.0;
+  if (var < 0.0) var = 0.0;
+  if (min_ms) *min_ms = have ? it->second.min_ms : 0.0;
+  if (max_ms) *max_ms = have ? it->second.max_ms : 0.0;
+  if (std_ms) *std_ms = std::sqrt(var);
   return TSD_OK;
 }
 

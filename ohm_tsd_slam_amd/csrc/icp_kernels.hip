@@ -202,7 +202,10 @@ __device__ __forceinline__ double sep_bound(double x, double y, double rs2, doub
 // a third candidate in the same 256-ulp bucket sends the point to the exact whole-wave search.
 constexpr int WIN = 2 * HW + 1;
 constexpr int WIN_ROUNDS = 6;
-constexpr double WIN_REACH = 0.03;               // sin^2 of ~10 degrees: about the widest arc the window grows to at 0.25 degree per slot
+#ifndef TSD_ICP_WIN_REACH
+#define TSD_ICP_WIN_REACH 0.03
+#endif
+constexpr double WIN_REACH = TSD_ICP_WIN_REACH;  // sin^2 of ~10 degrees: about the widest arc the window grows to at 0.25 degree per slot
 constexpr int LIST_PAST_WINDOW = 1 << 30;         // work-list entry: the tier-1 window was already tried (in place)
 #ifndef TSD_ICP_INLINE_MAX
 #define TSD_ICP_INLINE_MAX 0

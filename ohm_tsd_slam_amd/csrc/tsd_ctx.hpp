@@ -128,6 +128,7 @@ struct IcpBatchEntry {
 
 struct KernelTimer {
   double total_ms = 0.0;
+  double sum_sq = 0.0, min_ms = 1e300, max_ms = 0.0;   // of the timed dispatches (tsd_profile_get_spread)
   int launches = 0;
   unsigned tick = 0;         // launches seen (sampling: every profile_every-th one is timed)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
