@@ -10,6 +10,9 @@ one robot's scans are strictly sequential (the next ray cast needs this push), s
   python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg1|cfg2|cfg3] [--scene room|pillars|comb]
                   [--mode slam|push] [--storage f64|q32] [--robots R]
 
+  The next scan is announced to the localiser (a replay knows it): its ingest, copy and tables run while the current scan is being
+  registered (tsd_scan_stage); --no-lookahead turns that off.
+
   --mode push   (default for --scene comb, whose ranges do not depend on the pose, so there is nothing to localise
                 against): a step = one TsdGrid::push from the ground-truth pose (tables + classify + update + halo).
                 This is the HBM-bound leg SURVEY 8(d) prices against the roofline (cfg3 / comb = bandwidth stress).
@@ -180,6 +183,7 @@ def main():
     ap.add_argument("--mode", default=None, choices=["slam", "push"])
     ap.add_argument("--storage", default="f64", choices=["f64", "q32"])
     ap.add_argument("--robots", type=int, default=1)
+    ap.add_argument("--no-lookahead", action="store_true", help="do not announce the next scan to the localiser (no staging ahead)")
     ap.add_argument("--python-feeders", action="store_true", help="--robots: Python feeder threads instead of the native replay tsd_node_play")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scans", type=int, default=10)
@@ -352,7 +356,9 @@ def run_slam(args, gc, geo, scene, K, W, every, device, rank, local_rank, world_
         merger = multigpu.NativeOccupancyMerger(grid, world_size, rank, ids[0])
 
     def step(k, r=0):
-        node.laser(scans[r][k], geo.angle_min, geo.angle_increment, robot=r)
+        # (a replay knows the next scan: announced, the localiser stages it on the device during this registration)
+        nxt = scans[r][k + 1] if (R == 1 and not args.no_lookahead and k + 1 < len(scans[r])) else None
+        node.laser(scans[r][k], geo.angle_min, geo.angle_increment, robot=r, ahead=nxt)
         if merger is not None and r == 0 and k % MERGE_EVERY == 0:
             merger.merge_async()            # extraction kernels + RCCL max all-reduce over xGMI, in stream order, no wait
 

@@ -230,6 +230,16 @@ int tsd_sensor_set_pose(tsd_sensor* s, const double pose33[9], const double* ray
 int tsd_scan(tsd_sensor* s, const double* ranges, const uint8_t* mask, const uint8_t* mask_push,
              const tsd_icp_params* params, const tsd_gate_params* gates, tsd_scan_result* result);
 
+/* tsd_scan in two halves, and the NEXT scan staged ahead.  tsd_scan = tsd_scan_submit + tsd_scan_collect.  Between the two a
+ * caller that already holds the next scan (a queued LaserScan; a replayed log) hands it to tsd_scan_stage: its copy and the
+ * range-query tables of its push run on the side stream while the current registration is busy, and the next
+ * tsd_scan_submit(s, NULL, NULL, NULL, ...) starts from the staged data -- the host's per-scan work no longer sits between
+ * the ray cast and the registration.  A staged scan that is not the one that comes next is dropped by passing the real one. */
+int tsd_scan_submit(tsd_sensor* s, const double* ranges /* NULL: the staged scan */, const uint8_t* mask, const uint8_t* mask_push,
+                    const tsd_icp_params* params, const tsd_gate_params* gates);
+int tsd_scan_stage(tsd_sensor* s, const double* ranges, const uint8_t* mask, const uint8_t* mask_push /* may be NULL: = mask */);
+int tsd_scan_collect(tsd_sensor* s, tsd_scan_result* result);
+
 /* The same scan in two halves for several robots on ONE grid (the reference's multi-robot mode, SlamNode.cpp:101-122),
  * one calling thread per SENSOR.  tsd_scan_begin enqueues copy, tables, ray cast and registration (+ gates,
  * Sensor::transform) on the sensor's own stream and buffers; tsd_scan_wait blocks the calling thread until the result

@@ -151,6 +151,9 @@ ABI = {
     "tsd_sensor_set_pose": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),
     "tsd_scan": (C.c_int, [C.c_void_p, _dp, _u8p, _u8p, C.POINTER(IcpParams), C.POINTER(GateParams),
                            C.POINTER(ScanResult)]),
+    "tsd_scan_submit": (C.c_int, [C.c_void_p, _dp, _u8p, _u8p, C.POINTER(IcpParams), C.POINTER(GateParams)]),
+    "tsd_scan_stage": (C.c_int, [C.c_void_p, _dp, _u8p, _u8p]),
+    "tsd_scan_collect": (C.c_int, [C.c_void_p, C.POINTER(ScanResult)]),
     "tsd_scan_begin": (C.c_int, [C.c_void_p, _dp, _u8p, _u8p, C.POINTER(IcpParams), C.POINTER(GateParams)]),
     "tsd_scan_wait": (C.c_int, [C.c_void_p]),
     "tsd_scan_finish": (C.c_int, [C.c_void_p, C.POINTER(ScanResult)]),
@@ -469,6 +472,24 @@ class TsdSensorDevice:
     def set_pose(self, pose, rays_world, rays_local):
         pose, rw, rl = _f64(pose).reshape(9), _f64(rays_world), _f64(rays_local)
         self.grid._check(self.lib.tsd_sensor_set_pose(self.h, _d(pose), _d(rw), _d(rl)), "tsd_sensor_set_pose")
+
+    def scan_ahead(self, ranges, mask, mask_push, params: IcpParams, gates: GateParams, nxt=None) -> ScanResult:
+        """tsd_scan_submit (``ranges`` None: the scan staged by the previous call) + tsd_scan_stage of ``nxt`` = (ranges, mask,
+        mask_push) while the registration runs + tsd_scan_collect"""
+        if ranges is None:
+            rc = self.lib.tsd_scan_submit(self.h, None, None, None, C.byref(params), C.byref(gates))
+        else:
+            rg, mk = _f64(ranges), np.ascontiguousarray(mask, dtype=np.uint8)
+            mp = np.ascontiguousarray(mask_push, dtype=np.uint8) if mask_push is not None else None
+            rc = self.lib.tsd_scan_submit(self.h, _d(rg), _u8(mk), _u8(mp) if mp is not None else None, C.byref(params), C.byref(gates))
+        self.grid._check(rc, "tsd_scan_submit")
+        if nxt is not None:
+            rg, mk = _f64(nxt[0]), np.ascontiguousarray(nxt[1], dtype=np.uint8)
+            mp = np.ascontiguousarray(nxt[2], dtype=np.uint8) if nxt[2] is not None else None
+            self.grid._check(self.lib.tsd_scan_stage(self.h, _d(rg), _u8(mk), _u8(mp) if mp is not None else None), "tsd_scan_stage")
+        r = ScanResult()
+        self.grid._check(self.lib.tsd_scan_collect(self.h, C.byref(r)), "tsd_scan_collect")
+        return r
 
     def scan(self, ranges, mask, mask_push, params: IcpParams, gates: GateParams) -> ScanResult:
         rg = _f64(ranges)

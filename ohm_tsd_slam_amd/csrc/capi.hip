@@ -247,6 +247,7 @@ struct ConcTiming {
   ConcTiming() : on(getenv("TSD_CONC_TIMING") != nullptr) { for (auto& v : ns) v = 0; n = 0; }
 };
 static ConcTiming g_conc_timing;
+static ConcTiming g_scan_timing;      // the same for tsd_scan (one robot): where the host time of a scan goes
 static inline unsigned long long now_ns()
 {
   return (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -256,6 +257,12 @@ struct ConcLap {
   ConcLap() : t(g_conc_timing.on ? now_ns() : 0) {}
   void lap(int i) { if (g_conc_timing.on) { const unsigned long long u = now_ns(); g_conc_timing.ns[i] += u - t; t = u; } }
 };
+struct ScanLap {
+  unsigned long long t;
+  ScanLap() : t(g_scan_timing.on ? now_ns() : 0) {}
+  void lap(int i) { if (g_scan_timing.on) { const unsigned long long u = now_ns(); g_scan_timing.ns[i] += u - t; t = u; } }
+};
+static unsigned long long g_scan_last_return = 0;
 
 // every grid WRITE enqueued on the context's stream goes behind the ray casts the concurrent multi-robot path has in
 // flight on the sensors' own streams (no-op without such sensors)
@@ -376,6 +383,13 @@ tsd_ctx* tsd_create(int device, int map_size_log2, double cell_size, double max_
 void tsd_destroy(tsd_ctx* ctx)
 {
   if (!ctx) return;
+  if (g_scan_timing.on && g_scan_timing.n) {
+    const double n = (double)g_scan_timing.n;
+    static const char* names[8] = {"caller (between calls)", "stage+copy+tables", "ray cast", "wait copy + icp launch", "push launches", "next ray cast", "wait result", "result"};
+    fprintf(stderr, "TSD_CONC_TIMING tsd_scan calls %.0f; host us per scan:", n);
+    for (int i = 0; i < 8; i++) fprintf(stderr, " %s %.1f", names[i], 1e-3 * (double)g_scan_timing.ns[i] / n);
+    fprintf(stderr, "\n");
+  }
   if (g_conc_timing.on && g_conc_timing.n) {
     const double n = (double)g_conc_timing.n;
     static const char* names[8] = {"begin:copy+tables", "begin:lock", "begin:ordered", "begin:raycast+icp", "wait", "finish:lock", "finish:push", "finish:result"};
@@ -1076,8 +1090,7 @@ tsd_sensor* tsd_sensor_create(tsd_ctx* ctx, int beams, double ang_res, double ph
   A(hipMalloc(&s->d_state, sizeof(SensorDev)));
   A(hipMalloc(&s->d_rays, nb * 16));
   A(hipMalloc(&s->d_rays_local, nb * 16));
-  A(hipMalloc(&s->d_scan2[0], nb * 10 + 64));
-  A(hipMalloc(&s->d_scan2[1], nb * 10 + 64));
+  for (int i = 0; i < 3; i++) A(hipMalloc(&s->d_scan2[i], nb * 10 + 64));
   // the scan result is written by the kernel straight into coherent pinned host memory
   A(hipHostMalloc(&s->h_result, sizeof(ScanResultDev), hipHostMallocMapped | hipHostMallocCoherent));
   if (ok) { std::memset(s->h_result, 0, sizeof(ScanResultDev)); A(hipHostGetDevicePointer((void**)&s->d_result, s->h_result, 0)); }
@@ -1098,10 +1111,10 @@ void tsd_sensor_destroy(tsd_sensor* s)
   for (hipEvent_t e : {s->ev_rc_done, s->ev_icp_done}) if (e) hipEventDestroy(e);
   if (s->stream) hipStreamDestroy(s->stream);
   hipFree(s->d_coords); hipFree(s->d_normals); hipFree(s->d_mask_m); hipFree(s->d_icp_res); hipFree(s->d_icp_trace);
-  hipFree(s->d_rmq2[0]); hipFree(s->d_rmq2[1]);
+  hipFree(s->d_rmq2[0]); hipFree(s->d_rmq2[1]); hipFree(s->d_rmq2[2]);
   if (s->h_stage2[0]) hipHostFree(s->h_stage2[0]);
   if (s->h_stage2[1]) hipHostFree(s->h_stage2[1]);
-  hipFree(s->d_state); hipFree(s->d_rays); hipFree(s->d_rays_local); hipFree(s->d_scan2[0]); hipFree(s->d_scan2[1]);
+  hipFree(s->d_state); hipFree(s->d_rays); hipFree(s->d_rays_local); hipFree(s->d_scan2[0]); hipFree(s->d_scan2[1]); hipFree(s->d_scan2[2]);
   hipHostFree(s->h_result);
   delete s;
 }
@@ -1145,14 +1158,14 @@ int tsd_sensor_set_pose(tsd_sensor* s, const double pose33[9], const double* ray
   return TSD_OK;
 }
 
-int tsd_scan(tsd_sensor* s, const double* ranges, const uint8_t* mask, const uint8_t* mask_push,
-             const tsd_icp_params* params, const tsd_gate_params* gates, tsd_scan_result* result)
+static int sensor_conc_init(tsd_sensor* s, bool own_stream);
+
+// copy + range-query tables of one scan on the side stream, into the sensor's buffers the scan in flight does not use
+static int scan_stage_impl(tsd_sensor* s, const double* ranges, const uint8_t* mask, const uint8_t* mask_push)
 {
-  if (!s || !s->ctx || !ranges || !mask || !params || !gates || !result) return TSD_E_ARG;
   tsd_ctx* ctx = s->ctx;
-  if (!s->posed) return set_error(ctx, TSD_E_ARG, "tsd_scan before tsd_sensor_set_pose", hipSuccess);
-  TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const size_t nb = (size_t)s->beams;
+  if (int rc = sensor_conc_init(s, false)) return rc;       // (the sensor's own table buffers)
   // One H2D: ranges | mask | mask_push, on the side stream into the buffer the previous scan does not use: the
   // copy and the range-query tables of this scan's push (which only depend on the scan) run while the previous
   // push and this scan's ray cast are still busy on the main stream.
@@ -1161,17 +1174,60 @@ int tsd_scan(tsd_sensor* s, const double* ranges, const uint8_t* mask, const uin
   std::memcpy(h, ranges, nb * 8);
   std::memcpy(h + nb * 8, mask, nb);
   std::memcpy(h + nb * 9, mask_push ? mask_push : mask, nb);
-  char* d_scan = s->d_scan2[s->scan_slot];
-  s->scan_slot ^= 1;
+  // three buffers in turn (see tsd_sensor::stage_slot): the push that read this one three scans ago is done
+  const int sslot = s->stage_slot;
+  char* d_scan = s->d_scan2[sslot];
+  s->stage_slot = (s->stage_slot + 1) % 3;
   TSD_HIP_CHECK(ctx, hipMemcpyAsync(d_scan, h, nb * 10, hipMemcpyHostToDevice, ctx->stream2));
   TSD_HIP_CHECK(ctx, hipEventRecord(ctx->stage_ev[slot], ctx->stream2));
   TSD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_h2d, ctx->stream2));
-  const double* d_ranges = reinterpret_cast<const double*>(d_scan);
-  const uint8_t* d_mask = reinterpret_cast<const uint8_t*>(d_scan + nb * 8);
-  const uint8_t* d_mask_push = reinterpret_cast<const uint8_t*>(d_scan + nb * 9);
-  int rc = launch_push_tables(ctx, ctx->stream2, s->beams, d_ranges, d_mask_push, s->phi_min, s->ang_res);
+  s->st_ranges = reinterpret_cast<const double*>(d_scan);
+  s->st_mask = reinterpret_cast<const uint8_t*>(d_scan + nb * 8);
+  s->st_mask_push = reinterpret_cast<const uint8_t*>(d_scan + nb * 9);
+  s->st_rmq = s->d_rmq2[sslot]; s->st_slot = sslot;
+  LaunchTarget tg;
+  tg.rmq = s->st_rmq;
+  TargetScope scope(ctx, &tg);
+  int rc = launch_push_tables(ctx, ctx->stream2, s->beams, s->st_ranges, s->st_mask_push, s->phi_min, s->ang_res);
   if (rc != TSD_OK) return rc;
   TSD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_tables, ctx->stream2));
+  s->staged = true;
+  return TSD_OK;
+}
+
+int tsd_scan_stage(tsd_sensor* s, const double* ranges, const uint8_t* mask, const uint8_t* mask_push)
+{
+  if (!s || !s->ctx || !ranges || !mask) return TSD_E_ARG;
+  tsd_ctx* ctx = s->ctx;
+  if (!s->posed) return set_error(ctx, TSD_E_ARG, "tsd_scan_stage before tsd_sensor_set_pose", hipSuccess);
+  if (s->staged) return set_error(ctx, TSD_E_ARG, "tsd_scan_stage: a staged scan is waiting for tsd_scan_submit already", hipSuccess);
+  TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  return scan_stage_impl(s, ranges, mask, mask_push);
+}
+
+int tsd_scan_submit(tsd_sensor* s, const double* ranges, const uint8_t* mask, const uint8_t* mask_push,
+                    const tsd_icp_params* params, const tsd_gate_params* gates)
+{
+  if (!s || !s->ctx || !params || !gates || (ranges && !mask)) return TSD_E_ARG;
+  tsd_ctx* ctx = s->ctx;
+  if (!s->posed) return set_error(ctx, TSD_E_ARG, "tsd_scan before tsd_sensor_set_pose", hipSuccess);
+  if (s->submitted) return set_error(ctx, TSD_E_ARG, "tsd_scan_submit: the previous scan was not collected", hipSuccess);
+  if (!ranges && !s->staged) return set_error(ctx, TSD_E_ARG, "tsd_scan_submit without a scan (none given, none staged)", hipSuccess);
+  TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  ScanLap lap;
+  if (g_scan_timing.on && g_scan_last_return && lap.t - g_scan_last_return < 1000000ull) g_scan_timing.ns[0] += lap.t - g_scan_last_return;   // (one-off pauses of the caller excluded)
+  const bool staged_ahead = ranges == nullptr;
+  if (ranges) {
+    s->staged = false;                       // (a scan staged ahead that is not the one that came is dropped)
+    int rcs = scan_stage_impl(s, ranges, mask, mask_push);
+    if (rcs != TSD_OK) return rcs;
+  }
+  s->staged = false;
+  const double* d_ranges = s->st_ranges;
+  const uint8_t* d_mask = s->st_mask;
+  const uint8_t* d_mask_push = s->st_mask_push;
+  int rc = TSD_OK;
+  lap.lap(1);
 
   // The ray cast needs nothing from the scan (its pose arguments were left on the device by the previous
   // registration), so the previous tsd_scan enqueued it right behind its push; it is launched here only if
@@ -1184,6 +1240,7 @@ int tsd_scan(tsd_sensor* s, const double* ranges, const uint8_t* mask, const uin
     if (rc != TSD_OK) return rc;
   }
   s->rc_pending = false;
+  lap.lap(2);
   IcpArgs ia;
   const double ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   fill_icp_args(ia, ident, params);
@@ -1197,24 +1254,45 @@ int tsd_scan(tsd_sensor* s, const double* ranges, const uint8_t* mask, const uin
   sp.gates = GateArgs{gates->reg_trs_max, gates->reg_sin_rot_max, gates->trs_min, gates->rot_min};
   // The ray cast did not need the scan, the registration does.  The copy is short and the ray cast long, so the
   // host waits for the copy itself (a few microseconds, the device is busy meanwhile) instead of putting a
-  // cross-stream barrier between the two kernels; the barrier is the fall-back.
-  if (!host_saw_event(ctx->ev_h2d, 40)) TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_h2d, 0));
+  // cross-stream barrier between the two kernels; the barrier is the fall-back.  (A scan staged ahead was copied
+  // during the previous registration: nothing to wait for.)
+  if (!host_saw_event(ctx->ev_h2d, staged_ahead ? 2 : 40)) TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_h2d, 0));
   rc = launch_icp(ctx, ia, s->d_state->icpP, s->d_rays_local, d_ranges, d_mask, &sp);
   if (rc != TSD_OK) return rc;
+  lap.lap(3);
   PushArgs pa;
   std::memset(&pa, 0, sizeof(pa));
   pa.beams = s->beams;                                   // LDS size of the launch
   pa.max_range = s->max_range;                           // tile window of the launch (the rest is read on the device)
-  if (!host_saw_event(ctx->ev_tables, 60)) TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_tables, 0));
-  // the registration moves the sensor by at most the gate (a larger step is rejected: pose unchanged)
-  rc = launch_push(ctx, pa, s->pos[0], s->pos[1], gates->reg_trs_max, &s->d_state->push, d_ranges, d_mask_push);
+  if (!host_saw_event(ctx->ev_tables, staged_ahead ? 2 : 60)) TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_tables, 0));
+  {
+    LaunchTarget tg;
+    tg.rmq = s->st_rmq;                                  // this scan's tables (the sensor's own buffers)
+    TargetScope scope(ctx, &tg);
+    // the registration moves the sensor by at most the gate (a larger step is rejected: pose unchanged)
+    rc = launch_push(ctx, pa, s->pos[0], s->pos[1], gates->reg_trs_max, &s->d_state->push, d_ranges, d_mask_push);
+  }
   if (rc != TSD_OK) return rc;
   ctx->epoch++;                                          // the grid changes
+  lap.lap(4);
   // the next scan's ray cast, right behind the push (see above): the host's work on the next scan no longer sits
   // between this push and that ray cast
   rc = launch_raycast(ctx, ra, &s->d_state->rc, s->d_rays);
   if (rc != TSD_OK) return rc;
   s->rc_pending = true; s->rc_epoch = ctx->epoch;
+  lap.lap(5);
+  s->submitted = true;
+  return TSD_OK;
+}
+
+int tsd_scan_collect(tsd_sensor* s, tsd_scan_result* result)
+{
+  if (!s || !s->ctx || !result) return TSD_E_ARG;
+  tsd_ctx* ctx = s->ctx;
+  if (!s->submitted) return set_error(ctx, TSD_E_ARG, "tsd_scan_collect without tsd_scan_submit", hipSuccess);
+  s->submitted = false;
+  ScanLap lap;
+  const unsigned long long seq = s->seq;
   // The result is known once k_scan_post has run; the push kernels behind it only touch the grid, and
   // whatever the caller enqueues next is ordered behind them on the stream.  So the host does not wait for
   // the stream: it polls the sequence number and prepares the next scan while the push is still running.
@@ -1233,12 +1311,24 @@ int tsd_scan(tsd_sensor* s, const double* ranges, const uint8_t* mask, const uin
 #endif
     }
   }
+  lap.lap(6);
   copy_icp_result(&s->h_result->icp, &result->icp);
   for (int i = 0; i < 9; i++) result->pose[i] = s->h_result->pose[i];
   s->pos[0] = result->pose[2]; s->pos[1] = result->pose[5];
   result->reg_error = s->h_result->reg_error; result->pushed = s->h_result->pushed;
   result->no_model = s->h_result->no_model; result->reserved = 0;
+  lap.lap(7);
+  if (g_scan_timing.on) { g_scan_timing.n++; g_scan_last_return = now_ns(); }
   return TSD_OK;
+}
+
+int tsd_scan(tsd_sensor* s, const double* ranges, const uint8_t* mask, const uint8_t* mask_push,
+             const tsd_icp_params* params, const tsd_gate_params* gates, tsd_scan_result* result)
+{
+  if (!s || !s->ctx || !ranges || !mask || !params || !gates || !result) return TSD_E_ARG;
+  const int rc = tsd_scan_submit(s, ranges, mask, mask_push, params, gates);
+  if (rc != TSD_OK) return rc;
+  return tsd_scan_collect(s, result);
 }
 
 
@@ -1255,7 +1345,7 @@ int tsd_scan(tsd_sensor* s, const double* ranges, const uint8_t* mask, const uin
 // for every grid write enqueued before it, a push for every ray cast ticketed since the last grid write; registrations
 // overlap freely.  The push is enqueued only once its registration has finished: events order by ENQUEUE time, so a
 // push enqueued ahead of time would pull every later ray cast of every robot behind its own registration.
-static int sensor_conc_init(tsd_sensor* s, bool own_stream = true)
+static int sensor_conc_init(tsd_sensor* s, bool own_stream)
 {
   tsd_ctx* ctx = s->ctx;
   bool ok = true;
@@ -1269,7 +1359,7 @@ static int sensor_conc_init(tsd_sensor* s, bool own_stream = true)
   const size_t nb = (size_t)s->beams;
   A(hipMalloc(&s->d_coords, nb * 16)); A(hipMalloc(&s->d_normals, nb * 16)); A(hipMalloc(&s->d_mask_m, nb));
   A(hipMalloc(&s->d_icp_res, sizeof(IcpResultDev))); A(hipMalloc(&s->d_icp_trace, sizeof(double) * TSD_ICP_TRACE_STRIDE * TSD_ICP_TRACE_MAX));
-  A(hipMalloc(&s->d_rmq2[0], push_rmq_bytes(s->beams))); A(hipMalloc(&s->d_rmq2[1], push_rmq_bytes(s->beams)));
+  for (int i = 0; i < 3; i++) A(hipMalloc(&s->d_rmq2[i], push_rmq_bytes(s->beams)));
   A(hipHostMalloc(&s->h_stage2[0], nb * 10 + 64, hipHostMallocDefault)); A(hipHostMalloc(&s->h_stage2[1], nb * 10 + 64, hipHostMallocDefault));
   if (!ok) return set_error(ctx, TSD_E_HIP, "tsd_scan_begin: per-sensor streams / buffers", hipGetLastError());
   s->conc_ready = true;
@@ -1284,7 +1374,7 @@ int tsd_scan_begin(tsd_sensor* s, const double* ranges, const uint8_t* mask, con
   if (!s->posed) return set_error(ctx, TSD_E_ARG, "tsd_scan_begin before tsd_sensor_set_pose", hipSuccess);
   if (s->inflight) return set_error(ctx, TSD_E_ARG, "tsd_scan_begin: the previous scan of this sensor was not finished", hipSuccess);
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  int rc = sensor_conc_init(s);
+  int rc = sensor_conc_init(s, true);
   if (rc != TSD_OK) return rc;
   const size_t nb = (size_t)s->beams;
   ConcLap lap;

@@ -218,6 +218,20 @@ void ThreadLocalize::laserCallBack(const std::shared_ptr<sensor_msgs::msg::Laser
   }
 }
 
+void ThreadLocalize::announceNext(const std::shared_ptr<sensor_msgs::msg::LaserScan> scan)
+{
+  auto copy = std::make_shared<sensor_msgs::msg::LaserScan>(*scan);
+  for(auto& iter : copy->ranges)
+  {
+    if(iter < _lasMinRange)
+      iter = 0.0;
+  }
+  if(_reverseScan)
+    std::reverse(copy->ranges.begin(), copy->ranges.end());
+  std::lock_guard<std::mutex> lk(_dataMutex);
+  _ahead = copy;
+}
+
 void ThreadLocalize::eventLoop(void)
 {
   while(_stayActive)
@@ -257,8 +271,14 @@ void ThreadLocalize::processScan(const std::vector<float>& ranges, const builtin
   _stampLaserOld = _stampLaser;
   _stampLaser = stamp;
 
-  _sensor->setRealMeasurementData(ranges);
-  _sensor->setStandardMask();
+  // (a scan that was announced, ingested and staged on the device during the previous registration is in _sensor already)
+  const bool staged = _stagedValid && _stagedStampNs == rep.stampNs;
+  if(_stagedValid && !staged) _stagedValid = false;     // something else came: tsd_scan_submit drops the staged scan
+  if(!staged)
+  {
+    _sensor->setRealMeasurementData(ranges);
+    _sensor->setStandardMask();
+  }
 
   if(!_haveLastPose)   // first call (ThreadLocalize.cpp:342-350)
   {
@@ -402,9 +422,37 @@ void ThreadLocalize::processScanFused(ScanReport& rep)
   tsd_gate_params gates = {_trnsMax, _rotMax, TRNS_MIN, ROT_MIN};
   tsd_scan_result sr;
   std::memset(&sr, 0, sizeof(sr));
-  // several robots on one grid: split scan, so that the robots' registrations overlap on the device
-  const int rc = _concurrent ? _grid.scanConcurrent(_sensor, maskPush.data(), _icpParams, gates, &sr)
-                             : _grid.scan(_sensor, maskPush.data(), _icpParams, gates, &sr);
+  int rc;
+  if(_concurrent)
+  {
+    // several robots on one grid: the grid's dispatcher batches the robots' scans (or the split scan)
+    rc = _grid.scanConcurrent(_sensor, maskPush.data(), _icpParams, gates, &sr);
+  }
+  else
+  {
+    const bool useStaged = _stagedValid;
+    _stagedValid = false;
+    rc = _grid.scanSubmit(_sensor, useStaged, maskPush.data(), _icpParams, gates);
+    // the next scan, if it is known already: ingest + copy + tables while the device registers this one
+    std::shared_ptr<sensor_msgs::msg::LaserScan> next;
+    {
+      std::lock_guard<std::mutex> lk(_dataMutex);
+      next.swap(_ahead);
+    }
+    if(rc == TSD_OK && next && next->ranges.size() == _sensor->getRealMeasurementSize())
+    {
+      _sensor->setRealMeasurementData(next->ranges);
+      _sensor->setStandardMask();
+      std::vector<uint8_t> maskNext;
+      _sensor->maskForMapping(maskNext);
+      if(_grid.scanStage(_sensor, maskNext.data()) == TSD_OK)
+      {
+        _stagedValid = true;
+        _stagedStampNs = (long long)next->header.stamp.sec * 1000000000LL + (long long)next->header.stamp.nanosec;
+      }
+    }
+    if(rc == TSD_OK) rc = _grid.scanCollect(_sensor, &sr);
+  }
   _sensor->getTransformation().getData(rep.pose);
   if(rc != TSD_OK)
   {

@@ -45,6 +45,10 @@ public:
   /** this grid is shared with other localisers (SlamNode's multi-robot mode): use the split scan of the fused path
    *  (tsd_scan_begin / _wait / _finish) so that the robots' registrations overlap on the device */
   void setConcurrent(bool on) { _concurrent = on; }
+  /** the scan that will come NEXT is known already (queued behind the one being processed; a replayed log): the fused path
+   *  ingests it and stages it on the device while the current registration runs (tsd_scan_stage).  The following
+   *  laserCallBack with the same stamp then starts from the staged data. */
+  void announceNext(const std::shared_ptr<sensor_msgs::msg::LaserScan> scan);
   struct ScanReport {
     double pose[9]; double T[9]; double rms; int pairs; int iterations; int icpState;
     int validModel; int validScene; bool regError; bool pushed; bool noModel; bool initialised;
@@ -100,6 +104,9 @@ private:
   bool _haveLastPose;
   builtin_interfaces::msg::Time _stampLaser, _stampLaserOld;
 
+  std::shared_ptr<sensor_msgs::msg::LaserScan> _ahead;      // announced next scan (clamped like laserCallBack does)
+  bool _stagedValid = false;                                // _sensor holds, and the device has staged, the scan with ...
+  long long _stagedStampNs = 0;                             // ... this stamp
   std::deque<std::shared_ptr<sensor_msgs::msg::LaserScan>> _laserData;
   std::mutex _dataMutex;
   bool _busy;

@@ -182,6 +182,22 @@ int tsd_node_laser(tsd_node* n, int robot, const float* ranges, int count, doubl
   return TSD_OK;
 }
 
+// the scan that tsd_node_laser will deliver NEXT (ThreadLocalize::announceNext): known ahead in a replay, or queued
+int tsd_node_laser_ahead(tsd_node* n, int robot, const float* ranges, int count, double angle_min, double angle_increment,
+                         long long stamp_ns)
+{
+  if(!n || robot < 0 || robot >= (int)n->localizers.size())
+    return TSD_E_ARG;
+  auto scan = std::make_shared<sensor_msgs::msg::LaserScan>();
+  scan->ranges.assign(ranges, ranges + count);
+  scan->angle_min = (float)angle_min;
+  scan->angle_increment = (float)angle_increment;
+  scan->header.stamp.sec = (int32_t)(stamp_ns / 1000000000LL);
+  scan->header.stamp.nanosec = (uint32_t)(stamp_ns % 1000000000LL);
+  n->localizers[robot]->announceNext(scan);
+  return TSD_OK;
+}
+
 // Replay of recorded scans, the way `rosbag play` feeds the reference node: one publisher thread per robot, each handing
 // its robot's scans to laserCallBack in order (synchronous facade: the callback returns when the scan has been processed, so
 // every robot runs as fast as the node lets it and the robots' scans overlap).  scans[r] = n_scans x count floats.
@@ -195,9 +211,14 @@ int tsd_node_play(tsd_node* n, int robots, const float* const* scans, int first,
   for(int r = 0; r < robots; r++)
     pubs.emplace_back([&, r] {
       for(int k = first; k < first + n_scans; k++)
+      {
+        if(k + 1 < first + n_scans)       // (a replay knows the next scan: the localiser stages it during this registration)
+          tsd_node_laser_ahead(n, r, scans[r] + (size_t)(k + 1) * (size_t)count, count, angle_min, angle_increment,
+                               stamp0_ns + (long long)(k + 1) * stamp_step_ns);
         if(tsd_node_laser(n, r, scans[r] + (size_t)k * (size_t)count, count, angle_min, angle_increment,
                           stamp0_ns + (long long)k * stamp_step_ns) != TSD_OK)
           failed++;
+      }
     });
   for(auto& t : pubs)
     t.join();

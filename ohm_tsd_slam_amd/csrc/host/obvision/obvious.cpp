@@ -346,6 +346,28 @@ int TsdGrid::scan(SensorPolar2D* sensor, const uint8_t* maskPush, const tsd_icp_
   return rc;
 }
 
+int TsdGrid::scanSubmit(SensorPolar2D* sensor, bool useStaged, const uint8_t* maskPush, const tsd_icp_params& params,
+                        const tsd_gate_params& gates)
+{
+  std::lock_guard<std::mutex> lk(_mutex);
+  if (useStaged) return tsd_scan_submit(sensor->deviceHandle(), nullptr, nullptr, nullptr, &params, &gates);
+  return tsd_scan_submit(sensor->deviceHandle(), sensor->getRealMeasurementData(), sensor->maskBytes(), maskPush, &params, &gates);
+}
+
+int TsdGrid::scanStage(SensorPolar2D* sensor, const uint8_t* maskPush)
+{
+  std::lock_guard<std::mutex> lk(_mutex);
+  return tsd_scan_stage(sensor->deviceHandle(), sensor->getRealMeasurementData(), sensor->maskBytes(), maskPush);
+}
+
+int TsdGrid::scanCollect(SensorPolar2D* sensor, tsd_scan_result* result)
+{
+  // (the wait itself needs no lock: it polls the sensor's own result record)
+  const int rc = tsd_scan_collect(sensor->deviceHandle(), result);
+  if (rc == TSD_OK && result->pushed) _initialPushAccomplished = true;
+  return rc;
+}
+
 void TsdGrid::enableBatchedScans(int robots, int slots)
 {
   if (!_batcher && _ctx && robots > 1) _batcher.reset(new ScanBatcher(_ctx, robots, slots));

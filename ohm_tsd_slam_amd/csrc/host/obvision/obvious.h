@@ -189,6 +189,14 @@ public:
   virtual int scan(SensorPolar2D* sensor, const uint8_t* maskPush, const tsd_icp_params& params,
                    const tsd_gate_params& gates, tsd_scan_result* result);
 
+  // tsd_scan in two halves with the next scan staged in between (tsd_scan_submit / _stage / _collect): a caller that
+  // already holds the next LaserScan has its copy and tables done while the current registration runs.
+  // scanSubmit(sensor == data source or nullptr for the scan staged by scanStage)
+  virtual int scanSubmit(SensorPolar2D* sensor, bool useStaged, const uint8_t* maskPush, const tsd_icp_params& params,
+                         const tsd_gate_params& gates);
+  virtual int scanStage(SensorPolar2D* sensor, const uint8_t* maskPush);
+  virtual int scanCollect(SensorPolar2D* sensor, tsd_scan_result* result);
+
   // the same scan in two halves for several robots on this one grid (tsd_scan_begin / _wait / _finish): the mutex is
   // held for the two enqueue steps only, the wait in between is lock-free, so the robots' registrations overlap
   virtual int scanConcurrent(SensorPolar2D* sensor, const uint8_t* maskPush, const tsd_icp_params& params,

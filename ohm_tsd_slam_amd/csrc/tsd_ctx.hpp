@@ -225,12 +225,19 @@ struct tsd_sensor {
   tsd::SensorDev* d_state = nullptr;
   double* d_rays = nullptr;        // [2*beams] world rays, normalised to the cell size
   double* d_rays_local = nullptr;  // [2*beams]
-  char* d_scan2[2] = {nullptr, nullptr};   // ranges[beams] | mask[beams] | mask_push[beams], alternating between scans
+  char* d_scan2[3] = {nullptr, nullptr, nullptr};   // ranges[beams] | mask[beams] | mask_push[beams], used in turn (split scan: 0 / 1)
   int scan_slot = 0;
   tsd::ScanResultDev* h_result = nullptr;   // pinned, coherent, written by k_scan_post directly
   tsd::ScanResultDev* d_result = nullptr;   // device address of h_result
   unsigned long long seq = 0;
   double pos[2] = {0, 0};          // host mirror of the sensor position (window of the push launches)
+  // tsd_scan_stage / _submit / _collect: the scan that is staged (copied, tables built) and not yet submitted
+  bool staged = false, submitted = false;
+  const double* st_ranges = nullptr; const uint8_t* st_mask = nullptr; const uint8_t* st_mask_push = nullptr;
+  char* st_rmq = nullptr; int st_slot = 0;
+  int stage_slot = 0;              // the scan / table buffers are used in turn, THREE of them: the scan staged ahead of scan k+2 goes
+                                   // where scan k was, and by then the host has seen the result of scan k+1, whose ray cast ran behind
+                                   // the push of scan k on the stream -- so that push is done without any event on the stream
   bool rc_pending = false;         // the next scan's ray cast was enqueued behind this scan's push ...
   unsigned long long rc_epoch = 0; // ... when the context was in this state
 
@@ -244,7 +251,7 @@ struct tsd_sensor {
   volatile int rc_recorded = 1;                // ... whose ev_rc_done record has been issued (by the sensor's own thread)
   double* d_coords = nullptr; double* d_normals = nullptr; uint8_t* d_mask_m = nullptr;
   tsd::IcpResultDev* d_icp_res = nullptr; double* d_icp_trace = nullptr;
-  char* d_rmq2[2] = {nullptr, nullptr}; int rmq_slot = 0;
+  char* d_rmq2[3] = {nullptr, nullptr, nullptr}; int rmq_slot = 0;
   char* h_stage2[2] = {nullptr, nullptr};   // pinned staging of the scan, alternating
   bool inflight = false;           // begin() without finish()
   tsd_gate_params conc_gates{};

@@ -34,6 +34,7 @@ HOST_ABI = {
     "tsd_node_report": (None, [C.c_void_p, C.c_int, _dp]),
     "tsd_node_pose_msg": (None, [C.c_void_p, C.c_int, _dp]),
     "tsd_node_pose_topic": (C.c_char_p, [C.c_void_p, C.c_int]),
+    "tsd_node_laser_ahead": (C.c_int, [C.c_void_p, C.c_int, _fp, C.c_int, C.c_double, C.c_double, C.c_longlong]),
     "tsd_node_play": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(_fp), C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_longlong, C.c_longlong]),
     "tsd_node_batch_stats": (None, [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "tsd_node_grid_ctx": (C.c_void_p, [C.c_void_p]),
@@ -140,11 +141,16 @@ class SlamNode:
     def set_synchronous(self, on: bool):
         self.lib.tsd_node_set_synchronous(self.h, int(on))
 
-    def laser(self, ranges_f32, angle_min, angle_increment, robot: int = 0, stamp_ns: int | None = None):
+    def laser(self, ranges_f32, angle_min, angle_increment, robot: int = 0, stamp_ns: int | None = None, ahead=None):
+        """``ahead``: the scan the NEXT call will deliver (known in a replay): announced to the localiser, which stages it on
+        the device while this scan's registration runs."""
         r = np.ascontiguousarray(ranges_f32, dtype=np.float32)
         if stamp_ns is None:
             self._stamp += 25_000_000
             stamp_ns = self._stamp
+        if ahead is not None:
+            a = np.ascontiguousarray(ahead, dtype=np.float32)
+            self.lib.tsd_node_laser_ahead(self.h, robot, a.ctypes.data_as(_fp), a.size, angle_min, angle_increment, stamp_ns + 25_000_000)
         rc = self.lib.tsd_node_laser(self.h, robot, r.ctypes.data_as(_fp), r.size, angle_min, angle_increment, stamp_ns)
         if rc != 0:
             raise capi.TsdError(f"tsd_node_laser failed ({rc})")
