@@ -217,6 +217,39 @@ def test_facade_two_robots_concurrently(oracle):
     node.close()
 
 
+def test_facade_next_scan_staged_ahead_is_bit_identical(oracle):
+    """The next scan announced to the localiser (ThreadLocalize::announceNext -> tsd_scan_stage during the current registration,
+    what bench.py does) must change nothing: same reports and the same grid, bit for bit, as feeding the scans one by one.
+    Every fifth announcement is a WRONG scan (another stamp comes next): the staged scan has to be dropped."""
+    gc, geo, scene = synth.CONFIGS["cfg2"]
+    world = synth.World(scene, gc)
+    n = 30
+    scans = synth.scans_for(world, geo, synth.trajectory(world, n))
+    out = []
+    for ahead in (False, True):
+        node = facade.SlamNode(facade.node_params(gc, geo), synchronous=True)
+        reps = []
+        for k in range(n):
+            nxt = None
+            if ahead and k + 1 < n:
+                nxt = scans[k + 1] if k % 5 != 4 else scans[0]
+            if ahead and k % 5 == 4 and k + 1 < n:
+                # announce with a stamp that will not come: laser() announces for stamp + 25 ms, the next call then jumps by 50 ms
+                node.laser(scans[k], geo.angle_min, geo.angle_increment, ahead=nxt)
+                node._stamp += 25_000_000
+            else:
+                node.laser(scans[k], geo.angle_min, geo.angle_increment, ahead=nxt)
+            r = node.report()
+            reps.append((r["pose"].copy(), r["pairs"], r["iterations"], r["icp_state"], r["pushed"], r["valid_model"], r["valid_scene"]))
+        dig = node.grid().digest()
+        out.append((reps, dig))
+        node.close()
+    (ra, da), (rb, db) = out
+    for k, (x, y) in enumerate(zip(ra, rb)):
+        assert np.array_equal(x[0], y[0]) and x[1:] == y[1:], f"scan {k}: {x} != {y}"
+    assert da == db
+
+
 def test_facade_four_robots_replayed_through_the_dispatcher(oracle):
     """Four robots on one grid fed by the native replay (one publisher thread per robot, what bench.py --robots does): the
     facade's dispatcher groups their scans into batches (tsd_batch_*).  Every scan is processed, the scans travel in batches
