@@ -1611,7 +1611,7 @@ int tsd_batch_begin(tsd_batch* b, int n, tsd_sensor* const* sensors, const doubl
     fill_icp_args(e.a, ident, &params[i]);
     e.a.beams = s->beams; e.a.ccw = s->ccw ? 1 : 0;
     e.P_dev = s->d_state->icpP; e.coords = s->d_coords; e.mask_m = s->d_mask_m; e.rays_local = s->d_rays_local;
-    e.ranges = d_ranges; e.mask = d_mask; e.out = s->d_icp_res; e.trace = s->d_icp_trace; e.normals = s->d_normals;
+    e.ranges = d_ranges; e.mask = d_mask; e.out = s->d_icp_res; e.trace = nullptr /* no reader in the fused path */; e.normals = s->d_normals;
     const unsigned long long seq = ++s->seq;
     b->seqs[(size_t)i] = seq;
     e.post.st = s->d_state; e.post.rays = s->d_rays; e.post.out = s->d_result; e.post.seq = seq; e.post.beams = s->beams;

@@ -412,7 +412,8 @@ __device__ __forceinline__ NnResult wave_search(const IcpLds& L, int nM, double 
 }
 
 
-// pair sums of one step.  Closed form: sum mx, my, sx, sy, d2 and the four centred products (9); point to line:
+// pair sums of one step.  Closed form: sum mx, my, sx, sy, d2 and the four centred products (9; the estimator's two sums kept as
+// four: accumulating nominator and denominator per pair, 7 sums, measured no faster); point to line:
 // the six entries of A, the three of b, sum |n.(s - m)| (10).  The row pitch of the transpose buffer is the
 // next odd number (conflict-free columns).
 constexpr int NSUM_CF = 9, NSUM_PTL = 10;
@@ -1094,7 +1095,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     else if (iter >= max_it) state = TSD_ICP_MAXITERATIONS;
     rms_prev = rms;
     STAMP(5);
-    if (tid == 0 && iter <= TSD_ICP_TRACE_MAX && !(ABL & 64)) {
+    if (tid == 0 && iter <= TSD_ICP_TRACE_MAX && !(ABL & 64) && L.tail->trace) {
       double* tr = L.tail->trace + TSD_ICP_TRACE_STRIDE * (iter - 1);
       tr[0] = (double)pairs; tr[1] = rms; tr[2] = thr_before; tr[3] = (double)state;
       tr[4] = co; tr[5] = si; tr[6] = dX; tr[7] = dY;          // Tlast = [[co, -si, dX], [si, co, dY]] (NaN: no estimate this step)
@@ -1186,11 +1187,17 @@ static int launch_icp_shape_est(tsd_ctx* ctx, const IcpArgs& a, int n, int cap, 
   }
   ScopedKernelTimer t(ctx, "icp");
   const LaunchTarget* tg = launch_target();       // concurrent multi-robot path: the sensor's own stream and buffers
+  // the per-iteration record (tsd_icp_trace) is kept by tsd_icp / tsd_localize; the fused scan has no reader for it and skips
+  // the 64-byte store per step (the diagnostic stamp builds keep it: they park their counters there)
+  double* trace_buf = tg && tg->trace ? tg->trace : ctx->d_icp_trace;
+#ifndef TSD_ICP_STAMPS
+  if (post.st) trace_buf = nullptr;
+#endif
   hipExtLaunchKernelGGL((k_icp<R, MAXT, PTL>), dim3(1), dim3(T), lds, launch_stream(ctx), t.a, t.b, 0, a, P_dev, cap, ctx->d_model, ctx->d_scene,
                      ctx->d_morig, ctx->d_start, tg && tg->coords ? tg->coords : ctx->d_coords, tg && tg->mask_m ? tg->mask_m : ctx->d_mask_m,
                      d_rays_local ? d_rays_local : ctx->d_rays_local, d_ranges ? d_ranges : ctx->d_ranges,
                      d_mask ? d_mask : ctx->d_mask, tg && tg->icp_res ? tg->icp_res : ctx->d_icp_res,
-                     tg && tg->trace ? tg->trace : ctx->d_icp_trace, post, ctx->d_mnormals, tg && tg->normals ? tg->normals : ctx->d_normals);
+                     trace_buf, post, ctx->d_mnormals, tg && tg->normals ? tg->normals : ctx->d_normals);
   TSD_HIP_CHECK(ctx, hipGetLastError());
   return TSD_OK;
 }
