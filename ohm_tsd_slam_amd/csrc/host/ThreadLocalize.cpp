@@ -438,6 +438,14 @@ void ThreadLocalize::processScanFused(ScanReport& rep)
     {
       std::lock_guard<std::mutex> lk(_dataMutex);
       next.swap(_ahead);
+      if(!next && !_synchronous && !_laserData.empty())
+      {
+        // threaded mode: the newest scan that queued up meanwhile is what the event loop takes next -- unless a newer one
+        // still arrives, in which case the staged one is dropped like the reference drops it (ThreadLocalize.cpp:319-332)
+        next = std::make_shared<sensor_msgs::msg::LaserScan>(*_laserData.front());
+        if(_reverseScan)
+          std::reverse(next->ranges.begin(), next->ranges.end());
+      }
     }
     if(rc == TSD_OK && next && next->ranges.size() == _sensor->getRealMeasurementSize())
     {
