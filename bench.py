@@ -31,6 +31,7 @@ duration come from HIP events on every n-th dispatch of each kernel INSIDE the t
 from __future__ import annotations
 
 import argparse
+import gc as pygc
 import json
 import math
 import os
@@ -183,6 +184,8 @@ def main():
     ap.add_argument("--mode", default=None, choices=["slam", "push"])
     ap.add_argument("--storage", default="f64", choices=["f64", "q32"])
     ap.add_argument("--robots", type=int, default=1)
+    ap.add_argument("--pg-backend", choices=["gloo", "nccl"], default="gloo",
+                    help="torch.distributed backend of the control plane (rendezvous, barrier, max over ranks); the occupancy merge is RCCL either way")
     ap.add_argument("--no-lookahead", action="store_true", help="do not announce the next scan to the localiser (no staging ahead)")
     ap.add_argument("--python-feeders", action="store_true", help="--robots: Python feeder threads instead of the native replay tsd_node_play")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -209,10 +212,19 @@ def main():
     torch = None
     use_dist = world_size > 1 or args.force_dist
     if use_dist:
-        import torch  # plumbing only: process group (RCCL) and the barrier / max-over-ranks of the contract
+        # torch.distributed is the launcher's control plane only: rendezvous, the 128-byte RCCL id, barrier and max-over-ranks
+        # of the contract -- on the CPU (gloo).  The data-path collective is RCCL behind the C ABI (include/tsd_comm.h).  A "nccl"
+        # process group here would bring torch's own communicator and streams into the process, and HIP maps streams onto a few
+        # hardware queues: measured, the scan's side stream then shares a queue with its main stream (12 % slower scans, and the
+        # staging of the next scan lands behind the ray cast instead of beside the registration).  --pg-backend nccl restores it.
+        import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", local_rank))
+        if args.pg_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", local_rank))
+        else:
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+            dist.init_process_group("gloo", rank=rank, world_size=world_size)
 
     from ohm_tsd_slam_amd import capi, facade, multigpu, synth
     gc, geo, default_scene = synth.CONFIGS[args.config]
@@ -355,12 +367,21 @@ def run_slam(args, gc, geo, scene, K, W, every, device, rank, local_rank, world_
         dist.broadcast_object_list(ids, src=0)
         merger = multigpu.NativeOccupancyMerger(grid, world_size, rank, ids[0])
 
+    merges = [0]
+
     def step(k, r=0):
         # (a replay knows the next scan: announced, the localiser stages it on the device during this registration)
         nxt = scans[r][k + 1] if (R == 1 and not args.no_lookahead and k + 1 < len(scans[r])) else None
         node.laser(scans[r][k], geo.angle_min, geo.angle_increment, robot=r, ahead=nxt)
-        if merger is not None and r == 0 and k % MERGE_EVERY == 0:
-            merger.merge_async()            # extraction kernels + RCCL max all-reduce over xGMI, in stream order, no wait
+        # the occupancy merge: every MERGE_EVERY scans of the timed region, placed in the middle of each period (a region
+        # shorter than one period still holds ONE merge, in its middle, so that the collective is always part of what is
+        # timed); a few more at the end of the warm-up (RCCL sets its channels up on the first calls)
+        if merger is not None and r == 0:
+            s_t = k - (1 + W)
+            period = min(MERGE_EVERY, max(K, 1))
+            if (s_t >= 0 and s_t % period == period // 2) or (k <= W and k > W - 3):      # (warm-up: up to three, RCCL's first calls are slow)
+                merger.merge_async()        # extraction kernels + RCCL max all-reduce over xGMI, in stream order, no wait
+                merges[0] += 1 if s_t >= 0 else 0
 
     def run_range(k0, k1):
         if R == 1:
@@ -390,14 +411,23 @@ def run_slam(args, gc, geo, scene, K, W, every, device, rank, local_rank, world_
         torch.cuda.synchronize()
         dist.barrier()
     b0 = node.batch_stats()
+    # (the interpreter's cyclic collector off for the timed loop: with torch imported -- the multi-GPU launcher -- one
+    # generation-2 pass is a 40 ms pause in the middle of the region, the same step in every run)
+    pygc.collect()
+    pygc.disable()
     t0 = time.perf_counter()
     run_range(1 + W, 1 + W + K)
     grid.sync()
     if dist is not None:
         merger.wait()
         torch.cuda.synchronize()
-        dist.barrier()
+    # this rank's K steps are done (device idle, merge complete).  The closing barrier follows; the job's time is the MAX over the
+    # ranks of these local times (all ranks left the opening barrier together), which the all-reduce below takes -- so the
+    # barrier's own latency (0.2-0.4 ms over gloo, a tenth of a 20-step region) is not part of anybody's K steps.
     elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+    pygc.enable()
     upd_ms, upd_launches = grid.profile_get("push_update")
     stages = stage_table(grid, K)
     icp_min, icp_max, icp_std = grid.profile_spread("icp")
@@ -411,7 +441,7 @@ def run_slam(args, gc, geo, scene, K, W, every, device, rank, local_rank, world_
         errs.append(math.hypot(final["pose"][0, 2] - poses[r][-1, 0], final["pose"][1, 2] - poses[r][-1, 1]))
 
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}" if args.pg_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if args.calibrate:
@@ -429,6 +459,7 @@ def run_slam(args, gc, geo, scene, K, W, every, device, rank, local_rank, world_
                                + (", point-to-line estimator" if args.estimator else ""),
                    "robots": world_size * R, "robots_per_grid": R, "mode": "slam", "storage": "f64",
                    "occupancy_merge_every": MERGE_EVERY if world_size > 1 else None,
+                   "occupancy_merges_in_timed_region": merges[0] if merger is not None else None,
                    "note": "single-stream latency chain per robot: a scan's ray cast needs the previous scan's push"
                            if R == 1 else "robots' scans batched by the facade's dispatcher (tsd_batch_*), two batch slots in turn",
                    "scans_per_batch": (bstats[1] / max(bstats[0], 1)) if R > 1 else None},

@@ -248,6 +248,7 @@ struct ConcTiming {
 };
 static ConcTiming g_conc_timing;
 static ConcTiming g_scan_timing;      // the same for tsd_scan (one robot): where the host time of a scan goes
+static ConcTiming g_stage_timing;     // ... and of the staging of a scan (acquire, host copy, hipMemcpyAsync, records, tables)
 static inline unsigned long long now_ns()
 {
   return (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -257,10 +258,19 @@ struct ConcLap {
   ConcLap() : t(g_conc_timing.on ? now_ns() : 0) {}
   void lap(int i) { if (g_conc_timing.on) { const unsigned long long u = now_ns(); g_conc_timing.ns[i] += u - t; t = u; } }
 };
+static unsigned long long g_scan_lap_max[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+static unsigned long long g_scan_lap_max_at[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 struct ScanLap {
   unsigned long long t;
   ScanLap() : t(g_scan_timing.on ? now_ns() : 0) {}
-  void lap(int i) { if (g_scan_timing.on) { const unsigned long long u = now_ns(); g_scan_timing.ns[i] += u - t; t = u; } }
+  void lap(int i)
+  {
+    if (!g_scan_timing.on) return;
+    const unsigned long long u = now_ns();
+    g_scan_timing.ns[i] += u - t;
+    if (u - t > g_scan_lap_max[i]) { g_scan_lap_max[i] = u - t; g_scan_lap_max_at[i] = (unsigned long long)g_scan_timing.n; }
+    t = u;
+  }
 };
 static unsigned long long g_scan_last_return = 0;
 
@@ -383,11 +393,20 @@ tsd_ctx* tsd_create(int device, int map_size_log2, double cell_size, double max_
 void tsd_destroy(tsd_ctx* ctx)
 {
   if (!ctx) return;
+  if (g_stage_timing.on && g_stage_timing.n) {
+    const double n = (double)g_stage_timing.n;
+    static const char* names[8] = {"acquire", "host copy", "hipMemcpyAsync", "records", "tables launch", "-", "-", "-"};
+    fprintf(stderr, "TSD_CONC_TIMING stagings %.0f; host us each:", n);
+    for (int i = 0; i < 5; i++) fprintf(stderr, " %s %.1f", names[i], 1e-3 * (double)g_stage_timing.ns[i] / n);
+    fprintf(stderr, "\n");
+  }
   if (g_scan_timing.on && g_scan_timing.n) {
     const double n = (double)g_scan_timing.n;
     static const char* names[8] = {"caller (between calls)", "stage+copy+tables", "ray cast", "wait copy + icp launch", "push launches", "next ray cast", "wait result", "result"};
     fprintf(stderr, "TSD_CONC_TIMING tsd_scan calls %.0f; host us per scan:", n);
     for (int i = 0; i < 8; i++) fprintf(stderr, " %s %.1f", names[i], 1e-3 * (double)g_scan_timing.ns[i] / n);
+    fprintf(stderr, "\nTSD_CONC_TIMING longest single lap (us @ call):");
+    for (int i = 0; i < 8; i++) fprintf(stderr, " %s %.0f @%llu", names[i], 1e-3 * (double)g_scan_lap_max[i], g_scan_lap_max_at[i]);
     fprintf(stderr, "\n");
   }
   if (g_conc_timing.on && g_conc_timing.n) {
@@ -1170,17 +1189,23 @@ static int scan_stage_impl(tsd_sensor* s, const double* ranges, const uint8_t* m
   // copy and the range-query tables of this scan's push (which only depend on the scan) run while the previous
   // push and this scan's ray cast are still busy on the main stream.
   int slot;
+  unsigned long long tl = g_stage_timing.on ? now_ns() : 0;
+  auto LAP = [&](int i) { if (g_stage_timing.on) { const unsigned long long u = now_ns(); g_stage_timing.ns[i] += u - tl; tl = u; } };
   char* h = stage_acquire(ctx, &slot);
+  LAP(0);
   std::memcpy(h, ranges, nb * 8);
   std::memcpy(h + nb * 8, mask, nb);
   std::memcpy(h + nb * 9, mask_push ? mask_push : mask, nb);
+  LAP(1);
   // three buffers in turn (see tsd_sensor::stage_slot): the push that read this one three scans ago is done
   const int sslot = s->stage_slot;
   char* d_scan = s->d_scan2[sslot];
   s->stage_slot = (s->stage_slot + 1) % 3;
   TSD_HIP_CHECK(ctx, hipMemcpyAsync(d_scan, h, nb * 10, hipMemcpyHostToDevice, ctx->stream2));
+  LAP(2);
   TSD_HIP_CHECK(ctx, hipEventRecord(ctx->stage_ev[slot], ctx->stream2));
   TSD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_h2d, ctx->stream2));
+  LAP(3);
   s->st_ranges = reinterpret_cast<const double*>(d_scan);
   s->st_mask = reinterpret_cast<const uint8_t*>(d_scan + nb * 8);
   s->st_mask_push = reinterpret_cast<const uint8_t*>(d_scan + nb * 9);
@@ -1191,6 +1216,12 @@ static int scan_stage_impl(tsd_sensor* s, const double* ranges, const uint8_t* m
   int rc = launch_push_tables(ctx, ctx->stream2, s->beams, s->st_ranges, s->st_mask_push, s->phi_min, s->ang_res);
   if (rc != TSD_OK) return rc;
   TSD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_tables, ctx->stream2));
+  // make sure the side stream's commands are on their way now: with more streams in the process than hardware queues (a
+  // communicator's, a framework's) the runtime was seen to hold them back until the next synchronisation, and the
+  // registration that waits for this copy with them (a 40 ms stall once in ~200 scans)
+  (void)hipStreamQuery(ctx->stream2);
+  LAP(4);
+  if (g_stage_timing.on) g_stage_timing.n++;
   s->staged = true;
   return TSD_OK;
 }
@@ -1215,7 +1246,11 @@ int tsd_scan_submit(tsd_sensor* s, const double* ranges, const uint8_t* mask, co
   if (!ranges && !s->staged) return set_error(ctx, TSD_E_ARG, "tsd_scan_submit without a scan (none given, none staged)", hipSuccess);
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   ScanLap lap;
-  if (g_scan_timing.on && g_scan_last_return && lap.t - g_scan_last_return < 1000000ull) g_scan_timing.ns[0] += lap.t - g_scan_last_return;   // (one-off pauses of the caller excluded)
+  if (g_scan_timing.on && g_scan_last_return) {
+    const unsigned long long gap = lap.t - g_scan_last_return;
+    if (gap < 1000000ull) g_scan_timing.ns[0] += gap;   // (one-off pauses of the caller excluded from the average)
+    if (gap > g_scan_lap_max[0] && g_scan_timing.n > 8) { g_scan_lap_max[0] = gap; g_scan_lap_max_at[0] = (unsigned long long)g_scan_timing.n; }
+  }
   const bool staged_ahead = ranges == nullptr;
   if (ranges) {
     s->staged = false;                       // (a scan staged ahead that is not the one that came is dropped)
@@ -1300,7 +1335,12 @@ int tsd_scan_collect(tsd_sensor* s, tsd_scan_result* result)
     volatile unsigned long long* vseq = &s->h_result->seq;
     unsigned long long spins = 0;
     while (__atomic_load_n(vseq, __ATOMIC_ACQUIRE) != seq) {
-      if (++spins > 2000000ull) {          // ~ a second: something is wrong, fall back to a real wait
+      ++spins;
+      // A registration takes 0.15-0.3 ms.  Past that, nudge the runtime: with other streams in the process (a communicator's,
+      // a framework's) it was seen to sit on an enqueued launch until the next query / synchronisation of the stream -- a
+      // 40 ms stall at the same scan of every run (profiles/r2_dist_stall.txt); a stream query is a few microseconds.
+      if ((spins & 0x3FFFull) == 0) { (void)hipStreamQuery(ctx->stream); (void)hipStreamQuery(ctx->stream2); }
+      if (spins > 4000000ull) {            // ~ a tenth of a second: something is wrong, fall back to a real wait
         TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         if (__atomic_load_n(vseq, __ATOMIC_ACQUIRE) != seq)
           return set_error(ctx, TSD_E_HIP, "tsd_scan: result record never arrived", hipSuccess);
