@@ -238,10 +238,15 @@ k_push_classify(GridDev g, const PushArgs* __restrict__ a_dev, const char* __res
                 uint32_t* __restrict__ list, uint32_t* __restrict__ list_win, double* __restrict__ list_pw,
                 unsigned int* __restrict__ list_cnt /* [2] */, int parity, int tx0, int ty0, int ntx, int nty)
 {
+  // FOUR lanes per tile, one corner each: the four back-projections (an fp64 atan2 apiece, by far the longest chain of this
+  // kernel, and the kernel a pure latency chain: a few dozen waves on the whole chip) run side by side instead of one after
+  // the other.  The quad shares everything else (same values in its four lanes); its first lane owns the tile's side effects.
   const PushArgs a = *a_dev;
   const int lane = threadIdx.x;
-  const int t = blockIdx.x * 64 + lane;
-  if (t == 0) list_cnt[parity ^ 1] = 0u;                    // the next push's counter (nobody uses it now)
+  const int corner = lane & 3;
+  const bool owner = corner == 0;
+  const int t = blockIdx.x * 16 + (lane >> 2);
+  if (t == 0 && owner) list_cnt[parity ^ 1] = 0u;           // the next push's counter (nobody uses it now)
   const bool in_window = t < ntx * nty;
   const int p = in_window ? (ty0 + t / ntx) * g.PX + tx0 + t % ntx : 0;
   uint32_t rec = 0u, kind = 0u, far_flag = 0u;
@@ -260,16 +265,23 @@ k_push_classify(GridDev g, const PushArgs* __restrict__ a_dev, const char* __res
       rec = REC_RANGE_PASS;
       bool all_vis = true, any_vis = false;
       int lo = 0, hi = 0;
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
+      {
+        const int k = corner;
         const double ex = (k & 1) ? e[1][0] : e[0][0], ey = (k & 2) ? e[2][1] : e[0][1];
         int ik = backproject(a.Pi, ex, ey, a.phi_min, a.ang_res_inv, a.phi_lower, a.phi_upper);
         if (ik == -1) { ik = a.beams - 1; all_vis = false; }
         else if (ik == -2) { ik = 0; all_vis = false; }
         else any_vis = true;
-        // minmaxArray<int> (mathbase.h:55-64)
-        if (k == 0) { lo = ik; hi = ik; }
-        else { if (lo > ik) lo = ik; else if (hi < ik) hi = ik; }
+        // minmaxArray<int> (mathbase.h:55-64) over the four corners = minimum and maximum over the quad's lanes
+        lo = ik; hi = ik;
+      }
+      // (the whole quad is here or nowhere: the range cull above depends on the tile only)
+#pragma unroll
+      for (int m = 1; m <= 2; m <<= 1) {
+        const int lo2 = __shfl_xor(lo, m, 64), hi2 = __shfl_xor(hi, m, 64);
+        const int av2 = __shfl_xor((int)all_vis, m, 64), an2 = __shfl_xor((int)any_vis, m, 64);
+        lo = lo2 < lo ? lo2 : lo; hi = hi2 > hi ? hi2 : hi;
+        all_vis = all_vis && av2 != 0; any_vis = any_vis || an2 != 0;
       }
       int action = 0;
       if (any_vis) {
@@ -311,16 +323,19 @@ k_push_classify(GridDev g, const PushArgs* __restrict__ a_dev, const char* __res
         // TsdGridPartition::increaseEmptiness (TsdGridPartition.cpp:136-164), isInRange then returns false
         if (g.flags[p]) kind = KIND_EMPTY;
         else {
-          double v = g.init_weight[p] + 1.0; v = fmin(v, MAX_WEIGHT); g.init_weight[p] = v;
+          if (owner) {
+            double v = g.init_weight[p] + 1.0; v = fmin(v, MAX_WEIGHT); g.init_weight[p] = v;
+            tile_totals[(size_t)p * TOT_FIELDS + 6] += 1u;
+          }
           rec |= REC_EMPTIED_UNINIT;
-          tile_totals[(size_t)p * TOT_FIELDS + 6] += 1u;
         }
       }
-      tile_totals[(size_t)p * TOT_FIELDS + 1] += 1u;         // (this lane owns the tile: no atomics)
+      if (owner) tile_totals[(size_t)p * TOT_FIELDS + 1] += 1u;         // (this lane owns the tile: no atomics)
     }
     if (kind == 0u && dirty[p] != 0) { kind = KIND_HALO; rec |= REC_LISTED; }       // written by freeFootprint since the last push
   }
-  if (in_window && (kind == 0u || kind == KIND_HALO)) tile_rec[p] = rec;   // UPDATE / EMPTY: the workgroup writes the final record
+  if (in_window && owner && (kind == 0u || kind == KIND_HALO)) tile_rec[p] = rec;   // UPDATE / EMPTY: the workgroup writes the final record
+  if (!owner) kind = 0u;
   const unsigned long long listed = __ballot(kind != 0u);
   if (listed) {
     unsigned int base = 0;
@@ -1077,7 +1092,7 @@ int launch_push(tsd_ctx* ctx, const PushArgs& a, double cx, double cy, double sl
   const int n_window = ntx * nty;
   {
     ScopedKernelTimer t(ctx, "push_classify");
-    hipExtLaunchKernelGGL(k_push_classify, dim3((n_window + 63) / 64), dim3(64), 0, ctx->stream, t.a, t.b, 0, g, a_dev, rmq,
+    hipExtLaunchKernelGGL(k_push_classify, dim3((n_window + 15) / 16), dim3(64), 0, ctx->stream, t.a, t.b, 0, g, a_dev, rmq,
                        ctx->d_tile_rec, ctx->d_dirty, ctx->d_tile_totals, ctx->d_list, ctx->d_list_win, ctx->d_list_pw, ctx->d_list_cnt, parity,
                        box.x0, box.y0, ntx, nty);
   }
