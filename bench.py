@@ -220,6 +220,8 @@ def main():
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
+        # (one node by contract: RCCL's bootstrap over the loopback interface too, the container's hostname may not resolve)
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         if args.pg_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", local_rank))
         else:
