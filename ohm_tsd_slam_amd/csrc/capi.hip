@@ -1670,9 +1670,14 @@ int tsd_batch_begin(tsd_batch* b, int n, tsd_sensor* const* sensors, const doubl
     // profiles/r2_multi_robot_timeline.txt) on the chain ray casts -> pushes -> ray casts that bounds a round.  The entries
     // it reads come with the batch's copy; the registration waits for it by event.
     std::lock_guard<std::mutex> lk(ctx->order_mutex);
-    TSD_HIP_CHECK(ctx, hipEventRecord(b->ev_copy_done, b->stream));
-    TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, b->ev_copy_done, 0));
-    rc = launch_raycast_batch(ctx, ctx->stream, reinterpret_cast<const RaycastBatchEntry*>(d_base + off_rc), n, max_beams);
+    if (n <= RC_BATCH_BYVAL) {
+      // (the entries as kernel arguments: nothing of the batch's copy is needed, one wait less on the grid's stream)
+      rc = launch_raycast_batch_byval(ctx, ctx->stream, h_rc, n, max_beams);
+    } else {
+      TSD_HIP_CHECK(ctx, hipEventRecord(b->ev_copy_done, b->stream));
+      TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, b->ev_copy_done, 0));
+      rc = launch_raycast_batch(ctx, ctx->stream, reinterpret_cast<const RaycastBatchEntry*>(d_base + off_rc), n, max_beams);
+    }
     if (rc != TSD_OK) return rc;
     TSD_HIP_CHECK(ctx, hipEventRecord(b->ev_rc_done, ctx->stream));
     TSD_HIP_CHECK(ctx, hipStreamWaitEvent(b->stream, b->ev_rc_done, 0));

@@ -24,6 +24,7 @@
 //
 // Latency-bound gather (L2 / Infinity-Cache resident tiles): reported as time, not as a roofline.
 #include "tsd_ctx.hpp"
+#include <cstring>
 
 namespace tsd {
 
@@ -536,6 +537,27 @@ k_raycast_batch(GridDev g, const RaycastBatchEntry* __restrict__ entries, double
   RaycastArgs none;
   none.beams = 0;
   raycast_beam(g, none, e.a_dev, e.rays, e.coords, e.normals, e.mask, dbg);
+}
+
+// the same with the entries as kernel arguments: the launch does not depend on the batch's copy of its argument tables
+__global__ void __launch_bounds__(64)
+k_raycast_batch_args(GridDev g, RaycastBatchArgs args, double* dbg)
+{
+  const RaycastBatchEntry e = args.e[blockIdx.y];
+  RaycastArgs none;
+  none.beams = 0;
+  raycast_beam(g, none, e.a_dev, e.rays, e.coords, e.normals, e.mask, dbg);
+}
+
+int launch_raycast_batch_byval(tsd_ctx* ctx, hipStream_t stream, const RaycastBatchEntry* h_entries, int n, int max_beams)
+{
+  RaycastBatchArgs args;
+  std::memset(&args, 0, sizeof(args));
+  for (int i = 0; i < n && i < RC_BATCH_BYVAL; i++) args.e[i] = h_entries[i];
+  ScopedKernelTimer t(ctx, "raycast");
+  hipExtLaunchKernelGGL(k_raycast_batch_args, dim3(max_beams, n), dim3(64), 0, stream, t.a, t.b, 0, ctx->grid, args, ctx->d_icp_trace);
+  TSD_HIP_CHECK(ctx, hipGetLastError());
+  return TSD_OK;
 }
 
 int launch_raycast_batch(tsd_ctx* ctx, hipStream_t stream, const RaycastBatchEntry* d_entries, int n, int max_beams)

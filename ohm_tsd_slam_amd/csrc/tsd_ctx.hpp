@@ -114,6 +114,8 @@ struct RaycastBatchEntry {
   const RaycastArgs* a_dev; const double* rays;
   double* coords; double* normals; uint8_t* mask;
 };
+constexpr int RC_BATCH_BYVAL = 16;     // ray-cast entries that travel as kernel arguments (640 B): no copy to wait for
+struct RaycastBatchArgs { RaycastBatchEntry e[RC_BATCH_BYVAL]; };
 struct TablesBatchEntry {
   const double* ranges; const uint8_t* mask; char* rmq;
   double phi_min, ang_res;
@@ -326,6 +328,7 @@ int launch_icp(tsd_ctx* ctx, const IcpArgs& a, const double* P_dev = nullptr, co
 int launch_scan_prepare(tsd_ctx* ctx, SensorDev* st);
 // batched launches on `stream`; the entry arrays live in device memory, `host` is the host copy they were staged from
 int launch_raycast_batch(tsd_ctx* ctx, hipStream_t stream, const RaycastBatchEntry* d_entries, int n, int max_beams);
+int launch_raycast_batch_byval(tsd_ctx* ctx, hipStream_t stream, const RaycastBatchEntry* h_entries, int n, int max_beams);   // n <= RC_BATCH_BYVAL
 int launch_push_tables_batch(tsd_ctx* ctx, hipStream_t stream, const TablesBatchEntry* d_entries, int n, int max_beams);
 int launch_icp_batch(tsd_ctx* ctx, hipStream_t stream, const IcpBatchEntry* host, const IcpBatchEntry* d_entries, int n);
 
