@@ -1,5 +1,5 @@
 import sys, time
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import os
 if len(sys.argv) > 1 and sys.argv[1] == 'torch':
