@@ -1697,10 +1697,14 @@ int tsd_batch_push(tsd_batch* b)
   tsd_ctx* ctx = b->ctx;
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   std::lock_guard<std::mutex> lk_order(ctx->order_mutex);
-  TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, b->ev_icp_done, 0));
+  const bool gate = !getenv("TSD_BATCH_EVENT_WAIT");      // (A/B switch: the stream event for the whole batch's kernel instead)
+  if (!gate) TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, b->ev_icp_done, 0));
   if (int rcw = wait_for_readers(ctx)) return rcw;
   for (int i = 0; i < b->n; i++) {
     tsd_sensor* s = b->sensors[(size_t)i];
+    // robot i's push starts when robot i's registration is done (its epilogue has left the push arguments and published the
+    // scan's sequence number), not when the slowest registration of the batch is
+    if (gate) { if (int rcg = launch_wait_seq(ctx, &s->d_state->done_seq, b->seqs[(size_t)i])) return rcg; }
     const size_t nb = (size_t)s->beams;
     PushArgs pa;
     std::memset(&pa, 0, sizeof(pa));

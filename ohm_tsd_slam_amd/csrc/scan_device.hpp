@@ -177,6 +177,8 @@ __device__ inline void scan_post_body(const ScanPostArgs& sp, const double T[9],
     // `out` is coherent host memory: publish the record, then the sequence number the host polls
     __threadfence_system();
     __hip_atomic_store(&out->seq, sp.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // the same for a gate kernel on another stream (a batched robot's push starts when ITS registration is done)
+    __hip_atomic_store(&st->done_seq, sp.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 

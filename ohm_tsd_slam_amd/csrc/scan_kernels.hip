@@ -19,4 +19,24 @@ int launch_scan_prepare(tsd_ctx* ctx, SensorDev* st)
   return TSD_OK;
 }
 
+// Gate ahead of a batched robot's push: ONE wave polls the sensor's sequence number (written by its registration's epilogue,
+// which runs on the batch's own stream) and ends when it has arrived; the push kernels behind it on the stream then start with
+// fresh caches.  Replaces a cross-queue event wait for the whole batch's kernel by a wait for this robot's own workgroup.
+// Bounded (~2 s): a registration that never ran ends in a push of stale arguments gated off by `enabled` at worst, not a hang.
+__global__ void __launch_bounds__(64) k_wait_seq(const unsigned long long* seq, unsigned long long value)
+{
+  if (threadIdx.x == 0) {
+    unsigned int polls = 0u;
+    while (__hip_atomic_load(seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != value && ++polls < (1u << 21))
+      __builtin_amdgcn_s_sleep(32);
+  }
+}
+
+int launch_wait_seq(tsd_ctx* ctx, const unsigned long long* seq, unsigned long long value)
+{
+  hipLaunchKernelGGL(k_wait_seq, dim3(1), dim3(64), 0, ctx->stream, seq, value);
+  TSD_HIP_CHECK(ctx, hipGetLastError());
+  return TSD_OK;
+}
+
 }  // namespace tsd

@@ -72,6 +72,8 @@ struct SensorDev {
   RaycastArgs rc;            // arguments of the NEXT ray cast / registration, derived from `pose`
   double icpP[6];
   PushArgs push;             // arguments of this scan's push (enabled = gate result)
+  unsigned long long done_seq;   // sequence number of the latest scan whose epilogue has written all of the above (device scope):
+                                 // what the gate kernel ahead of a batched robot's push waits for (launch_wait_seq)
 };
 
 // fused scan path: what k_icp's epilogue needs (st == nullptr: plain registration)
@@ -326,6 +328,8 @@ int launch_raycast(tsd_ctx* ctx, const RaycastArgs& a, const RaycastArgs* a_dev 
 int launch_icp(tsd_ctx* ctx, const IcpArgs& a, const double* P_dev = nullptr, const double* d_rays_local = nullptr,
                const double* d_ranges = nullptr, const uint8_t* d_mask = nullptr, const ScanPostArgs* post = nullptr);
 int launch_scan_prepare(tsd_ctx* ctx, SensorDev* st);
+// one wave on the context's stream that waits (on the device, bounded) until *seq == value
+int launch_wait_seq(tsd_ctx* ctx, const unsigned long long* seq, unsigned long long value);
 // batched launches on `stream`; the entry arrays live in device memory, `host` is the host copy they were staged from
 int launch_raycast_batch(tsd_ctx* ctx, hipStream_t stream, const RaycastBatchEntry* d_entries, int n, int max_beams);
 int launch_raycast_batch_byval(tsd_ctx* ctx, hipStream_t stream, const RaycastBatchEntry* h_entries, int n, int max_beams);   // n <= RC_BATCH_BYVAL
