@@ -464,7 +464,9 @@ def run_slam(args, gc, geo, scene, K, W, every, device, rank, local_rank, world_
                    "occupancy_merges_in_timed_region": merges[0] if merger is not None else None,
                    "note": "single-stream latency chain per robot: a scan's ray cast needs the previous scan's push"
                            if R == 1 else "robots' scans batched by the facade's dispatcher (tsd_batch_*), two batch slots in turn",
-                   "scans_per_batch": (bstats[1] / max(bstats[0], 1)) if R > 1 else None},
+                   "scans_per_batch": (bstats[1] / max(bstats[0], 1)) if R > 1 else None,
+                   "stage_note": ("the batched registration kernel is launched ahead of its ray casts and waits for them on the device: "
+                                  "its dispatch time (stages_ms.icp, ms_icp_iterate) includes that wait") if R > 1 else None},
         "ms_icp_iterate": stages["icp"], "ms_icp_per_iteration": (stages["icp"] / 30.0) if stages["icp"] else None,
         "ms_icp_iterate_spread": {"min": icp_min, "max": icp_max, "std": icp_std, "of": "the sampled dispatches"},
         "ms_raycast": stages["raycast"],

@@ -1570,6 +1570,8 @@ tsd_batch* tsd_batch_create(tsd_ctx* ctx, int max_scans)
   for (hipEvent_t* e : {&b->ev_rc_done, &b->ev_icp_done, &b->ev_copy_done}) A(hipEventCreateWithFlags(e, hipEventDisableTiming));
   A(hipHostMalloc(&b->h_stage, bytes, hipHostMallocDefault));
   A(hipMalloc(&b->d_stage2[0], bytes)); A(hipMalloc(&b->d_stage2[1], bytes));
+  A(hipMalloc(&b->d_rc_flag, sizeof(unsigned int)));
+  if (ok) A(hipMemset(b->d_rc_flag, 0, sizeof(unsigned int)));
   if (!ok) { set_error(ctx, TSD_E_HIP, "tsd_batch_create", hipGetLastError()); tsd_batch_destroy(b); return nullptr; }
   std::lock_guard<std::mutex> lk(ctx->order_mutex);
   ctx->batches.push_back(b);
@@ -1591,7 +1593,7 @@ void tsd_batch_destroy(tsd_batch* b)
   for (hipEvent_t e : {b->ev_rc_done, b->ev_icp_done, b->ev_copy_done}) if (e) hipEventDestroy(e);
   if (b->stream) hipStreamDestroy(b->stream);
   if (b->h_stage) hipHostFree(b->h_stage);
-  hipFree(b->d_stage2[0]); hipFree(b->d_stage2[1]);
+  hipFree(b->d_stage2[0]); hipFree(b->d_stage2[1]); hipFree(b->d_rc_flag);
   delete b;
 }
 
@@ -1658,6 +1660,12 @@ int tsd_batch_begin(tsd_batch* b, int n, tsd_sensor* const* sensors, const doubl
     e.post.gmin_x = ctx->grid.min_x; e.post.gmax_x = ctx->grid.max_x; e.post.gmin_y = ctx->grid.min_y; e.post.gmax_y = ctx->grid.max_y;
     e.post.gates = GateArgs{gates[i].reg_trs_max, gates[i].reg_sin_rot_max, gates[i].trs_min, gates[i].rot_min};
   }
+  // the registrations go out AHEAD of the ray casts and wait for the slot's flag on the device (TSD_BATCH_EVENT_WAIT: events)
+  const bool dev_wait = !getenv("TSD_BATCH_EVENT_WAIT");
+  if (dev_wait) {
+    b->rc_batches++;
+    for (int i = 0; i < n; i++) { h_icp[i].rc_flag = b->d_rc_flag; h_icp[i].rc_target = b->rc_batches; }
+  }
   TSD_HIP_CHECK(ctx, hipMemcpyAsync(d_base, h_base, off, hipMemcpyHostToDevice, b->stream));
   b->d_stage_cur = d_base;
   int rc = launch_push_tables_batch(ctx, b->stream, reinterpret_cast<const TablesBatchEntry*>(d_base + off_tb), n, max_beams);
@@ -1670,6 +1678,10 @@ int tsd_batch_begin(tsd_batch* b, int n, tsd_sensor* const* sensors, const doubl
     // profiles/r2_multi_robot_timeline.txt) on the chain ray casts -> pushes -> ray casts that bounds a round.  The entries
     // it reads come with the batch's copy; the registration waits for it by event.
     std::lock_guard<std::mutex> lk(ctx->order_mutex);
+    if (dev_wait) {
+      rc = launch_icp_batch(ctx, b->stream, h_icp, reinterpret_cast<const IcpBatchEntry*>(d_base), n);
+      if (rc != TSD_OK) return rc;
+    }
     if (n <= RC_BATCH_BYVAL) {
       // (the entries as kernel arguments: nothing of the batch's copy is needed, one wait less on the grid's stream)
       rc = launch_raycast_batch_byval(ctx, ctx->stream, h_rc, n, max_beams);
@@ -1679,11 +1691,18 @@ int tsd_batch_begin(tsd_batch* b, int n, tsd_sensor* const* sensors, const doubl
       rc = launch_raycast_batch(ctx, ctx->stream, reinterpret_cast<const RaycastBatchEntry*>(d_base + off_rc), n, max_beams);
     }
     if (rc != TSD_OK) return rc;
-    TSD_HIP_CHECK(ctx, hipEventRecord(b->ev_rc_done, ctx->stream));
-    TSD_HIP_CHECK(ctx, hipStreamWaitEvent(b->stream, b->ev_rc_done, 0));
+    if (dev_wait) {
+      rc = launch_set_flag(ctx, b->d_rc_flag, b->rc_batches);
+      if (rc != TSD_OK) return rc;
+    } else {
+      TSD_HIP_CHECK(ctx, hipEventRecord(b->ev_rc_done, ctx->stream));
+      TSD_HIP_CHECK(ctx, hipStreamWaitEvent(b->stream, b->ev_rc_done, 0));
+    }
   }
-  rc = launch_icp_batch(ctx, b->stream, h_icp, reinterpret_cast<const IcpBatchEntry*>(d_base), n);
-  if (rc != TSD_OK) return rc;
+  if (!dev_wait) {
+    rc = launch_icp_batch(ctx, b->stream, h_icp, reinterpret_cast<const IcpBatchEntry*>(d_base), n);
+    if (rc != TSD_OK) return rc;
+  }
   TSD_HIP_CHECK(ctx, hipEventRecord(b->ev_icp_done, b->stream));
   for (int i = 0; i < n; i++) { sensors[i]->inflight = true; sensors[i]->rc_pending = false; }
   b->n = n; b->push_enqueued = false;

@@ -1150,6 +1150,17 @@ __global__ void __launch_bounds__(MAXT)
 k_icp_batch(const IcpBatchEntry* __restrict__ entries, int cap)
 {
   const IcpBatchEntry& e = entries[blockIdx.x];
+  if (e.rc_flag) {
+    // launched ahead of the batch's ray casts: wait until the word behind them says this batch's are done (one thread polls;
+    // bounded, so that a ray cast that never ran ends in garbage, not a hang)
+    if (threadIdx.x == 0) {
+      unsigned int polls = 0u;
+      while ((int)(__hip_atomic_load(e.rc_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - e.rc_target) < 0 && ++polls < (1u << 21))
+        __builtin_amdgcn_s_sleep(32);
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
   icp_workgroup<R, MAXT, PTL>(e.a, e.P_dev, cap, nullptr, nullptr, nullptr, nullptr, e.coords, e.mask_m, e.rays_local, e.ranges, e.mask, e.out,
                               e.trace, e.post, nullptr, e.normals);
 }

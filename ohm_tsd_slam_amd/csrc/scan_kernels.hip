@@ -32,6 +32,21 @@ __global__ void __launch_bounds__(64) k_wait_seq(const unsigned long long* seq, 
   }
 }
 
+// The other direction: the batched registrations are launched AHEAD of their ray casts (which run on the grid's stream, between
+// the pushes) and wait on the device for this word, set by a one-wave kernel right behind the ray casts -- a kernel boundary, so
+// the ray casts' outputs are visible device-wide when it runs.  No event on the grid's stream, no cross-queue hand-off.
+__global__ void __launch_bounds__(64) k_set_flag(unsigned int* flag, unsigned int value)
+{
+  if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+int launch_set_flag(tsd_ctx* ctx, unsigned int* flag, unsigned int value)
+{
+  hipLaunchKernelGGL(k_set_flag, dim3(1), dim3(64), 0, ctx->stream, flag, value);
+  TSD_HIP_CHECK(ctx, hipGetLastError());
+  return TSD_OK;
+}
+
 int launch_wait_seq(tsd_ctx* ctx, const unsigned long long* seq, unsigned long long value)
 {
   hipLaunchKernelGGL(k_wait_seq, dim3(1), dim3(64), 0, ctx->stream, seq, value);

@@ -128,6 +128,8 @@ struct IcpBatchEntry {
   const double* P_dev; const double* coords; const uint8_t* mask_m; const double* rays_local; const double* ranges;
   const uint8_t* mask; IcpResultDev* out; double* trace; const double* normals;
   ScanPostArgs post;
+  const unsigned int* rc_flag;       // the slot's "ray casts of batch number N are done" word (nullptr: the stream waited already)
+  unsigned int rc_target, pad;
 };
 
 struct KernelTimer {
@@ -270,6 +272,8 @@ struct tsd_batch {
   size_t head_bytes = 0;             // bytes of the three entry arrays in front of the scans
   hipStream_t stream = nullptr;
   hipEvent_t ev_rc_done = nullptr, ev_icp_done = nullptr, ev_copy_done = nullptr;
+  unsigned int* d_rc_flag = nullptr;    // number of the slot's latest batch whose ray casts have finished (set by a one-wave kernel
+  unsigned int rc_batches = 0;          // behind them on the grid's stream); batches begun on this slot
   char* h_stage = nullptr;           // pinned: entries + scans of the batch being enqueued
   char* d_stage2[2] = {nullptr, nullptr};   // device copies, alternating (the pushes of the previous batch still read theirs)
   int stage_slot = 0;
@@ -330,6 +334,8 @@ int launch_icp(tsd_ctx* ctx, const IcpArgs& a, const double* P_dev = nullptr, co
 int launch_scan_prepare(tsd_ctx* ctx, SensorDev* st);
 // one wave on the context's stream that waits (on the device, bounded) until *seq == value
 int launch_wait_seq(tsd_ctx* ctx, const unsigned long long* seq, unsigned long long value);
+// one wave on the context's stream that publishes *flag = value (device scope) once everything ahead of it on the stream is done
+int launch_set_flag(tsd_ctx* ctx, unsigned int* flag, unsigned int value);
 // batched launches on `stream`; the entry arrays live in device memory, `host` is the host copy they were staged from
 int launch_raycast_batch(tsd_ctx* ctx, hipStream_t stream, const RaycastBatchEntry* d_entries, int n, int max_beams);
 int launch_raycast_batch_byval(tsd_ctx* ctx, hipStream_t stream, const RaycastBatchEntry* h_entries, int n, int max_beams);   // n <= RC_BATCH_BYVAL
