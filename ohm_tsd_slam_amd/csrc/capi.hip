@@ -1552,6 +1552,15 @@ int tsd_scan_finish(tsd_sensor* s, tsd_scan_result* result)
 // threads can produce.  tsd_batch_push may be called before the registrations have finished (the pushes are gated on the
 // device like tsd_scan's); a ray cast enqueued later waits for it, one enqueued earlier does not.
 static inline size_t align64(size_t v) { return (v + 63u) & ~(size_t)63u; }
+// The two hand-offs of a batch (ray casts -> registrations, a robot's registration -> its push) are waits ON THE DEVICE (a flag /
+// a gate kernel, see below) unless the kernels cannot run side by side: rocprofv3's counter collection serialises dispatches
+// (ROCPROF_COUNTER_COLLECTION is in the environment then), and a kernel that waits for one behind it would only leave through
+// its poll bound.  TSD_BATCH_EVENT_WAIT=1 selects the stream events by hand (A/B measurements).
+static bool batch_device_waits()
+{
+  static const bool on = !getenv("TSD_BATCH_EVENT_WAIT") && !getenv("ROCPROF_COUNTER_COLLECTION");
+  return on;
+}
 
 tsd_batch* tsd_batch_create(tsd_ctx* ctx, int max_scans)
 {
@@ -1661,7 +1670,7 @@ int tsd_batch_begin(tsd_batch* b, int n, tsd_sensor* const* sensors, const doubl
     e.post.gates = GateArgs{gates[i].reg_trs_max, gates[i].reg_sin_rot_max, gates[i].trs_min, gates[i].rot_min};
   }
   // the registrations go out AHEAD of the ray casts and wait for the slot's flag on the device (TSD_BATCH_EVENT_WAIT: events)
-  const bool dev_wait = !getenv("TSD_BATCH_EVENT_WAIT");
+  const bool dev_wait = batch_device_waits();
   if (dev_wait) {
     b->rc_batches++;
     for (int i = 0; i < n; i++) { h_icp[i].rc_flag = b->d_rc_flag; h_icp[i].rc_target = b->rc_batches; }
@@ -1716,7 +1725,7 @@ int tsd_batch_push(tsd_batch* b)
   tsd_ctx* ctx = b->ctx;
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   std::lock_guard<std::mutex> lk_order(ctx->order_mutex);
-  const bool gate = !getenv("TSD_BATCH_EVENT_WAIT");      // (A/B switch: the stream event for the whole batch's kernel instead)
+  const bool gate = batch_device_waits();                 // (else: the stream event for the whole batch's kernel)
   if (!gate) TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, b->ev_icp_done, 0));
   if (int rcw = wait_for_readers(ctx)) return rcw;
   for (int i = 0; i < b->n; i++) {
