@@ -1558,7 +1558,8 @@ static inline size_t align64(size_t v) { return (v + 63u) & ~(size_t)63u; }
 // its poll bound.  TSD_BATCH_EVENT_WAIT=1 selects the stream events by hand (A/B measurements).
 static bool batch_device_waits()
 {
-  static const bool on = !getenv("TSD_BATCH_EVENT_WAIT") && !getenv("ROCPROF_COUNTER_COLLECTION");
+  static const bool on = !getenv("TSD_BATCH_EVENT_WAIT") && !getenv("ROCPROF_COUNTER_COLLECTION") &&
+                         !getenv("AMD_SERIALIZE_KERNEL") && !getenv("HIP_LAUNCH_BLOCKING") && !getenv("CUDA_LAUNCH_BLOCKING");   // (blocking launches: the same problem)
   return on;
 }
 
