@@ -266,7 +266,11 @@ int tsd_scan_finish(tsd_sensor* s, tsd_scan_result* result);
  *                      casts enqueued later wait for these pushes, ray casts enqueued earlier do not
  *   tsd_batch_poll     1 when every result record of the batch has arrived, 0 otherwise (never blocks)
  *   tsd_batch_results  waits for the records, enqueues the pushes unless tsd_batch_push did, fills results[0..n), frees the slot
- * The sensors of a batch must be distinct, attached to the batch's grid and without a scan in flight; one estimator per batch. */
+ * The sensors of a batch must be distinct, attached to the batch's grid and without a scan in flight; one estimator per batch.
+ * Hand-offs inside a batch (ray casts -> registrations, a robot's registration -> its push) are waits on the device (a flag set by
+ * a one-wave kernel behind the ray casts; a one-wave gate kernel ahead of each push), which needs the kernels of different streams
+ * to run side by side: under rocprofv3 counter collection or blocking launches (ROCPROF_COUNTER_COLLECTION, AMD_SERIALIZE_KERNEL,
+ * HIP_LAUNCH_BLOCKING in the environment) or with TSD_BATCH_EVENT_WAIT=1 the library uses stream events instead. */
 #define TSD_BATCH_MAX_SCANS 64
 typedef struct tsd_batch tsd_batch;
 tsd_batch* tsd_batch_create(tsd_ctx* ctx, int max_scans);
