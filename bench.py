@@ -21,9 +21,12 @@ one robot's scans are strictly sequential (the next ray cast needs this push), s
                 scans replayed by one native publisher thread per robot (tsd_node_play; --python-feeders: Python
                 threads); the facade's dispatcher batches the robots' scans (tsd_batch_*); value = all robots' scans / wall time.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): one robot + one grid per GPU (BASELINE configs[3]/[4]);
-every 50 scans the ranks merge their int8 occupancy maps with an RCCL max all-reduce.  Weak scaling: `value` =
-scans of all ranks / max-over-ranks time.
+N > 1: one rank per GPU, one robot + one grid per rank (BASELINE configs[3]/[4]); every 50 scans the ranks merge their int8
+occupancy maps with an RCCL max all-reduce.  Weak scaling: `value` = scans of all ranks / max-over-ranks time.  The ranks come
+from `python -m torch.distributed.run ... bench.py --gpus N` (the driver's form), or -- when --gpus N > 1 is given WITHOUT a
+launcher -- bench.py starts that very command itself as a child process before anything touches the GPU and relays rank 0's
+line.  It never prints `n_gpus: N` from fewer than N ranks: a launcher world that is not --gpus, a machine with fewer than N
+GPUs, an RCCL communicator whose size is not N on every rank, or a child that fails all end in a non-zero exit code.
 
 Prints ONE JSON line on rank 0.  Stage times (`stages_ms`, `ms_icp_iterate`, ...) and the roofline kernel's
 duration come from HIP events on every n-th dispatch of each kernel INSIDE the timed region.
@@ -48,7 +51,8 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 MERGE_EVERY = 50             # occupancy merge period in scans (cfg 4/5)
 CALIB_DOUBLES = 8 << 20      # k_calib_rmw: 2 arrays x 8 Mi doubles -> 128 MiB read + 128 MiB written per launch
-PROFILE_TAG = "r2"           # profiles/<tag>_<workload>_pmc.json: the committed rocprofv3 PMC summary of this round
+PROFILE_TAG = "r3"           # profiles/<tag>_<workload>_pmc.json: the committed rocprofv3 PMC summary of this round
+STREAM_DOUBLES = 48 << 20    # tsd_measure_stream: 2 arrays x 48 Mi doubles = 768 MiB footprint (3x the 256 MiB Infinity Cache)
 STAGES = ("raycast", "icp", "push_classify", "push_update", "push_halo")
 
 
@@ -76,6 +80,29 @@ def pmc_traffic(kernel: str, key: str):
         fr = known / (cal["FETCH_SIZE_KB"] * 1024.0)
         fw = known / (cal["WRITE_SIZE_KB"] * 1024.0)
     return (k["FETCH_SIZE_KB"] * fr + k["WRITE_SIZE_KB"] * fw) * 1024.0, os.path.basename(path)
+
+
+def profile_fraction(kernel: str, key: str):
+    """roofline fraction recomputed from the files committed under profiles/ for this workload: the algorithmic bytes per
+    launch of the bench line that ran under rocprofv3 (<tag>_<key>_bench_under_rocprof.json) over the average duration of
+    `kernel` in rocprofv3's own --kernel-trace --stats table (<tag>_<key>_kernel_stats.csv).  None when not committed."""
+    import csv
+    bj = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_{key}_bench_under_rocprof.json")
+    ks = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_{key}_kernel_stats.csv")
+    if not (os.path.exists(bj) and os.path.exists(ks)):
+        return None
+    try:
+        lines = [l for l in open(bj).read().splitlines() if l.startswith("{")]
+        b = json.loads(lines[-1])["roofline"]["algorithmic_bytes_per_launch"]
+        for r in csv.DictReader(open(ks)):
+            if r["Name"].split("(")[0].strip().endswith("tsd::" + kernel):
+                avg_ns = float(r["AverageNs"])
+                gbs = b / avg_ns
+                return {"frac": gbs / HBM_PEAK_GBS, "achieved": gbs, "avg_launch_us": avg_ns / 1e3, "calls": int(r["Calls"]),
+                        "source": os.path.basename(ks)}
+    except Exception:      # a malformed summary is not the bench's problem
+        return None
+    return None
 
 
 def algorithmic_bytes(st: dict, pushes: int, beams: int, cell_bytes: int = 16) -> float:
@@ -200,17 +227,35 @@ def main():
                     help="also launch the PMC calibration kernel (known byte count; used by tools/profile_bench.sh)")
     ap.add_argument("--occupancy", type=int, default=0, help="also run the occupancy extraction (row N1) this many times "
                                                            "after the timed region (profiling)")
+    ap.add_argument("--registration-mode", type=int, default=0, choices=[0, 3],
+                    help="0: ICP only (the bench line, SURVEY 8(d)); 3: TSD_PDF pre-registration ahead of the ICP (config/single-laser.yaml:28), "
+                         "fixed tsdpdf_seed; stages_ms.tsdpdf = the scoring kernels")
+    ap.add_argument("--no-second-pass", action="store_true", help="skip the --no-lookahead comparison pass (value_no_lookahead)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="multi-rank plumbing only (no GPU work): the ranks rendezvous over gloo, sum their ranks, rank 0 prints "
+                         "{launch_check, world_size}.  With --gpus N and no launcher this goes through the self-launch path.")
     args = ap.parse_args()
+
+    launched = "WORLD_SIZE" in os.environ
+    if not launched and (args.gpus > 1 or args.force_dist or args.launch_check):
+        # no launcher around us: start the ranks ourselves, as a CHILD process, before anything here has touched the GPU
+        sys.exit(self_launch(args))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
-    if world_size > 1 and args.gpus != world_size:
-        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_size}; reporting n_gpus={world_size}", file=sys.stderr)
-    n_gpus = world_size if world_size > 1 else args.gpus
+    if launched and args.gpus != world_size:
+        # one line of output must never claim more (or other) GPUs than ranks that ran
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world_size} ranks; refusing to run "
+                  f"(start it as: python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)", file=sys.stderr)
+        sys.exit(2)
+    n_gpus = world_size
     dist = None
     torch = None
-    use_dist = world_size > 1 or args.force_dist
+    use_dist = launched
+    if args.launch_check:
+        sys.exit(launch_check(rank, world_size))
     if use_dist:
         # torch.distributed is the launcher's control plane only: rendezvous, the 128-byte RCCL id, barrier and max-over-ranks
         # of the contract -- on the CPU (gloo).  The data-path collective is RCCL behind the C ABI (include/tsd_comm.h).  A "nccl"
@@ -219,6 +264,9 @@ def main():
         # staging of the next scan lands behind the ray cast instead of beside the registration).  --pg-backend nccl restores it.
         import torch
         import torch.distributed as dist
+        if torch.cuda.device_count() <= local_rank:
+            print(f"bench.py: rank {rank} has no GPU (local rank {local_rank}, {torch.cuda.device_count()} visible)", file=sys.stderr)
+            sys.exit(3)
         torch.cuda.set_device(local_rank)
         # (one node by contract: RCCL's bootstrap over the loopback interface too, the container's hostname may not resolve)
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
@@ -234,19 +282,26 @@ def main():
     mode = args.mode or ("push" if scene == "comb" else "slam")
     if args.storage == "q32" and mode != "push":
         ap.error("--storage q32 is measured in --mode push (the C++ facade links the fp64 library)")
+    if mode == "push" and world_size > 1:
+        ap.error("--mode push is a one-GPU workload")
     K, W = args.steps, args.warmup
     # (several robots: many more dispatches per step, and every sampled one costs the chain of dependent launches ~10 us)
     every = args.sample_every or (32 if args.robots > 1 else (8 if K >= 80 else 4))
+    # the roofline kernel: EVERY dispatch in a short run (the driver's 20 steps would otherwise leave five samples)
+    every_upd = args.sample_every or (1 if (K < 50 and args.robots == 1) else every)
     device = local_rank if use_dist else 0
     cell_bytes = 8 if args.storage == "q32" else 16
 
     if mode == "push":
-        out = run_push(args, gc, geo, scene, K, W, every, device, capi, synth)
+        out = run_push(args, gc, geo, scene, K, W, every, every_upd, device, capi, synth)
     else:
-        out = run_slam(args, gc, geo, scene, K, W, every, device, rank, local_rank, world_size, use_dist, dist, torch,
+        out = run_slam(args, gc, geo, scene, K, W, every, every_upd, device, rank, local_rank, world_size, use_dist, dist, torch,
                        facade, multigpu, synth)
+    rc = 0
     if rank == 0:
         st, pushes, upd_ms, upd_launches = out.pop("_stats")
+        stream_best, stream_mean = out.pop("_stream")
+        ranks = out.pop("_ranks", None)
         bytes_per_launch = algorithmic_bytes(st, pushes, geo.beams, cell_bytes) / max(pushes, 1)
         upd_avg_ms = upd_ms / max(upd_launches, 1)
         achieved = bytes_per_launch / (upd_avg_ms * 1e-3) / 1e9 if upd_avg_ms > 0 else 0.0
@@ -260,20 +315,113 @@ def main():
             "dtype": "f64", "data": "synthetic",
         }
         line.update(out)
+        if ranks is not None:
+            # what the ranks themselves report: the size of the RCCL communicator each one is in, its own rate, its merge cost
+            worlds = sorted({r["rccl_world"] for r in ranks})
+            rates = [r["scans_per_s"] for r in ranks]
+            line["rccl_world"] = worlds[0] if len(worlds) == 1 else worlds
+            line["ranks_reporting"] = len(ranks)
+            line["per_rank_scans_per_s"] = {"min": min(rates), "max": max(rates)}
+            nm = sum(r["merges_timed"] for r in ranks)
+            line["ms_occupancy_merge"] = {
+                "extract": max(r["ms_merge_extract"] for r in ranks), "allreduce": max(r["ms_merge_allreduce"] for r in ranks),
+                "total": max(r["ms_merge_extract"] + r["ms_merge_allreduce"] for r in ranks), "merges_timed_per_rank": nm // max(len(ranks), 1),
+                "of": "mean per merge on the slowest rank; HIP events: extraction kernels on the grid's stream, then map-written -> "
+                      "end of ncclAllReduce(int8, max) on the communicator's stream (includes the wait for the other ranks)",
+                "bytes_per_rank_ring": multigpu.merge_bytes_per_rank(gc.cells, world_size)}
+            if len(ranks) != world_size or worlds != [world_size]:
+                print(f"bench.py: {len(ranks)} ranks reported RCCL world sizes {worlds}, expected {world_size} of {world_size}: not a valid "
+                      f"{world_size}-GPU measurement", file=sys.stderr)
+                rc = 4
         line["roofline"] = {"kernel": "k_push_update", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                            "peak_measured": stream_best, "peak_measured_mean": stream_mean,
+                            "frac_of_peak_measured": (achieved / stream_best) if stream_best else None,
+                            "peak_measured_how": f"k_calib_rmw (read-modify-write stream, 8 B per lane like the push) over a "
+                                                 f"{16 * STREAM_DOUBLES >> 20} MiB footprint, best / mean of 5 event-timed launches, this box, after the timed region",
+                            "frac_from_profile": profile_fraction("k_push_update", key),
                             "algorithmic_bytes_per_launch": bytes_per_launch, "cell_bytes": cell_bytes,
                             "avg_launch_ms": upd_avg_ms, "launches": upd_launches,
-                            "timing": f"HIP events on every {every}th dispatch, inside the timed region"}
-        if not args.no_cpu_baseline and world_size == 1 and args.robots == 1:
+                            "timing": f"HIP events on every {'' if every_upd == 1 else str(every_upd) + 'th '}dispatch of k_push_update, inside the timed region"}
+        if not args.no_cpu_baseline and world_size == 1 and args.robots == 1 and not args.registration_mode:
             line["cpu_baseline"] = cpu_baseline(args.config, scene, mode, min(args.cpu_scans, K))
-        print(json.dumps(line), flush=True)
+        if rc == 0:
+            print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    sys.exit(rc)
 
 
-def run_push(args, gc, geo, scene, K, W, every, device, capi, synth):
+def self_launch(args) -> int:
+    """`bench.py --gpus N` without a launcher: start `python -m torch.distributed.run --nproc-per-node N bench.py <same args>`
+    as a child process (this process has not touched the GPU and never will), relay rank 0's JSON line, return the child's
+    exit code.  Refuses (non-zero, no JSON line) when the machine has fewer than N GPUs."""
+    import socket
+    import subprocess
+    n = max(args.gpus, 1)
+    if not args.launch_check:
+        try:
+            import torch
+            have = torch.cuda.device_count()            # (counts devices without initialising the GPU)
+        except Exception as e:                           # noqa: BLE001
+            print(f"bench.py: cannot count GPUs ({e})", file=sys.stderr)
+            return 3
+        if have < n:
+            print(f"bench.py: --gpus {n} needs {n} GPUs, this machine shows {have}: not starting (no line is printed for a run "
+                  f"that did not happen)", file=sys.stderr)
+            return 3
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.pop("WORLD_SIZE", None)
+    try:
+        child = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    except OSError as e:
+        print(f"bench.py: could not start the ranks: {e}", file=sys.stderr)
+        return 3
+    lines = [l for l in child.stdout.splitlines() if l.startswith("{")]
+    for l in child.stdout.splitlines():
+        if not l.startswith("{"):
+            print(l, file=sys.stderr)
+    if child.returncode != 0:
+        print(f"bench.py: the {n}-rank child exited with {child.returncode}", file=sys.stderr)
+        return child.returncode
+    if len(lines) != 1:
+        print(f"bench.py: expected ONE line from rank 0 of the {n}-rank child, got {len(lines)}", file=sys.stderr)
+        return 5
+    d = json.loads(lines[0])
+    if not args.launch_check and d.get("n_gpus") != n:
+        print(f"bench.py: the child reported n_gpus={d.get('n_gpus')}, asked for {n}", file=sys.stderr)
+        return 5
+    print(lines[0], flush=True)
+    return 0
+
+
+def launch_check(rank: int, world_size: int) -> int:
+    """--launch-check: what the launcher path needs and nothing else -- every rank joins a gloo group on 127.0.0.1, the ranks
+    are summed; rank 0 prints one line.  Runs without a GPU (the CPU test of the self-launch path)."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    t = torch.tensor([float(rank)], dtype=torch.float64)
+    dist.all_reduce(t)
+    got = [None] * world_size
+    dist.all_gather_object(got, {"rank": rank, "pid": os.getpid()})
+    ok = int(t.item()) == world_size * (world_size - 1) // 2 and sorted(g["rank"] for g in got) == list(range(world_size)) \
+        and len({g["pid"] for g in got}) == world_size
+    if rank == 0:
+        print(json.dumps({"launch_check": bool(ok), "world_size": world_size, "ranks_seen": len(got), "processes": len({g["pid"] for g in got})}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if ok else 6
+
+
+def run_push(args, gc, geo, scene, K, W, every, every_upd, device, capi, synth):
     """Push-only steps: TsdGrid::push from the ground-truth pose, host scan in, nothing read back."""
     from ohm_tsd_slam_amd import facade
     world = synth.World(scene, gc)
@@ -298,7 +446,7 @@ def run_push(args, gc, geo, scene, K, W, every, device, capi, synth):
         step(k)
     grid.sync()
     grid.push_stats_total(reset=True)
-    grid.profile(True, kernels=f"push_classify,push_update,push_halo/{every}")
+    grid.profile(True, kernels=f"push_classify,push_update:{every_upd},push_halo/{every}")
     grid.profile_reset()
     t0 = time.perf_counter()
     for k in range(1 + W, 1 + W + K):
@@ -309,6 +457,7 @@ def run_push(args, gc, geo, scene, K, W, every, device, capi, synth):
     stages = stage_table(grid, K)
     st, pushes = grid.push_stats_total()
     grid.profile(False)
+    stream = grid.measure_stream(STREAM_DOUBLES, 5)
     if args.calibrate:
         grid.calibrate_rmw(CALIB_DOUBLES, 3)
     for _ in range(args.occupancy):
@@ -323,13 +472,13 @@ def run_push(args, gc, geo, scene, K, W, every, device, capi, synth):
         "pushes_in_timed_region": pushes, "cells_updated_per_push": st["cells_updated"] / max(pushes, 1),
         "cells_visited_per_push": st["cells_visited"] / max(pushes, 1),
         "tiles_updated_per_push": st["tiles_update"] / max(pushes, 1),
-        "_stats": (st, pushes, upd_ms, upd_launches),
+        "_stats": (st, pushes, upd_ms, upd_launches), "_stream": stream,
     }
     grid.close()
     return out
 
 
-def run_slam(args, gc, geo, scene, K, W, every, device, rank, local_rank, world_size, use_dist, dist, torch, facade, multigpu, synth):
+def run_slam(args, gc, geo, scene, K, W, every, every_upd, device, rank, local_rank, world_size, use_dist, dist, torch, facade, multigpu, synth):
     R = args.robots
     # robot r starts 0.7 m further along -x (launch/multi_slam.launch:40).  Ranks own one grid each (--gpus N);
     # --robots R puts R robots on this rank's ONE grid (the reference's own multi-robot mode)
@@ -359,129 +508,173 @@ def run_slam(args, gc, geo, scene, K, W, every, device, rank, local_rank, world_
                            f"robot{r}/registration_mode": 0})
     if args.estimator:
         params["icp_estimator"] = args.estimator
-    node = facade.SlamNode(params, device=device, synchronous=True)
-    grid = node.grid()
-    merger = None
-    if use_dist:
-        # the merge itself is the C ABI of include/tsd_comm.h (extraction kernels + ncclAllReduce(int8, max) on the grid's
-        # stream); torch.distributed only carries the communicator's unique id to the ranks
-        ids = [multigpu.NativeOccupancyMerger.new_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        merger = multigpu.NativeOccupancyMerger(grid, world_size, rank, ids[0])
+    if args.registration_mode:
+        # registration_mode 3 = TSD_PDF pre-registration ahead of the ICP (what config/single-laser.yaml:28 ships); a fixed seed
+        # makes the reference's rand() draws reproducible
+        params["registration_mode"] = args.registration_mode
+        params["tsdpdf_seed"] = 20261003
 
-    merges = [0]
+    def one_pass(lookahead: bool, full: bool):
+        """init + W warm-up scans + K timed scans on a fresh node; `full`: with the occupancy merge (N > 1), the stage table and
+        everything else the line reports; otherwise just the rate (the --no-lookahead comparison)."""
+        node = facade.SlamNode(params, device=device, synchronous=True)
+        grid = node.grid()
+        merger = None
+        if use_dist and full:
+            # the merge itself is the C ABI of include/tsd_comm.h (extraction kernels + ncclAllReduce(int8, max) on the grid's
+            # stream); torch.distributed only carries the communicator's unique id to the ranks
+            ids = [multigpu.NativeOccupancyMerger.new_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            merger = multigpu.NativeOccupancyMerger(grid, world_size, rank, ids[0])
+            merger.profile(True)
 
-    def step(k, r=0):
-        # (a replay knows the next scan: announced, the localiser stages it on the device during this registration)
-        nxt = scans[r][k + 1] if (R == 1 and not args.no_lookahead and k + 1 < len(scans[r])) else None
-        node.laser(scans[r][k], geo.angle_min, geo.angle_increment, robot=r, ahead=nxt)
-        # the occupancy merge: every MERGE_EVERY scans of the timed region, placed in the middle of each period (a region
-        # shorter than one period still holds ONE merge, in its middle, so that the collective is always part of what is
-        # timed); a few more at the end of the warm-up (RCCL sets its channels up on the first calls)
-        if merger is not None and r == 0:
-            s_t = k - (1 + W)
-            period = min(MERGE_EVERY, max(K, 1))
-            if (s_t >= 0 and s_t % period == period // 2) or (k <= W and k > W - 3):      # (warm-up: up to three, RCCL's first calls are slow)
-                merger.merge_async()        # extraction kernels + RCCL max all-reduce over xGMI, in stream order, no wait
-                merges[0] += 1 if s_t >= 0 else 0
+        merges = [0]
 
-    def run_range(k0, k1):
-        if R == 1:
-            for k in range(k0, k1):
-                step(k)
-            return
-        # one publisher thread per robot, like `rosbag play` feeding the reference node: laserCallBack runs the event-loop
-        # body on the publisher's thread (synchronous facade), so the robots' scans overlap on the device like the reference's
-        # N ThreadLocalize workers do.  Native threads (tsd_node_play) unless --python-feeders.
-        if not args.python_feeders:
-            node.play(scans32, k0, k1 - k0, geo.angle_min, geo.angle_increment)
-            return
-        ts = [threading.Thread(target=lambda rr=r: [step(k, rr) for k in range(k0, k1)]) for r in range(R)]
-        for t in ts:
-            t.start()
-        for t in ts:
-            t.join()
+        def step(k, r=0):
+            # (a replay knows the next scan: announced, the localiser stages it on the device during this registration)
+            nxt = scans[r][k + 1] if (R == 1 and lookahead and k + 1 < len(scans[r])) else None
+            node.laser(scans[r][k], geo.angle_min, geo.angle_increment, robot=r, ahead=nxt)
+            # the occupancy merge: every MERGE_EVERY scans of the timed region, placed in the middle of each period (a region
+            # shorter than one period still holds ONE merge, in its middle, so that the collective is always part of what is
+            # timed); a few more at the end of the warm-up (RCCL sets its channels up on the first calls)
+            if merger is not None and r == 0:
+                s_t = k - (1 + W)
+                period = min(MERGE_EVERY, max(K, 1))
+                if (s_t >= 0 and s_t % period == period // 2) or (k <= W and k > W - 3):      # (warm-up: up to three, RCCL's first calls are slow)
+                    merger.merge_async()        # extraction kernels + RCCL max all-reduce over xGMI, in stream order, no wait
+                    merges[0] += 1 if s_t >= 0 else 0
 
-    for r in range(R):
-        node.laser(scans[r][0], geo.angle_min, geo.angle_increment, robot=r)          # init: freeFootprint + initPush
-    run_range(1, 1 + W)
-    grid.sync()
-    grid.push_stats_total(reset=True)
-    grid.profile(True, kernels=f"all/{every}")      # HIP events on every n-th dispatch of each kernel
-    grid.profile_reset()
-    if dist is not None:
-        torch.cuda.synchronize()
-        dist.barrier()
-    b0 = node.batch_stats()
-    # (the interpreter's cyclic collector off for the timed loop: with torch imported -- the multi-GPU launcher -- one
-    # generation-2 pass is a 40 ms pause in the middle of the region, the same step in every run)
-    pygc.collect()
-    pygc.disable()
-    t0 = time.perf_counter()
-    run_range(1 + W, 1 + W + K)
-    grid.sync()
-    if dist is not None:
-        merger.wait()
-        torch.cuda.synchronize()
-    # this rank's K steps are done (device idle, merge complete).  The closing barrier follows; the job's time is the MAX over the
-    # ranks of these local times (all ranks left the opening barrier together), which the all-reduce below takes -- so the
-    # barrier's own latency (0.2-0.4 ms over gloo, a tenth of a 20-step region) is not part of anybody's K steps.
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        dist.barrier()
-    pygc.enable()
-    upd_ms, upd_launches = grid.profile_get("push_update")
-    stages = stage_table(grid, K)
-    icp_min, icp_max, icp_std = grid.profile_spread("icp")
-    b1 = node.batch_stats()
-    bstats = (b1[0] - b0[0], b1[1] - b0[1])
-    st, pushes = grid.push_stats_total()
-    grid.profile(False)
-    errs = []
-    for r in range(R):
-        final = node.report(robot=r)
-        errs.append(math.hypot(final["pose"][0, 2] - poses[r][-1, 0], final["pose"][1, 2] - poses[r][-1, 1]))
+        def run_range(k0, k1):
+            if R == 1:
+                for k in range(k0, k1):
+                    step(k)
+                return
+            # one publisher thread per robot, like `rosbag play` feeding the reference node: laserCallBack runs the event-loop
+            # body on the publisher's thread (synchronous facade), so the robots' scans overlap on the device like the reference's
+            # N ThreadLocalize workers do.  Native threads (tsd_node_play) unless --python-feeders.
+            if not args.python_feeders:
+                node.play(scans32, k0, k1 - k0, geo.angle_min, geo.angle_increment)
+                return
+            ts = [threading.Thread(target=lambda rr=r: [step(k, rr) for k in range(k0, k1)]) for r in range(R)]
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join()
 
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}" if args.pg_backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    if args.calibrate:
-        grid.calibrate_rmw(CALIB_DOUBLES, 3)
-    for _ in range(args.occupancy):
-        grid.occupancy(False, 2)
+        for r in range(R):
+            node.laser(scans[r][0], geo.angle_min, geo.angle_increment, robot=r)          # init: freeFootprint + initPush
+        run_range(1, 1 + W)
+        grid.sync()
+        if merger is not None:
+            merger.wait()
+            warm_merge = merger.merge_times()    # (the warm-up merges -- RCCL's channel set-up -- are not what a merge costs)
+        grid.push_stats_total(reset=True)
+        grid.profile(True, kernels=f"push_update:{every_upd},all/{every}")      # HIP events on every n-th dispatch of each kernel
+        grid.profile_reset()
+        if dist is not None and full:
+            torch.cuda.synchronize()
+            dist.barrier()
+        b0 = node.batch_stats()
+        # (the interpreter's cyclic collector off for the timed loop: with torch imported -- the multi-GPU launcher -- one
+        # generation-2 pass is a 40 ms pause in the middle of the region, the same step in every run)
+        pygc.collect()
+        pygc.disable()
+        t0 = time.perf_counter()
+        run_range(1 + W, 1 + W + K)
+        grid.sync()
+        if merger is not None:
+            merger.wait()
+            torch.cuda.synchronize()
+        # this rank's K steps are done (device idle, merge complete).  The closing barrier follows; the job's time is the MAX over the
+        # ranks of these local times (all ranks left the opening barrier together), which the all-reduce below takes -- so the
+        # barrier's own latency (0.2-0.4 ms over gloo, a tenth of a 20-step region) is not part of anybody's K steps.
+        elapsed = time.perf_counter() - t0
+        if dist is not None and full:
+            dist.barrier()
+        pygc.enable()
+        if not full:
+            grid.profile(False)
+            node.close()
+            return {"value": R * K / elapsed}
+        upd_ms, upd_launches = grid.profile_get("push_update")
+        stages = stage_table(grid, K)
+        icp_min, icp_max, icp_std = grid.profile_spread("icp")
+        _, icp_n = grid.profile_get("icp")
+        b1 = node.batch_stats()
+        bstats = (b1[0] - b0[0], b1[1] - b0[1])
+        st, pushes = grid.push_stats_total()
+        grid.profile(False)
+        errs = []
+        for r in range(R):
+            final = node.report(robot=r)
+            errs.append(math.hypot(final["pose"][0, 2] - poses[r][-1, 0], final["pose"][1, 2] - poses[r][-1, 1]))
 
-    pushes_per_step = pushes / max(K * R, 1)
-    stage_sum = sum(v * (pushes_per_step if k.startswith("push") else 1.0) for k, v in stages.items() if v is not None)
-    out = {
-        "value": world_size * R * K / elapsed, "ms_per_step": 1e3 * elapsed / K,
-        "config": {"workload": f"{args.config}: {gc.cells}x{gc.cells} cells @ {gc.cell_size} m, {geo.beams} beams, "
-                               f"scene '{scene}', icp_iterations 30, "
-                               + (f"{R} robots on one grid per GPU" if R > 1 else "one robot + one grid per GPU")
-                               + (", point-to-line estimator" if args.estimator else ""),
-                   "robots": world_size * R, "robots_per_grid": R, "mode": "slam", "storage": "f64",
-                   "occupancy_merge_every": MERGE_EVERY if world_size > 1 else None,
-                   "occupancy_merges_in_timed_region": merges[0] if merger is not None else None,
-                   "note": "single-stream latency chain per robot: a scan's ray cast needs the previous scan's push"
-                           if R == 1 else "robots' scans batched by the facade's dispatcher (tsd_batch_*), two batch slots in turn",
-                   "scans_per_batch": (bstats[1] / max(bstats[0], 1)) if R > 1 else None,
-                   "stage_note": ("the batched registration kernel is launched ahead of its ray casts and waits for them on the device: "
-                                  "its dispatch time (stages_ms.icp, ms_icp_iterate) includes that wait") if R > 1 else None},
-        "ms_icp_iterate": stages["icp"], "ms_icp_per_iteration": (stages["icp"] / 30.0) if stages["icp"] else None,
-        "ms_icp_iterate_spread": {"min": icp_min, "max": icp_max, "std": icp_std, "of": "the sampled dispatches"},
-        "ms_raycast": stages["raycast"],
-        "ms_push_kernels": sum(v for k, v in stages.items() if k.startswith("push") and v is not None),
-        "stages_ms": stages, "stages_sum_ms_per_scan": stage_sum,
-        "stage_timing": f"HIP events on every {every}th dispatch of each kernel, inside the timed region",
-        "pushes_in_timed_region": pushes, "cells_updated_per_push": st["cells_updated"] / max(pushes, 1),
-        "cells_visited_per_push": st["cells_visited"] / max(pushes, 1),
-        "tiles_updated_per_push": st["tiles_update"] / max(pushes, 1),
-        "tracking_error_m": max(errs),
-        "_stats": (st, pushes, upd_ms, upd_launches),
-    }
-    if merger is not None:
-        merger.close()        # (the communicator refers to the grid context: it goes first)
-    node.close()
+        ranks = None
+        local_elapsed = elapsed
+        if dist is not None:
+            ex, ar, nm = merger.merge_times()
+            ex -= warm_merge[0]; ar -= warm_merge[1]; nm -= warm_merge[2]
+            mine = {"rank": rank, "rccl_world": merger.world_size(), "scans_per_s": R * K / local_elapsed, "merges_timed": nm,
+                    "ms_merge_extract": ex / max(nm, 1), "ms_merge_allreduce": ar / max(nm, 1)}
+            ranks = [None] * world_size
+            dist.all_gather_object(ranks, mine)
+            t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}" if args.pg_backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        stream = grid.measure_stream(STREAM_DOUBLES, 5) if rank == 0 else (None, None)
+        if args.calibrate:
+            grid.calibrate_rmw(CALIB_DOUBLES, 3)
+        for _ in range(args.occupancy):
+            grid.occupancy(False, 2)
+        occ_ms, occ_n = grid.profile_get("occupancy") if args.occupancy else (0.0, 0)
+        pdf_ms, pdf_n = grid.profile_get("tsdpdf")
+
+        pushes_per_step = pushes / max(K * R, 1)
+        stage_sum = sum(v * (pushes_per_step if k.startswith("push") else 1.0) for k, v in stages.items() if v is not None)
+        if pdf_n:
+            stages = dict(stages, tsdpdf=pdf_ms / pdf_n)
+            stage_sum += pdf_ms / pdf_n
+        out = {
+            "value": world_size * R * K / elapsed, "ms_per_step": 1e3 * elapsed / K,
+            "config": {"workload": f"{args.config}: {gc.cells}x{gc.cells} cells @ {gc.cell_size} m, {geo.beams} beams, "
+                                   f"scene '{scene}', icp_iterations 30, registration_mode {args.registration_mode}, "
+                                   + (f"{R} robots on one grid per GPU" if R > 1 else "one robot + one grid per GPU")
+                                   + (", point-to-line estimator" if args.estimator else ""),
+                       "robots": world_size * R, "robots_per_grid": R, "mode": "slam", "storage": "f64",
+                       "lookahead": bool(lookahead and R == 1),
+                       "occupancy_merge_every": MERGE_EVERY if use_dist else None,
+                       "occupancy_merges_in_timed_region": merges[0] if merger is not None else None,
+                       "note": "single-stream latency chain per robot: a scan's ray cast needs the previous scan's push"
+                               if R == 1 else "robots' scans batched by the facade's dispatcher (tsd_batch_*), two batch slots in turn",
+                       "scans_per_batch": (bstats[1] / max(bstats[0], 1)) if R > 1 else None,
+                       "stage_note": ("the batched registration kernel is launched ahead of its ray casts and waits for them on the device: "
+                                      "its dispatch time (stages_ms.icp, ms_icp_iterate) includes that wait") if R > 1 else None},
+            "ms_icp_iterate": stages["icp"], "ms_icp_per_iteration": (stages["icp"] / 30.0) if stages["icp"] else None,
+            "ms_icp_iterate_spread": {"min": icp_min, "max": icp_max, "std": icp_std, "samples": icp_n,
+                                      "max_over_mean": (icp_max / stages["icp"]) if stages["icp"] else None, "of": "the sampled dispatches"},
+            "ms_raycast": stages["raycast"],
+            "ms_push_kernels": sum(v for k, v in stages.items() if k.startswith("push") and v is not None),
+            "stages_ms": stages, "stages_sum_ms_per_scan": stage_sum,
+            "stage_timing": f"HIP events on every {every}th dispatch of each kernel (k_push_update: every "
+                            f"{'one' if every_upd == 1 else str(every_upd) + 'th'}), inside the timed region",
+            "pushes_in_timed_region": pushes, "cells_updated_per_push": st["cells_updated"] / max(pushes, 1),
+            "cells_visited_per_push": st["cells_visited"] / max(pushes, 1),
+            "tiles_updated_per_push": st["tiles_update"] / max(pushes, 1),
+            "tracking_error_m": max(errs),
+            "_stats": (st, pushes, upd_ms, upd_launches), "_stream": stream, "_ranks": ranks,
+        }
+        if args.occupancy and occ_n:
+            out["ms_occupancy_extract"] = occ_ms / occ_n
+        if merger is not None:
+            merger.close()        # (the communicator refers to the grid context: it goes first)
+        node.close()
+        return out
+
+    out = one_pass(not args.no_lookahead, True)
+    if R == 1 and not use_dist and not args.no_lookahead and not args.no_second_pass:
+        # the same K scans on a fresh node WITHOUT announcing the next scan: what a live 40 Hz scanner gets (it never has the
+        # next LaserScan queued; the reference's localiser takes the newest scan, ThreadLocalize.cpp:319-332)
+        out["value_no_lookahead"] = one_pass(False, False)["value"]
     return out
 
 

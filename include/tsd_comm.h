@@ -46,6 +46,11 @@ int tsd_comm_occupancy_allreduce(tsd_comm* comm, int inflate, int inflate_factor
 int tsd_comm_allreduce_map(tsd_comm* comm);
 /* Wait for the merge; merged_host (cells * cells bytes, row = y like nav_msgs/OccupancyGrid.data) may be NULL. */
 int tsd_comm_occupancy_wait(tsd_comm* comm, int8_t* merged_host);
+/* What a merge costs, measured with HIP events when switched on: the extraction kernels (context stream) and the collective
+ * (from "map written" to the end of ncclAllReduce on the communicator's stream, i.e. including the wait for the slowest rank).
+ * tsd_comm_merge_times waits for the merges issued so far and returns the running totals since tsd_comm_create. */
+int tsd_comm_profile(tsd_comm* comm, int on);
+int tsd_comm_merge_times(tsd_comm* comm, double* extract_ms_total, double* allreduce_ms_total, int* merges);
 /* device address of the (merged) map */
 void* tsd_comm_map_dev(tsd_comm* comm);
 

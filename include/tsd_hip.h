@@ -342,7 +342,8 @@ int tsd_color_image(tsd_ctx* ctx, uint8_t* rgb_host, unsigned int width, unsigne
  * "push_halo", "raycast", "icp", "occupancy", "tsdpdf". */
 int tsd_profile_enable(tsd_ctx* ctx, int on);
 /* restrict timing to a comma separated list of kernel names, or "all"; a "/n" suffix times every n-th
- * launch only (two event records cost ~13 us of stream time per timed launch) */
+ * launch only (two event records cost ~13 us of stream time per timed launch); a name may carry its own
+ * period, "push_update:1,all/8" = every dispatch of k_push_update, every 8th of the others */
 int tsd_profile_select(tsd_ctx* ctx, const char* kernels_csv);
 int tsd_profile_reset(tsd_ctx* ctx);
 int tsd_profile_get(tsd_ctx* ctx, const char* kernel, double* total_ms, int* launches);
@@ -353,6 +354,11 @@ int tsd_profile_get_spread(tsd_ctx* ctx, const char* kernel, double* min_ms, dou
  * of n_doubles fp64 values with the push kernel's 8-byte-per-lane access shape (known traffic: 16 B read
  * + 16 B written per element and launch).  Allocates and frees its own scratch. */
 int tsd_calibrate_rmw(tsd_ctx* ctx, int64_t n_doubles, int reps);
+
+/* The box's own stream bandwidth with the push kernel's access shape: `reps` event-timed launches of k_calib_rmw over two
+ * arrays of n_doubles (each read and written once per launch: 32 B per element).  Choose n_doubles so that the footprint
+ * (16 B per element) exceeds the 256 MiB Infinity Cache, or the figure is a cache bandwidth.  GB/s, best and mean launch. */
+int tsd_measure_stream(tsd_ctx* ctx, int64_t n_doubles, int reps, double* gbs_best, double* gbs_mean);
 
 /* Sum of the work counters of every push completed on this ctx since the last reset (the numerator of
  * the algorithmic-bytes formula without a host sync per push).  Waits for pushes still in flight. */

@@ -182,6 +182,7 @@ ABI = {
     "tsd_occupancy_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "tsd_occupancy_dev_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "tsd_calibrate_rmw": (C.c_int, [C.c_void_p, C.c_int64, C.c_int]),
+    "tsd_measure_stream": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, _dp, _dp]),
     "tsd_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "tsd_profile_select": (C.c_int, [C.c_void_p, C.c_char_p]),
     "tsd_profile_reset": (C.c_int, [C.c_void_p]),
@@ -402,6 +403,12 @@ class TsdGridDevice:
     def occupancy_into(self, dev_ptr: int, inflate=False, inflate_factor=2):
         self._check(self.lib.tsd_occupancy_dev(self.h, C.c_void_p(dev_ptr), int(inflate), inflate_factor),
                     "tsd_occupancy_dev")
+
+    def measure_stream(self, n_doubles: int, reps: int = 5):
+        """(best, mean) GB/s of the RMW stream kernel over two arrays of ``n_doubles`` (tsd_measure_stream)"""
+        best, mean = C.c_double(), C.c_double()
+        self._check(self.lib.tsd_measure_stream(self.h, n_doubles, reps, C.byref(best), C.byref(mean)), "tsd_measure_stream")
+        return best.value, mean.value
 
     def calibrate_rmw(self, n_doubles: int, reps: int = 3):
         self._check(self.lib.tsd_calibrate_rmw(self.h, n_doubles, reps), "tsd_calibrate_rmw")

@@ -51,7 +51,10 @@ ScopedKernelTimer::ScopedKernelTimer(tsd_ctx* c, const char* n, bool around_) : 
 {
   if (!kernel_is_timed(ctx, n)) return;
   std::lock_guard<std::mutex> lk(ctx->misc_mutex);
-  if (ctx->profile_every > 1 && (ctx->timers[n].tick++ % ctx->profile_every) != 0) return;   // every n-th launch of THIS kernel
+  unsigned every = ctx->profile_every;
+  for (unsigned i = 0; i < sizeof(kKernelNames) / sizeof(kKernelNames[0]); i++)
+    if (ctx->profile_every_k[i] && std::strcmp(kKernelNames[i], n) == 0) every = ctx->profile_every_k[i];
+  if (every > 1 && (ctx->timers[n].tick++ % every) != 0) return;   // every n-th launch of THIS kernel
   a = pool_get(ctx); b = pool_get(ctx);
   if (!a || !b) { a = b = nullptr; return; }
   if (around) hipEventRecord(a, ctx->stream);
@@ -1022,6 +1025,40 @@ int tsd_calibrate_rmw(tsd_ctx* ctx, int64_t n_doubles, int reps)
   return rc;
 }
 
+int tsd_measure_stream(tsd_ctx* ctx, int64_t n_doubles, int reps, double* gbs_best, double* gbs_mean)
+{
+  if (!ctx || n_doubles <= 0 || reps <= 0 || reps > 64) return TSD_E_ARG;
+  TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  double *t = nullptr, *w = nullptr;
+  const size_t bytes = (size_t)n_doubles * sizeof(double);
+  TSD_HIP_CHECK(ctx, hipMalloc(&t, bytes));
+  hipError_t e = hipMalloc(&w, bytes);
+  if (e != hipSuccess) { hipFree(t); return set_error(ctx, TSD_E_HIP, "tsd_measure_stream", e); }
+  hipMemsetAsync(t, 0, bytes, ctx->stream);
+  hipMemsetAsync(w, 0, bytes, ctx->stream);
+  int rc = launch_calibrate(ctx, t, w, (size_t)n_doubles);      // untimed: first touch
+  std::vector<hipEvent_t> ev((size_t)reps + 1, nullptr);
+  for (auto& x : ev) if (hipEventCreate(&x) != hipSuccess) rc = set_error(ctx, TSD_E_HIP, "tsd_measure_stream: events", hipGetLastError());
+  if (rc == TSD_OK) hipEventRecord(ev[0], ctx->stream);
+  for (int r = 0; r < reps && rc == TSD_OK; r++) { rc = launch_calibrate(ctx, t, w, (size_t)n_doubles); hipEventRecord(ev[(size_t)r + 1], ctx->stream); }
+  hipStreamSynchronize(ctx->stream);
+  double best = 0.0, sum = 0.0; int n = 0;
+  for (int r = 0; r < reps && rc == TSD_OK; r++) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ev[(size_t)r], ev[(size_t)r + 1]) != hipSuccess || !(ms > 0.f)) continue;
+    const double gbs = 4.0 * (double)bytes / ((double)ms * 1e-3) / 1e9;     // two arrays, each read and written once
+    if (gbs > best) best = gbs;
+    sum += gbs; n++;
+  }
+  for (auto x : ev) if (x) hipEventDestroy(x);
+  hipFree(t); hipFree(w);
+  if (rc != TSD_OK) return rc;
+  if (!n) return set_error(ctx, TSD_E_HIP, "tsd_measure_stream: no timed launch", hipSuccess);
+  if (gbs_best) *gbs_best = best;
+  if (gbs_mean) *gbs_mean = sum / n;
+  return TSD_OK;
+}
+
 int tsd_profile_enable(tsd_ctx* ctx, int on)
 {
   if (!ctx) return TSD_E_ARG;
@@ -1033,17 +1070,32 @@ int tsd_profile_enable(tsd_ctx* ctx, int on)
 int tsd_profile_select(tsd_ctx* ctx, const char* kernels_csv)
 {
   if (!ctx || !kernels_csv) return TSD_E_ARG;
+  // "a,b,c/n": the listed kernels (or "all"), every n-th launch of each; a name may carry its own period, "a:m", which
+  // wins over the list's (bench.py times EVERY dispatch of the roofline kernel in a short run and every n-th of the others)
   unsigned mask = 0;
   std::string csv(kernels_csv);
   ctx->profile_every = 1;
-  const size_t slash = csv.find('/');          // "names/n": time every n-th launch only
+  const size_t slash = csv.rfind('/');
   if (slash != std::string::npos) {
     const int n = std::atoi(csv.c_str() + slash + 1);
     ctx->profile_every = n > 1 ? (unsigned)n : 1u;
     csv = csv.substr(0, slash);
   }
-  for (unsigned i = 0; i < sizeof(kKernelNames) / sizeof(kKernelNames[0]); i++)
-    if (csv == "all" || ("," + csv + ",").find(std::string(",") + kKernelNames[i] + ",") != std::string::npos) mask |= 1u << i;
+  constexpr unsigned NK = sizeof(kKernelNames) / sizeof(kKernelNames[0]);
+  for (unsigned i = 0; i < NK; i++) ctx->profile_every_k[i] = 0;
+  size_t pos = 0;
+  while (pos <= csv.size()) {
+    size_t end = csv.find(',', pos);
+    if (end == std::string::npos) end = csv.size();
+    std::string tok = csv.substr(pos, end - pos);
+    pos = end + 1;
+    if (tok.empty()) continue;
+    unsigned own = 0;
+    const size_t colon = tok.find(':');
+    if (colon != std::string::npos) { const int m = std::atoi(tok.c_str() + colon + 1); own = m >= 1 ? (unsigned)m : 1u; tok = tok.substr(0, colon); }
+    for (unsigned i = 0; i < NK; i++)
+      if (tok == "all" || tok == kKernelNames[i]) { mask |= 1u << i; if (own && tok != "all") ctx->profile_every_k[i] = own; }
+  }
   ctx->profile_mask = mask;
   return TSD_OK;
 }

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "../../include/tsd_comm.h"
 
@@ -24,8 +25,23 @@ struct tsd_comm {
   hipEvent_t ev_extracted = nullptr;   // map written by the extraction kernels (context stream)
   hipEvent_t ev_reduced = nullptr;     // all-reduce finished with the map (collective stream)
   bool reduced_pending = false;
+  // tsd_comm_profile: HIP events around the extraction (context stream) and the collective (communicator stream) of every merge
+  bool profile = false;
+  struct Timed { hipEvent_t t0, t1, t2; };   // before the extraction, after it, after the all-reduce
+  std::vector<Timed> pending;
+  std::vector<hipEvent_t> pool;
+  double extract_ms = 0.0, allreduce_ms = 0.0;
+  int merges_timed = 0;
   std::string err;
 };
+
+static hipEvent_t comm_event(tsd_comm* c)
+{
+  if (!c->pool.empty()) { hipEvent_t e = c->pool.back(); c->pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
 
 static int fail(tsd_comm* c, const char* what, const char* detail)
 {
@@ -82,6 +98,8 @@ void tsd_comm_destroy(tsd_comm* c)
   if (c->ctx) tsd_sync(c->ctx);
   if (c->cstream) hipStreamSynchronize(c->cstream);
   if (c->comm) ncclCommDestroy(c->comm);
+  for (auto& t : c->pending) { hipEventDestroy(t.t0); hipEventDestroy(t.t1); hipEventDestroy(t.t2); }
+  for (hipEvent_t e : c->pool) hipEventDestroy(e);
   if (c->ev_extracted) hipEventDestroy(c->ev_extracted);
   if (c->ev_reduced) hipEventDestroy(c->ev_reduced);
   if (c->cstream) hipStreamDestroy(c->cstream);
@@ -94,11 +112,15 @@ int tsd_comm_rank(const tsd_comm* c) { return c ? c->rank : -1; }
 const char* tsd_comm_last_error(const tsd_comm* c) { return c ? c->err.c_str() : "null comm"; }
 void* tsd_comm_map_dev(tsd_comm* c) { return c ? c->d_map : nullptr; }
 
-int tsd_comm_allreduce_map(tsd_comm* c)
+static int allreduce_map_impl(tsd_comm* c, hipEvent_t t0)
 {
-  if (!c) return TSD_E_ARG;
-  if (hipSetDevice(c->device) != hipSuccess) return fail(c, "hipSetDevice", "");
   hipStream_t stream = static_cast<hipStream_t>(tsd_stream(c->ctx));
+  hipEvent_t t1 = nullptr, t2 = nullptr;
+  if (c->profile) {
+    if (!t0) { t0 = comm_event(c); if (t0) hipEventRecord(t0, stream); }
+    t1 = comm_event(c); t2 = comm_event(c);
+    if (t1) hipEventRecord(t1, stream);                 // the map is written: the extraction's share ends here
+  }
   // the map is complete once everything enqueued on the context's stream so far has run
   if (hipEventRecord(c->ev_extracted, stream) != hipSuccess || hipStreamWaitEvent(c->cstream, c->ev_extracted, 0) != hipSuccess)
     return fail(c, "event hand-over to the collective stream", "");
@@ -107,7 +129,41 @@ int tsd_comm_allreduce_map(tsd_comm* c)
   const ncclResult_t r = ncclAllReduce(c->d_map, c->d_map, c->cells2, ncclInt8, ncclMax, c->comm, c->cstream);
   if (r != ncclSuccess) return fail(c, "ncclAllReduce", ncclGetErrorString(r));
   if (hipEventRecord(c->ev_reduced, c->cstream) != hipSuccess) return fail(c, "hipEventRecord", "");
+  if (t0 && t1 && t2) { hipEventRecord(t2, c->cstream); c->pending.push_back({t0, t1, t2}); }
   c->reduced_pending = true;
+  return TSD_OK;
+}
+
+int tsd_comm_allreduce_map(tsd_comm* c)
+{
+  if (!c) return TSD_E_ARG;
+  if (hipSetDevice(c->device) != hipSuccess) return fail(c, "hipSetDevice", "");
+  return allreduce_map_impl(c, nullptr);
+}
+
+int tsd_comm_profile(tsd_comm* c, int on)
+{
+  if (!c) return TSD_E_ARG;
+  c->profile = on != 0;
+  return TSD_OK;
+}
+
+int tsd_comm_merge_times(tsd_comm* c, double* extract_ms_total, double* allreduce_ms_total, int* merges)
+{
+  if (!c) return TSD_E_ARG;
+  if (hipSetDevice(c->device) != hipSuccess) return fail(c, "hipSetDevice", "");
+  for (auto& t : c->pending) {
+    float a = 0.f, b = 0.f;
+    if (hipEventSynchronize(t.t2) == hipSuccess && hipEventElapsedTime(&a, t.t0, t.t1) == hipSuccess &&
+        hipEventElapsedTime(&b, t.t1, t.t2) == hipSuccess) {
+      c->extract_ms += (double)a; c->allreduce_ms += (double)b; c->merges_timed++;
+    }
+    c->pool.push_back(t.t0); c->pool.push_back(t.t1); c->pool.push_back(t.t2);
+  }
+  c->pending.clear();
+  if (extract_ms_total) *extract_ms_total = c->extract_ms;
+  if (allreduce_ms_total) *allreduce_ms_total = c->allreduce_ms;
+  if (merges) *merges = c->merges_timed;
   return TSD_OK;
 }
 
@@ -119,9 +175,11 @@ int tsd_comm_occupancy_allreduce(tsd_comm* c, int inflate, int inflate_factor)
     if (hipStreamWaitEvent(static_cast<hipStream_t>(tsd_stream(c->ctx)), c->ev_reduced, 0) != hipSuccess) return fail(c, "hipStreamWaitEvent", "");
     c->reduced_pending = false;
   }
+  hipEvent_t t0 = nullptr;
+  if (c->profile) { t0 = comm_event(c); if (t0) hipEventRecord(t0, static_cast<hipStream_t>(tsd_stream(c->ctx))); }
   const int rc = tsd_occupancy_dev_async(c->ctx, c->d_map, inflate, inflate_factor);     // extraction kernels, stream order
-  if (rc != TSD_OK) { c->err = tsd_last_error(c->ctx); return rc; }
-  return tsd_comm_allreduce_map(c);
+  if (rc != TSD_OK) { c->err = tsd_last_error(c->ctx); if (t0) c->pool.push_back(t0); return rc; }
+  return allreduce_map_impl(c, t0);
 }
 
 int tsd_comm_occupancy_wait(tsd_comm* c, int8_t* merged_host)

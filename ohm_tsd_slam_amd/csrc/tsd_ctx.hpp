@@ -216,6 +216,7 @@ struct tsd_ctx {
   // profiling: bit i of profile_mask times kernel i (names in capi.hip: kKernelNames)
   unsigned profile_mask = 0;
   unsigned profile_every = 1;   // time every n-th launch of a selected kernel ("name/n" in tsd_profile_select)
+  unsigned profile_every_k[16] = {};   // a kernel's own period ("name:m"), 0 = the list's
   bool profile = false;
   std::map<std::string, tsd::KernelTimer> timers;
   std::vector<hipEvent_t> event_pool;

@@ -15,8 +15,9 @@ The collective itself lives behind the C ABI (``include/tsd_comm.h``, ``lib/libt
 ``ncclAllReduce(int8, max)`` enqueued on the grid context's own stream, so a C++ host can merge without Python or
 torch.  :class:`NativeOccupancyMerger` is the thin ctypes caller ``bench.py`` uses; ``torch.distributed`` is only the
 launcher's process group (rank / world size, the 128-byte unique id travels through it, barrier and max-over-ranks of
-the bench contract).  :class:`OccupancyMerger` is the same merge over ``torch.distributed`` tensors, kept for the gloo
-CPU tests of the semantics (world_size 2 without a GPU).
+the bench contract).  :class:`OccupancyMerger` is a TEST-ONLY twin: the same element-wise maximum over ``torch.distributed`` tensors, so that the
+merge semantics can be checked with two ranks on CPU (gloo, ``tests/test_cpu_multigpu.py``) where RCCL cannot run.  Nothing
+in ``bench.py`` or the facade uses it.
 """
 from __future__ import annotations
 
@@ -43,6 +44,8 @@ COMM_ABI = {
     "tsd_comm_allreduce_map": (C.c_int, [C.c_void_p]),
     "tsd_comm_occupancy_wait": (C.c_int, [C.c_void_p, C.POINTER(C.c_int8)]),
     "tsd_comm_map_dev": (C.c_void_p, [C.c_void_p]),
+    "tsd_comm_profile": (C.c_int, [C.c_void_p, C.c_int]),
+    "tsd_comm_merge_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
 }
 _comm_lib = None
 
@@ -104,6 +107,19 @@ class NativeOccupancyMerger:
 
     def wait(self):
         self._check(self.lib.tsd_comm_occupancy_wait(self.h, None), "tsd_comm_occupancy_wait")
+
+    def world_size(self) -> int:
+        """what the RCCL communicator itself says (``tsd_comm_world_size``), not what the launcher's environment claims"""
+        return int(self.lib.tsd_comm_world_size(self.h))
+
+    def profile(self, on: bool = True):
+        self._check(self.lib.tsd_comm_profile(self.h, int(on)), "tsd_comm_profile")
+
+    def merge_times(self):
+        """(extraction ms, all-reduce ms, merges timed): totals over the merges issued while ``profile`` was on"""
+        a, b, n = C.c_double(), C.c_double(), C.c_int()
+        self._check(self.lib.tsd_comm_merge_times(self.h, C.byref(a), C.byref(b), C.byref(n)), "tsd_comm_merge_times")
+        return a.value, b.value, n.value
 
     def merged(self) -> np.ndarray:
         out = np.empty(self.cells * self.cells, dtype=np.int8)

@@ -1,7 +1,14 @@
-"""The N > 1 path on CPU: two ranks (gloo, 127.0.0.1), one robot + one grid per rank, occupancy maps
-merged with the same ``OccupancyMerger`` that ``bench.py --gpus N`` uses over RCCL.  The per-rank maps
-come from the oracle here (no GPU in this suite); the merge semantics (element-wise max: occupied >
-free > unknown) are checked against numpy."""
+"""The N > 1 path on CPU: two ranks (gloo, 127.0.0.1), one robot + one grid per rank.
+
+* The merge SEMANTICS (element-wise max: occupied > free > unknown) with two ranks, through ``multigpu.OccupancyMerger`` --
+  a test-only twin over ``torch.distributed`` tensors.  It is NOT what ``bench.py --gpus N`` runs: that is the native RCCL
+  merge behind the C ABI (``include/tsd_comm.h`` -> ``multigpu.NativeOccupancyMerger``), which needs GPUs (RCCL refuses two
+  ranks on one device; the one-rank run is tests/test_gpu_multigpu_plumbing.py).  The per-rank maps come from the oracle here.
+* The LAUNCH path of ``bench.py``: ``--gpus 2`` without a launcher starts two ranks itself (``--launch-check``: rendezvous only,
+  no GPU), refuses to print a line when the machine does not have the GPUs, and refuses a launcher world that is not ``--gpus``."""
+import json
+import subprocess
+import sys
 import os
 import socket
 
@@ -94,3 +101,42 @@ def test_single_rank_is_a_no_op():
     assert multigpu.merge_bytes_per_rank(4096, 1) == 0.0
     assert multigpu.merge_bytes_per_rank(4096, 8) == 2 * 7 / 8 * 4096 * 4096
     assert multigpu.robot_offset_x(0) == 0.37 and abs(multigpu.robot_offset_x(1) + 0.33) < 1e-12
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*argv, env=None):
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], cwd=ROOT, env=e, capture_output=True, text=True, timeout=300)
+
+
+def test_bench_gpus2_without_launcher_spawns_two_ranks():
+    """`bench.py --gpus 2` with no launcher around it: two rank PROCESSES come up (torch.distributed.run as a child) and meet
+    over gloo on 127.0.0.1; rank 0's one line is relayed."""
+    out = _bench("--gpus", "2", "--launch-check")
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d == {"launch_check": True, "world_size": 2, "ranks_seen": 2, "processes": 2}
+
+
+def test_bench_never_claims_gpus_it_does_not_have():
+    """No GPUs for the ranks => non-zero exit and NO result line (round 2 printed n_gpus: 8 from one process)."""
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this machine has the GPUs")
+    out = _bench("--gpus", "2", "--steps", "5", "--warmup", "1", "--no-cpu-baseline")
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")], out.stdout[-500:]
+    assert "GPUs" in out.stderr
+
+
+def test_bench_refuses_a_launcher_world_that_is_not_gpus():
+    out = _bench("--gpus", "8", "--steps", "5", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert "WORLD_SIZE=2" in out.stderr
