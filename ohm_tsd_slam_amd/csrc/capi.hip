@@ -1305,7 +1305,12 @@ int tsd_scan_submit(tsd_sensor* s, const double* ranges, const uint8_t* mask, co
   }
   const bool staged_ahead = ranges == nullptr;
   if (ranges) {
-    s->staged = false;                       // (a scan staged ahead that is not the one that came is dropped)
+    // A scan staged ahead that is not the one that came is dropped -- and its buffers are REUSED for the scan that did come: the
+    // three-buffer rotation is only safe when it advances once per scan (the buffer two rotations back may still be read by the
+    // push of the previous scan, which is ordered behind nothing the host has seen).  The new copy and tables follow the dropped
+    // ones on the side stream, and nothing else ever read the dropped data.
+    if (s->staged) s->stage_slot = s->st_slot;
+    s->staged = false;
     int rcs = scan_stage_impl(s, ranges, mask, mask_push);
     if (rcs != TSD_OK) return rcs;
   }
@@ -1605,14 +1610,54 @@ int tsd_scan_finish(tsd_sensor* s, tsd_scan_result* result)
 // device like tsd_scan's); a ray cast enqueued later waits for it, one enqueued earlier does not.
 static inline size_t align64(size_t v) { return (v + 63u) & ~(size_t)63u; }
 // The two hand-offs of a batch (ray casts -> registrations, a robot's registration -> its push) are waits ON THE DEVICE (a flag /
-// a gate kernel, see below) unless the kernels cannot run side by side: rocprofv3's counter collection serialises dispatches
-// (ROCPROF_COUNTER_COLLECTION is in the environment then), and a kernel that waits for one behind it would only leave through
-// its poll bound.  TSD_BATCH_EVENT_WAIT=1 selects the stream events by hand (A/B measurements).
-static bool batch_device_waits()
+// a gate kernel, see below) when -- and only when -- a start-up probe on the very streams involved has shown that a kernel on one can
+// wait for a kernel launched after it on the other (probe_cross_stream_wait, both directions).  That is not a given: HIP maps streams
+// onto a few in-order hardware queues (GPU_MAX_HW_QUEUES), so two streams may share one; rocprofv3's counter collection, blocking
+// launches or a debugger serialise dispatches altogether.  Otherwise: stream events.  Whatever the mode, a device-side wait is
+// bounded and a wait that runs out is an ERROR the caller sees (k_icp_batch / k_wait_seq), never a registration on stale data.
+//   TSD_BATCH_EVENT_WAIT=1          stream events, no probe (A/B measurements)
+//   TSD_BATCH_FORCE_DEVICE_WAIT=1   device waits whatever the probe says (tests of the failure path)
+//   TSD_BATCH_POLL_BOUND=<polls>    bound of the device-side waits, ~1 us per poll (default 2^21)
+static int batch_choose_wait_mode(tsd_batch* b)
 {
-  static const bool on = !getenv("TSD_BATCH_EVENT_WAIT") && !getenv("ROCPROF_COUNTER_COLLECTION") &&
-                         !getenv("AMD_SERIALIZE_KERNEL") && !getenv("HIP_LAUNCH_BLOCKING") && !getenv("CUDA_LAUNCH_BLOCKING");   // (blocking launches: the same problem)
-  return on;
+  tsd_ctx* ctx = b->ctx;
+  b->dev_wait = false;
+  if (const char* e = getenv("TSD_BATCH_POLL_BOUND")) { const long v = std::atol(e); if (v >= 16 && v <= (1l << 30)) b->poll_bound = (unsigned int)v; }
+  if (getenv("TSD_BATCH_EVENT_WAIT")) return TSD_OK;
+  bool ab = false, ba = false;
+  int rc = probe_cross_stream_wait(ctx, b->stream, ctx->stream, b->d_rc_flag, &ab);     // a registration waiting for the ray casts' flag
+  if (rc == TSD_OK) rc = probe_cross_stream_wait(ctx, ctx->stream, b->stream, b->d_rc_flag, &ba);   // a push gate waiting for the registration
+  if (rc != TSD_OK) return rc;
+  TSD_HIP_CHECK(ctx, hipMemset(b->d_rc_flag, 0, 2 * sizeof(unsigned int)));
+  b->dev_wait = ab && ba;
+  if (!b->dev_wait && getenv("TSD_BATCH_FORCE_DEVICE_WAIT")) b->dev_wait = true;
+  if (getenv("TSD_BATCH_VERBOSE"))
+    fprintf(stderr, "tsd_batch_create: cross-stream probe %d/%d -> %s hand-offs\n", (int)ab, (int)ba, b->dev_wait ? "device-side" : "event");
+  return TSD_OK;
+}
+
+// a push gate of this slot gave up (its registration never reported done): an error for whoever calls next, and events from now on
+static int batch_gate_error(tsd_batch* b)
+{
+  if (!b->h_gate_err || __atomic_load_n(b->h_gate_err, __ATOMIC_ACQUIRE) == 0u) return TSD_OK;
+  __atomic_store_n(b->h_gate_err, 0u, __ATOMIC_RELEASE);
+  b->dev_wait = false;
+  return set_error(b->ctx, TSD_E_HIP, "batched path: a push gate timed out waiting for its registration; that push was skipped "
+                                       "(the slot uses stream events from now on)", hipSuccess);
+}
+
+// leave a batch that cannot be completed: nothing of it stays in flight, the sensors are free again
+static void batch_abandon(tsd_batch* b, bool registration_launched)
+{
+  tsd_ctx* ctx = b->ctx;
+  if (registration_launched && b->dev_wait) {
+    // the registration kernel is (or will be) polling: tell it that this batch is off, on a stream it does not wait behind
+    (void)launch_set_flag(ctx, ctx->stream, b->d_rc_flag + 1, b->rc_batches);
+  }
+  if (b->stream) hipStreamSynchronize(b->stream);
+  hipStreamSynchronize(ctx->stream);
+  for (tsd_sensor* s : b->sensors) if (s) s->inflight = false;
+  b->n = 0; b->push_enqueued = false;
 }
 
 tsd_batch* tsd_batch_create(tsd_ctx* ctx, int max_scans)
@@ -1632,10 +1677,13 @@ tsd_batch* tsd_batch_create(tsd_ctx* ctx, int max_scans)
   for (hipEvent_t* e : {&b->ev_rc_done, &b->ev_icp_done, &b->ev_copy_done}) A(hipEventCreateWithFlags(e, hipEventDisableTiming));
   A(hipHostMalloc(&b->h_stage, bytes, hipHostMallocDefault));
   A(hipMalloc(&b->d_stage2[0], bytes)); A(hipMalloc(&b->d_stage2[1], bytes));
-  A(hipMalloc(&b->d_rc_flag, sizeof(unsigned int)));
-  if (ok) A(hipMemset(b->d_rc_flag, 0, sizeof(unsigned int)));
+  A(hipMalloc(&b->d_rc_flag, 2 * sizeof(unsigned int)));
+  if (ok) A(hipMemset(b->d_rc_flag, 0, 2 * sizeof(unsigned int)));
+  A(hipHostMalloc(&b->h_gate_err, sizeof(unsigned int), hipHostMallocMapped | hipHostMallocCoherent));
+  if (ok) { *b->h_gate_err = 0u; A(hipHostGetDevicePointer((void**)&b->d_gate_err, b->h_gate_err, 0)); }
   if (!ok) { set_error(ctx, TSD_E_HIP, "tsd_batch_create", hipGetLastError()); tsd_batch_destroy(b); return nullptr; }
   std::lock_guard<std::mutex> lk(ctx->order_mutex);
+  if (batch_choose_wait_mode(b) != TSD_OK) { b->ctx = nullptr; tsd_batch_destroy(b); return nullptr; }   // (detached: destroy takes no lock)
   ctx->batches.push_back(b);
   return b;
 }
@@ -1656,6 +1704,7 @@ void tsd_batch_destroy(tsd_batch* b)
   if (b->stream) hipStreamDestroy(b->stream);
   if (b->h_stage) hipHostFree(b->h_stage);
   hipFree(b->d_stage2[0]); hipFree(b->d_stage2[1]); hipFree(b->d_rc_flag);
+  if (b->h_gate_err) hipHostFree(b->h_gate_err);
   delete b;
 }
 
@@ -1669,6 +1718,13 @@ int tsd_batch_begin(tsd_batch* b, int n, tsd_sensor* const* sensors, const doubl
   tsd_ctx* ctx = b->ctx;
   if (n > b->max_scans) return set_error(ctx, TSD_E_CAPACITY, "tsd_batch_begin: more scans than the batch was created for", hipSuccess);
   if (b->n) return set_error(ctx, TSD_E_ARG, "tsd_batch_begin: the previous batch of this slot was not collected (tsd_batch_results)", hipSuccess);
+  if (int rcg = batch_gate_error(b)) return rcg;
+  // everything that can be refused is refused HERE, before any state of the slot or of a sensor changes and before any launch
+  for (int i = 0; i < n; i++) {
+    if (params[i].estimator != params[0].estimator) return set_error(ctx, TSD_E_ARG, "tsd_batch_begin: one estimator per batch", hipSuccess);
+    if (params[i].estimator != TSD_ESTIMATOR_CLOSED_FORM && params[i].estimator != TSD_ESTIMATOR_POINT_TO_LINE)
+      return set_error(ctx, TSD_E_ARG, "tsd_icp_params.estimator", hipSuccess);
+  }
   for (int i = 0; i < n; i++) {
     tsd_sensor* s = sensors[i];
     if (!s || s->ctx != ctx || !ranges[i] || !mask[i]) return set_error(ctx, TSD_E_ARG, "tsd_batch_begin: sensor / scan", hipSuccess);
@@ -1722,16 +1778,20 @@ int tsd_batch_begin(tsd_batch* b, int n, tsd_sensor* const* sensors, const doubl
     e.post.gmin_x = ctx->grid.min_x; e.post.gmax_x = ctx->grid.max_x; e.post.gmin_y = ctx->grid.min_y; e.post.gmax_y = ctx->grid.max_y;
     e.post.gates = GateArgs{gates[i].reg_trs_max, gates[i].reg_sin_rot_max, gates[i].trs_min, gates[i].rot_min};
   }
-  // the registrations go out AHEAD of the ray casts and wait for the slot's flag on the device (TSD_BATCH_EVENT_WAIT: events)
-  const bool dev_wait = batch_device_waits();
+  // the registrations go out AHEAD of the ray casts and wait for the slot's flag on the device (where the probe allowed it)
+  const bool dev_wait = b->dev_wait;
   if (dev_wait) {
     b->rc_batches++;
-    for (int i = 0; i < n; i++) { h_icp[i].rc_flag = b->d_rc_flag; h_icp[i].rc_target = b->rc_batches; }
+    for (int i = 0; i < n; i++) { h_icp[i].rc_flag = b->d_rc_flag; h_icp[i].rc_target = b->rc_batches; h_icp[i].poll_bound = b->poll_bound; }
   }
-  TSD_HIP_CHECK(ctx, hipMemcpyAsync(d_base, h_base, off, hipMemcpyHostToDevice, b->stream));
+  bool icp_launched = false;
+  // (from here on a failure leaves through batch_abandon: nothing of the batch stays in flight, no kernel keeps polling)
+  auto FAIL = [&](int code) { batch_abandon(b, icp_launched); return code; };
+  if (hipMemcpyAsync(d_base, h_base, off, hipMemcpyHostToDevice, b->stream) != hipSuccess)
+    return FAIL(set_error(ctx, TSD_E_HIP, "tsd_batch_begin: copy", hipGetLastError()));
   b->d_stage_cur = d_base;
   int rc = launch_push_tables_batch(ctx, b->stream, reinterpret_cast<const TablesBatchEntry*>(d_base + off_tb), n, max_beams);
-  if (rc != TSD_OK) return rc;
+  if (rc != TSD_OK) return FAIL(rc);
   {
     // ORDERED SECTION: the ray casts read the grid, so they go behind every grid write enqueued so far and take their place in
     // the order for the writes that follow
@@ -1742,30 +1802,32 @@ int tsd_batch_begin(tsd_batch* b, int n, tsd_sensor* const* sensors, const doubl
     std::lock_guard<std::mutex> lk(ctx->order_mutex);
     if (dev_wait) {
       rc = launch_icp_batch(ctx, b->stream, h_icp, reinterpret_cast<const IcpBatchEntry*>(d_base), n);
-      if (rc != TSD_OK) return rc;
+      if (rc != TSD_OK) return FAIL(rc);
+      icp_launched = true;
     }
     if (n <= RC_BATCH_BYVAL) {
       // (the entries as kernel arguments: nothing of the batch's copy is needed, one wait less on the grid's stream)
       rc = launch_raycast_batch_byval(ctx, ctx->stream, h_rc, n, max_beams);
     } else {
-      TSD_HIP_CHECK(ctx, hipEventRecord(b->ev_copy_done, b->stream));
-      TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, b->ev_copy_done, 0));
+      if (hipEventRecord(b->ev_copy_done, b->stream) != hipSuccess || hipStreamWaitEvent(ctx->stream, b->ev_copy_done, 0) != hipSuccess)
+        return FAIL(set_error(ctx, TSD_E_HIP, "tsd_batch_begin: copy event", hipGetLastError()));
       rc = launch_raycast_batch(ctx, ctx->stream, reinterpret_cast<const RaycastBatchEntry*>(d_base + off_rc), n, max_beams);
     }
-    if (rc != TSD_OK) return rc;
+    if (rc != TSD_OK) return FAIL(rc);
     if (dev_wait) {
-      rc = launch_set_flag(ctx, b->d_rc_flag, b->rc_batches);
-      if (rc != TSD_OK) return rc;
+      rc = launch_set_flag(ctx, ctx->stream, b->d_rc_flag, b->rc_batches);
+      if (rc != TSD_OK) return FAIL(rc);
     } else {
-      TSD_HIP_CHECK(ctx, hipEventRecord(b->ev_rc_done, ctx->stream));
-      TSD_HIP_CHECK(ctx, hipStreamWaitEvent(b->stream, b->ev_rc_done, 0));
+      if (hipEventRecord(b->ev_rc_done, ctx->stream) != hipSuccess || hipStreamWaitEvent(b->stream, b->ev_rc_done, 0) != hipSuccess)
+        return FAIL(set_error(ctx, TSD_E_HIP, "tsd_batch_begin: ray-cast event", hipGetLastError()));
     }
   }
   if (!dev_wait) {
     rc = launch_icp_batch(ctx, b->stream, h_icp, reinterpret_cast<const IcpBatchEntry*>(d_base), n);
-    if (rc != TSD_OK) return rc;
+    if (rc != TSD_OK) return FAIL(rc);
+    icp_launched = true;
   }
-  TSD_HIP_CHECK(ctx, hipEventRecord(b->ev_icp_done, b->stream));
+  if (hipEventRecord(b->ev_icp_done, b->stream) != hipSuccess) return FAIL(set_error(ctx, TSD_E_HIP, "tsd_batch_begin: event", hipGetLastError()));
   for (int i = 0; i < n; i++) { sensors[i]->inflight = true; sensors[i]->rc_pending = false; }
   b->n = n; b->push_enqueued = false;
   return TSD_OK;
@@ -1778,14 +1840,14 @@ int tsd_batch_push(tsd_batch* b)
   tsd_ctx* ctx = b->ctx;
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   std::lock_guard<std::mutex> lk_order(ctx->order_mutex);
-  const bool gate = batch_device_waits();                 // (else: the stream event for the whole batch's kernel)
+  const bool gate = b->dev_wait;                          // (else: the stream event for the whole batch's kernel)
   if (!gate) TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, b->ev_icp_done, 0));
   if (int rcw = wait_for_readers(ctx)) return rcw;
   for (int i = 0; i < b->n; i++) {
     tsd_sensor* s = b->sensors[(size_t)i];
     // robot i's push starts when robot i's registration is done (its epilogue has left the push arguments and published the
     // scan's sequence number), not when the slowest registration of the batch is
-    if (gate) { if (int rcg = launch_wait_seq(ctx, &s->d_state->done_seq, b->seqs[(size_t)i])) return rcg; }
+    if (gate) { if (int rcg = launch_wait_seq(ctx, &s->d_state->done_seq, b->seqs[(size_t)i], &s->d_state->push, b->d_gate_err, b->poll_bound)) return rcg; }
     const size_t nb = (size_t)s->beams;
     PushArgs pa;
     std::memset(&pa, 0, sizeof(pa));
@@ -1822,8 +1884,10 @@ int tsd_batch_results(tsd_batch* b, tsd_scan_result* results)
   unsigned long long spins = 0;
   while (tsd_batch_poll(b) != 1) {
     if (++spins > 4000000ull) {              // something is wrong: a real wait on the batch's stream
-      if (hipStreamSynchronize(b->stream) != hipSuccess || tsd_batch_poll(b) != 1)
+      if (hipStreamSynchronize(b->stream) != hipSuccess || tsd_batch_poll(b) != 1) {
+        batch_abandon(b, true);              // (the slot and its sensors are usable again; this batch's scans are lost)
         return set_error(ctx, TSD_E_HIP, "tsd_batch_results: result records never arrived", hipSuccess);
+      }
       break;
     }
 #if defined(__x86_64__)
@@ -1831,19 +1895,29 @@ int tsd_batch_results(tsd_batch* b, tsd_scan_result* results)
 #endif
   }
   int rc = tsd_batch_push(b);               // (no-op when the caller enqueued the pushes ahead of the results)
-  if (rc != TSD_OK) return rc;
+  if (rc != TSD_OK) { batch_abandon(b, true); return rc; }
+  int failed = 0;
   for (int i = 0; i < b->n; i++) {
     tsd_sensor* s = b->sensors[(size_t)i];
     tsd_scan_result* r = &results[i];
     copy_icp_result(&s->h_result->icp, &r->icp);
     for (int k = 0; k < 9; k++) r->pose[k] = s->h_result->pose[k];
-    s->pos[0] = r->pose[2]; s->pos[1] = r->pose[5];
     r->reg_error = s->h_result->reg_error; r->pushed = s->h_result->pushed;
-    r->no_model = s->h_result->no_model; r->reserved = 0;
+    r->no_model = s->h_result->no_model; r->reserved = s->h_result->reserved;
+    if (r->reserved != 0) failed = r->reserved;       // this robot's registration never ran (k_icp_batch): flagged, pose untouched
+    else { s->pos[0] = r->pose[2]; s->pos[1] = r->pose[5]; }
     s->inflight = false;
   }
   b->n = 0;
-  return TSD_OK;
+  if (failed) {
+    // a device-side wait gave up, so kernels of the two streams do not run side by side here (any more): events from now on
+    b->dev_wait = false;
+    return set_error(ctx, TSD_E_HIP, failed == BATCH_FAIL_TIMEOUT
+                       ? "batched path: a registration's device-side wait for its ray casts timed out; its scan was NOT registered "
+                         "(tsd_scan_result.reserved = 1 marks the robots concerned; the slot uses stream events from now on)"
+                       : "batched path: the batch was abandoned before its registrations ran", hipSuccess);
+  }
+  return batch_gate_error(b);
 }
 
 }  // extern "C"

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <limits>
 
 namespace ohm_tsd_slam
@@ -272,7 +273,10 @@ void ThreadLocalize::processScan(const std::vector<float>& ranges, const builtin
   _stampLaser = stamp;
 
   // (a scan that was announced, ingested and staged on the device during the previous registration is in _sensor already)
-  const bool staged = _stagedValid && _stagedStampNs == rep.stampNs;
+  // Accepted only if it IS this scan: same stamp AND the same readings (drivers that leave the stamp at 0 or repeat it must not
+  // get the previously staged ranges registered in place of the scan they delivered); anything else is a drop.
+  const bool staged = _stagedValid && _stagedStampNs == rep.stampNs && _stagedRanges.size() == ranges.size() &&
+                      (ranges.empty() || std::memcmp(_stagedRanges.data(), ranges.data(), ranges.size() * sizeof(float)) == 0);
   if(_stagedValid && !staged) _stagedValid = false;     // something else came: tsd_scan_submit drops the staged scan
   if(!staged)
   {
@@ -457,6 +461,7 @@ void ThreadLocalize::processScanFused(ScanReport& rep)
       {
         _stagedValid = true;
         _stagedStampNs = (long long)next->header.stamp.sec * 1000000000LL + (long long)next->header.stamp.nanosec;
+        _stagedRanges = next->ranges;
       }
     }
     if(rc == TSD_OK) rc = _grid.scanCollect(_sensor, &sr);

@@ -106,7 +106,8 @@ private:
 
   std::shared_ptr<sensor_msgs::msg::LaserScan> _ahead;      // announced next scan (clamped like laserCallBack does)
   bool _stagedValid = false;                                // _sensor holds, and the device has staged, the scan with ...
-  long long _stagedStampNs = 0;                             // ... this stamp
+  long long _stagedStampNs = 0;                             // ... this stamp ...
+  std::vector<float> _stagedRanges;                         // ... and these readings (in the sensor's beam order)
   std::deque<std::shared_ptr<sensor_msgs::msg::LaserScan>> _laserData;
   std::mutex _dataMutex;
   bool _busy;

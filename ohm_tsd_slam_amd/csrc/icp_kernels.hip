@@ -1151,14 +1151,27 @@ k_icp_batch(const IcpBatchEntry* __restrict__ entries, int cap)
 {
   const IcpBatchEntry& e = entries[blockIdx.x];
   if (e.rc_flag) {
-    // launched ahead of the batch's ray casts: wait until the word behind them says this batch's are done (one thread polls;
-    // bounded, so that a ray cast that never ran ends in garbage, not a hang)
+    // launched ahead of the batch's ray casts: wait until the word behind them says this batch's are done (one thread polls).
+    // Bounded -- and a wait that runs out, or a batch the host abandoned, does NOT register on whatever the ray-cast buffers hold:
+    // the workgroup reports why (reserved = BATCH_FAIL_*), leaves pose and grid alone and publishes the sequence numbers, so the
+    // host gets an error instead of a pose (tsd_batch_results -> TSD_E_HIP).
+    __shared__ int s_fail;
     if (threadIdx.x == 0) {
       unsigned int polls = 0u;
-      while ((int)(__hip_atomic_load(e.rc_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - e.rc_target) < 0 && ++polls < (1u << 21))
+      int fail = 0;
+      for (;;) {
+        if ((int)(__hip_atomic_load(e.rc_flag + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - e.rc_target) >= 0) { fail = BATCH_FAIL_ABORTED; break; }
+        if ((int)(__hip_atomic_load(e.rc_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - e.rc_target) >= 0) break;
+        if (++polls >= e.poll_bound) { fail = BATCH_FAIL_TIMEOUT; break; }
         __builtin_amdgcn_s_sleep(32);
+      }
+      s_fail = fail;
     }
     __syncthreads();
+    if (s_fail) {
+      if (threadIdx.x == 0) scan_post_failed(e.post, s_fail);
+      return;
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   icp_workgroup<R, MAXT, PTL>(e.a, e.P_dev, cap, nullptr, nullptr, nullptr, nullptr, e.coords, e.mask_m, e.rays_local, e.ranges, e.mask, e.out,

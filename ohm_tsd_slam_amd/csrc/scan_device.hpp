@@ -145,6 +145,9 @@ __device__ inline void scan_post_body(const ScanPostArgs& sp, const double T[9],
       rays[i] = nx; rays[beams + i] = ny;
     }
   }
+  // every wave has turned its rays before thread 0 publishes the sequence numbers: a ray cast of this sensor on ANOTHER stream
+  // (the batched path) is ordered behind this scan only through them
+  __syncthreads();
   if (threadIdx.x == 0) {
     double pose[9], last[9];
     for (int i = 0; i < 9; i++) { pose[i] = st->pose[i]; last[i] = st->last_pose[i]; }
@@ -180,6 +183,26 @@ __device__ inline void scan_post_body(const ScanPostArgs& sp, const double T[9],
     // the same for a gate kernel on another stream (a batched robot's push starts when ITS registration is done)
     __hip_atomic_store(&st->done_seq, sp.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
+}
+
+// A batched registration that did not run (k_icp_batch: its ray casts never reported done, or the host abandoned the batch):
+// no pose change, the push of this scan switched off, and a result record that says why -- tsd_batch_results turns a non-zero
+// `reserved` into an error for the caller (the reference's contract: "failures are logged and the scan is skipped",
+// ThreadLocalize.cpp:354-358, :381-387).  One thread.
+__device__ inline void scan_post_failed(const ScanPostArgs& sp, int why)
+{
+  SensorDev* st = sp.st;
+  st->push.enabled = 0;
+  ScanResultDev* out = sp.out;
+  IcpResultDev r;
+  for (int i = 0; i < 9; i++) r.T[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  r.rms = 0.0; r.pairs = 0; r.iterations = 0; r.state = TSD_ICP_NOTMATCHABLE; r.n_model = 0; r.n_scene = 0; r.reserved = why;
+  out->icp = r;
+  for (int i = 0; i < 9; i++) out->pose[i] = st->pose[i];
+  out->reg_error = 1; out->pushed = 0; out->no_model = 0; out->reserved = why;
+  __threadfence_system();
+  __hip_atomic_store(&out->seq, sp.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&st->done_seq, sp.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace tsd

@@ -22,13 +22,21 @@ int launch_scan_prepare(tsd_ctx* ctx, SensorDev* st)
 // Gate ahead of a batched robot's push: ONE wave polls the sensor's sequence number (written by its registration's epilogue,
 // which runs on the batch's own stream) and ends when it has arrived; the push kernels behind it on the stream then start with
 // fresh caches.  Replaces a cross-queue event wait for the whole batch's kernel by a wait for this robot's own workgroup.
-// Bounded (~2 s): a registration that never ran ends in a push of stale arguments gated off by `enabled` at worst, not a hang.
-__global__ void __launch_bounds__(64) k_wait_seq(const unsigned long long* seq, unsigned long long value)
+// Bounded (~2 s).  A registration that never reported done must not let the push through with the PREVIOUS scan's arguments:
+// the gate then switches the push off (the three push kernels read `enabled` from this very record) and raises the slot's error
+// word in coherent host memory, which the next tsd_batch_* call on the slot turns into TSD_E_HIP.
+__global__ void __launch_bounds__(64) k_wait_seq(const unsigned long long* seq, unsigned long long value, PushArgs* push,
+                                                 unsigned int* err_host, unsigned int poll_bound)
 {
   if (threadIdx.x == 0) {
     unsigned int polls = 0u;
-    while (__hip_atomic_load(seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != value && ++polls < (1u << 21))
+    bool arrived;
+    while (!(arrived = __hip_atomic_load(seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == value) && ++polls < poll_bound)
       __builtin_amdgcn_s_sleep(32);
+    if (!arrived) {
+      push->enabled = 0;
+      __hip_atomic_store(err_host, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -40,17 +48,51 @@ __global__ void __launch_bounds__(64) k_set_flag(unsigned int* flag, unsigned in
   if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-int launch_set_flag(tsd_ctx* ctx, unsigned int* flag, unsigned int value)
+// probe: wait (bounded) for *flag == value; out = 1 seen, 2 gave up
+__global__ void __launch_bounds__(64) k_probe_wait(const unsigned int* flag, unsigned int value, unsigned int poll_bound, unsigned int* out)
 {
-  hipLaunchKernelGGL(k_set_flag, dim3(1), dim3(64), 0, ctx->stream, flag, value);
+  if (threadIdx.x == 0) {
+    unsigned int polls = 0u;
+    bool seen;
+    while (!(seen = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == value) && ++polls < poll_bound)
+      __builtin_amdgcn_s_sleep(32);
+    *out = seen ? 1u : 2u;
+  }
+}
+
+int launch_set_flag(tsd_ctx* ctx, hipStream_t stream, unsigned int* flag, unsigned int value)
+{
+  hipLaunchKernelGGL(k_set_flag, dim3(1), dim3(64), 0, stream, flag, value);
   TSD_HIP_CHECK(ctx, hipGetLastError());
   return TSD_OK;
 }
 
-int launch_wait_seq(tsd_ctx* ctx, const unsigned long long* seq, unsigned long long value)
+int launch_wait_seq(tsd_ctx* ctx, const unsigned long long* seq, unsigned long long value, PushArgs* push, unsigned int* err_host,
+                    unsigned int poll_bound)
 {
-  hipLaunchKernelGGL(k_wait_seq, dim3(1), dim3(64), 0, ctx->stream, seq, value);
+  hipLaunchKernelGGL(k_wait_seq, dim3(1), dim3(64), 0, ctx->stream, seq, value, push, err_host, poll_bound);
   TSD_HIP_CHECK(ctx, hipGetLastError());
+  return TSD_OK;
+}
+
+// d_words: [0] flag, [1] result of the waiter.  The waiter goes out FIRST, on `a`; the setter behind it in host order, on `b`.
+// Side by side the waiter sees the flag after a few microseconds; on a shared in-order queue (or with dispatches serialised by a
+// profiler / blocking launches) it can only leave through its bound (~5 ms here), and says so.
+int probe_cross_stream_wait(tsd_ctx* ctx, hipStream_t a, hipStream_t b, unsigned int* d_words, bool* ok)
+{
+  *ok = false;
+  TSD_HIP_CHECK(ctx, hipMemsetAsync(d_words, 0, 2 * sizeof(unsigned int), a));
+  TSD_HIP_CHECK(ctx, hipStreamSynchronize(a));
+  TSD_HIP_CHECK(ctx, hipStreamSynchronize(b));
+  hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(64), 0, a, d_words, 1u, 5000u, d_words + 1);
+  TSD_HIP_CHECK(ctx, hipGetLastError());
+  hipLaunchKernelGGL(k_set_flag, dim3(1), dim3(64), 0, b, d_words, 1u);
+  TSD_HIP_CHECK(ctx, hipGetLastError());
+  TSD_HIP_CHECK(ctx, hipStreamSynchronize(a));
+  TSD_HIP_CHECK(ctx, hipStreamSynchronize(b));
+  unsigned int res = 0u;
+  TSD_HIP_CHECK(ctx, hipMemcpy(&res, d_words + 1, sizeof(res), hipMemcpyDeviceToHost));
+  *ok = res == 1u;
   return TSD_OK;
 }
 

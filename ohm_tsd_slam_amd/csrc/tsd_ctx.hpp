@@ -128,9 +128,15 @@ struct IcpBatchEntry {
   const double* P_dev; const double* coords; const uint8_t* mask_m; const double* rays_local; const double* ranges;
   const uint8_t* mask; IcpResultDev* out; double* trace; const double* normals;
   ScanPostArgs post;
-  const unsigned int* rc_flag;       // the slot's "ray casts of batch number N are done" word (nullptr: the stream waited already)
-  unsigned int rc_target, pad;
+  const unsigned int* rc_flag;       // the slot's hand-off words (nullptr: the stream waited already): [0] number of the latest batch
+                                     // whose ray casts are done, [1] number of the latest batch the host gave up on (tsd_batch_begin failed)
+  unsigned int rc_target;
+  unsigned int poll_bound;           // polls (about a microsecond each) before the wait gives up and REPORTS it (BATCH_FAIL_*)
 };
+// why a batched registration did not run (ScanResultDev::reserved / tsd_scan_result.reserved; 0 = it ran)
+constexpr int BATCH_FAIL_TIMEOUT = 1;    // its ray casts never reported done within the poll bound
+constexpr int BATCH_FAIL_ABORTED = 2;    // the host abandoned the batch
+constexpr unsigned int BATCH_POLL_BOUND = 1u << 21;   // ~2 s
 
 struct KernelTimer {
   double total_ms = 0.0;
@@ -273,8 +279,13 @@ struct tsd_batch {
   size_t head_bytes = 0;             // bytes of the three entry arrays in front of the scans
   hipStream_t stream = nullptr;
   hipEvent_t ev_rc_done = nullptr, ev_icp_done = nullptr, ev_copy_done = nullptr;
-  unsigned int* d_rc_flag = nullptr;    // number of the slot's latest batch whose ray casts have finished (set by a one-wave kernel
-  unsigned int rc_batches = 0;          // behind them on the grid's stream); batches begun on this slot
+  unsigned int* d_rc_flag = nullptr;    // [2]: number of the slot's latest batch whose ray casts have finished (set by a one-wave kernel
+  unsigned int rc_batches = 0;          // behind them on the grid's stream) / that the host abandoned; batches begun on this slot
+  bool dev_wait = false;                // the two hand-offs of a batch are waits ON THE DEVICE (proven possible by the probe in
+                                        // tsd_batch_create) instead of stream events
+  unsigned int poll_bound = tsd::BATCH_POLL_BOUND;
+  unsigned int* h_gate_err = nullptr;   // pinned, coherent: set by a push gate (k_wait_seq) whose registration never reported done
+  unsigned int* d_gate_err = nullptr;   // its device address
   char* h_stage = nullptr;           // pinned: entries + scans of the batch being enqueued
   char* d_stage2[2] = {nullptr, nullptr};   // device copies, alternating (the pushes of the previous batch still read theirs)
   int stage_slot = 0;
@@ -333,10 +344,15 @@ int launch_raycast(tsd_ctx* ctx, const RaycastArgs& a, const RaycastArgs* a_dev 
 int launch_icp(tsd_ctx* ctx, const IcpArgs& a, const double* P_dev = nullptr, const double* d_rays_local = nullptr,
                const double* d_ranges = nullptr, const uint8_t* d_mask = nullptr, const ScanPostArgs* post = nullptr);
 int launch_scan_prepare(tsd_ctx* ctx, SensorDev* st);
-// one wave on the context's stream that waits (on the device, bounded) until *seq == value
-int launch_wait_seq(tsd_ctx* ctx, const unsigned long long* seq, unsigned long long value);
-// one wave on the context's stream that publishes *flag = value (device scope) once everything ahead of it on the stream is done
-int launch_set_flag(tsd_ctx* ctx, unsigned int* flag, unsigned int value);
+// one wave on the context's stream that waits (on the device, bounded) until *seq == value; when the bound runs out it switches
+// the push behind it off (push->enabled = 0) and raises *err_host (coherent host memory) instead of letting stale arguments through
+int launch_wait_seq(tsd_ctx* ctx, const unsigned long long* seq, unsigned long long value, PushArgs* push, unsigned int* err_host,
+                    unsigned int poll_bound);
+// one wave on `stream` that publishes *flag = value (device scope) once everything ahead of it on the stream is done
+int launch_set_flag(tsd_ctx* ctx, hipStream_t stream, unsigned int* flag, unsigned int value);
+// start-up probe of tsd_batch_create: can a kernel on stream `a` wait for a flag that a kernel launched AFTER it on stream `b`
+// sets?  (No when the two streams share an in-order hardware queue, or when something serialises dispatches.)
+int probe_cross_stream_wait(tsd_ctx* ctx, hipStream_t a, hipStream_t b, unsigned int* d_flag2, bool* ok);
 // batched launches on `stream`; the entry arrays live in device memory, `host` is the host copy they were staged from
 int launch_raycast_batch(tsd_ctx* ctx, hipStream_t stream, const RaycastBatchEntry* d_entries, int n, int max_beams);
 int launch_raycast_batch_byval(tsd_ctx* ctx, hipStream_t stream, const RaycastBatchEntry* h_entries, int n, int max_beams);   // n <= RC_BATCH_BYVAL

@@ -187,3 +187,31 @@ def test_batch_argument_errors(oracle):
         batch.begin([sensors[0]], [ing[0][0]], [ing[0][1]], None, params, gates)
     assert len(b2.results()) == 2
     b2.close(); batch.close()
+
+
+import os      # noqa: E402
+import subprocess  # noqa: E402
+import sys     # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("env_extra,must_be_clean", [
+    ({"TSD_BATCH_VERBOSE": "1"}, True),                                   # the box as it is: the probe decides, every result right
+    ({"GPU_MAX_HW_QUEUES": "1", "TSD_BATCH_VERBOSE": "1"}, False),        # every stream on ONE in-order hardware queue
+    ({"GPU_MAX_HW_QUEUES": "1", "TSD_BATCH_FORCE_DEVICE_WAIT": "1", "TSD_BATCH_POLL_BOUND": "30000", "TSD_BATCH_VERBOSE": "1"}, False),
+    ({"TSD_BATCH_EVENT_WAIT": "1"}, True),
+])
+def test_batched_path_never_delivers_stale_registrations(env_extra, must_be_clean):
+    """The hand-offs inside a batch are waits on the device only where a start-up probe has shown that the streams involved run
+    side by side; and where such a wait still runs out (forced here: one hardware queue, device waits insisted on, a short
+    bound), the caller gets a non-zero code -- correct results or an error, never a pose from stale ray-cast output with rc 0
+    (tests/batch_serial_check.py exits 9 for that)."""
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TSD_BATCH_") and k != "GPU_MAX_HW_QUEUES"}
+    env.update(env_extra)
+    out = subprocess.run([sys.executable, "-m", "tests.batch_serial_check"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-3000:], out.stderr[-3000:])
+    assert "batch_serial_check ok" in out.stdout
+    if must_be_clean:
+        assert ", 0 calls returned an error" in out.stdout, out.stdout[-2000:]
+    print(out.stdout[-600:], out.stderr[-600:])

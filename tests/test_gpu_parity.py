@@ -471,6 +471,42 @@ def test_fused_scan_with_host_calls_in_between(oracle):
     H.assert_grids_equal(a.grid.download_tiles(), b.grid.download_tiles(), 0.0)
 
 
+def test_staged_scan_dropped_every_scan_at_cfg3(oracle):
+    """A scan staged ahead that is NOT the one that comes next is dropped by tsd_scan_submit.  The three scan / table buffers
+    of the sensor are used in turn, and a drop must not advance that rotation twice per scan: the decoy staged after scan k+1
+    would then overwrite the buffers the push of scan k may still be reading (nothing the host has seen orders that push).  A
+    decoy is staged and dropped after EVERY scan here, at cfg 3 where a push takes longest; poses, push decisions and the
+    whole-grid digest must equal the plain tsd_scan loop."""
+    from tests.slam_driver import HipSlamFused, slam_kwargs
+    gc, geo, _ = synth.CONFIGS["cfg3"]
+    world = synth.World("pillars", gc)
+    poses = synth.trajectory(world, 14)
+    scans = synth.scans_for(world, geo, poses)
+    kw = slam_kwargs(gc, geo)
+    a, b = HipSlamFused(oracle, **kw), HipSlamFused(oracle, **kw)
+
+    def ingest(r32):
+        r = np.array(r32, dtype=np.float32)
+        r[r < kw["laser_min_range"]] = 0.0
+        data, mask = oracle.ingest_f32(r, kw["max_range"], kw["angle_increment"])
+        _, mask_push = oracle.ingest_f64(data, kw["max_range"], kw["angle_increment"])
+        return data, mask, mask_push
+
+    for k in range(len(scans)):
+        ra = a.process_scan(scans[k])
+        if k == 0:
+            rb = b.process_scan(scans[k])
+        else:
+            data, mask, mask_push = ingest(scans[k])
+            decoy = ingest(np.roll(np.asarray(scans[k - 1], dtype=np.float32), 97) * np.float32(0.5))   # nothing like the next scan
+            sr = b.sensor.scan_ahead(data, mask, mask_push, b.params, b.gates, nxt=decoy)
+            rb = dict(pose=np.array(sr.pose[:]).reshape(3, 3), pushed=int(sr.pushed), pairs=int(sr.icp.pairs), valid_model=int(sr.icp.n_model))
+        d, ang = H.pose_delta(ra["pose"], rb["pose"])
+        assert d == 0.0 and ang == 0.0, f"scan {k}: {d} {ang}"
+        assert ra["pushed"] == rb["pushed"] and ra["pairs"] == rb["pairs"] and ra["valid_model"] == rb["valid_model"], k
+    assert a.grid.digest() == b.grid.digest()
+
+
 def test_push_degenerate_scans(oracle):
     """All beams masked / all infinite / a single valid beam / every beam at max range: same tile
     classification and cells on both sides, no crash, nothing updated where nothing is visible."""
