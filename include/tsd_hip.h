@@ -290,6 +290,16 @@ int tsd_batch_results(tsd_batch* b, tsd_scan_result* results /* [n] */);
  * when the step had too few pairs to estimate), for i < min(iterations, max_iters). */
 int tsd_icp_trace(tsd_ctx* ctx, double* out, int max_iters);
 
+/* Parity / debug entry: the pair lists of the first `calls` PairAssignment::determinePairs calls (PairAssignment.cpp:38-84: exact
+ * 1-NN, then DistanceFilter.cpp:32-64 with its threshold schedule for params->iterations, then ReciprocalFilter.cpp:32-78) on a
+ * STATIC scene -- the scene is not moved between the calls -- as the registration kernel itself forms them (the same code path as
+ * tsd_icp: tiers of the exact NN search, LDS atomic-min reciprocal filter; a dedicated instantiation writes the winners out).
+ * n_pairs[k] pairs of call k at model_idx / scene_idx[k * n_scene + i], in ascending model index like the reference's output.
+ * This is what tests/golden/ref_chain_pairs.npz holds from the COMPILED reference, so the HIP filter chain is pinned to it directly. */
+int tsd_icp_pairs(tsd_ctx* ctx, const double* model_xy, int n_model, const double* scene_xy, int n_scene, const double pose33[9],
+                  const tsd_icp_params* params, int calls, int* n_pairs /* [calls] */, int* model_idx /* [calls * n_scene] */,
+                  int* scene_idx /* [calls * n_scene] */);
+
 /* ---- map I/O --------------------------------------------------------------------------------- */
 /* Canonical dump / restore of the tile state: initialized[tiles], init_weight[tiles],
  * tsd[tiles][1089], weight[tiles][1089] (uninitialised tiles read back NaN / 0).  Logical content of

@@ -181,6 +181,7 @@ ABI = {
     "tsd_occupancy": (C.c_int, [C.c_void_p, _i8p, C.c_int, C.c_int, _ip]),
     "tsd_occupancy_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "tsd_occupancy_dev_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "tsd_icp_pairs": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, C.c_int, _dp, C.POINTER(IcpParams), C.c_int, _ip, _ip, _ip]),
     "tsd_calibrate_rmw": (C.c_int, [C.c_void_p, C.c_int64, C.c_int]),
     "tsd_measure_stream": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, _dp, _dp]),
     "tsd_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
@@ -362,6 +363,17 @@ class TsdGridDevice:
                                    max_range, C.byref(params), C.byref(r))
         self._check(rc, "tsd_localize")
         return IcpOut(np.array(r.T[:]).reshape(3, 3), r.rms, r.pairs, r.iterations, r.state, r.n_model, r.n_scene)
+
+    def icp_pairs(self, model_xy, scene_xy, pose, params: IcpParams, calls: int):
+        """tsd_icp_pairs: [(model_idx, scene_idx)] of each of the first ``calls`` determinePairs calls on the static scene"""
+        m, sc, ps = _f64(model_xy).reshape(-1), _f64(scene_xy).reshape(-1), _f64(pose).reshape(9)
+        nm, ns = len(m) // 2, len(sc) // 2
+        n = np.zeros(calls, dtype=np.int32)
+        mi, si = np.zeros(calls * ns, dtype=np.int32), np.zeros(calls * ns, dtype=np.int32)
+        rc = self.lib.tsd_icp_pairs(self.h, _d(m), nm, _d(sc), ns, _d(ps), C.byref(params), calls, n.ctypes.data_as(_ip),
+                                    mi.ctypes.data_as(_ip), si.ctypes.data_as(_ip))
+        self._check(rc, "tsd_icp_pairs")
+        return [(mi[k * ns:k * ns + n[k]].copy(), si[k * ns:k * ns + n[k]].copy()) for k in range(calls)]
 
     def icp_trace(self, iterations):
         """per iteration: pairs, rms, DistanceFilter threshold before the step, state, Tlast as (c, s, tx, ty)"""

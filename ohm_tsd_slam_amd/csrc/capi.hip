@@ -611,28 +611,15 @@ int tsd_icp(tsd_ctx* ctx, const double* model_xy, int n_model, const double* sce
   return tsd_icp_normals(ctx, model_xy, nullptr, n_model, scene_xy, n_scene, pose33, params, result);
 }
 
-int tsd_icp_normals(tsd_ctx* ctx, const double* model_xy, const double* model_normals_xy, int n_model,
-                    const double* scene_xy, int n_scene, const double pose33[9], const tsd_icp_params* params,
-                    tsd_icp_result* result)
+// Direct-mode inputs of a registration on their way to the device.  The kernel's exact nearest-neighbour walk wants the model in
+// angular order about the origin of the sensor frame (what the ray cast emits by construction); arbitrary callers get it sorted
+// here; the original indices travel along for the lowest-index tie rule (`order`: slot -> original model index), and every scene
+// point gets the slot where its own direction falls as first search position.  Ordering only: no arithmetic on the data.
+static int stage_icp_inputs(tsd_ctx* ctx, const IcpArgs& a, const double* model_xy, const double* model_normals_xy, int n_model,
+                            const double* scene_xy, int n_scene, bool normals, std::vector<int>& order)
 {
-  if (ctx) ctx->epoch++;                  // (invalidates ray casts enqueued ahead of their scan)
-  if (!ctx || !pose33 || !params || !result || n_model < 0 || n_scene < 0) return TSD_E_ARG;
-  if (params->estimator != TSD_ESTIMATOR_CLOSED_FORM && params->estimator != TSD_ESTIMATOR_POINT_TO_LINE)
-    return set_error(ctx, TSD_E_ARG, "tsd_icp_params.estimator", hipSuccess);
-  if (params->estimator == TSD_ESTIMATOR_POINT_TO_LINE && n_model > 0 && !model_normals_xy)
-    return set_error(ctx, TSD_E_ARG, "the point-to-line estimator needs the model normals (tsd_icp_normals)", hipSuccess);
-  if ((n_model > 0 && !model_xy) || (n_scene > 0 && !scene_xy)) return TSD_E_ARG;
-  if (n_model > TSD_MAX_ICP_POINTS || n_scene > TSD_MAX_ICP_POINTS)
-    return set_error(ctx, TSD_E_CAPACITY, "icp points > TSD_MAX_ICP_POINTS", hipSuccess);
-  TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  IcpArgs a;
-  fill_icp_args(a, pose33, params);
-  a.n_model = n_model; a.n_scene = n_scene; a.beams = 0;
-  // The kernel's exact nearest-neighbour walk wants the model in angular order about the origin of the
-  // sensor frame (what the ray-cast emits by construction).  Arbitrary callers get it sorted here; the
-  // original indices travel along for the lowest-index tie rule, and every scene point gets the slot
-  // where its own direction falls as first search position.  Ordering only: no arithmetic on the data.
-  std::vector<int> order((size_t)n_model), start((size_t)n_scene);
+  order.resize((size_t)n_model);
+  std::vector<int> start((size_t)n_scene);
   std::vector<double> ang((size_t)n_model);
   for (int j = 0; j < n_model; j++) ang[(size_t)j] = std::atan2(model_xy[2 * j + 1], model_xy[2 * j]);
   std::iota(order.begin(), order.end(), 0);
@@ -651,7 +638,7 @@ int tsd_icp_normals(tsd_ctx* ctx, const double* model_xy, const double* model_no
   int s;
   char* h = stage_acquire(ctx, &s);
   const size_t mb = (size_t)n_model * 16, sb = (size_t)n_scene * 16, ob = (size_t)n_model * 4, tb = (size_t)n_scene * 4;
-  const size_t nb = (params->estimator == TSD_ESTIMATOR_POINT_TO_LINE) ? mb : 0;
+  const size_t nb = normals ? mb : 0;
   if (mb + sb + ob + tb + nb > ctx->stage_bytes) return set_error(ctx, TSD_E_CAPACITY, "icp staging", hipSuccess);
   double* hm = reinterpret_cast<double*>(h);
   for (int k = 0; k < n_model; k++) { const int j = order[(size_t)k]; hm[2 * k] = model_xy[2 * j]; hm[2 * k + 1] = model_xy[2 * j + 1]; }
@@ -669,11 +656,82 @@ int tsd_icp_normals(tsd_ctx* ctx, const double* model_xy, const double* model_no
     TSD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_mnormals, hn, nb, hipMemcpyHostToDevice, ctx->stream));
   }
   TSD_HIP_CHECK(ctx, hipEventRecord(ctx->stage_ev[s], ctx->stream));
-  int rc = launch_icp(ctx, a);
+  return TSD_OK;
+}
+
+int tsd_icp_normals(tsd_ctx* ctx, const double* model_xy, const double* model_normals_xy, int n_model,
+                    const double* scene_xy, int n_scene, const double pose33[9], const tsd_icp_params* params,
+                    tsd_icp_result* result)
+{
+  if (ctx) ctx->epoch++;                  // (invalidates ray casts enqueued ahead of their scan)
+  if (!ctx || !pose33 || !params || !result || n_model < 0 || n_scene < 0) return TSD_E_ARG;
+  if (params->estimator != TSD_ESTIMATOR_CLOSED_FORM && params->estimator != TSD_ESTIMATOR_POINT_TO_LINE)
+    return set_error(ctx, TSD_E_ARG, "tsd_icp_params.estimator", hipSuccess);
+  if (params->estimator == TSD_ESTIMATOR_POINT_TO_LINE && n_model > 0 && !model_normals_xy)
+    return set_error(ctx, TSD_E_ARG, "the point-to-line estimator needs the model normals (tsd_icp_normals)", hipSuccess);
+  if ((n_model > 0 && !model_xy) || (n_scene > 0 && !scene_xy)) return TSD_E_ARG;
+  if (n_model > TSD_MAX_ICP_POINTS || n_scene > TSD_MAX_ICP_POINTS)
+    return set_error(ctx, TSD_E_CAPACITY, "icp points > TSD_MAX_ICP_POINTS", hipSuccess);
+  TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  IcpArgs a;
+  fill_icp_args(a, pose33, params);
+  a.n_model = n_model; a.n_scene = n_scene; a.beams = 0;
+  std::vector<int> order;
+  int rc = stage_icp_inputs(ctx, a, model_xy, model_normals_xy, n_model, scene_xy, n_scene, params->estimator == TSD_ESTIMATOR_POINT_TO_LINE, order);
+  if (rc != TSD_OK) return rc;
+  rc = launch_icp(ctx, a);
   if (rc != TSD_OK) return rc;
   TSD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_icp_res, ctx->d_icp_res, sizeof(IcpResultDev), hipMemcpyDeviceToHost, ctx->stream));
   TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   copy_icp_result(ctx->h_icp_res, result);
+  return TSD_OK;
+}
+
+int tsd_icp_pairs(tsd_ctx* ctx, const double* model_xy, int n_model, const double* scene_xy, int n_scene, const double pose33[9],
+                  const tsd_icp_params* params, int calls, int* n_pairs, int* model_idx, int* scene_idx)
+{
+  if (ctx) ctx->epoch++;
+  if (!ctx || !pose33 || !params || !n_pairs || !model_idx || !scene_idx || n_model < 1 || n_scene < 1 || !model_xy || !scene_xy) return TSD_E_ARG;
+  if (calls < 1 || calls > TSD_ICP_TRACE_MAX) return set_error(ctx, TSD_E_ARG, "tsd_icp_pairs: calls out of range", hipSuccess);
+  if (params->estimator != TSD_ESTIMATOR_CLOSED_FORM) return set_error(ctx, TSD_E_ARG, "tsd_icp_pairs: closed-form instantiation only", hipSuccess);
+  if (n_model > TSD_MAX_ICP_POINTS || n_scene > TSD_MAX_ICP_POINTS)
+    return set_error(ctx, TSD_E_CAPACITY, "icp points > TSD_MAX_ICP_POINTS", hipSuccess);
+  TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  IcpArgs a;
+  fill_icp_args(a, pose33, params);        // (the threshold schedule comes from params->iterations, like the node's DistanceFilter)
+  a.n_model = n_model; a.n_scene = n_scene; a.beams = 0;
+  a.iterations = calls;                    // ... the number of determinePairs calls from `calls`
+  std::vector<int> order;
+  int rc = stage_icp_inputs(ctx, a, model_xy, nullptr, n_model, scene_xy, n_scene, false, order);
+  if (rc != TSD_OK) return rc;
+  const int cap = icp_pairs_cap(n_model, n_scene);
+  const size_t words = (size_t)calls * (size_t)cap;
+  int* d_pairs = nullptr;
+  TSD_HIP_CHECK(ctx, hipMalloc(&d_pairs, words * sizeof(int)));
+  std::vector<int> h_pairs(words);
+  hipError_t e = hipMemsetAsync(d_pairs, 0xFF, words * sizeof(int), ctx->stream);
+  if (e == hipSuccess) rc = launch_icp_pairs(ctx, a, d_pairs);
+  if (e == hipSuccess && rc == TSD_OK) e = hipMemcpyAsync(h_pairs.data(), d_pairs, words * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess && rc == TSD_OK) e = hipStreamSynchronize(ctx->stream);
+  hipFree(d_pairs);
+  if (e != hipSuccess) return set_error(ctx, TSD_E_HIP, "tsd_icp_pairs", e);
+  if (rc != TSD_OK) return rc;
+  // ReciprocalFilter leaves at most one pair per model point and emits them in ascending MODEL index (ReciprocalFilter.cpp:16-21,
+  // :32-78): slot -> original model index, then that order
+  std::vector<std::pair<int, int>> pr;
+  for (int k = 0; k < calls; k++) {
+    pr.clear();
+    for (int slot = 0; slot < n_model; slot++) {
+      const int si = h_pairs[(size_t)k * (size_t)cap + (size_t)slot];
+      if (si >= 0) pr.emplace_back(order[(size_t)slot], si);
+    }
+    std::sort(pr.begin(), pr.end());
+    n_pairs[k] = (int)pr.size();
+    for (size_t i = 0; i < pr.size() && i < (size_t)n_scene; i++) {
+      model_idx[(size_t)k * (size_t)n_scene + i] = pr[i].first;
+      scene_idx[(size_t)k * (size_t)n_scene + i] = pr[i].second;
+    }
+  }
   return TSD_OK;
 }
 

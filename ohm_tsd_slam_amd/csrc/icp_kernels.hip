@@ -463,7 +463,10 @@ __device__ __forceinline__ void block_totals(const IcpLds& L, const double (&v)[
 
 // the whole registration of one workgroup; k_icp (one registration per launch) and k_icp_batch (workgroup x = registration x
 // of a batch) are thin wrappers
-template <int R, int MAXT, bool PTL>
+// PAIRS (parity / debug instantiation, tsd_icp_pairs): the scene is NOT moved between the steps and every step's surviving pair list
+// is written out -- the repeated PairAssignment::determinePairs calls on a static scene that the compiled reference's chain
+// (PairAssignment.cpp:38-84 -> DistanceFilter -> ReciprocalFilter) is driven with in tests/golden/ref_chain_pairs.npz.
+template <int R, int MAXT, bool PTL, bool PAIRS = false>
 __device__ __forceinline__ void
 icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __restrict__ g_model, const double* __restrict__ g_scene,
       const int* __restrict__ g_morig, const int* __restrict__ g_start,
@@ -471,7 +474,8 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
       const double* __restrict__ g_rays_local, const double* __restrict__ g_ranges,
       const uint8_t* __restrict__ g_mask, IcpResultDev* __restrict__ out,
       double* __restrict__ trace /* [TSD_ICP_TRACE_MAX][TSD_ICP_TRACE_STRIDE] = pairs, rms, thr_before, state, Tlast (co, si, dX, dY) */, const ScanPostArgs& post,
-      const double* __restrict__ g_mnormals /* direct mode */, const double* __restrict__ g_normals /* fused: ray cast */)
+      const double* __restrict__ g_mnormals /* direct mode */, const double* __restrict__ g_normals /* fused: ray cast */,
+      int* __restrict__ pairs_out = nullptr /* PAIRS: [steps][cap] winning scene index per model slot, preset to -1 */)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   IcpLds L;
@@ -690,7 +694,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
   double thr = a.thr0;                       // DistanceFilter::_distSqr after reset()
   double rms_prev = 10e12;
   unsigned int conv_cnt = 0;
-  const unsigned int max_it = (unsigned)a.iterations, conv_need = (unsigned)a.iterations;
+  const unsigned int max_it = (unsigned)a.iterations, conv_need = PAIRS ? ~0u : (unsigned)a.iterations;
   // rows of the pose's rotation block are unit vectors up to rounding: |R_p s| <= pnorm |s| per axis
   const double pnorm = fmax(sqrt(P00 * P00 + P01 * P01), sqrt(P10 * P10 + P11 * P11)) * (1.0 + 1e-9);
 
@@ -921,6 +925,11 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     }
 #pragma unroll
     for (int q = 0; q < R; q++) cnt += __popcll(__ballot(win[q]));
+    if constexpr (PAIRS) {
+#pragma unroll
+      for (int q = 0; q < R; q++)
+        if (win[q]) pairs_out[(size_t)iter * (size_t)cap + (size_t)hint[q]] = pid[q];
+    }
     STAMP(2);
 
     // -- phase D/F: ClosedFormEstimator2D::setPairs + estimateTransformation in ONE pass over the pairs.
@@ -1051,7 +1060,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
       // bound of tier 0.
 #pragma unroll
       for (int q = 0; q < R; q++) {
-        if (q >= Rn) continue;
+        if (q >= Rn || PAIRS) continue;          // (PAIRS: a static scene, determinePairs called again and again)
         const double x = sx[q], y = sy[q];
         double nx = 0.0, ny = 0.0;
         nx += x * co; nx += y * (-si);
@@ -1141,6 +1150,18 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
 {
   icp_workgroup<R, MAXT, PTL>(a, P_dev, cap, g_model, g_scene, g_morig, g_start, g_coords, g_mask_m, g_rays_local, g_ranges, g_mask, out, trace,
                               post, g_mnormals, g_normals);
+}
+
+// the same kernel with the per-step pair lists written out and the scene held still (direct mode, closed form): tsd_icp_pairs
+template <int R, int MAXT>
+__global__ void __launch_bounds__(MAXT)
+k_icp_pairs(IcpArgs a, int cap, const double* __restrict__ g_model, const double* __restrict__ g_scene,
+            const int* __restrict__ g_morig, const int* __restrict__ g_start, IcpResultDev* __restrict__ out, double* __restrict__ trace,
+            int* __restrict__ pairs_out)
+{
+  ScanPostArgs post{};
+  icp_workgroup<R, MAXT, false, true>(a, nullptr, cap, g_model, g_scene, g_morig, g_start, nullptr, nullptr, nullptr, nullptr, nullptr, out, trace,
+                                      post, nullptr, nullptr, pairs_out);
 }
 
 // the registrations of a batch of robots in ONE launch (tsd_batch_begin): workgroup x = entry x, fused mode only (model and
@@ -1265,6 +1286,39 @@ int launch_icp(tsd_ctx* ctx, const IcpArgs& a, const double* P_dev, const double
   }
   if (nthr <= 3 * 512) return launch_icp_shape<3, 512>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post, ctx->icp_shape >= 64 ? ctx->icp_shape : 0);
   return launch_icp_shape<8, 256>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post);
+}
+
+template <int R, int MAXT>
+static int launch_icp_pairs_shape(tsd_ctx* ctx, const IcpArgs& a, int n, int cap, int* d_pairs)
+{
+  int T = ((n + R - 1) / R + 63) & ~63;
+  if (T < 64) T = 64;
+  if (T > MAXT) return set_error(ctx, TSD_E_CAPACITY, "icp workgroup shape", hipSuccess);
+  const size_t lds = icp_lds_bytes_for(cap, T, false);
+  if (lds > 160u * 1024u) return set_error(ctx, TSD_E_CAPACITY, "registration does not fit the LDS of one CU", hipSuccess);
+  {
+    std::lock_guard<std::mutex> lk_misc(ctx->misc_mutex);
+    size_t& configured = ctx->lds_configured[reinterpret_cast<const void*>(k_icp_pairs<R, MAXT>)];
+    if (lds > configured) {
+      TSD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_icp_pairs<R, MAXT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      configured = lds;
+    }
+  }
+  hipLaunchKernelGGL((k_icp_pairs<R, MAXT>), dim3(1), dim3(T), lds, ctx->stream, a, cap, ctx->d_model, ctx->d_scene, ctx->d_morig, ctx->d_start,
+                     ctx->d_icp_res, ctx->d_icp_trace, d_pairs);
+  TSD_HIP_CHECK(ctx, hipGetLastError());
+  return TSD_OK;
+}
+
+// direct mode, closed form, the default workgroup shapes of launch_icp; d_pairs = [a.iterations][icp_pairs_cap(n)] ints preset to -1
+int icp_pairs_cap(int n_model, int n_scene) { return icp_cap_for(n_model > n_scene ? n_model : n_scene); }
+int launch_icp_pairs(tsd_ctx* ctx, const IcpArgs& a, int* d_pairs)
+{
+  const int n = a.n_model > a.n_scene ? a.n_model : a.n_scene;
+  if (n > TSD_MAX_ICP_POINTS) return set_error(ctx, TSD_E_CAPACITY, "icp points > TSD_MAX_ICP_POINTS", hipSuccess);
+  const int cap = icp_cap_for(n);
+  if (a.n_scene <= 3 * 512) return launch_icp_pairs_shape<3, 512>(ctx, a, a.n_scene, cap, d_pairs);
+  return launch_icp_pairs_shape<8, 256>(ctx, a, a.n_scene, cap, d_pairs);
 }
 
 template <int R, int MAXT, bool PTL>

@@ -343,6 +343,8 @@ int launch_grid_digest(tsd_ctx* ctx, unsigned long long* d_out, double* d_sums);
 int launch_raycast(tsd_ctx* ctx, const RaycastArgs& a, const RaycastArgs* a_dev = nullptr, const double* d_rays = nullptr);
 int launch_icp(tsd_ctx* ctx, const IcpArgs& a, const double* P_dev = nullptr, const double* d_rays_local = nullptr,
                const double* d_ranges = nullptr, const uint8_t* d_mask = nullptr, const ScanPostArgs* post = nullptr);
+int launch_icp_pairs(tsd_ctx* ctx, const IcpArgs& a, int* d_pairs);
+int icp_pairs_cap(int n_model, int n_scene);
 int launch_scan_prepare(tsd_ctx* ctx, SensorDev* st);
 // one wave on the context's stream that waits (on the device, bounded) until *seq == value; when the bound runs out it switches
 // the push behind it off (push->enabled = 0) and raises *err_host (coherent host memory) instead of letting stale arguments through

@@ -507,6 +507,34 @@ def test_staged_scan_dropped_every_scan_at_cfg3(oracle):
     assert a.grid.digest() == b.grid.digest()
 
 
+def test_hip_pair_chain_equals_compiled_reference_fixture():
+    """tests/golden/ref_chain_pairs.npz holds pair lists produced by the COMPILED reference (its own PairAssignment.cpp,
+    DistanceFilter.cpp, ReciprocalFilter.cpp; tests/golden/make_ref_chain_fixture.py) for repeated determinePairs() calls on a
+    static scene.  The registration kernel's own pair formation (tsd_icp_pairs: the k_icp code path with the scene held still)
+    must give the same lists, bit for bit and in the same order, for all five cases (icp_iterations 30 / 25 / 11 / 10 / 4, i.e.
+    the threshold schedule incl. its unsigned wrap): row I4 of the HIP side pinned to the reference directly, no oracle in between."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_chain_pairs.npz"))
+    g = capi.TsdGridDevice(8, 0.05, 0.15)
+    total = 0
+    for case in range(int(z["n_cases"])):
+        model, scene = z[f"model_{case}"], z[f"scene_{case}"]
+        iters, calls = int(z[f"iters_{case}"]), int(z[f"calls_{case}"])
+        b = z[f"bounds_{case}"]
+        prm = g.icp_params(iters, 0.4, 0.02)
+        prm.min_x, prm.max_x, prm.min_y, prm.max_y = float(b[0]), float(b[1]), float(b[2]), float(b[3])
+        got = g.icp_pairs(model, scene, np.eye(3), prm, calls)
+        for k in range(calls):
+            assert np.array_equal(z[f"pm_{case}_{k}"], got[k][0]), (case, k, "model indices")
+            assert np.array_equal(z[f"ps_{case}_{k}"], got[k][1]), (case, k, "scene indices")
+            total += len(got[k][0])
+        # the same inputs through the ordinary registration: its first step's pair count is the first list's length
+        r = g.icp(model, scene, np.eye(3), prm)
+        assert int(g.icp_trace(1)[0][0]) == len(z[f"pm_{case}_0"])
+    assert total > 2000
+    g.close()
+
+
 def test_push_degenerate_scans(oracle):
     """All beams masked / all infinite / a single valid beam / every beam at max range: same tile
     classification and cells on both sides, no crash, nothing updated where nothing is visible."""
