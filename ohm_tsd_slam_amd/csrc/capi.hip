@@ -324,6 +324,7 @@ tsd_ctx* tsd_create(int device, int map_size_log2, double cell_size, double max_
   if (!ctx) return nullptr;
   ctx->device = device;
   ctx->map_log2 = map_size_log2;
+  { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->n_cus = cus; }
   GridDev& g = ctx->grid;
   // TsdGrid::init (TsdGrid.cpp:112-169)
   g.N = 1 << map_size_log2;
@@ -356,8 +357,7 @@ tsd_ctx* tsd_create(int device, int map_size_log2, double cell_size, double max_
   A(hipMalloc(&ctx->d_tile_totals, T * 8 * sizeof(uint32_t)));
   A(hipMalloc(&ctx->d_pushes, 2 * sizeof(unsigned long long)));
   A(hipMalloc(&ctx->d_list, T * sizeof(uint32_t)));
-  A(hipMalloc(&ctx->d_list_win, T * sizeof(uint32_t)));
-  A(hipMalloc(&ctx->d_list_pw, T * sizeof(double)));
+  A(hipMalloc(&ctx->d_list_aux, T * push_list_aux_bytes()));
   A(hipMalloc(&ctx->d_push_args, sizeof(PushArgs)));
   A(hipMalloc(&ctx->d_list_cnt, 2 * sizeof(unsigned int)));
   A(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
@@ -428,7 +428,7 @@ void tsd_destroy(tsd_ctx* ctx)
   GridDev& g = ctx->grid;
   hipFree(g.flags); hipFree(g.init_weight); hipFree(g.tsd); hipFree(g.weight); hipFree(g.negmask);
   if (ctx->stream2) hipStreamSynchronize(ctx->stream2);
-  hipFree(ctx->d_rmq2[0]); hipFree(ctx->d_rmq2[1]); hipFree(ctx->d_tile_rec); hipFree(ctx->d_dirty); hipFree(ctx->d_tile_totals); hipFree(ctx->d_pushes); hipFree(ctx->d_list); hipFree(ctx->d_list_win); hipFree(ctx->d_list_pw); hipFree(ctx->d_push_args); hipFree(ctx->d_list_cnt);
+  hipFree(ctx->d_rmq2[0]); hipFree(ctx->d_rmq2[1]); hipFree(ctx->d_tile_rec); hipFree(ctx->d_dirty); hipFree(ctx->d_tile_totals); hipFree(ctx->d_pushes); hipFree(ctx->d_list); hipFree(ctx->d_list_aux); hipFree(ctx->d_push_args); hipFree(ctx->d_list_cnt);
   if (ctx->ev_tables) hipEventDestroy(ctx->ev_tables);
   if (ctx->ev_h2d) hipEventDestroy(ctx->ev_h2d);
   if (ctx->ev_grid) hipEventDestroy(ctx->ev_grid);

@@ -228,6 +228,54 @@ constexpr uint32_t LIST_INTERIOR = 1u << 26;     // far tile whose four corners 
                                                  // an end of the field of view or the +-pi cut (k_push_update skips those tests)
 constexpr int TOT_FIELDS = 8;   // cells updated, range pass, update, new, new from empty, emptied init, emptied uninit, -
 
+// what k_push_classify leaves for the workgroup of a listed tile besides the entry word (one 48-byte record, two 16-byte loads + one)
+struct PushListAux {
+  uint32_t win, pad;             // beams the cells of the tile can project to: lo | hi << 16
+  double pw;                     // partition weight of an UPDATE tile (TsdGrid.cpp:239-243)
+  // phase A of k_push_update (fp32 beam estimate), all relative to the tile's centroid c = ((x0 + 16.5) cs, (y0 + 16.5) cs) -- the
+  // centre of cell (ix, iy) is c + (ix - 16, iy - 16) cs -- with l_c = PoseInv (c, 1) and M = PoseInv's rotation * cs:
+  float A, B;                    // l_c x (M d) = dx A + dy B   (d = cell offset in cells)
+  float C, D;                    // l_c . (M d) = dx C + dy D
+  float lc2, th_c;               // |l_c|^2, angle of l_c (atan2_estimate)
+  float lcx, lcy;                // l_c itself (near tiles)
+};
+static_assert(sizeof(PushListAux) == 48, "PushListAux");
+
+// ---- beam index of a cell without the fp64 atan2 ------------------------------------------------------------
+// SensorPolar2D::backProject (SensorPolar2D.cpp:117-135) decides round((atan2(ly, lx) - phi_min) / res) and the two
+// bound checks from fp64 values.  The kernel ESTIMATES the beam coordinate u = (angle - phi_min) / res in fp32:
+//   far tiles (sensor further than 3 circumradii from the tile centre -- all but a handful): the cell's angle is the
+//       tile centre's plus a small delta, |delta| < 0.34 rad, and delta = atan(cross / dot) by a four-term series;
+//       ~17 fp32 instructions
+//   near tiles: a six-term minimax arctangent over the full circle; ~30
+// Every source of error (fp32 coordinates relative to the tile centre, v_rcp_f32, the series truncation t^9 / 9, the
+// fp32 product with 1 / res at u <= 4096) stays below 4e-3 beams by the error budget, so an estimate further than 0.02
+// beams from a rounding boundary (j +- 0.5), from the ends of the field of view and from the +-pi cut of atan2 names the
+// reference's beam with a margin of 5x.  Checked on the device: the -DTSD_PUSH_VERIFY_INDEX build compares every decided
+// cell with the exact formulation inside the kernel -- 749 M cells over the BASELINE scenes, none decided wrongly
+// (tools/push_verify_index.sh, profiles/r2_push_index_estimate_verified.txt).  The other cells (4-5 %) are not decided by the estimate at all: they go to
+// a queue in LDS and get the exact fp64 formulation, densely (one lane per queued cell), instead of dragging their
+// whole wave through it.
+constexpr int IDX_UNSURE = INT_MIN;
+constexpr float IDX_MARGIN = 0.02f;
+__device__ __forceinline__ float atan2_estimate(float y, float x)      // |error| < 2e-6 rad
+{
+  const float ax = fabsf(x), ay = fabsf(y);
+  const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+  const float t = mn * __builtin_amdgcn_rcpf(mx);
+  const float t2 = t * t;
+  // minimax odd polynomial of atan on [0, 1] (Abramowitz-Stegun 4.4.49 class, 6 terms)
+  float r = -0.0117212f;
+  r = fmaf(r, t2, 0.05265332f);
+  r = fmaf(r, t2, -0.11643287f);
+  r = fmaf(r, t2, 0.19354346f);
+  r = fmaf(r, t2, -0.33262347f);
+  r = fmaf(r, t2, 0.99997726f);
+  r *= t;
+  r = ay > ax ? 1.57079637f - r : r;
+  r = x < 0.f ? 3.14159274f - r : r;
+  return y < 0.f ? -r : r;
+}
 // isInRange for every tile of the launch window, one LANE per tile (TsdGridComponent.cpp:43-124: range cull,
 // four corner back-projections, the two beam-range tests as O(1) table look-ups).  Tiles that need work go
 // to the list (one atomic per wave); increaseEmptiness of a tile that was never materialised is done here
@@ -235,7 +283,7 @@ constexpr int TOT_FIELDS = 8;   // cells updated, range pass, update, new, new f
 __global__ void __launch_bounds__(64)
 k_push_classify(GridDev g, const PushArgs* __restrict__ a_dev, const char* __restrict__ rmq_buf,
                 uint32_t* __restrict__ tile_rec, const uint8_t* __restrict__ dirty, uint32_t* __restrict__ tile_totals,
-                uint32_t* __restrict__ list, uint32_t* __restrict__ list_win, double* __restrict__ list_pw,
+                uint32_t* __restrict__ list, PushListAux* __restrict__ list_aux,
                 unsigned int* __restrict__ list_cnt /* [2] */, int parity, int tx0, int ty0, int ntx, int nty)
 {
   // FOUR lanes per tile, one corner each: the four back-projections (an fp64 atan2 apiece, by far the longest chain of this
@@ -251,6 +299,7 @@ k_push_classify(GridDev g, const PushArgs* __restrict__ a_dev, const char* __res
   const int p = in_window ? (ty0 + t / ntx) * g.PX + tx0 + t % ntx : 0;
   uint32_t rec = 0u, kind = 0u, far_flag = 0u;
   double pw = 0.0;
+  double tcx = 0.0, tcy = 0.0;                               // the tile's centroid (UPDATE tiles)
   uint32_t win = (uint32_t)(a.beams - 1) << 16;              // beams the cells of the tile can project to: lo | hi << 16
   if (in_window && a.enabled) {
     double e[4][2], cx, cy, rad;
@@ -318,6 +367,7 @@ k_push_classify(GridDev g, const PushArgs* __restrict__ a_dev, const char* __res
         if (dc > a.max_range) dc = a.max_range;
         pw = (a.max_range - dc) / a.max_range;
         pw *= pw;
+        tcx = cx; tcy = cy;
       }
       else if (action == 1) {
         // TsdGridPartition::increaseEmptiness (TsdGridPartition.cpp:136-164), isInRange then returns false
@@ -344,168 +394,256 @@ k_push_classify(GridDev g, const PushArgs* __restrict__ a_dev, const char* __res
     if (kind != 0u) {
       const unsigned int slot = base + __popcll(listed & ((1ull << lane) - 1ull));
       list[slot] = (uint32_t)p | far_flag | (kind << KIND_SHIFT);
-      list_win[slot] = win;
-      list_pw[slot] = pw;
+      PushListAux x;
+      x.win = win; x.pad = 0u; x.pw = pw;
+      // the linear forms of k_push_update's phase A (see PushListAux): fp64 here, once per tile, instead of fp32 in every lane there
+      const double lcx = a.Pi[0] * tcx + a.Pi[1] * tcy + a.Pi[2], lcy = a.Pi[3] * tcx + a.Pi[4] * tcy + a.Pi[5];
+      const double axx = a.Pi[0] * g.cs, axy = a.Pi[1] * g.cs, ayx = a.Pi[3] * g.cs, ayy = a.Pi[4] * g.cs;
+      x.A = (float)(lcx * ayx - lcy * axx); x.B = (float)(lcx * ayy - lcy * axy);
+      x.C = (float)(lcx * axx + lcy * ayx); x.D = (float)(lcx * axy + lcy * ayy);
+      x.lc2 = (float)(lcx * lcx + lcy * lcy);
+      x.lcx = (float)lcx; x.lcy = (float)lcy;
+      x.th_c = atan2_estimate(x.lcy, x.lcx);
+      list_aux[slot] = x;
     }
   }
 }
 
-// ---- beam index of a cell without the fp64 atan2 ------------------------------------------------------------
-// SensorPolar2D::backProject (SensorPolar2D.cpp:117-135) decides round((atan2(ly, lx) - phi_min) / res) and the two
-// bound checks from fp64 values.  The kernel ESTIMATES the beam coordinate u = (angle - phi_min) / res in fp32:
-//   far tiles (sensor further than 3 circumradii from the tile centre -- all but a handful): the cell's angle is the
-//       tile centre's plus a small delta, |delta| < 0.34 rad, and delta = atan(cross / dot) by a four-term series;
-//       ~17 fp32 instructions
-//   near tiles: a six-term minimax arctangent over the full circle; ~30
-// Every source of error (fp32 coordinates relative to the tile centre, v_rcp_f32, the series truncation t^9 / 9, the
-// fp32 product with 1 / res at u <= 4096) stays below 4e-3 beams by the error budget, so an estimate further than 0.02
-// beams from a rounding boundary (j +- 0.5), from the ends of the field of view and from the +-pi cut of atan2 names the
-// reference's beam with a margin of 5x.  Checked on the device: the -DTSD_PUSH_VERIFY_INDEX build compares every decided
-// cell with the exact formulation inside the kernel -- 749 M cells over the BASELINE scenes, none decided wrongly
-// (tools/push_verify_index.sh, profiles/r2_push_index_estimate_verified.txt).  The other cells (4-5 %) are not decided by the estimate at all: they go to
-// a queue in LDS and get the exact fp64 formulation, densely (one lane per queued cell), instead of dragging their
-// whole wave through it.
-constexpr int IDX_UNSURE = INT_MIN;
-constexpr float IDX_MARGIN = 0.02f;
-__device__ __forceinline__ float atan2_estimate(float y, float x)      // |error| < 2e-6 rad
-{
-  const float ax = fabsf(x), ay = fabsf(y);
-  const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
-  const float t = mn * __builtin_amdgcn_rcpf(mx);
-  const float t2 = t * t;
-  // minimax odd polynomial of atan on [0, 1] (Abramowitz-Stegun 4.4.49 class, 6 terms)
-  float r = -0.0117212f;
-  r = fmaf(r, t2, 0.05265332f);
-  r = fmaf(r, t2, -0.11643287f);
-  r = fmaf(r, t2, 0.19354346f);
-  r = fmaf(r, t2, -0.33262347f);
-  r = fmaf(r, t2, 0.99997726f);
-  r *= t;
-  r = ay > ax ? 1.57079637f - r : r;
-  r = x < 0.f ? 3.14159274f - r : r;
-  return y < 0.f ? -r : r;
-}
-// beam index from the estimated angle `th` (radians, possibly outside (-pi, pi] by the small delta)
+// Classification of one cell by its estimated angle `th` (radians, possibly outside (-pi, pi] by the small delta).  The beam
+// coordinate u = (angle - phi_min) / res is shifted by one half, v = u + 0.5, so that the rounding boundaries of
+// round() -- and the two ends of the field of view, phi_lower = phi_min - res / 2 and phi_upper = phi_min + (beams - 0.5) res --
+// all sit at INTEGER v: boundary jb (0 .. beams) is the direction beta_jb = phi_min + (jb - 0.5) res.
+//   returns  >= 0       the beam, decided (v further than IDX_MARGIN from every boundary)
+//            -1         outside the field of view, decided
+//            IDX_UNSURE within IDX_MARGIN of boundary `jb` (0 .. beams), or -- jb = IDX_CUT -- at the +-pi cut of atan2
 // interior (wave-uniform, LIST_INTERIOR): the tile lies inside the field of view by a beam and away from the cut, the angle is
-// continuous over it -- only the distance to a rounding boundary is left to test
-__device__ __forceinline__ int index_from_angle(float th, float phi_min_f, float inv_res_f, int beams, bool interior = false)
+// continuous over it -- only the distance to a rounding boundary is left to test.
+constexpr int IDX_CUT = 0x1FFF;
+__device__ __forceinline__ int classify_angle(float th, float phi_min_f, float inv_res_f, int beams, bool interior, int& jb)
 {
   const float PI_F = 3.14159274f;
+  jb = IDX_CUT;
   if (!interior) {
     if (th > PI_F) th -= 2.0f * PI_F;                        // the reference's atan2 lives in (-pi, pi]
     else if (th <= -PI_F) th += 2.0f * PI_F;
     if (fabsf(th) > PI_F - 1e-3f) return IDX_UNSURE;         // at the cut the two branches are 2 pi apart: exact path
   }
-  const float u = (th - phi_min_f) * inv_res_f;            // beam coordinate
+  const float v = fmaf(th - phi_min_f, inv_res_f, 0.5f);    // beam coordinate + 1/2
   if (!interior) {
-    if (u < -0.5f - IDX_MARGIN || u > (float)beams - 0.5f + IDX_MARGIN) return -1;     // outside the field of view for sure
-    if (!(u > -0.5f + IDX_MARGIN && u < (float)beams - 0.5f - IDX_MARGIN)) return IDX_UNSURE;
+    const float vb = (float)beams;
+    if (v < -IDX_MARGIN || v > vb + IDX_MARGIN) return -1;     // outside the field of view for sure
+    // whatever is not STRICTLY inside by the margin belongs to the end's boundary (0 / beams): a decided beam is always 0 .. beams - 1
+    if (!(v > IDX_MARGIN && v < vb - IDX_MARGIN)) { jb = v < 1.0f ? 0 : beams; return IDX_UNSURE; }
   }
-  const float j = rintf(u);
-  if (fabsf(u - j) > 0.5f - IDX_MARGIN) return IDX_UNSURE;
-  return (int)j;
+  const float jf = rintf(v);
+  jb = (int)jf;
+  if (!(fabsf(v - jf) >= IDX_MARGIN)) return IDX_UNSURE;     // (also a NaN: never a decided beam)
+  return (int)floorf(v);
 }
 
+// SensorPolar2D::backProject itself (fp64 atan2, bound checks, round) for the cells nothing cheaper can decide: OUT OF LINE on
+// purpose.  Inlined, the atan2 expansion's ~40 extra live registers would be part of k_push_update's allocation (64 VGPRs = 8
+// waves per SIMD) although the path runs for a handful of cells per push; as a call the caller's registers are saved around it
+// only when it is taken.  The arguments are re-read from memory for the same reason.
+__device__ __noinline__ int backproject_cold(const PushArgs* __restrict__ a_dev, double x, double y)
+{
+  const PushArgs a = *a_dev;
+  return backproject(a.Pi, x, y, a.phi_min, a.ang_res_inv, a.phi_lower, a.phi_upper);
+}
 
-// One workgroup per listed tile (TsdGrid.cpp:237-274): scan window staged in LDS, 4 cells per thread, row-major =>
-// coalesced 8-byte RMW; lazy TsdGridPartition::init (TsdGridPartition.cpp:88-134) folded in (a fresh tile's
-// old value is known, so it is written once, halo included).  KIND_EMPTY: increaseEmptiness over the 33x33
-// cells.  The workgroup leaves the tile's record and adds it to the tile's running totals.
-//
-// Instruction diet (the kernel is issue bound once the pushes are large: cfg3 / comb visits 10 M cells):
-//   pass A  beam index of every cell from the fp32 estimate above; undecided cells queue up in LDS
-//   drain   the queued cells, one lane each: the exact fp64 atan2 formulation
-//   pass B  mask / range of the beam from LDS; an fp32 test throws out the cells that lie behind the surface by more
-//           than the truncation for sure (|l|^2 against (range + maxTruncation)^2 with a 1e-5 margin, fp32 being good
-//           to 6e-7 here) -- a wave whose cells are all such skips the exact distance altogether -- then the exact
-//           IEEE distance / signed distance for the rest, the reads of the cells addTsd will touch, addTsd, the writes.
+// fp32 limit of the squared sensor distance up to which a cell of beam (r, mask) can be touched by addTsd: the cells that lie
+// behind the surface by more than the truncation FOR SURE are beyond it (|l|^2 against (range + maxTruncation)^2 with a 1e-5
+// margin, fp32 being good to 6e-7 here); an infinite reading updates up to lowReflectivityRange; a masked beam never (-1).
+__device__ __forceinline__ float beam_limit(double r, unsigned mk, float mtf, float low2f)
+{
+  if (mk == 0u) return -1.0f;
+  if (isinf(r)) return low2f;
+  const float rf = (float)r + mtf;
+  return rf * rf * 1.00001f;
+}
+
+// One workgroup per listed tile (TsdGrid.cpp:237-274), up to EIGHT workgroups per compute unit.  Round-3 structure: the phases of a
+// tile talk to each other through LDS and keep next to nothing in registers across their boundaries, so that the kernel fits 64
+// VGPRs (8 waves per SIMD; the round-2 kernel needed 128 and was bound by instruction issue at 4 waves per SIMD with ~175
+// instructions per visited cell, 52 % of which were not updated):
+//   staging  once per workgroup: the scan's ranges (fp64) and a per-beam fp32 distance limit (beam_limit) in LDS
+//   phase A  fp32 only, 4 cells per thread: beam coordinate from the estimate above, classification, and for decided cells the
+//            candidate test -- one LDS read and one compare against the beam's limit.  Candidates are COMPACTED into an LDS list
+//            (cell | beam << 10), one LDS atomic per wave; cells within IDX_MARGIN of a boundary go to a wave-local list
+//   fix-up   (same wave, no barrier) the undecided cells, densely, one lane each: the side of the boundary direction beta_jb the
+//            cell's fp64 sensor-frame vector lies on -- the sign of |l| sin(angle - beta) = bx ly - by lx, good to 1e-16 where
+//            the reference's own rounding chain is good to 1e-15 -- names the reference's beam unless |sin| < 1e-11; those cells,
+//            and cells at the +-pi cut, take the reference's formulation itself (fp64 atan2), a cold path
+//   phase C  the exact part over the COMPACTED candidates, full waves, one cell per lane and pass: tsd / weight reads, the IEEE
+//            distance, signed distance, addTsd (TsdGridPartition.h:170-212), the writes
+// Lazy TsdGridPartition::init (TsdGridPartition.cpp:88-134) is folded in (a fresh tile's old value is known: non-candidates get
+// the init value from phase A / the fix-up, candidates start from it in phase C); KIND_EMPTY: increaseEmptiness over the 33x33
+// cells.  The workgroup leaves the tile's record and adds it to the tile's running totals (no-return atomics).
 #ifndef TSD_UPDATE_WPS
-#define TSD_UPDATE_WPS 4
+#define TSD_UPDATE_WPS 6
 #endif
-#ifndef TSD_UPDATE_BATCH
-#define TSD_UPDATE_BATCH 2
+#ifndef TSD_UPDATE_CB
+#define TSD_UPDATE_CB 1
 #endif
-__global__ void __launch_bounds__(UPDATE_BLOCK, TSD_UPDATE_WPS)      // 4 waves per SIMD = four workgroups per CU: the listed tiles of a usual push are resident at once
+constexpr int UPD_CAND_MAX = TILE_INTERIOR;
+__host__ __device__ inline size_t update_lds_bytes(int beams)
+{
+  const size_t bp = (size_t)((beams + 3) & ~3);
+  return bp * sizeof(double) + bp * sizeof(float) + UPD_CAND_MAX * sizeof(uint32_t) + (UPDATE_BLOCK / 64) * 256 * sizeof(uint32_t) +
+         2 * 2 * TILE_DIM * sizeof(double);
+}
+
+// Workgroup barrier that orders LDS only.  __syncthreads() also drains the wave's global-memory counter (s_waitcnt vmcnt(0)): every
+// wave would sit out the full latency of the stores it has just issued at the end of each tile.  Nothing in k_push_update hands
+// GLOBAL data from one wave to another inside the launch (a cell is read and written by one lane), so LDS order is all it needs.
+__device__ __forceinline__ void lds_barrier()
+{
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// per-tile values of phase A (wave-uniform)
+struct TileA {
+  float A, B, C, D, lc2, th_c, lcx, lcy;     // PushListAux
+  float axx, axy, ayx, ayy;                   // PoseInv's rotation * cellSize (near tiles)
+  float cs2;                                  // cellSize^2
+  float phi_min, inv_res, mt, low2;
+  int beams, wlo, whi;
+};
+
+// Beam classification + candidate test of ONE cell, offset (dxc, dyc) cells from the tile's centroid.  Returns the entry for the
+// candidate / undecided lists (cell | beam or boundary << 10) and sets the two flags.  FAR: the sensor is further than three
+// circumradii from the centroid -- the cell's angle is the centroid's plus a small delta, |delta| < 0.34 rad, tan(delta) = cross / dot
+// with both products LINEAR in the cell offset (coefficients from k_push_classify), atan by a four-term series; near tiles use the
+// six-term minimax arctangent.  INTERIOR (implies FAR): no end of the field of view, no cut -- only rounding boundaries.
+template <bool FAR, bool INTERIOR>
+__device__ __forceinline__ uint32_t classify_cell(const TileA& t, float dxc, float dyc, float pA, float pC, float qx, int c,
+                                                  const float* __restrict__ s_lim, const double* __restrict__ ranges,
+                                                  const uint8_t* __restrict__ mask, bool& cand, bool& unsure, bool& outside)
+{
+  float th_rel, d2f;          // angle relative to th_c (FAR) or the angle itself
+  if constexpr (FAR) {
+    const float cr = fmaf(dyc, t.B, pA);                        // l_c x l
+    const float dt = fmaf(dyc, t.D, pC);                        // l_c . l  (> 0: |delta| < 0.34 rad)
+    d2f = fmaf(2.0f, dt, fmaf(t.cs2 * dyc, dyc, qx));          // |l|^2 = 2 l_c.l - |l_c|^2 + cs^2 |d|^2
+    const float tt = cr * __builtin_amdgcn_rcpf(dt);
+    const float t2 = tt * tt;
+    float r = fmaf(t2, -0.142857143f, 0.2f);
+    r = fmaf(r, t2, -0.333333333f);
+    r = fmaf(r, t2, 1.0f);
+    th_rel = r * tt;
+  } else {
+    const float lxf = fmaf(t.axy, dyc, fmaf(t.axx, dxc, t.lcx)), lyf = fmaf(t.ayy, dyc, fmaf(t.ayx, dxc, t.lcy));
+    d2f = fmaf(lxf, lxf, lyf * lyf);
+    th_rel = atan2_estimate(lyf, lxf);
+  }
+  int jb, index;
+  if constexpr (INTERIOR) {
+    // v = (th_c + delta - phi_min) / res + 1/2: boundaries at integer v
+    const float vc = fmaf(t.th_c - t.phi_min, t.inv_res, 0.5f);
+    const float v = fmaf(th_rel, t.inv_res, vc);
+    const float jf = rintf(v);
+    jb = (int)jf;
+    index = !(fabsf(v - jf) >= IDX_MARGIN) ? IDX_UNSURE : (int)floorf(v);
+  } else {
+    index = classify_angle(FAR ? t.th_c + th_rel : th_rel, t.phi_min, t.inv_res, t.beams, false, jb);
+  }
+  unsure = index == IDX_UNSURE;
+  outside = !unsure && index < 0;
+  cand = false;
+  if (unsure) return (uint32_t)c | ((uint32_t)jb << 10);
+  if (outside) return 0u;
+  // the beam's limit from LDS; a beam outside the staged window -- possible only through rounding at the window's ends -- is
+  // fetched from global memory by the lanes concerned
+  const int il = min(max(index, t.wlo), t.whi);
+  float lim = s_lim[il];
+  asm volatile("" : "+v"(lim));      // (keeps the LDS read an LDS read: no pointer select)
+  if (__builtin_expect(il != index, 0)) lim = beam_limit(ranges[index], (unsigned)mask[index], t.mt, t.low2);
+  cand = !(d2f > lim);
+  return (uint32_t)c | ((uint32_t)index << 10);
+}
+
+__global__ void __launch_bounds__(UPDATE_BLOCK, TSD_UPDATE_WPS)
 k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __restrict__ ranges,
               const uint8_t* __restrict__ mask, uint32_t* __restrict__ tile_rec, uint32_t* __restrict__ tile_totals,
-              const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_win, const double* __restrict__ list_pw,
-              const unsigned int* __restrict__ list_cnt, int parity, double* __restrict__ dbg)
+              const uint32_t* __restrict__ list, const PushListAux* __restrict__ list_aux,
+              const unsigned int* __restrict__ list_cnt, int parity, const double2* __restrict__ bdir, double* __restrict__ dbg)
 {
-#ifdef TSD_PUSH_STAMPS   // diagnostic: 100 MHz wall clock at the phases of every 8th listed tile (thread 0)
-#define PSTAMP(i) do { if (threadIdx.x == 0 && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 128) dbg[(blockIdx.x >> 3) * 8 + (i)] = (double)wall_clock64(); } while (0)
+  static_assert(UPDATE_BLOCK == 256, "phase A: 4 cells per thread, 32 x 2 cells per wave and pass");
+#ifdef TSD_PUSH_STAMPS   // diagnostic build (tools/push_stamps_r3.sh): shader cycles per phase, summed over the tiles of every 8th workgroup (thread 0)
+  long long st_acc[6] = {0, 0, 0, 0, 0, 0}; long long st_t = clock64(); const long long st_w0 = wall_clock64(); int st_tiles = 0;
+#define PSTAMP(i) do { const long long now_ = clock64(); st_acc[i] += now_ - st_t; st_t = now_; } while (0)
 #else
 #define PSTAMP(i) do {} while (0)
 #endif
-  PSTAMP(0);
   // the list length, this workgroup's first entry (read speculatively) and the arguments arrive together
   const unsigned int n_list = list_cnt[parity];
   const uint32_t first = list[blockIdx.x];
-  const uint32_t first_win = list_win[blockIdx.x];
-  const double first_pw = list_pw[blockIdx.x];
+  const PushListAux first_aux = list_aux[blockIdx.x];
   const PushArgs a = *a_dev;
   if (blockIdx.x >= n_list) return;
-  PSTAMP(1);
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  unsigned int* s_upd = reinterpret_cast<unsigned int*>(smem);             // [4] cells updated per wave
-  __shared__ unsigned long long s_neg_store;
-  unsigned long long* s_neg = &s_neg_store;                               // groups of the tile that received a negative value
-  __shared__ unsigned int s_qn;                                           // cells queued for the exact beam index
-  __shared__ unsigned short s_queue[TILE_INTERIOR];
-  __shared__ short s_idx[TILE_INTERIOR];                                  // their exact index (-1 / -2: outside the field of view)
-  double* s_ranges = reinterpret_cast<double*>(smem + 16);
-  uint8_t* s_mask = reinterpret_cast<uint8_t*>(smem + 16 + (size_t)((a.beams + 1) & ~1) * sizeof(double));
-  const float phi_min_f = (float)a.phi_min, inv_res_f = (float)a.ang_res_inv;
+  const int Bp = (a.beams + 3) & ~3;
+  double* s_ranges = reinterpret_cast<double*>(smem);                      // [Bp]
+  double* s_d2 = s_ranges + Bp;                                            // [2][2][32] by tile parity: (ccx - trx)^2 per column, (ccy - try)^2 per row
+  float* s_lim = reinterpret_cast<float*>(s_d2 + 4 * TILE_DIM);            // [Bp] beam_limit of every staged beam
+  uint32_t* s_cand = reinterpret_cast<uint32_t*>(s_lim + Bp);              // [1024] candidates of the tile: cell | beam << 10
+  uint32_t* s_uns = s_cand + UPD_CAND_MAX + wave * 256;                    // [256] this wave's undecided cells: cell | jb << 10
+  __shared__ unsigned int s_cnt[2][2];                                     // by tile parity: candidates listed, cells updated
+  __shared__ unsigned long long s_neg[2];                                  // groups of the tile that received a negative value
+  const double max_trunc = g.max_trunc;
+  TileA ta;
+  ta.phi_min = (float)a.phi_min; ta.inv_res = (float)a.ang_res_inv; ta.beams = a.beams;
+  ta.mt = (float)max_trunc;
+  ta.low2 = (float)(a.low_refl * a.low_refl) * 1.00001f;
+  ta.axx = (float)(a.Pi[0] * g.cs); ta.axy = (float)(a.Pi[1] * g.cs); ta.ayx = (float)(a.Pi[3] * g.cs); ta.ayy = (float)(a.Pi[4] * g.cs);
+  ta.cs2 = (float)(g.cs * g.cs);
   // The scan is staged once per workgroup, together with the first tile's state: only the beams the tile can project
-  // to when the workgroup has a single tile (the usual case), all of them when it will loop over several.  Reads
+  // to when the workgroup has a single tile (the usual case), all of them when it will loop over several.  Beams
   // outside the staged window go to global memory.
   const int p_first = (int)(first & LIST_TILE_MASK);
   const uint8_t flag_first = g.flags[p_first];
   const double iw_first = g.init_weight[p_first];
   int wlo = 0, whi = a.beams - 1;
   if (n_list <= gridDim.x) {
-    wlo = (int)(first_win & 0xFFFFu) - 1; whi = (int)(first_win >> 16) + 1;
+    wlo = (int)(first_aux.win & 0xFFFFu) - 1; whi = (int)(first_aux.win >> 16) + 1;
     if (wlo < 0) wlo = 0;
     if (whi > a.beams - 1) whi = a.beams - 1;
   }
+  ta.wlo = wlo; ta.whi = whi;
   if (whi - wlo + 1 <= UPDATE_BLOCK) {
     // the usual tile, seen from outside: a few dozen beams, at most one element of each array per thread
     const int j = wlo + tid;
     const bool in_r = j <= whi;
     const double rj = in_r ? ranges[j] : 0.0;
-    const uint8_t mj = in_r ? mask[j] : (uint8_t)0;
-    if (in_r) { s_ranges[j] = rj; s_mask[j] = mj; }
-  } else if (a.beams <= 2048) {
-    // every read issued before the first LDS write: one memory latency for the whole staging
-    constexpr int NR = 2048 / 2 / UPDATE_BLOCK, NM = 2048 / UPDATE_BLOCK;
-    const int p0 = wlo >> 1, p1 = whi >> 1;                    // pairs of ranges
-    const double2* r2 = reinterpret_cast<const double2*>(ranges);
-    double2 rr[NR]; uint8_t mm[NM];
-#pragma unroll
-    for (int i = 0; i < NR; i++) { const int j = p0 + tid + i * UPDATE_BLOCK; rr[i] = j <= p1 ? r2[j] : make_double2(0.0, 0.0); }
-#pragma unroll
-    for (int i = 0; i < NM; i++) { const int j = wlo + tid + i * UPDATE_BLOCK; mm[i] = j <= whi ? mask[j] : (uint8_t)0; }
-    double2* s_r2 = reinterpret_cast<double2*>(s_ranges);
-#pragma unroll
-    for (int i = 0; i < NR; i++) { const int j = p0 + tid + i * UPDATE_BLOCK; if (j <= p1) s_r2[j] = rr[i]; }
-#pragma unroll
-    for (int i = 0; i < NM; i++) { const int j = wlo + tid + i * UPDATE_BLOCK; if (j <= whi) s_mask[j] = mm[i]; }
+    const unsigned mj = in_r ? (unsigned)mask[j] : 0u;
+    if (in_r) { s_ranges[j] = rj; s_lim[j] = beam_limit(rj, mj, ta.mt, ta.low2); }
   } else {
-    for (int i = tid; i < a.beams; i += UPDATE_BLOCK) { s_ranges[i] = ranges[i]; s_mask[i] = mask[i]; }
+    // every read of a round issued before its first LDS write (4 x 256 beams per round)
+    for (int j0 = wlo; j0 <= whi; j0 += 4 * UPDATE_BLOCK) {
+      double rr[4]; unsigned mm[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) { const int j = j0 + tid + i * UPDATE_BLOCK; const bool in_r = j <= whi; rr[i] = in_r ? ranges[j] : 0.0; mm[i] = in_r ? (unsigned)mask[j] : 0u; }
+#pragma unroll
+      for (int i = 0; i < 4; i++) { const int j = j0 + tid + i * UPDATE_BLOCK; if (j <= whi) { s_ranges[j] = rr[i]; s_lim[j] = beam_limit(rr[i], mm[i], ta.mt, ta.low2); } }
+    }
   }
+  if (tid < 2) { s_cnt[tid][0] = 0u; s_cnt[tid][1] = 0u; s_neg[tid] = 0ull; }
 
-  // Software pipeline over the workgroup's tiles (a large push gives every workgroup a dozen): the list entry of the
-  // NEXT tile is requested at the top of an iteration and its tile state after pass A, so an iteration's only
+  // Software pipeline over the workgroup's tiles (a large push gives every workgroup several): the list entry of the
+  // NEXT tile is requested at the top of an iteration and its tile state after phase A, so an iteration's only
   // dependent trip to memory is the read of the cells it updates.
-  uint32_t nx_entry = first; double nx_pw = first_pw; uint8_t nx_flag = flag_first; double nx_iw = iw_first;
+  uint32_t nx_entry = first; PushListAux nx_aux = first_aux; uint8_t nx_flag = flag_first; double nx_iw = iw_first;
+  unsigned int tp = 0u;                                                   // parity of the UPDATE tiles of this workgroup (counters)
+  bool synced = false;
   for (unsigned int li = blockIdx.x; li < n_list; li += gridDim.x) {
     const uint32_t entry = nx_entry;
-    const double pw = nx_pw;
+    const PushListAux aux = nx_aux;
     const bool initialised = nx_flag != 0;
     const double iw = nx_iw;
     const unsigned int li_n = li + gridDim.x;
     const bool has_next = li_n < n_list;
-    if (has_next) { nx_entry = list[li_n]; nx_pw = list_pw[li_n]; }
+    if (has_next) { nx_entry = list[li_n]; nx_aux = list_aux[li_n]; }
     const uint32_t kind = entry >> KIND_SHIFT;
     const int p = (int)(entry & LIST_TILE_MASK);
     if (kind == KIND_HALO) {
@@ -532,224 +670,231 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
     }
 
     // ---- UPDATE ----
-    if (tid == 0) { *s_neg = 0ull; s_qn = 0u; }
-    __syncthreads();               // scan staged; s_upd / queue of a previous tile consumed
-    PSTAMP(2);
-
+    // (one barrier before the workgroup's first tile: scan staged, counters zeroed.  Later tiles need none here: the candidate list
+    // was consumed before the previous tile's closing barrier, and the counters / distance tables alternate by tile parity -- a
+    // parity's counters are zeroed by thread 0 behind the closing barrier of the tile that used them, one whole tile before their
+    // next use.)
+    if (!synced) { lds_barrier(); synced = true; }
+    PSTAMP(0);            // staging / list / previous tile's record
     const bool fresh = !initialised;
     rec |= REC_UPDATE | REC_LISTED;
     if (fresh) rec |= REC_NEW | (iw > 0.0 ? REC_NEW_FROM_EMPTY : 0u);
     // TsdGridPartition::init values (TsdGridPartition.cpp:98-120)
     const double t_init = (iw > 0.0) ? 1.0 : __builtin_nan("");
     const double w_init = iw;
-    const double max_trunc = g.max_trunc;
-    const double inv_max_trunc = 1.0 / max_trunc;
-    const double eps = -g.cs / 2.0;
-    // (partition weight `pw`, TsdGrid.cpp:239-243: evaluated once per tile by k_push_classify)
-
     const unsigned x0 = (unsigned)(p % g.PX) * TILE_DIM, y0 = (unsigned)(p / g.PX) * TILE_DIM;
-    unsigned int n_upd = 0;
-    constexpr int CPT = (TILE_DIM * TILE_DIM) / UPDATE_BLOCK;
-    int bidx[CPT]; float d2f[CPT];
-    // Cell k of this thread: (ix, iy0 + 8 k).  A wave covers a 32 x 2 strip of cells per k: two 256-byte rows per
-    // access.  (Measured alternative, -DTSD_UPDATE_BLOCKS: 16 x 4 blocks -- four 128-byte segments per access -- so that
-    // fewer waves straddle the edge of the region addTsd touches: 25 % SLOWER at cfg3 / comb, 111 vs 89 us; the access
-    // shape outweighs the divergence.)
-#ifndef TSD_UPDATE_BLOCKS
-    const unsigned ix = (unsigned)tid & 31u, iy0 = (unsigned)tid >> 5;
-#else
-    const unsigned ix = (((unsigned)tid >> 6) & 1u) * 16u + ((unsigned)tid & 15u);
-    const unsigned iy0 = ((unsigned)tid >> 7) * 4u + (((unsigned)tid >> 4) & 3u);
-#endif
-    const int c0 = (int)(iy0 * 32u + ix);                                  // offset of cell k: c0 + 256 k
+    unsigned int* cnt = s_cnt[tp];
+    double* d2x = s_d2 + tp * 2 * TILE_DIM;                        // [32] columns, then [32] rows
+    // the two squares of the exact cell distance depend on the column / the row only: one lane each, once per tile
+    if (tid < 2 * TILE_DIM) {
+      const bool col = tid < TILE_DIM;
+      const unsigned i = (unsigned)tid & 31u;
+      const double cc = ((double)((col ? x0 : y0) + i) + 0.5) * g.cs;       // TsdGridPartition.cpp:127-128
+      const double dw = cc - (col ? a.trx : a.try_);
+      d2x[tid] = dw * dw;
+    }
 
-    // ---- pass A: beam index of every cell from the fp32 estimate (sensor frame relative to the tile centre)
+    // ---- phase A: every cell's beam from the fp32 estimate, candidate test, compaction.
+    // Cell k of this thread: (ix, iy0 + 8 k); a wave covers a 32 x 2 strip of cells per k.
     {
-      // tile centre = corner of the four middle cells; l_c = PoseInv * (centre, 1) in fp64 once, the cells relative
-      // to it in fp32: l = l_c + (PoseInv's rotation * cellSize) * (cell offset in cells), exact small offsets
-      const double ccx_c = (double)(x0 + 16u) * g.cs, ccy_c = (double)(y0 + 16u) * g.cs;
-      const double lcx = a.Pi[0] * ccx_c + a.Pi[1] * ccy_c + a.Pi[2], lcy = a.Pi[3] * ccx_c + a.Pi[4] * ccy_c + a.Pi[5];
-      const float lcxf = (float)lcx, lcyf = (float)lcy;
-      const float axx = (float)(a.Pi[0] * g.cs), axy = (float)(a.Pi[1] * g.cs), ayx = (float)(a.Pi[3] * g.cs), ayy = (float)(a.Pi[4] * g.cs);
+      const unsigned ix = (unsigned)tid & 31u, iy0 = (unsigned)tid >> 5;
+      const int c0 = (int)(iy0 * 32u + ix);                                  // offset of cell k: c0 + 256 k
+      ta.A = aux.A; ta.B = aux.B; ta.C = aux.C; ta.D = aux.D; ta.lc2 = aux.lc2; ta.th_c = aux.th_c; ta.lcx = aux.lcx; ta.lcy = aux.lcy;
       const bool far = (entry & LIST_FAR) != 0u;
       const bool interior = (entry & LIST_INTERIOR) != 0u;
-      const float th_c = atan2_estimate(lcyf, lcxf);
-      const float dxc = (float)ix - 15.5f;
-      const float bx = fmaf(axx, dxc, lcxf), by = fmaf(ayx, dxc, lcyf);
+      const float dxc = (float)ix - 16.0f;
+      const float pA = dxc * ta.A, pC = fmaf(dxc, ta.C, ta.lc2), qx = fmaf(ta.cs2 * dxc, dxc, -ta.lc2);
+      constexpr int CPT = TILE_INTERIOR / UPDATE_BLOCK;
+      uint32_t ent[CPT];                 // list entry of cell k: candidate (bit k of `cm`) or undecided (bit k of `um`)
+      unsigned cm = 0u, um = 0u;
 #pragma unroll
       for (int k = 0; k < CPT; k++) {
-        const float dyc = (float)(iy0 + 8u * (unsigned)k) - 15.5f;
-        const float lxf = fmaf(axy, dyc, bx), lyf = fmaf(ayy, dyc, by);
-        d2f[k] = fmaf(lxf, lxf, lyf * lyf);
-        float th;
-        if (far) {
-          // angle relative to the tile centre: tan(delta) = cross / dot, |delta| < 0.34 rad; atan by its series
-          const float cr = lcxf * lyf - lcyf * lxf, dt = fmaf(lcxf, lxf, lcyf * lyf);
-          const float t = cr * __builtin_amdgcn_rcpf(dt);
-          const float t2 = t * t;
-          float r = fmaf(t2, -0.142857143f, 0.2f);
-          r = fmaf(r, t2, -0.333333333f);
-          r = fmaf(r, t2, 1.0f);
-          th = fmaf(r, t, th_c);
-        } else {
-          th = atan2_estimate(lyf, lxf);
-        }
-        bidx[k] = index_from_angle(th, phi_min_f, inv_res_f, a.beams, interior);
-      }
+        const int c = c0 + UPDATE_BLOCK * k;
+        const float dyc = (float)(iy0 + 8u * (unsigned)k) - 16.0f;
+        bool cand, unsure, outside;
+        if (interior) ent[k] = classify_cell<true, true>(ta, dxc, dyc, pA, pC, qx, c, s_lim, ranges, mask, cand, unsure, outside);
+        else if (far) ent[k] = classify_cell<true, false>(ta, dxc, dyc, pA, pC, qx, c, s_lim, ranges, mask, cand, unsure, outside);
+        else          ent[k] = classify_cell<false, false>(ta, dxc, dyc, pA, pC, qx, c, s_lim, ranges, mask, cand, unsure, outside);
+        if (cand) cm |= 1u << k;
+        if (unsure) um |= 1u << k;
+        // a freshly materialised tile: cells that addTsd will not touch get the init value here
+        if (fresh && !cand && !unsure) { st_tsd(T + c, t_init); st_w(W + c, w_init); }
 #ifdef TSD_PUSH_VERIFY_INDEX   // diagnostic build: every decided cell against the exact formulation
-#pragma unroll
-      for (int k = 0; k < CPT; k++) {
-        const double ccx = ((double)(x0 + ix) + 0.5) * g.cs, ccy = ((double)(y0 + iy0 + 8u * (unsigned)k) + 0.5) * g.cs;
-        const int ex = backproject(a.Pi, ccx, ccy, a.phi_min, a.ang_res_inv, a.phi_lower, a.phi_upper);
-        if (bidx[k] != IDX_UNSURE && (bidx[k] < 0 ? ex >= 0 : ex != bidx[k])) atomicAdd(reinterpret_cast<unsigned long long*>(dbg + 1000), 1ull);
-        if (bidx[k] == IDX_UNSURE) atomicAdd(reinterpret_cast<unsigned long long*>(dbg + 1001), 1ull);
-        atomicAdd(reinterpret_cast<unsigned long long*>(dbg + 1002), 1ull);
-      }
+        {
+          const double ccx = ((double)(x0 + ix) + 0.5) * g.cs, ccy = ((double)(y0 + iy0 + 8u * (unsigned)k) + 0.5) * g.cs;
+          const int ex = backproject(a.Pi, ccx, ccy, a.phi_min, a.ang_res_inv, a.phi_lower, a.phi_upper);
+          const int index = outside ? -1 : (int)(ent[k] >> 10);
+          if (!unsure && (index < 0 ? ex >= 0 : ex != index)) {
+            atomicAdd(reinterpret_cast<unsigned long long*>(dbg + 1000), 1ull);
+            const unsigned long long slot = atomicAdd(reinterpret_cast<unsigned long long*>(dbg + 1005), 1ull);
+            if (slot < 40) { double* o = dbg + 1010 + slot * 8; o[0] = p; o[1] = c; o[2] = index; o[3] = ex; o[4] = (double)(entry >> 26); o[5] = ta.th_c; o[6] = a.trx; o[7] = a.try_; }
+          }
+          if (unsure) atomicAdd(reinterpret_cast<unsigned long long*>(dbg + 1001), 1ull);
+          atomicAdd(reinterpret_cast<unsigned long long*>(dbg + 1002), 1ull);
+        }
 #endif
-      // undecided cells -> queue (one LDS atomic per wave and k)
+      }
+      // compaction: one LDS atomic per wave for its candidates of all four strips; the undecided cells into the wave's own list
+      const unsigned long long lt = (1ull << lane) - 1ull;
+      unsigned nc = 0u, nu = 0u;
+#pragma unroll
+      for (int k = 0; k < CPT; k++) { nc += (unsigned)__popcll(__ballot((cm >> k) & 1u)); nu += (unsigned)__popcll(__ballot((um >> k) & 1u)); }
+      unsigned base = 0u;
+      if (nc) { if (lane == 0) base = atomicAdd(&cnt[0], nc); base = (unsigned)__builtin_amdgcn_readfirstlane((int)base); }
+      unsigned ub = 0u;
 #pragma unroll
       for (int k = 0; k < CPT; k++) {
-        const bool un = bidx[k] == IDX_UNSURE;
-        const unsigned long long m = __ballot(un);
-        if (m) {
-          unsigned int base = 0;
-          if (lane == 0) base = atomicAdd(&s_qn, (unsigned int)__popcll(m));
-          base = __shfl(base, 0, 64);
-          if (un) s_queue[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(c0 + UPDATE_BLOCK * k);
+        const unsigned long long bc = __ballot((cm >> k) & 1u), bu = __ballot((um >> k) & 1u);
+        if ((cm >> k) & 1u) s_cand[base + (unsigned)__popcll(bc & lt)] = ent[k];
+        if ((um >> k) & 1u) s_uns[ub + (unsigned)__popcll(bu & lt)] = ent[k];
+        base += (unsigned)__popcll(bc); ub += (unsigned)__popcll(bu);
+      }
+      // ---- fix-up of the wave's undecided cells, one lane each (LDS executes a wave's accesses in order: no barrier)
+      for (unsigned q0 = 0u; q0 < nu; q0 += 64u) {
+        const unsigned q = q0 + (unsigned)lane;
+        const bool on = q < nu;
+        const uint32_t e = on ? s_uns[q] : 0u;
+        const int c = (int)(e & 1023u);
+        const int jbq = (int)(e >> 10);
+        const double ccx = ((double)(x0 + ((unsigned)c & 31u)) + 0.5) * g.cs;   // TsdGridPartition.cpp:127-128
+        const double ccy = ((double)(y0 + ((unsigned)c >> 5)) + 0.5) * g.cs;
+        // PoseInv * (x, y, 1)^T as SensorPolar2D::backProject forms it (dgemm order)
+        double lx = 0.0, ly = 0.0;
+        lx += a.Pi[0] * ccx; lx += a.Pi[1] * ccy; lx += a.Pi[2] * 1.0;
+        ly += a.Pi[3] * ccx; ly += a.Pi[4] * ccy; ly += a.Pi[5] * 1.0;
+        int index = -1;
+        bool hard = on && jbq == IDX_CUT;
+        const double l2 = lx * lx + ly * ly;
+        if (on && !hard) {
+          const double2 bd = bdir[jbq];
+          const double cr = bd.x * ly - bd.y * lx;                  // |l| sin(angle - beta_jb)
+          if (cr * cr > 1e-22 * l2) {
+            // beyond the boundary (phi > beta): beam jb, or past phi_upper (-1); before it: beam jb - 1, or before phi_lower (-2 -> negative)
+            index = cr > 0.0 ? (jbq < a.beams ? jbq : -1) : jbq - 1;
+          } else hard = true;
+        }
+        if (__builtin_expect(__any(hard), 0)) {
+          // within 1e-11 rad of a boundary, or at the cut: the reference's own formulation decides (fp64 atan2, bound checks, round)
+#ifndef TSD_EXP_NO_HARD
+          if (hard) index = backproject_cold(a_dev, ccx, ccy);
+#endif
+        }
+#ifdef TSD_PUSH_VERIFY_INDEX
+        if (on) {
+          const int ex = backproject(a.Pi, ccx, ccy, a.phi_min, a.ang_res_inv, a.phi_lower, a.phi_upper);
+          if (index < 0 ? ex >= 0 : ex != index) atomicAdd(reinterpret_cast<unsigned long long*>(dbg + 1003), 1ull);
+          if (hard) atomicAdd(reinterpret_cast<unsigned long long*>(dbg + 1004), 1ull);
+        }
+#endif
+        bool cand = false;
+        if (on && index >= 0) {
+          const int il = min(max(index, wlo), whi);
+          float lim = s_lim[il];
+          asm volatile("" : "+v"(lim));
+          if (__builtin_expect(il != index, 0)) lim = beam_limit(ranges[index], (unsigned)mask[index], ta.mt, ta.low2);
+          cand = !((float)l2 > lim * 1.00001f);         // (|l|^2 from the fp64 vector here: within 1e-7 of phase A's fp32 form; the margin covers it)
+        }
+        if (fresh && on && !cand) { st_tsd(T + c, t_init); st_w(W + c, w_init); }
+        const unsigned long long bq = __ballot(cand);
+        if (bq) {
+          unsigned b2 = 0u;
+          if (lane == 0) b2 = atomicAdd(&cnt[0], (unsigned)__popcll(bq));
+          b2 = (unsigned)__builtin_amdgcn_readfirstlane((int)b2);
+          if (cand) s_cand[b2 + (unsigned)__popcll(bq & lt)] = (uint32_t)c | ((uint32_t)index << 10);
         }
       }
     }
     if (has_next) { const int pn = (int)(nx_entry & LIST_TILE_MASK); nx_flag = g.flags[pn]; nx_iw = g.init_weight[pn]; }   // (next tile's state: in flight during the rest)
-    __syncthreads();
-    // ---- drain: the exact formulation (SensorPolar2D::backProject: fp64 atan2, bound checks, round) for the queued cells
-    {
-      const unsigned int nq = s_qn;
-      for (unsigned int q = (unsigned)tid; q < nq; q += UPDATE_BLOCK) {
-        const unsigned c = s_queue[q];
-        const double ccx = ((double)(x0 + (c & 31u)) + 0.5) * g.cs;   // TsdGridPartition.cpp:127-128
-        const double ccy = ((double)(y0 + (c >> 5)) + 0.5) * g.cs;
-        s_idx[c] = (short)backproject(a.Pi, ccx, ccy, a.phi_min, a.ang_res_inv, a.phi_lower, a.phi_upper);
-      }
-    }
-    __syncthreads();
-    PSTAMP(3);
+    PSTAMP(1);            // phase A + fix-up
+    lds_barrier();
+    PSTAMP(2);            // wait for the other waves' phase A
 
-    // ---- pass B: signed distance and whether addTsd will touch the cell (sd >= -maxTruncation: cells behind the
-    // surface cost no HBM traffic)
-    unsigned cnd = 0u;                                           // bit k: cell k is a candidate
-    const double ccx = ((double)(x0 + ix) + 0.5) * g.cs;
-    const double dxw = ccx - a.trx, dxw2 = dxw * dxw;
-    const float low2f = (float)(a.low_refl * a.low_refl) * 1.00001f;
-    const float mtf = (float)max_trunc;
-    // (B1) candidates: valid beam, and not behind the surface by more than the truncation for sure.  (Registers are
-    // tight at four workgroups per CU -- a spilled dword costs scratch traffic per tile -- so the range is looked up
-    // again in B3 instead of being kept.)
+    // ---- phase C: the exact part over the compacted candidates (candidates = the cells addTsd touches plus a sliver at the
+    // truncation boundary), CB cells per lane and pass, their reads in flight together
+    {
+      const unsigned n_cand = cnt[0];
+      const double inv_max_trunc = 1.0 / max_trunc;
+      const double eps = -g.cs / 2.0;
+      unsigned long long wrote_neg = 0ull;
+      unsigned n_upd = 0u;
+      constexpr int CB = TSD_UPDATE_CB;
+      for (unsigned q0 = (unsigned)tid; q0 < n_cand; q0 += CB * UPDATE_BLOCK) {
+        int cc[CB], idx[CB]; bool on[CB];
+        double tv[CB], wv[CB], rr[CB], dd[CB];
 #pragma unroll
-    for (int k = 0; k < CPT; k++) {
-      const int c = c0 + UPDATE_BLOCK * k;
-      int index = bidx[k];
-      if (index == IDX_UNSURE) index = s_idx[c];
-      bidx[k] = index;
-      // mask and range of the beam from LDS, both at once (a select between an LDS and a global pointer would turn
-      // into a flat load with a full wait per cell); a beam outside the staged window -- possible only through
-      // rounding at the window's ends -- is fetched from global memory by the lanes concerned
-      const bool staged_beam = index >= wlo && index <= whi;
-      const int il = index < wlo ? wlo : (index > whi ? whi : index);
-      unsigned mk = s_mask[il];
-      double r = s_ranges[il];
-      asm volatile("" : "+v"(mk), "+v"(r));      // (keeps the two LDS reads LDS reads: no pointer select)
-      if (__builtin_expect(index >= 0 && !staged_beam, 0)) { mk = mask[index]; r = ranges[index]; }
-      bool cand = index >= 0 && mk != 0u;
-      if (cand) {
-        const float rf = (float)r + mtf;
-        const float lim2 = isinf(r) ? low2f : rf * rf * 1.00001f;
-        cand = !(d2f[k] > lim2);
-      }
-      cnd |= cand ? (1u << k) : 0u;
-    }
-    // (B2-B4) in two halves of two cells (a rolled loop: half the registers of doing all four at once, which is what keeps
-    // the kernel at four workgroups per CU without scratch spills): the candidates' reads go out -- candidates are the
-    // updated cells plus a sliver at the truncation boundary -- and are in flight during the exact distances; then
-    // addTsd and the writes
-    unsigned long long wrote_neg = 0ull;
-    constexpr int HB = TSD_UPDATE_BATCH;          // cells per batch: 2 (default) or 4
-#pragma unroll 1
-    for (int h = 0; h < CPT / HB; h++) {
-      int idx2[HB];
-      if constexpr (HB == 2) { idx2[0] = h ? bidx[2] : bidx[0]; idx2[1] = h ? bidx[3] : bidx[1]; }
-      else { for (int j = 0; j < HB; j++) idx2[j] = bidx[j]; }
-      const unsigned cn2 = cnd >> (HB * h);
-      double tv[HB], wv[HB], sdv[HB]; bool hit[HB];
+        for (int j = 0; j < CB; j++) {
+          const unsigned q = q0 + (unsigned)(j * UPDATE_BLOCK);
+          on[j] = q < n_cand;
+          const uint32_t e = s_cand[on[j] ? q : q0];
+          cc[j] = (int)(e & 1023u);
+          idx[j] = (int)(e >> 10);
+        }
 #pragma unroll
-      for (int j = 0; j < HB; j++) {
-        const int c = c0 + UPDATE_BLOCK * (HB * h + j);
-        tv[j] = t_init; wv[j] = w_init;
-        if (((cn2 >> j) & 1u) && !fresh) { tv[j] = ld_tsd(T + c); wv[j] = ld_w(W + c); }
-      }
-#pragma unroll
-      for (int j = 0; j < HB; j++) {
-        hit[j] = false; sdv[j] = 0.0;
-        if ((cn2 >> j) & 1u) {
-          const int index = idx2[j];
-          const bool staged_beam = index >= wlo && index <= whi;
-          const int il = index < wlo ? wlo : (index > whi ? whi : index);
+        for (int j = 0; j < CB; j++) {
+          tv[j] = t_init; wv[j] = w_init;
+          if (on[j] && !fresh) { tv[j] = ld_tsd(T + cc[j]); wv[j] = ld_w(W + cc[j]); }
+          const int index = idx[j];
+          const int il = min(max(index, wlo), whi);
           double r = s_ranges[il];
+          const double dx2 = d2x[cc[j] & 31], dy2 = d2x[TILE_DIM + (cc[j] >> 5)];
           asm volatile("" : "+v"(r));
-          if (__builtin_expect(!staged_beam, 0)) r = ranges[index];
-          const double ccy = ((double)(y0 + iy0 + 8u * (unsigned)(HB * h + j)) + 0.5) * g.cs;
-          const double dyw = ccy - a.try_;
-          const double dist = sqrt_normal(dxw2 + dyw * dyw);        // (ccx - trx)^2 + (ccy - try)^2, then the IEEE root
+          if (__builtin_expect(il != index, 0)) r = ranges[index];
+          rr[j] = r; dd[j] = dx2 + dy2;                              // (ccx - trx)^2 + (ccy - try)^2
+        }
+#pragma unroll
+        for (int j = 0; j < CB; j++) {
+          const int c = cc[j];
+          const double r = rr[j];
+          const double dist = sqrt_normal(dd[j]);                    // ... then the IEEE root
           double sd = 0.0; bool ok = false;
           if (!isinf(r)) { sd = r - dist; ok = true; }
           else if (dist < a.low_refl) { sd = max_trunc; ok = true; }
-          hit[j] = ok && sd >= -max_trunc;
-          sdv[j] = sd;
+          bool touched = false;
+          if (on[j] && ok && sd >= -max_trunc) touched = add_tsd(tv[j], wv[j], sd, aux.pw, max_trunc, inv_max_trunc, eps);
+          if (touched) n_upd++;
+          if (touched && tv[j] < 0.0) wrote_neg |= neg_bit((unsigned)c & 31u, (unsigned)c >> 5);
+          if (on[j] && (touched || fresh)) { st_tsd(T + c, tv[j]); st_w(W + c, wv[j]); }
         }
       }
-#pragma unroll
-      for (int j = 0; j < HB; j++) {
-        const int c = c0 + UPDATE_BLOCK * (HB * h + j);
-        bool touched = false;
-        if (hit[j]) touched = add_tsd(tv[j], wv[j], sdv[j], pw, max_trunc, inv_max_trunc, eps);
-        if (touched) n_upd++;
-        if (touched && tv[j] < 0.0) wrote_neg |= neg_bit((unsigned)c & 31u, (unsigned)c >> 5);
-        if (touched || fresh) { st_tsd(T + c, tv[j]); st_w(W + c, wv[j]); }
-      }
+      if (wrote_neg) atomicOr(&s_neg[tp], wrote_neg);                 // (LDS; folded into the tile's mask below)
+      const unsigned wu = (unsigned)wave_sum_i((int)n_upd);
+      if (lane == 0 && wu) atomicAdd(&cnt[1], wu);
     }
-    PSTAMP(4);
-    if (wrote_neg) atomicOr(s_neg, wrote_neg);                      // (LDS; folded into the tile's mask below)
     if (fresh) {
       // halo cells of a freshly materialised tile keep the init value until k_push_halo
       for (int h = tid; h < 2 * TILE_DIM + 1; h += UPDATE_BLOCK) {      // the halo strip: column 32, then row 32
         st_tsd(T + HALO_COL + h, t_init); st_w(W + HALO_COL + h, w_init);
       }
     }
-    PSTAMP(5);
-    const unsigned wu = (unsigned)wave_sum_i((int)n_upd);
-    if (lane == 0) s_upd[tid >> 6] = wu;
-    __syncthreads();               // every thread is done with the cells (and has read `initialised`)
-    PSTAMP(6);
+    PSTAMP(3);            // phase C
+    lds_barrier();                 // every thread is done with the candidate list (and has read `initialised`)
+    PSTAMP(4);            // wait for the other waves' phase C
     if (tid == 0) {
-      unsigned cells = 0;
-      for (int w = 0; w < UPDATE_BLOCK / 64; w++) cells += s_upd[w];
+      const unsigned cells = cnt[1];
+      const unsigned long long nm = s_neg[tp];
+      cnt[0] = 0u; cnt[1] = 0u; s_neg[tp] = 0ull;      // this parity is used again by the tile after the next: behind that tile's first barrier
       tile_rec[p] = rec | (cells << REC_CELLS_SHIFT);
       // The tile's running totals and mask: NO-RETURN atomics (fire and forget; every tile has its own words, so
-      // nothing contends).  As read-add-write they were four dependent trips to memory by thread 0 at the end of every
-      // tile, with the rest of the workgroup waiting for it at the next tile's first barrier.
-      const unsigned long long nm = *s_neg;
+      // nothing contends).
       uint32_t* tot = tile_totals + (size_t)p * TOT_FIELDS;
-#ifndef TSD_RMW_RECORDS
       if (nm) atomicOr(&g.negmask[p], nm);
       atomicAdd(&tot[0], cells); atomicAdd(&tot[2], 1u);
       if (fresh) { atomicAdd(&tot[3], 1u); if (iw > 0.0) atomicAdd(&tot[4], 1u); }
-#else
-      if (nm) g.negmask[p] |= nm;
-      tot[0] += cells; tot[2] += 1u;
-      if (fresh) { tot[3] += 1u; if (iw > 0.0) tot[4] += 1u; }
-#endif
       if (fresh) g.flags[p] = 1;   // publish the tile
     }
+    tp ^= 1u;
+#ifdef TSD_PUSH_STAMPS
+    st_tiles++;
+#endif
   }
+#ifdef TSD_PUSH_STAMPS
+  if (threadIdx.x == 0 && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 256) {
+    double* o = dbg + (blockIdx.x >> 3) * 8;
+    PSTAMP(5);
+    o[0] = (double)st_w0; o[1] = (double)wall_clock64(); o[2] = (double)st_tiles;
+    for (int i = 0; i < 5; i++) o[3 + i] = (double)st_acc[i];
+  }
+#endif
 }
 
 // TsdGrid::propagateBorders (TsdGrid.cpp:372-427), incremental form.
@@ -1013,6 +1158,7 @@ int launch_free_footprint(tsd_ctx* ctx, unsigned minX, unsigned maxX, unsigned m
 }
 
 size_t push_rmq_bytes(int beams) { return rmq_bytes(beams); }
+size_t push_list_aux_bytes() { return sizeof(PushListAux); }
 
 int launch_push_tables(tsd_ctx* ctx, hipStream_t stream, int beams, const double* d_ranges, const uint8_t* d_mask,
                        double phi_min, double ang_res)
@@ -1093,17 +1239,22 @@ int launch_push(tsd_ctx* ctx, const PushArgs& a, double cx, double cy, double sl
   {
     ScopedKernelTimer t(ctx, "push_classify");
     hipExtLaunchKernelGGL(k_push_classify, dim3((n_window + 15) / 16), dim3(64), 0, ctx->stream, t.a, t.b, 0, g, a_dev, rmq,
-                       ctx->d_tile_rec, ctx->d_dirty, ctx->d_tile_totals, ctx->d_list, ctx->d_list_win, ctx->d_list_pw, ctx->d_list_cnt, parity,
+                       ctx->d_tile_rec, ctx->d_dirty, ctx->d_tile_totals, ctx->d_list, reinterpret_cast<PushListAux*>(ctx->d_list_aux), ctx->d_list_cnt, parity,
                        box.x0, box.y0, ntx, nty);
   }
   TSD_HIP_CHECK(ctx, hipGetLastError());
-  const int n_groups = n_window < 2048 ? n_window : 2048;      // resident at once; a longer list is looped over
+  // as many workgroups as are RESIDENT at once (TSD_UPDATE_WPS per compute unit), never more: every workgroup loops over the
+  // list with that stride, and a second round of workgroups would start its whole share of the list when the first round is done
+  int per_cu = TSD_UPDATE_WPS;
+  { const size_t lds_wg = update_lds_bytes(a.beams) + 64; const int by_lds = (int)((160u * 1024u) / lds_wg); if (by_lds < per_cu) per_cu = by_lds < 1 ? 1 : by_lds; }
+  const int resident = ctx->n_cus * per_cu;
+  const int n_groups = n_window < resident ? n_window : resident;
   {
     ScopedKernelTimer t(ctx, "push_update");
-    const size_t lds = 16 + (size_t)((a.beams + 1) & ~1) * sizeof(double) + (size_t)((a.beams + 15) & ~15);
+    const size_t lds = update_lds_bytes(a.beams);
     hipExtLaunchKernelGGL(k_push_update, dim3(n_groups), dim3(UPDATE_BLOCK), lds, ctx->stream, t.a, t.b, 0, g, a_dev, d_ranges, d_mask,
-                       ctx->d_tile_rec, ctx->d_tile_totals, ctx->d_list, ctx->d_list_win, ctx->d_list_pw, ctx->d_list_cnt, parity,
-                       ctx->d_icp_trace);
+                       ctx->d_tile_rec, ctx->d_tile_totals, ctx->d_list, reinterpret_cast<const PushListAux*>(ctx->d_list_aux), ctx->d_list_cnt, parity,
+                       rmq_view(rmq, a.beams).bdir, ctx->d_icp_trace);
   }
   TSD_HIP_CHECK(ctx, hipGetLastError());
   {

@@ -151,6 +151,7 @@ struct KernelTimer {
 struct tsd_sensor;
 struct tsd_ctx {
   int device = 0;
+  int n_cus = 256;                           // compute units of the device (MI355X: 256): persistent grids are sized by it
   hipStream_t stream = nullptr;
   std::mutex order_mutex;                    // the ordered sections of the concurrent multi-robot path and every grid-writing entry point
   std::mutex misc_mutex;                     // timers / per-kernel attribute cache: touched by launches that run outside the caller's lock
@@ -177,8 +178,8 @@ struct tsd_ctx {
   // tile window of the push launches: what the last push covered and what freeFootprint dirtied since
   tsd::TileBox box_prev{}, box_dirty{};
   uint32_t* d_list = nullptr;               // [tiles] work list of the current push (tile | kind << 28)
-  uint32_t* d_list_win = nullptr;           // [tiles] beams a listed tile can project to (lo | hi << 16)
-  double* d_list_pw = nullptr;              // [tiles] partition weight of a listed UPDATE tile (TsdGrid.cpp:239-243)
+  char* d_list_aux = nullptr;               // [tiles] PushListAux of every list entry (push_kernels.hip): beam window, partition weight,
+                                            // the linear forms of k_push_update's beam estimate
   tsd::PushArgs* d_push_args = nullptr;     // arguments of an unfused tsd_push (the fused scan keeps them in the sensor state)
   unsigned int* d_list_cnt = nullptr;       // [2] its length, by push parity
   unsigned int push_parity = 0;
@@ -335,6 +336,7 @@ int launch_push(tsd_ctx* ctx, const PushArgs& a, double cx, double cy, double sl
 int launch_push_tables(tsd_ctx* ctx, hipStream_t stream, int beams, const double* d_ranges, const uint8_t* d_mask,
                        double phi_min, double ang_res);
 size_t push_rmq_bytes(int beams);
+size_t push_list_aux_bytes();
 int launch_free_footprint(tsd_ctx* ctx, unsigned minX, unsigned maxX, unsigned minY, unsigned maxY);
 int launch_neg_scan(tsd_ctx* ctx);
 int launch_export_tiles(tsd_ctx* ctx, int t0, int n, double* d_t, double* d_w);
