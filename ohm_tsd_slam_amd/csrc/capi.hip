@@ -359,7 +359,7 @@ tsd_ctx* tsd_create(int device, int map_size_log2, double cell_size, double max_
   A(hipMalloc(&ctx->d_list, T * sizeof(uint32_t)));
   A(hipMalloc(&ctx->d_list_aux, T * push_list_aux_bytes()));
   A(hipMalloc(&ctx->d_push_args, sizeof(PushArgs)));
-  A(hipMalloc(&ctx->d_list_cnt, 2 * sizeof(unsigned int)));
+  A(hipMalloc(&ctx->d_list_cnt, push_list_cnt_bytes()));
   A(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
   A(hipEventCreateWithFlags(&ctx->ev_tables, hipEventDisableTiming));
   ctx->stage_bytes = (size_t)TSD_MAX_BEAMS * (8 * 5 + 1) + 256;   // ranges + 2x rays(2) + mask; >= icp staging (80 KB)
@@ -381,7 +381,8 @@ tsd_ctx* tsd_create(int device, int map_size_log2, double cell_size, double max_
   A(hipMalloc(&ctx->d_start, TSD_MAX_ICP_POINTS * sizeof(int)));
   if (const char* e = std::getenv("TSD_ICP_SHAPE")) ctx->icp_shape = std::atoi(e);
   A(hipMalloc(&ctx->d_icp_res, sizeof(IcpResultDev)));
-  A(hipMalloc(&ctx->d_icp_trace, sizeof(double) * TSD_ICP_TRACE_STRIDE * TSD_ICP_TRACE_MAX));
+  A(hipMalloc(&ctx->d_icp_trace, sizeof(double) * TSD_ICP_TRACE_STRIDE * TSD_ICP_TRACE_MAX * 2));     // (second half: scratch of the diagnostic stamp builds)
+  if (ok) A(hipMemset(ctx->d_icp_trace, 0, sizeof(double) * TSD_ICP_TRACE_STRIDE * TSD_ICP_TRACE_MAX * 2));
   A(hipHostMalloc(&ctx->h_icp_res, sizeof(IcpResultDev), hipHostMallocDefault));
   ctx->h_out_bytes = (size_t)TSD_MAX_BEAMS * (8 * 4 + 1) + 256;
   A(hipHostMalloc(&ctx->h_out, ctx->h_out_bytes, hipHostMallocDefault));
@@ -466,7 +467,7 @@ int tsd_reset(tsd_ctx* ctx)
   TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_tile_totals, 0, T * 8 * sizeof(uint32_t), ctx->stream));
   TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_pushes, 0, 2 * sizeof(unsigned long long), ctx->stream));
   ctx->box_prev = TileBox{}; ctx->box_dirty = TileBox{};
-  TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_list_cnt, 0, 2 * sizeof(unsigned int), ctx->stream));
+  TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_list_cnt, 0, push_list_cnt_bytes(), ctx->stream));
   TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_occ, 0xFF, (size_t)g.N * g.N, ctx->stream));   // -1 (ThreadGrid.cpp:27-28)
   TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return TSD_OK;
@@ -784,7 +785,7 @@ int tsd_icp_trace(tsd_ctx* ctx, double* out, int max_iters)
   if (!ctx || !out || max_iters < 0) return TSD_E_ARG;
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  const int n = max_iters < TSD_ICP_TRACE_MAX ? max_iters : TSD_ICP_TRACE_MAX;
+  const int n = max_iters < 2 * TSD_ICP_TRACE_MAX ? max_iters : 2 * TSD_ICP_TRACE_MAX;     // (rows beyond TSD_ICP_TRACE_MAX: diagnostic builds' scratch)
   TSD_HIP_CHECK(ctx, hipMemcpy(out, ctx->d_icp_trace, sizeof(double) * TSD_ICP_TRACE_STRIDE * (size_t)n, hipMemcpyDeviceToHost));
   return TSD_OK;
 }

@@ -46,16 +46,18 @@ struct RmqView {
   const unsigned short* inf;        // [B + 1]
   const unsigned short* tmax;       // [levels][Bp]
   const unsigned short* tmin;
-  const double2* bdir;              // [B + 1] unit vectors of the beam boundaries phi_min + (j - 0.5) * res (fast_index)
+  const double2* bdir;              // [B + 1] unit vectors of the beam boundaries beta_j = phi_min + (j - 0.5) * res
+  const double2* rot;               // [ROT_N] (cos, sin) of k * res: beta_(j0 + k) = beta_j0 turned by rot[k] (k_push_update's fix-up, in LDS)
   int Bp, levels;
 };
+constexpr int ROT_N = 128;
 
 __host__ __device__ inline int rmq_levels(int beams) { int l = 1; while ((1 << l) <= beams) l++; return l; }
 __host__ __device__ inline size_t rmq_bytes(int beams)
 {
   const size_t bp = (size_t)((beams + 3) & ~3);
   return 2 * bp * sizeof(double) + ((size_t)(beams + 1 + 7) & ~(size_t)7) * 2 + 2 * (size_t)rmq_levels(beams) * bp * 2 + 64 +
-         ((size_t)beams + 2) * sizeof(double2);
+         ((size_t)beams + 2) * sizeof(double2) + 128 * sizeof(double2);
 }
 __host__ __device__ inline RmqView rmq_view(char* buf, int beams)
 {
@@ -70,6 +72,7 @@ __host__ __device__ inline RmqView rmq_view(char* buf, int beams)
   v.tmax = tmax; v.tmin = tmax + (size_t)v.levels * bp;
   const size_t used = 2 * bp * sizeof(double) + ((size_t)(beams + 1 + 7) & ~(size_t)7) * 2 + 2 * (size_t)v.levels * bp * 2;
   v.bdir = reinterpret_cast<const double2*>(buf + ((used + 15) & ~(size_t)15));
+  v.rot = v.bdir + ((size_t)beams + 2);
   return v;
 }
 
@@ -95,6 +98,8 @@ push_tables_body(const double* __restrict__ ranges, const uint8_t* __restrict__ 
       const double beta = phi_min + ((double)j - 0.5) * ang_res;
       gb[j] = make_double2(cos(beta), sin(beta));
     }
+    double2* gr = const_cast<double2*>(gv.rot);
+    for (int k = tid; k < ROT_N; k += T) { const double al = (double)k * ang_res; gr[k] = make_double2(cos(al), sin(al)); }
   }
   for (int i = tid; i < B; i += T) {
     const double d = ranges[i];
@@ -228,18 +233,29 @@ constexpr uint32_t LIST_INTERIOR = 1u << 26;     // far tile whose four corners 
                                                  // an end of the field of view or the +-pi cut (k_push_update skips those tests)
 constexpr int TOT_FIELDS = 8;   // cells updated, range pass, update, new, new from empty, emptied init, emptied uninit, -
 
-// what k_push_classify leaves for the workgroup of a listed tile besides the entry word (one 48-byte record, two 16-byte loads + one)
+// The work of one push is two lists in ONE array of `tiles` words: UPDATE tiles from the front (list[0 .. nU)), everything else that
+// needs a visit -- increaseEmptiness of a materialised tile, tiles whose halos freeFootprint dirtied -- from the back
+// (list[tiles - 1 - k], k < nO).  Counters, by push parity: cnt[CNT_WORDS * parity + {0: nU, 1: nO}], then the TICKET HEADS of
+// k_push_update's tile queue: TICKET_HEADS counters, each on a 128-byte line of its own (one word shared by every workgroup
+// saturates at ~88 returning atomics per microsecond, MI355X_MICROARCH.md "dequeue": a 10 000-tile push would take 120 us for its
+// tickets alone).  Head h hands out the tiles G + h + TICKET_HEADS * k beyond the G that the G workgroups start with.
+constexpr int CNT_U = 0, CNT_O = 1, TICKET_HEADS = 32, TICKET_STRIDE = 32 /* words */, CNT_TICKET = 32;
+constexpr int CNT_WORDS = CNT_TICKET + TICKET_HEADS * TICKET_STRIDE;
+// What k_push_classify leaves for the workgroup of an UPDATE tile: one 64-byte record (one scalar load), at the entry's own index.
 struct PushListAux {
-  uint32_t win, pad;             // beams the cells of the tile can project to: lo | hi << 16
-  double pw;                     // partition weight of an UPDATE tile (TsdGrid.cpp:239-243)
+  uint32_t entry, win;           // the list word (tile | flags | kind << 28); beams the tile's cells can project to: lo | hi << 16
+  double pw;                     // partition weight (TsdGrid.cpp:239-243)
   // phase A of k_push_update (fp32 beam estimate), all relative to the tile's centroid c = ((x0 + 16.5) cs, (y0 + 16.5) cs) -- the
   // centre of cell (ix, iy) is c + (ix - 16, iy - 16) cs -- with l_c = PoseInv (c, 1) and M = PoseInv's rotation * cs:
   float A, B;                    // l_c x (M d) = dx A + dy B   (d = cell offset in cells)
   float C, D;                    // l_c . (M d) = dx C + dy D
   float lc2, th_c;               // |l_c|^2, angle of l_c (atan2_estimate)
   float lcx, lcy;                // l_c itself (near tiles)
+  double iw;                     // the tile's _initWeight and ...
+  uint32_t flag, jb0;            // ... _initialized when it was classified (nothing changes them before the tile's own workgroup does);
+                                 // jb0 = max(lo - 1, 0): the boundary whose direction the workgroup fetches for the tile's fix-up
 };
-static_assert(sizeof(PushListAux) == 48, "PushListAux");
+static_assert(sizeof(PushListAux) == 64, "PushListAux");
 
 // ---- beam index of a cell without the fp64 atan2 ------------------------------------------------------------
 // SensorPolar2D::backProject (SensorPolar2D.cpp:117-135) decides round((atan2(ly, lx) - phi_min) / res) and the two
@@ -280,24 +296,36 @@ __device__ __forceinline__ float atan2_estimate(float y, float x)      // |error
 // four corner back-projections, the two beam-range tests as O(1) table look-ups).  Tiles that need work go
 // to the list (one atomic per wave); increaseEmptiness of a tile that was never materialised is done here
 // (TsdGridPartition.cpp:157-162).  Every tile of the window gets its record.
-__global__ void __launch_bounds__(64)
+// CLASSIFY_BLOCK threads = CLASSIFY_BLOCK / 4 tiles per workgroup (four lanes each).  Two sizes: the kernel is a chain of fp64 atan2
+// and dependent look-ups per wave, so a small window wants its waves spread over many compute units (256 threads), while a large one
+// is bound by the list counters' atomic rate and wants as few atomics as possible (1024 threads: one pair per 256 tiles).
+template <int CLASSIFY_BLOCK>
+__global__ void __launch_bounds__(CLASSIFY_BLOCK)
 k_push_classify(GridDev g, const PushArgs* __restrict__ a_dev, const char* __restrict__ rmq_buf,
                 uint32_t* __restrict__ tile_rec, const uint8_t* __restrict__ dirty, uint32_t* __restrict__ tile_totals,
                 uint32_t* __restrict__ list, PushListAux* __restrict__ list_aux,
-                unsigned int* __restrict__ list_cnt /* [2] */, int parity, int tx0, int ty0, int ntx, int nty)
+                unsigned int* __restrict__ list_cnt /* [2][CNT_WORDS] */, int parity, int tx0, int ty0, int ntx, int nty)
 {
   // FOUR lanes per tile, one corner each: the four back-projections (an fp64 atan2 apiece, by far the longest chain of this
   // kernel, and the kernel a pure latency chain: a few dozen waves on the whole chip) run side by side instead of one after
   // the other.  The quad shares everything else (same values in its four lanes); its first lane owns the tile's side effects.
   const PushArgs a = *a_dev;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int corner = lane & 3;
   const bool owner = corner == 0;
-  const int t = blockIdx.x * 16 + (lane >> 2);
-  if (t == 0 && owner) list_cnt[parity ^ 1] = 0u;           // the next push's counter (nobody uses it now)
+  const int t = blockIdx.x * (CLASSIFY_BLOCK / 4) + ((int)threadIdx.x >> 2);
+  if (t < 16 && owner) {      // the next push's counters (nobody uses them now)
+    if (t < 2) list_cnt[CNT_WORDS * (parity ^ 1) + t] = 0u;
+    list_cnt[CNT_WORDS * (parity ^ 1) + CNT_TICKET + TICKET_STRIDE * t] = 0u;
+    list_cnt[CNT_WORDS * (parity ^ 1) + CNT_TICKET + TICKET_STRIDE * (t + 16)] = 0u;
+  }
   const bool in_window = t < ntx * nty;
   const int p = in_window ? (ty0 + t / ntx) * g.PX + tx0 + t % ntx : 0;
   uint32_t rec = 0u, kind = 0u, far_flag = 0u;
+  // the tile's state, requested before anything else: it travels in the list record of an UPDATE tile (k_push_update then needs no
+  // dependent read for it) and decides the increaseEmptiness case below
+  const uint8_t t_flag = in_window ? g.flags[p] : (uint8_t)0;
+  const double t_iw = in_window ? g.init_weight[p] : 0.0;
   double pw = 0.0;
   double tcx = 0.0, tcy = 0.0;                               // the tile's centroid (UPDATE tiles)
   uint32_t win = (uint32_t)(a.beams - 1) << 16;              // beams the cells of the tile can project to: lo | hi << 16
@@ -371,10 +399,10 @@ k_push_classify(GridDev g, const PushArgs* __restrict__ a_dev, const char* __res
       }
       else if (action == 1) {
         // TsdGridPartition::increaseEmptiness (TsdGridPartition.cpp:136-164), isInRange then returns false
-        if (g.flags[p]) kind = KIND_EMPTY;
+        if (t_flag) kind = KIND_EMPTY;
         else {
           if (owner) {
-            double v = g.init_weight[p] + 1.0; v = fmin(v, MAX_WEIGHT); g.init_weight[p] = v;
+            double v = t_iw + 1.0; v = fmin(v, MAX_WEIGHT); g.init_weight[p] = v;
             tile_totals[(size_t)p * TOT_FIELDS + 6] += 1u;
           }
           rec |= REC_EMPTIED_UNINIT;
@@ -386,16 +414,31 @@ k_push_classify(GridDev g, const PushArgs* __restrict__ a_dev, const char* __res
   }
   if (in_window && owner && (kind == 0u || kind == KIND_HALO)) tile_rec[p] = rec;   // UPDATE / EMPTY: the workgroup writes the final record
   if (!owner) kind = 0u;
-  const unsigned long long listed = __ballot(kind != 0u);
-  if (listed) {
-    unsigned int base = 0;
-    if (lane == 0) base = atomicAdd(&list_cnt[parity], (unsigned int)__popcll(listed));
-    base = __shfl(base, 0, 64);
-    if (kind != 0u) {
-      const unsigned int slot = base + __popcll(listed & ((1ull << lane) - 1ull));
-      list[slot] = (uint32_t)p | far_flag | (kind << KIND_SHIFT);
+  // List slots: the waves' counts meet in LDS and ONE lane of the workgroup draws the slots of all 256 tiles with one atomic per
+  // list.  (One atomic per wave, round 2: every wave of the grid hit the same word with a RETURNING atomic, and one word hands out
+  // ~88 of those per microsecond -- the 2 400 waves of a cfg 3 window spent 20 us of the kernel's 21 queueing for list slots.)
+  const unsigned long long ub = __ballot(kind == KIND_UPDATE), ob = __ballot(kind != 0u && kind != KIND_UPDATE);
+  __shared__ unsigned int s_wu[CLASSIFY_BLOCK / 64], s_wo[CLASSIFY_BLOCK / 64], s_base[2];
+  if (lane == 0) { s_wu[wave] = (unsigned int)__popcll(ub); s_wo[wave] = (unsigned int)__popcll(ob); }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned int tu = 0u, to = 0u;
+    for (int w = 0; w < CLASSIFY_BLOCK / 64; w++) { tu += s_wu[w]; to += s_wo[w]; }
+    s_base[0] = tu ? atomicAdd(&list_cnt[CNT_WORDS * parity + CNT_U], tu) : 0u;
+    s_base[1] = to ? atomicAdd(&list_cnt[CNT_WORDS * parity + CNT_O], to) : 0u;
+  }
+  __syncthreads();
+  if (ub | ob) {
+    unsigned int base_u = s_base[0], base_o = s_base[1];
+    for (int w = 0; w < wave; w++) { base_u += s_wu[w]; base_o += s_wo[w]; }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const uint32_t word = (uint32_t)p | far_flag | (kind << KIND_SHIFT);
+    if (kind != 0u && kind != KIND_UPDATE) list[(unsigned)g.tiles - 1u - (base_o + (unsigned)__popcll(ob & lt))] = word;
+    if (kind == KIND_UPDATE) {
+      const unsigned int slot = base_u + (unsigned)__popcll(ub & lt);
+      list[slot] = word;
       PushListAux x;
-      x.win = win; x.pad = 0u; x.pw = pw;
+      x.entry = word; x.win = win; x.pw = pw;
       // the linear forms of k_push_update's phase A (see PushListAux): fp64 here, once per tile, instead of fp32 in every lane there
       const double lcx = a.Pi[0] * tcx + a.Pi[1] * tcy + a.Pi[2], lcy = a.Pi[3] * tcx + a.Pi[4] * tcy + a.Pi[5];
       const double axx = a.Pi[0] * g.cs, axy = a.Pi[1] * g.cs, ayx = a.Pi[3] * g.cs, ayy = a.Pi[4] * g.cs;
@@ -404,10 +447,13 @@ k_push_classify(GridDev g, const PushArgs* __restrict__ a_dev, const char* __res
       x.lc2 = (float)(lcx * lcx + lcy * lcy);
       x.lcx = (float)lcx; x.lcy = (float)lcy;
       x.th_c = atan2_estimate(x.lcy, x.lcx);
+      x.iw = t_iw; x.flag = t_flag;
+      x.jb0 = (win & 0xFFFFu) > 0u ? (win & 0xFFFFu) - 1u : 0u;
       list_aux[slot] = x;
     }
   }
 }
+
 
 // Classification of one cell by its estimated angle `th` (radians, possibly outside (-pi, pi] by the small delta).  The beam
 // coordinate u = (angle - phi_min) / res is shifted by one half, v = u + 0.5, so that the rounding boundaries of
@@ -480,17 +526,19 @@ __device__ __forceinline__ float beam_limit(double r, unsigned mk, float mtf, fl
 // the init value from phase A / the fix-up, candidates start from it in phase C); KIND_EMPTY: increaseEmptiness over the 33x33
 // cells.  The workgroup leaves the tile's record and adds it to the tile's running totals (no-return atomics).
 #ifndef TSD_UPDATE_WPS
-#define TSD_UPDATE_WPS 6
-#endif
-#ifndef TSD_UPDATE_CB
-#define TSD_UPDATE_CB 1
+#define TSD_UPDATE_WPS 5
 #endif
 constexpr int UPD_CAND_MAX = TILE_INTERIOR;
+constexpr int UPD_CPT = TILE_INTERIOR / UPDATE_BLOCK;            // cells per thread: 4
+#ifndef TSD_UPDATE_CB
+#define TSD_UPDATE_CB 2
+#endif
+constexpr int UPD_CB = TSD_UPDATE_CB;                            // exact part: cells per lane and pass
 __host__ __device__ inline size_t update_lds_bytes(int beams)
 {
   const size_t bp = (size_t)((beams + 3) & ~3);
-  return bp * sizeof(double) + bp * sizeof(float) + UPD_CAND_MAX * sizeof(uint32_t) + (UPDATE_BLOCK / 64) * 256 * sizeof(uint32_t) +
-         2 * 2 * TILE_DIM * sizeof(double);
+  return bp * sizeof(double) + 2 * 2 * TILE_DIM * sizeof(double) + ROT_N * sizeof(double2) + bp * sizeof(float) +
+         2 * UPD_CAND_MAX * sizeof(uint32_t) + (UPDATE_BLOCK / 64) * 256 * sizeof(uint32_t);
 }
 
 // Workgroup barrier that orders LDS only.  __syncthreads() also drains the wave's global-memory counter (s_waitcnt vmcnt(0)): every
@@ -501,7 +549,7 @@ __device__ __forceinline__ void lds_barrier()
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// per-tile values of phase A (wave-uniform)
+// wave-uniform values of phase A
 struct TileA {
   float A, B, C, D, lc2, th_c, lcx, lcy;     // PushListAux
   float axx, axy, ayx, ayy;                   // PoseInv's rotation * cellSize (near tiles)
@@ -510,17 +558,16 @@ struct TileA {
   int beams, wlo, whi;
 };
 
-// Beam classification + candidate test of ONE cell, offset (dxc, dyc) cells from the tile's centroid.  Returns the entry for the
-// candidate / undecided lists (cell | beam or boundary << 10) and sets the two flags.  FAR: the sensor is further than three
-// circumradii from the centroid -- the cell's angle is the centroid's plus a small delta, |delta| < 0.34 rad, tan(delta) = cross / dot
-// with both products LINEAR in the cell offset (coefficients from k_push_classify), atan by a four-term series; near tiles use the
-// six-term minimax arctangent.  INTERIOR (implies FAR): no end of the field of view, no cut -- only rounding boundaries.
+// Beam classification of ONE cell, offset (dxc, dyc) cells from the tile's centroid: the beam (>= 0, decided), -1 (outside the
+// field of view, decided) or IDX_UNSURE with the boundary `jb`; d2f = the fp32 squared sensor distance.  FAR: the sensor is further
+// than three circumradii from the centroid -- the cell's angle is the centroid's plus a small delta, |delta| < 0.34 rad,
+// tan(delta) = cross / dot with both products LINEAR in the cell offset (coefficients from k_push_classify), atan by a four-term
+// series; near tiles use the six-term minimax arctangent.  INTERIOR (implies FAR): no end of the field of view, no cut -- only
+// rounding boundaries.
 template <bool FAR, bool INTERIOR>
-__device__ __forceinline__ uint32_t classify_cell(const TileA& t, float dxc, float dyc, float pA, float pC, float qx, int c,
-                                                  const float* __restrict__ s_lim, const double* __restrict__ ranges,
-                                                  const uint8_t* __restrict__ mask, bool& cand, bool& unsure, bool& outside)
+__device__ __forceinline__ int classify_cell(const TileA& t, float dxc, float dyc, float pA, float pC, float qx, float vc, int& jb, float& d2f)
 {
-  float th_rel, d2f;          // angle relative to th_c (FAR) or the angle itself
+  float th_rel;          // angle relative to th_c (FAR) or the angle itself
   if constexpr (FAR) {
     const float cr = fmaf(dyc, t.B, pA);                        // l_c x l
     const float dt = fmaf(dyc, t.D, pC);                        // l_c . l  (> 0: |delta| < 0.34 rad)
@@ -536,219 +583,210 @@ __device__ __forceinline__ uint32_t classify_cell(const TileA& t, float dxc, flo
     d2f = fmaf(lxf, lxf, lyf * lyf);
     th_rel = atan2_estimate(lyf, lxf);
   }
-  int jb, index;
   if constexpr (INTERIOR) {
     // v = (th_c + delta - phi_min) / res + 1/2: boundaries at integer v
-    const float vc = fmaf(t.th_c - t.phi_min, t.inv_res, 0.5f);
     const float v = fmaf(th_rel, t.inv_res, vc);
     const float jf = rintf(v);
     jb = (int)jf;
-    index = !(fabsf(v - jf) >= IDX_MARGIN) ? IDX_UNSURE : (int)floorf(v);
+    return !(fabsf(v - jf) >= IDX_MARGIN) ? IDX_UNSURE : (int)floorf(v);
   } else {
-    index = classify_angle(FAR ? t.th_c + th_rel : th_rel, t.phi_min, t.inv_res, t.beams, false, jb);
+    return classify_angle(FAR ? t.th_c + th_rel : th_rel, t.phi_min, t.inv_res, t.beams, false, jb);
   }
-  unsure = index == IDX_UNSURE;
-  outside = !unsure && index < 0;
-  cand = false;
-  if (unsure) return (uint32_t)c | ((uint32_t)jb << 10);
-  if (outside) return 0u;
-  // the beam's limit from LDS; a beam outside the staged window -- possible only through rounding at the window's ends -- is
-  // fetched from global memory by the lanes concerned
-  const int il = min(max(index, t.wlo), t.whi);
-  float lim = s_lim[il];
-  asm volatile("" : "+v"(lim));      // (keeps the LDS read an LDS read: no pointer select)
-  if (__builtin_expect(il != index, 0)) lim = beam_limit(ranges[index], (unsigned)mask[index], t.mt, t.low2);
-  cand = !(d2f > lim);
-  return (uint32_t)c | ((uint32_t)index << 10);
 }
 
+// per-tile values the exact part (phase C) and the tile's record need; two tiles are in flight per workgroup
+struct TileC {
+  tsd_cell_t* T; w_cell_t* W;
+  double pw, iw;
+  int p;
+  bool fresh;
+};
+
+// One workgroup per resident slot of the device, each taking UPDATE tiles off a queue (TsdGrid.cpp:237-274).  Per tile:
+//   phase A  fp32 only, 4 cells per thread: beam coordinate from the estimate above, classification, and for decided cells the
+//            candidate test -- one LDS read and one compare against the beam's limit (beam_limit).  Candidates are COMPACTED into an
+//            LDS list (cell | beam << 10), one LDS atomic per wave; cells within IDX_MARGIN of a boundary go to a wave-local list
+//   fix-up   (same wave, no barrier) the undecided cells, densely, one lane each: the side of the boundary direction beta_jb the
+//            cell's fp64 sensor-frame vector lies on -- the sign of |l| sin(angle - beta) = bx ly - by lx, good to 1e-16 where
+//            the reference's own rounding chain is good to 1e-15 -- names the reference's beam unless |sin| < 1e-11; those cells,
+//            and cells at the +-pi cut, take the reference's formulation itself (fp64 atan2), an out-of-line cold path
+//   phase C  the exact part over the COMPACTED candidates, full waves, up to 4 cells per lane: tsd / weight reads, the IEEE
+//            distance, signed distance, addTsd (TsdGridPartition.h:170-212), the writes
+// SOFTWARE PIPELINE over the workgroup's tiles: the cell reads of tile n are issued, then phase A of tile n + 1 runs while they are
+// in flight, then the exact part of tile n -- so a tile costs max(memory latency, phase A) + the exact arithmetic instead of their
+// sum, with ONE workgroup barrier per tile.  Everything a phase hands to the next lives in LDS, double / triple buffered by tile
+// number (candidate lists and distance tables x2, counters x3); the registers carried across phase A are the cells in flight.
+// Tiles come off a device-wide ticket counter (the first one is the workgroup's own index): a workgroup that drew cheap tiles takes
+// more of them.  Lazy TsdGridPartition::init (TsdGridPartition.cpp:88-134) is folded in (a fresh tile's old value is known:
+// non-candidates get the init value from phase A / the fix-up, candidates start from it in phase C).  increaseEmptiness of
+// materialised tiles (TsdGridPartition.cpp:136-164, the `other` list) follows the tile queue.
 __global__ void __launch_bounds__(UPDATE_BLOCK, TSD_UPDATE_WPS)
 k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __restrict__ ranges,
               const uint8_t* __restrict__ mask, uint32_t* __restrict__ tile_rec, uint32_t* __restrict__ tile_totals,
               const uint32_t* __restrict__ list, const PushListAux* __restrict__ list_aux,
-              const unsigned int* __restrict__ list_cnt, int parity, const double2* __restrict__ bdir, double* __restrict__ dbg)
+              unsigned int* __restrict__ list_cnt, int parity, const double2* __restrict__ bdir, const double2* __restrict__ rot,
+              double* __restrict__ dbg)
 {
-  static_assert(UPDATE_BLOCK == 256, "phase A: 4 cells per thread, 32 x 2 cells per wave and pass");
+  static_assert(UPDATE_BLOCK == 256 && UPD_CPT == 4, "phase A: 4 cells per thread, 32 x 2 cells per wave and pass");
 #ifdef TSD_PUSH_STAMPS   // diagnostic build (tools/push_stamps_r3.sh): shader cycles per phase, summed over the tiles of every 8th workgroup (thread 0)
-  long long st_acc[6] = {0, 0, 0, 0, 0, 0}; long long st_t = clock64(); const long long st_w0 = wall_clock64(); int st_tiles = 0;
+  long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long st_t = clock64(); const long long st_w0 = wall_clock64(); int st_tiles = 0;
 #define PSTAMP(i) do { const long long now_ = clock64(); st_acc[i] += now_ - st_t; st_t = now_; } while (0)
 #else
 #define PSTAMP(i) do {} while (0)
 #endif
-  // the list length, this workgroup's first entry (read speculatively) and the arguments arrive together
-  const unsigned int n_list = list_cnt[parity];
-  const uint32_t first = list[blockIdx.x];
-  const PushListAux first_aux = list_aux[blockIdx.x];
+  unsigned int* const cntw = list_cnt + CNT_WORDS * parity;
+  const unsigned int n_upd_tiles = cntw[CNT_U], n_other = cntw[CNT_O];
+  const PushListAux first_aux = list_aux[blockIdx.x];           // read speculatively: arrives with the list lengths and the arguments
   const PushArgs a = *a_dev;
-  if (blockIdx.x >= n_list) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int Bp = (a.beams + 3) & ~3;
   double* s_ranges = reinterpret_cast<double*>(smem);                      // [Bp]
-  double* s_d2 = s_ranges + Bp;                                            // [2][2][32] by tile parity: (ccx - trx)^2 per column, (ccy - try)^2 per row
-  float* s_lim = reinterpret_cast<float*>(s_d2 + 4 * TILE_DIM);            // [Bp] beam_limit of every staged beam
-  uint32_t* s_cand = reinterpret_cast<uint32_t*>(s_lim + Bp);              // [1024] candidates of the tile: cell | beam << 10
-  uint32_t* s_uns = s_cand + UPD_CAND_MAX + wave * 256;                    // [256] this wave's undecided cells: cell | jb << 10
-  __shared__ unsigned int s_cnt[2][2];                                     // by tile parity: candidates listed, cells updated
-  __shared__ unsigned long long s_neg[2];                                  // groups of the tile that received a negative value
+  double* s_d2 = s_ranges + Bp;                                            // [2][2][32] by tile number & 1: (ccx - trx)^2 per column, (ccy - try)^2 per row
+  double2* s_rot = reinterpret_cast<double2*>(s_d2 + 4 * TILE_DIM);        // [ROT_N] (cos, sin)(k * res)
+  float* s_lim = reinterpret_cast<float*>(s_rot + ROT_N);                  // [Bp] beam_limit of every staged beam
+  uint32_t* s_cand = reinterpret_cast<uint32_t*>(s_lim + Bp);              // [2][1024] candidates by tile number & 1: cell | beam << 10
+  uint32_t* s_uns = s_cand + 2 * UPD_CAND_MAX + wave * 256;                // [256] this wave's undecided cells: cell | jb << 10
+  __shared__ unsigned int s_cnt[3][2];                                     // by tile number % 3: candidates listed, cells updated
+  __shared__ unsigned long long s_neg[3];                                  // groups of the tile that received a negative value
+  __shared__ unsigned int s_tk[4];                                         // list index of tile number n at [n & 3]
   const double max_trunc = g.max_trunc;
-  TileA ta;
-  ta.phi_min = (float)a.phi_min; ta.inv_res = (float)a.ang_res_inv; ta.beams = a.beams;
-  ta.mt = (float)max_trunc;
-  ta.low2 = (float)(a.low_refl * a.low_refl) * 1.00001f;
-  ta.axx = (float)(a.Pi[0] * g.cs); ta.axy = (float)(a.Pi[1] * g.cs); ta.ayx = (float)(a.Pi[3] * g.cs); ta.ayy = (float)(a.Pi[4] * g.cs);
-  ta.cs2 = (float)(g.cs * g.cs);
-  // The scan is staged once per workgroup, together with the first tile's state: only the beams the tile can project
-  // to when the workgroup has a single tile (the usual case), all of them when it will loop over several.  Beams
-  // outside the staged window go to global memory.
-  const int p_first = (int)(first & LIST_TILE_MASK);
-  const uint8_t flag_first = g.flags[p_first];
-  const double iw_first = g.init_weight[p_first];
-  int wlo = 0, whi = a.beams - 1;
-  if (n_list <= gridDim.x) {
-    wlo = (int)(first_aux.win & 0xFFFFu) - 1; whi = (int)(first_aux.win >> 16) + 1;
-    if (wlo < 0) wlo = 0;
-    if (whi > a.beams - 1) whi = a.beams - 1;
-  }
-  ta.wlo = wlo; ta.whi = whi;
-  if (whi - wlo + 1 <= UPDATE_BLOCK) {
-    // the usual tile, seen from outside: a few dozen beams, at most one element of each array per thread
-    const int j = wlo + tid;
-    const bool in_r = j <= whi;
-    const double rj = in_r ? ranges[j] : 0.0;
-    const unsigned mj = in_r ? (unsigned)mask[j] : 0u;
-    if (in_r) { s_ranges[j] = rj; s_lim[j] = beam_limit(rj, mj, ta.mt, ta.low2); }
-  } else {
-    // every read of a round issued before its first LDS write (4 x 256 beams per round)
-    for (int j0 = wlo; j0 <= whi; j0 += 4 * UPDATE_BLOCK) {
-      double rr[4]; unsigned mm[4];
-#pragma unroll
-      for (int i = 0; i < 4; i++) { const int j = j0 + tid + i * UPDATE_BLOCK; const bool in_r = j <= whi; rr[i] = in_r ? ranges[j] : 0.0; mm[i] = in_r ? (unsigned)mask[j] : 0u; }
-#pragma unroll
-      for (int i = 0; i < 4; i++) { const int j = j0 + tid + i * UPDATE_BLOCK; if (j <= whi) { s_ranges[j] = rr[i]; s_lim[j] = beam_limit(rr[i], mm[i], ta.mt, ta.low2); } }
+
+  if (blockIdx.x < n_upd_tiles) {
+    TileA ta;
+    ta.phi_min = (float)a.phi_min; ta.inv_res = (float)a.ang_res_inv; ta.beams = a.beams;
+    ta.mt = (float)max_trunc;
+    ta.low2 = (float)(a.low_refl * a.low_refl) * 1.00001f;
+    ta.axx = (float)(a.Pi[0] * g.cs); ta.axy = (float)(a.Pi[1] * g.cs); ta.ayx = (float)(a.Pi[3] * g.cs); ta.ayy = (float)(a.Pi[4] * g.cs);
+    ta.cs2 = (float)(g.cs * g.cs);
+    // the queue: tile 0 of this workgroup is its own index, the others come off its ticket head, requested two tiles ahead
+    const bool more_than_one = n_upd_tiles > gridDim.x;
+    unsigned int* const head = cntw + CNT_TICKET + TICKET_STRIDE * (blockIdx.x % TICKET_HEADS);
+    const unsigned int head_first = gridDim.x + blockIdx.x % TICKET_HEADS;
+    // (the RAW counter value is carried to where the ticket is needed: nothing may consume the returning atomic early, or thread 0's
+    // wave sits out a device-scope round trip in the middle of its step; csrc/Makefile switches the compiler's atomic optimiser off for
+    // this file for the same reason -- it would turn the one-lane atomic into a wave scan that needs the result at once)
+    auto draw = [&]() { return atomicAdd(head, 1u); };
+    auto ticket_of = [&](unsigned raw) { return head_first + TICKET_HEADS * raw; };
+    unsigned int tk_pending = 0u;                  // (thread 0) the ticket requested during the previous step
+    if (tid == 0) {
+      s_tk[0] = blockIdx.x;
+      s_tk[1] = more_than_one ? ticket_of(draw()) : ~0u;        // tile 1; tile n's step requests tile n + 2
     }
-  }
-  if (tid < 2) { s_cnt[tid][0] = 0u; s_cnt[tid][1] = 0u; s_neg[tid] = 0ull; }
-
-  // Software pipeline over the workgroup's tiles (a large push gives every workgroup several): the list entry of the
-  // NEXT tile is requested at the top of an iteration and its tile state after phase A, so an iteration's only
-  // dependent trip to memory is the read of the cells it updates.
-  uint32_t nx_entry = first; PushListAux nx_aux = first_aux; uint8_t nx_flag = flag_first; double nx_iw = iw_first;
-  unsigned int tp = 0u;                                                   // parity of the UPDATE tiles of this workgroup (counters)
-  bool synced = false;
-  for (unsigned int li = blockIdx.x; li < n_list; li += gridDim.x) {
-    const uint32_t entry = nx_entry;
-    const PushListAux aux = nx_aux;
-    const bool initialised = nx_flag != 0;
-    const double iw = nx_iw;
-    const unsigned int li_n = li + gridDim.x;
-    const bool has_next = li_n < n_list;
-    if (has_next) { nx_entry = list[li_n]; nx_aux = list_aux[li_n]; }
-    const uint32_t kind = entry >> KIND_SHIFT;
-    const int p = (int)(entry & LIST_TILE_MASK);
-    if (kind == KIND_HALO) {
-      if (has_next) { const int pn = (int)(nx_entry & LIST_TILE_MASK); nx_flag = g.flags[pn]; nx_iw = g.init_weight[pn]; }
-      continue;
+    // The scan is staged once per workgroup: only the beams the tile can project to when the workgroup has a single tile (the
+    // usual case), all of them when it may take several.  Beams outside the staged window go to global memory.
+    int wlo = 0, whi = a.beams - 1;
+    if (!more_than_one) {
+      wlo = (int)(first_aux.win & 0xFFFFu) - 1; whi = (int)(first_aux.win >> 16) + 1;
+      if (wlo < 0) wlo = 0;
+      if (whi > a.beams - 1) whi = a.beams - 1;
     }
-
-    tsd_cell_t* __restrict__ T = g.tsd + (size_t)p * TILE_STRIDE;
-    w_cell_t* __restrict__ W = g.weight + (size_t)p * TILE_STRIDE;
-    uint32_t rec = REC_RANGE_PASS;
-
-    if (kind == KIND_EMPTY) {
-      // all 33x33 cells, halo included; the average uses the NEW weight
-      for (int i = tid; i < TILE_CELLS; i += UPDATE_BLOCK) {      // (interior, halo column, halo row: offsets 0..1088)
-        double t = ld_tsd(T + i), w = ld_w(W + i);
-        if (isnan(t)) { w += 1.0; t = 1.0; }
-        else { w = fmin(w + 1, MAX_WEIGHT); t = (t * (w - 1.0) + 1.0) / w; }
-        st_tsd(T + i, t); st_w(W + i, w);
+    ta.wlo = wlo; ta.whi = whi;
+    if (whi - wlo + 1 <= UPDATE_BLOCK) {
+      // the usual tile, seen from outside: a few dozen beams, at most one element of each array per thread
+      const int j = wlo + tid;
+      const bool in_r = j <= whi;
+      const double rj = in_r ? ranges[j] : 0.0;
+      const unsigned mj = in_r ? (unsigned)mask[j] : 0u;
+      if (in_r) { s_ranges[j] = rj; s_lim[j] = beam_limit(rj, mj, ta.mt, ta.low2); }
+    } else {
+      // every read of a round issued before its first LDS write (4 x 256 beams per round)
+      for (int j0 = wlo; j0 <= whi; j0 += 4 * UPDATE_BLOCK) {
+        double rr[4]; unsigned mm[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const int j = j0 + tid + i * UPDATE_BLOCK; const bool in_r = j <= whi; rr[i] = in_r ? ranges[j] : 0.0; mm[i] = in_r ? (unsigned)mask[j] : 0u; }
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const int j = j0 + tid + i * UPDATE_BLOCK; if (j <= whi) { s_ranges[j] = rr[i]; s_lim[j] = beam_limit(rr[i], mm[i], ta.mt, ta.low2); } }
       }
-      rec |= REC_EMPTIED_INIT | REC_LISTED;
-      if (tid == 0) { tile_rec[p] = rec; atomicAdd(&tile_totals[(size_t)p * TOT_FIELDS + 5], 1u); }
-      if (has_next) { const int pn = (int)(nx_entry & LIST_TILE_MASK); nx_flag = g.flags[pn]; nx_iw = g.init_weight[pn]; }
-      continue;
     }
+    if (tid < ROT_N) s_rot[tid] = rot[tid];
+    if (tid < 3) { s_cnt[tid][0] = 0u; s_cnt[tid][1] = 0u; s_neg[tid] = 0ull; }
+    lds_barrier();                     // scan staged, counters zeroed, first tickets in place
+    PSTAMP(0);
 
-    // ---- UPDATE ----
-    // (one barrier before the workgroup's first tile: scan staged, counters zeroed.  Later tiles need none here: the candidate list
-    // was consumed before the previous tile's closing barrier, and the counters / distance tables alternate by tile parity -- a
-    // parity's counters are zeroed by thread 0 behind the closing barrier of the tile that used them, one whole tile before their
-    // next use.)
-    if (!synced) { lds_barrier(); synced = true; }
-    PSTAMP(0);            // staging / list / previous tile's record
-    const bool fresh = !initialised;
-    rec |= REC_UPDATE | REC_LISTED;
-    if (fresh) rec |= REC_NEW | (iw > 0.0 ? REC_NEW_FROM_EMPTY : 0u);
-    // TsdGridPartition::init values (TsdGridPartition.cpp:98-120)
-    const double t_init = (iw > 0.0) ? 1.0 : __builtin_nan("");
-    const double w_init = iw;
-    const unsigned x0 = (unsigned)(p % g.PX) * TILE_DIM, y0 = (unsigned)(p / g.PX) * TILE_DIM;
-    unsigned int* cnt = s_cnt[tp];
-    double* d2x = s_d2 + tp * 2 * TILE_DIM;                        // [32] columns, then [32] rows
-    // the two squares of the exact cell distance depend on the column / the row only: one lane each, once per tile
-    if (tid < 2 * TILE_DIM) {
-      const bool col = tid < TILE_DIM;
-      const unsigned i = (unsigned)tid & 31u;
-      const double cc = ((double)((col ? x0 : y0) + i) + 0.5) * g.cs;       // TsdGridPartition.cpp:127-128
-      const double dw = cc - (col ? a.trx : a.try_);
-      d2x[tid] = dw * dw;
-    }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const unsigned ix = (unsigned)tid & 31u, iy0 = (unsigned)tid >> 5;
+    const int c0 = (int)(iy0 * 32u + ix);                                  // phase A: cell k of this thread is c0 + 256 k = (ix, iy0 + 8 k)
+    const float dxc = (float)ix - 16.0f;
 
-    // ---- phase A: every cell's beam from the fp32 estimate, candidate test, compaction.
-    // Cell k of this thread: (ix, iy0 + 8 k); a wave covers a 32 x 2 strip of cells per k.
-    {
-      const unsigned ix = (unsigned)tid & 31u, iy0 = (unsigned)tid >> 5;
-      const int c0 = (int)(iy0 * 32u + ix);                                  // offset of cell k: c0 + 256 k
-      ta.A = aux.A; ta.B = aux.B; ta.C = aux.C; ta.D = aux.D; ta.lc2 = aux.lc2; ta.th_c = aux.th_c; ta.lcx = aux.lcx; ta.lcy = aux.lcy;
-      const bool far = (entry & LIST_FAR) != 0u;
-      const bool interior = (entry & LIST_INTERIOR) != 0u;
-      const float dxc = (float)ix - 16.0f;
+    // ---- phase A of tile number `n` (list record `x`): fills candidate list / counters / distance tables of that tile number
+    auto phase_a = [&](unsigned n, const PushListAux& x, const TileC& tc, const double2 bd0 /* direction of boundary x.jb0 */) {
+      uint32_t* cand_list = s_cand + (n & 1u) * UPD_CAND_MAX;
+      unsigned int* cnt = s_cnt[n % 3u];
+      const unsigned x0 = (unsigned)(tc.p % g.PX) * TILE_DIM, y0 = (unsigned)(tc.p / g.PX) * TILE_DIM;
+      const double t_init = (tc.iw > 0.0) ? 1.0 : __builtin_nan("");      // TsdGridPartition::init values (TsdGridPartition.cpp:98-120)
+      // the two squares of the exact cell distance depend on the column / the row only: one lane each, once per tile
+      if (tid < 2 * TILE_DIM) {
+        const bool col = tid < TILE_DIM;
+        const unsigned i = (unsigned)tid & 31u;
+        const double cc = ((double)((col ? x0 : y0) + i) + 0.5) * g.cs;       // TsdGridPartition.cpp:127-128
+        const double dw = cc - (col ? a.trx : a.try_);
+        s_d2[(n & 1u) * 2 * TILE_DIM + tid] = dw * dw;
+      }
+      ta.A = x.A; ta.B = x.B; ta.C = x.C; ta.D = x.D; ta.lc2 = x.lc2; ta.th_c = x.th_c; ta.lcx = x.lcx; ta.lcy = x.lcy;
+      const bool far = (x.entry & LIST_FAR) != 0u;
+      const bool interior = (x.entry & LIST_INTERIOR) != 0u;
       const float pA = dxc * ta.A, pC = fmaf(dxc, ta.C, ta.lc2), qx = fmaf(ta.cs2 * dxc, dxc, -ta.lc2);
-      constexpr int CPT = TILE_INTERIOR / UPDATE_BLOCK;
-      uint32_t ent[CPT];                 // list entry of cell k: candidate (bit k of `cm`) or undecided (bit k of `um`)
-      unsigned cm = 0u, um = 0u;
+      const float vc = fmaf(ta.th_c - ta.phi_min, ta.inv_res, 0.5f);
+      int idx[UPD_CPT]; float d2f[UPD_CPT];      // beam (or boundary, undecided cells) and fp32 squared distance of cell k
+      unsigned um = 0u, om = 0u;                 // undecided / decided-outside
 #pragma unroll
-      for (int k = 0; k < CPT; k++) {
-        const int c = c0 + UPDATE_BLOCK * k;
+      for (int k = 0; k < UPD_CPT; k++) {
         const float dyc = (float)(iy0 + 8u * (unsigned)k) - 16.0f;
-        bool cand, unsure, outside;
-        if (interior) ent[k] = classify_cell<true, true>(ta, dxc, dyc, pA, pC, qx, c, s_lim, ranges, mask, cand, unsure, outside);
-        else if (far) ent[k] = classify_cell<true, false>(ta, dxc, dyc, pA, pC, qx, c, s_lim, ranges, mask, cand, unsure, outside);
-        else          ent[k] = classify_cell<false, false>(ta, dxc, dyc, pA, pC, qx, c, s_lim, ranges, mask, cand, unsure, outside);
-        if (cand) cm |= 1u << k;
+        int jb, index;
+        if (interior) index = classify_cell<true, true>(ta, dxc, dyc, pA, pC, qx, vc, jb, d2f[k]);
+        else if (far) index = classify_cell<true, false>(ta, dxc, dyc, pA, pC, qx, vc, jb, d2f[k]);
+        else          index = classify_cell<false, false>(ta, dxc, dyc, pA, pC, qx, vc, jb, d2f[k]);
+        const bool unsure = index == IDX_UNSURE;
         if (unsure) um |= 1u << k;
+        if (!unsure && index < 0) om |= 1u << k;
+        idx[k] = unsure ? jb : index;
+      }
+      PSTAMP(6);     // (sub-phase: d2 table, setup, classification)
+      // the beams' limits from LDS, the four reads in flight together; a beam outside the staged window -- possible only through
+      // rounding at the window's ends -- is fetched from global memory by the lanes concerned
+      float lim[UPD_CPT];
+#pragma unroll
+      for (int k = 0; k < UPD_CPT; k++) lim[k] = s_lim[min(max(idx[k], wlo), whi)];
+      asm volatile("" : "+v"(lim[0]), "+v"(lim[1]), "+v"(lim[2]), "+v"(lim[3]));      // (keeps the LDS reads LDS reads: no pointer select)
+      unsigned cm = 0u;
+#pragma unroll
+      for (int k = 0; k < UPD_CPT; k++) {
+        const bool decided_in = !(((um | om) >> k) & 1u);
+        if (__builtin_expect(decided_in && (idx[k] < wlo || idx[k] > whi), 0)) lim[k] = beam_limit(ranges[idx[k]], (unsigned)mask[idx[k]], ta.mt, ta.low2);
+        const bool cand = decided_in && !(d2f[k] > lim[k]);
+        if (cand) cm |= 1u << k;
         // a freshly materialised tile: cells that addTsd will not touch get the init value here
-        if (fresh && !cand && !unsure) { st_tsd(T + c, t_init); st_w(W + c, w_init); }
+        if (tc.fresh && !cand && !((um >> k) & 1u)) st_cell(tc.T, tc.W, c0 + UPDATE_BLOCK * k, t_init, tc.iw);
 #ifdef TSD_PUSH_VERIFY_INDEX   // diagnostic build: every decided cell against the exact formulation
         {
           const double ccx = ((double)(x0 + ix) + 0.5) * g.cs, ccy = ((double)(y0 + iy0 + 8u * (unsigned)k) + 0.5) * g.cs;
           const int ex = backproject(a.Pi, ccx, ccy, a.phi_min, a.ang_res_inv, a.phi_lower, a.phi_upper);
-          const int index = outside ? -1 : (int)(ent[k] >> 10);
-          if (!unsure && (index < 0 ? ex >= 0 : ex != index)) {
-            atomicAdd(reinterpret_cast<unsigned long long*>(dbg + 1000), 1ull);
-            const unsigned long long slot = atomicAdd(reinterpret_cast<unsigned long long*>(dbg + 1005), 1ull);
-            if (slot < 40) { double* o = dbg + 1010 + slot * 8; o[0] = p; o[1] = c; o[2] = index; o[3] = ex; o[4] = (double)(entry >> 26); o[5] = ta.th_c; o[6] = a.trx; o[7] = a.try_; }
-          }
+          const bool unsure = (um >> k) & 1u;
+          const int index = ((om >> k) & 1u) ? -1 : idx[k];
+          if (!unsure && (index < 0 ? ex >= 0 : ex != index)) atomicAdd(reinterpret_cast<unsigned long long*>(dbg + 1000), 1ull);
           if (unsure) atomicAdd(reinterpret_cast<unsigned long long*>(dbg + 1001), 1ull);
           atomicAdd(reinterpret_cast<unsigned long long*>(dbg + 1002), 1ull);
         }
 #endif
       }
+      PSTAMP(7);     // (sub-phase: limits, candidate test, fresh stores)
       // compaction: one LDS atomic per wave for its candidates of all four strips; the undecided cells into the wave's own list
-      const unsigned long long lt = (1ull << lane) - 1ull;
       unsigned nc = 0u, nu = 0u;
 #pragma unroll
-      for (int k = 0; k < CPT; k++) { nc += (unsigned)__popcll(__ballot((cm >> k) & 1u)); nu += (unsigned)__popcll(__ballot((um >> k) & 1u)); }
+      for (int k = 0; k < UPD_CPT; k++) { nc += (unsigned)__popcll(__ballot((cm >> k) & 1u)); nu += (unsigned)__popcll(__ballot((um >> k) & 1u)); }
       unsigned base = 0u;
       if (nc) { if (lane == 0) base = atomicAdd(&cnt[0], nc); base = (unsigned)__builtin_amdgcn_readfirstlane((int)base); }
       unsigned ub = 0u;
 #pragma unroll
-      for (int k = 0; k < CPT; k++) {
+      for (int k = 0; k < UPD_CPT; k++) {
         const unsigned long long bc = __ballot((cm >> k) & 1u), bu = __ballot((um >> k) & 1u);
-        if ((cm >> k) & 1u) s_cand[base + (unsigned)__popcll(bc & lt)] = ent[k];
-        if ((um >> k) & 1u) s_uns[ub + (unsigned)__popcll(bu & lt)] = ent[k];
+        const uint32_t e = (uint32_t)(c0 + UPDATE_BLOCK * k) | ((uint32_t)idx[k] << 10);
+        if ((cm >> k) & 1u) cand_list[base + (unsigned)__popcll(bc & lt)] = e;
+        if ((um >> k) & 1u) s_uns[ub + (unsigned)__popcll(bu & lt)] = e;
         base += (unsigned)__popcll(bc); ub += (unsigned)__popcll(bu);
       }
+      PSTAMP(8);     // (sub-phase: compaction)
       // ---- fix-up of the wave's undecided cells, one lane each (LDS executes a wave's accesses in order: no barrier)
       for (unsigned q0 = 0u; q0 < nu; q0 += 64u) {
         const unsigned q = q0 + (unsigned)lane;
@@ -766,7 +804,13 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
         bool hard = on && jbq == IDX_CUT;
         const double l2 = lx * lx + ly * ly;
         if (on && !hard) {
-          const double2 bd = bdir[jbq];
+          // the boundary's direction: beta_jb0 (from the tile's record) turned by (jb - jb0) * res -- a table in LDS.  No global read
+          // here: a wave's memory operations complete in order, and a wait in the middle of phase A would also wait for the cell
+          // reads of the previous tile that this phase is there to overlap.  (Near tiles see the whole scan: the global table.)
+          const int kr = jbq - (int)x.jb0;
+          double2 bd;
+          if (__builtin_expect(kr >= 0 && kr < ROT_N, 1)) { const double2 rc = s_rot[kr]; bd.x = bd0.x * rc.x - bd0.y * rc.y; bd.y = bd0.y * rc.x + bd0.x * rc.y; }
+          else bd = bdir[jbq];
           const double cr = bd.x * ly - bd.y * lx;                  // |l| sin(angle - beta_jb)
           if (cr * cr > 1e-22 * l2) {
             // beyond the boundary (phi > beta): beam jb, or past phi_upper (-1); before it: beam jb - 1, or before phi_lower (-2 -> negative)
@@ -775,9 +819,7 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
         }
         if (__builtin_expect(__any(hard), 0)) {
           // within 1e-11 rad of a boundary, or at the cut: the reference's own formulation decides (fp64 atan2, bound checks, round)
-#ifndef TSD_EXP_NO_HARD
           if (hard) index = backproject_cold(a_dev, ccx, ccy);
-#endif
         }
 #ifdef TSD_PUSH_VERIFY_INDEX
         if (on) {
@@ -789,103 +831,141 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
         bool cand = false;
         if (on && index >= 0) {
           const int il = min(max(index, wlo), whi);
-          float lim = s_lim[il];
-          asm volatile("" : "+v"(lim));
-          if (__builtin_expect(il != index, 0)) lim = beam_limit(ranges[index], (unsigned)mask[index], ta.mt, ta.low2);
-          cand = !((float)l2 > lim * 1.00001f);         // (|l|^2 from the fp64 vector here: within 1e-7 of phase A's fp32 form; the margin covers it)
+          float lm = s_lim[il];
+          asm volatile("" : "+v"(lm));
+          if (__builtin_expect(il != index, 0)) lm = beam_limit(ranges[index], (unsigned)mask[index], ta.mt, ta.low2);
+          cand = !((float)l2 > lm * 1.00001f);         // (|l|^2 from the fp64 vector here: within 1e-7 of phase A's fp32 form; the margin covers it)
         }
-        if (fresh && on && !cand) { st_tsd(T + c, t_init); st_w(W + c, w_init); }
+        if (tc.fresh && on && !cand) st_cell(tc.T, tc.W, c, t_init, tc.iw);
         const unsigned long long bq = __ballot(cand);
         if (bq) {
           unsigned b2 = 0u;
           if (lane == 0) b2 = atomicAdd(&cnt[0], (unsigned)__popcll(bq));
           b2 = (unsigned)__builtin_amdgcn_readfirstlane((int)b2);
-          if (cand) s_cand[b2 + (unsigned)__popcll(bq & lt)] = (uint32_t)c | ((uint32_t)index << 10);
+          if (cand) cand_list[b2 + (unsigned)__popcll(bq & lt)] = (uint32_t)c | ((uint32_t)index << 10);
         }
       }
-    }
-    if (has_next) { const int pn = (int)(nx_entry & LIST_TILE_MASK); nx_flag = g.flags[pn]; nx_iw = g.init_weight[pn]; }   // (next tile's state: in flight during the rest)
-    PSTAMP(1);            // phase A + fix-up
-    lds_barrier();
-    PSTAMP(2);            // wait for the other waves' phase A
+      if (tc.fresh) {
+        // halo cells of a freshly materialised tile keep the init value until k_push_halo
+        for (int h = tid; h < 2 * TILE_DIM + 1; h += UPDATE_BLOCK) {      // the halo strip: column 32, then row 32
+          st_tsd(tc.T + HALO_COL + h, t_init); st_w(tc.W + HALO_COL + h, tc.iw);
+        }
+      }
+      PSTAMP(9);     // (sub-phase: fix-up)
+    };
+    auto tile_of = [&](const PushListAux& x) {
+      TileC tc;
+      tc.p = (int)(x.entry & LIST_TILE_MASK);
+      tc.T = g.tsd + (size_t)tc.p * TILE_STRIDE; tc.W = g.weight + (size_t)tc.p * TILE_STRIDE;
+      tc.pw = x.pw; tc.iw = x.iw; tc.fresh = x.flag == 0u;
+      return tc;
+    };
 
-    // ---- phase C: the exact part over the compacted candidates (candidates = the cells addTsd touches plus a sliver at the
-    // truncation boundary), CB cells per lane and pass, their reads in flight together
-    {
-      const unsigned n_cand = cnt[0];
-      const double inv_max_trunc = 1.0 / max_trunc;
-      const double eps = -g.cs / 2.0;
+    // ---- the tile loop: phase A -> barrier -> exact part -> barrier -> record.  (Measured alternative, round 3: a software pipeline
+    // that issues the cell reads of tile n, runs phase A of tile n + 1 while they are in flight and then the exact part of tile n --
+    // one barrier per tile, the cells of a tile held in registers across phase A.  It removes the memory wait from the exact part
+    // but needs 128 registers (4 workgroups per compute unit instead of 6) and the kernel is bound by VALU issue either way: 75.6 us
+    // against 75.0 us at cfg3 / comb, 16.9 against 14.5 us at cfg2.  profiles/r3_push_update_structure.txt.)
+    const double inv_max_trunc = 1.0 / max_trunc;
+    const double eps = -g.cs / 2.0;
+    unsigned i_cur = blockIdx.x, i_next = s_tk[1];        // list indices of tiles n / n + 1 (>= n_upd_tiles: none)
+    PushListAux xc = first_aux;                           // their records
+    PushListAux xn = list_aux[i_next < n_upd_tiles ? i_next : 0u];
+    double2 bdc = bdir[xc.jb0];                           // direction of tile n's boundary jb0 (a scalar read)
+    for (unsigned n = 0u; i_cur < n_upd_tiles; n++) {
+      const unsigned slot = n % 3u;
+      // tile n + 1's boundary direction: its record arrived during the previous tile, this scalar read arrives during this one
+      const double2 bdn = bdir[xn.jb0];
+      // thread 0: the ticket of tile n + 2, consumed at the end of this tile
+      if (tid == 0 && more_than_one) tk_pending = draw();
+      const TileC tcur = tile_of(xc);
+      phase_a(n, xc, tcur, bdc);
+      PSTAMP(1);
+      lds_barrier();
+      PSTAMP(2);
+      const unsigned n_cand = s_cnt[slot][0];
+      const uint32_t* cand_list = s_cand + (n & 1u) * UPD_CAND_MAX;
+      const double* d2x = s_d2 + (n & 1u) * 2 * TILE_DIM;
+      const double t_init = (tcur.iw > 0.0) ? 1.0 : __builtin_nan("");
+      // the exact part: UPD_CB cells per lane and pass, their reads in flight together
       unsigned long long wrote_neg = 0ull;
       unsigned n_upd = 0u;
-      constexpr int CB = TSD_UPDATE_CB;
-      for (unsigned q0 = (unsigned)tid; q0 < n_cand; q0 += CB * UPDATE_BLOCK) {
-        int cc[CB], idx[CB]; bool on[CB];
-        double tv[CB], wv[CB], rr[CB], dd[CB];
+      for (unsigned q0 = (unsigned)tid; q0 < n_cand; q0 += UPD_CB * UPDATE_BLOCK) {
+        uint32_t ce[UPD_CB]; double tv[UPD_CB], wv[UPD_CB];
 #pragma unroll
-        for (int j = 0; j < CB; j++) {
+        for (int j = 0; j < UPD_CB; j++) {
           const unsigned q = q0 + (unsigned)(j * UPDATE_BLOCK);
-          on[j] = q < n_cand;
-          const uint32_t e = s_cand[on[j] ? q : q0];
-          cc[j] = (int)(e & 1023u);
-          idx[j] = (int)(e >> 10);
+          ce[j] = q < n_cand ? cand_list[q] : 0xFFFFFFFFu;
+          tv[j] = t_init; wv[j] = tcur.iw;
+          if (q < n_cand && !tcur.fresh) { tv[j] = ld_tsd(tcur.T + (ce[j] & 1023u)); wv[j] = ld_w(tcur.W + (ce[j] & 1023u)); }
         }
 #pragma unroll
-        for (int j = 0; j < CB; j++) {
-          tv[j] = t_init; wv[j] = w_init;
-          if (on[j] && !fresh) { tv[j] = ld_tsd(T + cc[j]); wv[j] = ld_w(W + cc[j]); }
-          const int index = idx[j];
+        for (int j = 0; j < UPD_CB; j++) {
+          const bool on = ce[j] != 0xFFFFFFFFu;
+          const int c = (int)(ce[j] & 1023u);
+          const int index = on ? (int)(ce[j] >> 10) : wlo;
           const int il = min(max(index, wlo), whi);
           double r = s_ranges[il];
-          const double dx2 = d2x[cc[j] & 31], dy2 = d2x[TILE_DIM + (cc[j] >> 5)];
+          const double dx2 = d2x[c & 31], dy2 = d2x[TILE_DIM + (c >> 5)];
           asm volatile("" : "+v"(r));
           if (__builtin_expect(il != index, 0)) r = ranges[index];
-          rr[j] = r; dd[j] = dx2 + dy2;                              // (ccx - trx)^2 + (ccy - try)^2
-        }
-#pragma unroll
-        for (int j = 0; j < CB; j++) {
-          const int c = cc[j];
-          const double r = rr[j];
-          const double dist = sqrt_normal(dd[j]);                    // ... then the IEEE root
+          const double dist = sqrt_normal(dx2 + dy2);                // (ccx - trx)^2 + (ccy - try)^2, then the IEEE root
           double sd = 0.0; bool ok = false;
           if (!isinf(r)) { sd = r - dist; ok = true; }
           else if (dist < a.low_refl) { sd = max_trunc; ok = true; }
           bool touched = false;
-          if (on[j] && ok && sd >= -max_trunc) touched = add_tsd(tv[j], wv[j], sd, aux.pw, max_trunc, inv_max_trunc, eps);
+          if (on && ok && sd >= -max_trunc) touched = add_tsd(tv[j], wv[j], sd, tcur.pw, max_trunc, inv_max_trunc, eps);
           if (touched) n_upd++;
           if (touched && tv[j] < 0.0) wrote_neg |= neg_bit((unsigned)c & 31u, (unsigned)c >> 5);
-          if (on[j] && (touched || fresh)) { st_tsd(T + c, tv[j]); st_w(W + c, wv[j]); }
+          if (on && (touched || tcur.fresh)) st_cell(tcur.T, tcur.W, c, tv[j], wv[j]);
         }
       }
-      if (wrote_neg) atomicOr(&s_neg[tp], wrote_neg);                 // (LDS; folded into the tile's mask below)
+      if (wrote_neg) atomicOr(&s_neg[slot], wrote_neg);               // (LDS; folded into the tile's mask below)
       const unsigned wu = (unsigned)wave_sum_i((int)n_upd);
-      if (lane == 0 && wu) atomicAdd(&cnt[1], wu);
-    }
-    if (fresh) {
-      // halo cells of a freshly materialised tile keep the init value until k_push_halo
-      for (int h = tid; h < 2 * TILE_DIM + 1; h += UPDATE_BLOCK) {      // the halo strip: column 32, then row 32
-        st_tsd(T + HALO_COL + h, t_init); st_w(W + HALO_COL + h, w_init);
+      if (lane == 0 && wu) atomicAdd(&s_cnt[slot][1], wu);
+      if (tid == 0) s_tk[(n + 2u) & 3u] = more_than_one ? ticket_of(tk_pending) : ~0u;
+      PSTAMP(3);
+      lds_barrier();               // tile n done by every wave; the next ticket in place
+      PSTAMP(4);
+      if (tid == 0) {
+        // the record of tile n (this slot's counters are next used by tile n + 3: behind two more barriers)
+        const unsigned cells = s_cnt[slot][1];
+        const unsigned long long nm = s_neg[slot];
+        s_cnt[slot][0] = 0u; s_cnt[slot][1] = 0u; s_neg[slot] = 0ull;
+        uint32_t rec = REC_RANGE_PASS | REC_UPDATE | REC_LISTED;
+        if (tcur.fresh) rec |= REC_NEW | (tcur.iw > 0.0 ? REC_NEW_FROM_EMPTY : 0u);
+        tile_rec[tcur.p] = rec | (cells << REC_CELLS_SHIFT);
+        // The tile's running totals and mask: NO-RETURN atomics (fire and forget; every tile has its own words, so nothing contends).
+        uint32_t* tot = tile_totals + (size_t)tcur.p * TOT_FIELDS;
+        if (nm) atomicOr(&g.negmask[tcur.p], nm);
+        atomicAdd(&tot[0], cells); atomicAdd(&tot[2], 1u);
+        if (tcur.fresh) { atomicAdd(&tot[3], 1u); if (tcur.iw > 0.0) atomicAdd(&tot[4], 1u); }
+        if (tcur.fresh) g.flags[tcur.p] = 1;   // publish the tile
       }
-    }
-    PSTAMP(3);            // phase C
-    lds_barrier();                 // every thread is done with the candidate list (and has read `initialised`)
-    PSTAMP(4);            // wait for the other waves' phase C
-    if (tid == 0) {
-      const unsigned cells = cnt[1];
-      const unsigned long long nm = s_neg[tp];
-      cnt[0] = 0u; cnt[1] = 0u; s_neg[tp] = 0ull;      // this parity is used again by the tile after the next: behind that tile's first barrier
-      tile_rec[p] = rec | (cells << REC_CELLS_SHIFT);
-      // The tile's running totals and mask: NO-RETURN atomics (fire and forget; every tile has its own words, so
-      // nothing contends).
-      uint32_t* tot = tile_totals + (size_t)p * TOT_FIELDS;
-      if (nm) atomicOr(&g.negmask[p], nm);
-      atomicAdd(&tot[0], cells); atomicAdd(&tot[2], 1u);
-      if (fresh) { atomicAdd(&tot[3], 1u); if (iw > 0.0) atomicAdd(&tot[4], 1u); }
-      if (fresh) g.flags[p] = 1;   // publish the tile
-    }
-    tp ^= 1u;
 #ifdef TSD_PUSH_STAMPS
-    st_tiles++;
+      st_tiles++;
 #endif
+      // advance: the record of tile n + 2 is requested now, one tile ahead of its phase A
+      i_cur = i_next; i_next = s_tk[(n + 2u) & 3u];
+      xc = xn; bdc = bdn; xn = list_aux[i_next < n_upd_tiles ? i_next : 0u];
+      PSTAMP(0);
+    }
+  }
+
+  // ---- the other list: increaseEmptiness of materialised tiles, all 33 x 33 cells, halo included; the average uses the NEW weight
+  for (unsigned int k = blockIdx.x; k < n_other; k += gridDim.x) {
+    const uint32_t entry = list[(unsigned)g.tiles - 1u - k];
+    if ((entry >> KIND_SHIFT) != KIND_EMPTY) continue;
+    const int p = (int)(entry & LIST_TILE_MASK);
+    tsd_cell_t* __restrict__ T = g.tsd + (size_t)p * TILE_STRIDE;
+    w_cell_t* __restrict__ W = g.weight + (size_t)p * TILE_STRIDE;
+    for (int i = tid; i < TILE_CELLS; i += UPDATE_BLOCK) {      // (interior, halo column, halo row: offsets 0..1088)
+      double t = ld_tsd(T + i), w = ld_w(W + i);
+      if (isnan(t)) { w += 1.0; t = 1.0; }
+      else { w = fmin(w + 1, MAX_WEIGHT); t = (t * (w - 1.0) + 1.0) / w; }
+      st_cell(T, W, i, t, w);
+    }
+    if (tid == 0) { tile_rec[p] = REC_RANGE_PASS | REC_EMPTIED_INIT | REC_LISTED; atomicAdd(&tile_totals[(size_t)p * TOT_FIELDS + 5], 1u); }
   }
 #ifdef TSD_PUSH_STAMPS
   if (threadIdx.x == 0 && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 256) {
@@ -893,6 +973,8 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
     PSTAMP(5);
     o[0] = (double)st_w0; o[1] = (double)wall_clock64(); o[2] = (double)st_tiles;
     for (int i = 0; i < 5; i++) o[3 + i] = (double)st_acc[i];
+    double* o2 = dbg + 2048 + (blockIdx.x >> 3) * 8;      // (the trace buffer is followed by the stamp build's own 16 KB)
+    for (int i = 0; i < 5; i++) o2[i] = (double)st_acc[6 + i];
   }
 #endif
 }
@@ -920,13 +1002,14 @@ k_push_halo(GridDev g, uint8_t* __restrict__ dirty, unsigned long long* __restri
       if (!(fabs(sx - cx) <= slack && fabs(sy - cy) <= slack)) pushes[1] += 1ull;
     }
   }
-  const unsigned int n_list = list_cnt[parity];
-  const uint32_t first = list[wv];                            // speculative: arrives with the list length
+  const unsigned int n_u = list_cnt[CNT_WORDS * parity + CNT_U], n_list = n_u + list_cnt[CNT_WORDS * parity + CNT_O];
+  const uint32_t first = list[wv];                            // speculative: arrives with the list lengths
   const int PX = g.PX;
   const bool colhalf = lane < TILE_DIM;
   const int i = lane & 31;
   for (unsigned int li = wv; li < n_list; li += gridDim.x * 4) {
-    const uint32_t entry = (li == wv) ? first : list[li];
+    // UPDATE tiles from the front of the array, the others (emptied, dirtied) from its back
+    const uint32_t entry = li < n_u ? ((li == wv) ? first : list[li]) : list[(unsigned)g.tiles - 1u - (li - n_u)];
     const int p = (int)(entry & LIST_TILE_MASK);
     if (lane == 0 && dirty[p] != 0) dirty[p] = 0;
     const int px = p % PX, py = p / PX;
@@ -948,8 +1031,8 @@ k_push_halo(GridDev g, uint8_t* __restrict__ dirty, unsigned long long* __restri
     // job 2 (lanes 0 and 32 only): the corner cells
     size_t src[3], dst[3]; bool on[3];
     if (colhalf) {
-      on[0] = fR != 0;  src[0] = (size_t)(p + 1) * TILE_STRIDE + (size_t)i * TILE_DIM;  dst[0] = own + HALO_COL + i;
-      on[1] = fL != 0;  src[1] = own + (size_t)i * TILE_DIM;                           dst[1] = (size_t)(p - 1) * TILE_STRIDE + HALO_COL + i;
+      on[0] = fR != 0;  src[0] = (size_t)(p + 1) * TILE_STRIDE + EDGE_COL + i;           dst[0] = own + HALO_COL + i;      // (the packed copy of column 0)
+      on[1] = fL != 0;  src[1] = own + EDGE_COL + i;                                   dst[1] = (size_t)(p - 1) * TILE_STRIDE + HALO_COL + i;
       on[2] = lane == 0 && fUR != 0; src[2] = (size_t)(p + PX + 1) * TILE_STRIDE;      dst[2] = own + HALO_ROW + TILE_DIM;
     } else {
       on[0] = fU != 0;  src[0] = (size_t)(p + PX) * TILE_STRIDE + i;                   dst[0] = own + HALO_ROW + i;
@@ -983,8 +1066,9 @@ k_free_footprint(GridDev g, unsigned minX, unsigned maxX, unsigned minY, unsigne
     const unsigned lx = (unsigned)(can % TILE_PITCH), ly = (unsigned)(can / TILE_PITCH);
     const unsigned col = tx * TILE_DIM + lx, row = ty * TILE_DIM + ly;
     const bool inside = lx < TILE_DIM && ly < TILE_DIM && col >= minX && col < maxX && row >= minY && row < maxY;
-    if (inside) { st_tsd(T + i, 1.0); if (fresh) st_w(W + i, iw); }
-    else if (fresh) { st_tsd(T + i, t_init); st_w(W + i, iw); }
+    const bool edge = i < TILE_INTERIOR && (i & (TILE_DIM - 1)) == 0;        // a cell of column 0: its packed copy follows it
+    if (inside) { st_tsd(T + i, 1.0); if (edge) st_tsd(T + EDGE_COL + (i >> 5), 1.0); if (fresh) { st_w(W + i, iw); if (edge) st_w(W + EDGE_COL + (i >> 5), iw); } }
+    else if (fresh) st_cell(T, W, i, t_init, iw);
   }
   __syncthreads();            // every thread has read `fresh`
   if (tid == 0) {
@@ -1063,7 +1147,7 @@ k_import_tiles(GridDev g, int t0, const double* __restrict__ in_t, const double*
   const double* iw = in_w + (size_t)blockIdx.x * TILE_CELLS;
   for (int i = threadIdx.x; i < TILE_CELLS; i += 256) {
     const int can = canonical_of_off(i);
-    st_tsd(T + i, it[can]); st_w(W + i, iw[can]);
+    st_cell(T, W, i, it[can], iw[can]);
   }
 }
 int launch_export_tiles(tsd_ctx* ctx, int t0, int n, double* d_t, double* d_w)
@@ -1159,6 +1243,7 @@ int launch_free_footprint(tsd_ctx* ctx, unsigned minX, unsigned maxX, unsigned m
 
 size_t push_rmq_bytes(int beams) { return rmq_bytes(beams); }
 size_t push_list_aux_bytes() { return sizeof(PushListAux); }
+size_t push_list_cnt_bytes() { return 2 * CNT_WORDS * sizeof(unsigned int); }
 
 int launch_push_tables(tsd_ctx* ctx, hipStream_t stream, int beams, const double* d_ranges, const uint8_t* d_mask,
                        double phi_min, double ang_res)
@@ -1238,9 +1323,14 @@ int launch_push(tsd_ctx* ctx, const PushArgs& a, double cx, double cy, double sl
   const int n_window = ntx * nty;
   {
     ScopedKernelTimer t(ctx, "push_classify");
-    hipExtLaunchKernelGGL(k_push_classify, dim3((n_window + 15) / 16), dim3(64), 0, ctx->stream, t.a, t.b, 0, g, a_dev, rmq,
-                       ctx->d_tile_rec, ctx->d_dirty, ctx->d_tile_totals, ctx->d_list, reinterpret_cast<PushListAux*>(ctx->d_list_aux), ctx->d_list_cnt, parity,
-                       box.x0, box.y0, ntx, nty);
+    if (n_window <= 12288)
+      hipExtLaunchKernelGGL((k_push_classify<256>), dim3((n_window + 63) / 64), dim3(256), 0, ctx->stream, t.a, t.b, 0, g, a_dev, rmq,
+                         ctx->d_tile_rec, ctx->d_dirty, ctx->d_tile_totals, ctx->d_list, reinterpret_cast<PushListAux*>(ctx->d_list_aux), ctx->d_list_cnt, parity,
+                         box.x0, box.y0, ntx, nty);
+    else
+      hipExtLaunchKernelGGL((k_push_classify<1024>), dim3((n_window + 255) / 256), dim3(1024), 0, ctx->stream, t.a, t.b, 0, g, a_dev, rmq,
+                         ctx->d_tile_rec, ctx->d_dirty, ctx->d_tile_totals, ctx->d_list, reinterpret_cast<PushListAux*>(ctx->d_list_aux), ctx->d_list_cnt, parity,
+                         box.x0, box.y0, ntx, nty);
   }
   TSD_HIP_CHECK(ctx, hipGetLastError());
   // as many workgroups as are RESIDENT at once (TSD_UPDATE_WPS per compute unit), never more: every workgroup loops over the
@@ -1254,7 +1344,7 @@ int launch_push(tsd_ctx* ctx, const PushArgs& a, double cx, double cy, double sl
     const size_t lds = update_lds_bytes(a.beams);
     hipExtLaunchKernelGGL(k_push_update, dim3(n_groups), dim3(UPDATE_BLOCK), lds, ctx->stream, t.a, t.b, 0, g, a_dev, d_ranges, d_mask,
                        ctx->d_tile_rec, ctx->d_tile_totals, ctx->d_list, reinterpret_cast<const PushListAux*>(ctx->d_list_aux), ctx->d_list_cnt, parity,
-                       rmq_view(rmq, a.beams).bdir, ctx->d_icp_trace);
+                       rmq_view(rmq, a.beams).bdir, rmq_view(rmq, a.beams).rot, ctx->d_icp_trace);
   }
   TSD_HIP_CHECK(ctx, hipGetLastError());
   {

@@ -181,7 +181,7 @@ struct tsd_ctx {
   char* d_list_aux = nullptr;               // [tiles] PushListAux of every list entry (push_kernels.hip): beam window, partition weight,
                                             // the linear forms of k_push_update's beam estimate
   tsd::PushArgs* d_push_args = nullptr;     // arguments of an unfused tsd_push (the fused scan keeps them in the sensor state)
-  unsigned int* d_list_cnt = nullptr;       // [2] its length, by push parity
+  unsigned int* d_list_cnt = nullptr;       // by push parity: UPDATE tiles listed, other tiles listed, the ticket heads of k_push_update's tile queue
   unsigned int push_parity = 0;
   unsigned long long epoch = 0;             // bumped by everything that changes the grid, a sensor pose or the ctx's ray-cast outputs
   hipStream_t stream2 = nullptr;             // side stream: the tables are built while ray cast / ICP run
@@ -337,6 +337,7 @@ int launch_push_tables(tsd_ctx* ctx, hipStream_t stream, int beams, const double
                        double phi_min, double ang_res);
 size_t push_rmq_bytes(int beams);
 size_t push_list_aux_bytes();
+size_t push_list_cnt_bytes();
 int launch_free_footprint(tsd_ctx* ctx, unsigned minX, unsigned maxX, unsigned minY, unsigned maxY);
 int launch_neg_scan(tsd_ctx* ctx);
 int launch_export_tiles(tsd_ctx* ctx, int t0, int n, double* d_t, double* d_w);

@@ -10,7 +10,8 @@ lib=$root/ohm_tsd_slam_amd/lib
 diag=${DIAG_DIR:-diag}            # DIAG_DIR=diag_<name>: several variants side by side
 mkdir -p $lib/$diag/obj
 cd $root/ohm_tsd_slam_amd/csrc
-hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -I../../include "$@" -c $tu.hip -o $lib/$diag/obj/$tu.o
+extra=""; if [ "$tu" = "push_kernels" ]; then extra="-mllvm -amdgpu-atomic-optimizer-strategy=None"; fi
+hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -I../../include $extra "$@" -c $tu.hip -o $lib/$diag/obj/$tu.o
 objs=""
 for o in $lib/obj/*.o; do b=$(basename $o); if [ "$b" = "$tu.o" ]; then objs="$objs $lib/$diag/obj/$tu.o"; else objs="$objs $o"; fi; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o $lib/$diag/libtsd_hip.so $objs

@@ -19,14 +19,15 @@ for k in range(12):
     g.push(pose, data, mask, geo.angle_increment, geo.angle_min, 30.0, 0.001, 2.0, want_stats=False)
     g.sync()
     if k in (6, 11):
-        tr = np.zeros((256, 8)); g.lib.tsd_icp_trace(g.h, tr.ctypes.data_as(capi._dp), 256)
-        st = tr[tr[:, 1] > 0]
-        st = st[st[:, 1] > st[:, 1].max() - 100000]          # this push's workgroups only (100 MHz clock: within 1 ms of the last one to end)
+        tr2 = np.zeros((512, 8)); g.lib.tsd_icp_trace(g.h, tr2.ctypes.data_as(capi._dp), 512)
+        tr, sub = tr2[:256], tr2[256:]
+        sel = (tr[:, 1] > 0) & (tr[:, 1] > tr[:, 1].max() - 100000)          # this push's workgroups only (100 MHz clock: within 1 ms of the last one to end)
+        st, sub = tr[sel], sub[sel]
         t0 = st[:, 0].min()
         life = (st[:, 1] - st[:, 0]) * 0.01
         print(f"   workgroup start after the first: median {np.median((st[:,0]-t0)*0.01):.2f} p90 {np.percentile((st[:,0]-t0)*0.01, 90):.2f} max {((st[:,0]-t0)*0.01).max():.2f} us; "
               f"end after the first start: median {np.median((st[:,1]-t0)*0.01):.2f} p90 {np.percentile((st[:,1]-t0)*0.01, 90):.2f} max {((st[:,1]-t0)*0.01).max():.2f} us; life p10 {np.percentile(life,10):.2f} p90 {np.percentile(life,90):.2f} max {life.max():.2f}")
-        st = st[st[:, 2] > 0]
+        sub = sub[st[:, 2] > 0]; st = st[st[:, 2] > 0]
         span = (st[:, 1].max() - t0) * 0.01
         tiles = st[:, 2]
         print(f"{sys.argv[1]}/{sys.argv[2]} push {k}: {len(st)} sampled workgroups, UPDATE tiles each: median {np.median(tiles):.0f} max {tiles.max():.0f}; "
@@ -37,4 +38,6 @@ for k in range(12):
             c = st[:, 3 + i]
             print(f"   {nm:46s}: {100*np.median(c/tot):5.1f} % of thread 0's cycles; per tile median {np.median(c/tiles):8.0f} cycles")
         print(f"   cycles per tile (thread 0): median {np.median(tot/tiles):.0f}")
+        for i, nm in enumerate(["A: d2 table, setup, classification", "A: limits, candidate test", "A: compaction", "A: fix-up", "step: ticket, entries, reads issued"]):
+            print(f"      {nm:40s}: per tile median {np.median(sub[:, i]/tiles):8.0f} cycles")
 PY
