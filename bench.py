@@ -230,6 +230,8 @@ def main():
     ap.add_argument("--registration-mode", type=int, default=0, choices=[0, 3],
                     help="0: ICP only (the bench line, SURVEY 8(d)); 3: TSD_PDF pre-registration ahead of the ICP (config/single-laser.yaml:28), "
                          "fixed tsdpdf_seed; stages_ms.tsdpdf = the scoring kernels")
+    ap.add_argument("--no-stream", action="store_true", help="skip the stream-bandwidth measurement (roofline.peak_measured): profile passes, whose "
+                                                            "calibration counts k_calib_rmw launches of ONE known size")
     ap.add_argument("--no-second-pass", action="store_true", help="skip the --no-lookahead comparison pass (value_no_lookahead)")
     ap.add_argument("--launch-check", action="store_true",
                     help="multi-rank plumbing only (no GPU work): the ranks rendezvous over gloo, sum their ranks, rank 0 prints "
@@ -457,7 +459,7 @@ def run_push(args, gc, geo, scene, K, W, every, every_upd, device, capi, synth):
     stages = stage_table(grid, K)
     st, pushes = grid.push_stats_total()
     grid.profile(False)
-    stream = grid.measure_stream(STREAM_DOUBLES, 5)
+    stream = grid.measure_stream(STREAM_DOUBLES, 5) if not args.no_stream else (None, None)
     if args.calibrate:
         grid.calibrate_rmw(CALIB_DOUBLES, 3)
     for _ in range(args.occupancy):
@@ -621,7 +623,7 @@ def run_slam(args, gc, geo, scene, K, W, every, every_upd, device, rank, local_r
             t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}" if args.pg_backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        stream = grid.measure_stream(STREAM_DOUBLES, 5) if rank == 0 else (None, None)
+        stream = grid.measure_stream(STREAM_DOUBLES, 5) if (rank == 0 and not args.no_stream) else (None, None)
         if args.calibrate:
             grid.calibrate_rmw(CALIB_DOUBLES, 3)
         for _ in range(args.occupancy):

@@ -70,7 +70,7 @@ constexpr int IR_DBG = 40;
 
 // what the kernel needs again only after the last step (and the trace pointer, once per step by one
 // thread): parked in LDS so that it does not sit in scalar registers through the loop
-struct IcpTail { IcpResultDev* out; double* trace; ScanPostArgs post; };
+struct IcpTail { IcpResultDev* out; double* trace; ScanPostArgs post; ScanPostPre pre; };
 
 struct IcpLds {
   IcpTail* tail;
@@ -529,6 +529,11 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
 #define SSTAMP(i) do {} while (0)
 #endif
 
+  // fused scan: the sensor state the epilogue needs (pose, _lastPose) is requested NOW, ahead of the inputs, and parked in LDS once
+  // it is there -- its memory round trip rides along with the inputs' instead of opening the epilogue
+  ScanPostPre pre_regs;
+  if (tid == 0 && post.st) scan_post_preload(post, &pre_regs);
+
   // ---------------------------------------------------------------- inputs
   if (a.beams > 0) {
     // fused mode: maskMatrix compaction of the ray-cast model and of the scan's cartesian points.
@@ -537,16 +542,16 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     // instead of one per dependent step); the launcher guarantees beams <= R * T.
     bool fm[R], fs[R];
     double rr[R], lx[R], ly[R];
-    double2 cm[R], nn[R];
+    double cmx[R], cmy[R], nnx[R], nny[R];       // (plain doubles: an array of double2 stays an alloca -- scratch memory -- in this compiler)
 #pragma unroll
     for (int q = 0; q < R; q++) {
       const int b = q * T + tid;
       const int bc = b < a.beams ? b : 0;
       const uint8_t mm = g_mask_m[bc], ms = g_mask[bc];
       rr[q] = g_ranges[bc];
-      cm[q] = *reinterpret_cast<const double2*>(g_coords + 2 * (size_t)bc);
+      { const double2 c2 = *reinterpret_cast<const double2*>(g_coords + 2 * (size_t)bc); cmx[q] = c2.x; cmy[q] = c2.y; }
       lx[q] = g_rays_local[bc]; ly[q] = g_rays_local[a.beams + bc];
-      nn[q] = L.nxy ? *reinterpret_cast<const double2*>(g_normals + 2 * (size_t)bc) : make_double2(0.0, 0.0);
+      { const double2 n2 = L.nxy ? *reinterpret_cast<const double2*>(g_normals + 2 * (size_t)bc) : make_double2(0.0, 0.0); nnx[q] = n2.x; nny[q] = n2.y; }
       fm[q] = (b < a.beams) && mm != 0;
       fs[q] = (b < a.beams) && !isinf(rr[q]) && ms != 0;
     }
@@ -571,7 +576,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
         runM += c_m; runS += c_s;
       }
       offM += __popcll(bm[q] & lt); offS += __popcll(bs[q] & lt);
-      if (fm[q] && offM < cap) { L.mxy[offM] = cm[q]; L.morig[offM] = offM; if (L.nxy) L.nxy[offM] = nn[q]; }
+      if (fm[q] && offM < cap) { L.mxy[offM] = make_double2(cmx[q], cmy[q]); L.morig[offM] = offM; if (L.nxy) L.nxy[offM] = make_double2(nnx[q], nny[q]); }
       if (fs[q] && offS < cap) {
         // coords = raysLocal(j,i) * data[i] (Sensor.cpp:176-179)
         L.stage_s[offS] = make_double2(lx[q] * rr[q], ly[q] * rr[q]);
@@ -600,6 +605,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
   }
   if (tid == 0) {
     L.tail->out = out; L.tail->trace = trace; L.tail->post = post;
+    if (post.st) L.tail->pre = pre_regs;                      // (fused scan: the sensor state the epilogue starts from, requested at the top)
     L.ired[IR_CNT] = 0; L.ired[IR_RMAX] = 0; L.ired[IR_CNT2] = 0; L.ired[IR_TIE] = 0;
   }
 
@@ -616,7 +622,8 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     r.rms = 0.0; r.pairs = 0; r.iterations = 0; r.state = TSD_ICP_NOTMATCHABLE;
     r.n_model = nM; r.n_scene = nS; r.reserved = (nM > cap || nS > cap) ? TSD_E_CAPACITY : 0;
     if (tid == 0) *out = r;
-    if (post.st) scan_post_body(post, r.T, r, post.gmin_x, post.gmax_x, post.gmin_y, post.gmax_y);
+    __syncthreads();            // (the tail, incl. the preloaded sensor state, is thread 0's)
+    if (post.st) scan_post_body(post, L.tail->pre, r.T, r, post.gmin_x, post.gmax_x, post.gmin_y, post.gmax_y);
     return;
   }
 
@@ -1132,10 +1139,10 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     r.T[6] = 0.0; r.T[7] = 0.0; r.T[8] = 1.0;
     r.rms = rms; r.pairs = pairs; r.iterations = (int)iter; r.state = state;
     r.n_model = nM; r.n_scene = nS; r.reserved = 0;
-    const IcpTail tl = *L.tail;
+    const IcpTail& tl = *L.tail;
     if (tid == 0) *tl.out = r;
     // fused scan: gates, Sensor::transform, push / next-scan arguments, result record for the host
-    if (tl.post.st) scan_post_body(tl.post, r.T, r, tl.post.gmin_x, tl.post.gmax_x, tl.post.gmin_y, tl.post.gmax_y);
+    if (tl.post.st) scan_post_body(tl.post, L.tail->pre, r.T, r, tl.post.gmin_x, tl.post.gmax_x, tl.post.gmin_y, tl.post.gmax_y);
   }
 }
 
@@ -1270,20 +1277,9 @@ int launch_icp(tsd_ctx* ctx, const IcpArgs& a, const double* P_dev, const double
   if (n > TSD_MAX_ICP_POINTS) return set_error(ctx, TSD_E_CAPACITY, "icp points > TSD_MAX_ICP_POINTS", hipSuccess);
   const int cap = icp_cap_for(n);
   const int nthr = a.beams > 0 ? a.beams : a.n_scene;     // scene points decide the thread count
-  switch (ctx->icp_shape) {      // TSD_ICP_SHAPE: experiments only (a shape that cannot hold the points falls through)
-    case 2: if (nthr <= 2 * 576) return launch_icp_shape<2, 576>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post);
-            break;
-    case 3: if (nthr <= 3 * 512) return launch_icp_shape<3, 512>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post, 512);
-            break;
-    // six waves: four share two SIMDs and hold two 64-point groups each, the two lone waves hold up to five
-    // (evens out the issue load per SIMD, but five register slots spill: slower than the default as measured)
-    case 7: if (nthr <= 64 * (ICP_RL * 6 + (5 - ICP_RL) * 2)) return launch_icp_shape<5, 512>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post, 384);
-            break;
-    case 5: if (nthr <= 5 * 256) return launch_icp_shape<5, 256>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post);
-            break;
-    case 8: return launch_icp_shape<8, 256>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post);
-    default: break;
-  }
+  // (round 3: the experimental shapes <2,576>, <5,512> and <5,256> are gone -- measured no faster in round 2, and the first spilled
+  // 21-27 registers per lane; TSD_ICP_SHAPE=8 forces the 8-points-per-thread shape, TSD_ICP_SHAPE >= 64 a thread count of <3,512>)
+  if (ctx->icp_shape == 8) return launch_icp_shape<8, 256>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post);
   if (nthr <= 3 * 512) return launch_icp_shape<3, 512>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post, ctx->icp_shape >= 64 ? ctx->icp_shape : 0);
   return launch_icp_shape<8, 256>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post);
 }

@@ -28,8 +28,12 @@ __device__ __forceinline__ int8_t occ_from_tsd(const GridDev& g, int p, int ly, 
 // One workgroup per tile, one thread per 4 consecutive cells of a row: the map is read and written 4 bytes per
 // lane (16-byte aligned rows), the tile's cells 32 bytes per lane.  A tile nobody writes (most of the grid) only
 // forwards the persistent map to the output.
+// work list of k_occ_mark: the tiles that hold cells (processed and initialised), in OCC_SHARDS segments of the list with a counter
+// each on its own 128-byte line (tile p goes to shard p % OCC_SHARDS, which has room for exactly tiles / OCC_SHARDS entries) -- one
+// counter for all tiles would hand out ~88 slots per microsecond (MI355X_MICROARCH.md "dequeue"), 45 us for a cfg 2 map
+constexpr int OCC_SHARDS = 32, OCC_HEAD_STRIDE = 32;
 __global__ void __launch_bounds__(256)
-k_occ_cells(GridDev g, int8_t* __restrict__ content, int8_t* __restrict__ out)
+k_occ_cells(GridDev g, int8_t* __restrict__ content, int8_t* __restrict__ out, unsigned int* __restrict__ heads, uint32_t* __restrict__ list)
 {
   const int p = blockIdx.x;
   const int PX = g.PX;
@@ -45,6 +49,10 @@ k_occ_cells(GridDev g, int8_t* __restrict__ content, int8_t* __restrict__ out)
   uint32_t* c4 = reinterpret_cast<uint32_t*>(content + gi);
   uint32_t* o4 = reinterpret_cast<uint32_t*>(out + gi);
   if (own_proc && own_init) {
+    if (threadIdx.x == 0) {
+      const unsigned sh = (unsigned)p % OCC_SHARDS, cap = ((unsigned)g.tiles + OCC_SHARDS - 1) / OCC_SHARDS;
+      list[sh * cap + atomicAdd(&heads[sh * OCC_HEAD_STRIDE], 1u)] = (uint32_t)p;
+    }
     const tsd_cell_t* t = g.tsd + (size_t)p * TILE_STRIDE + ly * TILE_DIM + lx0;     // interior row, 4 cells
     const double t0 = ld_tsd(t), t1 = ld_tsd(t + 1), t2 = ld_tsd(t + 2), t3 = ld_tsd(t + 3);
     const uint32_t v = (t0 > 0.0 ? 0u : 0xFFu) | (t1 > 0.0 ? 0u : 0xFF00u) | (t2 > 0.0 ? 0u : 0xFF0000u) | (t3 > 0.0 ? 0u : 0xFF000000u);
@@ -86,44 +94,51 @@ __device__ __forceinline__ void occ_mark(const GridDev& g, int8_t* out, double x
   }
 }
 
+// One 256-thread workgroup per LISTED tile (k_occ_cells' work list), a fixed grid looping over the list's shards.  (Round 2: one
+// workgroup per tile of the grid -- 16 384 launches at cfg 2, of which three quarters found their tile uninitialised and left.)
 __global__ void __launch_bounds__(256)
-k_occ_mark(GridDev g, int8_t* __restrict__ out, int* __restrict__ count, int inflate, int factor)
+k_occ_mark(GridDev g, int8_t* __restrict__ out, int* __restrict__ count, int inflate, int factor,
+           const unsigned int* __restrict__ heads, const uint32_t* __restrict__ list)
 {
-  const int p = blockIdx.x;
   const int PX = g.PX;
-  const int X = p % PX, Y = p / PX;
-  if (!tile_processed(X, Y, PX) || !g.flags[p]) return;
+  const unsigned sh = blockIdx.x % OCC_SHARDS, cap = ((unsigned)g.tiles + OCC_SHARDS - 1) / OCC_SHARDS;
+  const unsigned n_sh = heads[sh * OCC_HEAD_STRIDE];
   // the tile (33 x 33 doubles) through LDS: every cell is looked at by up to four scan positions
   __shared__ double T[TILE_CELLS];
-  {
-    const tsd_cell_t* Tg = g.tsd + (size_t)p * TILE_STRIDE;
-    for (int i = threadIdx.x; i < TILE_CELLS; i += 256) T[canonical_of_off(i)] = ld_tsd(Tg + i);   // LDS copy in the 33 x 33 form
-  }
-  __syncthreads();
   const double cs = g.cs;
   int n = 0;
-  // row scans: py in 0..32, px in 1..32 (:38-60); column scans: px in 0..32, py in 1..32 (:62-80)
-  for (int c = threadIdx.x; c < 2 * TILE_PITCH * TILE_DIM; c += 256) {
-    const bool col = c >= TILE_PITCH * TILE_DIM;
-    const int cc = col ? c - TILE_PITCH * TILE_DIM : c;
-    const int a = cc / TILE_DIM;          // fixed index 0..32
-    const int b = cc % TILE_DIM + 1;      // running index 1..32
-    const int py = col ? b : a, px = col ? a : b;
-    const double prev = col ? T[(py - 1) * TILE_PITCH + px] : T[py * TILE_PITCH + px - 1];
-    const double cur = T[py * TILE_PITCH + px];
-    if ((prev > 0 && cur < 0) || (prev < 0 && cur > 0)) {
-      const double interp = prev / (prev - cur);
-      double x, y;
-      if (!col) {
-        x = px * cs + cs * (interp - 1.0) + (X * TILE_DIM) * cs;
-        y = py * cs + (Y * TILE_DIM) * cs;
-      } else {
-        x = px * cs + (X * TILE_DIM) * cs;
-        y = py * cs + cs * (interp - 1.0) + (Y * TILE_DIM) * cs;
-      }
-      occ_mark(g, out, x, y, inflate, factor);
-      n++;
+  for (unsigned k = blockIdx.x / OCC_SHARDS; k < n_sh; k += gridDim.x / OCC_SHARDS) {
+    const int p = (int)list[sh * cap + k];
+    const int X = p % PX, Y = p / PX;
+    {
+      const tsd_cell_t* Tg = g.tsd + (size_t)p * TILE_STRIDE;
+      for (int i = threadIdx.x; i < TILE_CELLS; i += 256) T[canonical_of_off(i)] = ld_tsd(Tg + i);   // LDS copy in the 33 x 33 form
     }
+    __syncthreads();
+    // row scans: py in 0..32, px in 1..32 (:38-60); column scans: px in 0..32, py in 1..32 (:62-80)
+    for (int c = threadIdx.x; c < 2 * TILE_PITCH * TILE_DIM; c += 256) {
+      const bool col = c >= TILE_PITCH * TILE_DIM;
+      const int cc = col ? c - TILE_PITCH * TILE_DIM : c;
+      const int a = cc / TILE_DIM;          // fixed index 0..32
+      const int b = cc % TILE_DIM + 1;      // running index 1..32
+      const int py = col ? b : a, px = col ? a : b;
+      const double prev = col ? T[(py - 1) * TILE_PITCH + px] : T[py * TILE_PITCH + px - 1];
+      const double cur = T[py * TILE_PITCH + px];
+      if ((prev > 0 && cur < 0) || (prev < 0 && cur > 0)) {
+        const double interp = prev / (prev - cur);
+        double x, y;
+        if (!col) {
+          x = px * cs + cs * (interp - 1.0) + (X * TILE_DIM) * cs;
+          y = py * cs + (Y * TILE_DIM) * cs;
+        } else {
+          x = px * cs + (X * TILE_DIM) * cs;
+          y = py * cs + cs * (interp - 1.0) + (Y * TILE_DIM) * cs;
+        }
+        occ_mark(g, out, x, y, inflate, factor);
+        n++;
+      }
+    }
+    __syncthreads();            // (the LDS copy is rewritten by the next tile)
   }
   n = wave_sum_i(n);
   if ((threadIdx.x & 63) == 0 && n) atomicAdd(count, n);
@@ -164,14 +179,18 @@ int launch_color_image(tsd_ctx* ctx, const double* d_px, const double* d_py, uns
   return TSD_OK;
 }
 
+size_t occ_heads_bytes() { return OCC_SHARDS * OCC_HEAD_STRIDE * sizeof(unsigned int); }
+
 int launch_occupancy(tsd_ctx* ctx, int8_t* d_out, int inflate, int inflate_factor)
 {
   ScopedKernelTimer t(ctx, "occupancy", true);
   TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_occ_count, 0, sizeof(int), ctx->stream));
+  TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_occ_heads, 0, OCC_SHARDS * OCC_HEAD_STRIDE * sizeof(unsigned int), ctx->stream));
   hipLaunchKernelGGL(k_occ_cells, dim3(ctx->grid.tiles), dim3(256), 0, ctx->stream, ctx->grid,
-                     ctx->d_occ, d_out);
-  hipLaunchKernelGGL(k_occ_mark, dim3(ctx->grid.tiles), dim3(256), 0, ctx->stream, ctx->grid, d_out,
-                     ctx->d_occ_count, inflate, inflate_factor);
+                     ctx->d_occ, d_out, ctx->d_occ_heads, ctx->d_occ_list);
+  const int mark_groups = ctx->grid.tiles < 2048 ? ((ctx->grid.tiles + OCC_SHARDS - 1) / OCC_SHARDS) * OCC_SHARDS : 2048;   // a multiple of the shards
+  hipLaunchKernelGGL(k_occ_mark, dim3(mark_groups), dim3(256), 0, ctx->stream, ctx->grid, d_out,
+                     ctx->d_occ_count, inflate, inflate_factor, ctx->d_occ_heads, ctx->d_occ_list);
   TSD_HIP_CHECK(ctx, hipGetLastError());
   return TSD_OK;
 }

@@ -1031,8 +1031,8 @@ k_push_halo(GridDev g, uint8_t* __restrict__ dirty, unsigned long long* __restri
     // job 2 (lanes 0 and 32 only): the corner cells
     size_t src[3], dst[3]; bool on[3];
     if (colhalf) {
-      on[0] = fR != 0;  src[0] = (size_t)(p + 1) * TILE_STRIDE + EDGE_COL + i;           dst[0] = own + HALO_COL + i;      // (the packed copy of column 0)
-      on[1] = fL != 0;  src[1] = own + EDGE_COL + i;                                   dst[1] = (size_t)(p - 1) * TILE_STRIDE + HALO_COL + i;
+      on[0] = fR != 0;  src[0] = (size_t)(p + 1) * TILE_STRIDE + (size_t)i * TILE_DIM;  dst[0] = own + HALO_COL + i;
+      on[1] = fL != 0;  src[1] = own + (size_t)i * TILE_DIM;                           dst[1] = (size_t)(p - 1) * TILE_STRIDE + HALO_COL + i;
       on[2] = lane == 0 && fUR != 0; src[2] = (size_t)(p + PX + 1) * TILE_STRIDE;      dst[2] = own + HALO_ROW + TILE_DIM;
     } else {
       on[0] = fU != 0;  src[0] = (size_t)(p + PX) * TILE_STRIDE + i;                   dst[0] = own + HALO_ROW + i;
@@ -1066,9 +1066,8 @@ k_free_footprint(GridDev g, unsigned minX, unsigned maxX, unsigned minY, unsigne
     const unsigned lx = (unsigned)(can % TILE_PITCH), ly = (unsigned)(can / TILE_PITCH);
     const unsigned col = tx * TILE_DIM + lx, row = ty * TILE_DIM + ly;
     const bool inside = lx < TILE_DIM && ly < TILE_DIM && col >= minX && col < maxX && row >= minY && row < maxY;
-    const bool edge = i < TILE_INTERIOR && (i & (TILE_DIM - 1)) == 0;        // a cell of column 0: its packed copy follows it
-    if (inside) { st_tsd(T + i, 1.0); if (edge) st_tsd(T + EDGE_COL + (i >> 5), 1.0); if (fresh) { st_w(W + i, iw); if (edge) st_w(W + EDGE_COL + (i >> 5), iw); } }
-    else if (fresh) st_cell(T, W, i, t_init, iw);
+    if (inside) { st_tsd(T + i, 1.0); if (fresh) st_w(W + i, iw); }
+    else if (fresh) { st_tsd(T + i, t_init); st_w(W + i, iw); }
   }
   __syncthreads();            // every thread has read `fresh`
   if (tid == 0) {

@@ -24,36 +24,61 @@ __device__ __forceinline__ void d_mat3_mul(const double A[9], const double B[9],
   for (int i = 0; i < 9; i++) C[i] = R[i];
 }
 
-// same elimination order as tsd::mat3_inv on the host (capi.hip)
+// 3 x 3 LU with partial pivoting (first maximum), rows in REGISTERS: the textbook loops index the rows and the permutation with the
+// pivot found at run time, which the compiler can only do through scratch memory (private_segment 96 B per lane in every k_icp
+// instantiation of round 2, a chain of dependent scratch round trips at the end of each registration).  Here the two possible row
+// exchanges are conditional swaps of named values; the arithmetic and its order are those of gsl_linalg_LU_decomp.
+struct Lu3 {
+  double r0[3], r1[3], r2[3];       // rows of L\U after elimination (L below the diagonal)
+  int p0, p1, p2;                   // row i of the factorisation is row p_i of A
+};
+__device__ __forceinline__ void lu3_swap(double (&a)[3], double (&b)[3], int& pa, int& pb, bool doit)
+{
+#pragma unroll
+  for (int k = 0; k < 3; k++) { const double x = a[k], y = b[k]; a[k] = doit ? y : x; b[k] = doit ? x : y; }
+  const int t = pa; pa = doit ? pb : pa; pb = doit ? t : pb;
+}
+__device__ __forceinline__ Lu3 lu3_decomp(const double A[9])
+{
+  Lu3 f;
+#pragma unroll
+  for (int k = 0; k < 3; k++) { f.r0[k] = A[k]; f.r1[k] = A[3 + k]; f.r2[k] = A[6 + k]; }
+  f.p0 = 0; f.p1 = 1; f.p2 = 2;
+  {  // column 0: pivot = first row of maximal |.|
+    int piv = 0; double best = fabs(f.r0[0]);
+    if (fabs(f.r1[0]) > best) { best = fabs(f.r1[0]); piv = 1; }
+    if (fabs(f.r2[0]) > best) { piv = 2; }
+    lu3_swap(f.r0, f.r1, f.p0, f.p1, piv == 1);
+    lu3_swap(f.r0, f.r2, f.p0, f.p2, piv == 2);
+    f.r1[0] = f.r1[0] / f.r0[0]; f.r1[1] -= f.r1[0] * f.r0[1]; f.r1[2] -= f.r1[0] * f.r0[2];
+    f.r2[0] = f.r2[0] / f.r0[0]; f.r2[1] -= f.r2[0] * f.r0[1]; f.r2[2] -= f.r2[0] * f.r0[2];
+  }
+  {  // column 1
+    lu3_swap(f.r1, f.r2, f.p1, f.p2, fabs(f.r2[1]) > fabs(f.r1[1]));
+    f.r2[1] = f.r2[1] / f.r1[1]; f.r2[2] -= f.r2[1] * f.r1[2];
+  }
+  return f;
+}
+// x = A^-1 b for b already permuted (b0 = b[p0] ...): unit-lower forward substitution, upper back substitution
+__device__ __forceinline__ void lu3_solve_permuted(const Lu3& f, double b0, double b1, double b2, double& x0, double& x1, double& x2)
+{
+  x0 = b0; x1 = b1; x2 = b2;
+  x1 -= f.r1[0] * x0;
+  x2 -= f.r2[0] * x0; x2 -= f.r2[1] * x1;
+  x2 = x2 / f.r2[2];
+  x1 -= f.r1[2] * x2; x1 = x1 / f.r1[1];
+  x0 -= f.r0[1] * x1; x0 -= f.r0[2] * x2; x0 = x0 / f.r0[0];
+}
+
+// same elimination order as tsd::mat3_inv on the host (capi.hip): obvious::Matrix::invert (gsl/Matrix.cpp:168-179)
 __device__ inline void d_mat3_inv(const double A[9], double Ainv[9])
 {
-  double lu[9];
-  int perm[3] = {0, 1, 2};
-  for (int i = 0; i < 9; i++) lu[i] = A[i];
-  for (int j = 0; j < 3; j++) {
-    int piv = j;
-    double best = fabs(lu[3 * j + j]);
-    for (int i = j + 1; i < 3; i++)
-      if (fabs(lu[3 * i + j]) > best) { best = fabs(lu[3 * i + j]); piv = i; }
-    if (piv != j) {
-      for (int k = 0; k < 3; k++) { const double t = lu[3 * j + k]; lu[3 * j + k] = lu[3 * piv + k]; lu[3 * piv + k] = t; }
-      const int t = perm[j]; perm[j] = perm[piv]; perm[piv] = t;
-    }
-    for (int i = j + 1; i < 3; i++) {
-      lu[3 * i + j] = lu[3 * i + j] / lu[3 * j + j];
-      for (int k = j + 1; k < 3; k++) lu[3 * i + k] -= lu[3 * i + j] * lu[3 * j + k];
-    }
-  }
+  const Lu3 f = lu3_decomp(A);
+#pragma unroll
   for (int c = 0; c < 3; c++) {
-    double x[3];
-    for (int i = 0; i < 3; i++) x[i] = (perm[i] == c) ? 1.0 : 0.0;
-    for (int i = 1; i < 3; i++)
-      for (int k = 0; k < i; k++) x[i] -= lu[3 * i + k] * x[k];
-    for (int i = 2; i >= 0; i--) {
-      for (int k = i + 1; k < 3; k++) x[i] -= lu[3 * i + k] * x[k];
-      x[i] = x[i] / lu[3 * i + i];
-    }
-    for (int i = 0; i < 3; i++) Ainv[3 * i + c] = x[i];
+    double x0, x1, x2;
+    lu3_solve_permuted(f, f.p0 == c ? 1.0 : 0.0, f.p1 == c ? 1.0 : 0.0, f.p2 == c ? 1.0 : 0.0, x0, x1, x2);
+    Ainv[c] = x0; Ainv[3 + c] = x1; Ainv[6 + c] = x2;
   }
 }
 
@@ -61,30 +86,11 @@ __device__ inline void d_mat3_inv(const double A[9], double Ainv[9])
 // gsl_linalg_LU_solve (x = P b, unit-lower forward substitution, upper back substitution); 3 x 3
 __device__ inline void d_lu3_solve(const double A[9], const double b[3], double x[3])
 {
-  double lu[9];
-  int perm[3] = {0, 1, 2};
-  for (int i = 0; i < 9; i++) lu[i] = A[i];
-  for (int j = 0; j < 3; j++) {
-    int piv = j;
-    double best = fabs(lu[3 * j + j]);
-    for (int i = j + 1; i < 3; i++)
-      if (fabs(lu[3 * i + j]) > best) { best = fabs(lu[3 * i + j]); piv = i; }
-    if (piv != j) {
-      for (int k = 0; k < 3; k++) { const double t = lu[3 * j + k]; lu[3 * j + k] = lu[3 * piv + k]; lu[3 * piv + k] = t; }
-      const int t = perm[j]; perm[j] = perm[piv]; perm[piv] = t;
-    }
-    for (int i = j + 1; i < 3; i++) {
-      lu[3 * i + j] = lu[3 * i + j] / lu[3 * j + j];
-      for (int k = j + 1; k < 3; k++) lu[3 * i + k] -= lu[3 * i + j] * lu[3 * j + k];
-    }
-  }
-  for (int i = 0; i < 3; i++) x[i] = b[perm[i]];
-  for (int i = 1; i < 3; i++)
-    for (int k = 0; k < i; k++) x[i] -= lu[3 * i + k] * x[k];
-  for (int i = 2; i >= 0; i--) {
-    for (int k = i + 1; k < 3; k++) x[i] -= lu[3 * i + k] * x[k];
-    x[i] = x[i] / lu[3 * i + i];
-  }
+  const Lu3 f = lu3_decomp(A);
+  const double b0 = f.p0 == 0 ? b[0] : (f.p0 == 1 ? b[1] : b[2]);
+  const double b1 = f.p1 == 0 ? b[0] : (f.p1 == 1 ? b[1] : b[2]);
+  const double b2 = f.p2 == 0 ? b[0] : (f.p2 == 1 ? b[1] : b[2]);
+  lu3_solve_permuted(f, b0, b1, b2, x[0], x[1], x[2]);
 }
 
 // ThreadLocalize::calcAngle (ThreadLocalize.cpp:715-726)
@@ -116,13 +122,31 @@ __device__ inline void d_derive_args(SensorDev* st, double gmin_x, double gmax_x
   }
 }
 
+// What the epilogue needs of the sensor's state, read at the START of the registration kernel (its loads then travel with the
+// kernel's input loads) and parked in LDS: the epilogue itself begins without a trip to memory.
+struct ScanPostPre {
+  double pose[9], last[9];
+  double last_angle;          // calcAngle(_lastPose), left by the scan that set _lastPose
+  int have_last, pad;
+};
+__device__ inline void scan_post_preload(const ScanPostArgs& sp, ScanPostPre* pre /* LDS */)
+{
+  const SensorDev* st = sp.st;
+  for (int i = 0; i < 9; i++) { pre->pose[i] = st->pose[i]; pre->last[i] = st->last_pose[i]; }
+  pre->last_angle = st->last_angle; pre->have_last = st->have_last_pose;
+}
+
 // The steps of ThreadLocalize::eventLoop between the registration and the push, run by the whole
-// workgroup that produced T (the epilogue of k_icp in the fused scan path): thread 0 owns the pose
-// bookkeeping, all threads turn the rays.  T = Icp::getFinalTransformation(), n_model = ray-cast hits.
-__device__ inline void scan_post_body(const ScanPostArgs& sp, const double T[9], const IcpResultDev& icp,
+// workgroup that produced T (the epilogue of k_icp in the fused scan path).  T = Icp::getFinalTransformation(), n_model = ray-cast
+// hits.  Three things run SIDE BY SIDE once every thread knows whether the pose moves (isRegistrationError): the rays are turned by
+// all waves but the last; lane 0 of the last wave does the pose bookkeeping and the push gate (isPoseChangeSignificant: libm asin /
+// acos / sin chains); lane 0 of the last-but-one wave inverts the new pose for the next ray cast and this scan's push (an LU with
+// three dependent divisions).  Round 2 ran these one after the other on thread 0, behind a read of the sensor state from memory.
+__device__ inline void scan_post_body(const ScanPostArgs& sp, const ScanPostPre& pre, const double T[9], const IcpResultDev& icp,
                                       double gmin_x, double gmax_x, double gmin_y, double gmax_y)
 {
   SensorDev* st = sp.st;
+  const int W = (int)(blockDim.x >> 6), wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
   const bool no_model = icp.n_model == 0;   // "Raycasting found no coordinates" (ThreadLocalize.cpp:354-358)
   // isRegistrationError (every thread: the ray update below depends on it)
   bool reg_error = false;
@@ -133,11 +157,18 @@ __device__ inline void scan_post_body(const ScanPostArgs& sp, const double T[9],
     reg_error = (trns > sp.gates.reg_trs_max) || (fabs(sin(dphi)) > sp.gates.reg_sin_rot_max);
   }
   const bool moved = !no_model && !reg_error;
-  if (moved) {
-    // Sensor::transform: (*_rays) = R * (*_rays)
+  // workgroup-shared hand-over of the two lone lanes' results (64-byte aligned scratch in the model's LDS would do as well;
+  // static: a few words)
+  __shared__ int s_pushed;
+  __shared__ double s_pose[9];
+  const bool lone_gate = wave == W - 1 && lane == 0;
+  const bool lone_inv = W >= 2 ? (wave == W - 2 && lane == 0) : lone_gate;
+  if (moved && !(W >= 3 && wave >= W - 2)) {
+    // Sensor::transform: (*_rays) = R * (*_rays)   (the last two waves sit this out when there are others)
     double* rays = sp.rays;
     const int beams = sp.beams;
-    for (int i = threadIdx.x; i < beams; i += blockDim.x) {
+    const int nthr = W >= 3 ? (W - 2) * 64 : (int)blockDim.x;
+    for (int i = threadIdx.x; i < beams; i += nthr) {
       const double x = rays[i], y = rays[beams + i];
       double nx = 0.0, ny = 0.0;
       nx += T[0] * x; nx += T[1] * y;
@@ -145,38 +176,63 @@ __device__ inline void scan_post_body(const ScanPostArgs& sp, const double T[9],
       rays[i] = nx; rays[beams + i] = ny;
     }
   }
-  // every wave has turned its rays before thread 0 publishes the sequence numbers: a ray cast of this sensor on ANOTHER stream
-  // (the batched path) is ordered behind this scan only through them
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double pose[9], last[9];
-    for (int i = 0; i < 9; i++) { pose[i] = st->pose[i]; last[i] = st->last_pose[i]; }
+  double cur[9];
+  for (int i = 0; i < 9; i++) cur[i] = pre.pose[i];
+  if (moved && (lone_gate || lone_inv)) d_mat3_mul(pre.pose, T, cur);          // _T = _T * T
+  if (lone_inv) {
+    // pose dependent kernel arguments (d_derive_args): pose^-1 for back projection / ray cast output, sensor position,
+    // RayCastPolar2D's "sensor inside the grid" defaults (RayCastPolar2D.cpp:128-146)
+    if (moved) {
+      double Pi[9];
+      d_mat3_inv(cur, Pi);
+      for (int i = 0; i < 6; i++) { st->rc.Pi[i] = Pi[i]; st->push.Pi[i] = Pi[i]; st->icpP[i] = cur[i]; }
+      const double trx = cur[2], try_ = cur[5];
+      st->rc.trx = trx; st->rc.try_ = try_;
+      st->push.trx = trx; st->push.try_ = try_;
+      if (trx > gmin_x && trx < gmax_x && try_ > gmin_y && try_ < gmax_y) {
+        st->rc.gxmin = -10e9; st->rc.gymin = -10e9; st->rc.gxmax = 10e9; st->rc.gymax = 10e9;
+      } else {
+        st->rc.gxmin = 10e9; st->rc.gymin = 10e9; st->rc.gxmax = -10e9; st->rc.gymax = -10e9;
+      }
+    }
+  }
+  if (lone_gate) {
     // first scan after init: _lastPose = pose before the registration (ThreadLocalize.cpp:342-350)
-    if (!st->have_last_pose) {
-      for (int i = 0; i < 9; i++) { last[i] = pose[i]; st->last_pose[i] = pose[i]; }
+    double last_angle = pre.last_angle;
+    double lastX = pre.last[2], lastY = pre.last[5];
+    if (!pre.have_last) {
+      for (int i = 0; i < 9; i++) st->last_pose[i] = pre.pose[i];
       st->have_last_pose = 1;
+      last_angle = d_calc_angle(pre.pose); lastX = pre.pose[2]; lastY = pre.pose[5];
+      st->last_angle = last_angle;
     }
     int pushed = 0;
     if (moved) {
-      double cur[9];
-      d_mat3_mul(pose, T, cur);                     // _T = _T * T
-      for (int i = 0; i < 9; i++) { pose[i] = cur[i]; st->pose[i] = cur[i]; }
+      for (int i = 0; i < 9; i++) st->pose[i] = cur[i];
       // isPoseChangeSignificant(_lastPose, curPose)
-      const double dX = cur[2] - last[2], dY = cur[5] - last[5];
-      double dphi = d_calc_angle(cur) - d_calc_angle(last);
+      const double dX = cur[2] - lastX, dY = cur[5] - lastY;
+      const double cur_angle = d_calc_angle(cur);
+      double dphi = cur_angle - last_angle;
       dphi = fabs(sin(dphi));
       const double trns = sqrt(dX * dX + dY * dY);
       if (dphi > sp.gates.rot_min || trns > sp.gates.trs_min) {
         pushed = 1;
         for (int i = 0; i < 9; i++) st->last_pose[i] = cur[i];
+        st->last_angle = cur_angle;
       }
-      d_derive_args(st, gmin_x, gmax_x, gmin_y, gmax_y);
     }
     st->push.enabled = pushed;
+    s_pushed = pushed;
+    for (int i = 0; i < 9; i++) s_pose[i] = cur[i];
+  }
+  // every wave has turned its rays and both lone lanes have written the sensor's state before the sequence numbers go out: a ray
+  // cast of this sensor on ANOTHER stream (the batched path) is ordered behind this scan only through them
+  __syncthreads();
+  if (threadIdx.x == 0) {
     ScanResultDev* out = sp.out;
     out->icp = icp;
-    for (int i = 0; i < 9; i++) out->pose[i] = pose[i];
-    out->reg_error = reg_error ? 1 : 0; out->pushed = pushed; out->no_model = no_model ? 1 : 0; out->reserved = 0;
+    for (int i = 0; i < 9; i++) out->pose[i] = s_pose[i];
+    out->reg_error = reg_error ? 1 : 0; out->pushed = s_pushed; out->no_model = no_model ? 1 : 0; out->reserved = 0;
     // `out` is coherent host memory: publish the record, then the sequence number the host polls
     __threadfence_system();
     __hip_atomic_store(&out->seq, sp.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -91,7 +91,8 @@ int probe_cross_stream_wait(tsd_ctx* ctx, hipStream_t a, hipStream_t b, unsigned
   TSD_HIP_CHECK(ctx, hipStreamSynchronize(a));
   TSD_HIP_CHECK(ctx, hipStreamSynchronize(b));
   unsigned int res = 0u;
-  TSD_HIP_CHECK(ctx, hipMemcpy(&res, d_words + 1, sizeof(res), hipMemcpyDeviceToHost));
+  TSD_HIP_CHECK(ctx, hipMemcpyAsync(&res, d_words + 1, sizeof(res), hipMemcpyDeviceToHost, a));       // (not the NULL stream: see tsd_create)
+  TSD_HIP_CHECK(ctx, hipStreamSynchronize(a));
   *ok = res == 1u;
   return TSD_OK;
 }

@@ -69,6 +69,7 @@ struct SensorDev {
   double last_pose[9];       // ThreadLocalize::_lastPose
   int have_last_pose;
   int pad;
+  double last_angle;         // ThreadLocalize::calcAngle(_lastPose), kept with it (the push gate needs it every scan)
   RaycastArgs rc;            // arguments of the NEXT ray cast / registration, derived from `pose`
   double icpP[6];
   PushArgs push;             // arguments of this scan's push (enabled = gate result)
@@ -218,6 +219,8 @@ struct tsd_ctx {
   // occupancy
   int8_t* d_occ = nullptr;       // persistent map (ThreadGrid::_occGridContent)
   int* d_occ_count = nullptr;
+  unsigned int* d_occ_heads = nullptr;   // sharded counters + [tiles] work list of k_occ_mark (occupancy_kernels.hip)
+  uint32_t* d_occ_list = nullptr;
 
 
   // profiling: bit i of profile_mask times kernel i (names in capi.hip: kKernelNames)
@@ -366,6 +369,7 @@ int launch_icp_batch(tsd_ctx* ctx, hipStream_t stream, const IcpBatchEntry* host
 
 int launch_calibrate(tsd_ctx* ctx, double* t, double* w, size_t n);
 int launch_occupancy(tsd_ctx* ctx, int8_t* d_out, int inflate, int inflate_factor);
+size_t occ_heads_bytes();
 int launch_color_image(tsd_ctx* ctx, const double* d_px, const double* d_py, unsigned width, unsigned height, uint8_t* d_image);
 size_t icp_lds_bytes();
 

@@ -8,10 +8,6 @@
 //     [1024, 1056)   halo column  (ix == 32, iy = 0..31)   } the duplicated 1-cell halo of
 //     [1056, 1089)   halo row     (iy == 32, ix = 0..32)   } TsdGridPartition.cpp:97, kept with its stale-halo semantics
 //     [1089, 1120)   padding
-//     [1120, 1152)   EDGE_COL: a packed COPY of interior column 0 (cell (0, iy) at + iy), kept up to date by every writer of those
-//                    cells (st_cell).  The halo refresh needs a neighbour's column 0 -- 32 cells at a 256-byte pitch, one cache line
-//                    per cell and array in the interior -- and reads these 256 contiguous bytes instead (round 2's k_push_halo
-//                    fetched 4-8 x the bytes it wrote).
 // (round 1 kept the reference's 33-cell row pitch: every 256-byte interior row then straddled five 64-byte
 // segments instead of four and the update kernel moved 1.4-1.5 x its algorithmic bytes.)
 // `flags[p]` is TsdGridPartition::_initialized, `init_weight[p]` is _initWeight.  All arithmetic is fp64 in the
@@ -37,8 +33,7 @@ constexpr int TILE_CELLS  = 33 * 33;
 constexpr int TILE_INTERIOR = TILE_DIM * TILE_DIM;
 constexpr int HALO_COL    = TILE_INTERIOR;              // + iy
 constexpr int HALO_ROW    = TILE_INTERIOR + TILE_DIM;   // + ix (0..32)
-constexpr int EDGE_COL    = 1120;                       // + iy: copy of interior cell (0, iy)
-constexpr int TILE_STRIDE = 1152;          // whole 128-byte lines for 4-byte and 8-byte cells
+constexpr int TILE_STRIDE = 1120;          // 1089 rounded up to whole 128-byte lines for 4-byte and 8-byte cells
 constexpr double MAX_WEIGHT = 32.0;        // TSDGRIDMAXWEIGHT, reconstruct_defs.h:4
 
 // device offset of cell (ix, iy), 0..32 each, inside its tile
@@ -73,11 +68,13 @@ __device__ __forceinline__ double ld_w(const w_cell_t* p) { return *p; }
 __device__ __forceinline__ void st_w(w_cell_t* p, double v) { *p = v; }
 #endif
 
-// store one cell (device offset `off` inside the tile) and, when it is a cell of interior column 0, its packed copy
+// store one cell (device offset `off` inside the tile).  (Round 3 tried a packed copy of interior column 0 per tile, kept up to date
+// here, so that the halo refresh reads 256 contiguous bytes instead of 32 cache lines per column: k_push_halo 24.4 -> 13.5 us at
+// cfg3 / comb, but the extra predicate + stores per candidate cost the VALU-bound k_push_update 9 us there and 0.5 us at cfg2, where
+// the halo kernel is a latency chain and gained nothing.  Net zero / negative: taken out again.  profiles/r3_push_update_structure.txt.)
 __device__ __forceinline__ void st_cell(tsd_cell_t* T, w_cell_t* W, int off, double t, double w)
 {
   st_tsd(T + off, t); st_w(W + off, w);
-  if (off < TILE_INTERIOR && (off & (TILE_DIM - 1)) == 0) { st_tsd(T + EDGE_COL + (off >> 5), t); st_w(W + EDGE_COL + (off >> 5), w); }
 }
 
 struct GridDev {
