@@ -626,10 +626,16 @@ def run_slam(args, gc, geo, scene, K, W, every, every_upd, device, rank, local_r
         stream = grid.measure_stream(STREAM_DOUBLES, 5) if (rank == 0 and not args.no_stream) else (None, None)
         if args.calibrate:
             grid.calibrate_rmw(CALIB_DOUBLES, 3)
-        for _ in range(args.occupancy):
-            grid.occupancy(False, 2)
-        occ_ms, occ_n = grid.profile_get("occupancy") if args.occupancy else (0.0, 0)
         pdf_ms, pdf_n = grid.profile_get("tsdpdf")
+        occ_ms, occ_n = 0.0, 0
+        if args.occupancy:
+            # row N1 (occupancy extraction: k_occ_cells + k_occ_mark, events around both) on the map the timed region built
+            grid.occupancy(False, 2)
+            grid.profile(True, kernels="occupancy"); grid.profile_reset()
+            for _ in range(args.occupancy):
+                grid.occupancy(False, 2)
+            occ_ms, occ_n = grid.profile_get("occupancy")
+            grid.profile(False)
 
         pushes_per_step = pushes / max(K * R, 1)
         stage_sum = sum(v * (pushes_per_step if k.startswith("push") else 1.0) for k, v in stages.items() if v is not None)

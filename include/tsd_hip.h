@@ -268,9 +268,14 @@ int tsd_scan_finish(tsd_sensor* s, tsd_scan_result* result);
  *   tsd_batch_results  waits for the records, enqueues the pushes unless tsd_batch_push did, fills results[0..n), frees the slot
  * The sensors of a batch must be distinct, attached to the batch's grid and without a scan in flight; one estimator per batch.
  * Hand-offs inside a batch (ray casts -> registrations, a robot's registration -> its push) are waits on the device (a flag set by
- * a one-wave kernel behind the ray casts; a one-wave gate kernel ahead of each push), which needs the kernels of different streams
- * to run side by side: under rocprofv3 counter collection or blocking launches (ROCPROF_COUNTER_COLLECTION, AMD_SERIALIZE_KERNEL,
- * HIP_LAUNCH_BLOCKING in the environment) or with TSD_BATCH_EVENT_WAIT=1 the library uses stream events instead. */
+ * a one-wave kernel behind the ray casts; a one-wave gate kernel ahead of each push) ONLY where tsd_batch_create's start-up probe has
+ * shown that kernels of the two streams involved run side by side (not a given: HIP maps streams onto a few in-order hardware queues,
+ * profilers and blocking launches serialise dispatches); otherwise stream events.  TSD_BATCH_EVENT_WAIT=1 forces events.
+ * Failure contract (the reference's: "failures are logged and the scan is skipped", ThreadLocalize.cpp:354-358, :381-387): a
+ * device-side wait is bounded, and one that runs out does NOT register or push on stale data -- the robots concerned get
+ * tsd_scan_result.reserved = 1 (timeout) / 2 (batch abandoned), pose and grid untouched, and tsd_batch_results (or the next
+ * tsd_batch_* call on the slot, for a push gate) returns TSD_E_HIP with tsd_last_error() saying so; the slot then uses events, and
+ * slot and sensors stay usable. */
 #define TSD_BATCH_MAX_SCANS 64
 typedef struct tsd_batch tsd_batch;
 tsd_batch* tsd_batch_create(tsd_ctx* ctx, int max_scans);
