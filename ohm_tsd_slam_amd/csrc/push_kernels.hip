@@ -241,8 +241,9 @@ constexpr int TOT_FIELDS = 8;   // cells updated, range pass, update, new, new f
 // tickets alone).  Head h hands out the tiles G + h + TICKET_HEADS * k beyond the G that the G workgroups start with.
 constexpr int CNT_U = 0, CNT_O = 1, TICKET_HEADS = 32, TICKET_STRIDE = 32 /* words */, CNT_TICKET = 32;
 constexpr int CNT_WORDS = CNT_TICKET + TICKET_HEADS * TICKET_STRIDE;
-// What k_push_classify leaves for the workgroup of an UPDATE tile: one 64-byte record (one scalar load), at the entry's own index.
-struct PushListAux {
+// What k_push_classify leaves for the workgroup of an UPDATE tile: one 128-byte record (a cache line, at the entry's own index),
+// fetched as ONE vector register per wave -- lane i holds word i -- and unpacked with v_readlane.
+struct PushListAuxBody {
   uint32_t entry, win;           // the list word (tile | flags | kind << 28); beams the tile's cells can project to: lo | hi << 16
   double pw;                     // partition weight (TsdGrid.cpp:239-243)
   // phase A of k_push_update (fp32 beam estimate), all relative to the tile's centroid c = ((x0 + 16.5) cs, (y0 + 16.5) cs) -- the
@@ -253,9 +254,11 @@ struct PushListAux {
   float lcx, lcy;                // l_c itself (near tiles)
   double iw;                     // the tile's _initWeight and ...
   uint32_t flag, jb0;            // ... _initialized when it was classified (nothing changes them before the tile's own workgroup does);
-                                 // jb0 = max(lo - 1, 0): the boundary whose direction the workgroup fetches for the tile's fix-up
+                                 // jb0 = max(lo - 1, 0): the boundary the tile's fix-up starts from, and ...
+  double2 bd;                    // ... its direction (cos, sin)(beta_jb0), words 16..19
 };
-static_assert(sizeof(PushListAux) == 64, "PushListAux");
+struct alignas(128) PushListAux : PushListAuxBody {};      // (the writer stores the 80 bytes of the body only)
+static_assert(sizeof(PushListAuxBody) == 80 && sizeof(PushListAux) == 128, "PushListAux");
 
 // ---- beam index of a cell without the fp64 atan2 ------------------------------------------------------------
 // SensorPolar2D::backProject (SensorPolar2D.cpp:117-135) decides round((atan2(ly, lx) - phi_min) / res) and the two
@@ -329,6 +332,7 @@ k_push_classify(GridDev g, const PushArgs* __restrict__ a_dev, const char* __res
   double pw = 0.0;
   double tcx = 0.0, tcy = 0.0;                               // the tile's centroid (UPDATE tiles)
   uint32_t win = (uint32_t)(a.beams - 1) << 16;              // beams the cells of the tile can project to: lo | hi << 16
+  double2 bd0 = make_double2(1.0, 0.0);                      // direction of boundary jb0 = max(lo - 1, 0) of a far tile, 0 of a near one
   if (in_window && a.enabled) {
     double e[4][2], cx, cy, rad;
     tile_geometry(g, p, e, cx, cy, rad);
@@ -360,6 +364,8 @@ k_push_classify(GridDev g, const PushArgs* __restrict__ a_dev, const char* __res
         lo = lo2 < lo ? lo2 : lo; hi = hi2 > hi ? hi2 : hi;
         all_vis = all_vis && av2 != 0; any_vis = any_vis || an2 != 0;
       }
+      // (requested here, next to the table look-ups below, used when the record is written)
+      bd0 = rmq_view(const_cast<char*>(rmq_buf), a.beams).bdir[(distance > 3.0 * rad && lo > 1) ? lo - 1 : 0];
       int action = 0;
       if (any_vis) {
         const RmqView rv = rmq_view(const_cast<char*>(rmq_buf), a.beams);
@@ -437,7 +443,7 @@ k_push_classify(GridDev g, const PushArgs* __restrict__ a_dev, const char* __res
     if (kind == KIND_UPDATE) {
       const unsigned int slot = base_u + (unsigned)__popcll(ub & lt);
       list[slot] = word;
-      PushListAux x;
+      PushListAuxBody x;
       x.entry = word; x.win = win; x.pw = pw;
       // the linear forms of k_push_update's phase A (see PushListAux): fp64 here, once per tile, instead of fp32 in every lane there
       const double lcx = a.Pi[0] * tcx + a.Pi[1] * tcy + a.Pi[2], lcy = a.Pi[3] * tcx + a.Pi[4] * tcy + a.Pi[5];
@@ -449,7 +455,8 @@ k_push_classify(GridDev g, const PushArgs* __restrict__ a_dev, const char* __res
       x.th_c = atan2_estimate(x.lcy, x.lcx);
       x.iw = t_iw; x.flag = t_flag;
       x.jb0 = (win & 0xFFFFu) > 0u ? (win & 0xFFFFu) - 1u : 0u;
-      list_aux[slot] = x;
+      x.bd = bd0;
+      static_cast<PushListAuxBody&>(list_aux[slot]) = x;
     }
   }
 }
@@ -538,7 +545,7 @@ __host__ __device__ inline size_t update_lds_bytes(int beams)
 {
   const size_t bp = (size_t)((beams + 3) & ~3);
   return bp * sizeof(double) + 2 * 2 * TILE_DIM * sizeof(double) + ROT_N * sizeof(double2) + bp * sizeof(float) +
-         2 * UPD_CAND_MAX * sizeof(uint32_t) + (UPDATE_BLOCK / 64) * 256 * sizeof(uint32_t);
+         2 * UPD_CAND_MAX * sizeof(uint32_t);
 }
 
 // Workgroup barrier that orders LDS only.  __syncthreads() also drains the wave's global-memory counter (s_waitcnt vmcnt(0)): every
@@ -636,9 +643,30 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
 #endif
   unsigned int* const cntw = list_cnt + CNT_WORDS * parity;
   const unsigned int n_upd_tiles = cntw[CNT_U], n_other = cntw[CNT_O];
-  const PushListAux first_aux = list_aux[blockIdx.x];           // read speculatively: arrives with the list lengths and the arguments
+  const int tid = threadIdx.x, lane = tid & 63;
+  // A tile's list record travels as ONE vector register per wave (lane i holds dword i of the 64-byte record) from the request to
+  // the tile's turn, its boundary direction likewise: requested a tile ahead, unpacked by v_readlane when the tile starts.  (As
+  // scalar loads the compiler moves the requests to the point of first use and, short of scalar registers, waits for them on the
+  // spot -- two memory round trips at the head of every tile, ~1.3 us of a tile's ~7 at cfg 3.)
+  auto rec_request = [&](unsigned i) { return reinterpret_cast<const uint32_t*>(list_aux + i)[lane & 31]; };
+  auto rec_word = [&](uint32_t v, int k) { return (uint32_t)__builtin_amdgcn_readlane((int)v, k); };
+  auto rec_unpack = [&](uint32_t v) {
+    PushListAux x;
+    x.entry = rec_word(v, 0); x.win = rec_word(v, 1);
+    x.pw = __hiloint2double((int)rec_word(v, 3), (int)rec_word(v, 2));
+    x.A = __uint_as_float(rec_word(v, 4)); x.B = __uint_as_float(rec_word(v, 5)); x.C = __uint_as_float(rec_word(v, 6)); x.D = __uint_as_float(rec_word(v, 7));
+    x.lc2 = __uint_as_float(rec_word(v, 8)); x.th_c = __uint_as_float(rec_word(v, 9)); x.lcx = __uint_as_float(rec_word(v, 10)); x.lcy = __uint_as_float(rec_word(v, 11));
+    x.iw = __hiloint2double((int)rec_word(v, 13), (int)rec_word(v, 12));
+    x.flag = rec_word(v, 14); x.jb0 = rec_word(v, 15);
+    return x;
+  };
+  auto bd_unpack = [&](uint32_t v) {
+    double2 d;
+    d.x = __hiloint2double((int)rec_word(v, 17), (int)rec_word(v, 16)); d.y = __hiloint2double((int)rec_word(v, 19), (int)rec_word(v, 18));
+    return d;
+  };
+  const uint32_t first_v = rec_request(blockIdx.x);             // read speculatively: arrives with the list lengths and the arguments
   const PushArgs a = *a_dev;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int Bp = (a.beams + 3) & ~3;
   double* s_ranges = reinterpret_cast<double*>(smem);                      // [Bp]
@@ -646,8 +674,8 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
   double2* s_rot = reinterpret_cast<double2*>(s_d2 + 4 * TILE_DIM);        // [ROT_N] (cos, sin)(k * res)
   float* s_lim = reinterpret_cast<float*>(s_rot + ROT_N);                  // [Bp] beam_limit of every staged beam
   uint32_t* s_cand = reinterpret_cast<uint32_t*>(s_lim + Bp);              // [2][1024] candidates by tile number & 1: cell | beam << 10
-  uint32_t* s_uns = s_cand + 2 * UPD_CAND_MAX + wave * 256;                // [256] this wave's undecided cells: cell | jb << 10
-  __shared__ unsigned int s_cnt[3][2];                                     // by tile number % 3: candidates listed, cells updated
+  __shared__ unsigned long long s_cu[3];                                   // by tile number % 3: candidates listed (low word) | undecided cells listed (high word)
+  __shared__ unsigned int s_upd[3];                                        // cells updated
   __shared__ unsigned long long s_neg[3];                                  // groups of the tile that received a negative value
   __shared__ unsigned int s_tk[4];                                         // list index of tile number n at [n & 3]
   const double max_trunc = g.max_trunc;
@@ -675,8 +703,11 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
     }
     // The scan is staged once per workgroup: only the beams the tile can project to when the workgroup has a single tile (the
     // usual case), all of them when it may take several.  Beams outside the staged window go to global memory.
+    uint32_t xc_v = first_v;                              // tile n's record
+    PushListAux xc = rec_unpack(xc_v);
     int wlo = 0, whi = a.beams - 1;
     if (!more_than_one) {
+      const PushListAux& first_aux = xc;
       wlo = (int)(first_aux.win & 0xFFFFu) - 1; whi = (int)(first_aux.win >> 16) + 1;
       if (wlo < 0) wlo = 0;
       if (whi > a.beams - 1) whi = a.beams - 1;
@@ -700,7 +731,7 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
       }
     }
     if (tid < ROT_N) s_rot[tid] = rot[tid];
-    if (tid < 3) { s_cnt[tid][0] = 0u; s_cnt[tid][1] = 0u; s_neg[tid] = 0ull; }
+    if (tid < 3) { s_cu[tid] = 0ull; s_upd[tid] = 0u; s_neg[tid] = 0ull; }
     lds_barrier();                     // scan staged, counters zeroed, first tickets in place
     PSTAMP(0);
 
@@ -710,10 +741,9 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
     const float dxc = (float)ix - 16.0f;
 
     // ---- phase A of tile number `n` (list record `x`): fills candidate list / counters / distance tables of that tile number
-    auto phase_a = [&](unsigned n, const PushListAux& x, const TileC& tc, const double2 bd0 /* direction of boundary x.jb0 */) {
+    auto phase_a = [&](unsigned n, const PushListAux& x, const TileC& tc, const unsigned x0, const unsigned y0) {
       uint32_t* cand_list = s_cand + (n & 1u) * UPD_CAND_MAX;
-      unsigned int* cnt = s_cnt[n % 3u];
-      const unsigned x0 = (unsigned)(tc.p % g.PX) * TILE_DIM, y0 = (unsigned)(tc.p / g.PX) * TILE_DIM;
+      unsigned long long* cnt = &s_cu[n % 3u];
       const double t_init = (tc.iw > 0.0) ? 1.0 : __builtin_nan("");      // TsdGridPartition::init values (TsdGridPartition.cpp:98-120)
       // the two squares of the exact cell distance depend on the column / the row only: one lane each, once per tile
       if (tid < 2 * TILE_DIM) {
@@ -743,6 +773,10 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
         idx[k] = unsure ? jb : index;
       }
       PSTAMP(6);     // (sub-phase: d2 table, setup, classification)
+#if defined(TSD_ABLATE) && (TSD_ABLATE & 8)      // instruction-count ablation (tools/push_ablate_r3.sh; results are WRONG): classification only
+      if (idx[0] + idx[1] + idx[2] + idx[3] + (int)(um + om) + (int)(d2f[0] + d2f[1] + d2f[2] + d2f[3]) == 0x7fffffff) dbg[0] = 1.0;
+      return;
+#endif
       // the beams' limits from LDS, the four reads in flight together; a beam outside the staged window -- possible only through
       // rounding at the window's ends -- is fetched from global memory by the lanes concerned
       float lim[UPD_CPT];
@@ -771,87 +805,36 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
 #endif
       }
       PSTAMP(7);     // (sub-phase: limits, candidate test, fresh stores)
-      // compaction: one LDS atomic per wave for its candidates of all four strips; the undecided cells into the wave's own list
+      // compaction: ONE LDS atomic per wave for its cells of all four strips -- the candidates go to the front of the tile's list, the
+      // undecided cells (cell | boundary << 10) to its back; the exact part settles those, densely, behind the barrier
       unsigned nc = 0u, nu = 0u;
 #pragma unroll
       for (int k = 0; k < UPD_CPT; k++) { nc += (unsigned)__popcll(__ballot((cm >> k) & 1u)); nu += (unsigned)__popcll(__ballot((um >> k) & 1u)); }
-      unsigned base = 0u;
-      if (nc) { if (lane == 0) base = atomicAdd(&cnt[0], nc); base = (unsigned)__builtin_amdgcn_readfirstlane((int)base); }
-      unsigned ub = 0u;
+#if defined(TSD_ABLATE) && (TSD_ABLATE & 1)      // ablation: no fix-up
+      nu = 0u; um = 0u;
+#endif
+      unsigned base = 0u, ub = 0u;
+      if (nc | nu) {
+        unsigned long long got = 0ull;
+        if (lane == 0) got = atomicAdd(cnt, (unsigned long long)nc | ((unsigned long long)nu << 32));
+        base = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)got);
+        ub = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(got >> 32));
+      }
 #pragma unroll
       for (int k = 0; k < UPD_CPT; k++) {
         const unsigned long long bc = __ballot((cm >> k) & 1u), bu = __ballot((um >> k) & 1u);
         const uint32_t e = (uint32_t)(c0 + UPDATE_BLOCK * k) | ((uint32_t)idx[k] << 10);
         if ((cm >> k) & 1u) cand_list[base + (unsigned)__popcll(bc & lt)] = e;
-        if ((um >> k) & 1u) s_uns[ub + (unsigned)__popcll(bu & lt)] = e;
+        if ((um >> k) & 1u) cand_list[(unsigned)(UPD_CAND_MAX - 1) - (ub + (unsigned)__popcll(bu & lt))] = e;
         base += (unsigned)__popcll(bc); ub += (unsigned)__popcll(bu);
       }
       PSTAMP(8);     // (sub-phase: compaction)
-      // ---- fix-up of the wave's undecided cells, one lane each (LDS executes a wave's accesses in order: no barrier)
-      for (unsigned q0 = 0u; q0 < nu; q0 += 64u) {
-        const unsigned q = q0 + (unsigned)lane;
-        const bool on = q < nu;
-        const uint32_t e = on ? s_uns[q] : 0u;
-        const int c = (int)(e & 1023u);
-        const int jbq = (int)(e >> 10);
-        const double ccx = ((double)(x0 + ((unsigned)c & 31u)) + 0.5) * g.cs;   // TsdGridPartition.cpp:127-128
-        const double ccy = ((double)(y0 + ((unsigned)c >> 5)) + 0.5) * g.cs;
-        // PoseInv * (x, y, 1)^T as SensorPolar2D::backProject forms it (dgemm order)
-        double lx = 0.0, ly = 0.0;
-        lx += a.Pi[0] * ccx; lx += a.Pi[1] * ccy; lx += a.Pi[2] * 1.0;
-        ly += a.Pi[3] * ccx; ly += a.Pi[4] * ccy; ly += a.Pi[5] * 1.0;
-        int index = -1;
-        bool hard = on && jbq == IDX_CUT;
-        const double l2 = lx * lx + ly * ly;
-        if (on && !hard) {
-          // the boundary's direction: beta_jb0 (from the tile's record) turned by (jb - jb0) * res -- a table in LDS.  No global read
-          // here: a wave's memory operations complete in order, and a wait in the middle of phase A would also wait for the cell
-          // reads of the previous tile that this phase is there to overlap.  (Near tiles see the whole scan: the global table.)
-          const int kr = jbq - (int)x.jb0;
-          double2 bd;
-          if (__builtin_expect(kr >= 0 && kr < ROT_N, 1)) { const double2 rc = s_rot[kr]; bd.x = bd0.x * rc.x - bd0.y * rc.y; bd.y = bd0.y * rc.x + bd0.x * rc.y; }
-          else bd = bdir[jbq];
-          const double cr = bd.x * ly - bd.y * lx;                  // |l| sin(angle - beta_jb)
-          if (cr * cr > 1e-22 * l2) {
-            // beyond the boundary (phi > beta): beam jb, or past phi_upper (-1); before it: beam jb - 1, or before phi_lower (-2 -> negative)
-            index = cr > 0.0 ? (jbq < a.beams ? jbq : -1) : jbq - 1;
-          } else hard = true;
-        }
-        if (__builtin_expect(__any(hard), 0)) {
-          // within 1e-11 rad of a boundary, or at the cut: the reference's own formulation decides (fp64 atan2, bound checks, round)
-          if (hard) index = backproject_cold(a_dev, ccx, ccy);
-        }
-#ifdef TSD_PUSH_VERIFY_INDEX
-        if (on) {
-          const int ex = backproject(a.Pi, ccx, ccy, a.phi_min, a.ang_res_inv, a.phi_lower, a.phi_upper);
-          if (index < 0 ? ex >= 0 : ex != index) atomicAdd(reinterpret_cast<unsigned long long*>(dbg + 1003), 1ull);
-          if (hard) atomicAdd(reinterpret_cast<unsigned long long*>(dbg + 1004), 1ull);
-        }
-#endif
-        bool cand = false;
-        if (on && index >= 0) {
-          const int il = min(max(index, wlo), whi);
-          float lm = s_lim[il];
-          asm volatile("" : "+v"(lm));
-          if (__builtin_expect(il != index, 0)) lm = beam_limit(ranges[index], (unsigned)mask[index], ta.mt, ta.low2);
-          cand = !((float)l2 > lm * 1.00001f);         // (|l|^2 from the fp64 vector here: within 1e-7 of phase A's fp32 form; the margin covers it)
-        }
-        if (tc.fresh && on && !cand) st_cell(tc.T, tc.W, c, t_init, tc.iw);
-        const unsigned long long bq = __ballot(cand);
-        if (bq) {
-          unsigned b2 = 0u;
-          if (lane == 0) b2 = atomicAdd(&cnt[0], (unsigned)__popcll(bq));
-          b2 = (unsigned)__builtin_amdgcn_readfirstlane((int)b2);
-          if (cand) cand_list[b2 + (unsigned)__popcll(bq & lt)] = (uint32_t)c | ((uint32_t)index << 10);
-        }
-      }
       if (tc.fresh) {
         // halo cells of a freshly materialised tile keep the init value until k_push_halo
         for (int h = tid; h < 2 * TILE_DIM + 1; h += UPDATE_BLOCK) {      // the halo strip: column 32, then row 32
           st_tsd(tc.T + HALO_COL + h, t_init); st_w(tc.W + HALO_COL + h, tc.iw);
         }
       }
-      PSTAMP(9);     // (sub-phase: fix-up)
     };
     auto tile_of = [&](const PushListAux& x) {
       TileC tc;
@@ -869,38 +852,101 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
     const double inv_max_trunc = 1.0 / max_trunc;
     const double eps = -g.cs / 2.0;
     unsigned i_cur = blockIdx.x, i_next = s_tk[1];        // list indices of tiles n / n + 1 (>= n_upd_tiles: none)
-    PushListAux xc = first_aux;                           // their records
-    PushListAux xn = list_aux[i_next < n_upd_tiles ? i_next : 0u];
-    double2 bdc = bdir[xc.jb0];                           // direction of tile n's boundary jb0 (a scalar read)
+    uint32_t xn_v = rec_request(i_next < n_upd_tiles ? i_next : 0u);        // tile n + 1's record, in flight
     for (unsigned n = 0u; i_cur < n_upd_tiles; n++) {
       const unsigned slot = n % 3u;
-      // tile n + 1's boundary direction: its record arrived during the previous tile, this scalar read arrives during this one
-      const double2 bdn = bdir[xn.jb0];
       // thread 0: the ticket of tile n + 2, consumed at the end of this tile
       if (tid == 0 && more_than_one) tk_pending = draw();
       const TileC tcur = tile_of(xc);
-      phase_a(n, xc, tcur, bdc);
+      const unsigned x0 = (unsigned)(tcur.p % g.PX) * TILE_DIM, y0 = (unsigned)(tcur.p / g.PX) * TILE_DIM;
+      phase_a(n, xc, tcur, x0, y0);
       PSTAMP(1);
+      // tile n + 1's record and the ticket of tile n + 2 were requested a whole phase A ago: the wave takes delivery HERE, where that
+      // costs nothing -- at their points of use (behind the exact part) the same wait would also sit out the tile's own stores
+      asm volatile("" : "+v"(xn_v), "+v"(tk_pending));
       lds_barrier();
       PSTAMP(2);
-      const unsigned n_cand = s_cnt[slot][0];
-      const uint32_t* cand_list = s_cand + (n & 1u) * UPD_CAND_MAX;
+      const unsigned long long cu = s_cu[slot];
+#if defined(TSD_ABLATE) && (TSD_ABLATE & 2)      // ablation: no exact part
+      const unsigned n_cand = 0u, n_uns = 0u;
+#else
+      const unsigned n_cand = (unsigned)cu, n_uns = (unsigned)(cu >> 32);
+#endif
+      const unsigned n_tot = n_cand + n_uns;
+      uint32_t* cand_list = s_cand + (n & 1u) * UPD_CAND_MAX;
       const double* d2x = s_d2 + (n & 1u) * 2 * TILE_DIM;
       const double t_init = (tcur.iw > 0.0) ? 1.0 : __builtin_nan("");
-      // the exact part: UPD_CB cells per lane and pass, their reads in flight together
+      // ---- fix-up of the tile's undecided cells (~4 % of the cells: one partly filled wave per tile), one lane each, in place: entry
+      // n_cand + u of the exact part below lives at list[1023 - u] and is settled here BY THE THREAD THAT WILL READ IT there (an LDS
+      // hand-off inside one lane: no barrier).  The side of the boundary direction beta_jb the cell's fp64 sensor-frame vector lies on
+      // -- the sign of |l| sin(angle - beta) = bx ly - by lx -- names the reference's beam unless |sin| < 1e-11.
+      for (unsigned u = ((unsigned)tid - n_cand) & (unsigned)(UPDATE_BLOCK - 1); u < n_uns; u += UPDATE_BLOCK) {
+        const uint32_t e = cand_list[(unsigned)(UPD_CAND_MAX - 1) - u];
+        const int c = (int)(e & 1023u);
+        const int jbq = (int)(e >> 10);
+        const double ccx = ((double)(x0 + ((unsigned)c & 31u)) + 0.5) * g.cs;   // TsdGridPartition.cpp:127-128
+        const double ccy = ((double)(y0 + ((unsigned)c >> 5)) + 0.5) * g.cs;
+        // PoseInv * (x, y, 1)^T as SensorPolar2D::backProject forms it (dgemm order)
+        double lx = 0.0, ly = 0.0;
+        lx += a.Pi[0] * ccx; lx += a.Pi[1] * ccy; lx += a.Pi[2] * 1.0;
+        ly += a.Pi[3] * ccx; ly += a.Pi[4] * ccy; ly += a.Pi[5] * 1.0;
+        int index = -1;
+        bool hard = jbq == IDX_CUT;
+        const double l2 = lx * lx + ly * ly;
+        if (!hard) {
+          // the boundary's direction: beta_jb0 (from the tile's record) turned by (jb - jb0) * res -- a table in LDS; near tiles see the
+          // whole scan: the global table
+          const int kr = jbq - (int)xc.jb0;
+          const double2 bdc = bd_unpack(xc_v);
+          double2 bd;
+          if (__builtin_expect(kr >= 0 && kr < ROT_N, 1)) { const double2 rc = s_rot[kr]; bd.x = bdc.x * rc.x - bdc.y * rc.y; bd.y = bdc.y * rc.x + bdc.x * rc.y; }
+          else bd = bdir[jbq];
+          const double cr = bd.x * ly - bd.y * lx;                  // |l| sin(angle - beta_jb)
+          if (cr * cr > 1e-22 * l2) {
+            // beyond the boundary (phi > beta): beam jb, or past phi_upper (-1); before it: beam jb - 1, or before phi_lower (-2 -> negative)
+            index = cr > 0.0 ? (jbq < a.beams ? jbq : -1) : jbq - 1;
+          } else hard = true;
+        }
+        if (__builtin_expect(__any(hard), 0)) {
+          // within 1e-11 rad of a boundary, or at the cut: the reference's own formulation decides (fp64 atan2, bound checks, round)
+          if (hard) index = backproject_cold(a_dev, ccx, ccy);
+        }
+#ifdef TSD_PUSH_VERIFY_INDEX
+        {
+          const int ex = backproject(a.Pi, ccx, ccy, a.phi_min, a.ang_res_inv, a.phi_lower, a.phi_upper);
+          if (index < 0 ? ex >= 0 : ex != index) atomicAdd(reinterpret_cast<unsigned long long*>(dbg + 1003), 1ull);
+          if (hard) atomicAdd(reinterpret_cast<unsigned long long*>(dbg + 1004), 1ull);
+        }
+#endif
+        bool cand = false;
+        if (index >= 0) {
+          const int il = min(max(index, wlo), whi);
+          float lm = s_lim[il];
+          asm volatile("" : "+v"(lm));
+          if (__builtin_expect(il != index, 0)) lm = beam_limit(ranges[index], (unsigned)mask[index], ta.mt, ta.low2);
+          cand = !((float)l2 > lm * 1.00001f);         // (|l|^2 from the fp64 vector here: within 1e-7 of phase A's fp32 form; the margin covers it)
+        }
+        if (tcur.fresh && !cand) st_cell(tcur.T, tcur.W, c, t_init, tcur.iw);
+        cand_list[(unsigned)(UPD_CAND_MAX - 1) - u] = cand ? ((uint32_t)c | ((uint32_t)index << 10)) : 0xFFFFFFFFu;
+      }
+      PSTAMP(9);     // (sub-phase: fix-up)
+      // the exact part: UPD_CB cells per lane and pass, their reads in flight together; a wave skips the cells of a pass none of its
+      // lanes has (a tile's last pass is rarely full)
       unsigned long long wrote_neg = 0ull;
       unsigned n_upd = 0u;
-      for (unsigned q0 = (unsigned)tid; q0 < n_cand; q0 += UPD_CB * UPDATE_BLOCK) {
+      for (unsigned q0 = (unsigned)tid; q0 < n_tot; q0 += UPD_CB * UPDATE_BLOCK) {
         uint32_t ce[UPD_CB]; double tv[UPD_CB], wv[UPD_CB];
 #pragma unroll
         for (int j = 0; j < UPD_CB; j++) {
           const unsigned q = q0 + (unsigned)(j * UPDATE_BLOCK);
-          ce[j] = q < n_cand ? cand_list[q] : 0xFFFFFFFFu;
+          ce[j] = q < n_tot ? cand_list[q < n_cand ? q : (unsigned)(UPD_CAND_MAX - 1) - (q - n_cand)] : 0xFFFFFFFFu;
           tv[j] = t_init; wv[j] = tcur.iw;
-          if (q < n_cand && !tcur.fresh) { tv[j] = ld_tsd(tcur.T + (ce[j] & 1023u)); wv[j] = ld_w(tcur.W + (ce[j] & 1023u)); }
+          if (ce[j] != 0xFFFFFFFFu && !tcur.fresh) { tv[j] = ld_tsd(tcur.T + (ce[j] & 1023u)); wv[j] = ld_w(tcur.W + (ce[j] & 1023u)); }
         }
 #pragma unroll
         for (int j = 0; j < UPD_CB; j++) {
+          // (lanes leave the loop from the top down: the first active lane is the wave's lane 0)
+          if (j > 0 && !((unsigned)__builtin_amdgcn_readfirstlane((int)q0) + (unsigned)(j * UPDATE_BLOCK) < n_tot)) break;
           const bool on = ce[j] != 0xFFFFFFFFu;
           const int c = (int)(ce[j] & 1023u);
           const int index = on ? (int)(ce[j] >> 10) : wlo;
@@ -922,16 +968,16 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
       }
       if (wrote_neg) atomicOr(&s_neg[slot], wrote_neg);               // (LDS; folded into the tile's mask below)
       const unsigned wu = (unsigned)wave_sum_i((int)n_upd);
-      if (lane == 0 && wu) atomicAdd(&s_cnt[slot][1], wu);
+      if (lane == 0 && wu) atomicAdd(&s_upd[slot], wu);
       if (tid == 0) s_tk[(n + 2u) & 3u] = more_than_one ? ticket_of(tk_pending) : ~0u;
       PSTAMP(3);
       lds_barrier();               // tile n done by every wave; the next ticket in place
       PSTAMP(4);
       if (tid == 0) {
         // the record of tile n (this slot's counters are next used by tile n + 3: behind two more barriers)
-        const unsigned cells = s_cnt[slot][1];
+        const unsigned cells = s_upd[slot];
         const unsigned long long nm = s_neg[slot];
-        s_cnt[slot][0] = 0u; s_cnt[slot][1] = 0u; s_neg[slot] = 0ull;
+        s_cu[slot] = 0ull; s_upd[slot] = 0u; s_neg[slot] = 0ull;
         uint32_t rec = REC_RANGE_PASS | REC_UPDATE | REC_LISTED;
         if (tcur.fresh) rec |= REC_NEW | (tcur.iw > 0.0 ? REC_NEW_FROM_EMPTY : 0u);
         tile_rec[tcur.p] = rec | (cells << REC_CELLS_SHIFT);
@@ -947,12 +993,15 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
 #endif
       // advance: the record of tile n + 2 is requested now, one tile ahead of its phase A
       i_cur = i_next; i_next = s_tk[(n + 2u) & 3u];
-      xc = xn; bdc = bdn; xn = list_aux[i_next < n_upd_tiles ? i_next : 0u];
+      xc_v = xn_v; xc = rec_unpack(xc_v); xn_v = rec_request(i_next < n_upd_tiles ? i_next : 0u);
       PSTAMP(0);
     }
   }
 
   // ---- the other list: increaseEmptiness of materialised tiles, all 33 x 33 cells, halo included; the average uses the NEW weight
+#if defined(TSD_ABLATE) && (TSD_ABLATE & 4)        // ablation: no increaseEmptiness tiles
+  if (n_other) return;
+#endif
   for (unsigned int k = blockIdx.x; k < n_other; k += gridDim.x) {
     const uint32_t entry = list[(unsigned)g.tiles - 1u - k];
     if ((entry >> KIND_SHIFT) != KIND_EMPTY) continue;
