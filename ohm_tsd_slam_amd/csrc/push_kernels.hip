@@ -988,6 +988,7 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
         if (tcur.fresh) { atomicAdd(&tot[3], 1u); if (tcur.iw > 0.0) atomicAdd(&tot[4], 1u); }
         if (tcur.fresh) g.flags[tcur.p] = 1;   // publish the tile
       }
+      PSTAMP(10);    // (sub-phase: the tile's record)
 #ifdef TSD_PUSH_STAMPS
       st_tiles++;
 #endif
@@ -1385,11 +1386,17 @@ int launch_push(tsd_ctx* ctx, const PushArgs& a, double cx, double cy, double sl
   // list with that stride, and a second round of workgroups would start its whole share of the list when the first round is done
   int per_cu = TSD_UPDATE_WPS;
   { const size_t lds_wg = update_lds_bytes(a.beams) + 64; const int by_lds = (int)((160u * 1024u) / lds_wg); if (by_lds < per_cu) per_cu = by_lds < 1 ? 1 : by_lds; }
+#ifdef TSD_DIAG_PER_CU      // diagnostic build (tools/push_variants_r3.sh): fewer resident workgroups from the same code, held down by an LDS pad
+  if (TSD_DIAG_PER_CU < per_cu) per_cu = TSD_DIAG_PER_CU;
+#endif
   const int resident = ctx->n_cus * per_cu;
   const int n_groups = n_window < resident ? n_window : resident;
   {
     ScopedKernelTimer t(ctx, "push_update");
-    const size_t lds = update_lds_bytes(a.beams);
+    size_t lds = update_lds_bytes(a.beams);
+#ifdef TSD_DIAG_PER_CU
+    { const size_t pad = (160u * 1024u) / (size_t)(per_cu + 1) + 512u; if (lds < pad) lds = pad; }
+#endif
     hipExtLaunchKernelGGL(k_push_update, dim3(n_groups), dim3(UPDATE_BLOCK), lds, ctx->stream, t.a, t.b, 0, g, a_dev, d_ranges, d_mask,
                        ctx->d_tile_rec, ctx->d_tile_totals, ctx->d_list, reinterpret_cast<const PushListAux*>(ctx->d_list_aux), ctx->d_list_cnt, parity,
                        rmq_view(rmq, a.beams).bdir, rmq_view(rmq, a.beams).rot, ctx->d_icp_trace);
@@ -1397,7 +1404,10 @@ int launch_push(tsd_ctx* ctx, const PushArgs& a, double cx, double cy, double sl
   TSD_HIP_CHECK(ctx, hipGetLastError());
   {
     ScopedKernelTimer t(ctx, "push_halo");
-    const int n_waves = n_window < 4096 ? n_window : 4096;        // one wave per listed tile; a longer list is looped over
+#ifndef TSD_HALO_WAVES
+#define TSD_HALO_WAVES 16384
+#endif
+    const int n_waves = n_window < TSD_HALO_WAVES ? n_window : TSD_HALO_WAVES;        // one wave per listed tile; a longer list is looped over
     hipExtLaunchKernelGGL(k_push_halo, dim3((n_waves + 3) / 4), dim3(256), 0, ctx->stream, t.a, t.b, 0, g, ctx->d_dirty, ctx->d_pushes,
                        a_dev, ctx->d_list, ctx->d_tile_rec, ctx->d_list_cnt, parity, cx, cy, slack + g.cs);
   }

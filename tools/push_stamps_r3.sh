@@ -38,6 +38,6 @@ for k in range(12):
             c = st[:, 3 + i]
             print(f"   {nm:46s}: {100*np.median(c/tot):5.1f} % of thread 0's cycles; per tile median {np.median(c/tiles):8.0f} cycles")
         print(f"   cycles per tile (thread 0): median {np.median(tot/tiles):.0f}")
-        for i, nm in enumerate(["A: d2 table, setup, classification", "A: limits, candidate test", "A: compaction", "A: fix-up", "step: ticket, entries, reads issued"]):
+        for i, nm in enumerate(["A: d2 table, setup, classification", "A: limits, candidate test", "A: compaction", "A: fix-up", "record of the tile (thread 0)"]):
             print(f"      {nm:40s}: per tile median {np.median(sub[:, i]/tiles):8.0f} cycles")
 PY
