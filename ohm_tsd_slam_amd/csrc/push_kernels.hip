@@ -200,16 +200,14 @@ __device__ __forceinline__ double div_normal(double n, double d)
   return __builtin_fma(__builtin_fma(-d, q, n), r, q);
 }
 
-// TsdGridPartition::addTsd (TsdGridPartition.h:170-212); the `fabs(sd) < _eps` branch is dead because
-// _eps = -cellSize/2 (TsdGridPartition.cpp:95) and is kept only as a comparison against eps.
-__device__ __forceinline__ bool add_tsd(double& tsd, double& weight, double sd, double part_weight,
-                                        double max_trunc, double inv_max_trunc, double eps)
+// TsdGridPartition::addTsd (TsdGridPartition.h:170-212).  The reference's `if(fabs(sd) < _eps) w = 1.0` never fires: _eps is
+// -cellSize / 2 (TsdGridPartition.cpp:95), negative for every grid tsd_create accepts, and fabs() is not -- so the weight of a
+// measurement is 0.01 * the partition weight for every cell of the tile, `w` here, formed once per tile.
+__device__ __forceinline__ bool add_tsd(double& tsd, double& weight, double sd, double w,
+                                        double max_trunc, double inv_max_trunc)
 {
   if (sd >= -max_trunc) {
     const double v = fmin(sd * inv_max_trunc, 1.0);
-    double w = 0.01;
-    if (fabs(sd) < eps) w = 1.0;
-    w *= part_weight;
     if (isnan(tsd)) {
       tsd = v;
       weight += w;
@@ -275,7 +273,6 @@ static_assert(sizeof(PushListAuxBody) == 80 && sizeof(PushListAux) == 128, "Push
 // (tools/push_verify_index.sh, profiles/r2_push_index_estimate_verified.txt).  The other cells (4-5 %) are not decided by the estimate at all: they go to
 // a queue in LDS and get the exact fp64 formulation, densely (one lane per queued cell), instead of dragging their
 // whole wave through it.
-constexpr int IDX_UNSURE = INT_MIN;
 constexpr float IDX_MARGIN = 0.02f;
 __device__ __forceinline__ float atan2_estimate(float y, float x)      // |error| < 2e-6 rad
 {
@@ -466,32 +463,31 @@ k_push_classify(GridDev g, const PushArgs* __restrict__ a_dev, const char* __res
 // coordinate u = (angle - phi_min) / res is shifted by one half, v = u + 0.5, so that the rounding boundaries of
 // round() -- and the two ends of the field of view, phi_lower = phi_min - res / 2 and phi_upper = phi_min + (beams - 0.5) res --
 // all sit at INTEGER v: boundary jb (0 .. beams) is the direction beta_jb = phi_min + (jb - 0.5) res.
-//   returns  >= 0       the beam, decided (v further than IDX_MARGIN from every boundary)
-//            -1         outside the field of view, decided
-//            IDX_UNSURE within IDX_MARGIN of boundary `jb` (0 .. beams), or -- jb = IDX_CUT -- at the +-pi cut of atan2
-// interior (wave-uniform, LIST_INTERIOR): the tile lies inside the field of view by a beam and away from the cut, the angle is
-// continuous over it -- only the distance to a rounding boundary is left to test.
+//   decided inside   (!uns && !out)  j = the beam (v further than IDX_MARGIN from every boundary)
+//   decided outside  (out)           outside the field of view
+//   undecided        (uns)           within IDX_MARGIN of boundary j (0 .. beams), or -- j = IDX_CUT -- at the +-pi cut of atan2
+// The three answers are lane masks, never integers in a vector register: the compiler keeps them in scalar register pairs and the
+// ballots of the compaction are those pairs.
 constexpr int IDX_CUT = 0x1FFF;
-__device__ __forceinline__ int classify_angle(float th, float phi_min_f, float inv_res_f, int beams, bool interior, int& jb)
+struct CellClass { int j; bool uns, out; };
+__device__ __forceinline__ CellClass classify_angle(float th, float phi_min_f, float inv_res_f, int beams)
 {
   const float PI_F = 3.14159274f;
-  jb = IDX_CUT;
-  if (!interior) {
-    if (th > PI_F) th -= 2.0f * PI_F;                        // the reference's atan2 lives in (-pi, pi]
-    else if (th <= -PI_F) th += 2.0f * PI_F;
-    if (fabsf(th) > PI_F - 1e-3f) return IDX_UNSURE;         // at the cut the two branches are 2 pi apart: exact path
-  }
+  if (th > PI_F) th -= 2.0f * PI_F;                          // the reference's atan2 lives in (-pi, pi]
+  else if (th <= -PI_F) th += 2.0f * PI_F;
+  const bool cut = fabsf(th) > PI_F - 1e-3f;                 // at the cut the two branches are 2 pi apart: exact path
   const float v = fmaf(th - phi_min_f, inv_res_f, 0.5f);    // beam coordinate + 1/2
-  if (!interior) {
-    const float vb = (float)beams;
-    if (v < -IDX_MARGIN || v > vb + IDX_MARGIN) return -1;     // outside the field of view for sure
-    // whatever is not STRICTLY inside by the margin belongs to the end's boundary (0 / beams): a decided beam is always 0 .. beams - 1
-    if (!(v > IDX_MARGIN && v < vb - IDX_MARGIN)) { jb = v < 1.0f ? 0 : beams; return IDX_UNSURE; }
-  }
+  const float vb = (float)beams;
+  const bool outside = v < -IDX_MARGIN || v > vb + IDX_MARGIN;        // outside the field of view for sure
+  // whatever is not STRICTLY inside by the margin belongs to the end's boundary (0 / beams): a decided beam is always 0 .. beams - 1
+  const bool end = !(v > IDX_MARGIN && v < vb - IDX_MARGIN);
   const float jf = rintf(v);
-  jb = (int)jf;
-  if (!(fabsf(v - jf) >= IDX_MARGIN)) return IDX_UNSURE;     // (also a NaN: never a decided beam)
-  return (int)floorf(v);
+  const bool close = !(fabsf(v - jf) >= IDX_MARGIN);         // (also a NaN: never a decided beam)
+  CellClass c;
+  c.uns = cut || (!outside && (end || close));
+  c.out = !cut && outside;
+  c.j = cut ? IDX_CUT : end ? (v < 1.0f ? 0 : beams) : close ? (int)jf : (int)floorf(v);
+  return c;
 }
 
 // SensorPolar2D::backProject itself (fp64 atan2, bound checks, round) for the cells nothing cheaper can decide: OUT OF LINE on
@@ -565,14 +561,14 @@ struct TileA {
   int beams, wlo, whi;
 };
 
-// Beam classification of ONE cell, offset (dxc, dyc) cells from the tile's centroid: the beam (>= 0, decided), -1 (outside the
-// field of view, decided) or IDX_UNSURE with the boundary `jb`; d2f = the fp32 squared sensor distance.  FAR: the sensor is further
+// Beam classification of ONE cell, offset (dxc, dyc) cells from the tile's centroid (CellClass: decided beam / decided outside the
+// field of view / undecided with its boundary); d2f = the fp32 squared sensor distance.  FAR: the sensor is further
 // than three circumradii from the centroid -- the cell's angle is the centroid's plus a small delta, |delta| < 0.34 rad,
 // tan(delta) = cross / dot with both products LINEAR in the cell offset (coefficients from k_push_classify), atan by a four-term
 // series; near tiles use the six-term minimax arctangent.  INTERIOR (implies FAR): no end of the field of view, no cut -- only
 // rounding boundaries.
 template <bool FAR, bool INTERIOR>
-__device__ __forceinline__ int classify_cell(const TileA& t, float dxc, float dyc, float pA, float pC, float qx, float vc, int& jb, float& d2f)
+__device__ __forceinline__ CellClass classify_cell(const TileA& t, float dxc, float dyc, float pA, float pC, float qx, float vc, float& d2f)
 {
   float th_rel;          // angle relative to th_c (FAR) or the angle itself
   if constexpr (FAR) {
@@ -594,10 +590,12 @@ __device__ __forceinline__ int classify_cell(const TileA& t, float dxc, float dy
     // v = (th_c + delta - phi_min) / res + 1/2: boundaries at integer v
     const float v = fmaf(th_rel, t.inv_res, vc);
     const float jf = rintf(v);
-    jb = (int)jf;
-    return !(fabsf(v - jf) >= IDX_MARGIN) ? IDX_UNSURE : (int)floorf(v);
+    CellClass c;
+    c.uns = !(fabsf(v - jf) >= IDX_MARGIN); c.out = false;
+    c.j = c.uns ? (int)jf : (int)floorf(v);
+    return c;
   } else {
-    return classify_angle(FAR ? t.th_c + th_rel : th_rel, t.phi_min, t.inv_res, t.beams, false, jb);
+    return classify_angle(FAR ? t.th_c + th_rel : th_rel, t.phi_min, t.inv_res, t.beams);
   }
 }
 
@@ -759,47 +757,44 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
       const float pA = dxc * ta.A, pC = fmaf(dxc, ta.C, ta.lc2), qx = fmaf(ta.cs2 * dxc, dxc, -ta.lc2);
       const float vc = fmaf(ta.th_c - ta.phi_min, ta.inv_res, 0.5f);
       int idx[UPD_CPT]; float d2f[UPD_CPT];      // beam (or boundary, undecided cells) and fp32 squared distance of cell k
-      unsigned um = 0u, om = 0u;                 // undecided / decided-outside
+      bool uns[UPD_CPT], in[UPD_CPT];            // undecided / decided inside the field of view (lane masks)
 #pragma unroll
       for (int k = 0; k < UPD_CPT; k++) {
         const float dyc = (float)(iy0 + 8u * (unsigned)k) - 16.0f;
-        int jb, index;
-        if (interior) index = classify_cell<true, true>(ta, dxc, dyc, pA, pC, qx, vc, jb, d2f[k]);
-        else if (far) index = classify_cell<true, false>(ta, dxc, dyc, pA, pC, qx, vc, jb, d2f[k]);
-        else          index = classify_cell<false, false>(ta, dxc, dyc, pA, pC, qx, vc, jb, d2f[k]);
-        const bool unsure = index == IDX_UNSURE;
-        if (unsure) um |= 1u << k;
-        if (!unsure && index < 0) om |= 1u << k;
-        idx[k] = unsure ? jb : index;
+        CellClass cc;
+        if (interior) cc = classify_cell<true, true>(ta, dxc, dyc, pA, pC, qx, vc, d2f[k]);
+        else if (far) cc = classify_cell<true, false>(ta, dxc, dyc, pA, pC, qx, vc, d2f[k]);
+        else          cc = classify_cell<false, false>(ta, dxc, dyc, pA, pC, qx, vc, d2f[k]);
+        idx[k] = cc.j; uns[k] = cc.uns; in[k] = !cc.uns && !cc.out;
       }
       PSTAMP(6);     // (sub-phase: d2 table, setup, classification)
 #if defined(TSD_ABLATE) && (TSD_ABLATE & 8)      // instruction-count ablation (tools/push_ablate_r3.sh; results are WRONG): classification only
-      if (idx[0] + idx[1] + idx[2] + idx[3] + (int)(um + om) + (int)(d2f[0] + d2f[1] + d2f[2] + d2f[3]) == 0x7fffffff) dbg[0] = 1.0;
+      if (idx[0] + idx[1] + idx[2] + idx[3] + (int)uns[0] + (int)uns[1] + (int)uns[2] + (int)uns[3] + (int)in[0] + (int)in[1] + (int)in[2] + (int)in[3] + (int)(d2f[0] + d2f[1] + d2f[2] + d2f[3]) == 0x7fffffff) dbg[0] = 1.0;
       return;
 #endif
-      // the beams' limits from LDS, the four reads in flight together; a beam outside the staged window -- possible only through
-      // rounding at the window's ends -- is fetched from global memory by the lanes concerned
+      // the beams' limits from LDS, the four reads in flight together.  A decided beam outside the staged window -- possible only
+      // through rounding at the window's ends -- joins the undecided cells (boundary = the beam: the exact test names it again, and
+      // that path reads any beam)
       float lim[UPD_CPT];
 #pragma unroll
-      for (int k = 0; k < UPD_CPT; k++) lim[k] = s_lim[min(max(idx[k], wlo), whi)];
-      asm volatile("" : "+v"(lim[0]), "+v"(lim[1]), "+v"(lim[2]), "+v"(lim[3]));      // (keeps the LDS reads LDS reads: no pointer select)
-      unsigned cm = 0u;
+      for (int k = 0; k < UPD_CPT; k++) {
+        const int il = min(max(idx[k], wlo), whi);
+        lim[k] = s_lim[il];
+        if (in[k] && il != idx[k]) { in[k] = false; uns[k] = true; }
+      }
+      bool cand[UPD_CPT];
 #pragma unroll
       for (int k = 0; k < UPD_CPT; k++) {
-        const bool decided_in = !(((um | om) >> k) & 1u);
-        if (__builtin_expect(decided_in && (idx[k] < wlo || idx[k] > whi), 0)) lim[k] = beam_limit(ranges[idx[k]], (unsigned)mask[idx[k]], ta.mt, ta.low2);
-        const bool cand = decided_in && !(d2f[k] > lim[k]);
-        if (cand) cm |= 1u << k;
+        cand[k] = in[k] && !(d2f[k] > lim[k]);
         // a freshly materialised tile: cells that addTsd will not touch get the init value here
-        if (tc.fresh && !cand && !((um >> k) & 1u)) st_cell(tc.T, tc.W, c0 + UPDATE_BLOCK * k, t_init, tc.iw);
+        if (tc.fresh && !cand[k] && !uns[k]) st_cell(tc.T, tc.W, c0 + UPDATE_BLOCK * k, t_init, tc.iw);
 #ifdef TSD_PUSH_VERIFY_INDEX   // diagnostic build: every decided cell against the exact formulation
         {
           const double ccx = ((double)(x0 + ix) + 0.5) * g.cs, ccy = ((double)(y0 + iy0 + 8u * (unsigned)k) + 0.5) * g.cs;
           const int ex = backproject(a.Pi, ccx, ccy, a.phi_min, a.ang_res_inv, a.phi_lower, a.phi_upper);
-          const bool unsure = (um >> k) & 1u;
-          const int index = ((om >> k) & 1u) ? -1 : idx[k];
-          if (!unsure && (index < 0 ? ex >= 0 : ex != index)) atomicAdd(reinterpret_cast<unsigned long long*>(dbg + 1000), 1ull);
-          if (unsure) atomicAdd(reinterpret_cast<unsigned long long*>(dbg + 1001), 1ull);
+          const int index = in[k] ? idx[k] : -1;
+          if (!uns[k] && (index < 0 ? ex >= 0 : ex != index)) atomicAdd(reinterpret_cast<unsigned long long*>(dbg + 1000), 1ull);
+          if (uns[k]) atomicAdd(reinterpret_cast<unsigned long long*>(dbg + 1001), 1ull);
           atomicAdd(reinterpret_cast<unsigned long long*>(dbg + 1002), 1ull);
         }
 #endif
@@ -807,12 +802,14 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
       PSTAMP(7);     // (sub-phase: limits, candidate test, fresh stores)
       // compaction: ONE LDS atomic per wave for its cells of all four strips -- the candidates go to the front of the tile's list, the
       // undecided cells (cell | boundary << 10) to its back; the exact part settles those, densely, behind the barrier
+#if defined(TSD_ABLATE) && (TSD_ABLATE & 1)      // ablation: no fix-up
+#pragma unroll
+      for (int k = 0; k < UPD_CPT; k++) uns[k] = false;
+#endif
+      unsigned long long bc[UPD_CPT], bu[UPD_CPT];
       unsigned nc = 0u, nu = 0u;
 #pragma unroll
-      for (int k = 0; k < UPD_CPT; k++) { nc += (unsigned)__popcll(__ballot((cm >> k) & 1u)); nu += (unsigned)__popcll(__ballot((um >> k) & 1u)); }
-#if defined(TSD_ABLATE) && (TSD_ABLATE & 1)      // ablation: no fix-up
-      nu = 0u; um = 0u;
-#endif
+      for (int k = 0; k < UPD_CPT; k++) { bc[k] = __ballot(cand[k]); bu[k] = __ballot(uns[k]); nc += (unsigned)__popcll(bc[k]); nu += (unsigned)__popcll(bu[k]); }
       unsigned base = 0u, ub = 0u;
       if (nc | nu) {
         unsigned long long got = 0ull;
@@ -822,11 +819,10 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
       }
 #pragma unroll
       for (int k = 0; k < UPD_CPT; k++) {
-        const unsigned long long bc = __ballot((cm >> k) & 1u), bu = __ballot((um >> k) & 1u);
         const uint32_t e = (uint32_t)(c0 + UPDATE_BLOCK * k) | ((uint32_t)idx[k] << 10);
-        if ((cm >> k) & 1u) cand_list[base + (unsigned)__popcll(bc & lt)] = e;
-        if ((um >> k) & 1u) cand_list[(unsigned)(UPD_CAND_MAX - 1) - (ub + (unsigned)__popcll(bu & lt))] = e;
-        base += (unsigned)__popcll(bc); ub += (unsigned)__popcll(bu);
+        if (cand[k]) cand_list[base + (unsigned)__popcll(bc[k] & lt)] = e;
+        if (bu[k] && uns[k]) cand_list[(unsigned)(UPD_CAND_MAX - 1) - (ub + (unsigned)__popcll(bu[k] & lt))] = e;
+        base += (unsigned)__popcll(bc[k]); ub += (unsigned)__popcll(bu[k]);
       }
       PSTAMP(8);     // (sub-phase: compaction)
       if (tc.fresh) {
@@ -850,7 +846,6 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
     // but needs 128 registers (4 workgroups per compute unit instead of 6) and the kernel is bound by VALU issue either way: 75.6 us
     // against 75.0 us at cfg3 / comb, 16.9 against 14.5 us at cfg2.  profiles/r3_push_update_structure.txt.)
     const double inv_max_trunc = 1.0 / max_trunc;
-    const double eps = -g.cs / 2.0;
     unsigned i_cur = blockIdx.x, i_next = s_tk[1];        // list indices of tiles n / n + 1 (>= n_upd_tiles: none)
     uint32_t xn_v = rec_request(i_next < n_upd_tiles ? i_next : 0u);        // tile n + 1's record, in flight
     for (unsigned n = 0u; i_cur < n_upd_tiles; n++) {
@@ -933,7 +928,8 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
       // the exact part: UPD_CB cells per lane and pass, their reads in flight together; a wave skips the cells of a pass none of its
       // lanes has (a tile's last pass is rarely full)
       unsigned long long wrote_neg = 0ull;
-      unsigned n_upd = 0u;
+      unsigned n_upd = 0u;                                  // cells this WAVE updated (a scalar: population counts of the lane masks)
+      const double w_meas = 0.01 * tcur.pw;                 // (TsdGridPartition.h:193-196: w = 0.01, then w *= partition weight)
       for (unsigned q0 = (unsigned)tid; q0 < n_tot; q0 += UPD_CB * UPDATE_BLOCK) {
         uint32_t ce[UPD_CB]; double tv[UPD_CB], wv[UPD_CB];
 #pragma unroll
@@ -960,15 +956,14 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
           if (!isinf(r)) { sd = r - dist; ok = true; }
           else if (dist < a.low_refl) { sd = max_trunc; ok = true; }
           bool touched = false;
-          if (on && ok && sd >= -max_trunc) touched = add_tsd(tv[j], wv[j], sd, tcur.pw, max_trunc, inv_max_trunc, eps);
-          if (touched) n_upd++;
+          if (on && ok && sd >= -max_trunc) touched = add_tsd(tv[j], wv[j], sd, w_meas, max_trunc, inv_max_trunc);
+          n_upd += (unsigned)__popcll(__ballot(touched));
           if (touched && tv[j] < 0.0) wrote_neg |= neg_bit((unsigned)c & 31u, (unsigned)c >> 5);
           if (on && (touched || tcur.fresh)) st_cell(tcur.T, tcur.W, c, tv[j], wv[j]);
         }
       }
       if (wrote_neg) atomicOr(&s_neg[slot], wrote_neg);               // (LDS; folded into the tile's mask below)
-      const unsigned wu = (unsigned)wave_sum_i((int)n_upd);
-      if (lane == 0 && wu) atomicAdd(&s_upd[slot], wu);
+      if (lane == 0 && n_upd) atomicAdd(&s_upd[slot], n_upd);
       if (tid == 0) s_tk[(n + 2u) & 3u] = more_than_one ? ticket_of(tk_pending) : ~0u;
       PSTAMP(3);
       lds_barrier();               // tile n done by every wave; the next ticket in place
