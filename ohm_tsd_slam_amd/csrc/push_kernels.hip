@@ -665,6 +665,26 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
   };
   const uint32_t first_v = rec_request(blockIdx.x);             // read speculatively: arrives with the list lengths and the arguments
   const PushArgs a = *a_dev;
+  // ... and, for a workgroup that will take several tiles, so does the whole scan (the first STAGE_R x 256 beams: a UTM-30LX scan in
+  // one round) and the rotation table: one memory round trip.  (A single-tile workgroup stages only the beams its tile can project
+  // to, behind the record: 1 read per thread instead of 5 -- measured 0.7 us better at cfg 2 than staging everything up front.)
+  const bool more_than_one = n_upd_tiles > gridDim.x;
+#ifndef TSD_STAGE_UPFRONT       // diagnostic: 1 = every workgroup stages the whole scan up front
+#define TSD_STAGE_UPFRONT 0
+#endif
+  const bool stage_all = more_than_one || TSD_STAGE_UPFRONT;
+  constexpr int STAGE_R = 5;
+  double st_r[STAGE_R]; unsigned st_m[STAGE_R];
+#pragma unroll
+  for (int i = 0; i < STAGE_R; i++) { st_r[i] = 0.0; st_m[i] = 0u; }
+  if (stage_all) {
+#pragma unroll
+    for (int i = 0; i < STAGE_R; i++) {       // (unconditional reads of a clamped index: a predicated read is waited for on the spot)
+      const int j = tid + i * UPDATE_BLOCK, jc = j < a.beams ? j : 0;
+      st_r[i] = ranges[jc]; st_m[i] = (unsigned)mask[jc];
+    }
+  }
+  const double2 st_rot = rot[tid < ROT_N ? tid : 0];
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int Bp = (a.beams + 3) & ~3;
   double* s_ranges = reinterpret_cast<double*>(smem);                      // [Bp]
@@ -686,7 +706,6 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
     ta.axx = (float)(a.Pi[0] * g.cs); ta.axy = (float)(a.Pi[1] * g.cs); ta.ayx = (float)(a.Pi[3] * g.cs); ta.ayy = (float)(a.Pi[4] * g.cs);
     ta.cs2 = (float)(g.cs * g.cs);
     // the queue: tile 0 of this workgroup is its own index, the others come off its ticket head, requested two tiles ahead
-    const bool more_than_one = n_upd_tiles > gridDim.x;
     unsigned int* const head = cntw + CNT_TICKET + TICKET_STRIDE * (blockIdx.x % TICKET_HEADS);
     const unsigned int head_first = gridDim.x + blockIdx.x % TICKET_HEADS;
     // (the RAW counter value is carried to where the ticket is needed: nothing may consume the returning atomic early, or thread 0's
@@ -699,36 +718,36 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
       s_tk[0] = blockIdx.x;
       s_tk[1] = more_than_one ? ticket_of(draw()) : ~0u;        // tile 1; tile n's step requests tile n + 2
     }
-    // The scan is staged once per workgroup: only the beams the tile can project to when the workgroup has a single tile (the
-    // usual case), all of them when it may take several.  Beams outside the staged window go to global memory.
+    // The scan is staged once per workgroup: all of it when the workgroup may take several tiles (from the reads issued at the top),
+    // only the beams the tile can project to when it has a single one.  Beams outside the staged window: see phase A.
     uint32_t xc_v = first_v;                              // tile n's record
     PushListAux xc = rec_unpack(xc_v);
     int wlo = 0, whi = a.beams - 1;
-    if (!more_than_one) {
-      const PushListAux& first_aux = xc;
-      wlo = (int)(first_aux.win & 0xFFFFu) - 1; whi = (int)(first_aux.win >> 16) + 1;
-      if (wlo < 0) wlo = 0;
-      if (whi > a.beams - 1) whi = a.beams - 1;
-    }
-    ta.wlo = wlo; ta.whi = whi;
-    if (whi - wlo + 1 <= UPDATE_BLOCK) {
-      // the usual tile, seen from outside: a few dozen beams, at most one element of each array per thread
-      const int j = wlo + tid;
-      const bool in_r = j <= whi;
-      const double rj = in_r ? ranges[j] : 0.0;
-      const unsigned mj = in_r ? (unsigned)mask[j] : 0u;
-      if (in_r) { s_ranges[j] = rj; s_lim[j] = beam_limit(rj, mj, ta.mt, ta.low2); }
-    } else {
-      // every read of a round issued before its first LDS write (4 x 256 beams per round)
-      for (int j0 = wlo; j0 <= whi; j0 += 4 * UPDATE_BLOCK) {
+    if (stage_all) {
+#pragma unroll
+      for (int i = 0; i < STAGE_R; i++) { const int j = tid + i * UPDATE_BLOCK; if (j <= whi) { s_ranges[j] = st_r[i]; s_lim[j] = beam_limit(st_r[i], st_m[i], ta.mt, ta.low2); } }
+      // (longer scans: further rounds, every read of a round issued before its first LDS write)
+      for (int j0 = STAGE_R * UPDATE_BLOCK; j0 <= whi; j0 += 4 * UPDATE_BLOCK) {
         double rr[4]; unsigned mm[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) { const int j = j0 + tid + i * UPDATE_BLOCK; const bool in_r = j <= whi; rr[i] = in_r ? ranges[j] : 0.0; mm[i] = in_r ? (unsigned)mask[j] : 0u; }
+        for (int i = 0; i < 4; i++) { const int j = j0 + tid + i * UPDATE_BLOCK, jc = j <= whi ? j : 0; rr[i] = ranges[jc]; mm[i] = (unsigned)mask[jc]; }
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const int j = j0 + tid + i * UPDATE_BLOCK; if (j <= whi) { s_ranges[j] = rr[i]; s_lim[j] = beam_limit(rr[i], mm[i], ta.mt, ta.low2); } }
+      }
+    } else {
+      wlo = (int)(xc.win & 0xFFFFu) - 1; whi = (int)(xc.win >> 16) + 1;
+      if (wlo < 0) wlo = 0;
+      if (whi > a.beams - 1) whi = a.beams - 1;
+      for (int j0 = wlo; j0 <= whi; j0 += 4 * UPDATE_BLOCK) {      // (the usual tile, seen from outside: a few dozen beams, one round)
+        double rr[4]; unsigned mm[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const int j = j0 + tid + i * UPDATE_BLOCK, jc = j <= whi ? j : wlo; rr[i] = ranges[jc]; mm[i] = (unsigned)mask[jc]; }
 #pragma unroll
         for (int i = 0; i < 4; i++) { const int j = j0 + tid + i * UPDATE_BLOCK; if (j <= whi) { s_ranges[j] = rr[i]; s_lim[j] = beam_limit(rr[i], mm[i], ta.mt, ta.low2); } }
       }
     }
-    if (tid < ROT_N) s_rot[tid] = rot[tid];
+    ta.wlo = wlo; ta.whi = whi;
+    if (tid < ROT_N) s_rot[tid] = st_rot;
     if (tid < 3) { s_cu[tid] = 0ull; s_upd[tid] = 0u; s_neg[tid] = 0ull; }
     lds_barrier();                     // scan staged, counters zeroed, first tickets in place
     PSTAMP(0);
@@ -937,7 +956,11 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
           const unsigned q = q0 + (unsigned)(j * UPDATE_BLOCK);
           ce[j] = q < n_tot ? cand_list[q < n_cand ? q : (unsigned)(UPD_CAND_MAX - 1) - (q - n_cand)] : 0xFFFFFFFFu;
           tv[j] = t_init; wv[j] = tcur.iw;
+#if defined(TSD_ABLATE) && (TSD_ABLATE & 16)     // ablation: the cell reads hit the first line of the tile (what hiding their latency could buy at most)
+          if (ce[j] != 0xFFFFFFFFu && !tcur.fresh) { tv[j] = ld_tsd(tcur.T + (ce[j] & 7u)); wv[j] = ld_w(tcur.W + (ce[j] & 7u)); }
+#else
           if (ce[j] != 0xFFFFFFFFu && !tcur.fresh) { tv[j] = ld_tsd(tcur.T + (ce[j] & 1023u)); wv[j] = ld_w(tcur.W + (ce[j] & 1023u)); }
+#endif
         }
 #pragma unroll
         for (int j = 0; j < UPD_CB; j++) {
