@@ -292,6 +292,19 @@ __device__ __forceinline__ float atan2_estimate(float y, float x)      // |error
   r = x < 0.f ? 3.14159274f - r : r;
   return y < 0.f ? -r : r;
 }
+// A read the optimiser must leave where it is written: LLVM's sink pass moves a plain read of __restrict__ const memory into the
+// conditional block of its only use -- where it is then issued late and waited for alone (a memory round trip of its own in kernels
+// that are chains of round trips).  A relaxed single-thread-scope atomic read is an ordinary global_load in the ISA, and stays put.
+template <typename T>
+__device__ __forceinline__ T ld_pinned(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SINGLETHREAD); }
+// Workgroup barrier that orders LDS only.  __syncthreads() also drains the wave's global-memory counter (s_waitcnt vmcnt(0)): every
+// wave would sit out the full latency of the stores it has just issued at the end of each tile.  Nothing in k_push_update hands
+// GLOBAL data from one wave to another inside the launch (a cell is read and written by one lane), so LDS order is all it needs.
+__device__ __forceinline__ void lds_barrier()
+{
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // isInRange for every tile of the launch window, one LANE per tile (TsdGridComponent.cpp:43-124: range cull,
 // four corner back-projections, the two beam-range tests as O(1) table look-ups).  Tiles that need work go
 // to the list (one atomic per wave); increaseEmptiness of a tile that was never materialised is done here
@@ -324,8 +337,11 @@ k_push_classify(GridDev g, const PushArgs* __restrict__ a_dev, const char* __res
   uint32_t rec = 0u, kind = 0u, far_flag = 0u;
   // the tile's state, requested before anything else: it travels in the list record of an UPDATE tile (k_push_update then needs no
   // dependent read for it) and decides the increaseEmptiness case below
-  const uint8_t t_flag = in_window ? g.flags[p] : (uint8_t)0;
-  const double t_iw = in_window ? g.init_weight[p] : 0.0;
+  // (unconditional reads -- p is 0 outside the window: the compiler waits for a predicated read on the spot, and this kernel is a
+  // chain of memory round trips: every one of them that rides along with another is ~0.6 us off the kernel)
+  // ld_pinned: the optimiser otherwise SINKS a read into the conditional block of its only use, behind that block's other waits.
+  const uint8_t t_flag = ld_pinned(&g.flags[p]), t_dirty = ld_pinned(&dirty[p]);      // (used inside `in_window` regions only)
+  const double t_iw = ld_pinned(&g.init_weight[p]);
   double pw = 0.0;
   double tcx = 0.0, tcy = 0.0;                               // the tile's centroid (UPDATE tiles)
   uint32_t win = (uint32_t)(a.beams - 1) << 16;              // beams the cells of the tile can project to: lo | hi << 16
@@ -371,8 +387,8 @@ k_push_classify(GridDev g, const PushArgs* __restrict__ a_dev, const char* __res
         const unsigned short* tm = rv.tmax + (size_t)k * rv.Bp;
         const unsigned short* tn = rv.tmin + (size_t)k * rv.Bp;
         const int j2 = hi - (1 << k) + 1;
+        const unsigned short n0 = ld_pinned(&rv.inf[lo]), n1 = ld_pinned(&rv.inf[hi + 1]);     // (issued with the index look-ups, used last)
         const unsigned short i0 = tm[lo], i1 = tm[j2], i2 = tn[lo], i3 = tn[j2];
-        const unsigned short n0 = rv.inf[lo], n1 = rv.inf[hi + 1];
         const double amax = fmax(rv.A[i0], rv.A[i1]);
         const double bmin = fmin(rv.Bv[i2], rv.Bv[i3]);
         const bool has_inf = n1 != n0;
@@ -406,14 +422,14 @@ k_push_classify(GridDev g, const PushArgs* __restrict__ a_dev, const char* __res
         else {
           if (owner) {
             double v = t_iw + 1.0; v = fmin(v, MAX_WEIGHT); g.init_weight[p] = v;
-            tile_totals[(size_t)p * TOT_FIELDS + 6] += 1u;
+            atomicAdd(&tile_totals[(size_t)p * TOT_FIELDS + 6], 1u);      // (no-return atomics: nothing waits for them; += is a read, a wait and a write)
           }
           rec |= REC_EMPTIED_UNINIT;
         }
       }
-      if (owner) tile_totals[(size_t)p * TOT_FIELDS + 1] += 1u;         // (this lane owns the tile: no atomics)
+      if (owner) atomicAdd(&tile_totals[(size_t)p * TOT_FIELDS + 1], 1u);
     }
-    if (kind == 0u && dirty[p] != 0) { kind = KIND_HALO; rec |= REC_LISTED; }       // written by freeFootprint since the last push
+    if (kind == 0u && t_dirty != 0) { kind = KIND_HALO; rec |= REC_LISTED; }       // written by freeFootprint since the last push
   }
   if (in_window && owner && (kind == 0u || kind == KIND_HALO)) tile_rec[p] = rec;   // UPDATE / EMPTY: the workgroup writes the final record
   if (!owner) kind = 0u;
@@ -423,14 +439,15 @@ k_push_classify(GridDev g, const PushArgs* __restrict__ a_dev, const char* __res
   const unsigned long long ub = __ballot(kind == KIND_UPDATE), ob = __ballot(kind != 0u && kind != KIND_UPDATE);
   __shared__ unsigned int s_wu[CLASSIFY_BLOCK / 64], s_wo[CLASSIFY_BLOCK / 64], s_base[2];
   if (lane == 0) { s_wu[wave] = (unsigned int)__popcll(ub); s_wo[wave] = (unsigned int)__popcll(ob); }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned int tu = 0u, to = 0u;
-    for (int w = 0; w < CLASSIFY_BLOCK / 64; w++) { tu += s_wu[w]; to += s_wo[w]; }
-    s_base[0] = tu ? atomicAdd(&list_cnt[CNT_WORDS * parity + CNT_U], tu) : 0u;
-    s_base[1] = to ? atomicAdd(&list_cnt[CNT_WORDS * parity + CNT_O], to) : 0u;
+  lds_barrier();             // (LDS only: a __syncthreads() would also sit out every wave's stores and counters above)
+  if (threadIdx.x == 0 || threadIdx.x == 64) {
+    // lane 0 of wave 0 draws the UPDATE slots, lane 0 of wave 1 the others': the two returning atomics are in flight together
+    const bool upd = threadIdx.x == 0;
+    unsigned int tot = 0u;
+    for (int w = 0; w < CLASSIFY_BLOCK / 64; w++) tot += upd ? s_wu[w] : s_wo[w];
+    s_base[upd ? 0 : 1] = tot ? atomicAdd(&list_cnt[CNT_WORDS * parity + (upd ? CNT_U : CNT_O)], tot) : 0u;
   }
-  __syncthreads();
+  lds_barrier();
   if (ub | ob) {
     unsigned int base_u = s_base[0], base_o = s_base[1];
     for (int w = 0; w < wave; w++) { base_u += s_wu[w]; base_o += s_wo[w]; }
@@ -542,14 +559,6 @@ __host__ __device__ inline size_t update_lds_bytes(int beams)
   const size_t bp = (size_t)((beams + 3) & ~3);
   return bp * sizeof(double) + 2 * 2 * TILE_DIM * sizeof(double) + ROT_N * sizeof(double2) + bp * sizeof(float) +
          2 * UPD_CAND_MAX * sizeof(uint32_t);
-}
-
-// Workgroup barrier that orders LDS only.  __syncthreads() also drains the wave's global-memory counter (s_waitcnt vmcnt(0)): every
-// wave would sit out the full latency of the stores it has just issued at the end of each tile.  Nothing in k_push_update hands
-// GLOBAL data from one wave to another inside the launch (a cell is read and written by one lane), so LDS order is all it needs.
-__device__ __forceinline__ void lds_barrier()
-{
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 // wave-uniform values of phase A
@@ -1079,17 +1088,23 @@ k_push_halo(GridDev g, uint8_t* __restrict__ dirty, unsigned long long* __restri
     // UPDATE tiles from the front of the array, the others (emptied, dirtied) from its back
     const uint32_t entry = li < n_u ? ((li == wv) ? first : list[li]) : list[(unsigned)g.tiles - 1u - (li - n_u)];
     const int p = (int)(entry & LIST_TILE_MASK);
-    if (lane == 0 && dirty[p] != 0) dirty[p] = 0;
     const int px = p % PX, py = p / PX;
     const bool hasR = px < PX - 1, hasU = py < PX - 1, hasL = px > 0, hasD = py > 0;
-    // all nine flags in flight at once
-    const uint8_t f0 = g.flags[p];
-    const uint8_t fR = hasR ? g.flags[p + 1] : 0, fU = hasU ? g.flags[p + PX] : 0, fUR = (hasR && hasU) ? g.flags[p + PX + 1] : 0;
-    uint8_t fL = hasL ? g.flags[p - 1] : 0, fD = hasD ? g.flags[p - PX] : 0, fDL = (hasL && hasD) ? g.flags[p - PX - 1] : 0;
+    // all nine flags, the three records and the dirty mark in flight at once: UNCONDITIONAL reads (a missing neighbour reads the
+    // tile itself and the value is dropped).  As `has ? flags[q] : 0` each read was predicated, and the compiler waits for a
+    // predicated read on the spot -- up to twelve memory round trips in a row per tile (round 3, ISA of rounds 1-2).
+    const int qR = hasR ? p + 1 : p, qU = hasU ? p + PX : p, qUR = (hasR && hasU) ? p + PX + 1 : p;
+    const int qL = hasL ? p - 1 : p, qD = hasD ? p - PX : p, qDL = (hasL && hasD) ? p - PX - 1 : p;
+    const uint8_t f0 = g.flags[p], dty = dirty[p];
+    const uint8_t fR_ = g.flags[qR], fU_ = g.flags[qU], fUR_ = g.flags[qUR], fL_ = g.flags[qL], fD_ = g.flags[qD], fDL_ = g.flags[qDL];
+    const uint32_t rL_ = tile_rec[qL], rD_ = tile_rec[qD], rDL_ = tile_rec[qDL];
+    if (lane == 0 && dty != 0) dirty[p] = 0;
+    const uint8_t fR = hasR ? fR_ : (uint8_t)0, fU = hasU ? fU_ : (uint8_t)0, fUR = (hasR && hasU) ? fUR_ : (uint8_t)0;
+    uint8_t fL = hasL ? fL_ : (uint8_t)0, fD = hasD ? fD_ : (uint8_t)0, fDL = (hasL && hasD) ? fDL_ : (uint8_t)0;
     // a left / lower / diagonal neighbour that is on this push's list refreshes its own halo from this tile itself
     // (its job 0 / corner job is the very same copy): skipping the mirror job halves the column gathers where the
     // listed tiles are dense.  Records outside this push's window are never "listed" (see launch_push).
-    const uint32_t rL = hasL ? tile_rec[p - 1] : 0u, rD = hasD ? tile_rec[p - PX] : 0u, rDL = (hasL && hasD) ? tile_rec[p - PX - 1] : 0u;
+    const uint32_t rL = hasL ? rL_ : 0u, rD = hasD ? rD_ : 0u, rDL = (hasL && hasD) ? rDL_ : 0u;
     if (!f0) continue;
     if (rL & REC_LISTED) fL = 0;
     if (rD & REC_LISTED) fD = 0;
@@ -1109,7 +1124,7 @@ k_push_halo(GridDev g, uint8_t* __restrict__ dirty, unsigned long long* __restri
     }
     tsd_cell_t tv[3]; w_cell_t wv_[3];
 #pragma unroll
-    for (int k = 0; k < 3; k++) { tv[k] = tsd_cell_t(); wv_[k] = w_cell_t(); if (on[k]) { tv[k] = g.tsd[src[k]]; wv_[k] = g.weight[src[k]]; } }
+    for (int k = 0; k < 3; k++) { const size_t sk = on[k] ? src[k] : own; tv[k] = g.tsd[sk]; wv_[k] = g.weight[sk]; }      // (unconditional: see the flags)
 #pragma unroll
     for (int k = 0; k < 3; k++) if (on[k]) { g.tsd[dst[k]] = tv[k]; g.weight[dst[k]] = wv_[k]; }
   }
