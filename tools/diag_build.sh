@@ -11,7 +11,8 @@ diag=${DIAG_DIR:-diag}            # DIAG_DIR=diag_<name>: several variants side 
 mkdir -p $lib/$diag/obj
 cd $root/ohm_tsd_slam_amd/csrc
 extra=""; if [ "$tu" = "push_kernels" ]; then extra="-mllvm -amdgpu-atomic-optimizer-strategy=None"; fi
-hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -I../../include $extra "$@" -c $tu.hip -o $lib/$diag/obj/$tu.o
+src=${DIAG_SRC:-$tu.hip}          # DIAG_SRC=<other source of the same translation unit>: an A/B against a previous version kept beside it
+hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -I../../include $extra "$@" -c $src -o $lib/$diag/obj/$tu.o
 objs=""
 for o in $lib/obj/*.o; do b=$(basename $o); if [ "$b" = "$tu.o" ]; then objs="$objs $lib/$diag/obj/$tu.o"; else objs="$objs $o"; fi; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o $lib/$diag/libtsd_hip.so $objs
