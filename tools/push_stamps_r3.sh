@@ -38,6 +38,14 @@ for k in range(12):
             c = st[:, 3 + i]
             print(f"   {nm:46s}: {100*np.median(c/tot):5.1f} % of thread 0's cycles; per tile median {np.median(c/tiles):8.0f} cycles")
         print(f"   cycles per tile (thread 0): median {np.median(tot/tiles):.0f}")
+        # the slowest decile of the workgroups against the rest: which phase makes them slow
+        life_s = (st[:, 1] - st[:, 0]) * 0.01
+        slow = life_s >= np.percentile(life_s, 90)
+        for lab, m in (("slowest 10 %", slow), ("the others", ~slow)):
+            if m.sum() == 0: continue
+            parts = " ".join(f"{nm.split()[0]}:{np.median(st[m, 3 + i] / tiles[m]):.0f}" for i, nm in enumerate(names))
+            subs = " ".join(f"{lab2}:{np.median(sub[m, i] / tiles[m]):.0f}" for i, lab2 in enumerate(["A-class", "A-lim", "A-compact", "fix-up", "record"]))
+            print(f"   {lab:13s} ({m.sum()} wg, life median {np.median(life_s[m]):.2f} us, tiles {np.median(tiles[m]):.0f}): {parts} | {subs}")
         for i, nm in enumerate(["A: d2 table, setup, classification", "A: limits, candidate test", "A: compaction", "A: fix-up", "record of the tile (thread 0)"]):
             print(f"      {nm:40s}: per tile median {np.median(sub[:, i]/tiles):8.0f} cycles")
 PY

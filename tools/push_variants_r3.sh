@@ -2,9 +2,12 @@
 # diagnostic (GPU box): k_push_update variants (-DTSD_UPDATE_WPS=<waves per SIMD> -DTSD_UPDATE_CB=<cells per lane and pass of phase C>)
 # built into lib/diag_<name>, timed on the push-only benches and the slam bench; no parity here (the product build has the tests)
 cd $GRAFT_REPO_ROOT
+# a variant is "<flags>" or "<source file beside push_kernels.hip>|<flags>" (an A/B against a previous version of the file, same call)
 for v in "$@"; do
-  name=$(echo "$v" | tr -d ' =-' | tr 'A-Z' 'a-z')
-  DIAG_DIR=diag_$name tools/diag_build.sh push_kernels $v > /dev/null 2>&1 || { echo "variant [$v] failed to build"; continue; }
+  name=$(echo "$v" | tr -d ' =-|._' | tr 'A-Z' 'a-z')
+  src=push_kernels.hip; fl=$v
+  case "$v" in *"|"*) src=${v%%|*}; fl=${v#*|};; esac
+  DIAG_SRC=$src DIAG_DIR=diag_$name tools/diag_build.sh push_kernels $fl > /dev/null 2>&1 || { echo "variant [$v] failed to build"; continue; }
   export TSD_LIB_DIR=$GRAFT_REPO_ROOT/ohm_tsd_slam_amd/lib/diag_$name
   for w in "cfg3 comb" "cfg3 pillars" "cfg2 comb" "cfg2 pillars"; do set -- $w
     python3 bench.py --config $1 --scene $2 --mode push --steps 100 --no-cpu-baseline 2>/dev/null | python3 -c "
