@@ -292,11 +292,6 @@ __device__ __forceinline__ float atan2_estimate(float y, float x)      // |error
   r = x < 0.f ? 3.14159274f - r : r;
   return y < 0.f ? -r : r;
 }
-// A read the optimiser must leave where it is written: LLVM's sink pass moves a plain read of __restrict__ const memory into the
-// conditional block of its only use -- where it is then issued late and waited for alone (a memory round trip of its own in kernels
-// that are chains of round trips).  A relaxed single-thread-scope atomic read is an ordinary global_load in the ISA, and stays put.
-template <typename T>
-__device__ __forceinline__ T ld_pinned(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SINGLETHREAD); }
 // Workgroup barrier that orders LDS only.  __syncthreads() also drains the wave's global-memory counter (s_waitcnt vmcnt(0)): every
 // wave would sit out the full latency of the stores it has just issued at the end of each tile.  Nothing in k_push_update hands
 // GLOBAL data from one wave to another inside the launch (a cell is read and written by one lane), so LDS order is all it needs.

@@ -380,8 +380,8 @@ raycast_beam(const GridDev& g, const RaycastArgs& a_val, const RaycastArgs* __re
 #pragma unroll
         for (int j = 0; j < RC_S; j++) {
           fl[j] = 0; qv[j].t00 = qv[j].t01 = qv[j].t10 = qv[j].t11 = 0.0;
-          if (r0 + 4 * j >= n_cand) continue;
-          fl[j] = g.flags[tp[j]];
+          if (r0 + 4 * j >= n_cand) continue;                   // (wave-uniform)
+          fl[j] = ld_pinned(&g.flags[tp[j]]);                   // (pinned, like the quad's reads: one memory round trip for the five)
           qv[j] = load_quad(g.tsd + (size_t)tp[j] * TILE_STRIDE, lxy[j] & 0xFF, lxy[j] >> 8);
         }
 #pragma unroll
@@ -491,7 +491,7 @@ raycast_beam(const GridDev& g, const RaycastArgs& a_val, const RaycastArgs* __re
     int p, lx, ly; double dx, dy;
     okn = coord2cell(g, sx, sy, p, lx, ly, dx, dy);
     if (okn) {
-      const uint8_t f = g.flags[p];
+      const uint8_t f = ld_pinned(&g.flags[p]);
       const Quad q = load_quad(g.tsd + (size_t)p * TILE_STRIDE, lx, ly);
       const double wx = fabs((sx - dx) * g.inv_cs), wy = fabs((sy - dy) * g.inv_cs);
       v = q.t00 * (1. - wy) * (1. - wx) + q.t10 * wy * (1. - wx) + q.t01 * (1. - wy) * wx + q.t11 * wy * wx;

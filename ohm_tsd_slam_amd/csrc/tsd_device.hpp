@@ -162,13 +162,34 @@ __device__ __forceinline__ int interpolate_bilinear(const GridDev& g, double x, 
   return INTERP_SUCCESS;
 }
 
+// A read the optimiser must leave where it is written: LLVM's sink pass moves a plain read of __restrict__ const memory into the
+// conditional block of its only use -- where it is then issued late and waited for alone (a memory round trip of its own in kernels
+// that are chains of round trips).  A relaxed single-thread-scope atomic read is an ordinary global_load in the ISA, and stays put.
+template <typename T>
+__device__ __forceinline__ T ld_pinned(const T* p)
+{
+#ifdef TSD_NO_PINNED      // diagnostic build (tools/tu_ab.sh): plain reads, for the A/B
+  return *p;
+#else
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SINGLETHREAD);
+#endif
+}
+__device__ __forceinline__ double ld_tsd_pinned(const tsd_cell_t* p)
+{
+#ifdef TSD_STORAGE_Q32
+  const int32_t q = ld_pinned(p); return q == Q_NAN ? __builtin_nan("") : ldexp((double)q, -30);
+#else
+  return ld_pinned(p);
+#endif
+}
 // the four cells a bilinear look-up at anchor (lx, ly) touches, reads issued together (the halo strip when lx / ly == 31)
 struct Quad { double t00, t01, t10, t11; };
 __device__ __forceinline__ Quad load_quad(const tsd_cell_t* __restrict__ tile, int lx, int ly)
 {
+  // (pinned: the callers issue these next to the tile's flag read; as plain reads they are sunk behind the test of the flag)
   Quad q;
-  q.t00 = ld_tsd(tile + cell_off(lx, ly));     q.t01 = ld_tsd(tile + cell_off(lx + 1, ly));
-  q.t10 = ld_tsd(tile + cell_off(lx, ly + 1)); q.t11 = ld_tsd(tile + cell_off(lx + 1, ly + 1));
+  q.t00 = ld_tsd_pinned(tile + cell_off(lx, ly));     q.t01 = ld_tsd_pinned(tile + cell_off(lx + 1, ly));
+  q.t10 = ld_tsd_pinned(tile + cell_off(lx, ly + 1)); q.t11 = ld_tsd_pinned(tile + cell_off(lx + 1, ly + 1));
   return q;
 }
 
