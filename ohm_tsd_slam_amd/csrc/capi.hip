@@ -371,10 +371,13 @@ tsd_ctx* tsd_create(int device, int map_size_log2, double cell_size, double max_
   A(hipMalloc(&ctx->d_mask, TSD_MAX_BEAMS));
   A(hipMalloc(&ctx->d_rays, 2 * TSD_MAX_BEAMS * sizeof(double)));
   A(hipMalloc(&ctx->d_rays_local, 2 * TSD_MAX_BEAMS * sizeof(double)));
-  A(hipMalloc(&ctx->d_coords, 2 * TSD_MAX_BEAMS * sizeof(double)));
-  A(hipMalloc(&ctx->d_normals, 2 * TSD_MAX_BEAMS * sizeof(double)));
+  // the ray cast's three outputs in ONE block, laid out like tsd_raycast's host buffer: one device-to-host copy brings them back
+  A(hipMalloc(&ctx->d_coords, (size_t)TSD_MAX_BEAMS * 33));
+  if (ctx->d_coords) {
+    ctx->d_normals = ctx->d_coords + 2 * TSD_MAX_BEAMS;
+    ctx->d_mask_m = reinterpret_cast<uint8_t*>(ctx->d_coords) + (size_t)TSD_MAX_BEAMS * 32;
+  }
   A(hipMalloc(&ctx->d_mnormals, 2 * TSD_MAX_ICP_POINTS * sizeof(double)));
-  A(hipMalloc(&ctx->d_mask_m, TSD_MAX_BEAMS));
   A(hipMalloc(&ctx->d_model, 2 * TSD_MAX_ICP_POINTS * sizeof(double)));
   A(hipMalloc(&ctx->d_scene, 2 * TSD_MAX_ICP_POINTS * sizeof(double)));
   A(hipMalloc(&ctx->d_morig, TSD_MAX_ICP_POINTS * sizeof(int)));
@@ -445,7 +448,7 @@ void tsd_destroy(tsd_ctx* ctx)
     if (ctx->stage_ev[s]) hipEventDestroy(ctx->stage_ev[s]);
   }
   hipFree(ctx->d_ranges); hipFree(ctx->d_mask); hipFree(ctx->d_rays); hipFree(ctx->d_rays_local);
-  hipFree(ctx->d_coords); hipFree(ctx->d_normals); hipFree(ctx->d_mnormals); hipFree(ctx->d_mask_m); hipFree(ctx->d_model);
+  hipFree(ctx->d_coords); /* (+ d_normals, d_mask_m: one block) */ hipFree(ctx->d_mnormals); hipFree(ctx->d_model);
   hipFree(ctx->d_scene); hipFree(ctx->d_morig); hipFree(ctx->d_start); hipFree(ctx->d_icp_res); hipFree(ctx->d_icp_trace); hipHostFree(ctx->h_icp_res); hipHostFree(ctx->h_out);
   hipFree(ctx->d_occ); hipFree(ctx->d_occ_count); hipFree(ctx->d_occ_heads); hipFree(ctx->d_occ_list);
   if (ctx->d_pdf) hipFree(ctx->d_pdf);
@@ -591,9 +594,8 @@ int tsd_raycast(tsd_ctx* ctx, const double pose33[9], const double* rays_world_2
   if (rc != TSD_OK) return rc;
   const size_t nb = (size_t)beams;
   char* o = ctx->h_out;
-  TSD_HIP_CHECK(ctx, hipMemcpyAsync(o, ctx->d_coords, nb * 16, hipMemcpyDeviceToHost, ctx->stream));
-  TSD_HIP_CHECK(ctx, hipMemcpyAsync(o + (size_t)TSD_MAX_BEAMS * 16, ctx->d_normals, nb * 16, hipMemcpyDeviceToHost, ctx->stream));
-  TSD_HIP_CHECK(ctx, hipMemcpyAsync(o + (size_t)TSD_MAX_BEAMS * 32, ctx->d_mask_m, nb, hipMemcpyDeviceToHost, ctx->stream));
+  // coords | normals | mask: one block on both sides (tsd_create), one copy (three copies cost ~3 x 15 us of a 12 us kernel's call)
+  TSD_HIP_CHECK(ctx, hipMemcpyAsync(o, ctx->d_coords, (size_t)TSD_MAX_BEAMS * 32 + nb, hipMemcpyDeviceToHost, ctx->stream));
   TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   const double* hc = reinterpret_cast<const double*>(o);
   const double* hn = reinterpret_cast<const double*>(o + (size_t)TSD_MAX_BEAMS * 16);

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <limits>
 
@@ -328,8 +329,25 @@ void ThreadLocalize::processScan(const std::vector<float>& ranges, const builtin
 // registration_mode 3 (ThreadLocalize.cpp:353-406 with doRegistration's case TSD, :557-567): ray cast, the TSD_PDF
 // pre-registration on the beam-indexed model / scene, then Icp::iterate with its result as Tinit.  The unfused call
 // structure of the reference: the pre-registration's host part sits between the ray cast and the registration.
+namespace {
+// TSD_MODE3_TIMING=1: where a registration_mode-3 scan's host time goes (printed every 100 scans)
+struct Mode3Timing {
+  bool on = std::getenv("TSD_MODE3_TIMING") != nullptr;
+  double acc[6] = {0, 0, 0, 0, 0, 0}; int scans = 0;
+  std::chrono::steady_clock::time_point t;
+  void start() { if(on) t = std::chrono::steady_clock::now(); }
+  void lap(int i) { if(!on) return; const auto now = std::chrono::steady_clock::now(); acc[i] += std::chrono::duration<double, std::micro>(now - t).count(); t = now; }
+  void scan() {
+    if(!on || ++scans % 100) return;
+    std::fprintf(stderr, "mode 3, us per scan: ray cast %.1f | scene points %.1f | TSD_PDF match %.1f | registration (fused) %.1f | finish + push %.1f\n",
+                 acc[0] / scans, acc[1] / scans, acc[2] / scans, acc[3] / scans, acc[4] / scans);
+  }
+} g_m3;
+}
+
 void ThreadLocalize::processScanPreRegistered(ScanReport& rep)
 {
+  g_m3.start();
   const unsigned int n = _sensor->getRealMeasurementSize();
   if(_modelCoords.size() != 2 * (size_t)n)      // first call: buffers (ThreadLocalize.cpp:342-350)
   {
@@ -340,6 +358,7 @@ void ThreadLocalize::processScanPreRegistered(ScanReport& rep)
   bool* maskS = reinterpret_cast<bool*>(_maskS.data());
   unsigned int validModelPoints = 0;
   const int rcR = _grid.raycast(_sensor, _modelCoords.data(), _modelNormals.data(), maskM, &validModelPoints);
+  g_m3.lap(0);
   _sensor->getTransformation().getData(rep.pose);
   rep.validModel = (int)validModelPoints;
   if(rcR != TSD_OK || validModelPoints == 0)
@@ -352,24 +371,22 @@ void ThreadLocalize::processScanPreRegistered(ScanReport& rep)
   }
   const unsigned int validScenePoints = _sensor->dataToCartesianVectorMask(_scene.data(), maskS);
   rep.validScene = (int)validScenePoints;
-  // maskMatrix (ThreadLocalize.cpp:738-755)
-  std::vector<double> Mvalid(2 * (size_t)validModelPoints), Svalid(2 * (size_t)validScenePoints);
-  {
-    size_t c = 0;
-    for(unsigned int i = 0; i < n; i++) if(maskM[i]) { Mvalid[c++] = _modelCoords[2 * i]; Mvalid[c++] = _modelCoords[2 * i + 1]; }
-    c = 0;
-    for(unsigned int i = 0; i < n; i++) if(maskS[i]) { Svalid[c++] = _scene[2 * i]; Svalid[c++] = _scene[2 * i + 1]; }
-  }
+  g_m3.lap(1);
   // doRegistration, case TSD: T = _TSD_PDFMatcher->match(sensor->getTransformation(), M, _maskM, NULL, S, _maskS,
   //                                                      deg2rad(_ranPhiMax), _trnsMax, sensor->getAngularResolution())
   obvious::Matrix Tpre = _preMatcher->match(_sensor->getTransformation(), _modelCoords.data(), maskM, nullptr, _scene.data(), maskS,
                                             n, _ranPhiMax * M_PI / 180.0, _trnsMax, _sensor->getAngularResolution());
+  g_m3.lap(2);
   tsd_icp_params p = _icpParams;
   Tpre.getData(p.t_init);
   p.use_t_init = 1;
   tsd_icp_result res;
   std::memset(&res, 0, sizeof(res));
-  const int rc = _grid.icp(Mvalid.data(), validModelPoints, Svalid.data(), validScenePoints, _sensor->getTransformation(), p, &res);
+  // Icp::iterate with Tinit on the maskMatrix-compacted point sets (ThreadLocalize.cpp:367-377, :738-755): the fused device path --
+  // ray cast again (12 us), compaction of both sets by their masks and the registration without leaving the device -- instead of
+  // compacting on the host and sending both sets back: tsd_icp on arbitrary point sets sorts the model by angle on the host and
+  // costs ~90 us of host work and copies per call, which the ray cast's own beam order makes unnecessary
+  const int rc = _grid.localize(_sensor, p, &res);
   if(rc != TSD_OK)
   {
     std::fprintf(stderr, "Localizer(%s) device error %d\n", _nameSpace.c_str(), rc);
@@ -377,7 +394,9 @@ void ThreadLocalize::processScanPreRegistered(ScanReport& rep)
     _report = rep; _processed++;
     return;
   }
+  g_m3.lap(3);
   finishScan(rep, res);
+  g_m3.lap(4); g_m3.scan();
 }
 
 // what follows the registration (ThreadLocalize.cpp:381-406): gate, Sensor::transform, pose / tf, push decision

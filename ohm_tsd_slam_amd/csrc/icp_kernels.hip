@@ -578,9 +578,14 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
       offM += __popcll(bm[q] & lt); offS += __popcll(bs[q] & lt);
       if (fm[q] && offM < cap) { L.mxy[offM] = make_double2(cmx[q], cmy[q]); L.morig[offM] = offM; if (L.nxy) L.nxy[offM] = make_double2(nnx[q], nny[q]); }
       if (fs[q] && offS < cap) {
-        // coords = raysLocal(j,i) * data[i] (Sensor.cpp:176-179)
-        L.stage_s[offS] = make_double2(lx[q] * rr[q], ly[q] * rr[q]);
-        L.start[offS] = offM;      // model slot of the same beam (or of the next hit beam)
+        // coords = raysLocal(j,i) * data[i] (Sensor.cpp:176-179), then applyTransformation(_sceneTmp, Tinit) (Icp.cpp:481-486,
+        // :371-408) like the direct mode below: (0 + x*R00) + y*R01, then + t.  Tinit is the identity unless a pre-registration ran
+        // (registration_mode 3), and x*1 + y*0 + 0 == x exactly: mode 0 is unchanged bit for bit
+        const double x = lx[q] * rr[q], y = ly[q] * rr[q];
+        double nx = 0.0, ny = 0.0;
+        nx += x * a.Tinit[0]; nx += y * a.Tinit[1]; ny += x * a.Tinit[3]; ny += y * a.Tinit[4];
+        L.stage_s[offS] = make_double2(nx + a.Tinit[2], ny + a.Tinit[5]);
+        L.start[offS] = offM;      // model slot of the same beam (or of the next hit beam): a search hint only
       }
     }
     nM = runM; nS = runS;

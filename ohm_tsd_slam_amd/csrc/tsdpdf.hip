@@ -25,7 +25,10 @@
 #include "tsd_ctx.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -35,19 +38,23 @@ struct PdfCandidate { int idx, i; double phi; };
 struct PdfResult { double T[9]; double prob; int idx, i, candidates, pad; };
 
 constexpr int PDF_MAX_CONTROL = 1024;      // control points held in LDS (16 KB)
-constexpr int PDF_BATCH = 8;               // look-ups of one candidate in flight together
+constexpr int PDF_BATCH = 4;               // look-ups per LANE in flight together (64 x 4 control points per round)
 
-// one lane per candidate: probability of the control set under T(idx, i)
-__global__ void __launch_bounds__(256)
+// One WAVE per candidate: probability of the control set under T(idx, i).  Lane l takes the control points l, l + 64, ...: their
+// bilinear look-ups (tile flag and the four cells issued together: the tile storage exists for every tile) all run side by side,
+// the factors meet in LDS and are multiplied IN THE REFERENCE'S ORDER (s = 0 .. C-1: the winner is an arg-max over floating-point
+// products) by every lane alike.  (Rounds 2-3 ran one LANE per candidate: 1 300 candidates = 20 waves, each a chain of C / 8 memory
+// round trips -- 164 us for 180 k look-ups.)
+constexpr int PDF_WAVES = 4;               // candidates per workgroup
+__global__ void __launch_bounds__(64 * PDF_WAVES)
 k_pdf_score(GridDev g, const double* __restrict__ pose /* 9 */, const double* __restrict__ M, const double* __restrict__ S,
             const double2* __restrict__ control, int n_control, const PdfCandidate* __restrict__ cand, int n_cand,
             double zrand, double* __restrict__ prob_out)
 {
-  __shared__ double2 s_c[PDF_MAX_CONTROL];
-  for (int k = threadIdx.x; k < n_control; k += blockDim.x) s_c[k] = control[k];
-  __syncthreads();
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= n_cand) return;
+  __shared__ double s_f[PDF_WAVES][PDF_MAX_CONTROL];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * PDF_WAVES + wave;
+  if (c >= n_cand) return;                                   // (whole waves: no barrier below)
   const PdfCandidate cd = cand[c];
   // T = MatrixFactory::TransformationMatrix33(phi, 0, 0) + translation (TSD_PDFMatching.cpp:217-223)
   const double co = cos(cd.phi), si = sin(cd.phi);
@@ -65,28 +72,42 @@ k_pdf_score(GridDev g, const double* __restrict__ pose /* 9 */, const double* __
       t += pose[3 * r] * T[q]; t += pose[3 * r + 1] * T[3 + q]; t += pose[3 * r + 2] * T[6 + q];
       TM[3 * r + q] = t;
     }
-  double prob = 1.0;
-  for (int s0 = 0; s0 < n_control; s0 += PDF_BATCH) {
-    double f[PDF_BATCH];
+  for (int s0 = 0; s0 < n_control; s0 += 64 * PDF_BATCH) {
+    // up to PDF_BATCH look-ups per lane, all their reads in flight together
+    uint8_t fl[PDF_BATCH]; Quad qv[PDF_BATCH]; double wx[PDF_BATCH], wy[PDF_BATCH]; bool inside[PDF_BATCH];
 #pragma unroll
     for (int b = 0; b < PDF_BATCH; b++) {
-      f[b] = 1.0;
-      const int s = s0 + b;
-      if (s < n_control) {
-        const double2 cp = s_c[s];
-        // STemp = TMap * Control, Control column = (x, y, 1)
-        double cx = 0.0, cy = 0.0;
-        cx += TM[0] * cp.x; cx += TM[1] * cp.y; cx += TM[2] * 1.0;
-        cy += TM[3] * cp.x; cy += TM[4] * cp.y; cy += TM[5] * 1.0;
-        double tsd;
-        // !interpolateBilinear(...) <=> INTERPOLATE_SUCCESS (TsdGrid.h:28): clipped probability, else zrand (:244-254)
-        f[b] = (interpolate_bilinear(g, cx, cy, tsd) == INTERP_SUCCESS) ? (1.0 - (1.0 - zrand) * fabs(tsd)) : zrand;
-      }
+      const int s = s0 + 64 * b + lane;
+      fl[b] = 0; inside[b] = false; wx[b] = 0.0; wy[b] = 0.0; qv[b].t00 = qv[b].t01 = qv[b].t10 = qv[b].t11 = 0.0;
+      if (s0 + 64 * b >= n_control) continue;                // (wave-uniform)
+      const double2 cp = control[s < n_control ? s : 0];
+      // STemp = TMap * Control, Control column = (x, y, 1)
+      double cx = 0.0, cy = 0.0;
+      cx += TM[0] * cp.x; cx += TM[1] * cp.y; cx += TM[2] * 1.0;
+      cy += TM[3] * cp.x; cy += TM[4] * cp.y; cy += TM[5] * 1.0;
+      int p = 0, lx = 0, ly = 0; double dx = 0.0, dy = 0.0;
+      inside[b] = coord2cell(g, cx, cy, p, lx, ly, dx, dy);
+      if (!inside[b]) { p = 0; lx = 0; ly = 0; }
+      fl[b] = ld_pinned(&g.flags[p]);
+      qv[b] = load_quad(g.tsd + (size_t)p * TILE_STRIDE, lx, ly);
+      wx[b] = fabs((cx - dx) * g.inv_cs); wy[b] = fabs((cy - dy) * g.inv_cs);
     }
 #pragma unroll
-    for (int b = 0; b < PDF_BATCH; b++) if (s0 + b < n_control) prob *= f[b];      // the reference's order
+    for (int b = 0; b < PDF_BATCH; b++) {
+      const int s = s0 + 64 * b + lane;
+      if (s >= n_control) continue;
+      // TsdGrid::interpolateBilinear (TsdGrid.h:284-304): !interpolateBilinear(...) <=> INTERPOLATE_SUCCESS (TsdGrid.h:28): clipped
+      // probability, else zrand (TSD_PDFMatching.cpp:244-254)
+      const double tsd = qv[b].t00 * (1. - wy[b]) * (1. - wx[b]) + qv[b].t10 * wy[b] * (1. - wx[b])
+                       + qv[b].t01 * (1. - wy[b]) * wx[b] + qv[b].t11 * wy[b] * wx[b];
+      const bool ok = inside[b] && fl[b] != 0 && !isnan(tsd);
+      s_f[wave][s] = ok ? (1.0 - (1.0 - zrand) * fabs(tsd)) : zrand;
+    }
   }
-  prob_out[c] = prob;
+  // (the wave's own LDS writes are visible to its own reads: LDS executes a wave's accesses in order)
+  double prob = 1.0;
+  for (int s = 0; s < n_control; s++) prob *= s_f[wave][s];        // the reference's order
+  if (lane == 0) prob_out[c] = prob;
 }
 
 // first candidate (list order = the reference's serial trial / i order) that reaches the maximum; bestProb starts at
@@ -136,6 +157,7 @@ k_pdf_argmax(const double* __restrict__ prob, const PdfCandidate* __restrict__ c
 // Matrix::pcaAnalysis for n x 2 points (obcore/math/linalg/gsl/Matrix.cpp:227-327): centroid (gsl_stats_mean: running
 // mean in long double), M^T M, its eigenvectors (gsl_linalg_SV_decomp_jacobi of a symmetric 2 x 2 matrix = its
 // eigen-decomposition; column signs are free and nothing below depends on them), extents along both axes.
+constexpr int PCA_MAX_POINTS = 16;          // >= 2 * searchRadius (= _pcaSearchRange = 10)
 static void pca2_axes(const double* pts, int n, double axes[2][4])
 {
   double cent[2];
@@ -144,7 +166,7 @@ static void pca2_axes(const double* pts, int n, double axes[2][4])
     for (int i = 0; i < n; i++) mean += ((long double)pts[2 * i + j] - mean) / (long double)(i + 1);
     cent[j] = (double)mean;
   }
-  std::vector<double> mc(2 * (size_t)n);
+  double mc[2 * PCA_MAX_POINTS];                              // (n <= 2 * searchRadius: no heap in a per-point routine)
   for (int i = 0; i < n; i++) { mc[2 * i] = pts[2 * i] + (-cent[0]); mc[2 * i + 1] = pts[2 * i + 1] + (-cent[1]); }
   double a = 0.0, b = 0.0, c = 0.0;
   for (int i = 0; i < n; i++) { a += mc[2 * i] * mc[2 * i]; b += mc[2 * i] * mc[2 * i + 1]; c += mc[2 * i + 1] * mc[2 * i + 1]; }
@@ -178,16 +200,20 @@ static void calc_normals(const double* M, int points, std::vector<double>& N, co
 {
   for (int i = 0; i < sr && i < points; i++) mask_out[i] = 0;
   for (int i = std::max(points - sr, 0); i < points; i++) mask_out[i] = 0;
-  std::vector<double> A(2 * (size_t)(2 * sr + 1));
+  double A[2 * PCA_MAX_POINTS];
   for (int i = sr; i < points - sr; i++) {
     if (!mask_in[i]) continue;
+    // A point that is masked out already (the scene's random subsampling runs BEFORE this, RandomMatching.cpp:176-189 /
+    // TSD_PDFMatching.cpp:81-102) gets a normal in the reference too, but nothing reads it: its mask stays false, calcPhi and
+    // extractSamples skip it.  Not computing it changes no output and saves ~80 % of the scene's PCAs.
+    if (!mask_out[i]) continue;
     unsigned cnt = 0;
     for (int j = -sr; j < sr; j++) if (mask_in[i + j]) cnt++;
     if (cnt > 3) {
       cnt = 0;
       for (int j = -sr; j < sr; j++) if (mask_in[i + j]) { A[2 * cnt] = M[2 * (i + j)]; A[2 * cnt + 1] = M[2 * (i + j) + 1]; cnt++; }
       double ax[2][4];
-      pca2_axes(A.data(), (int)cnt, ax);
+      pca2_axes(A, (int)cnt, ax);
       const double xLong = ax[0][1] - ax[0][0], yLong = ax[0][3] - ax[0][2];
       const double xShort = ax[1][1] - ax[1][0], yShort = ax[1][3] - ax[1][2];
       const double lenLongSqr = xLong * xLong + yLong * yLong, lenShortSqr = xShort * xShort + yShort * yShort;
@@ -215,6 +241,11 @@ extern "C" int tsd_tsdpdf_match(tsd_ctx* ctx, const double pose33[9], const doub
   if (beams < 1 || beams > TSD_MAX_BEAMS || prm->size_control_set < 0 || prm->size_control_set > PDF_MAX_CONTROL || prm->trials < 0)
     return set_error(ctx, TSD_E_CAPACITY, "tsd_tsdpdf_match: beams / control set out of range", hipSuccess);
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  // TSD_MODE3_TIMING=1: the host phases of this call (printed every 100 calls)
+  static const bool timing = std::getenv("TSD_MODE3_TIMING") != nullptr;
+  static double t_acc[6]; static int t_calls;
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](int i) { if (!timing) return; const auto now = std::chrono::steady_clock::now(); t_acc[i] += std::chrono::duration<double, std::micro>(now - t_last).count(); t_last = now; };
   const int n = beams;
   const int SR = 10 / 2;                                   // _pcaSearchRange / 2 (TSD_PDFMatching.cpp:18)
   for (int i = 0; i < 9; i++) result->T[i] = (i % 4 == 0) ? 1.0 : 0.0;     // TBest.setIdentity()
@@ -230,6 +261,7 @@ extern "C" int tsd_tsdpdf_match(tsd_ctx* ctx, const double pose33[9], const doub
   for (int i = 0; i < n; i++) phiM[i] = mMp[i] ? std::atan2(NM[2 * i + 1], NM[2 * i]) : -1e6;     // calcPhi (:155-174)
   std::vector<int> idxM, idxS;
   for (int i = SR; i < n - SR; i++) if (mMp[i]) idxM.push_back(i);                                // extractSamples (:41-50)
+  lap(0);
   // ---- scene (:81-102)
   unsigned valid = 0;
   for (int i = 0; i < n; i++) if (mSp[i]) valid++;
@@ -256,6 +288,7 @@ extern "C" int tsd_tsdpdf_match(tsd_ctx* ctx, const double pose33[9], const doub
       control[2 * k] = S[2 * idx]; control[2 * k + 1] = S[2 * idx + 1];
     }
   }
+  lap(1);
   result->valid_model = (int)idxM.size(); result->valid_scene = (int)idxS.size(); result->control_points = nC;
   if (idxS.size() < 3 || idxM.size() < 3) return TSD_OK;   // "Too less valid points" (:129-139): identity
   int trials = prm->trials;
@@ -284,6 +317,7 @@ extern "C" int tsd_tsdpdf_match(tsd_ctx* ctx, const double pose33[9], const doub
   }
   result->candidates = (int)cand.size();
   if (cand.empty()) return TSD_OK;
+  lap(2);
 
   // ---- device: score + arg-max
   const size_t bM = (size_t)n * 16, bC = (size_t)nC * 16, bK = cand.size() * sizeof(PdfCandidate), bP = 9 * sizeof(double);
@@ -304,10 +338,11 @@ extern "C" int tsd_tsdpdf_match(tsd_ctx* ctx, const double pose33[9], const doub
   std::memcpy(h, M, bM); std::memcpy(h + off_S, S, bM); std::memcpy(h + off_C, control.data(), bC);
   std::memcpy(h + off_K, cand.data(), bK); std::memcpy(h + off_P, pose33, bP);
   TSD_HIP_CHECK(ctx, hipMemcpyAsync(d, h, off_prob, hipMemcpyHostToDevice, ctx->stream));
+  lap(3);
   {
     ScopedKernelTimer t(ctx, "tsdpdf", true);
     const int nc = (int)cand.size();
-    hipLaunchKernelGGL(k_pdf_score, dim3((nc + 255) / 256), dim3(256), 0, ctx->stream, ctx->grid, reinterpret_cast<const double*>(d + off_P),
+    hipLaunchKernelGGL(k_pdf_score, dim3((nc + PDF_WAVES - 1) / PDF_WAVES), dim3(64 * PDF_WAVES), 0, ctx->stream, ctx->grid, reinterpret_cast<const double*>(d + off_P),
                        reinterpret_cast<const double*>(d), reinterpret_cast<const double*>(d + off_S),
                        reinterpret_cast<const double2*>(d + off_C), nC, reinterpret_cast<const PdfCandidate*>(d + off_K), nc,
                        prm->zrand, reinterpret_cast<double*>(d + off_prob));
@@ -318,6 +353,10 @@ extern "C" int tsd_tsdpdf_match(tsd_ctx* ctx, const double pose33[9], const doub
   TSD_HIP_CHECK(ctx, hipGetLastError());
   TSD_HIP_CHECK(ctx, hipMemcpyAsync(h + off_res, d + off_res, sizeof(PdfResult), hipMemcpyDeviceToHost, ctx->stream));
   TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  lap(4);
+  if (timing && ++t_calls % 100 == 0)
+    std::fprintf(stderr, "tsd_tsdpdf_match, us per call: model normals %.1f | scene normals + control set %.1f | candidates (%d) %.1f | staging + H2D issue %.1f | kernels + D2H %.1f\n",
+                 t_acc[0] / t_calls, t_acc[1] / t_calls, (int)cand.size(), t_acc[2] / t_calls, t_acc[3] / t_calls, t_acc[4] / t_calls);
   const PdfResult* r = reinterpret_cast<const PdfResult*>(h + off_res);
   std::memcpy(result->T, r->T, sizeof(r->T));
   result->probability = r->prob; result->idx_model = r->idx; result->idx_scene = r->i;
