@@ -151,7 +151,9 @@ int tsd_icp_normals(tsd_ctx* ctx, const double* model_xy, const double* model_no
 
 /* Fused body of ThreadLocalize::eventLoop between setStandardMask and isRegistrationError
  * (ThreadLocalize.cpp:353-377): ray cast -> dataToCartesianVectorMask -> maskMatrix compaction ->
- * doRegistration, without leaving the device.  rays_local_2xB = Sensor::_raysLocal. */
+ * doRegistration, without leaving the device.  rays_local_2xB = Sensor::_raysLocal.  params->t_init (use_t_init != 0) is the
+ * Tinit of Icp::iterate (Icp.cpp:481-486), applied while the device stages the scene: registration_mode 3 hands its
+ * pre-registration result over this way (csrc/host/ThreadLocalize.cpp: processScanPreRegistered). */
 int tsd_localize(tsd_ctx* ctx, const double pose33[9], const double* rays_world_2xB,
                  const double* rays_local_2xB, const double* ranges, const uint8_t* mask, int beams,
                  double min_range, double max_range, const tsd_icp_params* params,

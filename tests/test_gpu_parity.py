@@ -309,6 +309,32 @@ def test_localize_fused_matches_pieces(oracle):
     assert d <= TOL_POSE_M and a <= TOL_POSE_RAD
 
 
+def test_localize_fused_with_t_init_matches_direct_call_and_oracle(oracle):
+    """registration_mode 3's registration: tsd_localize with tsd_icp_params.t_init (Tinit applied while the device stages the
+    scene, Icp.cpp:481-486) == tsd_icp on the maskMatrix-compacted sets with the same Tinit == the oracle's Icp::iterate(Tinit)."""
+    gc = synth.GridConfig(10, 0.05)
+    geo = synth.ScanGeometry.utm30lx()
+    world = synth.World("pillars", gc)
+    og, dg = build_map(oracle, gc, geo, world)
+    pose, rl, rw, data, mask, M, S = icp_inputs(oracle, gc, geo, world, 3, og)
+    bounds = (0.0, og.max_x, 0.0, og.max_x)
+    Tinit = synth.pose_matrix(0.04, -0.03, 0.02)
+    ro = oracle.icp_init(M, S, pose, 30, 0.4, 0.02, bounds, Tinit, nn_mode=1)
+    p = dg.icp_params(30, 0.4, 0.02, t_init=Tinit)
+    rd = dg.icp(M, S, pose, p)
+    rf = dg.localize(pose, rw, rl, data, mask, H.MIN_RANGE, H.MAX_RANGE, p)
+    assert (rf.n_model, rf.n_scene) == (len(M), len(S))
+    assert (rf.pairs, rf.iterations, rf.state) == (rd.pairs, rd.iterations, rd.state) == (ro["pairs"], ro["iterations"], ro["state"])
+    d, a = H.pose_delta(rd.T, rf.T)
+    assert d <= 1e-12 and a <= 1e-12 and abs(rf.rms - rd.rms) <= 1e-12
+    d, a = H.pose_delta(ro["T"], rf.T)
+    assert d <= 1e-9 and a <= 1e-9
+    # and the identity Tinit is the plain call, bit for bit (x*1 + y*0 + 0 == x)
+    r0 = dg.localize(pose, rw, rl, data, mask, H.MIN_RANGE, H.MAX_RANGE, dg.icp_params(30, 0.4, 0.02))
+    r1 = dg.localize(pose, rw, rl, data, mask, H.MIN_RANGE, H.MAX_RANGE, dg.icp_params(30, 0.4, 0.02, t_init=np.eye(3)))
+    assert np.array_equal(np.asarray(r0.T), np.asarray(r1.T)) and r0.rms == r1.rms and r0.pairs == r1.pairs
+
+
 @pytest.mark.parametrize("fused", [False, True])
 def test_closed_loop_trajectory(oracle, fused):
     """init -> [raycast -> ICP -> transform -> push] x K on both sides, poses compared every scan.
