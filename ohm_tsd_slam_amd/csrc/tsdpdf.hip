@@ -152,6 +152,107 @@ k_pdf_argmax(const double* __restrict__ prob, const PdfCandidate* __restrict__ c
   }
 }
 
+// ---- RandomMatching::calcNormals + calcPhi on the device (second half of round 3) ---------------------------------------------
+// One thread per point: Matrix::pcaAnalysis over its <= 10 masked-in neighbours, the axis-ratio test, the normal's sign, its angle.
+// The host restatement below (kept: it is what the oracle mirrors statement by statement) spends ~140 us per 1 081-point set, serial;
+// this is the same arithmetic in the same order with two exceptions, both below 1e-15 relative: gsl_stats_mean's running mean in
+// `long double` (64-bit significand, no device type) is carried in double-double (106 bits: at least as accurate, rounds to the same
+// double unless the x87 chain's own rounding error crosses a rounding boundary, ~0.5 % of the means, 1 ulp then), and atan2 / cos / sin
+// are the device library's instead of glibc's.  Discrete outcomes (masks) can differ only for a point whose axis ratio sits within
+// ~1e-15 of its threshold.
+struct DD { double hi, lo; };
+__device__ __forceinline__ DD dd_quick_two_sum(double a, double b) { const double s = a + b; return DD{s, b - (s - a)}; }
+__device__ __forceinline__ DD dd_two_sum(double a, double b) { const double s = a + b, bb = s - a; return DD{s, (a - (s - bb)) + (b - bb)}; }
+__device__ __forceinline__ DD dd_two_prod(double a, double b) { const double p = a * b; return DD{p, __builtin_fma(a, b, -p)}; }
+__device__ __forceinline__ DD dd_add(DD a, DD b)
+{
+  DD s = dd_two_sum(a.hi, b.hi);
+  const DD t = dd_two_sum(a.lo, b.lo);
+  s.lo += t.hi; s = dd_quick_two_sum(s.hi, s.lo);
+  s.lo += t.lo; return dd_quick_two_sum(s.hi, s.lo);
+}
+__device__ __forceinline__ DD dd_div_d(DD a, double b)
+{
+  const double q1 = a.hi / b;
+  const DD p = dd_two_prod(q1, b);
+  DD r = dd_two_sum(a.hi, -p.hi);
+  r.lo += a.lo; r.lo -= p.lo;
+  const double q2 = (r.hi + r.lo) / b;
+  return dd_quick_two_sum(q1, q2);
+}
+struct PdfNormalsSet { const double* xy; const uint8_t* mask_in; uint8_t* mask_io; double* phi; };
+
+__global__ void __launch_bounds__(256)
+k_pdf_normals(PdfNormalsSet set0, PdfNormalsSet set1, int points, int sr)
+{
+  const PdfNormalsSet st = blockIdx.y == 0 ? set0 : set1;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= points) return;
+  const double NO_PHI = -1e6;                                 // calcPhi's value for a masked-out point (RandomMatching.cpp:155-174)
+  if (i < sr || i >= points - sr) { st.mask_io[i] = 0; st.phi[i] = NO_PHI; return; }
+  if (!st.mask_in[i] || !st.mask_io[i]) { st.mask_io[i] = 0; st.phi[i] = NO_PHI; return; }   // (mask_io <= mask_in on entry)
+  double A[2 * 10];
+  int cnt = 0;
+  for (int j = -sr; j < sr; j++)
+    if (st.mask_in[i + j] && cnt < 10) { A[2 * cnt] = st.xy[2 * (i + j)]; A[2 * cnt + 1] = st.xy[2 * (i + j) + 1]; cnt++; }
+  if (cnt <= 3) { st.mask_io[i] = 0; st.phi[i] = NO_PHI; return; }
+  // Matrix::pcaAnalysis (gsl/Matrix.cpp:227-327), see pca2_axes below
+  double cent[2];
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    DD mean = DD{0.0, 0.0};
+    for (int k = 0; k < cnt; k++) {
+      DD d = dd_two_sum(A[2 * k + j], -mean.hi);            // x - mean
+      d.lo -= mean.lo; d = dd_quick_two_sum(d.hi, d.lo);
+      mean = dd_add(mean, dd_div_d(d, (double)(k + 1)));
+    }
+    cent[j] = mean.hi;
+  }
+  double mc[2 * 10];
+  for (int k = 0; k < cnt; k++) { mc[2 * k] = A[2 * k] + (-cent[0]); mc[2 * k + 1] = A[2 * k + 1] + (-cent[1]); }
+  double a = 0.0, b = 0.0, c = 0.0;
+  for (int k = 0; k < cnt; k++) { a += mc[2 * k] * mc[2 * k]; b += mc[2 * k] * mc[2 * k + 1]; c += mc[2 * k + 1] * mc[2 * k + 1]; }
+  const double th = 0.5 * atan2(2.0 * b, a - c);
+  const double V[2][2] = {{cos(th), -sin(th)}, {sin(th), cos(th)}};
+  double mx[2], mn[2];
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    mx[q] = -__builtin_inf(); mn[q] = __builtin_inf();
+    for (int r = 0; r < cnt; r++) {
+      double pr = 0.0;
+      pr += V[0][q] * mc[2 * r]; pr += V[1][q] * mc[2 * r + 1];
+      mx[q] = fmax(mx[q], pr); mn[q] = fmin(mn[q], pr);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const double ext = mx[q] - mn[q];
+    const double align = ext > 1e-6 ? (mx[q] + mn[q]) / 2.0 : 0.0;
+#pragma unroll
+    for (int j = 0; j < 2; j++) cent[j] += V[j][q] * align;
+  }
+  double ax[2][4];
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const double ext = mx[q] - mn[q];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const double e = V[j][q] * ext / 2.0;
+      ax[q][2 * j] = cent[j] - e; ax[q][2 * j + 1] = cent[j] + e;
+    }
+  }
+  // RandomMatching::calcNormals (RandomMatching.cpp:82-153)
+  const double xLong = ax[0][1] - ax[0][0], yLong = ax[0][3] - ax[0][2];
+  const double xShort = ax[1][1] - ax[1][0], yShort = ax[1][3] - ax[1][2];
+  const double lenLongSqr = xLong * xLong + yLong * yLong, lenShortSqr = xShort * xShort + yShort * yShort;
+  if (lenShortSqr > 1e-6 && (lenLongSqr / lenShortSqr) < 4.0) { st.mask_io[i] = 0; st.phi[i] = NO_PHI; return; }
+  const double len = sqrt(lenShortSqr);
+  double nx, ny;
+  if ((st.xy[2 * i] * xShort + st.xy[2 * i + 1] * yShort) < 0.0) { nx = xShort / len; ny = yShort / len; }
+  else { nx = -xShort / len; ny = -yShort / len; }
+  st.phi[i] = atan2(ny, nx);
+}
+
 // ---- host side: RandomMatching's O(beams) preparation ------------------------------------------------------
 
 // Matrix::pcaAnalysis for n x 2 points (obcore/math/linalg/gsl/Matrix.cpp:227-327): centroid (gsl_stats_mean: running
@@ -254,15 +355,9 @@ extern "C" int tsd_tsdpdf_match(tsd_ctx* ctx, const double pose33[9], const doub
   if (n < 3) return TSD_OK;                                // "Model and scene contain too less points" (:53-57)
   const double* M = model_xy_2B; const double* S = scene_xy_2B;
 
-  // ---- model (:63-77)
-  std::vector<double> NM(2 * (size_t)n, 0.0), NS(2 * (size_t)n, 0.0), phiM((size_t)n), phiS((size_t)n);
+  // ---- masks, then the normals of both sets (:63-102)
+  std::vector<double> phiM((size_t)n), phiS((size_t)n);
   std::vector<uint8_t> mMp(mask_m, mask_m + n), mSp(mask_s, mask_s + n);
-  calc_normals(M, n, NM, mask_m, mMp, SR);
-  for (int i = 0; i < n; i++) phiM[i] = mMp[i] ? std::atan2(NM[2 * i + 1], NM[2 * i]) : -1e6;     // calcPhi (:155-174)
-  std::vector<int> idxM, idxS;
-  for (int i = SR; i < n - SR; i++) if (mMp[i]) idxM.push_back(i);                                // extractSamples (:41-50)
-  lap(0);
-  // ---- scene (:81-102)
   unsigned valid = 0;
   for (int i = 0; i < n; i++) if (mSp[i]) valid++;
   double probability = 180.0 / (double)valid;
@@ -272,8 +367,62 @@ extern "C" int tsd_tsdpdf_match(tsd_ctx* ctx, const double pose33[9], const doub
     const int thresh = (int)(1000.0 - probability * 1000.0 + 0.5);
     for (int i = 0; i < n; i++) if ((draws_subsample[i] % 1000) < thresh) mSp[i] = 0;
   }
-  calc_normals(S, n, NS, mask_s, mSp, SR);
-  for (int i = 0; i < n; i++) phiS[i] = mSp[i] ? std::atan2(NS[2 * i + 1], NS[2 * i]) : -1e6;
+  const bool res_ok = prm->ang_res > 1e-6;                 // (reported where the reference does, behind the point-count exits: :171-175)
+  const double phi_max = std::min(prm->phi_max, M_PI * 0.5);
+  int span = res_ok ? (int)std::floor(phi_max / prm->ang_res) : n;
+  if (span > n) span = n;
+  // device buffer: [M | S | mask_in M, S | mask_io M, S | phi M, S | control | candidates | pose | prob | result]; the candidate
+  // list is sized for its upper bound (trials x (2 span) scene points) because the normals come back before it is known
+  const size_t max_cand = (size_t)std::max(prm->trials, 0) * (size_t)std::min(2 * span + 1, n) + 1;
+  const size_t bM = (size_t)n * 16, bMask = ((size_t)n + 15) & ~(size_t)15, bPhi = (size_t)n * 8;
+  const size_t bC = (size_t)std::max(prm->size_control_set, 1) * 16, bK = max_cand * sizeof(PdfCandidate), bP = 80;
+  const size_t off_S = bM, off_mi = 2 * bM, off_mo = off_mi + 2 * bMask, off_phi = off_mo + 2 * bMask;
+  const size_t off_C = off_phi + 2 * bPhi, off_K = off_C + bC, off_P = off_K + ((bK + 15) & ~(size_t)15);
+  const size_t off_prob = off_P + bP, off_res = off_prob + max_cand * sizeof(double);
+  const size_t total = off_res + sizeof(PdfResult);
+  if (total > ctx->pdf_bytes) {
+    TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_pdf) hipFree(ctx->d_pdf);
+    if (ctx->h_pdf) hipHostFree(ctx->h_pdf);
+    ctx->d_pdf = nullptr; ctx->h_pdf = nullptr; ctx->pdf_bytes = 0;
+    const size_t want = total + total / 4;
+    TSD_HIP_CHECK(ctx, hipMalloc(&ctx->d_pdf, want));
+    TSD_HIP_CHECK(ctx, hipHostMalloc(&ctx->h_pdf, want, hipHostMallocDefault));
+    ctx->pdf_bytes = want;
+  }
+  TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));          // (the pinned buffer of a previous call is free)
+  char* h = ctx->h_pdf; char* d = ctx->d_pdf;
+  static const bool host_normals = std::getenv("TSD_PDF_HOST_NORMALS") != nullptr;     // A/B and cross-check: the host restatement
+  std::memcpy(h, M, bM); std::memcpy(h + off_S, S, bM);
+  if (host_normals) {
+    std::vector<double> NM(2 * (size_t)n, 0.0), NS(2 * (size_t)n, 0.0);
+    calc_normals(M, n, NM, mask_m, mMp, SR);
+    for (int i = 0; i < n; i++) phiM[i] = mMp[i] ? std::atan2(NM[2 * i + 1], NM[2 * i]) : -1e6;     // calcPhi (:155-174)
+    lap(0);
+    calc_normals(S, n, NS, mask_s, mSp, SR);
+    for (int i = 0; i < n; i++) phiS[i] = mSp[i] ? std::atan2(NS[2 * i + 1], NS[2 * i]) : -1e6;
+    TSD_HIP_CHECK(ctx, hipMemcpyAsync(d, h, 2 * bM, hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    std::memcpy(h + off_mi, mask_m, (size_t)n); std::memcpy(h + off_mi + bMask, mask_s, (size_t)n);
+    std::memcpy(h + off_mo, mMp.data(), (size_t)n); std::memcpy(h + off_mo + bMask, mSp.data(), (size_t)n);
+    TSD_HIP_CHECK(ctx, hipMemcpyAsync(d, h, off_phi, hipMemcpyHostToDevice, ctx->stream));
+    PdfNormalsSet sm{reinterpret_cast<const double*>(d), reinterpret_cast<const uint8_t*>(d + off_mi), reinterpret_cast<uint8_t*>(d + off_mo),
+                     reinterpret_cast<double*>(d + off_phi)};
+    PdfNormalsSet ss{reinterpret_cast<const double*>(d + off_S), reinterpret_cast<const uint8_t*>(d + off_mi + bMask),
+                     reinterpret_cast<uint8_t*>(d + off_mo + bMask), reinterpret_cast<double*>(d + off_phi + bPhi)};
+    {
+      ScopedKernelTimer t(ctx, "tsdpdf", true);
+      hipLaunchKernelGGL(k_pdf_normals, dim3((n + 255) / 256, 2), dim3(256), 0, ctx->stream, sm, ss, n, SR);
+    }
+    TSD_HIP_CHECK(ctx, hipGetLastError());
+    TSD_HIP_CHECK(ctx, hipMemcpyAsync(h + off_mo, d + off_mo, off_C - off_mo, hipMemcpyDeviceToHost, ctx->stream));   // masks + angles
+    TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(mMp.data(), h + off_mo, (size_t)n); std::memcpy(mSp.data(), h + off_mo + bMask, (size_t)n);
+    std::memcpy(phiM.data(), h + off_phi, bPhi); std::memcpy(phiS.data(), h + off_phi + bPhi, bPhi);
+    lap(0);
+  }
+  std::vector<int> idxM, idxS;
+  for (int i = SR; i < n - SR; i++) if (mMp[i]) idxM.push_back(i);                                // extractSamples (:41-50)
   for (int i = SR; i < n - SR; i++) if (mSp[i]) idxS.push_back(i);
   // ---- control set (:106-118, RandomMatching::pickControlSet :52-80)
   int nC = prm->size_control_set;
@@ -293,10 +442,7 @@ extern "C" int tsd_tsdpdf_match(tsd_ctx* ctx, const double pose33[9], const doub
   if (idxS.size() < 3 || idxM.size() < 3) return TSD_OK;   // "Too less valid points" (:129-139): identity
   int trials = prm->trials;
   if ((int)idxM.size() < trials) trials = (int)idxM.size();
-  double phi_max = std::min(prm->phi_max, M_PI * 0.5);
-  if (!(prm->ang_res > 1e-6)) return set_error(ctx, TSD_E_ARG, "tsd_tsdpdf_match: resolution not properly set", hipSuccess);   // :171-175
-  int span = (int)std::floor(phi_max / prm->ang_res);
-  if (span > n) span = n;
+  if (!res_ok) return set_error(ctx, TSD_E_ARG, "tsd_tsdpdf_match: resolution not properly set", hipSuccess);   // :171-175
   // ---- candidates in the reference's serial order (:185-215)
   std::vector<PdfCandidate> cand;
   {
@@ -317,27 +463,15 @@ extern "C" int tsd_tsdpdf_match(tsd_ctx* ctx, const double pose33[9], const doub
   }
   result->candidates = (int)cand.size();
   if (cand.empty()) return TSD_OK;
+  if (cand.size() > max_cand) return set_error(ctx, TSD_E_CAPACITY, "tsd_tsdpdf_match: candidate bound", hipSuccess);
   lap(2);
 
   // ---- device: score + arg-max
-  const size_t bM = (size_t)n * 16, bC = (size_t)nC * 16, bK = cand.size() * sizeof(PdfCandidate), bP = 9 * sizeof(double);
-  const size_t off_S = bM, off_C = 2 * bM, off_K = off_C + ((bC + 15) & ~(size_t)15), off_P = off_K + ((bK + 15) & ~(size_t)15);
-  const size_t off_prob = off_P + 80, off_res = off_prob + cand.size() * sizeof(double);
-  const size_t total = off_res + sizeof(PdfResult);
-  if (total > ctx->pdf_bytes) {
-    if (ctx->d_pdf) hipFree(ctx->d_pdf);
-    if (ctx->h_pdf) hipHostFree(ctx->h_pdf);
-    ctx->d_pdf = nullptr; ctx->h_pdf = nullptr; ctx->pdf_bytes = 0;
-    const size_t want = total * 2;
-    TSD_HIP_CHECK(ctx, hipMalloc(&ctx->d_pdf, want));
-    TSD_HIP_CHECK(ctx, hipHostMalloc(&ctx->h_pdf, want, hipHostMallocDefault));
-    ctx->pdf_bytes = want;
-  }
-  TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));          // (the pinned buffer of a previous call is free)
-  char* h = ctx->h_pdf; char* d = ctx->d_pdf;
-  std::memcpy(h, M, bM); std::memcpy(h + off_S, S, bM); std::memcpy(h + off_C, control.data(), bC);
-  std::memcpy(h + off_K, cand.data(), bK); std::memcpy(h + off_P, pose33, bP);
-  TSD_HIP_CHECK(ctx, hipMemcpyAsync(d, h, off_prob, hipMemcpyHostToDevice, ctx->stream));
+  const size_t bKu = cand.size() * sizeof(PdfCandidate);
+  std::memcpy(h + off_C, control.data(), (size_t)nC * 16);
+  std::memcpy(h + off_K, cand.data(), bKu); std::memcpy(h + off_P, pose33, 9 * sizeof(double));
+  TSD_HIP_CHECK(ctx, hipMemcpyAsync(d + off_C, h + off_C, bC + bKu, hipMemcpyHostToDevice, ctx->stream));
+  TSD_HIP_CHECK(ctx, hipMemcpyAsync(d + off_P, h + off_P, bP, hipMemcpyHostToDevice, ctx->stream));
   lap(3);
   {
     ScopedKernelTimer t(ctx, "tsdpdf", true);
@@ -355,8 +489,8 @@ extern "C" int tsd_tsdpdf_match(tsd_ctx* ctx, const double pose33[9], const doub
   TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   lap(4);
   if (timing && ++t_calls % 100 == 0)
-    std::fprintf(stderr, "tsd_tsdpdf_match, us per call: model normals %.1f | scene normals + control set %.1f | candidates (%d) %.1f | staging + H2D issue %.1f | kernels + D2H %.1f\n",
-                 t_acc[0] / t_calls, t_acc[1] / t_calls, (int)cand.size(), t_acc[2] / t_calls, t_acc[3] / t_calls, t_acc[4] / t_calls);
+    std::fprintf(stderr, "tsd_tsdpdf_match, us per call: normals of both sets (%s) %.1f | lists + control set %.1f | candidates (%d) %.1f | staging + H2D issue %.1f | kernels + D2H %.1f\n",
+                 host_normals ? "host" : "device", t_acc[0] / t_calls, t_acc[1] / t_calls, (int)cand.size(), t_acc[2] / t_calls, t_acc[3] / t_calls, t_acc[4] / t_calls);
   const PdfResult* r = reinterpret_cast<const PdfResult*>(h + off_res);
   std::memcpy(result->T, r->T, sizeof(r->T));
   result->probability = r->prob; result->idx_model = r->idx; result->idx_scene = r->i;
