@@ -381,6 +381,17 @@ int tsd_measure_stream(tsd_ctx* ctx, int64_t n_doubles, int reps, double* gbs_be
  * the algorithmic-bytes formula without a host sync per push).  Waits for pushes still in flight. */
 int tsd_push_stats_total(tsd_ctx* ctx, tsd_push_stats* total, int64_t* pushes, int reset);
 
+/* registration_mode 3 inside the fused scan (ThreadLocalize.cpp:557-567 with the call structure of tsd_scan): arms the
+ * pre-registration -- obvious::TSD_PDFMatching::match, as tsd_tsdpdf_match -- for the NEXT tsd_scan_submit / tsd_scan of this sensor.
+ * It then runs on the device between that scan's ray cast (whose hits are its model) and its registration (whose Tinit it becomes,
+ * Icp.cpp:481-486): PCA normals of both point sets, extractSamples, pickControlSet, the trial picks and the candidate list in the
+ * reference's serial order, scoring, arg-max -- nothing returns to the host in between.  scene_xy_2B / mask_s: what
+ * Sensor::dataToCartesianVectorMask gives for the scan (beam-indexed); the draws as in tsd_tsdpdf_match.  One-shot. */
+int tsd_scan_preregister(tsd_sensor* s, const tsd_tsdpdf_params* params, const double* scene_xy_2B, const uint8_t* mask_s,
+                         const int* draws_subsample, const int* draws_control, const int* draws_trials);
+/* the pre-registration's outcome for the scan collected last (TBest, probability, winning pair, counts) */
+int tsd_scan_preregistration_result(tsd_sensor* s, tsd_tsdpdf_result* result);
+
 #ifdef __cplusplus
 }
 #endif

@@ -169,6 +169,8 @@ ABI = {
     "tsd_icp_trace": (C.c_int, [C.c_void_p, _dp, C.c_int]),
     "tsd_tsdpdf_match": (C.c_int, [C.c_void_p, _dp, _dp, _u8p, _dp, _u8p, C.c_int, C.POINTER(TsdPdfParams), _ip, _ip, _ip,
                                    C.POINTER(TsdPdfResult)]),
+    "tsd_scan_preregister": (C.c_int, [C.c_void_p, C.POINTER(TsdPdfParams), _dp, _u8p, _ip, _ip, _ip]),
+    "tsd_scan_preregistration_result": (C.c_int, [C.c_void_p, C.POINTER(TsdPdfResult)]),
     "tsd_color_image": (C.c_int, [C.c_void_p, _u8p, C.c_uint, C.c_uint]),
     "tsd_store_grid_text": (C.c_int, [C.c_void_p, C.c_char_p]),
     "tsd_load_grid_text": (C.c_int, [C.c_void_p, C.c_char_p]),
@@ -509,6 +511,22 @@ class TsdSensorDevice:
         r = ScanResult()
         self.grid._check(self.lib.tsd_scan_collect(self.h, C.byref(r)), "tsd_scan_collect")
         return r
+
+    def preregister(self, scene_xy, mask_s, trials, size_control_set, zrand, phi_max, ang_res, draws_sub, draws_ctrl, draws_trials):
+        """tsd_scan_preregister: registration_mode 3's TSD_PDF pre-registration for the NEXT scan of this sensor, on the device
+        between its ray cast and its registration"""
+        prm = TsdPdfParams(int(trials), int(size_control_set), 0.0, float(zrand), float(phi_max), float(ang_res))
+        S, mS = _f64(scene_xy).reshape(-1), np.ascontiguousarray(mask_s, dtype=np.uint8)
+        ds, dc, dt = (np.ascontiguousarray(x, dtype=np.int32) for x in (draws_sub, draws_ctrl, draws_trials))
+        rc = self.lib.tsd_scan_preregister(self.h, C.byref(prm), _d(S), _u8(mS), ds.ctypes.data_as(_ip), dc.ctypes.data_as(_ip),
+                                           dt.ctypes.data_as(_ip))
+        self.grid._check(rc, "tsd_scan_preregister")
+
+    def preregistration_result(self) -> dict:
+        r = TsdPdfResult()
+        self.grid._check(self.lib.tsd_scan_preregistration_result(self.h, C.byref(r)), "tsd_scan_preregistration_result")
+        return {"T": np.array(r.T[:]).reshape(3, 3), "prob": r.probability, "idx": r.idx_model, "i": r.idx_scene,
+                "candidates": r.candidates, "valid_model": r.valid_model, "valid_scene": r.valid_scene, "control_points": r.control_points}
 
     def scan(self, ranges, mask, mask_push, params: IcpParams, gates: GateParams) -> ScanResult:
         rg = _f64(ranges)

@@ -152,6 +152,7 @@ static void fill_icp_args(IcpArgs& a, const double pose33[9], const tsd_icp_para
   // Tinit of Icp::iterate (rows 0, 1 of the 3x3): the identity unless the caller hands a pre-registration result over
   const double I6[6] = {1, 0, 0, 0, 1, 0};
   for (int i = 0; i < 6; i++) a.Tinit[i] = p->use_t_init ? p->t_init[i] : I6[i];
+  a.Tinit_dev = nullptr;
 }
 
 static void fill_raycast_args(const tsd_ctx* ctx, RaycastArgs& a, const double pose33[9], int beams,
@@ -1248,6 +1249,8 @@ void tsd_sensor_destroy(tsd_sensor* s)
   for (hipEvent_t e : {s->ev_rc_done, s->ev_icp_done}) if (e) hipEventDestroy(e);
   if (s->stream) hipStreamDestroy(s->stream);
   hipFree(s->d_coords); hipFree(s->d_normals); hipFree(s->d_mask_m); hipFree(s->d_icp_res); hipFree(s->d_icp_trace);
+  if (s->d_pre) hipFree(s->d_pre);
+  if (s->h_pre) hipHostFree(s->h_pre);
   hipFree(s->d_rmq2[0]); hipFree(s->d_rmq2[1]); hipFree(s->d_rmq2[2]);
   if (s->h_stage2[0]) hipHostFree(s->h_stage2[0]);
   if (s->h_stage2[1]) hipHostFree(s->h_stage2[1]);
@@ -1403,6 +1406,17 @@ int tsd_scan_submit(tsd_sensor* s, const double* ranges, const uint8_t* mask, co
   const double ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   fill_icp_args(ia, ident, params);
   ia.beams = s->beams; ia.ccw = s->ccw ? 1 : 0;
+  // registration_mode 3: the pre-registration armed by tsd_scan_preregister runs here, between the ray cast and the registration,
+  // whose Tinit it leaves on the device
+  s->pre_ran = false;
+  if (s->pre_armed) {
+    s->pre_armed = false;
+    const LaunchTarget* tgp = launch_target();
+    rc = launch_preregistration(ctx, s, launch_stream(ctx), tgp && tgp->coords ? tgp->coords : ctx->d_coords,
+                                tgp && tgp->mask_m ? tgp->mask_m : ctx->d_mask_m, s->d_state->icpP, &ia.Tinit_dev);
+    if (rc != TSD_OK) return rc;
+    s->pre_ran = true;
+  }
   // the gates, Sensor::transform and the push decision run as the epilogue of the registration kernel
   const unsigned long long seq = ++s->seq;
   ScanPostArgs sp;

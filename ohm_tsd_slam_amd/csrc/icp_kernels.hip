@@ -511,6 +511,10 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
 #pragma unroll
     for (int i = 0; i < 6; i++) a.P[i] = P_dev[i];
   }
+  if (a.Tinit_dev) {   // fused registration_mode 3: so does Tinit (k_pdf_argmax's result, the kernel right before this one)
+#pragma unroll
+    for (int i = 0; i < 6; i++) a.Tinit[i] = a.Tinit_dev[i];
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int T = blockDim.x, W = T >> 6;
   int nM = 0, nS = 0;

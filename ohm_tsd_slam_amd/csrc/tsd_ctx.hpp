@@ -41,7 +41,8 @@ struct IcpArgs {
   int beams;                 // fused mode (compaction from per-beam arrays) when > 0
   int ccw;                   // model slots ascend counter-clockwise about the sensor (1) or clockwise (0)
   int estimator;             // TSD_ESTIMATOR_*
-  double Tinit[6];           // rows 0, 1 of Icp::iterate's Tinit (identity in registration_mode 0; direct mode only)
+  double Tinit[6];           // rows 0, 1 of Icp::iterate's Tinit (identity in registration_mode 0)
+  const double* Tinit_dev;   // the same on the device (fused registration_mode 3: the pre-registration's result, first six doubles), or nullptr
 };
 
 struct IcpResultDev {
@@ -255,6 +256,16 @@ struct tsd_sensor {
   int stage_slot = 0;              // the scan / table buffers are used in turn, THREE of them: the scan staged ahead of scan k+2 goes
                                    // where scan k was, and by then the host has seen the result of scan k+1, whose ray cast ran behind
                                    // the push of scan k on the stream -- so that push is done without any event on the stream
+  // fused registration_mode 3 (tsd_scan_preregister, tsdpdf.hip): inputs of the pre-registration that the next tsd_scan_submit runs
+  // on the device between its ray cast and its registration; one device + one pinned buffer, grown on demand
+  char* d_pre = nullptr; char* h_pre = nullptr; size_t pre_bytes = 0;
+  bool pre_armed = false, pre_ran = false;
+  struct PreLayout {
+    size_t off_S, off_ms, off_msp, off_dc, off_dt, in_bytes;             // inputs (host -> device each scan)
+    size_t off_mo_m, off_mo_s, off_phi_m, off_phi_s, off_C, off_K, off_prob, off_hdr, off_res;
+    int n, span, trials, size_control_set, max_cand;
+    double phi_max, zrand;
+  } pre{};
   bool rc_pending = false;         // the next scan's ray cast was enqueued behind this scan's push ...
   unsigned long long rc_epoch = 0; // ... when the context was in this state
 
@@ -340,6 +351,10 @@ int launch_push_tables(tsd_ctx* ctx, hipStream_t stream, int beams, const double
                        double phi_min, double ang_res);
 size_t push_rmq_bytes(int beams);
 size_t push_list_aux_bytes();
+// fused registration_mode 3: normals -> lists -> scoring -> arg-max on `stream`, model = the ray cast's outputs on the device;
+// *tinit_dev = where the registration kernel finds Tinit (tsdpdf.hip)
+int launch_preregistration(tsd_ctx* ctx, tsd_sensor* s, hipStream_t stream, const double* d_coords, const uint8_t* d_mask_m,
+                           const double* d_pose6, const double** tinit_dev);
 size_t push_list_cnt_bytes();
 int launch_free_footprint(tsd_ctx* ctx, unsigned minX, unsigned maxX, unsigned minY, unsigned maxY);
 int launch_neg_scan(tsd_ctx* ctx);

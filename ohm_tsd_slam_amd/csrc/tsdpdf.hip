@@ -36,6 +36,9 @@ namespace tsd {
 
 struct PdfCandidate { int idx, i; double phi; };
 struct PdfResult { double T[9]; double prob; int idx, i, candidates, pad; };
+// what k_pdf_prepare (the fused scan's device-side list building) leaves for the scoring and arg-max kernels, which the host then
+// launches without knowing the counts
+struct PdfHeader { int n_cand, n_control, n_model_valid, n_scene_valid, identity, pad[3]; };
 
 constexpr int PDF_MAX_CONTROL = 1024;      // control points held in LDS (16 KB)
 constexpr int PDF_BATCH = 4;               // look-ups per LANE in flight together (64 x 4 control points per round)
@@ -47,11 +50,12 @@ constexpr int PDF_BATCH = 4;               // look-ups per LANE in flight togeth
 // round trips -- 164 us for 180 k look-ups.)
 constexpr int PDF_WAVES = 4;               // candidates per workgroup
 __global__ void __launch_bounds__(64 * PDF_WAVES)
-k_pdf_score(GridDev g, const double* __restrict__ pose /* 9 */, const double* __restrict__ M, const double* __restrict__ S,
+k_pdf_score(GridDev g, const double* __restrict__ pose /* first two rows suffice */, const double* __restrict__ M, const double* __restrict__ S,
             const double2* __restrict__ control, int n_control, const PdfCandidate* __restrict__ cand, int n_cand,
-            double zrand, double* __restrict__ prob_out)
+            double zrand, double* __restrict__ prob_out, const PdfHeader* __restrict__ hdr /* counts from the device, or nullptr */)
 {
   __shared__ double s_f[PDF_WAVES][PDF_MAX_CONTROL];
+  if (hdr) { n_cand = hdr->identity ? 0 : hdr->n_cand; n_control = hdr->n_control; }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * PDF_WAVES + wave;
   if (c >= n_cand) return;                                   // (whole waves: no barrier below)
@@ -114,8 +118,9 @@ k_pdf_score(GridDev g, const double* __restrict__ pose /* 9 */, const double* __
 // 0.0 and is replaced on `>` only (TSD_PDFMatching.cpp:188,264)
 __global__ void __launch_bounds__(1024)
 k_pdf_argmax(const double* __restrict__ prob, const PdfCandidate* __restrict__ cand, int n_cand, const double* __restrict__ M,
-             const double* __restrict__ S, PdfResult* __restrict__ out)
+             const double* __restrict__ S, PdfResult* __restrict__ out, const PdfHeader* __restrict__ hdr)
 {
+  if (hdr) n_cand = hdr->identity ? 0 : hdr->n_cand;
   __shared__ double s_p[1024];
   __shared__ int s_k[1024];
   double bp = 0.0; int bk = -1;
@@ -180,7 +185,7 @@ __device__ __forceinline__ DD dd_div_d(DD a, double b)
   const double q2 = (r.hi + r.lo) / b;
   return dd_quick_two_sum(q1, q2);
 }
-struct PdfNormalsSet { const double* xy; const uint8_t* mask_in; uint8_t* mask_io; double* phi; };
+struct PdfNormalsSet { const double* xy; const uint8_t* mask_in; const uint8_t* mask_io_init; uint8_t* mask_io; double* phi; };
 
 __global__ void __launch_bounds__(256)
 k_pdf_normals(PdfNormalsSet set0, PdfNormalsSet set1, int points, int sr)
@@ -190,7 +195,8 @@ k_pdf_normals(PdfNormalsSet set0, PdfNormalsSet set1, int points, int sr)
   if (i >= points) return;
   const double NO_PHI = -1e6;                                 // calcPhi's value for a masked-out point (RandomMatching.cpp:155-174)
   if (i < sr || i >= points - sr) { st.mask_io[i] = 0; st.phi[i] = NO_PHI; return; }
-  if (!st.mask_in[i] || !st.mask_io[i]) { st.mask_io[i] = 0; st.phi[i] = NO_PHI; return; }   // (mask_io <= mask_in on entry)
+  if (!st.mask_in[i] || !st.mask_io_init[i]) { st.mask_io[i] = 0; st.phi[i] = NO_PHI; return; }   // (mask_io <= mask_in on entry)
+  st.mask_io[i] = 1;
   double A[2 * 10];
   int cnt = 0;
   for (int j = -sr; j < sr; j++)
@@ -251,6 +257,146 @@ k_pdf_normals(PdfNormalsSet set0, PdfNormalsSet set1, int points, int sr)
   if ((st.xy[2 * i] * xShort + st.xy[2 * i + 1] * yShort) < 0.0) { nx = xShort / len; ny = yShort / len; }
   else { nx = -xShort / len; ny = -yShort / len; }
   st.phi[i] = atan2(ny, nx);
+}
+
+// ---- the list building of TSD_PDFMatching::match on the device (fused scan: nothing returns to the host between the ray cast and the
+// registration).  ONE workgroup: extractSamples of both sets (index order), pickControlSet and the trial picks -- the reference erases
+// the picked element from a vector, i.e. picks the r-th REMAINING element in index order: a bitmap of the remaining positions and a
+// rank-select do the same -- then the candidates of every trial, counted, offset by a scan over the trials and written in the
+// reference's serial order (trial-major, scene index ascending).
+struct PdfPrepareArgs {
+  const uint8_t* mask_m; const uint8_t* mask_s;       // after the normals (mMp, mSp)
+  const double* phi_m; const double* phi_s;
+  const double* S;                                    // scene points, beam-indexed
+  const int* draws_control; const int* draws_trials;
+  double2* control; PdfCandidate* cand; PdfHeader* hdr;
+  int n, sr, span, trials_cfg, size_control_set, max_cand;
+  double phi_max;
+};
+constexpr int PDF_MAX_TRIALS = 1024;
+__device__ __forceinline__ int select_bit(unsigned long long w, int r)      // position of the r-th (0-based) set bit of w
+{
+  int pos = 0;
+#pragma unroll
+  for (int width = 32; width >= 1; width >>= 1) {
+    const int c = __popcll(w & (((1ull << width) - 1ull) << pos));
+    if (r >= c) { r -= c; pos += width; }
+  }
+  return pos;
+}
+__global__ void __launch_bounds__(1024)
+k_pdf_prepare(PdfPrepareArgs p)
+{
+  __shared__ int s_idx[TSD_MAX_BEAMS];                // the valid indices of a set, ascending
+  __shared__ unsigned long long s_rem[TSD_MAX_BEAMS / 64];
+  __shared__ int s_wcnt[16], s_trial[PDF_MAX_TRIALS], s_cnt[PDF_MAX_TRIALS + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  // extractSamples (RandomMatching.cpp:41-50): i = sr .. n - sr - 1 with the mask set, in index order
+  auto build_list = [&](const uint8_t* mask) {
+    int base = 0;
+    for (int c0 = 0; c0 < p.n; c0 += 1024) {
+      const int i = c0 + tid;
+      const bool f = i >= p.sr && i < p.n - p.sr && mask[i] != 0;
+      const unsigned long long b = __ballot(f);
+      if (lane == 0) s_wcnt[wave] = __popcll(b);
+      __syncthreads();
+      int off = base;
+      for (int w = 0; w < wave; w++) off += s_wcnt[w];
+      if (f) s_idx[off + __popcll(b & lt)] = i;
+      int tot = 0;
+      for (int w = 0; w < 16; w++) tot += s_wcnt[w];
+      base += tot;
+      __syncthreads();
+    }
+    for (int w = tid; w < TSD_MAX_BEAMS / 64; w += 1024) {
+      const int lo = w * 64;
+      s_rem[w] = base >= lo + 64 ? ~0ull : (base > lo ? ((1ull << (base - lo)) - 1ull) : 0ull);
+    }
+    __syncthreads();
+    return base;
+  };
+  // the r-th remaining position (wave 0, all lanes; positions < 4096 = 64 words, one per lane), removed from the bitmap
+  auto pick = [&](int r) {
+    const unsigned long long w = s_rem[lane];
+    const int c = __popcll(w);
+    int incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
+    const unsigned long long m = __ballot(incl > r);
+    const int wl = __ffsll((long long)m) - 1;                               // the word that holds it
+    const int before = __shfl(incl - c, wl, 64);
+    int pos = 0;
+    if (lane == wl) { const int bit = select_bit(w, r - before); s_rem[lane] = w & ~(1ull << bit); pos = lane * 64 + bit; }
+    return __shfl(pos, wl, 64);
+  };
+  // ---- scene: list, control set (pickControlSet, RandomMatching.cpp:52-80)
+  const int nS = build_list(p.mask_s);
+  int nC = p.size_control_set < nS ? p.size_control_set : nS;
+  if (wave == 0) {
+    for (int k = 0; k < nC; k++) {
+      const unsigned r = (unsigned)p.draws_control[k] % (unsigned)(nS - k);
+      const int idx = s_idx[pick((int)r)];
+      if (lane == 0) p.control[k] = make_double2(p.S[2 * idx], p.S[2 * idx + 1]);
+    }
+  }
+  __syncthreads();
+  // ---- model: list, trial picks (TSD_PDFMatching.cpp:185-199)
+  const int nM = build_list(p.mask_m);
+  int trials = p.trials_cfg < nM ? p.trials_cfg : nM;
+  if (trials > PDF_MAX_TRIALS) trials = PDF_MAX_TRIALS;                     // (the host refuses more)
+  const bool identity = nS < 3 || nM < 3;                                   // "Too less valid points" (:129-139)
+  if (identity) trials = 0;
+  if (wave == 0) {
+    for (int t = 0; t < trials; t++) {
+      const unsigned r = (unsigned)p.draws_trials[t] % (unsigned)(nM - t);
+      const int idx = s_idx[pick((int)r)];
+      if (lane == 0) s_trial[t] = idx;
+    }
+  }
+  __syncthreads();
+  // ---- candidates (:200-215): count per trial, scan, write
+  const double PI_D = 3.14159265358979323846;
+  auto trial_pass = [&](bool write) {
+    for (int t = wave; t < trials; t += 16) {
+      const int idx = s_trial[t];
+      const int iMin = idx - p.span > p.sr ? idx - p.span : p.sr, iMax = idx + p.span < p.n - p.sr ? idx + p.span : p.n - p.sr;
+      const double pm = p.phi_m[idx];
+      int cnt = 0;
+      for (int i0 = iMin; i0 < iMax; i0 += 64) {
+        const int i = i0 + lane;
+        bool ok = false; double phi = 0.0;
+        if (i < iMax && p.mask_s[i]) {
+          phi = pm - p.phi_s[i];
+          if (phi > PI_D) phi -= 2.0 * PI_D;
+          else if (phi < -PI_D) phi += 2.0 * PI_D;
+          ok = fabs(phi) < p.phi_max;
+        }
+        const unsigned long long b = __ballot(ok);
+        if (write && ok) {
+          const int at = s_cnt[t] + cnt + __popcll(b & lt);
+          if (at < p.max_cand) p.cand[at] = PdfCandidate{idx, i, phi};
+        }
+        cnt += __popcll(b);
+      }
+      if (!write && lane == 0) s_cnt[t] = cnt;
+    }
+    __syncthreads();
+  };
+  trial_pass(false);
+  if (tid == 0) {
+    int run = 0;
+    for (int t = 0; t < trials; t++) { const int c = s_cnt[t]; s_cnt[t] = run; run += c; }
+    s_cnt[trials] = run;
+  }
+  __syncthreads();
+  trial_pass(true);
+  if (tid == 0) {
+    PdfHeader h;
+    h.n_cand = s_cnt[trials] < p.max_cand ? s_cnt[trials] : p.max_cand; h.n_control = nC; h.n_model_valid = nM; h.n_scene_valid = nS;
+    h.identity = identity ? 1 : 0; h.pad[0] = h.pad[1] = h.pad[2] = 0;
+    *p.hdr = h;
+  }
 }
 
 // ---- host side: RandomMatching's O(beams) preparation ------------------------------------------------------
@@ -406,10 +552,11 @@ extern "C" int tsd_tsdpdf_match(tsd_ctx* ctx, const double pose33[9], const doub
     std::memcpy(h + off_mi, mask_m, (size_t)n); std::memcpy(h + off_mi + bMask, mask_s, (size_t)n);
     std::memcpy(h + off_mo, mMp.data(), (size_t)n); std::memcpy(h + off_mo + bMask, mSp.data(), (size_t)n);
     TSD_HIP_CHECK(ctx, hipMemcpyAsync(d, h, off_phi, hipMemcpyHostToDevice, ctx->stream));
-    PdfNormalsSet sm{reinterpret_cast<const double*>(d), reinterpret_cast<const uint8_t*>(d + off_mi), reinterpret_cast<uint8_t*>(d + off_mo),
-                     reinterpret_cast<double*>(d + off_phi)};
+    PdfNormalsSet sm{reinterpret_cast<const double*>(d), reinterpret_cast<const uint8_t*>(d + off_mi), reinterpret_cast<const uint8_t*>(d + off_mo),
+                     reinterpret_cast<uint8_t*>(d + off_mo), reinterpret_cast<double*>(d + off_phi)};
     PdfNormalsSet ss{reinterpret_cast<const double*>(d + off_S), reinterpret_cast<const uint8_t*>(d + off_mi + bMask),
-                     reinterpret_cast<uint8_t*>(d + off_mo + bMask), reinterpret_cast<double*>(d + off_phi + bPhi)};
+                     reinterpret_cast<const uint8_t*>(d + off_mo + bMask), reinterpret_cast<uint8_t*>(d + off_mo + bMask),
+                     reinterpret_cast<double*>(d + off_phi + bPhi)};
     {
       ScopedKernelTimer t(ctx, "tsdpdf", true);
       hipLaunchKernelGGL(k_pdf_normals, dim3((n + 255) / 256, 2), dim3(256), 0, ctx->stream, sm, ss, n, SR);
@@ -479,10 +626,10 @@ extern "C" int tsd_tsdpdf_match(tsd_ctx* ctx, const double pose33[9], const doub
     hipLaunchKernelGGL(k_pdf_score, dim3((nc + PDF_WAVES - 1) / PDF_WAVES), dim3(64 * PDF_WAVES), 0, ctx->stream, ctx->grid, reinterpret_cast<const double*>(d + off_P),
                        reinterpret_cast<const double*>(d), reinterpret_cast<const double*>(d + off_S),
                        reinterpret_cast<const double2*>(d + off_C), nC, reinterpret_cast<const PdfCandidate*>(d + off_K), nc,
-                       prm->zrand, reinterpret_cast<double*>(d + off_prob));
+                       prm->zrand, reinterpret_cast<double*>(d + off_prob), nullptr);
     hipLaunchKernelGGL(k_pdf_argmax, dim3(1), dim3(1024), 0, ctx->stream, reinterpret_cast<const double*>(d + off_prob),
                        reinterpret_cast<const PdfCandidate*>(d + off_K), nc, reinterpret_cast<const double*>(d),
-                       reinterpret_cast<const double*>(d + off_S), reinterpret_cast<PdfResult*>(d + off_res));
+                       reinterpret_cast<const double*>(d + off_S), reinterpret_cast<PdfResult*>(d + off_res), nullptr);
   }
   TSD_HIP_CHECK(ctx, hipGetLastError());
   TSD_HIP_CHECK(ctx, hipMemcpyAsync(h + off_res, d + off_res, sizeof(PdfResult), hipMemcpyDeviceToHost, ctx->stream));
@@ -494,5 +641,120 @@ extern "C" int tsd_tsdpdf_match(tsd_ctx* ctx, const double pose33[9], const doub
   const PdfResult* r = reinterpret_cast<const PdfResult*>(h + off_res);
   std::memcpy(result->T, r->T, sizeof(r->T));
   result->probability = r->prob; result->idx_model = r->idx; result->idx_scene = r->i;
+  return TSD_OK;
+}
+
+// ---- registration_mode 3 inside the fused scan -----------------------------------------------------------------------------
+extern "C" int tsd_scan_preregister(tsd_sensor* s, const tsd_tsdpdf_params* prm, const double* scene_xy_2B, const uint8_t* mask_s,
+                                    const int* draws_subsample, const int* draws_control, const int* draws_trials)
+{
+  if (!s || !s->ctx || !prm || !scene_xy_2B || !mask_s || !draws_subsample || !draws_control || !draws_trials) return TSD_E_ARG;
+  tsd_ctx* ctx = s->ctx;
+  const int n = s->beams;
+  if (n < 1 || n > TSD_MAX_BEAMS || prm->size_control_set < 0 || prm->size_control_set > PDF_MAX_CONTROL || prm->trials < 0 ||
+      prm->trials > PDF_MAX_TRIALS)
+    return set_error(ctx, TSD_E_CAPACITY, "tsd_scan_preregister: beams / control set / trials out of range", hipSuccess);
+  if (!(prm->ang_res > 1e-6)) return set_error(ctx, TSD_E_ARG, "tsd_scan_preregister: resolution not properly set", hipSuccess);
+  if (s->submitted) return set_error(ctx, TSD_E_ARG, "tsd_scan_preregister: the previous scan was not collected", hipSuccess);
+  TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  tsd_sensor::PreLayout L{};
+  L.n = n; L.trials = prm->trials; L.size_control_set = prm->size_control_set; L.zrand = prm->zrand;
+  L.phi_max = std::min(prm->phi_max, M_PI * 0.5);
+  L.span = (int)std::floor(L.phi_max / prm->ang_res);
+  if (L.span > n) L.span = n;
+  L.max_cand = (int)std::min<size_t>((size_t)std::max(prm->trials, 0) * (size_t)std::min(2 * L.span + 1, n) + 1, (size_t)1 << 22);
+  const size_t bM = (size_t)n * 16, bMask = ((size_t)n + 15) & ~(size_t)15, bPhi = (size_t)n * 8;
+  auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  L.off_S = 0; L.off_ms = bM; L.off_msp = L.off_ms + bMask; L.off_dc = L.off_msp + bMask;
+  L.off_dt = L.off_dc + al((size_t)std::max(prm->size_control_set, 1) * 4);
+  L.in_bytes = L.off_dt + al((size_t)std::max(prm->trials, 1) * 4);
+  L.off_mo_m = L.in_bytes; L.off_mo_s = L.off_mo_m + bMask; L.off_phi_m = L.off_mo_s + bMask; L.off_phi_s = L.off_phi_m + bPhi;
+  L.off_C = L.off_phi_s + bPhi; L.off_K = L.off_C + al((size_t)std::max(prm->size_control_set, 1) * 16);
+  L.off_prob = L.off_K + al((size_t)L.max_cand * sizeof(PdfCandidate)); L.off_hdr = L.off_prob + al((size_t)L.max_cand * 8);
+  L.off_res = L.off_hdr + al(sizeof(PdfHeader));
+  const size_t total = L.off_res + al(sizeof(PdfResult));
+  if (total > s->pre_bytes) {
+    TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (s->d_pre) hipFree(s->d_pre);
+    if (s->h_pre) hipHostFree(s->h_pre);
+    s->d_pre = nullptr; s->h_pre = nullptr; s->pre_bytes = 0;
+    TSD_HIP_CHECK(ctx, hipMalloc(&s->d_pre, total));
+    TSD_HIP_CHECK(ctx, hipHostMalloc(&s->h_pre, total, hipHostMallocDefault));
+    s->pre_bytes = total;
+  }
+  // (the pinned buffer is free: the previous scan was collected, i.e. its copy from here and its read-back have completed)
+  char* h = s->h_pre;
+  std::memcpy(h + L.off_S, scene_xy_2B, bM);
+  std::memcpy(h + L.off_ms, mask_s, (size_t)n);
+  uint8_t* mSp = reinterpret_cast<uint8_t*>(h + L.off_msp);
+  std::memcpy(mSp, mask_s, (size_t)n);
+  unsigned valid = 0;
+  for (int i = 0; i < n; i++) if (mSp[i]) valid++;
+  double probability = 180.0 / (double)valid;
+  if (probability < 0.99) {                                // subsampleMask (RandomMatching.cpp:176-189)
+    if (probability > 1.0) probability = 1.0;
+    if (probability < 0.0) probability = 0.0;
+    const int thresh = (int)(1000.0 - probability * 1000.0 + 0.5);
+    for (int i = 0; i < n; i++) if ((draws_subsample[i] % 1000) < thresh) mSp[i] = 0;
+  }
+  std::memcpy(h + L.off_dc, draws_control, (size_t)prm->size_control_set * 4);
+  std::memcpy(h + L.off_dt, draws_trials, (size_t)prm->trials * 4);
+  s->pre = L;
+  s->pre_armed = true;
+  return TSD_OK;
+}
+
+namespace tsd {
+int launch_preregistration(tsd_ctx* ctx, tsd_sensor* s, hipStream_t stream, const double* d_coords, const uint8_t* d_mask_m,
+                           const double* d_pose6, const double** tinit_dev)
+{
+  const tsd_sensor::PreLayout& L = s->pre;
+  char* d = s->d_pre;
+  const int n = L.n, SR = 10 / 2;
+  TSD_HIP_CHECK(ctx, hipMemcpyAsync(d, s->h_pre, L.in_bytes, hipMemcpyHostToDevice, stream));
+  PdfNormalsSet sm{d_coords, d_mask_m, d_mask_m, reinterpret_cast<uint8_t*>(d + L.off_mo_m), reinterpret_cast<double*>(d + L.off_phi_m)};
+  PdfNormalsSet ss{reinterpret_cast<const double*>(d + L.off_S), reinterpret_cast<const uint8_t*>(d + L.off_ms),
+                   reinterpret_cast<const uint8_t*>(d + L.off_msp), reinterpret_cast<uint8_t*>(d + L.off_mo_s),
+                   reinterpret_cast<double*>(d + L.off_phi_s)};
+  PdfPrepareArgs pa;
+  pa.mask_m = reinterpret_cast<const uint8_t*>(d + L.off_mo_m); pa.mask_s = reinterpret_cast<const uint8_t*>(d + L.off_mo_s);
+  pa.phi_m = reinterpret_cast<const double*>(d + L.off_phi_m); pa.phi_s = reinterpret_cast<const double*>(d + L.off_phi_s);
+  pa.S = reinterpret_cast<const double*>(d + L.off_S);
+  pa.draws_control = reinterpret_cast<const int*>(d + L.off_dc); pa.draws_trials = reinterpret_cast<const int*>(d + L.off_dt);
+  pa.control = reinterpret_cast<double2*>(d + L.off_C); pa.cand = reinterpret_cast<PdfCandidate*>(d + L.off_K);
+  pa.hdr = reinterpret_cast<PdfHeader*>(d + L.off_hdr);
+  pa.n = n; pa.sr = SR; pa.span = L.span; pa.trials_cfg = L.trials; pa.size_control_set = L.size_control_set; pa.max_cand = L.max_cand;
+  pa.phi_max = L.phi_max;
+  {
+    ScopedKernelTimer t(ctx, "tsdpdf", true);
+    hipLaunchKernelGGL(k_pdf_normals, dim3((n + 255) / 256, 2), dim3(256), 0, stream, sm, ss, n, SR);
+    hipLaunchKernelGGL(k_pdf_prepare, dim3(1), dim3(1024), 0, stream, pa);
+    hipLaunchKernelGGL(k_pdf_score, dim3((L.max_cand + PDF_WAVES - 1) / PDF_WAVES), dim3(64 * PDF_WAVES), 0, stream, ctx->grid, d_pose6,
+                       d_coords, reinterpret_cast<const double*>(d + L.off_S), reinterpret_cast<const double2*>(d + L.off_C), 0,
+                       reinterpret_cast<const PdfCandidate*>(d + L.off_K), 0, L.zrand, reinterpret_cast<double*>(d + L.off_prob),
+                       reinterpret_cast<const PdfHeader*>(d + L.off_hdr));
+    hipLaunchKernelGGL(k_pdf_argmax, dim3(1), dim3(1024), 0, stream, reinterpret_cast<const double*>(d + L.off_prob),
+                       reinterpret_cast<const PdfCandidate*>(d + L.off_K), 0, d_coords, reinterpret_cast<const double*>(d + L.off_S),
+                       reinterpret_cast<PdfResult*>(d + L.off_res), reinterpret_cast<const PdfHeader*>(d + L.off_hdr));
+  }
+  TSD_HIP_CHECK(ctx, hipGetLastError());
+  // header + result back with the scan's own result (the copy completes before the registration kernel behind it starts)
+  TSD_HIP_CHECK(ctx, hipMemcpyAsync(s->h_pre + L.off_hdr, d + L.off_hdr, (L.off_res - L.off_hdr) + sizeof(PdfResult), hipMemcpyDeviceToHost, stream));
+  *tinit_dev = reinterpret_cast<const double*>(d + L.off_res);
+  return TSD_OK;
+}
+}  // namespace tsd
+
+extern "C" int tsd_scan_preregistration_result(tsd_sensor* s, tsd_tsdpdf_result* result)
+{
+  if (!s || !s->ctx || !result) return TSD_E_ARG;
+  if (!s->pre_ran || s->submitted) return set_error(s->ctx, TSD_E_ARG, "tsd_scan_preregistration_result: no collected scan with a pre-registration", hipSuccess);
+  const PdfHeader* hd = reinterpret_cast<const PdfHeader*>(s->h_pre + s->pre.off_hdr);
+  const PdfResult* r = reinterpret_cast<const PdfResult*>(s->h_pre + s->pre.off_res);
+  std::memcpy(result->T, r->T, sizeof(r->T));
+  result->probability = r->prob; result->idx_model = r->idx; result->idx_scene = r->i;
+  result->candidates = hd->identity ? 0 : hd->n_cand;
+  result->valid_model = hd->n_model_valid; result->valid_scene = hd->n_scene_valid; result->control_points = hd->n_control;
+  result->reserved = 0;
   return TSD_OK;
 }

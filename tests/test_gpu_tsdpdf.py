@@ -57,6 +57,50 @@ def test_tsdpdf_match_matches_oracle(oracle, cfg, scene, ctrl, zrand, seed):
     assert d < 0.15 and a < 0.05, (d, a)
 
 
+@pytest.mark.parametrize("cfg,scene,ctrl,zrand,seed", [("cfg2", "pillars", 140, 0.25, 2), ("cfg1", "room", 360, 0.05, 7)])
+def test_fused_preregistration_matches_the_unfused_calls(oracle, cfg, scene, ctrl, zrand, seed):
+    """tsd_scan_preregister + tsd_scan (everything between the ray cast and the registration on the device: normals, sample lists,
+    control set, trial picks, candidates, scoring, arg-max, Tinit handed over on the device) == tsd_tsdpdf_match on the ray cast's
+    outputs + tsd_localize with its T as t_init, and == the oracle."""
+    gc, geo, _ = synth.CONFIGS[cfg]
+    og, dg, pose, co, mo, sc, ms, Ttrue = _map_and_scan(oracle, gc, geo, scene, 3, 8, dyaw=0.05)
+    world = synth.World(scene, gc)
+    _, (x, y, yaw) = H.sensor_pose(world, 8)
+    data, mask = oracle.ingest_f32(world.scan(x, y, yaw + 0.05, geo), H.MAX_RANGE, geo.angle_increment)
+    _, mask_push = oracle.ingest_f64(data, H.MAX_RANGE, geo.angle_increment)
+    rl, rw = H.world_rays(oracle, geo, pose, gc.cell_size)
+    rng = np.random.default_rng(seed)
+    trials = 100
+    ds, dc, dt = (rng.integers(0, 2 ** 31 - 1, n) for n in (geo.beams, ctrl, trials))
+    phi_max = math.radians(30.0)
+    # the unfused reference: pre-registration on the host-visible ray cast, then the registration with Tinit
+    ch, nh, mh, cnt = dg.raycast(pose, rw, H.MIN_RANGE, H.MAX_RANGE)
+    rm = dg.tsdpdf_match(pose, ch, mh, sc, ms, trials, ctrl, zrand, phi_max, geo.angle_increment, ds, dc, dt)
+    ro = oracle.tsdpdf_match(og, pose, co, mo, sc, ms, trials, ctrl, zrand, phi_max, geo.angle_increment, ds, dc, dt)
+    assert (rm["candidates"], rm["idx"], rm["i"]) == (ro["candidates"], ro["idx"], ro["i"])
+    p = dg.icp_params(30, 0.4, 0.02, t_init=rm["T"])
+    rf = dg.localize(pose, rw, rl, data, mask, H.MIN_RANGE, H.MAX_RANGE, p)
+    # fused: one scan of a device sensor
+    sensor = capi.TsdSensorDevice(dg, geo.beams, geo.angle_increment, geo.angle_min, H.MAX_RANGE, H.MIN_RANGE, H.LOW_REFL)
+    sensor.set_pose(pose, rw, rl)
+    gates = capi.GateParams(10.0, 1.0, 1e9, 2.0)            # (wide registration gate, no push: this test is about the registration's inputs)
+    sensor.preregister(sc, ms, trials, ctrl, zrand, phi_max, geo.angle_increment, ds, dc, dt)
+    sr = sensor.scan(data, mask, mask_push, dg.icp_params(30, 0.4, 0.02), gates)
+    pr = sensor.preregistration_result()
+    assert (pr["candidates"], pr["idx"], pr["i"]) == (rm["candidates"], rm["idx"], rm["i"]), (pr, rm)
+    assert (pr["valid_model"], pr["valid_scene"], pr["control_points"]) == (rm["valid_model"], rm["valid_scene"], rm["control"])
+    assert np.max(np.abs(pr["T"] - rm["T"])) <= 1e-12 and abs(pr["prob"] - rm["prob"]) <= 1e-9 * rm["prob"]
+    assert (sr.icp.pairs, sr.icp.iterations, sr.icp.state, sr.icp.n_model, sr.icp.n_scene) == (rf.pairs, rf.iterations, rf.state, rf.n_model, rf.n_scene)
+    d, a = H.pose_delta(np.asarray(rf.T), np.array(sr.icp.T[:]).reshape(3, 3))
+    assert d <= 1e-11 and a <= 1e-11
+    # a scan without an armed pre-registration is the plain scan again (one-shot)
+    sensor.set_pose(pose, rw, rl)
+    s0 = sensor.scan(data, mask, mask_push, dg.icp_params(30, 0.4, 0.02), gates)
+    r0 = dg.localize(pose, rw, rl, data, mask, H.MIN_RANGE, H.MAX_RANGE, dg.icp_params(30, 0.4, 0.02))
+    assert (s0.icp.pairs, s0.icp.iterations) == (r0.pairs, r0.iterations)
+    sensor.close()
+
+
 def test_tsdpdf_degenerate_inputs(oracle):
     """too few valid points -> identity (TSD_PDFMatching.cpp:53-57, :129-139); all-false masks; tiny control set"""
     gc, geo, _ = synth.CONFIGS["cfg1"]
