@@ -291,7 +291,10 @@ void ThreadLocalize::processScan(const std::vector<float>& ranges, const builtin
     _haveLastPose = true;
   }
 
-  if(_regMode == 3 && _preMatcher)
+  // registration_mode 3: inside the fused scan (the pre-registration on the device between the ray cast and the registration) when
+  // this robot has the fused path to itself; the reference's own call structure otherwise (and with TSD_MODE3_UNFUSED set: A/B)
+  static const bool mode3Unfused = std::getenv("TSD_MODE3_UNFUSED") != nullptr;
+  if(_regMode == 3 && _preMatcher && (mode3Unfused || !_fused || !_sensor->deviceHandle() || _concurrent))
   {
     processScanPreRegistered(rep);
     return;
@@ -455,7 +458,21 @@ void ThreadLocalize::processScanFused(ScanReport& rep)
   {
     const bool useStaged = _stagedValid;
     _stagedValid = false;
-    rc = _grid.scanSubmit(_sensor, useStaged, maskPush.data(), _icpParams, gates);
+    rc = TSD_OK;
+    if(_regMode == 3 && _preMatcher)
+    {
+      // doRegistration, case TSD (ThreadLocalize.cpp:557-567): the scene points and the match's three rand() streams are all the
+      // pre-registration needs from the host; its model is the ray cast's output, on the device
+      const unsigned int n = _sensor->getRealMeasurementSize();
+      if(_scene.size() != 2 * (size_t)n) { _scene.assign(2 * (size_t)n, 0.0); _maskS.assign(n, 0); }
+      bool* maskS = reinterpret_cast<bool*>(_maskS.data());
+      _sensor->dataToCartesianVectorMask(_scene.data(), maskS);
+      std::vector<int> dSub, dCtrl, dTrials;
+      _preMatcher->drawStreams(n, dSub, dCtrl, dTrials);
+      rc = _grid.scanPreregister(_sensor, _preMatcher->params(_ranPhiMax * M_PI / 180.0, _sensor->getAngularResolution()), _scene.data(), maskS,
+                                 dSub.data(), dCtrl.data(), dTrials.data());
+    }
+    if(rc == TSD_OK) rc = _grid.scanSubmit(_sensor, useStaged, maskPush.data(), _icpParams, gates);
     // the next scan, if it is known already: ingest + copy + tables while the device registers this one
     std::shared_ptr<sensor_msgs::msg::LaserScan> next;
     {

@@ -360,6 +360,13 @@ int TsdGrid::scanStage(SensorPolar2D* sensor, const uint8_t* maskPush)
   return tsd_scan_stage(sensor->deviceHandle(), sensor->getRealMeasurementData(), sensor->maskBytes(), maskPush);
 }
 
+int TsdGrid::scanPreregister(SensorPolar2D* sensor, const tsd_tsdpdf_params& prm, const double* scene, const bool* maskS,
+                             const int* dSub, const int* dCtrl, const int* dTrials)
+{
+  std::lock_guard<std::mutex> lk(_mutex);
+  return tsd_scan_preregister(sensor->deviceHandle(), &prm, scene, reinterpret_cast<const uint8_t*>(maskS), dSub, dCtrl, dTrials);
+}
+
 int TsdGrid::scanCollect(SensorPolar2D* sensor, tsd_scan_result* result)
 {
   // (the wait itself needs no lock: it polls the sensor's own result record)
@@ -574,23 +581,35 @@ TSD_PDFMatching::TSD_PDFMatching(TsdGrid& grid, unsigned int trials, double epsT
   std::memset(&_last, 0, sizeof(_last));
 }
 
+void TSD_PDFMatching::drawStreams(unsigned int points, std::vector<int>& dSub, std::vector<int>& dCtrl, std::vector<int>& dTrials)
+{
+  // the three rand() streams, in the reference's call order
+  if (_seed >= 0) std::srand((unsigned)(_seed + (long)_calls));
+  _calls++;
+  dSub.assign(points, 0); dCtrl.assign(_sizeControlSet > 0 ? _sizeControlSet : 1, 0); dTrials.assign(_trials > 0 ? _trials : 1, 0);
+  for (auto& v : dSub) v = std::rand();                      // RandomMatching::subsampleMask (RandomMatching.cpp:183)
+  for (auto& v : dCtrl) v = std::rand();                     // RandomMatching::pickControlSet (:65)
+  if (_seed < 0) std::srand((unsigned)time(NULL));           // TSD_PDFMatching.cpp:184
+  for (auto& v : dTrials) v = std::rand();                   // TSD_PDFMatching.cpp:190
+}
+
+tsd_tsdpdf_params TSD_PDFMatching::params(double phiMax, double resolution) const
+{
+  tsd_tsdpdf_params prm;
+  prm.trials = (int)_trials; prm.size_control_set = (int)_sizeControlSet; prm.eps_thresh = _epsThresh; prm.zrand = _zrand;
+  prm.phi_max = phiMax; prm.ang_res = resolution;
+  return prm;
+}
+
 Matrix TSD_PDFMatching::match(Matrix TSensor, const double* M, const bool* maskM, const double* /*NM*/, const double* S,
                               const bool* maskS, unsigned int points, double phiMax, const double /*transMax*/,
                               const double resolution)
 {
   Matrix TBest(3, 3);
   TBest.setIdentity();
-  // the three rand() streams, in the reference's call order
-  if (_seed >= 0) std::srand((unsigned)(_seed + (long)_calls));
-  _calls++;
-  std::vector<int> dSub(points), dCtrl(_sizeControlSet > 0 ? _sizeControlSet : 1), dTrials(_trials > 0 ? _trials : 1);
-  for (auto& v : dSub) v = std::rand();                      // RandomMatching::subsampleMask (RandomMatching.cpp:183)
-  for (auto& v : dCtrl) v = std::rand();                     // RandomMatching::pickControlSet (:65)
-  if (_seed < 0) std::srand((unsigned)time(NULL));           // TSD_PDFMatching.cpp:184
-  for (auto& v : dTrials) v = std::rand();                   // TSD_PDFMatching.cpp:190
-  tsd_tsdpdf_params prm;
-  prm.trials = (int)_trials; prm.size_control_set = (int)_sizeControlSet; prm.eps_thresh = _epsThresh; prm.zrand = _zrand;
-  prm.phi_max = phiMax; prm.ang_res = resolution;
+  std::vector<int> dSub, dCtrl, dTrials;
+  drawStreams(points, dSub, dCtrl, dTrials);
+  const tsd_tsdpdf_params prm = params(phiMax, resolution);
   double pose[9];
   TSensor.getData(pose);
   int rc;

@@ -195,6 +195,9 @@ public:
   virtual int scanSubmit(SensorPolar2D* sensor, bool useStaged, const uint8_t* maskPush, const tsd_icp_params& params,
                          const tsd_gate_params& gates);
   virtual int scanStage(SensorPolar2D* sensor, const uint8_t* maskPush);
+  // registration_mode 3 inside the fused scan: arms the pre-registration of the sensor's next scanSubmit (tsd_scan_preregister)
+  virtual int scanPreregister(SensorPolar2D* sensor, const tsd_tsdpdf_params& prm, const double* scene, const bool* maskS,
+                              const int* dSub, const int* dCtrl, const int* dTrials);
   virtual int scanCollect(SensorPolar2D* sensor, tsd_scan_result* result);
 
   // the same scan in two halves for several robots on this one grid (tsd_scan_begin / _wait / _finish): the mutex is
@@ -233,6 +236,11 @@ public:
    *  default -1 keeps the reference's behaviour (srand(time(NULL)) before the trial picks, TSD_PDFMatching.cpp:184) */
   void setSeed(long seed) { _seed = seed; }
   const tsd_tsdpdf_result& lastResult() const { return _last; }
+  /** the three rand() streams of one match() call, drawn in the reference's order (RandomMatching.cpp:183, :65;
+   *  TSD_PDFMatching.cpp:184-190) -- what match() itself uses and what the fused scan hands to tsd_scan_preregister */
+  void drawStreams(unsigned int points, std::vector<int>& dSub, std::vector<int>& dCtrl, std::vector<int>& dTrials);
+  /** the parameters of match() as the C ABI takes them */
+  tsd_tsdpdf_params params(double phiMax, double resolution) const;
 private:
   TsdGrid& _grid;
   unsigned int _trials, _sizeControlSet;

@@ -30,6 +30,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 namespace tsd {
@@ -197,36 +198,51 @@ k_pdf_normals(PdfNormalsSet set0, PdfNormalsSet set1, int points, int sr)
   if (i < sr || i >= points - sr) { st.mask_io[i] = 0; st.phi[i] = NO_PHI; return; }
   if (!st.mask_in[i] || !st.mask_io_init[i]) { st.mask_io[i] = 0; st.phi[i] = NO_PHI; return; }   // (mask_io <= mask_in on entry)
   st.mask_io[i] = 1;
-  double A[2 * 10];
+  // the <= 10 neighbours stay in their slots j = -5 .. 4 (registers, every loop unrolled over the ten slots and skipping the
+  // masked-out ones in order): the same sequence of operations as over the compacted list, without an indexed private array
+  constexpr int NB = 10;
+  double ax_[NB], ay_[NB]; bool v_[NB];
   int cnt = 0;
-  for (int j = -sr; j < sr; j++)
-    if (st.mask_in[i + j] && cnt < 10) { A[2 * cnt] = st.xy[2 * (i + j)]; A[2 * cnt + 1] = st.xy[2 * (i + j) + 1]; cnt++; }
+#pragma unroll
+  for (int j = 0; j < NB; j++) {
+    const int q = i + j - NB / 2;
+    v_[j] = (j - NB / 2 >= -sr) && (j - NB / 2 < sr) && st.mask_in[q] != 0;
+    ax_[j] = v_[j] ? st.xy[2 * q] : 0.0; ay_[j] = v_[j] ? st.xy[2 * q + 1] : 0.0;
+    cnt += v_[j] ? 1 : 0;
+  }
   if (cnt <= 3) { st.mask_io[i] = 0; st.phi[i] = NO_PHI; return; }
   // Matrix::pcaAnalysis (gsl/Matrix.cpp:227-327), see pca2_axes below
   double cent[2];
 #pragma unroll
-  for (int j = 0; j < 2; j++) {
+  for (int j2 = 0; j2 < 2; j2++) {
     DD mean = DD{0.0, 0.0};
-    for (int k = 0; k < cnt; k++) {
-      DD d = dd_two_sum(A[2 * k + j], -mean.hi);            // x - mean
+    int k = 0;
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+      if (!v_[j]) continue;
+      k++;
+      DD d = dd_two_sum(j2 == 0 ? ax_[j] : ay_[j], -mean.hi);            // x - mean
       d.lo -= mean.lo; d = dd_quick_two_sum(d.hi, d.lo);
-      mean = dd_add(mean, dd_div_d(d, (double)(k + 1)));
+      mean = dd_add(mean, dd_div_d(d, (double)k));
     }
-    cent[j] = mean.hi;
+    cent[j2] = mean.hi;
   }
-  double mc[2 * 10];
-  for (int k = 0; k < cnt; k++) { mc[2 * k] = A[2 * k] + (-cent[0]); mc[2 * k + 1] = A[2 * k + 1] + (-cent[1]); }
+#pragma unroll
+  for (int j = 0; j < NB; j++) { ax_[j] = ax_[j] + (-cent[0]); ay_[j] = ay_[j] + (-cent[1]); }      // mc (slots of masked-out neighbours: unused)
   double a = 0.0, b = 0.0, c = 0.0;
-  for (int k = 0; k < cnt; k++) { a += mc[2 * k] * mc[2 * k]; b += mc[2 * k] * mc[2 * k + 1]; c += mc[2 * k + 1] * mc[2 * k + 1]; }
+#pragma unroll
+  for (int j = 0; j < NB; j++) if (v_[j]) { a += ax_[j] * ax_[j]; b += ax_[j] * ay_[j]; c += ay_[j] * ay_[j]; }
   const double th = 0.5 * atan2(2.0 * b, a - c);
   const double V[2][2] = {{cos(th), -sin(th)}, {sin(th), cos(th)}};
   double mx[2], mn[2];
 #pragma unroll
   for (int q = 0; q < 2; q++) {
     mx[q] = -__builtin_inf(); mn[q] = __builtin_inf();
-    for (int r = 0; r < cnt; r++) {
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+      if (!v_[j]) continue;
       double pr = 0.0;
-      pr += V[0][q] * mc[2 * r]; pr += V[1][q] * mc[2 * r + 1];
+      pr += V[0][q] * ax_[j]; pr += V[1][q] * ay_[j];
       mx[q] = fmax(mx[q], pr); mn[q] = fmin(mn[q], pr);
     }
   }
@@ -273,101 +289,168 @@ struct PdfPrepareArgs {
   int n, sr, span, trials_cfg, size_control_set, max_cand;
   double phi_max;
 };
-constexpr int PDF_MAX_TRIALS = 1024;
-__device__ __forceinline__ int select_bit(unsigned long long w, int r)      // position of the r-th (0-based) set bit of w
+constexpr int PDF_MAX_TRIALS = 512;        // (k_pdf_prepare keeps every per-trial array in LDS)
+__device__ __forceinline__ int select_bit32(unsigned int w, int r)          // position of the r-th (0-based) set bit of w (r < popc(w))
 {
   int pos = 0;
 #pragma unroll
-  for (int width = 32; width >= 1; width >>= 1) {
-    const int c = __popcll(w & (((1ull << width) - 1ull) << pos));
+  for (int width = 16; width >= 1; width >>= 1) {
+    const int c = __popc(w & (((1u << width) - 1u) << pos));
     if (r >= c) { r -= c; pos += width; }
   }
   return pos;
 }
+// inclusive prefix sum over the 64 lanes of a wave: DPP row shifts inside the 16-lane rows, then the row totals (row_bcast)
+__device__ __forceinline__ int wave_incl_scan(int v)
+{
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);     // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);     // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);     // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);     // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);     // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);     // row_bcast:31 -> rows 2, 3
+  return v;
+}
 __global__ void __launch_bounds__(1024)
 k_pdf_prepare(PdfPrepareArgs p)
 {
-  __shared__ int s_idx[TSD_MAX_BEAMS];                // the valid indices of a set, ascending
-  __shared__ unsigned long long s_rem[TSD_MAX_BEAMS / 64];
-  __shared__ int s_wcnt[16], s_trial[PDF_MAX_TRIALS], s_cnt[PDF_MAX_TRIALS + 1];
+  // everything the picks and the candidate passes read lives in LDS: the two sample lists, the scene's masks and angles
+  __shared__ unsigned short s_idx[2][TSD_MAX_BEAMS];          // [0] scene, [1] model: valid indices, ascending
+  extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+  double* s_phi_s = s_dyn;                                    // [n]
+  double* s_pm = s_dyn + p.n;                                 // [trials] the picked model points' angles
+  __shared__ unsigned char s_mask_s[TSD_MAX_BEAMS];
+  __shared__ int s_wcnt[2][16], s_trial[PDF_MAX_TRIALS], s_cnt[PDF_MAX_TRIALS + 1];
+  __shared__ int s_draw_c[PDF_MAX_CONTROL], s_draw_t[PDF_MAX_TRIALS];      // the draws (a global read per pick would be a round trip per pick)
+  __shared__ unsigned short s_ctrl[PDF_MAX_CONTROL];                        // picked control points (scene indices)
+  __shared__ unsigned short s_q[2][64 * 64 + 64];                                // per set and bitmap word: the picks that fell into it (k | rank << 10)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned long long lt = (1ull << lane) - 1ull;
-  // extractSamples (RandomMatching.cpp:41-50): i = sr .. n - sr - 1 with the mask set, in index order
-  auto build_list = [&](const uint8_t* mask) {
-    int base = 0;
-    for (int c0 = 0; c0 < p.n; c0 += 1024) {
-      const int i = c0 + tid;
-      const bool f = i >= p.sr && i < p.n - p.sr && mask[i] != 0;
-      const unsigned long long b = __ballot(f);
-      if (lane == 0) s_wcnt[wave] = __popcll(b);
-      __syncthreads();
-      int off = base;
-      for (int w = 0; w < wave; w++) off += s_wcnt[w];
-      if (f) s_idx[off + __popcll(b & lt)] = i;
-      int tot = 0;
-      for (int w = 0; w < 16; w++) tot += s_wcnt[w];
-      base += tot;
-      __syncthreads();
-    }
-    for (int w = tid; w < TSD_MAX_BEAMS / 64; w += 1024) {
-      const int lo = w * 64;
-      s_rem[w] = base >= lo + 64 ? ~0ull : (base > lo ? ((1ull << (base - lo)) - 1ull) : 0ull);
-    }
+#ifdef TSD_PDF_STAMPS    // diagnostic build: where the kernel's time goes (thread 0, 100 MHz clock, printed)
+  long long st_[8]; int sn_ = 0;
+#define QSTAMP() do { if (tid == 0 && sn_ < 8) st_[sn_++] = wall_clock64(); } while (0)
+#else
+#define QSTAMP() do {} while (0)
+#endif
+  QSTAMP();
+  for (int i = tid; i < p.n; i += 1024) { s_phi_s[i] = p.phi_s[i]; s_mask_s[i] = p.mask_s[i]; }
+  for (int i = tid; i < p.size_control_set && i < PDF_MAX_CONTROL; i += 1024) s_draw_c[i] = p.draws_control[i];
+  for (int i = tid; i < p.trials_cfg && i < PDF_MAX_TRIALS; i += 1024) s_draw_t[i] = p.draws_trials[i];
+  // extractSamples (RandomMatching.cpp:41-50) of both sets at once: i = sr .. n - sr - 1 with the mask set, in index order
+  int nS = 0, nM = 0;
+  for (int c0 = 0; c0 < p.n; c0 += 1024) {
+    const int i = c0 + tid;
+    const bool in = i >= p.sr && i < p.n - p.sr;
+    const bool fs = in && p.mask_s[i] != 0, fm = in && p.mask_m[i] != 0;
+    const unsigned long long bs = __ballot(fs), bm = __ballot(fm);
+    if (lane == 0) { s_wcnt[0][wave] = __popcll(bs); s_wcnt[1][wave] = __popcll(bm); }
     __syncthreads();
-    return base;
-  };
-  // the r-th remaining position (wave 0, all lanes; positions < 4096 = 64 words, one per lane), removed from the bitmap
-  auto pick = [&](int r) {
-    const unsigned long long w = s_rem[lane];
-    const int c = __popcll(w);
-    int incl = c;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
-    const unsigned long long m = __ballot(incl > r);
-    const int wl = __ffsll((long long)m) - 1;                               // the word that holds it
-    const int before = __shfl(incl - c, wl, 64);
-    int pos = 0;
-    if (lane == wl) { const int bit = select_bit(w, r - before); s_rem[lane] = w & ~(1ull << bit); pos = lane * 64 + bit; }
-    return __shfl(pos, wl, 64);
-  };
-  // ---- scene: list, control set (pickControlSet, RandomMatching.cpp:52-80)
-  const int nS = build_list(p.mask_s);
-  int nC = p.size_control_set < nS ? p.size_control_set : nS;
-  if (wave == 0) {
-    for (int k = 0; k < nC; k++) {
-      const unsigned r = (unsigned)p.draws_control[k] % (unsigned)(nS - k);
-      const int idx = s_idx[pick((int)r)];
-      if (lane == 0) p.control[k] = make_double2(p.S[2 * idx], p.S[2 * idx + 1]);
+    int offS = nS, offM = nM, totS = 0, totM = 0;
+    for (int w = 0; w < 16; w++) {
+      const int cs = s_wcnt[0][w], cm = s_wcnt[1][w];
+      if (w < wave) { offS += cs; offM += cm; }
+      totS += cs; totM += cm;
     }
+    if (fs) s_idx[0][offS + __popcll(bs & lt)] = (unsigned short)i;
+    if (fm) s_idx[1][offM + __popcll(bm & lt)] = (unsigned short)i;
+    nS += totS; nM += totM;
+    __syncthreads();
   }
-  __syncthreads();
-  // ---- model: list, trial picks (TSD_PDFMatching.cpp:185-199)
-  const int nM = build_list(p.mask_m);
+  QSTAMP();
+  const int nC = p.size_control_set < nS ? p.size_control_set : nS;
+  const bool identity = nS < 3 || nM < 3;                                   // "Too less valid points" (:129-139)
   int trials = p.trials_cfg < nM ? p.trials_cfg : nM;
   if (trials > PDF_MAX_TRIALS) trials = PDF_MAX_TRIALS;                     // (the host refuses more)
-  const bool identity = nS < 3 || nM < 3;                                   // "Too less valid points" (:129-139)
   if (identity) trials = 0;
-  if (wave == 0) {
-    for (int t = 0; t < trials; t++) {
-      const unsigned r = (unsigned)p.draws_trials[t] % (unsigned)(nM - t);
-      const int idx = s_idx[pick((int)r)];
-      if (lane == 0) s_trial[t] = idx;
+  // pickControlSet (RandomMatching.cpp:52-80) by wave 0 and the trial picks (TSD_PDFMatching.cpp:185-199) by wave 1, side by side.
+  // The reference erases the picked element from a vector, i.e. picks the r-th REMAINING element in index order: lane j keeps word j
+  // of the bitmap of remaining positions in a register; prefix sum of the population counts, rank-select inside the word.
+  // (the ranks first, all at once: r_k = draw_k mod (remaining before pick k) -- an integer division per pick off the serial chain)
+  for (int k = tid; k < nC; k += 1024) s_draw_c[k] = (int)((unsigned)s_draw_c[k] % (unsigned)(nS - k));
+  for (int k = tid; k < trials; k += 1024) s_draw_t[k] = (int)((unsigned)s_draw_t[k] % (unsigned)(nM - k));
+  __syncthreads();
+  if (wave < 2) {
+    const int count = wave == 0 ? nS : nM, picks = wave == 0 ? nC : trials;
+    const int* ranks = wave == 0 ? s_draw_c : s_draw_t;
+    // lane j holds positions [j * bpl, (j + 1) * bpl) of the bitmap of remaining elements, bpl the smallest power of two that covers
+    // `count` with 64 lanes: the picks spread over as many lanes as possible (pass 2 is serial per lane)
+    int sh = 0;
+    while ((64 << sh) < count) sh++;
+    const int bpl = 1 << sh, lo = lane << sh;
+    const int nbits = count >= lo + bpl ? bpl : (count > lo ? count - lo : 0);
+    const unsigned long long w0 = nbits >= 64 ? ~0ull : ((1ull << nbits) - 1ull);
+    unsigned int wl32 = (unsigned int)w0, wh32 = (unsigned int)(w0 >> 32);   // this lane's word, as two halves
+    const int c0 = nbits;
+    int c = c0;                                                             // elements left in this lane's word ...
+    int incl = wave_incl_scan(c);                                           // ... and in the words up to it: kept up to date per pick
+    unsigned short* q = s_q[wave];
+    // pass 1, serial over the picks but a handful of per-lane instructions each, no cross-lane traffic: the counts are monotone over
+    // the lanes, so "the word that holds rank r" is the lane with excl <= r < incl, and the lanes behind it are those with incl > r.
+    // Queued per word: which pick, and its rank inside the word at that moment.
+    // (the ranks wait in registers, 64 per register, and reach the lanes by v_readlane: an LDS read per pick would put an LDS round
+    // trip into every step of this loop)
+    constexpr int RK = (PDF_MAX_CONTROL > PDF_MAX_TRIALS ? PDF_MAX_CONTROL : PDF_MAX_TRIALS) / 64;
+    int rk[RK];
+#pragma unroll
+    for (int j = 0; j < RK; j++) rk[j] = (j * 64 + lane < picks) ? ranks[j * 64 + lane] : 0;
+#pragma unroll
+    for (int j = 0; j < RK; j++) {
+      if (j * 64 >= picks) break;
+      const int lim = picks - j * 64 < 64 ? picks - j * 64 : 64;
+      for (int l = 0; l < lim; l++) {
+        const int k = j * 64 + l;
+        const int r = __builtin_amdgcn_readlane(rk[j], l);
+        // (branch-free: a lane that is not the word writes to a slot of its own beyond the queues)
+        const int excl = incl - c;
+        const bool behind = incl > r, mine = behind && excl <= r;
+        q[mine ? lane * 64 + (c0 - c) : 64 * 64 + lane] = (unsigned short)(k | ((r - excl) << 10));
+        c -= mine ? 1 : 0;
+        incl -= behind ? 1 : 0;
+      }
+    }
+    // pass 2, every word on its own lane: its picks in order -- rank-select in the word as it stands, clear the bit, note the position
+    unsigned short* out = wave == 0 ? s_ctrl : reinterpret_cast<unsigned short*>(s_trial);     // POSITIONS (translated below)
+    const int nq = c0 - c;
+    for (int j = 0; j < nq; j++) {
+      const unsigned e = q[lane * 64 + j];
+      int rr = (int)(e >> 10);
+      const int cl = __popc(wl32);
+      const bool hi = rr >= cl;
+      if (hi) rr -= cl;
+      const int bit = select_bit32(hi ? wh32 : wl32, rr);
+      if (hi) wh32 &= ~(1u << bit); else wl32 &= ~(1u << bit);
+      out[e & 1023u] = (unsigned short)(lo + bit + (hi ? 32 : 0));
     }
   }
   __syncthreads();
-  // ---- candidates (:200-215): count per trial, scan, write
+  // positions -> scene / model indices, all at once (s_trial's picks were parked as 16-bit positions in its own storage: read all, then write)
+  {
+    int idx_t[(PDF_MAX_TRIALS + 1023) / 1024];
+#pragma unroll
+    for (int j = 0; j < (PDF_MAX_TRIALS + 1023) / 1024; j++) { const int k = tid + 1024 * j; idx_t[j] = k < trials ? (int)s_idx[1][reinterpret_cast<unsigned short*>(s_trial)[k]] : 0; }
+    for (int k = tid; k < nC; k += 1024) s_ctrl[k] = s_idx[0][s_ctrl[k]];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < (PDF_MAX_TRIALS + 1023) / 1024; j++) { const int k = tid + 1024 * j; if (k < trials) s_trial[k] = idx_t[j]; }
+  }
+  __syncthreads();
+  QSTAMP();
+  for (int k = tid; k < nC; k += 1024) { const int idx = s_ctrl[k]; p.control[k] = make_double2(p.S[2 * idx], p.S[2 * idx + 1]); }
+  for (int t = tid; t < trials; t += 1024) s_pm[t] = p.phi_m[s_trial[t]];      // (one round trip for all trials, not one per trial)
+  __syncthreads();
+  // ---- candidates (:200-215): count per trial, scan over the trials, write in the reference's serial order
   const double PI_D = 3.14159265358979323846;
   auto trial_pass = [&](bool write) {
     for (int t = wave; t < trials; t += 16) {
       const int idx = s_trial[t];
       const int iMin = idx - p.span > p.sr ? idx - p.span : p.sr, iMax = idx + p.span < p.n - p.sr ? idx + p.span : p.n - p.sr;
-      const double pm = p.phi_m[idx];
+      const double pm = s_pm[t];
       int cnt = 0;
       for (int i0 = iMin; i0 < iMax; i0 += 64) {
         const int i = i0 + lane;
         bool ok = false; double phi = 0.0;
-        if (i < iMax && p.mask_s[i]) {
-          phi = pm - p.phi_s[i];
+        if (i < iMax && s_mask_s[i]) {
+          phi = pm - s_phi_s[i];
           if (phi > PI_D) phi -= 2.0 * PI_D;
           else if (phi < -PI_D) phi += 2.0 * PI_D;
           ok = fabs(phi) < p.phi_max;
@@ -383,14 +466,29 @@ k_pdf_prepare(PdfPrepareArgs p)
     }
     __syncthreads();
   };
+  QSTAMP();
   trial_pass(false);
-  if (tid == 0) {
+  QSTAMP();
+  if (wave == 0) {
+    // exclusive scan of the per-trial counts (<= 1024 of them: 16 rounds of one wave)
     int run = 0;
-    for (int t = 0; t < trials; t++) { const int c = s_cnt[t]; s_cnt[t] = run; run += c; }
-    s_cnt[trials] = run;
+    for (int t0 = 0; t0 < trials; t0 += 64) {
+      const int t = t0 + lane;
+      const int c = t < trials ? s_cnt[t] : 0;
+      const int incl = wave_incl_scan(c);
+      if (t < trials) s_cnt[t] = run + incl - c;
+      run += __builtin_amdgcn_readlane(incl, 63);
+    }
+    if (lane == 0) s_cnt[trials] = run;
   }
   __syncthreads();
+  QSTAMP();
   trial_pass(true);
+  QSTAMP();
+#ifdef TSD_PDF_STAMPS
+  if (tid == 0) printf("k_pdf_prepare (x10 ns): lists %lld | picks %lld | control + angles %lld | count pass %lld | scan %lld | write pass %lld  (nS %d nM %d nC %d trials %d)\n",
+                       st_[1] - st_[0], st_[2] - st_[1], st_[3] - st_[2], st_[4] - st_[3], st_[5] - st_[4], st_[6] - st_[5], nS, nM, nC, trials);
+#endif
   if (tid == 0) {
     PdfHeader h;
     h.n_cand = s_cnt[trials] < p.max_cand ? s_cnt[trials] : p.max_cand; h.n_control = nC; h.n_model_valid = nM; h.n_scene_valid = nS;
@@ -725,10 +823,20 @@ int launch_preregistration(tsd_ctx* ctx, tsd_sensor* s, hipStream_t stream, cons
   pa.hdr = reinterpret_cast<PdfHeader*>(d + L.off_hdr);
   pa.n = n; pa.sr = SR; pa.span = L.span; pa.trials_cfg = L.trials; pa.size_control_set = L.size_control_set; pa.max_cand = L.max_cand;
   pa.phi_max = L.phi_max;
+  const size_t prep_lds = ((size_t)n + (size_t)PDF_MAX_TRIALS) * sizeof(double);
+  {
+    // (k_pdf_prepare's static LDS is ~33 KB; beyond ~3 000 beams the dynamic part needs the attribute)
+    std::lock_guard<std::mutex> lk_misc(ctx->misc_mutex);
+    size_t& configured = ctx->lds_configured[reinterpret_cast<const void*>(k_pdf_prepare)];
+    if (prep_lds > configured) {
+      TSD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pdf_prepare), hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds));
+      configured = prep_lds;
+    }
+  }
   {
     ScopedKernelTimer t(ctx, "tsdpdf", true);
     hipLaunchKernelGGL(k_pdf_normals, dim3((n + 255) / 256, 2), dim3(256), 0, stream, sm, ss, n, SR);
-    hipLaunchKernelGGL(k_pdf_prepare, dim3(1), dim3(1024), 0, stream, pa);
+    hipLaunchKernelGGL(k_pdf_prepare, dim3(1), dim3(1024), prep_lds, stream, pa);
     hipLaunchKernelGGL(k_pdf_score, dim3((L.max_cand + PDF_WAVES - 1) / PDF_WAVES), dim3(64 * PDF_WAVES), 0, stream, ctx->grid, d_pose6,
                        d_coords, reinterpret_cast<const double*>(d + L.off_S), reinterpret_cast<const double2*>(d + L.off_C), 0,
                        reinterpret_cast<const PdfCandidate*>(d + L.off_K), 0, L.zrand, reinterpret_cast<double*>(d + L.off_prob),
