@@ -177,13 +177,15 @@ __device__ __forceinline__ DD dd_add(DD a, DD b)
   s.lo += t.hi; s = dd_quick_two_sum(s.hi, s.lo);
   s.lo += t.lo; return dd_quick_two_sum(s.hi, s.lo);
 }
-__device__ __forceinline__ DD dd_div_d(DD a, double b)
+// a / b for a small integer b, rb = 1 / b rounded: the two partial quotients only have to be good to an ulp or two (the remainder is
+// formed exactly), so they are products with rb -- an IEEE division costs ~35 instructions, and the running mean needs 40 of them
+__device__ __forceinline__ DD dd_div_d(DD a, double b, double rb)
 {
-  const double q1 = a.hi / b;
+  const double q1 = a.hi * rb;
   const DD p = dd_two_prod(q1, b);
   DD r = dd_two_sum(a.hi, -p.hi);
   r.lo += a.lo; r.lo -= p.lo;
-  const double q2 = (r.hi + r.lo) / b;
+  const double q2 = (r.hi + r.lo) * rb;
   return dd_quick_two_sum(q1, q2);
 }
 struct PdfNormalsSet { const double* xy; const uint8_t* mask_in; const uint8_t* mask_io_init; uint8_t* mask_io; double* phi; };
@@ -223,7 +225,7 @@ k_pdf_normals(PdfNormalsSet set0, PdfNormalsSet set1, int points, int sr)
       k++;
       DD d = dd_two_sum(j2 == 0 ? ax_[j] : ay_[j], -mean.hi);            // x - mean
       d.lo -= mean.lo; d = dd_quick_two_sum(d.hi, d.lo);
-      mean = dd_add(mean, dd_div_d(d, (double)k));
+      mean = dd_add(mean, dd_div_d(d, (double)k, __builtin_amdgcn_rcp((double)k)));      // (v_rcp_f64: good to an ulp, which is all dd_div_d asks)
     }
     cent[j2] = mean.hi;
   }
