@@ -294,7 +294,7 @@ void ThreadLocalize::processScan(const std::vector<float>& ranges, const builtin
   // registration_mode 3: inside the fused scan (the pre-registration on the device between the ray cast and the registration) when
   // this robot has the fused path to itself; the reference's own call structure otherwise (and with TSD_MODE3_UNFUSED set: A/B)
   static const bool mode3Unfused = std::getenv("TSD_MODE3_UNFUSED") != nullptr;
-  if(_regMode == 3 && _preMatcher && (mode3Unfused || !_fused || !_sensor->deviceHandle() || _concurrent))
+  if(_regMode == 3 && _preMatcher && (mode3Unfused || !_preFusedOk || !_fused || !_sensor->deviceHandle() || _concurrent))
   {
     processScanPreRegistered(rep);
     return;
@@ -471,6 +471,15 @@ void ThreadLocalize::processScanFused(ScanReport& rep)
       _preMatcher->drawStreams(n, dSub, dCtrl, dTrials);
       rc = _grid.scanPreregister(_sensor, _preMatcher->params(_ranPhiMax * M_PI / 180.0, _sensor->getAngularResolution()), _scene.data(), maskS,
                                  dSub.data(), dCtrl.data(), dTrials.data());
+      if(rc == TSD_E_CAPACITY)
+      {
+        // more trials / control points than the device-side list building holds in LDS: the reference's call structure instead,
+        // from this scan on (nothing was enqueued; the draws are consumed, like a match() that ran)
+        std::fprintf(stderr, "Localizer(%s): registration_mode 3 runs unfused (%s)\n", _nameSpace.c_str(), tsd_last_error(_grid.context()));
+        _preFusedOk = false;
+        processScanPreRegistered(rep);
+        return;
+      }
     }
     if(rc == TSD_OK) rc = _grid.scanSubmit(_sensor, useStaged, maskPush.data(), _icpParams, gates);
     // the next scan, if it is known already: ingest + copy + tables while the device registers this one

@@ -106,6 +106,7 @@ private:
 
   std::shared_ptr<sensor_msgs::msg::LaserScan> _ahead;      // announced next scan (clamped like laserCallBack does)
   bool _stagedValid = false;                                // _sensor holds, and the device has staged, the scan with ...
+  bool _preFusedOk = true;          // registration_mode 3: the device-side pre-registration takes these parameters (else: the unfused calls)
   long long _stagedStampNs = 0;                             // ... this stamp ...
   std::vector<float> _stagedRanges;                         // ... and these readings (in the sensor's beam order)
   std::deque<std::shared_ptr<sensor_msgs::msg::LaserScan>> _laserData;
