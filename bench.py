@@ -345,6 +345,16 @@ def main():
                             "algorithmic_bytes_per_launch": bytes_per_launch, "cell_bytes": cell_bytes,
                             "avg_launch_ms": upd_avg_ms, "launches": upd_launches,
                             "timing": f"HIP events on every {'' if every_upd == 1 else str(every_upd) + 'th '}dispatch of k_push_update, inside the timed region"}
+        # SURVEY 8(d) prices B against the time of the push's kernels together; the object above is the dominant one.  Since round 3
+        # k_push_update also writes the halo cells its changes belong to (propagateBorders' work, taken off k_push_halo), so the pair
+        # of figures to watch is this one.
+        stg = line.get("stages_ms") or {}
+        if all(stg.get(k) for k in ("push_classify", "push_update", "push_halo")):
+            t_push = stg["push_classify"] + stg["push_update"] + stg["push_halo"]
+            line["roofline"]["push_kernels"] = {
+                "kernels": "k_push_classify + k_push_update + k_push_halo", "sum_avg_launch_ms": t_push,
+                "achieved": bytes_per_launch / (t_push * 1e-3) / 1e9, "frac": bytes_per_launch / (t_push * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "of": "the same algorithmic bytes over the summed average durations of the three kernels of one push (sampled dispatches)"}
         if not args.no_cpu_baseline and world_size == 1 and args.robots == 1 and not args.registration_mode:
             line["cpu_baseline"] = cpu_baseline(args.config, scene, mode, min(args.cpu_scans, K))
         if rc == 0:

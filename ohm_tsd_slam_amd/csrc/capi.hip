@@ -882,6 +882,15 @@ int tsd_upload_tiles(tsd_ctx* ctx, const uint8_t* initialized, const double* ini
   if (rc != TSD_OK) return rc;
   rc = launch_neg_scan(ctx);              // which tiles can show a sign change to the ray cast
   if (rc != TSD_OK) return rc;
+  // The halos came as they were given (the text format does not store them: NaN): nothing says they agree with the neighbours' edge
+  // cells, which the incremental propagateBorders of the push relies on for the tiles it does not touch.  Every tile that holds data is
+  // marked like a freeFootprint write: the next push refreshes the halos around all of them -- the reference's full sweep after its
+  // first push (TsdGrid.cpp:372-427).
+  TSD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_dirty, initialized, T, hipMemcpyHostToDevice, ctx->stream));
+  {
+    TileBox all; all.x0 = 0; all.y0 = 0; all.x1 = g.PX - 1; all.y1 = g.PX - 1;
+    ctx->box_dirty.add(all);
+  }
   TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return TSD_OK;
 }

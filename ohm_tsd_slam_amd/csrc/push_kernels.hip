@@ -22,6 +22,10 @@
 #include "tsd_ctx.hpp"
 #include <climits>
 
+#ifndef TSD_WRITER_MIRRORS
+#define TSD_WRITER_MIRRORS 1     // k_push_update mirrors the edge cells it changes into the neighbours' halos (0: k_push_halo gathers them all)
+#endif
+
 namespace tsd {
 
 #ifndef TSD_UPDATE_BLOCK
@@ -336,6 +340,17 @@ k_push_classify(GridDev g, const PushArgs* __restrict__ a_dev, const char* __res
   // chain of memory round trips: every one of them that rides along with another is ~0.6 us off the kernel)
   // ld_pinned: the optimiser otherwise SINKS a read into the conditional block of its only use, behind that block's other waits.
   const uint8_t t_flag = ld_pinned(&g.flags[p]), t_dirty = ld_pinned(&dirty[p]);      // (used inside `in_window` regions only)
+#if TSD_WRITER_MIRRORS
+  // which of the left / lower / diagonal neighbours hold data BEFORE this push: k_push_update mirrors the edge cells it changes into
+  // their halos (a neighbour materialised by this very push gets its halo from k_push_halo)
+  unsigned nbr = 0u;
+  {
+    const int ppx = p % g.PX, ppy = p / g.PX;
+    const bool hL = ppx > 0, hD = ppy > 0;
+    const uint8_t nL = ld_pinned(&g.flags[hL ? p - 1 : p]), nD = ld_pinned(&g.flags[hD ? p - g.PX : p]), nDL = ld_pinned(&g.flags[(hL && hD) ? p - g.PX - 1 : p]);
+    nbr = ((hL && nL) ? 2u : 0u) | ((hD && nD) ? 4u : 0u) | ((hL && hD && nDL) ? 8u : 0u);
+  }
+#endif
   const double t_iw = ld_pinned(&g.init_weight[p]);
   double pw = 0.0;
   double tcx = 0.0, tcy = 0.0;                               // the tile's centroid (UPDATE tiles)
@@ -463,6 +478,9 @@ k_push_classify(GridDev g, const PushArgs* __restrict__ a_dev, const char* __res
       x.lcx = (float)lcx; x.lcy = (float)lcy;
       x.th_c = atan2_estimate(x.lcy, x.lcx);
       x.iw = t_iw; x.flag = t_flag;
+#if TSD_WRITER_MIRRORS
+      x.flag |= nbr;               // bit 0: the tile's _initialized; bits 1 / 2 / 3: left / lower / diagonal neighbour holds data
+#endif
       x.jb0 = (win & 0xFFFFu) > 0u ? (win & 0xFFFFu) - 1u : 0u;
       x.bd = bd0;
       static_cast<PushListAuxBody&>(list_aux[slot]) = x;
@@ -700,6 +718,11 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
   __shared__ unsigned int s_upd[3];                                        // cells updated
   __shared__ unsigned long long s_neg[3];                                  // groups of the tile that received a negative value
   __shared__ unsigned int s_tk[4];                                         // list index of tile number n at [n & 3]
+#if TSD_WRITER_MIRRORS
+  // the tile's edge cells that this push changed (slot y: cell (0, y); slot 32 + x: cell (x, 0), x > 0): value, weight, "changed"
+  // (a NaN weight = unchanged: weights are never NaN)
+  __shared__ __attribute__((aligned(16))) double2 s_edge[2 * TILE_DIM];
+#endif
   const double max_trunc = g.max_trunc;
 
   if (blockIdx.x < n_upd_tiles) {
@@ -753,6 +776,9 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
     ta.wlo = wlo; ta.whi = whi;
     if (tid < ROT_N) s_rot[tid] = st_rot;
     if (tid < 3) { s_cu[tid] = 0ull; s_upd[tid] = 0u; s_neg[tid] = 0ull; }
+#if TSD_WRITER_MIRRORS
+    if (tid < 2 * TILE_DIM) s_edge[tid] = make_double2(0.0, __builtin_nan(""));
+#endif
     lds_barrier();                     // scan staged, counters zeroed, first tickets in place
     PSTAMP(0);
 
@@ -859,7 +885,7 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
       TileC tc;
       tc.p = (int)(x.entry & LIST_TILE_MASK);
       tc.T = g.tsd + (size_t)tc.p * TILE_STRIDE; tc.W = g.weight + (size_t)tc.p * TILE_STRIDE;
-      tc.pw = x.pw; tc.iw = x.iw; tc.fresh = x.flag == 0u;
+      tc.pw = x.pw; tc.iw = x.iw; tc.fresh = (x.flag & 1u) == 0u;
       return tc;
     };
 
@@ -877,6 +903,7 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
       if (tid == 0 && more_than_one) tk_pending = draw();
       const TileC tcur = tile_of(xc);
       const unsigned x0 = (unsigned)(tcur.p % g.PX) * TILE_DIM, y0 = (unsigned)(tcur.p / g.PX) * TILE_DIM;
+
       phase_a(n, xc, tcur, x0, y0);
       PSTAMP(1);
       // tile n + 1's record and the ticket of tile n + 2 were requested a whole phase A ago: the wave takes delivery HERE, where that
@@ -987,6 +1014,12 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
           n_upd += (unsigned)__popcll(__ballot(touched));
           if (touched && tv[j] < 0.0) wrote_neg |= neg_bit((unsigned)c & 31u, (unsigned)c >> 5);
           if (on && (touched || tcur.fresh)) st_cell(tcur.T, tcur.W, c, tv[j], wv[j]);
+#if TSD_WRITER_MIRRORS
+          // a changed cell of column 0 / row 0 is also a halo cell of the left / lower / diagonal neighbour: parked for the mirror pass
+          // (a fresh tile's surroundings are refreshed by k_push_halo)
+          if (touched && !tcur.fresh && ((c & 31) == 0 || (c >> 5) == 0))
+            s_edge[(c & 31) == 0 ? (c >> 5) : TILE_DIM + (c & 31)] = make_double2(tv[j], wv[j]);
+#endif
         }
       }
       if (wrote_neg) atomicOr(&s_neg[slot], wrote_neg);               // (LDS; folded into the tile's mask below)
@@ -995,6 +1028,34 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
       PSTAMP(3);
       lds_barrier();               // tile n done by every wave; the next ticket in place
       PSTAMP(4);
+#if TSD_WRITER_MIRRORS
+      if (tid >= 64 && tid < 128) {
+        // TsdGrid::propagateBorders (TsdGrid.cpp:372-427) for what THIS tile changed: its column 0 is the left neighbour's halo column,
+        // its row 0 the lower neighbour's halo row, its cell (0, 0) the diagonal neighbour's corner -- written from here, 64 lanes at
+        // once, instead of being gathered by k_push_halo line by line (32 lines for 32 cells).  Only where the neighbour holds data;
+        // untouched cells are in place from earlier pushes.
+        const int l = lane;
+        const double2 e = s_edge[l == TILE_DIM ? 0 : l];                // (cell (0, 0) heads both the column and the row)
+        const double2 e0 = s_edge[0];
+#ifdef TSD_DBG_NF7
+        const unsigned nf = (x0 > 0u ? 1u : 0u) | (y0 > 0u ? 2u : 0u) | ((x0 > 0u && y0 > 0u) ? 4u : 0u);
+#else
+        const unsigned nf = xc.flag >> 1;                                // bits 0 / 1 / 2: left / lower / diagonal neighbour held data before this push
+#endif
+        s_edge[l] = make_double2(0.0, __builtin_nan(""));               // (this wave's reads above precede this write: in order)
+#ifdef TSD_DBG_MIRROR
+        if (l < TILE_DIM && !isnan(e.y) && !(nf & 1u) && x0 > 0u) printf("tile %d: changed (0,%d), left neighbour %d not mirrored: record flag %u, flags now %d, fresh %d\n", tcur.p, l, tcur.p - 1, xc.flag, (int)g.flags[tcur.p - 1], (int)tcur.fresh);
+#endif
+        const bool f = !isnan(e.y), f0 = !isnan(e0.y);
+        const size_t PXs = (size_t)g.PX;
+        if (l < TILE_DIM) {
+          if (f && (nf & 1u)) { const size_t o = ((size_t)tcur.p - 1) * TILE_STRIDE + HALO_COL + l; st_tsd(g.tsd + o, e.x); st_w(g.weight + o, e.y); }
+        } else {
+          if (f && (nf & 2u)) { const size_t o = ((size_t)tcur.p - PXs) * TILE_STRIDE + HALO_ROW + (l - TILE_DIM); st_tsd(g.tsd + o, e.x); st_w(g.weight + o, e.y); }
+        }
+        if (l == 0 && f0 && (nf & 4u)) { const size_t o = ((size_t)tcur.p - PXs - 1) * TILE_STRIDE + HALO_ROW + TILE_DIM; st_tsd(g.tsd + o, e0.x); st_w(g.weight + o, e0.y); }
+      }
+#endif
       if (tid == 0) {
         // the record of tile n (this slot's counters are next used by tile n + 3: behind two more barriers)
         const unsigned cells = s_upd[slot];
@@ -1093,6 +1154,9 @@ k_push_halo(GridDev g, uint8_t* __restrict__ dirty, unsigned long long* __restri
     const uint8_t f0 = g.flags[p], dty = dirty[p];
     const uint8_t fR_ = g.flags[qR], fU_ = g.flags[qU], fUR_ = g.flags[qUR], fL_ = g.flags[qL], fD_ = g.flags[qD], fDL_ = g.flags[qDL];
     const uint32_t rL_ = tile_rec[qL], rD_ = tile_rec[qD], rDL_ = tile_rec[qDL];
+#if TSD_WRITER_MIRRORS
+    const uint32_t r0 = tile_rec[p];
+#endif
     if (lane == 0 && dty != 0) dirty[p] = 0;
     const uint8_t fR = hasR ? fR_ : (uint8_t)0, fU = hasU ? fU_ : (uint8_t)0, fUR = (hasR && hasU) ? fUR_ : (uint8_t)0;
     uint8_t fL = hasL ? fL_ : (uint8_t)0, fD = hasD ? fD_ : (uint8_t)0, fDL = (hasL && hasD) ? fDL_ : (uint8_t)0;
@@ -1101,9 +1165,25 @@ k_push_halo(GridDev g, uint8_t* __restrict__ dirty, unsigned long long* __restri
     // listed tiles are dense.  Records outside this push's window are never "listed" (see launch_push).
     const uint32_t rL = hasL ? rL_ : 0u, rD = hasD ? rD_ : 0u, rDL = (hasL && hasD) ? rDL_ : 0u;
     if (!f0) continue;
+#if TSD_WRITER_MIRRORS
+    // An UPDATE tile that held data before this push and was not touched by freeFootprint has nothing to do here: what it changed of
+    // its column 0 / row 0 / corner, its own workgroup wrote into the neighbours' halos (k_push_update's mirror pass), and what its
+    // right / upper neighbours changed arrived the same way or is brought by THEIR jobs below.  Left for this kernel: tiles
+    // materialised by this push (everything around them), increaseEmptiness tiles (all 33 x 33 cells changed, own halo included),
+    // tiles freeFootprint wrote to.
+    const bool plain_u = (entry >> KIND_SHIFT) == KIND_UPDATE && !(r0 & REC_NEW) && dty == 0;
+    if (plain_u) continue;
+    // (a neighbour that is on the list and surely does its own job 0 -- materialised, emptied or halo-only this push -- needs no
+    // mirror job from here; a plain UPDATE neighbour does nothing in this kernel, so it does)
+    auto own_job = [](uint32_t r) { return (r & REC_LISTED) != 0u && !((r & REC_UPDATE) != 0u && !(r & REC_NEW)); };
+    if (own_job(rL)) fL = 0;
+    if (own_job(rD)) fD = 0;
+    if (own_job(rDL)) fDL = 0;
+#else
     if (rL & REC_LISTED) fL = 0;
     if (rD & REC_LISTED) fD = 0;
     if (rDL & REC_LISTED) fDL = 0;
+#endif
     const size_t own = (size_t)p * TILE_STRIDE;
     // job 0: own halo from the right / upper neighbour; job 1: the left / lower neighbour's halo from this tile;
     // job 2 (lanes 0 and 32 only): the corner cells

@@ -1,0 +1,24 @@
+import sys, numpy as np
+sys.path.insert(0,'.')
+from oracle import pyoracle as O
+from ohm_tsd_slam_amd import capi, synth
+from tests import helpers as H
+from tests.test_gpu_parity import make_pair, push_both
+O.build()
+gc = synth.GridConfig(8, 0.1); geo = synth.ScanGeometry.full_circle_360(); world = synth.World("room", gc)
+og, dg = make_pair(O, gc)
+PX = (1 << 8) // 32
+for k in range(6):
+    so, sd = push_both(O, og, dg, world, geo, k * 5)
+    oi, oiw, ot, ow = og.dump(); gi, giw, gt, gw = dg.download_tiles()
+    bad = (np.isnan(ot) != np.isnan(gt)) & oi.astype(bool)[:, None]
+    if bad.any():
+        tiles = np.nonzero(bad.any(axis=1))[0]
+        print("push", k, "tiles with NaN-pattern differences:", tiles[:10])
+        for t in tiles[:4]:
+            cells = np.nonzero(bad[t])[0]
+            xy = [(int(c % 33), int(c // 33)) for c in cells[:12]]
+            print("  tile", t, "(px,py)=", (t % PX, t // PX), "cells (x,y):", xy, "oracle", ot[t][cells[:4]], "hip", gt[t][cells[:4]], "flags nbrs L/R/U/D:", [int(oi[q]) if 0 <= q < oi.size else -1 for q in (t-1, t+1, t+PX, t-PX)])
+        break
+else:
+    print("no difference in 6 pushes")

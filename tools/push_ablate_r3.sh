@@ -5,7 +5,7 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 for ab in ${TSD_ABLATE_SET:-0 1 2 4 6 14} "$@"; do
-  DIAG_DIR=diag_ab$ab tools/diag_build.sh push_kernels -DTSD_ABLATE=$ab > /dev/null 2>&1 || { echo "ablate $ab failed to build"; continue; }
+  DIAG_DIR=diag_ab$ab tools/diag_build.sh push_kernels -DTSD_ABLATE=$ab $TSD_ABLATE_EXTRA > /dev/null 2>&1 || { echo "ablate $ab failed to build"; continue; }
   export TSD_LIB_DIR=$GRAFT_REPO_ROOT/ohm_tsd_slam_amd/lib/diag_ab$ab
   for w in "cfg3 comb" "cfg2 pillars"; do set -- $w
     rm -rf gpurun_out/ab_tmp
