@@ -1037,15 +1037,8 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
         const int l = lane;
         const double2 e = s_edge[l == TILE_DIM ? 0 : l];                // (cell (0, 0) heads both the column and the row)
         const double2 e0 = s_edge[0];
-#ifdef TSD_DBG_NF7
-        const unsigned nf = (x0 > 0u ? 1u : 0u) | (y0 > 0u ? 2u : 0u) | ((x0 > 0u && y0 > 0u) ? 4u : 0u);
-#else
         const unsigned nf = xc.flag >> 1;                                // bits 0 / 1 / 2: left / lower / diagonal neighbour held data before this push
-#endif
         s_edge[l] = make_double2(0.0, __builtin_nan(""));               // (this wave's reads above precede this write: in order)
-#ifdef TSD_DBG_MIRROR
-        if (l < TILE_DIM && !isnan(e.y) && !(nf & 1u) && x0 > 0u) printf("tile %d: changed (0,%d), left neighbour %d not mirrored: record flag %u, flags now %d, fresh %d\n", tcur.p, l, tcur.p - 1, xc.flag, (int)g.flags[tcur.p - 1], (int)tcur.fresh);
-#endif
         const bool f = !isnan(e.y), f0 = !isnan(e0.y);
         const size_t PXs = (size_t)g.PX;
         if (l < TILE_DIM) {

@@ -1,3 +1,5 @@
+"""Diagnostic (GPU box; uses oracle/): after each of six pushes of the room scene, which tiles / cells of the HIP grid differ from the
+oracle's in their NaN pattern -- halo cells show up as x or y == 32.  usage: python tools/dbg_halo.py"""
 import sys, numpy as np
 sys.path.insert(0,'.')
 from oracle import pyoracle as O
