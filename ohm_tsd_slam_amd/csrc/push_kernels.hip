@@ -1017,8 +1017,10 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
 #if TSD_WRITER_MIRRORS
           // a changed cell of column 0 / row 0 is also a halo cell of the left / lower / diagonal neighbour: parked for the mirror pass
           // (a fresh tile's surroundings are refreshed by k_push_halo)
+#if !(defined(TSD_MIRROR_ABL) && (TSD_MIRROR_ABL & 1))        // (timing experiment: results wrong)
           if (touched && !tcur.fresh && ((c & 31) == 0 || (c >> 5) == 0))
             s_edge[(c & 31) == 0 ? (c >> 5) : TILE_DIM + (c & 31)] = make_double2(tv[j], wv[j]);
+#endif
 #endif
         }
       }
@@ -1028,7 +1030,7 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
       PSTAMP(3);
       lds_barrier();               // tile n done by every wave; the next ticket in place
       PSTAMP(4);
-#if TSD_WRITER_MIRRORS
+#if TSD_WRITER_MIRRORS && !(defined(TSD_MIRROR_ABL) && (TSD_MIRROR_ABL & 2))
       if (tid >= 64 && tid < 128) {
         // TsdGrid::propagateBorders (TsdGrid.cpp:372-427) for what THIS tile changed: its column 0 is the left neighbour's halo column,
         // its row 0 the lower neighbour's halo row, its cell (0, 0) the diagonal neighbour's corner -- written from here, 64 lanes at
