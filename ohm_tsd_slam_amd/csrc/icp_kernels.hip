@@ -1151,7 +1151,13 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     const IcpTail& tl = *L.tail;
     if (tid == 0) *tl.out = r;
     // fused scan: gates, Sensor::transform, push / next-scan arguments, result record for the host
+#ifdef TSD_ICP_STAMPS
+    const long long ep0 = wall_clock64();
+#endif
     if (tl.post.st) scan_post_body(tl.post, L.tail->pre, r.T, r, tl.post.gmin_x, tl.post.gmax_x, tl.post.gmin_y, tl.post.gmax_y);
+#ifdef TSD_ICP_STAMPS
+    if (tid == 0 && tl.post.st) printf("ICPDBG epilogue %lld x10ns (thread 0, incl. the record's system-scope publication)\n", wall_clock64() - ep0);
+#endif
   }
 }
 
