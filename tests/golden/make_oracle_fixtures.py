@@ -140,10 +140,54 @@ def baseline_configs():
     np.savez_compressed(os.path.join(HERE, "oracle_baseline_configs.npz"), **out)
 
 
+def tsdpdf():
+    """SURVEY 8(f) row N3: TSD_PDFMatching::match with fixed rand() draws on a small map, and Icp::iterate with its result as Tinit
+    (registration_mode 3).  Inputs: the pushes that build the map, the pose the robot believes, the float32 scan; the three draw
+    streams.  Outputs: the match (winner, counts, T, probability) and the registration."""
+    gc = synth.GridConfig(8, 0.05)
+    geo = synth.ScanGeometry.full_circle_360()
+    world = synth.World("room", gc)
+    g = O.Grid(gc.map_size_log2, gc.cell_size, gc.max_trunc)
+    poses, scans = [], []
+    for k in range(4):
+        pose, (x, y, yaw) = H.sensor_pose(world, k)
+        r = world.scan(x, y, yaw, geo)
+        data, mask = O.ingest_f32(r, H.MAX_RANGE, geo.angle_increment)
+        g.push(pose, data, mask, geo.angle_increment, geo.angle_min, H.MAX_RANGE, H.MIN_RANGE, H.LOW_REFL)
+        poses.append(pose); scans.append(r)
+    pose, _ = H.sensor_pose(world, 3)                              # where the robot believes it is
+    _, (x, y, yaw) = H.sensor_pose(world, 8)                       # where the scan is taken
+    rl, rw = H.world_rays(O, geo, pose, gc.cell_size)
+    co, no, mo, cnt = g.raycast(pose, rw, H.MIN_RANGE, H.MAX_RANGE)
+    r32 = world.scan(x, y, yaw + 0.05, geo)
+    data, mask = O.ingest_f32(r32, H.MAX_RANGE, geo.angle_increment)
+    sc, ms, _ = O.scene_from_scan(rl, data, mask)
+    rng = np.random.default_rng(20261003)
+    trials, ctrl, zrand, phi_max = 100, 140, 0.25, math.radians(30.0)
+    ds, dc, dt = (rng.integers(0, 2 ** 31 - 1, n).astype(np.int32) for n in (geo.beams, ctrl, trials))
+    m = O.tsdpdf_match(g, pose, co, mo, sc, ms, trials, ctrl, zrand, phi_max, geo.angle_increment, ds, dc, dt)
+    M = co.reshape(-1, 2)[mo.astype(bool)]
+    S = sc.reshape(-1, 2)[ms.astype(bool)]
+    icp = O.icp_init(M, S, pose, 30, 0.4, 0.02, (0.0, g.max_x, 0.0, g.max_x), m["T"], nn_mode=1)
+    np.savez_compressed(
+        os.path.join(HERE, "oracle_tsdpdf.npz"), map_size_log2=gc.map_size_log2, cell_size=gc.cell_size, max_trunc=gc.max_trunc,
+        beams=geo.beams, angle_min=geo.angle_min, angle_increment=geo.angle_increment, push_poses=np.array(poses), push_scans=np.array(scans),
+        pose=pose, rays_world=rw, rays_local=rl, scan=r32, rc_mask=mo, rc_coords=co, scene=sc, scene_mask=ms,
+        trials=trials, size_control_set=ctrl, zrand=zrand, phi_max=phi_max, draws_sub=ds, draws_ctrl=dc, draws_trials=dt,
+        match_T=m["T"], match_prob=m["prob"], match_counts=np.array([m["candidates"], m["idx"], m["i"]]),
+        icp_T=icp["T"], icp_counts=np.array([icp["pairs"], icp["iterations"], icp["state"], len(M), len(S)]), icp_rms=icp["rms"])
+    g.close()
+
+
 if __name__ == "__main__":
     O.build()
+    if len(sys.argv) > 1 and sys.argv[1] == "tsdpdf":                 # (only the N3 fixture: the others take minutes)
+        tsdpdf()
+        print("oracle_tsdpdf.npz", os.path.getsize(os.path.join(HERE, "oracle_tsdpdf.npz")), "bytes")
+        sys.exit(0)
     push_raycast_icp()
     trajectory()
     baseline_configs()
-    for f in ("oracle_push_raycast_icp.npz", "oracle_trajectory.npz", "oracle_baseline_configs.npz"):
+    tsdpdf()
+    for f in ("oracle_push_raycast_icp.npz", "oracle_trajectory.npz", "oracle_baseline_configs.npz", "oracle_tsdpdf.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

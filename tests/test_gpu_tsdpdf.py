@@ -101,6 +101,44 @@ def test_fused_preregistration_matches_the_unfused_calls(oracle, cfg, scene, ctr
     sensor.close()
 
 
+def test_hip_matches_the_committed_tsdpdf_fixture():
+    """No oracle at run time: the committed vectors of tests/golden/oracle_tsdpdf.npz (make_oracle_fixtures.py) against the HIP path,
+    through tsd_tsdpdf_match + tsd_localize(t_init) and through the fused scan (tsd_scan_preregister)."""
+    import os
+    f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_tsdpdf.npz"))
+    from oracle import pyoracle as O        # (only the scan ingest: part of the inputs' preparation, not of what is checked)
+    res, phi = float(f["angle_increment"]), float(f["angle_min"])
+    dg = capi.TsdGridDevice(int(f["map_size_log2"]), float(f["cell_size"]), float(f["max_trunc"]))
+    for k in range(len(f["push_poses"])):
+        data, mask = O.ingest_f32(f["push_scans"][k], H.MAX_RANGE, res)
+        dg.push(f["push_poses"][k], data, mask, res, phi, H.MAX_RANGE, H.MIN_RANGE, H.LOW_REFL, want_stats=False)
+    pose, rw, rl = f["pose"], f["rays_world"], f["rays_local"]
+    ch, nh, mh, cnt = dg.raycast(pose, rw, H.MIN_RANGE, H.MAX_RANGE)
+    sel = np.repeat(mh.astype(bool), 2)
+    assert np.array_equal(mh, f["rc_mask"]) and np.max(np.abs(ch[sel] - f["rc_coords"][sel])) <= 1e-9
+    args = (int(f["trials"]), int(f["size_control_set"]), float(f["zrand"]), float(f["phi_max"]), res, f["draws_sub"], f["draws_ctrl"], f["draws_trials"])
+    m = dg.tsdpdf_match(pose, ch, mh, f["scene"], f["scene_mask"], *args)
+    assert [m["candidates"], m["idx"], m["i"]] == list(f["match_counts"])
+    assert np.max(np.abs(m["T"] - f["match_T"])) <= 1e-12 and abs(m["prob"] - float(f["match_prob"])) <= 1e-9 * float(f["match_prob"])
+    data, mask = O.ingest_f32(f["scan"], H.MAX_RANGE, res)
+    r = dg.localize(pose, rw, rl, data, mask, H.MIN_RANGE, H.MAX_RANGE, dg.icp_params(30, 0.4, 0.02, t_init=m["T"]))
+    assert [r.pairs, r.iterations, r.state, r.n_model, r.n_scene] == list(f["icp_counts"])
+    d, a = H.pose_delta(f["icp_T"], np.asarray(r.T))
+    assert d <= 1e-9 and a <= 1e-9 and abs(r.rms - float(f["icp_rms"])) <= 1e-9
+    # the fused scan
+    _, mask_push = O.ingest_f64(data, H.MAX_RANGE, res)
+    sensor = capi.TsdSensorDevice(dg, int(f["beams"]), res, phi, H.MAX_RANGE, H.MIN_RANGE, H.LOW_REFL)
+    sensor.set_pose(pose, rw, rl)
+    sensor.preregister(f["scene"], f["scene_mask"], *args)
+    sr = sensor.scan(data, mask, mask_push, dg.icp_params(30, 0.4, 0.02), capi.GateParams(10.0, 1.0, 1e9, 2.0))
+    pr = sensor.preregistration_result()
+    assert [pr["candidates"], pr["idx"], pr["i"]] == list(f["match_counts"]) and np.max(np.abs(pr["T"] - f["match_T"])) <= 1e-12
+    assert [sr.icp.pairs, sr.icp.iterations, sr.icp.state, sr.icp.n_model, sr.icp.n_scene] == list(f["icp_counts"])
+    d, a = H.pose_delta(f["icp_T"], np.array(sr.icp.T[:]).reshape(3, 3))
+    assert d <= 1e-9 and a <= 1e-9
+    sensor.close()
+
+
 def test_tsdpdf_degenerate_inputs(oracle):
     """too few valid points -> identity (TSD_PDFMatching.cpp:53-57, :129-139); all-false masks; tiny control set"""
     gc, geo, _ = synth.CONFIGS["cfg1"]
