@@ -2,7 +2,7 @@
 # diagnostic: per-phase cycle stamps of k_icp inside the closed SLAM loop of bench.py (cfg2)
 $GRAFT_REPO_ROOT/tools/diag_build.sh icp_kernels -DTSD_ICP_STAMPS $TSD_EXTRA
 export TSD_LIB_DIR=$GRAFT_REPO_ROOT/ohm_tsd_slam_amd/lib/diag
-cd $GRAFT_REPO_ROOT && python3 - <<'PY' 2>&1 | grep -E 'ICPDBG|avg over|SLOW' | sort -t' ' -k11,11n | tail -12
+cd $GRAFT_REPO_ROOT && python3 - <<'PY' 2>&1 | grep -E "${TSD_GREP:-ICPDBG|avg over|SLOW|cycles/step|searched/step}" | tail -${TSD_TAIL:-12}
 import numpy as np, sys
 sys.path.insert(0, '.')
 from ohm_tsd_slam_amd import capi, facade, synth
