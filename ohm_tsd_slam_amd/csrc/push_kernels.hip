@@ -558,6 +558,9 @@ __device__ __forceinline__ float beam_limit(double r, unsigned mk, float mtf, fl
 // Lazy TsdGridPartition::init (TsdGridPartition.cpp:88-134) is folded in (a fresh tile's old value is known: non-candidates get
 // the init value from phase A / the fix-up, candidates start from it in phase C); KIND_EMPTY: increaseEmptiness over the 33x33
 // cells.  The workgroup leaves the tile's record and adds it to the tile's running totals (no-return atomics).
+#ifndef TSD_UPDATE_PREFETCH
+#define TSD_UPDATE_PREFETCH 1
+#endif
 #ifndef TSD_UPDATE_WPS
 #define TSD_UPDATE_WPS 5
 #endif
@@ -904,7 +907,23 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
       const TileC tcur = tile_of(xc);
       const unsigned x0 = (unsigned)(tcur.p % g.PX) * TILE_DIM, y0 = (unsigned)(tcur.p / g.PX) * TILE_DIM;
 
+#if TSD_UPDATE_PREFETCH
+      // A workgroup with a single tile (cfg 2: every workgroup) is one latency chain -- record -> scan window -> phase A -> cells ->
+      // stores: the tile's lines are requested HERE (one lane per 128-byte line: wave 0 the values, wave 1 the weights), arrive during
+      // phase A, and the exact part's reads, a barrier later, find them in L2: 13.5 -> 13.0 us at cfg2 / pillars.  Measured and not
+      // done: the same for workgroups with several tiles (bound by instruction issue: +0.4-0.8 us at cfg 3), and requesting the lines
+      // as soon as the record names the tile (the scan window's reads then queue behind 64 single-line requests: 14.5 us).
+      tsd_cell_t pf_t = 0; w_cell_t pf_w = 0;
+      if (!more_than_one && !tcur.fresh) {
+        constexpr int CPL_T = 128 / (int)sizeof(tsd_cell_t), CPL_W = 128 / (int)sizeof(w_cell_t);
+        if (tid < 64 && lane < TILE_INTERIOR / CPL_T) pf_t = ld_pinned(tcur.T + CPL_T * lane);
+        if (tid >= 64 && tid < 128 && lane < TILE_INTERIOR / CPL_W) pf_w = ld_pinned(tcur.W + CPL_W * lane);
+      }
+#endif
       phase_a(n, xc, tcur, x0, y0);
+#if TSD_UPDATE_PREFETCH
+      asm volatile("" : : "v"(pf_t), "v"(pf_w));
+#endif
       PSTAMP(1);
       // tile n + 1's record and the ticket of tile n + 2 were requested a whole phase A ago: the wave takes delivery HERE, where that
       // costs nothing -- at their points of use (behind the exact part) the same wait would also sit out the tile's own stores
