@@ -1258,6 +1258,7 @@ void tsd_sensor_destroy(tsd_sensor* s)
   for (hipEvent_t e : {s->ev_rc_done, s->ev_icp_done}) if (e) hipEventDestroy(e);
   if (s->stream) hipStreamDestroy(s->stream);
   hipFree(s->d_coords); hipFree(s->d_normals); hipFree(s->d_mask_m); hipFree(s->d_icp_res); hipFree(s->d_icp_trace);
+  if (s->ev_pre) hipEventDestroy(s->ev_pre);
   if (s->d_pre) hipFree(s->d_pre);
   if (s->h_pre) hipHostFree(s->h_pre);
   hipFree(s->d_rmq2[0]); hipFree(s->d_rmq2[1]); hipFree(s->d_rmq2[2]);

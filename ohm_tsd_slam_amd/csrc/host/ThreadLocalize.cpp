@@ -467,10 +467,12 @@ void ThreadLocalize::processScanFused(ScanReport& rep)
       if(_scene.size() != 2 * (size_t)n) { _scene.assign(2 * (size_t)n, 0.0); _maskS.assign(n, 0); }
       bool* maskS = reinterpret_cast<bool*>(_maskS.data());
       _sensor->dataToCartesianVectorMask(_scene.data(), maskS);
-      std::vector<int> dSub, dCtrl, dTrials;
-      _preMatcher->drawStreams(n, dSub, dCtrl, dTrials);
+      // (the draws do not depend on the scan: they were taken from rand() while the previous scan registered -- same values, same
+      // order, as long as this localiser is the process's only rand() user, which it is in the reference's single-robot node too)
+      if(!_drawsReady || _dSub.size() != n) _preMatcher->drawStreams(n, _dSub, _dCtrl, _dTrials);
+      _drawsReady = false;
       rc = _grid.scanPreregister(_sensor, _preMatcher->params(_ranPhiMax * M_PI / 180.0, _sensor->getAngularResolution()), _scene.data(), maskS,
-                                 dSub.data(), dCtrl.data(), dTrials.data());
+                                 _dSub.data(), _dCtrl.data(), _dTrials.data());
       if(rc == TSD_E_CAPACITY)
       {
         // more trials / control points than the device-side list building holds in LDS: the reference's call structure instead,
@@ -508,6 +510,11 @@ void ThreadLocalize::processScanFused(ScanReport& rep)
         _stagedStampNs = (long long)next->header.stamp.sec * 1000000000LL + (long long)next->header.stamp.nanosec;
         _stagedRanges = next->ranges;
       }
+    }
+    if(rc == TSD_OK && _regMode == 3 && _preMatcher && _preFusedOk && !_drawsReady)
+    {
+      _preMatcher->drawStreams(_sensor->getRealMeasurementSize(), _dSub, _dCtrl, _dTrials);      // the next scan's, while the device is busy
+      _drawsReady = true;
     }
     if(rc == TSD_OK) rc = _grid.scanCollect(_sensor, &sr);
   }

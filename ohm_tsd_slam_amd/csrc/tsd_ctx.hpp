@@ -259,6 +259,8 @@ struct tsd_sensor {
   // fused registration_mode 3 (tsd_scan_preregister, tsdpdf.hip): inputs of the pre-registration that the next tsd_scan_submit runs
   // on the device between its ray cast and its registration; one device + one pinned buffer, grown on demand
   char* d_pre = nullptr; char* h_pre = nullptr; size_t pre_bytes = 0;
+  hipEvent_t ev_pre = nullptr;              // the pre-registration's inputs are on the device (copied on the side stream by tsd_scan_preregister)
+  bool pre_copied = false;
   bool pre_armed = false, pre_ran = false;
   struct PreLayout {
     size_t off_S, off_ms, off_msp, off_dc, off_dt, in_bytes;             // inputs (host -> device each scan)

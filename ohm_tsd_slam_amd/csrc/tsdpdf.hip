@@ -119,7 +119,8 @@ k_pdf_score(GridDev g, const double* __restrict__ pose /* first two rows suffice
 // 0.0 and is replaced on `>` only (TSD_PDFMatching.cpp:188,264)
 __global__ void __launch_bounds__(1024)
 k_pdf_argmax(const double* __restrict__ prob, const PdfCandidate* __restrict__ cand, int n_cand, const double* __restrict__ M,
-             const double* __restrict__ S, PdfResult* __restrict__ out, const PdfHeader* __restrict__ hdr)
+             const double* __restrict__ S, PdfResult* __restrict__ out, const PdfHeader* __restrict__ hdr,
+             PdfHeader* __restrict__ host_hdr, PdfResult* __restrict__ host_res /* fused scan: pinned host memory, or nullptr */)
 {
   if (hdr) n_cand = hdr->identity ? 0 : hdr->n_cand;
   __shared__ double s_p[1024];
@@ -155,6 +156,9 @@ k_pdf_argmax(const double* __restrict__ prob, const PdfCandidate* __restrict__ c
       r.prob = s_p[0]; r.idx = cd.idx; r.i = cd.i;
     }
     *out = r;
+    // fused scan: header and result go to the host from here (stores into pinned memory, complete when the kernel ends) -- a copy
+    // behind this kernel would sit between it and the registration (a blit kernel: ~8 us with its hand-offs)
+    if (host_res) { *host_res = r; *host_hdr = *hdr; }
   }
 }
 
@@ -729,7 +733,7 @@ extern "C" int tsd_tsdpdf_match(tsd_ctx* ctx, const double pose33[9], const doub
                        prm->zrand, reinterpret_cast<double*>(d + off_prob), nullptr);
     hipLaunchKernelGGL(k_pdf_argmax, dim3(1), dim3(1024), 0, ctx->stream, reinterpret_cast<const double*>(d + off_prob),
                        reinterpret_cast<const PdfCandidate*>(d + off_K), nc, reinterpret_cast<const double*>(d),
-                       reinterpret_cast<const double*>(d + off_S), reinterpret_cast<PdfResult*>(d + off_res), nullptr);
+                       reinterpret_cast<const double*>(d + off_S), reinterpret_cast<PdfResult*>(d + off_res), nullptr, nullptr, nullptr);
   }
   TSD_HIP_CHECK(ctx, hipGetLastError());
   TSD_HIP_CHECK(ctx, hipMemcpyAsync(h + off_res, d + off_res, sizeof(PdfResult), hipMemcpyDeviceToHost, ctx->stream));
@@ -800,6 +804,19 @@ extern "C" int tsd_scan_preregister(tsd_sensor* s, const tsd_tsdpdf_params* prm,
   std::memcpy(h + L.off_dc, draws_control, (size_t)prm->size_control_set * 4);
   std::memcpy(h + L.off_dt, draws_trials, (size_t)prm->trials * 4);
   s->pre = L;
+  // The inputs go to the device NOW, on the side stream: the caller is between two scans -- the previous scan's push and this scan's ray
+  // cast are still running on the main stream -- so the copy (6 us on a DMA engine + ~9 us until a kernel behind it on the same stream
+  // starts) is off the scan's chain.  The previous scan's kernels that read d_pre ran ahead of its registration, which has ended (the
+  // scan was collected).  TSD_PRE_COPY_MAIN=1: the copy at tsd_scan_submit, on the main stream (round 3's first form; A/B).
+  static const bool copy_main = [] { const char* e = std::getenv("TSD_PRE_COPY_MAIN"); return e && *e == '1'; }();
+  s->pre_copied = false;
+  if (!copy_main) {
+    if (!s->ev_pre) TSD_HIP_CHECK(ctx, hipEventCreateWithFlags(&s->ev_pre, hipEventDisableTiming));
+    TSD_HIP_CHECK(ctx, hipMemcpyAsync(s->d_pre, s->h_pre, L.in_bytes, hipMemcpyHostToDevice, ctx->stream2));
+    TSD_HIP_CHECK(ctx, hipEventRecord(s->ev_pre, ctx->stream2));
+    (void)hipStreamQuery(ctx->stream2);
+    s->pre_copied = true;
+  }
   s->pre_armed = true;
   return TSD_OK;
 }
@@ -810,8 +827,14 @@ int launch_preregistration(tsd_ctx* ctx, tsd_sensor* s, hipStream_t stream, cons
 {
   const tsd_sensor::PreLayout& L = s->pre;
   char* d = s->d_pre;
+  char* h_dev = nullptr;                    // the pinned buffer as the device sees it (header + result are written there by k_pdf_argmax)
+  TSD_HIP_CHECK(ctx, hipHostGetDevicePointer(reinterpret_cast<void**>(&h_dev), s->h_pre, 0));
   const int n = L.n, SR = 10 / 2;
-  TSD_HIP_CHECK(ctx, hipMemcpyAsync(d, s->h_pre, L.in_bytes, hipMemcpyHostToDevice, stream));
+  if (!s->pre_copied) TSD_HIP_CHECK(ctx, hipMemcpyAsync(d, s->h_pre, L.in_bytes, hipMemcpyHostToDevice, stream));
+  else if (hipEventQuery(s->ev_pre) != hipSuccess) {
+    (void)hipGetLastError();                 // (hipErrorNotReady is sticky as "last error")
+    TSD_HIP_CHECK(ctx, hipStreamWaitEvent(stream, s->ev_pre, 0));
+  }
   PdfNormalsSet sm{d_coords, d_mask_m, d_mask_m, reinterpret_cast<uint8_t*>(d + L.off_mo_m), reinterpret_cast<double*>(d + L.off_phi_m)};
   PdfNormalsSet ss{reinterpret_cast<const double*>(d + L.off_S), reinterpret_cast<const uint8_t*>(d + L.off_ms),
                    reinterpret_cast<const uint8_t*>(d + L.off_msp), reinterpret_cast<uint8_t*>(d + L.off_mo_s),
@@ -845,11 +868,10 @@ int launch_preregistration(tsd_ctx* ctx, tsd_sensor* s, hipStream_t stream, cons
                        reinterpret_cast<const PdfHeader*>(d + L.off_hdr));
     hipLaunchKernelGGL(k_pdf_argmax, dim3(1), dim3(1024), 0, stream, reinterpret_cast<const double*>(d + L.off_prob),
                        reinterpret_cast<const PdfCandidate*>(d + L.off_K), 0, d_coords, reinterpret_cast<const double*>(d + L.off_S),
-                       reinterpret_cast<PdfResult*>(d + L.off_res), reinterpret_cast<const PdfHeader*>(d + L.off_hdr));
+                       reinterpret_cast<PdfResult*>(d + L.off_res), reinterpret_cast<const PdfHeader*>(d + L.off_hdr),
+                       reinterpret_cast<PdfHeader*>(h_dev + L.off_hdr), reinterpret_cast<PdfResult*>(h_dev + L.off_res));
   }
   TSD_HIP_CHECK(ctx, hipGetLastError());
-  // header + result back with the scan's own result (the copy completes before the registration kernel behind it starts)
-  TSD_HIP_CHECK(ctx, hipMemcpyAsync(s->h_pre + L.off_hdr, d + L.off_hdr, (L.off_res - L.off_hdr) + sizeof(PdfResult), hipMemcpyDeviceToHost, stream));
   *tinit_dev = reinterpret_cast<const double*>(d + L.off_res);
   return TSD_OK;
 }
