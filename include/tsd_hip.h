@@ -386,7 +386,9 @@ int tsd_push_stats_total(tsd_ctx* ctx, tsd_push_stats* total, int64_t* pushes, i
  * It then runs on the device between that scan's ray cast (whose hits are its model) and its registration (whose Tinit it becomes,
  * Icp.cpp:481-486): PCA normals of both point sets, extractSamples, pickControlSet, the trial picks and the candidate list in the
  * reference's serial order, scoring, arg-max -- nothing returns to the host in between.  scene_xy_2B / mask_s: what
- * Sensor::dataToCartesianVectorMask gives for the scan (beam-indexed); the draws as in tsd_tsdpdf_match.  One-shot. */
+ * Sensor::dataToCartesianVectorMask gives for the scan (beam-indexed); the draws as in tsd_tsdpdf_match.  One-shot.  The inputs are
+ * copied at the call (the caller's buffers are free on return) and travel to the device on the side stream right away; call it after the
+ * previous scan was collected (TSD_E_ARG otherwise). */
 int tsd_scan_preregister(tsd_sensor* s, const tsd_tsdpdf_params* params, const double* scene_xy_2B, const uint8_t* mask_s,
                          const int* draws_subsample, const int* draws_control, const int* draws_trials);
 /* the pre-registration's outcome for the scan collected last (TBest, probability, winning pair, counts) */
