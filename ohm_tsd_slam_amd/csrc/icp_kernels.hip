@@ -45,9 +45,13 @@ constexpr int ICP_RL = 2;                       // register slots every wave fil
 constexpr int ICP_PAD = 96;                     // wrapped copies of the model at both ends of its LDS array
 #ifndef TSD_ICP_REFRESH_A
 #define TSD_ICP_REFRESH_A 6
-#define TSD_ICP_REFRESH_B 12
+#define TSD_ICP_REFRESH_B 15
 #endif
 constexpr unsigned REFRESH_A = TSD_ICP_REFRESH_A, REFRESH_B = TSD_ICP_REFRESH_B;   // steps with a scheduled bound renewal
+#ifndef TSD_ICP_WEAK_MULT
+#define TSD_ICP_WEAK_MULT 36.0
+#endif
+constexpr double WEAK_MULT = TSD_ICP_WEAK_MULT;        // a scheduled renewal takes the bounds with less than sqrt(this) x slack in distance
 constexpr int IR_CNT = 32, IR_RMAX = 33, IR_CNT2 = 34, IR_TIE = 35;   // words of IcpLds::ired
 // -DTSD_ICP_ABLATE=<bits>: timing experiments that switch parts of a step off (the RESULTS are wrong; tools/icp_ablate.sh):
 //   1 no searches (a point that fails tier 0 is dropped)   2 no in-place window searches (everything through the work list)
@@ -769,9 +773,12 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
         bd[q] = pre ? d : __builtin_inf();
         keep[q] = pre & same & (d <= thr);
         // Bounds only ever decay, and a point whose slack runs out costs a work-list pass however few such
-        // points there are in that step.  Two scheduled passes renew every bound with less than 2x slack
-        // in distance while the steps are still large, instead of a trickle of passes later.
-        const bool weak = refresh & pre & known & !drop & (lb2 < 4.0 * d);
+        // points there are in that step.  Two scheduled passes (steps 6 and 15) renew every bound with less than
+        // 6x slack in distance instead of a trickle of passes later.  (Round 3, tools/icp_stamps_slam.sh: with 2x
+        // slack and steps 6 / 12, 13-15 of the last 17 steps still had 1-60 searching points -- good pairs at 3 m
+        // range whose 2x slack of a few millimetres the scene's remaining motion eats; 6x at steps 6 / 15:
+        // 0.161 -> 0.157 ms per registration in the same session, a third renewal buys nothing.)
+        const bool weak = refresh & pre & known & !drop & (lb2 < WEAK_MULT * d);
         need[q] = (pre & !same & !drop) | weak;
         if constexpr ((ABL & 1) != 0) need[q] = false;
         keep[q] = keep[q] & !need[q];
