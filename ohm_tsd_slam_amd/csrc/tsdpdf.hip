@@ -35,7 +35,11 @@
 
 namespace tsd {
 
-struct PdfCandidate { int idx, i; double phi; };
+// a candidate (idx, i) of trial t: `ti` = t << 12 | i -- its place in the reference's serial order (trial-major, scene index ascending),
+// which is what the arg-max breaks ties on; the LIST order is free (k_pdf_prepare writes it in one pass, in whatever order its waves arrive)
+struct PdfCandidate { int idx, ti; double phi; };
+constexpr int PDF_I_BITS = 12, PDF_I_MASK = (1 << PDF_I_BITS) - 1;
+static_assert(TSD_MAX_BEAMS <= (1 << PDF_I_BITS), "scene index field of PdfCandidate::ti");
 struct PdfResult { double T[9]; double prob; int idx, i, candidates, pad; };
 // what k_pdf_prepare (the fused scan's device-side list building) leaves for the scoring and arg-max kernels, which the host then
 // launches without knowing the counts
@@ -63,7 +67,8 @@ k_pdf_score(GridDev g, const double* __restrict__ pose /* first two rows suffice
   const PdfCandidate cd = cand[c];
   // T = MatrixFactory::TransformationMatrix33(phi, 0, 0) + translation (TSD_PDFMatching.cpp:217-223)
   const double co = cos(cd.phi), si = sin(cd.phi);
-  const double sx = S[2 * cd.i], sy = S[2 * cd.i + 1];
+  const int ci = cd.ti & PDF_I_MASK;
+  const double sx = S[2 * ci], sy = S[2 * ci + 1];
   const double T02 = M[2 * cd.idx] - (co * sx + (-si) * sy);
   const double T12 = M[2 * cd.idx + 1] - (si * sx + co * sy);
   // TMap = TSensor * T (3 x 3 dgemm: k ascending from 0.0)
@@ -115,7 +120,7 @@ k_pdf_score(GridDev g, const double* __restrict__ pose /* first two rows suffice
   if (lane == 0) prob_out[c] = prob;
 }
 
-// first candidate (list order = the reference's serial trial / i order) that reaches the maximum; bestProb starts at
+// first candidate in the reference's serial trial / i order (the key `ti`) that reaches the maximum; bestProb starts at
 // 0.0 and is replaced on `>` only (TSD_PDFMatching.cpp:188,264)
 __global__ void __launch_bounds__(1024)
 k_pdf_argmax(const double* __restrict__ prob, const PdfCandidate* __restrict__ cand, int n_cand, const double* __restrict__ M,
@@ -124,20 +129,21 @@ k_pdf_argmax(const double* __restrict__ prob, const PdfCandidate* __restrict__ c
 {
   if (hdr) n_cand = hdr->identity ? 0 : hdr->n_cand;
   __shared__ double s_p[1024];
-  __shared__ int s_k[1024];
-  double bp = 0.0; int bk = -1;
-  for (int c = threadIdx.x; c < n_cand; c += 1024) {      // ascending c per thread: `>` keeps the earliest
+  __shared__ int s_k[1024], s_o[1024];                      // list position and serial-order key of the thread's best
+  double bp = 0.0; int bk = -1, bo = 0x7fffffff;
+  for (int c = threadIdx.x; c < n_cand; c += 1024) {
     const double p = prob[c];
-    if (p > bp) { bp = p; bk = c; }
+    const int o = cand[c].ti;
+    if (p > bp || (p == bp && p > 0.0 && o < bo)) { bp = p; bk = c; bo = o; }
   }
-  s_p[threadIdx.x] = bp; s_k[threadIdx.x] = bk;
+  s_p[threadIdx.x] = bp; s_k[threadIdx.x] = bk; s_o[threadIdx.x] = bo;
   __syncthreads();
   for (int h = 512; h > 0; h >>= 1) {
     if ((int)threadIdx.x < h) {
-      const double p2 = s_p[threadIdx.x + h]; const int k2 = s_k[threadIdx.x + h];
-      const double p1 = s_p[threadIdx.x]; const int k1 = s_k[threadIdx.x];
-      const bool take = k2 >= 0 && (p2 > p1 || (p2 == p1 && (k1 < 0 || k2 < k1)));
-      if (take) { s_p[threadIdx.x] = p2; s_k[threadIdx.x] = k2; }
+      const double p2 = s_p[threadIdx.x + h]; const int k2 = s_k[threadIdx.x + h], o2 = s_o[threadIdx.x + h];
+      const double p1 = s_p[threadIdx.x]; const int k1 = s_k[threadIdx.x], o1 = s_o[threadIdx.x];
+      const bool take = k2 >= 0 && (p2 > p1 || (p2 == p1 && (k1 < 0 || o2 < o1)));
+      if (take) { s_p[threadIdx.x] = p2; s_k[threadIdx.x] = k2; s_o[threadIdx.x] = o2; }
     }
     __syncthreads();
   }
@@ -149,11 +155,12 @@ k_pdf_argmax(const double* __restrict__ prob, const PdfCandidate* __restrict__ c
     if (k >= 0 && s_p[0] > 0.0) {
       const PdfCandidate cd = cand[k];
       const double co = cos(cd.phi), si = sin(cd.phi);
-      const double sx = S[2 * cd.i], sy = S[2 * cd.i + 1];
+      const int ci = cd.ti & PDF_I_MASK;
+      const double sx = S[2 * ci], sy = S[2 * ci + 1];
       r.T[0] = co; r.T[1] = -si; r.T[3] = si; r.T[4] = co;
       r.T[2] = M[2 * cd.idx] - (co * sx + (-si) * sy);
       r.T[5] = M[2 * cd.idx + 1] - (si * sx + co * sy);
-      r.prob = s_p[0]; r.idx = cd.idx; r.i = cd.i;
+      r.prob = s_p[0]; r.idx = cd.idx; r.i = ci;
     }
     *out = r;
     // fused scan: header and result go to the host from here (stores into pinned memory, complete when the kernel ends) -- a copy
@@ -284,8 +291,8 @@ k_pdf_normals(PdfNormalsSet set0, PdfNormalsSet set1, int points, int sr)
 // ---- the list building of TSD_PDFMatching::match on the device (fused scan: nothing returns to the host between the ray cast and the
 // registration).  ONE workgroup: extractSamples of both sets (index order), pickControlSet and the trial picks -- the reference erases
 // the picked element from a vector, i.e. picks the r-th REMAINING element in index order: a bitmap of the remaining positions and a
-// rank-select do the same -- then the candidates of every trial, counted, offset by a scan over the trials and written in the
-// reference's serial order (trial-major, scene index ascending).
+// rank-select do the same -- then the candidates of every trial in one pass over the window's part of the sampled scene list, each
+// carrying its place in the reference's serial order (trial-major, scene index ascending) as the key the arg-max breaks ties on.
 struct PdfPrepareArgs {
   const uint8_t* mask_m; const uint8_t* mask_s;       // after the normals (mMp, mSp)
   const double* phi_m; const double* phi_s;
@@ -325,21 +332,23 @@ k_pdf_prepare(PdfPrepareArgs p)
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
   double* s_phi_s = s_dyn;                                    // [n]
   double* s_pm = s_dyn + p.n;                                 // [trials] the picked model points' angles
-  __shared__ unsigned char s_mask_s[TSD_MAX_BEAMS];
-  __shared__ int s_wcnt[2][16], s_trial[PDF_MAX_TRIALS], s_cnt[PDF_MAX_TRIALS + 1];
+  __shared__ unsigned short s_rank[TSD_MAX_BEAMS];            // position in s_idx[0] of the first sampled scene point with index >= i
+  __shared__ int s_wcnt[2][16], s_trial[PDF_MAX_TRIALS];
   __shared__ int s_draw_c[PDF_MAX_CONTROL], s_draw_t[PDF_MAX_TRIALS];      // the draws (a global read per pick would be a round trip per pick)
   __shared__ unsigned short s_ctrl[PDF_MAX_CONTROL];                        // picked control points (scene indices)
   __shared__ unsigned short s_q[2][64 * 64 + 64];                                // per set and bitmap word: the picks that fell into it (k | rank << 10)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned long long lt = (1ull << lane) - 1ull;
 #ifdef TSD_PDF_STAMPS    // diagnostic build: where the kernel's time goes (thread 0, 100 MHz clock, printed)
-  long long st_[8]; int sn_ = 0;
+  long long st_[8]; int sn_ = 0; long long sx_[6] = {0, 0, 0, 0, 0, 0}; int sxn_ = 0;
 #define QSTAMP() do { if (tid == 0 && sn_ < 8) st_[sn_++] = wall_clock64(); } while (0)
+#define XSTAMP() do { if (tid == 0 && sxn_ < 6) sx_[sxn_++] = wall_clock64(); } while (0)
 #else
 #define QSTAMP() do {} while (0)
+#define XSTAMP() do {} while (0)
 #endif
   QSTAMP();
-  for (int i = tid; i < p.n; i += 1024) { s_phi_s[i] = p.phi_s[i]; s_mask_s[i] = p.mask_s[i]; }
+  for (int i = tid; i < p.n; i += 1024) s_phi_s[i] = p.phi_s[i];
   for (int i = tid; i < p.size_control_set && i < PDF_MAX_CONTROL; i += 1024) s_draw_c[i] = p.draws_control[i];
   for (int i = tid; i < p.trials_cfg && i < PDF_MAX_TRIALS; i += 1024) s_draw_t[i] = p.draws_trials[i];
   // extractSamples (RandomMatching.cpp:41-50) of both sets at once: i = sr .. n - sr - 1 with the mask set, in index order
@@ -357,6 +366,7 @@ k_pdf_prepare(PdfPrepareArgs p)
       if (w < wave) { offS += cs; offM += cm; }
       totS += cs; totM += cm;
     }
+    if (i < p.n) s_rank[i] = (unsigned short)(offS + __popcll(bs & lt));      // sampled scene points with an index below i
     if (fs) s_idx[0][offS + __popcll(bs & lt)] = (unsigned short)i;
     if (fm) s_idx[1][offM + __popcll(bm & lt)] = (unsigned short)i;
     nS += totS; nM += totM;
@@ -375,6 +385,7 @@ k_pdf_prepare(PdfPrepareArgs p)
   for (int k = tid; k < nC; k += 1024) s_draw_c[k] = (int)((unsigned)s_draw_c[k] % (unsigned)(nS - k));
   for (int k = tid; k < trials; k += 1024) s_draw_t[k] = (int)((unsigned)s_draw_t[k] % (unsigned)(nM - k));
   __syncthreads();
+  XSTAMP();
   if (wave < 2) {
     const int count = wave == 0 ? nS : nM, picks = wave == 0 ? nC : trials;
     const int* ranks = wave == 0 ? s_draw_c : s_draw_t;
@@ -389,6 +400,8 @@ k_pdf_prepare(PdfPrepareArgs p)
     const int c0 = nbits;
     int c = c0;                                                             // elements left in this lane's word ...
     int incl = wave_incl_scan(c);                                           // ... and in the words up to it: kept up to date per pick
+    int excl = incl - c, qn = 0;                                            // elements in the words before it; picks queued for this word
+    const int picks_u = __builtin_amdgcn_readfirstlane(picks);
     unsigned short* q = s_q[wave];
     // pass 1, serial over the picks but a handful of per-lane instructions each, no cross-lane traffic: the counts are monotone over
     // the lanes, so "the word that holds rank r" is the lane with excl <= r < incl, and the lanes behind it are those with incl > r.
@@ -399,21 +412,28 @@ k_pdf_prepare(PdfPrepareArgs p)
     int rk[RK];
 #pragma unroll
     for (int j = 0; j < RK; j++) rk[j] = (j * 64 + lane < picks) ? ranks[j * 64 + lane] : 0;
+    // (delivery HERE: left to the compiler, the wait for these LDS reads lands at the head of the pick loop -- which is also its back
+    // edge, so every pick would sit out the round trip of the previous pick's queue write: 160 cycles per pick instead of ~40)
+#pragma unroll
+    for (int j = 0; j < RK; j++) asm volatile("" : "+v"(rk[j]));
 #pragma unroll
     for (int j = 0; j < RK; j++) {
-      if (j * 64 >= picks) break;
-      const int lim = picks - j * 64 < 64 ? picks - j * 64 : 64;
-      for (int l = 0; l < lim; l++) {
+      if (j * 64 >= picks_u) break;
+      const int lim = picks_u - j * 64 < 64 ? picks_u - j * 64 : 64;
+      for (int l = 0; l < lim; l++) {      // (~140 cycles per pick, a lone wave's issue rate for these ~18 instructions: unrolling changes nothing)
         const int k = j * 64 + l;
         const int r = __builtin_amdgcn_readlane(rk[j], l);
-        // (branch-free: a lane that is not the word writes to a slot of its own beyond the queues)
-        const int excl = incl - c;
-        const bool behind = incl > r, mine = behind && excl <= r;
-        q[mine ? lane * 64 + (c0 - c) : 64 * 64 + lane] = (unsigned short)(k | ((r - excl) << 10));
-        c -= mine ? 1 : 0;
+        // (branch-free: a lane that is not the word writes to a slot of its own beyond the queues.  excl and incl are carried
+        // separately: each is one compare + one subtract per pick, and neither waits for the other)
+        const bool after = excl > r, behind = incl > r, mine = behind && !after;
+        q[mine ? lane * 64 + qn : 64 * 64 + lane] = (unsigned short)(k | ((r - excl) << 10));
+        qn += mine ? 1 : 0;
+        excl -= after ? 1 : 0;
         incl -= behind ? 1 : 0;
       }
     }
+    c = c0 - qn;
+    XSTAMP();
     // pass 2, every word on its own lane: its picks in order -- rank-select in the word as it stands, clear the bit, note the position
     unsigned short* out = wave == 0 ? s_ctrl : reinterpret_cast<unsigned short*>(s_trial);     // POSITIONS (translated below)
     const int nq = c0 - c;
@@ -427,8 +447,10 @@ k_pdf_prepare(PdfPrepareArgs p)
       if (hi) wh32 &= ~(1u << bit); else wl32 &= ~(1u << bit);
       out[e & 1023u] = (unsigned short)(lo + bit + (hi ? 32 : 0));
     }
+    XSTAMP();
   }
   __syncthreads();
+  XSTAMP();
   // positions -> scene / model indices, all at once (s_trial's picks were parked as 16-bit positions in its own storage: read all, then write)
   {
     int idx_t[(PDF_MAX_TRIALS + 1023) / 1024];
@@ -444,60 +466,51 @@ k_pdf_prepare(PdfPrepareArgs p)
   for (int k = tid; k < nC; k += 1024) { const int idx = s_ctrl[k]; p.control[k] = make_double2(p.S[2 * idx], p.S[2 * idx + 1]); }
   for (int t = tid; t < trials; t += 1024) s_pm[t] = p.phi_m[s_trial[t]];      // (one round trip for all trials, not one per trial)
   __syncthreads();
-  // ---- candidates (:200-215): count per trial, scan over the trials, write in the reference's serial order
+  // ---- candidates (:200-215) in ONE pass: wave w takes the trials w, w + 16, ...; the matches of a 64-beam round draw their list places
+  // from one LDS counter (one atomic per wave and round).  The list order is whatever order the waves arrive in; the reference's serial
+  // order lives in the key `ti` (PdfCandidate), which is all the arg-max needs.  (Round 3's first form counted per trial, scanned the
+  // counts and wrote in a second pass: 14 us of this kernel's 31.)
   const double PI_D = 3.14159265358979323846;
-  auto trial_pass = [&](bool write) {
-    for (int t = wave; t < trials; t += 16) {
-      const int idx = s_trial[t];
-      const int iMin = idx - p.span > p.sr ? idx - p.span : p.sr, iMax = idx + p.span < p.n - p.sr ? idx + p.span : p.n - p.sr;
-      const double pm = s_pm[t];
-      int cnt = 0;
-      for (int i0 = iMin; i0 < iMax; i0 += 64) {
-        const int i = i0 + lane;
-        bool ok = false; double phi = 0.0;
-        if (i < iMax && s_mask_s[i]) {
-          phi = pm - s_phi_s[i];
-          if (phi > PI_D) phi -= 2.0 * PI_D;
-          else if (phi < -PI_D) phi += 2.0 * PI_D;
-          ok = fabs(phi) < p.phi_max;
-        }
-        const unsigned long long b = __ballot(ok);
-        if (write && ok) {
-          const int at = s_cnt[t] + cnt + __popcll(b & lt);
-          if (at < p.max_cand) p.cand[at] = PdfCandidate{idx, i, phi};
-        }
-        cnt += __popcll(b);
-      }
-      if (!write && lane == 0) s_cnt[t] = cnt;
-    }
-    __syncthreads();
-  };
-  QSTAMP();
-  trial_pass(false);
-  QSTAMP();
-  if (wave == 0) {
-    // exclusive scan of the per-trial counts (<= 1024 of them: 16 rounds of one wave)
-    int run = 0;
-    for (int t0 = 0; t0 < trials; t0 += 64) {
-      const int t = t0 + lane;
-      const int c = t < trials ? s_cnt[t] : 0;
-      const int incl = wave_incl_scan(c);
-      if (t < trials) s_cnt[t] = run + incl - c;
-      run += __builtin_amdgcn_readlane(incl, 63);
-    }
-    if (lane == 0) s_cnt[trials] = run;
-  }
+  __shared__ int s_ncand;
+  if (tid == 0) s_ncand = 0;
   __syncthreads();
   QSTAMP();
-  trial_pass(true);
-  QSTAMP();
+  for (int t = wave; t < trials; t += 16) {
+    const int idx = s_trial[t];
+    const int iMin = idx - p.span > p.sr ? idx - p.span : p.sr, iMax = idx + p.span < p.n - p.sr ? idx + p.span : p.n - p.sr;
+    const double pm = s_pm[t];
+    // (the sampled scene points are a sixth of the beams: the window's part of their LIST, one 64-entry round per trial as a rule)
+    const int kLo = iMin < iMax ? (int)s_rank[iMin] : 0, kHi = iMin < iMax ? (int)s_rank[iMax] : 0;
+    for (int k0 = kLo; k0 < kHi; k0 += 64) {
+      const int k = k0 + lane;
+      const int i = k < kHi ? (int)s_idx[0][k] : 0;
+      bool ok = false; double phi = 0.0;
+      if (k < kHi) {
+        phi = pm - s_phi_s[i];
+        if (phi > PI_D) phi -= 2.0 * PI_D;
+        else if (phi < -PI_D) phi += 2.0 * PI_D;
+        ok = fabs(phi) < p.phi_max;
+      }
+      const unsigned long long b = __ballot(ok);
+      if (b) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&s_ncand, __popcll(b));
+        base = __builtin_amdgcn_readfirstlane(base);
+        const int at = base + __popcll(b & lt);
+        if (ok && at < p.max_cand) p.cand[at] = PdfCandidate{idx, (t << PDF_I_BITS) | i, phi};
+      }
+    }
+  }
+  __syncthreads();
+  QSTAMP(); QSTAMP(); QSTAMP();
 #ifdef TSD_PDF_STAMPS
+  if (tid == 0) printf("   picks in detail (x10 ns): ranks + barrier %lld | pass 1 %lld | pass 2 %lld | wait for the other wave %lld\n", sx_[0] - st_[1], sx_[1] - sx_[0], sx_[2] - sx_[1], sx_[3] - sx_[2]);
   if (tid == 0) printf("k_pdf_prepare (x10 ns): lists %lld | picks %lld | control + angles %lld | count pass %lld | scan %lld | write pass %lld  (nS %d nM %d nC %d trials %d)\n",
                        st_[1] - st_[0], st_[2] - st_[1], st_[3] - st_[2], st_[4] - st_[3], st_[5] - st_[4], st_[6] - st_[5], nS, nM, nC, trials);
 #endif
   if (tid == 0) {
     PdfHeader h;
-    h.n_cand = s_cnt[trials] < p.max_cand ? s_cnt[trials] : p.max_cand; h.n_control = nC; h.n_model_valid = nM; h.n_scene_valid = nS;
+    h.n_cand = s_ncand < p.max_cand ? s_ncand : p.max_cand; h.n_control = nC; h.n_model_valid = nM; h.n_scene_valid = nS;
     h.identity = identity ? 1 : 0; h.pad[0] = h.pad[1] = h.pad[2] = 0;
     *p.hdr = h;
   }
@@ -708,7 +721,7 @@ extern "C" int tsd_tsdpdf_match(tsd_ctx* ctx, const double pose33[9], const doub
         double phi = phiM[idx] - phiS[i];
         if (phi > M_PI) phi -= 2.0 * M_PI;
         else if (phi < -M_PI) phi += 2.0 * M_PI;
-        if (std::fabs(phi) < phi_max) cand.push_back(PdfCandidate{idx, i, phi});
+        if (std::fabs(phi) < phi_max) cand.push_back(PdfCandidate{idx, (int)(((unsigned)trial << PDF_I_BITS) | (unsigned)i), phi});
       }
     }
   }
