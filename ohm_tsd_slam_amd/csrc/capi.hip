@@ -43,7 +43,9 @@ static hipEvent_t pool_get(tsd_ctx* ctx)
 {
   if (!ctx->event_pool.empty()) { hipEvent_t e = ctx->event_pool.back(); ctx->event_pool.pop_back(); return e; }
   hipEvent_t e = nullptr;
-  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  // (timing only: no system-scope fence when the event completes -- the default makes every sampled kernel write its dirty lines back
+  // to memory before the next one starts)
+  if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) return nullptr;
   return e;
 }
 
