@@ -247,7 +247,8 @@ constexpr int CNT_WORDS = CNT_TICKET + TICKET_HEADS * TICKET_STRIDE;
 // fetched as ONE vector register per wave -- lane i holds word i -- and unpacked with v_readlane.
 struct PushListAuxBody {
   uint32_t entry, win;           // the list word (tile | flags | kind << 28); beams the tile's cells can project to: lo | hi << 16
-  double pw;                     // partition weight (TsdGrid.cpp:239-243)
+  double pw;                     // 0.01 * partition weight (TsdGrid.cpp:239-243; TsdGridPartition.h:193-196: w = 0.01, then w *= the weight):
+                                 // the product is formed where the weight is, so that the update kernel needs no vector-register constant
   // phase A of k_push_update (fp32 beam estimate), all relative to the tile's centroid c = ((x0 + 16.5) cs, (y0 + 16.5) cs) -- the
   // centre of cell (ix, iy) is c + (ix - 16, iy - 16) cs -- with l_c = PoseInv (c, 1) and M = PoseInv's rotation * cs:
   float A, B;                    // l_c x (M d) = dx A + dy B   (d = cell offset in cells)
@@ -468,7 +469,7 @@ k_push_classify(GridDev g, const PushArgs* __restrict__ a_dev, const char* __res
       const unsigned int slot = base_u + (unsigned)__popcll(ub & lt);
       list[slot] = word;
       PushListAuxBody x;
-      x.entry = word; x.win = win; x.pw = pw;
+      x.entry = word; x.win = win; x.pw = 0.01 * pw;
       // the linear forms of k_push_update's phase A (see PushListAux): fp64 here, once per tile, instead of fp32 in every lane there
       const double lcx = a.Pi[0] * tcx + a.Pi[1] * tcy + a.Pi[2], lcy = a.Pi[3] * tcx + a.Pi[4] * tcy + a.Pi[5];
       const double axx = a.Pi[0] * g.cs, axy = a.Pi[1] * g.cs, ayx = a.Pi[3] * g.cs, ayy = a.Pi[4] * g.cs;
@@ -998,13 +999,13 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
       // lanes has (a tile's last pass is rarely full)
       unsigned long long wrote_neg = 0ull;
       unsigned n_upd = 0u;                                  // cells this WAVE updated (a scalar: population counts of the lane masks)
-      const double w_meas = 0.01 * tcur.pw;                 // (TsdGridPartition.h:193-196: w = 0.01, then w *= partition weight)
+      const double w_meas = tcur.pw;                        // 0.01 * partition weight (TsdGridPartition.h:193-196), from the tile's record
       for (unsigned q0 = (unsigned)tid; q0 < n_tot; q0 += UPD_CB * UPDATE_BLOCK) {
         uint32_t ce[UPD_CB]; double tv[UPD_CB], wv[UPD_CB];
 #pragma unroll
         for (int j = 0; j < UPD_CB; j++) {
           const unsigned q = q0 + (unsigned)(j * UPDATE_BLOCK);
-          ce[j] = q < n_tot ? cand_list[q < n_cand ? q : (unsigned)(UPD_CAND_MAX - 1) - (q - n_cand)] : 0xFFFFFFFFu;
+          ce[j] = q < n_tot ? cand_list[q < n_cand ? q : ((unsigned)(UPD_CAND_MAX - 1) + n_cand) - q] : 0xFFFFFFFFu;
           tv[j] = t_init; wv[j] = tcur.iw;
 #if defined(TSD_ABLATE) && (TSD_ABLATE & 16)     // ablation: the cell reads hit the first line of the tile (what hiding their latency could buy at most)
           if (ce[j] != 0xFFFFFFFFu && !tcur.fresh) { tv[j] = ld_tsd(tcur.T + (ce[j] & 7u)); wv[j] = ld_w(tcur.W + (ce[j] & 7u)); }
@@ -1059,7 +1060,13 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
         const double2 e = s_edge[l == TILE_DIM ? 0 : l];                // (cell (0, 0) heads both the column and the row)
         const double2 e0 = s_edge[0];
         const unsigned nf = xc.flag >> 1;                                // bits 0 / 1 / 2: left / lower / diagonal neighbour held data before this push
-        s_edge[l] = make_double2(0.0, __builtin_nan(""));               // (this wave's reads above precede this write: in order)
+        {
+          // (the "unchanged" marker is built HERE from a scalar the compiler cannot hoist: as a loop invariant it was kept in four
+          // vector registers, spilled, and reloaded from scratch memory once per tile)
+          unsigned nan_hi = 0x7ff80000u;
+          asm volatile("" : "+s"(nan_hi));
+          s_edge[l] = make_double2(0.0, __hiloint2double((int)nan_hi, 0));      // (this wave's reads above precede this write: in order)
+        }
         const bool f = !isnan(e.y), f0 = !isnan(e0.y);
         const size_t PXs = (size_t)g.PX;
         if (l < TILE_DIM) {
