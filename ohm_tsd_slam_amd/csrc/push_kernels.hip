@@ -988,7 +988,7 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
           const int il = min(max(index, wlo), whi);
           float lm = s_lim[il];
           asm volatile("" : "+v"(lm));
-          if (__builtin_expect(il != index, 0)) lm = beam_limit(ranges[index], (unsigned)mask[index], ta.mt, ta.low2);
+          if (__builtin_expect(il != index, 0)) { lm = beam_limit(ranges[index], (unsigned)mask[index], ta.mt, ta.low2); asm volatile("" : "+v"(lm)); }
           cand = !((float)l2 > lm * 1.00001f);         // (|l|^2 from the fp64 vector here: within 1e-7 of phase A's fp32 form; the margin covers it)
         }
         if (tcur.fresh && !cand) st_cell(tcur.T, tcur.W, c, t_init, tcur.iw);
@@ -1024,8 +1024,19 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
           double r = s_ranges[il];
           const double dx2 = d2x[c & 31], dy2 = d2x[TILE_DIM + (c >> 5)];
           asm volatile("" : "+v"(r));
-          if (__builtin_expect(il != index, 0)) r = ranges[index];
+          // (a beam outside the staged window -- rounding at the window's ends, rare: read AND delivered inside the branch.  Left to the
+          // compiler, the wait for this read sits behind the branch, on every pass, as s_waitcnt vmcnt(0) -- which is also a wait for
+          // the previous cell's stores)
+          if (__builtin_expect(il != index, 0)) { r = ranges[index]; asm volatile("" : "+v"(r)); }
           const double dist = sqrt_normal(dx2 + dy2);                // (ccx - trx)^2 + (ccy - try)^2, then the IEEE root
+          // Every cell read of the pass is taken delivery of HERE -- behind the first root, ahead of the first store.  The cells'
+          // values are consumed inside branches, so left to the compiler each later use (and each reuse of their registers) is
+          // guarded by s_waitcnt vmcnt(0), which on this hardware is also a wait for the stores issued in between: the second
+          // cell of a pass then sits out the first cell's store round trip.
+          if (j == 0) {
+#pragma unroll
+            for (int jj = 0; jj < UPD_CB; jj++) asm volatile("" : "+v"(tv[jj]), "+v"(wv[jj]));
+          }
           double sd = 0.0; bool ok = false;
           if (!isinf(r)) { sd = r - dist; ok = true; }
           else if (dist < a.low_refl) { sd = max_trunc; ok = true; }
