@@ -53,18 +53,37 @@ constexpr int PDF_BATCH = 4;               // look-ups per LANE in flight togeth
 // the factors meet in LDS and are multiplied IN THE REFERENCE'S ORDER (s = 0 .. C-1: the winner is an arg-max over floating-point
 // products) by every lane alike.  (Rounds 2-3 ran one LANE per candidate: 1 300 candidates = 20 waves, each a chain of C / 8 memory
 // round trips -- 164 us for 180 k look-ups.)
-constexpr int PDF_WAVES = 4;               // candidates per workgroup
+constexpr int PDF_WAVES = 4;               // candidates per workgroup and round
+constexpr int PDF_SCORE_GRID = 1024;       // workgroups of the fused scan's scoring launch (4 096 waves stride over the candidates)
 __global__ void __launch_bounds__(64 * PDF_WAVES)
 k_pdf_score(GridDev g, const double* __restrict__ pose /* first two rows suffice */, const double* __restrict__ M, const double* __restrict__ S,
             const double2* __restrict__ control, int n_control, const PdfCandidate* __restrict__ cand, int n_cand,
-            double zrand, double* __restrict__ prob_out, const PdfHeader* __restrict__ hdr /* counts from the device, or nullptr */)
+            double zrand, double* __restrict__ prob_out, const PdfHeader* __restrict__ hdr /* counts from the device, or nullptr */,
+            int max_cand_alloc, int control_alloc /* entries the two arrays are allocated to (speculative reads) */)
 {
   __shared__ double s_f[PDF_WAVES][PDF_MAX_CONTROL];
-  if (hdr) { n_cand = hdr->identity ? 0 : hdr->n_cand; n_control = hdr->n_control; }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c = blockIdx.x * PDF_WAVES + wave;
-  if (c >= n_cand) return;                                   // (whole waves: no barrier below)
-  const PdfCandidate cd = cand[c];
+  // The header in one go; a fixed grid whose waves stride over the candidates (the fused scan does not know their number on the host:
+  // launching one wave for each of the max_cand possible ones -- 24 000 for 1 300 real ones -- cost more than the scoring); then the
+  // candidate and the first batch of control points together; the scene / model points follow the candidate, the look-ups the control
+  // points.  As written first -- header field by field, then the candidate, then per batch control point -> wait -> look-ups -- the
+  // kernel was a chain of ten memory round trips for 140 control points.
+  if (hdr) {
+    const int4 h0 = reinterpret_cast<const int4*>(hdr)[0];        // n_cand, n_control, n_model_valid, n_scene_valid
+    const int ident = hdr->identity;
+    n_cand = ident ? 0 : h0.x; n_control = h0.y;
+  }
+  for (int c = blockIdx.x * PDF_WAVES + wave; c < n_cand; c += (int)gridDim.x * PDF_WAVES) {       // (whole waves: no barrier below)
+  const int c_rd = c < max_cand_alloc ? c : 0;
+  const int idx_rd = ld_pinned(&cand[c_rd].idx), ti_rd = ld_pinned(&cand[c_rd].ti);
+  const double phi_rd = ld_pinned(&cand[c_rd].phi);
+  double cpx[PDF_BATCH], cpy[PDF_BATCH];
+#pragma unroll
+  for (int b = 0; b < PDF_BATCH; b++) {
+    const int s = 64 * b + lane, sc = s < control_alloc ? s : 0;
+    cpx[b] = ld_pinned(&control[sc].x); cpy[b] = ld_pinned(&control[sc].y);
+  }
+  PdfCandidate cd; cd.idx = idx_rd; cd.ti = ti_rd; cd.phi = phi_rd;
   // T = MatrixFactory::TransformationMatrix33(phi, 0, 0) + translation (TSD_PDFMatching.cpp:217-223)
   const double co = cos(cd.phi), si = sin(cd.phi);
   const int ci = cd.ti & PDF_I_MASK;
@@ -85,12 +104,18 @@ k_pdf_score(GridDev g, const double* __restrict__ pose /* first two rows suffice
   for (int s0 = 0; s0 < n_control; s0 += 64 * PDF_BATCH) {
     // up to PDF_BATCH look-ups per lane, all their reads in flight together
     uint8_t fl[PDF_BATCH]; Quad qv[PDF_BATCH]; double wx[PDF_BATCH], wy[PDF_BATCH]; bool inside[PDF_BATCH];
+    if (s0 > 0) {                                             // (more than 64 * PDF_BATCH control points: the next batch, again ahead of its look-ups)
+#pragma unroll
+      for (int b = 0; b < PDF_BATCH; b++) {
+        const int s = s0 + 64 * b + lane, sc = s < n_control ? s : 0;
+        cpx[b] = ld_pinned(&control[sc].x); cpy[b] = ld_pinned(&control[sc].y);
+      }
+    }
 #pragma unroll
     for (int b = 0; b < PDF_BATCH; b++) {
-      const int s = s0 + 64 * b + lane;
       fl[b] = 0; inside[b] = false; wx[b] = 0.0; wy[b] = 0.0; qv[b].t00 = qv[b].t01 = qv[b].t10 = qv[b].t11 = 0.0;
       if (s0 + 64 * b >= n_control) continue;                // (wave-uniform)
-      const double2 cp = control[s < n_control ? s : 0];
+      const double2 cp = make_double2(cpx[b], cpy[b]);
       // STemp = TMap * Control, Control column = (x, y, 1)
       double cx = 0.0, cy = 0.0;
       cx += TM[0] * cp.x; cx += TM[1] * cp.y; cx += TM[2] * 1.0;
@@ -118,6 +143,7 @@ k_pdf_score(GridDev g, const double* __restrict__ pose /* first two rows suffice
   double prob = 1.0;
   for (int s = 0; s < n_control; s++) prob *= s_f[wave][s];        // the reference's order
   if (lane == 0) prob_out[c] = prob;
+  }
 }
 
 // first candidate in the reference's serial trial / i order (the key `ti`) that reaches the maximum; bestProb starts at
@@ -208,19 +234,32 @@ k_pdf_normals(PdfNormalsSet set0, PdfNormalsSet set1, int points, int sr)
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= points) return;
   const double NO_PHI = -1e6;                                 // calcPhi's value for a masked-out point (RandomMatching.cpp:155-174)
+  // Everything the thread reads is requested HERE, unconditionally, on clamped indices (pinned reads: the optimiser cannot sink them
+  // into the conditions below): its two masks, the masks and coordinates of the ten neighbour slots -- ONE memory round trip.  As
+  // written first (a read per condition, coordinates only behind a set mask) the kernel was a chain of thirteen: 13 us for 2 x 1 081
+  // points.
+  constexpr int NB = 10;
+  const uint8_t m_in = ld_pinned(&st.mask_in[i]), m_io = ld_pinned(&st.mask_io_init[i]);
+  uint8_t mq[NB]; double ax_[NB], ay_[NB]; bool v_[NB];
+#pragma unroll
+  for (int j = 0; j < NB; j++) {
+    int q = i + j - NB / 2;
+    q = q < 0 ? 0 : (q >= points ? points - 1 : q);
+    mq[j] = ld_pinned(&st.mask_in[q]);
+    ax_[j] = ld_pinned(&st.xy[2 * q]); ay_[j] = ld_pinned(&st.xy[2 * q + 1]);
+  }
   if (i < sr || i >= points - sr) { st.mask_io[i] = 0; st.phi[i] = NO_PHI; return; }
-  if (!st.mask_in[i] || !st.mask_io_init[i]) { st.mask_io[i] = 0; st.phi[i] = NO_PHI; return; }   // (mask_io <= mask_in on entry)
+  if (!m_in || !m_io) { st.mask_io[i] = 0; st.phi[i] = NO_PHI; return; }   // (mask_io <= mask_in on entry)
   st.mask_io[i] = 1;
   // the <= 10 neighbours stay in their slots j = -5 .. 4 (registers, every loop unrolled over the ten slots and skipping the
   // masked-out ones in order): the same sequence of operations as over the compacted list, without an indexed private array
-  constexpr int NB = 10;
-  double ax_[NB], ay_[NB]; bool v_[NB];
+  // (sr <= i < points - sr here, so no slot inside the search radius was clamped)
+  const double own_x = ax_[NB / 2], own_y = ay_[NB / 2];
   int cnt = 0;
 #pragma unroll
   for (int j = 0; j < NB; j++) {
-    const int q = i + j - NB / 2;
-    v_[j] = (j - NB / 2 >= -sr) && (j - NB / 2 < sr) && st.mask_in[q] != 0;
-    ax_[j] = v_[j] ? st.xy[2 * q] : 0.0; ay_[j] = v_[j] ? st.xy[2 * q + 1] : 0.0;
+    v_[j] = (j - NB / 2 >= -sr) && (j - NB / 2 < sr) && mq[j] != 0;
+    if (!v_[j]) { ax_[j] = 0.0; ay_[j] = 0.0; }
     cnt += v_[j] ? 1 : 0;
   }
   if (cnt <= 3) { st.mask_io[i] = 0; st.phi[i] = NO_PHI; return; }
@@ -283,7 +322,7 @@ k_pdf_normals(PdfNormalsSet set0, PdfNormalsSet set1, int points, int sr)
   if (lenShortSqr > 1e-6 && (lenLongSqr / lenShortSqr) < 4.0) { st.mask_io[i] = 0; st.phi[i] = NO_PHI; return; }
   const double len = sqrt(lenShortSqr);
   double nx, ny;
-  if ((st.xy[2 * i] * xShort + st.xy[2 * i + 1] * yShort) < 0.0) { nx = xShort / len; ny = yShort / len; }
+  if ((own_x * xShort + own_y * yShort) < 0.0) { nx = xShort / len; ny = yShort / len; }
   else { nx = -xShort / len; ny = -yShort / len; }
   st.phi[i] = atan2(ny, nx);
 }
@@ -743,7 +782,7 @@ extern "C" int tsd_tsdpdf_match(tsd_ctx* ctx, const double pose33[9], const doub
     hipLaunchKernelGGL(k_pdf_score, dim3((nc + PDF_WAVES - 1) / PDF_WAVES), dim3(64 * PDF_WAVES), 0, ctx->stream, ctx->grid, reinterpret_cast<const double*>(d + off_P),
                        reinterpret_cast<const double*>(d), reinterpret_cast<const double*>(d + off_S),
                        reinterpret_cast<const double2*>(d + off_C), nC, reinterpret_cast<const PdfCandidate*>(d + off_K), nc,
-                       prm->zrand, reinterpret_cast<double*>(d + off_prob), nullptr);
+                       prm->zrand, reinterpret_cast<double*>(d + off_prob), nullptr, nc, nC > 0 ? nC : 1);
     hipLaunchKernelGGL(k_pdf_argmax, dim3(1), dim3(1024), 0, ctx->stream, reinterpret_cast<const double*>(d + off_prob),
                        reinterpret_cast<const PdfCandidate*>(d + off_K), nc, reinterpret_cast<const double*>(d),
                        reinterpret_cast<const double*>(d + off_S), reinterpret_cast<PdfResult*>(d + off_res), nullptr, nullptr, nullptr);
@@ -875,10 +914,10 @@ int launch_preregistration(tsd_ctx* ctx, tsd_sensor* s, hipStream_t stream, cons
     ScopedKernelTimer t(ctx, "tsdpdf", true);
     hipLaunchKernelGGL(k_pdf_normals, dim3((n + 255) / 256, 2), dim3(256), 0, stream, sm, ss, n, SR);
     hipLaunchKernelGGL(k_pdf_prepare, dim3(1), dim3(1024), prep_lds, stream, pa);
-    hipLaunchKernelGGL(k_pdf_score, dim3((L.max_cand + PDF_WAVES - 1) / PDF_WAVES), dim3(64 * PDF_WAVES), 0, stream, ctx->grid, d_pose6,
+    hipLaunchKernelGGL(k_pdf_score, dim3(std::min((L.max_cand + PDF_WAVES - 1) / PDF_WAVES, PDF_SCORE_GRID)), dim3(64 * PDF_WAVES), 0, stream, ctx->grid, d_pose6,
                        d_coords, reinterpret_cast<const double*>(d + L.off_S), reinterpret_cast<const double2*>(d + L.off_C), 0,
                        reinterpret_cast<const PdfCandidate*>(d + L.off_K), 0, L.zrand, reinterpret_cast<double*>(d + L.off_prob),
-                       reinterpret_cast<const PdfHeader*>(d + L.off_hdr));
+                       reinterpret_cast<const PdfHeader*>(d + L.off_hdr), L.max_cand, std::max(L.size_control_set, 1));
     hipLaunchKernelGGL(k_pdf_argmax, dim3(1), dim3(1024), 0, stream, reinterpret_cast<const double*>(d + L.off_prob),
                        reinterpret_cast<const PdfCandidate*>(d + L.off_K), 0, d_coords, reinterpret_cast<const double*>(d + L.off_S),
                        reinterpret_cast<PdfResult*>(d + L.off_res), reinterpret_cast<const PdfHeader*>(d + L.off_hdr),
