@@ -318,6 +318,14 @@ raycast_beam(const GridDev& g, const RaycastArgs& a_val, const RaycastArgs* __re
       if (xb > g.N - 1) xb = g.N - 1;
       if (yb > g.N - 1) yb = g.N - 1;
       const int txa = xa >> 5, txb = xb >> 5, tya = ya >> 5, tyb = yb >> 5;   // at most 2 x 2 tiles (RC_BLK + 2 <= 32)
+      // the (up to) four tiles' masks are requested TOGETHER, whether the box reaches into a second column / row of tiles or not (then
+      // the same word again): read one at a time behind its condition, a box over 2 x 2 tiles was four memory round trips in a row --
+      // and the slowest beam is the kernel's duration
+      unsigned long long nm[2][2];
+#pragma unroll
+      for (int iy = 0; iy < 2; iy++)
+#pragma unroll
+        for (int ix = 0; ix < 2; ix++) nm[iy][ix] = ld_pinned(&g.negmask[(iy ? tyb : tya) * PX + (ix ? txb : txa)]);
       bool any = false;
 #pragma unroll
       for (int iy = 0; iy < 2; iy++) {
@@ -329,7 +337,7 @@ raycast_beam(const GridDev& g, const RaycastArgs& a_val, const RaycastArgs* __re
           const int cx1 = (xb < tx * TILE_DIM + 31 ? xb : tx * TILE_DIM + 31) - tx * TILE_DIM;
           const int cy0 = (ya > ty * TILE_DIM ? ya : ty * TILE_DIM) - ty * TILE_DIM;
           const int cy1 = (yb < ty * TILE_DIM + 31 ? yb : ty * TILE_DIM + 31) - ty * TILE_DIM;
-          any |= (g.negmask[ty * PX + tx] & neg_rect(cx0 >> 2, cx1 >> 2, cy0 >> 2, cy1 >> 2)) != 0ull;
+          any |= (nm[iy][ix] & neg_rect(cx0 >> 2, cx1 >> 2, cy0 >> 2, cy1 >> 2)) != 0ull;
         }
       }
       return any;
