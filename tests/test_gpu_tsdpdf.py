@@ -57,7 +57,9 @@ def test_tsdpdf_match_matches_oracle(oracle, cfg, scene, ctrl, zrand, seed):
     assert d < 0.15 and a < 0.05, (d, a)
 
 
-@pytest.mark.parametrize("cfg,scene,ctrl,zrand,seed", [("cfg2", "pillars", 140, 0.25, 2), ("cfg1", "room", 360, 0.05, 7)])
+# (zrand = 1.0: every factor is exactly 1.0, every candidate ties -- the first in the reference's serial trial / i order has to win, in the
+# unfused call (list in serial order) and in the fused one (list in whatever order the waves arrived, the order carried as a key))
+@pytest.mark.parametrize("cfg,scene,ctrl,zrand,seed", [("cfg2", "pillars", 140, 0.25, 2), ("cfg1", "room", 360, 0.05, 7), ("cfg2", "pillars", 140, 1.0, 11)])
 def test_fused_preregistration_matches_the_unfused_calls(oracle, cfg, scene, ctrl, zrand, seed):
     """tsd_scan_preregister + tsd_scan (everything between the ray cast and the registration on the device: normals, sample lists,
     control set, trial picks, candidates, scoring, arg-max, Tinit handed over on the device) == tsd_tsdpdf_match on the ray cast's
