@@ -398,6 +398,7 @@ tsd_ctx* tsd_create(int device, int map_size_log2, double cell_size, double max_
   A(hipMalloc(&ctx->d_occ, (size_t)g.N * g.N));
   A(hipMalloc(&ctx->d_occ_count, sizeof(int)));
   A(hipMalloc(&ctx->d_occ_heads, occ_heads_bytes()));
+  A(hipMemsetAsync(ctx->d_occ_heads, 0, occ_heads_bytes(), ctx->stream));
   A(hipMalloc(&ctx->d_occ_list, (T + 32) * sizeof(uint32_t)));
   A(hipEventCreateWithFlags(&ctx->ev_grid, hipEventDisableTiming));
   if (!ok) { tsd_destroy(ctx); return nullptr; }

@@ -220,7 +220,8 @@ struct tsd_ctx {
   // occupancy
   int8_t* d_occ = nullptr;       // persistent map (ThreadGrid::_occGridContent)
   int* d_occ_count = nullptr;
-  unsigned int* d_occ_heads = nullptr;   // sharded counters + [tiles] work list of k_occ_mark (occupancy_kernels.hip)
+  unsigned int* d_occ_heads = nullptr;   // sharded counters (two sets, used in turn) of k_occ_mark's work list (occupancy_kernels.hip)
+  int occ_parity = 0;
   uint32_t* d_occ_list = nullptr;
 
 
