@@ -216,7 +216,7 @@ def main():
     ap.add_argument("--no-lookahead", action="store_true", help="do not announce the next scan to the localiser (no staging ahead)")
     ap.add_argument("--python-feeders", action="store_true", help="--robots: Python feeder threads instead of the native replay tsd_node_play")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-scans", type=int, default=10)
+    ap.add_argument("--cpu-scans", type=int, default=200, help="scans of the CPU baseline per thread count (bounded by --steps): ~8 s of CPU work at the default")
     ap.add_argument("--sample-every", type=int, default=0, help="time every n-th dispatch of each kernel (0 = auto)")
     ap.add_argument("--estimator", type=int, default=0, choices=[0, 1],
                     help="0: ClosedFormEstimator2D, what the node constructs (the bench line); 1: PointToLine2DEstimator")
