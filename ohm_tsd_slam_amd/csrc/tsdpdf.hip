@@ -831,6 +831,7 @@ extern "C" int tsd_scan_preregister(tsd_sensor* s, const tsd_tsdpdf_params* prm,
   const size_t total = L.off_res + al(sizeof(PdfResult));
   if (total > s->pre_bytes) {
     TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream2));      // (an armed, not yet submitted pre-registration's copy may still read the old buffer)
     if (s->d_pre) hipFree(s->d_pre);
     if (s->h_pre) hipHostFree(s->h_pre);
     s->d_pre = nullptr; s->h_pre = nullptr; s->pre_bytes = 0;
