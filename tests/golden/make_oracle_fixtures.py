@@ -140,6 +140,47 @@ def baseline_configs():
     np.savez_compressed(os.path.join(HERE, "oracle_baseline_configs.npz"), **out)
 
 
+def n1_n4():
+    """SURVEY 8(f) rows N1 and N4.  N1 on a grid of its own (256 x 256 cells = 8 x 8 tiles: the extraction skips the outer ring of
+    tiles, so the small grid of the push fixture shows nothing): the occupancy map after every push, plain and inflated (`content`
+    persists like ThreadGrid::_occGridContent), and the colour image of the final grid.  N4 on the model (with the ray cast's normals)
+    and scene of oracle_push_raycast_icp.npz (which must exist): the point-to-line registration."""
+    gc = synth.GridConfig(8, 0.1)
+    geo = synth.ScanGeometry.full_circle_360()
+    world = synth.World("room", gc)
+    g = O.Grid(gc.map_size_log2, gc.cell_size, gc.max_trunc)
+    content = {False: np.full(gc.cells * gc.cells, -1, dtype=np.int8), True: np.full(gc.cells * gc.cells, -1, dtype=np.int8)}
+    occ = {False: [], True: []}; marks = {False: [], True: []}
+    poses, scans = [], []
+    for k in range(4):
+        pose, (x, y, yaw) = H.sensor_pose(world, 4 * k)
+        r = world.scan(x, y, yaw, geo).copy()
+        data, mask = O.ingest_f32(r, H.MAX_RANGE, geo.angle_increment)
+        g.push(pose, data, mask, geo.angle_increment, geo.angle_min, H.MAX_RANGE, H.MIN_RANGE, H.LOW_REFL)
+        poses.append(pose); scans.append(r)
+        for inflate in (False, True):
+            o, n = g.occupancy(content[inflate], inflate, 2)
+            occ[inflate].append(np.array(o, dtype=np.int8).reshape(gc.cells, gc.cells).copy()); marks[inflate].append(n)
+    img = g.color_image()
+    g.close()
+    f = np.load(os.path.join(HERE, "oracle_push_raycast_icp.npz"))
+    g2 = O.Grid(int(f["map_size_log2"]), float(f["cell_size"]), float(f["max_trunc"]))
+    M, S = f["icp_model"], f["icp_scene"]
+    N = f["rc_normals"].reshape(-1, 2)[f["rc_mask"].astype(bool)]
+    ptl = O.icp(M, S, f["rc_pose"], 30, 0.4, 0.02, (0.0, g2.max_x, 0.0, g2.max_x), nn_mode=0, model_normals_xy=N)
+    g2.close()
+    np.savez_compressed(
+        os.path.join(HERE, "oracle_n1_n4.npz"),
+        map_size_log2=gc.map_size_log2, cell_size=gc.cell_size, max_trunc=gc.max_trunc,
+        beams=geo.beams, angle_min=geo.angle_min, angle_increment=geo.angle_increment,
+        push_poses=np.array(poses), push_scans=np.array(scans),
+        occ_plain=np.array(occ[False]), occ_inflated=np.array(occ[True]), marks_plain=np.array(marks[False]),
+        marks_inflated=np.array(marks[True]), color_image=np.asarray(img),
+        ptl_normals=N, ptl_T=ptl["T"], ptl_rms=ptl["rms"], ptl_pairs=ptl["pairs"], ptl_iterations=ptl["iterations"], ptl_state=ptl["state"])
+    print("oracle_n1_n4.npz", os.path.getsize(os.path.join(HERE, "oracle_n1_n4.npz")), "bytes; marks", marks[False], marks[True],
+          "ptl pairs", ptl["pairs"], "rms", ptl["rms"])
+
+
 def tsdpdf():
     """SURVEY 8(f) row N3: TSD_PDFMatching::match with fixed rand() draws on a small map, and Icp::iterate with its result as Tinit
     (registration_mode 3).  Inputs: the pushes that build the map, the pose the robot believes, the float32 scan; the three draw
@@ -185,9 +226,13 @@ if __name__ == "__main__":
         tsdpdf()
         print("oracle_tsdpdf.npz", os.path.getsize(os.path.join(HERE, "oracle_tsdpdf.npz")), "bytes")
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "n1n4":                   # (only the N1 / N4 fixture, on top of the committed push fixture)
+        n1_n4()
+        sys.exit(0)
     push_raycast_icp()
     trajectory()
     baseline_configs()
     tsdpdf()
-    for f in ("oracle_push_raycast_icp.npz", "oracle_trajectory.npz", "oracle_baseline_configs.npz", "oracle_tsdpdf.npz"):
+    n1_n4()
+    for f in ("oracle_push_raycast_icp.npz", "oracle_trajectory.npz", "oracle_baseline_configs.npz", "oracle_tsdpdf.npz", "oracle_n1_n4.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

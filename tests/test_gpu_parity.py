@@ -828,6 +828,36 @@ def test_golden_push_raycast_icp_fixture():
     assert (rf.pairs, rf.n_model, rf.n_scene) == (int(f["icp_pairs"]), len(f["icp_model"]), len(f["icp_scene"]))
 
 
+def test_golden_n1_n4_fixture():
+    """tests/golden/oracle_n1_n4.npz WITHOUT the oracle: occupancy maps (plain / inflated) after every push and the colour image
+    (row N1) byte for byte; the point-to-line registration (row N4) on the model / scene of the push fixture."""
+    import os
+    import ctypes as C
+    from ohm_tsd_slam_amd import facade
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    f = np.load(os.path.join(gold, "oracle_n1_n4.npz"))
+    res, phi = float(f["angle_increment"]), float(f["angle_min"])
+    HL = facade.load_library()
+    for inflate, key in ((False, "plain"), (True, "inflated")):
+        dg = capi.TsdGridDevice(int(f["map_size_log2"]), float(f["cell_size"]), float(f["max_trunc"]))
+        for k in range(len(f["push_poses"])):
+            r = np.ascontiguousarray(f["push_scans"][k], dtype=np.float32)
+            data = np.zeros(r.size); mask = np.zeros(r.size, dtype=np.uint8)
+            HL.tsd_host_sensor_ingest_f32(r.ctypes.data_as(C.POINTER(C.c_float)), r.size, res, phi, H.MAX_RANGE,
+                                          data.ctypes.data_as(C.POINTER(C.c_double)), mask.ctypes.data_as(C.POINTER(C.c_uint8)), 0)
+            dg.push(f["push_poses"][k], data, mask, res, phi, H.MAX_RANGE, H.MIN_RANGE, H.LOW_REFL, want_stats=False)
+            od, nd = dg.occupancy(inflate, 2)
+            assert nd == int(f["marks_" + key][k]) and np.array_equal(od, f["occ_" + key][k]), (key, k)
+        if not inflate:
+            assert np.array_equal(np.asarray(dg.color_image()), f["color_image"])
+    p = np.load(os.path.join(gold, "oracle_push_raycast_icp.npz"))
+    dg = capi.TsdGridDevice(int(p["map_size_log2"]), float(p["cell_size"]), float(p["max_trunc"]))
+    rd = dg.icp(p["icp_model"], p["icp_scene"], p["rc_pose"], dg.icp_params(30, 0.4, 0.02, estimator=1), model_normals_xy=f["ptl_normals"])
+    assert (rd.pairs, rd.iterations, rd.state) == (int(f["ptl_pairs"]), int(f["ptl_iterations"]), int(f["ptl_state"]))
+    d, a = H.pose_delta(f["ptl_T"], rd.T)
+    assert d <= 1e-9 and a <= 1e-9 and abs(rd.rms - float(f["ptl_rms"])) <= 1e-9
+
+
 def test_golden_trajectory_fixture():
     import os
     f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_trajectory.npz"))
