@@ -288,7 +288,9 @@ def main():
         ap.error("--mode push is a one-GPU workload")
     K, W = args.steps, args.warmup
     # (several robots: many more dispatches per step, and every sampled one costs the chain of dependent launches ~10 us)
-    every = args.sample_every or (32 if args.robots > 1 else (8 if K >= 80 else 4))
+    every = args.sample_every or (32 if args.robots > 1 else 8)
+    # the registration (the metric's second half, and its spread) keeps every fourth dispatch in a short run
+    every_icp = args.sample_every or (every if (K >= 80 or args.robots > 1) else 4)
     # the roofline kernel: every SECOND dispatch in a short run (the driver's 20 steps would otherwise leave five samples; every
     # dispatch was measured to cost the 20-step `value` 2.5 %: 4 800 against 4 920, 5 040 with a sixteenth of the dispatches sampled)
     every_upd = args.sample_every or (2 if (K < 50 and args.robots == 1) else every)
@@ -298,7 +300,7 @@ def main():
     if mode == "push":
         out = run_push(args, gc, geo, scene, K, W, every, every_upd, device, capi, synth)
     else:
-        out = run_slam(args, gc, geo, scene, K, W, every, every_upd, device, rank, local_rank, world_size, use_dist, dist, torch,
+        out = run_slam(args, gc, geo, scene, K, W, every, every_upd, every_icp, device, rank, local_rank, world_size, use_dist, dist, torch,
                        facade, multigpu, synth)
     rc = 0
     if rank == 0:
@@ -491,7 +493,7 @@ def run_push(args, gc, geo, scene, K, W, every, every_upd, device, capi, synth):
     return out
 
 
-def run_slam(args, gc, geo, scene, K, W, every, every_upd, device, rank, local_rank, world_size, use_dist, dist, torch, facade, multigpu, synth):
+def run_slam(args, gc, geo, scene, K, W, every, every_upd, every_icp, device, rank, local_rank, world_size, use_dist, dist, torch, facade, multigpu, synth):
     R = args.robots
     # robot r starts 0.7 m further along -x (launch/multi_slam.launch:40).  Ranks own one grid each (--gpus N);
     # --robots R puts R robots on this rank's ONE grid (the reference's own multi-robot mode)
@@ -582,7 +584,7 @@ def run_slam(args, gc, geo, scene, K, W, every, every_upd, device, rank, local_r
             merger.wait()
             warm_merge = merger.merge_times()    # (the warm-up merges -- RCCL's channel set-up -- are not what a merge costs)
         grid.push_stats_total(reset=True)
-        grid.profile(True, kernels=f"push_update:{every_upd},all/{every}")      # HIP events on every n-th dispatch of each kernel
+        grid.profile(True, kernels=f"push_update:{every_upd},icp:{every_icp},all/{every}")      # HIP events on every n-th dispatch of each kernel
         grid.profile_reset()
         if dist is not None and full:
             torch.cuda.synchronize()
@@ -674,7 +676,7 @@ def run_slam(args, gc, geo, scene, K, W, every, every_upd, device, rank, local_r
             "ms_raycast": stages["raycast"],
             "ms_push_kernels": sum(v for k, v in stages.items() if k.startswith("push") and v is not None),
             "stages_ms": stages, "stages_sum_ms_per_scan": stage_sum,
-            "stage_timing": f"HIP events on every {every}th dispatch of each kernel (k_push_update: every "
+            "stage_timing": f"HIP events on every {every}th dispatch of each kernel (k_icp: every {every_icp}th; k_push_update: every "
                             f"{'one' if every_upd == 1 else ('second' if every_upd == 2 else str(every_upd) + 'th')}), inside the timed region",
             "pushes_in_timed_region": pushes, "cells_updated_per_push": st["cells_updated"] / max(pushes, 1),
             "cells_visited_per_push": st["cells_visited"] / max(pushes, 1),
