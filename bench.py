@@ -232,7 +232,11 @@ def main():
                          "fixed tsdpdf_seed; stages_ms.tsdpdf = the scoring kernels")
     ap.add_argument("--no-stream", action="store_true", help="skip the stream-bandwidth measurement (roofline.peak_measured): profile passes, whose "
                                                             "calibration counts k_calib_rmw launches of ONE known size")
-    ap.add_argument("--no-second-pass", action="store_true", help="skip the --no-lookahead comparison pass (value_no_lookahead)")
+    ap.add_argument("--no-second-pass", action="store_true", help="skip the comparison passes (value_no_lookahead, value_async_mapping)")
+    ap.add_argument("--async-mapping", action="store_true",
+                    help="`value` with the facade's async_mapping = 1 (the push beside the next registration, the next ray cast one "
+                         "push behind: the reference's own ThreadMapping is asynchronous); default: strict order, and the "
+                         "asynchronous rate as value_async_mapping")
     ap.add_argument("--launch-check", action="store_true",
                     help="multi-rank plumbing only (no GPU work): the ranks rendezvous over gloo, sum their ranks, rank 0 prints "
                          "{launch_check, world_size}.  With --gpus N and no launcher this goes through the self-launch path.")
@@ -529,10 +533,10 @@ def run_slam(args, gc, geo, scene, K, W, every, every_upd, every_icp, device, ra
         params["registration_mode"] = args.registration_mode
         params["tsdpdf_seed"] = 20261003
 
-    def one_pass(lookahead: bool, full: bool):
+    def one_pass(lookahead: bool, full: bool, async_mapping: bool = False):
         """init + W warm-up scans + K timed scans on a fresh node; `full`: with the occupancy merge (N > 1), the stage table and
-        everything else the line reports; otherwise just the rate (the --no-lookahead comparison)."""
-        node = facade.SlamNode(params, device=device, synchronous=True)
+        everything else the line reports; otherwise just the rate (the comparison passes)."""
+        node = facade.SlamNode(dict(params, async_mapping=1) if async_mapping else params, device=device, synchronous=True)
         grid = node.grid()
         merger = None
         if use_dist and full:
@@ -691,11 +695,17 @@ def run_slam(args, gc, geo, scene, K, W, every, every_upd, every_icp, device, ra
         node.close()
         return out
 
-    out = one_pass(not args.no_lookahead, True)
+    out = one_pass(not args.no_lookahead, True, args.async_mapping and R == 1)
+    out["config"]["mapping"] = ("asynchronous: the push runs beside the next registration, the next ray cast is one push behind"
+                                if (args.async_mapping and R == 1) else "strict: the next ray cast sees this scan's push")
     if R == 1 and not use_dist and not args.no_lookahead and not args.no_second_pass:
         # the same K scans on a fresh node WITHOUT announcing the next scan: what a live 40 Hz scanner gets (it never has the
         # next LaserScan queued; the reference's localiser takes the newest scan, ThreadLocalize.cpp:319-332)
-        out["value_no_lookahead"] = one_pass(False, False)["value"]
+        out["value_no_lookahead"] = one_pass(False, False, args.async_mapping)["value"]
+        if not args.async_mapping:
+            # ... and with the mapper asynchronous like the reference's (ThreadMapping.cpp:51-76): a different, equally legitimate order
+            # of the same work (tests/test_gpu_async_mapping.py) -- reported beside `value`, never as it
+            out["value_async_mapping"] = one_pass(True, False, True)["value"]
     return out
 
 

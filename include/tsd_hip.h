@@ -391,6 +391,14 @@ int tsd_push_stats_total(tsd_ctx* ctx, tsd_push_stats* total, int64_t* pushes, i
  * previous scan was collected (TSD_E_ARG otherwise). */
 int tsd_scan_preregister(tsd_sensor* s, const tsd_tsdpdf_params* params, const double* scene_xy_2B, const uint8_t* mask_s,
                          const int* draws_subsample, const int* draws_control, const int* draws_trials);
+/* Asynchronous mapping for the fused scan of this sensor.  The reference's ThreadMapping is a thread of its own: queuePush returns at
+ * once and the push lands when the mapping thread gets to it (ThreadMapping.cpp:51-76), so the localiser's next ray cast may or may not
+ * see it.  on = 0 (default): strict order -- the next scan's ray cast sees this scan's push.  on = 1: the next scan's ray cast is taken
+ * right behind this scan's registration, on a grid WITHOUT this scan's push (exactly one push behind, every scan: one of the
+ * reference's interleavings, and a deterministic one), and the push runs beside the next registration on a stream of its own.  Every
+ * other entry point of the context is ordered behind a push still in flight there.  Not while a scan is in flight. */
+int tsd_sensor_set_async_mapping(tsd_sensor* s, int on);
+
 /* the pre-registration's outcome for the scan collected last (TBest, probability, winning pair, counts) */
 int tsd_scan_preregistration_result(tsd_sensor* s, tsd_tsdpdf_result* result);
 

@@ -171,6 +171,7 @@ ABI = {
                                    C.POINTER(TsdPdfResult)]),
     "tsd_scan_preregister": (C.c_int, [C.c_void_p, C.POINTER(TsdPdfParams), _dp, _u8p, _ip, _ip, _ip]),
     "tsd_scan_preregistration_result": (C.c_int, [C.c_void_p, C.POINTER(TsdPdfResult)]),
+    "tsd_sensor_set_async_mapping": (C.c_int, [C.c_void_p, C.c_int]),
     "tsd_color_image": (C.c_int, [C.c_void_p, _u8p, C.c_uint, C.c_uint]),
     "tsd_store_grid_text": (C.c_int, [C.c_void_p, C.c_char_p]),
     "tsd_load_grid_text": (C.c_int, [C.c_void_p, C.c_char_p]),
@@ -521,6 +522,10 @@ class TsdSensorDevice:
         rc = self.lib.tsd_scan_preregister(self.h, C.byref(prm), _d(S), _u8(mS), ds.ctypes.data_as(_ip), dc.ctypes.data_as(_ip),
                                            dt.ctypes.data_as(_ip))
         self.grid._check(rc, "tsd_scan_preregister")
+
+    def set_async_mapping(self, on=True):
+        """tsd_sensor_set_async_mapping: the fused scan's push beside the next registration (the next ray cast one push behind)."""
+        self.grid._check(self.lib.tsd_sensor_set_async_mapping(self.h, 1 if on else 0), "tsd_sensor_set_async_mapping")
 
     def preregistration_result(self) -> dict:
         r = TsdPdfResult()

@@ -301,6 +301,17 @@ static int wait_for_readers(tsd_ctx* ctx)
   return TSD_OK;
 }
 
+// Asynchronous mapping (tsd_sensor_set_async_mapping): the fused scan's push may still be running on the push stream.  Everything
+// else that goes to the context's stream -- every entry point but the fused scan's own -- is ordered behind it first.
+int drain_async_push(tsd_ctx* ctx)
+{
+  if (ctx->async_pending) {
+    TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_async_push, 0));
+    ctx->async_pending = false;
+  }
+  return TSD_OK;
+}
+
 }  // namespace tsd
 
 using namespace tsd;
@@ -446,6 +457,9 @@ void tsd_destroy(tsd_ctx* ctx)
   if (ctx->ev_h2d) hipEventDestroy(ctx->ev_h2d);
   if (ctx->ev_grid) hipEventDestroy(ctx->ev_grid);
   if (ctx->stream2) hipStreamDestroy(ctx->stream2);
+  if (ctx->stream_push) { hipStreamSynchronize(ctx->stream_push); hipStreamDestroy(ctx->stream_push); }
+  if (ctx->ev_async_rc) hipEventDestroy(ctx->ev_async_rc);
+  if (ctx->ev_async_push) hipEventDestroy(ctx->ev_async_push);
   for (hipEvent_t e : ctx->event_pool) hipEventDestroy(e);
   for (int s = 0; s < tsd_ctx::kSlots; s++) {
     if (ctx->h_stage[s]) hipHostFree(ctx->h_stage[s]);
@@ -466,6 +480,7 @@ int tsd_reset(tsd_ctx* ctx)
   if (ctx) ctx->epoch++;                  // (invalidates ray casts enqueued ahead of their scan)
   if (!ctx) return TSD_E_ARG;
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (int rcd_ = drain_async_push(ctx)) return rcd_;
   std::lock_guard<std::mutex> lk_order(ctx->order_mutex);
   if (int rcw = wait_for_readers(ctx)) return rcw;
   GridDev& g = ctx->grid;
@@ -498,6 +513,7 @@ int tsd_set_max_truncation(tsd_ctx* ctx, double val)
 int tsd_sync(tsd_ctx* ctx)
 {
   if (!ctx) return TSD_E_ARG;
+  if (int rcd_ = drain_async_push(ctx)) return rcd_;
   TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return TSD_OK;
 }
@@ -520,6 +536,7 @@ int tsd_free_footprint(tsd_ctx* ctx, const double center[2], double width, doubl
   if (ctx) ctx->epoch++;                  // (invalidates ray casts enqueued ahead of their scan)
   if (!ctx || !center) return TSD_E_ARG;
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (int rcd_ = drain_async_push(ctx)) return rcd_;
   const GridDev& g = ctx->grid;
   // TsdGrid.cpp:611-622
   const unsigned minX = static_cast<unsigned>((center[0] - width * 0.5) / g.cs + 0.5);
@@ -544,6 +561,7 @@ int tsd_push(tsd_ctx* ctx, const double pose33[9], const double* ranges, const u
   if (!ctx || !pose33 || !ranges || !mask) return TSD_E_ARG;
   if (beams < 1 || beams > TSD_MAX_BEAMS) return set_error(ctx, TSD_E_CAPACITY, "beams out of range", hipSuccess);
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (int rcd_ = drain_async_push(ctx)) return rcd_;
   PushArgs a;
   double Pi[9];
   mat3_inv(pose33, Pi);
@@ -587,6 +605,7 @@ int tsd_raycast(tsd_ctx* ctx, const double pose33[9], const double* rays_world_2
   if (!ctx || !pose33 || !rays_world_2xB || !coords_2B || !normals_2B || !mask_B) return TSD_E_ARG;
   if (beams < 1 || beams > TSD_MAX_BEAMS) return set_error(ctx, TSD_E_CAPACITY, "beams out of range", hipSuccess);
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (int rcd_ = drain_async_push(ctx)) return rcd_;
   RaycastArgs a;
   fill_raycast_args(ctx, a, pose33, beams, min_range, max_range);
   int s;
@@ -685,6 +704,7 @@ int tsd_icp_normals(tsd_ctx* ctx, const double* model_xy, const double* model_no
   if (n_model > TSD_MAX_ICP_POINTS || n_scene > TSD_MAX_ICP_POINTS)
     return set_error(ctx, TSD_E_CAPACITY, "icp points > TSD_MAX_ICP_POINTS", hipSuccess);
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (int rcd_ = drain_async_push(ctx)) return rcd_;
   IcpArgs a;
   fill_icp_args(a, pose33, params);
   a.n_model = n_model; a.n_scene = n_scene; a.beams = 0;
@@ -709,6 +729,7 @@ int tsd_icp_pairs(tsd_ctx* ctx, const double* model_xy, int n_model, const doubl
   if (n_model > TSD_MAX_ICP_POINTS || n_scene > TSD_MAX_ICP_POINTS)
     return set_error(ctx, TSD_E_CAPACITY, "icp points > TSD_MAX_ICP_POINTS", hipSuccess);
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (int rcd_ = drain_async_push(ctx)) return rcd_;
   IcpArgs a;
   fill_icp_args(a, pose33, params);        // (the threshold schedule comes from params->iterations, like the node's DistanceFilter)
   a.n_model = n_model; a.n_scene = n_scene; a.beams = 0;
@@ -757,6 +778,7 @@ int tsd_localize(tsd_ctx* ctx, const double pose33[9], const double* rays_world_
   if (beams < 1 || beams > TSD_MAX_BEAMS || beams > TSD_MAX_ICP_POINTS)
     return set_error(ctx, TSD_E_CAPACITY, "beams out of range for fused localize", hipSuccess);
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (int rcd_ = drain_async_push(ctx)) return rcd_;
   const size_t nb = (size_t)beams;
   int s;
   char* h = stage_acquire(ctx, &s);
@@ -795,6 +817,7 @@ int tsd_icp_trace(tsd_ctx* ctx, double* out, int max_iters)
 {
   if (!ctx || !out || max_iters < 0) return TSD_E_ARG;
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (int rcd_ = drain_async_push(ctx)) return rcd_;
   TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   const int n = max_iters < 2 * TSD_ICP_TRACE_MAX ? max_iters : 2 * TSD_ICP_TRACE_MAX;     // (rows beyond TSD_ICP_TRACE_MAX: diagnostic builds' scratch)
   TSD_HIP_CHECK(ctx, hipMemcpy(out, ctx->d_icp_trace, sizeof(double) * TSD_ICP_TRACE_STRIDE * (size_t)n, hipMemcpyDeviceToHost));
@@ -805,6 +828,7 @@ int tsd_download_tile_state(tsd_ctx* ctx, uint8_t* initialized, double* init_wei
 {
   if (!ctx || !initialized || !init_weight) return TSD_E_ARG;
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (int rcd_ = drain_async_push(ctx)) return rcd_;
   TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   const size_t T = (size_t)ctx->grid.tiles;
   TSD_HIP_CHECK(ctx, hipMemcpy(initialized, ctx->grid.flags, T, hipMemcpyDeviceToHost));
@@ -856,6 +880,7 @@ int tsd_upload_tiles(tsd_ctx* ctx, const uint8_t* initialized, const double* ini
   if (ctx) ctx->epoch++;                  // (invalidates ray casts enqueued ahead of their scan)
   if (!ctx || !initialized || !init_weight || !tsd_in || !weight_in) return TSD_E_ARG;
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (int rcd_ = drain_async_push(ctx)) return rcd_;
   std::lock_guard<std::mutex> lk_order(ctx->order_mutex);
   if (int rcw = wait_for_readers(ctx)) return rcw;
   TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -902,6 +927,7 @@ int tsd_grid_digest(tsd_ctx* ctx, tsd_grid_digest_t* out)
 {
   if (!ctx || !out) return TSD_E_ARG;
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (int rcd_ = drain_async_push(ctx)) return rcd_;
   const size_t T = (size_t)ctx->grid.tiles;
   unsigned long long* d_o = nullptr; double* d_s = nullptr;
   TSD_HIP_CHECK(ctx, hipMalloc(&d_o, T * 2 * sizeof(unsigned long long)));
@@ -1032,6 +1058,7 @@ int tsd_occupancy_dev_async(tsd_ctx* ctx, void* occ_dev, int inflate, int inflat
 {
   if (!ctx || !occ_dev) return TSD_E_ARG;
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (int rcd_ = drain_async_push(ctx)) return rcd_;
   return launch_occupancy(ctx, static_cast<int8_t*>(occ_dev), inflate, inflate_factor);
 }
 
@@ -1047,6 +1074,7 @@ int tsd_color_image(tsd_ctx* ctx, uint8_t* rgb_host, unsigned int width, unsigne
 {
   if (!ctx || !rgb_host || width == 0 || height == 0) return TSD_E_ARG;
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (int rcd_ = drain_async_push(ctx)) return rcd_;
   // px / py exactly as the reference accumulates them (TsdGrid.cpp:433-486): start at 0, += step per pixel
   std::vector<double> pq((size_t)width + height);
   const double stepW = ctx->grid.max_x / (double)width, stepH = ctx->grid.max_y / (double)height;
@@ -1071,6 +1099,7 @@ int tsd_occupancy(tsd_ctx* ctx, int8_t* occ_host, int inflate, int inflate_facto
 {
   if (!ctx || !occ_host) return TSD_E_ARG;
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (int rcd_ = drain_async_push(ctx)) return rcd_;
   const size_t cells = (size_t)ctx->grid.N * ctx->grid.N;
   int8_t* d_out = nullptr;
   TSD_HIP_CHECK(ctx, hipMalloc(&d_out, cells));
@@ -1091,6 +1120,7 @@ int tsd_calibrate_rmw(tsd_ctx* ctx, int64_t n_doubles, int reps)
 {
   if (!ctx || n_doubles <= 0 || reps <= 0) return TSD_E_ARG;
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (int rcd_ = drain_async_push(ctx)) return rcd_;
   double *t = nullptr, *w = nullptr;
   TSD_HIP_CHECK(ctx, hipMalloc(&t, (size_t)n_doubles * sizeof(double)));
   hipError_t e = hipMalloc(&w, (size_t)n_doubles * sizeof(double));
@@ -1108,6 +1138,7 @@ int tsd_measure_stream(tsd_ctx* ctx, int64_t n_doubles, int reps, double* gbs_be
 {
   if (!ctx || n_doubles <= 0 || reps <= 0 || reps > 64) return TSD_E_ARG;
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (int rcd_ = drain_async_push(ctx)) return rcd_;
   double *t = nullptr, *w = nullptr;
   const size_t bytes = (size_t)n_doubles * sizeof(double);
   TSD_HIP_CHECK(ctx, hipMalloc(&t, bytes));
@@ -1221,6 +1252,7 @@ int tsd_push_stats_total(tsd_ctx* ctx, tsd_push_stats* total, int64_t* pushes, i
 {
   if (!ctx) return TSD_E_ARG;
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (int rcd_ = drain_async_push(ctx)) return rcd_;
   return read_total_stats(ctx, total, pushes, reset != 0);
 }
 
@@ -1262,6 +1294,7 @@ void tsd_sensor_destroy(tsd_sensor* s)
   if (s->stream) hipStreamDestroy(s->stream);
   hipFree(s->d_coords); hipFree(s->d_normals); hipFree(s->d_mask_m); hipFree(s->d_icp_res); hipFree(s->d_icp_trace);
   if (s->ev_pre) hipEventDestroy(s->ev_pre);
+  if (s->d_push_slot) { if (s->ctx && s->ctx->stream_push) hipStreamSynchronize(s->ctx->stream_push); hipFree(s->d_push_slot); }
   if (s->d_pre) hipFree(s->d_pre);
   if (s->h_pre) hipHostFree(s->h_pre);
   hipFree(s->d_rmq2[0]); hipFree(s->d_rmq2[1]); hipFree(s->d_rmq2[2]);
@@ -1279,6 +1312,7 @@ int tsd_sensor_set_pose(tsd_sensor* s, const double pose33[9], const double* ray
   if (!s || !s->ctx || !pose33 || !rays_world_2xB || !rays_local_2xB) return TSD_E_ARG;
   tsd_ctx* ctx = s->ctx;
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (int rcd_ = drain_async_push(ctx)) return rcd_;
   const size_t nb = (size_t)s->beams;
   SensorDev st;
   std::memset(&st, 0, sizeof(st));
@@ -1360,6 +1394,27 @@ static int scan_stage_impl(tsd_sensor* s, const double* ranges, const uint8_t* m
   return TSD_OK;
 }
 
+int tsd_sensor_set_async_mapping(tsd_sensor* s, int on)
+{
+  if (!s || !s->ctx) return TSD_E_ARG;
+  tsd_ctx* ctx = s->ctx;
+  if (s->submitted) return set_error(ctx, TSD_E_ARG, "tsd_sensor_set_async_mapping: a scan is in flight", hipSuccess);
+  TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (int rcd_ = drain_async_push(ctx)) return rcd_;
+  if (on) {
+    if (!ctx->stream_push) TSD_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream_push, hipStreamNonBlocking));
+    // (both events order kernels of ONE device against each other: no system-scope fence when they complete)
+    if (!ctx->ev_async_rc) TSD_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_async_rc, hipEventDisableTiming | hipEventDisableSystemFence));
+    if (!ctx->ev_async_push) TSD_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_async_push, hipEventDisableTiming | hipEventDisableSystemFence));
+    if (!s->d_push_slot) TSD_HIP_CHECK(ctx, hipMalloc(&s->d_push_slot, 2 * sizeof(tsd::PushArgs)));
+  }
+  s->async_mapping = on != 0;
+  // a ray cast enqueued ahead by the previous scan saw (strict) or did not see (asynchronous) that scan's push: the next scan of the
+  // other kind casts again
+  s->rc_pending = false;
+  return TSD_OK;
+}
+
 int tsd_scan_stage(tsd_sensor* s, const double* ranges, const uint8_t* mask, const uint8_t* mask_push)
 {
   if (!s || !s->ctx || !ranges || !mask) return TSD_E_ARG;
@@ -1410,6 +1465,7 @@ int tsd_scan_submit(tsd_sensor* s, const double* ranges, const uint8_t* mask, co
   std::memset(&ra, 0, sizeof(ra));
   ra.beams = s->beams;                                   // grid size of the launch; the rest is read on the device
   if (!(s->rc_pending && s->rc_epoch == ctx->epoch)) {
+    if (int rcd_ = drain_async_push(ctx)) return rcd_;     // (asynchronous mapping: a push still on the push stream comes first)
     rc = launch_raycast(ctx, ra, &s->d_state->rc, s->d_rays);
     if (rc != TSD_OK) return rc;
   }
@@ -1437,6 +1493,9 @@ int tsd_scan_submit(tsd_sensor* s, const double* ranges, const uint8_t* mask, co
   sp.st = s->d_state; sp.rays = s->d_rays; sp.out = s->d_result; sp.seq = seq; sp.beams = s->beams;
   sp.gmin_x = ctx->grid.min_x; sp.gmax_x = ctx->grid.max_x; sp.gmin_y = ctx->grid.min_y; sp.gmax_y = ctx->grid.max_y;
   sp.gates = GateArgs{gates->reg_trs_max, gates->reg_sin_rot_max, gates->trs_min, gates->rot_min};
+  const bool async_map = s->async_mapping && s->d_push_slot != nullptr;
+  tsd::PushArgs* const push_slot = async_map ? s->d_push_slot + (seq & 1ull) : nullptr;
+  sp.push_copy = push_slot;
   // The ray cast did not need the scan, the registration does.  The copy is short and the ray cast long, so the
   // host waits for the copy itself (a few microseconds, the device is busy meanwhile) instead of putting a
   // cross-stream barrier between the two kernels; the barrier is the fall-back.  (A scan staged ahead was copied
@@ -1449,23 +1508,52 @@ int tsd_scan_submit(tsd_sensor* s, const double* ranges, const uint8_t* mask, co
   std::memset(&pa, 0, sizeof(pa));
   pa.beams = s->beams;                                   // LDS size of the launch
   pa.max_range = s->max_range;                           // tile window of the launch (the rest is read on the device)
-  if (!host_saw_event(ctx->ev_tables, staged_ahead ? 2 : 60)) TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_tables, 0));
-  {
-    LaunchTarget tg;
-    tg.rmq = s->st_rmq;                                  // this scan's tables (the sensor's own buffers)
-    TargetScope scope(ctx, &tg);
-    // the registration moves the sensor by at most the gate (a larger step is rejected: pose unchanged)
-    rc = launch_push(ctx, pa, s->pos[0], s->pos[1], gates->reg_trs_max, &s->d_state->push, d_ranges, d_mask_push);
+  if (!async_map) {
+    if (int rcd_ = drain_async_push(ctx)) return rcd_;   // (a push left on the push stream by an earlier, asynchronous scan)
+    if (!host_saw_event(ctx->ev_tables, staged_ahead ? 2 : 60)) TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_tables, 0));
+    {
+      LaunchTarget tg;
+      tg.rmq = s->st_rmq;                                  // this scan's tables (the sensor's own buffers)
+      TargetScope scope(ctx, &tg);
+      // the registration moves the sensor by at most the gate (a larger step is rejected: pose unchanged)
+      rc = launch_push(ctx, pa, s->pos[0], s->pos[1], gates->reg_trs_max, &s->d_state->push, d_ranges, d_mask_push);
+    }
+    if (rc != TSD_OK) return rc;
+    ctx->epoch++;                                          // the grid changes
+    lap.lap(4);
+    // the next scan's ray cast, right behind the push (see above): the host's work on the next scan no longer sits
+    // between this push and that ray cast
+    rc = launch_raycast(ctx, ra, &s->d_state->rc, s->d_rays);
+    if (rc != TSD_OK) return rc;
+    s->rc_pending = true; s->rc_epoch = ctx->epoch;
+    lap.lap(5);
+  } else {
+    // Asynchronous mapping (the reference's ThreadMapping: queuePush returns at once and the push lands when the mapping thread gets
+    // to it, ThreadMapping.cpp:51-76): the NEXT scan's ray cast goes right behind this registration, on a grid that does not hold
+    // this scan's push yet -- exactly one push behind, every scan -- and this scan's push runs beside the next registration on the
+    // push stream.  Grid accesses stay ordered: ray cast (k+1) behind push (k-1) [first wait], push (k) behind ray cast (k+1)
+    // [second wait]; the push reads its own copy of its arguments (the next registration's epilogue rewrites the sensor's).
+    if (ctx->async_pending) { TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_async_push, 0)); ctx->async_pending = false; }
+    rc = launch_raycast(ctx, ra, &s->d_state->rc, s->d_rays);
+    if (rc != TSD_OK) return rc;
+    TSD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_async_rc, ctx->stream));
+    lap.lap(4);
+    TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream_push, ctx->ev_async_rc, 0));
+    TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream_push, ctx->ev_tables, 0));
+    {
+      LaunchTarget tg;
+      tg.rmq = s->st_rmq;
+      TargetScope scope(ctx, &tg);
+      rc = launch_push(ctx, pa, s->pos[0], s->pos[1], gates->reg_trs_max, push_slot, d_ranges, d_mask_push, ctx->stream_push);
+    }
+    if (rc != TSD_OK) return rc;
+    TSD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_async_push, ctx->stream_push));
+    (void)hipStreamQuery(ctx->stream_push);
+    ctx->async_pending = true;
+    ctx->epoch++;                                          // the grid changes ...
+    s->rc_pending = true; s->rc_epoch = ctx->epoch;        // ... and the ray cast enqueued above is, by design, the one that does not see it
+    lap.lap(5);
   }
-  if (rc != TSD_OK) return rc;
-  ctx->epoch++;                                          // the grid changes
-  lap.lap(4);
-  // the next scan's ray cast, right behind the push (see above): the host's work on the next scan no longer sits
-  // between this push and that ray cast
-  rc = launch_raycast(ctx, ra, &s->d_state->rc, s->d_rays);
-  if (rc != TSD_OK) return rc;
-  s->rc_pending = true; s->rc_epoch = ctx->epoch;
-  lap.lap(5);
   s->submitted = true;
   return TSD_OK;
 }
@@ -1564,6 +1652,7 @@ int tsd_scan_begin(tsd_sensor* s, const double* ranges, const uint8_t* mask, con
   if (!s->posed) return set_error(ctx, TSD_E_ARG, "tsd_scan_begin before tsd_sensor_set_pose", hipSuccess);
   if (s->inflight) return set_error(ctx, TSD_E_ARG, "tsd_scan_begin: the previous scan of this sensor was not finished", hipSuccess);
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (int rcd_ = drain_async_push(ctx)) return rcd_;
   int rc = sensor_conc_init(s, true);
   if (rc != TSD_OK) return rc;
   const size_t nb = (size_t)s->beams;
@@ -1653,6 +1742,7 @@ int tsd_scan_finish(tsd_sensor* s, tsd_scan_result* result)
   if (!s || !s->ctx || !result || !s->inflight) return TSD_E_ARG;
   tsd_ctx* ctx = s->ctx;
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (int rcd_ = drain_async_push(ctx)) return rcd_;
   ConcLap lap;
   int rc = tsd_scan_wait(s);
   if (rc != TSD_OK) return set_error(ctx, TSD_E_HIP, "tsd_scan_finish: result record never arrived", hipSuccess);
@@ -1827,6 +1917,7 @@ int tsd_batch_begin(tsd_batch* b, int n, tsd_sensor* const* sensors, const doubl
     for (int j = 0; j < i; j++) if (sensors[j] == s) return set_error(ctx, TSD_E_ARG, "tsd_batch_begin: a sensor appears twice", hipSuccess);
   }
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (int rcd_ = drain_async_push(ctx)) return rcd_;
   for (int i = 0; i < n; i++) if (int rc = sensor_conc_init(sensors[i], false)) return rc;
 
   // staging: [registration entries | ray-cast entries | tables entries | scan 0 | scan 1 ...], one copy for all of it, into the
@@ -1933,6 +2024,7 @@ int tsd_batch_push(tsd_batch* b)
   if (!b->n || b->push_enqueued) return TSD_OK;
   tsd_ctx* ctx = b->ctx;
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (int rcd_ = drain_async_push(ctx)) return rcd_;
   std::lock_guard<std::mutex> lk_order(ctx->order_mutex);
   const bool gate = b->dev_wait;                          // (else: the stream event for the whole batch's kernel)
   if (!gate) TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, b->ev_icp_done, 0));

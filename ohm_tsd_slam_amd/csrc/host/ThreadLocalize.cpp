@@ -107,6 +107,10 @@ ThreadLocalize::ThreadLocalize(obvious::TsdGrid* grid, ThreadMapping* mapper, co
   // over the grid extent, maxRMS 0, max iterations == convergence counter == icpIterations
   std::memset(&_icpParams, 0, sizeof(_icpParams));
   _icpParams.iterations      = icpIterations;
+  // "async_mapping" (addition, default 0): the reference's mapper is a thread of its own -- queuePush returns at once and the push lands
+  // when the mapping thread gets to it (ThreadMapping.cpp:51-76).  0 keeps the strict order this facade has by default (the next ray
+  // cast sees this scan's push); 1 lets the push run beside the next registration, the next ray cast exactly one push behind.
+  _asyncMapping = param(node, _robotName + "async_mapping", 0).as_int() != 0;
   // The node constructs ClosedFormEstimator2D (ThreadLocalize.cpp:214); "icp_estimator" = 1 selects the reference's
   // other estimator, PointToLine2DEstimator, on the ray cast's normals (an addition: the reference has no such key)
   _icpParams.estimator       = (int)param(node, _robotName + "icp_estimator", 0).as_int() == 1
@@ -608,6 +612,12 @@ void ThreadLocalize::init(const sensor_msgs::msg::LaserScan& scan)
   }
   if(_fused && _grid.attachSensor(_sensor) != TSD_OK)
     std::fprintf(stderr, "Localizer (%s): no device sensor, using the unfused path\n", _nameSpace.c_str());
+  else if(_fused && _asyncMapping && !_concurrent && _sensor->deviceHandle())
+  {
+    std::lock_guard<std::mutex> lk(_grid.mutex());
+    if(tsd_sensor_set_async_mapping(_sensor->deviceHandle(), 1) != TSD_OK)
+      std::fprintf(stderr, "Localizer (%s): asynchronous mapping not available (%s)\n", _nameSpace.c_str(), tsd_last_error(_grid.context()));
+  }
   _initialized = true;
   {
     std::lock_guard<std::mutex> lk(_reportMutex);

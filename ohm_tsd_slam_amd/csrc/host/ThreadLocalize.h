@@ -106,6 +106,7 @@ private:
 
   std::shared_ptr<sensor_msgs::msg::LaserScan> _ahead;      // announced next scan (clamped like laserCallBack does)
   bool _stagedValid = false;                                // _sensor holds, and the device has staged, the scan with ...
+  bool _asyncMapping = false;       // "async_mapping" (addition): the fused scan's push beside the next registration (tsd_sensor_set_async_mapping)
   bool _preFusedOk = true;          // registration_mode 3: the device-side pre-registration takes these parameters (else: the unfused calls)
   // registration_mode 3, fused: the NEXT scan's three rand() streams, drawn while the device registers this one (1 311 rand() calls
   // are 23 us of host time -- more than the host has between two scans before the device runs dry)

@@ -1478,8 +1478,9 @@ int launch_push_tables_batch(tsd_ctx* ctx, hipStream_t stream, const TablesBatch
 
 // the tables of this scan must already be in ctx->d_rmq (launch_push_tables, ordered before this)
 int launch_push(tsd_ctx* ctx, const PushArgs& a, double cx, double cy, double slack, const PushArgs* a_dev,
-                const double* d_ranges, const uint8_t* d_mask)
+                const double* d_ranges, const uint8_t* d_mask, hipStream_t stream_arg)
 {
+  const hipStream_t stream = stream_arg ? stream_arg : ctx->stream;
   const GridDev& g = ctx->grid;
   if (!a_dev) return set_error(ctx, TSD_E_ARG, "launch_push: the arguments must be on the device", hipSuccess);
   char* const rmq = (launch_target() && launch_target()->rmq) ? launch_target()->rmq : ctx->d_rmq;
@@ -1513,11 +1514,11 @@ int launch_push(tsd_ctx* ctx, const PushArgs& a, double cx, double cy, double sl
   {
     ScopedKernelTimer t(ctx, "push_classify");
     if (n_window <= 12288)
-      hipExtLaunchKernelGGL((k_push_classify<256>), dim3((n_window + 63) / 64), dim3(256), 0, ctx->stream, t.a, t.b, 0, g, a_dev, rmq,
+      hipExtLaunchKernelGGL((k_push_classify<256>), dim3((n_window + 63) / 64), dim3(256), 0, stream, t.a, t.b, 0, g, a_dev, rmq,
                          ctx->d_tile_rec, ctx->d_dirty, ctx->d_tile_totals, ctx->d_list, reinterpret_cast<PushListAux*>(ctx->d_list_aux), ctx->d_list_cnt, parity,
                          box.x0, box.y0, ntx, nty);
     else
-      hipExtLaunchKernelGGL((k_push_classify<1024>), dim3((n_window + 255) / 256), dim3(1024), 0, ctx->stream, t.a, t.b, 0, g, a_dev, rmq,
+      hipExtLaunchKernelGGL((k_push_classify<1024>), dim3((n_window + 255) / 256), dim3(1024), 0, stream, t.a, t.b, 0, g, a_dev, rmq,
                          ctx->d_tile_rec, ctx->d_dirty, ctx->d_tile_totals, ctx->d_list, reinterpret_cast<PushListAux*>(ctx->d_list_aux), ctx->d_list_cnt, parity,
                          box.x0, box.y0, ntx, nty);
   }
@@ -1537,7 +1538,7 @@ int launch_push(tsd_ctx* ctx, const PushArgs& a, double cx, double cy, double sl
 #ifdef TSD_DIAG_PER_CU
     { const size_t pad = (160u * 1024u) / (size_t)(per_cu + 1) + 512u; if (lds < pad) lds = pad; }
 #endif
-    hipExtLaunchKernelGGL(k_push_update, dim3(n_groups), dim3(UPDATE_BLOCK), lds, ctx->stream, t.a, t.b, 0, g, a_dev, d_ranges, d_mask,
+    hipExtLaunchKernelGGL(k_push_update, dim3(n_groups), dim3(UPDATE_BLOCK), lds, stream, t.a, t.b, 0, g, a_dev, d_ranges, d_mask,
                        ctx->d_tile_rec, ctx->d_tile_totals, ctx->d_list, reinterpret_cast<const PushListAux*>(ctx->d_list_aux), ctx->d_list_cnt, parity,
                        rmq_view(rmq, a.beams).bdir, rmq_view(rmq, a.beams).rot, ctx->d_icp_trace);
   }
@@ -1548,7 +1549,7 @@ int launch_push(tsd_ctx* ctx, const PushArgs& a, double cx, double cy, double sl
 #define TSD_HALO_WAVES 16384
 #endif
     const int n_waves = n_window < TSD_HALO_WAVES ? n_window : TSD_HALO_WAVES;        // one wave per listed tile; a longer list is looped over
-    hipExtLaunchKernelGGL(k_push_halo, dim3((n_waves + 3) / 4), dim3(256), 0, ctx->stream, t.a, t.b, 0, g, ctx->d_dirty, ctx->d_pushes,
+    hipExtLaunchKernelGGL(k_push_halo, dim3((n_waves + 3) / 4), dim3(256), 0, stream, t.a, t.b, 0, g, ctx->d_dirty, ctx->d_pushes,
                        a_dev, ctx->d_list, ctx->d_tile_rec, ctx->d_list_cnt, parity, cx, cy, slack + g.cs);
   }
   TSD_HIP_CHECK(ctx, hipGetLastError());

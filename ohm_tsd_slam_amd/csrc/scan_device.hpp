@@ -229,6 +229,7 @@ __device__ inline void scan_post_body(const ScanPostArgs& sp, const ScanPostPre&
   // cast of this sensor on ANOTHER stream (the batched path) is ordered behind this scan only through them
   __syncthreads();
   if (threadIdx.x == 0) {
+    if (sp.push_copy) *sp.push_copy = st->push;      // (asynchronous mapping: this scan's push reads its own copy)
     ScanResultDev* out = sp.out;
     out->icp = icp;
     for (int i = 0; i < 9; i++) out->pose[i] = s_pose[i];
@@ -249,6 +250,7 @@ __device__ inline void scan_post_failed(const ScanPostArgs& sp, int why)
 {
   SensorDev* st = sp.st;
   st->push.enabled = 0;
+  if (sp.push_copy) *sp.push_copy = st->push;
   ScanResultDev* out = sp.out;
   IcpResultDev r;
   for (int i = 0; i < 9; i++) r.T[i] = (i % 4 == 0) ? 1.0 : 0.0;

@@ -88,6 +88,8 @@ struct ScanPostArgs {
   double gmin_x, gmax_x, gmin_y, gmax_y;   // TsdGrid::getMin/Max* (RayCastPolar2D's isInsideGrid)
   int beams;
   int pad;
+  PushArgs* push_copy;       // asynchronous mapping: where this scan's push arguments are left for a push that runs beside the NEXT
+                             // registration (whose epilogue rewrites st->push); nullptr = strict order, the push reads st->push
 };
 
 // inclusive tile rectangle (empty when x1 < x0)
@@ -187,6 +189,11 @@ struct tsd_ctx {
   unsigned int push_parity = 0;
   unsigned long long epoch = 0;             // bumped by everything that changes the grid, a sensor pose or the ctx's ray-cast outputs
   hipStream_t stream2 = nullptr;             // side stream: the tables are built while ray cast / ICP run
+  // asynchronous mapping (tsd_sensor_set_async_mapping): the fused scan's push on a stream of its own, beside the next registration
+  hipStream_t stream_push = nullptr;
+  hipEvent_t ev_async_rc = nullptr;          // "the next scan's ray cast has read the grid" (recorded on `stream`)
+  hipEvent_t ev_async_push = nullptr;        // "the push enqueued last on stream_push is done"
+  bool async_pending = false;                // a push on stream_push that `stream` has not been ordered behind yet
   hipEvent_t ev_tables = nullptr;
 
   // scan staging: ring of pinned slots + device buffers
@@ -260,6 +267,8 @@ struct tsd_sensor {
   // fused registration_mode 3 (tsd_scan_preregister, tsdpdf.hip): inputs of the pre-registration that the next tsd_scan_submit runs
   // on the device between its ray cast and its registration; one device + one pinned buffer, grown on demand
   char* d_pre = nullptr; char* h_pre = nullptr; size_t pre_bytes = 0;
+  bool async_mapping = false;               // tsd_sensor_set_async_mapping
+  tsd::PushArgs* d_push_slot = nullptr;          // [2] push arguments by scan parity (asynchronous mapping)
   hipEvent_t ev_pre = nullptr;              // the pre-registration's inputs are on the device (copied on the side stream by tsd_scan_preregister)
   bool pre_copied = false;
   bool pre_armed = false, pre_ran = false;
@@ -343,13 +352,14 @@ struct ScopedKernelTimer {
   ~ScopedKernelTimer();
 };
 void drain_timers(tsd_ctx* ctx);
+int drain_async_push(tsd_ctx* ctx);          // asynchronous mapping: order the context's stream behind the push stream's last push (capi.hip)
 bool kernel_is_timed(const tsd_ctx* ctx, const char* name);
 
 // per-file launchers.  The *_dev pointers are the fused scan path: the kernels then read their pose
 // dependent arguments from the device-resident sensor state instead of the by-value copy.
 // (cx, cy) is where the host knows the sensor to be and `slack` how far the device-side pose may be from it
 int launch_push(tsd_ctx* ctx, const PushArgs& a, double cx, double cy, double slack, const PushArgs* a_dev = nullptr,
-                const double* d_ranges = nullptr, const uint8_t* d_mask = nullptr);
+                const double* d_ranges = nullptr, const uint8_t* d_mask = nullptr, hipStream_t stream = nullptr /* nullptr: ctx->stream */);
 int launch_push_tables(tsd_ctx* ctx, hipStream_t stream, int beams, const double* d_ranges, const uint8_t* d_mask,
                        double phi_min, double ang_res);
 size_t push_rmq_bytes(int beams);

@@ -204,7 +204,7 @@ def _reference_parameter_table(robot=""):
 
 def test_declared_parameters_equal_the_references():
     # the facade's own additions (documented in INTEGRATION.md), everything else must be the reference's
-    additions = {"icp_estimator", "tsdpdf_seed", "pub_tsd_color_map", "object_inflation_factor", "use_object_inflation"}   # (the last three: ThreadGrid.cpp:42-47)
+    additions = {"icp_estimator", "tsdpdf_seed", "async_mapping", "pub_tsd_color_map", "object_inflation_factor", "use_object_inflation"}   # (the last three: ThreadGrid.cpp:42-47)
     got = facade.declared_parameters()
     node, ctor, init = _reference_parameter_table("")
     want = {**node, **ctor, **init}

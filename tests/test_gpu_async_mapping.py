@@ -1,0 +1,113 @@
+"""Asynchronous mapping (tsd_sensor_set_async_mapping): the fused scan's push runs beside the NEXT registration, so the next scan's ray
+cast sees the grid one push behind -- one of the interleavings of the reference's ThreadLocalize / ThreadMapping pair
+(ThreadMapping.cpp:51-76: queuePush returns at once), and a deterministic one.  The oracle side is that order on the oracle's
+primitives: ray cast, THEN the previous scan's push, registration, gates."""
+import numpy as np
+import pytest
+
+from ohm_tsd_slam_amd import synth
+from tests import helpers as H
+from tests.slam_driver import HipSlamFused, slam_kwargs
+
+pytestmark = pytest.mark.gpu
+
+
+class OracleOnePushBehind:
+    def __init__(self, o, **kw):
+        self.o, self.kw = o, kw
+        self.g = o.Grid(kw["map_size_log2"], kw["cell_size"], kw["truncation_radius"] * kw["cell_size"])
+        self.initialized = False
+        self.pending = None
+
+    def flush(self):
+        if self.pending is not None:
+            kw = self.kw
+            pose, d2, m2 = self.pending
+            self.g.push(pose, d2, m2, kw["angle_increment"], kw["angle_min"], kw["max_range"], kw["min_range"], kw["low_refl_range"])
+            self.pending = None
+
+    def process_scan(self, ranges_f32):
+        import math
+        o, kw, g = self.o, self.kw, self.g
+        r = np.array(ranges_f32, dtype=np.float32)
+        r[r < kw["laser_min_range"]] = 0.0
+        B, res, phi_min = kw["beams"], kw["angle_increment"], kw["angle_min"]
+        out = dict(pushed=0, reg_error=0, pairs=0)
+        if not self.initialized:
+            W = (1 << kw["map_size_log2"]) * kw["cell_size"]
+            phi = kw["local_offset_yaw"]
+            sx = W * 0.5 + kw["x_offset"] + kw["local_offset_x"]
+            sy = W * 0.5 + kw["y_offset"] + kw["local_offset_y"]
+            Tinit = np.array([[math.cos(phi), -math.sin(phi), sx], [math.sin(phi), math.cos(phi), sy], [0, 0, 1.0]])
+            self.rays_local = o.rays_local(B, phi_min, res)
+            self.rays = o.rays_transform(Tinit, self.rays_local)
+            self.ray_norm = 1.0
+            self.pose = o.mat3_mul(np.eye(3), Tinit)
+            data, mask = o.ingest_f32(r, kw["max_range"], res)
+            g.free_footprint([sx + kw["footprint_x_offset"], sy], kw["footprint_width"], kw["footprint_height"])
+            g.push(self.pose, data, mask, res, phi_min, kw["max_range"], kw["min_range"], kw["low_refl_range"])     # initPush: synchronous
+            self.initialized = True
+            self.last_pose = None
+            out.update(pose=self.pose.copy(), pushed=1)
+            return out
+        data, mask = o.ingest_f32(r, kw["max_range"], res)
+        if self.last_pose is None:
+            self.last_pose = self.pose.copy()
+        self.rays = o.rays_rescale(self.rays, kw["cell_size"], self.ray_norm)
+        self.ray_norm = kw["cell_size"]
+        co, no, mo, cnt = g.raycast(self.pose, self.rays, kw["min_range"], kw["max_range"])      # the grid WITHOUT the previous scan's push
+        self.flush()                                                                             # ... which lands now
+        if cnt == 0:
+            out.update(pose=self.pose.copy(), no_model=1)
+            return out
+        scene, ms, _ = o.scene_from_scan(self.rays_local, data, mask)
+        M = co.reshape(-1, 2)[mo.astype(bool)]
+        S = scene.reshape(-1, 2)[ms.astype(bool)]
+        icp = o.icp(M, S, self.pose, kw["icp_iterations"], kw["dist_filter_max"], kw["dist_filter_min"], (0.0, g.max_x, 0.0, g.max_x), nn_mode=1)
+        T = icp["T"]
+        out.update(pairs=icp["pairs"], T=T)
+        Tf = o.f64(T).reshape(9)
+        if o.lib().ora_is_registration_error(o.d(Tf), kw["reg_trs_max"], kw["reg_sin_rot_max"]):
+            out.update(pose=self.pose.copy(), reg_error=1)
+            return out
+        self.rays = o.rays_transform(T, self.rays)
+        self.pose = o.mat3_mul(self.pose, T)
+        out["pose"] = self.pose.copy()
+        lp, cp = o.f64(self.last_pose).reshape(9), o.f64(self.pose).reshape(9)
+        if o.lib().ora_is_pose_change_significant(o.d(lp), o.d(cp)):
+            self.last_pose = self.pose.copy()
+            d2, m2 = o.ingest_f64(data, kw["max_range"], res)
+            self.pending = (self.pose.copy(), d2, m2)
+            out["pushed"] = 1
+        return out
+
+
+@pytest.mark.parametrize("cfg,n", [("cfg1", 30), ("cfg2", 14)])
+def test_async_mapping_is_exactly_one_push_behind(oracle, cfg, n):
+    gc, geo, scene = synth.CONFIGS[cfg]
+    world = synth.World(scene, gc)
+    poses = synth.trajectory(world, n)
+    scans = synth.scans_for(world, geo, poses)
+    kw = slam_kwargs(gc, geo)
+    hs = HipSlamFused(oracle, **kw)
+    hstrict = HipSlamFused(oracle, **kw)              # the default order beside it: the two must not be the same thing
+    oa = OracleOnePushBehind(oracle, **kw)
+    strict_differs = False
+    for k in range(n):
+        rh = hs.process_scan(scans[k])
+        if k == 0:
+            hs.sensor.set_async_mapping(True)
+        rs = hstrict.process_scan(scans[k])
+        strict_differs |= rs["pairs"] != rh["pairs"] or H.pose_delta(rs["pose"], rh["pose"])[0] > 1e-7
+        ro = oa.process_scan(scans[k])
+        assert (rh["pushed"], rh["reg_error"], rh["pairs"]) == (ro["pushed"], ro["reg_error"], ro["pairs"]), (k, rh, ro)
+        d, a = H.pose_delta(ro["pose"], rh["pose"])
+        assert d <= 1e-9 and a <= 1e-9, (k, d, a)
+    assert strict_differs, "one push behind gave the strict order's results: the mode did nothing"
+    oa.flush()
+    hs.grid.sync()
+    H.assert_grids_equal(oa.g.dump(), hs.grid.download_tiles(), 1e-9)      # (the poses agree to 1e-13, the cells pushed from them likewise)
+    # switching back is allowed between scans and is the strict order again
+    hs.sensor.set_async_mapping(False)
+    rs = hs.process_scan(scans[-1])
+    assert rs["pairs"] > 0
