@@ -1480,6 +1480,9 @@ int tsd_scan_submit(tsd_sensor* s, const double* ranges, const uint8_t* mask, co
   s->pre_ran = false;
   if (s->pre_armed) {
     s->pre_armed = false;
+    // (asynchronous mapping: the scoring reads the grid -- the previous scan's push, still on the push stream, lands first.  The order
+    // is then ray cast, previous push, pre-registration, registration: still one of the reference's interleavings, without the overlap)
+    if (int rcd_ = drain_async_push(ctx)) return rcd_;
     const LaunchTarget* tgp = launch_target();
     rc = launch_preregistration(ctx, s, launch_stream(ctx), tgp && tgp->coords ? tgp->coords : ctx->d_coords,
                                 tgp && tgp->mask_m ? tgp->mask_m : ctx->d_mask_m, s->d_state->icpP, &ia.Tinit_dev);
