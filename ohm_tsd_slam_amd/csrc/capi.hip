@@ -1537,9 +1537,16 @@ int tsd_scan_submit(tsd_sensor* s, const double* ranges, const uint8_t* mask, co
     // push stream.  Grid accesses stay ordered: ray cast (k+1) behind push (k-1) [first wait], push (k) behind ray cast (k+1)
     // [second wait]; the push reads its own copy of its arguments (the next registration's epilogue rewrites the sensor's).
     if (ctx->async_pending) { TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_async_push, 0)); ctx->async_pending = false; }
-    rc = launch_raycast(ctx, ra, &s->d_state->rc, s->d_rays);
-    if (rc != TSD_OK) return rc;
-    TSD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_async_rc, ctx->stream));
+    {
+      // (the event the push waits for is the ray cast's own completion -- a marker behind it would sit between the ray cast and the
+      // next registration)
+      LaunchTarget tgr;
+      tgr.rc_done = ctx->ev_async_rc;
+      TargetScope scope_r(ctx, &tgr);
+      rc = launch_raycast(ctx, ra, &s->d_state->rc, s->d_rays);
+      if (rc != TSD_OK) return rc;
+      if (!tgr.rc_done_used) TSD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_async_rc, ctx->stream));
+    }
     lap.lap(4);
     TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream_push, ctx->ev_async_rc, 0));
     TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream_push, ctx->ev_tables, 0));

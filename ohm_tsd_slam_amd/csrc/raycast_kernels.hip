@@ -580,7 +580,9 @@ int launch_raycast(tsd_ctx* ctx, const RaycastArgs& a, const RaycastArgs* a_dev,
 {
   ScopedKernelTimer t(ctx, "raycast");
   const LaunchTarget* tg = launch_target();       // concurrent multi-robot path: the sensor's own stream and output buffers
-  hipExtLaunchKernelGGL(k_raycast, dim3(a.beams), dim3(64), 0, launch_stream(ctx), t.a, t.b, 0, ctx->grid, a, a_dev, d_rays ? d_rays : ctx->d_rays,
+  hipEvent_t stop = t.b;
+  if (tg && tg->rc_done && !t.b) { stop = tg->rc_done; const_cast<LaunchTarget*>(tg)->rc_done_used = true; }
+  hipExtLaunchKernelGGL(k_raycast, dim3(a.beams), dim3(64), 0, launch_stream(ctx), t.a, stop, 0, ctx->grid, a, a_dev, d_rays ? d_rays : ctx->d_rays,
                      tg && tg->coords ? tg->coords : ctx->d_coords, tg && tg->normals ? tg->normals : ctx->d_normals,
                      tg && tg->mask_m ? tg->mask_m : ctx->d_mask_m, ctx->d_icp_trace);
   TSD_HIP_CHECK(ctx, hipGetLastError());

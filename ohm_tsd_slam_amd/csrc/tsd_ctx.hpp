@@ -112,6 +112,8 @@ struct LaunchTarget {
   double* coords = nullptr; double* normals = nullptr; uint8_t* mask_m = nullptr;   // ray-cast outputs
   IcpResultDev* icp_res = nullptr; double* trace = nullptr;
   char* rmq = nullptr;                                                // range-query tables of the scan's push
+  hipEvent_t rc_done = nullptr;                                       // launch_raycast: completes with the ray cast itself (the kernel's own stop
+  bool rc_done_used = false;                                          // event: no marker behind it); used = false when the dispatch is being timed
 };
 
 // ---- batched scans (tsd_batch_*): one launch of each kernel for the robots of a batch; block (.., y) of the batched ray cast /
