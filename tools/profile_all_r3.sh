@@ -16,6 +16,7 @@ find gpurun_out -name "*kernel_trace.csv" -delete 2>/dev/null; find gpurun_out -
 python3 bench.py --steps 20 --warmup 5 > gpurun_out/profiles_new/r3_bench_20steps.json 2> gpurun_out/r3_bench20.err
 python3 bench.py > gpurun_out/profiles_new/r3_bench_200steps.json 2> gpurun_out/r3_bench200.err
 python3 bench.py --registration-mode 3 --no-cpu-baseline > gpurun_out/profiles_new/r3_bench_mode3.json 2> gpurun_out/r3_bench_mode3.err
+python3 bench.py --async-mapping --no-cpu-baseline > gpurun_out/profiles_new/r3_bench_async_mapping.json 2> gpurun_out/r3_bench_async.err
 python3 bench.py --robots 8 --no-cpu-baseline > gpurun_out/profiles_new/r3_multi_robot_one_grid_8.json 2> gpurun_out/r3_bench_r8.err
 python3 bench.py --config cfg3 --scene comb --mode push --steps 100 --no-cpu-baseline > gpurun_out/profiles_new/r3_bench_cfg3_comb_push.json 2> gpurun_out/r3_bench_c3.err
 python3 bench.py --gpus 1 --force-dist --no-cpu-baseline > gpurun_out/profiles_new/r3_bench_force_dist_1rank.json 2> gpurun_out/r3_bench_fd.err
