@@ -111,3 +111,17 @@ def test_async_mapping_is_exactly_one_push_behind(oracle, cfg, n):
     hs.sensor.set_async_mapping(False)
     rs = hs.process_scan(scans[-1])
     assert rs["pairs"] > 0
+
+
+def test_async_mapping_with_one_hardware_queue():
+    """All streams of the process on ONE in-order hardware queue (GPU_MAX_HW_QUEUES=1): the two hand-offs between the context's stream
+    and the push stream must neither deadlock nor change a result -- the cfg 1 case above in a child process (the variable is read
+    when the runtime comes up)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "tests/test_gpu_async_mapping.py", "-k", "one_push_behind and cfg1"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
