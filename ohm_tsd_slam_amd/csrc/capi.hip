@@ -1480,12 +1480,14 @@ int tsd_scan_submit(tsd_sensor* s, const double* ranges, const uint8_t* mask, co
   s->pre_ran = false;
   if (s->pre_armed) {
     s->pre_armed = false;
-    // (asynchronous mapping: the scoring reads the grid -- the previous scan's push, still on the push stream, lands first.  The order
-    // is then ray cast, previous push, pre-registration, registration: still one of the reference's interleavings, without the overlap)
-    if (int rcd_ = drain_async_push(ctx)) return rcd_;
+    // (asynchronous mapping: the SCORING reads the grid -- the previous scan's push, still on the push stream, has to land first; the
+    // normals and the list building ahead of it do not, and run beside that push.  The order is then ray cast, previous push,
+    // pre-registration, registration: still one of the reference's interleavings)
+    hipEvent_t before_score = nullptr;
+    if (ctx->async_pending) { before_score = ctx->ev_async_push; ctx->async_pending = false; }
     const LaunchTarget* tgp = launch_target();
     rc = launch_preregistration(ctx, s, launch_stream(ctx), tgp && tgp->coords ? tgp->coords : ctx->d_coords,
-                                tgp && tgp->mask_m ? tgp->mask_m : ctx->d_mask_m, s->d_state->icpP, &ia.Tinit_dev);
+                                tgp && tgp->mask_m ? tgp->mask_m : ctx->d_mask_m, s->d_state->icpP, &ia.Tinit_dev, before_score);
     if (rc != TSD_OK) return rc;
     s->pre_ran = true;
   }

@@ -612,9 +612,6 @@ void ThreadLocalize::init(const sensor_msgs::msg::LaserScan& scan)
   }
   if(_fused && _grid.attachSensor(_sensor) != TSD_OK)
     std::fprintf(stderr, "Localizer (%s): no device sensor, using the unfused path\n", _nameSpace.c_str());
-  else if(_fused && _asyncMapping && _regMode == 3)
-    std::fprintf(stderr, "Localizer (%s): async_mapping is not combined with registration_mode 3 (the pre-registration's scoring reads the "
-                         "grid and would have to wait for the push anyway); strict order\n", _nameSpace.c_str());
   else if(_fused && _asyncMapping && !_concurrent && _sensor->deviceHandle())
   {
     std::lock_guard<std::mutex> lk(_grid.mutex());

@@ -876,7 +876,7 @@ extern "C" int tsd_scan_preregister(tsd_sensor* s, const tsd_tsdpdf_params* prm,
 
 namespace tsd {
 int launch_preregistration(tsd_ctx* ctx, tsd_sensor* s, hipStream_t stream, const double* d_coords, const uint8_t* d_mask_m,
-                           const double* d_pose6, const double** tinit_dev)
+                           const double* d_pose6, const double** tinit_dev, hipEvent_t before_score)
 {
   const tsd_sensor::PreLayout& L = s->pre;
   char* d = s->d_pre;
@@ -915,6 +915,8 @@ int launch_preregistration(tsd_ctx* ctx, tsd_sensor* s, hipStream_t stream, cons
     ScopedKernelTimer t(ctx, "tsdpdf", true);
     hipLaunchKernelGGL(k_pdf_normals, dim3((n + 255) / 256, 2), dim3(256), 0, stream, sm, ss, n, SR);
     hipLaunchKernelGGL(k_pdf_prepare, dim3(1), dim3(1024), prep_lds, stream, pa);
+    // (asynchronous mapping: the scoring is the first kernel of the chain that reads the grid)
+    if (before_score) TSD_HIP_CHECK(ctx, hipStreamWaitEvent(stream, before_score, 0));
     hipLaunchKernelGGL(k_pdf_score, dim3(std::min((L.max_cand + PDF_WAVES - 1) / PDF_WAVES, PDF_SCORE_GRID)), dim3(64 * PDF_WAVES), 0, stream, ctx->grid, d_pose6,
                        d_coords, reinterpret_cast<const double*>(d + L.off_S), reinterpret_cast<const double2*>(d + L.off_C), 0,
                        reinterpret_cast<const PdfCandidate*>(d + L.off_K), 0, L.zrand, reinterpret_cast<double*>(d + L.off_prob),

@@ -26,7 +26,7 @@ class OracleOnePushBehind:
             self.g.push(pose, d2, m2, kw["angle_increment"], kw["angle_min"], kw["max_range"], kw["min_range"], kw["low_refl_range"])
             self.pending = None
 
-    def process_scan(self, ranges_f32):
+    def process_scan(self, ranges_f32, draws=None):
         import math
         o, kw, g = self.o, self.kw, self.g
         r = np.array(ranges_f32, dtype=np.float32)
@@ -63,7 +63,15 @@ class OracleOnePushBehind:
         scene, ms, _ = o.scene_from_scan(self.rays_local, data, mask)
         M = co.reshape(-1, 2)[mo.astype(bool)]
         S = scene.reshape(-1, 2)[ms.astype(bool)]
-        icp = o.icp(M, S, self.pose, kw["icp_iterations"], kw["dist_filter_max"], kw["dist_filter_min"], (0.0, g.max_x, 0.0, g.max_x), nn_mode=1)
+        if draws is None:
+            icp = o.icp(M, S, self.pose, kw["icp_iterations"], kw["dist_filter_max"], kw["dist_filter_min"], (0.0, g.max_x, 0.0, g.max_x), nn_mode=1)
+        else:
+            # registration_mode 3: the pre-registration scores on the grid WITH the previous scan's push (it landed above)
+            m = o.tsdpdf_match(g, self.pose, co, mo, scene, ms, kw["trials"], kw["size_control_set"], kw["zrand"],
+                               np.radians(kw["ransac_phi_max"]), res, *draws)
+            out["pre"] = (m["candidates"], m["idx"], m["i"])
+            icp = o.icp_init(M, S, self.pose, kw["icp_iterations"], kw["dist_filter_max"], kw["dist_filter_min"],
+                             (0.0, g.max_x, 0.0, g.max_x), m["T"], nn_mode=1)
         T = icp["T"]
         out.update(pairs=icp["pairs"], T=T)
         Tf = o.f64(T).reshape(9)
@@ -125,3 +133,52 @@ def test_async_mapping_with_one_hardware_queue():
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "tests/test_gpu_async_mapping.py", "-k", "one_push_behind and cfg1"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+class HipFusedMode3(HipSlamFused):
+    """HipSlamFused with the TSD_PDF pre-registration armed ahead of every scan (tsd_scan_preregister), given draws."""
+
+    def process_scan(self, ranges_f32, draws=None):
+        if not self.initialized or draws is None:
+            return super().process_scan(ranges_f32)
+        o, kw = self.o, self.kw
+        r = np.array(ranges_f32, dtype=np.float32)
+        r[r < kw["laser_min_range"]] = 0.0
+        res = kw["angle_increment"]
+        data, mask = o.ingest_f32(r, kw["max_range"], res)
+        _, mask_push = o.ingest_f64(data, kw["max_range"], res)
+        sc, ms, _ = o.scene_from_scan(self.rays_local, data, mask)
+        self.sensor.preregister(sc, ms, kw["trials"], kw["size_control_set"], kw["zrand"], np.radians(kw["ransac_phi_max"]), res, *draws)
+        sr = self.sensor.scan(data, mask, mask_push, self.params, self.gates)
+        pr = self.sensor.preregistration_result()
+        self.pose = np.array(sr.pose[:]).reshape(3, 3)
+        return dict(pose=self.pose.copy(), pushed=int(sr.pushed), reg_error=int(sr.reg_error), pairs=int(sr.icp.pairs),
+                    pre=(pr["candidates"], pr["idx"], pr["i"]))
+
+
+def test_async_mapping_with_the_pre_registration(oracle):
+    """registration_mode 3 with the mapper asynchronous: ray cast (one push behind), the previous push lands -- beside the normals and
+    the list building, which do not read the grid --, THEN the scoring, the arg-max and the registration."""
+    gc, geo, scene = synth.CONFIGS["cfg1"]
+    world = synth.World(scene, gc)
+    n = 16
+    poses = synth.trajectory(world, n)
+    scans = synth.scans_for(world, geo, poses)
+    kw = slam_kwargs(gc, geo, trials=40, size_control_set=120)
+    hs = HipFusedMode3(oracle, **kw)
+    oa = OracleOnePushBehind(oracle, **kw)
+    rng = np.random.default_rng(77)
+    for k in range(n):
+        draws = None if k == 0 else tuple(rng.integers(0, 2 ** 31 - 1, m) for m in (geo.beams, kw["size_control_set"], kw["trials"]))
+        rh = hs.process_scan(scans[k], draws)
+        if k == 0:
+            hs.sensor.set_async_mapping(True)
+        ro = oa.process_scan(scans[k], draws)
+        if k > 0:
+            assert rh["pre"] == ro["pre"], (k, rh["pre"], ro["pre"])
+        assert (rh["pushed"], rh["reg_error"], rh["pairs"]) == (ro["pushed"], ro["reg_error"], ro["pairs"]), (k, rh, ro)
+        d, a = H.pose_delta(ro["pose"], rh["pose"])
+        assert d <= 1e-9 and a <= 1e-9, (k, d, a)
+    oa.flush()
+    hs.grid.sync()
+    H.assert_grids_equal(oa.g.dump(), hs.grid.download_tiles(), 1e-9)
