@@ -269,6 +269,7 @@ struct tsd_sensor {
   // fused registration_mode 3 (tsd_scan_preregister, tsdpdf.hip): inputs of the pre-registration that the next tsd_scan_submit runs
   // on the device between its ray cast and its registration; one device + one pinned buffer, grown on demand
   char* d_pre = nullptr; char* h_pre = nullptr; size_t pre_bytes = 0;
+  char* h_pre_dev = nullptr;                // h_pre as the device sees it (looked up once per allocation)
   bool async_mapping = false;               // tsd_sensor_set_async_mapping
   tsd::PushArgs* d_push_slot = nullptr;          // [2] push arguments by scan parity (asynchronous mapping)
   hipEvent_t ev_pre = nullptr;              // the pre-registration's inputs are on the device (copied on the side stream by tsd_scan_preregister)

@@ -837,6 +837,7 @@ extern "C" int tsd_scan_preregister(tsd_sensor* s, const tsd_tsdpdf_params* prm,
     s->d_pre = nullptr; s->h_pre = nullptr; s->pre_bytes = 0;
     TSD_HIP_CHECK(ctx, hipMalloc(&s->d_pre, total));
     TSD_HIP_CHECK(ctx, hipHostMalloc(&s->h_pre, total, hipHostMallocDefault));
+    TSD_HIP_CHECK(ctx, hipHostGetDevicePointer(reinterpret_cast<void**>(&s->h_pre_dev), s->h_pre, 0));
     s->pre_bytes = total;
   }
   // (the pinned buffer is free: the previous scan was collected, i.e. its copy from here and its read-back have completed)
@@ -880,8 +881,7 @@ int launch_preregistration(tsd_ctx* ctx, tsd_sensor* s, hipStream_t stream, cons
 {
   const tsd_sensor::PreLayout& L = s->pre;
   char* d = s->d_pre;
-  char* h_dev = nullptr;                    // the pinned buffer as the device sees it (header + result are written there by k_pdf_argmax)
-  TSD_HIP_CHECK(ctx, hipHostGetDevicePointer(reinterpret_cast<void**>(&h_dev), s->h_pre, 0));
+  char* h_dev = s->h_pre_dev;               // the pinned buffer as the device sees it (header + result are written there by k_pdf_argmax)
   const int n = L.n, SR = 10 / 2;
   if (!s->pre_copied) TSD_HIP_CHECK(ctx, hipMemcpyAsync(d, s->h_pre, L.in_bytes, hipMemcpyHostToDevice, stream));
   else if (hipEventQuery(s->ev_pre) != hipSuccess) {
