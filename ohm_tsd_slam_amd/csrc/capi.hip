@@ -1294,6 +1294,7 @@ void tsd_sensor_destroy(tsd_sensor* s)
   if (s->stream) hipStreamDestroy(s->stream);
   hipFree(s->d_coords); hipFree(s->d_normals); hipFree(s->d_mask_m); hipFree(s->d_icp_res); hipFree(s->d_icp_trace);
   if (s->ev_pre) hipEventDestroy(s->ev_pre);
+  if (s->ev_pre_done) hipEventDestroy(s->ev_pre_done);
   if (s->d_push_slot) { if (s->ctx && s->ctx->stream_push) hipStreamSynchronize(s->ctx->stream_push); hipFree(s->d_push_slot); }
   if (s->d_pre) hipFree(s->d_pre);
   if (s->h_pre) hipHostFree(s->h_pre);

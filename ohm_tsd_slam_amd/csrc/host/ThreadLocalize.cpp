@@ -462,8 +462,10 @@ void ThreadLocalize::processScanFused(ScanReport& rep)
   {
     const bool useStaged = _stagedValid;
     _stagedValid = false;
+    const bool preStaged = _preStagedValid && useStaged;      // (armed while the previous scan registered; a dropped staged scan takes it along)
+    _preStagedValid = false;
     rc = TSD_OK;
-    if(_regMode == 3 && _preMatcher)
+    if(_regMode == 3 && _preMatcher && !preStaged)
     {
       // doRegistration, case TSD (ThreadLocalize.cpp:557-567): the scene points and the match's three rand() streams are all the
       // pre-registration needs from the host; its model is the ray cast's output, on the device
@@ -513,9 +515,23 @@ void ThreadLocalize::processScanFused(ScanReport& rep)
         _stagedValid = true;
         _stagedStampNs = (long long)next->header.stamp.sec * 1000000000LL + (long long)next->header.stamp.nanosec;
         _stagedRanges = next->ranges;
+        if(_regMode == 3 && _preMatcher && _preFusedOk)
+        {
+          // ... and its pre-registration: scene points, draws and the inputs' copy NOW, while the device registers this scan -- between
+          // two scans the host then only submits (the device was waiting for the host there: 40 us of host work per scan in mode 3)
+          const unsigned int n = _sensor->getRealMeasurementSize();
+          if(_scene.size() != 2 * (size_t)n) { _scene.assign(2 * (size_t)n, 0.0); _maskS.assign(n, 0); }
+          bool* maskS = reinterpret_cast<bool*>(_maskS.data());
+          _sensor->dataToCartesianVectorMask(_scene.data(), maskS);
+          if(!_drawsReady || _dSub.size() != n) _preMatcher->drawStreams(n, _dSub, _dCtrl, _dTrials);
+          _drawsReady = false;
+          if(_grid.scanPreregister(_sensor, _preMatcher->params(_ranPhiMax * M_PI / 180.0, _sensor->getAngularResolution()), _scene.data(), maskS,
+                                   _dSub.data(), _dCtrl.data(), _dTrials.data()) == TSD_OK)
+            _preStagedValid = true;
+        }
       }
     }
-    if(rc == TSD_OK && _regMode == 3 && _preMatcher && _preFusedOk && !_drawsReady)
+    if(rc == TSD_OK && _regMode == 3 && _preMatcher && _preFusedOk && !_drawsReady && !_preStagedValid)
     {
       _preMatcher->drawStreams(_sensor->getRealMeasurementSize(), _dSub, _dCtrl, _dTrials);      // the next scan's, while the device is busy
       _drawsReady = true;

@@ -112,6 +112,7 @@ private:
   // are 23 us of host time -- more than the host has between two scans before the device runs dry)
   std::vector<int> _dSub, _dCtrl, _dTrials;
   bool _drawsReady = false;
+  bool _preStagedValid = false;     // the staged scan's pre-registration is armed on the device already (tsd_scan_preregister ahead of the collect)
   long long _stagedStampNs = 0;                             // ... this stamp ...
   std::vector<float> _stagedRanges;                         // ... and these readings (in the sensor's beam order)
   std::deque<std::shared_ptr<sensor_msgs::msg::LaserScan>> _laserData;

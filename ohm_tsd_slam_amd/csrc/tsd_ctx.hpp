@@ -270,6 +270,9 @@ struct tsd_sensor {
   // on the device between its ray cast and its registration; one device + one pinned buffer, grown on demand
   char* d_pre = nullptr; char* h_pre = nullptr; size_t pre_bytes = 0;
   char* h_pre_dev = nullptr;                // h_pre as the device sees it (looked up once per allocation)
+  hipEvent_t ev_pre_done = nullptr;         // the in-flight scan's pre-registration kernels have read their inputs (the arg-max's own stop event)
+  bool pre_done_valid = false;
+  size_t pre_res_off_hdr = 0, pre_res_off_res = 0;      // where the collected scan's header / result are in h_pre (the layout may be re-armed meanwhile)
   bool async_mapping = false;               // tsd_sensor_set_async_mapping
   tsd::PushArgs* d_push_slot = nullptr;          // [2] push arguments by scan parity (asynchronous mapping)
   hipEvent_t ev_pre = nullptr;              // the pre-registration's inputs are on the device (copied on the side stream by tsd_scan_preregister)

@@ -811,8 +811,11 @@ extern "C" int tsd_scan_preregister(tsd_sensor* s, const tsd_tsdpdf_params* prm,
       prm->trials > PDF_MAX_TRIALS)
     return set_error(ctx, TSD_E_CAPACITY, "tsd_scan_preregister: beams / control set / trials out of range", hipSuccess);
   if (!(prm->ang_res > 1e-6)) return set_error(ctx, TSD_E_ARG, "tsd_scan_preregister: resolution not properly set", hipSuccess);
-  if (s->submitted) return set_error(ctx, TSD_E_ARG, "tsd_scan_preregister: the previous scan was not collected", hipSuccess);
+  // A scan of this sensor may be IN FLIGHT (submitted, not collected): the pre-registration of the scan after it is then armed ahead --
+  // its inputs are copied behind that scan's own pre-registration kernels (which read the same device buffer), beside its registration.
+  const bool inflight = s->submitted;
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (inflight && s->ev_pre) TSD_HIP_CHECK(ctx, hipEventSynchronize(s->ev_pre));      // (the in-flight scan's own copy has left the pinned buffer)
   tsd_sensor::PreLayout L{};
   L.n = n; L.trials = prm->trials; L.size_control_set = prm->size_control_set; L.zrand = prm->zrand;
   L.phi_max = std::min(prm->phi_max, M_PI * 0.5);
@@ -864,7 +867,9 @@ extern "C" int tsd_scan_preregister(tsd_sensor* s, const tsd_tsdpdf_params* prm,
   // scan was collected).  TSD_PRE_COPY_MAIN=1: the copy at tsd_scan_submit, on the main stream (round 3's first form; A/B).
   static const bool copy_main = [] { const char* e = std::getenv("TSD_PRE_COPY_MAIN"); return e && *e == '1'; }();
   s->pre_copied = false;
+  if (copy_main && inflight) return set_error(ctx, TSD_E_ARG, "tsd_scan_preregister ahead of the collect needs the side-stream copy (TSD_PRE_COPY_MAIN is set)", hipSuccess);
   if (!copy_main) {
+    if (inflight && s->pre_done_valid) TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream2, s->ev_pre_done, 0));
     if (!s->ev_pre) TSD_HIP_CHECK(ctx, hipEventCreateWithFlags(&s->ev_pre, hipEventDisableTiming));
     TSD_HIP_CHECK(ctx, hipMemcpyAsync(s->d_pre, s->h_pre, L.in_bytes, hipMemcpyHostToDevice, ctx->stream2));
     TSD_HIP_CHECK(ctx, hipEventRecord(s->ev_pre, ctx->stream2));
@@ -921,10 +926,15 @@ int launch_preregistration(tsd_ctx* ctx, tsd_sensor* s, hipStream_t stream, cons
                        d_coords, reinterpret_cast<const double*>(d + L.off_S), reinterpret_cast<const double2*>(d + L.off_C), 0,
                        reinterpret_cast<const PdfCandidate*>(d + L.off_K), 0, L.zrand, reinterpret_cast<double*>(d + L.off_prob),
                        reinterpret_cast<const PdfHeader*>(d + L.off_hdr), L.max_cand, std::max(L.size_control_set, 1));
-    hipLaunchKernelGGL(k_pdf_argmax, dim3(1), dim3(1024), 0, stream, reinterpret_cast<const double*>(d + L.off_prob),
+    // (the arg-max's own completion is the event a pre-registration armed AHEAD waits for before it overwrites the inputs: no marker
+    // between this kernel and the registration)
+    if (!s->ev_pre_done) TSD_HIP_CHECK(ctx, hipEventCreateWithFlags(&s->ev_pre_done, hipEventDisableTiming | hipEventDisableSystemFence));
+    hipExtLaunchKernelGGL(k_pdf_argmax, dim3(1), dim3(1024), 0, stream, nullptr, s->ev_pre_done, 0, reinterpret_cast<const double*>(d + L.off_prob),
                        reinterpret_cast<const PdfCandidate*>(d + L.off_K), 0, d_coords, reinterpret_cast<const double*>(d + L.off_S),
                        reinterpret_cast<PdfResult*>(d + L.off_res), reinterpret_cast<const PdfHeader*>(d + L.off_hdr),
                        reinterpret_cast<PdfHeader*>(h_dev + L.off_hdr), reinterpret_cast<PdfResult*>(h_dev + L.off_res));
+    s->pre_done_valid = true;
+    s->pre_res_off_hdr = L.off_hdr; s->pre_res_off_res = L.off_res;
   }
   TSD_HIP_CHECK(ctx, hipGetLastError());
   *tinit_dev = reinterpret_cast<const double*>(d + L.off_res);
@@ -936,8 +946,8 @@ extern "C" int tsd_scan_preregistration_result(tsd_sensor* s, tsd_tsdpdf_result*
 {
   if (!s || !s->ctx || !result) return TSD_E_ARG;
   if (!s->pre_ran || s->submitted) return set_error(s->ctx, TSD_E_ARG, "tsd_scan_preregistration_result: no collected scan with a pre-registration", hipSuccess);
-  const PdfHeader* hd = reinterpret_cast<const PdfHeader*>(s->h_pre + s->pre.off_hdr);
-  const PdfResult* r = reinterpret_cast<const PdfResult*>(s->h_pre + s->pre.off_res);
+  const PdfHeader* hd = reinterpret_cast<const PdfHeader*>(s->h_pre + s->pre_res_off_hdr);
+  const PdfResult* r = reinterpret_cast<const PdfResult*>(s->h_pre + s->pre_res_off_res);
   std::memcpy(result->T, r->T, sizeof(r->T));
   result->probability = r->prob; result->idx_model = r->idx; result->idx_scene = r->i;
   result->candidates = hd->identity ? 0 : hd->n_cand;
