@@ -387,8 +387,9 @@ int tsd_push_stats_total(tsd_ctx* ctx, tsd_push_stats* total, int64_t* pushes, i
  * Icp.cpp:481-486): PCA normals of both point sets, extractSamples, pickControlSet, the trial picks and the candidate list in the
  * reference's serial order, scoring, arg-max -- nothing returns to the host in between.  scene_xy_2B / mask_s: what
  * Sensor::dataToCartesianVectorMask gives for the scan (beam-indexed); the draws as in tsd_tsdpdf_match.  One-shot.  The inputs are
- * copied at the call (the caller's buffers are free on return) and travel to the device on the side stream right away; call it after the
- * previous scan was collected (TSD_E_ARG otherwise). */
+ * copied at the call (the caller's buffers are free on return) and travel to the device on the side stream right away.  It may be
+ * called while a scan of this sensor is in flight (submitted, not yet collected): it then arms the scan AFTER that one, and the copy is
+ * ordered behind the in-flight scan's own pre-registration kernels. */
 int tsd_scan_preregister(tsd_sensor* s, const tsd_tsdpdf_params* params, const double* scene_xy_2B, const uint8_t* mask_s,
                          const int* draws_subsample, const int* draws_control, const int* draws_trials);
 /* Asynchronous mapping for the fused scan of this sensor.  The reference's ThreadMapping is a thread of its own: queuePush returns at
