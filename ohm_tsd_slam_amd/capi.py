@@ -495,9 +495,10 @@ class TsdSensorDevice:
         pose, rw, rl = _f64(pose).reshape(9), _f64(rays_world), _f64(rays_local)
         self.grid._check(self.lib.tsd_sensor_set_pose(self.h, _d(pose), _d(rw), _d(rl)), "tsd_sensor_set_pose")
 
-    def scan_ahead(self, ranges, mask, mask_push, params: IcpParams, gates: GateParams, nxt=None) -> ScanResult:
+    def scan_ahead(self, ranges, mask, mask_push, params: IcpParams, gates: GateParams, nxt=None, nxt_pre=None) -> ScanResult:
         """tsd_scan_submit (``ranges`` None: the scan staged by the previous call) + tsd_scan_stage of ``nxt`` = (ranges, mask,
-        mask_push) while the registration runs + tsd_scan_collect"""
+        mask_push) while the registration runs (+ tsd_scan_preregister(*nxt_pre) for that staged scan, also ahead of the collect)
+        + tsd_scan_collect"""
         if ranges is None:
             rc = self.lib.tsd_scan_submit(self.h, None, None, None, C.byref(params), C.byref(gates))
         else:
@@ -509,6 +510,8 @@ class TsdSensorDevice:
             rg, mk = _f64(nxt[0]), np.ascontiguousarray(nxt[1], dtype=np.uint8)
             mp = np.ascontiguousarray(nxt[2], dtype=np.uint8) if nxt[2] is not None else None
             self.grid._check(self.lib.tsd_scan_stage(self.h, _d(rg), _u8(mk), _u8(mp) if mp is not None else None), "tsd_scan_stage")
+        if nxt_pre is not None:
+            self.preregister(*nxt_pre)
         r = ScanResult()
         self.grid._check(self.lib.tsd_scan_collect(self.h, C.byref(r)), "tsd_scan_collect")
         return r

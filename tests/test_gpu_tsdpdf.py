@@ -103,6 +103,53 @@ def test_fused_preregistration_matches_the_unfused_calls(oracle, cfg, scene, ctr
     sensor.close()
 
 
+def test_preregistration_armed_ahead_of_the_collect(oracle):
+    """tsd_scan_preregister while the previous scan is in flight (what the facade does for a staged scan: scene points, draws and the
+    inputs' copy while the device registers) == arming it between the two scans: same winner, same registration, same pose."""
+    gc, geo, scene = synth.CONFIGS["cfg2"]
+    og, dg, pose, co, mo, sc, ms, Ttrue = _map_and_scan(oracle, gc, geo, scene, 3, 8, dyaw=0.05)
+    world = synth.World(scene, gc)
+    rl, rw = H.world_rays(oracle, geo, pose, gc.cell_size)
+    rng = np.random.default_rng(31)
+    phi_max, res = math.radians(30.0), geo.angle_increment
+    scans = []
+    for k, dy in ((8, 0.05), (9, 0.02)):
+        _, (x, y, yaw) = H.sensor_pose(world, k)
+        data, mask = oracle.ingest_f32(world.scan(x, y, yaw + dy, geo), H.MAX_RANGE, res)
+        _, mask_push = oracle.ingest_f64(data, H.MAX_RANGE, res)
+        scn, msk, _ = oracle.scene_from_scan(rl, data, mask)
+        draws = tuple(rng.integers(0, 2 ** 31 - 1, n) for n in (geo.beams, 140, 100))
+        scans.append((data, mask, mask_push, (scn, msk, 100, 140, 0.25, phi_max, res) + draws))
+    gates = capi.GateParams(1.0, 0.5, 0.05, 0.03)            # (the node's gates: the first scan pushes, the second sees that push)
+    outs = []
+    for ahead in (False, True):
+        g2 = capi.TsdGridDevice(gc.map_size_log2, gc.cell_size, gc.max_trunc)
+        g2.upload_tiles(*dg.download_tiles())
+        sensor = capi.TsdSensorDevice(g2, geo.beams, res, geo.angle_min, H.MAX_RANGE, H.MIN_RANGE, H.LOW_REFL)
+        sensor.set_pose(pose, rw, rl)
+        p = g2.icp_params(30, 0.4, 0.02)
+        sensor.preregister(*scans[0][3])
+        if not ahead:
+            r1 = sensor.scan(scans[0][0], scans[0][1], scans[0][2], p, gates)
+            pr1 = sensor.preregistration_result()
+            sensor.preregister(*scans[1][3])
+            r2 = sensor.scan(scans[1][0], scans[1][1], scans[1][2], p, gates)
+        else:
+            r1 = sensor.scan_ahead(scans[0][0], scans[0][1], scans[0][2], p, gates, nxt=scans[1][:3], nxt_pre=scans[1][3])
+            pr1 = sensor.preregistration_result()          # (the first scan's, although the second is armed already)
+            r2 = sensor.scan_ahead(None, None, None, p, gates)
+        pr2 = sensor.preregistration_result()
+        outs.append((pr1, pr2, r1, r2))
+        sensor.close()
+    (a1, a2, ra1, ra2), (b1, b2, rb1, rb2) = outs
+    for x, y in ((a1, b1), (a2, b2)):
+        assert (x["candidates"], x["idx"], x["i"]) == (y["candidates"], y["idx"], y["i"]) and np.array_equal(x["T"], y["T"])
+    for x, y in ((ra1, rb1), (ra2, rb2)):
+        assert (x.icp.pairs, x.icp.iterations, x.pushed) == (y.icp.pairs, y.icp.iterations, y.pushed)
+        assert np.array_equal(np.array(x.pose[:]), np.array(y.pose[:]))
+    assert ra1.pushed == 1 and a2["candidates"] > 0
+
+
 def test_hip_matches_the_committed_tsdpdf_fixture():
     """No oracle at run time: the committed vectors of tests/golden/oracle_tsdpdf.npz (make_oracle_fixtures.py) against the HIP path,
     through tsd_tsdpdf_match + tsd_localize(t_init) and through the fused scan (tsd_scan_preregister)."""
