@@ -51,7 +51,7 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 MERGE_EVERY = 50             # occupancy merge period in scans (cfg 4/5)
 CALIB_DOUBLES = 8 << 20      # k_calib_rmw: 2 arrays x 8 Mi doubles -> 128 MiB read + 128 MiB written per launch
-PROFILE_TAG = "r3"           # profiles/<tag>_<workload>_pmc.json: the committed rocprofv3 PMC summary of this round
+PROFILE_TAG = "r4"           # profiles/<tag>_<workload>_pmc.json: the committed rocprofv3 PMC summary of this round
 STREAM_DOUBLES = 48 << 20    # tsd_measure_stream: 2 arrays x 48 Mi doubles = 768 MiB footprint (3x the 256 MiB Infinity Cache)
 STAGES = ("raycast", "icp", "push_classify", "push_update", "push_halo")
 
@@ -80,6 +80,16 @@ def pmc_traffic(kernel: str, key: str):
         fr = known / (cal["FETCH_SIZE_KB"] * 1024.0)
         fw = known / (cal["WRITE_SIZE_KB"] * 1024.0)
     return (k["FETCH_SIZE_KB"] * fr + k["WRITE_SIZE_KB"] * fw) * 1024.0, os.path.basename(path)
+
+
+def profile_algorithmic_bytes(key: str):
+    """algorithmic bytes per launch of the bench line that ran UNDER rocprofv3 for this workload (the run the PMC counters belong to)"""
+    bj = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_{key}_bench_under_rocprof.json")
+    try:
+        lines = [l for l in open(bj).read().splitlines() if l.startswith("{")]
+        return float(json.loads(lines[-1])["roofline"]["algorithmic_bytes_per_launch"])
+    except Exception:
+        return None
 
 
 def profile_fraction(kernel: str, key: str):
@@ -233,6 +243,7 @@ def main():
     ap.add_argument("--no-stream", action="store_true", help="skip the stream-bandwidth measurement (roofline.peak_measured): profile passes, whose "
                                                             "calibration counts k_calib_rmw launches of ONE known size")
     ap.add_argument("--no-second-pass", action="store_true", help="skip the comparison passes (value_no_lookahead, value_async_mapping)")
+    ap.add_argument("--comparison-passes", type=int, default=3, help="passes behind value_no_lookahead / value_async_mapping (median reported)")
     ap.add_argument("--async-mapping", action="store_true",
                     help="`value` with the facade's async_mapping = 1 (the push beside the next registration, the next ray cast one "
                          "push behind: the reference's own ThreadMapping is asynchronous); default: strict order, and the "
@@ -338,12 +349,18 @@ def main():
                 "of": "mean per merge on the slowest rank; HIP events: extraction kernels on the grid's stream, then map-written -> "
                       "end of ncclAllReduce(int8, max) on the communicator's stream (includes the wait for the other ranks)",
                 "bytes_per_rank_ring": multigpu.merge_bytes_per_rank(gc.cells, world_size)}
+            if line.get("merge_checked") is False:
+                print("bench.py: the RCCL occupancy merge is NOT the element-wise maximum of the ranks' maps: not a valid measurement", file=sys.stderr)
+                rc = 4
             if len(ranks) != world_size or worlds != [world_size]:
                 print(f"bench.py: {len(ranks)} ranks reported RCCL world sizes {worlds}, expected {world_size} of {world_size}: not a valid "
                       f"{world_size}-GPU measurement", file=sys.stderr)
                 rc = 4
         line["roofline"] = {"kernel": "k_push_update", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                            # (counter bytes over the algorithmic bytes of the SAME run -- the one under rocprofv3 -- not of this one,
+                            # which may have a different number of steps)
+                            "traffic_ratio": (traffic / profile_algorithmic_bytes(key)) if (traffic and profile_algorithmic_bytes(key)) else None,
                             "peak_measured": stream_best, "peak_measured_mean": stream_mean,
                             "frac_of_peak_measured": (achieved / stream_best) if stream_best else None,
                             "peak_measured_how": f"k_calib_rmw (read-modify-write stream, 8 B per lane like the push) over a "
@@ -362,7 +379,8 @@ def main():
                 "kernels": "k_push_classify + k_push_update + k_push_halo", "sum_avg_launch_ms": t_push,
                 "achieved": bytes_per_launch / (t_push * 1e-3) / 1e9, "frac": bytes_per_launch / (t_push * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "of": "the same algorithmic bytes over the summed average durations of the three kernels of one push (sampled dispatches)"}
-        if not args.no_cpu_baseline and world_size == 1 and args.robots == 1 and not args.registration_mode:
+        if not args.no_cpu_baseline and args.robots == 1 and not args.registration_mode:
+            # (rank 0 only, whatever N: one robot's workload on this box's host cores; the other ranks wait at the closing barrier)
             line["cpu_baseline"] = cpu_baseline(args.config, scene, mode, min(args.cpu_scans, K))
         if rc == 0:
             print(json.dumps(line), flush=True)
@@ -584,8 +602,28 @@ def run_slam(args, gc, geo, scene, K, W, every, every_upd, every_icp, device, ra
             node.laser(scans[r][0], geo.angle_min, geo.angle_increment, robot=r)          # init: freeFootprint + initPush
         run_range(1, 1 + W)
         grid.sync()
+        merge_checked = None
         if merger is not None:
             merger.wait()
+            # ONCE, before anything is timed: is the native merge (extraction kernels + ncclAllReduce(int8, max) over RCCL) the
+            # element-wise maximum of the ranks' OWN occupancy maps?  Every rank extracts its own map (tsd_occupancy), the maps'
+            # maximum is formed over the control plane (gloo, CPU), and every rank compares.  The reference has no merge
+            # (SlamNode.cpp:101-122 shares one grid): the checker is the definition.
+            merger.merge_async()
+            merged = merger.merged().reshape(-1)
+            own, _ = grid.occupancy(False, 2)
+            t = torch.from_numpy(np.ascontiguousarray(own.reshape(-1)))
+            if args.pg_backend == "nccl":
+                t = t.to(f"cuda:{local_rank}")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            want = t.cpu().numpy()
+            mine_ok = bool(np.array_equal(merged, want)) and bool((own == 100).any())
+            ok = torch.tensor([1 if mine_ok else 0], dtype=torch.int32, device=t.device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            merge_checked = bool(int(ok.item()) == 1)
+            if not mine_ok:
+                print(f"bench.py: rank {rank}: the RCCL occupancy merge differs from the element-wise maximum of the ranks' maps in "
+                      f"{int((merged != want).sum())} cells", file=sys.stderr)
             warm_merge = merger.merge_times()    # (the warm-up merges -- RCCL's channel set-up -- are not what a merge costs)
         grid.push_stats_total(reset=True)
         grid.profile(True, kernels=f"push_update:{every_upd},icp:{every_icp},all/{every}")      # HIP events on every n-th dispatch of each kernel
@@ -669,6 +707,8 @@ def run_slam(args, gc, geo, scene, K, W, every, every_upd, every_icp, device, ra
                        "lookahead": bool(lookahead and R == 1),
                        "occupancy_merge_every": MERGE_EVERY if use_dist else None,
                        "occupancy_merges_in_timed_region": merges[0] if merger is not None else None,
+                       "occupancy_merge_checked": "merged map == element-wise max of every rank's own tsd_occupancy map, on every rank, once in the warm-up"
+                                                  if merge_checked else None,
                        "note": "single-stream latency chain per robot: a scan's ray cast needs the previous scan's push"
                                if R == 1 else "robots' scans batched by the facade's dispatcher (tsd_batch_*), two batch slots in turn",
                        "scans_per_batch": (bstats[1] / max(bstats[0], 1)) if R > 1 else None,
@@ -688,6 +728,8 @@ def run_slam(args, gc, geo, scene, K, W, every, every_upd, every_icp, device, ra
             "tracking_error_m": max(errs),
             "_stats": (st, pushes, upd_ms, upd_launches), "_stream": stream, "_ranks": ranks,
         }
+        if merger is not None:
+            out["merge_checked"] = merge_checked
         if args.occupancy and occ_n:
             out["ms_occupancy_extract"] = occ_ms / occ_n
         if merger is not None:
@@ -701,11 +743,15 @@ def run_slam(args, gc, geo, scene, K, W, every, every_upd, every_icp, device, ra
     if R == 1 and not use_dist and not args.no_lookahead and not args.no_second_pass:
         # the same K scans on a fresh node WITHOUT announcing the next scan: what a live 40 Hz scanner gets (it never has the
         # next LaserScan queued; the reference's localiser takes the newest scan, ThreadLocalize.cpp:319-332)
-        out["value_no_lookahead"] = one_pass(False, False, args.async_mapping)["value"]
+        # (three passes each, median + spread: one pass of 20 scans on a fresh node is not a number -- VERDICT r3)
+        def med3(*a):
+            v = sorted(one_pass(*a)["value"] for _ in range(args.comparison_passes))
+            return v[len(v) // 2], {"min": v[0], "max": v[-1], "passes": len(v)}
+        out["value_no_lookahead"], out["value_no_lookahead_spread"] = med3(False, False, args.async_mapping)
         if not args.async_mapping:
             # ... and with the mapper asynchronous like the reference's (ThreadMapping.cpp:51-76): a different, equally legitimate order
             # of the same work (tests/test_gpu_async_mapping.py) -- reported beside `value`, never as it
-            out["value_async_mapping"] = one_pass(True, False, True)["value"]
+            out["value_async_mapping"], out["value_async_mapping_spread"] = med3(True, False, True)
     return out
 
 

@@ -399,6 +399,10 @@ int tsd_scan_preregister(tsd_sensor* s, const tsd_tsdpdf_params* params, const d
  * reference's interleavings, and a deterministic one), and the push runs beside the next registration on a stream of its own.  Every
  * other entry point of the context is ordered behind a push still in flight there.  Not while a scan is in flight. */
 int tsd_sensor_set_async_mapping(tsd_sensor* s, int on);
+/* TEST HOOK: every asynchronous push of this context is held back by `microseconds` on the push stream (a one-wave kernel ahead of
+ * it), 0 = off.  Lets a test make the push stream lag behind the registrations the way a busy device can
+ * (tests/test_gpu_async_mapping.py: the scan / table buffers of a lagging push must not be re-staged under it). */
+int tsd_debug_stall_push_stream(tsd_ctx* ctx, unsigned int microseconds);
 
 /* the pre-registration's outcome for the scan collected last (TBest, probability, winning pair, counts) */
 int tsd_scan_preregistration_result(tsd_sensor* s, tsd_tsdpdf_result* result);

@@ -172,6 +172,7 @@ ABI = {
     "tsd_scan_preregister": (C.c_int, [C.c_void_p, C.POINTER(TsdPdfParams), _dp, _u8p, _ip, _ip, _ip]),
     "tsd_scan_preregistration_result": (C.c_int, [C.c_void_p, C.POINTER(TsdPdfResult)]),
     "tsd_sensor_set_async_mapping": (C.c_int, [C.c_void_p, C.c_int]),
+    "tsd_debug_stall_push_stream": (C.c_int, [C.c_void_p, C.c_uint]),
     "tsd_color_image": (C.c_int, [C.c_void_p, _u8p, C.c_uint, C.c_uint]),
     "tsd_store_grid_text": (C.c_int, [C.c_void_p, C.c_char_p]),
     "tsd_load_grid_text": (C.c_int, [C.c_void_p, C.c_char_p]),

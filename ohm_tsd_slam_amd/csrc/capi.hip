@@ -339,6 +339,8 @@ tsd_ctx* tsd_create(int device, int map_size_log2, double cell_size, double max_
   ctx->device = device;
   ctx->map_log2 = map_size_log2;
   { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->n_cus = cus; }
+  // (tests: a device that shows fewer compute units -- a compute partition, a CU-masked queue -- sizes the resident grids smaller)
+  if (const char* e = std::getenv("TSD_DEBUG_N_CUS")) { const int v = std::atoi(e); if (v > 0 && v < ctx->n_cus) ctx->n_cus = v; }
   GridDev& g = ctx->grid;
   // TsdGrid::init (TsdGrid.cpp:112-169)
   g.N = 1 << map_size_log2;
@@ -459,7 +461,7 @@ void tsd_destroy(tsd_ctx* ctx)
   if (ctx->stream2) hipStreamDestroy(ctx->stream2);
   if (ctx->stream_push) { hipStreamSynchronize(ctx->stream_push); hipStreamDestroy(ctx->stream_push); }
   if (ctx->ev_async_rc) hipEventDestroy(ctx->ev_async_rc);
-  if (ctx->ev_async_push) hipEventDestroy(ctx->ev_async_push);
+  // (ev_async_push is one of a sensor's ev_slot_push[]: the sensor owns it)
   for (hipEvent_t e : ctx->event_pool) hipEventDestroy(e);
   for (int s = 0; s < tsd_ctx::kSlots; s++) {
     if (ctx->h_stage[s]) hipHostFree(ctx->h_stage[s]);
@@ -469,6 +471,8 @@ void tsd_destroy(tsd_ctx* ctx)
   hipFree(ctx->d_coords); /* (+ d_normals, d_mask_m: one block) */ hipFree(ctx->d_mnormals); hipFree(ctx->d_model);
   hipFree(ctx->d_scene); hipFree(ctx->d_morig); hipFree(ctx->d_start); hipFree(ctx->d_icp_res); hipFree(ctx->d_icp_trace); hipHostFree(ctx->h_icp_res); hipHostFree(ctx->h_out);
   hipFree(ctx->d_occ); hipFree(ctx->d_occ_count); hipFree(ctx->d_occ_heads); hipFree(ctx->d_occ_list);
+  if (ctx->d_occ_out) hipFree(ctx->d_occ_out);
+  if (ctx->d_img) hipFree(ctx->d_img);
   if (ctx->d_pdf) hipFree(ctx->d_pdf);
   if (ctx->h_pdf) hipHostFree(ctx->h_pdf);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -818,9 +822,11 @@ int tsd_icp_trace(tsd_ctx* ctx, double* out, int max_iters)
   if (!ctx || !out || max_iters < 0) return TSD_E_ARG;
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (int rcd_ = drain_async_push(ctx)) return rcd_;
-  TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   const int n = max_iters < 2 * TSD_ICP_TRACE_MAX ? max_iters : 2 * TSD_ICP_TRACE_MAX;     // (rows beyond TSD_ICP_TRACE_MAX: diagnostic builds' scratch)
-  TSD_HIP_CHECK(ctx, hipMemcpy(out, ctx->d_icp_trace, sizeof(double) * TSD_ICP_TRACE_STRIDE * (size_t)n, hipMemcpyDeviceToHost));
+  // (every copy of this library goes through the context's own stream: a plain hipMemcpy / hipMemset brings the NULL stream
+  // alive, and that stream takes one of the few hardware queues the scan / batch streams are mapped onto -- DESIGN 5)
+  TSD_HIP_CHECK(ctx, hipMemcpyAsync(out, ctx->d_icp_trace, sizeof(double) * TSD_ICP_TRACE_STRIDE * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return TSD_OK;
 }
 
@@ -829,10 +835,10 @@ int tsd_download_tile_state(tsd_ctx* ctx, uint8_t* initialized, double* init_wei
   if (!ctx || !initialized || !init_weight) return TSD_E_ARG;
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (int rcd_ = drain_async_push(ctx)) return rcd_;
-  TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   const size_t T = (size_t)ctx->grid.tiles;
-  TSD_HIP_CHECK(ctx, hipMemcpy(initialized, ctx->grid.flags, T, hipMemcpyDeviceToHost));
-  TSD_HIP_CHECK(ctx, hipMemcpy(init_weight, ctx->grid.init_weight, T * sizeof(double), hipMemcpyDeviceToHost));
+  TSD_HIP_CHECK(ctx, hipMemcpyAsync(initialized, ctx->grid.flags, T, hipMemcpyDeviceToHost, ctx->stream));
+  TSD_HIP_CHECK(ctx, hipMemcpyAsync(init_weight, ctx->grid.init_weight, T * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return TSD_OK;
 }
 
@@ -886,8 +892,9 @@ int tsd_upload_tiles(tsd_ctx* ctx, const uint8_t* initialized, const double* ini
   TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   const GridDev& g = ctx->grid;
   const size_t T = (size_t)g.tiles;
-  TSD_HIP_CHECK(ctx, hipMemcpy(g.flags, initialized, T, hipMemcpyHostToDevice));
-  TSD_HIP_CHECK(ctx, hipMemcpy(g.init_weight, init_weight, T * sizeof(double), hipMemcpyHostToDevice));
+  TSD_HIP_CHECK(ctx, hipMemcpyAsync(g.flags, initialized, T, hipMemcpyHostToDevice, ctx->stream));
+  TSD_HIP_CHECK(ctx, hipMemcpyAsync(g.init_weight, init_weight, T * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   const int chunk = g.tiles < kIoChunk ? g.tiles : kIoChunk;
   double* d_t = nullptr; double* d_w = nullptr;
   const size_t cb = (size_t)chunk * TSD_TILE_CELLS * sizeof(double);
@@ -1080,17 +1087,23 @@ int tsd_color_image(tsd_ctx* ctx, uint8_t* rgb_host, unsigned int width, unsigne
   const double stepW = ctx->grid.max_x / (double)width, stepH = ctx->grid.max_y / (double)height;
   { double v = 0.0; for (unsigned w = 0; w < width; w++) { pq[w] = v; v += stepW; } }
   { double v = 0.0; for (unsigned h = 0; h < height; h++) { pq[(size_t)width + h] = v; v += stepH; } }
-  double* d_pq = nullptr; uint8_t* d_img = nullptr;
-  const size_t img_bytes = (size_t)3 * width * height;
-  TSD_HIP_CHECK(ctx, hipMalloc(&d_pq, pq.size() * sizeof(double)));
-  hipError_t e = hipMalloc(&d_img, img_bytes);
-  if (e != hipSuccess) { hipFree(d_pq); return set_error(ctx, TSD_E_HIP, "hipMalloc(image)", e); }
+  // (device staging kept by the context and grown on demand: ThreadGrid publishes map and image every occ_grid_time_interval
+  // beside the localisers, ThreadGrid.cpp:72-133 -- a hipMalloc / hipFree pair per call would stall every stream of the device)
+  const size_t img_bytes = (size_t)3 * width * height, pq_bytes = pq.size() * sizeof(double);
+  if (ctx->img_bytes < img_bytes + pq_bytes + 64) {
+    TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_img) hipFree(ctx->d_img);
+    ctx->d_img = nullptr; ctx->img_bytes = 0;
+    TSD_HIP_CHECK(ctx, hipMalloc(&ctx->d_img, img_bytes + pq_bytes + 64));
+    ctx->img_bytes = img_bytes + pq_bytes + 64;
+  }
+  double* d_pq = reinterpret_cast<double*>(ctx->d_img);
+  uint8_t* d_img = ctx->d_img + ((pq_bytes + 63) & ~(size_t)63);
   int rc = TSD_OK;
-  e = hipMemcpyAsync(d_pq, pq.data(), pq.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+  hipError_t e = hipMemcpyAsync(d_pq, pq.data(), pq_bytes, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) rc = launch_color_image(ctx, d_pq, d_pq + width, width, height, d_img);
-  if (e == hipSuccess && rc == TSD_OK) e = hipStreamSynchronize(ctx->stream);
-  if (e == hipSuccess && rc == TSD_OK) e = hipMemcpy(rgb_host, d_img, img_bytes, hipMemcpyDeviceToHost);
-  hipFree(d_pq); hipFree(d_img);
+  if (e == hipSuccess && rc == TSD_OK) e = hipMemcpyAsync(rgb_host, d_img, img_bytes, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);       // (also when the launch failed: `pq` must outlive its copy)
   if (e != hipSuccess) return set_error(ctx, TSD_E_HIP, "tsd_color_image", e);
   return rc;
 }
@@ -1101,18 +1114,17 @@ int tsd_occupancy(tsd_ctx* ctx, int8_t* occ_host, int inflate, int inflate_facto
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (int rcd_ = drain_async_push(ctx)) return rcd_;
   const size_t cells = (size_t)ctx->grid.N * ctx->grid.N;
-  int8_t* d_out = nullptr;
-  TSD_HIP_CHECK(ctx, hipMalloc(&d_out, cells));
-  int rc = launch_occupancy(ctx, d_out, inflate, inflate_factor);
+  if (!ctx->d_occ_out) TSD_HIP_CHECK(ctx, hipMalloc(&ctx->d_occ_out, cells));      // once per context (see tsd_color_image)
+  int rc = launch_occupancy(ctx, ctx->d_occ_out, inflate, inflate_factor);
   if (rc == TSD_OK) {
-    hipError_t e = hipStreamSynchronize(ctx->stream);
-    if (e == hipSuccess) e = hipMemcpy(occ_host, d_out, cells, hipMemcpyDeviceToHost);
     int n = 0;
-    if (e == hipSuccess) e = hipMemcpy(&n, ctx->d_occ_count, sizeof(int), hipMemcpyDeviceToHost);
+    hipError_t e = hipMemcpyAsync(occ_host, ctx->d_occ_out, cells, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&n, ctx->d_occ_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    const hipError_t es = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = es;
     if (n_surface) *n_surface = n;
     if (e != hipSuccess) rc = set_error(ctx, TSD_E_HIP, "tsd_occupancy copy", e);
   }
-  hipFree(d_out);
   return rc;
 }
 
@@ -1296,6 +1308,14 @@ void tsd_sensor_destroy(tsd_sensor* s)
   if (s->ev_pre) hipEventDestroy(s->ev_pre);
   if (s->ev_pre_done) hipEventDestroy(s->ev_pre_done);
   if (s->d_push_slot) { if (s->ctx && s->ctx->stream_push) hipStreamSynchronize(s->ctx->stream_push); hipFree(s->d_push_slot); }
+  for (int i = 0; i < 3; i++)
+    if (s->ev_slot_push[i]) {
+      if (s->ctx && s->ctx->ev_async_push == s->ev_slot_push[i]) {      // (the push stream was drained above)
+        if (s->ctx->async_pending) hipStreamWaitEvent(s->ctx->stream, s->ev_slot_push[i], 0);
+        s->ctx->async_pending = false; s->ctx->ev_async_push = nullptr;
+      }
+      hipEventDestroy(s->ev_slot_push[i]);
+    }
   if (s->d_pre) hipFree(s->d_pre);
   if (s->h_pre) hipHostFree(s->h_pre);
   hipFree(s->d_rmq2[0]); hipFree(s->d_rmq2[1]); hipFree(s->d_rmq2[2]);
@@ -1370,6 +1390,13 @@ static int scan_stage_impl(tsd_sensor* s, const double* ranges, const uint8_t* m
   const int sslot = s->stage_slot;
   char* d_scan = s->d_scan2[sslot];
   s->stage_slot = (s->stage_slot + 1) % 3;
+  // Asynchronous mapping: the push that last read this buffer (three scans back) ran on the push stream beside a registration, and
+  // nothing the host has seen since is ordered behind it -- the copy and the tables below wait for that push's own event (done long
+  // ago in practice: one query; the stream-side wait is the fall-back).  Strict order: see tsd_sensor::stage_slot.
+  if (s->slot_push_valid[sslot]) {
+    if (!host_saw_event(s->ev_slot_push[sslot], 0)) TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream2, s->ev_slot_push[sslot], 0));
+    else s->slot_push_valid[sslot] = false;
+  }
   TSD_HIP_CHECK(ctx, hipMemcpyAsync(d_scan, h, nb * 10, hipMemcpyHostToDevice, ctx->stream2));
   LAP(2);
   TSD_HIP_CHECK(ctx, hipEventRecord(ctx->stage_ev[slot], ctx->stream2));
@@ -1406,13 +1433,23 @@ int tsd_sensor_set_async_mapping(tsd_sensor* s, int on)
     if (!ctx->stream_push) TSD_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream_push, hipStreamNonBlocking));
     // (both events order kernels of ONE device against each other: no system-scope fence when they complete)
     if (!ctx->ev_async_rc) TSD_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_async_rc, hipEventDisableTiming | hipEventDisableSystemFence));
-    if (!ctx->ev_async_push) TSD_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_async_push, hipEventDisableTiming | hipEventDisableSystemFence));
+    // "the push of the scan that used scan / table buffer i is done": one event per buffer, so that the staging of a later scan
+    // into that buffer can be ordered behind the push that last read it (scan_stage_impl); ctx->ev_async_push is the newest of them
+    for (int i = 0; i < 3; i++)
+      if (!s->ev_slot_push[i]) TSD_HIP_CHECK(ctx, hipEventCreateWithFlags(&s->ev_slot_push[i], hipEventDisableTiming | hipEventDisableSystemFence));
     if (!s->d_push_slot) TSD_HIP_CHECK(ctx, hipMalloc(&s->d_push_slot, 2 * sizeof(tsd::PushArgs)));
   }
   s->async_mapping = on != 0;
   // a ray cast enqueued ahead by the previous scan saw (strict) or did not see (asynchronous) that scan's push: the next scan of the
   // other kind casts again
   s->rc_pending = false;
+  return TSD_OK;
+}
+
+int tsd_debug_stall_push_stream(tsd_ctx* ctx, unsigned int microseconds)
+{
+  if (!ctx) return TSD_E_ARG;
+  ctx->debug_push_stall_us = microseconds;
   return TSD_OK;
 }
 
@@ -1557,9 +1594,12 @@ int tsd_scan_submit(tsd_sensor* s, const double* ranges, const uint8_t* mask, co
       LaunchTarget tg;
       tg.rmq = s->st_rmq;
       TargetScope scope(ctx, &tg);
+      if (ctx->debug_push_stall_us) launch_stall(ctx, ctx->stream_push, ctx->debug_push_stall_us);     // (tests: a push stream that lags)
       rc = launch_push(ctx, pa, s->pos[0], s->pos[1], gates->reg_trs_max, push_slot, d_ranges, d_mask_push, ctx->stream_push);
     }
     if (rc != TSD_OK) return rc;
+    ctx->ev_async_push = s->ev_slot_push[s->st_slot];      // (st_slot: the buffers of the scan being submitted)
+    s->slot_push_valid[s->st_slot] = true;
     TSD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_async_push, ctx->stream_push));
     (void)hipStreamQuery(ctx->stream_push);
     ctx->async_pending = true;

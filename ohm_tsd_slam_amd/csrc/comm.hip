@@ -73,12 +73,17 @@ tsd_comm* tsd_comm_create(tsd_ctx* ctx, int world_size, int rank, const char id_
     std::fprintf(stderr, "tsd_comm_create: no device memory for the map\n");
     delete c; return nullptr;
   }
-  hipMemset(c->d_map, 0xFF, c->cells2);           // -1 = unknown
+  // (-1 = unknown; filled on the communicator's own stream, created first: a plain hipMemset would bring the NULL stream alive,
+  // which takes one of the few hardware queues the scan's streams are mapped onto -- DESIGN 5)
   if (hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_extracted, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_reduced, hipEventDisableTiming) != hipSuccess) {
     std::fprintf(stderr, "tsd_comm_create: stream / events\n");
     hipFree(c->d_map); delete c; return nullptr;
+  }
+  if (hipMemsetAsync(c->d_map, 0xFF, c->cells2, c->cstream) != hipSuccess || hipStreamSynchronize(c->cstream) != hipSuccess) {
+    std::fprintf(stderr, "tsd_comm_create: clearing the map\n");
+    hipStreamDestroy(c->cstream); hipFree(c->d_map); delete c; return nullptr;
   }
   ncclUniqueId id;
   std::memcpy(id.internal, id_in, TSD_COMM_ID_BYTES);

@@ -349,7 +349,9 @@ struct Mode3Timing {
     std::fprintf(stderr, "mode 3, us per scan: ray cast %.1f | scene points %.1f | TSD_PDF match %.1f | registration (fused) %.1f | finish + push %.1f\n",
                  acc[0] / scans, acc[1] / scans, acc[2] / scans, acc[3] / scans, acc[4] / scans);
   }
-} g_m3;
+};
+// (one per localiser thread: every robot of a multi-robot node takes this path from its own thread)
+thread_local Mode3Timing g_m3;
 }
 
 void ThreadLocalize::processScanPreRegistered(ScanReport& rep)
@@ -463,6 +465,9 @@ void ThreadLocalize::processScanFused(ScanReport& rep)
     const bool useStaged = _stagedValid;
     _stagedValid = false;
     const bool preStaged = _preStagedValid && useStaged;      // (armed while the previous scan registered; a dropped staged scan takes it along)
+    // ... but not its draws: they do not depend on the scan, and the scan that came instead uses the very same ones, so that a seeded
+    // sequence (tsdpdf_seed) stays one drawStreams() call per REGISTERED scan, as in the unfused path
+    if(_preStagedValid && !useStaged) _drawsReady = true;
     _preStagedValid = false;
     rc = TSD_OK;
     if(_regMode == 3 && _preMatcher && !preStaged)

@@ -737,13 +737,16 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
     ta.axx = (float)(a.Pi[0] * g.cs); ta.axy = (float)(a.Pi[1] * g.cs); ta.ayx = (float)(a.Pi[3] * g.cs); ta.ayy = (float)(a.Pi[4] * g.cs);
     ta.cs2 = (float)(g.cs * g.cs);
     // the queue: tile 0 of this workgroup is its own index, the others come off its ticket head, requested two tiles ahead
-    unsigned int* const head = cntw + CNT_TICKET + TICKET_STRIDE * (blockIdx.x % TICKET_HEADS);
-    const unsigned int head_first = gridDim.x + blockIdx.x % TICKET_HEADS;
+    // (a grid smaller than TICKET_HEADS -- a small compute partition, a CU mask -- uses as many heads as it has workgroups: a head
+    // nobody owns would leave its residue class of the list unprocessed)
+    const unsigned int n_heads = gridDim.x < (unsigned)TICKET_HEADS ? gridDim.x : (unsigned)TICKET_HEADS;
+    unsigned int* const head = cntw + CNT_TICKET + TICKET_STRIDE * (blockIdx.x % n_heads);
+    const unsigned int head_first = gridDim.x + blockIdx.x % n_heads;
     // (the RAW counter value is carried to where the ticket is needed: nothing may consume the returning atomic early, or thread 0's
     // wave sits out a device-scope round trip in the middle of its step; csrc/Makefile switches the compiler's atomic optimiser off for
     // this file for the same reason -- it would turn the one-lane atomic into a wave scan that needs the result at once)
     auto draw = [&]() { return atomicAdd(head, 1u); };
-    auto ticket_of = [&](unsigned raw) { return head_first + TICKET_HEADS * raw; };
+    auto ticket_of = [&](unsigned raw) { return head_first + n_heads * raw; };
     unsigned int tk_pending = 0u;                  // (thread 0) the ticket requested during the previous step
     if (tid == 0) {
       s_tk[0] = blockIdx.x;

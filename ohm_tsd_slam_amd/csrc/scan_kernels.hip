@@ -60,6 +60,23 @@ __global__ void __launch_bounds__(64) k_probe_wait(const unsigned int* flag, uns
   }
 }
 
+// tests only (tsd_debug_stall_push_stream): one wave that holds its stream for `us` microseconds of the 100 MHz wall clock (bounded)
+__global__ void __launch_bounds__(64) k_stall(unsigned int us)
+{
+  if (threadIdx.x == 0) {
+    const unsigned long long t0 = wall_clock64(), ticks = 100ull * us;
+    unsigned int polls = 0u;
+    while (wall_clock64() - t0 < ticks && ++polls < 4000000u) __builtin_amdgcn_s_sleep(32);
+  }
+}
+
+int launch_stall(tsd_ctx* ctx, hipStream_t stream, unsigned int us)
+{
+  hipLaunchKernelGGL(k_stall, dim3(1), dim3(64), 0, stream, us);
+  TSD_HIP_CHECK(ctx, hipGetLastError());
+  return TSD_OK;
+}
+
 int launch_set_flag(tsd_ctx* ctx, hipStream_t stream, unsigned int* flag, unsigned int value)
 {
   hipLaunchKernelGGL(k_set_flag, dim3(1), dim3(64), 0, stream, flag, value);

@@ -194,7 +194,8 @@ struct tsd_ctx {
   // asynchronous mapping (tsd_sensor_set_async_mapping): the fused scan's push on a stream of its own, beside the next registration
   hipStream_t stream_push = nullptr;
   hipEvent_t ev_async_rc = nullptr;          // "the next scan's ray cast has read the grid" (recorded on `stream`)
-  hipEvent_t ev_async_push = nullptr;        // "the push enqueued last on stream_push is done"
+  hipEvent_t ev_async_push = nullptr;        // "the push enqueued last on stream_push is done" (one of a sensor's ev_slot_push[], not owned)
+  unsigned int debug_push_stall_us = 0;      // tsd_debug_stall_push_stream (tests)
   bool async_pending = false;                // a push on stream_push that `stream` has not been ordered behind yet
   hipEvent_t ev_tables = nullptr;
 
@@ -232,7 +233,8 @@ struct tsd_ctx {
   unsigned int* d_occ_heads = nullptr;   // sharded counters (two sets, used in turn) of k_occ_mark's work list (occupancy_kernels.hip)
   int occ_parity = 0;
   uint32_t* d_occ_list = nullptr;
-
+  int8_t* d_occ_out = nullptr;   // tsd_occupancy's device staging (allocated on first use, kept)
+  uint8_t* d_img = nullptr; size_t img_bytes = 0;   // tsd_color_image's (coordinate tables + image), grown on demand
 
   // profiling: bit i of profile_mask times kernel i (names in capi.hip: kKernelNames)
   unsigned profile_mask = 0;
@@ -265,7 +267,12 @@ struct tsd_sensor {
   char* st_rmq = nullptr; int st_slot = 0;
   int stage_slot = 0;              // the scan / table buffers are used in turn, THREE of them: the scan staged ahead of scan k+2 goes
                                    // where scan k was, and by then the host has seen the result of scan k+1, whose ray cast ran behind
-                                   // the push of scan k on the stream -- so that push is done without any event on the stream
+                                   // the push of scan k on the stream -- so that push is done without any event on the stream.
+                                   // That argument needs the STRICT order.  With asynchronous mapping ray cast k+1 runs behind push
+                                   // k-1 and push k beside registration k+1 on the push stream: the host has no proof that it is
+                                   // done, so the staging waits for the buffer's own push event (below).
+  hipEvent_t ev_slot_push[3] = {nullptr, nullptr, nullptr};   // asynchronous mapping: "the push that read buffer i is done"
+  bool slot_push_valid[3] = {false, false, false};            // ... recorded and not yet seen complete
   // fused registration_mode 3 (tsd_scan_preregister, tsdpdf.hip): inputs of the pre-registration that the next tsd_scan_submit runs
   // on the device between its ray cast and its registration; one device + one pinned buffer, grown on demand
   char* d_pre = nullptr; char* h_pre = nullptr; size_t pre_bytes = 0;
@@ -392,6 +399,7 @@ int launch_wait_seq(tsd_ctx* ctx, const unsigned long long* seq, unsigned long l
                     unsigned int poll_bound);
 // one wave on `stream` that publishes *flag = value (device scope) once everything ahead of it on the stream is done
 int launch_set_flag(tsd_ctx* ctx, hipStream_t stream, unsigned int* flag, unsigned int value);
+int launch_stall(tsd_ctx* ctx, hipStream_t stream, unsigned int us);
 // start-up probe of tsd_batch_create: can a kernel on stream `a` wait for a flag that a kernel launched AFTER it on stream `b`
 // sets?  (No when the two streams share an in-order hardware queue, or when something serialises dispatches.)
 int probe_cross_stream_wait(tsd_ctx* ctx, hipStream_t a, hipStream_t b, unsigned int* d_flag2, bool* ok);

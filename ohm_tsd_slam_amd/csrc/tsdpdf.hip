@@ -644,6 +644,8 @@ extern "C" int tsd_tsdpdf_match(tsd_ctx* ctx, const double pose33[9], const doub
   if (beams < 1 || beams > TSD_MAX_BEAMS || prm->size_control_set < 0 || prm->size_control_set > PDF_MAX_CONTROL || prm->trials < 0)
     return set_error(ctx, TSD_E_CAPACITY, "tsd_tsdpdf_match: beams / control set out of range", hipSuccess);
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (int rcd_ = drain_async_push(ctx)) return rcd_;     // (the scoring reads the grid: behind a push still on the push stream)
+  TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   // TSD_MODE3_TIMING=1: the host phases of this call (printed every 100 calls)
   static const bool timing = std::getenv("TSD_MODE3_TIMING") != nullptr;
   static double t_acc[6]; static int t_calls;
@@ -832,6 +834,11 @@ extern "C" int tsd_scan_preregister(tsd_sensor* s, const tsd_tsdpdf_params* prm,
   L.off_prob = L.off_K + al((size_t)L.max_cand * sizeof(PdfCandidate)); L.off_hdr = L.off_prob + al((size_t)L.max_cand * 8);
   L.off_res = L.off_hdr + al(sizeof(PdfHeader));
   const size_t total = L.off_res + al(sizeof(PdfResult));
+  // The in-flight scan's arg-max writes its header and result into the PINNED buffer at the offsets of ITS layout (pre_res_off_*),
+  // and tsd_scan_preregistration_result reads them there after the collect: a layout that needs new buffers, or whose inputs would
+  // reach into those records, cannot be armed ahead -- the caller arms it after tsd_scan_collect.
+  if (inflight && s->pre_ran && (total > s->pre_bytes || L.in_bytes > s->pre_res_off_hdr))
+    return set_error(ctx, TSD_E_ARG, "tsd_scan_preregister: a larger layout than the in-flight scan's cannot be armed ahead of its collect", hipSuccess);
   if (total > s->pre_bytes) {
     TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream2));      // (an armed, not yet submitted pre-registration's copy may still read the old buffer)

@@ -1,9 +1,13 @@
 """The N > 1 path on CPU: two ranks (gloo, 127.0.0.1), one robot + one grid per rank.
 
-* The merge SEMANTICS (element-wise max: occupied > free > unknown) with two ranks, through ``multigpu.OccupancyMerger`` --
+* The merge SEMANTICS (element-wise max: occupied > free > unknown) with two ranks, through ``tests/gloo_merger.py`` --
   a test-only twin over ``torch.distributed`` tensors.  It is NOT what ``bench.py --gpus N`` runs: that is the native RCCL
   merge behind the C ABI (``include/tsd_comm.h`` -> ``multigpu.NativeOccupancyMerger``), which needs GPUs (RCCL refuses two
-  ranks on one device; the one-rank run is tests/test_gpu_multigpu_plumbing.py).  The per-rank maps come from the oracle here.
+  ranks on one device; the one-rank run is tests/test_gpu_multigpu_plumbing.py, the N-rank run with its own check against
+  the element-wise maximum is tests/test_gpu_multigpu_nranks.py, skipped below two GPUs).  The per-rank maps come from the
+  oracle here.
+* The COMMON MAP FRAME: robots that start `local_offset_x` apart in one room mark the room's walls in the same cells of their
+  own maps (tests/nranks_common.py holds the check the GPU test applies to the HIP path's maps).
 * The LAUNCH path of ``bench.py``: ``--gpus 2`` without a launcher starts two ranks itself (``--launch-check``: rendezvous only,
   no GPU), refuses to print a line when the machine does not have the GPUs, and refuses a launcher world that is not ``--gpus``."""
 import json
@@ -21,6 +25,7 @@ import torch.multiprocessing as mp  # noqa: E402
 
 from ohm_tsd_slam_amd import multigpu, synth  # noqa: E402
 from tests import helpers as H  # noqa: E402
+from tests import gloo_merger, nranks_common  # noqa: E402
 
 
 def _free_port():
@@ -32,13 +37,10 @@ def _free_port():
 def _rank_map(rank, n_scans=3):
     """Occupancy map of robot `rank` after a few pushes (oracle = checker-side generator of test data)."""
     from oracle import pyoracle as O
-    gc = synth.GridConfig(8, 0.05)
-    geo = synth.ScanGeometry.full_circle_360()
-    off = multigpu.robot_offset_x(rank)
-    world = synth.World("room", gc, start_xy=[0.5 * gc.width + off, 0.5 * gc.width - 0.21])
+    gc, geo, world = nranks_common.setup()
     grid = O.Grid(gc.map_size_log2, gc.cell_size, gc.max_trunc)
     for k in range(n_scans):
-        pose, (x, y, yaw) = H.sensor_pose(world, k)
+        pose, (x, y, yaw) = nranks_common.robot_pose(world, rank, k)
         data, mask = O.ingest_f32(world.scan(x, y, yaw, geo), H.MAX_RANGE, geo.angle_increment)
         grid.push(pose, data, mask, geo.angle_increment, geo.angle_min, H.MAX_RANGE, H.MIN_RANGE, H.LOW_REFL)
     content = np.full(gc.cells * gc.cells, -1, dtype=np.int8)
@@ -52,7 +54,7 @@ def _worker(rank, world_size, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world_size)
     try:
         gc, mine = _rank_map(rank)
-        merger = multigpu.OccupancyMerger(gc.cells)
+        merger = gloo_merger.OccupancyMerger(gc.cells)
         assert merger.active
         merger.fill_from_host(mine)
         merger.merge_async()                       # would overlap the next scans on a GPU
@@ -90,10 +92,24 @@ def test_occupancy_merge_two_ranks_gloo():
     both = (maps[0] == 100) | (maps[1] == 100)
     assert np.array_equal(want == 100, both)
     assert np.array_equal(want == -1, (maps[0] == -1) & (maps[1] == -1))
+    # the two robots start 0.7 m apart in ONE room: the walls land in the same cells of both maps (common map frame)
+    gc = nranks_common.setup()[0]
+    nranks_common.assert_common_frame(maps[0].reshape(gc.cells, gc.cells), maps[1].reshape(gc.cells, gc.cells), gc, 0, 1)
+
+
+def test_common_frame_check_detects_a_wrong_frame():
+    """the check itself: a map expressed in the robot's OWN start frame (shifted by its local_offset_x) must fail it"""
+    gc = nranks_common.setup()[0]
+    a = _rank_map(0)[1].reshape(gc.cells, gc.cells)
+    b = _rank_map(1)[1].reshape(gc.cells, gc.cells)
+    nranks_common.assert_common_frame(a, b, gc, 0, 1)
+    shift = int(round((multigpu.robot_offset_x(0) - multigpu.robot_offset_x(1)) / gc.cell_size))
+    with pytest.raises(AssertionError):
+        nranks_common.assert_common_frame(a, np.roll(b, shift, axis=1), gc, 0, 1)
 
 
 def test_single_rank_is_a_no_op():
-    merger = multigpu.OccupancyMerger(8)
+    merger = gloo_merger.OccupancyMerger(8)
     assert not merger.active
     merger.fill_from_host(np.arange(64, dtype=np.int8) % 3 - 1)
     assert merger.merge_async() is None

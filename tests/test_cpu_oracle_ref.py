@@ -1,10 +1,11 @@
 """Pins the oracle against the REAL reference where the reference builds in this image.
 
 oracle/_ref/libtsd_ref.so is compiled from /root/reference's own PairAssignment.cpp, DistanceFilter.cpp,
-ReciprocalFilter.cpp and mathbase.h (oracle/Makefile target _ref).  It exists only in the build
-container; on the GPU box (no /root/reference, but the prebuilt .so travels) the tests still run, and
-they are skipped only if the library is absent.  The committed fixture tests/golden/ref_chain_*.npz
-(generated from the same library by tests/golden/make_ref_chain_fixture.py) covers that case.
+ReciprocalFilter.cpp and mathbase.h (oracle/Makefile target _ref).  These are CPU tests (`-m "not gpu"`): they run in the build
+container, where /root/reference exists and the library is built, and are skipped wherever the library is absent.  Nothing in
+the `-m gpu` suite loads it (GPUTEST.native_so_loaded lists the product libraries and the oracle only): on the GPU box the
+reference's outputs are represented by the committed fixture tests/golden/ref_chain_pairs.npz (generated from this library by
+tests/golden/make_ref_chain_fixture.py), which the HIP path meets directly (test_hip_pair_chain_equals_compiled_reference_fixture).
 """
 import ctypes as C
 import os

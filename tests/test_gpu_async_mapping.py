@@ -121,6 +121,58 @@ def test_async_mapping_is_exactly_one_push_behind(oracle, cfg, n):
     assert rs["pairs"] > 0
 
 
+class HipFusedAhead(HipSlamFused):
+    """HipSlamFused with the NEXT scan staged ahead of the collect (tsd_scan_submit / _stage / _collect): what the facade does when
+    the next LaserScan is known (ThreadLocalize::announceNext)."""
+
+    def _ingest(self, ranges_f32):
+        o, kw = self.o, self.kw
+        r = np.array(ranges_f32, dtype=np.float32)
+        r[r < kw["laser_min_range"]] = 0.0
+        data, mask = o.ingest_f32(r, kw["max_range"], kw["angle_increment"])
+        _, mask_push = o.ingest_f64(data, kw["max_range"], kw["angle_increment"])
+        return data, mask, mask_push
+
+    def process_scan(self, ranges_f32, nxt_f32=None, staged=False):
+        if not self.initialized:
+            return super().process_scan(ranges_f32)
+        nxt = self._ingest(nxt_f32) if nxt_f32 is not None else None
+        cur = (None, None, None) if staged else self._ingest(ranges_f32)
+        sr = self.sensor.scan_ahead(*cur, self.params, self.gates, nxt=nxt)
+        self.pose = np.array(sr.pose[:]).reshape(3, 3)
+        return dict(pose=self.pose.copy(), pushed=int(sr.pushed), reg_error=int(sr.reg_error), pairs=int(sr.icp.pairs))
+
+
+@pytest.mark.parametrize("stall_us", [0, 3000])
+def test_async_mapping_staged_ahead_under_a_lagging_push_stream(oracle, stall_us):
+    """with the mapper asynchronous, scan k+3 is staged into the scan / table buffers of scan k while nothing the
+    host has seen proves that push k -- on the push stream, beside registration k+1 -- has finished reading them.  Every push is held
+    back by 3 ms here (tsd_debug_stall_push_stream; a registration takes 0.15 ms), so an unguarded staging WOULD overwrite the
+    buffers under the push; the per-buffer push event keeps the order, and results and grid equal the one-push-behind order."""
+    gc, geo, scene = synth.CONFIGS["cfg1"]
+    world = synth.World(scene, gc)
+    n = 24
+    poses = synth.trajectory(world, n)
+    scans = synth.scans_for(world, geo, poses)
+    kw = slam_kwargs(gc, geo)
+    hs = HipFusedAhead(oracle, **kw)
+    oa = OracleOnePushBehind(oracle, **kw)
+    for k in range(n):
+        nxt = scans[k + 1] if (k >= 1 and k + 1 < n) else None
+        rh = hs.process_scan(scans[k], nxt, staged=(k >= 2))
+        if k == 0:
+            hs.sensor.set_async_mapping(True)
+            hs.grid._check(hs.grid.lib.tsd_debug_stall_push_stream(hs.grid.h, stall_us), "tsd_debug_stall_push_stream")
+        ro = oa.process_scan(scans[k])
+        assert (rh["pushed"], rh["reg_error"], rh["pairs"]) == (ro["pushed"], ro["reg_error"], ro["pairs"]), (k, rh, ro)
+        d, a = H.pose_delta(ro["pose"], rh["pose"])
+        assert d <= 1e-9 and a <= 1e-9, (k, d, a)
+    oa.flush()
+    hs.grid.sync()
+    H.assert_grids_equal(oa.g.dump(), hs.grid.download_tiles(), 1e-9)
+    hs.grid._check(hs.grid.lib.tsd_debug_stall_push_stream(hs.grid.h, 0), "tsd_debug_stall_push_stream")
+
+
 def test_async_mapping_with_one_hardware_queue():
     """All streams of the process on ONE in-order hardware queue (GPU_MAX_HW_QUEUES=1): the two hand-offs between the context's stream
     and the push stream must neither deadlock nor change a result -- the cfg 1 case above in a child process (the variable is read

@@ -943,3 +943,19 @@ def test_golden_baseline_config_fixture(tag, cfg, scene):
     assert [dd["cells_valid"], dd["tiles_initialized"]] == [int(tg[0]), int(tg[1])]
     assert abs(dd["sum_tsd"] - tg[2]) <= 1e-6 * max(1.0, abs(tg[2])) and abs(dd["sum_weight"] - tg[3]) <= 1e-6 * max(1.0, abs(tg[3]))
     node.close()
+
+
+def test_push_on_a_device_with_few_compute_units():
+    """k_push_update's ticket queue handed tiles out through 32 heads owned by blockIdx % 32 -- with a resident grid of
+    fewer than 32 workgroups (a small compute partition, a CU mask) whole residue classes of the UPDATE list would never be
+    processed, silently.  TSD_DEBUG_N_CUS=4 makes the context size its launches for four compute units (20 workgroups): the
+    cfg 2 golden digests (bit-exact 64-bit hashes of the whole grid) must still come out."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TSD_DEBUG_N_CUS="4")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "tests/test_gpu_parity.py", "-k",
+                        "golden_baseline_config_fixture and cfg2 or push_comb_scene"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
