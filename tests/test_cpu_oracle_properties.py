@@ -445,3 +445,207 @@ def test_estimators_against_numpy_rederivation():
     tlp = rp["trace"][0]
     assert int(tlp[0]) == len(pm) and abs(tlp[1] - np.mean(np.abs(resid))) <= 1e-15
     assert np.max(np.abs(tlp[4:8] - np.array([math.cos(xsol[0]), math.sin(xsol[0]), xsol[1], xsol[2]]))) <= 1e-11
+
+
+# ------------------------------------------------------------------------------------------------
+# row N3 (TSD_PDF pre-registration): an independent derivation written from TSD_PDFMatching.cpp:31-294, RandomMatching.cpp:41-189
+# and Matrix::pcaAnalysis (gsl/Matrix.cpp:227-326) -- NOT from oracle/tsd_oracle.c, whose restatement is the most inventive
+# one of the oracle: it replaces gsl_linalg_SV_decomp_jacobi of the 2 x 2 scatter matrix by a closed-form eigen-decomposition and
+# carries gsl_stats_mean's long-double running mean by hand.  Here the principal axes come from numpy's LAPACK SVD of the centred
+# n x 2 window itself (no scatter matrix, no closed form) and the mean from np.longdouble.
+def _np_pca_axes(A):
+    """Matrix::pcaAnalysis for an n x 2 point set -> axes[2][4] = rows (x0, x1, y0, y1) of the long / the short principal axis"""
+    n = len(A)
+    cent = np.zeros(2)
+    for j in range(2):                         # gsl_stats_mean: running mean in long double, rounded to double at the end
+        m = np.longdouble(0.0)
+        for i in range(n):
+            m += (np.longdouble(A[i, j]) - m) / np.longdouble(i + 1)
+        cent[j] = float(m)
+    Mc = A - cent
+    _, _, Vt = np.linalg.svd(Mc, full_matrices=True)          # rows of Vt = right singular vectors = eigenvectors of Mc^T Mc, descending
+    V = Vt.T                                                   # (column signs are free: the normal is oriented afterwards)
+    P = V.T @ Mc.T                                             # coordinates in the eigenvectors' system
+    for i in range(2):
+        mx, mn = P[i].max(), P[i].min()
+        align = (mx + mn) / 2.0 if (mx - mn) > 1e-6 else 0.0
+        for j in range(2):
+            cent[j] += V[j, i] * align
+    axes = np.zeros((2, 4))
+    for i in range(2):
+        ext = P[i].max() - P[i].min()
+        for j in range(2):
+            e = V[j, i] * ext / 2.0
+            axes[i, 2 * j], axes[i, 2 * j + 1] = cent[j] - e, cent[j] + e
+    return axes
+
+
+def _np_calc_normals(X, mask_in, mask_out, sr):
+    """RandomMatching::calcNormals (:94-157): PCA over the masked-in points of the window [i - sr, i + sr) -- asymmetric as written"""
+    n = len(X)
+    N = np.zeros((n, 2))
+    mask_out[:sr] = False
+    mask_out[n - sr:] = False
+    for i in range(sr, n - sr):
+        if not mask_in[i]:
+            continue
+        win = [i + j for j in range(-sr, sr) if mask_in[i + j]]
+        if len(win) <= 3:
+            mask_out[i] = False
+            continue
+        ax = _np_pca_axes(X[win])
+        x_long, y_long = ax[0, 1] - ax[0, 0], ax[0, 3] - ax[0, 2]
+        x_short, y_short = ax[1, 1] - ax[1, 0], ax[1, 3] - ax[1, 2]
+        len_long, len_short = x_long * x_long + y_long * y_long, x_short * x_short + y_short * y_short
+        if len_short > 1e-6 and len_long / len_short < 4.0:
+            mask_out[i] = False
+            continue
+        ln = math.sqrt(len_short)
+        sgn = 1.0 if (X[i, 0] * x_short + X[i, 1] * y_short) < 0.0 else -1.0
+        N[i] = sgn * x_short / ln, sgn * y_short / ln
+    return N
+
+
+def np_tsdpdf_match(gc, dump, pose, M, mask_m, S, mask_s, trials, size_control_set, zrand, phi_max, resolution, d_sub, d_ctrl, d_trials):
+    """TSD_PDFMatching::match (:31-294) with the three rand() streams as inputs -> dict(T, prob, idx, i, candidates)"""
+    n, sr = len(M), 10 // 2
+    out = dict(T=np.eye(3), prob=0.0, idx=-1, i=-1, candidates=0)
+    if n < 3:
+        return out
+    m_m = np.array(mask_m, dtype=bool)
+    m_mp = m_m.copy()
+    NM = _np_calc_normals(M, m_m, m_mp, sr)
+    phi_m = np.where(m_mp, np.arctan2(NM[:, 1], NM[:, 0]), -1e6)
+    idx_m = [i for i in range(sr, n - sr) if m_mp[i]]
+    m_s = np.array(mask_s, dtype=bool)
+    m_sp = m_s.copy()
+    probability = 180.0 / float(m_sp.sum())
+    if probability < 0.99:                                                     # subsampleMask (:176-189): one rand() per beam
+        thresh = int(1000.0 - min(max(probability, 0.0), 1.0) * 1000.0 + 0.5)
+        m_sp[(np.asarray(d_sub[:n], dtype=np.int64) % 1000) < thresh] = False
+    NS = _np_calc_normals(S, m_s, m_sp, sr)                                    # (maskIn = the mask BEFORE the sub-sampling)
+    phi_s = np.where(m_sp, np.arctan2(NS[:, 1], NS[:, 0]), -1e6)
+    idx_s = [i for i in range(sr, n - sr) if m_sp[i]]
+    tmp, control = list(idx_s), []                                            # pickControlSet (:52-76): the r-th REMAINING index
+    k = 0
+    while len(control) < min(size_control_set, len(idx_s)):
+        control.append(tmp.pop(int(d_ctrl[k]) % len(tmp)))
+        k += 1
+    C = S[control]
+    if len(idx_s) < 3 or len(idx_m) < 3:
+        return out
+    n_trials = min(trials, len(idx_m))
+    phi_max = min(phi_max, math.pi * 0.5)
+    assert resolution > 1e-6
+    span = min(int(math.floor(phi_max / resolution)), n)
+    remaining = list(idx_m)
+    best = 0.0
+    for trial in range(n_trials):
+        idx = remaining.pop(int(d_trials[trial]) % len(remaining))
+        for i in range(max(idx - span, sr), min(idx + span, n - sr)):
+            if not m_sp[i]:
+                continue
+            phi = phi_m[idx] - phi_s[i]
+            if phi > math.pi:
+                phi -= 2.0 * math.pi
+            elif phi < -math.pi:
+                phi += 2.0 * math.pi
+            if not abs(phi) < phi_max:
+                continue
+            out["candidates"] += 1
+            c, s = math.cos(phi), math.sin(phi)
+            T = np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
+            T[0, 2] = M[idx, 0] - (T[0, 0] * S[i, 0] + T[0, 1] * S[i, 1])
+            T[1, 2] = M[idx, 1] - (T[1, 0] * S[i, 0] + T[1, 1] * S[i, 1])
+            TMap = np.asarray(pose) @ T
+            prob = 1.0
+            for q in C:                                                       # the product in control-set order
+                wx = TMap[0, 0] * q[0] + TMap[0, 1] * q[1] + TMap[0, 2]
+                wy = TMap[1, 0] * q[0] + TMap[1, 1] * q[1] + TMap[1, 2]
+                st, tsd = _np_bilinear(gc, dump, wx, wy)
+                prob *= (1.0 - (1.0 - zrand) * abs(tsd)) if st == 0 else zrand
+            if prob > best:                                                   # strict: the first best of a serial run
+                best = prob
+                out.update(T=T, prob=prob, idx=idx, i=i)
+    return out
+
+
+def _np_T_tolerance(M, mask_m, S, mask_s, idx, i, sr=5):
+    """How far two CORRECT evaluations of the winner's T may differ.  pcaAnalysis hands an axis back as its two end points
+    cent -/+ e and calcNormals forms the normal from their difference, (cent + e) - (cent - e): each component carries an absolute
+    rounding error of ~ulp(cent), so the normal's direction is only known to ~ulp(|cent|) / |short axis|.  On a synthetic flat wall
+    the short axis of a scene window is the fp32 range rounding (1e-7 .. 1e-6 m at a few metres): 1e-10 .. 1e-9 rad, whoever
+    computes it (gsl's Jacobi, the oracle's closed form, LAPACK: they differ in the last bit of V).  T's rotation inherits that
+    angle, its translation that angle times |s_i|.  For windows with real extent (1e-3 m) the bound is 1e-12."""
+    worst = 0.0
+    for X, mask, c in ((M, np.asarray(mask_m, dtype=bool), idx), (S, np.asarray(mask_s, dtype=bool), i)):
+        win = [c + j for j in range(-sr, sr) if mask[c + j]]
+        ax = _np_pca_axes(X[win])
+        short = math.hypot(ax[1, 1] - ax[1, 0], ax[1, 3] - ax[1, 2])
+        worst = max(worst, 4.0 * np.spacing(np.abs(X[win]).max()) / short)
+    return 1e-12 + worst * max(1.0, float(np.hypot(*S[i])))
+
+
+def _tsdpdf_case(cfg, seed, n_push, k_scene, trials, size_control_set, phi_max_deg):
+    gc, geo, scene = synth.CONFIGS[cfg]
+    world = synth.World(scene, gc)
+    g = O.Grid(gc.map_size_log2, gc.cell_size, gc.max_trunc)
+    for k in range(n_push):
+        pose, (x, y, yaw) = H.sensor_pose(world, k)
+        data, mask = O.ingest_f32(world.scan(x, y, yaw, geo), H.MAX_RANGE, geo.angle_increment)
+        g.push(pose, data, mask, geo.angle_increment, geo.angle_min, H.MAX_RANGE, H.MIN_RANGE, H.LOW_REFL)
+    pose, _ = H.sensor_pose(world, n_push - 1)
+    rl, rw = H.world_rays(O, geo, pose, gc.cell_size)
+    co, no, mo, cnt = g.raycast(pose, rw, H.MIN_RANGE, H.MAX_RANGE)
+    _, (x, y, yaw) = H.sensor_pose(world, k_scene)                            # the scene: a scan from a later pose
+    data, mask = O.ingest_f32(world.scan(x, y, yaw, geo), H.MAX_RANGE, geo.angle_increment)
+    sc, ms, _ = O.scene_from_scan(rl, data, mask)
+    rng = np.random.default_rng(seed)
+    draws = tuple(rng.integers(0, 2 ** 31 - 1, m).astype(np.int32) for m in (geo.beams, max(size_control_set, 1), max(trials, 1)))
+    args = (trials, size_control_set, 0.05, math.radians(phi_max_deg), geo.angle_increment) + draws
+    return gc, g, pose, co, mo, sc, ms, args
+
+
+@pytest.mark.parametrize("cfg,seed,n_push,k_scene,trials,ctrl,phi", [
+    ("cfg1", 1, 4, 5, 100, 140, 30.0),       # the node's defaults (ThreadLocalize.cpp:105-129)
+    ("cfg1", 2, 3, 6, 50, 180, 30.0),        # config/single-laser.yaml's ransac_* values
+    ("cfg1", 3, 4, 4, 20, 40, 60.0),
+    ("cfg2", 4, 3, 4, 30, 140, 30.0),        # 1081 beams: the sub-sampling branch (180 / valid < 0.99)
+])
+def test_tsdpdf_match_against_numpy_rederivation(cfg, seed, n_push, k_scene, trials, ctrl, phi):
+    """ora_tsdpdf_match against the derivation above -- winner (idx, i) and candidate count exact, probability
+    <= 1e-9 relative, T within what the reference's own normal formulation determines (_np_T_tolerance: 1e-12 for windows with
+    real extent, up to ~1e-9 on flat synthetic walls); also on the committed draws of tests/golden/oracle_tsdpdf.npz (next test)."""
+    O.build()
+    gc, g, pose, co, mo, sc, ms, args = _tsdpdf_case(cfg, seed, n_push, k_scene, trials, ctrl, phi)
+    m = O.tsdpdf_match(g, pose, co, mo, sc, ms, *args)
+    ref = np_tsdpdf_match(gc, g.dump(), pose, co.reshape(-1, 2), mo, sc.reshape(-1, 2), ms, *args)
+    assert ref["candidates"] > 50 and ref["idx"] >= 0, "the case must have candidates to mean anything"
+    assert (m["candidates"], m["idx"], m["i"]) == (ref["candidates"], ref["idx"], ref["i"])
+    tol = _np_T_tolerance(co.reshape(-1, 2), mo, sc.reshape(-1, 2), ms, ref["idx"], ref["i"])
+    assert tol < 1e-6 and np.max(np.abs(m["T"] - ref["T"])) <= tol
+    # (a T that moves the control points by `tol` changes each of the <= ctrl factors by up to tol / maxTruncation, relative)
+    assert abs(m["prob"] - ref["prob"]) <= (1e-9 + ctrl * tol / gc.max_trunc) * ref["prob"]
+    g.close()
+
+
+def test_tsdpdf_fixture_against_numpy_rederivation():
+    """the committed draws (tests/golden/oracle_tsdpdf.npz): the fixture's winner / counts / T / probability re-derived in numpy"""
+    import os
+    O.build()
+    f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_tsdpdf.npz"))
+    gc = synth.GridConfig(int(f["map_size_log2"]), float(f["cell_size"]))
+    assert abs(gc.max_trunc - float(f["max_trunc"])) < 1e-15
+    g = O.Grid(gc.map_size_log2, gc.cell_size, gc.max_trunc)
+    res, phi0 = float(f["angle_increment"]), float(f["angle_min"])
+    for k in range(len(f["push_poses"])):
+        data, mask = O.ingest_f32(f["push_scans"][k], H.MAX_RANGE, res)
+        g.push(f["push_poses"][k], data, mask, res, phi0, H.MAX_RANGE, H.MIN_RANGE, H.LOW_REFL)
+    ref = np_tsdpdf_match(gc, g.dump(), f["pose"], f["rc_coords"].reshape(-1, 2), f["rc_mask"], f["scene"].reshape(-1, 2), f["scene_mask"],
+                          int(f["trials"]), int(f["size_control_set"]), float(f["zrand"]), float(f["phi_max"]), res,
+                          f["draws_sub"], f["draws_ctrl"], f["draws_trials"])
+    assert [ref["candidates"], ref["idx"], ref["i"]] == list(f["match_counts"])
+    tol = _np_T_tolerance(f["rc_coords"].reshape(-1, 2), f["rc_mask"], f["scene"].reshape(-1, 2), f["scene_mask"], ref["idx"], ref["i"])
+    assert tol < 1e-6 and np.max(np.abs(ref["T"] - f["match_T"])) <= tol       # (3e-10 here: a 4e-7 m short axis at 4.4 m, see _np_T_tolerance)
+    assert abs(ref["prob"] - float(f["match_prob"])) <= (1e-9 + int(f["size_control_set"]) * tol / gc.max_trunc) * float(f["match_prob"])
+    g.close()
