@@ -61,6 +61,22 @@ constexpr int IR_CNT = 32, IR_RMAX = 33, IR_CNT2 = 34, IR_TIE = 35;   // words o
 #define TSD_ICP_ABLATE 0
 #endif
 constexpr int ABL = TSD_ICP_ABLATE;
+// -DTSD_ICP_OPT=<bits>: round-4 restructurings of the steady-state step, each one switchable for same-call A/Bs (tools/icp_ab.sh,
+// tools/icp_timeline.sh); the default is all of them.  Results are identical bit for bit unless noted.
+//   1  tier 0's per-point flags as three compares (the "known" / "pre" cases folded into the operands)
+//   2  the reciprocal filter's returning atomics issued together, one wait
+//   4  work-list counter, tie flag and slot minima read together behind barrier 1 (one LDS round trip instead of three)
+//   8  closed form: seven pair sums + the pair count reduced inside a wave in registers (DPP halving + gfx950's permlane swaps) instead
+//      of nine through an LDS transpose  [summation order changes: the totals' last bits]
+//   16 loop control on wave-uniform scalars (readfirstlane): scalar branches instead of exec-mask loops
+//   32 scene points go to the waves that have a SIMD's issue priority first: waves 0-3 of a workgroup are the older wave of their SIMD
+//      and issue at full rate, waves 4+ only get the slots the older wave leaves (tools/exp/valu.hip: 4.9 against 8.9 cycles per fp64
+//      instruction) -- so waves 0-3 take three 64-point blocks each and waves 4-7 share what is left, one block each where possible,
+//      and the launch brings as many of them as there are blocks left  [which wave sums which pairs changes: rounding of the totals]
+#ifndef TSD_ICP_OPT
+#define TSD_ICP_OPT 63
+#endif
+constexpr int OPT = TSD_ICP_OPT;
 // -DTSD_ICP_DUP=<bits>: timing experiments that run a part of every step TWICE with the same outcome (results unchanged), so the
 // time difference is that part's cost in place:  1 cross-wave reduction   2 closed form   4 transform + bound update (second
 // time on copies)   8 an extra workgroup barrier
@@ -116,6 +132,11 @@ __host__ __device__ inline size_t icp_lds_bytes_for(int cap, int threads, bool n
          icp_region_bytes(cap, threads) + sizeof(double) * (2 * ICP_MAXW * 16 + 16) + ((sizeof(IcpTail) + 15) & ~(size_t)15) +
          sizeof(int) * 64 + 64 + (normals ? sizeof(double2) * (size_t)cap : 0);
 }
+#ifdef TSD_ICP_TIMELINE
+constexpr size_t ICP_TL_BYTES = 4 * ICP_MAXW * 16 * sizeof(long long);     // the timeline build's stamp buffer behind the kernel's LDS
+#else
+constexpr size_t ICP_TL_BYTES = 0;
+#endif
 
 // a wave-uniform value the compiler must keep in a vector register
 __device__ __forceinline__ double vreg(double x) { asm volatile("" : "+v"(x)); return x; }
@@ -429,7 +450,7 @@ __host__ __device__ constexpr int nsum_pitch(int ns) { return ns | 1; }
 // instructions for nine values where nine shuffle trees cost ~200; fixed order => deterministic.
 template <int MAXW, int NSUM>
 __device__ __forceinline__ void block_totals(const IcpLds& L, const double (&v)[NSUM], int cnt, double (&tot)[NSUM],
-                                             int& cnt_total, int tid, int lane, int wave, int W)
+                                             int& cnt_total, int tid, int lane, int wave, int W, long long* tl = nullptr)
 {
   constexpr int NSUMP = nsum_pitch(NSUM);
   double* row = L.tr + (size_t)tid * NSUMP;
@@ -447,7 +468,9 @@ __device__ __forceinline__ void block_totals(const IcpLds& L, const double (&v)[
   acc += dpp_shr0<0x112>(acc);     // row_shr:2  -> lane 4*col + 3 holds the column total of this wave
   if (part == 3 && col < NSUM) L.red[wave * 16 + col] = acc;
   if (lane == 0) L.red[wave * 16 + NSUM] = (double)cnt;      // the pair count rides along (exact in fp64)
+  if (tl && lane == 0) { asm volatile("" : "+v"(acc)); tl[7] = clock64(); }       // (timeline build) the wave's partial sums are on their way
   __syncthreads();
+  if (tl && lane == 0) tl[8] = clock64();                                        // past barrier 2
   double t = 0.0;
   if (lane <= NSUM) {
     double x[MAXW];
@@ -463,6 +486,81 @@ __device__ __forceinline__ void block_totals(const IcpLds& L, const double (&v)[
 #pragma unroll
   for (int k = 0; k < NSUM; k++) tot[k] = bc[k];
   cnt_total = (int)bc[NSUM];
+}
+
+// The same for EIGHT values per thread without the LDS transpose (round 4; OPT 8): the transpose costs every wave 9 LDS writes and 16
+// reads per lane and step, all waves at the same moment -- 1 150 cycles of the 8 600-cycle step, more with more waves
+// (profiles/r4_icp_critical_path.txt).  Here a wave reduces in registers by halving: lane pairs exchange HALF of their values (the even
+// lane keeps and completes values 0-3, the odd lane 4-7; DPP quad permutes), quads half of those, so that after two steps lane j of every quad holds the
+// quad's sums of two values; two row shifts, then the two cross-row swaps gfx950 has (v_permlane16_swap / v_permlane32_swap) finish
+// them: ~75 vector instructions, no LDS.  Lanes 12-15 hand the wave's eight sums to LDS, and behind the barrier eight lanes add the
+// waves' rows (rows of absent waves are zero: no branches) and pass the totals on through the wave's broadcast row.
+// Fixed order => deterministic; the order differs from the transpose's, i.e. the totals' last bits do.
+template <int CTRL>
+__device__ __forceinline__ double dpp_quad(double v)                   // quad_perm CTRL of v (every lane has a source)
+{
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double swap16_sum(double x)                 // x[row r] + x[row r ^ 1] in every lane
+{
+  const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(x), __double2loint(x), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(x), false, false);
+  return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ double swap32_sum(double x)                 // x[lane] + x[lane ^ 32] in every lane
+{
+  const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(x), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(x), false, false);
+  return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+template <int MAXW>
+__device__ __forceinline__ void block_totals8(const IcpLds& L, const double (&v)[8], double (&tot)[8], int lane, int wave, long long* tl = nullptr)
+{
+  constexpr int X1 = 0xB1, X2 = 0x4E;                // quad_perm [1,0,3,2] (lane ^ 1), [2,3,0,1] (lane ^ 2)
+  const bool odd = (lane & 1) != 0, up = (lane & 2) != 0;
+  double w[4], u[2];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    // even lanes: v[i] + the odd neighbour's v[i]; odd lanes: v[i+4] + the even neighbour's v[i+4]
+    const double keep = odd ? v[i + 4] : v[i], send = odd ? v[i] : v[i + 4];
+    w[i] = keep + dpp_quad<X1>(send);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    // lanes 0, 1 of a quad: w[i] + (lane ^ 2)'s w[i]; lanes 2, 3: w[i+2] + (lane ^ 2)'s w[i+2]
+    const double keep = up ? w[i + 2] : w[i], send = up ? w[i] : w[i + 2];
+    u[i] = keep + dpp_quad<X2>(send);
+  }
+  // lane j of a quad now holds the quad's sums of values base(j), base(j) + 1 with base = {0, 4, 2, 6}[j]
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    u[i] += dpp_shr0<0x114>(u[i]);      // row_shr:4
+    u[i] += dpp_shr0<0x118>(u[i]);      // row_shr:8  -> lanes 12-15 of a row: the row's sums
+    u[i] = swap16_sum(u[i]);
+    u[i] = swap32_sum(u[i]);            // -> lanes 12-15 of every row: the wave's sums
+  }
+  const int j = lane & 3;
+  const int base = ((j & 1) << 2) | (j & 2);
+  if (lane >= 12 && lane < 16) *reinterpret_cast<double2*>(L.red + wave * 16 + base) = make_double2(u[0], u[1]);
+  if (tl && lane == 0) { asm volatile("" : "+v"(u[0])); tl[7] = clock64(); }
+  __syncthreads();
+  if (tl && lane == 0) tl[8] = clock64();
+  double* bc = L.red + (ICP_MAXW + wave) * 16;
+  if (lane < 8) {
+    double x[MAXW];
+#pragma unroll
+    for (int r = 0; r < MAXW; r++) x[r] = L.red[r * 16 + lane];      // (rows of waves the launch does not have were zeroed at the start)
+#pragma unroll
+    for (int st = 1; st < MAXW; st <<= 1)
+#pragma unroll
+      for (int r = 0; r + st < MAXW; r += 2 * st) x[r] += x[r + st];
+    bc[lane] = x[0];
+  }
+  // broadcast through LDS (a wave's LDS accesses execute in order)
+#pragma unroll
+  for (int k = 0; k < 8; k += 2) { const double2 t2 = *reinterpret_cast<const double2*>(bc + k); tot[k] = t2.x; tot[k + 1] = t2.y; }
 }
 
 // the whole registration of one workgroup; k_icp (one registration per launch) and k_icp_batch (workgroup x = registration x
@@ -535,6 +633,18 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
 #define SSTAMP(i) do { const long long now_ = clock64(); st_acc[i] += now_ - st_t; st_t = now_; } while (0)
 #else
 #define SSTAMP(i) do {} while (0)
+#endif
+
+#ifdef TSD_ICP_TIMELINE
+  // diagnostic build (tools/icp_timeline.sh): lane 0 of EVERY wave stamps the shader clock at 14 points of four steady-state steps
+  // (TL_FIRST ..), so that each wave's own chain and the waits at the two barriers can be read off: profiles/r4_icp_critical_path.txt.
+  // A stamp is s_memtime + wait + one LDS write (~60 cycles, the same for every interval).
+  constexpr int TL_FIRST = 19, TL_STEPS = 4, TL_N = 16;
+  long long* tlbuf = reinterpret_cast<long long*>(smem + icp_lds_bytes_for(cap, (int)blockDim.x, PTL));       // [TL_STEPS][W][TL_N], behind the kernel's own LDS
+#define TL(i) do { if (lane == 0 && iter >= (unsigned)TL_FIRST && iter < (unsigned)(TL_FIRST + TL_STEPS)) \
+                     tlbuf[((iter - TL_FIRST) * W + wave) * TL_N + (i)] = clock64(); } while (0)
+#else
+#define TL(i) do {} while (0)
 #endif
 
   // fused scan: the sensor state the epilogue needs (pose, _lastPose) is requested NOW, ahead of the inputs, and parked in LDS once
@@ -649,7 +759,14 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
   // a wave count that is no multiple of four some waves have a SIMD to themselves: they take the slots beyond
   // the first ICP_RL of every wave, which evens out the instruction issue per SIMD.  blk = 64-point group.
   int pid[R];
-  {
+  if constexpr ((OPT & 32) != 0) {
+    const int nOld = W < 4 ? W : 4, nYoung = W - nOld;
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+      const int blk = wave < 4 ? q * nOld + wave : nOld * R + q * nYoung + (wave - 4);
+      pid[q] = blk * 64 + lane;
+    }
+  } else {
     const int rr = W & 3;
     const bool asym = R >= 5 && W > 4 && rr != 0;        // (needs the register slots: experimental shape 7 only)
     int nH = 0, hrank = 0;
@@ -694,6 +811,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     L.mxy[-1 - i] = L.mxy[nM - 1 - (i % nM)];
   }
   for (int k = tid; k < cap; k += T) { L.slotD[k] = ~0ull; L.slotI[k] = INT_MAX; }
+  if constexpr ((OPT & 8) != 0) { for (int k = tid; k < ICP_MAXW * 16; k += T) L.red[k] = 0.0; }    // (block_totals8 reads the rows of absent waves)
 #ifdef TSD_ICP_STAMPS
   if (tid == 0) for (int i = 0; i < 8; i++) L.ired[IR_DBG + i] = 0;
 #endif
@@ -725,6 +843,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
 
   while (state == TSD_ICP_PROCESSING) {
     const double thr_before = thr;
+    TL(0);
 
     // -- phase A: pre-filter + exact NN + distance filter (per scene point)
     // OutOfBoundsFilter2D: when even a disc of the largest possible scene radius around the sensor
@@ -741,6 +860,11 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
       double2 mh[R], mh2[R];
 #pragma unroll
       for (int q = 0; q < R; q++) { mh[q] = L.mxy[hint[q]]; mh2[q] = L.mxy[hint2[q]]; }   // all reads in flight
+#ifdef TSD_ICP_TIMELINE
+#pragma unroll
+      for (int q = 0; q < R; q++) { asm volatile("" : "+v"(mh[q].x), "+v"(mh2[q].x)); }
+      TL(1);                                   // the neighbours' coordinates have arrived
+#endif
 #pragma unroll
       for (int q = 0; q < R; q++) {
         bd[q] = __builtin_inf(); keep[q] = false; need[q] = false; ent[q] = -1; mw[q] = mh[q];
@@ -765,6 +889,26 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
         const int kn = swp ? hint2[q] : hint[q], ko = swp ? hint[q] : hint2[q];
         mw[q] = swp ? mh2[q] : mh[q];
         hint[q] = kn; hint2[q] = ko;
+        if constexpr ((OPT & 1) != 0) {
+          // The same decisions from three compares.  "known" (lb > 0) is folded into the bound (max(lb, 0)^2 = 0 makes `same` and `drop`
+          // false: the point searches), "pre" into the operands (distance and bound +inf: `drop` is true, nothing is kept or searched).
+          const double lbp = fmax(lb[q], 0.0);
+          const double inf = __builtin_inf();
+          const double lb2 = pre ? lbp * lbp : inf;
+          const double de = pre ? d : inf;
+          const bool same = de < lb2;                              // neighbour proven
+          const bool le = de <= thr;                               // DistanceFilter
+          const bool drop = (lb2 > thr) & !le;                     // no pair whoever the neighbour is
+          bd[q] = de;
+          keep[q] = same & le;
+          need[q] = !(same | drop);
+          if (refresh) {                                           // (wave-uniform; see below)
+            const bool weak = !drop & (lb2 < WEAK_MULT * de) & (lb2 > 0.0);
+            need[q] = need[q] | weak;
+            keep[q] = keep[q] & !weak;
+          }
+          if constexpr ((ABL & 1) != 0) need[q] = false;
+        } else {
         const double lbq = lb[q];
         const double lb2 = lbq * lbq;
         const bool known = lbq > 0.0;
@@ -782,9 +926,11 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
         need[q] = (pre & !same & !drop) | weak;
         if constexpr ((ABL & 1) != 0) need[q] = false;
         keep[q] = keep[q] & !need[q];
+        }
         ent[q] = -1;
       }
     }
+    TL(2);                                     // tier 0 decided
     bool past_window[R];                       // the window was already tried in place and could not prove the point
 #pragma unroll
     for (int q = 0; q < R; q++) past_window[q] = false;
@@ -830,6 +976,24 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     // Pairs settled by tier 0 go in right away; two scene points with the SAME d2 to one slot are the only
     // case that needs the index round below, and the later of the two sees its own value come back.
     bool tie = false;
+    if constexpr ((OPT & 2) != 0) {
+      // (the three returning atomics leave together and are taken delivery of once: consumed inside its branch, each one was
+      // waited for on the spot -- three LDS round trips in a row, 760 cycles of the step: profiles/r4_icp_critical_path.txt)
+      unsigned long long mine[R], was[R];
+#pragma unroll
+      for (int q = 0; q < R; q++) { mine[q] = (unsigned long long)__double_as_longlong(bd[q]); was[q] = ~0ull; }
+#pragma unroll
+      for (int q = 0; q < R; q++)
+        if (keep[q] && !(ABL & 16)) was[q] = atomicMin(&L.slotD[hint[q]], mine[q]);
+#pragma unroll
+      for (int q = 0; q < R; q++)
+        if (need[q]) {
+          ent[q] = atomicAdd(&L.ired[IR_CNT], 1);
+          if (ent[q] < lcap) { L.list_xy[ent[q]] = make_double2(sx[q], sy[q]); L.list_k[ent[q]] = hint[q] | (past_window[q] ? LIST_PAST_WINDOW : 0); }
+        }
+#pragma unroll
+      for (int q = 0; q < R; q++) tie |= keep[q] & (was[q] == mine[q]);
+    } else {
 #pragma unroll
     for (int q = 0; q < R; q++) {
       if (keep[q] && !(ABL & 16)) {
@@ -842,10 +1006,25 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
         if (ent[q] < lcap) { L.list_xy[ent[q]] = make_double2(sx[q], sy[q]); L.list_k[ent[q]] = hint[q] | (past_window[q] ? LIST_PAST_WINDOW : 0); }
       }
     }
+    }
     if (tie) L.ired[IR_TIE] = 1;
+    TL(3);                                     // the reciprocal filter's atomics are back
     __syncthreads();
+    TL(4);                                     // past barrier 1
     STAMP(0);
-    const int n_need = L.ired[IR_CNT];
+    // One LDS round trip for everything the step needs behind barrier 1: the work-list counter, the tie flag and -- speculatively, they
+    // are final only when nobody searches, which is the steady state -- the slot minima.
+    unsigned long long sd[R];
+    int tie_any = 0;
+    int n_need;
+    if constexpr ((OPT & 4) != 0) {
+      int nn = L.ired[IR_CNT];
+      tie_any = L.ired[IR_TIE];
+#pragma unroll
+      for (int q = 0; q < R; q++) sd[q] = L.slotD[hint[q]];
+      asm volatile("" : "+v"(nn), "+v"(tie_any));                 // (all five reads issued before the first is waited for)
+      n_need = nn;
+    } else n_need = L.ired[IR_CNT];
     if (n_need > 0) {
       tie = false;
       for (int base = 0; base < n_need; base += lcap) {       // one pass unless more than lcap points search
@@ -910,6 +1089,11 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
       }
       if (tie) L.ired[IR_TIE] = 1;
       __syncthreads();
+      if constexpr ((OPT & 4) != 0) {                              // the searches' pairs went into the slots: read again
+        tie_any = L.ired[IR_TIE];
+#pragma unroll
+        for (int q = 0; q < R; q++) sd[q] = L.slotD[hint[q]];
+      }
     }
 #ifdef TSD_ICP_STAMPS
     if (tid == 0) L.ired[IR_DBG] += n_need;
@@ -923,14 +1107,17 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     bool win[R];
     int cnt = 0;
     {
-      unsigned long long sd[R];
+      if constexpr ((OPT & 4) == 0) {
 #pragma unroll
-      for (int q = 0; q < R; q++) sd[q] = L.slotD[hint[q]];
+        for (int q = 0; q < R; q++) sd[q] = L.slotD[hint[q]];
+        tie_any = L.ired[IR_TIE];
+      }
 #pragma unroll
       for (int q = 0; q < R; q++) win[q] = keep[q] & (sd[q] == (unsigned long long)__double_as_longlong(bd[q]));
       if constexpr ((ABL & 16) != 0) { for (int q = 0; q < R; q++) win[q] = keep[q]; }
     }
-    if (L.ired[IR_TIE]) {
+    TL(5);                                     // winners known (work-list counter + slot minima read)
+    if (tie_any) {
       // equal d2 somewhere: the lowest scene index of the candidates wins its slot
 #pragma unroll
       for (int q = 0; q < R; q++)
@@ -960,14 +1147,30 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     // step's centroids c0 instead and correcting, sum (a-ca)(b-cb) = sum (a-c0a)(b-c0b) - n (ca-c0a)(cb-c0b),
     // is the same quantity with the same conditioning (c0 is within millimetres of c); the very first
     // step has no c0 and runs the pass twice, i.e. the reference's two passes.
-    constexpr int NSUM = PTL ? NSUM_PTL : NSUM_CF;
     constexpr bool ptl = PTL;                           // PointToLine2DEstimator instead of ClosedFormEstimator2D
+    constexpr bool RED8 = !PTL && (OPT & 8) != 0;       // closed form: seven sums + the pair count, reduced in registers (block_totals8)
+    constexpr int NSUM = PTL ? NSUM_PTL : (RED8 ? 8 : NSUM_CF);
     double tot[NSUM];
     for (int pass = ((iter == 0 && !ptl) ? 0 : 1); pass < 2; pass++) {
       double v[NSUM];
 #pragma unroll
       for (int k = 0; k < NSUM; k++) v[k] = 0.0;
-      if constexpr (!PTL) {
+      if constexpr (RED8) {
+        // the estimator's nominator / denominator terms accumulated per pair (7 sums instead of 9: what the reduction pays per value
+        // is what counts now), the lane's pair count as the eighth value (exact in fp64)
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+          if (win[q]) {
+            const double2 m = mw[q];
+            v[0] += m.x; v[1] += m.y; v[2] += sx[q]; v[3] += sy[q];
+            const double dx = sx[q] - m.x, dy = sy[q] - m.y;
+            v[4] += dx * dx + dy * dy;
+            const double xF = m.x - c0[0], yF = m.y - c0[1], xS = sx[q] - c0[2], yS = sy[q] - c0[3];
+            v[5] += yF * xS - xF * yS; v[6] += xF * xS + yF * yS;
+            v[7] += 1.0;
+          }
+        }
+      } else if constexpr (!PTL) {
 #pragma unroll
         for (int q = 0; q < R; q++) {
           if (win[q]) {
@@ -1000,9 +1203,16 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
         }
       }
       STAMP(3);
+      TL(6);                                   // this thread's pair sums
+#ifdef TSD_ICP_TIMELINE
+      long long* const tl_row = (iter >= (unsigned)TL_FIRST && iter < (unsigned)(TL_FIRST + TL_STEPS)) ? tlbuf + ((iter - TL_FIRST) * W + wave) * TL_N : nullptr;
+#else
+      long long* const tl_row = nullptr;
+#endif
       if constexpr ((ABL & 8) != 0) { for (int k = 0; k < NSUM; k++) tot[k] = v[k] * 300.0; pairs = 300; }
-      else block_totals<MAXT / 64, NSUM>(L, v, cnt, tot, pairs, tid, lane, wave, W);
-      if constexpr ((DUP & 1) != 0) {
+      else if constexpr (RED8) { block_totals8<MAXT / 64>(L, v, tot, lane, wave, tl_row); pairs = (int)tot[7]; }
+      else block_totals<MAXT / 64, NSUM>(L, v, cnt, tot, pairs, tid, lane, wave, W, tl_row);
+      if constexpr ((DUP & 1) != 0 && !RED8) {
         __syncthreads();
         double v2[NSUM];
 #pragma unroll
@@ -1011,6 +1221,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
       }
       if constexpr ((DUP & 8) != 0) __syncthreads();
       STAMP(4);
+      TL(10);                                  // totals in registers
       if (pass == 0) {                     // first step only: centroids first, then the centred pass
         if (pairs > 0) {
           const double inv0 = 1.0 / (double)pairs;
@@ -1027,6 +1238,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     STAMP(3);
 
     double co = __builtin_nan(""), si = __builtin_nan(""), dX = __builtin_nan(""), dY = __builtin_nan("");   // Tlast of this step (trace)
+    if constexpr ((OPT & 16) != 0) pairs = __builtin_amdgcn_readfirstlane(pairs);
     if (pairs > 2) {
       if constexpr (PTL) {
         // PointToLine2DEstimator: Matrix::solve = gsl_linalg_LU_decomp + LU_solve (gsl/Matrix.cpp:343-355);
@@ -1043,8 +1255,14 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
         rms = tot[4] * size_inv;
         const double cmx = tot[0] * size_inv, cmy = tot[1] * size_inv, csx = tot[2] * size_inv, csy = tot[3] * size_inv;
         const double emx = cmx - c0[0], emy = cmy - c0[1], esx = csx - c0[2], esy = csy - c0[3];
-        const double nom = (tot[5] - np * (emy * esx)) - (tot[6] - np * (emx * esy));
-        const double den = (tot[7] - np * (emx * esx)) + (tot[8] - np * (emy * esy));
+        double nom, den;
+        if constexpr (RED8) {
+          nom = tot[5] - np * (emy * esx - emx * esy);
+          den = tot[6] - np * (emx * esx + emy * esy);
+        } else {
+          nom = (tot[5] - np * (emy * esx)) - (tot[6] - np * (emx * esy));
+          den = (tot[7] - np * (emx * esx)) + (tot[8] - np * (emy * esy));
+        }
         c0[0] = cmx; c0[1] = cmy; c0[2] = csx; c0[3] = csy;
         // every wave evaluates the closed form itself (wave-uniform inputs): no broadcast barrier
 #ifdef TSD_ICP_EXACT_TRIG
@@ -1061,7 +1279,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
 #endif
         dX = (cmx - (co * csx - si * csy));
         dY = (cmy - (co * csy + si * csx));
-        if constexpr ((DUP & 2) != 0) {
+        if constexpr ((DUP & 2) != 0 && !RED8) {
           // the same closed form again, on inputs the compiler cannot recognise, chained behind the first result
           const double z = vreg(0.0) * co;
           const double np2 = vreg(np) + z;
@@ -1078,6 +1296,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
         }
       }
       STAMP(4);
+      TL(11);                                  // closed form done
       // applyTransformation(sceneTmp): data * R^T (dgemm NoTrans,Trans), then + t (Icp.cpp:371-408).
       // The distance each point moves (rounded up, fp32 is plenty for a bound) eats into its neighbour
       // bound of tier 0.
@@ -1120,11 +1339,23 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     } else {
       state = TSD_ICP_NOTMATCHABLE;
     }
+    TL(12);                                    // scene moved, bounds updated
     // -- loop control (Icp.cpp:489-511)
     iter++;
+    if constexpr ((OPT & 16) != 0) {
+      // (every lane holds the same rms: the decisions as wave-uniform scalars, so that the loop is a scalar branch and not an
+      // exec-mask loop over a per-lane `state`)
+      const int conv_hit = __builtin_amdgcn_readfirstlane((int)(fabs(rms - rms_prev) < 10e-10));
+      const int rms_done = __builtin_amdgcn_readfirstlane((int)(rms <= 0.0));
+      state = __builtin_amdgcn_readfirstlane(state);
+      conv_cnt = conv_hit ? conv_cnt + 1 : 0;
+      if (rms_done || conv_cnt >= conv_need) state = TSD_ICP_SUCCESS;
+      else if (iter >= max_it) state = TSD_ICP_MAXITERATIONS;
+    } else {
     if (fabs(rms - rms_prev) < 10e-10) conv_cnt++; else conv_cnt = 0;
     if (rms <= 0.0 || conv_cnt >= conv_need) state = TSD_ICP_SUCCESS;
     else if (iter >= max_it) state = TSD_ICP_MAXITERATIONS;
+    }
     rms_prev = rms;
     STAMP(5);
     if (tid == 0 && iter <= TSD_ICP_TRACE_MAX && !(ABL & 64) && L.tail->trace) {
@@ -1139,6 +1370,12 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     }
   }
 
+#ifdef TSD_ICP_TIMELINE
+  __syncthreads();
+  if (L.tail->trace)
+    for (int i = tid; i < TL_STEPS * W * TL_N; i += T)
+      L.tail->trace[TSD_ICP_TRACE_STRIDE * TSD_ICP_TRACE_MAX + i] = (double)(tlbuf[i] - tlbuf[0]);
+#endif
 #ifdef TSD_ICP_STAMPS
   __syncthreads();
   if (tid == 0) {
@@ -1235,6 +1472,23 @@ static int icp_cap_for(int n)
   return cap;
 }
 
+// threads of a registration of n points with R register slots per lane (see OPT 32: four "old" waves take R blocks of 64 points each,
+// younger waves one block each where the blocks left allow it)
+static int icp_threads_for(int n, int R, int maxt)
+{
+  int T = ((n + R - 1) / R + 63) & ~63;
+  if (T < 64) T = 64;
+  if ((OPT & 32) != 0) {
+    const int B = (n + 63) / 64;
+    if (B > 4 * R) {
+      int W = 4 + (B - 4 * R);
+      if (W > maxt / 64) W = maxt / 64;
+      if (64 * W > T) T = 64 * W;
+    }
+  }
+  return T;
+}
+
 // workgroup shape: R scene points per thread, T threads.  One CU runs the whole registration and is
 // issue bound, so few waves (per-wave reduction / control cost paid once per SIMD) win.
 template <int R, int MAXT, bool PTL>
@@ -1242,12 +1496,11 @@ static int launch_icp_shape_est(tsd_ctx* ctx, const IcpArgs& a, int n, int cap, 
                             const double* d_rays_local, const double* d_ranges, const uint8_t* d_mask,
                             const ScanPostArgs& post, int force_T = 0)
 {
-  int T = ((n + R - 1) / R + 63) & ~63;
-  if (T < 64) T = 64;
+  int T = icp_threads_for(n, R, MAXT);
   if (force_T > T) T = force_T;
   if (T > MAXT) return set_error(ctx, TSD_E_CAPACITY, "icp workgroup shape", hipSuccess);
   const bool ptl = a.estimator == TSD_ESTIMATOR_POINT_TO_LINE;
-  const size_t lds = icp_lds_bytes_for(cap, T, ptl);
+  const size_t lds = icp_lds_bytes_for(cap, T, ptl) + ICP_TL_BYTES;
   if (lds > 160u * 1024u) return set_error(ctx, TSD_E_CAPACITY, "registration does not fit the LDS of one CU (point-to-line: model normals too)", hipSuccess);
   {
     // the attribute is per device: remembered per context (and kernel instantiation), not per process
@@ -1309,8 +1562,7 @@ int launch_icp(tsd_ctx* ctx, const IcpArgs& a, const double* P_dev, const double
 template <int R, int MAXT>
 static int launch_icp_pairs_shape(tsd_ctx* ctx, const IcpArgs& a, int n, int cap, int* d_pairs)
 {
-  int T = ((n + R - 1) / R + 63) & ~63;
-  if (T < 64) T = 64;
+  int T = icp_threads_for(n, R, MAXT);
   if (T > MAXT) return set_error(ctx, TSD_E_CAPACITY, "icp workgroup shape", hipSuccess);
   const size_t lds = icp_lds_bytes_for(cap, T, false);
   if (lds > 160u * 1024u) return set_error(ctx, TSD_E_CAPACITY, "registration does not fit the LDS of one CU", hipSuccess);
@@ -1342,8 +1594,7 @@ int launch_icp_pairs(tsd_ctx* ctx, const IcpArgs& a, int* d_pairs)
 template <int R, int MAXT, bool PTL>
 static int launch_icp_batch_shape(tsd_ctx* ctx, hipStream_t stream, const IcpBatchEntry* d_entries, int n, int nthr, int cap)
 {
-  int T = ((nthr + R - 1) / R + 63) & ~63;
-  if (T < 64) T = 64;
+  int T = icp_threads_for(nthr, R, MAXT);
   if (T > MAXT) return set_error(ctx, TSD_E_CAPACITY, "icp workgroup shape", hipSuccess);
   const size_t lds = icp_lds_bytes_for(cap, T, PTL);
   if (lds > 160u * 1024u) return set_error(ctx, TSD_E_CAPACITY, "registration does not fit the LDS of one CU", hipSuccess);
