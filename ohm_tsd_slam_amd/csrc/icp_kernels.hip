@@ -133,7 +133,11 @@ __host__ __device__ inline size_t icp_lds_bytes_for(int cap, int threads, bool n
          sizeof(int) * 64 + 64 + (normals ? sizeof(double2) * (size_t)cap : 0);
 }
 #ifdef TSD_ICP_TIMELINE
-constexpr size_t ICP_TL_BYTES = 4 * ICP_MAXW * 16 * sizeof(long long);     // the timeline build's stamp buffer behind the kernel's LDS
+#ifndef TSD_ICP_TL_FIRST
+#define TSD_ICP_TL_FIRST 19
+#define TSD_ICP_TL_STEPS 4
+#endif
+constexpr size_t ICP_TL_BYTES = (size_t)TSD_ICP_TL_STEPS * 8 * 16 * sizeof(long long);     // the timeline build's stamp buffer behind the kernel's LDS (<= 8 waves)
 #else
 constexpr size_t ICP_TL_BYTES = 0;
 #endif
@@ -639,7 +643,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
   // diagnostic build (tools/icp_timeline.sh): lane 0 of EVERY wave stamps the shader clock at 14 points of four steady-state steps
   // (TL_FIRST ..), so that each wave's own chain and the waits at the two barriers can be read off: profiles/r4_icp_critical_path.txt.
   // A stamp is s_memtime + wait + one LDS write (~60 cycles, the same for every interval).
-  constexpr int TL_FIRST = 19, TL_STEPS = 4, TL_N = 16;
+  constexpr int TL_FIRST = TSD_ICP_TL_FIRST, TL_STEPS = TSD_ICP_TL_STEPS, TL_N = 16;
   long long* tlbuf = reinterpret_cast<long long*>(smem + icp_lds_bytes_for(cap, (int)blockDim.x, PTL));       // [TL_STEPS][W][TL_N], behind the kernel's own LDS
 #define TL(i) do { if (lane == 0 && iter >= (unsigned)TL_FIRST && iter < (unsigned)(TL_FIRST + TL_STEPS)) \
                      tlbuf[((iter - TL_FIRST) * W + wave) * TL_N + (i)] = clock64(); } while (0)
@@ -838,6 +842,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
 
   double c0[4] = {0.0, 0.0, 0.0, 0.0};       // centring point of the pair sums: last step's centroids
 
+  const bool has_trace = trace != nullptr;   // (a scalar: reading the pointer back from LDS every step cost thread 0's wave a round trip)
   int Rn = 0;                                // register slots of this wave that hold scene points (wave-uniform)
   for (int q = 0; q < R; q++) Rn += (pid[q] - lane < nS) ? 1 : 0;
 
@@ -1050,6 +1055,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
           }
         }
         __syncthreads();
+        TL(13);                                // (search step) the window pass is done
         const int n2 = L.ired[IR_CNT2];
 #ifdef TSD_ICP_STAMPS
         if (tid == 0) L.ired[IR_DBG + 1] += n2;
@@ -1070,6 +1076,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
           if (tid == 0) L.ired[IR_DBG + 5] += (int)((clock64() - t2_begin) >> 4);
 #endif
         }
+        TL(14);                                // (search step) the whole-wave searches are done
 #pragma unroll
         for (int q = 0; q < R; q++)
           if (need[q] && ent[q] >= base && ent[q] < base + lcap) {
@@ -1358,7 +1365,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     }
     rms_prev = rms;
     STAMP(5);
-    if (tid == 0 && iter <= TSD_ICP_TRACE_MAX && !(ABL & 64) && L.tail->trace) {
+    if (has_trace && tid == 0 && iter <= TSD_ICP_TRACE_MAX && !(ABL & 64)) {
       double* tr = L.tail->trace + TSD_ICP_TRACE_STRIDE * (iter - 1);
       tr[0] = (double)pairs; tr[1] = rms; tr[2] = thr_before; tr[3] = (double)state;
       tr[4] = co; tr[5] = si; tr[6] = dX; tr[7] = dY;          // Tlast = [[co, -si, dX], [si, co, dY]] (NaN: no estimate this step)
@@ -1372,9 +1379,15 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
 
 #ifdef TSD_ICP_TIMELINE
   __syncthreads();
-  if (L.tail->trace)
-    for (int i = tid; i < TL_STEPS * W * TL_N; i += T)
-      L.tail->trace[TSD_ICP_TRACE_STRIDE * TSD_ICP_TRACE_MAX + i] = (double)(tlbuf[i] - tlbuf[0]);
+  if (L.tail->trace) {
+    if constexpr (TL_STEPS <= 4) {
+      for (int i = tid; i < TL_STEPS * W * TL_N; i += T)
+        L.tail->trace[TSD_ICP_TRACE_STRIDE * TSD_ICP_TRACE_MAX + i] = (double)(tlbuf[i] - tlbuf[0]);
+    } else {                                    // many steps: wave 0's stamps only
+      for (int i = tid; i < TL_STEPS * TL_N; i += T)
+        L.tail->trace[TSD_ICP_TRACE_STRIDE * TSD_ICP_TRACE_MAX + i] = (double)(tlbuf[((i / TL_N) * W) * TL_N + (i % TL_N)] - tlbuf[0]);
+    }
+  }
 #endif
 #ifdef TSD_ICP_STAMPS
   __syncthreads();
