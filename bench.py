@@ -237,6 +237,10 @@ def main():
                     help="also launch the PMC calibration kernel (known byte count; used by tools/profile_bench.sh)")
     ap.add_argument("--occupancy", type=int, default=0, help="also run the occupancy extraction (row N1) this many times "
                                                            "after the timed region (profiling)")
+    ap.add_argument("--occupancy-every-ms", type=float, default=0.0,
+                    help="a map thread calls tsd_occupancy (extraction kernels + the map's copy to the host) every so many milliseconds "
+                         "DURING the timed region, beside the localisers -- what ThreadGrid does every occ_grid_time_interval "
+                         "(ThreadGrid.cpp:72-133); the line reports occupancy_calls_in_timed_region")
     ap.add_argument("--registration-mode", type=int, default=0, choices=[0, 3],
                     help="0: ICP only (the bench line, SURVEY 8(d)); 3: TSD_PDF pre-registration ahead of the ICP (config/single-laser.yaml:28), "
                          "fixed tsdpdf_seed; stages_ms.tsdpdf = the scoring kernels")
@@ -636,8 +640,21 @@ def run_slam(args, gc, geo, scene, K, W, every, every_upd, every_icp, device, ra
         # generation-2 pass is a 40 ms pause in the middle of the region, the same step in every run)
         pygc.collect()
         pygc.disable()
+        occ_calls = [0]
+        occ_stop = threading.Event()
+        occ_thread = None
+        if args.occupancy_every_ms > 0 and full:
+            def map_thread():
+                while not occ_stop.wait(args.occupancy_every_ms * 1e-3):
+                    grid.occupancy(False, 2)
+                    occ_calls[0] += 1
+            grid.occupancy(False, 2)                   # (its buffers and its copy stream exist before anything is timed)
+            occ_thread = threading.Thread(target=map_thread)
+            occ_thread.start()
         t0 = time.perf_counter()
         run_range(1 + W, 1 + W + K)
+        if occ_thread is not None:
+            occ_stop.set(); occ_thread.join()
         grid.sync()
         if merger is not None:
             merger.wait()
@@ -728,6 +745,8 @@ def run_slam(args, gc, geo, scene, K, W, every, every_upd, every_icp, device, ra
             "tracking_error_m": max(errs),
             "_stats": (st, pushes, upd_ms, upd_launches), "_stream": stream, "_ranks": ranks,
         }
+        if args.occupancy_every_ms > 0:
+            out["occupancy_calls_in_timed_region"] = occ_calls[0]
         if merger is not None:
             out["merge_checked"] = merge_checked
         if args.occupancy and occ_n:

@@ -472,6 +472,8 @@ void tsd_destroy(tsd_ctx* ctx)
   hipFree(ctx->d_scene); hipFree(ctx->d_morig); hipFree(ctx->d_start); hipFree(ctx->d_icp_res); hipFree(ctx->d_icp_trace); hipHostFree(ctx->h_icp_res); hipHostFree(ctx->h_out);
   hipFree(ctx->d_occ); hipFree(ctx->d_occ_count); hipFree(ctx->d_occ_heads); hipFree(ctx->d_occ_list);
   if (ctx->d_occ_out) hipFree(ctx->d_occ_out);
+  if (ctx->stream_io) { hipStreamSynchronize(ctx->stream_io); hipStreamDestroy(ctx->stream_io); }
+  if (ctx->ev_io) hipEventDestroy(ctx->ev_io);
   if (ctx->d_img) hipFree(ctx->d_img);
   if (ctx->d_pdf) hipFree(ctx->d_pdf);
   if (ctx->h_pdf) hipHostFree(ctx->h_pdf);
@@ -1115,12 +1117,21 @@ int tsd_occupancy(tsd_ctx* ctx, int8_t* occ_host, int inflate, int inflate_facto
   if (int rcd_ = drain_async_push(ctx)) return rcd_;
   const size_t cells = (size_t)ctx->grid.N * ctx->grid.N;
   if (!ctx->d_occ_out) TSD_HIP_CHECK(ctx, hipMalloc(&ctx->d_occ_out, cells));      // once per context (see tsd_color_image)
+  // The map leaves on a stream of its own behind the extraction kernels' event: 16 MiB at 4096^2 are ~0.7 ms of PCIe, and on the grid's
+  // stream every push and ray cast enqueued meanwhile (the localisers keep running: ThreadGrid.cpp:72-133 extracts beside them) would
+  // sit behind the copy; the caller waits for the copy stream only.
+  if (!ctx->stream_io) {
+    TSD_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream_io, hipStreamNonBlocking));
+    TSD_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_io, hipEventDisableTiming));
+  }
   int rc = launch_occupancy(ctx, ctx->d_occ_out, inflate, inflate_factor);
   if (rc == TSD_OK) {
     int n = 0;
-    hipError_t e = hipMemcpyAsync(occ_host, ctx->d_occ_out, cells, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(&n, ctx->d_occ_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
-    const hipError_t es = hipStreamSynchronize(ctx->stream);
+    hipError_t e = hipEventRecord(ctx->ev_io, ctx->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream_io, ctx->ev_io, 0);
+    if (e == hipSuccess) e = hipMemcpyAsync(occ_host, ctx->d_occ_out, cells, hipMemcpyDeviceToHost, ctx->stream_io);
+    if (e == hipSuccess) e = hipMemcpyAsync(&n, ctx->d_occ_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream_io);
+    const hipError_t es = hipStreamSynchronize(ctx->stream_io);
     if (e == hipSuccess) e = es;
     if (n_surface) *n_surface = n;
     if (e != hipSuccess) rc = set_error(ctx, TSD_E_HIP, "tsd_occupancy copy", e);

@@ -234,6 +234,7 @@ struct tsd_ctx {
   int occ_parity = 0;
   uint32_t* d_occ_list = nullptr;
   int8_t* d_occ_out = nullptr;   // tsd_occupancy's device staging (allocated on first use, kept)
+  hipStream_t stream_io = nullptr; hipEvent_t ev_io = nullptr;   // ... and the stream its copy to the host leaves on (created on first use)
   uint8_t* d_img = nullptr; size_t img_bytes = 0;   // tsd_color_image's (coordinate tables + image), grown on demand
 
   // profiling: bit i of profile_mask times kernel i (names in capi.hip: kKernelNames)
