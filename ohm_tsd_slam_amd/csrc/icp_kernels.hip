@@ -40,7 +40,10 @@ namespace tsd {
 
 constexpr int ICP_MAXW = 16;                    // waves per workgroup at most
 constexpr double SLACK = 1.0 - 1e-9;            // conservative factor on every pruning bound
-constexpr int HW = 6;                           // tier-1 window: k-6 .. k+6
+#ifndef TSD_ICP_HW
+#define TSD_ICP_HW 6
+#endif
+constexpr int HW = TSD_ICP_HW;                  // tier-1 window: k-HW .. k+HW
 constexpr int ICP_RL = 2;                       // register slots every wave fills before the lone waves take more
 constexpr int ICP_PAD = 96;                     // wrapped copies of the model at both ends of its LDS array
 #ifndef TSD_ICP_REFRESH_A
@@ -230,7 +233,10 @@ __device__ __forceinline__ double sep_bound(double x, double y, double rs2, doub
 // agree; the two nearest are therefore re-evaluated exactly at the end (ties: lower original index) and
 // a third candidate in the same 256-ulp bucket sends the point to the exact whole-wave search.
 constexpr int WIN = 2 * HW + 1;
-constexpr int WIN_ROUNDS = 6;
+#ifndef TSD_ICP_WIN_ROUNDS
+#define TSD_ICP_WIN_ROUNDS 6
+#endif
+constexpr int WIN_ROUNDS = TSD_ICP_WIN_ROUNDS;
 #ifndef TSD_ICP_WIN_REACH
 #define TSD_ICP_WIN_REACH 0.03
 #endif
