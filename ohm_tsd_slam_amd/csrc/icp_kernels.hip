@@ -258,7 +258,7 @@ __device__ __forceinline__ double pack_code(double d, int code)
   return __hiloint2double(__double2hiint(d), (__double2loint(d) & ~0xFF) | code);
 }
 __device__ __forceinline__ NnResult window_search(const IcpLds& L, int nM, double x, double y, int c,
-                                                  double thr, double sgn)
+                                                  double thr, double sgn, int* rounds_out = nullptr)
 {
   NnResult r;
   r.best = __builtin_inf(); r.lbsq = 0.0; r.bk = -1; r.bk2 = -1; r.resolved = false;
@@ -299,6 +299,9 @@ __device__ __forceinline__ NnResult window_search(const IcpLds& L, int nM, doubl
     else { side = 1; b = hi + 1; hi += WIN; }
   }
   if (!(b1 < __builtin_inf())) return r;        // no finite distance at all (non-finite point): tier 2 sorts it out
+#ifdef TSD_ICP_TIMELINE
+  if (rounds_out) *rounds_out = lo == -HW && hi == HW ? 1 : 1 + (hi - lo + 1 - WIN) / WIN;
+#endif
   // unpack the two nearest and evaluate them exactly
   const int o1 = (__double2loint(b1) & 0xFF) - 128, o2 = (__double2loint(b2) & 0xFF) - 128;
   int k1 = wrap_slot(c + o1, nM), k2 = wrap_slot(c + o2, nM);
@@ -1055,7 +1058,24 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
             const double2 s = L.list_xy[e];
             const int lk = L.list_k[e];
             NnResult r; r.resolved = false;
+#ifdef TSD_ICP_TIMELINE
+            int rounds = 0;
+            const long long ws0 = clock64();
+            if (!(lk & LIST_PAST_WINDOW)) r = window_search(L, nM, s.x, s.y, lk, thr, sgn, &rounds);
+            {
+              // (diagnostic) per list round of wave 0: entries, lanes' largest / mean number of window rounds, cycles of the call
+              int mx = rounds;
+              for (int o = 32; o; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+              int sm = rounds;
+              for (int o = 32; o; o >>= 1) sm += __shfl_xor(sm, o);
+              if (wave == 0 && lane == 0 && iter < 32u) {
+                double* dd = L.tail->trace + TSD_ICP_TRACE_STRIDE * (TSD_ICP_TRACE_MAX + 128) + 8 * iter;
+                if (e0 == 0) { dd[0] = (double)n; dd[1] = (double)mx; dd[2] = (double)sm; dd[3] = (double)(clock64() - ws0); dd[4] = (double)__popcll(__ballot(true)); }
+              }
+            }
+#else
             if (!(lk & LIST_PAST_WINDOW)) r = window_search(L, nM, s.x, s.y, lk, thr, sgn);
+#endif
             if (r.resolved) { L.res_d[e] = r.best; L.res_k[e] = r.bk; L.res_k2[e] = r.bk2; L.res_lb[e] = lb_from_sq(r.lbsq); }
             else L.list2[atomicAdd(&L.ired[IR_CNT2], 1)] = e;      // tier 2, shared out over all waves below
           }

@@ -28,6 +28,9 @@ for k in (5, 12, 17):
     print("  step lengths (wave 0, T0 -> next T0):", np.diff(t0).astype(int).tolist())
     print("  barrier 1 -> winners known (the search block when there is one):", (tl[:, 5] - tl[:, 4]).astype(int).tolist())
     print("  top -> barrier 1:", (tl[:, 4] - tl[:, 0]).astype(int).tolist())
+    ws = tr.reshape(-1)[(256 + 128) * 8: (256 + 128) * 8 + 30 * 8].reshape(30, 8)
+    print("  list pass, wave 0's first round, per step: (entries on the list, lanes active, largest / mean window rounds of a lane, cycles of the window_search call)")
+    print("   ", [(int(w[0]), int(w[4]), int(w[1]), round(w[2] / max(w[4], 1), 2), int(w[3])) for w in ws if w[0] > 0])
     srch = [i for i in range(30) if tl[i, 13] > tl[i, 4]]
     print("  search steps", srch)
     print("    barrier 1 -> window pass done:", [int(tl[i, 13] - tl[i, 4]) for i in srch])

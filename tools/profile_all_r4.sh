@@ -8,7 +8,7 @@ tools/profile_bench.sh r4_cfg3_comb_push --config cfg3 --scene comb --mode push
 tools/profile_sq.sh r4_cfg3_comb_push --config cfg3 --scene comb --mode push > gpurun_out/profiles_new/r4_cfg3_comb_push_sq_counters.txt 2>&1
 tools/profile_sq.sh r4_cfg2_pillars > gpurun_out/profiles_new/r4_cfg2_pillars_sq_counters.txt 2>&1
 # N3: registration_mode 3 (TSD_PDF pre-registration ahead of the ICP), kernel trace only
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r4_cfg2_pillars_mode3_stats -o run -- python3 bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-second-pass --no-stream --registration-mode 3 > gpurun_out/prof_r4_cfg2_pillars_mode3_stats.json 2> gpurun_out/prof_r4_cfg2_pillars_mode3_stats.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r4_cfg2_pillars_mode3_stats -o run -- python3 bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-second-pass --no-stream --registration-mode 3 > gpurun_out/prof_r4_cfg2_pillars_mode3_stats.json 2> gpurun_out/prof_r4_cfg2_pillars_mode3_stats.err
 cp $(find gpurun_out/prof_r4_cfg2_pillars_mode3_stats -name "*kernel_stats.csv" | head -1) gpurun_out/profiles_new/r4_cfg2_pillars_mode3_kernel_stats.csv
 cp gpurun_out/prof_r4_cfg2_pillars_mode3_stats.json gpurun_out/profiles_new/r4_cfg2_pillars_mode3_bench_under_rocprof.json
 find gpurun_out -name "*kernel_trace.csv" -delete 2>/dev/null; find gpurun_out -name "*counter_collection.csv" -delete 2>/dev/null

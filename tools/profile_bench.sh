@@ -9,9 +9,9 @@ set -u
 tag=$1; shift
 export TMPDIR=/tmp
 args="--steps 100 --warmup 5 --no-cpu-baseline --no-second-pass --no-stream --calibrate $*"
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_stats -o run -- python3 bench.py $args > gpurun_out/prof_${tag}_stats.json 2> gpurun_out/prof_${tag}_stats.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_${tag}_fetch -o run -- python3 bench.py $args > gpurun_out/prof_${tag}_fetch.json 2> gpurun_out/prof_${tag}_fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof_${tag}_write -o run -- python3 bench.py $args > gpurun_out/prof_${tag}_write.json 2> gpurun_out/prof_${tag}_write.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_stats -o run -- python3 bench.py $args > gpurun_out/prof_${tag}_stats.json 2> gpurun_out/prof_${tag}_stats.err
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_${tag}_fetch -o run -- python3 bench.py $args > gpurun_out/prof_${tag}_fetch.json 2> gpurun_out/prof_${tag}_fetch.err
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof_${tag}_write -o run -- python3 bench.py $args > gpurun_out/prof_${tag}_write.json 2> gpurun_out/prof_${tag}_write.err
 # keep what travels back small: the per-dispatch traces are not needed once summarised
 python3 tools/profile_summarise.py ${tag} > gpurun_out/prof_${tag}_summary.txt 2>&1
 find gpurun_out/prof_${tag}_stats gpurun_out/prof_${tag}_fetch gpurun_out/prof_${tag}_write -name "*kernel_trace.csv" -delete 2>/dev/null
