@@ -2019,16 +2019,25 @@ int tsd_batch_begin(tsd_batch* b, int n, tsd_sensor* const* sensors, const doubl
     std::memset(&e, 0, sizeof(e));
     fill_icp_args(e.a, ident, &params[i]);
     e.a.beams = s->beams; e.a.ccw = s->ccw ? 1 : 0;
+    // registration_mode 3 (tsd_scan_preregister armed this sensor): the registration starts from the pre-registration's result, which
+    // k_pdf_argmax leaves in the sensor's own buffer (the kernels go out below, behind the batch's ray casts)
+    if (s->pre_armed) e.a.Tinit_dev = reinterpret_cast<const double*>(s->d_pre + s->pre.off_res);
     e.P_dev = s->d_state->icpP; e.coords = s->d_coords; e.mask_m = s->d_mask_m; e.rays_local = s->d_rays_local;
     e.ranges = d_ranges; e.mask = d_mask; e.out = s->d_icp_res; e.trace = nullptr /* no reader in the fused path */; e.normals = s->d_normals;
     const unsigned long long seq = ++s->seq;
     b->seqs[(size_t)i] = seq;
+    if (!s->pre_armed) s->pre_ran = false;                 // (tsd_scan_preregistration_result: this scan has none)
     e.post.st = s->d_state; e.post.rays = s->d_rays; e.post.out = s->d_result; e.post.seq = seq; e.post.beams = s->beams;
     e.post.gmin_x = ctx->grid.min_x; e.post.gmax_x = ctx->grid.max_x; e.post.gmin_y = ctx->grid.min_y; e.post.gmax_y = ctx->grid.max_y;
     e.post.gates = GateArgs{gates[i].reg_trs_max, gates[i].reg_sin_rot_max, gates[i].trs_min, gates[i].rot_min};
   }
-  // the registrations go out AHEAD of the ray casts and wait for the slot's flag on the device (where the probe allowed it)
-  const bool dev_wait = b->dev_wait;
+  // the registrations go out AHEAD of the ray casts and wait for the slot's flag on the device (where the probe allowed it).
+  // A batch that carries a pre-registration (registration_mode 3) orders its registrations behind the grid stream's work by an
+  // event instead: the pre-registration kernels sit between the ray casts and the registrations, on the grid's stream -- the scoring
+  // reads the grid, like the ray casts, and takes its place between the pushes the same way.
+  bool any_pre = false;
+  for (int i = 0; i < n; i++) any_pre |= sensors[i]->pre_armed;
+  const bool dev_wait = b->dev_wait && !any_pre;
   if (dev_wait) {
     b->rc_batches++;
     for (int i = 0; i < n; i++) { h_icp[i].rc_flag = b->d_rc_flag; h_icp[i].rc_target = b->rc_batches; h_icp[i].poll_bound = b->poll_bound; }
@@ -2063,6 +2072,19 @@ int tsd_batch_begin(tsd_batch* b, int n, tsd_sensor* const* sensors, const doubl
       rc = launch_raycast_batch(ctx, ctx->stream, reinterpret_cast<const RaycastBatchEntry*>(d_base + off_rc), n, max_beams);
     }
     if (rc != TSD_OK) return FAIL(rc);
+    if (any_pre) {
+      // TSD_PDFMatching::match of every armed robot (ThreadLocalize.cpp:557-567, each robot's own thread in the reference) on the
+      // model its ray cast just produced; all of them score against the grid as it is before any push of this batch
+      for (int i = 0; i < n; i++) {
+        tsd_sensor* s = sensors[i];
+        if (!s->pre_armed) continue;
+        s->pre_armed = false;
+        const double* tinit = nullptr;
+        rc = launch_preregistration(ctx, s, ctx->stream, s->d_coords, s->d_mask_m, s->d_state->icpP, &tinit, nullptr);
+        if (rc != TSD_OK) return FAIL(rc);
+        s->pre_ran = true;
+      }
+    }
     if (dev_wait) {
       rc = launch_set_flag(ctx, ctx->stream, b->d_rc_flag, b->rc_batches);
       if (rc != TSD_OK) return FAIL(rc);

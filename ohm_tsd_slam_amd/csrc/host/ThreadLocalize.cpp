@@ -298,7 +298,8 @@ void ThreadLocalize::processScan(const std::vector<float>& ranges, const builtin
   // registration_mode 3: inside the fused scan (the pre-registration on the device between the ray cast and the registration) when
   // this robot has the fused path to itself; the reference's own call structure otherwise (and with TSD_MODE3_UNFUSED set: A/B)
   static const bool mode3Unfused = std::getenv("TSD_MODE3_UNFUSED") != nullptr;
-  if(_regMode == 3 && _preMatcher && (mode3Unfused || !_preFusedOk || !_fused || !_sensor->deviceHandle() || _concurrent))
+  // (several robots on one grid: the batched dispatcher runs the pre-registration behind its batch's ray casts; the split scan does not)
+  if(_regMode == 3 && _preMatcher && (mode3Unfused || !_preFusedOk || !_fused || !_sensor->deviceHandle() || (_concurrent && !_grid.batcher())))
   {
     processScanPreRegistered(rep);
     return;
@@ -458,7 +459,27 @@ void ThreadLocalize::processScanFused(ScanReport& rep)
   if(_concurrent)
   {
     // several robots on one grid: the grid's dispatcher batches the robots' scans (or the split scan)
-    rc = _grid.scanConcurrent(_sensor, maskPush.data(), _icpParams, gates, &sr);
+    rc = TSD_OK;
+    if(_regMode == 3 && _preMatcher && _preFusedOk && _grid.batcher())
+    {
+      // doRegistration, case TSD (ThreadLocalize.cpp:557-567), armed for this robot's scan of the batch: scene points + the three
+      // rand() streams from the host, everything else on the device behind the batch's ray casts (tsd_batch_begin)
+      const unsigned int n = _sensor->getRealMeasurementSize();
+      if(_scene.size() != 2 * (size_t)n) { _scene.assign(2 * (size_t)n, 0.0); _maskS.assign(n, 0); }
+      bool* maskS = reinterpret_cast<bool*>(_maskS.data());
+      _sensor->dataToCartesianVectorMask(_scene.data(), maskS);
+      _preMatcher->drawStreams(n, _dSub, _dCtrl, _dTrials);
+      rc = _grid.scanPreregister(_sensor, _preMatcher->params(_ranPhiMax * M_PI / 180.0, _sensor->getAngularResolution()), _scene.data(), maskS,
+                                 _dSub.data(), _dCtrl.data(), _dTrials.data());
+      if(rc == TSD_E_CAPACITY)
+      {
+        std::fprintf(stderr, "Localizer(%s): registration_mode 3 runs unfused (%s)\n", _nameSpace.c_str(), tsd_last_error(_grid.context()));
+        _preFusedOk = false;
+        processScanPreRegistered(rep);
+        return;
+      }
+    }
+    if(rc == TSD_OK) rc = _grid.scanConcurrent(_sensor, maskPush.data(), _icpParams, gates, &sr);
   }
   else
   {

@@ -583,8 +583,12 @@ TSD_PDFMatching::TSD_PDFMatching(TsdGrid& grid, unsigned int trials, double epsT
 
 void TSD_PDFMatching::drawStreams(unsigned int points, std::vector<int>& dSub, std::vector<int>& dCtrl, std::vector<int>& dTrials)
 {
-  // the three rand() streams, in the reference's call order
-  if (_seed >= 0) std::srand((unsigned)(_seed + (long)_calls));
+  // the three rand() streams, in the reference's call order.  (Seeded -- tests only --: srand + the draws as ONE step under a process-
+  // wide lock, so that several robots' localiser threads each get their own reproducible sequence; unseeded it is the reference's
+  // plain rand(), whose interleaving between threads is as unspecified as in the reference.)
+  static std::mutex seededDraws;
+  std::unique_lock<std::mutex> lk(seededDraws, std::defer_lock);
+  if (_seed >= 0) { lk.lock(); std::srand((unsigned)(_seed + (long)_calls)); }
   _calls++;
   dSub.assign(points, 0); dCtrl.assign(_sizeControlSet > 0 ? _sizeControlSet : 1, 0); dTrials.assign(_trials > 0 ? _trials : 1, 0);
   for (auto& v : dSub) v = std::rand();                      // RandomMatching::subsampleMask (RandomMatching.cpp:183)

@@ -816,6 +816,7 @@ extern "C" int tsd_scan_preregister(tsd_sensor* s, const tsd_tsdpdf_params* prm,
   // A scan of this sensor may be IN FLIGHT (submitted, not collected): the pre-registration of the scan after it is then armed ahead --
   // its inputs are copied behind that scan's own pre-registration kernels (which read the same device buffer), beside its registration.
   const bool inflight = s->submitted;
+  if (s->inflight) return set_error(ctx, TSD_E_ARG, "tsd_scan_preregister: the sensor has a batched / split scan in flight (arm it between two scans)", hipSuccess);
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (inflight && s->ev_pre) TSD_HIP_CHECK(ctx, hipEventSynchronize(s->ev_pre));      // (the in-flight scan's own copy has left the pinned buffer)
   tsd_sensor::PreLayout L{};

@@ -52,7 +52,7 @@ class Robot:
         self.rays = self.o.rays_rescale(self.rays, self.cs, 1.0)
 
     # ---- oracle side, split like a batch: localise against the grid as it is, apply the push later
-    def localise(self, og, data, mask, bounds):
+    def localise(self, og, data, mask, bounds, draws=None):
         o, kw = self.o, self.kw
         out = dict(pushed=0, reg_error=0, pairs=0, valid_model=0, no_model=0, iterations=0, state=0)
         if self.last_pose is None:
@@ -66,7 +66,15 @@ class Robot:
         scene, ms, _ = o.scene_from_scan(self.rays_local, data, mask)
         M = co.reshape(-1, 2)[mo.astype(bool)]
         S = scene.reshape(-1, 2)[ms.astype(bool)]
-        r = o.icp(M, S, self.pose, kw["icp_iterations"], kw["dist_filter_max"], kw["dist_filter_min"], bounds)
+        if draws is None:
+            r = o.icp(M, S, self.pose, kw["icp_iterations"], kw["dist_filter_max"], kw["dist_filter_min"], bounds)
+        else:
+            # registration_mode 3 (ThreadLocalize.cpp:557-567): TSD_PDFMatching::match on the beam-indexed sets, its result is Tinit
+            m = o.tsdpdf_match(og, self.pose, co, mo, scene, ms, kw["trials"], kw["size_control_set"], kw["zrand"],
+                               np.radians(kw["ransac_phi_max"]), kw["angle_increment"], *draws)
+            out["pre"] = (m["candidates"], m["idx"], m["i"])
+            self.scene_last = (scene, ms)
+            r = o.icp_init(M, S, self.pose, kw["icp_iterations"], kw["dist_filter_max"], kw["dist_filter_min"], bounds, m["T"])
         T = r["T"]
         out.update(pairs=r["pairs"], iterations=r["iterations"], state=r["state"])
         Tf = o.f64(T).reshape(9)
@@ -139,6 +147,44 @@ def test_batch_matches_oracle(oracle, cfg, n_robots, n_scans):
         res = batch.results()
         for i, (ro, sr) in enumerate(zip(ros, res)):
             worst = max(worst, _compare(k, i, ro, sr))
+    H.assert_grids_equal(og.dump(), dg.download_tiles(), 1e-5)
+    batch.close()
+    for s in sensors:
+        s.close()
+
+
+def test_batch_with_the_pre_registration_matches_oracle(oracle):
+    """registration_mode 3 for several robots on one grid (the reference runs `case TSD` in every robot's thread,
+    /root/reference/src/ThreadLocalize.cpp:557-567): every robot's pre-registration is armed (tsd_scan_preregister: scene points + the
+    three rand() streams) and runs INSIDE the batch -- normals, lists, scoring, arg-max on the device behind the batch's ray casts,
+    against the grid as it is before any push of the batch -- and its result is the Tinit of that robot's registration.  Oracle side:
+    the same order on the oracle's primitives.  Winner, candidate count, pairs, iterations, state, gates exact; poses within the bar."""
+    n_robots, n_scans = 3, 8
+    gc, geo, kw, og, dg, robots, scans, sensors, params, gates = _setup(oracle, "cfg1", n_robots, n_scans)
+    kw.update(trials=40, size_control_set=120)
+    batch = capi.TsdBatch(dg, n_robots)
+    bounds = (dg.min_x, dg.max_x, dg.min_y, dg.max_y)
+    rng = np.random.default_rng(4242)
+    phi_max, res = np.radians(kw["ransac_phi_max"]), kw["angle_increment"]
+    for k in range(1, n_scans):
+        ing = [rb.ingest(sc[k]) for rb, sc in zip(robots, scans)]
+        draws = [tuple(rng.integers(0, 2 ** 31 - 1, m) for m in (geo.beams, kw["size_control_set"], kw["trials"])) for _ in robots]
+        # robot 1 sits every third round out of the pre-registration: armed and unarmed scans may share a batch
+        armed = [not (i == 1 and k % 3 == 0) for i in range(n_robots)]
+        ros = [rb.localise(og, d_, m_, bounds, dr if a else None) for rb, (d_, m_, _), dr, a in zip(robots, ing, draws, armed)]
+        for rb in robots:
+            rb.apply_push(og)
+        for rb, s, (d_, m_, _), dr, a in zip(robots, sensors, ing, draws, armed):
+            if a:
+                sc, ms, _n = oracle.scene_from_scan(rb.rays_local, d_, m_)
+                s.preregister(sc, ms, kw["trials"], kw["size_control_set"], kw["zrand"], phi_max, res, *dr)
+        batch.begin(sensors, [x[0] for x in ing], [x[1] for x in ing], [x[2] for x in ing], params, gates)
+        res_h = batch.results()
+        for i, (ro, sr) in enumerate(zip(ros, res_h)):
+            _compare(k, i, ro, sr)
+            if armed[i] and not ro["no_model"]:
+                pr = sensors[i].preregistration_result()
+                assert (pr["candidates"], pr["idx"], pr["i"]) == ro["pre"], f"round {k} robot {i}: pre-registration {pr} vs {ro['pre']}"
     H.assert_grids_equal(og.dump(), dg.download_tiles(), 1e-5)
     batch.close()
     for s in sensors:

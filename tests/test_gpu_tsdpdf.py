@@ -269,3 +269,50 @@ def test_facade_registration_mode_3_matches_oracle(oracle, cfg, n, trials):
     e = math.hypot(rh["pose"][0, 2] - poses[-1, 0], rh["pose"][1, 2] - poses[-1, 1])
     assert e < 0.1, f"tracking error {e} m"
     node.close()
+
+
+def test_facade_two_robots_registration_mode_3_through_the_batched_path(oracle):
+    """registration_mode 3 for the reference's multi-robot mode (every ThreadLocalize runs `case TSD` itself,
+    /root/reference/src/ThreadLocalize.cpp:557-567; SlamNode.cpp:101-122: one shared grid): the facade's dispatcher batches the robots'
+    scans and the pre-registration runs fused inside the batch (tsd_scan_preregister + tsd_batch_*), no longer through the unfused host
+    calls.  Fed in turn (a batch of one each time = the serial loop) against the oracle's shared-grid loop in mode 3, each robot with
+    its own seeded rand() sequence."""
+    gc, geo, scene = synth.CONFIGS["cfg1"]
+    n = 10
+    offs = [(0.37, -0.21, 0.1), (-0.7, 0.4, 0.0)]
+    geo_msg = synth.ScanGeometry(geo.beams, float(np.float32(geo.angle_min)), float(np.float32(geo.angle_increment)))
+    ctrl, zrand, phimax, trials, seeds = 120, 0.25, 30.0, 60, (4711, 815)
+    scans = []
+    for (ox, oy, yaw) in offs:
+        w = synth.World(scene, gc, start_xy=[0.5 * gc.width + ox, 0.5 * gc.width + oy])
+        scans.append(synth.scans_for(w, geo, synth.trajectory(w, n, yaw0=yaw)))
+    mode3 = dict(registration_mode=3, trials=trials, size_control_set=ctrl, zrand=zrand, ransac_phi_max=phimax)
+    so0 = oracle.Slam(**slam_kwargs(gc, geo_msg, local_offset_x=offs[0][0], local_offset_y=offs[0][1], local_offset_yaw=offs[0][2], **mode3))
+    so1 = oracle.Slam(shared_with=so0, **slam_kwargs(gc, geo_msg, local_offset_x=offs[1][0], local_offset_y=offs[1][1],
+                                                       local_offset_yaw=offs[1][2], **mode3))
+    sos = (so0, so1)
+    params = facade.node_params(gc, geo, robot_nbr=2)
+    params.update({"robot_0/name": "georg", "robot_1/name": "simon", "trials": trials, "sizeControlSet": ctrl, "zrand": zrand})
+    for name, (ox, oy, yaw), seed in zip(("georg", "simon"), offs, seeds):
+        params.update({f"tsd_slam/{name}/local_offset_x": ox, f"tsd_slam/{name}/local_offset_y": oy, f"tsd_slam/{name}/local_offset_yaw": yaw,
+                       f"{name}/dist_filter_max": 0.4, f"{name}/dist_filter_min": 0.02, f"{name}/icp_iterations": 30,
+                       f"{name}/registration_mode": 3, f"{name}/ransac_phi_max": phimax, f"{name}/tsdpdf_seed": seed})
+    params = {k: v for k, v in params.items() if not k.startswith("tsd_slam/local_offset")}
+    node = facade.SlamNode(params, synchronous=True)
+    b0 = node.batch_stats()
+    for k in range(n):
+        for r in (0, 1):
+            if k > 0:
+                sos[r].set_draws(*_libc_draws(seeds[r] + (k - 1), geo.beams, ctrl, trials))
+            ro = sos[r].process_scan(scans[r][k])
+            node.laser(scans[r][k], geo.angle_min, geo.angle_increment, robot=r)
+            rh = node.report(r)
+            d, a = H.pose_delta(np.array(ro.pose[:]).reshape(3, 3), rh["pose"])
+            assert d <= 1e-4 and a <= 1e-4, f"scan {k} robot {r}: {d} m {a} rad"
+            if k > 0:
+                assert (ro.pairs, ro.iterations, ro.icp_state) == (rh["pairs"], rh["iterations"], rh["icp_state"]), f"scan {k} robot {r}"
+                assert bool(ro.pushed) == bool(rh["pushed"]) and bool(ro.reg_error) == bool(rh["reg_error"])
+    b1 = node.batch_stats()
+    assert b1[1] - b0[1] == 2 * (n - 1), "the robots' scans did not go through the batched dispatcher"
+    H.assert_grids_equal(so0.grid.dump(), node.grid().download_tiles(), 1e-5)
+    node.close()
