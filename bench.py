@@ -546,7 +546,9 @@ def run_slam(args, gc, geo, scene, K, W, every, every_upd, every_icp, device, ra
             params[f"tsd_slam/robot{r}/local_offset_yaw"] = 0.1
             # the ICP keys are per robot in multi-robot mode (ThreadLocalize.cpp:86-88: _robotName + "dist_filter_max" ...)
             params.update({f"robot{r}/dist_filter_max": 0.4, f"robot{r}/dist_filter_min": 0.02, f"robot{r}/icp_iterations": 30,
-                           f"robot{r}/registration_mode": 0})
+                           f"robot{r}/registration_mode": args.registration_mode})
+            if args.registration_mode:
+                params[f"robot{r}/tsdpdf_seed"] = 20261003 + 1000 * r
     if args.estimator:
         params["icp_estimator"] = args.estimator
     if args.registration_mode:
