@@ -389,7 +389,12 @@ int tsd_push_stats_total(tsd_ctx* ctx, tsd_push_stats* total, int64_t* pushes, i
  * Sensor::dataToCartesianVectorMask gives for the scan (beam-indexed); the draws as in tsd_tsdpdf_match.  One-shot.  The inputs are
  * copied at the call (the caller's buffers are free on return) and travel to the device on the side stream right away.  It may be
  * called while a scan of this sensor is in flight (submitted, not yet collected): it then arms the scan AFTER that one, and the copy is
- * ordered behind the in-flight scan's own pre-registration kernels. */
+ * ordered behind the in-flight scan's own pre-registration kernels (refused with TSD_E_ARG when that needs a larger layout than the
+ * in-flight scan's: arm it after the collect).
+ * Several robots on one grid: a sensor armed this way may be part of a tsd_batch_begin -- its pre-registration then runs inside the
+ * batch, on the grid's stream behind the batch's ray casts (all armed robots score against the grid as it is before any push of the
+ * batch; the reference runs `case TSD` in every robot's own thread, ThreadLocalize.cpp:557-567), and its result is that robot's Tinit.
+ * Armed and unarmed sensors may share a batch.  Not while the sensor has a batched / split scan in flight. */
 int tsd_scan_preregister(tsd_sensor* s, const tsd_tsdpdf_params* params, const double* scene_xy_2B, const uint8_t* mask_s,
                          const int* draws_subsample, const int* draws_control, const int* draws_trials);
 /* Asynchronous mapping for the fused scan of this sensor.  The reference's ThreadMapping is a thread of its own: queuePush returns at
