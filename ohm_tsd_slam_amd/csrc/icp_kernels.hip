@@ -100,7 +100,7 @@ struct IcpLds {
   double2* mxy;                    // model (angular order)
   double2* uxy;                    // unit direction of every model point (0,0 for a point at the origin)
   double2* nxy;                    // model normals (point-to-line estimator only; nullptr otherwise)
-  unsigned long long* slotD;       // [cap] reciprocal filter: min d2 (bit pattern) per model slot
+  unsigned long long* slotD;       // [2][cap] reciprocal filter: min d2 (bit pattern) per model slot, the two halves used by alternate steps
   int* slotI;                      // [cap] winning scene index per model slot
   int* morig;                      // original model index of a slot (tie-breaking)
   double2* list_xy;                // [lcap] work list: point
@@ -128,7 +128,7 @@ __host__ __device__ inline size_t icp_region_bytes(int cap, int threads)
   if (tr > b) b = tr;
   return (b + 15u) & ~(size_t)15u;
 }
-__host__ __device__ inline size_t icp_lds_bytes_for(int cap, int threads, bool normals = false)
+__host__ __device__ inline size_t icp_lds_base_bytes(int cap, int threads, bool normals)      // with ONE half of the slot array
 {
   // the staging (cap double2 + cap int) aliases the list + result arrays: 40 * lc >= 20 * cap
   return sizeof(double2) * 2 * (size_t)cap + sizeof(double2) * 2 * ICP_PAD + sizeof(unsigned long long) * (size_t)cap + sizeof(int) * 2 * (size_t)cap +
@@ -144,6 +144,16 @@ constexpr size_t ICP_TL_BYTES = (size_t)TSD_ICP_TL_STEPS * 8 * 16 * sizeof(long 
 #else
 constexpr size_t ICP_TL_BYTES = 0;
 #endif
+// The reciprocal filter's slot array has two halves used by alternate steps wherever the CU's 160 KB hold them (every shape the node
+// runs; not the largest point counts of tsd_icp with the point-to-line estimator's normals): see the loop.  Same rule on both sides.
+__host__ __device__ inline int icp_slot_halves(int cap, int threads, bool normals)
+{
+  return icp_lds_base_bytes(cap, threads, normals) + sizeof(unsigned long long) * (size_t)cap + ICP_TL_BYTES <= 160u * 1024u ? 2 : 1;
+}
+__host__ __device__ inline size_t icp_lds_bytes_for(int cap, int threads, bool normals = false)
+{
+  return icp_lds_base_bytes(cap, threads, normals) + sizeof(unsigned long long) * (size_t)cap * (size_t)(icp_slot_halves(cap, threads, normals) - 1);
+}
 
 // a wave-uniform value the compiler must keep in a vector register
 __device__ __forceinline__ double vreg(double x) { asm volatile("" : "+v"(x)); return x; }
@@ -610,7 +620,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     p = reinterpret_cast<char*>(L.list_xy) + icp_region_bytes(cap, (int)blockDim.x);
     // staging view of the same 40*lcap bytes: cap double2 then cap int (40*lcap >= 20*cap)
     L.start = reinterpret_cast<int*>(reinterpret_cast<char*>(L.stage_s) + sizeof(double2) * (size_t)cap);
-    L.slotD = reinterpret_cast<unsigned long long*>(p); p += sizeof(unsigned long long) * (size_t)cap;
+    L.slotD = reinterpret_cast<unsigned long long*>(p); p += sizeof(unsigned long long) * (size_t)icp_slot_halves(cap, (int)blockDim.x, PTL) * (size_t)cap;
     L.red = reinterpret_cast<double*>(p); p += sizeof(double) * 2 * ICP_MAXW * 16;
     L.cst = reinterpret_cast<double*>(p); p += sizeof(double) * 16;
     L.tail = reinterpret_cast<IcpTail*>(p); p += (sizeof(IcpTail) + 15) & ~(size_t)15;
@@ -823,7 +833,8 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     L.mxy[nM + i] = L.mxy[i % nM];
     L.mxy[-1 - i] = L.mxy[nM - 1 - (i % nM)];
   }
-  for (int k = tid; k < cap; k += T) { L.slotD[k] = ~0ull; L.slotI[k] = INT_MAX; }
+  const int slot_halves = icp_slot_halves(cap, T, PTL);
+  for (int k = tid; k < cap; k += T) { L.slotD[k] = ~0ull; if (slot_halves == 2) L.slotD[cap + k] = ~0ull; L.slotI[k] = INT_MAX; }
   if constexpr ((OPT & 8) != 0) { for (int k = tid; k < ICP_MAXW * 16; k += T) L.red[k] = 0.0; }    // (block_totals8 reads the rows of absent waves)
 #ifdef TSD_ICP_STAMPS
   if (tid == 0) for (int i = 0; i < 8; i++) L.ired[IR_DBG + i] = 0;
@@ -858,6 +869,11 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
   while (state == TSD_ICP_PROCESSING) {
     const double thr_before = thr;
     TL(0);
+    // The slots a step's pairs went into are given back behind barrier 2 of that step, and the next step's atomics come before ITS
+    // barrier 1: nothing orders the two.  They are a transform and a tier 0 apart (~2 500 cycles) while the waves leave a barrier within
+    // tens of cycles of each other, so the hand-back always won -- but only by timing.  Alternate steps use alternate halves of the slot
+    // array (where the LDS holds two, icp_slot_halves): a half is given back a whole step (two barriers) before it is used again.
+    unsigned long long* const slotD = L.slotD + (size_t)(iter & (unsigned)(slot_halves - 1)) * (size_t)cap;
 
     // -- phase A: pre-filter + exact NN + distance filter (per scene point)
     // OutOfBoundsFilter2D: when even a disc of the largest possible scene radius around the sensor
@@ -998,7 +1014,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
       for (int q = 0; q < R; q++) { mine[q] = (unsigned long long)__double_as_longlong(bd[q]); was[q] = ~0ull; }
 #pragma unroll
       for (int q = 0; q < R; q++)
-        if (keep[q] && !(ABL & 16)) was[q] = atomicMin(&L.slotD[hint[q]], mine[q]);
+        if (keep[q] && !(ABL & 16)) was[q] = atomicMin(&slotD[hint[q]], mine[q]);
 #pragma unroll
       for (int q = 0; q < R; q++)
         if (need[q]) {
@@ -1012,7 +1028,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     for (int q = 0; q < R; q++) {
       if (keep[q] && !(ABL & 16)) {
         const unsigned long long mine = (unsigned long long)__double_as_longlong(bd[q]);
-        tie |= atomicMin(&L.slotD[hint[q]], mine) == mine;
+        tie |= atomicMin(&slotD[hint[q]], mine) == mine;
       }
       // work list of the points that need a search (an entry beyond the list capacity waits for its pass)
       if (need[q]) {
@@ -1035,7 +1051,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
       int nn = L.ired[IR_CNT];
       tie_any = L.ired[IR_TIE];
 #pragma unroll
-      for (int q = 0; q < R; q++) sd[q] = L.slotD[hint[q]];
+      for (int q = 0; q < R; q++) sd[q] = slotD[hint[q]];
       asm volatile("" : "+v"(nn), "+v"(tie_any));                 // (all five reads issued before the first is waited for)
       n_need = nn;
     } else n_need = L.ired[IR_CNT];
@@ -1114,7 +1130,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
               keep[q] = bd[q] <= thr;                                  // DistanceFilter::filter
               if (keep[q]) {
                 const unsigned long long mine = (unsigned long long)__double_as_longlong(bd[q]);
-                tie |= atomicMin(&L.slotD[k], mine) == mine;
+                tie |= atomicMin(&slotD[k], mine) == mine;
               }
             } else { bd[q] = __builtin_inf(); lb[q] = -1.0; }          // non-finite input point
           }
@@ -1125,7 +1141,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
       if constexpr ((OPT & 4) != 0) {                              // the searches' pairs went into the slots: read again
         tie_any = L.ired[IR_TIE];
 #pragma unroll
-        for (int q = 0; q < R; q++) sd[q] = L.slotD[hint[q]];
+        for (int q = 0; q < R; q++) sd[q] = slotD[hint[q]];
       }
     }
 #ifdef TSD_ICP_STAMPS
@@ -1142,7 +1158,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     {
       if constexpr ((OPT & 4) == 0) {
 #pragma unroll
-        for (int q = 0; q < R; q++) sd[q] = L.slotD[hint[q]];
+        for (int q = 0; q < R; q++) sd[q] = slotD[hint[q]];
         tie_any = L.ired[IR_TIE];
       }
 #pragma unroll
@@ -1266,7 +1282,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     // everybody is past the winner test: give the touched slots back, clear the work list counter
 #pragma unroll
     for (int q = 0; q < R; q++)
-      if (keep[q]) L.slotD[hint[q]] = ~0ull;
+      if (keep[q]) slotD[hint[q]] = ~0ull;
     if (tid == 0) L.ired[IR_CNT] = 0;
     STAMP(3);
 
