@@ -559,8 +559,14 @@ __device__ __forceinline__ float beam_limit(double r, unsigned mk, float mtf, fl
 // Lazy TsdGridPartition::init (TsdGridPartition.cpp:88-134) is folded in (a fresh tile's old value is known: non-candidates get
 // the init value from phase A / the fix-up, candidates start from it in phase C); KIND_EMPTY: increaseEmptiness over the 33x33
 // cells.  The workgroup leaves the tile's record and adds it to the tile's running totals (no-return atomics).
+// -DTSD_UPDATE_PREFETCH=1: single-tile workgroups (cfg 2) request their tile's 128 lines ahead of phase A.  Round 3's default; round 4
+// switched it OFF: it buys the kernel 0.4 us inside the SLAM loop (13.4 -> 13.0 us; nothing push-only, nothing in scans/s: 5 735 against
+// 5 757) for 5.5 MB of reads per push that nothing uses -- 52 % of a visited tile's cells are not candidates -- i.e. HBM traffic 24.4 MB
+// against 18.9 MB for 15 MB of algorithmic bytes (1.63 -> 1.26; same-call A/B and PMC passes, gpurun_out/r4l).  Requesting
+// only the lines that hold candidates, as soon as phase A knows them, was built and measured worse (15.3 us: eight more live registers
+// in a 96-register kernel spill).
 #ifndef TSD_UPDATE_PREFETCH
-#define TSD_UPDATE_PREFETCH 1
+#define TSD_UPDATE_PREFETCH 0
 #endif
 #ifndef TSD_UPDATE_WPS
 #define TSD_UPDATE_WPS 5
