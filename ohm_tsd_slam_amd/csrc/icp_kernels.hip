@@ -72,12 +72,14 @@ constexpr int ABL = TSD_ICP_ABLATE;
 //   8  closed form: seven pair sums + the pair count reduced inside a wave in registers (DPP halving + gfx950's permlane swaps) instead
 //      of nine through an LDS transpose  [summation order changes: the totals' last bits]
 //   16 loop control on wave-uniform scalars (readfirstlane): scalar branches instead of exec-mask loops
+//   64 tier 0 trimmed: exact ties looked at once per wave (not a branch per point), the bound renewals' flags formed in the two steps
+//      that renew (not a branch per point and step), max(lb, 0) as one instruction
 //   32 scene points go to the waves that have a SIMD's issue priority first: waves 0-3 of a workgroup are the older wave of their SIMD
 //      and issue at full rate, waves 4+ only get the slots the older wave leaves (tools/exp/valu.hip: 4.9 against 8.9 cycles per fp64
 //      instruction) -- so waves 0-3 take three 64-point blocks each and waves 4-7 share what is left, one block each where possible,
 //      and the launch brings as many of them as there are blocks left  [which wave sums which pairs changes: rounding of the totals]
 #ifndef TSD_ICP_OPT
-#define TSD_ICP_OPT 63
+#define TSD_ICP_OPT 127
 #endif
 constexpr int OPT = TSD_ICP_OPT;
 // -DTSD_ICP_DUP=<bits>: timing experiments that run a part of every step TWICE with the same outcome (results unchanged), so the
@@ -860,6 +862,14 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
   // rows of the pose's rotation block are unit vectors up to rounding: |R_p s| <= pnorm |s| per axis
   const double pnorm = fmax(sqrt(P00 * P00 + P01 * P01), sqrt(P10 * P10 + P11 * P11)) * (1.0 + 1e-9);
 
+  // OutOfBoundsFilter2D can filter nothing while a disc of radius (largest scene radius + accumulated translation) x pnorm around the
+  // sensor lies inside the bounds: the largest accumulated translation (squared, rounded down) for which that holds
+  double tcum_lim2 = -1.0;
+  {
+    const double slack = fmin(fmin(P02 - bmin_x, bmax_x - P02), fmin(P12 - bmin_y, bmax_y - P12));
+    const double lim = ((slack - 2e-6) / (pnorm * (1.0 + 2e-6)) - scene_rmax) * (1.0 - 1e-6);
+    if (lim > 0.0) tcum_lim2 = lim * lim * (1.0 - 1e-6);
+  }
   double c0[4] = {0.0, 0.0, 0.0, 0.0};       // centring point of the pair sums: last step's centroids
 
   const bool has_trace = trace != nullptr;   // (a scalar: reading the pointer back from LDS every step cost thread 0's wave a round trip)
@@ -878,10 +888,16 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     // -- phase A: pre-filter + exact NN + distance filter (per scene point)
     // OutOfBoundsFilter2D: when even a disc of the largest possible scene radius around the sensor
     // lies inside the bounds nothing can be filtered and the per-point transform is skipped.
-    const double tcum = (double)(__builtin_amdgcn_sqrtf((float)(Tf[2] * Tf[2] + Tf[5] * Tf[5]) * 1.000001f) * 1.000001f);
-    const double reach = (scene_rmax + tcum) * pnorm * (1.0 + 1e-6) + 1e-6;
-    const bool all_in = (int)(P02 - reach > bmin_x) & (int)(P02 + reach < bmax_x) &
-                        (int)(P12 - reach > bmin_y) & (int)(P12 + reach < bmax_y);
+    bool all_in;
+    if constexpr ((OPT & 64) != 0) {
+      // (the same sufficient condition solved for the accumulated translation once, ahead of the loop: three operations per step)
+      all_in = (Tf[2] * Tf[2] + Tf[5] * Tf[5]) * (1.0 + 4e-6) < tcum_lim2;
+    } else {
+      const double tcum = (double)(__builtin_amdgcn_sqrtf((float)(Tf[2] * Tf[2] + Tf[5] * Tf[5]) * 1.000001f) * 1.000001f);
+      const double reach = (scene_rmax + tcum) * pnorm * (1.0 + 1e-6) + 1e-6;
+      all_in = (int)(P02 - reach > bmin_x) & (int)(P02 + reach < bmax_x) &
+               (int)(P12 - reach > bmin_y) & (int)(P12 + reach < bmax_y);
+    }
     double bd[R]; bool keep[R], need[R];
     int ent[R];
     double2 mw[R];                            // the neighbour's coordinates
@@ -914,7 +930,13 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
         const double dx1 = x - mh[q].x, dy1 = y - mh[q].y, dx2 = x - mh2[q].x, dy2 = y - mh2[q].y;
         const double d1 = dx1 * dx1 + dy1 * dy1, d2 = dx2 * dx2 + dy2 * dy2;
         bool swp = (ABL & 32) ? false : d2 < d1;
-        if (d2 == d1 && hint2[q] != hint[q]) swp = L.morig[hint2[q]] < L.morig[hint[q]];   // exact tie (rare)
+        if constexpr ((OPT & 64) != 0) {
+          // (an exact tie between two different candidates -- rare -- is settled by the original model index: looked for once per wave)
+          if (__builtin_expect(__ballot((d2 == d1) & (hint2[q] != hint[q])) != 0ull, 0))
+            if (d2 == d1 && hint2[q] != hint[q]) swp = L.morig[hint2[q]] < L.morig[hint[q]];
+        } else {
+          if (d2 == d1 && hint2[q] != hint[q]) swp = L.morig[hint2[q]] < L.morig[hint[q]];   // exact tie (rare)
+        }
         const double d = swp ? d2 : d1;
         const int kn = swp ? hint2[q] : hint[q], ko = swp ? hint[q] : hint2[q];
         mw[q] = swp ? mh2[q] : mh[q];
@@ -922,7 +944,9 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
         if constexpr ((OPT & 1) != 0) {
           // The same decisions from three compares.  "known" (lb > 0) is folded into the bound (max(lb, 0)^2 = 0 makes `same` and `drop`
           // false: the point searches), "pre" into the operands (distance and bound +inf: `drop` is true, nothing is kept or searched).
-          const double lbp = fmax(lb[q], 0.0);
+          double lbp;
+          if constexpr ((OPT & 64) != 0) asm("v_max_f64 %0, %1, 0" : "=v"(lbp) : "v"(lb[q]));      // (fmax() brings a canonicalising v_max along)
+          else lbp = fmax(lb[q], 0.0);
           const double inf = __builtin_inf();
           const double lb2 = pre ? lbp * lbp : inf;
           const double de = pre ? d : inf;
@@ -932,10 +956,12 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
           bd[q] = de;
           keep[q] = same & le;
           need[q] = !(same | drop);
-          if (refresh) {                                           // (wave-uniform; see below)
-            const bool weak = !drop & (lb2 < WEAK_MULT * de) & (lb2 > 0.0);
-            need[q] = need[q] | weak;
-            keep[q] = keep[q] & !weak;
+          if constexpr ((OPT & 64) == 0) {
+            if (refresh) {                                         // (wave-uniform; see below)
+              const bool weak = !drop & (lb2 < WEAK_MULT * de) & (lb2 > 0.0);
+              need[q] = need[q] | weak;
+              keep[q] = keep[q] & !weak;
+            }
           }
           if constexpr ((ABL & 1) != 0) need[q] = false;
         } else {
@@ -958,6 +984,21 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
         keep[q] = keep[q] & !need[q];
         }
         ent[q] = -1;
+      }
+      if constexpr ((OPT & 1) != 0 && (OPT & 64) != 0 && (ABL & 1) == 0) {
+        // the two scheduled bound renewals (see `weak` below): formed here, in the two steps that renew, from what the loop above left
+        // -- bd is +inf for a point outside the bounds or an empty register slot, which makes `drop` true
+        if (refresh) {
+#pragma unroll
+          for (int q = 0; q < R; q++) {
+            if (q >= Rn) continue;
+            const double lbp = fmax(lb[q], 0.0), lb2 = bd[q] < __builtin_inf() ? lbp * lbp : __builtin_inf();
+            const bool drop = (lb2 > thr) & !(bd[q] <= thr);
+            const bool weak = !drop & (lb2 < WEAK_MULT * bd[q]) & (lb2 > 0.0);
+            need[q] = need[q] | weak;
+            keep[q] = keep[q] & !weak;
+          }
+        }
       }
     }
     TL(2);                                     // tier 0 decided
