@@ -573,7 +573,6 @@ __device__ __forceinline__ void block_totals8(const IcpLds& L, const double (&v)
   __syncthreads();
   if (tl && lane == 0) tl[8] = clock64();
   double* bc = L.red + (ICP_MAXW + wave) * 16;
-  double xs = 0.0;
   if (lane < 8) {
     double x[MAXW];
 #pragma unroll
@@ -582,17 +581,7 @@ __device__ __forceinline__ void block_totals8(const IcpLds& L, const double (&v)
     for (int st = 1; st < MAXW; st <<= 1)
 #pragma unroll
       for (int r = 0; r + st < MAXW; r += 2 * st) x[r] += x[r + st];
-    if constexpr ((OPT & 128) == 0) bc[lane] = x[0];
-    else {
-      // lanes 0-7 hold the totals: to every lane through v_readlane (scalar registers) instead of an LDS write + read
-      asm volatile("" : "+v"(x[0]));
-      xs = x[0];
-    }
-  }
-  if constexpr ((OPT & 128) != 0) {
-#pragma unroll
-    for (int k = 0; k < 8; k++) tot[k] = read_lane(xs, k);
-    return;
+    bc[lane] = x[0];
   }
   // broadcast through LDS (a wave's LDS accesses execute in order)
 #pragma unroll
@@ -959,18 +948,6 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
           if constexpr ((OPT & 64) != 0) asm("v_max_f64 %0, %1, 0" : "=v"(lbp) : "v"(lb[q]));      // (fmax() brings a canonicalising v_max along)
           else lbp = fmax(lb[q], 0.0);
           const double inf = __builtin_inf();
-          if constexpr ((OPT & 256) != 0) {
-            // (a point outside the bounds keeps the defaults -- distance +inf, neither kept nor searched -- by a branch on the lane
-            // mask instead of four selects per point: in the steady state every point is inside)
-            if (pre) {
-              const double lb2 = lbp * lbp;
-              const bool same = d < lb2, le = d <= thr;
-              const bool drop = (lb2 > thr) & !le;
-              bd[q] = d;
-              keep[q] = same & le;
-              need[q] = !(same | drop);
-            }
-          } else {
           const double lb2 = pre ? lbp * lbp : inf;
           const double de = pre ? d : inf;
           const bool same = de < lb2;                              // neighbour proven
@@ -985,7 +962,6 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
               need[q] = need[q] | weak;
               keep[q] = keep[q] & !weak;
             }
-          }
           }
           if constexpr ((ABL & 1) != 0) need[q] = false;
         } else {
