@@ -704,7 +704,8 @@ def run_slam(args, gc, geo, scene, K, W, every, every_upd, every_icp, device, ra
         occ_ms, occ_n = 0.0, 0
         if args.occupancy:
             # row N1 (occupancy extraction: k_occ_cells + k_occ_mark, events around both) on the map the timed region built
-            grid.occupancy(False, 2)
+            occ_map, occ_changes = grid.occupancy(False, 2)
+            occ_marked = int((occ_map == 100).sum())
             grid.profile(True, kernels="occupancy"); grid.profile_reset()
             for _ in range(args.occupancy):
                 grid.occupancy(False, 2)
@@ -753,6 +754,8 @@ def run_slam(args, gc, geo, scene, K, W, every, every_upd, every_icp, device, ra
             out["merge_checked"] = merge_checked
         if args.occupancy and occ_n:
             out["ms_occupancy_extract"] = occ_ms / occ_n
+            out["occupancy_sign_changes"] = int(occ_changes)      # what RayCastAxisAligned2D::calcCoords returns: marks written
+            out["occupancy_cells_marked"] = occ_marked
         if merger is not None:
             merger.close()        # (the communicator refers to the grid context: it goes first)
         node.close()
