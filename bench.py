@@ -308,8 +308,9 @@ def main():
     K, W = args.steps, args.warmup
     # (several robots: many more dispatches per step, and every sampled one costs the chain of dependent launches ~10 us)
     every = args.sample_every or (32 if args.robots > 1 else 8)
-    # the registration (the metric's second half, and its spread) keeps every fourth dispatch in a short run
-    every_icp = args.sample_every or (every if (K >= 80 or args.robots > 1) else 4)
+    # the registration (the metric's second half, and its spread) keeps every second dispatch in a short run: ten samples in the driver's
+    # 20 steps, at ~3 us of the chain per sampled dispatch
+    every_icp = args.sample_every or (every if (K >= 80 or args.robots > 1) else (2 if K < 50 else 4))
     # the roofline kernel: every SECOND dispatch in a short run (the driver's 20 steps would otherwise leave five samples; every
     # dispatch was measured to cost the 20-step `value` 2.5 %: 4 800 against 4 920, 5 040 with a sixteenth of the dispatches sampled)
     every_upd = args.sample_every or (2 if (K < 50 and args.robots == 1) else every)
