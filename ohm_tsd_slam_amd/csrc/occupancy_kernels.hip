@@ -112,6 +112,13 @@ k_occ_mark(GridDev g, int8_t* __restrict__ out, int* __restrict__ count, int inf
   const unsigned n_sh = heads[sh * OCC_HEAD_STRIDE];
   // the tile (33 x 33 doubles) through LDS: every cell is looked at by up to four scan positions
   __shared__ double T[TILE_CELLS];
+  // The scan positions that hold a sign change (a few dozen of a surface tile's 2 112) are LISTED, and the interpolation, the two
+  // divisions and the rounding of a mark run over the list, one lane per change: inside the scan loop the ~250 instructions of a mark
+  // were executed by the whole wave for every loop round in which ANY lane had a change -- 12 of this kernel's 21 us at cfg 2
+  // (seven variants of the stores themselves had changed nothing).
+  __shared__ unsigned short s_ev[2 * TILE_PITCH * TILE_DIM];
+  __shared__ int s_nev;
+  if (threadIdx.x == 0) s_nev = 0;
   const double cs = g.cs;
   int n = 0;
   // A tile's 1 089 cells are five reads per thread, requested TOGETHER (as a plain loop the compiler had read -> wait -> LDS write five
@@ -143,21 +150,32 @@ k_occ_mark(GridDev g, int8_t* __restrict__ out, int* __restrict__ count, int inf
       const int py = col ? b : a, px = col ? a : b;
       const double prev = col ? T[(py - 1) * TILE_PITCH + px] : T[py * TILE_PITCH + px - 1];
       const double cur = T[py * TILE_PITCH + px];
-      if ((prev > 0 && cur < 0) || (prev < 0 && cur > 0)) {
-        const double interp = prev / (prev - cur);
-        double x, y;
-        if (!col) {
-          x = px * cs + cs * (interp - 1.0) + (X * TILE_DIM) * cs;
-          y = py * cs + (Y * TILE_DIM) * cs;
-        } else {
-          x = px * cs + (X * TILE_DIM) * cs;
-          y = py * cs + cs * (interp - 1.0) + (Y * TILE_DIM) * cs;
-        }
-        occ_mark(g, out, x, y, inflate, factor);
-        n++;
-      }
+      if ((prev > 0 && cur < 0) || (prev < 0 && cur > 0)) s_ev[atomicAdd(&s_nev, 1)] = (unsigned short)c;
     }
-    __syncthreads();            // (the LDS copy is rewritten by the next tile)
+    __syncthreads();
+    const int nev = s_nev;
+    for (int e = threadIdx.x; e < nev; e += 256) {
+      const int c = (int)s_ev[e];
+      const bool col = c >= TILE_PITCH * TILE_DIM;
+      const int cc = col ? c - TILE_PITCH * TILE_DIM : c;
+      const int a = cc / TILE_DIM, b = cc % TILE_DIM + 1;
+      const int py = col ? b : a, px = col ? a : b;
+      const double prev = col ? T[(py - 1) * TILE_PITCH + px] : T[py * TILE_PITCH + px - 1];
+      const double cur = T[py * TILE_PITCH + px];
+      const double interp = prev / (prev - cur);
+      double x, y;
+      if (!col) {
+        x = px * cs + cs * (interp - 1.0) + (X * TILE_DIM) * cs;
+        y = py * cs + (Y * TILE_DIM) * cs;
+      } else {
+        x = px * cs + (X * TILE_DIM) * cs;
+        y = py * cs + cs * (interp - 1.0) + (Y * TILE_DIM) * cs;
+      }
+      occ_mark(g, out, x, y, inflate, factor);
+      n++;
+    }
+    __syncthreads();            // (the LDS copy and the list are rewritten by the next tile)
+    if (threadIdx.x == 0) s_nev = 0;
     p = p_next;
   }
   n = wave_sum_i(n);
