@@ -658,14 +658,16 @@ def run_slam(args, gc, geo, scene, K, W, every, every_upd, every_icp, device, ra
         run_range(1 + W, 1 + W + K)
         if occ_thread is not None:
             occ_stop.set(); occ_thread.join()
-        grid.sync()
         if merger is not None:
-            merger.wait()
-            torch.cuda.synchronize()
+            torch.cuda.synchronize()      # the whole device: the grid's streams, the communicator's stream and the merge on it
+        else:
+            grid.sync()
         # this rank's K steps are done (device idle, merge complete).  The closing barrier follows; the job's time is the MAX over the
         # ranks of these local times (all ranks left the opening barrier together), which the all-reduce below takes -- so the
         # barrier's own latency (0.2-0.4 ms over gloo, a tenth of a 20-step region) is not part of anybody's K steps.
         elapsed = time.perf_counter() - t0
+        if merger is not None:
+            grid.sync(); merger.wait()    # (nothing left to wait for: the library's own bookkeeping of the merge's events)
         if dist is not None and full:
             dist.barrier()
         pygc.enable()
