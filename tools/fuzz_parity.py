@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of the HIP path against the oracle (test infrastructure: uses oracle/), beyond the fixed cases of tests/:
+random grid sizes / cell sizes / scenes / scan geometries, random sensor poses (not a trajectory), scans with zero / NaN / over-range
+readings sprinkled in, then per case: pushes (stats + every cell), ray casts (hit masks exact, coordinates 1e-9), registrations
+(pairs / iterations / state exact, T 1e-9), occupancy maps (byte-exact).  Stops at the first mismatch and prints the seed.
+usage (GPU box): python3 tools/fuzz_parity.py [cases] [first_seed]"""
+import math, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ohm_tsd_slam_amd import capi, synth
+from oracle import pyoracle as O
+from tests import helpers as H
+
+O.build()
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+t_start = time.time()
+tot = dict(pushes=0, raycasts=0, icps=0, occs=0)
+
+
+def spoil(rng, r32):
+    """zero / NaN / over-range / tiny readings at random beams (Sensor.cpp:246-272 treats each differently)"""
+    r = r32.copy()
+    n = len(r)
+    for val in (0.0, np.nan, 45.0, 0.0005):
+        k = rng.integers(0, max(2, n // 40))
+        r[rng.integers(0, n, k)] = val
+    if rng.random() < 0.3:                      # a dropped sector
+        a = rng.integers(0, n - 20); r[a:a + rng.integers(3, 20)] = 0.0
+    return r
+
+
+for case in range(n_cases):
+    seed = seed0 + case
+    rng = np.random.default_rng(seed)
+    map_log2 = int(rng.choice([8, 9, 9, 10, 10]))
+    cs = float(rng.choice([0.03, 0.05, 0.05, 0.07, 0.1]))
+    scene = str(rng.choice(["room", "pillars"]))
+    geo = synth.ScanGeometry.full_circle_360() if rng.random() < 0.4 else synth.ScanGeometry.utm30lx()
+    gc = synth.GridConfig(map_log2, cs)
+    world = synth.World(scene, gc)
+    W = gc.cells * cs
+    og = O.Grid(gc.map_size_log2, gc.cell_size, gc.max_trunc)
+    dg = capi.TsdGridDevice(gc.map_size_log2, gc.cell_size, gc.max_trunc)
+    content = np.full(gc.cells * gc.cells, -1, dtype=np.int8)
+    tag = f"seed {seed}: 2^{map_log2} cells @ {cs} m, {scene}, {geo.beams} beams"
+    try:
+        # a cluster of poses around a random point of the free space near the start (pushes must overlap for the registration to work)
+        x0 = world.start[0] + rng.uniform(-0.15, 0.15) * min(W, 20.0)
+        y0 = world.start[1] + rng.uniform(-0.15, 0.15) * min(W, 20.0)
+        yaw0 = rng.uniform(-math.pi, math.pi)
+        n_push = int(rng.integers(3, 9))
+        for k in range(n_push):
+            x = x0 + rng.uniform(-0.4, 0.4); y = y0 + rng.uniform(-0.4, 0.4); yaw = yaw0 + rng.uniform(-0.3, 0.3)
+            pose = synth.pose_matrix(x, y, yaw)
+            r32 = world.scan(x, y, yaw, geo)
+            if rng.random() < 0.6:
+                r32 = spoil(rng, r32)
+            data, mask = O.ingest_f32(r32, H.MAX_RANGE, geo.angle_increment)
+            so = og.push(pose, data, mask, geo.angle_increment, geo.angle_min, H.MAX_RANGE, H.MIN_RANGE, H.LOW_REFL)
+            sd = dg.push(pose, data, mask, geo.angle_increment, geo.angle_min, H.MAX_RANGE, H.MIN_RANGE, H.LOW_REFL)
+            assert so == sd, f"push {k}: stats differ\n oracle {so}\n hip    {sd}"
+            H.assert_grids_equal(og.dump(), dg.download_tiles(), 0.0)
+            tot["pushes"] += 1
+            if rng.random() < 0.3:
+                inflate = bool(rng.random() < 0.5)
+                oo, no = og.occupancy(content, inflate, 2)
+                od, nd = dg.occupancy(inflate, 2)
+                assert no == nd, f"occupancy: sign changes {no} / {nd}"
+                assert np.array_equal(oo.reshape(gc.cells, gc.cells), od), "occupancy maps differ"
+                tot["occs"] += 1
+        for k in range(3):
+            x = x0 + rng.uniform(-0.5, 0.5); y = y0 + rng.uniform(-0.5, 0.5); yaw = yaw0 + rng.uniform(-0.4, 0.4)
+            pose = synth.pose_matrix(x, y, yaw)
+            rl, rw = H.world_rays(O, geo, pose, gc.cell_size)
+            co, no_, mo, cnt_o = og.raycast(pose, rw, H.MIN_RANGE, H.MAX_RANGE)
+            cd, nd_, md, cnt_d = dg.raycast(pose, rw, H.MIN_RANGE, H.MAX_RANGE)
+            assert np.array_equal(mo, md), f"ray cast {k}: hit masks differ at beams {np.nonzero(mo != md)[0][:10]}"
+            sel = np.repeat(mo.astype(bool), 2)
+            if sel.any():
+                assert np.max(np.abs(co[sel] - cd[sel])) <= 1e-9 and np.max(np.abs(no_[sel] - nd_[sel])) <= 1e-9, "ray cast coordinates"
+            tot["raycasts"] += 1
+            # registration of a scan taken from a displaced pose against this ray cast's model
+            dxy = rng.uniform(-0.08, 0.08, 2); dyaw = rng.uniform(-0.03, 0.03)
+            r32 = world.scan(x + dxy[0], y + dxy[1], yaw + dyaw, geo)
+            if rng.random() < 0.5:
+                r32 = spoil(rng, r32)
+            data, mask = O.ingest_f32(r32, H.MAX_RANGE, geo.angle_increment)
+            scn, ms, _ = O.scene_from_scan(rl, data, mask)
+            M = co.reshape(-1, 2)[mo.astype(bool)]
+            S = scn.reshape(-1, 2)[ms.astype(bool)]
+            if len(M) < 3 or len(S) < 3:
+                continue
+            iters = int(rng.choice([30, 30, 25, 11, 5]))
+            bounds = (0.0, og.max_x, 0.0, og.max_x)
+            ro = O.icp(M, S, pose, iters, 0.4, 0.02, bounds, nn_mode=0)
+            rd = dg.icp(M, S, pose, dg.icp_params(iters, 0.4, 0.02))
+            assert (ro["pairs"], ro["iterations"], ro["state"]) == (rd.pairs, rd.iterations, rd.state), \
+                f"registration {k}: oracle {(ro['pairs'], ro['iterations'], ro['state'])} hip {(rd.pairs, rd.iterations, rd.state)}"
+            d, a = H.pose_delta(ro["T"], rd.T)
+            assert d <= 1e-9 and a <= 1e-9, f"registration {k}: |dT| {d} m {a} rad"
+            tot["icps"] += 1
+    except AssertionError as e:
+        print("MISMATCH", tag, "--", e)
+        sys.exit(1)
+    finally:
+        dg.close() if hasattr(dg, "close") else None
+    if case % 10 == 9:
+        print(f"{case + 1} cases ok ({tag}); {tot}; {time.time() - t_start:.0f} s", flush=True)
+print(f"all {n_cases} cases ok from seed {seed0}: {tot}; {time.time() - t_start:.0f} s")
