@@ -3,7 +3,9 @@
 random grid sizes / cell sizes / scenes / scan geometries, random sensor poses (not a trajectory), scans with zero / NaN / over-range
 readings sprinkled in, then per case: pushes (stats + every cell), ray casts (hit masks exact, coordinates 1e-9), registrations
 (pairs / iterations / state exact, T 1e-9), occupancy maps (byte-exact).  Stops at the first mismatch and prints the seed.
-usage (GPU box): python3 tools/fuzz_parity.py [cases] [first_seed]"""
+"hard": poses anywhere in the grid, at its edges and outside of it, any heading; registrations from up to 0.5 m / 0.2 rad away (few
+pairs, dropped points, not-matchable results) and with the point-to-line estimator.
+usage (GPU box): python3 tools/fuzz_parity.py [cases] [first_seed] [hard]"""
 import math, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,6 +16,7 @@ from tests import helpers as H
 O.build()
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+hard = len(sys.argv) > 3 and sys.argv[3] == "hard"
 t_start = time.time()
 tot = dict(pushes=0, raycasts=0, icps=0, occs=0)
 
@@ -48,6 +51,8 @@ for case in range(n_cases):
         # a cluster of poses around a random point of the free space near the start (pushes must overlap for the registration to work)
         x0 = world.start[0] + rng.uniform(-0.15, 0.15) * min(W, 20.0)
         y0 = world.start[1] + rng.uniform(-0.15, 0.15) * min(W, 20.0)
+        if hard and rng.random() < 0.7:
+            x0 = rng.uniform(-0.1, 1.1) * W; y0 = rng.uniform(-0.1, 1.1) * W
         yaw0 = rng.uniform(-math.pi, math.pi)
         n_push = int(rng.integers(3, 9))
         for k in range(n_push):
@@ -82,6 +87,8 @@ for case in range(n_cases):
             tot["raycasts"] += 1
             # registration of a scan taken from a displaced pose against this ray cast's model
             dxy = rng.uniform(-0.08, 0.08, 2); dyaw = rng.uniform(-0.03, 0.03)
+            if hard and rng.random() < 0.5:
+                dxy = rng.uniform(-0.5, 0.5, 2); dyaw = rng.uniform(-0.2, 0.2)
             r32 = world.scan(x + dxy[0], y + dxy[1], yaw + dyaw, geo)
             if rng.random() < 0.5:
                 r32 = spoil(rng, r32)
@@ -95,10 +102,19 @@ for case in range(n_cases):
             bounds = (0.0, og.max_x, 0.0, og.max_x)
             ro = O.icp(M, S, pose, iters, 0.4, 0.02, bounds, nn_mode=0)
             rd = dg.icp(M, S, pose, dg.icp_params(iters, 0.4, 0.02))
+            ptl = False
+            if hard and rng.random() < 0.3:
+                ptl = True
+                # PointToLine2DEstimator on the same pairs machinery (the ray cast's normals)
+                N = no_.reshape(-1, 2)[mo.astype(bool)]
+                ro = O.icp(M, S, pose, iters, 0.4, 0.02, bounds, nn_mode=0, model_normals_xy=N)
+                rd = dg.icp(M, S, pose, dg.icp_params(iters, 0.4, 0.02, estimator=1), model_normals_xy=N)
             assert (ro["pairs"], ro["iterations"], ro["state"]) == (rd.pairs, rd.iterations, rd.state), \
                 f"registration {k}: oracle {(ro['pairs'], ro['iterations'], ro['state'])} hip {(rd.pairs, rd.iterations, rd.state)}"
             d, a = H.pose_delta(ro["T"], rd.T)
-            assert d <= 1e-9 and a <= 1e-9, f"registration {k}: |dT| {d} m {a} rad"
+            tol_T = 1e-6 if ptl else 1e-9      # (point-to-line: the device library's cos / sin of the LU solution against libm's, every step)
+            assert d <= tol_T and a <= tol_T, (f"registration {k}: |dT| {d} m {a} rad; estimator {'point-to-line' if ptl else 'closed form'}, pairs {rd.pairs} of "
+                                             f"{len(S)} scene / {len(M)} model points, iterations {rd.iterations}, state {rd.state}, rms {rd.rms} / {ro['rms']}, offset {dxy} {dyaw}")
             tot["icps"] += 1
     except AssertionError as e:
         print("MISMATCH", tag, "--", e)
