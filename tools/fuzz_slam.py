@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Randomised closed-loop sweep of the C++ facade (ThreadLocalize::laserCallBack -> fused tsd_scan, the path bench.py drives) against
+the oracle's SLAM loop (test infrastructure: uses oracle/): random grids / scenes / scan geometries, random motion per scan (steps below
+and above the 0.05 m push gate, turns, an occasional jump that trips the registration-error gate), spoiled readings, and the next scan
+ANNOUNCED ahead at random -- sometimes the scan that then really comes, sometimes a decoy (staged, then dropped), sometimes nothing.
+Per scan: pose 1e-9, pairs / pushed / registration error exact; at the end every cell of the grid.  Short trajectories (the free-running
+loop amplifies last-bit differences over hundreds of scans).  Modes: registration_mode 0; "async": asynchronous mapping
+against the oracle's primitives one push behind is covered by tests/test_gpu_async_mapping.py, not here.
+usage (GPU box): python3 tools/fuzz_slam.py [cases] [first_seed]"""
+import math, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ohm_tsd_slam_amd import facade, synth
+from oracle import pyoracle as O
+from tests import helpers as H
+from tests.slam_driver import slam_kwargs
+
+O.build()
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+t_start = time.time()
+tot = dict(scans=0, pushes=0, reg_errors=0, decoys=0, announced=0)
+
+
+def spoil(rng, r32):
+    r = r32.copy()
+    n = len(r)
+    for val in (0.0, np.nan, 45.0, 0.1):
+        r[rng.integers(0, n, rng.integers(0, max(2, n // 40)))] = val
+    return r
+
+
+for case in range(n_cases):
+    seed = seed0 + case
+    rng = np.random.default_rng(seed)
+    map_log2 = int(rng.choice([9, 10, 10, 11]))
+    cs = float(rng.choice([0.03, 0.05, 0.05]))
+    scene = str(rng.choice(["room", "pillars"]))
+    geo = synth.ScanGeometry.full_circle_360() if rng.random() < 0.4 else synth.ScanGeometry.utm30lx()
+    if os.environ.get("FUZZ_GEO") == "utm": geo = synth.ScanGeometry.utm30lx()
+    if os.environ.get("FUZZ_GEO") == "360": geo = synth.ScanGeometry.full_circle_360()
+    gc = synth.GridConfig(map_log2, cs)
+    world = synth.World(scene, gc)
+    n = int(rng.integers(8, 22))
+    # ground truth: the node's start pose, then random increments in the robot's frame
+    x, y, yaw = world.start[0], world.start[1], 0.1
+    truth = [(x, y, yaw)]
+    for k in range(1, n):
+        u = rng.random()
+        step = rng.uniform(0.0, 0.04) if u < 0.2 else rng.uniform(0.05, 0.12)          # below / above the push gate
+        dyaw = rng.uniform(-0.04, 0.04)
+        if u > 0.95 and k > 2:
+            step = rng.uniform(1.1, 1.6)                                                  # the registration-error gate (reg_trs_max 1.0)
+        x += step * math.cos(yaw); y += step * math.sin(yaw); yaw += dyaw
+        truth.append((x, y, yaw))
+    scans = []
+    for (px, py, pyaw) in truth:
+        r32 = world.scan(px, py, pyaw, geo)
+        sp = spoil(rng, r32) if rng.random() < 0.4 else r32
+        scans.append(r32 if os.environ.get("FUZZ_NO_SPOIL") else sp)
+    tag = f"seed {seed}: 2^{map_log2} cells @ {cs} m, {scene}, {geo.beams} beams, {n} scans"
+    node = facade.SlamNode(facade.node_params(gc, geo), device=0, synchronous=True)
+    # (sensor_msgs/LaserScan carries angle_min / angle_increment as float32, the facade's scan type likewise -- ros_shim.h:38,
+    # ThreadLocalize.cpp:632-642: the oracle's loop gets the same rounded values)
+    osl = O.Slam(**slam_kwargs(gc, geo, threads=8, angle_min=float(np.float32(geo.angle_min)), angle_increment=float(np.float32(geo.angle_increment))))
+    try:
+        for k in range(n):
+            u = rng.random()
+            ahead = None
+            if k + 1 < n and u < 0.6:
+                ahead = scans[k + 1]; tot["announced"] += 1
+            elif u < 0.8:
+                ahead = scans[int(rng.integers(0, n))] if rng.random() < 0.5 else spoil(rng, scans[k]); tot["decoys"] += 1
+            if os.environ.get("FUZZ_NO_AHEAD"):
+                ahead = None
+            node.laser(scans[k], geo.angle_min, geo.angle_increment, ahead=ahead)
+            ro = osl.process_scan(scans[k])
+            rh = node.report()
+            Po = np.array(ro.pose).reshape(3, 3)
+            d, a = H.pose_delta(Po, rh["pose"])
+            assert d <= 1e-9 and a <= 1e-9, (f"scan {k}: |dpose| {d} m {a} rad (oracle pairs {ro.pairs}, hip {rh.get('pairs')}; rms {ro.rms} / {rh['rms']}; "
+                                             f"iterations {ro.iterations} / {rh['iterations']}; valid model {ro.valid_model} / {rh['valid_model']}; T hip {rh['T'].reshape(-1)[:6]})")
+            assert int(ro.pushed) == int(rh["pushed"]) and int(ro.reg_error) == int(rh["reg_error"]), \
+                f"scan {k}: pushed {ro.pushed} / {rh['pushed']}, reg_error {ro.reg_error} / {rh['reg_error']}"
+            if k > 0 and not ro.reg_error:
+                assert int(ro.pairs) == int(rh["pairs"]), f"scan {k}: pairs {ro.pairs} / {rh['pairs']}"
+            tot["scans"] += 1; tot["pushes"] += int(ro.pushed); tot["reg_errors"] += int(ro.reg_error)
+        H.assert_grids_equal(osl.grid.dump(), node.grid().download_tiles(), 1e-9)      # (free-running: the poses differ by ~1e-14)
+    except AssertionError as e:
+        print("MISMATCH", tag, "--", e)
+        sys.exit(1)
+    finally:
+        node.close()
+    if case % 10 == 9:
+        print(f"{case + 1} cases ok ({tag}); {tot}; {time.time() - t_start:.0f} s", flush=True)
+print(f"all {n_cases} cases ok from seed {seed0}: {tot}; {time.time() - t_start:.0f} s")
