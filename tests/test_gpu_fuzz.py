@@ -21,6 +21,6 @@ def test_randomised_facade_closed_loop_short():
     """tools/fuzz_slam.py: the C++ facade's fused scan path against the oracle's SLAM loop on random trajectories with spoiled readings
     and look-ahead announcements that are kept, replaced by a decoy or absent; poses 1e-9 per scan (the oracle gets the float32-rounded
     scan angles a LaserScan carries), gates and pair counts exact, the final grid 1e-9."""
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_slam.py"), "25", "4242"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_slam.py"), "30", "4242", "mode3"], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
-    assert "all 25 cases ok" in p.stdout
+    assert "all 30 cases ok" in p.stdout

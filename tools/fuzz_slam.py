@@ -6,8 +6,10 @@ ANNOUNCED ahead at random -- sometimes the scan that then really comes, sometime
 Per scan: pose 1e-9, pairs / pushed / registration error exact; at the end every cell of the grid.  Short trajectories (the free-running
 loop amplifies last-bit differences over hundreds of scans).  Modes: registration_mode 0; "async": asynchronous mapping
 against the oracle's primitives one push behind is covered by tests/test_gpu_async_mapping.py, not here.
-usage (GPU box): python3 tools/fuzz_slam.py [cases] [first_seed]"""
-import math, os, sys, time
+"mode3": half of the cases run registration_mode 3 (TSD_PDF pre-registration inside the fused scan, config/single-laser.yaml's mode) with
+random trials / control-set sizes, both sides fed the same seeded rand() draws (a decoy announcement must not consume a scan's draws).
+usage (GPU box): python3 tools/fuzz_slam.py [cases] [first_seed] [mode3]"""
+import ctypes as C, math, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ohm_tsd_slam_amd import facade, synth
@@ -18,8 +20,16 @@ from tests.slam_driver import slam_kwargs
 O.build()
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+with_mode3 = len(sys.argv) > 3 and sys.argv[3] == "mode3"
+_libc = C.CDLL(None)
+
+
+def libc_draws(seed, n_sub, n_ctrl, n_trials):
+    """what the facade's TSD_PDFMatching draws for `tsdpdf_seed` >= 0: srand(seed + call), then rand() in this order"""
+    _libc.srand(C.c_uint(seed))
+    return ([_libc.rand() for _ in range(n_sub)], [_libc.rand() for _ in range(n_ctrl)], [_libc.rand() for _ in range(n_trials)])
 t_start = time.time()
-tot = dict(scans=0, pushes=0, reg_errors=0, decoys=0, announced=0)
+tot = dict(scans=0, pushes=0, reg_errors=0, decoys=0, announced=0, mode3_cases=0)
 
 
 def spoil(rng, r32):
@@ -59,10 +69,18 @@ for case in range(n_cases):
         sp = spoil(rng, r32) if rng.random() < 0.4 else r32
         scans.append(r32 if os.environ.get("FUZZ_NO_SPOIL") else sp)
     tag = f"seed {seed}: 2^{map_log2} cells @ {cs} m, {scene}, {geo.beams} beams, {n} scans"
-    node = facade.SlamNode(facade.node_params(gc, geo), device=0, synchronous=True)
+    mode3 = with_mode3 and rng.random() < 0.5
+    params = facade.node_params(gc, geo)
+    extra = {}
+    if mode3:
+        trials = int(rng.choice([30, 60, 100, 200])); ctrl = int(rng.choice([60, 100, 140, 200])); pseed = int(rng.integers(1, 100000))
+        params.update({"registration_mode": 3, "trials": trials, "sizeControlSet": ctrl, "zrand": 0.25, "ransac_phi_max": 30.0, "tsdpdf_seed": pseed})
+        extra = dict(registration_mode=3, trials=trials, size_control_set=ctrl, zrand=0.25, ransac_phi_max=30.0)
+        tag += f", mode 3 ({trials} trials, {ctrl} control points)"
+    node = facade.SlamNode(params, device=0, synchronous=True)
     # (sensor_msgs/LaserScan carries angle_min / angle_increment as float32, the facade's scan type likewise -- ros_shim.h:38,
     # ThreadLocalize.cpp:632-642: the oracle's loop gets the same rounded values)
-    osl = O.Slam(**slam_kwargs(gc, geo, threads=8, angle_min=float(np.float32(geo.angle_min)), angle_increment=float(np.float32(geo.angle_increment))))
+    osl = O.Slam(**slam_kwargs(gc, geo, threads=8, angle_min=float(np.float32(geo.angle_min)), angle_increment=float(np.float32(geo.angle_increment)), **extra))
     try:
         for k in range(n):
             u = rng.random()
@@ -74,6 +92,8 @@ for case in range(n_cases):
             if os.environ.get("FUZZ_NO_AHEAD"):
                 ahead = None
             node.laser(scans[k], geo.angle_min, geo.angle_increment, ahead=ahead)
+            if mode3 and k > 0:
+                osl.set_draws(*libc_draws(pseed + (k - 1), geo.beams, ctrl, trials))
             ro = osl.process_scan(scans[k])
             rh = node.report()
             Po = np.array(ro.pose).reshape(3, 3)
@@ -85,6 +105,7 @@ for case in range(n_cases):
             if k > 0 and not ro.reg_error:
                 assert int(ro.pairs) == int(rh["pairs"]), f"scan {k}: pairs {ro.pairs} / {rh['pairs']}"
             tot["scans"] += 1; tot["pushes"] += int(ro.pushed); tot["reg_errors"] += int(ro.reg_error)
+        tot["mode3_cases"] += int(mode3)
         H.assert_grids_equal(osl.grid.dump(), node.grid().download_tiles(), 1e-9)      # (free-running: the poses differ by ~1e-14)
     except AssertionError as e:
         print("MISMATCH", tag, "--", e)
