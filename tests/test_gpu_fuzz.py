@@ -24,3 +24,12 @@ def test_randomised_facade_closed_loop_short():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_slam.py"), "30", "4242", "mode3"], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert "all 30 cases ok" in p.stdout
+
+
+@pytest.mark.gpu
+def test_randomised_async_mapping_short():
+    """tools/fuzz_async.py: asynchronous mapping through the staged scan with random staging (kept / replaced / absent) and a push stream
+    held back by up to 3 ms per push, against the one-push-behind order on the oracle's primitives."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_async.py"), "30", "31337"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "all 30 cases ok" in p.stdout
