@@ -6,7 +6,7 @@ readings sprinkled in, then per case: pushes (stats + every cell), ray casts (hi
 "hard": poses anywhere in the grid, at its edges and outside of it, any heading; registrations from up to 0.5 m / 0.2 rad away (few
 pairs, dropped points, not-matchable results) and with the point-to-line estimator.
 usage (GPU box): python3 tools/fuzz_parity.py [cases] [first_seed] [hard]"""
-import math, os, sys, time
+import math, os, sys, tempfile, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ohm_tsd_slam_amd import capi, synth
@@ -18,7 +18,7 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 hard = len(sys.argv) > 3 and sys.argv[3] == "hard"
 t_start = time.time()
-tot = dict(pushes=0, raycasts=0, icps=0, occs=0)
+tot = dict(pushes=0, raycasts=0, icps=0, occs=0, files=0)
 
 
 def spoil(rng, r32):
@@ -74,6 +74,19 @@ for case in range(n_cases):
                 assert no == nd, f"occupancy: sign changes {no} / {nd}"
                 assert np.array_equal(oo.reshape(gc.cells, gc.cells), od), "occupancy maps differ"
                 tot["occs"] += 1
+        if map_log2 <= 9 and rng.random() < 0.3:
+            # TsdGrid::storeGrid / TsdGrid(file) (TsdGrid.cpp:548-607, :25-110): the text files byte for byte, the reloaded grids cell for cell
+            with tempfile.TemporaryDirectory() as td:
+                fo, fh = os.path.join(td, "oracle.grid"), os.path.join(td, "hip.grid")
+                assert og.store_text(fo)
+                dg.store_text(fh)
+                assert open(fo, "rb").read() == open(fh, "rb").read(), "text grid files differ"
+                og2 = O.Grid.load_text(fo, gc.cell_size)
+                dg2 = capi.TsdGridDevice(gc.map_size_log2, gc.cell_size, gc.max_trunc)
+                dg2.load_text(fh)
+                H.assert_grids_equal(og2.dump(), dg2.download_tiles(), 0.0)
+                dg2.close()
+            tot["files"] += 1
         for k in range(3):
             x = x0 + rng.uniform(-0.5, 0.5); y = y0 + rng.uniform(-0.5, 0.5); yaw = yaw0 + rng.uniform(-0.4, 0.4)
             pose = synth.pose_matrix(x, y, yaw)
