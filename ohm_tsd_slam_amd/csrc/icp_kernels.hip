@@ -209,12 +209,20 @@ __device__ __forceinline__ double lb_from_sq(double lbsq)
   return (double)__builtin_amdgcn_sqrtf((float)lbsq) * (1.0 - 1e-6);
 }
 
-// running three smallest squared distances (the two smallest with their slots)
+// running three smallest squared distances (the two smallest with their slots), the whole-wave walk's.  EXACT ties are ordered by the
+// original model index (the first-minimum rule of a linear scan): a candidate at the SAME distance as a kept one goes in front of it
+// when its original index is lower -- three and more model points at exactly the same distance from a scene point (a scene point at the
+// centre of a lattice cell: tools/fuzz_icp.py) arrive in different 64-slot windows of the walk, and comparing distances alone kept
+// whichever came first.
 struct Top3 { double b1, b2, b3; int k1, k2; };
-__device__ __forceinline__ void top3_insert(Top3& t, double d, int k)
+__device__ __forceinline__ bool top3_before(const IcpLds& L, double d, int k, double dk, int kk)      // (d, k) ahead of the kept (dk, kk)?
 {
-  if (d < t.b1) { t.b3 = t.b2; t.b2 = t.b1; t.k2 = t.k1; t.b1 = d; t.k1 = k; }
-  else if (d < t.b2) { t.b3 = t.b2; t.b2 = d; t.k2 = k; }
+  return d < dk || (d == dk && kk >= 0 && k >= 0 && L.morig[k] < L.morig[kk]);
+}
+__device__ __forceinline__ void top3_insert(const IcpLds& L, Top3& t, double d, int k)
+{
+  if (top3_before(L, d, k, t.b1, t.k1)) { t.b3 = t.b2; t.b2 = t.b1; t.k2 = t.k1; t.b1 = d; t.k1 = k; }
+  else if (top3_before(L, d, k, t.b2, t.k2)) { t.b3 = t.b2; t.b2 = d; t.k2 = k; }
   else if (d < t.b3) t.b3 = d;
 }
 // exact tie between the two nearest: the lower original model index is the neighbour
@@ -432,8 +440,8 @@ __device__ __forceinline__ NnResult wave_search(const IcpLds& L, int nM, double 
         }
       }
       const int wk = __builtin_amdgcn_readlane(k, wl);
-      top3_insert(t, wmin, wk);
-      if (rnk == 0 && far_so_far && wmin > thr) { top3_insert(t, wmin, wk); top3_insert(t, wmin, wk); break; }
+      top3_insert(L, t, wmin, wk);
+      if (rnk == 0 && far_so_far && wmin > thr) { top3_insert(L, t, wmin, wk); top3_insert(L, t, wmin, wk); break; }
       if (lane == wl) dd = __builtin_inf();
     }
     top3_tiebreak(L, t);

@@ -42,3 +42,12 @@ def test_randomised_batched_robots_short():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_batch.py"), "15", "2024"], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert "all 15 cases ok" in p.stdout
+
+
+@pytest.mark.gpu
+def test_randomised_icp_point_sets_short():
+    """tools/fuzz_icp.py: tsd_icp on synthetic point sets -- lattices (exact multi-way ties), circles, polylines, clouds, duplicates,
+    outliers, non-finite points, 3..2048 model points in random order."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_icp.py"), "600", "1"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "all 600 cases ok" in p.stdout

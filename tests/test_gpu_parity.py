@@ -645,6 +645,35 @@ def test_icp_exact_ties_and_unsorted_models(oracle):
         assert d <= TOL_POSE_M and a <= TOL_POSE_RAD
 
 
+def test_icp_four_way_exact_ties(oracle):
+    """Scene points at the CENTRE of a lattice cell: four model points at exactly the same distance, given in random order, so that
+    the lowest original index is as often the third or fourth that the search meets as the first (round 4, tools/fuzz_icp.py seed 11:
+    the whole-wave walk compared distances alone and kept whichever of the tied points it met first; pair counts agreed, pairs and T
+    did not).  The first pair list must equal the oracle's, pair for pair."""
+    gc = synth.GridConfig(8, 0.05)
+    dg = capi.TsdGridDevice(gc.map_size_log2, gc.cell_size, gc.max_trunc)
+    og = oracle.Grid(gc.map_size_log2, gc.cell_size, gc.max_trunc)
+    bounds = (0.0, og.max_x, 0.0, og.max_x)
+    for seed, h in ((1, 0.125), (2, 0.25), (3, 0.125)):
+        rng = np.random.default_rng(seed)
+        xs, ys = np.meshgrid(np.arange(-2.0, 2.01, h), np.arange(-1.5, 1.51, h))
+        M = np.stack([xs.ravel(), ys.ravel()], axis=1)
+        M = M[np.hypot(M[:, 0], M[:, 1]) > 0.3]
+        M = M[rng.permutation(len(M))]
+        S = M[rng.choice(len(M), len(M) // 3, replace=False)] + np.array([h / 2, h / 2])
+        pose = synth.pose_matrix(6.4, 6.4, float(rng.uniform(-3, 3)))
+        pm, ps, _ = oracle.icp_pairs(M, S, pose, 3, 0.2, 0.02, bounds, 0.2 * 0.2, nn_mode=0)
+        hm, hs = dg.icp_pairs(M, S, pose, dg.icp_params(3, 0.2, 0.02), 1)[0]
+        assert sorted(zip(ps.tolist(), pm.tolist())) == sorted(zip(hs.tolist(), hm.tolist())), f"lattice {h}: pair lists differ"
+        assert len(pm) > 20
+        for iters in (1, 3, 30):
+            ro = oracle.icp(M, S, pose, iters, 0.2, 0.02, bounds, nn_mode=0)
+            rd = dg.icp(M, S, pose, dg.icp_params(iters, 0.2, 0.02))
+            assert (ro["pairs"], ro["iterations"], ro["state"]) == (rd.pairs, rd.iterations, rd.state), (h, iters)
+            d, a = H.pose_delta(ro["T"], rd.T)
+            assert d <= 1e-9 and a <= 1e-9, (h, iters, d, a)
+
+
 # ------------------------------------------------------------------------------------------------
 # BASELINE.json full sizes: cfg 2 (4096^2) cell-for-cell against the oracle, cfg 3 (16384^2) through
 # size-independent properties plus the oracle on the touched tiles
