@@ -68,6 +68,11 @@ for case in range(n_cases):
         S[rng.integers(0, len(S), 2)] = [np.nan, np.inf][int(rng.integers(0, 2))]
     S = S[rng.permutation(len(S))][:2048]
     iters = int(rng.choice([1, 2, 3, 5, 11, 25, 30, 30]))
+    if kind == "lattice":
+        # One step only, and the pair LIST itself is compared below: from the second step on a lattice scene lands on exact ties again
+        # and again, and the last bits of T (the estimators' own, inside the tolerance) then decide which of two equidistant model
+        # points is the neighbour -- the oracle's scene off the lattice by 1e-17, the device's exactly on it: both right, different pairs
+        iters = 1
     # the sensor's pose in the map: the out-of-bounds filter works on pose * scene
     px, py, pyaw = rng.uniform(1.0, 11.8), rng.uniform(1.0, 11.8), rng.uniform(-math.pi, math.pi)
     pose = synth.pose_matrix(px, py, pyaw)
@@ -78,9 +83,14 @@ for case in range(n_cases):
         rd = dg.icp(M, S, pose, dg.icp_params(iters, dmax, dmin))
         # (a noise-free scene converges to a residual of EXACTLY 0.0 on one side and 1e-30 on the other -- the estimator's last bits --
         # and `rms <= maxRMS (0.0)` then labels the same final step SUCCESS here and MAXITERATIONS there: same T, same counts)
+        # ... or ends the oracle's loop at that step (`rms <= 0.0`: SUCCESS after 3 iterations) while the device's runs on to the last one
         zero_rms = abs(ro["rms"]) < 1e-20 and abs(rd.rms) < 1e-20 and {ro["state"], rd.state} <= {3, 5}
-        assert (ro["pairs"], ro["iterations"]) == (rd.pairs, rd.iterations) and (ro["state"] == rd.state or zero_rms), \
+        assert ro["pairs"] == rd.pairs and ((ro["iterations"], ro["state"]) == (rd.iterations, rd.state) or zero_rms), \
             f"oracle {(ro['pairs'], ro['iterations'], ro['state'])} hip {(rd.pairs, rd.iterations, rd.state)}"
+        if kind == "lattice":
+            pm, ps, _ = O.icp_pairs(M, S, pose, 1, dmax, dmin, bounds, dmax * dmax, nn_mode=0)
+            hm, hs = dg.icp_pairs(M, S, pose, dg.icp_params(1, dmax, dmin), 1)[0]
+            assert sorted(zip(ps.tolist(), pm.tolist())) == sorted(zip(hs.tolist(), hm.tolist())), "pair lists differ"
         d, a = H.pose_delta(ro["T"], rd.T)
         ok_T = (d <= 1e-9 and a <= 1e-9) or (not np.isfinite(ro["T"]).all() and not np.isfinite(rd.T).all())
         assert ok_T, f"|dT| {d} m {a} rad"
