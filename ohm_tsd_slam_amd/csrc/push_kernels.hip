@@ -183,7 +183,10 @@ __device__ __forceinline__ void tile_geometry(const GridDev& g, int p, double e[
 // oracle's libm sqrt and IEEE division -- the grid digests of tests/golden pin exactly that.)
 __device__ __forceinline__ double sqrt_normal(double x)
 {
-  // AMDGPU's f64 sqrt lowering without the 2^+-256 scaling and the zero / inf pass-through
+  // AMDGPU's f64 sqrt lowering without the 2^+-256 scaling and the inf pass-through.  Zero -- the cell whose centre IS the sensor
+  // position, to the last bit: a start pose configured onto a cell centre (tools/fuzz_parity.py, exact poses) -- makes the core 0 * inf
+  // = NaN, which silently skipped that cell's update: the closing v_max_f64 with 0 turns exactly that NaN into the root of zero (IEEE
+  // maximum: the operand that is a number) and leaves every other result bit for bit what it was.
   const double y = __builtin_amdgcn_rsq(x);
   const double g0 = x * y, h0 = 0.5 * y;
   const double r0 = __builtin_fma(-h0, g0, 0.5);
@@ -191,7 +194,10 @@ __device__ __forceinline__ double sqrt_normal(double x)
   const double d0 = __builtin_fma(-g1, g1, x);
   const double g2 = __builtin_fma(d0, h1, g1);
   const double d1 = __builtin_fma(-g2, g2, x);
-  return __builtin_fma(d1, h1, g2);
+  const double r = __builtin_fma(d1, h1, g2);
+  double out;
+  asm("v_max_f64 %0, %1, 0" : "=v"(out) : "v"(r));
+  return out;
 }
 __device__ __forceinline__ double div_normal(double n, double d)
 {

@@ -645,6 +645,32 @@ def test_icp_exact_ties_and_unsorted_models(oracle):
         assert d <= TOL_POSE_M and a <= TOL_POSE_RAD
 
 
+def test_push_sensor_exactly_on_a_cell_centre(oracle):
+    """The cell whose centre IS the sensor position (heading 0: PoseInv * centre is exactly (0, 0), atan2(0, 0) = 0 names the beam at
+    angle 0, the distance is 0 and sd = the reading): round 4, tools/fuzz_parity.py with exact poses -- the update kernel's square root
+    without the zero pass-through made 0 * inf = NaN of that distance and silently skipped the cell."""
+    gc = synth.GridConfig(9, 0.1)
+    geo = synth.ScanGeometry.full_circle_360()
+    world = synth.World("pillars", gc)
+    og, dg = make_pair(oracle, gc)
+    ix, iy = 260, 250
+    x, y = (ix + 0.5) * gc.cell_size, (iy + 0.5) * gc.cell_size
+    for k, yaw in enumerate((0.0, 0.0, math.pi / 2)):
+        pose = synth.pose_matrix(x, y, yaw)
+        data, mask = oracle.ingest_f32(world.scan(x, y, yaw, geo), H.MAX_RANGE, geo.angle_increment)
+        so = og.push(pose, data, mask, geo.angle_increment, geo.angle_min, H.MAX_RANGE, H.MIN_RANGE, H.LOW_REFL)
+        sd = dg.push(pose, data, mask, geo.angle_increment, geo.angle_min, H.MAX_RANGE, H.MIN_RANGE, H.LOW_REFL)
+        if yaw == 0.0:
+            assert so == sd, f"push {k}: {so} {sd}"
+            H.assert_grids_equal(og.dump(), dg.download_tiles(), 0.0)
+    # the cell under the sensor was updated by both heading-0 pushes (weight = two measurements' worth)
+    oi, oiw, ot, ow = og.dump()
+    p = (iy // 32) * (gc.cells // 32) + ix // 32
+    w_cell = ow.reshape(-1, 33, 33)[p, iy % 32, ix % 32]
+    t_cell = ot.reshape(-1, 33, 33)[p, iy % 32, ix % 32]
+    assert w_cell > 0.0 and t_cell == 1.0, (w_cell, t_cell)
+
+
 def test_icp_four_way_exact_ties(oracle):
     """Scene points at the CENTRE of a lattice cell: four model points at exactly the same distance, given in random order, so that
     the lowest original index is as often the third or fourth that the search meets as the first (round 4, tools/fuzz_icp.py seed 11:
