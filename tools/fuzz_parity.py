@@ -118,6 +118,13 @@ for case in range(n_cases):
             tot["files"] += 1
         for k in range(3):
             x = x0 + rng.uniform(-0.5, 0.5); y = y0 + rng.uniform(-0.5, 0.5); yaw = yaw0 + rng.uniform(-0.4, 0.4)
+            if hard and rng.random() < 0.3:
+                # exact poses for the ray cast too: rays along the axes and diagonals, samples ON cell and tile boundaries, the repeated
+                # `position += ray` of the reference landing on exact ties
+                q = float(rng.choice([cs, 0.5 * cs, 32 * cs]))
+                x = round(x / q) * q + (0.5 * cs if rng.random() < 0.5 else 0.0); y = round(y / q) * q + (0.5 * cs if rng.random() < 0.5 else 0.0)
+                qa = float(rng.choice([geo.angle_increment, 0.5 * geo.angle_increment, math.pi / 2, math.pi / 4]))
+                yaw = round(yaw / qa) * qa
             pose = synth.pose_matrix(x, y, yaw)
             rl, rw = H.world_rays(O, geo, pose, gc.cell_size)
             co, no_, mo, cnt_o = og.raycast(pose, rw, H.MIN_RANGE, H.MAX_RANGE)
