@@ -43,10 +43,16 @@ for case in range(n_cases):
     gc = synth.GridConfig(map_log2, cs)
     world = synth.World(scene, gc)
     W = gc.cells * cs
+    # a device that shows only a few compute units (TSD_DEBUG_N_CUS, read when the context is created): the update kernel's workgroups
+    # then take SEVERAL tiles each off the ticket queue -- on the full device the small grids of this sweep give every workgroup one tile
+    if hard and rng.random() < 0.4:
+        os.environ["TSD_DEBUG_N_CUS"] = str(int(rng.choice([1, 2, 4, 16])))
+    else:
+        os.environ.pop("TSD_DEBUG_N_CUS", None)
     og = O.Grid(gc.map_size_log2, gc.cell_size, gc.max_trunc)
     dg = capi.TsdGridDevice(gc.map_size_log2, gc.cell_size, gc.max_trunc)
     content = np.full(gc.cells * gc.cells, -1, dtype=np.int8)
-    tag = f"seed {seed}: 2^{map_log2} cells @ {cs} m, {scene}, {geo.beams} beams"
+    tag = f"seed {seed}: 2^{map_log2} cells @ {cs} m, {scene}, {geo.beams} beams" + (f", {os.environ['TSD_DEBUG_N_CUS']} compute units" if "TSD_DEBUG_N_CUS" in os.environ else "")
     try:
         # a cluster of poses around a random point of the free space near the start (pushes must overlap for the registration to work)
         x0 = world.start[0] + rng.uniform(-0.15, 0.15) * min(W, 20.0)
