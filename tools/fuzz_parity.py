@@ -5,7 +5,7 @@ readings sprinkled in, then per case: pushes (stats + every cell), ray casts (hi
 (pairs / iterations / state exact, T 1e-9), occupancy maps (byte-exact).  Stops at the first mismatch and prints the seed.
 "hard": poses anywhere in the grid, at its edges and outside of it, any heading; registrations from up to 0.5 m / 0.2 rad away (few
 pairs, dropped points, not-matchable results) and with the point-to-line estimator.
-usage (GPU box): python3 tools/fuzz_parity.py [cases] [first_seed] [hard]"""
+usage (GPU box): python3 tools/fuzz_parity.py [cases] [first_seed] [hard|easy] [big]"""
 import math, os, sys, tempfile, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -40,6 +40,10 @@ for case in range(n_cases):
     cs = float(rng.choice([0.03, 0.05, 0.05, 0.07, 0.1]))
     scene = str(rng.choice(["room", "pillars"]))
     geo = synth.ScanGeometry.full_circle_360() if rng.random() < 0.4 else synth.ScanGeometry.utm30lx()
+    if len(sys.argv) > 4 and sys.argv[4] == "big":
+        # 2^12 cells at 0.01 m: 16 384 tiles, all of them inside the 30 m range -- the classification kernel's 1 024-thread form (windows
+        # of more than 12 288 tiles) and several tiles per workgroup on the full device
+        map_log2, cs = 12, 0.01
     gc = synth.GridConfig(map_log2, cs)
     world = synth.World(scene, gc)
     W = gc.cells * cs
