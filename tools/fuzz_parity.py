@@ -106,6 +106,25 @@ for case in range(n_cases):
                 assert so == sd, f"push {k}: stats differ\n oracle {so}\n hip    {sd}"
                 H.assert_grids_equal(og.dump(), dg.download_tiles(), 0.0)
             tot["pushes"] += 1
+            if hard and rng.random() < 0.25:
+                # TsdGrid::freeFootprint (TsdGrid.cpp:609-638) between two pushes: rectangles inside, across the edge of and outside the
+                # grid (the reference refuses those: both sides must agree on that too); the next push refreshes the halos it dirtied
+                fc = [x + rng.uniform(-1.0, 1.0), y + rng.uniform(-1.0, 1.0)]
+                fw, fh_ = float(rng.uniform(0.05, 2.5)), float(rng.uniform(0.05, 2.5))
+                r_o, r_h = og.free_footprint(fc, fw, fh_), dg.free_footprint(fc, fw, fh_)
+                assert bool(r_o) == bool(r_h), f"freeFootprint accepted by one side only ({r_o} / {r_h})"
+                od_, gd_ = og.dump(), dg.download_tiles()
+                assert np.array_equal(od_[0], gd_[0]) and np.array_equal(od_[1], gd_[1]), "freeFootprint: tile state differs"
+                sel_ = od_[0].astype(bool)
+                # (interior cells: the halos a footprint dirties are refreshed by the NEXT push on both sides, TsdGrid.cpp:372-427)
+                a_, b_ = od_[2].reshape(-1, 33, 33)[sel_][:, :32, :32], gd_[2].reshape(-1, 33, 33)[sel_][:, :32, :32]
+                assert np.array_equal(np.isnan(a_), np.isnan(b_)) and np.array_equal(a_[~np.isnan(a_)], b_[~np.isnan(b_)]), "freeFootprint: cells differ"
+                tot["footprints"] = tot.get("footprints", 0) + 1
+            if rng.random() < 0.15:
+                wimg, himg = (gc.cells, gc.cells) if rng.random() < 0.3 else (int(rng.integers(8, 700)), int(rng.integers(8, 500)))
+                io_, ih_ = og.color_image(wimg, himg), dg.color_image(wimg, himg)
+                assert np.array_equal(io_, ih_), f"colour image {wimg} x {himg} differs"
+                tot["images"] = tot.get("images", 0) + 1
             if rng.random() < 0.3:
                 inflate = bool(rng.random() < 0.5)
                 oo, no = og.occupancy(content, inflate, 2)
