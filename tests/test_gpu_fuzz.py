@@ -39,9 +39,9 @@ def test_randomised_async_mapping_short():
 def test_randomised_batched_robots_short():
     """tools/fuzz_batch.py: 2-6 robots on one grid through tsd_batch_* -- every round split at random into one or two slots begun
     together -- against the same order on the oracle's primitives."""
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_batch.py"), "15", "2024"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_batch.py"), "16", "2024", "mode3"], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
-    assert "all 15 cases ok" in p.stdout
+    assert "all 16 cases ok" in p.stdout
 
 
 @pytest.mark.gpu

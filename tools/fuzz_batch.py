@@ -5,7 +5,9 @@ random offsets, each moving at random (steps below and above the push gate, turn
 at random into one or two batch slots that are BEGUN together (both slots' ray casts read the grid before any push of the round), the
 pushes follow slot by slot in robot order, the results are collected afterwards -- the two-slot pattern of the facade's dispatcher, with
 the device-side waits and gates it uses.  Per robot and round: ray-cast hits, gates, pairs / iterations / state exact, pose 1e-9; final
-grid 1e-9.   usage (GPU box): python3 tools/fuzz_batch.py [cases] [first_seed]"""
+grid 1e-9.  "mode3": in half of the cases a random subset of the robots has its TSD_PDF pre-registration armed every round
+(tsd_scan_preregister with random draws; armed and unarmed scans share batches), winner and candidate count compared too.
+usage (GPU box): python3 tools/fuzz_batch.py [cases] [first_seed] [mode3]"""
 import math, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,8 +20,9 @@ import tests.test_gpu_batch as T
 O.build()
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+with_mode3 = len(sys.argv) > 3 and sys.argv[3] == "mode3"
 t_start = time.time()
-tot = dict(rounds=0, scans=0, pushes=0, two_slot_rounds=0)
+tot = dict(rounds=0, scans=0, pushes=0, two_slot_rounds=0, armed_scans=0)
 
 
 def spoil(rng, r32):
@@ -42,9 +45,13 @@ for case in range(n_cases):
     n = int(rng.integers(5, 14))
     geo_msg = synth.ScanGeometry(geo.beams, float(np.float32(geo.angle_min)), float(np.float32(geo.angle_increment)))
     kw = slam_kwargs(gc, geo_msg)
+    mode3 = with_mode3 and rng.random() < 0.5
+    if mode3:
+        kw.update(trials=int(rng.choice([20, 40, 100])), size_control_set=int(rng.choice([60, 120, 140])))
+        phi_max3 = np.radians(kw["ransac_phi_max"])
     og = O.Grid(gc.map_size_log2, gc.cell_size, gc.truncation_radius * gc.cell_size)
     dg = capi.TsdGridDevice(gc.map_size_log2, gc.cell_size, gc.truncation_radius * gc.cell_size)
-    tag = f"seed {seed}: 2^{map_log2} cells, {scene}, {geo.beams} beams, {R} robots, {n} rounds"
+    tag = f"seed {seed}: 2^{map_log2} cells, {scene}, {geo.beams} beams, {R} robots, {n} rounds" + (", mode 3" if mode3 else "")
     robots, scans, sensors, slots = [], [], [], []
     try:
         world0 = synth.World(scene, gc)
@@ -78,7 +85,14 @@ for case in range(n_cases):
             groups = [g for g in (perm[:cut], perm[cut:]) if g]
             order = [i for g in groups for i in g]
             ing = {i: robots[i].ingest(scans[i][k]) for i in order}
-            ros = {i: robots[i].localise(og, ing[i][0], ing[i][1], bounds) for i in order}      # all against the grid before the round's pushes
+            draws = {i: (tuple(rng.integers(0, 2 ** 31 - 1, m) for m in (geo.beams, kw["size_control_set"], kw["trials"])) if (mode3 and rng.random() < 0.7) else None)
+                     for i in order}
+            ros = {i: robots[i].localise(og, ing[i][0], ing[i][1], bounds, draws[i]) for i in order}      # all against the grid before the round's pushes
+            for i in order:
+                if draws[i] is not None:
+                    sc_, ms_, _n = O.scene_from_scan(robots[i].rays_local, ing[i][0], ing[i][1])
+                    sensors[i].preregister(sc_, ms_, kw["trials"], kw["size_control_set"], kw["zrand"], phi_max3, kw["angle_increment"], *draws[i])
+                    tot["armed_scans"] += 1
             for i in order:
                 robots[i].apply_push(og)                                                            # ... the pushes in the round's order
             for si, grp in enumerate(groups):
@@ -91,6 +105,9 @@ for case in range(n_cases):
                     T._compare(k, i, ro, sr)
                     d, a = H.pose_delta(ro["pose"], np.array(sr.pose[:]).reshape(3, 3))
                     assert d <= 1e-9 and a <= 1e-9, f"round {k} robot {i}: |dpose| {d} m {a} rad"
+                    if draws[i] is not None and not ro["no_model"]:
+                        pr = sensors[i].preregistration_result()
+                        assert (pr["candidates"], pr["idx"], pr["i"]) == ro["pre"], f"round {k} robot {i}: pre-registration {pr} vs {ro['pre']}"
                     tot["scans"] += 1; tot["pushes"] += int(ro["pushed"])
             tot["rounds"] += 1; tot["two_slot_rounds"] += int(len(groups) == 2)
         dg.sync()
