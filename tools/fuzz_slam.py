@@ -47,6 +47,14 @@ for case in range(n_cases):
     cs = float(rng.choice([0.03, 0.05, 0.05]))
     scene = str(rng.choice(["room", "pillars"]))
     geo = synth.ScanGeometry.full_circle_360() if rng.random() < 0.4 else synth.ScanGeometry.utm30lx()
+    clockwise = False
+    if rng.random() < 0.3:
+        # any scanner: odd beam counts, narrow and wide fields of view -- and a CLOCKWISE one (negative increment from a positive
+        # angle_min: ThreadLocalize.cpp:491-497 reverses the scan and flips the angles)
+        nb = int(rng.choice([91, 181, 361, 541, 1000, 1440]))
+        fov = math.radians(float(rng.uniform(120.0, 340.0)))
+        geo = synth.ScanGeometry(nb, -0.5 * fov, fov / (nb - 1))
+        clockwise = bool(rng.random() < 0.4)
     if os.environ.get("FUZZ_GEO") == "utm": geo = synth.ScanGeometry.utm30lx()
     if os.environ.get("FUZZ_GEO") == "360": geo = synth.ScanGeometry.full_circle_360()
     gc = synth.GridConfig(map_log2, cs)
@@ -68,7 +76,12 @@ for case in range(n_cases):
         r32 = world.scan(px, py, pyaw, geo)
         sp = spoil(rng, r32) if rng.random() < 0.4 else r32
         scans.append(r32 if os.environ.get("FUZZ_NO_SPOIL") else sp)
-    tag = f"seed {seed}: 2^{map_log2} cells @ {cs} m, {scene}, {geo.beams} beams, {n} scans"
+    msg_min, msg_inc = geo.angle_min, geo.angle_increment
+    if clockwise:
+        # the same physical scanner mounted the other way round reports its beams from +|angle_min| downwards
+        scans = [np.ascontiguousarray(sc[::-1]) for sc in scans]
+        msg_min, msg_inc = -geo.angle_min, -geo.angle_increment
+    tag = f"seed {seed}: 2^{map_log2} cells @ {cs} m, {scene}, {geo.beams} beams{' (clockwise)' if clockwise else ''}, {n} scans"
     mode3 = with_mode3 and rng.random() < 0.5
     params = facade.node_params(gc, geo)
     extra = {}
@@ -80,7 +93,7 @@ for case in range(n_cases):
     node = facade.SlamNode(params, device=0, synchronous=True)
     # (sensor_msgs/LaserScan carries angle_min / angle_increment as float32, the facade's scan type likewise -- ros_shim.h:38,
     # ThreadLocalize.cpp:632-642: the oracle's loop gets the same rounded values)
-    osl = O.Slam(**slam_kwargs(gc, geo, threads=8, angle_min=float(np.float32(geo.angle_min)), angle_increment=float(np.float32(geo.angle_increment)), **extra))
+    osl = O.Slam(**slam_kwargs(gc, geo, threads=8, angle_min=float(np.float32(msg_min)), angle_increment=float(np.float32(msg_inc)), **extra))
     try:
         for k in range(n):
             u = rng.random()
@@ -91,7 +104,7 @@ for case in range(n_cases):
                 ahead = scans[int(rng.integers(0, n))] if rng.random() < 0.5 else spoil(rng, scans[k]); tot["decoys"] += 1
             if os.environ.get("FUZZ_NO_AHEAD"):
                 ahead = None
-            node.laser(scans[k], geo.angle_min, geo.angle_increment, ahead=ahead)
+            node.laser(scans[k], msg_min, msg_inc, ahead=ahead)
             if mode3 and k > 0:
                 osl.set_draws(*libc_draws(pseed + (k - 1), geo.beams, ctrl, trials))
             ro = osl.process_scan(scans[k])
