@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised check of the ORACLE itself (CPU only, no GPU, test infrastructure): the independent NumPy / pure-Python re-derivations of
 tests/test_cpu_oracle_properties.py -- one push into an empty grid for every cell, the ray march with bilinear look-ups and normals, the
-closed-form and point-to-line estimators -- against oracle/tsd_oracle.c on random grids, scenes, scanners, poses and spoiled scans
+closed-form and point-to-line estimators on the first step's pair list -- against oracle/tsd_oracle.c on random grids, scenes, scanners, poses and spoiled scans
 instead of the two or three fixed cases of the test suite.  usage: python3 tools/fuzz_oracle.py [cases] [first_seed]"""
 import math, os, sys, time
 import numpy as np
@@ -90,6 +90,38 @@ for case in range(n_cases):
                 assert abs(nn[0] - no[2 * b]) <= 1e-11 and abs(nn[1] - no[2 * b + 1]) <= 1e-11, f"beam {b}: normal"
                 tot["hits"] += 1
             tot["beams"] += 1
+        # ---- both estimators from the first step's pair list, by numpy: ClosedFormEstimator2D (centroids, atan2 of the centred sums) and
+        # PointToLine2DEstimator (normal equations by np.linalg.solve) against Tlast of the oracle's first iteration
+        M = co.reshape(-1, 2)[mo.astype(bool)]; Nn = no.reshape(-1, 2)[mo.astype(bool)]
+        dxy = rng.uniform(-0.06, 0.06, 2); dya = rng.uniform(-0.02, 0.02)
+        d3, m3 = O.ingest_f32(world.scan(xr + dxy[0], yr + dxy[1], yawr + dya, geo), 30.0, geo.angle_increment)
+        sc, ms, _ = O.scene_from_scan(rl, d3, m3)
+        S = sc.reshape(-1, 2)[ms.astype(bool)]
+        bnd = (0.0, g.max_x, 0.0, g.max_x)
+        if len(M) >= 10 and len(S) >= 10:
+            pm, ps, _ = O.icp_pairs(M, S, poser, 30, 0.4, 0.02, bnd, 0.4 ** 2)
+            if len(pm) >= 10:
+                m, s_ = M[pm], S[ps]
+                cm, csn = m.mean(0), s_.mean(0)
+                mse = np.mean(np.sum((s_ - m) ** 2, 1))
+                mc, scn = m - cm, s_ - csn
+                th = math.atan2(np.sum(mc[:, 1] * scn[:, 0] - mc[:, 0] * scn[:, 1]), np.sum(mc[:, 0] * scn[:, 0] + mc[:, 1] * scn[:, 1]))
+                c, si = math.cos(th), math.sin(th)
+                t = cm - np.array([c * csn[0] - si * csn[1], c * csn[1] + si * csn[0]])
+                tl = O.icp(M, S, poser, 30, 0.4, 0.02, bnd, trace=True)["trace"][0]
+                assert int(tl[0]) == len(pm) and abs(tl[1] - mse) <= 1e-14, "closed form: pairs / mean squared distance"
+                assert np.max(np.abs(tl[4:8] - np.array([c, si, t[0], t[1]]))) <= 1e-12, f"closed form: Tlast differs by {np.max(np.abs(tl[4:8] - np.array([c, si, t[0], t[1]])))}"
+                n = Nn[pm]
+                az = s_[:, 0] * n[:, 1] - s_[:, 1] * n[:, 0]
+                J = np.stack([az, n[:, 0], n[:, 1]], 1)
+                resid = np.sum((s_ - m) * n, 1)
+                A = J.T @ J
+                if np.linalg.cond(A) < 1e8:
+                    xsol = np.linalg.solve(A, -(J.T @ resid))
+                    tlp = O.icp(M, S, poser, 30, 0.4, 0.02, bnd, model_normals_xy=Nn, trace=True)["trace"][0]
+                    assert int(tlp[0]) == len(pm) and abs(tlp[1] - np.mean(np.abs(resid))) <= 1e-14, "point to line: pairs / residual"
+                    assert np.max(np.abs(tlp[4:8] - np.array([math.cos(xsol[0]), math.sin(xsol[0]), xsol[1], xsol[2]]))) <= 1e-9, "point to line: Tlast"
+                tot["estimators"] = tot.get("estimators", 0) + 1
     except AssertionError as e:
         print("MISMATCH", tag, "--", e)
         sys.exit(1)
