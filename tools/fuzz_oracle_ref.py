@@ -47,4 +47,30 @@ for case in range(n_cases):
     pairs_total += sum(len(r[0]) for r in ref)
     if case % 100 == 99:
         print(f"{case + 1} cases ok; {pairs_total} pairs compared; {time.time() - t0:.0f} s", flush=True)
-print(f"all {n_cases} cases ok from seed {seed0}: {pairs_total} pairs compared; {time.time() - t0:.0f} s")
+# ---- the text line readers of the grid file format (obcore/base/tools.cpp:190-215, getDoubleLine / getIntLine) on random lines: numbers
+# as %g writes them, integers beyond int range, special values, empty lines, garbage, CR LF
+import tempfile
+rng = np.random.default_rng(seed0)
+alphabet = list("0123456789") * 4 + list("+-.eE") * 2 + list(" \tabxnifNAINF,;")
+def rand_line():
+    u = rng.random()
+    if u < 0.35: return "%g" % rng.normal(0, 10.0 ** float(rng.integers(-12, 12)))
+    if u < 0.5: return str(int(rng.integers(-2 ** 33, 2 ** 33)))
+    if u < 0.55: return str(rng.choice(["nan", "inf", "-inf", "NaN", "INF", "", " ", "\r", "+", "-", ".", "e5", "1e", "1e+", "0x1p3", "1e400", "-1e400", "4.9e-324", "1.7976931348623157e308"]))
+    return "".join(rng.choice(alphabet, int(rng.integers(0, 14)))) + ("\r" if rng.random() < 0.1 else "")
+n_lines = 0
+for it in range(max(1, n_cases // 20)):
+    lines = [rand_line().replace("\n", "") for _ in range(200)]
+    text = "\n".join(lines) + "\n"
+    with tempfile.NamedTemporaryFile("wb", delete=False) as f:
+        f.write(text.encode()); path = f.name
+    for kind in (0, 1):
+        k = np.full(len(lines), kind, dtype=np.int32)
+        want, got = np.zeros(len(lines)), np.zeros(len(lines))
+        O.ref().ref_text_lines(text.encode(), k.ctypes.data_as(O._ip), len(lines), O.d(want))
+        assert O.lib().ora_text_lines(path.encode(), k.ctypes.data_as(O._ip), len(lines), O.d(got)) == 1
+        if not np.array_equal(want, got, equal_nan=True):
+            bad = [(l, w, g) for l, w, g in zip(lines, want, got) if not (w == g or (w != w and g != g))]
+            print("MISMATCH text line reader kind", kind, bad[:5]); sys.exit(1)
+    os.unlink(path); n_lines += 2 * len(lines)
+print(f"all {n_cases} cases ok from seed {seed0}: {pairs_total} pairs compared, {n_lines} text lines read; {time.time() - t0:.0f} s")
