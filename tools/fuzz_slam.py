@@ -8,7 +8,9 @@ loop amplifies last-bit differences over hundreds of scans).  Modes:
 against the oracle's primitives one push behind is covered by tests/test_gpu_async_mapping.py, not here.
 "mode3": half of the cases run registration_mode 3 (TSD_PDF pre-registration inside the fused scan, config/single-laser.yaml's mode) with
 random trials / control-set sizes, both sides fed the same seeded rand() draws (a decoy announcement must not consume a scan's draws).
-usage (GPU box): python3 tools/fuzz_slam.py [cases] [first_seed] [mode3]"""
+"async": half of the cases run the facade with `async_mapping: 1` (the push beside the next registration) against the one-push-behind
+order on the oracle's primitives (tests/test_gpu_async_mapping.py's OracleOnePushBehind).
+usage (GPU box): python3 tools/fuzz_slam.py [cases] [first_seed] [mode3|async]"""
 import ctypes as C, math, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -21,6 +23,7 @@ O.build()
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 with_mode3 = len(sys.argv) > 3 and sys.argv[3] == "mode3"
+with_async = len(sys.argv) > 3 and sys.argv[3] == "async"
 _libc = C.CDLL(None)
 
 
@@ -90,10 +93,27 @@ for case in range(n_cases):
         params.update({"registration_mode": 3, "trials": trials, "sizeControlSet": ctrl, "zrand": 0.25, "ransac_phi_max": 30.0, "tsdpdf_seed": pseed})
         extra = dict(registration_mode=3, trials=trials, size_control_set=ctrl, zrand=0.25, ransac_phi_max=30.0)
         tag += f", mode 3 ({trials} trials, {ctrl} control points)"
+    use_async = with_async and rng.random() < 0.5
+    if use_async:
+        params["async_mapping"] = 1
+        tag += ", asynchronous mapping"
     node = facade.SlamNode(params, device=0, synchronous=True)
     # (sensor_msgs/LaserScan carries angle_min / angle_increment as float32, the facade's scan type likewise -- ros_shim.h:38,
     # ThreadLocalize.cpp:632-642: the oracle's loop gets the same rounded values)
-    osl = O.Slam(**slam_kwargs(gc, geo, threads=8, angle_min=float(np.float32(msg_min)), angle_increment=float(np.float32(msg_inc)), **extra))
+    okw = slam_kwargs(gc, geo, threads=8, angle_min=float(np.float32(msg_min)), angle_increment=float(np.float32(msg_inc)), **extra)
+    if use_async:
+        from tests.test_gpu_async_mapping import OracleOnePushBehind
+        if clockwise:                                    # (the primitives-level driver has no clockwise branch: feed it the flipped scan itself)
+            okw.update(angle_min=float(np.float32(-msg_min)), angle_increment=float(np.float32(-msg_inc)))
+        oab = OracleOnePushBehind(O, **okw)
+        class _Wrap:                                       # the same result fields as O.Slam's
+            def process_scan(self, r):
+                d = oab.process_scan(r[::-1] if clockwise else r)
+                return type("R", (), dict(pose=np.asarray(d["pose"]).reshape(-1), pushed=d["pushed"], reg_error=d["reg_error"], pairs=d["pairs"],
+                                         rms=0.0, iterations=0, valid_model=0))()
+        osl = _Wrap(); osl.grid = None
+    else:
+        osl = O.Slam(**okw)
     try:
         for k in range(n):
             u = rng.random()
@@ -118,8 +138,12 @@ for case in range(n_cases):
             if k > 0 and not ro.reg_error:
                 assert int(ro.pairs) == int(rh["pairs"]), f"scan {k}: pairs {ro.pairs} / {rh['pairs']}"
             tot["scans"] += 1; tot["pushes"] += int(ro.pushed); tot["reg_errors"] += int(ro.reg_error)
-        tot["mode3_cases"] += int(mode3)
-        H.assert_grids_equal(osl.grid.dump(), node.grid().download_tiles(), 1e-9)      # (free-running: the poses differ by ~1e-14)
+        tot["mode3_cases"] += int(mode3); tot["async_cases"] = tot.get("async_cases", 0) + int(use_async)
+        if use_async:
+            oab.flush(); node.grid().sync()
+            H.assert_grids_equal(oab.g.dump(), node.grid().download_tiles(), 1e-9)
+        else:
+            H.assert_grids_equal(osl.grid.dump(), node.grid().download_tiles(), 1e-9)      # (free-running: the poses differ by ~1e-14)
     except AssertionError as e:
         print("MISMATCH", tag, "--", e)
         sys.exit(1)
