@@ -127,3 +127,86 @@ class HipSlamFused(HipSlam):
         self.pose = np.array(sr.pose[:]).reshape(3, 3)
         return dict(pose=self.pose.copy(), pushed=int(sr.pushed), reg_error=int(sr.reg_error), pairs=int(sr.icp.pairs),
                     valid_model=int(sr.icp.n_model), no_model=int(sr.no_model), T=np.array(sr.icp.T[:]).reshape(3, 3))
+
+
+class PrimitiveLoop:
+    """ThreadLocalize::eventLoop (ThreadLocalize.cpp:310-409) on ONE backend's primitives -- the oracle's (ray cast, Icp::iterate
+    with its per-iteration trace, push) or the unfused C ABI calls (tsd_raycast / tsd_icp + tsd_icp_trace / tsd_push) -- keeping the
+    inputs of the last registration on the host.  T_override advances the state with somebody else's registration result
+    (re-synced runs); out["T"] stays the backend's own."""
+
+    def __init__(self, oracle, kw, grid, is_hip, threads=1):
+        self.o, self.kw, self.g, self.hip, self.threads = oracle, kw, grid, is_hip, threads
+        O = oracle
+        self.cs = grid.cell_size
+        W = (1 << kw["map_size_log2"]) * self.cs
+        phi = kw["local_offset_yaw"]
+        self.sx = W * 0.5 + kw["x_offset"] + kw["local_offset_x"]
+        self.sy = W * 0.5 + kw["y_offset"] + kw["local_offset_y"]
+        Tinit = np.array([[math.cos(phi), -math.sin(phi), self.sx], [math.sin(phi), math.cos(phi), self.sy], [0, 0, 1.0]])
+        self.rays_local = O.rays_local(kw["beams"], kw["angle_min"], kw["angle_increment"])
+        self.rays = O.rays_transform(Tinit, self.rays_local)
+        self.pose = O.mat3_mul(np.eye(3), Tinit)
+        self.last_pose = None
+        self.first = True
+        if is_hip:
+            self.params = grid.icp_params(kw["icp_iterations"], kw["dist_filter_max"], kw["dist_filter_min"])
+            self.bounds = (grid.min_x, grid.max_x, grid.min_y, grid.max_y)
+        else:
+            self.bounds = (0.0, grid.max_x, 0.0, grid.max_x)        # TsdGrid's _minX/_maxX/_minY/_maxY (tsd_oracle.c: ora_grid_create)
+
+    def push(self, pose, data, mask):
+        kw = self.kw
+        a = (pose, data, mask, kw["angle_increment"], kw["angle_min"], kw["max_range"], kw["min_range"], kw["low_refl_range"])
+        return self.g.push(*a) if self.hip else self.g.push(*a, threads=self.threads)
+
+    def icp(self, M, S, pose):
+        kw, O = self.kw, self.o
+        if self.hip:
+            r = self.g.icp(M, S, pose, self.params)
+            tr = self.g.icp_trace(r.iterations)
+            return dict(T=r.T, pairs=r.pairs, iterations=r.iterations, state=r.state, rms=r.rms, trace=tr)
+        return O.icp(M, S, pose, kw["icp_iterations"], kw["dist_filter_max"], kw["dist_filter_min"], self.bounds,
+                     nn_mode=kw.get("nn_mode", 0), trace=True)
+
+    def scan(self, r32, T_override=None):
+        kw, O = self.kw, self.o
+        r = np.array(r32, dtype=np.float32)
+        r[r < kw["laser_min_range"]] = 0.0
+        data, mask = O.ingest_f32(r, kw["max_range"], kw["angle_increment"])
+        out = dict(pushed=0, reg_error=0, no_model=0, stats=None, trace=None, hit=None)
+        if self.first:
+            self.first = False
+            self.g.free_footprint([self.sx + kw["footprint_x_offset"], self.sy], kw["footprint_width"], kw["footprint_height"])
+            out["stats"] = self.push(self.pose, data, mask)
+            self.rays = O.rays_rescale(self.rays, self.cs, 1.0)
+            out.update(pose=self.pose.copy(), pushed=1)
+            return out
+        if self.last_pose is None:
+            self.last_pose = self.pose.copy()
+        a = (self.pose, self.rays, kw["min_range"], kw["max_range"])
+        co, no, mo, cnt = self.g.raycast(*a) if self.hip else self.g.raycast(*a, threads=self.threads)
+        out["hit"] = mo.copy()
+        if cnt == 0:
+            out.update(pose=self.pose.copy(), no_model=1)
+            return out
+        scene, ms, _ = O.scene_from_scan(self.rays_local, data, mask)
+        M = co.reshape(-1, 2)[mo.astype(bool)].copy()
+        S = scene.reshape(-1, 2)[ms.astype(bool)].copy()
+        self.inputs = (M, S, self.pose.copy())
+        res = self.icp(M, S, self.pose)
+        out.update(trace=res["trace"], pairs=res["pairs"], iterations=res["iterations"], state=res["state"], T=np.array(res["T"]))
+        T = res["T"] if T_override is None else np.array(T_override, dtype=np.float64).reshape(3, 3)
+        if O.lib().ora_is_registration_error(O.d(O.f64(T).reshape(9)), kw["reg_trs_max"], kw["reg_sin_rot_max"]):
+            out.update(pose=self.pose.copy(), reg_error=1)
+            return out
+        self.rays = O.rays_transform(T, self.rays)
+        self.pose = O.mat3_mul(self.pose, T)
+        out["pose"] = self.pose.copy()
+        lp, cp = O.f64(self.last_pose).reshape(9), O.f64(self.pose).reshape(9)
+        if O.lib().ora_is_pose_change_significant(O.d(lp), O.d(cp)):
+            self.last_pose = self.pose.copy()
+            d2, m2 = O.ingest_f64(data, kw["max_range"], kw["angle_increment"])
+            out["stats"] = self.push(self.pose, d2, m2)
+            out["pushed"] = 1
+        return out

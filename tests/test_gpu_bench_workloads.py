@@ -19,11 +19,12 @@ import pytest
 
 from ohm_tsd_slam_amd import capi, facade, synth
 from tests import helpers as H
-from tests.slam_driver import HipSlam, slam_kwargs
+from tests.slam_driver import HipSlam, PrimitiveLoop, slam_kwargs
 
 pytestmark = pytest.mark.gpu
 
 BENCH_SCANS = 1 + 5 + 200      # bench.py defaults: init + warm-up + timed
+LONG_RUN_SCANS = 420           # >= 400; the trajectory turns round at scan 250
 
 
 def _threads():
@@ -31,19 +32,38 @@ def _threads():
 
 
 def test_cfg2_pillars_bench_length(oracle):
+    """420 scans of cfg2 / pillars (bench.py times 206 of them; the robot turns round at scan 250, so the second leg
+    re-enters mapped ground with weights near their cap: VERDICT r4 item 1), three comparisons side by side:
+
+    ORACLE-LED re-sync: oracle loop free, the HIP loop's state advanced with the oracle's T -- every HIP registration on the
+      oracle's inputs: pairs / iterations / state / point counts exact, |dT| <= 1e-4 (north_star), grids cell for cell.
+    HIP-LED re-sync: the HIP loop (unfused C ABI calls) free, an oracle loop advanced with the HIP T -- every scan of the
+      HIP trajectory is what the oracle computes on the same inputs: hit masks and every iteration's pair count exact,
+      |dT| <= 1e-4, grids cell for cell.  By induction the HIP free run is a reference run on inputs that differ by
+      rounding (summation order of the estimator's totals, 1e-15 per registration, fed back through pose and map).
+    FREE: the fused facade (what bench.py drives) follows the HIP-led loop to rounding, and stays within 1e-6 of the free
+      oracle loop until the first scan whose pair count differs (tools/first_flip.py shows that flip is a tie at the
+      1e-12 level: profiles/r5_first_flip.txt); after a flip the two runs are two valid reference runs on perturbed
+      inputs, and their distance is reported, not bounded by a parity bar."""
     gc, geo, scene = synth.CONFIGS["cfg2"]
-    n = BENCH_SCANS
+    n = LONG_RUN_SCANS
+    checkpoints = (60, 130, 330, n - 1)
     world = synth.World(scene, gc)
     poses = synth.trajectory(world, n)
     scans = synth.scans_for(world, geo, poses)
     geo_msg = synth.ScanGeometry(geo.beams, float(np.float32(geo.angle_min)), float(np.float32(geo.angle_increment)))
     kw = slam_kwargs(gc, geo_msg, nn_mode=1, threads=_threads())
     so = oracle.Slam(**kw)
-    sh = HipSlam(oracle, fused=True, **kw)                       # re-synced: state advanced with the oracle's T
+    sh = HipSlam(oracle, fused=True, **kw)                       # oracle-led: state advanced with the oracle's T
+    hl = PrimitiveLoop(oracle, kw, capi.TsdGridDevice(gc.map_size_log2, gc.cell_size, gc.max_trunc), True)     # HIP-led, free
+    ol = PrimitiveLoop(oracle, kw, oracle.Grid(gc.map_size_log2, gc.cell_size, gc.max_trunc), False, _threads())  # follows hl
+    assert hl.bounds == ol.bounds
     node = facade.SlamNode(facade.node_params(gc, geo), synchronous=True, fused=True)   # free-running (bench path)
     worst_sync = (0.0, 0.0)
+    worst_led = (0.0, 0.0)
     worst_cell = 0.0
-    free = dict(max_pos=0.0, max_yaw=0.0, first_pair_flip=None, per_scan=[])
+    worst_facade = 0.0
+    free = dict(max_pos=0.0, max_yaw=0.0, max_pos_before_flip=0.0, first_pair_flip=None, per_scan=[])
     pushes = 0
     for k in range(n):
         ro = so.process_scan(scans[k])
@@ -61,31 +81,55 @@ def test_cfg2_pillars_bench_length(oracle):
             assert bool(ro.pushed) == bool(rh["pushed"]) and bool(ro.reg_error) == bool(rh["reg_error"])
             assert np.max(np.abs(Po - rh["pose"])) <= 1e-12, f"scan {k}: re-synced state drifted"
         pushes += int(ro.pushed)
-        if k in (60, 130, n - 1):                                # cell-for-cell: identical poses => identical grids
+        # HIP-led: the oracle on the HIP trajectory's inputs
+        r1 = hl.scan(scans[k])
+        r2 = ol.scan(scans[k], T_override=r1["T"] if k > 0 else None)
+        if k > 0:
+            assert np.array_equal(r1["hit"], r2["hit"]), f"scan {k}: ray cast hit masks differ on identical inputs"
+            assert np.array_equal(hl.inputs[1], ol.inputs[1]) and np.max(np.abs(hl.inputs[0] - ol.inputs[0])) <= 1e-9
+            assert (r1["iterations"], r1["state"]) == (r2["iterations"], r2["state"]), f"scan {k}"
+            assert np.array_equal(r1["trace"][:, 0], r2["trace"][:, 0]), \
+                f"scan {k}: pair counts per iteration differ on identical inputs\n{r1['trace'][:, 0]}\n{r2['trace'][:, 0]}"
+            d, a = H.pose_delta(r1["T"], r2["T"])
+            assert d <= 1e-4 and a <= 1e-4, f"scan {k}: T differs by {d} m {a} rad"
+            worst_led = (max(worst_led[0], d), max(worst_led[1], a))
+            assert (r1["pushed"], r1["reg_error"]) == (r2["pushed"], r2["reg_error"])
+            assert np.array_equal(r1["pose"], r2["pose"]), f"scan {k}: HIP-led state drifted"
+        assert r1["stats"] == r2["stats"], f"scan {k}: push statistics differ\n{r1['stats']}\n{r2['stats']}"
+        if k in checkpoints:                                     # cell-for-cell: identical poses => identical grids
             dt, dw = H.assert_grids_equal(so.grid.dump(), sh.grid.download_tiles(), 1e-9)
+            worst_cell = max(worst_cell, dt, dw)
+            dt, dw = H.assert_grids_equal(ol.g.dump(), hl.g.download_tiles(), 1e-9)
             worst_cell = max(worst_cell, dt, dw)
         # free-running facade
         node.laser(scans[k], geo.angle_min, geo.angle_increment)
         rf = node.report()
+        worst_facade = max(worst_facade, float(np.max(np.abs(np.asarray(rf["pose"]) - r1["pose"]))))
         d, a = H.pose_delta(Po, rf["pose"])
         free["max_pos"] = max(free["max_pos"], d); free["max_yaw"] = max(free["max_yaw"], a)
         if k > 0 and free["first_pair_flip"] is None and rf["pairs"] != ro.pairs:
             free["first_pair_flip"] = k
         if free["first_pair_flip"] is None:
             assert d <= 1e-6 and a <= 1e-6, f"free run, scan {k}: {d} m {a} rad before any pair decision flipped"
+            free["max_pos_before_flip"] = max(free["max_pos_before_flip"], d)
         free["per_scan"].append([k, d, a, int(rf.get("pairs", 0)), int(ro.pairs)])
-    assert pushes >= 200
-    # free-running: a flipped pair decision gives a transient difference that the registration contracts again
-    assert free["max_pos"] <= 5e-3 and free["max_yaw"] <= 5e-3, free
+    assert pushes >= 400
+    # the fused facade is the HIP-led loop (same kernels, the gates and Sensor::transform on the device)
+    assert worst_facade <= 1e-9, worst_facade
     eo = math.hypot(Po[0, 2] - poses[-1, 0], Po[1, 2] - poses[-1, 1])
+    eh = math.hypot(rf["pose"][0][2] - poses[-1, 0], rf["pose"][1][2] - poses[-1, 1])
+    assert eh <= eo + 0.05, (eh, eo)                             # both track the ground truth alike
     free.update(scans=n, resynced_max_T_diff_m=worst_sync[0], resynced_max_T_diff_rad=worst_sync[1],
-                oracle_tracking_error_m=eo, resynced_max_cell_diff=worst_cell)
+                hip_led_max_T_diff_m=worst_led[0], hip_led_max_T_diff_rad=worst_led[1], facade_vs_hip_led=worst_facade,
+                oracle_tracking_error_m=eo, facade_tracking_error_m=eh, resynced_max_cell_diff=worst_cell)
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, "free_run_divergence.json"), "w") as f:
         json.dump(free, f)
-    print("cfg2 x %d scans: re-synced max |dT| %.2e m %.2e rad; free-running max |dpose| %.2e m %.2e rad, first pair flip %s"
-          % (n, worst_sync[0], worst_sync[1], free["max_pos"], free["max_yaw"], free["first_pair_flip"]))
+    print("cfg2 x %d scans: oracle-led max |dT| %.2e m %.2e rad; HIP-led max |dT| %.2e m %.2e rad; facade vs HIP-led %.1e; "
+          "free-running max |dpose| %.2e m %.2e rad (%.1e before the first pair flip at scan %s)"
+          % (n, worst_sync[0], worst_sync[1], worst_led[0], worst_led[1], worst_facade, free["max_pos"], free["max_yaw"],
+             free["max_pos_before_flip"], free["first_pair_flip"]))
     node.close()
 
 
