@@ -124,6 +124,8 @@ ThreadLocalize::ThreadLocalize(obvious::TsdGrid* grid, ThreadMapping* mapper, co
 
   _posePub = _node->create_publisher<geometry_msgs::msg::PoseStamped>(poseTopic, 1);
   _tfBroadcaster = std::make_unique<tf2_ros::TransformBroadcaster>(*_node);
+  _tf_buffer = std::make_unique<tf2_ros::Buffer>(_node->get_clock());                     // ThreadLocalize.cpp:198-199
+  _tf_transform_listener = std::make_unique<tf2_ros::TransformListener>(*_tf_buffer);
   _poseStamped.header.frame_id = _tfMapFrameId;
   _tf.header.frame_id = _tfMapFrameId;
   _tf.child_frame_id = _robotName + _tfOdomFrameId;
@@ -682,20 +684,58 @@ bool ThreadLocalize::isRegistrationError(obvious::Matrix* T, const double trnsMa
   return (trnsAbs > trnsMax) || (std::abs(std::sin(deltaPhi)) > rotMax);
 }
 
+// ThreadLocalize.cpp:603-689.  What leaves on tf is map -> odom: the laser pose in the map, taken to base_footprint with the
+// laser -> base_footprint look-up and on to odom with base_footprint -> odom, i.e. pose * T_laser_footprint * T_footprint_odom.
+// A look-up that throws (no such frames yet) is skipped like the reference skips it, and -- also like the reference -- the message's
+// transform is written ONLY where the odom look-up succeeded (:657): without an odom tree the broadcaster repeats whatever _tf.transform
+// held (the identity at start, the last good correction later, NaN after sendNanTransform).  The PoseStamped is always the laser pose.
 void ThreadLocalize::sendTransform(obvious::Matrix* T)
 {
   const double curTheta = calcAngle(T);
   const double posX = (*T)(0, 2) + _gridOffSetX;
   const double posY = (*T)(1, 2) + _gridOffSetY;
 
-  // without a tf tree (laser->base_footprint, base_footprint->odom look-ups throw in the reference and
-  // are skipped, ThreadLocalize.cpp:617-661) map->odom carries the laser pose itself
+  tf2::Quaternion orientation;
+  orientation.setEuler(0.0, 0.0, curTheta);
+  tf2::Transform pose;
+  pose.setOrigin(tf2::Vector3(posX, posY, 0.0));
+  pose.setRotation(orientation);
   _tf.child_frame_id = _tfOdomFrameId;
   _tf.header.frame_id = _tfMapFrameId;
-  _tf.transform.translation.x = posX;
-  _tf.transform.translation.y = posY;
-  _tf.transform.translation.z = 0.0;
-  setYaw(_tf.transform.rotation, curTheta);
+
+  // pose <- pose * lookup(target, source); false when the buffer has no such transform
+  auto compose = [&](const std::string& target, const std::string& source, int which) -> bool
+  {
+    int state = 1;
+    std::string why;
+    try
+    {
+      const geometry_msgs::msg::TransformStamped st = _tf_buffer->lookupTransform(target, source, tf2::TimePointZero);
+      tf2::Transform step, product;
+      tf2::fromMsg(st.transform, step);
+      product.mult(pose, step);
+      pose = product;
+    }
+    catch(const tf2::TransformException& ex)
+    {
+      state = 0;
+      why = ex.what();
+    }
+    if(state != _tfLookUpState[which])      // (the reference logs this at INFO level on every scan; here: when it changes)
+    {
+      _tfLookUpState[which] = state;
+      if(!state)
+        std::fprintf(stderr, "Localizer(%s): no transform from %s to %s available (%s)\n", _nameSpace.c_str(), source.c_str(), target.c_str(), why.c_str());
+    }
+    return state != 0;
+  };
+  compose(_tfLaserFrameId, _tfFootprintFrameId, 0);                 // correction of laser to base_footprint (:618-641)
+  if(compose(_tfFootprintFrameId, _tfOdomFrameId, 1))               // correction of odom (:643-666)
+  {
+    _tf.child_frame_id = _tfOdomFrameId;
+    _tf.header.frame_id = _tfMapFrameId;
+    _tf.transform = tf2::toMsg(pose);
+  }
 
   _poseStamped.header.stamp    = _stampLaser;
   _poseStamped.pose.position.x = posX;

@@ -59,6 +59,10 @@ public:
   /** nothing queued and nothing being processed */
   bool idle();
   std::shared_ptr<rclcpp::Publisher<geometry_msgs::msg::PoseStamped>> posePublisher() { return _posePub; }
+  /** the tf buffer sendTransform looks laser -> base_footprint and base_footprint -> odom up in (a TransformListener fills it under
+   *  ROS; tests and ROS-free hosts feed it with Buffer::setTransform) and the broadcaster map -> odom leaves through */
+  tf2_ros::Buffer* tfBuffer() { return _tf_buffer.get(); }
+  tf2_ros::TransformBroadcaster* tfBroadcaster() { return _tfBroadcaster.get(); }
   obvious::SensorPolar2D* sensor() { return _sensor; }
 
   // every parameter the reference declares in the constructor (ThreadLocalize.cpp:86-129) / in init (:424-432)
@@ -121,6 +125,9 @@ private:
 
   std::shared_ptr<rclcpp::Publisher<geometry_msgs::msg::PoseStamped>> _posePub;
   std::unique_ptr<tf2_ros::TransformBroadcaster> _tfBroadcaster;
+  std::unique_ptr<tf2_ros::Buffer> _tf_buffer;                          // ThreadLocalize.h:403-404
+  std::unique_ptr<tf2_ros::TransformListener> _tf_transform_listener;
+  int _tfLookUpState[2] = {-1, -1};                                     // last outcome of the two look-ups (logged on change only)
   geometry_msgs::msg::PoseStamped _poseStamped;
   geometry_msgs::msg::TransformStamped _tf;
 

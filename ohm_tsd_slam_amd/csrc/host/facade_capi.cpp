@@ -287,6 +287,28 @@ const char* tsd_node_pose_topic(tsd_node* n, int robot)
   return n->localizers[robot]->posePublisher()->topic().c_str();
 }
 
+// last TransformStamped the robot's broadcaster sent (map -> odom): tx, ty, tz, qx, qy, qz, qw, send count; frames as "frame_id|child_frame_id"
+void tsd_node_tf_msg(tsd_node* n, int robot, double* out8, char* frames, int cap)
+{
+  auto* b = n->localizers[robot]->tfBroadcaster();
+  const auto m = b->last();
+  out8[0] = m.transform.translation.x; out8[1] = m.transform.translation.y; out8[2] = m.transform.translation.z;
+  out8[3] = m.transform.rotation.x; out8[4] = m.transform.rotation.y; out8[5] = m.transform.rotation.z;
+  out8[6] = m.transform.rotation.w; out8[7] = (double)b->count();
+  if(frames && cap > 0)
+    std::snprintf(frames, (size_t)cap, "%s|%s", m.header.frame_id.c_str(), m.child_frame_id.c_str());
+}
+
+// feed the robot's tf buffer (what a TransformListener does under ROS): `child` expressed in `parent`
+int tsd_node_set_transform(tsd_node* n, int robot, const char* parent, const char* child, const double xyz[3], const double qxyzw[4])
+{
+  geometry_msgs::msg::TransformStamped t;
+  t.header.frame_id = parent; t.child_frame_id = child;
+  t.transform.translation.x = xyz[0]; t.transform.translation.y = xyz[1]; t.transform.translation.z = xyz[2];
+  t.transform.rotation.x = qxyzw[0]; t.transform.rotation.y = qxyzw[1]; t.transform.rotation.z = qxyzw[2]; t.transform.rotation.w = qxyzw[3];
+  return n->localizers[robot]->tfBuffer()->setTransform(t, "tsd_node_set_transform", true) ? 0 : -1;
+}
+
 tsd_ctx* tsd_node_grid_ctx(tsd_node* n) { return n->grid ? n->grid->context() : nullptr; }
 // the facade's grid mutex (obvious::TsdGrid::mutex()): whoever talks to the context through the raw tsd_* ABI while the
 // node's worker threads may be running takes it around each call, like the facade's own classes do

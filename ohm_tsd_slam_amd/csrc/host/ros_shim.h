@@ -13,13 +13,19 @@
 #include <geometry_msgs/msg/pose_stamped.hpp>
 #include <geometry_msgs/msg/transform_stamped.hpp>
 #include <tf2_ros/transform_broadcaster.h>
+#include <tf2_ros/transform_listener.h>
+#include <tf2_ros/buffer.h>
+#include <tf2/LinearMath/Transform.h>
+#include <tf2_geometry_msgs/tf2_geometry_msgs.hpp>
 #else
 #define OHM_TSD_SLAM_HAVE_ROS 0
 #include <chrono>
 #include <cstdint>
 #include <map>
+#include <cmath>
 #include <memory>
 #include <mutex>
+#include <stdexcept>
 #include <string>
 #include <variant>
 #include <vector>
@@ -142,6 +148,163 @@ private:
   mutable std::mutex _mx;
   geometry_msgs::msg::TransformStamped _last;
   uint64_t _count = 0;
+};
+}  // namespace tf2_ros
+
+// tf2's linear algebra and the tf buffer, as far as ThreadLocalize::sendTransform uses them (ThreadLocalize.cpp:603-689):
+// Quaternion::setEuler, Transform::mult / setOrigin / setRotation, fromMsg / toMsg, Buffer::lookupTransform throwing
+// tf2::TransformException.  The arithmetic follows tf2's published LinearMath (Quaternion.h setEuler, Matrix3x3.h
+// setRotation / getRotation, Transform.h mult) so that the message the stand-in produces is the one the real library would.
+namespace tf2 {
+class TransformException : public std::runtime_error { public: explicit TransformException(const std::string& m) : std::runtime_error(m) {} };
+class LookupException : public TransformException { public: explicit LookupException(const std::string& m) : TransformException(m) {} };
+using TimePoint = std::chrono::time_point<std::chrono::system_clock, std::chrono::nanoseconds>;
+static const TimePoint TimePointZero = TimePoint(std::chrono::nanoseconds(0));
+
+class Vector3 {
+public:
+  Vector3() = default;
+  Vector3(double x, double y, double z) : _v{x, y, z} {}
+  double x() const { return _v[0]; }
+  double y() const { return _v[1]; }
+  double z() const { return _v[2]; }
+  double operator[](int i) const { return _v[i]; }
+private:
+  double _v[3] = {0, 0, 0};
+};
+
+class Quaternion {
+public:
+  Quaternion() = default;
+  Quaternion(double x, double y, double z, double w) : _q{x, y, z, w} {}
+  // tf2's argument order: yaw about Y, pitch about X, roll about Z -- sendTransform passes (0, 0, theta)
+  void setEuler(double yaw, double pitch, double roll) {
+    const double hy = yaw * 0.5, hp = pitch * 0.5, hr = roll * 0.5;
+    const double cy = std::cos(hy), sy = std::sin(hy), cp = std::cos(hp), sp = std::sin(hp), cr = std::cos(hr), sr = std::sin(hr);
+    _q[0] = cr * sp * cy + sr * cp * sy;
+    _q[1] = cr * cp * sy - sr * sp * cy;
+    _q[2] = sr * cp * cy - cr * sp * sy;
+    _q[3] = cr * cp * cy + sr * sp * sy;
+  }
+  double x() const { return _q[0]; }
+  double y() const { return _q[1]; }
+  double z() const { return _q[2]; }
+  double w() const { return _q[3]; }
+  double length2() const { return _q[0] * _q[0] + _q[1] * _q[1] + _q[2] * _q[2] + _q[3] * _q[3]; }
+private:
+  double _q[4] = {0, 0, 0, 1};
+};
+
+class Transform {
+public:
+  Transform() { for(int i = 0; i < 3; i++) for(int j = 0; j < 3; j++) _m[i][j] = (i == j) ? 1.0 : 0.0; }
+  void setOrigin(const Vector3& o) { _o = o; }
+  const Vector3& getOrigin() const { return _o; }
+  void setRotation(const Quaternion& q) {           // Matrix3x3::setRotation
+    const double d = q.length2(), s = 2.0 / d;
+    const double xs = q.x() * s, ys = q.y() * s, zs = q.z() * s;
+    const double wx = q.w() * xs, wy = q.w() * ys, wz = q.w() * zs;
+    const double xx = q.x() * xs, xy = q.x() * ys, xz = q.x() * zs;
+    const double yy = q.y() * ys, yz = q.y() * zs, zz = q.z() * zs;
+    _m[0][0] = 1.0 - (yy + zz); _m[0][1] = xy - wz;         _m[0][2] = xz + wy;
+    _m[1][0] = xy + wz;         _m[1][1] = 1.0 - (xx + zz); _m[1][2] = yz - wx;
+    _m[2][0] = xz - wy;         _m[2][1] = yz + wx;         _m[2][2] = 1.0 - (xx + yy);
+  }
+  Quaternion getRotation() const {                  // Matrix3x3::getRotation
+    const double trace = _m[0][0] + _m[1][1] + _m[2][2];
+    double t[4];
+    if(trace > 0.0) {
+      double s = std::sqrt(trace + 1.0);
+      t[3] = s * 0.5; s = 0.5 / s;
+      t[0] = (_m[2][1] - _m[1][2]) * s; t[1] = (_m[0][2] - _m[2][0]) * s; t[2] = (_m[1][0] - _m[0][1]) * s;
+    } else {
+      const int i = _m[0][0] < _m[1][1] ? (_m[1][1] < _m[2][2] ? 2 : 1) : (_m[0][0] < _m[2][2] ? 2 : 0);
+      const int j = (i + 1) % 3, k = (i + 2) % 3;
+      double s = std::sqrt(_m[i][i] - _m[j][j] - _m[k][k] + 1.0);
+      t[i] = s * 0.5; s = 0.5 / s;
+      t[3] = (_m[k][j] - _m[j][k]) * s; t[j] = (_m[j][i] + _m[i][j]) * s; t[k] = (_m[k][i] + _m[i][k]) * s;
+    }
+    return Quaternion(t[0], t[1], t[2], t[3]);
+  }
+  // this = t1 * t2: basis = b1 * b2, origin = b1 * o2 + o1
+  void mult(const Transform& t1, const Transform& t2) {
+    double m[3][3], o[3];
+    for(int i = 0; i < 3; i++) {
+      for(int j = 0; j < 3; j++) m[i][j] = t1._m[i][0] * t2._m[0][j] + t1._m[i][1] * t2._m[1][j] + t1._m[i][2] * t2._m[2][j];
+      o[i] = t1._m[i][0] * t2._o[0] + t1._m[i][1] * t2._o[1] + t1._m[i][2] * t2._o[2] + t1._o[i];
+    }
+    for(int i = 0; i < 3; i++) for(int j = 0; j < 3; j++) _m[i][j] = m[i][j];
+    _o = Vector3(o[0], o[1], o[2]);
+  }
+  Transform inverse() const {
+    Transform r;
+    for(int i = 0; i < 3; i++) for(int j = 0; j < 3; j++) r._m[i][j] = _m[j][i];
+    double o[3];
+    for(int i = 0; i < 3; i++) o[i] = -(r._m[i][0] * _o[0] + r._m[i][1] * _o[1] + r._m[i][2] * _o[2]);
+    r._o = Vector3(o[0], o[1], o[2]);
+    return r;
+  }
+private:
+  double _m[3][3];
+  Vector3 _o;
+};
+
+inline void fromMsg(const geometry_msgs::msg::Transform& in, Transform& out) {
+  out.setOrigin(Vector3(in.translation.x, in.translation.y, in.translation.z));
+  out.setRotation(Quaternion(in.rotation.x, in.rotation.y, in.rotation.z, in.rotation.w));
+}
+inline geometry_msgs::msg::Transform toMsg(const Transform& in) {
+  geometry_msgs::msg::Transform out;
+  out.translation.x = in.getOrigin().x(); out.translation.y = in.getOrigin().y(); out.translation.z = in.getOrigin().z();
+  const Quaternion q = in.getRotation();
+  out.rotation.x = q.x(); out.rotation.y = q.y(); out.rotation.z = q.z(); out.rotation.w = q.w();
+  return out;
+}
+}  // namespace tf2
+
+namespace tf2_ros {
+// the tf tree as a set of edges: setTransform stores "child in parent" (header.frame_id = parent), lookupTransform(target,
+// source) answers from a stored edge, its inverse or -- for target == source -- the identity, and throws tf2::LookupException
+// otherwise, which is what the real buffer does while no tree has been heard (the case the reference catches)
+class Buffer {
+public:
+  explicit Buffer(std::shared_ptr<rclcpp::Clock> = nullptr) {}
+  bool setTransform(const geometry_msgs::msg::TransformStamped& t, const std::string& /*authority*/, bool /*is_static*/ = false) {
+    if(t.header.frame_id.empty() || t.child_frame_id.empty() || t.header.frame_id == t.child_frame_id) return false;
+    std::lock_guard<std::mutex> lk(_mx);
+    _edges[std::make_pair(t.header.frame_id, t.child_frame_id)] = t;
+    return true;
+  }
+  void clear() { std::lock_guard<std::mutex> lk(_mx); _edges.clear(); }
+  geometry_msgs::msg::TransformStamped lookupTransform(const std::string& target, const std::string& source, const tf2::TimePoint&) const {
+    std::lock_guard<std::mutex> lk(_mx);
+    auto it = _edges.find(std::make_pair(target, source));
+    if(it != _edges.end()) return it->second;
+    it = _edges.find(std::make_pair(source, target));
+    if(it != _edges.end()) {
+      tf2::Transform t;
+      tf2::fromMsg(it->second.transform, t);
+      geometry_msgs::msg::TransformStamped r;
+      r.header.stamp = it->second.header.stamp; r.header.frame_id = target; r.child_frame_id = source;
+      r.transform = tf2::toMsg(t.inverse());
+      return r;
+    }
+    if(target == source)
+      for(const auto& e : _edges)
+        if(e.first.first == target || e.first.second == target) {
+          geometry_msgs::msg::TransformStamped r;
+          r.header.frame_id = target; r.child_frame_id = source;
+          return r;
+        }
+    throw tf2::LookupException("\"" + target + "\" passed to lookupTransform argument target_frame does not exist or is not connected to \"" + source + "\"");
+  }
+private:
+  mutable std::mutex _mx;
+  std::map<std::pair<std::string, std::string>, geometry_msgs::msg::TransformStamped> _edges;
+};
+class TransformListener {
+public:
+  explicit TransformListener(Buffer&) {}
 };
 }  // namespace tf2_ros
 #endif

@@ -34,6 +34,8 @@ HOST_ABI = {
     "tsd_node_report": (None, [C.c_void_p, C.c_int, _dp]),
     "tsd_node_pose_msg": (None, [C.c_void_p, C.c_int, _dp]),
     "tsd_node_pose_topic": (C.c_char_p, [C.c_void_p, C.c_int]),
+    "tsd_node_tf_msg": (None, [C.c_void_p, C.c_int, _dp, C.c_char_p, C.c_int]),
+    "tsd_node_set_transform": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, _dp, _dp]),
     "tsd_node_laser_ahead": (C.c_int, [C.c_void_p, C.c_int, _fp, C.c_int, C.c_double, C.c_double, C.c_longlong]),
     "tsd_node_play": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(_fp), C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_longlong, C.c_longlong]),
     "tsd_node_batch_stats": (None, [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
@@ -192,6 +194,23 @@ class SlamNode:
         self.lib.tsd_node_pose_msg(self.h, robot, buf.ctypes.data_as(_dp))
         return {"position": buf[:3].copy(), "orientation_xyzw": buf[3:7].copy(), "count": int(buf[7]),
                 "topic": self.lib.tsd_node_pose_topic(self.h, robot).decode()}
+
+    def tf_msg(self, robot: int = 0) -> dict:
+        """the last TransformStamped the robot's tf broadcaster sent (map -> odom, ThreadLocalize.cpp:603-689)"""
+        buf = np.zeros(8)
+        frames = C.create_string_buffer(256)
+        self.lib.tsd_node_tf_msg(self.h, robot, buf.ctypes.data_as(_dp), frames, 256)
+        parent, child = frames.value.decode().split("|")
+        return {"translation": buf[:3].copy(), "rotation_xyzw": buf[3:7].copy(), "count": int(buf[7]),
+                "frame_id": parent, "child_frame_id": child}
+
+    def set_transform(self, parent: str, child: str, xyz, q_xyzw, robot: int = 0):
+        """feed the robot's tf buffer (a TransformListener's job under ROS): frame `child` expressed in frame `parent`"""
+        t = np.ascontiguousarray(xyz, dtype=np.float64)
+        q = np.ascontiguousarray(q_xyzw, dtype=np.float64)
+        rc = self.lib.tsd_node_set_transform(self.h, robot, parent.encode(), child.encode(), t.ctypes.data_as(_dp), q.ctypes.data_as(_dp))
+        if rc != 0:
+            raise ValueError("tsd_node_set_transform refused %s -> %s" % (parent, child))
 
     def grid(self) -> "GridView":
         return GridView(self.lib.tsd_node_grid_ctx(self.h), self)

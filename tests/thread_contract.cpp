@@ -10,8 +10,10 @@
 //   shutdown        terminateThread() + alive(ms) end the loops; destructors join with work still queued (ThreadSLAM.cpp:19-33)
 // Prints "ok <case>" per case; exit code = number of failed checks.
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <set>
 #include <thread>
@@ -266,6 +268,81 @@ static void case_shutdown_with_work_queued()
   std::printf("ok shutdown_with_work_queued\n");
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// The tf half of sendTransform (ThreadLocalize.cpp:603-689).  (i) no tree: both look-ups throw, are skipped, and the message's
+// transform is NOT written (the reference assigns it only where the odom look-up succeeded, :657) -- the broadcaster repeats
+// the identity the message started with; the PoseStamped carries the laser pose.  (ii) odom -> base_footprint -> laser heard:
+// map -> odom = pose * T(laser <- footprint) * T(footprint <- odom); the numbers are printed ("tf_result ...") and
+// tests/test_cpu_thread_contract.py checks them against a numpy product of 4 x 4 matrices.  (iii) the tree goes away again: the
+// transform keeps its last good value.
+static void print_tf(const char* what, const geometry_msgs::msg::Transform& t)
+{
+  std::printf("tf_result %s %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", what, t.translation.x, t.translation.y, t.translation.z,
+              t.rotation.x, t.rotation.y, t.rotation.z, t.rotation.w);
+}
+
+static void case_tf_map_to_odom()
+{
+  Rig r(/*fused*/ false, /*synchronous*/ true);
+  r.loc->laserCallBack(make_scan(0));
+  r.loc->laserCallBack(make_scan(1));
+  auto* bc = r.loc->tfBroadcaster();
+  CHECK(bc->count() >= 1, "nothing was broadcast");
+  {
+    const auto m = bc->last();
+    CHECK(m.header.frame_id == "map" && m.child_frame_id == "odom", "frames %s -> %s", m.header.frame_id.c_str(), m.child_frame_id.c_str());
+    CHECK(m.transform.translation.x == 0.0 && m.transform.translation.y == 0.0 && m.transform.translation.z == 0.0 &&
+          m.transform.rotation.x == 0.0 && m.transform.rotation.y == 0.0 && m.transform.rotation.z == 0.0 && m.transform.rotation.w == 1.0,
+          "without a tf tree the transform was written (%g %g)", m.transform.translation.x, m.transform.translation.y);
+    CHECK(m.header.stamp.sec == 1, "stamp %d", m.header.stamp.sec);
+    const auto p = r.loc->posePublisher()->last();
+    const auto rep = r.loc->lastReport();
+    const double W = 512 * 0.05;
+    CHECK(std::fabs(p.pose.position.x - (rep.pose[2] - 0.5 * W)) < 1e-12 && std::fabs(p.pose.position.y - (rep.pose[5] - 0.5 * W)) < 1e-12,
+          "PoseStamped %g %g against pose %g %g", p.pose.position.x, p.pose.position.y, rep.pose[2], rep.pose[5]);
+  }
+  // odom -> base_footprint -> laser, both with a rotation that is not about z only
+  geometry_msgs::msg::TransformStamped ob, bl;
+  ob.header.frame_id = "odom"; ob.child_frame_id = "base_footprint";
+  ob.transform.translation.x = 1.25; ob.transform.translation.y = -0.5; ob.transform.translation.z = 0.0;
+  { tf2::Quaternion q; q.setEuler(0.02, -0.01, 0.7); ob.transform.rotation.x = q.x(); ob.transform.rotation.y = q.y(); ob.transform.rotation.z = q.z(); ob.transform.rotation.w = q.w(); }
+  bl.header.frame_id = "base_footprint"; bl.child_frame_id = "laser";
+  bl.transform.translation.x = 0.3; bl.transform.translation.y = 0.05; bl.transform.translation.z = 0.2;
+  { tf2::Quaternion q; q.setEuler(0.0, 0.0, -0.1); bl.transform.rotation.x = q.x(); bl.transform.rotation.y = q.y(); bl.transform.rotation.z = q.z(); bl.transform.rotation.w = q.w(); }
+  CHECK(r.loc->tfBuffer()->setTransform(ob, "test", false) && r.loc->tfBuffer()->setTransform(bl, "test", true), "setTransform");
+  const uint64_t before = bc->count();
+  r.loc->laserCallBack(make_scan(2));
+  CHECK(bc->count() == before + 1, "one scan, %llu broadcasts", (unsigned long long)(bc->count() - before));
+  const auto good = bc->last();
+  {
+    const auto p = r.loc->posePublisher()->last();
+    geometry_msgs::msg::Transform laser;
+    laser.translation.x = p.pose.position.x; laser.translation.y = p.pose.position.y; laser.translation.z = p.pose.position.z;
+    laser.rotation = p.pose.orientation;
+    print_tf("laser_pose", laser);
+    print_tf("odom_base", ob.transform);
+    print_tf("base_laser", bl.transform);
+    print_tf("map_odom", good.transform);
+    CHECK(good.header.frame_id == "map" && good.child_frame_id == "odom" && good.header.stamp.sec == 2, "frames / stamp of the corrected transform");
+  }
+  // the tree is lost again: the look-ups throw, the transform is left as it was
+  r.loc->tfBuffer()->clear();
+  r.loc->laserCallBack(make_scan(3));
+  {
+    const auto m = bc->last();
+    CHECK(m.header.stamp.sec == 3, "stamp %d", m.header.stamp.sec);
+    CHECK(std::memcmp(&m.transform, &good.transform, sizeof(m.transform)) == 0, "the transform changed although the odom look-up threw");
+  }
+  // only laser -> base_footprint known: still no write (the reference composes it into `pose` but publishes nothing new, :618-666)
+  r.loc->tfBuffer()->setTransform(bl, "test", true);
+  r.loc->laserCallBack(make_scan(4));
+  {
+    const auto m = bc->last();
+    CHECK(std::memcmp(&m.transform, &good.transform, sizeof(good.transform)) == 0, "the transform changed without an odom look-up");
+  }
+  std::printf("ok tf_map_to_odom\n");
+}
+
 int main()
 {
   case_first_scan_is_synchronous();
@@ -275,6 +352,7 @@ int main()
   case_announce_next_accept_and_drop();
   case_threaded_fused_stages_the_queued_scan();
   case_shutdown_with_work_queued();
+  case_tf_map_to_odom();
   if(g_failed) std::fprintf(stderr, "%d check(s) failed\n", g_failed);
   else std::printf("thread_contract: all cases ok\n");
   return g_failed;

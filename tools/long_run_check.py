@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
 """Diagnostic: the HIP facade and the CPU oracle SLAM side by side over a long cfg2 trajectory (test infrastructure:
-uses oracle/).  usage: python tools/long_run_check.py [n_scans]"""
+uses oracle/).  usage: python tools/long_run_check.py [n_scans] [--r4-angles]
+
+The facade receives sensor_msgs/LaserScan, whose angle_min / angle_increment are float32; the oracle loop must be given the same
+float32-rounded values (tests/test_gpu_bench_workloads.py does).  Round 4's version of this tool handed the oracle the float64 angles
+instead -- a scanner 1.5e-9 rad per beam different from the facade's -- and that, not a kernel, is what the 1e-2 m "divergence" of
+profiles/r4_soak_checks.txt (scans 326-339) was: --r4-angles reproduces it, the default run does not show it (profiles/r5_first_flip.txt)."""
 import math, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,14 +13,18 @@ from ohm_tsd_slam_amd import facade, synth
 from oracle import pyoracle as O
 from tests.slam_driver import slam_kwargs
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 340
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+n = int(args[0]) if args else 340
+r4_angles = "--r4-angles" in sys.argv
 gc, geo, scene = synth.CONFIGS["cfg2"]
 world = synth.World(scene, gc)
 poses = synth.trajectory(world, n)
 scans = synth.scans_for(world, geo, poses)
 node = facade.SlamNode(facade.node_params(gc, geo), device=0, synchronous=True)
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")
-osl = O.Slam(**slam_kwargs(gc, geo, threads=min(64, os.cpu_count() or 8), nn_mode=int(os.environ.get("NN_MODE", "0"))))
+geo_msg = synth.ScanGeometry(geo.beams, float(np.float32(geo.angle_min)), float(np.float32(geo.angle_increment)))
+print("oracle scanner geometry: %s" % ("float64 angles (round 4's mistake)" if r4_angles else "float32-rounded angles, as the LaserScan message carries them"))
+osl = O.Slam(**slam_kwargs(gc, geo if r4_angles else geo_msg, threads=min(64, os.cpu_count() or 8), nn_mode=int(os.environ.get("NN_MODE", "0"))))
 worst = 0.0; prev_dd = 1e-12
 for k in range(n):
     node.laser(scans[k], geo.angle_min, geo.angle_increment)
