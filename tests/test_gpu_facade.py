@@ -60,6 +60,44 @@ def test_facade_sync_loop_matches_oracle(oracle, cfg, n, fused):
     node.close()
 
 
+def _hom(t, q):
+    x, y, z, w = q
+    M = np.eye(4)
+    M[:3, :3] = [[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                 [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                 [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]]
+    M[:3, 3] = t
+    return M
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_facade_tf_map_to_odom(fused):
+    """ThreadLocalize::sendTransform's tf half (/root/reference/src/ThreadLocalize.cpp:617-661) on the real device loop: no tf tree ->
+    the broadcast transform is never written (identity), the PoseStamped is the laser pose; with odom -> base_footprint -> laser heard
+    -> map -> odom = laser pose * T(laser <- base_footprint) * T(base_footprint <- odom), against a numpy product."""
+    gc, geo, scene = synth.CONFIGS["cfg1"]
+    world = synth.World(scene, gc)
+    scans = synth.scans_for(world, geo, synth.trajectory(world, 6))
+    node = facade.SlamNode(facade.node_params(gc, geo), synchronous=True, fused=fused)
+    for k in range(3):
+        node.laser(scans[k], geo.angle_min, geo.angle_increment)
+    tf = node.tf_msg()
+    assert (tf["frame_id"], tf["child_frame_id"]) == ("map", "odom") and tf["count"] == 2
+    assert np.array_equal(tf["translation"], [0, 0, 0]) and np.array_equal(tf["rotation_xyzw"], [0, 0, 0, 1])
+    q_ob = np.array([0.0, 0.0, math.sin(0.35), math.cos(0.35)])
+    q_bl = np.array([0.0, 0.0, math.sin(-0.05), math.cos(-0.05)])
+    node.set_transform("odom", "base_footprint", [1.25, -0.5, 0.0], q_ob)
+    node.set_transform("base_footprint", "laser", [0.3, 0.05, 0.2], q_bl)
+    for k in range(3, 6):
+        node.laser(scans[k], geo.angle_min, geo.angle_increment)
+        tf, msg = node.tf_msg(), node.pose_msg()
+        laser = _hom(msg["position"], msg["orientation_xyzw"])
+        expect = laser @ np.linalg.inv(_hom([0.3, 0.05, 0.2], q_bl)) @ np.linalg.inv(_hom([1.25, -0.5, 0.0], q_ob))
+        assert np.max(np.abs(_hom(tf["translation"], tf["rotation_xyzw"]) - expect)) <= 1e-12, f"scan {k}"
+    assert tf["count"] == 5
+    node.close()
+
+
 @pytest.mark.parametrize("fused", [True, False])
 def test_facade_threads_contract(oracle, fused):
     gc, geo, scene = synth.CONFIGS["cfg1"]
