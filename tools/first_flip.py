@@ -15,7 +15,12 @@ statistics.  At the first scan + iteration that differs it
   (2) rebuilds that iteration's pair chain in numpy on both sides' inputs (OutOfBoundsFilter2D.cpp:27-37, exact 1-NN,
       DistanceFilter.cpp:32-64, ReciprocalFilter.cpp:32-78), lists the scene points whose fate differs and prints
       the deciding quantity on both sides with its margin.
-usage: python tools/first_flip.py [n_scans=340] [cfg=cfg2] [out=gpurun_out/first_flip.txt]"""
+usage: python tools/first_flip.py [n_scans=340] [cfg=cfg2] [out=gpurun_out/first_flip.txt] [--oracle-f64-angles]
+
+--oracle-f64-angles gives the ORACLE loop the scanner's float64 angle_min / angle_increment instead of the float32 values a
+sensor_msgs/LaserScan carries (what round 4's tools/long_run_check.py did by mistake: the two loops then process scanners that
+differ by 1.5e-9 rad per beam, drift apart at the 1e-8 level and do flip): it exercises the analysis below and shows what the
+1e-2 m "divergence" of profiles/r4_soak_checks.txt was."""
 import math, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -23,9 +28,11 @@ from ohm_tsd_slam_amd import capi, facade, synth
 from oracle import pyoracle as O
 from tests.slam_driver import PrimitiveLoop as Loop, slam_kwargs
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 340
-cfg = sys.argv[2] if len(sys.argv) > 2 else "cfg2"
-out_path = sys.argv[3] if len(sys.argv) > 3 else "gpurun_out/first_flip.txt"
+argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+F64_ANGLES = "--oracle-f64-angles" in sys.argv
+n = int(argv[0]) if len(argv) > 0 else 340
+cfg = argv[1] if len(argv) > 1 else "cfg2"
+out_path = argv[2] if len(argv) > 2 else "gpurun_out/first_flip.txt"
 THREADS = max(1, min(64, os.cpu_count() or 1))
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 lines = []
@@ -155,10 +162,13 @@ geo_msg = synth.ScanGeometry(geo.beams, float(np.float32(geo.angle_min)), float(
 kw = slam_kwargs(gc, geo_msg)
 og = O.Grid(gc.map_size_log2, gc.cell_size, gc.max_trunc)
 dg = capi.TsdGridDevice(gc.map_size_log2, gc.cell_size, gc.max_trunc)
-lo, lh = Loop(O, kw, og, False, THREADS), Loop(O, kw, dg, True)
+kw_o = slam_kwargs(gc, geo) if F64_ANGLES else kw
+lo, lh = Loop(O, kw_o, og, False, THREADS), Loop(O, kw, dg, True)
 assert lo.bounds == lh.bounds
 node = facade.SlamNode(facade.node_params(gc, geo), device=0, synchronous=True)
 say("# tools/first_flip.py %d %s: free-running oracle loop, HIP loop (unfused C ABI) and fused facade on the same scans" % (n, cfg))
+if F64_ANGLES:
+    say("# --oracle-f64-angles: the oracle loop's scanner has the float64 angles, the HIP loop's the message's float32 ones (round 4's tool error, on purpose)")
 flip = None
 worst_before = 0.0
 worst_facade = 0.0
