@@ -408,6 +408,10 @@ int tsd_sensor_set_async_mapping(tsd_sensor* s, int on);
  * it), 0 = off.  Lets a test make the push stream lag behind the registrations the way a busy device can
  * (tests/test_gpu_async_mapping.py: the scan / table buffers of a lagging push must not be re-staged under it). */
 int tsd_debug_stall_push_stream(tsd_ctx* ctx, unsigned int microseconds);
+/* TEST HOOK: on = 0 makes every registration of this context search for itself in its first step instead of taking that step's
+ * nearest neighbours from the helper workgroups the launch brings by default (icp_kernels.hip: IcpSeed).  The results are the same
+ * either way, bit for bit (tests/test_gpu_parity.py::test_icp_helpers_change_nothing); only the time differs. */
+int tsd_debug_set_icp_helpers(tsd_ctx* ctx, int on);
 
 /* the pre-registration's outcome for the scan collected last (TBest, probability, winning pair, counts) */
 int tsd_scan_preregistration_result(tsd_sensor* s, tsd_tsdpdf_result* result);

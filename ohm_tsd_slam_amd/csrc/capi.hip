@@ -399,7 +399,10 @@ tsd_ctx* tsd_create(int device, int map_size_log2, double cell_size, double max_
   A(hipMalloc(&ctx->d_morig, TSD_MAX_ICP_POINTS * sizeof(int)));
   A(hipMalloc(&ctx->d_start, TSD_MAX_ICP_POINTS * sizeof(int)));
   if (const char* e = std::getenv("TSD_ICP_SHAPE")) ctx->icp_shape = std::atoi(e);
+  if (const char* e = std::getenv("TSD_ICP_HELPERS")) ctx->icp_helpers = std::atoi(e) != 0;
   A(hipMalloc(&ctx->d_icp_res, sizeof(IcpResultDev)));
+  A(hipMalloc(&ctx->d_icp_seed, icp_seed_bytes(TSD_MAX_ICP_POINTS)));
+  if (ok) A(hipMemsetAsync(ctx->d_icp_seed, 0, icp_seed_bytes(TSD_MAX_ICP_POINTS), ctx->stream));
   A(hipMalloc(&ctx->d_icp_trace, sizeof(double) * TSD_ICP_TRACE_STRIDE * TSD_ICP_TRACE_MAX * 2));     // (second half: scratch of the diagnostic stamp builds)
   // (never the NULL stream: HIP maps streams onto a few hardware queues in the order they are first used, and a null stream that
   // comes alive here takes one of them -- the two batch slots of the multi-robot path then share a queue and their registrations
@@ -469,7 +472,7 @@ void tsd_destroy(tsd_ctx* ctx)
   }
   hipFree(ctx->d_ranges); hipFree(ctx->d_mask); hipFree(ctx->d_rays); hipFree(ctx->d_rays_local);
   hipFree(ctx->d_coords); /* (+ d_normals, d_mask_m: one block) */ hipFree(ctx->d_mnormals); hipFree(ctx->d_model);
-  hipFree(ctx->d_scene); hipFree(ctx->d_morig); hipFree(ctx->d_start); hipFree(ctx->d_icp_res); hipFree(ctx->d_icp_trace); hipHostFree(ctx->h_icp_res); hipHostFree(ctx->h_out);
+  hipFree(ctx->d_scene); hipFree(ctx->d_morig); hipFree(ctx->d_start); hipFree(ctx->d_icp_res); hipFree(ctx->d_icp_seed); hipFree(ctx->d_icp_trace); hipHostFree(ctx->h_icp_res); hipHostFree(ctx->h_out);
   hipFree(ctx->d_occ); hipFree(ctx->d_occ_count); hipFree(ctx->d_occ_heads); hipFree(ctx->d_occ_list);
   if (ctx->d_occ_out) hipFree(ctx->d_occ_out);
   if (ctx->stream_io) { hipStreamSynchronize(ctx->stream_io); hipStreamDestroy(ctx->stream_io); }
@@ -1315,7 +1318,7 @@ void tsd_sensor_destroy(tsd_sensor* s)
   if (s->stream) hipStreamSynchronize(s->stream);
   for (hipEvent_t e : {s->ev_rc_done, s->ev_icp_done}) if (e) hipEventDestroy(e);
   if (s->stream) hipStreamDestroy(s->stream);
-  hipFree(s->d_coords); hipFree(s->d_normals); hipFree(s->d_mask_m); hipFree(s->d_icp_res); hipFree(s->d_icp_trace);
+  hipFree(s->d_coords); hipFree(s->d_normals); hipFree(s->d_mask_m); hipFree(s->d_icp_res); hipFree(s->d_icp_seed); hipFree(s->d_icp_trace);
   if (s->ev_pre) hipEventDestroy(s->ev_pre);
   if (s->ev_pre_done) hipEventDestroy(s->ev_pre_done);
   if (s->d_push_slot) { if (s->ctx && s->ctx->stream_push) hipStreamSynchronize(s->ctx->stream_push); hipFree(s->d_push_slot); }
@@ -1461,6 +1464,13 @@ int tsd_debug_stall_push_stream(tsd_ctx* ctx, unsigned int microseconds)
 {
   if (!ctx) return TSD_E_ARG;
   ctx->debug_push_stall_us = microseconds;
+  return TSD_OK;
+}
+
+int tsd_debug_set_icp_helpers(tsd_ctx* ctx, int on)
+{
+  if (!ctx) return TSD_E_ARG;
+  ctx->icp_helpers = on ? 1 : 0;
   return TSD_OK;
 }
 
@@ -1701,6 +1711,8 @@ static int sensor_conc_init(tsd_sensor* s, bool own_stream)
   const size_t nb = (size_t)s->beams;
   A(hipMalloc(&s->d_coords, nb * 16)); A(hipMalloc(&s->d_normals, nb * 16)); A(hipMalloc(&s->d_mask_m, nb));
   A(hipMalloc(&s->d_icp_res, sizeof(IcpResultDev))); A(hipMalloc(&s->d_icp_trace, sizeof(double) * TSD_ICP_TRACE_STRIDE * TSD_ICP_TRACE_MAX));
+  A(hipMalloc(&s->d_icp_seed, icp_seed_bytes(s->beams)));
+  if (ok) A(hipMemset(s->d_icp_seed, 0, icp_seed_bytes(s->beams)));
   for (int i = 0; i < 3; i++) A(hipMalloc(&s->d_rmq2[i], push_rmq_bytes(s->beams)));
   A(hipHostMalloc(&s->h_stage2[0], nb * 10 + 64, hipHostMallocDefault)); A(hipHostMalloc(&s->h_stage2[1], nb * 10 + 64, hipHostMallocDefault));
   if (!ok) return set_error(ctx, TSD_E_HIP, "tsd_scan_begin: per-sensor streams / buffers", hipGetLastError());
@@ -1739,7 +1751,7 @@ int tsd_scan_begin(tsd_sensor* s, const double* ranges, const uint8_t* mask, con
   s->rmq_slot ^= 1;                         // (the previous push of this sensor may still read its tables)
   LaunchTarget tg;
   tg.stream = s->stream; tg.coords = s->d_coords; tg.normals = s->d_normals; tg.mask_m = s->d_mask_m;
-  tg.icp_res = s->d_icp_res; tg.trace = s->d_icp_trace; tg.rmq = s->d_rmq2[s->rmq_slot];
+  tg.icp_res = s->d_icp_res; tg.trace = s->d_icp_trace; tg.icp_seed = s->d_icp_seed; tg.rmq = s->d_rmq2[s->rmq_slot];
   TargetScope scope(ctx, &tg);
   rc = launch_push_tables(ctx, s->stream, s->beams, d_ranges, d_mask_push, s->phi_min, s->ang_res);
   if (rc != TSD_OK) return rc;
@@ -2031,6 +2043,7 @@ int tsd_batch_begin(tsd_batch* b, int n, tsd_sensor* const* sensors, const doubl
     e.post.gmin_x = ctx->grid.min_x; e.post.gmax_x = ctx->grid.max_x; e.post.gmin_y = ctx->grid.min_y; e.post.gmax_y = ctx->grid.max_y;
     e.post.gates = GateArgs{gates[i].reg_trs_max, gates[i].reg_sin_rot_max, gates[i].trs_min, gates[i].rot_min};
   }
+  for (int i = 0; i < n; i++) h_icp[i].seed = icp_batch_seed_args(ctx, sensors[i]->d_icp_seed, sensors[i]->beams, max_beams);
   // the registrations go out AHEAD of the ray casts and wait for the slot's flag on the device (where the probe allowed it).
   // A batch that carries a pre-registration (registration_mode 3) orders its registrations behind the grid stream's work by an
   // event instead: the pre-registration kernels sit between the ray casts and the registrations, on the grid's stream -- the scoring

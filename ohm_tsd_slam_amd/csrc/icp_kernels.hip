@@ -33,6 +33,7 @@
 //
 // No dense contraction anywhere => no MFMA; fp64 VALU + LDS.  Latency-bound: reported as ms/iterate.
 #include "scan_device.hpp"
+#include <atomic>
 #include <climits>
 #include <cstring>
 
@@ -40,58 +41,24 @@ namespace tsd {
 
 constexpr int ICP_MAXW = 16;                    // waves per workgroup at most
 constexpr double SLACK = 1.0 - 1e-9;            // conservative factor on every pruning bound
-#ifndef TSD_ICP_HW
-#define TSD_ICP_HW 6
-#endif
-constexpr int HW = TSD_ICP_HW;                  // tier-1 window: k-HW .. k+HW
-constexpr int ICP_RL = 2;                       // register slots every wave fills before the lone waves take more
+constexpr int HW = 6;                           // tier-1 window: k-HW .. k+HW (3 / 4 / 8 measured slower)
 constexpr int ICP_PAD = 96;                     // wrapped copies of the model at both ends of its LDS array
-#ifndef TSD_ICP_REFRESH_A
-#define TSD_ICP_REFRESH_A 6
-#define TSD_ICP_REFRESH_B 15
-#endif
-constexpr unsigned REFRESH_A = TSD_ICP_REFRESH_A, REFRESH_B = TSD_ICP_REFRESH_B;   // steps with a scheduled bound renewal
-#ifndef TSD_ICP_WEAK_MULT
-#define TSD_ICP_WEAK_MULT 36.0
-#endif
-constexpr double WEAK_MULT = TSD_ICP_WEAK_MULT;        // a scheduled renewal takes the bounds with less than sqrt(this) x slack in distance
-constexpr int IR_CNT = 32, IR_RMAX = 33, IR_CNT2 = 34, IR_TIE = 35;   // words of IcpLds::ired
-// -DTSD_ICP_ABLATE=<bits>: timing experiments that switch parts of a step off (the RESULTS are wrong; tools/icp_ablate.sh):
-//   1 no searches (a point that fails tier 0 is dropped)   2 no in-place window searches (everything through the work list)
-//   4 no closed form (identity step)   8 no cross-wave reduction (a thread's own sums stand in for the totals)
-//   16 no reciprocal filter (every kept pair wins)   32 no tier-0 runner-up
-#ifndef TSD_ICP_ABLATE
-#define TSD_ICP_ABLATE 0
-#endif
-constexpr int ABL = TSD_ICP_ABLATE;
-// -DTSD_ICP_OPT=<bits>: round-4 restructurings of the steady-state step, each one switchable for same-call A/Bs (tools/icp_ab.sh,
-// tools/icp_timeline.sh); the default is all of them.  Results are identical bit for bit unless noted.
-//   1  tier 0's per-point flags as three compares (the "known" / "pre" cases folded into the operands)
-//   2  the reciprocal filter's returning atomics issued together, one wait
-//   4  work-list counter, tie flag and slot minima read together behind barrier 1 (one LDS round trip instead of three)
-//   8  closed form: seven pair sums + the pair count reduced inside a wave in registers (DPP halving + gfx950's permlane swaps) instead
-//      of nine through an LDS transpose  [summation order changes: the totals' last bits]
-//   16 loop control on wave-uniform scalars (readfirstlane): scalar branches instead of exec-mask loops
-//   64 tier 0 trimmed: exact ties looked at once per wave (not a branch per point), the bound renewals' flags formed in the two steps
-//      that renew (not a branch per point and step), max(lb, 0) as one instruction
-//   32 scene points go to the waves that have a SIMD's issue priority first: waves 0-3 of a workgroup are the older wave of their SIMD
-//      and issue at full rate, waves 4+ only get the slots the older wave leaves (tools/exp/valu.hip: 4.9 against 8.9 cycles per fp64
-//      instruction) -- so waves 0-3 take three 64-point blocks each and waves 4-7 share what is left, one block each where possible,
-//      and the launch brings as many of them as there are blocks left  [which wave sums which pairs changes: rounding of the totals]
-#ifndef TSD_ICP_OPT
-#define TSD_ICP_OPT 127
-#endif
-constexpr int OPT = TSD_ICP_OPT;
-// -DTSD_ICP_DUP=<bits>: timing experiments that run a part of every step TWICE with the same outcome (results unchanged), so the
-// time difference is that part's cost in place:  1 cross-wave reduction   2 closed form   4 transform + bound update (second
-// time on copies)   8 an extra workgroup barrier
-#ifndef TSD_ICP_DUP
-#define TSD_ICP_DUP 0
-#endif
-constexpr int DUP = TSD_ICP_DUP;
-#ifdef TSD_ICP_STAMPS
-constexpr int IR_DBG = 40;
-#endif
+constexpr unsigned REFRESH_A = 6, REFRESH_B = 15;      // steps with a scheduled bound renewal
+constexpr double WEAK_MULT = 36.0;                     // a scheduled renewal takes the bounds with less than sqrt(this) x slack in distance
+constexpr int IR_CNT = 32, IR_RMAX = 33, IR_CNT2 = 34, IR_TIE = 35, IR_SEEDED = 36;   // words of IcpLds::ired
+// Step 0 of a registration is the one step in which EVERY scene point searches (no neighbour is known yet): ~20 000 cycles on the one
+// compute unit that runs the registration.  That search does not depend on anything the loop produces, so it is shared out: the launch
+// brings `helpers` more workgroups, each of which runs the same set-up (model, unit directions, padding in ITS OWN LDS), does the
+// tier-1 window search of step 0 for blockDim.x of the scene points -- the same function on the same inputs as the registration's own
+// list pass would run -- and leaves the results here, in global memory, behind a flag.  The registering workgroup finishes its own
+// set-up meanwhile, takes the results as the outcome of step 0's searches (bit for bit what it would have found itself) and starts
+// with a steady-state step.  Points the window cannot prove come back unresolved and go through the whole-wave search as before.
+// The wait for the helpers is bounded: helpers that did not get a compute unit in time (a push on another stream filling the device)
+// are not waited for -- the registration then searches itself; the results are the same either way, only the time differs.
+struct IcpSeed { double d, lb; int k, k2; };        // squared distance to the neighbour, bound, neighbour slot (-1: unresolved), runner-up
+constexpr int ICP_SEED_FLAGS = 16;                  // one word per helper workgroup: the sequence number of the launch whose seeds are complete
+constexpr int ICP_MAX_HELPERS = ICP_SEED_FLAGS;
+constexpr long long ICP_SEED_WAIT_TICKS = 1000;     // of the 100 MHz wall clock: 10 us
 
 // what the kernel needs again only after the last step (and the trace pointer, once per step by one
 // thread): parked in LDS so that it does not sit in scalar registers through the loop
@@ -253,19 +220,9 @@ __device__ __forceinline__ double sep_bound(double x, double y, double rs2, doub
 // agree; the two nearest are therefore re-evaluated exactly at the end (ties: lower original index) and
 // a third candidate in the same 256-ulp bucket sends the point to the exact whole-wave search.
 constexpr int WIN = 2 * HW + 1;
-#ifndef TSD_ICP_WIN_ROUNDS
-#define TSD_ICP_WIN_ROUNDS 6
-#endif
-constexpr int WIN_ROUNDS = TSD_ICP_WIN_ROUNDS;
-#ifndef TSD_ICP_WIN_REACH
-#define TSD_ICP_WIN_REACH 0.03
-#endif
-constexpr double WIN_REACH = TSD_ICP_WIN_REACH;  // sin^2 of ~10 degrees: about the widest arc the window grows to at 0.25 degree per slot
-constexpr int LIST_PAST_WINDOW = 1 << 30;         // work-list entry: the tier-1 window was already tried (in place)
-#ifndef TSD_ICP_INLINE_MAX
-#define TSD_ICP_INLINE_MAX 0
-#endif
-constexpr int INLINE_MAX = TSD_ICP_INLINE_MAX;  // points a wave resolves on the spot instead of listing them
+constexpr int WIN_ROUNDS = 6;
+constexpr double WIN_REACH = 0.03;               // sin^2 of ~10 degrees: about the widest arc the window grows to at 0.25 degree per slot
+constexpr int LIST_PAST_WINDOW = 1 << 30;         // work-list entry: the tier-1 window was already tried
 static_assert(ICP_PAD >= HW + WIN_ROUNDS * WIN, "padding must cover the widest window");
 __device__ __forceinline__ int wrap_slot(int k, int nM)
 {
@@ -395,17 +352,11 @@ __device__ __forceinline__ NnResult wave_search(const IcpLds& L, int nM, double 
   // hold yet).  One step of the walk below costs ~700 instructions (three ranked wave minima) and such a point
   // needs several, while sweeping ALL slots costs ~400: sweep first, walk only if the sweep cannot rank.
   if (nM <= (1 << 11)) {
-#ifdef TSD_ICP_STAMPS
-    if (lane == 0) atomicAdd(&L.ired[IR_DBG + 4], 1);
-#endif
     NnResult r;
     if (sweep_all(L, nM, x, y, lane, r)) return r;
     // (three candidates in one 2048-ulp bucket, or a non-finite point: the exact walk sorts it out)
   }
   for (;;) {
-#ifdef TSD_ICP_STAMPS
-    if (lane == 0) atomicAdd(&L.ired[IR_DBG + 3], 1);
-#endif
     const int o = w0 + lane;
     const bool act = lane < cnt;
     int k = start + o;
@@ -521,7 +472,7 @@ __device__ __forceinline__ void block_totals(const IcpLds& L, const double (&v)[
   cnt_total = (int)bc[NSUM];
 }
 
-// The same for EIGHT values per thread without the LDS transpose (round 4; OPT 8): the transpose costs every wave 9 LDS writes and 16
+// The same for EIGHT values per thread without the LDS transpose: the transpose costs every wave 9 LDS writes and 16
 // reads per lane and step, all waves at the same moment -- 1 150 cycles of the 8 600-cycle step, more with more waves
 // (profiles/r4_icp_critical_path.txt).  Here a wave reduces in registers by halving: lane pairs exchange HALF of their values (the even
 // lane keeps and completes values 0-3, the odd lane 4-7; DPP quad permutes), quads half of those, so that after two steps lane j of every quad holds the
@@ -610,6 +561,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
       const uint8_t* __restrict__ g_mask, IcpResultDev* __restrict__ out,
       double* __restrict__ trace /* [TSD_ICP_TRACE_MAX][TSD_ICP_TRACE_STRIDE] = pairs, rms, thr_before, state, Tlast (co, si, dX, dY) */, const ScanPostArgs& post,
       const double* __restrict__ g_mnormals /* direct mode */, const double* __restrict__ g_normals /* fused: ray cast */,
+      const IcpSeedArgs seed = IcpSeedArgs{nullptr, nullptr, 0u, 0}, const int role = 0 /* 0: the registration; h > 0: helper h of step 0's searches */,
       int* __restrict__ pairs_out = nullptr /* PAIRS: [steps][cap] winning scene index per model slot, preset to -1 */)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -653,21 +605,6 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int T = blockDim.x, W = T >> 6;
   int nM = 0, nS = 0;
-#ifdef TSD_ICP_STAMPS   // diagnostic build: cycles per phase (thread 0), written behind the trace records
-  long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  long long st_t = clock64();
-#define STAMP(i) do { const long long now_ = clock64(); st_acc[i] += now_ - st_t; st_t = now_; } while (0)
-#else
-#define STAMP(i) do {} while (0)
-#endif
-#ifdef TSD_ICP_STAMPS_SETUP   // diagnostic: the setup phase split up instead of the loop phases
-#undef STAMP
-#define STAMP(i) do {} while (0)
-#define SSTAMP(i) do { const long long now_ = clock64(); st_acc[i] += now_ - st_t; st_t = now_; } while (0)
-#else
-#define SSTAMP(i) do {} while (0)
-#endif
-
 #ifdef TSD_ICP_TIMELINE
   // diagnostic build (tools/icp_timeline.sh): lane 0 of EVERY wave stamps the shader clock at 14 points of four steady-state steps
   // (TL_FIRST ..), so that each wave's own chain and the waits at the two barriers can be read off: profiles/r4_icp_critical_path.txt.
@@ -683,7 +620,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
   // fused scan: the sensor state the epilogue needs (pose, _lastPose) is requested NOW, ahead of the inputs, and parked in LDS once
   // it is there -- its memory round trip rides along with the inputs' instead of opening the epilogue
   ScanPostPre pre_regs;
-  if (tid == 0 && post.st) scan_post_preload(post, &pre_regs);
+  if (tid == 0 && post.st && role == 0) scan_post_preload(post, &pre_regs);
 
   // ---------------------------------------------------------------- inputs
   if (a.beams > 0) {
@@ -706,7 +643,6 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
       fm[q] = (b < a.beams) && mm != 0;
       fs[q] = (b < a.beams) && !isinf(rr[q]) && ms != 0;
     }
-    SSTAMP(0);
     int* cnts = reinterpret_cast<int*>(L.red);           // [R][W][2] (the reduction rows are idle during setup)
     unsigned long long bm[R], bs[R];
 #pragma unroll
@@ -715,7 +651,6 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
       if (lane == 0) { cnts[(q * W + wave) * 2] = __popcll(bm[q]); cnts[(q * W + wave) * 2 + 1] = __popcll(bs[q]); }
     }
     __syncthreads();
-    SSTAMP(1);
     const unsigned long long lt = (1ull << lane) - 1ull;
     int runM = 0, runS = 0;
 #pragma unroll
@@ -742,7 +677,6 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     nM = runM; nS = runS;
     if (a.beams > R * T) nM = cap + 1;                   // (not reachable through launch_icp)
     __syncthreads();
-    SSTAMP(2);
   } else {
     nM = a.n_model; nS = a.n_scene;
     if (nM <= cap && nS <= cap) {
@@ -771,6 +705,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
   int pairs = 0, state = TSD_ICP_PROCESSING;
   unsigned int iter = 0;
 
+  if (role > 0 && (nM == 0 || nS == 0 || nM > cap || nS > cap)) return;      // (nothing to search; the registration does not wait)
   if (nM == 0 || nS == 0 || nM > cap || nS > cap) {
     // Icp::iterate early-out (Icp.cpp:467-471); ThreadLocalize never gets here with nM == 0
     IcpResultDev r;
@@ -788,30 +723,15 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
   int hint[R], hint2[R];
   bool have[R];
   float rmaxf = 0.f;
-  // Scene points -> register slots.  Waves i and i + 4 of a workgroup share a SIMD (tools/exp/hwid.hip), so with
-  // a wave count that is no multiple of four some waves have a SIMD to themselves: they take the slots beyond
-  // the first ICP_RL of every wave, which evens out the instruction issue per SIMD.  blk = 64-point group.
+  // Scene points -> register slots (blk = 64-point group).  Waves i and i + 4 of a workgroup share a SIMD (tools/exp/hwid.hip).
   int pid[R];
-  if constexpr ((OPT & 32) != 0) {
+  {
+    // waves 0-3 are the older wave of their SIMD and issue at full rate, waves 4+ get the slots the older wave leaves (tools/exp/valu.hip:
+    // 4.9 against 8.9 cycles per fp64 instruction): waves 0-3 take R 64-point blocks each, waves 4+ share what is left, one block each
     const int nOld = W < 4 ? W : 4, nYoung = W - nOld;
 #pragma unroll
     for (int q = 0; q < R; q++) {
       const int blk = wave < 4 ? q * nOld + wave : nOld * R + q * nYoung + (wave - 4);
-      pid[q] = blk * 64 + lane;
-    }
-  } else {
-    const int rr = W & 3;
-    const bool asym = R >= 5 && W > 4 && rr != 0;        // (needs the register slots: experimental shape 7 only)
-    int nH = 0, hrank = 0;
-    for (int w = 0; w < W; w++) {
-      const bool hv = !asym || (w & 3) >= rr;
-      if (hv && w < wave) hrank++;
-      if (hv) nH++;
-    }
-    const bool heavy = !asym || (wave & 3) >= rr;
-#pragma unroll
-    for (int q = 0; q < R; q++) {
-      const int blk = q < ICP_RL ? q * W + wave : (heavy ? ICP_RL * W + (q - ICP_RL) * nH + hrank : (1 << 20));
       pid[q] = blk * 64 + lane;
     }
   }
@@ -831,7 +751,6 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
       hint2[q] = hint[q];
     }
   }
-  SSTAMP(3);
   for (int k = tid; k < nM; k += T) {
     const double2 m = L.mxy[k];
     const double r2 = m.x * m.x + m.y * m.y;
@@ -843,19 +762,32 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     L.mxy[nM + i] = L.mxy[i % nM];
     L.mxy[-1 - i] = L.mxy[nM - 1 - (i % nM)];
   }
+  if (role > 0) {
+    // helper: step 0's window search for scene points (role - 1) * T + tid, from the staged scene (the registration's own list pass
+    // reads the same coordinates and the same hint from its registers)
+    __syncthreads();                   // unit directions and padding in place
+    const int i = (role - 1) * T + tid;
+    if (i < nS) {
+      const double2 s = L.stage_s[i];
+      int h = L.start[i];
+      h = h < 0 ? 0 : (h >= nM ? nM - 1 : h);
+      const NnResult r = window_search(L, nM, s.x, s.y, h, a.thr0, a.ccw ? 1.0 : -1.0);
+      IcpSeed sd;
+      sd.d = r.best; sd.lb = lb_from_sq(r.lbsq); sd.k = r.resolved ? r.bk : -1; sd.k2 = r.bk2;
+      seed.seeds[i] = sd;
+    }
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(seed.flags + (role - 1), seed.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
   const int slot_halves = icp_slot_halves(cap, T, PTL);
   for (int k = tid; k < cap; k += T) { L.slotD[k] = ~0ull; if (slot_halves == 2) L.slotD[cap + k] = ~0ull; L.slotI[k] = INT_MAX; }
-  if constexpr ((OPT & 8) != 0) { for (int k = tid; k < ICP_MAXW * 16; k += T) L.red[k] = 0.0; }    // (block_totals8 reads the rows of absent waves)
-#ifdef TSD_ICP_STAMPS
-  if (tid == 0) for (int i = 0; i < 8; i++) L.ired[IR_DBG + i] = 0;
-#endif
-  SSTAMP(4);
+  for (int k = tid; k < ICP_MAXW * 16; k += T) L.red[k] = 0.0;    // (block_totals8 reads the rows of absent waves)
   __syncthreads();                     // staging consumed (it aliases the work list); counters zeroed
   if (rmaxf > 0.f) atomicMax(&L.ired[IR_RMAX], __float_as_int(rmaxf));   // positive floats order like ints
   __syncthreads();
   const double scene_rmax = (double)__int_as_float(L.ired[IR_RMAX]);
-  STAMP(6);
-  SSTAMP(5);
 
   // ---------------------------------------------------------------- iterate
   // loop-invariant scalars: vector registers (the scalar file is the scarce one in this kernel)
@@ -884,6 +816,23 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
   int Rn = 0;                                // register slots of this wave that hold scene points (wave-uniform)
   for (int q = 0; q < R; q++) Rn += (pid[q] - lane < nS) ? 1 : 0;
 
+  // step 0's searches, done by the helper workgroups while this one set itself up (IcpSeed): wait for them -- a bounded wait
+  bool seeded = false;
+  if (!PAIRS && seed.helpers > 0) {
+    if (wave == 0) {
+      const long long t0 = wall_clock64();
+      bool ok;
+      for (;;) {
+        ok = lane >= seed.helpers || __hip_atomic_load(seed.flags + (lane < seed.helpers ? lane : 0), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == seed.seq;
+        if (__all(ok) || wall_clock64() - t0 > ICP_SEED_WAIT_TICKS) break;
+        __builtin_amdgcn_s_sleep(4);
+      }
+      if (lane == 0) L.ired[IR_SEEDED] = __all(ok) ? 1 : 0;
+    }
+    __syncthreads();
+    seeded = __builtin_amdgcn_readfirstlane(L.ired[IR_SEEDED]) != 0;
+  }
+
   while (state == TSD_ICP_PROCESSING) {
     const double thr_before = thr;
     TL(0);
@@ -896,21 +845,41 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     // -- phase A: pre-filter + exact NN + distance filter (per scene point)
     // OutOfBoundsFilter2D: when even a disc of the largest possible scene radius around the sensor
     // lies inside the bounds nothing can be filtered and the per-point transform is skipped.
-    bool all_in;
-    if constexpr ((OPT & 64) != 0) {
-      // (the same sufficient condition solved for the accumulated translation once, ahead of the loop: three operations per step)
-      all_in = (Tf[2] * Tf[2] + Tf[5] * Tf[5]) * (1.0 + 4e-6) < tcum_lim2;
-    } else {
-      const double tcum = (double)(__builtin_amdgcn_sqrtf((float)(Tf[2] * Tf[2] + Tf[5] * Tf[5]) * 1.000001f) * 1.000001f);
-      const double reach = (scene_rmax + tcum) * pnorm * (1.0 + 1e-6) + 1e-6;
-      all_in = (int)(P02 - reach > bmin_x) & (int)(P02 + reach < bmax_x) &
-               (int)(P12 - reach > bmin_y) & (int)(P12 + reach < bmax_y);
-    }
+    // (the sufficient condition solved for the accumulated translation once, ahead of the loop: three operations per step)
+    const bool all_in = (Tf[2] * Tf[2] + Tf[5] * Tf[5]) * (1.0 + 4e-6) < tcum_lim2;
     double bd[R]; bool keep[R], need[R];
     int ent[R];
     double2 mw[R];                            // the neighbour's coordinates
     const bool refresh = (iter == REFRESH_A) || (iter == REFRESH_B);
-    {
+    // OutOfBoundsFilter2D for one point: S.transform(P): (0 + x*R00) + y*R01, then + t (gsl/Matrix.cpp:403-432)
+    auto inside_bounds = [&](double x, double y) {
+      double wx = 0.0, wy = 0.0;
+      wx += x * P00; wx += y * P01;
+      wy += x * P10; wy += y * P11;
+      wx += P02; wy += P12;
+      return !((int)(wx < bmin_x) | (int)(wx > bmax_x) | (int)(wy < bmin_y) | (int)(wy > bmax_y));
+    };
+    const bool from_seeds = seeded && iter == 0u;          // (wave-uniform)
+    if (from_seeds) {
+      // step 0 with the helpers' results: exactly what this step's own list pass would have brought back for every point inside the
+      // bounds (neighbour, runner-up, bound, DistanceFilter); an unresolved point goes to the list for the whole-wave search
+      IcpSeed sv[R];
+#pragma unroll
+      for (int q = 0; q < R; q++) sv[q] = seed.seeds[pid[q] < nS ? pid[q] : 0];            // all reads in flight
+#pragma unroll
+      for (int q = 0; q < R; q++) {
+        bd[q] = __builtin_inf(); keep[q] = false; need[q] = false; ent[q] = -1;
+        if (q >= Rn) continue;
+        bool pre = have[q];
+        if (!all_in) pre = pre & inside_bounds(sx[q], sy[q]);
+        if (pre) {
+          if (sv[q].k >= 0) { bd[q] = sv[q].d; hint[q] = sv[q].k; hint2[q] = sv[q].k2; lb[q] = sv[q].lb; keep[q] = bd[q] <= thr; }
+          else need[q] = true;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < R; q++) mw[q] = L.mxy[hint[q]];
+    } else {
       double2 mh[R], mh2[R];
 #pragma unroll
       for (int q = 0; q < R; q++) { mh[q] = L.mxy[hint[q]]; mh2[q] = L.mxy[hint2[q]]; }   // all reads in flight
@@ -925,36 +894,24 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
         if (q >= Rn) continue;                  // (wave-uniform) no scene point in this register slot
         const double x = sx[q], y = sy[q];
         bool pre = have[q];
-        if (!all_in) {
-          // S.transform(P): (0 + x*R00) + y*R01, then + t (gsl/Matrix.cpp:403-432)
-          double wx = 0.0, wy = 0.0;
-          wx += x * P00; wx += y * P01;
-          wy += x * P10; wy += y * P11;
-          wx += P02; wy += P12;
-          pre = pre & !((int)(wx < bmin_x) | (int)(wx > bmax_x) | (int)(wy < bmin_y) | (int)(wy > bmax_y));
-        }
+        if (!all_in) pre = pre & inside_bounds(x, y);
         // the nearer of the last neighbour and its runner-up is the exact neighbour as long as it beats
         // the bound on everything else (a point hovering between two model points never searches)
         const double dx1 = x - mh[q].x, dy1 = y - mh[q].y, dx2 = x - mh2[q].x, dy2 = y - mh2[q].y;
         const double d1 = dx1 * dx1 + dy1 * dy1, d2 = dx2 * dx2 + dy2 * dy2;
-        bool swp = (ABL & 32) ? false : d2 < d1;
-        if constexpr ((OPT & 64) != 0) {
-          // (an exact tie between two different candidates -- rare -- is settled by the original model index: looked for once per wave)
-          if (__builtin_expect(__ballot((d2 == d1) & (hint2[q] != hint[q])) != 0ull, 0))
-            if (d2 == d1 && hint2[q] != hint[q]) swp = L.morig[hint2[q]] < L.morig[hint[q]];
-        } else {
-          if (d2 == d1 && hint2[q] != hint[q]) swp = L.morig[hint2[q]] < L.morig[hint[q]];   // exact tie (rare)
-        }
+        bool swp = d2 < d1;
+        // (an exact tie between two different candidates -- rare -- is settled by the original model index: looked for once per wave)
+        if (__builtin_expect(__ballot((d2 == d1) & (hint2[q] != hint[q])) != 0ull, 0))
+          if (d2 == d1 && hint2[q] != hint[q]) swp = L.morig[hint2[q]] < L.morig[hint[q]];
         const double d = swp ? d2 : d1;
         const int kn = swp ? hint2[q] : hint[q], ko = swp ? hint[q] : hint2[q];
         mw[q] = swp ? mh2[q] : mh[q];
         hint[q] = kn; hint2[q] = ko;
-        if constexpr ((OPT & 1) != 0) {
-          // The same decisions from three compares.  "known" (lb > 0) is folded into the bound (max(lb, 0)^2 = 0 makes `same` and `drop`
+        {
+          // The decisions from three compares.  "known" (lb > 0) is folded into the bound (max(lb, 0)^2 = 0 makes `same` and `drop`
           // false: the point searches), "pre" into the operands (distance and bound +inf: `drop` is true, nothing is kept or searched).
           double lbp;
-          if constexpr ((OPT & 64) != 0) asm("v_max_f64 %0, %1, 0" : "=v"(lbp) : "v"(lb[q]));      // (fmax() brings a canonicalising v_max along)
-          else lbp = fmax(lb[q], 0.0);
+          asm("v_max_f64 %0, %1, 0" : "=v"(lbp) : "v"(lb[q]));      // (fmax() brings a canonicalising v_max along)
           const double inf = __builtin_inf();
           const double lb2 = pre ? lbp * lbp : inf;
           const double de = pre ? d : inf;
@@ -964,146 +921,69 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
           bd[q] = de;
           keep[q] = same & le;
           need[q] = !(same | drop);
-          if constexpr ((OPT & 64) == 0) {
-            if (refresh) {                                         // (wave-uniform; see below)
-              const bool weak = !drop & (lb2 < WEAK_MULT * de) & (lb2 > 0.0);
-              need[q] = need[q] | weak;
-              keep[q] = keep[q] & !weak;
-            }
-          }
-          if constexpr ((ABL & 1) != 0) need[q] = false;
-        } else {
-        const double lbq = lb[q];
-        const double lb2 = lbq * lbq;
-        const bool known = lbq > 0.0;
-        const bool same = known & (d < lb2);                       // neighbour proven
-        const bool drop = known & (d > thr) & (lb2 > thr);          // no pair whoever it is
-        bd[q] = pre ? d : __builtin_inf();
-        keep[q] = pre & same & (d <= thr);
-        // Bounds only ever decay, and a point whose slack runs out costs a work-list pass however few such
-        // points there are in that step.  Two scheduled passes (steps 6 and 15) renew every bound with less than
-        // 6x slack in distance instead of a trickle of passes later.  (Round 3, tools/icp_stamps_slam.sh: with 2x
-        // slack and steps 6 / 12, 13-15 of the last 17 steps still had 1-60 searching points -- good pairs at 3 m
-        // range whose 2x slack of a few millimetres the scene's remaining motion eats; 6x at steps 6 / 15:
-        // 0.161 -> 0.157 ms per registration in the same session, a third renewal buys nothing.)
-        const bool weak = refresh & pre & known & !drop & (lb2 < WEAK_MULT * d);
-        need[q] = (pre & !same & !drop) | weak;
-        if constexpr ((ABL & 1) != 0) need[q] = false;
-        keep[q] = keep[q] & !need[q];
         }
         ent[q] = -1;
       }
-      if constexpr ((OPT & 1) != 0 && (OPT & 64) != 0 && (ABL & 1) == 0) {
-        // the two scheduled bound renewals (see `weak` below): formed here, in the two steps that renew, from what the loop above left
-        // -- bd is +inf for a point outside the bounds or an empty register slot, which makes `drop` true
-        if (refresh) {
+      // Bounds only ever decay, and a point whose slack runs out costs a work-list pass however few such points there are in that step.
+      // Two scheduled passes (steps 6 and 15) renew every bound with less than 6x slack in distance instead of a trickle of passes later
+      // (round 3, per-step search profile: with 2x slack and steps 6 / 12, 13-15 of the last 17 steps still had 1-60 searching points --
+      // good pairs at 3 m range whose slack of a few millimetres the scene's remaining motion eats; a third renewal buys nothing).
+      // Formed here, in the two steps that renew, from what the loop above left -- bd is +inf for a point outside the bounds or an empty
+      // register slot, which makes `drop` true.
+      if (refresh) {
 #pragma unroll
-          for (int q = 0; q < R; q++) {
-            if (q >= Rn) continue;
-            const double lbp = fmax(lb[q], 0.0), lb2 = bd[q] < __builtin_inf() ? lbp * lbp : __builtin_inf();
-            const bool drop = (lb2 > thr) & !(bd[q] <= thr);
-            const bool weak = !drop & (lb2 < WEAK_MULT * bd[q]) & (lb2 > 0.0);
-            need[q] = need[q] | weak;
-            keep[q] = keep[q] & !weak;
-          }
+        for (int q = 0; q < R; q++) {
+          if (q >= Rn) continue;
+          const double lbp = fmax(lb[q], 0.0), lb2 = bd[q] < __builtin_inf() ? lbp * lbp : __builtin_inf();
+          const bool drop = (lb2 > thr) & !(bd[q] <= thr);
+          const bool weak = !drop & (lb2 < WEAK_MULT * bd[q]) & (lb2 > 0.0);
+          need[q] = need[q] | weak;
+          keep[q] = keep[q] & !weak;
         }
       }
     }
     TL(2);                                     // tier 0 decided
-    bool past_window[R];                       // the window was already tried in place and could not prove the point
-#pragma unroll
-    for (int q = 0; q < R; q++) past_window[q] = false;
-    // A wave with only a few points to search resolves them on the spot (one lane-per-point window each):
-    // no list, no barrier.  The dense work list pays off when many lanes of a wave would idle otherwise.
-    {
-      int wneed = 0;
-#pragma unroll
-      for (int q = 0; q < R; q++) wneed += __popcll(__ballot(need[q]));
-      if (wneed > 0 && wneed <= ((ABL & 2) ? 0 : INLINE_MAX)) {
-        bool tolist[R];
-#pragma unroll
-        for (int q = 0; q < R; q++) tolist[q] = false;
-        for (int pass = 0; pass < R; pass++) {
-          int sel = -1;
-#pragma unroll
-          for (int q = R - 1; q >= 0; q--) if (need[q]) sel = q;
-          if (!__ballot(sel >= 0)) break;
-          double x = 0.0, y = 0.0; int hk = 0;
-#pragma unroll
-          for (int q = 0; q < R; q++) if (sel == q) { x = sx[q]; y = sy[q]; hk = hint[q]; }
-          if (sel >= 0) {
-            const NnResult r = window_search(L, nM, x, y, hk, thr, sgn);
-            const double2 mk = L.mxy[r.bk >= 0 ? r.bk : 0];
-            const double lbn = lb_from_sq(r.lbsq);
-#pragma unroll
-            for (int q = 0; q < R; q++)
-              if (sel == q) {
-                need[q] = false;
-                if (r.resolved) { bd[q] = r.best; hint[q] = r.bk; hint2[q] = r.bk2; lb[q] = lbn; mw[q] = mk; keep[q] = r.best <= thr; }
-                else tolist[q] = true;
-              }
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < R; q++) { need[q] = tolist[q]; past_window[q] = tolist[q]; }
-#ifdef TSD_ICP_STAMPS
-        if (lane == 0) atomicAdd(&L.ired[IR_DBG + 2], wneed);
-#endif
-      }
-    }
     // -- ReciprocalFilter, first half: per model slot the smallest d2 (LDS atomic min on the bit pattern).
     // Pairs settled by tier 0 go in right away; two scene points with the SAME d2 to one slot are the only
     // case that needs the index round below, and the later of the two sees its own value come back.
     bool tie = false;
-    if constexpr ((OPT & 2) != 0) {
+    {
       // (the three returning atomics leave together and are taken delivery of once: consumed inside its branch, each one was
       // waited for on the spot -- three LDS round trips in a row, 760 cycles of the step: profiles/r4_icp_critical_path.txt)
+      const int list_flag = from_seeds ? LIST_PAST_WINDOW : 0;      // (a listed point of a seeded step 0: its window was tried by a helper)
       unsigned long long mine[R], was[R];
 #pragma unroll
       for (int q = 0; q < R; q++) { mine[q] = (unsigned long long)__double_as_longlong(bd[q]); was[q] = ~0ull; }
 #pragma unroll
       for (int q = 0; q < R; q++)
-        if (keep[q] && !(ABL & 16)) was[q] = atomicMin(&slotD[hint[q]], mine[q]);
+        if (keep[q]) was[q] = atomicMin(&slotD[hint[q]], mine[q]);
+      // work list of the points that need a search (an entry beyond the list capacity waits for its pass)
 #pragma unroll
       for (int q = 0; q < R; q++)
         if (need[q]) {
           ent[q] = atomicAdd(&L.ired[IR_CNT], 1);
-          if (ent[q] < lcap) { L.list_xy[ent[q]] = make_double2(sx[q], sy[q]); L.list_k[ent[q]] = hint[q] | (past_window[q] ? LIST_PAST_WINDOW : 0); }
+          if (ent[q] < lcap) { L.list_xy[ent[q]] = make_double2(sx[q], sy[q]); L.list_k[ent[q]] = hint[q] | list_flag; }
         }
 #pragma unroll
       for (int q = 0; q < R; q++) tie |= keep[q] & (was[q] == mine[q]);
-    } else {
-#pragma unroll
-    for (int q = 0; q < R; q++) {
-      if (keep[q] && !(ABL & 16)) {
-        const unsigned long long mine = (unsigned long long)__double_as_longlong(bd[q]);
-        tie |= atomicMin(&slotD[hint[q]], mine) == mine;
-      }
-      // work list of the points that need a search (an entry beyond the list capacity waits for its pass)
-      if (need[q]) {
-        ent[q] = atomicAdd(&L.ired[IR_CNT], 1);
-        if (ent[q] < lcap) { L.list_xy[ent[q]] = make_double2(sx[q], sy[q]); L.list_k[ent[q]] = hint[q] | (past_window[q] ? LIST_PAST_WINDOW : 0); }
-      }
-    }
     }
     if (tie) L.ired[IR_TIE] = 1;
     TL(3);                                     // the reciprocal filter's atomics are back
     __syncthreads();
     TL(4);                                     // past barrier 1
-    STAMP(0);
     // One LDS round trip for everything the step needs behind barrier 1: the work-list counter, the tie flag and -- speculatively, they
     // are final only when nobody searches, which is the steady state -- the slot minima.
     unsigned long long sd[R];
     int tie_any = 0;
     int n_need;
-    if constexpr ((OPT & 4) != 0) {
+    {
       int nn = L.ired[IR_CNT];
       tie_any = L.ired[IR_TIE];
 #pragma unroll
       for (int q = 0; q < R; q++) sd[q] = slotD[hint[q]];
       asm volatile("" : "+v"(nn), "+v"(tie_any));                 // (all five reads issued before the first is waited for)
       n_need = nn;
-    } else n_need = L.ired[IR_CNT];
+    }
     if (n_need > 0) {
       tie = false;
       for (int base = 0; base < n_need; base += lcap) {       // one pass unless more than lcap points search
@@ -1113,7 +993,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
           for (int q = 0; q < R; q++)
             if (need[q] && ent[q] >= base && ent[q] < base + lcap) {
               L.list_xy[ent[q] - base] = make_double2(sx[q], sy[q]);
-              L.list_k[ent[q] - base] = hint[q] | (past_window[q] ? LIST_PAST_WINDOW : 0);
+              L.list_k[ent[q] - base] = hint[q] | (from_seeds ? LIST_PAST_WINDOW : 0);
             }
           __syncthreads();
         }
@@ -1148,12 +1028,6 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
         __syncthreads();
         TL(13);                                // (search step) the window pass is done
         const int n2 = L.ired[IR_CNT2];
-#ifdef TSD_ICP_STAMPS
-        if (tid == 0) L.ired[IR_DBG + 1] += n2;
-#endif
-#ifdef TSD_ICP_STAMPS
-        const long long t2_begin = clock64();
-#endif
         if (n2 > 0) {
           for (int i = wave; i < n2; i += W) {
             const int es = L.list2[i];
@@ -1163,9 +1037,6 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
           }
           __syncthreads();
           if (tid == 0) L.ired[IR_CNT2] = 0;
-#ifdef TSD_ICP_STAMPS
-          if (tid == 0) L.ired[IR_DBG + 5] += (int)((clock64() - t2_begin) >> 4);
-#endif
         }
         TL(14);                                // (search step) the whole-wave searches are done
 #pragma unroll
@@ -1187,33 +1058,19 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
       }
       if (tie) L.ired[IR_TIE] = 1;
       __syncthreads();
-      if constexpr ((OPT & 4) != 0) {                              // the searches' pairs went into the slots: read again
-        tie_any = L.ired[IR_TIE];
+      tie_any = L.ired[IR_TIE];                                    // the searches' pairs went into the slots: read again
 #pragma unroll
-        for (int q = 0; q < R; q++) sd[q] = slotD[hint[q]];
-      }
+      for (int q = 0; q < R; q++) sd[q] = slotD[hint[q]];
     }
-#ifdef TSD_ICP_STAMPS
-    if (tid == 0) L.ired[IR_DBG] += n_need;
-#endif
     // threshold schedule (DistanceFilter.cpp:62-63)
     thr *= thr_mult;
     if (thr < thr_min) thr = thr_min;
-    STAMP(1);
 
     // -- ReciprocalFilter, second half: the pair whose d2 stands in its slot wins
     bool win[R];
     int cnt = 0;
-    {
-      if constexpr ((OPT & 4) == 0) {
 #pragma unroll
-        for (int q = 0; q < R; q++) sd[q] = slotD[hint[q]];
-        tie_any = L.ired[IR_TIE];
-      }
-#pragma unroll
-      for (int q = 0; q < R; q++) win[q] = keep[q] & (sd[q] == (unsigned long long)__double_as_longlong(bd[q]));
-      if constexpr ((ABL & 16) != 0) { for (int q = 0; q < R; q++) win[q] = keep[q]; }
-    }
+    for (int q = 0; q < R; q++) win[q] = keep[q] & (sd[q] == (unsigned long long)__double_as_longlong(bd[q]));
     TL(5);                                     // winners known (work-list counter + slot minima read)
     if (tie_any) {
       // equal d2 somewhere: the lowest scene index of the candidates wins its slot
@@ -1238,7 +1095,6 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
       for (int q = 0; q < R; q++)
         if (win[q]) pairs_out[(size_t)iter * (size_t)cap + (size_t)hint[q]] = pid[q];
     }
-    STAMP(2);
 
     // -- phase D/F: ClosedFormEstimator2D::setPairs + estimateTransformation in ONE pass over the pairs.
     // The reference centres the pairs on their centroids (two passes).  Centring on the previous
@@ -1246,7 +1102,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     // is the same quantity with the same conditioning (c0 is within millimetres of c); the very first
     // step has no c0 and runs the pass twice, i.e. the reference's two passes.
     constexpr bool ptl = PTL;                           // PointToLine2DEstimator instead of ClosedFormEstimator2D
-    constexpr bool RED8 = !PTL && (OPT & 8) != 0;       // closed form: seven sums + the pair count, reduced in registers (block_totals8)
+    constexpr bool RED8 = !PTL;                         // closed form: seven sums + the pair count, reduced in registers (block_totals8)
     constexpr int NSUM = PTL ? NSUM_PTL : (RED8 ? 8 : NSUM_CF);
     double tot[NSUM];
     for (int pass = ((iter == 0 && !ptl) ? 0 : 1); pass < 2; pass++) {
@@ -1266,18 +1122,6 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
             const double xF = m.x - c0[0], yF = m.y - c0[1], xS = sx[q] - c0[2], yS = sy[q] - c0[3];
             v[5] += yF * xS - xF * yS; v[6] += xF * xS + yF * yS;
             v[7] += 1.0;
-          }
-        }
-      } else if constexpr (!PTL) {
-#pragma unroll
-        for (int q = 0; q < R; q++) {
-          if (win[q]) {
-            const double2 m = mw[q];
-            v[0] += m.x; v[1] += m.y; v[2] += sx[q]; v[3] += sy[q];
-            const double dx = sx[q] - m.x, dy = sy[q] - m.y;
-            v[4] += dx * dx + dy * dy;
-            const double xF = m.x - c0[0], yF = m.y - c0[1], xS = sx[q] - c0[2], yS = sy[q] - c0[3];
-            v[5] += yF * xS; v[6] += xF * yS; v[7] += xF * xS; v[8] += yF * yS;
           }
         }
       } else {
@@ -1300,25 +1144,14 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
           }
         }
       }
-      STAMP(3);
       TL(6);                                   // this thread's pair sums
 #ifdef TSD_ICP_TIMELINE
       long long* const tl_row = (iter >= (unsigned)TL_FIRST && iter < (unsigned)(TL_FIRST + TL_STEPS)) ? tlbuf + ((iter - TL_FIRST) * W + wave) * TL_N : nullptr;
 #else
       long long* const tl_row = nullptr;
 #endif
-      if constexpr ((ABL & 8) != 0) { for (int k = 0; k < NSUM; k++) tot[k] = v[k] * 300.0; pairs = 300; }
-      else if constexpr (RED8) { block_totals8<MAXT / 64>(L, v, tot, lane, wave, tl_row); pairs = (int)tot[7]; }
+      if constexpr (RED8) { block_totals8<MAXT / 64>(L, v, tot, lane, wave, tl_row); pairs = (int)tot[7]; }
       else block_totals<MAXT / 64, NSUM>(L, v, cnt, tot, pairs, tid, lane, wave, W, tl_row);
-      if constexpr ((DUP & 1) != 0 && !RED8) {
-        __syncthreads();
-        double v2[NSUM];
-#pragma unroll
-        for (int k = 0; k < NSUM; k++) v2[k] = vreg(v[k]);
-        block_totals<MAXT / 64, NSUM>(L, v2, cnt, tot, pairs, tid, lane, wave, W);
-      }
-      if constexpr ((DUP & 8) != 0) __syncthreads();
-      STAMP(4);
       TL(10);                                  // totals in registers
       if (pass == 0) {                     // first step only: centroids first, then the centred pass
         if (pairs > 0) {
@@ -1333,10 +1166,9 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     for (int q = 0; q < R; q++)
       if (keep[q]) slotD[hint[q]] = ~0ull;
     if (tid == 0) L.ired[IR_CNT] = 0;
-    STAMP(3);
 
     double co = __builtin_nan(""), si = __builtin_nan(""), dX = __builtin_nan(""), dY = __builtin_nan("");   // Tlast of this step (trace)
-    if constexpr ((OPT & 16) != 0) pairs = __builtin_amdgcn_readfirstlane(pairs);
+    pairs = __builtin_amdgcn_readfirstlane(pairs);
     if (pairs > 2) {
       if constexpr (PTL) {
         // PointToLine2DEstimator: Matrix::solve = gsl_linalg_LU_decomp + LU_solve (gsl/Matrix.cpp:343-355);
@@ -1349,18 +1181,12 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
         co = cos(xs[0]); si = sin(xs[0]); dX = xs[1]; dY = xs[2];
       } else {
         const double np = (double)pairs;
-        const double size_inv = (ABL & 4) ? 0.0033 : 1.0 / np;
+        const double size_inv = 1.0 / np;
         rms = tot[4] * size_inv;
         const double cmx = tot[0] * size_inv, cmy = tot[1] * size_inv, csx = tot[2] * size_inv, csy = tot[3] * size_inv;
         const double emx = cmx - c0[0], emy = cmy - c0[1], esx = csx - c0[2], esy = csy - c0[3];
-        double nom, den;
-        if constexpr (RED8) {
-          nom = tot[5] - np * (emy * esx - emx * esy);
-          den = tot[6] - np * (emx * esx + emy * esy);
-        } else {
-          nom = (tot[5] - np * (emy * esx)) - (tot[6] - np * (emx * esy));
-          den = (tot[7] - np * (emx * esx)) + (tot[8] - np * (emy * esy));
-        }
+        const double nom = tot[5] - np * (emy * esx - emx * esy);
+        const double den = tot[6] - np * (emx * esx + emy * esy);
         c0[0] = cmx; c0[1] = cmy; c0[2] = csx; c0[3] = csy;
         // every wave evaluates the closed form itself (wave-uniform inputs): no broadcast barrier
 #ifdef TSD_ICP_EXACT_TRIG
@@ -1370,30 +1196,13 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
         // from the reference's atan2 -> cos/sin by rounding only (DESIGN.md "ICP", tolerance 1e-4)
         {
           const double h2 = nom * nom + den * den;
-          if constexpr ((ABL & 4) != 0) { co = 1.0 - 1e-12 * h2; si = 1e-9 * h2; }
-          else if (h2 > 0.0) { const double inv = rsqrt(h2); co = den * inv; si = nom * inv; }
+          if (h2 > 0.0) { const double inv = rsqrt(h2); co = den * inv; si = nom * inv; }
           else { co = signbit(den) ? -1.0 : 1.0; si = 0.0; }
         }
 #endif
         dX = (cmx - (co * csx - si * csy));
         dY = (cmy - (co * csy + si * csx));
-        if constexpr ((DUP & 2) != 0 && !RED8) {
-          // the same closed form again, on inputs the compiler cannot recognise, chained behind the first result
-          const double z = vreg(0.0) * co;
-          const double np2 = vreg(np) + z;
-          const double sinv = 1.0 / np2;
-          const double m0 = vreg(tot[0]) * sinv, m1 = vreg(tot[1]) * sinv, m2 = vreg(tot[2]) * sinv, m3 = vreg(tot[3]) * sinv;
-          const double e0 = m0 - vreg(emx + m0 - emx - m0 + c0[0] * 0.0), e1 = m1 - vreg(0.0), e2 = m2 - vreg(0.0), e3 = m3 - vreg(0.0);
-          const double nom2 = (vreg(tot[5]) - np2 * (e1 * e2)) - (vreg(tot[6]) - np2 * (e0 * e3));
-          const double den2 = (vreg(tot[7]) - np2 * (e0 * e2)) + (vreg(tot[8]) - np2 * (e1 * e3));
-          const double h22 = nom2 * nom2 + den2 * den2;
-          double co2 = 1.0, si2 = 0.0;
-          if (h22 > 0.0) { const double inv2 = rsqrt(h22); co2 = den2 * inv2; si2 = nom2 * inv2; }
-          const double dX2 = (m0 - (co2 * m2 - si2 * m3)), dY2 = (m1 - (co2 * m3 + si2 * m2));
-          dX += 0.0 * (dX2 + dY2);      // (0 * finite = 0: keeps the chain alive without changing the value)
-        }
       }
-      STAMP(4);
       TL(11);                                  // closed form done
       // applyTransformation(sceneTmp): data * R^T (dgemm NoTrans,Trans), then + t (Icp.cpp:371-408).
       // The distance each point moves (rounded up, fp32 is plenty for a bound) eats into its neighbour
@@ -1410,16 +1219,6 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
         const float disp = __builtin_amdgcn_sqrtf((float)(ex * ex + ey * ey) * 1.000001f) * 1.000001f;
         lb[q] = lb[q] - (double)disp;
         sx[q] = nx; sy[q] = ny;
-        if constexpr ((DUP & 4) != 0) {
-          const double x2 = vreg(nx), y2 = vreg(ny);
-          double mx = 0.0, my = 0.0;
-          mx += x2 * co; mx += y2 * (-si);
-          my += x2 * si; my += y2 * co;
-          mx = mx + dX; my = my + dY;
-          const double fx = mx - x2, fy = my - y2;
-          const float disp2 = __builtin_amdgcn_sqrtf((float)(fx * fx + fy * fy) * 1.000001f) * 1.000001f;
-          lb[q] = lb[q] - 0.0 * (double)disp2;
-        }
       }
       {
         // Tfinal = Tlast * Tfinal (Icp.cpp:452): the 4x4 product restricted to its non-trivial entries
@@ -1440,7 +1239,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     TL(12);                                    // scene moved, bounds updated
     // -- loop control (Icp.cpp:489-511)
     iter++;
-    if constexpr ((OPT & 16) != 0) {
+    {
       // (every lane holds the same rms: the decisions as wave-uniform scalars, so that the loop is a scalar branch and not an
       // exec-mask loop over a per-lane `state`)
       const int conv_hit = __builtin_amdgcn_readfirstlane((int)(fabs(rms - rms_prev) < 10e-10));
@@ -1449,22 +1248,12 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
       conv_cnt = conv_hit ? conv_cnt + 1 : 0;
       if (rms_done || conv_cnt >= conv_need) state = TSD_ICP_SUCCESS;
       else if (iter >= max_it) state = TSD_ICP_MAXITERATIONS;
-    } else {
-    if (fabs(rms - rms_prev) < 10e-10) conv_cnt++; else conv_cnt = 0;
-    if (rms <= 0.0 || conv_cnt >= conv_need) state = TSD_ICP_SUCCESS;
-    else if (iter >= max_it) state = TSD_ICP_MAXITERATIONS;
     }
     rms_prev = rms;
-    STAMP(5);
-    if (has_trace && tid == 0 && iter <= TSD_ICP_TRACE_MAX && !(ABL & 64)) {
+    if (has_trace && tid == 0 && iter <= TSD_ICP_TRACE_MAX) {
       double* tr = L.tail->trace + TSD_ICP_TRACE_STRIDE * (iter - 1);
       tr[0] = (double)pairs; tr[1] = rms; tr[2] = thr_before; tr[3] = (double)state;
       tr[4] = co; tr[5] = si; tr[6] = dX; tr[7] = dY;          // Tlast = [[co, -si, dX], [si, co, dY]] (NaN: no estimate this step)
-#ifdef TSD_ICP_STAMPS
-      tr[2] = (double)st_acc[1];        // cumulative phase-A cycles      (diagnostic build only)
-      tr[1] = (double)L.ired[IR_DBG];   // cumulative searched points
-      tr[3] = (double)L.ired[IR_DBG + 1];   // cumulative whole-wave searches
-#endif
     }
   }
 
@@ -1480,14 +1269,6 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     }
   }
 #endif
-#ifdef TSD_ICP_STAMPS
-  __syncthreads();
-  if (tid == 0) {
-    st_acc[7] = L.ired[IR_DBG + 1];     // setup cycles / wave searches
-    printf("ICPDBG wave searches %d walk steps %d sweeps %d tier2 cycles %d inline pts %d\n", L.ired[IR_DBG + 1], L.ired[IR_DBG + 3], L.ired[IR_DBG + 4], L.ired[IR_DBG + 5] << 4, L.ired[IR_DBG + 2]);
-    for (int i = 0; i < 8; i++) L.tail->trace[TSD_ICP_TRACE_STRIDE * TSD_ICP_TRACE_MAX - 8 + i] = (double)st_acc[i];
-  }
-#endif
   {
     // Icp::getFinalTransformation (Icp.cpp:528-546)
     IcpResultDev r;
@@ -1499,13 +1280,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     const IcpTail& tl = *L.tail;
     if (tid == 0) *tl.out = r;
     // fused scan: gates, Sensor::transform, push / next-scan arguments, result record for the host
-#ifdef TSD_ICP_STAMPS
-    const long long ep0 = wall_clock64();
-#endif
     if (tl.post.st) scan_post_body(tl.post, L.tail->pre, r.T, r, tl.post.gmin_x, tl.post.gmax_x, tl.post.gmin_y, tl.post.gmax_y);
-#ifdef TSD_ICP_STAMPS
-    if (tid == 0 && tl.post.st) printf("ICPDBG epilogue %lld x10ns (thread 0, incl. the record's system-scope publication)\n", wall_clock64() - ep0);
-#endif
   }
 }
 
@@ -1516,10 +1291,11 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
       const double* __restrict__ g_coords, const uint8_t* __restrict__ g_mask_m,
       const double* __restrict__ g_rays_local, const double* __restrict__ g_ranges,
       const uint8_t* __restrict__ g_mask, IcpResultDev* __restrict__ out, double* __restrict__ trace, ScanPostArgs post,
-      const double* __restrict__ g_mnormals, const double* __restrict__ g_normals)
+      const double* __restrict__ g_mnormals, const double* __restrict__ g_normals, IcpSeedArgs seed)
 {
+  // workgroup 0 registers; workgroups 1 .. seed.helpers do step 0's searches for it (IcpSeed)
   icp_workgroup<R, MAXT, PTL>(a, P_dev, cap, g_model, g_scene, g_morig, g_start, g_coords, g_mask_m, g_rays_local, g_ranges, g_mask, out, trace,
-                              post, g_mnormals, g_normals);
+                              post, g_mnormals, g_normals, seed, (int)blockIdx.x);
 }
 
 // the same kernel with the per-step pair lists written out and the scene held still (direct mode, closed form): tsd_icp_pairs
@@ -1531,16 +1307,18 @@ k_icp_pairs(IcpArgs a, int cap, const double* __restrict__ g_model, const double
 {
   ScanPostArgs post{};
   icp_workgroup<R, MAXT, false, true>(a, nullptr, cap, g_model, g_scene, g_morig, g_start, nullptr, nullptr, nullptr, nullptr, nullptr, out, trace,
-                                      post, nullptr, nullptr, pairs_out);
+                                      post, nullptr, nullptr, IcpSeedArgs{nullptr, nullptr, 0u, 0}, 0, pairs_out);
 }
 
 // the registrations of a batch of robots in ONE launch (tsd_batch_begin): workgroup x = entry x, fused mode only (model and
 // scene come from the ray cast's / the scan's per-beam arrays); each registration still runs on one compute unit
 template <int R, int MAXT, bool PTL>
 __global__ void __launch_bounds__(MAXT)
-k_icp_batch(const IcpBatchEntry* __restrict__ entries, int cap)
+k_icp_batch(const IcpBatchEntry* __restrict__ entries, int cap, int n_entries)
 {
-  const IcpBatchEntry& e = entries[blockIdx.x];
+  // workgroups 0 .. n - 1 register entry x; workgroup n * h + x (h >= 1) is helper h of entry x (IcpSeed)
+  const IcpBatchEntry& e = entries[blockIdx.x % (unsigned)n_entries];
+  const int role = (int)(blockIdx.x / (unsigned)n_entries);
   if (e.rc_flag) {
     // launched ahead of the batch's ray casts: wait until the word behind them says this batch's are done (one thread polls).
     // Bounded -- and a wait that runs out, or a batch the host abandoned, does NOT register on whatever the ray-cast buffers hold:
@@ -1560,13 +1338,14 @@ k_icp_batch(const IcpBatchEntry* __restrict__ entries, int cap)
     }
     __syncthreads();
     if (s_fail) {
-      if (threadIdx.x == 0) scan_post_failed(e.post, s_fail);
+      if (threadIdx.x == 0 && role == 0) scan_post_failed(e.post, s_fail);
       return;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
+  if (role > e.seed.helpers) return;
   icp_workgroup<R, MAXT, PTL>(e.a, e.P_dev, cap, nullptr, nullptr, nullptr, nullptr, e.coords, e.mask_m, e.rays_local, e.ranges, e.mask, e.out,
-                              e.trace, e.post, nullptr, e.normals);
+                              e.trace, e.post, nullptr, e.normals, e.seed, role);
 }
 
 static int icp_cap_for(int n)
@@ -1576,19 +1355,37 @@ static int icp_cap_for(int n)
   return cap;
 }
 
-// threads of a registration of n points with R register slots per lane (see OPT 32: four "old" waves take R blocks of 64 points each,
+// helper workgroups of a registration with n scene points in workgroups of T threads (IcpSeed): one point per helper lane
+static std::atomic<unsigned int> g_seed_seq{1u};
+int icp_helpers_for(const tsd_ctx* ctx, int n, int T)
+{
+  if (!ctx->icp_helpers) return 0;
+  const int h = (n + T - 1) / T;
+  return h > ICP_MAX_HELPERS ? ICP_MAX_HELPERS : h;
+}
+size_t icp_seed_bytes(int points) { return sizeof(unsigned int) * ICP_SEED_FLAGS + sizeof(IcpSeed) * (size_t)points; }
+IcpSeedArgs icp_seed_args(void* buf, int helpers)
+{
+  IcpSeedArgs sa;
+  sa.flags = reinterpret_cast<unsigned int*>(buf);
+  sa.seeds = reinterpret_cast<IcpSeed*>(reinterpret_cast<char*>(buf) + sizeof(unsigned int) * ICP_SEED_FLAGS);
+  unsigned int q = g_seed_seq.fetch_add(1u);
+  if (q == 0u) q = g_seed_seq.fetch_add(1u);         // (0 is what a fresh buffer holds)
+  sa.seq = q; sa.helpers = buf ? helpers : 0;
+  return sa;
+}
+
+// threads of a registration of n points with R register slots per lane (four "old" waves take R blocks of 64 points each,
 // younger waves one block each where the blocks left allow it)
 static int icp_threads_for(int n, int R, int maxt)
 {
   int T = ((n + R - 1) / R + 63) & ~63;
   if (T < 64) T = 64;
-  if ((OPT & 32) != 0) {
-    const int B = (n + 63) / 64;
-    if (B > 4 * R) {
-      int W = 4 + (B - 4 * R);
-      if (W > maxt / 64) W = maxt / 64;
-      if (64 * W > T) T = 64 * W;
-    }
+  const int B = (n + 63) / 64;
+  if (B > 4 * R) {
+    int W = 4 + (B - 4 * R);
+    if (W > maxt / 64) W = maxt / 64;
+    if (64 * W > T) T = 64 * W;
   }
   return T;
 }
@@ -1619,16 +1416,16 @@ static int launch_icp_shape_est(tsd_ctx* ctx, const IcpArgs& a, int n, int cap, 
   ScopedKernelTimer t(ctx, "icp");
   const LaunchTarget* tg = launch_target();       // concurrent multi-robot path: the sensor's own stream and buffers
   // the per-iteration record (tsd_icp_trace) is kept by tsd_icp / tsd_localize; the fused scan has no reader for it and skips
-  // the 64-byte store per step (the diagnostic stamp builds keep it: they park their counters there)
+  // the 64-byte store per step
   double* trace_buf = tg && tg->trace ? tg->trace : ctx->d_icp_trace;
-#ifndef TSD_ICP_STAMPS
   if (post.st) trace_buf = nullptr;
-#endif
-  hipExtLaunchKernelGGL((k_icp<R, MAXT, PTL>), dim3(1), dim3(T), lds, launch_stream(ctx), t.a, t.b, 0, a, P_dev, cap, ctx->d_model, ctx->d_scene,
+  void* seed_buf = tg && tg->icp_seed ? tg->icp_seed : ctx->d_icp_seed;
+  const IcpSeedArgs sa = icp_seed_args(seed_buf, icp_helpers_for(ctx, n, T));
+  hipExtLaunchKernelGGL((k_icp<R, MAXT, PTL>), dim3(1 + sa.helpers), dim3(T), lds, launch_stream(ctx), t.a, t.b, 0, a, P_dev, cap, ctx->d_model, ctx->d_scene,
                      ctx->d_morig, ctx->d_start, tg && tg->coords ? tg->coords : ctx->d_coords, tg && tg->mask_m ? tg->mask_m : ctx->d_mask_m,
                      d_rays_local ? d_rays_local : ctx->d_rays_local, d_ranges ? d_ranges : ctx->d_ranges,
                      d_mask ? d_mask : ctx->d_mask, tg && tg->icp_res ? tg->icp_res : ctx->d_icp_res,
-                     trace_buf, post, ctx->d_mnormals, tg && tg->normals ? tg->normals : ctx->d_normals);
+                     trace_buf, post, ctx->d_mnormals, tg && tg->normals ? tg->normals : ctx->d_normals, sa);
   TSD_HIP_CHECK(ctx, hipGetLastError());
   return TSD_OK;
 }
@@ -1696,7 +1493,7 @@ int launch_icp_pairs(tsd_ctx* ctx, const IcpArgs& a, int* d_pairs)
 }
 
 template <int R, int MAXT, bool PTL>
-static int launch_icp_batch_shape(tsd_ctx* ctx, hipStream_t stream, const IcpBatchEntry* d_entries, int n, int nthr, int cap)
+static int launch_icp_batch_shape(tsd_ctx* ctx, hipStream_t stream, const IcpBatchEntry* d_entries, int n, int nthr, int cap, int helpers)
 {
   int T = icp_threads_for(nthr, R, MAXT);
   if (T > MAXT) return set_error(ctx, TSD_E_CAPACITY, "icp workgroup shape", hipSuccess);
@@ -1712,7 +1509,7 @@ static int launch_icp_batch_shape(tsd_ctx* ctx, hipStream_t stream, const IcpBat
     }
   }
   ScopedKernelTimer t(ctx, "icp");
-  hipExtLaunchKernelGGL((k_icp_batch<R, MAXT, PTL>), dim3(n), dim3(T), lds, stream, t.a, t.b, 0, d_entries, cap);
+  hipExtLaunchKernelGGL((k_icp_batch<R, MAXT, PTL>), dim3(n * (1 + helpers)), dim3(T), lds, stream, t.a, t.b, 0, d_entries, cap, n);
   TSD_HIP_CHECK(ctx, hipGetLastError());
   return TSD_OK;
 }
@@ -1731,13 +1528,23 @@ int launch_icp_batch(tsd_ctx* ctx, hipStream_t stream, const IcpBatchEntry* host
   const int cap = icp_cap_for(beams);
   const bool ptl = host[0].a.estimator == TSD_ESTIMATOR_POINT_TO_LINE;
   if (host[0].a.estimator != TSD_ESTIMATOR_CLOSED_FORM && !ptl) return set_error(ctx, TSD_E_ARG, "tsd_icp_params.estimator", hipSuccess);
+  // (the entries' seed arguments were filled by the caller with icp_batch_helpers(): the largest helper count of the batch sizes the grid)
+  int helpers = 0;
+  for (int i = 0; i < n; i++) if (host[i].seed.helpers > helpers) helpers = host[i].seed.helpers;
   if (beams <= 3 * 512)
-    return ptl ? launch_icp_batch_shape<3, 512, true>(ctx, stream, d_entries, n, beams, cap)
-               : launch_icp_batch_shape<3, 512, false>(ctx, stream, d_entries, n, beams, cap);
-  return ptl ? launch_icp_batch_shape<8, 256, true>(ctx, stream, d_entries, n, beams, cap)
-             : launch_icp_batch_shape<8, 256, false>(ctx, stream, d_entries, n, beams, cap);
+    return ptl ? launch_icp_batch_shape<3, 512, true>(ctx, stream, d_entries, n, beams, cap, helpers)
+               : launch_icp_batch_shape<3, 512, false>(ctx, stream, d_entries, n, beams, cap, helpers);
+  return ptl ? launch_icp_batch_shape<8, 256, true>(ctx, stream, d_entries, n, beams, cap, helpers)
+             : launch_icp_batch_shape<8, 256, false>(ctx, stream, d_entries, n, beams, cap, helpers);
 }
 
 size_t icp_lds_bytes() { return icp_lds_bytes_for(TSD_MAX_ICP_POINTS, 256); }
+
+// seed arguments of one entry of a batch (tsd_batch_begin): the workgroup shape launch_icp_batch will choose for `batch_beams`
+IcpSeedArgs icp_batch_seed_args(const tsd_ctx* ctx, void* buf, int beams, int batch_beams)
+{
+  const int T = batch_beams <= 3 * 512 ? icp_threads_for(batch_beams, 3, 512) : icp_threads_for(batch_beams, 8, 256);
+  return icp_seed_args(buf, icp_helpers_for(ctx, beams, T));
+}
 
 }  // namespace tsd

@@ -111,6 +111,7 @@ struct LaunchTarget {
   hipStream_t stream = nullptr;                                       // ray cast + registration
   double* coords = nullptr; double* normals = nullptr; uint8_t* mask_m = nullptr;   // ray-cast outputs
   IcpResultDev* icp_res = nullptr; double* trace = nullptr;
+  void* icp_seed = nullptr;                                           // the registration's helper hand-off (icp_kernels.hip: IcpSeed)
   char* rmq = nullptr;                                                // range-query tables of the scan's push
   hipEvent_t rc_done = nullptr;                                       // launch_raycast: completes with the ray cast itself (the kernel's own stop
   bool rc_done_used = false;                                          // event: no marker behind it); used = false when the dispatch is being timed
@@ -129,6 +130,9 @@ struct TablesBatchEntry {
   double phi_min, ang_res;
   int beams, pad;
 };
+// step 0's searches of a registration, done by helper workgroups (icp_kernels.hip: IcpSeed): flags, results, launch number, helpers
+struct IcpSeed;
+struct IcpSeedArgs { unsigned int* flags; IcpSeed* seeds; unsigned int seq; int helpers; };
 struct IcpBatchEntry {
   IcpArgs a;
   const double* P_dev; const double* coords; const uint8_t* mask_m; const double* rays_local; const double* ranges;
@@ -138,6 +142,7 @@ struct IcpBatchEntry {
                                      // whose ray casts are done, [1] number of the latest batch the host gave up on (tsd_batch_begin failed)
   unsigned int rc_target;
   unsigned int poll_bound;           // polls (about a microsecond each) before the wait gives up and REPORTS it (BATCH_FAIL_*)
+  IcpSeedArgs seed;
 };
 // why a batched registration did not run (ScanResultDev::reserved / tsd_scan_result.reserved; 0 = it ran)
 constexpr int BATCH_FAIL_TIMEOUT = 1;    // its ray casts never reported done within the poll bound
@@ -218,6 +223,8 @@ struct tsd_ctx {
   int* d_morig = nullptr;        // [TSD_MAX_ICP_POINTS] original index of every angle-sorted model point
   int* d_start = nullptr;        // [TSD_MAX_ICP_POINTS] first search slot of every scene point
   int icp_shape = 0;             // 0 = default workgroup shape (env TSD_ICP_SHAPE for experiments)
+  int icp_helpers = 1;           // step 0's searches by helper workgroups (tsd_debug_set_icp_helpers: 0 = the registration searches itself)
+  void* d_icp_seed = nullptr;    // their hand-off buffer (icp_seed_bytes(TSD_MAX_ICP_POINTS))
   tsd::IcpResultDev* d_icp_res = nullptr;
   double* d_icp_trace = nullptr;            // [TSD_ICP_TRACE_MAX][TSD_ICP_TRACE_STRIDE]
   tsd::IcpResultDev* h_icp_res = nullptr;    // pinned
@@ -304,7 +311,7 @@ struct tsd_sensor {
   unsigned long long rc_ticket = 0;            // ticket of the sensor's most recent ray cast ...
   volatile int rc_recorded = 1;                // ... whose ev_rc_done record has been issued (by the sensor's own thread)
   double* d_coords = nullptr; double* d_normals = nullptr; uint8_t* d_mask_m = nullptr;
-  tsd::IcpResultDev* d_icp_res = nullptr; double* d_icp_trace = nullptr;
+  tsd::IcpResultDev* d_icp_res = nullptr; double* d_icp_trace = nullptr; void* d_icp_seed = nullptr;
   char* d_rmq2[3] = {nullptr, nullptr, nullptr}; int rmq_slot = 0;
   char* h_stage2[2] = {nullptr, nullptr};   // pinned staging of the scan, alternating
   bool inflight = false;           // begin() without finish()
@@ -409,6 +416,8 @@ int launch_raycast_batch(tsd_ctx* ctx, hipStream_t stream, const RaycastBatchEnt
 int launch_raycast_batch_byval(tsd_ctx* ctx, hipStream_t stream, const RaycastBatchEntry* h_entries, int n, int max_beams);   // n <= RC_BATCH_BYVAL
 int launch_push_tables_batch(tsd_ctx* ctx, hipStream_t stream, const TablesBatchEntry* d_entries, int n, int max_beams);
 int launch_icp_batch(tsd_ctx* ctx, hipStream_t stream, const IcpBatchEntry* host, const IcpBatchEntry* d_entries, int n);
+size_t icp_seed_bytes(int points);
+IcpSeedArgs icp_batch_seed_args(const tsd_ctx* ctx, void* buf, int beams, int batch_beams);
 
 int launch_calibrate(tsd_ctx* ctx, double* t, double* w, size_t n);
 int launch_occupancy(tsd_ctx* ctx, int8_t* d_out, int inflate, int inflate_factor);

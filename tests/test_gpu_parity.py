@@ -700,6 +700,75 @@ def test_icp_four_way_exact_ties(oracle):
             assert d <= 1e-9 and a <= 1e-9, (h, iters, d, a)
 
 
+def test_icp_helpers_change_nothing(oracle):
+    """Step 0's nearest-neighbour searches come from helper workgroups by default (icp_kernels.hip: IcpSeed) -- the same search function on
+    the same inputs, run on other compute units while the registering workgroup sets itself up.  With the helpers switched off
+    (tsd_debug_set_icp_helpers) the registration searches itself: T, rms, counts and the WHOLE per-iteration trace (pairs, rms,
+    threshold, state, Tlast) must be bit-identical, for the closed form and the point-to-line estimator, direct and fused calls, point
+    sets with unresolvable windows (lattices: exact ties; sparse far points: whole-wave searches), and agree with the oracle."""
+    gc = synth.GridConfig(9, 0.05)
+    dg = capi.TsdGridDevice(gc.map_size_log2, gc.cell_size, gc.max_trunc)
+    og = oracle.Grid(gc.map_size_log2, gc.cell_size, gc.max_trunc)
+    bounds = (0.0, og.max_x, 0.0, og.max_x)
+    rng = np.random.default_rng(77)
+    cases = []
+    for n in (40, 300, 1081, 1500, 2000):                       # one helper .. several, both workgroup shapes
+        phi = np.sort(rng.uniform(-2.3, 2.3, n))
+        r = 3.0 + 1.5 * np.sin(3 * phi) + rng.normal(0, 0.01, n)
+        M = np.stack([r * np.cos(phi), r * np.sin(phi)], axis=1)
+        S = M[rng.permutation(n)[: max(8, int(0.9 * n))]] + rng.normal(0, 0.02, (max(8, int(0.9 * n)), 2))
+        a = rng.uniform(-0.03, 0.03)
+        R = np.array([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]])
+        S = S @ R.T + rng.uniform(-0.05, 0.05, 2)
+        S[:: 7] += rng.uniform(0.3, 0.8, (len(S[:: 7]), 2))    # far from the model: whole-wave searches
+        cases.append((M, S))
+    xs, ys = np.meshgrid(np.arange(-2.0, 2.01, 0.25), np.arange(-1.5, 1.51, 0.25))
+    L = np.stack([xs.ravel(), ys.ravel()], axis=1)
+    L = L[np.hypot(L[:, 0], L[:, 1]) > 0.3]
+    cases.append((L[rng.permutation(len(L))], L[rng.choice(len(L), len(L) // 3, replace=False)] + 0.125))       # exact ties
+    pose = synth.pose_matrix(12.8, 12.8, 0.4)
+    for ci, (M, S) in enumerate(cases):
+        for est in (0, 1):
+            nrm = None
+            if est == 1:
+                nrm = M / np.linalg.norm(M, axis=1, keepdims=True)
+            out = []
+            for on in (True, False):
+                dg.set_icp_helpers(on)
+                p = dg.icp_params(30, 0.4, 0.02, estimator=est)
+                r = dg.icp(M, S, pose, p, model_normals_xy=nrm)
+                out.append((r, dg.icp_trace(r.iterations)))
+            dg.set_icp_helpers(True)
+            (ra, ta), (rb, tb) = out
+            assert (ra.pairs, ra.iterations, ra.state) == (rb.pairs, rb.iterations, rb.state), (ci, est)
+            assert np.array_equal(ra.T, rb.T) and ra.rms == rb.rms, (ci, est, ra.T - rb.T)
+            assert np.array_equal(ta, tb, equal_nan=True), (ci, est)
+            if est == 0:
+                ro = oracle.icp(M, S, pose, 30, 0.4, 0.02, bounds, nn_mode=0)
+                assert (ro["pairs"], ro["iterations"], ro["state"]) == (ra.pairs, ra.iterations, ra.state), ci
+                d, a = H.pose_delta(ro["T"], ra.T)
+                assert d <= 1e-9 and a <= 1e-9, (ci, d, a)
+    # fused: ray cast + registration from a mapped grid
+    geo = synth.ScanGeometry.utm30lx()
+    world = synth.World("room", gc)
+    pose0, (x, y, yaw) = H.sensor_pose(world, 0)
+    r32 = world.scan(x, y, yaw, geo)
+    data, mask = oracle.ingest_f32(r32, H.MAX_RANGE, geo.angle_increment)
+    dg.push(pose0, data, mask, geo.angle_increment, geo.angle_min, H.MAX_RANGE, H.MIN_RANGE, H.LOW_REFL, want_stats=False)
+    pose1, (x1, y1, yaw1) = H.sensor_pose(world, 2)
+    d1, m1 = oracle.ingest_f32(world.scan(x1, y1, yaw1, geo), H.MAX_RANGE, geo.angle_increment)
+    rl, rw = H.world_rays(oracle, geo, pose0, gc.cell_size)
+    out = []
+    for on in (True, False):
+        dg.set_icp_helpers(on)
+        r = dg.localize(pose0, rw, rl, d1, m1, H.MIN_RANGE, H.MAX_RANGE, dg.icp_params(30, 0.4, 0.02))
+        out.append((r, dg.icp_trace(r.iterations)))
+    dg.set_icp_helpers(True)
+    (ra, ta), (rb, tb) = out
+    assert ra.pairs > 500 and (ra.pairs, ra.iterations, ra.state, ra.n_model, ra.n_scene) == (rb.pairs, rb.iterations, rb.state, rb.n_model, rb.n_scene)
+    assert np.array_equal(ra.T, rb.T) and np.array_equal(ta, tb, equal_nan=True)
+
+
 # ------------------------------------------------------------------------------------------------
 # BASELINE.json full sizes: cfg 2 (4096^2) cell-for-cell against the oracle, cfg 3 (16384^2) through
 # size-independent properties plus the oracle on the touched tiles
