@@ -22,16 +22,9 @@
 #include "tsd_ctx.hpp"
 #include <climits>
 
-#ifndef TSD_WRITER_MIRRORS
-#define TSD_WRITER_MIRRORS 1     // k_push_update mirrors the edge cells it changes into the neighbours' halos (0: k_push_halo gathers them all)
-#endif
-
 namespace tsd {
 
-#ifndef TSD_UPDATE_BLOCK
-#define TSD_UPDATE_BLOCK 256
-#endif
-constexpr int UPDATE_BLOCK = TSD_UPDATE_BLOCK;     // threads of the per-tile workgroup (64, 128 or 256)
+constexpr int UPDATE_BLOCK = 256;                  // threads of the per-tile workgroup
 
 // ---- per-tile record written by k_push_tiles -------------------------------------------------------
 constexpr uint32_t REC_RANGE_PASS = 1u, REC_UPDATE = 2u, REC_NEW = 4u, REC_NEW_FROM_EMPTY = 8u,
@@ -347,7 +340,6 @@ k_push_classify(GridDev g, const PushArgs* __restrict__ a_dev, const char* __res
   // chain of memory round trips: every one of them that rides along with another is ~0.6 us off the kernel)
   // ld_pinned: the optimiser otherwise SINKS a read into the conditional block of its only use, behind that block's other waits.
   const uint8_t t_flag = ld_pinned(&g.flags[p]), t_dirty = ld_pinned(&dirty[p]);      // (used inside `in_window` regions only)
-#if TSD_WRITER_MIRRORS
   // which of the left / lower / diagonal neighbours hold data BEFORE this push: k_push_update mirrors the edge cells it changes into
   // their halos (a neighbour materialised by this very push gets its halo from k_push_halo)
   unsigned nbr = 0u;
@@ -357,7 +349,6 @@ k_push_classify(GridDev g, const PushArgs* __restrict__ a_dev, const char* __res
     const uint8_t nL = ld_pinned(&g.flags[hL ? p - 1 : p]), nD = ld_pinned(&g.flags[hD ? p - g.PX : p]), nDL = ld_pinned(&g.flags[(hL && hD) ? p - g.PX - 1 : p]);
     nbr = ((hL && nL) ? 2u : 0u) | ((hD && nD) ? 4u : 0u) | ((hL && hD && nDL) ? 8u : 0u);
   }
-#endif
   const double t_iw = ld_pinned(&g.init_weight[p]);
   double pw = 0.0;
   double tcx = 0.0, tcy = 0.0;                               // the tile's centroid (UPDATE tiles)
@@ -485,9 +476,7 @@ k_push_classify(GridDev g, const PushArgs* __restrict__ a_dev, const char* __res
       x.lcx = (float)lcx; x.lcy = (float)lcy;
       x.th_c = atan2_estimate(x.lcy, x.lcx);
       x.iw = t_iw; x.flag = t_flag;
-#if TSD_WRITER_MIRRORS
       x.flag |= nbr;               // bit 0: the tile's _initialized; bits 1 / 2 / 3: left / lower / diagonal neighbour holds data
-#endif
       x.jb0 = (win & 0xFFFFu) > 0u ? (win & 0xFFFFu) - 1u : 0u;
       x.bd = bd0;
       static_cast<PushListAuxBody&>(list_aux[slot]) = x;
@@ -565,24 +554,13 @@ __device__ __forceinline__ float beam_limit(double r, unsigned mk, float mtf, fl
 // Lazy TsdGridPartition::init (TsdGridPartition.cpp:88-134) is folded in (a fresh tile's old value is known: non-candidates get
 // the init value from phase A / the fix-up, candidates start from it in phase C); KIND_EMPTY: increaseEmptiness over the 33x33
 // cells.  The workgroup leaves the tile's record and adds it to the tile's running totals (no-return atomics).
-// -DTSD_UPDATE_PREFETCH=1: single-tile workgroups (cfg 2) request their tile's 128 lines ahead of phase A.  Round 3's default; round 4
-// switched it OFF: it buys the kernel 0.4 us inside the SLAM loop (13.4 -> 13.0 us; nothing push-only, nothing in scans/s: 5 735 against
-// 5 757) for 5.5 MB of reads per push that nothing uses -- 52 % of a visited tile's cells are not candidates -- i.e. HBM traffic 24.4 MB
-// against 18.9 MB for 15 MB of algorithmic bytes (1.63 -> 1.26; same-call A/B and PMC passes, gpurun_out/r4l).  Requesting
-// only the lines that hold candidates, as soon as phase A knows them, was built and measured worse (15.3 us: eight more live registers
-// in a 96-register kernel spill).
-#ifndef TSD_UPDATE_PREFETCH
-#define TSD_UPDATE_PREFETCH 0
-#endif
-#ifndef TSD_UPDATE_WPS
-#define TSD_UPDATE_WPS 5
-#endif
+// (Measured and not kept, rounds 3-4: single-tile workgroups requesting their tile's 128 lines ahead of phase A -- 0.4 us off the kernel inside
+// the SLAM loop for 5.5 MB of reads per push that nothing uses, traffic / algorithmic bytes 1.63 against 1.26; requesting only the lines that
+// hold candidates: slower, eight more live registers spill.)
+constexpr int UPDATE_WPS = 5;                                    // resident workgroups per SIMD the launch bounds ask for
 constexpr int UPD_CAND_MAX = TILE_INTERIOR;
 constexpr int UPD_CPT = TILE_INTERIOR / UPDATE_BLOCK;            // cells per thread: 4
-#ifndef TSD_UPDATE_CB
-#define TSD_UPDATE_CB 2
-#endif
-constexpr int UPD_CB = TSD_UPDATE_CB;                            // exact part: cells per lane and pass
+constexpr int UPD_CB = 2;                                        // exact part: cells per lane and pass
 __host__ __device__ inline size_t update_lds_bytes(int beams)
 {
   const size_t bp = (size_t)((beams + 3) & ~3);
@@ -663,7 +641,7 @@ struct TileC {
 // more of them.  Lazy TsdGridPartition::init (TsdGridPartition.cpp:88-134) is folded in (a fresh tile's old value is known:
 // non-candidates get the init value from phase A / the fix-up, candidates start from it in phase C).  increaseEmptiness of
 // materialised tiles (TsdGridPartition.cpp:136-164, the `other` list) follows the tile queue.
-__global__ void __launch_bounds__(UPDATE_BLOCK, TSD_UPDATE_WPS)
+__global__ void __launch_bounds__(UPDATE_BLOCK, UPDATE_WPS)
 k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __restrict__ ranges,
               const uint8_t* __restrict__ mask, uint32_t* __restrict__ tile_rec, uint32_t* __restrict__ tile_totals,
               const uint32_t* __restrict__ list, const PushListAux* __restrict__ list_aux,
@@ -707,10 +685,7 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
   // one round) and the rotation table: one memory round trip.  (A single-tile workgroup stages only the beams its tile can project
   // to, behind the record: 1 read per thread instead of 5 -- measured 0.7 us better at cfg 2 than staging everything up front.)
   const bool more_than_one = n_upd_tiles > gridDim.x;
-#ifndef TSD_STAGE_UPFRONT       // diagnostic: 1 = every workgroup stages the whole scan up front
-#define TSD_STAGE_UPFRONT 0
-#endif
-  const bool stage_all = more_than_one || TSD_STAGE_UPFRONT;
+  const bool stage_all = more_than_one;
   constexpr int STAGE_R = 5;
   double st_r[STAGE_R]; unsigned st_m[STAGE_R];
 #pragma unroll
@@ -734,11 +709,9 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
   __shared__ unsigned int s_upd[3];                                        // cells updated
   __shared__ unsigned long long s_neg[3];                                  // groups of the tile that received a negative value
   __shared__ unsigned int s_tk[4];                                         // list index of tile number n at [n & 3]
-#if TSD_WRITER_MIRRORS
   // the tile's edge cells that this push changed (slot y: cell (0, y); slot 32 + x: cell (x, 0), x > 0): value, weight, "changed"
   // (a NaN weight = unchanged: weights are never NaN)
   __shared__ __attribute__((aligned(16))) double2 s_edge[2 * TILE_DIM];
-#endif
   const double max_trunc = g.max_trunc;
 
   if (blockIdx.x < n_upd_tiles) {
@@ -795,9 +768,7 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
     ta.wlo = wlo; ta.whi = whi;
     if (tid < ROT_N) s_rot[tid] = st_rot;
     if (tid < 3) { s_cu[tid] = 0ull; s_upd[tid] = 0u; s_neg[tid] = 0ull; }
-#if TSD_WRITER_MIRRORS
     if (tid < 2 * TILE_DIM) s_edge[tid] = make_double2(0.0, __builtin_nan(""));
-#endif
     lds_barrier();                     // scan staged, counters zeroed, first tickets in place
     PSTAMP(0);
 
@@ -836,10 +807,6 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
         idx[k] = cc.j; uns[k] = cc.uns; in[k] = !cc.uns && !cc.out;
       }
       PSTAMP(6);     // (sub-phase: d2 table, setup, classification)
-#if defined(TSD_ABLATE) && (TSD_ABLATE & 8)      // instruction-count ablation (tools/push_ablate_r3.sh; results are WRONG): classification only
-      if (idx[0] + idx[1] + idx[2] + idx[3] + (int)uns[0] + (int)uns[1] + (int)uns[2] + (int)uns[3] + (int)in[0] + (int)in[1] + (int)in[2] + (int)in[3] + (int)(d2f[0] + d2f[1] + d2f[2] + d2f[3]) == 0x7fffffff) dbg[0] = 1.0;
-      return;
-#endif
       // the beams' limits from LDS, the four reads in flight together.  A decided beam outside the staged window -- possible only
       // through rounding at the window's ends -- joins the undecided cells (boundary = the beam: the exact test names it again, and
       // that path reads any beam)
@@ -870,10 +837,6 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
       PSTAMP(7);     // (sub-phase: limits, candidate test, fresh stores)
       // compaction: ONE LDS atomic per wave for its cells of all four strips -- the candidates go to the front of the tile's list, the
       // undecided cells (cell | boundary << 10) to its back; the exact part settles those, densely, behind the barrier
-#if defined(TSD_ABLATE) && (TSD_ABLATE & 1)      // ablation: no fix-up
-#pragma unroll
-      for (int k = 0; k < UPD_CPT; k++) uns[k] = false;
-#endif
       unsigned long long bc[UPD_CPT], bu[UPD_CPT];
       unsigned nc = 0u, nu = 0u;
 #pragma unroll
@@ -923,23 +886,7 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
       const TileC tcur = tile_of(xc);
       const unsigned x0 = (unsigned)(tcur.p % g.PX) * TILE_DIM, y0 = (unsigned)(tcur.p / g.PX) * TILE_DIM;
 
-#if TSD_UPDATE_PREFETCH
-      // A workgroup with a single tile (cfg 2: every workgroup) is one latency chain -- record -> scan window -> phase A -> cells ->
-      // stores: the tile's lines are requested HERE (one lane per 128-byte line: wave 0 the values, wave 1 the weights), arrive during
-      // phase A, and the exact part's reads, a barrier later, find them in L2: 13.5 -> 13.0 us at cfg2 / pillars.  Measured and not
-      // done: the same for workgroups with several tiles (bound by instruction issue: +0.4-0.8 us at cfg 3), and requesting the lines
-      // as soon as the record names the tile (the scan window's reads then queue behind 64 single-line requests: 14.5 us).
-      tsd_cell_t pf_t = 0; w_cell_t pf_w = 0;
-      if (!more_than_one && !tcur.fresh) {
-        constexpr int CPL_T = 128 / (int)sizeof(tsd_cell_t), CPL_W = 128 / (int)sizeof(w_cell_t);
-        if (tid < 64 && lane < TILE_INTERIOR / CPL_T) pf_t = ld_pinned(tcur.T + CPL_T * lane);
-        if (tid >= 64 && tid < 128 && lane < TILE_INTERIOR / CPL_W) pf_w = ld_pinned(tcur.W + CPL_W * lane);
-      }
-#endif
       phase_a(n, xc, tcur, x0, y0);
-#if TSD_UPDATE_PREFETCH
-      asm volatile("" : : "v"(pf_t), "v"(pf_w));
-#endif
       PSTAMP(1);
       // tile n + 1's record and the ticket of tile n + 2 were requested a whole phase A ago: the wave takes delivery HERE, where that
       // costs nothing -- at their points of use (behind the exact part) the same wait would also sit out the tile's own stores
@@ -947,11 +894,7 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
       lds_barrier();
       PSTAMP(2);
       const unsigned long long cu = s_cu[slot];
-#if defined(TSD_ABLATE) && (TSD_ABLATE & 2)      // ablation: no exact part
-      const unsigned n_cand = 0u, n_uns = 0u;
-#else
       const unsigned n_cand = (unsigned)cu, n_uns = (unsigned)(cu >> 32);
-#endif
       const unsigned n_tot = n_cand + n_uns;
       uint32_t* cand_list = s_cand + (n & 1u) * UPD_CAND_MAX;
       const double* d2x = s_d2 + (n & 1u) * 2 * TILE_DIM;
@@ -1022,11 +965,7 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
           const unsigned q = q0 + (unsigned)(j * UPDATE_BLOCK);
           ce[j] = q < n_tot ? cand_list[q < n_cand ? q : ((unsigned)(UPD_CAND_MAX - 1) + n_cand) - q] : 0xFFFFFFFFu;
           tv[j] = t_init; wv[j] = tcur.iw;
-#if defined(TSD_ABLATE) && (TSD_ABLATE & 16)     // ablation: the cell reads hit the first line of the tile (what hiding their latency could buy at most)
-          if (ce[j] != 0xFFFFFFFFu && !tcur.fresh) { tv[j] = ld_tsd(tcur.T + (ce[j] & 7u)); wv[j] = ld_w(tcur.W + (ce[j] & 7u)); }
-#else
           if (ce[j] != 0xFFFFFFFFu && !tcur.fresh) { tv[j] = ld_tsd(tcur.T + (ce[j] & 1023u)); wv[j] = ld_w(tcur.W + (ce[j] & 1023u)); }
-#endif
         }
 #pragma unroll
         for (int j = 0; j < UPD_CB; j++) {
@@ -1060,14 +999,10 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
           n_upd += (unsigned)__popcll(__ballot(touched));
           if (touched && tv[j] < 0.0) wrote_neg |= neg_bit((unsigned)c & 31u, (unsigned)c >> 5);
           if (on && (touched || tcur.fresh)) st_cell(tcur.T, tcur.W, c, tv[j], wv[j]);
-#if TSD_WRITER_MIRRORS
           // a changed cell of column 0 / row 0 is also a halo cell of the left / lower / diagonal neighbour: parked for the mirror pass
           // (a fresh tile's surroundings are refreshed by k_push_halo)
-#if !(defined(TSD_MIRROR_ABL) && (TSD_MIRROR_ABL & 1))        // (timing experiment: results wrong)
           if (touched && !tcur.fresh && ((c & 31) == 0 || (c >> 5) == 0))
             s_edge[(c & 31) == 0 ? (c >> 5) : TILE_DIM + (c & 31)] = make_double2(tv[j], wv[j]);
-#endif
-#endif
         }
       }
       if (wrote_neg) atomicOr(&s_neg[slot], wrote_neg);               // (LDS; folded into the tile's mask below)
@@ -1076,7 +1011,7 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
       PSTAMP(3);
       lds_barrier();               // tile n done by every wave; the next ticket in place
       PSTAMP(4);
-#if TSD_WRITER_MIRRORS && !(defined(TSD_MIRROR_ABL) && (TSD_MIRROR_ABL & 2))
+      {
       if (tid >= 64 && tid < 128) {
         // TsdGrid::propagateBorders (TsdGrid.cpp:372-427) for what THIS tile changed: its column 0 is the left neighbour's halo column,
         // its row 0 the lower neighbour's halo row, its cell (0, 0) the diagonal neighbour's corner -- written from here, 64 lanes at
@@ -1102,7 +1037,7 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
         }
         if (l == 0 && f0 && (nf & 4u)) { const size_t o = ((size_t)tcur.p - PXs - 1) * TILE_STRIDE + HALO_ROW + TILE_DIM; st_tsd(g.tsd + o, e0.x); st_w(g.weight + o, e0.y); }
       }
-#endif
+      }
       if (tid == 0) {
         // the record of tile n (this slot's counters are next used by tile n + 3: behind two more barriers)
         const unsigned cells = s_upd[slot];
@@ -1130,9 +1065,6 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
   }
 
   // ---- the other list: increaseEmptiness of materialised tiles, all 33 x 33 cells, halo included; the average uses the NEW weight
-#if defined(TSD_ABLATE) && (TSD_ABLATE & 4)        // ablation: no increaseEmptiness tiles
-  if (n_other) return;
-#endif
   for (unsigned int k = blockIdx.x; k < n_other; k += gridDim.x) {
     const uint32_t entry = list[(unsigned)g.tiles - 1u - k];
     if ((entry >> KIND_SHIFT) != KIND_EMPTY) continue;
@@ -1201,9 +1133,7 @@ k_push_halo(GridDev g, uint8_t* __restrict__ dirty, unsigned long long* __restri
     const uint8_t f0 = g.flags[p], dty = dirty[p];
     const uint8_t fR_ = g.flags[qR], fU_ = g.flags[qU], fUR_ = g.flags[qUR], fL_ = g.flags[qL], fD_ = g.flags[qD], fDL_ = g.flags[qDL];
     const uint32_t rL_ = tile_rec[qL], rD_ = tile_rec[qD], rDL_ = tile_rec[qDL];
-#if TSD_WRITER_MIRRORS
     const uint32_t r0 = tile_rec[p];
-#endif
     if (lane == 0 && dty != 0) dirty[p] = 0;
     const uint8_t fR = hasR ? fR_ : (uint8_t)0, fU = hasU ? fU_ : (uint8_t)0, fUR = (hasR && hasU) ? fUR_ : (uint8_t)0;
     uint8_t fL = hasL ? fL_ : (uint8_t)0, fD = hasD ? fD_ : (uint8_t)0, fDL = (hasL && hasD) ? fDL_ : (uint8_t)0;
@@ -1212,7 +1142,6 @@ k_push_halo(GridDev g, uint8_t* __restrict__ dirty, unsigned long long* __restri
     // listed tiles are dense.  Records outside this push's window are never "listed" (see launch_push).
     const uint32_t rL = hasL ? rL_ : 0u, rD = hasD ? rD_ : 0u, rDL = (hasL && hasD) ? rDL_ : 0u;
     if (!f0) continue;
-#if TSD_WRITER_MIRRORS
     // An UPDATE tile that held data before this push and was not touched by freeFootprint has nothing to do here: what it changed of
     // its column 0 / row 0 / corner, its own workgroup wrote into the neighbours' halos (k_push_update's mirror pass), and what its
     // right / upper neighbours changed arrived the same way or is brought by THEIR jobs below.  Left for this kernel: tiles
@@ -1226,11 +1155,6 @@ k_push_halo(GridDev g, uint8_t* __restrict__ dirty, unsigned long long* __restri
     if (own_job(rL)) fL = 0;
     if (own_job(rD)) fD = 0;
     if (own_job(rDL)) fDL = 0;
-#else
-    if (rL & REC_LISTED) fL = 0;
-    if (rD & REC_LISTED) fD = 0;
-    if (rDL & REC_LISTED) fDL = 0;
-#endif
     const size_t own = (size_t)p * TILE_STRIDE;
     // job 0: own halo from the right / upper neighbour; job 1: the left / lower neighbour's halo from this tile;
     // job 2 (lanes 0 and 32 only): the corner cells
@@ -1538,21 +1462,15 @@ int launch_push(tsd_ctx* ctx, const PushArgs& a, double cx, double cy, double sl
                          box.x0, box.y0, ntx, nty);
   }
   TSD_HIP_CHECK(ctx, hipGetLastError());
-  // as many workgroups as are RESIDENT at once (TSD_UPDATE_WPS per compute unit), never more: every workgroup loops over the
+  // as many workgroups as are RESIDENT at once (UPDATE_WPS per compute unit), never more: every workgroup loops over the
   // list with that stride, and a second round of workgroups would start its whole share of the list when the first round is done
-  int per_cu = TSD_UPDATE_WPS;
+  int per_cu = UPDATE_WPS;
   { const size_t lds_wg = update_lds_bytes(a.beams) + 64; const int by_lds = (int)((160u * 1024u) / lds_wg); if (by_lds < per_cu) per_cu = by_lds < 1 ? 1 : by_lds; }
-#ifdef TSD_DIAG_PER_CU      // diagnostic build (tools/push_variants_r3.sh): fewer resident workgroups from the same code, held down by an LDS pad
-  if (TSD_DIAG_PER_CU < per_cu) per_cu = TSD_DIAG_PER_CU;
-#endif
   const int resident = ctx->n_cus * per_cu;
   const int n_groups = n_window < resident ? n_window : resident;
   {
     ScopedKernelTimer t(ctx, "push_update");
     size_t lds = update_lds_bytes(a.beams);
-#ifdef TSD_DIAG_PER_CU
-    { const size_t pad = (160u * 1024u) / (size_t)(per_cu + 1) + 512u; if (lds < pad) lds = pad; }
-#endif
     hipExtLaunchKernelGGL(k_push_update, dim3(n_groups), dim3(UPDATE_BLOCK), lds, stream, t.a, t.b, 0, g, a_dev, d_ranges, d_mask,
                        ctx->d_tile_rec, ctx->d_tile_totals, ctx->d_list, reinterpret_cast<const PushListAux*>(ctx->d_list_aux), ctx->d_list_cnt, parity,
                        rmq_view(rmq, a.beams).bdir, rmq_view(rmq, a.beams).rot, ctx->d_icp_trace);
@@ -1560,10 +1478,8 @@ int launch_push(tsd_ctx* ctx, const PushArgs& a, double cx, double cy, double sl
   TSD_HIP_CHECK(ctx, hipGetLastError());
   {
     ScopedKernelTimer t(ctx, "push_halo");
-#ifndef TSD_HALO_WAVES
-#define TSD_HALO_WAVES 16384
-#endif
-    const int n_waves = n_window < TSD_HALO_WAVES ? n_window : TSD_HALO_WAVES;        // one wave per listed tile; a longer list is looped over
+    constexpr int HALO_WAVES = 16384;
+    const int n_waves = n_window < HALO_WAVES ? n_window : HALO_WAVES;        // one wave per listed tile; a longer list is looped over
     hipExtLaunchKernelGGL(k_push_halo, dim3((n_waves + 3) / 4), dim3(256), 0, stream, t.a, t.b, 0, g, ctx->d_dirty, ctx->d_pushes,
                        a_dev, ctx->d_list, ctx->d_tile_rec, ctx->d_list_cnt, parity, cx, cy, slack + g.cs);
   }
