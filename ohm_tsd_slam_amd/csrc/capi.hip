@@ -373,6 +373,7 @@ tsd_ctx* tsd_create(int device, int map_size_log2, double cell_size, double max_
   A(hipMalloc(&ctx->d_tile_totals, T * 8 * sizeof(uint32_t)));
   A(hipMalloc(&ctx->d_pushes, 2 * sizeof(unsigned long long)));
   A(hipMalloc(&ctx->d_list, T * sizeof(uint32_t)));
+  A(hipMalloc(&ctx->d_list_h, T * sizeof(uint32_t)));
   A(hipMalloc(&ctx->d_list_aux, T * push_list_aux_bytes()));
   A(hipMalloc(&ctx->d_push_args, sizeof(PushArgs)));
   A(hipMalloc(&ctx->d_list_cnt, push_list_cnt_bytes()));
@@ -457,7 +458,7 @@ void tsd_destroy(tsd_ctx* ctx)
   GridDev& g = ctx->grid;
   hipFree(g.flags); hipFree(g.init_weight); hipFree(g.tsd); hipFree(g.weight); hipFree(g.negmask);
   if (ctx->stream2) hipStreamSynchronize(ctx->stream2);
-  hipFree(ctx->d_rmq2[0]); hipFree(ctx->d_rmq2[1]); hipFree(ctx->d_tile_rec); hipFree(ctx->d_dirty); hipFree(ctx->d_tile_totals); hipFree(ctx->d_pushes); hipFree(ctx->d_list); hipFree(ctx->d_list_aux); hipFree(ctx->d_push_args); hipFree(ctx->d_list_cnt);
+  hipFree(ctx->d_rmq2[0]); hipFree(ctx->d_rmq2[1]); hipFree(ctx->d_tile_rec); hipFree(ctx->d_dirty); hipFree(ctx->d_tile_totals); hipFree(ctx->d_pushes); hipFree(ctx->d_list); hipFree(ctx->d_list_h); hipFree(ctx->d_list_aux); hipFree(ctx->d_push_args); hipFree(ctx->d_list_cnt);
   if (ctx->ev_tables) hipEventDestroy(ctx->ev_tables);
   if (ctx->ev_h2d) hipEventDestroy(ctx->ev_h2d);
   if (ctx->ev_grid) hipEventDestroy(ctx->ev_grid);
@@ -1751,7 +1752,7 @@ int tsd_scan_begin(tsd_sensor* s, const double* ranges, const uint8_t* mask, con
   s->rmq_slot ^= 1;                         // (the previous push of this sensor may still read its tables)
   LaunchTarget tg;
   tg.stream = s->stream; tg.coords = s->d_coords; tg.normals = s->d_normals; tg.mask_m = s->d_mask_m;
-  tg.icp_res = s->d_icp_res; tg.trace = s->d_icp_trace; tg.icp_seed = s->d_icp_seed; tg.rmq = s->d_rmq2[s->rmq_slot];
+  tg.icp_res = s->d_icp_res; tg.trace = s->d_icp_trace; tg.icp_seed = s->d_icp_seed; tg.icp_seed_points = s->beams; tg.rmq = s->d_rmq2[s->rmq_slot];
   TargetScope scope(ctx, &tg);
   rc = launch_push_tables(ctx, s->stream, s->beams, d_ranges, d_mask_push, s->phi_min, s->ang_res);
   if (rc != TSD_OK) return rc;

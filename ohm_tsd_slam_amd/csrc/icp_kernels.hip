@@ -45,20 +45,23 @@ constexpr int HW = 6;                           // tier-1 window: k-HW .. k+HW (
 constexpr int ICP_PAD = 96;                     // wrapped copies of the model at both ends of its LDS array
 constexpr unsigned REFRESH_A = 6, REFRESH_B = 15;      // steps with a scheduled bound renewal
 constexpr double WEAK_MULT = 36.0;                     // a scheduled renewal takes the bounds with less than sqrt(this) x slack in distance
-constexpr int IR_CNT = 32, IR_RMAX = 33, IR_CNT2 = 34, IR_TIE = 35, IR_SEEDED = 36;   // words of IcpLds::ired
+constexpr int IR_CNT = 32, IR_RMAX = 33, IR_CNT2 = 34, IR_TIE = 35;   // words of IcpLds::ired
 // Step 0 of a registration is the one step in which EVERY scene point searches (no neighbour is known yet): ~20 000 cycles on the one
 // compute unit that runs the registration.  That search does not depend on anything the loop produces, so it is shared out: the launch
-// brings `helpers` more workgroups, each of which runs the same set-up (model, unit directions, padding in ITS OWN LDS), does the
-// tier-1 window search of step 0 for blockDim.x of the scene points -- the same function on the same inputs as the registration's own
-// list pass would run -- and leaves the results here, in global memory, behind a flag.  The registering workgroup finishes its own
-// set-up meanwhile, takes the results as the outcome of step 0's searches (bit for bit what it would have found itself) and starts
-// with a steady-state step.  Points the window cannot prove come back unresolved and go through the whole-wave search as before.
-// The wait for the helpers is bounded: helpers that did not get a compute unit in time (a push on another stream filling the device)
-// are not waited for -- the registration then searches itself; the results are the same either way, only the time differs.
-struct IcpSeed { double d, lb; int k, k2; };        // squared distance to the neighbour, bound, neighbour slot (-1: unresolved), runner-up
-constexpr int ICP_SEED_FLAGS = 16;                  // one word per helper workgroup: the sequence number of the launch whose seeds are complete
-constexpr int ICP_MAX_HELPERS = ICP_SEED_FLAGS;
-constexpr long long ICP_SEED_WAIT_TICKS = 1000;     // of the 100 MHz wall clock: 10 us
+// brings `helpers` more workgroups, each of which runs the same set-up (model, unit directions, padding in ITS OWN LDS) and then the
+// tier-1 window search of step 0 for ICP_HELPER_POINTS of the scene points -- the same function on the same inputs as the registration's
+// own list pass would run.  A helper lane hands its result over as two 8-byte GRANULES {launch number, value}: (1) the bits of the
+// fp32 square root the bound is formed from, (2) neighbour slot | runner-up slot << 16 (0xFFFF: the window could not prove the point),
+// each ONE relaxed agent-scope atomic store -- a write-through store that carries its own tag, so there is no flag, no fence and no
+// barrier on either side (MI355X hand-off recipe R2).  The registering workgroup finishes its own set-up meanwhile; every lane then
+// re-reads ITS points' granules until their tags are this launch's and starts step 0 from neighbour, runner-up and bound -- tier 0
+// confirms them like any other step's (the distance is recomputed from the same coordinates by the same expression, the bound is
+// rebuilt from the same fp32 root: the state after step 0 is bit for bit what the workgroup's own search would have left).  The wait
+// is bounded and per wave: points whose granules did not arrive in time (helpers that got no compute unit: a push on another stream
+// filling the device) simply search in step 0 as they always did; the results are the same either way, only the time differs.
+constexpr int ICP_HELPER_POINTS = 256;              // scene points per helper workgroup: one per lane of its waves 0-3 (one wave per SIMD)
+constexpr int ICP_MAX_HELPERS = 16;
+constexpr long long ICP_SEED_WAIT_TICKS = 600;      // of the 100 MHz wall clock: 6 us
 
 // what the kernel needs again only after the last step (and the trace pointer, once per step by one
 // thread): parked in LDS so that it does not sit in scalar registers through the loop
@@ -561,7 +564,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
       const uint8_t* __restrict__ g_mask, IcpResultDev* __restrict__ out,
       double* __restrict__ trace /* [TSD_ICP_TRACE_MAX][TSD_ICP_TRACE_STRIDE] = pairs, rms, thr_before, state, Tlast (co, si, dX, dY) */, const ScanPostArgs& post,
       const double* __restrict__ g_mnormals /* direct mode */, const double* __restrict__ g_normals /* fused: ray cast */,
-      const IcpSeedArgs seed = IcpSeedArgs{nullptr, nullptr, 0u, 0}, const int role = 0 /* 0: the registration; h > 0: helper h of step 0's searches */,
+      const IcpSeedArgs seed = IcpSeedArgs{nullptr, 0u, 0, 0}, const int role = 0 /* 0: the registration; h > 0: helper h of step 0's searches */,
       int* __restrict__ pairs_out = nullptr /* PAIRS: [steps][cap] winning scene index per model slot, preset to -1 */)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -763,22 +766,22 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     L.mxy[-1 - i] = L.mxy[nM - 1 - (i % nM)];
   }
   if (role > 0) {
-    // helper: step 0's window search for scene points (role - 1) * T + tid, from the staged scene (the registration's own list pass
-    // reads the same coordinates and the same hint from its registers)
+    // helper: step 0's window search for scene points (role - 1) * ICP_HELPER_POINTS + tid, from the staged scene (the registration's
+    // own list pass reads the same coordinates and the same hint from its registers)
     __syncthreads();                   // unit directions and padding in place
-    const int i = (role - 1) * T + tid;
-    if (i < nS) {
+    const int per = T < ICP_HELPER_POINTS ? T : ICP_HELPER_POINTS;
+    const int i = (role - 1) * per + tid;
+    if (tid < per && i < nS) {
       const double2 s = L.stage_s[i];
       int h = L.start[i];
       h = h < 0 ? 0 : (h >= nM ? nM - 1 : h);
       const NnResult r = window_search(L, nM, s.x, s.y, h, a.thr0, a.ccw ? 1.0 : -1.0);
-      IcpSeed sd;
-      sd.d = r.best; sd.lb = lb_from_sq(r.lbsq); sd.k = r.resolved ? r.bk : -1; sd.k2 = r.bk2;
-      seed.seeds[i] = sd;
+      const unsigned int root = __float_as_uint(__builtin_amdgcn_sqrtf((float)r.lbsq));       // lb_from_sq's fp32 root
+      const unsigned int kk = r.resolved ? ((unsigned)r.bk | ((unsigned)r.bk2 << 16)) : 0xFFFFu;
+      const unsigned long long tag = (unsigned long long)seed.seq << 32;
+      __hip_atomic_store(seed.g + i, tag | root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(seed.g + seed.stride + i, tag | kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(seed.flags + (role - 1), seed.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
   const int slot_halves = icp_slot_halves(cap, T, PTL);
@@ -816,21 +819,36 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
   int Rn = 0;                                // register slots of this wave that hold scene points (wave-uniform)
   for (int q = 0; q < R; q++) Rn += (pid[q] - lane < nS) ? 1 : 0;
 
-  // step 0's searches, done by the helper workgroups while this one set itself up (IcpSeed): wait for them -- a bounded wait
-  bool seeded = false;
+  // step 0's searches, done by the helper workgroups while this one set itself up: every lane re-reads its points' granules until
+  // they carry this launch's number (a bounded wait, per wave) and takes neighbour, runner-up and bound from them
   if (!PAIRS && seed.helpers > 0) {
-    if (wave == 0) {
-      const long long t0 = wall_clock64();
-      bool ok;
-      for (;;) {
-        ok = lane >= seed.helpers || __hip_atomic_load(seed.flags + (lane < seed.helpers ? lane : 0), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == seed.seq;
-        if (__all(ok) || wall_clock64() - t0 > ICP_SEED_WAIT_TICKS) break;
-        __builtin_amdgcn_s_sleep(4);
+    const long long t0 = wall_clock64();
+    unsigned long long g0[R], g1[R];
+    bool got[R];
+    for (;;) {
+      bool ok = true;
+#pragma unroll
+      for (int q = 0; q < R; q++) {
+        const int i = have[q] ? pid[q] : 0;
+        g0[q] = __hip_atomic_load(seed.g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        g1[q] = __hip_atomic_load(seed.g + seed.stride + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      if (lane == 0) L.ired[IR_SEEDED] = __all(ok) ? 1 : 0;
+#pragma unroll
+      for (int q = 0; q < R; q++) {
+        got[q] = (unsigned)(g0[q] >> 32) == seed.seq && (unsigned)(g1[q] >> 32) == seed.seq;
+        ok &= got[q] | !have[q];
+      }
+      if (__all(ok) || wall_clock64() - t0 > ICP_SEED_WAIT_TICKS) break;
+      __builtin_amdgcn_s_sleep(2);
     }
-    __syncthreads();
-    seeded = __builtin_amdgcn_readfirstlane(L.ired[IR_SEEDED]) != 0;
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+      const unsigned kk = (unsigned)g1[q];
+      if (have[q] && got[q] && (kk & 0xFFFFu) != 0xFFFFu) {
+        hint[q] = (int)(kk & 0xFFFFu); hint2[q] = (int)(kk >> 16);
+        lb[q] = (double)__uint_as_float((unsigned)g0[q]) * (1.0 - 1e-6);          // lb_from_sq
+      }
+    }
   }
 
   while (state == TSD_ICP_PROCESSING) {
@@ -859,27 +877,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
       wx += P02; wy += P12;
       return !((int)(wx < bmin_x) | (int)(wx > bmax_x) | (int)(wy < bmin_y) | (int)(wy > bmax_y));
     };
-    const bool from_seeds = seeded && iter == 0u;          // (wave-uniform)
-    if (from_seeds) {
-      // step 0 with the helpers' results: exactly what this step's own list pass would have brought back for every point inside the
-      // bounds (neighbour, runner-up, bound, DistanceFilter); an unresolved point goes to the list for the whole-wave search
-      IcpSeed sv[R];
-#pragma unroll
-      for (int q = 0; q < R; q++) sv[q] = seed.seeds[pid[q] < nS ? pid[q] : 0];            // all reads in flight
-#pragma unroll
-      for (int q = 0; q < R; q++) {
-        bd[q] = __builtin_inf(); keep[q] = false; need[q] = false; ent[q] = -1;
-        if (q >= Rn) continue;
-        bool pre = have[q];
-        if (!all_in) pre = pre & inside_bounds(sx[q], sy[q]);
-        if (pre) {
-          if (sv[q].k >= 0) { bd[q] = sv[q].d; hint[q] = sv[q].k; hint2[q] = sv[q].k2; lb[q] = sv[q].lb; keep[q] = bd[q] <= thr; }
-          else need[q] = true;
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < R; q++) mw[q] = L.mxy[hint[q]];
-    } else {
+    {
       double2 mh[R], mh2[R];
 #pragma unroll
       for (int q = 0; q < R; q++) { mh[q] = L.mxy[hint[q]]; mh2[q] = L.mxy[hint2[q]]; }   // all reads in flight
@@ -950,7 +948,6 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     {
       // (the three returning atomics leave together and are taken delivery of once: consumed inside its branch, each one was
       // waited for on the spot -- three LDS round trips in a row, 760 cycles of the step: profiles/r4_icp_critical_path.txt)
-      const int list_flag = from_seeds ? LIST_PAST_WINDOW : 0;      // (a listed point of a seeded step 0: its window was tried by a helper)
       unsigned long long mine[R], was[R];
 #pragma unroll
       for (int q = 0; q < R; q++) { mine[q] = (unsigned long long)__double_as_longlong(bd[q]); was[q] = ~0ull; }
@@ -962,7 +959,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
       for (int q = 0; q < R; q++)
         if (need[q]) {
           ent[q] = atomicAdd(&L.ired[IR_CNT], 1);
-          if (ent[q] < lcap) { L.list_xy[ent[q]] = make_double2(sx[q], sy[q]); L.list_k[ent[q]] = hint[q] | list_flag; }
+          if (ent[q] < lcap) { L.list_xy[ent[q]] = make_double2(sx[q], sy[q]); L.list_k[ent[q]] = hint[q]; }
         }
 #pragma unroll
       for (int q = 0; q < R; q++) tie |= keep[q] & (was[q] == mine[q]);
@@ -993,7 +990,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
           for (int q = 0; q < R; q++)
             if (need[q] && ent[q] >= base && ent[q] < base + lcap) {
               L.list_xy[ent[q] - base] = make_double2(sx[q], sy[q]);
-              L.list_k[ent[q] - base] = hint[q] | (from_seeds ? LIST_PAST_WINDOW : 0);
+              L.list_k[ent[q] - base] = hint[q];
             }
           __syncthreads();
         }
@@ -1293,7 +1290,7 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
       const uint8_t* __restrict__ g_mask, IcpResultDev* __restrict__ out, double* __restrict__ trace, ScanPostArgs post,
       const double* __restrict__ g_mnormals, const double* __restrict__ g_normals, IcpSeedArgs seed)
 {
-  // workgroup 0 registers; workgroups 1 .. seed.helpers do step 0's searches for it (IcpSeed)
+  // workgroup 0 registers; workgroups 1 .. seed.helpers do step 0's searches for it
   icp_workgroup<R, MAXT, PTL>(a, P_dev, cap, g_model, g_scene, g_morig, g_start, g_coords, g_mask_m, g_rays_local, g_ranges, g_mask, out, trace,
                               post, g_mnormals, g_normals, seed, (int)blockIdx.x);
 }
@@ -1307,7 +1304,7 @@ k_icp_pairs(IcpArgs a, int cap, const double* __restrict__ g_model, const double
 {
   ScanPostArgs post{};
   icp_workgroup<R, MAXT, false, true>(a, nullptr, cap, g_model, g_scene, g_morig, g_start, nullptr, nullptr, nullptr, nullptr, nullptr, out, trace,
-                                      post, nullptr, nullptr, IcpSeedArgs{nullptr, nullptr, 0u, 0}, 0, pairs_out);
+                                      post, nullptr, nullptr, IcpSeedArgs{nullptr, 0u, 0, 0}, 0, pairs_out);
 }
 
 // the registrations of a batch of robots in ONE launch (tsd_batch_begin): workgroup x = entry x, fused mode only (model and
@@ -1316,7 +1313,7 @@ template <int R, int MAXT, bool PTL>
 __global__ void __launch_bounds__(MAXT)
 k_icp_batch(const IcpBatchEntry* __restrict__ entries, int cap, int n_entries)
 {
-  // workgroups 0 .. n - 1 register entry x; workgroup n * h + x (h >= 1) is helper h of entry x (IcpSeed)
+  // workgroups 0 .. n - 1 register entry x; workgroup n * h + x (h >= 1) is helper h of entry x
   const IcpBatchEntry& e = entries[blockIdx.x % (unsigned)n_entries];
   const int role = (int)(blockIdx.x / (unsigned)n_entries);
   if (e.rc_flag) {
@@ -1355,20 +1352,21 @@ static int icp_cap_for(int n)
   return cap;
 }
 
-// helper workgroups of a registration with n scene points in workgroups of T threads (IcpSeed): one point per helper lane
+// helper workgroups of a registration with n scene points in workgroups of T threads (see ICP_HELPER_POINTS)
 static std::atomic<unsigned int> g_seed_seq{1u};
 int icp_helpers_for(const tsd_ctx* ctx, int n, int T)
 {
   if (!ctx->icp_helpers) return 0;
-  const int h = (n + T - 1) / T;
-  return h > ICP_MAX_HELPERS ? ICP_MAX_HELPERS : h;
+  const int per = T < ICP_HELPER_POINTS ? T : ICP_HELPER_POINTS;
+  const int h = (n + per - 1) / per;
+  return h > ICP_MAX_HELPERS ? 0 : h;                // (more points than the helpers reach: the registration searches itself)
 }
-size_t icp_seed_bytes(int points) { return sizeof(unsigned int) * ICP_SEED_FLAGS + sizeof(IcpSeed) * (size_t)points; }
-IcpSeedArgs icp_seed_args(void* buf, int helpers)
+size_t icp_seed_bytes(int points) { return 2 * sizeof(unsigned long long) * (size_t)((points + 63) & ~63); }
+IcpSeedArgs icp_seed_args(void* buf, int points, int helpers)
 {
   IcpSeedArgs sa;
-  sa.flags = reinterpret_cast<unsigned int*>(buf);
-  sa.seeds = reinterpret_cast<IcpSeed*>(reinterpret_cast<char*>(buf) + sizeof(unsigned int) * ICP_SEED_FLAGS);
+  sa.g = reinterpret_cast<unsigned long long*>(buf);
+  sa.stride = (points + 63) & ~63;                   // the second granules follow the first (as laid out by icp_seed_bytes(points))
   unsigned int q = g_seed_seq.fetch_add(1u);
   if (q == 0u) q = g_seed_seq.fetch_add(1u);         // (0 is what a fresh buffer holds)
   sa.seq = q; sa.helpers = buf ? helpers : 0;
@@ -1419,8 +1417,9 @@ static int launch_icp_shape_est(tsd_ctx* ctx, const IcpArgs& a, int n, int cap, 
   // the 64-byte store per step
   double* trace_buf = tg && tg->trace ? tg->trace : ctx->d_icp_trace;
   if (post.st) trace_buf = nullptr;
-  void* seed_buf = tg && tg->icp_seed ? tg->icp_seed : ctx->d_icp_seed;
-  const IcpSeedArgs sa = icp_seed_args(seed_buf, icp_helpers_for(ctx, n, T));
+  const bool own_seed = tg && tg->icp_seed;
+  const IcpSeedArgs sa = icp_seed_args(own_seed ? tg->icp_seed : ctx->d_icp_seed, own_seed ? tg->icp_seed_points : TSD_MAX_ICP_POINTS,
+                                       icp_helpers_for(ctx, n, T));
   hipExtLaunchKernelGGL((k_icp<R, MAXT, PTL>), dim3(1 + sa.helpers), dim3(T), lds, launch_stream(ctx), t.a, t.b, 0, a, P_dev, cap, ctx->d_model, ctx->d_scene,
                      ctx->d_morig, ctx->d_start, tg && tg->coords ? tg->coords : ctx->d_coords, tg && tg->mask_m ? tg->mask_m : ctx->d_mask_m,
                      d_rays_local ? d_rays_local : ctx->d_rays_local, d_ranges ? d_ranges : ctx->d_ranges,
@@ -1540,11 +1539,12 @@ int launch_icp_batch(tsd_ctx* ctx, hipStream_t stream, const IcpBatchEntry* host
 
 size_t icp_lds_bytes() { return icp_lds_bytes_for(TSD_MAX_ICP_POINTS, 256); }
 
-// seed arguments of one entry of a batch (tsd_batch_begin): the workgroup shape launch_icp_batch will choose for `batch_beams`
+// seed arguments of one entry of a batch (tsd_batch_begin): the workgroup shape launch_icp_batch will choose for `batch_beams`;
+// `buf` was sized icp_seed_bytes(beams)
 IcpSeedArgs icp_batch_seed_args(const tsd_ctx* ctx, void* buf, int beams, int batch_beams)
 {
   const int T = batch_beams <= 3 * 512 ? icp_threads_for(batch_beams, 3, 512) : icp_threads_for(batch_beams, 8, 256);
-  return icp_seed_args(buf, icp_helpers_for(ctx, beams, T));
+  return icp_seed_args(buf, beams, icp_helpers_for(ctx, beams, T));
 }
 
 }  // namespace tsd

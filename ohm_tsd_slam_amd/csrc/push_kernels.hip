@@ -240,7 +240,7 @@ constexpr int TOT_FIELDS = 8;   // cells updated, range pass, update, new, new f
 // k_push_update's tile queue: TICKET_HEADS counters, each on a 128-byte line of its own (one word shared by every workgroup
 // saturates at ~88 returning atomics per microsecond, MI355X_MICROARCH.md "dequeue": a 10 000-tile push would take 120 us for its
 // tickets alone).  Head h hands out the tiles G + h + TICKET_HEADS * k beyond the G that the G workgroups start with.
-constexpr int CNT_U = 0, CNT_O = 1, TICKET_HEADS = 32, TICKET_STRIDE = 32 /* words */, CNT_TICKET = 32;
+constexpr int CNT_U = 0, CNT_O = 1, CNT_H = 2 /* UPDATE tiles k_push_halo has work for (list_h) */, TICKET_HEADS = 32, TICKET_STRIDE = 32 /* words */, CNT_TICKET = 32;
 constexpr int CNT_WORDS = CNT_TICKET + TICKET_HEADS * TICKET_STRIDE;
 // What k_push_classify leaves for the workgroup of an UPDATE tile: one 128-byte record (a cache line, at the entry's own index),
 // fetched as ONE vector register per wave -- lane i holds word i -- and unpacked with v_readlane.
@@ -315,7 +315,7 @@ template <int CLASSIFY_BLOCK>
 __global__ void __launch_bounds__(CLASSIFY_BLOCK)
 k_push_classify(GridDev g, const PushArgs* __restrict__ a_dev, const char* __restrict__ rmq_buf,
                 uint32_t* __restrict__ tile_rec, const uint8_t* __restrict__ dirty, uint32_t* __restrict__ tile_totals,
-                uint32_t* __restrict__ list, PushListAux* __restrict__ list_aux,
+                uint32_t* __restrict__ list, PushListAux* __restrict__ list_aux, uint32_t* __restrict__ list_h,
                 unsigned int* __restrict__ list_cnt /* [2][CNT_WORDS] */, int parity, int tx0, int ty0, int ntx, int nty)
 {
   // FOUR lanes per tile, one corner each: the four back-projections (an fp64 atan2 apiece, by far the longest chain of this
@@ -327,7 +327,7 @@ k_push_classify(GridDev g, const PushArgs* __restrict__ a_dev, const char* __res
   const bool owner = corner == 0;
   const int t = blockIdx.x * (CLASSIFY_BLOCK / 4) + ((int)threadIdx.x >> 2);
   if (t < 16 && owner) {      // the next push's counters (nobody uses them now)
-    if (t < 2) list_cnt[CNT_WORDS * (parity ^ 1) + t] = 0u;
+    if (t < 3) list_cnt[CNT_WORDS * (parity ^ 1) + t] = 0u;
     list_cnt[CNT_WORDS * (parity ^ 1) + CNT_TICKET + TICKET_STRIDE * t] = 0u;
     list_cnt[CNT_WORDS * (parity ^ 1) + CNT_TICKET + TICKET_STRIDE * (t + 16)] = 0u;
   }
@@ -444,24 +444,28 @@ k_push_classify(GridDev g, const PushArgs* __restrict__ a_dev, const char* __res
   // List slots: the waves' counts meet in LDS and ONE lane of the workgroup draws the slots of all 256 tiles with one atomic per
   // list.  (One atomic per wave, round 2: every wave of the grid hit the same word with a RETURNING atomic, and one word hands out
   // ~88 of those per microsecond -- the 2 400 waves of a cfg 3 window spent 20 us of the kernel's 21 queueing for list slots.)
+  // (hb: the UPDATE tiles k_push_halo has work for -- materialised by this push, or written by freeFootprint since the last one; what a
+  // plain UPDATE tile changes of its edges its own workgroup mirrors into the neighbours' halos.  That kernel walks list_h + the others.)
   const unsigned long long ub = __ballot(kind == KIND_UPDATE), ob = __ballot(kind != 0u && kind != KIND_UPDATE);
-  __shared__ unsigned int s_wu[CLASSIFY_BLOCK / 64], s_wo[CLASSIFY_BLOCK / 64], s_base[2];
-  if (lane == 0) { s_wu[wave] = (unsigned int)__popcll(ub); s_wo[wave] = (unsigned int)__popcll(ob); }
+  const unsigned long long hb = __ballot(kind == KIND_UPDATE && (t_flag == 0 || t_dirty != 0));
+  __shared__ unsigned int s_wu[CLASSIFY_BLOCK / 64], s_wo[CLASSIFY_BLOCK / 64], s_wh[CLASSIFY_BLOCK / 64], s_base[3];
+  if (lane == 0) { s_wu[wave] = (unsigned int)__popcll(ub); s_wo[wave] = (unsigned int)__popcll(ob); s_wh[wave] = (unsigned int)__popcll(hb); }
   lds_barrier();             // (LDS only: a __syncthreads() would also sit out every wave's stores and counters above)
-  if (threadIdx.x == 0 || threadIdx.x == 64) {
-    // lane 0 of wave 0 draws the UPDATE slots, lane 0 of wave 1 the others': the two returning atomics are in flight together
-    const bool upd = threadIdx.x == 0;
+  if (lane == 0 && wave < 3) {
+    // lane 0 of wave 0 draws the UPDATE slots, lane 0 of wave 1 the others', lane 0 of wave 2 the halo list's: the returning atomics are in flight together
+    const unsigned int* cnt_w = wave == 0 ? s_wu : (wave == 1 ? s_wo : s_wh);
     unsigned int tot = 0u;
-    for (int w = 0; w < CLASSIFY_BLOCK / 64; w++) tot += upd ? s_wu[w] : s_wo[w];
-    s_base[upd ? 0 : 1] = tot ? atomicAdd(&list_cnt[CNT_WORDS * parity + (upd ? CNT_U : CNT_O)], tot) : 0u;
+    for (int w = 0; w < CLASSIFY_BLOCK / 64; w++) tot += cnt_w[w];
+    s_base[wave] = tot ? atomicAdd(&list_cnt[CNT_WORDS * parity + (wave == 0 ? CNT_U : (wave == 1 ? CNT_O : CNT_H))], tot) : 0u;
   }
   lds_barrier();
   if (ub | ob) {
-    unsigned int base_u = s_base[0], base_o = s_base[1];
-    for (int w = 0; w < wave; w++) { base_u += s_wu[w]; base_o += s_wo[w]; }
+    unsigned int base_u = s_base[0], base_o = s_base[1], base_h = s_base[2];
+    for (int w = 0; w < wave; w++) { base_u += s_wu[w]; base_o += s_wo[w]; base_h += s_wh[w]; }
     const unsigned long long lt = (1ull << lane) - 1ull;
     const uint32_t word = (uint32_t)p | far_flag | (kind << KIND_SHIFT);
     if (kind != 0u && kind != KIND_UPDATE) list[(unsigned)g.tiles - 1u - (base_o + (unsigned)__popcll(ob & lt))] = word;
+    if (kind == KIND_UPDATE && (t_flag == 0 || t_dirty != 0)) list_h[base_h + (unsigned)__popcll(hb & lt)] = word;
     if (kind == KIND_UPDATE) {
       const unsigned int slot = base_u + (unsigned)__popcll(ub & lt);
       list[slot] = word;
@@ -1100,8 +1104,8 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
 // the two row copies; lane 0 / lane 32: the corner cells.
 __global__ void __launch_bounds__(256)
 k_push_halo(GridDev g, uint8_t* __restrict__ dirty, unsigned long long* __restrict__ pushes,
-            const PushArgs* __restrict__ a_dev, const uint32_t* __restrict__ list, const uint32_t* __restrict__ tile_rec,
-            const unsigned int* __restrict__ list_cnt, int parity, double cx, double cy, double slack)
+            const PushArgs* __restrict__ a_dev, const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_h,
+            const uint32_t* __restrict__ tile_rec, const unsigned int* __restrict__ list_cnt, int parity, double cx, double cy, double slack)
 {
   const int lane = threadIdx.x & 63;
   const unsigned int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1114,14 +1118,16 @@ k_push_halo(GridDev g, uint8_t* __restrict__ dirty, unsigned long long* __restri
       if (!(fabs(sx - cx) <= slack && fabs(sy - cy) <= slack)) pushes[1] += 1ull;
     }
   }
-  const unsigned int n_u = list_cnt[CNT_WORDS * parity + CNT_U], n_list = n_u + list_cnt[CNT_WORDS * parity + CNT_O];
-  const uint32_t first = list[wv];                            // speculative: arrives with the list lengths
+  // the tiles with work here: UPDATE tiles materialised by this push or written by freeFootprint (list_h), emptied and halo-only tiles
+  // (the back of `list`).  A plain UPDATE tile's edge changes were mirrored by its own workgroup.
+  const unsigned int n_u = list_cnt[CNT_WORDS * parity + CNT_H], n_list = n_u + list_cnt[CNT_WORDS * parity + CNT_O];
+  const uint32_t first = list_h[wv];                          // speculative: arrives with the list lengths
   const int PX = g.PX;
   const bool colhalf = lane < TILE_DIM;
   const int i = lane & 31;
   for (unsigned int li = wv; li < n_list; li += gridDim.x * 4) {
-    // UPDATE tiles from the front of the array, the others (emptied, dirtied) from its back
-    const uint32_t entry = li < n_u ? ((li == wv) ? first : list[li]) : list[(unsigned)g.tiles - 1u - (li - n_u)];
+    // UPDATE tiles from the halo list, the others (emptied, dirtied) from the back of the work list
+    const uint32_t entry = li < n_u ? ((li == wv) ? first : list_h[li]) : list[(unsigned)g.tiles - 1u - (li - n_u)];
     const int p = (int)(entry & LIST_TILE_MASK);
     const int px = p % PX, py = p / PX;
     const bool hasR = px < PX - 1, hasU = py < PX - 1, hasL = px > 0, hasD = py > 0;
@@ -1454,11 +1460,11 @@ int launch_push(tsd_ctx* ctx, const PushArgs& a, double cx, double cy, double sl
     ScopedKernelTimer t(ctx, "push_classify");
     if (n_window <= 12288)
       hipExtLaunchKernelGGL((k_push_classify<256>), dim3((n_window + 63) / 64), dim3(256), 0, stream, t.a, t.b, 0, g, a_dev, rmq,
-                         ctx->d_tile_rec, ctx->d_dirty, ctx->d_tile_totals, ctx->d_list, reinterpret_cast<PushListAux*>(ctx->d_list_aux), ctx->d_list_cnt, parity,
+                         ctx->d_tile_rec, ctx->d_dirty, ctx->d_tile_totals, ctx->d_list, reinterpret_cast<PushListAux*>(ctx->d_list_aux), ctx->d_list_h, ctx->d_list_cnt, parity,
                          box.x0, box.y0, ntx, nty);
     else
       hipExtLaunchKernelGGL((k_push_classify<1024>), dim3((n_window + 255) / 256), dim3(1024), 0, stream, t.a, t.b, 0, g, a_dev, rmq,
-                         ctx->d_tile_rec, ctx->d_dirty, ctx->d_tile_totals, ctx->d_list, reinterpret_cast<PushListAux*>(ctx->d_list_aux), ctx->d_list_cnt, parity,
+                         ctx->d_tile_rec, ctx->d_dirty, ctx->d_tile_totals, ctx->d_list, reinterpret_cast<PushListAux*>(ctx->d_list_aux), ctx->d_list_h, ctx->d_list_cnt, parity,
                          box.x0, box.y0, ntx, nty);
   }
   TSD_HIP_CHECK(ctx, hipGetLastError());
@@ -1478,10 +1484,13 @@ int launch_push(tsd_ctx* ctx, const PushArgs& a, double cx, double cy, double sl
   TSD_HIP_CHECK(ctx, hipGetLastError());
   {
     ScopedKernelTimer t(ctx, "push_halo");
-    constexpr int HALO_WAVES = 16384;
-    const int n_waves = n_window < HALO_WAVES ? n_window : HALO_WAVES;        // one wave per listed tile; a longer list is looped over
+    // one wave per tile of the halo list (tiles materialised / emptied / written by freeFootprint: a few dozen per push once the map
+    // stands, every tile of the window in the first push); a longer list is looped over.  (Round 4 launched one wave per WINDOW tile:
+    // 6 745 waves to move 0.35 MB at cfg 2.)
+    constexpr int HALO_WAVES = 2048;
+    const int n_waves = n_window < HALO_WAVES ? n_window : HALO_WAVES;
     hipExtLaunchKernelGGL(k_push_halo, dim3((n_waves + 3) / 4), dim3(256), 0, stream, t.a, t.b, 0, g, ctx->d_dirty, ctx->d_pushes,
-                       a_dev, ctx->d_list, ctx->d_tile_rec, ctx->d_list_cnt, parity, cx, cy, slack + g.cs);
+                       a_dev, ctx->d_list, ctx->d_list_h, ctx->d_tile_rec, ctx->d_list_cnt, parity, cx, cy, slack + g.cs);
   }
   TSD_HIP_CHECK(ctx, hipGetLastError());
   return TSD_OK;

@@ -111,7 +111,7 @@ struct LaunchTarget {
   hipStream_t stream = nullptr;                                       // ray cast + registration
   double* coords = nullptr; double* normals = nullptr; uint8_t* mask_m = nullptr;   // ray-cast outputs
   IcpResultDev* icp_res = nullptr; double* trace = nullptr;
-  void* icp_seed = nullptr;                                           // the registration's helper hand-off (icp_kernels.hip: IcpSeed)
+  void* icp_seed = nullptr; int icp_seed_points = 0;                  // the registration's helper hand-off (icp_seed_bytes(points))
   char* rmq = nullptr;                                                // range-query tables of the scan's push
   hipEvent_t rc_done = nullptr;                                       // launch_raycast: completes with the ray cast itself (the kernel's own stop
   bool rc_done_used = false;                                          // event: no marker behind it); used = false when the dispatch is being timed
@@ -130,9 +130,9 @@ struct TablesBatchEntry {
   double phi_min, ang_res;
   int beams, pad;
 };
-// step 0's searches of a registration, done by helper workgroups (icp_kernels.hip: IcpSeed): flags, results, launch number, helpers
-struct IcpSeed;
-struct IcpSeedArgs { unsigned int* flags; IcpSeed* seeds; unsigned int seq; int helpers; };
+// step 0's searches of a registration, done by helper workgroups (icp_kernels.hip, ICP_HELPER_POINTS): the hand-off granules
+// ([2][stride] 8-byte {launch number, value}), this launch's number, the helper workgroups the launch brings
+struct IcpSeedArgs { unsigned long long* g; unsigned int seq; int helpers; int stride; };
 struct IcpBatchEntry {
   IcpArgs a;
   const double* P_dev; const double* coords; const uint8_t* mask_m; const double* rays_local; const double* ranges;
@@ -189,6 +189,7 @@ struct tsd_ctx {
   // tile window of the push launches: what the last push covered and what freeFootprint dirtied since
   tsd::TileBox box_prev{}, box_dirty{};
   uint32_t* d_list = nullptr;               // [tiles] work list of the current push (tile | kind << 28)
+  uint32_t* d_list_h = nullptr;             // [tiles] the UPDATE tiles of that list k_push_halo has work for (materialised by the push, or dirty)
   char* d_list_aux = nullptr;               // [tiles] PushListAux of every list entry (push_kernels.hip): beam window, partition weight,
                                             // the linear forms of k_push_update's beam estimate
   tsd::PushArgs* d_push_args = nullptr;     // arguments of an unfused tsd_push (the fused scan keeps them in the sensor state)
