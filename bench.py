@@ -49,6 +49,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+SPREAD_STEPS = 200           # scans of the pass that times EVERY registration (ms_icp_iterate_spread: p50 / p99 / max)
 MERGE_EVERY = 50             # occupancy merge period in scans (cfg 4/5)
 CALIB_DOUBLES = 8 << 20      # k_calib_rmw: 2 arrays x 8 Mi doubles -> 128 MiB read + 128 MiB written per launch
 PROFILE_TAG = "r4"           # profiles/<tag>_<workload>_pmc.json: the committed rocprofv3 PMC summary of this round
@@ -223,7 +224,10 @@ def main():
     ap.add_argument("--robots", type=int, default=1)
     ap.add_argument("--pg-backend", choices=["gloo", "nccl"], default="gloo",
                     help="torch.distributed backend of the control plane (rendezvous, barrier, max over ranks); the occupancy merge is RCCL either way")
-    ap.add_argument("--no-lookahead", action="store_true", help="do not announce the next scan to the localiser (no staging ahead)")
+    ap.add_argument("--lookahead", action="store_true", help="replay mode as the line's own: announce scan k+1 to the localiser during registration k "
+                    "(staged on the device ahead).  Default: no announcement -- what a sensor_msgs/LaserScan subscriber sees; the replay "
+                    "rate is reported beside it as value_lookahead")
+    ap.add_argument("--no-lookahead", action="store_true", help="(the default since round 5; accepted for old command lines)")
     ap.add_argument("--python-feeders", action="store_true", help="--robots: Python feeder threads instead of the native replay tsd_node_play")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scans", type=int, default=200, help="scans of the CPU baseline per thread count (bounded by --steps): ~8 s of CPU work at the default")
@@ -246,8 +250,8 @@ def main():
                          "fixed tsdpdf_seed; stages_ms.tsdpdf = the scoring kernels")
     ap.add_argument("--no-stream", action="store_true", help="skip the stream-bandwidth measurement (roofline.peak_measured): profile passes, whose "
                                                             "calibration counts k_calib_rmw launches of ONE known size")
-    ap.add_argument("--no-second-pass", action="store_true", help="skip the comparison passes (value_no_lookahead, value_async_mapping)")
-    ap.add_argument("--comparison-passes", type=int, default=3, help="passes behind value_no_lookahead / value_async_mapping (median reported)")
+    ap.add_argument("--no-second-pass", action="store_true", help="skip the comparison passes (value_repeat, value_lookahead, value_async_mapping, the spread pass)")
+    ap.add_argument("--comparison-passes", type=int, default=3, help="passes behind value_repeat / value_lookahead / value_async_mapping (median reported)")
     ap.add_argument("--async-mapping", action="store_true",
                     help="`value` with the facade's async_mapping = 1 (the push beside the next registration, the next ray cast one "
                          "push behind: the reference's own ThreadMapping is asynchronous); default: strict order, and the "
@@ -531,7 +535,7 @@ def run_slam(args, gc, geo, scene, K, W, every, every_upd, every_icp, device, ra
     lanes = synth.free_lanes(world, R, 0.06 * leg, clearance=0.6) if R > 1 else [(float(world.start[0]), float(world.start[1]))]
     poses, scans = [], []
     for r in range(R):
-        p = synth.trajectory(world, 1 + W + K, leg=leg)
+        p = synth.trajectory(world, 1 + W + max(K, SPREAD_STEPS if R == 1 else K), leg=leg)
         p[:, 1] += lanes[r][1] - world.start[1]
         poses.append(p); scans.append(synth.scans_for(world, geo, p))
     scans32 = [np.ascontiguousarray(np.stack(sc), dtype=np.float32) for sc in scans]
@@ -558,9 +562,10 @@ def run_slam(args, gc, geo, scene, K, W, every, every_upd, every_icp, device, ra
         params["registration_mode"] = args.registration_mode
         params["tsdpdf_seed"] = 20261003
 
-    def one_pass(lookahead: bool, full: bool, async_mapping: bool = False):
+    def one_pass(lookahead: bool, full: bool, async_mapping: bool = False, K=K, every_icp_dispatch: bool = False):
         """init + W warm-up scans + K timed scans on a fresh node; `full`: with the occupancy merge (N > 1), the stage table and
-        everything else the line reports; otherwise just the rate (the comparison passes)."""
+        everything else the line reports; otherwise just the rate (the comparison passes).  every_icp_dispatch: HIP events around EVERY
+        registration of the region, returned as samples (the spread pass: its rate is not reported, the events cost stream time)."""
         node = facade.SlamNode(dict(params, async_mapping=1) if async_mapping else params, device=device, synchronous=True)
         grid = node.grid()
         merger = None
@@ -633,7 +638,10 @@ def run_slam(args, gc, geo, scene, K, W, every, every_upd, every_icp, device, ra
                       f"{int((merged != want).sum())} cells", file=sys.stderr)
             warm_merge = merger.merge_times()    # (the warm-up merges -- RCCL's channel set-up -- are not what a merge costs)
         grid.push_stats_total(reset=True)
-        grid.profile(True, kernels=f"push_update:{every_upd},icp:{every_icp},all/{every}")      # HIP events on every n-th dispatch of each kernel
+        if every_icp_dispatch:
+            grid.profile(True, kernels="icp:1")
+        else:
+            grid.profile(True, kernels=f"push_update:{every_upd},icp:{every_icp},all/{every}")      # HIP events on every n-th dispatch of each kernel
         grid.profile_reset()
         if dist is not None and full:
             torch.cuda.synchronize()
@@ -672,9 +680,10 @@ def run_slam(args, gc, geo, scene, K, W, every, every_upd, every_icp, device, ra
             dist.barrier()
         pygc.enable()
         if not full:
+            samples = grid.profile_samples("icp") if every_icp_dispatch else None
             grid.profile(False)
             node.close()
-            return {"value": R * K / elapsed}
+            return {"value": R * K / elapsed, "icp_samples_ms": samples}
         upd_ms, upd_launches = grid.profile_get("push_update")
         stages = stage_table(grid, K)
         icp_min, icp_max, icp_std = grid.profile_spread("icp")
@@ -738,8 +747,9 @@ def run_slam(args, gc, geo, scene, K, W, every, every_upd, every_icp, device, ra
                        "stage_note": ("the batched registration kernel is launched ahead of its ray casts and waits for them on the device: "
                                       "its dispatch time (stages_ms.icp, ms_icp_iterate) includes that wait") if R > 1 else None},
             "ms_icp_iterate": stages["icp"], "ms_icp_per_iteration": (stages["icp"] / 30.0) if stages["icp"] else None,
-            "ms_icp_iterate_spread": {"min": icp_min, "max": icp_max, "std": icp_std, "samples": icp_n,
-                                      "max_over_mean": (icp_max / stages["icp"]) if stages["icp"] else None, "of": "the sampled dispatches"},
+            "ms_icp_iterate_sampled": {"min": icp_min, "max": icp_max, "std": icp_std, "samples": icp_n,
+                                       "max_over_mean": (icp_max / stages["icp"]) if stages["icp"] else None,
+                                       "of": "the dispatches sampled inside the timed region"},
             "ms_raycast": stages["raycast"],
             "ms_push_kernels": sum(v for k, v in stages.items() if k.startswith("push") and v is not None),
             "stages_ms": stages, "stages_sum_ms_per_scan": stage_sum,
@@ -764,21 +774,37 @@ def run_slam(args, gc, geo, scene, K, W, every, every_upd, every_icp, device, ra
         node.close()
         return out
 
-    out = one_pass(not args.no_lookahead, True, args.async_mapping and R == 1)
+    out = one_pass(args.lookahead, True, args.async_mapping and R == 1)
     out["config"]["mapping"] = ("asynchronous: the push runs beside the next registration, the next ray cast is one push behind"
                                 if (args.async_mapping and R == 1) else "strict: the next ray cast sees this scan's push")
-    if R == 1 and not use_dist and not args.no_lookahead and not args.no_second_pass:
-        # the same K scans on a fresh node WITHOUT announcing the next scan: what a live 40 Hz scanner gets (it never has the
-        # next LaserScan queued; the reference's localiser takes the newest scan, ThreadLocalize.cpp:319-332)
-        # (three passes each, median + spread: one pass of 20 scans on a fresh node is not a number -- VERDICT r3)
+    if R == 1 and not use_dist and not args.no_second_pass:
+        # `value` is the rate a live scanner's subscriber gets: scan k+1 is handed over when scan k's result has been seen (it never has the
+        # next LaserScan queued; the reference's localiser takes the newest scan, ThreadLocalize.cpp:319-332).  Beside it, each the
+        # median of three passes on fresh nodes with its spread (one pass of 20 scans on a fresh node is not a number -- VERDICT r3):
+        #   value_repeat          the line's own configuration again
+        #   value_lookahead       a replay: scan k+1 announced during registration k and staged on the device ahead
+        #   value_async_mapping   the mapper asynchronous like the reference's (ThreadMapping.cpp:51-76): a different, equally legitimate
+        #                         order of the same work (tests/test_gpu_async_mapping.py) -- never reported as `value`
         def med3(*a):
             v = sorted(one_pass(*a)["value"] for _ in range(args.comparison_passes))
             return v[len(v) // 2], {"min": v[0], "max": v[-1], "passes": len(v)}
-        out["value_no_lookahead"], out["value_no_lookahead_spread"] = med3(False, False, args.async_mapping)
+        out["value_repeat"], out["value_repeat_spread"] = med3(args.lookahead, False, args.async_mapping)
+        if not args.lookahead:
+            out["value_lookahead"], out["value_lookahead_spread"] = med3(True, False, args.async_mapping)
+        else:
+            out["value_no_lookahead"], out["value_no_lookahead_spread"] = med3(False, False, args.async_mapping)
         if not args.async_mapping:
-            # ... and with the mapper asynchronous like the reference's (ThreadMapping.cpp:51-76): a different, equally legitimate order
-            # of the same work (tests/test_gpu_async_mapping.py) -- reported beside `value`, never as it
-            out["value_async_mapping"], out["value_async_mapping_spread"] = med3(True, False, True)
+            out["value_async_mapping"], out["value_async_mapping_spread"] = med3(args.lookahead, False, True)
+        # the registration's tail: EVERY dispatch of k_icp over SPREAD_STEPS scans (HIP events around each one; a pass of its own,
+        # because two event records per launch cost stream time)
+        sp = one_pass(args.lookahead, False, args.async_mapping, K=max(K, SPREAD_STEPS), every_icp_dispatch=True)["icp_samples_ms"]
+        if sp is not None and len(sp):
+            sp = np.sort(np.asarray(sp, dtype=np.float64))
+            out["ms_icp_iterate_spread"] = {
+                "p50": float(sp[len(sp) // 2]), "p90": float(sp[int(0.9 * (len(sp) - 1))]), "p99": float(sp[int(0.99 * (len(sp) - 1))]),
+                "max": float(sp[-1]), "min": float(sp[0]), "mean": float(sp.mean()), "samples": int(len(sp)),
+                "max_over_mean": float(sp[-1] / sp.mean()),
+                "of": f"every dispatch of k_icp over {max(K, SPREAD_STEPS)} scans of the same trajectory (a pass of its own)"}
     return out
 
 

@@ -366,6 +366,8 @@ int tsd_profile_reset(tsd_ctx* ctx);
 int tsd_profile_get(tsd_ctx* ctx, const char* kernel, double* total_ms, int* launches);
 /* spread of the timed dispatches of one kernel since the last reset: shortest, longest, standard deviation (ms) */
 int tsd_profile_get_spread(tsd_ctx* ctx, const char* kernel, double* min_ms, double* max_ms, double* std_ms);
+/* the timed dispatches themselves, in launch order (ms; at most 65 536 are kept): copies up to `cap` of them, returns how many there are */
+int tsd_profile_get_samples(tsd_ctx* ctx, const char* kernel, float* ms_out, int cap);
 
 /* Counter calibration for profiles/: `reps` launches of k_calib_rmw, a read-modify-write of two arrays
  * of n_doubles fp64 values with the push kernel's 8-byte-per-lane access shape (known traffic: 16 B read

@@ -195,6 +195,7 @@ ABI = {
     "tsd_push_stats_total": (C.c_int, [C.c_void_p, C.POINTER(PushStats), C.POINTER(C.c_int64), C.c_int]),
     "tsd_profile_get": (C.c_int, [C.c_void_p, C.c_char_p, _dp, _ip]),
     "tsd_profile_get_spread": (C.c_int, [C.c_void_p, C.c_char_p, _dp, _dp, _dp]),
+    "tsd_profile_get_samples": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_float), C.c_int]),
 }
 
 _lib = None
@@ -468,6 +469,13 @@ class TsdGridDevice:
         mn, mx, sd = C.c_double(0.0), C.c_double(0.0), C.c_double(0.0)
         self.lib.tsd_profile_get_spread(self.h, kernel.encode(), C.byref(mn), C.byref(mx), C.byref(sd))
         return mn.value, mx.value, sd.value
+
+    def profile_samples(self, kernel: str, cap: int = 65536) -> np.ndarray:
+        """the timed dispatches of one kernel since the last reset, in launch order (ms)"""
+        buf = np.zeros(cap, dtype=np.float32)
+        n = self.lib.tsd_profile_get_samples(self.h, kernel.encode(), buf.ctypes.data_as(C.POINTER(C.c_float)), cap)
+        self._check(min(n, 0), "tsd_profile_get_samples")
+        return buf[: min(n, cap)].copy()
 
     def profile_get(self, kernel: str):
         ms = C.c_double(0.0)

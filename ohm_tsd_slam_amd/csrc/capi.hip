@@ -80,6 +80,7 @@ void drain_timers(tsd_ctx* ctx)
         if ((double)ms < kv.second.min_ms) kv.second.min_ms = (double)ms;
         if ((double)ms > kv.second.max_ms) kv.second.max_ms = (double)ms;
         kv.second.launches++;
+        if (kv.second.samples.size() < KERNEL_TIMER_SAMPLES) kv.second.samples.push_back(ms);
       }
       ctx->event_pool.push_back(pr.first);     // recycled: no event creation in steady state
       ctx->event_pool.push_back(pr.second);
@@ -1273,6 +1274,19 @@ int tsd_profile_get_spread(tsd_ctx* ctx, const char* kernel, double* min_ms, dou
   if (max_ms) *max_ms = have ? it->second.max_ms : 0.0;
   if (std_ms) *std_ms = std::sqrt(var);
   return TSD_OK;
+}
+
+int tsd_profile_get_samples(tsd_ctx* ctx, const char* kernel, float* ms_out, int cap)
+{
+  if (!ctx || !kernel || cap < 0 || (cap > 0 && !ms_out)) return TSD_E_ARG;
+  hipStreamSynchronize(ctx->stream);
+  drain_timers(ctx);
+  std::lock_guard<std::mutex> lk(ctx->misc_mutex);
+  auto it = ctx->timers.find(kernel);
+  if (it == ctx->timers.end()) return 0;
+  const int n = (int)std::min(it->second.samples.size(), (size_t)cap);
+  for (int i = 0; i < n; i++) ms_out[i] = it->second.samples[(size_t)i];
+  return (int)it->second.samples.size();
 }
 
 int tsd_push_stats_total(tsd_ctx* ctx, tsd_push_stats* total, int64_t* pushes, int reset)

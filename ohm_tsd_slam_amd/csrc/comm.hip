@@ -62,6 +62,16 @@ int tsd_comm_unique_id(char id_out[TSD_COMM_ID_BYTES])
   return TSD_OK;
 }
 
+// what tsd_comm_create has built so far, given back on any of its failure paths (and by tsd_comm_destroy)
+static void comm_release(tsd_comm* c)
+{
+  if (c->ev_extracted) hipEventDestroy(c->ev_extracted);
+  if (c->ev_reduced) hipEventDestroy(c->ev_reduced);
+  if (c->cstream) hipStreamDestroy(c->cstream);
+  if (c->d_map) hipFree(c->d_map);
+  delete c;
+}
+
 tsd_comm* tsd_comm_create(tsd_ctx* ctx, int world_size, int rank, const char id_in[TSD_COMM_ID_BYTES])
 {
   if (!ctx || !id_in || world_size < 1 || rank < 0 || rank >= world_size) return nullptr;
@@ -69,29 +79,29 @@ tsd_comm* tsd_comm_create(tsd_ctx* ctx, int world_size, int rank, const char id_
   if (!c) return nullptr;
   c->ctx = ctx; c->world = world_size; c->rank = rank; c->device = tsd_device(ctx);
   c->cells2 = (size_t)tsd_cells(ctx) * (size_t)tsd_cells(ctx);
-  if (hipSetDevice(c->device) != hipSuccess || hipMalloc(&c->d_map, c->cells2) != hipSuccess) {
-    std::fprintf(stderr, "tsd_comm_create: no device memory for the map\n");
-    delete c; return nullptr;
-  }
+  auto fail = [&](const char* what) -> tsd_comm* {
+    std::fprintf(stderr, "tsd_comm_create: %s\n", what);
+    comm_release(c);
+    return nullptr;
+  };
+  if (hipSetDevice(c->device) != hipSuccess || hipMalloc(&c->d_map, c->cells2) != hipSuccess) return fail("no device memory for the map");
   // (-1 = unknown; filled on the communicator's own stream, created first: a plain hipMemset would bring the NULL stream alive,
   // which takes one of the few hardware queues the scan's streams are mapped onto -- DESIGN 5)
   if (hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_extracted, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_reduced, hipEventDisableTiming) != hipSuccess) {
-    std::fprintf(stderr, "tsd_comm_create: stream / events\n");
-    hipFree(c->d_map); delete c; return nullptr;
-  }
-  if (hipMemsetAsync(c->d_map, 0xFF, c->cells2, c->cstream) != hipSuccess || hipStreamSynchronize(c->cstream) != hipSuccess) {
-    std::fprintf(stderr, "tsd_comm_create: clearing the map\n");
-    hipStreamDestroy(c->cstream); hipFree(c->d_map); delete c; return nullptr;
-  }
+      hipEventCreateWithFlags(&c->ev_reduced, hipEventDisableTiming) != hipSuccess)
+    return fail("stream / events");
+  if (hipMemsetAsync(c->d_map, 0xFF, c->cells2, c->cstream) != hipSuccess || hipStreamSynchronize(c->cstream) != hipSuccess)
+    return fail("clearing the map");
   ncclUniqueId id;
   std::memcpy(id.internal, id_in, TSD_COMM_ID_BYTES);
   (void)hipGetLastError();      // RCCL reads the thread's sticky last error: an earlier hipErrorNotReady is not its business
   const ncclResult_t r = ncclCommInitRank(&c->comm, world_size, id, rank);
   if (r != ncclSuccess) {
+    c->comm = nullptr;
     std::fprintf(stderr, "tsd_comm_create: ncclCommInitRank: %s\n", ncclGetErrorString(r));
-    hipFree(c->d_map); delete c; return nullptr;
+    comm_release(c);               // (round 4 leaked the stream and the two events here)
+    return nullptr;
   }
   return c;
 }
@@ -105,11 +115,7 @@ void tsd_comm_destroy(tsd_comm* c)
   if (c->comm) ncclCommDestroy(c->comm);
   for (auto& t : c->pending) { hipEventDestroy(t.t0); hipEventDestroy(t.t1); hipEventDestroy(t.t2); }
   for (hipEvent_t e : c->pool) hipEventDestroy(e);
-  if (c->ev_extracted) hipEventDestroy(c->ev_extracted);
-  if (c->ev_reduced) hipEventDestroy(c->ev_reduced);
-  if (c->cstream) hipStreamDestroy(c->cstream);
-  if (c->d_map) hipFree(c->d_map);
-  delete c;
+  comm_release(c);
 }
 
 int tsd_comm_world_size(const tsd_comm* c) { return c ? c->world : 0; }

@@ -149,11 +149,13 @@ constexpr int BATCH_FAIL_TIMEOUT = 1;    // its ray casts never reported done wi
 constexpr int BATCH_FAIL_ABORTED = 2;    // the host abandoned the batch
 constexpr unsigned int BATCH_POLL_BOUND = 1u << 21;   // ~2 s
 
+constexpr size_t KERNEL_TIMER_SAMPLES = 65536;
 struct KernelTimer {
   double total_ms = 0.0;
   double sum_sq = 0.0, min_ms = 1e300, max_ms = 0.0;   // of the timed dispatches (tsd_profile_get_spread)
   int launches = 0;
   unsigned tick = 0;         // launches seen (sampling: every profile_every-th one is timed)
+  std::vector<float> samples;    // the timed dispatches themselves, in order (tsd_profile_get_samples; at most KERNEL_TIMER_SAMPLES are kept)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
 };
 

@@ -223,7 +223,7 @@ class GridView(capi.TsdGridDevice):
 
     _LOCKED = ("reset", "sync", "free_footprint", "push", "raycast", "icp", "localize", "icp_trace", "download_tile_state",
                "download_tiles", "upload_tiles", "digest", "occupancy", "occupancy_into", "calibrate_rmw", "profile", "store_text",
-               "load_text", "color_image", "push_stats_total", "profile_reset", "profile_get", "profile_spread", "tsdpdf_match")
+               "load_text", "color_image", "push_stats_total", "profile_reset", "profile_get", "profile_spread", "profile_samples", "tsdpdf_match")
 
     def __init__(self, ctx, node=None):  # noqa: D401 - does not call the base constructor on purpose
         self.lib = capi.load_library()
