@@ -78,14 +78,16 @@ constexpr long long ICP_HELPER_IDLE_TICKS = 100000; // a helper that hears nothi
 constexpr int ICP_REQ_GRANULES = 14, ICP_REQ_WORDS = 16;   // the request block in front of the result granules
 constexpr int ICP_REQ_DONE = 63;
 // renewal schedule: requests go out at the end of these steps, results are taken from two steps later on
-constexpr int ICP_N_REQ = 4;
-__device__ constexpr int ICP_REQ_STEP[ICP_N_REQ] = {3, 8, 13, 19};
-constexpr int ICP_REQ_LAG = 2, ICP_REQ_TRIES = 3;
-constexpr int ICP_FRESH_STEPS = 5;                  // a wave whose points were renewed by the helpers this many steps ago or less skips a scheduled renewal of its own
+// (the FIRST scheduled renewal, step 6, stays with the registering workgroup: the scene still moves a centimetre per step there, and a
+// bound that is two steps old when it arrives has lost most of its slack -- measured: five list passes in steps 6-10 instead of one)
+// requests go out at the end of steps FIRST, FIRST + EVERY, .. (LAST at most); the answer is looked for at the end of the step LAG later
+// and of the one after that
+constexpr int ICP_REQ_FIRST = 11, ICP_REQ_EVERY = 6, ICP_REQ_LAST = 23, ICP_REQ_LAG = 2;
 
 // what the kernel needs again only after the last step (and the trace pointer, once per step by one
 // thread): parked in LDS so that it does not sit in scalar registers through the loop
-struct IcpTail { IcpResultDev* out; double* trace; ScanPostArgs post; ScanPostPre pre; };
+struct IcpTail { IcpResultDev* out; double* trace; ScanPostArgs post; ScanPostPre pre; IcpSeedArgs seed; };
+constexpr int ICP_CST = 32;
 
 struct IcpLds {
   IcpTail* tail;
@@ -103,7 +105,7 @@ struct IcpLds {
   int* res_k2;                     // [lcap]          runner-up slot
   int* list2;                      // [lcap] entries the window could not prove (tier 2 work list)
   double* red;                     // [2][ICP_MAXW][16] wave partials of the pair sums, per-wave broadcast rows
-  double* cst;                     // [16] IcpArgs scalars (kept out of the scalar register file)
+  double* cst;                     // [ICP_CST] the helper hand-off's scratch: [0..6] a request's payload, [8..13] Tinit^-1, [16..21] the pending request's motion
   double* tr;                      // [T][NSUMP] transpose buffer of the pair sums (aliases the work list)
   int* ired;                       // [64] counters
   // setup only (alias the work list)
@@ -124,7 +126,7 @@ __host__ __device__ inline size_t icp_lds_base_bytes(int cap, int threads, bool 
 {
   // the staging (cap double2 + cap int) aliases the list + result arrays: 40 * lc >= 20 * cap
   return sizeof(double2) * 2 * (size_t)cap + sizeof(double2) * 2 * ICP_PAD + sizeof(unsigned long long) * (size_t)cap + sizeof(int) * 2 * (size_t)cap +
-         icp_region_bytes(cap, threads) + sizeof(double) * (2 * ICP_MAXW * 16 + 16) + ((sizeof(IcpTail) + 15) & ~(size_t)15) +
+         icp_region_bytes(cap, threads) + sizeof(double) * (2 * ICP_MAXW * 16 + ICP_CST) + ((sizeof(IcpTail) + 15) & ~(size_t)15) +
          sizeof(int) * 64 + 64 + (normals ? sizeof(double2) * (size_t)cap : 0);
 }
 #ifdef TSD_ICP_TIMELINE
@@ -628,7 +630,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     L.start = reinterpret_cast<int*>(reinterpret_cast<char*>(L.stage_s) + sizeof(double2) * (size_t)cap);
     L.slotD = reinterpret_cast<unsigned long long*>(p); p += sizeof(unsigned long long) * (size_t)icp_slot_halves(cap, (int)blockDim.x, PTL) * (size_t)cap;
     L.red = reinterpret_cast<double*>(p); p += sizeof(double) * 2 * ICP_MAXW * 16;
-    L.cst = reinterpret_cast<double*>(p); p += sizeof(double) * 16;
+    L.cst = reinterpret_cast<double*>(p); p += sizeof(double) * ICP_CST;
     L.tail = reinterpret_cast<IcpTail*>(p); p += (sizeof(IcpTail) + 15) & ~(size_t)15;
     L.tr = reinterpret_cast<double*>(L.list_xy);     // T * 72 B <= 40 * lcap B (checked by the launcher)
     L.slotI = reinterpret_cast<int*>(p); p += sizeof(int) * (size_t)cap;
@@ -738,7 +740,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     __syncthreads();
   }
   if (tid == 0) {
-    L.tail->out = out; L.tail->trace = trace; L.tail->post = post;
+    L.tail->out = out; L.tail->trace = trace; L.tail->post = post; L.tail->seed = seed;
     if (post.st) L.tail->pre = pre_regs;                      // (fused scan: the sensor state the epilogue starts from, requested at the top)
     L.ired[IR_CNT] = 0; L.ired[IR_RMAX] = 0; L.ired[IR_CNT2] = 0; L.ired[IR_TIE] = 0;
   }
@@ -925,12 +927,8 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
   // step 0's searches, done by the helper workgroups while this one set itself up: every lane re-reads its points' granules until
   // they answer request 0 of this launch (a bounded wait, per wave) and takes neighbour, runner-up and bound from them
   const bool helped = !PAIRS && seed.helpers > 0;
-  float dacc[R];                             // distance every point has moved since the latest request to the helpers (rounded up)
-#pragma unroll
-  for (int q = 0; q < R; q++) dacc[q] = 0.f;
-  int req_sent = 0;                          // requests published so far
-  int pend_r = 0, pend_from = 0, pend_tries = 0;   // the request whose results are still to be taken, from which step on, attempts made
-  int fresh_iter = -1000;                    // the step behind which this wave last took the helpers' results for all its points
+  bool pending = false;                      // a request's results are still to be taken
+  bool helper_renewed = false;               // this wave has taken a renewal of all its points from the helpers
   if (helped) {
     const long long t0 = wall_clock64();
     unsigned long long g0[R], g1[R];
@@ -964,17 +962,6 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
   while (state == TSD_ICP_PROCESSING) {
     const double thr_before = thr;
     TL(0);
-    // the helpers' answer to the pending request is asked for here and looked at behind this step's transform (the reads' latency under the step)
-    const bool take = pend_r != 0 && (int)iter >= pend_from;          // (wave-uniform)
-    unsigned long long hg0[R], hg1[R];
-    if (take) {
-#pragma unroll
-      for (int q = 0; q < R; q++) {
-        const int i = have[q] ? pid[q] : 0;
-        hg0[q] = __hip_atomic_load(seed.g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        hg1[q] = __hip_atomic_load(seed.g + seed.stride + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
     // The slots a step's pairs went into are given back behind barrier 2 of that step, and the next step's atomics come before ITS
     // barrier 1: nothing orders the two.  They are a transform and a tier 0 apart (~2 500 cycles) while the waves leave a barrier within
     // tens of cycles of each other, so the hand-back always won -- but only by timing.  Alternate steps use alternate halves of the slot
@@ -989,8 +976,8 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     double bd[R]; bool keep[R], need[R];
     int ent[R];
     double2 mw[R];                            // the neighbour's coordinates
-    // (a wave whose bounds the helpers have just renewed skips the scheduled renewal of its own)
-    const bool refresh = ((iter == REFRESH_A) || (iter == REFRESH_B)) && (int)iter - fresh_iter > ICP_FRESH_STEPS;
+    // (a wave whose bounds the helpers have renewed since skips the second scheduled renewal of its own)
+    const bool refresh = (iter == REFRESH_A) || (iter == REFRESH_B && !helper_renewed);
     // OutOfBoundsFilter2D for one point: S.transform(P): (0 + x*R00) + y*R01, then + t (gsl/Matrix.cpp:403-432)
     auto inside_bounds = [&](double x, double y) {
       double wx = 0.0, wy = 0.0;
@@ -1285,6 +1272,20 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     for (int q = 0; q < R; q++)
       if (keep[q]) slotD[hint[q]] = ~0ull;
     if (tid == 0) L.ired[IR_CNT] = 0;
+    // the helpers' answer to the pending request is asked for here and looked at behind this step's transform (the reads' latency under
+    // the closed form and the transform): at the end of the step ICP_REQ_LAG behind the request and of the one after it
+    const int since = (int)iter - (ICP_REQ_FIRST + ICP_REQ_LAG);
+    const bool take = pending && since >= 0 && (since % ICP_REQ_EVERY) <= 1;          // (wave-uniform)
+    unsigned long long hg0[R], hg1[R];
+    if (take) {
+      const IcpSeedArgs sd = L.tail->seed;
+#pragma unroll
+      for (int q = 0; q < R; q++) {
+        const int i = have[q] ? pid[q] : 0;
+        hg0[q] = __hip_atomic_load(sd.g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        hg1[q] = __hip_atomic_load(sd.g + sd.stride + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
 
     double co = __builtin_nan(""), si = __builtin_nan(""), dX = __builtin_nan(""), dY = __builtin_nan("");   // Tlast of this step (trace)
     pairs = __builtin_amdgcn_readfirstlane(pairs);
@@ -1337,7 +1338,6 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
         const double ex = nx - x, ey = ny - y;
         const float disp = __builtin_amdgcn_sqrtf((float)(ex * ex + ey * ey) * 1.000001f) * 1.000001f;
         lb[q] = lb[q] - (double)disp;
-        dacc[q] += disp * 1.00001f;
         sx[q] = nx; sy[q] = ny;
       }
       {
@@ -1357,32 +1357,47 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
       state = TSD_ICP_NOTMATCHABLE;
     }
     TL(12);                                    // scene moved, bounds updated
-    if (helped) {
-      if (take) {
-        // the helpers' renewal: neighbour, runner-up and a bound for the scene as it stood at the request, less what the point has
-        // moved since (and 1e-9 m for the helpers' coordinates, which differ from these by rounding): taken where it beats the bound
-        // the point has; next step's tier 0 confirms the neighbour from the registration's own coordinates
-        bool ok = true;
-        int hk[R], hk2[R]; float hroot[R]; bool hval[R];
+    if (take) {
+      // The helpers' renewal: neighbour, runner-up and a bound for the scene as it stood at the request.  Since then every point has
+      // moved by the rigid motion M = A_now A_req^-1; the straight distance |p - M^-1 p| it has covered (rounded up, plus 1e-9 m for
+      // the helpers' coordinates, which differ from these by rounding) comes off the bound, and the result is taken where it beats the
+      // bound the point has.  Next step's tier 0 confirms the neighbour from the registration's own coordinates.
+      const IcpSeedArgs sd = L.tail->seed;
+      const int rq = since / ICP_REQ_EVERY + 1;
+      bool ok = true;
+      int hk[R], hk2[R]; float hroot[R]; bool hval[R];
+#pragma unroll
+      for (int q = 0; q < R; q++) {
+        bool arrived;
+        hval[q] = seed_decode(sd, hg0[q], hg1[q], rq, hk[q], hk2[q], hroot[q], arrived);
+        ok &= arrived | !have[q];
+      }
+      if (__all(ok)) {
+        // B = A_req A_now^-1 with A_now = Tfinal Tinit^-1 (rigid: the inverse is R^T, -R^T t)
+        const double i0 = L.cst[8], i1 = L.cst[9], i2 = L.cst[10], i3 = L.cst[11], i4 = L.cst[12], i5 = L.cst[13];
+        const double n0 = Tf[0] * i0 + Tf[1] * i3, n1 = Tf[0] * i1 + Tf[1] * i4, n2 = Tf[0] * i2 + Tf[1] * i5 + Tf[2];
+        const double n3 = Tf[3] * i0 + Tf[4] * i3, n4 = Tf[3] * i1 + Tf[4] * i4, n5 = Tf[3] * i2 + Tf[4] * i5 + Tf[5];
+        const double v0 = n0, v1 = n3, v2 = -(n0 * n2 + n3 * n5), v3 = n1, v4 = n4, v5 = -(n1 * n2 + n4 * n5);      // A_now^-1
+        const double q0 = L.cst[16], q1 = L.cst[17], q2 = L.cst[18], q3 = L.cst[19], q4 = L.cst[20], q5 = L.cst[21];   // A_req
+        const double b0 = q0 * v0 + q1 * v3, b1 = q0 * v1 + q1 * v4, b2 = q0 * v2 + q1 * v5 + q2;
+        const double b3 = q3 * v0 + q4 * v3, b4 = q3 * v1 + q4 * v4, b5 = q3 * v2 + q4 * v5 + q5;
 #pragma unroll
         for (int q = 0; q < R; q++) {
-          bool arrived;
-          hval[q] = seed_decode(seed, hg0[q], hg1[q], pend_r, hk[q], hk2[q], hroot[q], arrived);
-          ok &= arrived | !have[q];
+          const double ex = (b0 * sx[q] + b1 * sy[q] + b2) - sx[q], ey = (b3 * sx[q] + b4 * sy[q] + b5) - sy[q];
+          const double moved = (double)(__builtin_amdgcn_sqrtf((float)(ex * ex + ey * ey) * 1.000001f) * 1.000001f) + 1e-9;
+          const double lbn = (double)hroot[q] * (1.0 - 1e-6) - moved;
+          if (have[q] && hval[q] && lbn > lb[q]) { hint[q] = hk[q]; hint2[q] = hk2[q]; lb[q] = lbn; }
         }
-        if (__all(ok)) {
-#pragma unroll
-          for (int q = 0; q < R; q++) {
-            const double lbn = (double)hroot[q] * (1.0 - 1e-6) - (double)dacc[q] - 1e-9;
-            if (have[q] && hval[q] && lbn > lb[q]) { hint[q] = hk[q]; hint2[q] = hk2[q]; lb[q] = lbn; }
-          }
-          pend_r = 0; fresh_iter = (int)iter;
-        } else if (++pend_tries >= ICP_REQ_TRIES) pend_r = 0;
-      }
-      if (req_sent < ICP_N_REQ && (int)iter == ICP_REQ_STEP[req_sent] && state == TSD_ICP_PROCESSING) {
+        pending = false; helper_renewed = true;
+      } else if (since % ICP_REQ_EVERY == 1) pending = false;             // (second look: given up)
+    }
+    {
+      const int at = (int)iter - ICP_REQ_FIRST;
+      if (helped && at >= 0 && (int)iter <= ICP_REQ_LAST && at % ICP_REQ_EVERY == 0 && state == TSD_ICP_PROCESSING) {
         // a request: the motion that takes the staged scene to the scene as it stands now, and the filter threshold of the next step
-        req_sent++;
         if (wave == W - 1) {
+          const IcpSeedArgs sd = L.tail->seed;
+          const int rq = at / ICP_REQ_EVERY + 1;
           const double i0 = L.cst[8], i1 = L.cst[9], i2 = L.cst[10], i3 = L.cst[11], i4 = L.cst[12], i5 = L.cst[13];
           if (lane == 0) {
             L.cst[0] = Tf[0] * i0 + Tf[1] * i3; L.cst[1] = Tf[0] * i1 + Tf[1] * i4; L.cst[2] = Tf[0] * i2 + Tf[1] * i5 + Tf[2];
@@ -1391,12 +1406,17 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
           }
           // (a wave's LDS accesses execute in order) fourteen lanes, one granule each: ONE store instruction
           const unsigned half = reinterpret_cast<const unsigned int*>(L.cst)[lane < ICP_REQ_GRANULES ? lane : 0];
-          const unsigned long long rtag = (unsigned long long)(((seed.seq & 0x3FFFFFFu) << 6) | (unsigned)req_sent) << 32;
-          if (lane < ICP_REQ_GRANULES) __hip_atomic_store(seed.g - ICP_REQ_WORDS + lane, rtag | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long rtag = (unsigned long long)(((sd.seq & 0x3FFFFFFu) << 6) | (unsigned)rq) << 32;
+          if (lane < ICP_REQ_GRANULES) __hip_atomic_store(sd.g - ICP_REQ_WORDS + lane, rtag | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          // the same motion kept for the moment the answer is taken (every wave computes it below from what it has: wave-uniform)
         }
+        // A_req, kept by every wave's own lane 0 ... one copy is enough: the last wave wrote L.cst[0..5]; the others read it at `take`,
+        // two steps and several barriers later -- copied to its own place so that the next request's payload cannot overwrite it early
+        if (wave == W - 1 && lane == 0) {
 #pragma unroll
-        for (int q = 0; q < R; q++) dacc[q] = 0.f;
-        pend_r = req_sent; pend_from = (int)iter + ICP_REQ_LAG; pend_tries = 0;
+          for (int k = 0; k < 6; k++) L.cst[16 + k] = L.cst[k];
+        }
+        pending = true;
       }
     }
     // -- loop control (Icp.cpp:489-511)
