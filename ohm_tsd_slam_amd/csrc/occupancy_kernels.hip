@@ -227,10 +227,10 @@ int launch_occupancy(tsd_ctx* ctx, int8_t* d_out, int inflate, int inflate_facto
   ctx->occ_parity ^= 1;
   hipLaunchKernelGGL(k_occ_cells, dim3(ctx->grid.tiles), dim3(256), 0, ctx->stream, ctx->grid,
                      ctx->d_occ, d_out, heads, ctx->d_occ_list, heads_next, ctx->d_occ_count);
-#ifndef TSD_OCC_MARK_GROUPS
-#define TSD_OCC_MARK_GROUPS 2048      // (measured at cfg 2, maps of 40 / 200 scans: 2 048 workgroups 9.3 / 12.3 us, 1 024: 10.5 / 12.6, 512: 14.1 / 17.7, 256: 21.9 / 28.2 --
-#endif                                //  a tile is a ~5 us chain of dependent round trips, so as many of them side by side as there are)
-  const int mark_groups = ctx->grid.tiles < TSD_OCC_MARK_GROUPS ? ((ctx->grid.tiles + OCC_SHARDS - 1) / OCC_SHARDS) * OCC_SHARDS : TSD_OCC_MARK_GROUPS;   // a multiple of the shards
+  // (measured at cfg 2, maps of 40 / 200 scans: 2 048 workgroups 9.3 / 12.3 us, 1 024: 10.5 / 12.6, 512: 14.1 / 17.7, 256: 21.9 / 28.2 --
+  //  a tile is a ~5 us chain of dependent round trips, so as many of them side by side as there are)
+  constexpr int OCC_MARK_GROUPS = 2048;
+  const int mark_groups = ctx->grid.tiles < OCC_MARK_GROUPS ? ((ctx->grid.tiles + OCC_SHARDS - 1) / OCC_SHARDS) * OCC_SHARDS : OCC_MARK_GROUPS;   // a multiple of the shards
   hipLaunchKernelGGL(k_occ_mark, dim3(mark_groups), dim3(256), 0, ctx->stream, ctx->grid, d_out,
                      ctx->d_occ_count, inflate, inflate_factor, heads, ctx->d_occ_list);
   TSD_HIP_CHECK(ctx, hipGetLastError());

@@ -177,9 +177,6 @@ raycast_beam(const GridDev& g, const RaycastArgs& a_val, const RaycastArgs* __re
 #else
 #define RSTAMP(i) do {} while (0)
 #endif
-#ifdef TSD_RC_STAMPS2
-  const long long st2_begin = clock64();
-#endif
   const RaycastArgs a = a_dev ? *a_dev : a_val;
   const int beam = blockIdx.x;
   const int lane = threadIdx.x;
@@ -480,9 +477,6 @@ raycast_beam(const GridDev& g, const RaycastArgs& a_val, const RaycastArgs* __re
   RSTAMP(4);
 #ifdef TSD_RC_STAMPS
   if (lane == 0 && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 128) dbg[(blockIdx.x >> 3) * 8 + 6] = closed ? 0.0 : 1.0;
-#endif
-#ifdef TSD_RC_STAMPS2    // diagnostic: every beam's cycles (negative: serial chain) -- dbg[beam % 1024]
-  if (lane == 0) dbg[beam & 1023] = (closed ? 1.0 : -1.0) * (double)(clock64() - st2_begin);
 #endif
   if (!found) { if (lane == 0) mask[beam] = 0; return; }
 
