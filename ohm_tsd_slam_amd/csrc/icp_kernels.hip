@@ -45,49 +45,27 @@ constexpr int HW = 6;                           // tier-1 window: k-HW .. k+HW (
 constexpr int ICP_PAD = 96;                     // wrapped copies of the model at both ends of its LDS array
 constexpr unsigned REFRESH_A = 6, REFRESH_B = 15;      // steps with a scheduled bound renewal
 constexpr double WEAK_MULT = 36.0;                     // a scheduled renewal takes the bounds with less than sqrt(this) x slack in distance
-constexpr int IR_CNT = 32, IR_RMAX = 33, IR_CNT2 = 34, IR_TIE = 35, IR_REQ = 36;   // words of IcpLds::ired
-// HELPER WORKGROUPS.  A registration's searches are of two kinds.  Those of steps 1-5 (a few hundred points whose bound the scene's
-// motion has eaten) are needed at once and stay with the registering workgroup.  But step 0 -- EVERY point searches, no neighbour is
-// known yet: ~20 000 cycles on the one compute unit that registers -- depends on nothing the loop produces, and the scheduled bound
-// RENEWALS (two passes over ~900 points, ~15 000 cycles each) are not urgent: a bound found for the scene as it was a few steps ago
-// is still a bound once the distance every point has moved since is taken off it.  Both are shared out: the launch brings `helpers`
-// more workgroups, each of which runs the same set-up (model, unit directions, padding in ITS OWN LDS) and then serves
-// ICP_HELPER_POINTS of the scene points for the whole registration:
-//   request 0   (implicit) the tier-1 window search of step 0, on the same inputs as the registration's own list pass would use;
-//   request r   the registering workgroup publishes A_r, the rigid motion that takes the staged scene to the scene as it stands now,
-//               and the filter threshold; the helpers move their points by it (equal to the registration's own coordinates to
-//               1e-14 m: it transforms step by step), search again -- window, then the whole-wave sweep for what the window cannot
-//               prove, shared over the helper's eight waves -- and hand back neighbour, runner-up and bound.
-// Hand-offs are 8-byte GRANULES {launch number, value}, each ONE relaxed agent-scope atomic store (a write-through store that carries
-// its own tag: no flag, no fence, no barrier on either side; MI355X hand-off recipe R2).  Per scene point two granules: (1) the fp32
-// square root the bound is formed from, its low six mantissa bits (rounded DOWN, it is a lower bound) replaced by the request number,
-// (2) neighbour slot | runner-up slot << 11 | request << 22 | invalid << 28.  The request is fourteen granules (the halves of A's six
-// entries and of the threshold), tag = launch number << 6 | request, one store instruction of fourteen lanes.
-// The registering workgroup takes the results two or more steps later, behind that step's transform: a point's new bound is the
-// handed-back one less the distance the point has moved since the request (accumulated per point, rounded up) less 1e-9 m, taken only
-// where it beats the bound the point has; tier 0 of the next step then confirms neighbour and runner-up from the registration's own
-// coordinates like any other step's.  Exactness does not depend on any of this -- tier 0 proves every neighbour from whatever
-// candidates and (valid) bound it is given -- so the pair lists, and with them every result, are the same with and without helpers
-// (tests/test_gpu_parity.py::test_icp_helpers_change_nothing); only the time differs.  All waits are bounded: granules that do not
-// arrive (helpers that got no compute unit: a push on another stream filling the device) are not waited for -- step 0 then searches
-// itself and the scheduled renewals run in the workgroup as they did in round 4.
+constexpr int IR_CNT = 32, IR_RMAX = 33, IR_CNT2 = 34, IR_TIE = 35;   // words of IcpLds::ired
+// Step 0 of a registration is the one step in which EVERY scene point searches (no neighbour is known yet): ~20 000 cycles on the one
+// compute unit that runs the registration.  That search does not depend on anything the loop produces, so it is shared out: the launch
+// brings `helpers` more workgroups, each of which runs the same set-up (model, unit directions, padding in ITS OWN LDS) and then the
+// tier-1 window search of step 0 for ICP_HELPER_POINTS of the scene points -- the same function on the same inputs as the registration's
+// own list pass would run.  A helper lane hands its result over as two 8-byte GRANULES {launch number, value}: (1) the bits of the
+// fp32 square root the bound is formed from, (2) neighbour slot | runner-up slot << 16 (0xFFFF: the window could not prove the point),
+// each ONE relaxed agent-scope atomic store -- a write-through store that carries its own tag, so there is no flag, no fence and no
+// barrier on either side (MI355X hand-off recipe R2).  The registering workgroup finishes its own set-up meanwhile; every lane then
+// re-reads ITS points' granules until their tags are this launch's and starts step 0 from neighbour, runner-up and bound -- tier 0
+// confirms them like any other step's (the distance is recomputed from the same coordinates by the same expression, the bound is
+// rebuilt from the same fp32 root: the state after step 0 is bit for bit what the workgroup's own search would have left).  The wait
+// is bounded and per wave: points whose granules did not arrive in time (helpers that got no compute unit: a push on another stream
+// filling the device) simply search in step 0 as they always did; the results are the same either way, only the time differs.
 constexpr int ICP_HELPER_POINTS = 256;              // scene points per helper workgroup: one per lane of its waves 0-3 (one wave per SIMD)
 constexpr int ICP_MAX_HELPERS = 16;
-constexpr long long ICP_SEED_WAIT_TICKS = 600;      // of the 100 MHz wall clock: 6 us (step 0's granules)
-constexpr long long ICP_HELPER_IDLE_TICKS = 100000; // a helper that hears nothing for 1 ms gives up (the registration's last act is to dismiss them)
-constexpr int ICP_REQ_GRANULES = 14, ICP_REQ_WORDS = 16;   // the request block in front of the result granules
-constexpr int ICP_REQ_DONE = 63;
-// renewal schedule: requests go out at the end of these steps, results are taken from two steps later on
-// (the FIRST scheduled renewal, step 6, stays with the registering workgroup: the scene still moves a centimetre per step there, and a
-// bound that is two steps old when it arrives has lost most of its slack -- measured: five list passes in steps 6-10 instead of one)
-// requests go out at the end of steps FIRST, FIRST + EVERY, .. (LAST at most); the answer is looked for at the end of the step LAG later
-// and of the one after that
-constexpr int ICP_REQ_FIRST = 11, ICP_REQ_EVERY = 6, ICP_REQ_LAST = 23, ICP_REQ_LAG = 2;
+constexpr long long ICP_SEED_WAIT_TICKS = 600;      // of the 100 MHz wall clock: 6 us
 
 // what the kernel needs again only after the last step (and the trace pointer, once per step by one
 // thread): parked in LDS so that it does not sit in scalar registers through the loop
-struct IcpTail { IcpResultDev* out; double* trace; ScanPostArgs post; ScanPostPre pre; IcpSeedArgs seed; };
-constexpr int ICP_CST = 32;
+struct IcpTail { IcpResultDev* out; double* trace; ScanPostArgs post; ScanPostPre pre; };
 
 struct IcpLds {
   IcpTail* tail;
@@ -105,7 +83,7 @@ struct IcpLds {
   int* res_k2;                     // [lcap]          runner-up slot
   int* list2;                      // [lcap] entries the window could not prove (tier 2 work list)
   double* red;                     // [2][ICP_MAXW][16] wave partials of the pair sums, per-wave broadcast rows
-  double* cst;                     // [ICP_CST] the helper hand-off's scratch: [0..6] a request's payload, [8..13] Tinit^-1, [16..21] the pending request's motion
+  double* cst;                     // [16] IcpArgs scalars (kept out of the scalar register file)
   double* tr;                      // [T][NSUMP] transpose buffer of the pair sums (aliases the work list)
   int* ired;                       // [64] counters
   // setup only (alias the work list)
@@ -126,7 +104,7 @@ __host__ __device__ inline size_t icp_lds_base_bytes(int cap, int threads, bool 
 {
   // the staging (cap double2 + cap int) aliases the list + result arrays: 40 * lc >= 20 * cap
   return sizeof(double2) * 2 * (size_t)cap + sizeof(double2) * 2 * ICP_PAD + sizeof(unsigned long long) * (size_t)cap + sizeof(int) * 2 * (size_t)cap +
-         icp_region_bytes(cap, threads) + sizeof(double) * (2 * ICP_MAXW * 16 + ICP_CST) + ((sizeof(IcpTail) + 15) & ~(size_t)15) +
+         icp_region_bytes(cap, threads) + sizeof(double) * (2 * ICP_MAXW * 16 + 16) + ((sizeof(IcpTail) + 15) & ~(size_t)15) +
          sizeof(int) * 64 + 64 + (normals ? sizeof(double2) * (size_t)cap : 0);
 }
 #ifdef TSD_ICP_TIMELINE
@@ -572,27 +550,6 @@ __device__ __forceinline__ void block_totals8(const IcpLds& L, const double (&v)
   for (int k = 0; k < 8; k += 2) { const double2 t2 = *reinterpret_cast<const double2*>(bc + k); tot[k] = t2.x; tot[k + 1] = t2.y; }
 }
 
-// ---- granules of the helper hand-off (see HELPER WORKGROUPS above)
-__device__ __forceinline__ void seed_store(const IcpSeedArgs& seed, int i, const NnResult& r, int req)
-{
-  const unsigned long long tag = (unsigned long long)seed.seq << 32;
-  const unsigned int root = (__float_as_uint(__builtin_amdgcn_sqrtf((float)r.lbsq)) & ~63u) | (unsigned)req;   // lb_from_sq's fp32 root, rounded down
-  const bool valid = r.resolved && r.bk >= 0 && r.bk2 >= 0;
-  const unsigned int kk = (valid ? ((unsigned)r.bk | ((unsigned)r.bk2 << 11)) : (1u << 28)) | ((unsigned)req << 22);
-  __hip_atomic_store(seed.g + i, tag | root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(seed.g + seed.stride + i, tag | kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// the two granules of a point as the registration reads them: true when both answer request `req` of this launch with a valid result
-__device__ __forceinline__ bool seed_decode(const IcpSeedArgs& seed, unsigned long long g0, unsigned long long g1, int req, int& k, int& k2, float& root,
-                                            bool& arrived)
-{
-  const unsigned v0 = (unsigned)g0, v1 = (unsigned)g1;
-  arrived = (unsigned)(g0 >> 32) == seed.seq && (unsigned)(g1 >> 32) == seed.seq && (int)(v0 & 63u) == req && (int)((v1 >> 22) & 63u) == req;
-  k = (int)(v1 & 0x7FFu); k2 = (int)((v1 >> 11) & 0x7FFu);
-  root = __uint_as_float(v0 & ~63u);
-  return arrived && ((v1 >> 28) & 1u) == 0u;
-}
-
 // the whole registration of one workgroup; k_icp (one registration per launch) and k_icp_batch (workgroup x = registration x
 // of a batch) are thin wrappers
 // PAIRS (parity / debug instantiation, tsd_icp_pairs): the scene is NOT moved between the steps and every step's surviving pair list
@@ -630,7 +587,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     L.start = reinterpret_cast<int*>(reinterpret_cast<char*>(L.stage_s) + sizeof(double2) * (size_t)cap);
     L.slotD = reinterpret_cast<unsigned long long*>(p); p += sizeof(unsigned long long) * (size_t)icp_slot_halves(cap, (int)blockDim.x, PTL) * (size_t)cap;
     L.red = reinterpret_cast<double*>(p); p += sizeof(double) * 2 * ICP_MAXW * 16;
-    L.cst = reinterpret_cast<double*>(p); p += sizeof(double) * ICP_CST;
+    L.cst = reinterpret_cast<double*>(p); p += sizeof(double) * 16;
     L.tail = reinterpret_cast<IcpTail*>(p); p += (sizeof(IcpTail) + 15) & ~(size_t)15;
     L.tr = reinterpret_cast<double*>(L.list_xy);     // T * 72 B <= 40 * lcap B (checked by the launcher)
     L.slotI = reinterpret_cast<int*>(p); p += sizeof(int) * (size_t)cap;
@@ -740,7 +697,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     __syncthreads();
   }
   if (tid == 0) {
-    L.tail->out = out; L.tail->trace = trace; L.tail->post = post; L.tail->seed = seed;
+    L.tail->out = out; L.tail->trace = trace; L.tail->post = post;
     if (post.st) L.tail->pre = pre_regs;                      // (fused scan: the sensor state the epilogue starts from, requested at the top)
     L.ired[IR_CNT] = 0; L.ired[IR_RMAX] = 0; L.ired[IR_CNT2] = 0; L.ired[IR_TIE] = 0;
   }
@@ -809,89 +766,27 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     L.mxy[-1 - i] = L.mxy[nM - 1 - (i % nM)];
   }
   if (role > 0) {
-    // ---- helper workgroup (see HELPER WORKGROUPS above): scene points (role - 1) * ICP_HELPER_POINTS + tid, one per lane of waves 0-3
+    // helper: step 0's window search for scene points (role - 1) * ICP_HELPER_POINTS + tid, from the staged scene (the registration's
+    // own list pass reads the same coordinates and the same hint from its registers)
     __syncthreads();                   // unit directions and padding in place
     const int per = T < ICP_HELPER_POINTS ? T : ICP_HELPER_POINTS;
     const int i = (role - 1) * per + tid;
-    const bool mine = tid < per && i < nS;
-    double x0 = 0.0, y0 = 0.0;
-    int kl = 0;                        // the point's last known neighbour: where the next window starts
-    if (mine) {
+    if (tid < per && i < nS) {
       const double2 s = L.stage_s[i];
-      x0 = s.x; y0 = s.y;
-      const int h = L.start[i];
-      kl = h < 0 ? 0 : (h >= nM ? nM - 1 : h);
+      int h = L.start[i];
+      h = h < 0 ? 0 : (h >= nM ? nM - 1 : h);
+      const NnResult r = window_search(L, nM, s.x, s.y, h, a.thr0, a.ccw ? 1.0 : -1.0);
+      const unsigned int root = __float_as_uint(__builtin_amdgcn_sqrtf((float)r.lbsq));       // lb_from_sq's fp32 root
+      const unsigned int kk = r.resolved ? ((unsigned)r.bk | ((unsigned)r.bk2 << 16)) : 0xFFFFu;
+      const unsigned long long tag = (unsigned long long)seed.seq << 32;
+      __hip_atomic_store(seed.g + i, tag | root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(seed.g + seed.stride + i, tag | kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __syncthreads();                   // the staging is in registers: its region is the helper's own work list from here on
-    const double sgn = a.ccw ? 1.0 : -1.0;
-    unsigned long long* const req = seed.g - ICP_REQ_WORDS;
-    double A[6] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0};
-    double thr_r = a.thr0;
-    int r = 0;
-    for (;;) {
-      // request r: the points as they stand now (request 0: x*1 + y*0 + 0 = the staged coordinates themselves)
-      double x = 0.0, y = 0.0;
-      x += x0 * A[0]; x += y0 * A[1]; x += A[2];
-      y += x0 * A[3]; y += y0 * A[4]; y += A[5];
-      NnResult res;
-      res.resolved = false; res.bk = -1; res.bk2 = -1; res.best = 0.0; res.lbsq = 0.0;
-      if (mine) res = window_search(L, nM, x, y, kl, thr_r, sgn);
-      const bool un = mine && !res.resolved;
-      int e = 0;
-      if (un) {                        // what the window cannot prove: a whole-wave search, shared over all waves below
-        e = atomicAdd(&L.ired[IR_CNT2], 1);
-        L.list_xy[e] = make_double2(x, y); L.list_k[e] = kl; L.res_k[e] = i;
-      }
-      if (mine && res.resolved) { seed_store(seed, i, res, r); kl = res.bk; }
-      __syncthreads();
-      const int n2 = L.ired[IR_CNT2];
-      for (int j = wave; j < n2; j += W) {
-        const double2 s2 = L.list_xy[j];
-        const NnResult rr = wave_search(L, nM, s2.x, s2.y, L.list_k[j], thr_r, sgn, lane);
-        if (lane == 0) { seed_store(seed, L.res_k[j], rr, r); L.res_k2[j] = rr.bk; }
-      }
-      __syncthreads();
-      if (un && L.res_k2[e] >= 0) kl = L.res_k2[e];
-      // ---- the next request: wave 0 polls the fourteen request granules (lane l: granule l) until they all carry a number other
-      // than r's, the registration dismisses the helpers, or nothing has been heard for a millisecond
-      if (wave == 0) {
-        const long long t0 = wall_clock64();
-        int next = -1;
-        for (;;) {
-          const unsigned long long w = __hip_atomic_load(req + (lane < ICP_REQ_GRANULES ? lane : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const unsigned tg = (unsigned)(w >> 32);
-          const unsigned tg0 = (unsigned)__builtin_amdgcn_readfirstlane((int)tg);
-          const bool cur = (tg0 >> 6) == (seed.seq & 0x3FFFFFFu);
-          const int rn = (int)(tg0 & 63u);
-          if (cur && rn == ICP_REQ_DONE) break;
-          if (cur && rn != r && __all(lane >= ICP_REQ_GRANULES || tg == tg0)) {
-            if (lane < ICP_REQ_GRANULES) reinterpret_cast<unsigned int*>(L.cst)[lane] = (unsigned)w;
-            next = rn;
-            break;
-          }
-          if (wall_clock64() - t0 > ICP_HELPER_IDLE_TICKS) break;
-          __builtin_amdgcn_s_sleep(8);
-        }
-        if (lane == 0) { L.ired[IR_REQ] = next; L.ired[IR_CNT2] = 0; }
-      }
-      __syncthreads();
-      r = L.ired[IR_REQ];
-      if (r < 0) return;
-#pragma unroll
-      for (int k = 0; k < 6; k++) A[k] = L.cst[k];
-      thr_r = L.cst[6];
-    }
+    return;
   }
   const int slot_halves = icp_slot_halves(cap, T, PTL);
   for (int k = tid; k < cap; k += T) { L.slotD[k] = ~0ull; if (slot_halves == 2) L.slotD[cap + k] = ~0ull; L.slotI[k] = INT_MAX; }
   for (int k = tid; k < ICP_MAXW * 16; k += T) L.red[k] = 0.0;    // (block_totals8 reads the rows of absent waves)
-  if (tid == 0) {
-    // the inverse of Tinit (a rigid motion: R^T, -R^T t), for the helpers' requests: A = Tfinal * Tinit^-1 takes the STAGED scene to the
-    // scene as it stands (mode 0: the identity)
-    const double r00 = a.Tinit[0], r01 = a.Tinit[1], tx = a.Tinit[2], r10 = a.Tinit[3], r11 = a.Tinit[4], ty = a.Tinit[5];
-    L.cst[8] = r00; L.cst[9] = r10; L.cst[10] = -(r00 * tx + r10 * ty);
-    L.cst[11] = r01; L.cst[12] = r11; L.cst[13] = -(r01 * tx + r11 * ty);
-  }
   __syncthreads();                     // staging consumed (it aliases the work list); counters zeroed
   if (rmaxf > 0.f) atomicMax(&L.ired[IR_RMAX], __float_as_int(rmaxf));   // positive floats order like ints
   __syncthreads();
@@ -925,13 +820,11 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
   for (int q = 0; q < R; q++) Rn += (pid[q] - lane < nS) ? 1 : 0;
 
   // step 0's searches, done by the helper workgroups while this one set itself up: every lane re-reads its points' granules until
-  // they answer request 0 of this launch (a bounded wait, per wave) and takes neighbour, runner-up and bound from them
-  const bool helped = !PAIRS && seed.helpers > 0;
-  bool pending = false;                      // a request's results are still to be taken
-  bool helper_renewed = false;               // this wave has taken a renewal of all its points from the helpers
-  if (helped) {
+  // they carry this launch's number (a bounded wait, per wave) and takes neighbour, runner-up and bound from them
+  if (!PAIRS && seed.helpers > 0) {
     const long long t0 = wall_clock64();
     unsigned long long g0[R], g1[R];
+    bool got[R];
     for (;;) {
       bool ok = true;
 #pragma unroll
@@ -942,19 +835,18 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
       }
 #pragma unroll
       for (int q = 0; q < R; q++) {
-        int k, k2; float root; bool arrived;
-        seed_decode(seed, g0[q], g1[q], 0, k, k2, root, arrived);
-        ok &= arrived | !have[q];
+        got[q] = (unsigned)(g0[q] >> 32) == seed.seq && (unsigned)(g1[q] >> 32) == seed.seq;
+        ok &= got[q] | !have[q];
       }
       if (__all(ok) || wall_clock64() - t0 > ICP_SEED_WAIT_TICKS) break;
       __builtin_amdgcn_s_sleep(2);
     }
 #pragma unroll
     for (int q = 0; q < R; q++) {
-      int k, k2; float root; bool arrived;
-      if (seed_decode(seed, g0[q], g1[q], 0, k, k2, root, arrived) && have[q]) {
-        hint[q] = k; hint2[q] = k2;
-        lb[q] = (double)root * (1.0 - 1e-6);          // lb_from_sq
+      const unsigned kk = (unsigned)g1[q];
+      if (have[q] && got[q] && (kk & 0xFFFFu) != 0xFFFFu) {
+        hint[q] = (int)(kk & 0xFFFFu); hint2[q] = (int)(kk >> 16);
+        lb[q] = (double)__uint_as_float((unsigned)g0[q]) * (1.0 - 1e-6);          // lb_from_sq
       }
     }
   }
@@ -976,8 +868,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     double bd[R]; bool keep[R], need[R];
     int ent[R];
     double2 mw[R];                            // the neighbour's coordinates
-    // (a wave whose bounds the helpers have renewed since skips the second scheduled renewal of its own)
-    const bool refresh = (iter == REFRESH_A) || (iter == REFRESH_B && !helper_renewed);
+    const bool refresh = (iter == REFRESH_A) || (iter == REFRESH_B);
     // OutOfBoundsFilter2D for one point: S.transform(P): (0 + x*R00) + y*R01, then + t (gsl/Matrix.cpp:403-432)
     auto inside_bounds = [&](double x, double y) {
       double wx = 0.0, wy = 0.0;
@@ -1272,20 +1163,6 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     for (int q = 0; q < R; q++)
       if (keep[q]) slotD[hint[q]] = ~0ull;
     if (tid == 0) L.ired[IR_CNT] = 0;
-    // the helpers' answer to the pending request is asked for here and looked at behind this step's transform (the reads' latency under
-    // the closed form and the transform): at the end of the step ICP_REQ_LAG behind the request and of the one after it
-    const int since = (int)iter - (ICP_REQ_FIRST + ICP_REQ_LAG);
-    const bool take = pending && since >= 0 && (since % ICP_REQ_EVERY) <= 1;          // (wave-uniform)
-    unsigned long long hg0[R], hg1[R];
-    if (take) {
-      const IcpSeedArgs sd = L.tail->seed;
-#pragma unroll
-      for (int q = 0; q < R; q++) {
-        const int i = have[q] ? pid[q] : 0;
-        hg0[q] = __hip_atomic_load(sd.g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        hg1[q] = __hip_atomic_load(sd.g + sd.stride + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
 
     double co = __builtin_nan(""), si = __builtin_nan(""), dX = __builtin_nan(""), dY = __builtin_nan("");   // Tlast of this step (trace)
     pairs = __builtin_amdgcn_readfirstlane(pairs);
@@ -1357,68 +1234,6 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
       state = TSD_ICP_NOTMATCHABLE;
     }
     TL(12);                                    // scene moved, bounds updated
-    if (take) {
-      // The helpers' renewal: neighbour, runner-up and a bound for the scene as it stood at the request.  Since then every point has
-      // moved by the rigid motion M = A_now A_req^-1; the straight distance |p - M^-1 p| it has covered (rounded up, plus 1e-9 m for
-      // the helpers' coordinates, which differ from these by rounding) comes off the bound, and the result is taken where it beats the
-      // bound the point has.  Next step's tier 0 confirms the neighbour from the registration's own coordinates.
-      const IcpSeedArgs sd = L.tail->seed;
-      const int rq = since / ICP_REQ_EVERY + 1;
-      bool ok = true;
-      int hk[R], hk2[R]; float hroot[R]; bool hval[R];
-#pragma unroll
-      for (int q = 0; q < R; q++) {
-        bool arrived;
-        hval[q] = seed_decode(sd, hg0[q], hg1[q], rq, hk[q], hk2[q], hroot[q], arrived);
-        ok &= arrived | !have[q];
-      }
-      if (__all(ok)) {
-        // B = A_req A_now^-1 with A_now = Tfinal Tinit^-1 (rigid: the inverse is R^T, -R^T t)
-        const double i0 = L.cst[8], i1 = L.cst[9], i2 = L.cst[10], i3 = L.cst[11], i4 = L.cst[12], i5 = L.cst[13];
-        const double n0 = Tf[0] * i0 + Tf[1] * i3, n1 = Tf[0] * i1 + Tf[1] * i4, n2 = Tf[0] * i2 + Tf[1] * i5 + Tf[2];
-        const double n3 = Tf[3] * i0 + Tf[4] * i3, n4 = Tf[3] * i1 + Tf[4] * i4, n5 = Tf[3] * i2 + Tf[4] * i5 + Tf[5];
-        const double v0 = n0, v1 = n3, v2 = -(n0 * n2 + n3 * n5), v3 = n1, v4 = n4, v5 = -(n1 * n2 + n4 * n5);      // A_now^-1
-        const double q0 = L.cst[16], q1 = L.cst[17], q2 = L.cst[18], q3 = L.cst[19], q4 = L.cst[20], q5 = L.cst[21];   // A_req
-        const double b0 = q0 * v0 + q1 * v3, b1 = q0 * v1 + q1 * v4, b2 = q0 * v2 + q1 * v5 + q2;
-        const double b3 = q3 * v0 + q4 * v3, b4 = q3 * v1 + q4 * v4, b5 = q3 * v2 + q4 * v5 + q5;
-#pragma unroll
-        for (int q = 0; q < R; q++) {
-          const double ex = (b0 * sx[q] + b1 * sy[q] + b2) - sx[q], ey = (b3 * sx[q] + b4 * sy[q] + b5) - sy[q];
-          const double moved = (double)(__builtin_amdgcn_sqrtf((float)(ex * ex + ey * ey) * 1.000001f) * 1.000001f) + 1e-9;
-          const double lbn = (double)hroot[q] * (1.0 - 1e-6) - moved;
-          if (have[q] && hval[q] && lbn > lb[q]) { hint[q] = hk[q]; hint2[q] = hk2[q]; lb[q] = lbn; }
-        }
-        pending = false; helper_renewed = true;
-      } else if (since % ICP_REQ_EVERY == 1) pending = false;             // (second look: given up)
-    }
-    {
-      const int at = (int)iter - ICP_REQ_FIRST;
-      if (helped && at >= 0 && (int)iter <= ICP_REQ_LAST && at % ICP_REQ_EVERY == 0 && state == TSD_ICP_PROCESSING) {
-        // a request: the motion that takes the staged scene to the scene as it stands now, and the filter threshold of the next step
-        if (wave == W - 1) {
-          const IcpSeedArgs sd = L.tail->seed;
-          const int rq = at / ICP_REQ_EVERY + 1;
-          const double i0 = L.cst[8], i1 = L.cst[9], i2 = L.cst[10], i3 = L.cst[11], i4 = L.cst[12], i5 = L.cst[13];
-          if (lane == 0) {
-            L.cst[0] = Tf[0] * i0 + Tf[1] * i3; L.cst[1] = Tf[0] * i1 + Tf[1] * i4; L.cst[2] = Tf[0] * i2 + Tf[1] * i5 + Tf[2];
-            L.cst[3] = Tf[3] * i0 + Tf[4] * i3; L.cst[4] = Tf[3] * i1 + Tf[4] * i4; L.cst[5] = Tf[3] * i2 + Tf[4] * i5 + Tf[5];
-            L.cst[6] = thr;
-          }
-          // (a wave's LDS accesses execute in order) fourteen lanes, one granule each: ONE store instruction
-          const unsigned half = reinterpret_cast<const unsigned int*>(L.cst)[lane < ICP_REQ_GRANULES ? lane : 0];
-          const unsigned long long rtag = (unsigned long long)(((sd.seq & 0x3FFFFFFu) << 6) | (unsigned)rq) << 32;
-          if (lane < ICP_REQ_GRANULES) __hip_atomic_store(sd.g - ICP_REQ_WORDS + lane, rtag | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          // the same motion kept for the moment the answer is taken (every wave computes it below from what it has: wave-uniform)
-        }
-        // A_req, kept by every wave's own lane 0 ... one copy is enough: the last wave wrote L.cst[0..5]; the others read it at `take`,
-        // two steps and several barriers later -- copied to its own place so that the next request's payload cannot overwrite it early
-        if (wave == W - 1 && lane == 0) {
-#pragma unroll
-          for (int k = 0; k < 6; k++) L.cst[16 + k] = L.cst[k];
-        }
-        pending = true;
-      }
-    }
     // -- loop control (Icp.cpp:489-511)
     iter++;
     {
@@ -1451,9 +1266,6 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     }
   }
 #endif
-  if (helped && tid == 0)      // dismiss the helpers
-    __hip_atomic_store(seed.g - ICP_REQ_WORDS, (unsigned long long)(((seed.seq & 0x3FFFFFFu) << 6) | (unsigned)ICP_REQ_DONE) << 32, __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
   {
     // Icp::getFinalTransformation (Icp.cpp:528-546)
     IcpResultDev r;
@@ -1549,11 +1361,11 @@ int icp_helpers_for(const tsd_ctx* ctx, int n, int T)
   const int h = (n + per - 1) / per;
   return h > ICP_MAX_HELPERS ? 0 : h;                // (more points than the helpers reach: the registration searches itself)
 }
-size_t icp_seed_bytes(int points) { return sizeof(unsigned long long) * (ICP_REQ_WORDS + 2 * (size_t)((points + 63) & ~63)); }
+size_t icp_seed_bytes(int points) { return 2 * sizeof(unsigned long long) * (size_t)((points + 63) & ~63); }
 IcpSeedArgs icp_seed_args(void* buf, int points, int helpers)
 {
   IcpSeedArgs sa;
-  sa.g = buf ? reinterpret_cast<unsigned long long*>(buf) + ICP_REQ_WORDS : nullptr;     // (the request block sits in front of the result granules)
+  sa.g = reinterpret_cast<unsigned long long*>(buf);
   sa.stride = (points + 63) & ~63;                   // the second granules follow the first (as laid out by icp_seed_bytes(points))
   unsigned int q = g_seed_seq.fetch_add(1u);
   if (q == 0u) q = g_seed_seq.fetch_add(1u);         // (0 is what a fresh buffer holds)
