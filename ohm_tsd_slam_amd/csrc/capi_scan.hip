@@ -812,15 +812,12 @@ int tsd_batch_begin(tsd_batch* b, int n, tsd_sensor* const* sensors, const doubl
     if (any_pre) {
       // TSD_PDFMatching::match of every armed robot (ThreadLocalize.cpp:557-567, each robot's own thread in the reference) on the
       // model its ray cast just produced; all of them score against the grid as it is before any push of this batch
-      for (int i = 0; i < n; i++) {
-        tsd_sensor* s = sensors[i];
-        if (!s->pre_armed) continue;
-        s->pre_armed = false;
-        const double* tinit = nullptr;
-        rc = launch_preregistration(ctx, s, ctx->stream, s->d_coords, s->d_mask_m, s->d_state->icpP, &tinit, nullptr);
-        if (rc != TSD_OK) return FAIL(rc);
-        s->pre_ran = true;
-      }
+      // (four launches for all of them: launch_preregistration_batch)
+      std::vector<tsd_sensor*> armed;
+      for (int i = 0; i < n; i++) if (sensors[i]->pre_armed) armed.push_back(sensors[i]);
+      rc = launch_preregistration_batch(ctx, ctx->stream, armed.data(), (int)armed.size());
+      if (rc != TSD_OK) return FAIL(rc);
+      for (tsd_sensor* s : armed) { s->pre_armed = false; s->pre_ran = true; }
     }
     if (dev_wait) {
       rc = launch_set_flag(ctx, ctx->stream, b->d_rc_flag, b->rc_batches);

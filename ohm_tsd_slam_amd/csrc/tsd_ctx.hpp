@@ -392,6 +392,7 @@ size_t push_list_aux_bytes();
 // *tinit_dev = where the registration kernel finds Tinit (tsdpdf.hip)
 int launch_preregistration(tsd_ctx* ctx, tsd_sensor* s, hipStream_t stream, const double* d_coords, const uint8_t* d_mask_m,
                            const double* d_pose6, const double** tinit_dev, hipEvent_t before_score = nullptr);
+int launch_preregistration_batch(tsd_ctx* ctx, hipStream_t stream, tsd_sensor* const* sensors, int n);
 size_t push_list_cnt_bytes();
 int launch_free_footprint(tsd_ctx* ctx, unsigned minX, unsigned maxX, unsigned minY, unsigned maxY);
 int launch_neg_scan(tsd_ctx* ctx);

@@ -55,11 +55,11 @@ constexpr int PDF_BATCH = 4;               // look-ups per LANE in flight togeth
 // round trips -- 164 us for 180 k look-ups.)
 constexpr int PDF_WAVES = 4;               // candidates per workgroup and round
 constexpr int PDF_SCORE_GRID = 1024;       // workgroups of the fused scan's scoring launch (4 096 waves stride over the candidates)
-__global__ void __launch_bounds__(64 * PDF_WAVES)
-k_pdf_score(GridDev g, const double* __restrict__ pose /* first two rows suffice */, const double* __restrict__ M, const double* __restrict__ S,
-            const double2* __restrict__ control, int n_control, const PdfCandidate* __restrict__ cand, int n_cand,
-            double zrand, double* __restrict__ prob_out, const PdfHeader* __restrict__ hdr /* counts from the device, or nullptr */,
-            int max_cand_alloc, int control_alloc /* entries the two arrays are allocated to (speculative reads) */)
+__device__ __forceinline__ void
+pdf_score_body(const GridDev& g, const double* __restrict__ pose /* first two rows suffice */, const double* __restrict__ M, const double* __restrict__ S,
+               const double2* __restrict__ control, int n_control, const PdfCandidate* __restrict__ cand, int n_cand,
+               double zrand, double* __restrict__ prob_out, const PdfHeader* __restrict__ hdr /* counts from the device, or nullptr */,
+               int max_cand_alloc, int control_alloc /* entries the two arrays are allocated to (speculative reads) */)
 {
   __shared__ double s_f[PDF_WAVES][PDF_MAX_CONTROL];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -146,12 +146,37 @@ k_pdf_score(GridDev g, const double* __restrict__ pose /* first two rows suffice
   }
 }
 
+__global__ void __launch_bounds__(64 * PDF_WAVES)
+k_pdf_score(GridDev g, const double* __restrict__ pose, const double* __restrict__ M, const double* __restrict__ S,
+            const double2* __restrict__ control, int n_control, const PdfCandidate* __restrict__ cand, int n_cand,
+            double zrand, double* __restrict__ prob_out, const PdfHeader* __restrict__ hdr, int max_cand_alloc, int control_alloc)
+{
+  pdf_score_body(g, pose, M, S, control, n_control, cand, n_cand, zrand, prob_out, hdr, max_cand_alloc, control_alloc);
+}
+
+// The pre-registrations of the armed robots of a BATCH (tsd_batch_begin, registration_mode 3 with several robots on one grid): the same
+// four kernels, one launch each for all robots -- block z (normals, scoring) / block x (list building, arg-max) = robot, its arguments
+// entry z / x of a by-value array.  Round 4 launched the four kernels per robot: 32 small dependent launches per batch of eight on the
+// grid's stream, 11.5 k scans/s where registration_mode 0 has 29 k.
+constexpr int PDF_BATCH_BYVAL = 16;        // robots per batched launch (the entries travel as kernel arguments: <= 2 KB)
+struct PdfScoreEntry {
+  const double* pose; const double* M; const double* S; const double2* control; const PdfCandidate* cand; double* prob;
+  const PdfHeader* hdr; double zrand; int max_cand, control_alloc;
+};
+struct PdfScoreBatch { PdfScoreEntry e[PDF_BATCH_BYVAL]; };
+__global__ void __launch_bounds__(64 * PDF_WAVES)
+k_pdf_score_batch(GridDev g, PdfScoreBatch b)
+{
+  const PdfScoreEntry& e = b.e[blockIdx.z];
+  pdf_score_body(g, e.pose, e.M, e.S, e.control, 0, e.cand, 0, e.zrand, e.prob, e.hdr, e.max_cand, e.control_alloc);
+}
+
 // first candidate in the reference's serial trial / i order (the key `ti`) that reaches the maximum; bestProb starts at
 // 0.0 and is replaced on `>` only (TSD_PDFMatching.cpp:188,264)
-__global__ void __launch_bounds__(1024)
-k_pdf_argmax(const double* __restrict__ prob, const PdfCandidate* __restrict__ cand, int n_cand, const double* __restrict__ M,
-             const double* __restrict__ S, PdfResult* __restrict__ out, const PdfHeader* __restrict__ hdr,
-             PdfHeader* __restrict__ host_hdr, PdfResult* __restrict__ host_res /* fused scan: pinned host memory, or nullptr */)
+__device__ __forceinline__ void
+pdf_argmax_body(const double* __restrict__ prob, const PdfCandidate* __restrict__ cand, int n_cand, const double* __restrict__ M,
+                const double* __restrict__ S, PdfResult* __restrict__ out, const PdfHeader* __restrict__ hdr,
+                PdfHeader* __restrict__ host_hdr, PdfResult* __restrict__ host_res /* fused scan: pinned host memory, or nullptr */)
 {
   if (hdr) n_cand = hdr->identity ? 0 : hdr->n_cand;
   __shared__ double s_p[1024];
@@ -195,6 +220,22 @@ k_pdf_argmax(const double* __restrict__ prob, const PdfCandidate* __restrict__ c
   }
 }
 
+__global__ void __launch_bounds__(1024)
+k_pdf_argmax(const double* __restrict__ prob, const PdfCandidate* __restrict__ cand, int n_cand, const double* __restrict__ M,
+             const double* __restrict__ S, PdfResult* __restrict__ out, const PdfHeader* __restrict__ hdr,
+             PdfHeader* __restrict__ host_hdr, PdfResult* __restrict__ host_res)
+{
+  pdf_argmax_body(prob, cand, n_cand, M, S, out, hdr, host_hdr, host_res);
+}
+struct PdfArgmaxEntry { const double* prob; const PdfCandidate* cand; const double* M; const double* S; PdfResult* out; const PdfHeader* hdr; PdfHeader* host_hdr; PdfResult* host_res; };
+struct PdfArgmaxBatch { PdfArgmaxEntry e[PDF_BATCH_BYVAL]; };
+__global__ void __launch_bounds__(1024)
+k_pdf_argmax_batch(PdfArgmaxBatch b)
+{
+  const PdfArgmaxEntry& e = b.e[blockIdx.x];
+  pdf_argmax_body(e.prob, e.cand, 0, e.M, e.S, e.out, e.hdr, e.host_hdr, e.host_res);
+}
+
 // ---- RandomMatching::calcNormals + calcPhi on the device (second half of round 3) ---------------------------------------------
 // One thread per point: Matrix::pcaAnalysis over its <= 10 masked-in neighbours, the axis-ratio test, the normal's sign, its angle.
 // The host restatement below (kept: it is what the oracle mirrors statement by statement) spends ~140 us per 1 081-point set, serial;
@@ -227,10 +268,8 @@ __device__ __forceinline__ DD dd_div_d(DD a, double b, double rb)
 }
 struct PdfNormalsSet { const double* xy; const uint8_t* mask_in; const uint8_t* mask_io_init; uint8_t* mask_io; double* phi; };
 
-__global__ void __launch_bounds__(256)
-k_pdf_normals(PdfNormalsSet set0, PdfNormalsSet set1, int points, int sr)
+__device__ __forceinline__ void pdf_normals_body(const PdfNormalsSet& st, int points, int sr)
 {
-  const PdfNormalsSet st = blockIdx.y == 0 ? set0 : set1;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= points) return;
   const double NO_PHI = -1e6;                                 // calcPhi's value for a masked-out point (RandomMatching.cpp:155-174)
@@ -326,6 +365,19 @@ k_pdf_normals(PdfNormalsSet set0, PdfNormalsSet set1, int points, int sr)
   else { nx = -xShort / len; ny = -yShort / len; }
   st.phi[i] = atan2(ny, nx);
 }
+__global__ void __launch_bounds__(256)
+k_pdf_normals(PdfNormalsSet set0, PdfNormalsSet set1, int points, int sr)
+{
+  pdf_normals_body(blockIdx.y == 0 ? set0 : set1, points, sr);
+}
+struct PdfNormalsEntry { PdfNormalsSet set0, set1; int points, sr; };
+struct PdfNormalsBatch { PdfNormalsEntry e[PDF_BATCH_BYVAL]; };
+__global__ void __launch_bounds__(256)
+k_pdf_normals_batch(PdfNormalsBatch b)
+{
+  const PdfNormalsEntry& e = b.e[blockIdx.z];
+  pdf_normals_body(blockIdx.y == 0 ? e.set0 : e.set1, e.points, e.sr);
+}
 
 // ---- the list building of TSD_PDFMatching::match on the device (fused scan: nothing returns to the host between the ray cast and the
 // registration).  ONE workgroup: extractSamples of both sets (index order), pickControlSet and the trial picks -- the reference erases
@@ -363,8 +415,7 @@ __device__ __forceinline__ int wave_incl_scan(int v)
   v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);     // row_bcast:31 -> rows 2, 3
   return v;
 }
-__global__ void __launch_bounds__(1024)
-k_pdf_prepare(PdfPrepareArgs p)
+__device__ __forceinline__ void pdf_prepare_body(const PdfPrepareArgs& p)
 {
   // everything the picks and the candidate passes read lives in LDS: the two sample lists, the scene's masks and angles
   __shared__ unsigned short s_idx[2][TSD_MAX_BEAMS];          // [0] scene, [1] model: valid indices, ascending
@@ -553,6 +604,17 @@ k_pdf_prepare(PdfPrepareArgs p)
     h.identity = identity ? 1 : 0; h.pad[0] = h.pad[1] = h.pad[2] = 0;
     *p.hdr = h;
   }
+}
+__global__ void __launch_bounds__(1024)
+k_pdf_prepare(PdfPrepareArgs p)
+{
+  pdf_prepare_body(p);
+}
+struct PdfPrepareBatch { PdfPrepareArgs e[PDF_BATCH_BYVAL]; };
+__global__ void __launch_bounds__(1024)
+k_pdf_prepare_batch(PdfPrepareBatch b)
+{
+  pdf_prepare_body(b.e[blockIdx.x]);
 }
 
 // ---- host side: RandomMatching's O(beams) preparation ------------------------------------------------------
@@ -889,23 +951,24 @@ extern "C" int tsd_scan_preregister(tsd_sensor* s, const tsd_tsdpdf_params* prm,
 }
 
 namespace tsd {
-int launch_preregistration(tsd_ctx* ctx, tsd_sensor* s, hipStream_t stream, const double* d_coords, const uint8_t* d_mask_m,
-                           const double* d_pose6, const double** tinit_dev, hipEvent_t before_score)
+// the four kernels' arguments of one sensor's armed pre-registration (its layout in s->d_pre, the ray cast's outputs, the pose)
+struct PreLaunch {
+  PdfNormalsEntry normals; PdfPrepareArgs prepare; PdfScoreEntry score; PdfArgmaxEntry argmax;
+  size_t prep_lds; int score_blocks;
+};
+static PreLaunch pre_launch_args(const tsd_sensor* s, const double* d_coords, const uint8_t* d_mask_m, const double* d_pose6)
 {
   const tsd_sensor::PreLayout& L = s->pre;
   char* d = s->d_pre;
   char* h_dev = s->h_pre_dev;               // the pinned buffer as the device sees it (header + result are written there by k_pdf_argmax)
   const int n = L.n, SR = 10 / 2;
-  if (!s->pre_copied) TSD_HIP_CHECK(ctx, hipMemcpyAsync(d, s->h_pre, L.in_bytes, hipMemcpyHostToDevice, stream));
-  else if (hipEventQuery(s->ev_pre) != hipSuccess) {
-    (void)hipGetLastError();                 // (hipErrorNotReady is sticky as "last error")
-    TSD_HIP_CHECK(ctx, hipStreamWaitEvent(stream, s->ev_pre, 0));
-  }
-  PdfNormalsSet sm{d_coords, d_mask_m, d_mask_m, reinterpret_cast<uint8_t*>(d + L.off_mo_m), reinterpret_cast<double*>(d + L.off_phi_m)};
-  PdfNormalsSet ss{reinterpret_cast<const double*>(d + L.off_S), reinterpret_cast<const uint8_t*>(d + L.off_ms),
-                   reinterpret_cast<const uint8_t*>(d + L.off_msp), reinterpret_cast<uint8_t*>(d + L.off_mo_s),
-                   reinterpret_cast<double*>(d + L.off_phi_s)};
-  PdfPrepareArgs pa;
+  PreLaunch pl;
+  pl.normals.set0 = PdfNormalsSet{d_coords, d_mask_m, d_mask_m, reinterpret_cast<uint8_t*>(d + L.off_mo_m), reinterpret_cast<double*>(d + L.off_phi_m)};
+  pl.normals.set1 = PdfNormalsSet{reinterpret_cast<const double*>(d + L.off_S), reinterpret_cast<const uint8_t*>(d + L.off_ms),
+                                  reinterpret_cast<const uint8_t*>(d + L.off_msp), reinterpret_cast<uint8_t*>(d + L.off_mo_s),
+                                  reinterpret_cast<double*>(d + L.off_phi_s)};
+  pl.normals.points = n; pl.normals.sr = SR;
+  PdfPrepareArgs& pa = pl.prepare;
   pa.mask_m = reinterpret_cast<const uint8_t*>(d + L.off_mo_m); pa.mask_s = reinterpret_cast<const uint8_t*>(d + L.off_mo_s);
   pa.phi_m = reinterpret_cast<const double*>(d + L.off_phi_m); pa.phi_s = reinterpret_cast<const double*>(d + L.off_phi_s);
   pa.S = reinterpret_cast<const double*>(d + L.off_S);
@@ -914,38 +977,97 @@ int launch_preregistration(tsd_ctx* ctx, tsd_sensor* s, hipStream_t stream, cons
   pa.hdr = reinterpret_cast<PdfHeader*>(d + L.off_hdr);
   pa.n = n; pa.sr = SR; pa.span = L.span; pa.trials_cfg = L.trials; pa.size_control_set = L.size_control_set; pa.max_cand = L.max_cand;
   pa.phi_max = L.phi_max;
-  const size_t prep_lds = ((size_t)n + (size_t)PDF_MAX_TRIALS) * sizeof(double);
-  {
-    // (k_pdf_prepare's static LDS is ~33 KB; beyond ~3 000 beams the dynamic part needs the attribute)
-    std::lock_guard<std::mutex> lk_misc(ctx->misc_mutex);
-    size_t& configured = ctx->lds_configured[reinterpret_cast<const void*>(k_pdf_prepare)];
-    if (prep_lds > configured) {
-      TSD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pdf_prepare), hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds));
-      configured = prep_lds;
-    }
+  pl.prep_lds = ((size_t)n + (size_t)PDF_MAX_TRIALS) * sizeof(double);
+  pl.score = PdfScoreEntry{d_pose6, d_coords, reinterpret_cast<const double*>(d + L.off_S), reinterpret_cast<const double2*>(d + L.off_C),
+                           reinterpret_cast<const PdfCandidate*>(d + L.off_K), reinterpret_cast<double*>(d + L.off_prob),
+                           reinterpret_cast<const PdfHeader*>(d + L.off_hdr), L.zrand, L.max_cand, std::max(L.size_control_set, 1)};
+  pl.score_blocks = std::min((L.max_cand + PDF_WAVES - 1) / PDF_WAVES, PDF_SCORE_GRID);
+  pl.argmax = PdfArgmaxEntry{reinterpret_cast<const double*>(d + L.off_prob), reinterpret_cast<const PdfCandidate*>(d + L.off_K), d_coords,
+                             reinterpret_cast<const double*>(d + L.off_S), reinterpret_cast<PdfResult*>(d + L.off_res),
+                             reinterpret_cast<const PdfHeader*>(d + L.off_hdr), reinterpret_cast<PdfHeader*>(h_dev + L.off_hdr),
+                             reinterpret_cast<PdfResult*>(h_dev + L.off_res)};
+  return pl;
+}
+// the inputs of an armed pre-registration must be on the device before its kernels: copied at arm time on the side stream (waited for
+// by event) or, where that was switched off, here
+static int pre_inputs_ready(tsd_ctx* ctx, tsd_sensor* s, hipStream_t stream)
+{
+  if (!s->pre_copied) TSD_HIP_CHECK(ctx, hipMemcpyAsync(s->d_pre, s->h_pre, s->pre.in_bytes, hipMemcpyHostToDevice, stream));
+  else if (hipEventQuery(s->ev_pre) != hipSuccess) {
+    (void)hipGetLastError();                 // (hipErrorNotReady is sticky as "last error")
+    TSD_HIP_CHECK(ctx, hipStreamWaitEvent(stream, s->ev_pre, 0));
   }
+  return TSD_OK;
+}
+static int pre_configure_lds(tsd_ctx* ctx, const void* kernel, size_t prep_lds)
+{
+  // (k_pdf_prepare's static LDS is ~33 KB; beyond ~3 000 beams the dynamic part needs the attribute)
+  std::lock_guard<std::mutex> lk_misc(ctx->misc_mutex);
+  size_t& configured = ctx->lds_configured[kernel];
+  if (prep_lds > configured) {
+    TSD_HIP_CHECK(ctx, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds));
+    configured = prep_lds;
+  }
+  return TSD_OK;
+}
+
+int launch_preregistration(tsd_ctx* ctx, tsd_sensor* s, hipStream_t stream, const double* d_coords, const uint8_t* d_mask_m,
+                           const double* d_pose6, const double** tinit_dev, hipEvent_t before_score)
+{
+  const tsd_sensor::PreLayout& L = s->pre;
+  if (int rc = pre_inputs_ready(ctx, s, stream)) return rc;
+  const PreLaunch pl = pre_launch_args(s, d_coords, d_mask_m, d_pose6);
+  if (int rc = pre_configure_lds(ctx, reinterpret_cast<const void*>(k_pdf_prepare), pl.prep_lds)) return rc;
   {
     ScopedKernelTimer t(ctx, "tsdpdf", true);
-    hipLaunchKernelGGL(k_pdf_normals, dim3((n + 255) / 256, 2), dim3(256), 0, stream, sm, ss, n, SR);
-    hipLaunchKernelGGL(k_pdf_prepare, dim3(1), dim3(1024), prep_lds, stream, pa);
+    hipLaunchKernelGGL(k_pdf_normals, dim3((L.n + 255) / 256, 2), dim3(256), 0, stream, pl.normals.set0, pl.normals.set1, L.n, pl.normals.sr);
+    hipLaunchKernelGGL(k_pdf_prepare, dim3(1), dim3(1024), pl.prep_lds, stream, pl.prepare);
     // (asynchronous mapping: the scoring is the first kernel of the chain that reads the grid)
     if (before_score) TSD_HIP_CHECK(ctx, hipStreamWaitEvent(stream, before_score, 0));
-    hipLaunchKernelGGL(k_pdf_score, dim3(std::min((L.max_cand + PDF_WAVES - 1) / PDF_WAVES, PDF_SCORE_GRID)), dim3(64 * PDF_WAVES), 0, stream, ctx->grid, d_pose6,
-                       d_coords, reinterpret_cast<const double*>(d + L.off_S), reinterpret_cast<const double2*>(d + L.off_C), 0,
-                       reinterpret_cast<const PdfCandidate*>(d + L.off_K), 0, L.zrand, reinterpret_cast<double*>(d + L.off_prob),
-                       reinterpret_cast<const PdfHeader*>(d + L.off_hdr), L.max_cand, std::max(L.size_control_set, 1));
+    hipLaunchKernelGGL(k_pdf_score, dim3(pl.score_blocks), dim3(64 * PDF_WAVES), 0, stream, ctx->grid, pl.score.pose, pl.score.M, pl.score.S,
+                       pl.score.control, 0, pl.score.cand, 0, pl.score.zrand, pl.score.prob, pl.score.hdr, pl.score.max_cand, pl.score.control_alloc);
     // (the arg-max's own completion is the event a pre-registration armed AHEAD waits for before it overwrites the inputs: no marker
     // between this kernel and the registration)
     if (!s->ev_pre_done) TSD_HIP_CHECK(ctx, hipEventCreateWithFlags(&s->ev_pre_done, hipEventDisableTiming | hipEventDisableSystemFence));
-    hipExtLaunchKernelGGL(k_pdf_argmax, dim3(1), dim3(1024), 0, stream, nullptr, s->ev_pre_done, 0, reinterpret_cast<const double*>(d + L.off_prob),
-                       reinterpret_cast<const PdfCandidate*>(d + L.off_K), 0, d_coords, reinterpret_cast<const double*>(d + L.off_S),
-                       reinterpret_cast<PdfResult*>(d + L.off_res), reinterpret_cast<const PdfHeader*>(d + L.off_hdr),
-                       reinterpret_cast<PdfHeader*>(h_dev + L.off_hdr), reinterpret_cast<PdfResult*>(h_dev + L.off_res));
+    hipExtLaunchKernelGGL(k_pdf_argmax, dim3(1), dim3(1024), 0, stream, nullptr, s->ev_pre_done, 0, pl.argmax.prob, pl.argmax.cand, 0, pl.argmax.M,
+                       pl.argmax.S, pl.argmax.out, pl.argmax.hdr, pl.argmax.host_hdr, pl.argmax.host_res);
     s->pre_done_valid = true;
     s->pre_res_off_hdr = L.off_hdr; s->pre_res_off_res = L.off_res;
   }
   TSD_HIP_CHECK(ctx, hipGetLastError());
-  *tinit_dev = reinterpret_cast<const double*>(d + L.off_res);
+  *tinit_dev = reinterpret_cast<const double*>(s->d_pre + L.off_res);
+  return TSD_OK;
+}
+
+// The armed pre-registrations of a batch's robots (tsd_batch_begin) in four launches instead of four per robot; each robot's result
+// lands where its own launch_preregistration would have put it (s->d_pre + off_res: the Tinit of its registration).
+int launch_preregistration_batch(tsd_ctx* ctx, hipStream_t stream, tsd_sensor* const* sensors, int n)
+{
+  for (int i0 = 0; i0 < n; i0 += PDF_BATCH_BYVAL) {
+    const int m = std::min(n - i0, PDF_BATCH_BYVAL);
+    PdfNormalsBatch bn{}; PdfPrepareBatch bp{}; PdfScoreBatch bs{}; PdfArgmaxBatch ba{};
+    int max_points = 0, max_blocks = 1;
+    size_t max_lds = 0;
+    for (int i = 0; i < m; i++) {
+      tsd_sensor* s = sensors[i0 + i];
+      if (int rc = pre_inputs_ready(ctx, s, stream)) return rc;
+      const PreLaunch pl = pre_launch_args(s, s->d_coords, s->d_mask_m, s->d_state->icpP);
+      bn.e[i] = pl.normals; bp.e[i] = pl.prepare; bs.e[i] = pl.score; ba.e[i] = pl.argmax;
+      max_points = std::max(max_points, pl.normals.points); max_blocks = std::max(max_blocks, pl.score_blocks); max_lds = std::max(max_lds, pl.prep_lds);
+      s->pre_done_valid = false;              // (no event of this sensor's own behind the batched arg-max; batches are armed between scans)
+      s->pre_res_off_hdr = s->pre.off_hdr; s->pre_res_off_res = s->pre.off_res;
+    }
+    if (int rc = pre_configure_lds(ctx, reinterpret_cast<const void*>(k_pdf_prepare_batch), max_lds)) return rc;
+    // (the scoring strides a fixed grid over each robot's candidates: a share of the single launch's grid per robot keeps the
+    // batch's workgroups at about that launch's number)
+    const int blocks = std::max(64, std::min(max_blocks, PDF_SCORE_GRID / std::max(1, m / 2)));
+    ScopedKernelTimer t(ctx, "tsdpdf", true);
+    hipLaunchKernelGGL(k_pdf_normals_batch, dim3((max_points + 255) / 256, 2, m), dim3(256), 0, stream, bn);
+    hipLaunchKernelGGL(k_pdf_prepare_batch, dim3(m), dim3(1024), max_lds, stream, bp);
+    hipLaunchKernelGGL(k_pdf_score_batch, dim3(blocks, 1, m), dim3(64 * PDF_WAVES), 0, stream, ctx->grid, bs);
+    hipLaunchKernelGGL(k_pdf_argmax_batch, dim3(m), dim3(1024), 0, stream, ba);
+    TSD_HIP_CHECK(ctx, hipGetLastError());
+  }
   return TSD_OK;
 }
 }  // namespace tsd

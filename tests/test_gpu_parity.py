@@ -849,6 +849,37 @@ def test_cfg3_full_size_properties(oracle):
     assert np.max(np.abs(co[sel] - cd[sel])) <= 1e-9 and np.max(np.abs(no[sel] - nd[sel])) <= 1e-9
 
 
+def test_map_size_15_smoke(oracle):
+    """The largest grid the node accepts (/root/reference/src/SlamNode.cpp:71-75: map_size up to 15 = 32 768 x 32 768 cells, 1 048 576
+    tiles; 18.8 GB of fp64 cells on the device): two pushes and a ray cast against the oracle -- push statistics, the state of every
+    tile and the hit mask exact, coordinates within 1e-9.  Skipped on a device with less than 45 GB free."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    free_b, total_b = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    if hip.hipMemGetInfo(ctypes.byref(free_b), ctypes.byref(total_b)) != 0 or free_b.value < 45 * (1 << 30):
+        pytest.skip("less than 45 GB of device memory free")
+    gc = synth.GridConfig(15, 0.01)
+    geo = synth.ScanGeometry.utm30lx()
+    world = synth.World("pillars", gc)
+    og, dg = make_pair(oracle, gc)
+    assert dg.tiles == 1 << 20 and og.tiles == dg.tiles
+    for k in range(2):
+        so, sd = push_both(oracle, og, dg, world, geo, k * 5)
+        assert so == sd, f"push {k}: {so} / {sd}"
+    assert sd["tiles_total"] == 1 << 20 and sd["cells_updated"] > 1000000
+    oi, oiw = og.tile_state()
+    di, diw = dg.download_tile_state()
+    assert np.array_equal(oi, di) and np.array_equal(oiw, diw) and int(oi.sum()) > 1000
+    pose, _ = H.sensor_pose(world, 7)
+    rl, rw = H.world_rays(oracle, geo, pose, gc.cell_size)
+    co, no, mo, cnt_o = og.raycast(pose, rw, H.MIN_RANGE, H.MAX_RANGE)
+    cd, nd, md, cnt_d = dg.raycast(pose, rw, H.MIN_RANGE, H.MAX_RANGE)
+    assert np.array_equal(mo, md) and cnt_o == cnt_d and cnt_o > 0.5 * geo.beams
+    sel = np.repeat(mo.astype(bool), 2)
+    assert np.max(np.abs(co[sel] - cd[sel])) <= 1e-9 and np.max(np.abs(no[sel] - nd[sel])) <= 1e-9
+    dg.close()
+
+
 # ------------------------------------------------------------------------------------------------
 # whole-grid digest (tsd_grid_digest): the hash the cfg 1-3 fixtures pin, against the oracle's digest of its own dump
 def test_grid_digest_matches_oracle(oracle):
