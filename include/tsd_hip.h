@@ -414,6 +414,10 @@ int tsd_debug_stall_push_stream(tsd_ctx* ctx, unsigned int microseconds);
  * nearest neighbours from the helper workgroups the launch brings by default (icp_kernels.hip: IcpSeed).  The results are the same
  * either way, bit for bit (tests/test_gpu_parity.py::test_icp_helpers_change_nothing); only the time differs. */
 int tsd_debug_set_icp_helpers(tsd_ctx* ctx, int on);
+/* TEST HOOK: on = 0 makes tsd_batch_push enqueue one push per robot, in the batch's order (the reference's mapper: one sensor after the
+ * other, ThreadMapping.cpp:43-76), instead of the one pass per tile that applies the robots' updates in that order inside every tile
+ * (csrc/push_multi.hip).  The grids are the same cell for cell, halo included (tests/test_gpu_batch.py). */
+int tsd_debug_set_push_multi(tsd_ctx* ctx, int on);
 
 /* the pre-registration's outcome for the scan collected last (TBest, probability, winning pair, counts) */
 int tsd_scan_preregistration_result(tsd_sensor* s, tsd_tsdpdf_result* result);

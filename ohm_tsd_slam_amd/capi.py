@@ -174,6 +174,7 @@ ABI = {
     "tsd_sensor_set_async_mapping": (C.c_int, [C.c_void_p, C.c_int]),
     "tsd_debug_stall_push_stream": (C.c_int, [C.c_void_p, C.c_uint]),
     "tsd_debug_set_icp_helpers": (C.c_int, [C.c_void_p, C.c_int]),
+    "tsd_debug_set_push_multi": (C.c_int, [C.c_void_p, C.c_int]),
     "tsd_color_image": (C.c_int, [C.c_void_p, _u8p, C.c_uint, C.c_uint]),
     "tsd_store_grid_text": (C.c_int, [C.c_void_p, C.c_char_p]),
     "tsd_load_grid_text": (C.c_int, [C.c_void_p, C.c_char_p]),
@@ -373,6 +374,10 @@ class TsdGridDevice:
     def set_icp_helpers(self, on: bool):
         """test hook: off = every registration does its first step's searches itself (same results, tsd_debug_set_icp_helpers)"""
         self._check(self.lib.tsd_debug_set_icp_helpers(self.h, 1 if on else 0), "tsd_debug_set_icp_helpers")
+
+    def set_push_multi(self, on: bool):
+        """test hook: off = tsd_batch_push enqueues one push per robot instead of one pass per tile (same grid, tsd_debug_set_push_multi)"""
+        self._check(self.lib.tsd_debug_set_push_multi(self.h, 1 if on else 0), "tsd_debug_set_push_multi")
 
     def icp_pairs(self, model_xy, scene_xy, pose, params: IcpParams, calls: int):
         """tsd_icp_pairs: [(model_idx, scene_idx)] of each of the first ``calls`` determinePairs calls on the static scene"""

@@ -373,6 +373,7 @@ tsd_ctx* tsd_create(int device, int map_size_log2, double cell_size, double max_
   A(hipMalloc(&ctx->d_start, TSD_MAX_ICP_POINTS * sizeof(int)));
   if (const char* e = std::getenv("TSD_ICP_SHAPE")) ctx->icp_shape = std::atoi(e);
   if (const char* e = std::getenv("TSD_ICP_HELPERS")) ctx->icp_helpers = std::atoi(e) != 0;
+  if (const char* e = std::getenv("TSD_PUSH_MULTI")) ctx->push_multi = std::atoi(e) != 0;
   A(hipMalloc(&ctx->d_icp_res, sizeof(IcpResultDev)));
   A(hipMalloc(&ctx->d_icp_seed, icp_seed_bytes(TSD_MAX_ICP_POINTS)));
   if (ok) A(hipMemsetAsync(ctx->d_icp_seed, 0, icp_seed_bytes(TSD_MAX_ICP_POINTS), ctx->stream));
@@ -430,7 +431,7 @@ void tsd_destroy(tsd_ctx* ctx)
   GridDev& g = ctx->grid;
   hipFree(g.flags); hipFree(g.init_weight); hipFree(g.tsd); hipFree(g.weight); hipFree(g.negmask);
   if (ctx->stream2) hipStreamSynchronize(ctx->stream2);
-  hipFree(ctx->d_rmq2[0]); hipFree(ctx->d_rmq2[1]); hipFree(ctx->d_tile_rec); hipFree(ctx->d_dirty); hipFree(ctx->d_tile_totals); hipFree(ctx->d_pushes); hipFree(ctx->d_list); hipFree(ctx->d_list_h); hipFree(ctx->d_list_aux); hipFree(ctx->d_push_args); hipFree(ctx->d_list_cnt);
+  hipFree(ctx->d_rmq2[0]); hipFree(ctx->d_rmq2[1]); hipFree(ctx->d_tile_rec); hipFree(ctx->d_dirty); hipFree(ctx->d_tile_totals); hipFree(ctx->d_pushes); hipFree(ctx->d_list); hipFree(ctx->d_list_h); hipFree(ctx->d_mp_mask); hipFree(ctx->d_mp_rec); hipFree(ctx->d_mp_list); hipFree(ctx->d_list_aux); hipFree(ctx->d_push_args); hipFree(ctx->d_list_cnt);
   if (ctx->ev_tables) hipEventDestroy(ctx->ev_tables);
   if (ctx->ev_h2d) hipEventDestroy(ctx->ev_h2d);
   if (ctx->ev_grid) hipEventDestroy(ctx->ev_grid);

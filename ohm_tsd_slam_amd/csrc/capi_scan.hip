@@ -198,6 +198,13 @@ int tsd_debug_set_icp_helpers(tsd_ctx* ctx, int on)
   return TSD_OK;
 }
 
+int tsd_debug_set_push_multi(tsd_ctx* ctx, int on)
+{
+  if (!ctx) return TSD_E_ARG;
+  ctx->push_multi = on ? 1 : 0;
+  return TSD_OK;
+}
+
 int tsd_scan_stage(tsd_sensor* s, const double* ranges, const uint8_t* mask, const uint8_t* mask_push)
 {
   if (!s || !s->ctx || !ranges || !mask) return TSD_E_ARG;
@@ -849,6 +856,28 @@ int tsd_batch_push(tsd_batch* b)
   const bool gate = b->dev_wait;                          // (else: the stream event for the whole batch's kernel)
   if (!gate) TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, b->ev_icp_done, 0));
   if (int rcw = wait_for_readers(ctx)) return rcw;
+  if (ctx->push_multi && b->n >= 2 && b->n <= push_multi_max_robots()) {
+    // The robots' pushes in ONE pass per tile (push_multi.hip): every tile the batch touches is read and written once, each robot's
+    // update applied in the batch's order -- the grid the serial pushes below leave, cell for cell.  One gate for all registrations.
+    const int n = b->n;
+    const unsigned long long* seqp[16]; unsigned long long seqv[16]; PushArgs* pushp[16];
+    const PushArgs* ap[16]; const double* rg[16]; const uint8_t* mk[16]; const char* rq[16];
+    double cx[16], cy[16], sl[16], mr[16]; int bm[16];
+    for (int i = 0; i < n; i++) {
+      tsd_sensor* s = b->sensors[(size_t)i];
+      const size_t nb = (size_t)s->beams;
+      const char* d_scan = b->d_stage_cur + b->scan_off[(size_t)i];
+      seqp[i] = &s->d_state->done_seq; seqv[i] = b->seqs[(size_t)i]; pushp[i] = &s->d_state->push;
+      ap[i] = &s->d_state->push; rg[i] = reinterpret_cast<const double*>(d_scan); mk[i] = reinterpret_cast<const uint8_t*>(d_scan + nb * 9);
+      rq[i] = s->d_rmq2[s->rmq_slot];
+      cx[i] = s->pos[0]; cy[i] = s->pos[1]; sl[i] = b->gates[(size_t)i].reg_trs_max; mr[i] = s->max_range; bm[i] = s->beams;
+    }
+    if (gate) { if (int rcg = launch_wait_seq_multi(ctx, n, seqp, seqv, pushp, b->d_gate_err, b->poll_bound)) return rcg; }
+    if (int rc = launch_push_multi(ctx, ctx->stream, n, ap, rg, mk, rq, cx, cy, sl, bm, mr)) return rc;
+    ctx->epoch++;
+    b->push_enqueued = true;
+    return TSD_OK;
+  }
   for (int i = 0; i < b->n; i++) {
     tsd_sensor* s = b->sensors[(size_t)i];
     // robot i's push starts when robot i's registration is done (its epilogue has left the push arguments and published the

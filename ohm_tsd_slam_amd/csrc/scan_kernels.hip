@@ -4,6 +4,7 @@
 // isPoseChangeSignificant, arguments of the push and of the next ray cast) are the epilogue of k_icp
 // (scan_device.hpp: scan_post_body); this file holds the argument derivation for a pose set from the host.
 #include "scan_device.hpp"
+#include <cstring>
 
 namespace tsd {
 
@@ -80,6 +81,35 @@ int launch_stall(tsd_ctx* ctx, hipStream_t stream, unsigned int us)
 int launch_set_flag(tsd_ctx* ctx, hipStream_t stream, unsigned int* flag, unsigned int value)
 {
   hipLaunchKernelGGL(k_set_flag, dim3(1), dim3(64), 0, stream, flag, value);
+  TSD_HIP_CHECK(ctx, hipGetLastError());
+  return TSD_OK;
+}
+
+// the same gate for ALL robots of a batch at once (their pushes run as one pass: push_multi.hip): lane i waits for robot i
+struct WaitSeqMulti { const unsigned long long* seq[16]; unsigned long long value[16]; PushArgs* push[16]; int n; };
+__global__ void __launch_bounds__(64) k_wait_seq_multi(WaitSeqMulti w, unsigned int* err_host, unsigned int poll_bound)
+{
+  const int i = threadIdx.x;
+  if (i < w.n) {
+    unsigned int polls = 0u;
+    bool arrived;
+    while (!(arrived = __hip_atomic_load(w.seq[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == w.value[i]) && ++polls < poll_bound)
+      __builtin_amdgcn_s_sleep(32);
+    if (!arrived) {
+      w.push[i]->enabled = 0;
+      __hip_atomic_store(err_host, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+int launch_wait_seq_multi(tsd_ctx* ctx, int n, const unsigned long long* const* seq, const unsigned long long* value, PushArgs* const* push,
+                          unsigned int* err_host, unsigned int poll_bound)
+{
+  if (n < 1 || n > 16) return set_error(ctx, TSD_E_ARG, "launch_wait_seq_multi", hipSuccess);
+  WaitSeqMulti w;
+  std::memset(&w, 0, sizeof(w));
+  w.n = n;
+  for (int i = 0; i < n; i++) { w.seq[i] = seq[i]; w.value[i] = value[i]; w.push[i] = push[i]; }
+  hipLaunchKernelGGL(k_wait_seq_multi, dim3(1), dim3(64), 0, ctx->stream, w, err_host, poll_bound);
   TSD_HIP_CHECK(ctx, hipGetLastError());
   return TSD_OK;
 }

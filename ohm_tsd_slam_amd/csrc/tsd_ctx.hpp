@@ -226,6 +226,9 @@ struct tsd_ctx {
   int* d_morig = nullptr;        // [TSD_MAX_ICP_POINTS] original index of every angle-sorted model point
   int* d_start = nullptr;        // [TSD_MAX_ICP_POINTS] first search slot of every scene point
   int icp_shape = 0;             // 0 = default workgroup shape (env TSD_ICP_SHAPE for experiments)
+  int push_multi = 1;            // the pushes of a batch of robots in one pass per tile (push_multi.hip; tsd_debug_set_push_multi: 0 = one push per robot)
+  void* d_mp_mask = nullptr; void* d_mp_rec = nullptr; void* d_mp_list = nullptr;      // its per-window-tile masks, (tile, robot) records, tile list
+  size_t mp_tiles = 0; unsigned mp_parity = 0;
   int icp_helpers = 1;           // step 0's searches by helper workgroups (tsd_debug_set_icp_helpers: 0 = the registration searches itself)
   void* d_icp_seed = nullptr;    // their hand-off buffer (icp_seed_bytes(TSD_MAX_ICP_POINTS))
   tsd::IcpResultDev* d_icp_res = nullptr;
@@ -420,6 +423,11 @@ int launch_raycast_batch(tsd_ctx* ctx, hipStream_t stream, const RaycastBatchEnt
 int launch_raycast_batch_byval(tsd_ctx* ctx, hipStream_t stream, const RaycastBatchEntry* h_entries, int n, int max_beams);   // n <= RC_BATCH_BYVAL
 int launch_push_tables_batch(tsd_ctx* ctx, hipStream_t stream, const TablesBatchEntry* d_entries, int n, int max_beams);
 int launch_icp_batch(tsd_ctx* ctx, hipStream_t stream, const IcpBatchEntry* host, const IcpBatchEntry* d_entries, int n);
+int push_multi_max_robots();
+int launch_push_multi(tsd_ctx* ctx, hipStream_t stream, int n, const PushArgs* const* a_dev, const double* const* d_ranges, const uint8_t* const* d_mask,
+                      const char* const* d_rmq, const double* cx, const double* cy, const double* slack, const int* beams, const double* max_range);
+int launch_wait_seq_multi(tsd_ctx* ctx, int n, const unsigned long long* const* seq, const unsigned long long* value, PushArgs* const* push,
+                          unsigned int* err_host, unsigned int poll_bound);
 size_t icp_seed_bytes(int points);
 IcpSeedArgs icp_batch_seed_args(const tsd_ctx* ctx, void* buf, int beams, int batch_beams);
 

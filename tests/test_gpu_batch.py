@@ -153,6 +153,46 @@ def test_batch_matches_oracle(oracle, cfg, n_robots, n_scans):
         s.close()
 
 
+@pytest.mark.parametrize("cfg,n_robots,n_scans", [("cfg1", 4, 12), ("cfg2", 6, 8)])
+def test_batch_push_in_one_pass_equals_serial_pushes(oracle, cfg, n_robots, n_scans):
+    """tsd_batch_push applies the robots' pushes in ONE pass per tile (csrc/push_multi.hip: every tile read and written once, the
+    robots' updates in the batch's order inside it, one halo pass at the end).  With tsd_debug_set_push_multi(0) it enqueues one push
+    per robot like the reference's mapper (ThreadMapping.cpp:43-76).  Two device grids driven identically, one in each mode: every
+    scan result, the accumulated push statistics and the WHOLE grid -- tile states, cells, halos: the canonical dump and its 64-bit
+    digest -- are bit-identical, and both equal the oracle's serial pushes within the suite's bar."""
+    runs = []
+    for multi in (True, False):
+        gc, geo, kw, og, dg, robots, scans, sensors, params, gates = _setup(oracle, cfg, n_robots, n_scans)
+        dg.set_push_multi(multi)
+        batch = capi.TsdBatch(dg, n_robots)
+        bounds = (dg.min_x, dg.max_x, dg.min_y, dg.max_y)
+        dg.push_stats_total(reset=True)
+        results = []
+        for k in range(1, n_scans):
+            ing = [rb.ingest(sc[k]) for rb, sc in zip(robots, scans)]
+            ros = [rb.localise(og, d_, m_, bounds) for rb, (d_, m_, _) in zip(robots, ing)]
+            for rb in robots:
+                rb.apply_push(og)
+            batch.begin(sensors, [x[0] for x in ing], [x[1] for x in ing], [x[2] for x in ing], params, gates)
+            res = batch.results()
+            for i, (ro, sr) in enumerate(zip(ros, res)):
+                _compare(k, i, ro, sr)
+            results.append([(np.array(sr.pose[:]).tobytes(), int(sr.pushed), int(sr.icp.pairs)) for sr in res])
+        H.assert_grids_equal(og.dump(), dg.download_tiles(), 1e-5)
+        runs.append((results, dg.push_stats_total(), dg.digest(), dg.download_tiles()))
+        batch.close()
+        for s in sensors:
+            s.close()
+        dg.close()
+    (ra, sa, da, ta), (rb_, sb, db, tb) = runs
+    assert ra == rb_, "scan results differ between the one-pass and the serial pushes"
+    assert sa == sb, f"push statistics differ: {sa} / {sb}"
+    assert sa[1] >= (n_scans - 1) * n_robots // 2
+    assert da == db, f"grid digests differ: {da} / {db}"
+    for x, y in zip(ta, tb):
+        assert np.array_equal(x, y, equal_nan=True)
+
+
 def test_batch_with_the_pre_registration_matches_oracle(oracle):
     """registration_mode 3 for several robots on one grid (the reference runs `case TSD` in every robot's thread,
     /root/reference/src/ThreadLocalize.cpp:557-567): every robot's pre-registration is armed (tsd_scan_preregister: scene points + the
