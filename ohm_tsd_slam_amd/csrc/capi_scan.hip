@@ -774,7 +774,12 @@ int tsd_batch_begin(tsd_batch* b, int n, tsd_sensor* const* sensors, const doubl
     e.post.gmin_x = ctx->grid.min_x; e.post.gmax_x = ctx->grid.max_x; e.post.gmin_y = ctx->grid.min_y; e.post.gmax_y = ctx->grid.max_y;
     e.post.gates = GateArgs{gates[i].reg_trs_max, gates[i].reg_sin_rot_max, gates[i].trs_min, gates[i].rot_min};
   }
-  for (int i = 0; i < n; i++) h_icp[i].seed = icp_batch_seed_args(ctx, sensors[i]->d_icp_seed, sensors[i]->beams, max_beams);
+  // (step 0's searches on helper workgroups: measured worth it for batches of up to four registrations -- +6 % scans/s at two per batch,
+  // even at four, -2 to -10 % at eight, where forty more polling workgroups sit beside the ray casts)
+  for (int i = 0; i < n; i++) {
+    h_icp[i].seed = icp_batch_seed_args(ctx, sensors[i]->d_icp_seed, sensors[i]->beams, max_beams);
+    if (n > 4) h_icp[i].seed.helpers = 0;
+  }
   // the registrations go out AHEAD of the ray casts and wait for the slot's flag on the device (where the probe allowed it).
   // A batch that carries a pre-registration (registration_mode 3) orders its registrations behind the grid stream's work by an
   // event instead: the pre-registration kernels sit between the ray casts and the registrations, on the grid's stream -- the scoring
