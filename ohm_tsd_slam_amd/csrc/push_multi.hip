@@ -56,7 +56,7 @@ k_mp_classify(GridDev g, MultiPushArgs mp, uint32_t* __restrict__ tile_rec, cons
     // (robot 0's blocks run whether its push is enabled or not) the window's per-push records are not kept by this path; the next
     // batch's list counter
     if (in_window && owner) tile_rec[p] = 0u;
-    if (blockIdx.x == 0 && threadIdx.x == 0) cnt[parity ^ 1] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { cnt[parity ^ 1] = 0u; cnt[2 + (parity ^ 1)] = 0u; }
   }
   const uint8_t t_dirty = ld_pinned(&dirty[p]);
   uint32_t kind = 0u, far_flag = 0u;
@@ -166,29 +166,41 @@ k_mp_classify(GridDev g, MultiPushArgs mp, uint32_t* __restrict__ tile_rec, cons
 
 // ------------------------------------------------------------------------------------------------------------------------------
 constexpr int MP_BLOCK = 256;
+constexpr int MP_ARG_DOUBLES = (sizeof(PushArgs) + 7) / 8;
 __host__ __device__ inline size_t mp_update_lds_bytes(int beams)
 {
   const size_t bp = (size_t)((beams + 3) & ~3);
-  return 2 * TILE_STRIDE * sizeof(double) + bp * sizeof(double) + 2 * TILE_DIM * sizeof(double) + ROT_N * sizeof(double2) + bp * sizeof(float) +
-         UPD_CAND_MAX * sizeof(uint32_t);
+  return 2 * TILE_STRIDE * sizeof(double) + bp * sizeof(double) + 2 * TILE_DIM * sizeof(double) + ROT_N * sizeof(double2) +
+         MP_MAX_ROBOTS * MP_ARG_DOUBLES * sizeof(double) + MP_MAX_ROBOTS * 32 * sizeof(uint32_t) + bp * sizeof(float) + UPD_CAND_MAX * sizeof(uint32_t);
 }
 
+// One workgroup per listed tile (tiles come off a ticket counter: a tile costs what the number of robots that see it costs).  Everything
+// the robots' updates of a tile read from memory is requested in TWO round trips for all of them -- (1) the tile's mask, state and cells
+// and every robot's 128-byte record, (2) the robots' scan windows, packed into one LDS pool (a far tile's window is a few dozen beams) --
+// and then robot after robot runs out of LDS: phase A, the fix-up, the exact part on the LDS cells.  (First form: record -> scan window
+// -> rotation table as three dependent round trips PER ROBOT: 9.5 us per robot and tile.)  The robots' arguments are staged once per
+// workgroup; the rotation table (cos, sin)(k * res) of the fix-up is robot 0's, shared by every robot with the same angular resolution
+// (another resolution reads its own table from memory).
 __global__ void __launch_bounds__(MP_BLOCK)
 k_mp_update(GridDev g, MultiPushArgs mp, uint32_t* __restrict__ tile_totals, unsigned long long* __restrict__ tmask,
-            const PushListAux* __restrict__ rec, const uint32_t* __restrict__ list, const unsigned int* __restrict__ cnt, int parity, int max_beams)
+            const PushListAux* __restrict__ rec, const uint32_t* __restrict__ list, unsigned int* __restrict__ cnt, int parity, int max_beams)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int Bp = (max_beams + 3) & ~3;
   double* s_t = reinterpret_cast<double*>(smem);                           // [TILE_STRIDE] the tile's values ...
   double* s_w = s_t + TILE_STRIDE;                                         // [TILE_STRIDE] ... and weights (device offsets)
-  double* s_ranges = s_w + TILE_STRIDE;                                    // [Bp] the current robot's scan (its window)
+  double* s_ranges = s_w + TILE_STRIDE;                                    // [Bp] pool: the robots' scan windows, one after the other
   double* s_d2 = s_ranges + Bp;                                            // [2][32] (ccx - trx)^2 per column, (ccy - try)^2 per row
-  double2* s_rot = reinterpret_cast<double2*>(s_d2 + 2 * TILE_DIM);        // [ROT_N] (cos, sin)(k * res)
-  float* s_lim = reinterpret_cast<float*>(s_rot + ROT_N);                  // [Bp] beam_limit of every staged beam
+  double2* s_rot = reinterpret_cast<double2*>(s_d2 + 2 * TILE_DIM);        // [ROT_N] (cos, sin)(k * res) of robot 0's resolution
+  double* s_args = reinterpret_cast<double*>(s_rot + ROT_N);               // [MP_MAX_ROBOTS][MP_ARG_DOUBLES] the robots' PushArgs
+  uint32_t* s_rec = reinterpret_cast<uint32_t*>(s_args + MP_MAX_ROBOTS * MP_ARG_DOUBLES);      // [MP_MAX_ROBOTS][32] the tile's records
+  float* s_lim = reinterpret_cast<float*>(s_rec + MP_MAX_ROBOTS * 32);     // [Bp] pool: beam_limit of every staged beam
   uint32_t* s_cand = reinterpret_cast<uint32_t*>(s_lim + Bp);              // [1024] candidates: cell | beam << 10
   __shared__ unsigned long long s_cu;                                      // candidates listed (low word) | undecided cells listed (high word)
   __shared__ unsigned int s_upd;                                           // cells updated by the current robot
   __shared__ unsigned long long s_neg;                                     // groups that received a negative value
+  __shared__ int s_off[MP_MAX_ROBOTS + 1];                                 // pool offset of every robot's window (-1: staged on its turn)
+  __shared__ unsigned int s_ticket;
   const int tid = threadIdx.x, lane = tid & 63;
   const unsigned int n_list = cnt[parity];
   const double max_trunc = g.max_trunc, inv_max_trunc = 1.0 / max_trunc;
@@ -196,20 +208,80 @@ k_mp_update(GridDev g, MultiPushArgs mp, uint32_t* __restrict__ tile_totals, uns
   const unsigned ix = (unsigned)tid & 31u, iy0 = (unsigned)tid >> 5;
   const int c0 = (int)(iy0 * 32u + ix);
   const float dxc = (float)ix - 16.0f;
+  const float mtf = (float)max_trunc;
+  // once per workgroup: every robot's arguments, robot 0's rotation table
+  for (int i = tid; i < mp.n * MP_ARG_DOUBLES; i += MP_BLOCK) {
+    const int r = i / MP_ARG_DOUBLES, k = i % MP_ARG_DOUBLES;
+    s_args[r * MP_ARG_DOUBLES + k] = reinterpret_cast<const double*>(mp.r[r].args)[k];
+  }
+  const int beams0 = mp.r[0].args->beams;
+  if (tid < ROT_N) s_rot[tid] = rmq_view(const_cast<char*>(mp.r[0].rmq), beams0).rot[tid];
+  __syncthreads();
+  const double res_inv0 = reinterpret_cast<const PushArgs*>(s_args)->ang_res_inv;
 
-  for (unsigned int li = blockIdx.x; li < n_list; li += gridDim.x) {
+  unsigned int li = blockIdx.x;
+  while (li < n_list) {
     const int t = (int)list[li];
     const int p = (mp.ty0 + t / mp.ntx) * g.PX + mp.tx0 + t % mp.ntx;
+    // ---- round trip 1: mask, tile state, cells (unconditionally: an uninitialised tile's storage exists), every robot's record
     const unsigned long long m = tmask[t];
-    bool flag = g.flags[p] != 0;
+    const uint8_t flag0 = g.flags[p];
     double iw = g.init_weight[p];
     tsd_cell_t* const T = g.tsd + (size_t)p * TILE_STRIDE;
     w_cell_t* const W = g.weight + (size_t)p * TILE_STRIDE;
+    {
+      const uint32_t* rw = reinterpret_cast<const uint32_t*>(rec + (size_t)t * MP_MAX_ROBOTS);
+      const uint32_t w0 = rw[tid], w1 = rw[tid + MP_BLOCK];              // 16 records x 32 words = 512 words
+      for (int i = tid; i < TILE_CELLS; i += MP_BLOCK) { s_t[i] = ld_tsd(T + i); s_w[i] = ld_w(W + i); }
+      s_rec[tid] = w0; s_rec[tid + MP_BLOCK] = w1;
+    }
+    bool flag = flag0 != 0;
     const unsigned x0 = (unsigned)(p % g.PX) * TILE_DIM, y0 = (unsigned)(p / g.PX) * TILE_DIM;
-    if (flag) for (int i = tid; i < TILE_CELLS; i += MP_BLOCK) { s_t[i] = ld_tsd(T + i); s_w[i] = ld_w(W + i); }
     if (tid == 0) { s_cu = 0ull; s_upd = 0u; s_neg = 0ull; }
     __syncthreads();                       // (every thread has read the mask: it is given back for the next batch)
-    if (tid == 0) tmask[t] = 0ull;
+    if (tid == 0) {
+      tmask[t] = 0ull;
+      // the pool: the updating robots' windows one after the other while they fit
+      int off = 0;
+      for (int r = 0; r < mp.n; r++) {
+        s_off[r] = -1;
+        if (!(m & (1ull << r))) continue;
+        const uint32_t win = s_rec[r * 32 + 1];
+        const int beams = reinterpret_cast<const PushArgs*>(s_args + r * MP_ARG_DOUBLES)->beams;
+        int wlo = (int)(win & 0xFFFFu) - 1, whi = (int)(win >> 16) + 1;
+        if (wlo < 0) wlo = 0;
+        if (whi > beams - 1) whi = beams - 1;
+        const int len = whi - wlo + 1;
+        if (off + len <= Bp) { s_off[r] = off; off += len; }
+      }
+      s_off[MP_MAX_ROBOTS] = off;
+    }
+    __syncthreads();
+    // ---- round trip 2: the pooled scan windows, every read issued before the first LDS write
+    {
+      const int total = s_off[MP_MAX_ROBOTS];
+      for (int e0 = 0; e0 < total; e0 += 4 * MP_BLOCK) {
+        double rr[4]; unsigned mm[4]; int at[4]; float lo2[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int e = e0 + tid + i * MP_BLOCK;
+          at[i] = -1; rr[i] = 0.0; mm[i] = 0u; lo2[i] = 0.f;
+          if (e < total) {
+            int r = 0;
+            for (int q = 0; q < mp.n; q++) if (s_off[q] >= 0 && s_off[q] <= e) r = q;       // (offsets ascend with the robot)
+            const uint32_t win = s_rec[r * 32 + 1];
+            int wlo = (int)(win & 0xFFFFu) - 1;
+            if (wlo < 0) wlo = 0;
+            const int j = wlo + (e - s_off[r]);
+            rr[i] = mp.r[r].ranges[j]; mm[i] = (unsigned)mp.r[r].mask[j]; at[i] = e;
+            const double lr = reinterpret_cast<const PushArgs*>(s_args + r * MP_ARG_DOUBLES)->low_refl;
+            lo2[i] = (float)(lr * lr) * 1.00001f;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) if (at[i] >= 0) { s_ranges[at[i]] = rr[i]; s_lim[at[i]] = beam_limit(rr[i], mm[i], mtf, lo2[i]); }
+      }
+    }
     bool changed = false, iw_changed = false;
     const bool was_init = flag;
     unsigned st_cells = 0u, st_upd = 0u, st_new = 0u, st_new_e = 0u, st_emp_i = 0u, st_emp_u = 0u;     // (thread 0's counts)
@@ -217,6 +289,7 @@ k_mp_update(GridDev g, MultiPushArgs mp, uint32_t* __restrict__ tile_totals, uns
       if (m & (1ull << (MP_EMPTY_SHIFT + r))) {
         // TsdGridPartition::increaseEmptiness (TsdGridPartition.cpp:136-164)
         if (flag) {
+          __syncthreads();
           for (int i = tid; i < TILE_CELLS; i += MP_BLOCK) {
             double tv = s_t[i], wv = s_w[i];
             if (isnan(tv)) { wv += 1.0; tv = 1.0; }
@@ -231,28 +304,35 @@ k_mp_update(GridDev g, MultiPushArgs mp, uint32_t* __restrict__ tile_totals, uns
       if (!(m & (1ull << r))) continue;
       // ---- robot r updates this tile (TsdGrid.cpp:237-274)
       const MultiPushRobot& rb = mp.r[r];
-      const PushArgs a = *rb.args;
-      const PushListAux x = rec[(size_t)t * MP_MAX_ROBOTS + r];
-      const RmqView rv = rmq_view(const_cast<char*>(rb.rmq), a.beams);
+      const PushArgs& a = *reinterpret_cast<const PushArgs*>(s_args + r * MP_ARG_DOUBLES);
+      const PushListAux& x = *reinterpret_cast<const PushListAux*>(s_rec + r * 32);
       if (!flag) {
         // lazy TsdGridPartition::init (TsdGridPartition.cpp:88-134): every cell, halo included, starts from the init value
         const double t_init = (iw > 0.0) ? 1.0 : __builtin_nan("");
         for (int i = tid; i < TILE_CELLS; i += MP_BLOCK) { s_t[i] = t_init; s_w[i] = iw; }
         flag = true; st_new++; if (iw > 0.0) st_new_e++;
       }
-      // the robot's scan: the beams the tile's cells can project to
       int wlo = (int)(x.win & 0xFFFFu) - 1, whi = (int)(x.win >> 16) + 1;
       if (wlo < 0) wlo = 0;
       if (whi > a.beams - 1) whi = a.beams - 1;
-      const float mtf = (float)max_trunc, low2f = (float)(a.low_refl * a.low_refl) * 1.00001f;
-      for (int j0 = wlo; j0 <= whi; j0 += 4 * MP_BLOCK) {
-        double rr[4]; unsigned mm[4];
+      const float low2f = (float)(a.low_refl * a.low_refl) * 1.00001f;
+      int pool = s_off[r];                 // where this robot's window sits in the pool
+      if (pool < 0) {
+        // (did not fit beside the others -- a robot that stands on the tile sees it with its whole scan: staged on its turn, at the
+        // pool's start, which the robots before it are through with)
+        __syncthreads();
+        for (int j0 = wlo; j0 <= whi; j0 += 4 * MP_BLOCK) {
+          double rr[4]; unsigned mm[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) { const int j = j0 + tid + i * MP_BLOCK, jc = j <= whi ? j : wlo; rr[i] = rb.ranges[jc]; mm[i] = (unsigned)rb.mask[jc]; }
+          for (int i = 0; i < 4; i++) { const int j = j0 + tid + i * MP_BLOCK, jc = j <= whi ? j : wlo; rr[i] = rb.ranges[jc]; mm[i] = (unsigned)rb.mask[jc]; }
 #pragma unroll
-        for (int i = 0; i < 4; i++) { const int j = j0 + tid + i * MP_BLOCK; if (j <= whi) { s_ranges[j] = rr[i]; s_lim[j] = beam_limit(rr[i], mm[i], mtf, low2f); } }
+          for (int i = 0; i < 4; i++) { const int j = j0 + tid + i * MP_BLOCK; if (j <= whi) { s_ranges[j - wlo] = rr[i]; s_lim[j - wlo] = beam_limit(rr[i], mm[i], mtf, low2f); } }
+        }
+        pool = 0;
+        // (pooled windows of LATER robots that sat there are gone: they are staged on their turn too)
+        if (tid == 0) for (int q = r + 1; q < mp.n; q++) s_off[q] = -1;
       }
-      if (tid < ROT_N) s_rot[tid] = rv.rot[tid];
+      const int pb = pool - wlo;           // pool index of beam j: pb + j
       if (tid < 2 * TILE_DIM) {
         const bool col = tid < TILE_DIM;
         const unsigned i = (unsigned)tid & 31u;
@@ -282,12 +362,12 @@ k_mp_update(GridDev g, MultiPushArgs mp, uint32_t* __restrict__ tile_totals, uns
         else          cc = classify_cell<false, false>(ta, dxc, dyc, pA, pC, qx, vc, d2f[k]);
         idx[k] = cc.j; uns[k] = cc.uns; in[k] = !cc.uns && !cc.out;
       }
-      lds_barrier();                       // the scan window, the tables and (a fresh tile) the init values are in LDS
+      lds_barrier();                       // the windows, the distance tables and (a fresh tile) the init values are in LDS
       float lim[UPD_CPT];
 #pragma unroll
       for (int k = 0; k < UPD_CPT; k++) {
         const int il = min(max(idx[k], wlo), whi);
-        lim[k] = s_lim[il];
+        lim[k] = s_lim[pb + il];
         if (in[k] && il != idx[k]) { in[k] = false; uns[k] = true; }
       }
       bool cand[UPD_CPT];
@@ -315,6 +395,7 @@ k_mp_update(GridDev g, MultiPushArgs mp, uint32_t* __restrict__ tile_totals, uns
       const unsigned long long cu = s_cu;
       const unsigned n_cand = (unsigned)cu, n_uns = (unsigned)(cu >> 32);
       const unsigned n_tot = n_cand + n_uns;
+      const bool own_rot = a.ang_res_inv != res_inv0;                       // (another scanner than robot 0's: its own table, from memory)
       // ---- fix-up of the undecided cells, one lane each, in place (entry n_cand + u of the exact part lives at list[1023 - u])
       for (unsigned u = ((unsigned)tid - n_cand) & (unsigned)(MP_BLOCK - 1); u < n_uns; u += MP_BLOCK) {
         const uint32_t e = s_cand[(unsigned)(UPD_CAND_MAX - 1) - u];
@@ -332,8 +413,10 @@ k_mp_update(GridDev g, MultiPushArgs mp, uint32_t* __restrict__ tile_totals, uns
           const int kr = jbq - (int)x.jb0;
           const double2 bdc = x.bd;
           double2 bd;
-          if (__builtin_expect(kr >= 0 && kr < ROT_N, 1)) { const double2 rc = s_rot[kr]; bd.x = bdc.x * rc.x - bdc.y * rc.y; bd.y = bdc.y * rc.x + bdc.x * rc.y; }
-          else bd = rv.bdir[jbq];
+          if (__builtin_expect(kr >= 0 && kr < ROT_N, 1)) {
+            const double2 rc = own_rot ? rmq_view(const_cast<char*>(rb.rmq), a.beams).rot[kr] : s_rot[kr];
+            bd.x = bdc.x * rc.x - bdc.y * rc.y; bd.y = bdc.y * rc.x + bdc.x * rc.y;
+          } else bd = rmq_view(const_cast<char*>(rb.rmq), a.beams).bdir[jbq];
           const double cr = bd.x * ly - bd.y * lx;                  // |l| sin(angle - beta_jb)
           if (cr * cr > 1e-22 * l2) index = cr > 0.0 ? (jbq < a.beams ? jbq : -1) : jbq - 1;
           else hard = true;
@@ -344,7 +427,7 @@ k_mp_update(GridDev g, MultiPushArgs mp, uint32_t* __restrict__ tile_totals, uns
         bool cd = false;
         if (index >= 0) {
           const int il = min(max(index, wlo), whi);
-          float lm = s_lim[il];
+          float lm = s_lim[pb + il];
           if (__builtin_expect(il != index, 0)) lm = beam_limit(rb.ranges[index], (unsigned)rb.mask[index], mtf, low2f);
           cd = !((float)l2 > lm * 1.00001f);
         }
@@ -360,7 +443,7 @@ k_mp_update(GridDev g, MultiPushArgs mp, uint32_t* __restrict__ tile_totals, uns
         const int c = (int)(ce & 1023u);
         const int index = on ? (int)(ce >> 10) : wlo;
         const int il = min(max(index, wlo), whi);
-        double rg = s_ranges[il];
+        double rg = s_ranges[pb + il];
         if (__builtin_expect(il != index, 0)) rg = rb.ranges[index];
         const double dist = sqrt_normal(s_d2[c & 31] + s_d2[TILE_DIM + (c >> 5)]);
         double sd = 0.0; bool ok = false;
@@ -374,12 +457,13 @@ k_mp_update(GridDev g, MultiPushArgs mp, uint32_t* __restrict__ tile_totals, uns
       }
       if (wrote_neg) atomicOr(&s_neg, wrote_neg);
       if (lane == 0 && n_upd) atomicAdd(&s_upd, n_upd);
-      __syncthreads();                     // robot r is through with the tile, its lists and its scan window
+      __syncthreads();                     // robot r is through with the tile and its lists
       if (tid == 0) { st_cells += s_upd; st_upd++; s_upd = 0u; s_cu = 0ull; }
       changed = true;
-      __syncthreads();
     }
-    // ---- the tile goes back to memory once
+    // ---- the tile goes back to memory once; the next tile's ticket is drawn meanwhile
+    __syncthreads();
+    if (tid == 0) s_ticket = atomicAdd(&cnt[2 + parity], 1u);
     if (changed) for (int i = tid; i < TILE_CELLS; i += MP_BLOCK) st_cell(T, W, i, s_t[i], s_w[i]);
     if (tid == 0) {
       if (changed && !was_init) g.flags[p] = 1;
@@ -395,6 +479,7 @@ k_mp_update(GridDev g, MultiPushArgs mp, uint32_t* __restrict__ tile_totals, uns
       if (st_emp_u) atomicAdd(&tot[6], st_emp_u);
     }
     __syncthreads();                       // (the LDS tile and the counters are reused by the workgroup's next tile)
+    li = gridDim.x + s_ticket;
   }
 }
 
@@ -499,16 +584,16 @@ int launch_push_multi(tsd_ctx* ctx, hipStream_t stream, int n, const PushArgs* c
     const size_t cap = n_window + n_window / 4 + 256;
     TSD_HIP_CHECK(ctx, hipMalloc(&ctx->d_mp_mask, cap * sizeof(unsigned long long)));
     TSD_HIP_CHECK(ctx, hipMalloc(&ctx->d_mp_rec, cap * MP_MAX_ROBOTS * sizeof(PushListAux)));
-    TSD_HIP_CHECK(ctx, hipMalloc(&ctx->d_mp_list, (cap + 2) * sizeof(uint32_t)));
+    TSD_HIP_CHECK(ctx, hipMalloc(&ctx->d_mp_list, (cap + 4) * sizeof(uint32_t)));
     TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_mp_mask, 0, cap * sizeof(unsigned long long), stream));
-    TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_mp_list, 0, (cap + 2) * sizeof(uint32_t), stream));
+    TSD_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_mp_list, 0, (cap + 4) * sizeof(uint32_t), stream));
     ctx->mp_tiles = cap;
     ctx->mp_parity = 0;
   }
   unsigned long long* tmask = reinterpret_cast<unsigned long long*>(ctx->d_mp_mask);
   PushListAux* rec = reinterpret_cast<PushListAux*>(ctx->d_mp_rec);
-  unsigned int* cnt = reinterpret_cast<unsigned int*>(ctx->d_mp_list);            // [2] counters, then the list
-  uint32_t* list = reinterpret_cast<uint32_t*>(ctx->d_mp_list) + 2;
+  unsigned int* cnt = reinterpret_cast<unsigned int*>(ctx->d_mp_list);            // [2] list lengths by parity, [2] ticket counters, then the list
+  uint32_t* list = reinterpret_cast<uint32_t*>(ctx->d_mp_list) + 4;
   const int parity = (int)(ctx->mp_parity & 1u);
   ctx->mp_parity++;
   {
