@@ -52,7 +52,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip
 SPREAD_STEPS = 200           # scans of the pass that times EVERY registration (ms_icp_iterate_spread: p50 / p99 / max)
 MERGE_EVERY = 50             # occupancy merge period in scans (cfg 4/5)
 CALIB_DOUBLES = 8 << 20      # k_calib_rmw: 2 arrays x 8 Mi doubles -> 128 MiB read + 128 MiB written per launch
-PROFILE_TAG = "r4"           # profiles/<tag>_<workload>_pmc.json: the committed rocprofv3 PMC summary of this round
+PROFILE_TAG = "r5"              # profiles/<tag>_<workload>_*: the committed rocprofv3 summaries the line reads its traffic from
 STREAM_DOUBLES = 48 << 20    # tsd_measure_stream: 2 arrays x 48 Mi doubles = 768 MiB footprint (3x the 256 MiB Infinity Cache)
 STAGES = ("raycast", "icp", "push_classify", "push_update", "push_halo")
 
