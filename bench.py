@@ -695,7 +695,7 @@ def run_slam(args, gc, geo, scene, K, W, every, every_upd, every_icp, device, ra
         errs = []
         for r in range(R):
             final = node.report(robot=r)
-            errs.append(math.hypot(final["pose"][0, 2] - poses[r][-1, 0], final["pose"][1, 2] - poses[r][-1, 1]))
+            errs.append(math.hypot(final["pose"][0, 2] - poses[r][W + K, 0], final["pose"][1, 2] - poses[r][W + K, 1]))    # (the last scan processed)
 
         ranks = None
         local_elapsed = elapsed
