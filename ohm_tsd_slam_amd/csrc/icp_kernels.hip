@@ -555,9 +555,9 @@ __device__ __forceinline__ void block_totals8(const IcpLds& L, const double (&v)
 // PAIRS (parity / debug instantiation, tsd_icp_pairs): the scene is NOT moved between the steps and every step's surviving pair list
 // is written out -- the repeated PairAssignment::determinePairs calls on a static scene that the compiled reference's chain
 // (PairAssignment.cpp:38-84 -> DistanceFilter -> ReciprocalFilter) is driven with in tests/golden/ref_chain_pairs.npz.
-template <int R, int MAXT, bool PTL, bool PAIRS = false>
+template <int R, int MAXT, bool PTL, bool PAIRS = false, int FCAP = 0, int FT = 0>
 __device__ __forceinline__ void
-icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __restrict__ g_model, const double* __restrict__ g_scene,
+icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const double* __restrict__ g_model, const double* __restrict__ g_scene,
       const int* __restrict__ g_morig, const int* __restrict__ g_start,
       const double* __restrict__ g_coords, const uint8_t* __restrict__ g_mask_m,
       const double* __restrict__ g_rays_local, const double* __restrict__ g_ranges,
@@ -569,6 +569,8 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   IcpLds L;
+  // (FCAP / FT: the capacity and thread count as compile-time constants -- the LDS layout's offsets then cost no scalar registers)
+  const int cap = FCAP ? FCAP : cap_rt;
   const int lcap = icp_list_cap(cap);
   {
     char* p = smem;
@@ -582,10 +584,10 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     L.res_k = reinterpret_cast<int*>(p); p += sizeof(int) * (size_t)lcap;
     L.res_k2 = reinterpret_cast<int*>(p); p += sizeof(int) * (size_t)lcap;
     L.list2 = reinterpret_cast<int*>(p);
-    p = reinterpret_cast<char*>(L.list_xy) + icp_region_bytes(cap, (int)blockDim.x);
+    p = reinterpret_cast<char*>(L.list_xy) + icp_region_bytes(cap, (FT ? FT : (int)blockDim.x));
     // staging view of the same 40*lcap bytes: cap double2 then cap int (40*lcap >= 20*cap)
     L.start = reinterpret_cast<int*>(reinterpret_cast<char*>(L.stage_s) + sizeof(double2) * (size_t)cap);
-    L.slotD = reinterpret_cast<unsigned long long*>(p); p += sizeof(unsigned long long) * (size_t)icp_slot_halves(cap, (int)blockDim.x, PTL) * (size_t)cap;
+    L.slotD = reinterpret_cast<unsigned long long*>(p); p += sizeof(unsigned long long) * (size_t)icp_slot_halves(cap, (FT ? FT : (int)blockDim.x), PTL) * (size_t)cap;
     L.red = reinterpret_cast<double*>(p); p += sizeof(double) * 2 * ICP_MAXW * 16;
     L.cst = reinterpret_cast<double*>(p); p += sizeof(double) * 16;
     L.tail = reinterpret_cast<IcpTail*>(p); p += (sizeof(IcpTail) + 15) & ~(size_t)15;
@@ -606,14 +608,14 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
     for (int i = 0; i < 6; i++) a.Tinit[i] = a.Tinit_dev[i];
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int T = blockDim.x, W = T >> 6;
+  const int T = FT ? FT : (int)blockDim.x, W = T >> 6;
   int nM = 0, nS = 0;
 #ifdef TSD_ICP_TIMELINE
   // diagnostic build (tools/icp_timeline.sh): lane 0 of EVERY wave stamps the shader clock at 14 points of four steady-state steps
   // (TL_FIRST ..), so that each wave's own chain and the waits at the two barriers can be read off: profiles/r4_icp_critical_path.txt.
   // A stamp is s_memtime + wait + one LDS write (~60 cycles, the same for every interval).
   constexpr int TL_FIRST = TSD_ICP_TL_FIRST, TL_STEPS = TSD_ICP_TL_STEPS, TL_N = 16;
-  long long* tlbuf = reinterpret_cast<long long*>(smem + icp_lds_bytes_for(cap, (int)blockDim.x, PTL));       // [TL_STEPS][W][TL_N], behind the kernel's own LDS
+  long long* tlbuf = reinterpret_cast<long long*>(smem + icp_lds_bytes_for(cap, (FT ? FT : (int)blockDim.x), PTL));       // [TL_STEPS][W][TL_N], behind the kernel's own LDS
 #define TL(i) do { if (lane == 0 && iter >= (unsigned)TL_FIRST && iter < (unsigned)(TL_FIRST + TL_STEPS)) \
                      tlbuf[((iter - TL_FIRST) * W + wave) * TL_N + (i)] = clock64(); } while (0)
 #else
@@ -1281,7 +1283,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap, const double
   }
 }
 
-template <int R, int MAXT, bool PTL>
+template <int R, int MAXT, bool PTL, int FCAP = 0, int FT = 0>
 __global__ void __launch_bounds__(MAXT)
 k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __restrict__ g_model, const double* __restrict__ g_scene,
       const int* __restrict__ g_morig, const int* __restrict__ g_start,
@@ -1291,7 +1293,7 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
       const double* __restrict__ g_mnormals, const double* __restrict__ g_normals, IcpSeedArgs seed)
 {
   // workgroup 0 registers; workgroups 1 .. seed.helpers do step 0's searches for it
-  icp_workgroup<R, MAXT, PTL>(a, P_dev, cap, g_model, g_scene, g_morig, g_start, g_coords, g_mask_m, g_rays_local, g_ranges, g_mask, out, trace,
+  icp_workgroup<R, MAXT, PTL, false, FCAP, FT>(a, P_dev, cap, g_model, g_scene, g_morig, g_start, g_coords, g_mask_m, g_rays_local, g_ranges, g_mask, out, trace,
                               post, g_mnormals, g_normals, seed, (int)blockIdx.x);
 }
 
@@ -1420,6 +1422,26 @@ static int launch_icp_shape_est(tsd_ctx* ctx, const IcpArgs& a, int n, int cap, 
   const bool own_seed = tg && tg->icp_seed;
   const IcpSeedArgs sa = icp_seed_args(own_seed ? tg->icp_seed : ctx->d_icp_seed, own_seed ? tg->icp_seed_points : TSD_MAX_ICP_POINTS,
                                        icp_helpers_for(ctx, n, T));
+  // The default scanner's shape (1081 beams: capacity 1088, 512 threads, closed form) has an instantiation of its own in which the
+  // capacity and the thread count are compile-time constants: the twenty offsets of the LDS layout then cost no scalar registers
+  // (spilled scalars of the loop 166 -> 56; -0.7 us per registration, profiles/r5_icp_helpers_ab.txt)
+  if (R == 3 && MAXT == 512 && !PTL && cap == 1088 && T == 512) {
+    {
+      std::lock_guard<std::mutex> lk_misc(ctx->misc_mutex);
+      size_t& configured = ctx->lds_configured[reinterpret_cast<const void*>(k_icp<3, 512, false, 1088, 512>)];
+      if (lds > configured) {
+        TSD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_icp<3, 512, false, 1088, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = lds;
+      }
+    }
+    hipExtLaunchKernelGGL((k_icp<3, 512, false, 1088, 512>), dim3(1 + sa.helpers), dim3(T), lds, launch_stream(ctx), t.a, t.b, 0, a, P_dev, cap, ctx->d_model, ctx->d_scene,
+                     ctx->d_morig, ctx->d_start, tg && tg->coords ? tg->coords : ctx->d_coords, tg && tg->mask_m ? tg->mask_m : ctx->d_mask_m,
+                     d_rays_local ? d_rays_local : ctx->d_rays_local, d_ranges ? d_ranges : ctx->d_ranges,
+                     d_mask ? d_mask : ctx->d_mask, tg && tg->icp_res ? tg->icp_res : ctx->d_icp_res,
+                     trace_buf, post, ctx->d_mnormals, tg && tg->normals ? tg->normals : ctx->d_normals, sa);
+    TSD_HIP_CHECK(ctx, hipGetLastError());
+    return TSD_OK;
+  }
   hipExtLaunchKernelGGL((k_icp<R, MAXT, PTL>), dim3(1 + sa.helpers), dim3(T), lds, launch_stream(ctx), t.a, t.b, 0, a, P_dev, cap, ctx->d_model, ctx->d_scene,
                      ctx->d_morig, ctx->d_start, tg && tg->coords ? tg->coords : ctx->d_coords, tg && tg->mask_m ? tg->mask_m : ctx->d_mask_m,
                      d_rays_local ? d_rays_local : ctx->d_rays_local, d_ranges ? d_ranges : ctx->d_ranges,
