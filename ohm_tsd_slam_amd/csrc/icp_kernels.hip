@@ -1311,7 +1311,7 @@ k_icp_pairs(IcpArgs a, int cap, const double* __restrict__ g_model, const double
 
 // the registrations of a batch of robots in ONE launch (tsd_batch_begin): workgroup x = entry x, fused mode only (model and
 // scene come from the ray cast's / the scan's per-beam arrays); each registration still runs on one compute unit
-template <int R, int MAXT, bool PTL>
+template <int R, int MAXT, bool PTL, int FCAP = 0, int FT = 0>
 __global__ void __launch_bounds__(MAXT)
 k_icp_batch(const IcpBatchEntry* __restrict__ entries, int cap, int n_entries)
 {
@@ -1343,7 +1343,7 @@ k_icp_batch(const IcpBatchEntry* __restrict__ entries, int cap, int n_entries)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   if (role > e.seed.helpers) return;
-  icp_workgroup<R, MAXT, PTL>(e.a, e.P_dev, cap, nullptr, nullptr, nullptr, nullptr, e.coords, e.mask_m, e.rays_local, e.ranges, e.mask, e.out,
+  icp_workgroup<R, MAXT, PTL, false, FCAP, FT>(e.a, e.P_dev, cap, nullptr, nullptr, nullptr, nullptr, e.coords, e.mask_m, e.rays_local, e.ranges, e.mask, e.out,
                               e.trace, e.post, nullptr, e.normals, e.seed, role);
 }
 
@@ -1530,6 +1530,20 @@ static int launch_icp_batch_shape(tsd_ctx* ctx, hipStream_t stream, const IcpBat
     }
   }
   ScopedKernelTimer t(ctx, "icp");
+  if (R == 3 && MAXT == 512 && !PTL && cap == 1088 && T == 512) {        // (the default scanner's shape: compile-time LDS layout, see launch_icp_shape_est)
+    {
+      std::lock_guard<std::mutex> lk_misc(ctx->misc_mutex);
+      size_t& configured = ctx->lds_configured[reinterpret_cast<const void*>(k_icp_batch<3, 512, false, 1088, 512>)];
+      if (lds > configured) {
+        TSD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_icp_batch<3, 512, false, 1088, 512>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = lds;
+      }
+    }
+    hipExtLaunchKernelGGL((k_icp_batch<3, 512, false, 1088, 512>), dim3(n * (1 + helpers)), dim3(T), lds, stream, t.a, t.b, 0, d_entries, cap, n);
+    TSD_HIP_CHECK(ctx, hipGetLastError());
+    return TSD_OK;
+  }
   hipExtLaunchKernelGGL((k_icp_batch<R, MAXT, PTL>), dim3(n * (1 + helpers)), dim3(T), lds, stream, t.a, t.b, 0, d_entries, cap, n);
   TSD_HIP_CHECK(ctx, hipGetLastError());
   return TSD_OK;
