@@ -773,6 +773,7 @@ int tsd_batch_begin(tsd_batch* b, int n, tsd_sensor* const* sensors, const doubl
     e.post.st = s->d_state; e.post.rays = s->d_rays; e.post.out = s->d_result; e.post.seq = seq; e.post.beams = s->beams;
     e.post.gmin_x = ctx->grid.min_x; e.post.gmax_x = ctx->grid.max_x; e.post.gmin_y = ctx->grid.min_y; e.post.gmax_y = ctx->grid.max_y;
     e.post.gates = GateArgs{gates[i].reg_trs_max, gates[i].reg_sin_rot_max, gates[i].trs_min, gates[i].rot_min};
+    e.post.publish_done = 1;               // (tsd_batch_push gates this robot's push on it)
   }
   // (step 0's searches on helper workgroups: measured worth it for batches of up to four registrations -- +6 % scans/s at two per batch,
   // even at four, -2 to -10 % at eight, where forty more polling workgroups sit beside the ray casts)

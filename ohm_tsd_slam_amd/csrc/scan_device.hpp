@@ -227,18 +227,35 @@ __device__ inline void scan_post_body(const ScanPostArgs& sp, const ScanPostPre&
   }
   // every wave has turned its rays and both lone lanes have written the sensor's state before the sequence numbers go out: a ray
   // cast of this sensor on ANOTHER stream (the batched path) is ordered behind this scan only through them
+  __shared__ unsigned long long s_record[sizeof(ScanResultDev) / 8];
   __syncthreads();
-  if (threadIdx.x == 0) {
-    if (sp.push_copy) *sp.push_copy = st->push;      // (asynchronous mapping: this scan's push reads its own copy)
-    ScanResultDev* out = sp.out;
-    out->icp = icp;
-    for (int i = 0; i < 9; i++) out->pose[i] = s_pose[i];
-    out->reg_error = reg_error ? 1 : 0; out->pushed = s_pushed; out->no_model = no_model ? 1 : 0; out->reserved = 0;
-    // `out` is coherent host memory: publish the record, then the sequence number the host polls
-    __threadfence_system();
-    __hip_atomic_store(&out->seq, sp.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    // the same for a gate kernel on another stream (a batched robot's push starts when ITS registration is done)
-    __hip_atomic_store(&st->done_seq, sp.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x < 64) {
+    // The result record: composed in LDS by lane 0, then stored word by word as relaxed system-scope atomics -- write-through stores
+    // to the coherent pinned buffer, ONE instruction of 24 lanes -- drained, then the sequence number the host polls.  (Round 4 wrote
+    // the record with plain stores behind __threadfence_system() and released the two sequence numbers: three write-backs of the L2
+    // and an invalidate at the end of every registration, ~3 us, for 200 bytes that never were in a cache.)
+    static_assert(sizeof(ScanResultDev) % 8 == 0 && sizeof(ScanResultDev) / 8 <= 64 && offsetof(ScanResultDev, seq) == sizeof(ScanResultDev) - 8, "ScanResultDev");
+    constexpr int NW = (int)(sizeof(ScanResultDev) / 8) - 1;           // words ahead of `seq`
+    if (threadIdx.x == 0) {
+      if (sp.push_copy) *sp.push_copy = st->push;      // (asynchronous mapping: this scan's push reads its own copy; a later kernel)
+      ScanResultDev r;
+      r.icp = icp;
+      for (int i = 0; i < 9; i++) r.pose[i] = s_pose[i];
+      r.reg_error = reg_error ? 1 : 0; r.pushed = s_pushed; r.no_model = no_model ? 1 : 0; r.reserved = 0;
+      r.seq = 0ull;
+      const unsigned long long* w = reinterpret_cast<const unsigned long long*>(&r);
+      for (int i = 0; i < NW; i++) s_record[i] = w[i];
+    }
+    // (a wave's LDS accesses execute in order)
+    unsigned long long* out = reinterpret_cast<unsigned long long*>(sp.out);
+    if ((int)threadIdx.x < NW) __hip_atomic_store(out + threadIdx.x, s_record[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(out + NW, sp.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      // the same number for a gate kernel on another stream (a batched robot's push starts when ITS registration is done): that
+      // reader takes the sensor's state, written with plain stores above -- a release, where there is such a reader
+      if (sp.publish_done) __hip_atomic_store(&st->done_seq, sp.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 

@@ -87,7 +87,7 @@ struct ScanPostArgs {
   GateArgs gates;
   double gmin_x, gmax_x, gmin_y, gmax_y;   // TsdGrid::getMin/Max* (RayCastPolar2D's isInsideGrid)
   int beams;
-  int pad;
+  int publish_done;          // also publish st->done_seq (agent-scope release): a gate kernel on another stream waits for it (batched scans)
   PushArgs* push_copy;       // asynchronous mapping: where this scan's push arguments are left for a push that runs beside the NEXT
                              // registration (whose epilogue rewrites st->push); nullptr = strict order, the push reads st->push
 };
