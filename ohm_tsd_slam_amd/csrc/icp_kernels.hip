@@ -233,12 +233,16 @@ __device__ __forceinline__ int wrap_slot(int k, int nM)
   k -= (k >= nM) ? nM : 0;
   return k;
 }
+// v_min_f64 / v_max_f64 as they are: fmin() / fmax() put a canonicalising v_max in front of every operand the compiler cannot prove
+// quiet, i.e. of every packed distance (13 extra instructions per window round).  A NaN operand loses against a number either way.
+__device__ __forceinline__ double min_raw(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double max_raw(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ double pack_code(double d, int code)
 {
   return __hiloint2double(__double2hiint(d), (__double2loint(d) & ~0xFF) | code);
 }
 __device__ __forceinline__ NnResult window_search(const IcpLds& L, int nM, double x, double y, int c,
-                                                  double thr, double sgn, int* rounds_out = nullptr)
+                                                  double thr, double sgn, int* rounds_out = nullptr, long long* tl = nullptr)
 {
   NnResult r;
   r.best = __builtin_inf(); r.lbsq = 0.0; r.bk = -1; r.bk2 = -1; r.resolved = false;
@@ -256,14 +260,18 @@ __device__ __forceinline__ NnResult window_search(const IcpLds& L, int nM, doubl
 #pragma unroll
     for (int j = 0; j < WIN; j++) m[j] = base[j];
     const double2 ulo = L.uxy[wrap_slot(c + b, nM)], uhi = L.uxy[wrap_slot(c + b + WIN - 1, nM)];
+#ifdef TSD_ICP_TIMELINE
+    if (tl && round == 0) { double t0 = m[0].x + m[WIN - 1].x + ulo.x + uhi.x; asm volatile("" : "+v"(t0)); tl[0] = clock64(); }
+#endif
     const int code0 = b + 128;
 #pragma unroll
     for (int j = 0; j < WIN; j++) {
       const double dx = x - m[j].x, dy = y - m[j].y;
-      const double d = pack_code(dx * dx + dy * dy, code0 + j);
-      const double h1 = fmax(b1, d); b1 = fmin(b1, d);
-      const double h2 = fmax(b2, h1); b2 = fmin(b2, h1);
-      b3 = fmin(b3, h2);
+      // (a filter value: fused, i.e. within 3 ulp of what the exact re-evaluation below computes -- the bucket test there allows for it)
+      const double d = pack_code(__builtin_fma(dy, dy, dx * dx), code0 + j);
+      const double h1 = max_raw(b1, d); b1 = min_raw(b1, d);
+      const double h2 = max_raw(b2, h1); b2 = min_raw(b2, h1);
+      b3 = min_raw(b3, h2);
     }
     // the low end must lie clockwise of s (in slot order) and the high end counter-clockwise
     double cr;
@@ -280,6 +288,7 @@ __device__ __forceinline__ NnResult window_search(const IcpLds& L, int nM, doubl
   }
   if (!(b1 < __builtin_inf())) return r;        // no finite distance at all (non-finite point): tier 2 sorts it out
 #ifdef TSD_ICP_TIMELINE
+  if (tl) { asm volatile("" : "+v"(b1), "+v"(b2), "+v"(b3), "+v"(blo), "+v"(bhi)); tl[1] = clock64(); }
   if (rounds_out) *rounds_out = lo == -HW && hi == HW ? 1 : 1 + (hi - lo + 1 - WIN) / WIN;
 #endif
   // unpack the two nearest and evaluate them exactly
@@ -290,9 +299,11 @@ __device__ __forceinline__ NnResult window_search(const IcpLds& L, int nM, doubl
   { const double dx = x - m1.x, dy = y - m1.y; d1 = dx * dx + dy * dy; }
   { const double dx = x - m2.x, dy = y - m2.y; d2 = dx * dx + dy * dy; }
   if (d2 < d1 || (d2 == d1 && L.morig[k2] < L.morig[k1])) { const int t = k1; k1 = k2; k2 = t; d1 = d2; }
-  // third candidate in the same bucket as the nearest: order unknown here
+  // third candidate in the same 256-ulp bucket as the nearest or in the next one: order unknown here (the filter values are fused
+  // multiply-adds, up to 3 ulp from the unfused distances that decide: two buckets apart, the order of the unfused values is the same)
   const double b3c = pack_code(b3, 0);
-  const bool crowded = !(b3c > pack_code(b1, 0));
+  const double b1n = __longlong_as_double(__double_as_longlong(pack_code(b1, 0)) + 0x100ll);      // start of the bucket after the nearest's
+  const bool crowded = !(b3c > b1n);
   r.best = d1; r.bk = k1; r.bk2 = k2;
   r.lbsq = fmin(b3c, fmin(blo, bhi));
   r.resolved = proven && !crowded && !isnan(d1);
@@ -311,11 +322,11 @@ __device__ __forceinline__ bool sweep_all(const IcpLds& L, int nM, double x, dou
   for (int k = lane; k < nM; k += 64) {
     const double2 m = L.mxy[k];
     const double dx = x - m.x, dy = y - m.y;
-    const double dd = dx * dx + dy * dy;
+    const double dd = __builtin_fma(dy, dy, dx * dx);          // (a filter value, like window_search's)
     const double d = __hiloint2double(__double2hiint(dd), (__double2loint(dd) & ~0x7FF) | k);
-    const double h1 = fmax(b1, d); b1 = fmin(b1, d);
-    const double h2 = fmax(b2, h1); b2 = fmin(b2, h1);
-    b3 = fmin(b3, h2);
+    const double h1 = max_raw(b1, d); b1 = min_raw(b1, d);
+    const double h2 = max_raw(b2, h1); b2 = min_raw(b2, h1);
+    b3 = min_raw(b3, h2);
   }
   double g[3];
 #pragma unroll
@@ -333,7 +344,7 @@ __device__ __forceinline__ bool sweep_all(const IcpLds& L, int nM, double x, dou
   if (d2 < d1 || (d2 == d1 && L.morig[k2] < L.morig[k1])) { const int t = k1; k1 = k2; k2 = t; d1 = d2; }
   const double c0 = __hiloint2double(__double2hiint(g[0]), __double2loint(g[0]) & ~0x7FF);
   const double c2 = g[2] < inf ? __hiloint2double(__double2hiint(g[2]), __double2loint(g[2]) & ~0x7FF) : inf;
-  if (!(c2 > c0)) return false;
+  if (!(c2 > __longlong_as_double(__double_as_longlong(c0) + 0x800ll))) return false;      // (same or next bucket: the exact walk decides)
   r.best = d1; r.bk = k1; r.bk2 = k2; r.lbsq = c2; r.resolved = true;
   return !isnan(d1);
 }
@@ -817,7 +828,11 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
   }
   double c0[4] = {0.0, 0.0, 0.0, 0.0};       // centring point of the pair sums: last step's centroids
 
+#ifdef TSD_ICP_TIMELINE
+  const bool has_trace = trace != nullptr && !post.st;
+#else
   const bool has_trace = trace != nullptr;   // (a scalar: reading the pointer back from LDS every step cost thread 0's wave a round trip)
+#endif
   int Rn = 0;                                // register slots of this wave that hold scene points (wave-uniform)
   for (int q = 0; q < R; q++) Rn += (pid[q] - lane < nS) ? 1 : 0;
 
@@ -1004,17 +1019,23 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
             NnResult r; r.resolved = false;
 #ifdef TSD_ICP_TIMELINE
             int rounds = 0;
+            long long st[2] = {0, 0};
             const long long ws0 = clock64();
-            if (!(lk & LIST_PAST_WINDOW)) r = window_search(L, nM, s.x, s.y, lk, thr, sgn, &rounds);
+            { double t0 = s.x + (double)lk; asm volatile("" : "+v"(t0)); }
+            const long long ws1 = clock64();
+            if (!(lk & LIST_PAST_WINDOW)) r = window_search(L, nM, s.x, s.y, lk, thr, sgn, &rounds, st);
+            asm volatile("" : "+v"(r.best), "+v"(r.lbsq));
+            const long long ws2 = clock64();
             {
               // (diagnostic) per list round of wave 0: entries, lanes' largest / mean number of window rounds, cycles of the call
               int mx = rounds;
               for (int o = 32; o; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
               int sm = rounds;
               for (int o = 32; o; o >>= 1) sm += __shfl_xor(sm, o);
-              if (wave == 0 && lane == 0 && iter < 32u) {
+              if (has_trace && wave == 0 && lane == 0 && iter < 32u) {
                 double* dd = L.tail->trace + TSD_ICP_TRACE_STRIDE * (TSD_ICP_TRACE_MAX + 128) + 8 * iter;
-                if (e0 == 0) { dd[0] = (double)n; dd[1] = (double)mx; dd[2] = (double)sm; dd[3] = (double)(clock64() - ws0); dd[4] = (double)__popcll(__ballot(true)); }
+                if (e0 == 0) { dd[0] = (double)n; dd[1] = (double)mx; dd[2] = (double)sm; dd[3] = (double)(ws2 - ws0); dd[4] = (double)__popcll(__ballot(true));
+                               dd[5] = (double)(ws1 - tlbuf[((iter - TL_FIRST) * W) * TL_N + 4]); dd[6] = (double)(st[0] - ws1); dd[7] = (double)(st[1] - st[0]); }
               }
             }
 #else
@@ -1419,6 +1440,9 @@ static int launch_icp_shape_est(tsd_ctx* ctx, const IcpArgs& a, int n, int cap, 
   // the 64-byte store per step
   double* trace_buf = tg && tg->trace ? tg->trace : ctx->d_icp_trace;
   if (post.st) trace_buf = nullptr;
+#ifdef TSD_ICP_TIMELINE
+  if (post.st) trace_buf = ctx->d_icp_trace;     // (diagnostic build: the stamps of a fused scan's registration; no per-step record)
+#endif
   const bool own_seed = tg && tg->icp_seed;
   const IcpSeedArgs sa = icp_seed_args(own_seed ? tg->icp_seed : ctx->d_icp_seed, own_seed ? tg->icp_seed_points : TSD_MAX_ICP_POINTS,
                                        icp_helpers_for(ctx, n, T));
