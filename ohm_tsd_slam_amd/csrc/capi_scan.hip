@@ -23,6 +23,11 @@ tsd_sensor* tsd_sensor_create(tsd_ctx* ctx, int beams, double ang_res, double ph
   A(hipMalloc(&s->d_rays, nb * 16));
   A(hipMalloc(&s->d_rays_local, nb * 16));
   for (int i = 0; i < 3; i++) A(hipMalloc(&s->d_scan2[i], nb * 10 + 64));
+  for (int i = 0; i < 3; i++) {
+    A(hipHostMalloc(&s->h_scan3[i], nb * 10 + 64, hipHostMallocMapped));
+    if (ok) A(hipHostGetDevicePointer((void**)&s->hd_scan3[i], s->h_scan3[i], 0));
+    A(hipEventCreateWithFlags(&s->ev_scan_copy[i], hipEventDisableTiming));
+  }
   // the scan result is written by the kernel straight into coherent pinned host memory
   A(hipHostMalloc(&s->h_result, sizeof(ScanResultDev), hipHostMallocMapped | hipHostMallocCoherent));
   if (ok) { std::memset(s->h_result, 0, sizeof(ScanResultDev)); A(hipHostGetDevicePointer((void**)&s->d_result, s->h_result, 0)); }
@@ -57,6 +62,7 @@ void tsd_sensor_destroy(tsd_sensor* s)
   if (s->d_pre) hipFree(s->d_pre);
   if (s->h_pre) hipHostFree(s->h_pre);
   hipFree(s->d_rmq2[0]); hipFree(s->d_rmq2[1]); hipFree(s->d_rmq2[2]);
+  for (int i = 0; i < 3; i++) { if (s->h_scan3[i]) hipHostFree(s->h_scan3[i]); if (s->ev_scan_copy[i]) hipEventDestroy(s->ev_scan_copy[i]); }
   if (s->h_stage2[0]) hipHostFree(s->h_stage2[0]);
   if (s->h_stage2[1]) hipHostFree(s->h_stage2[1]);
   hipFree(s->d_state); hipFree(s->d_rays); hipFree(s->d_rays_local); hipFree(s->d_scan2[0]); hipFree(s->d_scan2[1]); hipFree(s->d_scan2[2]);
@@ -106,28 +112,47 @@ int tsd_sensor_set_pose(tsd_sensor* s, const double pose33[9], const double* ray
 
 static int sensor_conc_init(tsd_sensor* s, bool own_stream);
 
-// copy + range-query tables of one scan on the side stream, into the sensor's buffers the scan in flight does not use
-static int scan_stage_impl(tsd_sensor* s, const double* ranges, const uint8_t* mask, const uint8_t* mask_push)
+// A scan comes in two steps.  scan_stage_host: the caller's arrays into the sensor's pinned buffer (the three scan / table buffers are
+// used in turn).  scan_stage_device: the copy into device memory and the range-query tables of this scan's push on the side stream --
+// they only depend on the scan and run while the main stream is busy.  tsd_scan_stage does both at once (a scan announced ahead);
+// tsd_scan_submit with a scan launches the registration between the two (it reads the pinned buffer itself).
+static int scan_stage_host(tsd_sensor* s, const double* ranges, const uint8_t* mask, const uint8_t* mask_push)
 {
   tsd_ctx* ctx = s->ctx;
   const size_t nb = (size_t)s->beams;
   if (int rc = sensor_conc_init(s, false)) return rc;       // (the sensor's own table buffers)
-  // One H2D: ranges | mask | mask_push, on the side stream into the buffer the previous scan does not use: the
-  // copy and the range-query tables of this scan's push (which only depend on the scan) run while the previous
-  // push and this scan's ray cast are still busy on the main stream.
-  int slot;
   unsigned long long tl = g_stage_timing.on ? now_ns() : 0;
   auto LAP = [&](int i) { if (g_stage_timing.on) { const unsigned long long u = now_ns(); g_stage_timing.ns[i] += u - tl; tl = u; } };
-  char* h = stage_acquire(ctx, &slot);
+  // three buffers in turn (see tsd_sensor::stage_slot): the push that read this one three scans ago is done -- and so is the device
+  // copy out of the pinned buffer, which that push was ordered behind; its event is looked at all the same (one query)
+  const int sslot = s->stage_slot;
+  s->stage_slot = (s->stage_slot + 1) % 3;
+  if (s->scan_copy_valid[sslot]) { TSD_HIP_CHECK(ctx, hipEventSynchronize(s->ev_scan_copy[sslot])); s->scan_copy_valid[sslot] = false; }
   LAP(0);
+  char* h = s->h_scan3[sslot];
   std::memcpy(h, ranges, nb * 8);
   std::memcpy(h + nb * 8, mask, nb);
   std::memcpy(h + nb * 9, mask_push ? mask_push : mask, nb);
   LAP(1);
-  // three buffers in turn (see tsd_sensor::stage_slot): the push that read this one three scans ago is done
-  const int sslot = s->stage_slot;
   char* d_scan = s->d_scan2[sslot];
-  s->stage_slot = (s->stage_slot + 1) % 3;
+  s->st_ranges = reinterpret_cast<const double*>(d_scan);
+  s->st_mask = reinterpret_cast<const uint8_t*>(d_scan + nb * 8);
+  s->st_mask_push = reinterpret_cast<const uint8_t*>(d_scan + nb * 9);
+  s->st_h_ranges = reinterpret_cast<const double*>(s->hd_scan3[sslot]);
+  s->st_h_mask = reinterpret_cast<const uint8_t*>(s->hd_scan3[sslot] + nb * 8);
+  s->st_rmq = s->d_rmq2[sslot]; s->st_slot = sslot;
+  s->st_device_done = false;
+  s->staged = true;
+  return TSD_OK;
+}
+
+static int scan_stage_device(tsd_sensor* s)
+{
+  tsd_ctx* ctx = s->ctx;
+  const size_t nb = (size_t)s->beams;
+  const int sslot = s->st_slot;
+  unsigned long long tl = g_stage_timing.on ? now_ns() : 0;
+  auto LAP = [&](int i) { if (g_stage_timing.on) { const unsigned long long u = now_ns(); g_stage_timing.ns[i] += u - tl; tl = u; } };
   // Asynchronous mapping: the push that last read this buffer (three scans back) ran on the push stream beside a registration, and
   // nothing the host has seen since is ordered behind it -- the copy and the tables below wait for that push's own event (done long
   // ago in practice: one query; the stream-side wait is the fall-back).  Strict order: see tsd_sensor::stage_slot.
@@ -135,15 +160,12 @@ static int scan_stage_impl(tsd_sensor* s, const double* ranges, const uint8_t* m
     if (!host_saw_event(s->ev_slot_push[sslot], 0)) TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream2, s->ev_slot_push[sslot], 0));
     else s->slot_push_valid[sslot] = false;
   }
-  TSD_HIP_CHECK(ctx, hipMemcpyAsync(d_scan, h, nb * 10, hipMemcpyHostToDevice, ctx->stream2));
+  TSD_HIP_CHECK(ctx, hipMemcpyAsync(s->d_scan2[sslot], s->h_scan3[sslot], nb * 10, hipMemcpyHostToDevice, ctx->stream2));
   LAP(2);
-  TSD_HIP_CHECK(ctx, hipEventRecord(ctx->stage_ev[slot], ctx->stream2));
+  TSD_HIP_CHECK(ctx, hipEventRecord(s->ev_scan_copy[sslot], ctx->stream2));
+  s->scan_copy_valid[sslot] = true;
   TSD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_h2d, ctx->stream2));
   LAP(3);
-  s->st_ranges = reinterpret_cast<const double*>(d_scan);
-  s->st_mask = reinterpret_cast<const uint8_t*>(d_scan + nb * 8);
-  s->st_mask_push = reinterpret_cast<const uint8_t*>(d_scan + nb * 9);
-  s->st_rmq = s->d_rmq2[sslot]; s->st_slot = sslot;
   LaunchTarget tg;
   tg.rmq = s->st_rmq;
   TargetScope scope(ctx, &tg);
@@ -156,8 +178,14 @@ static int scan_stage_impl(tsd_sensor* s, const double* ranges, const uint8_t* m
   (void)hipStreamQuery(ctx->stream2);
   LAP(4);
   if (g_stage_timing.on) g_stage_timing.n++;
-  s->staged = true;
+  s->st_device_done = true;
   return TSD_OK;
+}
+
+static int scan_stage_impl(tsd_sensor* s, const double* ranges, const uint8_t* mask, const uint8_t* mask_push)
+{
+  if (int rc = scan_stage_host(s, ranges, mask, mask_push)) return rc;
+  return scan_stage_device(s);
 }
 
 int tsd_sensor_set_async_mapping(tsd_sensor* s, int on)
@@ -238,10 +266,16 @@ int tsd_scan_submit(tsd_sensor* s, const double* ranges, const uint8_t* mask, co
     // ones on the side stream, and nothing else ever read the dropped data.
     if (s->staged) s->stage_slot = s->st_slot;
     s->staged = false;
-    int rcs = scan_stage_impl(s, ranges, mask, mask_push);
+    int rcs = scan_stage_host(s, ranges, mask, mask_push);
     if (rcs != TSD_OK) return rcs;
+    // (the pre-registration reads the scan from device memory: copy and tables first, as for a scan staged ahead)
+    if (s->pre_armed) { rcs = scan_stage_device(s); if (rcs != TSD_OK) return rcs; }
   }
   s->staged = false;
+  // A scan that came with this call is in the pinned buffer and nowhere else yet: its registration reads it from there, and the device
+  // copy + tables are enqueued BEHIND the registration's launch -- the host's work on them no longer sits between the result of the
+  // previous scan and this launch (the main stream ran dry for ~10 us per scan there; the push needs them 100+ us from now).
+  const bool icp_from_host = !s->st_device_done;
   const double* d_ranges = s->st_ranges;
   const uint8_t* d_mask = s->st_mask;
   const uint8_t* d_mask_push = s->st_mask_push;
@@ -295,9 +329,16 @@ int tsd_scan_submit(tsd_sensor* s, const double* ranges, const uint8_t* mask, co
   // host waits for the copy itself (a few microseconds, the device is busy meanwhile) instead of putting a
   // cross-stream barrier between the two kernels; the barrier is the fall-back.  (A scan staged ahead was copied
   // during the previous registration: nothing to wait for.)
-  if (!host_saw_event(ctx->ev_h2d, staged_ahead ? 2 : 40)) TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_h2d, 0));
-  rc = launch_icp(ctx, ia, s->d_state->icpP, s->d_rays_local, d_ranges, d_mask, &sp);
-  if (rc != TSD_OK) return rc;
+  if (icp_from_host) {
+    rc = launch_icp(ctx, ia, s->d_state->icpP, s->d_rays_local, s->st_h_ranges, s->st_h_mask, &sp);
+    if (rc != TSD_OK) return rc;
+    rc = scan_stage_device(s);
+    if (rc != TSD_OK) return rc;
+  } else {
+    if (!host_saw_event(ctx->ev_h2d, staged_ahead ? 2 : 40)) TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_h2d, 0));
+    rc = launch_icp(ctx, ia, s->d_state->icpP, s->d_rays_local, d_ranges, d_mask, &sp);
+    if (rc != TSD_OK) return rc;
+  }
   lap.lap(3);
   PushArgs pa;
   std::memset(&pa, 0, sizeof(pa));

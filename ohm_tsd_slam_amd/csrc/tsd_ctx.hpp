@@ -270,6 +270,15 @@ struct tsd_sensor {
   double* d_rays = nullptr;        // [2*beams] world rays, normalised to the cell size
   double* d_rays_local = nullptr;  // [2*beams]
   char* d_scan2[3] = {nullptr, nullptr, nullptr};   // ranges[beams] | mask[beams] | mask_push[beams], used in turn (split scan: 0 / 1)
+  // The same three scans in pinned host memory, where the caller's arrays are copied first.  A scan that was NOT staged ahead is read
+  // by its registration from here, over the host link (10 KB, requested at once at the top of k_icp): the registration is launched as
+  // soon as the scan is in this buffer, and the device copy + the push's range tables follow on the side stream beside it.
+  char* h_scan3[3] = {nullptr, nullptr, nullptr};
+  char* hd_scan3[3] = {nullptr, nullptr, nullptr};  // device addresses of h_scan3
+  hipEvent_t ev_scan_copy[3] = {nullptr, nullptr, nullptr};   // "the device copy out of h_scan3[i] is done" (before the host rewrites it)
+  bool scan_copy_valid[3] = {false, false, false};
+  const double* st_h_ranges = nullptr; const uint8_t* st_h_mask = nullptr;   // the staged scan's ranges / mask in h_scan3 (device addresses)
+  bool st_device_done = false;     // the staged scan's device copy and tables are enqueued
   int scan_slot = 0;
   tsd::ScanResultDev* h_result = nullptr;   // pinned, coherent, written by k_scan_post directly
   tsd::ScanResultDev* d_result = nullptr;   // device address of h_result
