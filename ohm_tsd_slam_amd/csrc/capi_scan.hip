@@ -268,8 +268,6 @@ int tsd_scan_submit(tsd_sensor* s, const double* ranges, const uint8_t* mask, co
     s->staged = false;
     int rcs = scan_stage_host(s, ranges, mask, mask_push);
     if (rcs != TSD_OK) return rcs;
-    // (the pre-registration reads the scan from device memory: copy and tables first, as for a scan staged ahead)
-    if (s->pre_armed) { rcs = scan_stage_device(s); if (rcs != TSD_OK) return rcs; }
   }
   s->staged = false;
   // A scan that came with this call is in the pinned buffer and nowhere else yet: its registration reads it from there, and the device
