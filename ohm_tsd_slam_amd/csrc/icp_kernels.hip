@@ -629,6 +629,8 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
   long long* tlbuf = reinterpret_cast<long long*>(smem + icp_lds_bytes_for(cap, (FT ? FT : (int)blockDim.x), PTL));       // [TL_STEPS][W][TL_N], behind the kernel's own LDS
 #define TL(i) do { if (lane == 0 && iter >= (unsigned)TL_FIRST && iter < (unsigned)(TL_FIRST + TL_STEPS)) \
                      tlbuf[((iter - TL_FIRST) * W + wave) * TL_N + (i)] = clock64(); } while (0)
+  const long long tk_entry = clock64();          // (whole-kernel phases: set-up, loop, epilogue -- row TSD_ICP_TRACE_MAX + 192 of the trace)
+  long long tk_loop0 = 0, tk_loop1 = 0, tk_seed = 0;
 #else
 #define TL(i) do {} while (0)
 #endif
@@ -836,6 +838,9 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
   int Rn = 0;                                // register slots of this wave that hold scene points (wave-uniform)
   for (int q = 0; q < R; q++) Rn += (pid[q] - lane < nS) ? 1 : 0;
 
+#ifdef TSD_ICP_TIMELINE
+  tk_seed = clock64();
+#endif
   // step 0's searches, done by the helper workgroups while this one set itself up: every lane re-reads its points' granules until
   // they carry this launch's number (a bounded wait, per wave) and takes neighbour, runner-up and bound from them
   if (!PAIRS && seed.helpers > 0) {
@@ -868,6 +873,9 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
     }
   }
 
+#ifdef TSD_ICP_TIMELINE
+  tk_loop0 = clock64();
+#endif
   while (state == TSD_ICP_PROCESSING) {
     const double thr_before = thr;
     TL(0);
@@ -1278,6 +1286,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
   }
 
 #ifdef TSD_ICP_TIMELINE
+  tk_loop1 = clock64();
   __syncthreads();
   if (L.tail->trace) {
     if constexpr (TL_STEPS <= 4) {
@@ -1301,6 +1310,13 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
     if (tid == 0) *tl.out = r;
     // fused scan: gates, Sensor::transform, push / next-scan arguments, result record for the host
     if (tl.post.st) scan_post_body(tl.post, L.tail->pre, r.T, r, tl.post.gmin_x, tl.post.gmax_x, tl.post.gmin_y, tl.post.gmax_y);
+#ifdef TSD_ICP_TIMELINE
+    if (tid == 0 && tl.trace) {
+      double* ph = tl.trace + TSD_ICP_TRACE_STRIDE * (TSD_ICP_TRACE_MAX + 192);
+      const long long tk_end = clock64();
+      ph[0] = (double)(tk_seed - tk_entry); ph[1] = (double)(tk_loop0 - tk_seed); ph[2] = (double)(tk_loop1 - tk_loop0); ph[3] = (double)(tk_end - tk_loop1);
+    }
+#endif
   }
 }
 
