@@ -29,8 +29,10 @@ tsd_sensor* tsd_sensor_create(tsd_ctx* ctx, int beams, double ang_res, double ph
     A(hipEventCreateWithFlags(&s->ev_scan_copy[i], hipEventDisableTiming));
   }
   // the scan result is written by the kernel straight into coherent pinned host memory
-  A(hipHostMalloc(&s->h_result, sizeof(ScanResultDev), hipHostMallocMapped | hipHostMallocCoherent));
-  if (ok) { std::memset(s->h_result, 0, sizeof(ScanResultDev)); A(hipHostGetDevicePointer((void**)&s->d_result, s->h_result, 0)); }
+  s->h_result = new (std::nothrow) ScanResultDev();
+  if (!s->h_result) ok = false; else std::memset(s->h_result, 0, sizeof(ScanResultDev));
+  A(hipHostMalloc(&s->h_rwords, sizeof(unsigned long long) * SCAN_RESULT_WORDS, hipHostMallocMapped | hipHostMallocCoherent));
+  if (ok) { std::memset(s->h_rwords, 0, sizeof(unsigned long long) * SCAN_RESULT_WORDS); A(hipHostGetDevicePointer((void**)&s->d_result, s->h_rwords, 0)); }
   if (!ok) { tsd_sensor_destroy(s); return nullptr; }
   ctx->sensors.push_back(s);
   return s;
@@ -66,7 +68,7 @@ void tsd_sensor_destroy(tsd_sensor* s)
   if (s->h_stage2[0]) hipHostFree(s->h_stage2[0]);
   if (s->h_stage2[1]) hipHostFree(s->h_stage2[1]);
   hipFree(s->d_state); hipFree(s->d_rays); hipFree(s->d_rays_local); hipFree(s->d_scan2[0]); hipFree(s->d_scan2[1]); hipFree(s->d_scan2[2]);
-  hipHostFree(s->h_result);
+  hipHostFree(s->h_rwords); delete s->h_result;
   delete s;
 }
 
@@ -111,6 +113,24 @@ int tsd_sensor_set_pose(tsd_sensor* s, const double pose33[9], const double* ray
 }
 
 static int sensor_conc_init(tsd_sensor* s, bool own_stream);
+
+// Has the result record of scan `seq` arrived?  It travels as tagged 8-byte words {low half of seq, four bytes of the record}
+// (scan_device.hpp: scan_post_body); once every word carries the tag the record is decoded into s->h_result.  The last word first: the
+// usual answer is "not yet" after one load.
+static bool scan_result_arrived(tsd_sensor* s, unsigned long long seq)
+{
+  if (s->h_result->seq == seq) return true;                      // (decoded by an earlier call)
+  const unsigned int tag = (unsigned int)seq;
+  unsigned long long w[SCAN_RESULT_WORDS];
+  for (int i = SCAN_RESULT_WORDS - 1; i >= 0; i--) {
+    w[i] = __atomic_load_n(&s->h_rwords[i], __ATOMIC_RELAXED);
+    if ((unsigned int)(w[i] >> 32) != tag) return false;
+  }
+  unsigned int* out = reinterpret_cast<unsigned int*>(s->h_result);
+  for (int i = 0; i < SCAN_RESULT_WORDS; i++) out[i] = (unsigned int)w[i];
+  s->h_result->seq = seq;                                          // (its own words carry the low half only)
+  return true;
+}
 
 // A scan comes in two steps.  scan_stage_host: the caller's arrays into the sensor's pinned buffer (the three scan / table buffers are
 // used in turn).  scan_stage_device: the copy into device memory and the range-query tables of this scan's push on the side stream --
@@ -414,9 +434,8 @@ int tsd_scan_collect(tsd_sensor* s, tsd_scan_result* result)
   // whatever the caller enqueues next is ordered behind them on the stream.  So the host does not wait for
   // the stream: it polls the sequence number and prepares the next scan while the push is still running.
   {
-    volatile unsigned long long* vseq = &s->h_result->seq;
     unsigned long long spins = 0;
-    while (__atomic_load_n(vseq, __ATOMIC_ACQUIRE) != seq) {
+    while (!scan_result_arrived(s, seq)) {
       ++spins;
       // A registration takes 0.15-0.3 ms.  Past that, nudge the runtime: with other streams in the process (a communicator's,
       // a framework's) it was seen to sit on an enqueued launch until the next query / synchronisation of the stream -- a
@@ -424,7 +443,7 @@ int tsd_scan_collect(tsd_sensor* s, tsd_scan_result* result)
       if ((spins & 0x3FFFull) == 0) { (void)hipStreamQuery(ctx->stream); (void)hipStreamQuery(ctx->stream2); }
       if (spins > 4000000ull) {            // ~ a tenth of a second: something is wrong, fall back to a real wait
         TSD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        if (__atomic_load_n(vseq, __ATOMIC_ACQUIRE) != seq)
+        if (!scan_result_arrived(s, seq))
           return set_error(ctx, TSD_E_HIP, "tsd_scan: result record never arrived", hipSuccess);
         break;
       }
@@ -569,11 +588,10 @@ int tsd_scan_begin(tsd_sensor* s, const double* ranges, const uint8_t* mask, con
 int tsd_scan_wait(tsd_sensor* s)
 {
   if (!s || !s->inflight) return TSD_E_ARG;
-  volatile unsigned long long* vseq = &s->h_result->seq;
   unsigned long long spins = 0;
-  while (__atomic_load_n(vseq, __ATOMIC_ACQUIRE) != s->seq) {
+  while (!scan_result_arrived(s, s->seq)) {
     if (++spins > 4000000ull) {            // something is wrong: a real wait on the sensor's stream
-      if (hipStreamSynchronize(s->stream) != hipSuccess || __atomic_load_n(vseq, __ATOMIC_ACQUIRE) != s->seq) return TSD_E_HIP;
+      if (hipStreamSynchronize(s->stream) != hipSuccess || !scan_result_arrived(s, s->seq)) return TSD_E_HIP;
       break;
     }
 #if defined(__x86_64__)
@@ -952,7 +970,7 @@ int tsd_batch_poll(tsd_batch* b)
 {
   if (!b) return TSD_E_ARG;
   for (int i = 0; i < b->n; i++)
-    if (__atomic_load_n(&b->sensors[(size_t)i]->h_result->seq, __ATOMIC_ACQUIRE) != b->seqs[(size_t)i]) return 0;
+    if (!scan_result_arrived(b->sensors[(size_t)i], b->seqs[(size_t)i])) return 0;
   return 1;
 }
 

@@ -630,7 +630,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
 #define TL(i) do { if (lane == 0 && iter >= (unsigned)TL_FIRST && iter < (unsigned)(TL_FIRST + TL_STEPS)) \
                      tlbuf[((iter - TL_FIRST) * W + wave) * TL_N + (i)] = clock64(); } while (0)
   const long long tk_entry = clock64();          // (whole-kernel phases: set-up, loop, epilogue -- row TSD_ICP_TRACE_MAX + 192 of the trace)
-  long long tk_loop0 = 0, tk_loop1 = 0, tk_seed = 0;
+  long long tk_loop0 = 0, tk_loop1 = 0, tk_seed = 0, tk_s[4] = {0, 0, 0, 0};
 #else
 #define TL(i) do {} while (0)
 #endif
@@ -661,6 +661,9 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
       fm[q] = (b < a.beams) && mm != 0;
       fs[q] = (b < a.beams) && !isinf(rr[q]) && ms != 0;
     }
+#ifdef TSD_ICP_TIMELINE
+    { double t0 = rr[0] + cmx[0] + lx[0] + (double)fm[0] + (double)fs[0]; asm volatile("" : "+v"(t0)); tk_s[0] = clock64(); }     // inputs arrived
+#endif
     int* cnts = reinterpret_cast<int*>(L.red);           // [R][W][2] (the reduction rows are idle during setup)
     unsigned long long bm[R], bs[R];
 #pragma unroll
@@ -695,6 +698,9 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
     nM = runM; nS = runS;
     if (a.beams > R * T) nM = cap + 1;                   // (not reachable through launch_icp)
     __syncthreads();
+#ifdef TSD_ICP_TIMELINE
+    tk_s[1] = clock64();                                 // compacted model and scene in LDS
+#endif
   } else {
     nM = a.n_model; nS = a.n_scene;
     if (nM <= cap && nS <= cap) {
@@ -799,6 +805,9 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
     }
     return;
   }
+#ifdef TSD_ICP_TIMELINE
+  tk_s[2] = clock64();                                   // scene in registers, unit directions and padding written
+#endif
   const int slot_halves = icp_slot_halves(cap, T, PTL);
   for (int k = tid; k < cap; k += T) { L.slotD[k] = ~0ull; if (slot_halves == 2) L.slotD[cap + k] = ~0ull; L.slotI[k] = INT_MAX; }
   for (int k = tid; k < ICP_MAXW * 16; k += T) L.red[k] = 0.0;    // (block_totals8 reads the rows of absent waves)
@@ -1309,11 +1318,22 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
     const IcpTail& tl = *L.tail;
     if (tid == 0) *tl.out = r;
     // fused scan: gates, Sensor::transform, push / next-scan arguments, result record for the host
+#ifdef TSD_ICP_TIMELINE
+    long long tke[6] = {0, 0, 0, 0, 0, 0};
+    if (tl.post.st) scan_post_body(tl.post, L.tail->pre, r.T, r, tl.post.gmin_x, tl.post.gmax_x, tl.post.gmin_y, tl.post.gmax_y, tke);
+    if (tid == 0 && tl.trace) {
+      double* pe = tl.trace + TSD_ICP_TRACE_STRIDE * (TSD_ICP_TRACE_MAX + 193);
+      pe[0] = (double)(tke[0] - tk_loop1); for (int i = 1; i < 6; i++) pe[i] = (double)(tke[i] - tke[i - 1]);
+      pe[6] = (double)(clock64() - tke[5]);
+    }
+#else
     if (tl.post.st) scan_post_body(tl.post, L.tail->pre, r.T, r, tl.post.gmin_x, tl.post.gmax_x, tl.post.gmin_y, tl.post.gmax_y);
+#endif
 #ifdef TSD_ICP_TIMELINE
     if (tid == 0 && tl.trace) {
       double* ph = tl.trace + TSD_ICP_TRACE_STRIDE * (TSD_ICP_TRACE_MAX + 192);
       const long long tk_end = clock64();
+      ph[4] = (double)(tk_s[0] - tk_entry); ph[5] = (double)(tk_s[1] - tk_s[0]); ph[6] = (double)(tk_s[2] - tk_s[1]); ph[7] = (double)(tk_seed - tk_s[2]);
       ph[0] = (double)(tk_seed - tk_entry); ph[1] = (double)(tk_loop0 - tk_seed); ph[2] = (double)(tk_loop1 - tk_loop0); ph[3] = (double)(tk_end - tk_loop1);
     }
 #endif

@@ -143,9 +143,15 @@ __device__ inline void scan_post_preload(const ScanPostArgs& sp, ScanPostPre* pr
 // acos / sin chains); lane 0 of the last-but-one wave inverts the new pose for the next ray cast and this scan's push (an LU with
 // three dependent divisions).  Round 2 ran these one after the other on thread 0, behind a read of the sensor state from memory.
 __device__ inline void scan_post_body(const ScanPostArgs& sp, const ScanPostPre& pre, const double T[9], const IcpResultDev& icp,
-                                      double gmin_x, double gmax_x, double gmin_y, double gmax_y)
+                                      double gmin_x, double gmax_x, double gmin_y, double gmax_y, long long* tk = nullptr /* timeline build: stamps */)
 {
   SensorDev* st = sp.st;
+#ifdef TSD_ICP_TIMELINE
+#define EPI_STAMP(i) do { if (tk && threadIdx.x == 0) tk[i] = clock64(); } while (0)
+#else
+#define EPI_STAMP(i) do {} while (0)
+#endif
+  EPI_STAMP(0);
   const int W = (int)(blockDim.x >> 6), wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
   const bool no_model = icp.n_model == 0;   // "Raycasting found no coordinates" (ThreadLocalize.cpp:354-358)
   // isRegistrationError (every thread: the ray update below depends on it)
@@ -153,10 +159,21 @@ __device__ inline void scan_post_body(const ScanPostArgs& sp, const ScanPostPre&
   if (!no_model) {
     const double dX = T[2], dY = T[5];
     const double trns = sqrt(dX * dX + dY * dY);
-    const double dphi = d_calc_angle(T);
-    reg_error = (trns > sp.gates.reg_trs_max) || (fabs(sin(dphi)) > sp.gates.reg_sin_rot_max);
+    // |sin(calcAngle(T))| is 0 or |sin(acos(T0))| = sqrt((1 - T0)(1 + T0)) (calcAngle returns 0, acos(T0) or 2 pi - acos(T0),
+    // ThreadLocalize.cpp:715-726).  The libm chain (asin, asin, acos, sin: ~2 000 cycles in front of everything the epilogue does) is
+    // only needed to DECIDE when that closed form lies within 1e-9 of the gate; otherwise both sides of the comparison agree.
+    const double t0 = T[0], t3 = T[3], t1 = T[1];
+    const bool arg_ok = fabs(t0) <= 1.0 && fabs(t3) <= 1.0 && fabs(t1) <= 1.0;
+    const bool turned = ((t3 > 0.0) && (t1 < 0.0)) || ((t3 < 0.0) && (t1 > 0.0));      // (asin keeps the sign)
+    const double s_fast = turned ? sqrt((1.0 - t0) * (1.0 + t0)) : 0.0;
+    const double g = sp.gates.reg_sin_rot_max;
+    bool rot_error;
+    if (arg_ok && fabs(s_fast - g) > 1e-9 * fmax(fabs(g), s_fast)) rot_error = s_fast > g;
+    else rot_error = fabs(sin(d_calc_angle(T))) > g;
+    reg_error = (trns > sp.gates.reg_trs_max) || rot_error;
   }
   const bool moved = !no_model && !reg_error;
+  EPI_STAMP(1);                              // gate decided
   // workgroup-shared hand-over of the two lone lanes' results (64-byte aligned scratch in the model's LDS would do as well;
   // static: a few words)
   __shared__ int s_pushed;
@@ -227,35 +244,42 @@ __device__ inline void scan_post_body(const ScanPostArgs& sp, const ScanPostPre&
   }
   // every wave has turned its rays and both lone lanes have written the sensor's state before the sequence numbers go out: a ray
   // cast of this sensor on ANOTHER stream (the batched path) is ordered behind this scan only through them
-  __shared__ unsigned long long s_record[sizeof(ScanResultDev) / 8];
+  // The result record leaves as TAGGED words: every 8-byte word = {low half of the scan's sequence number, four bytes of the record},
+  // all of them ONE store instruction of relaxed system-scope atomics (write-through stores into the coherent pinned buffer).  The host
+  // has the record when every word carries the tag -- no order among the stores is needed, so nothing is drained in between (the
+  // record-then-sequence-number form waited one trip over the host link between the two: ~1 700 cycles at the end of every
+  // registration; round 4's fence + release form ~3 us).  Its parts are written into LDS by the lanes that hold them, ahead of the
+  // barrier: the registration's result by thread 0, pose and flags by the gate lane.
+  __shared__ unsigned int s_record[SCAN_RESULT_WORDS];
+  if (threadIdx.x == 0) {
+    ScanResultDev r;
+    r.icp = icp;
+    const unsigned int* w = reinterpret_cast<const unsigned int*>(&r);
+    for (int i = 0; i < (int)(offsetof(ScanResultDev, pose) / 4); i++) s_record[i] = w[i];
+  }
+  if (lone_gate) {
+    ScanResultDev r;
+    for (int i = 0; i < 9; i++) r.pose[i] = s_pose[i];       // (this lane's own writes)
+    r.reg_error = reg_error ? 1 : 0; r.pushed = s_pushed; r.no_model = no_model ? 1 : 0; r.reserved = 0;
+    r.seq = sp.seq;
+    const unsigned int* w = reinterpret_cast<const unsigned int*>(&r);
+    for (int i = (int)(offsetof(ScanResultDev, pose) / 4); i < SCAN_RESULT_WORDS; i++) s_record[i] = w[i];
+  }
+  EPI_STAMP(2);                              // wave 0's rays turned (stores issued)
+  // every wave has turned its rays and both lone lanes have written the sensor's state before the sequence numbers go out: a ray
+  // cast of this sensor on ANOTHER stream (the batched path) is ordered behind this scan only through them
   __syncthreads();
+  EPI_STAMP(3);                              // everybody's, and the lone lanes' bookkeeping
   if (threadIdx.x < 64) {
-    // The result record: composed in LDS by lane 0, then stored word by word as relaxed system-scope atomics -- write-through stores
-    // to the coherent pinned buffer, ONE instruction of 24 lanes -- drained, then the sequence number the host polls.  (Round 4 wrote
-    // the record with plain stores behind __threadfence_system() and released the two sequence numbers: three write-backs of the L2
-    // and an invalidate at the end of every registration, ~3 us, for 200 bytes that never were in a cache.)
-    static_assert(sizeof(ScanResultDev) % 8 == 0 && sizeof(ScanResultDev) / 8 <= 64 && offsetof(ScanResultDev, seq) == sizeof(ScanResultDev) - 8, "ScanResultDev");
-    constexpr int NW = (int)(sizeof(ScanResultDev) / 8) - 1;           // words ahead of `seq`
-    if (threadIdx.x == 0) {
-      if (sp.push_copy) *sp.push_copy = st->push;      // (asynchronous mapping: this scan's push reads its own copy; a later kernel)
-      ScanResultDev r;
-      r.icp = icp;
-      for (int i = 0; i < 9; i++) r.pose[i] = s_pose[i];
-      r.reg_error = reg_error ? 1 : 0; r.pushed = s_pushed; r.no_model = no_model ? 1 : 0; r.reserved = 0;
-      r.seq = 0ull;
-      const unsigned long long* w = reinterpret_cast<const unsigned long long*>(&r);
-      for (int i = 0; i < NW; i++) s_record[i] = w[i];
-    }
-    // (a wave's LDS accesses execute in order)
-    unsigned long long* out = reinterpret_cast<unsigned long long*>(sp.out);
-    if ((int)threadIdx.x < NW) __hip_atomic_store(out + threadIdx.x, s_record[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (threadIdx.x == 0) {
-      __hip_atomic_store(out + NW, sp.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      // the same number for a gate kernel on another stream (a batched robot's push starts when ITS registration is done): that
-      // reader takes the sensor's state, written with plain stores above -- a release, where there is such a reader
-      if (sp.publish_done) __hip_atomic_store(&st->done_seq, sp.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (threadIdx.x == 0 && sp.push_copy) *sp.push_copy = st->push;      // (asynchronous mapping: this scan's push reads its own copy; a later kernel)
+    if ((int)threadIdx.x < SCAN_RESULT_WORDS)
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(sp.out) + threadIdx.x,
+                         ((unsigned long long)(unsigned int)sp.seq << 32) | (unsigned long long)s_record[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    EPI_STAMP(4);                            // record on its way
+    // the same number for a gate kernel on another stream (a batched robot's push starts when ITS registration is done): that
+    // reader takes the sensor's state, written with plain stores above -- a release, where there is such a reader
+    if (threadIdx.x == 0 && sp.publish_done) __hip_atomic_store(&st->done_seq, sp.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    EPI_STAMP(5);
   }
 }
 
@@ -268,15 +292,18 @@ __device__ inline void scan_post_failed(const ScanPostArgs& sp, int why)
   SensorDev* st = sp.st;
   st->push.enabled = 0;
   if (sp.push_copy) *sp.push_copy = st->push;
-  ScanResultDev* out = sp.out;
+  ScanResultDev rec;
   IcpResultDev r;
   for (int i = 0; i < 9; i++) r.T[i] = (i % 4 == 0) ? 1.0 : 0.0;
   r.rms = 0.0; r.pairs = 0; r.iterations = 0; r.state = TSD_ICP_NOTMATCHABLE; r.n_model = 0; r.n_scene = 0; r.reserved = why;
-  out->icp = r;
-  for (int i = 0; i < 9; i++) out->pose[i] = st->pose[i];
-  out->reg_error = 1; out->pushed = 0; out->no_model = 0; out->reserved = why;
-  __threadfence_system();
-  __hip_atomic_store(&out->seq, sp.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  rec.icp = r;
+  for (int i = 0; i < 9; i++) rec.pose[i] = st->pose[i];
+  rec.reg_error = 1; rec.pushed = 0; rec.no_model = 0; rec.reserved = why;
+  rec.seq = sp.seq;
+  const unsigned int* w = reinterpret_cast<const unsigned int*>(&rec);
+  for (int i = 0; i < SCAN_RESULT_WORDS; i++)           // (tagged words, see scan_post_body)
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(sp.out) + i, ((unsigned long long)(unsigned int)sp.seq << 32) | (unsigned long long)w[i],
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __hip_atomic_store(&st->done_seq, sp.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 

@@ -56,8 +56,12 @@ struct ScanResultDev {
   IcpResultDev icp;
   double pose[9];
   int reg_error, pushed, no_model, reserved;
-  unsigned long long seq;    // written last, system scope: the host spins on it instead of a stream sync
+  unsigned long long seq;    // the scan's sequence number
 };
+// On its way to the host the record travels as SCAN_RESULT_WORDS tagged 8-byte words {low half of seq, four bytes of the record}
+// (scan_post_body): the pinned buffer holds those, the host decodes them into a ScanResultDev of its own once all carry the tag.
+constexpr int SCAN_RESULT_WORDS = (int)(sizeof(ScanResultDev) / 4);
+static_assert(sizeof(ScanResultDev) % 8 == 0 && SCAN_RESULT_WORDS <= 64, "ScanResultDev: one store instruction of one wave");
 
 // gates of ThreadLocalize (ThreadLocalize.cpp:593-600, :728-736; ThreadLocalize.h:63-64)
 struct GateArgs {
@@ -280,8 +284,9 @@ struct tsd_sensor {
   const double* st_h_ranges = nullptr; const uint8_t* st_h_mask = nullptr;   // the staged scan's ranges / mask in h_scan3 (device addresses)
   bool st_device_done = false;     // the staged scan's device copy and tables are enqueued
   int scan_slot = 0;
-  tsd::ScanResultDev* h_result = nullptr;   // pinned, coherent, written by k_scan_post directly
-  tsd::ScanResultDev* d_result = nullptr;   // device address of h_result
+  tsd::ScanResultDev* h_result = nullptr;   // the last record that arrived, decoded (ordinary host memory)
+  unsigned long long* h_rwords = nullptr;   // pinned, coherent: SCAN_RESULT_WORDS tagged words, written by the registration's epilogue
+  tsd::ScanResultDev* d_result = nullptr;   // device address of h_rwords (ScanPostArgs::out)
   unsigned long long seq = 0;
   double pos[2] = {0, 0};          // host mirror of the sensor position (window of the push launches)
   // tsd_scan_stage / _submit / _collect: the scan that is staged (copied, tables built) and not yet submitted

@@ -39,7 +39,7 @@ for k in range(n):
         continue
     tr = np.zeros((512, 8)); dg.lib.tsd_icp_trace(dg.h, tr.ctypes.data_as(capi._dp), 512)
     tl = tr.reshape(-1)[256 * 8: 256 * 8 + 30 * 16].reshape(30, 16)
-    ph = tr.reshape(-1)[(256 + 192) * 8: (256 + 192) * 8 + 4].copy()
+    ph = tr.reshape(-1)[(256 + 192) * 8: (256 + 192) * 8 + 16].copy()
     steps = np.diff(tl[:, 0]).astype(int)
     srch = [i for i in range(30) if tl[i, 13] > tl[i, 4]]
     ws = tr.reshape(-1)[(256 + 128) * 8: (256 + 128) * 8 + 30 * 8].reshape(30, 8)
@@ -54,7 +54,9 @@ for k in range(n):
 us = np.array([r["us"] for r in rows])
 print(f"{len(rows)} registrations: mean {us.mean():.1f} us, p50 {np.median(us):.1f}, p90 {np.percentile(us, 90):.1f}, p99 {np.percentile(us, 99):.1f}, max {us.max():.1f}")
 phs = np.array([r["ph"] for r in rows])
-print("whole-kernel phases, mean cycles (thread 0): entry -> set-up done %d | wait for the helpers' granules %d | the 30 steps %d | epilogue %d" % tuple(phs.mean(axis=0)))
+print("whole-kernel phases, mean cycles (thread 0): entry -> set-up done %d | wait for the helpers' granules %d | the 30 steps %d | epilogue %d" % tuple(phs.mean(axis=0)[:4]))
+print("   set-up in parts: entry -> inputs arrived %d | -> compacted into LDS (2 barriers) %d | -> scene in registers, directions, padding %d | -> slots cleared, 2 barriers %d" % tuple(phs.mean(axis=0)[4:8]))
+print("   epilogue in parts: loop end -> trace dump, result %d | gate (atan2, sin) %d | wave 0's rays turned %d | barrier (all rays, pose bookkeeping) %d | record composed, stores issued %d | drained %d | sequence number, end %d" % tuple(phs.mean(axis=0)[8:15]))
 steady = np.array([np.median(r["steps"][18:]) for r in rows])
 print(f"steady step (median of steps 18..28): mean {steady.mean():.0f} cycles; sum of steps mean {np.mean([r['steps'].sum() for r in rows]):.0f}")
 print(f"search steps per registration: mean {np.mean([len(r['srch']) for r in rows]):.1f}, max {max(len(r['srch']) for r in rows)}")
