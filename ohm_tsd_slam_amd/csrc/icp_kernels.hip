@@ -226,6 +226,7 @@ constexpr int WIN = 2 * HW + 1;
 constexpr int WIN_ROUNDS = 6;
 constexpr double WIN_REACH = 0.03;               // sin^2 of ~10 degrees: about the widest arc the window grows to at 0.25 degree per slot
 constexpr int LIST_PAST_WINDOW = 1 << 30;         // work-list entry: the tier-1 window was already tried
+constexpr double LB_WINDOW_TRIED = -2.0;          // a point's bound: unknown (<= 0), and a helper's window search has already failed for it
 static_assert(ICP_PAD >= HW + WIN_ROUNDS * WIN, "padding must cover the widest window");
 __device__ __forceinline__ int wrap_slot(int k, int nM)
 {
@@ -875,9 +876,13 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
 #pragma unroll
     for (int q = 0; q < R; q++) {
       const unsigned kk = (unsigned)g1[q];
-      if (have[q] && got[q] && (kk & 0xFFFFu) != 0xFFFFu) {
-        hint[q] = (int)(kk & 0xFFFFu); hint2[q] = (int)(kk >> 16);
-        lb[q] = (double)__uint_as_float((unsigned)g0[q]) * (1.0 - 1e-6);          // lb_from_sq
+      if (have[q] && got[q]) {
+        if ((kk & 0xFFFFu) != 0xFFFFu) {
+          hint[q] = (int)(kk & 0xFFFFu); hint2[q] = (int)(kk >> 16);
+          lb[q] = (double)__uint_as_float((unsigned)g0[q]) * (1.0 - 1e-6);          // lb_from_sq
+        } else {
+          lb[q] = LB_WINDOW_TRIED;      // the helper's window search -- the one this workgroup would run -- proved nothing: tier 2 directly
+        }
       }
     }
   }
@@ -993,7 +998,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
       for (int q = 0; q < R; q++)
         if (need[q]) {
           ent[q] = atomicAdd(&L.ired[IR_CNT], 1);
-          if (ent[q] < lcap) { L.list_xy[ent[q]] = make_double2(sx[q], sy[q]); L.list_k[ent[q]] = hint[q]; }
+          if (ent[q] < lcap) { L.list_xy[ent[q]] = make_double2(sx[q], sy[q]); L.list_k[ent[q]] = hint[q] | (lb[q] == LB_WINDOW_TRIED ? LIST_PAST_WINDOW : 0); }
         }
 #pragma unroll
       for (int q = 0; q < R; q++) tie |= keep[q] & (was[q] == mine[q]);
@@ -1024,7 +1029,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
           for (int q = 0; q < R; q++)
             if (need[q] && ent[q] >= base && ent[q] < base + lcap) {
               L.list_xy[ent[q] - base] = make_double2(sx[q], sy[q]);
-              L.list_k[ent[q] - base] = hint[q];
+              L.list_k[ent[q] - base] = hint[q] | (lb[q] == LB_WINDOW_TRIED ? LIST_PAST_WINDOW : 0);
             }
           __syncthreads();
         }
