@@ -631,7 +631,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
 #define TL(i) do { if (lane == 0 && iter >= (unsigned)TL_FIRST && iter < (unsigned)(TL_FIRST + TL_STEPS)) \
                      tlbuf[((iter - TL_FIRST) * W + wave) * TL_N + (i)] = clock64(); } while (0)
   const long long tk_entry = clock64();          // (whole-kernel phases: set-up, loop, epilogue -- row TSD_ICP_TRACE_MAX + 192 of the trace)
-  long long tk_loop0 = 0, tk_loop1 = 0, tk_seed = 0, tk_s[4] = {0, 0, 0, 0};
+  long long tk_loop0 = 0, tk_loop1 = 0, tk_seed = 0, tk_s[6] = {0, 0, 0, 0, 0, 0};
 #else
 #define TL(i) do {} while (0)
 #endif
@@ -813,9 +813,17 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
   for (int k = tid; k < cap; k += T) { L.slotD[k] = ~0ull; if (slot_halves == 2) L.slotD[cap + k] = ~0ull; L.slotI[k] = INT_MAX; }
   for (int k = tid; k < ICP_MAXW * 16; k += T) L.red[k] = 0.0;    // (block_totals8 reads the rows of absent waves)
   __syncthreads();                     // staging consumed (it aliases the work list); counters zeroed
-  if (rmaxf > 0.f) atomicMax(&L.ired[IR_RMAX], __float_as_int(rmaxf));   // positive floats order like ints
+#ifdef TSD_ICP_TIMELINE
+  tk_s[3] = clock64();
+#endif
+  // (the wave's maximum first: 512 atomics on one LDS word are 512 turns -- 5 800 cycles of the set-up, tools/icp_tail.sh)
+  for (int o = 32; o; o >>= 1) rmaxf = fmaxf(rmaxf, __shfl_xor(rmaxf, o));
+  if (lane == 0 && rmaxf > 0.f) atomicMax(&L.ired[IR_RMAX], __float_as_int(rmaxf));   // positive floats order like ints
   __syncthreads();
   const double scene_rmax = (double)__int_as_float(L.ired[IR_RMAX]);
+#ifdef TSD_ICP_TIMELINE
+  { double t0 = scene_rmax; asm volatile("" : "+v"(t0)); tk_s[4] = clock64(); }
+#endif
 
   // ---------------------------------------------------------------- iterate
   // loop-invariant scalars: vector registers (the scalar file is the scarce one in this kernel)
@@ -850,6 +858,11 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
 
 #ifdef TSD_ICP_TIMELINE
   tk_seed = clock64();
+  if (lane == 0 && trace && role == 0) {        // every wave's own set-up stamps (rows TSD_ICP_TRACE_MAX + 194 ..)
+    double* pw = trace + TSD_ICP_TRACE_STRIDE * (TSD_ICP_TRACE_MAX + 194 + wave);
+    pw[0] = (double)(tk_s[0] - tk_entry); pw[1] = (double)(tk_s[1] - tk_entry); pw[2] = (double)(tk_s[2] - tk_entry); pw[3] = (double)(tk_seed - tk_entry);
+    pw[4] = (double)(tk_s[3] - tk_entry); pw[5] = (double)(tk_s[4] - tk_entry);
+  }
 #endif
   // step 0's searches, done by the helper workgroups while this one set itself up: every lane re-reads its points' granules until
   // they carry this launch's number (a bounded wait, per wave) and takes neighbour, runner-up and bound from them

@@ -40,6 +40,7 @@ for k in range(n):
     tr = np.zeros((512, 8)); dg.lib.tsd_icp_trace(dg.h, tr.ctypes.data_as(capi._dp), 512)
     tl = tr.reshape(-1)[256 * 8: 256 * 8 + 30 * 16].reshape(30, 16)
     ph = tr.reshape(-1)[(256 + 192) * 8: (256 + 192) * 8 + 16].copy()
+    pw = tr.reshape(-1)[(256 + 194) * 8: (256 + 194) * 8 + 64].reshape(8, 8)[:, :6].copy()
     steps = np.diff(tl[:, 0]).astype(int)
     srch = [i for i in range(30) if tl[i, 13] > tl[i, 4]]
     ws = tr.reshape(-1)[(256 + 128) * 8: (256 + 128) * 8 + 30 * 8].reshape(30, 8)
@@ -48,7 +49,7 @@ for k in range(n):
     if FUSED:
         ws = np.zeros_like(ws)
     rows.append(dict(k=k, us=1e3 * ms / cnt, nM=len(M), nS=len(S), pairs=int(out["pairs"]), steps=steps, srch=srch,
-                     first=int(tl[0, 0]), ph=ph, whole=[int(tl[i, 14] - tl[i, 13]) for i in srch], win=[int(tl[i, 13] - tl[i, 4]) for i in srch],
+                     first=int(tl[0, 0]), ph=ph, pw=pw, whole=[int(tl[i, 14] - tl[i, 13]) for i in srch], win=[int(tl[i, 13] - tl[i, 4]) for i in srch],
                      lists=[int(w[0]) if i in srch else 0 for i, w in enumerate(ws)],
                      rounds=[(int(ws[i][4]), int(ws[i][1])) for i in srch]))
 us = np.array([r["us"] for r in rows])
@@ -57,6 +58,10 @@ phs = np.array([r["ph"] for r in rows])
 print("whole-kernel phases, mean cycles (thread 0): entry -> set-up done %d | wait for the helpers' granules %d | the 30 steps %d | epilogue %d" % tuple(phs.mean(axis=0)[:4]))
 print("   set-up in parts: entry -> inputs arrived %d | -> compacted into LDS (2 barriers) %d | -> scene in registers, directions, padding %d | -> slots cleared, 2 barriers %d" % tuple(phs.mean(axis=0)[4:8]))
 print("   epilogue in parts: loop end -> trace dump, result %d | gate (atan2, sin) %d | wave 0's rays turned %d | barrier (all rays, pose bookkeeping) %d | record composed, stores issued %d | drained %d | sequence number, end %d" % tuple(phs.mean(axis=0)[8:15]))
+pws = np.array([r["pw"] for r in rows]).mean(axis=0)
+print("   set-up per wave (cycles since entry; rows = waves 0..7): inputs arrived | compacted (behind 2 barriers) | scene, directions, padding | set-up done")
+for w in range(8):
+    print("      wave %d: %6d %6d %6d | slots cleared, barrier %6d | rmax known %6d | set-up done %6d" % (w, pws[w][0], pws[w][1], pws[w][2], pws[w][4], pws[w][5], pws[w][3]))
 steady = np.array([np.median(r["steps"][18:]) for r in rows])
 print(f"steady step (median of steps 18..28): mean {steady.mean():.0f} cycles; sum of steps mean {np.mean([r['steps'].sum() for r in rows]):.0f}")
 print(f"search steps per registration: mean {np.mean([len(r['srch']) for r in rows]):.1f}, max {max(len(r['srch']) for r in rows)}")
