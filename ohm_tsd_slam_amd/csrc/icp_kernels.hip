@@ -580,6 +580,28 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
       int* __restrict__ pairs_out = nullptr /* PAIRS: [steps][cap] winning scene index per model slot, preset to -1 */)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // fused mode: every global read of the inputs is issued HERE, first thing, unconditionally and at once (one memory latency instead of
+  // one per dependent step; the launcher guarantees beams <= R * T) -- ahead of the LDS layout and of everything else the waves do on
+  // their way in: the younger wave of a SIMD issues at half rate and used to reach its loads 3 000 cycles after the older one
+  // (tools/icp_tail.sh, "inputs arrived"), and the first barrier of the set-up waits for the last wave's inputs.
+  bool in_fm[R], in_fs[R];
+  double in_rr[R], in_lx[R], in_ly[R];
+  double in_cmx[R], in_cmy[R], in_nnx[R], in_nny[R];       // (plain doubles: an array of double2 stays an alloca -- scratch memory -- in this compiler)
+  if (a.beams > 0) {
+    const int tid0 = threadIdx.x, T0 = FT ? FT : (int)blockDim.x;
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+      const int b = q * T0 + tid0;
+      const int bc = b < a.beams ? b : 0;
+      const uint8_t mm = g_mask_m[bc], ms = g_mask[bc];
+      in_rr[q] = g_ranges[bc];
+      { const double2 c2 = *reinterpret_cast<const double2*>(g_coords + 2 * (size_t)bc); in_cmx[q] = c2.x; in_cmy[q] = c2.y; }
+      in_lx[q] = g_rays_local[bc]; in_ly[q] = g_rays_local[a.beams + bc];
+      { const double2 n2 = PTL ? *reinterpret_cast<const double2*>(g_normals + 2 * (size_t)bc) : make_double2(0.0, 0.0); in_nnx[q] = n2.x; in_nny[q] = n2.y; }
+      in_fm[q] = (b < a.beams) && mm != 0;
+      in_fs[q] = (b < a.beams) && !isinf(in_rr[q]) && ms != 0;
+    }
+  }
   IcpLds L;
   // (FCAP / FT: the capacity and thread count as compile-time constants -- the LDS layout's offsets then cost no scalar registers)
   const int cap = FCAP ? FCAP : cap_rt;
@@ -643,25 +665,11 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
 
   // ---------------------------------------------------------------- inputs
   if (a.beams > 0) {
-    // fused mode: maskMatrix compaction of the ray-cast model and of the scan's cartesian points.
+    // fused mode: maskMatrix compaction of the ray-cast model and of the scan's cartesian points (read at the top of the function).
     // Model points stay in beam order = angular order about the sensor.
-    // Every global read of the kernel is issued here, unconditionally and at once (one memory latency
-    // instead of one per dependent step); the launcher guarantees beams <= R * T.
-    bool fm[R], fs[R];
-    double rr[R], lx[R], ly[R];
-    double cmx[R], cmy[R], nnx[R], nny[R];       // (plain doubles: an array of double2 stays an alloca -- scratch memory -- in this compiler)
-#pragma unroll
-    for (int q = 0; q < R; q++) {
-      const int b = q * T + tid;
-      const int bc = b < a.beams ? b : 0;
-      const uint8_t mm = g_mask_m[bc], ms = g_mask[bc];
-      rr[q] = g_ranges[bc];
-      { const double2 c2 = *reinterpret_cast<const double2*>(g_coords + 2 * (size_t)bc); cmx[q] = c2.x; cmy[q] = c2.y; }
-      lx[q] = g_rays_local[bc]; ly[q] = g_rays_local[a.beams + bc];
-      { const double2 n2 = L.nxy ? *reinterpret_cast<const double2*>(g_normals + 2 * (size_t)bc) : make_double2(0.0, 0.0); nnx[q] = n2.x; nny[q] = n2.y; }
-      fm[q] = (b < a.beams) && mm != 0;
-      fs[q] = (b < a.beams) && !isinf(rr[q]) && ms != 0;
-    }
+    bool (&fm)[R] = in_fm, (&fs)[R] = in_fs;
+    double (&rr)[R] = in_rr, (&lx)[R] = in_lx, (&ly)[R] = in_ly;
+    double (&cmx)[R] = in_cmx, (&cmy)[R] = in_cmy, (&nnx)[R] = in_nnx, (&nny)[R] = in_nny;
 #ifdef TSD_ICP_TIMELINE
     { double t0 = rr[0] + cmx[0] + lx[0] + (double)fm[0] + (double)fs[0]; asm volatile("" : "+v"(t0)); tk_s[0] = clock64(); }     // inputs arrived
 #endif
