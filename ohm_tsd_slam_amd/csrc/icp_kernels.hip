@@ -580,6 +580,9 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
       int* __restrict__ pairs_out = nullptr /* PAIRS: [steps][cap] winning scene index per model slot, preset to -1 */)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef TSD_ICP_TIMELINE
+  const long long tk_entry = clock64();          // (whole-kernel phases: set-up, loop, epilogue -- row TSD_ICP_TRACE_MAX + 192 of the trace)
+#endif
   // fused mode: every global read of the inputs is issued HERE, first thing, unconditionally and at once (one memory latency instead of
   // one per dependent step; the launcher guarantees beams <= R * T) -- ahead of the LDS layout and of everything else the waves do on
   // their way in: the younger wave of a SIMD issues at half rate and used to reach its loads 3 000 cycles after the older one
@@ -652,7 +655,6 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
   long long* tlbuf = reinterpret_cast<long long*>(smem + icp_lds_bytes_for(cap, (FT ? FT : (int)blockDim.x), PTL));       // [TL_STEPS][W][TL_N], behind the kernel's own LDS
 #define TL(i) do { if (lane == 0 && iter >= (unsigned)TL_FIRST && iter < (unsigned)(TL_FIRST + TL_STEPS)) \
                      tlbuf[((iter - TL_FIRST) * W + wave) * TL_N + (i)] = clock64(); } while (0)
-  const long long tk_entry = clock64();          // (whole-kernel phases: set-up, loop, epilogue -- row TSD_ICP_TRACE_MAX + 192 of the trace)
   long long tk_loop0 = 0, tk_loop1 = 0, tk_seed = 0, tk_s[6] = {0, 0, 0, 0, 0, 0};
 #else
 #define TL(i) do {} while (0)
