@@ -2,11 +2,59 @@
 // stream order, sensor state on the device), its split form for several robots on one grid (tsd_scan_begin / _wait / _finish) and the
 // batched form (tsd_batch_*: one launch of each kernel for the robots of a batch).
 #include "capi_internal.hpp"
+#include <csetjmp>
+#include <csignal>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 using namespace tsd;
 
 extern "C" {
 // ---------------------------------------------------------------------------------- fused scan path
+// Can this process store into fine-grained device memory of `device` through the PCIe BAR?  Asked once per device: the attribute, an
+// allocation, and ONE guarded store (a fault -- no mapping after all -- is caught and means "no").  TSD_SCAN_PINNED=1 says no.
+static sigjmp_buf g_bar_probe_jmp;
+static void bar_probe_fault(int) { siglongjmp(g_bar_probe_jmp, 1); }
+static bool host_writes_device_memory(tsd_ctx* ctx)
+{
+  const int device = ctx->device;
+  static std::mutex mu;
+  static int known[64];                          // 0: not asked, 1: yes, 2: no
+  std::lock_guard<std::mutex> lk(mu);
+  if (device < 0 || device >= 64) return false;
+  if (known[device]) return known[device] == 1;
+  known[device] = 2;
+#if defined(__x86_64__)
+  if (const char* e = std::getenv("TSD_SCAN_PINNED")) if (*e == '1') return false;
+  int large_bar = 0;
+  if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) != hipSuccess || !large_bar) { (void)hipGetLastError(); return false; }
+  volatile unsigned long long* p = nullptr;
+  if (hipExtMallocWithFlags((void**)&p, 4096, hipDeviceMallocFinegrained) != hipSuccess || !p) { (void)hipGetLastError(); return false; }
+  struct sigaction sa, old_segv, old_bus;
+  std::memset(&sa, 0, sizeof(sa));
+  sa.sa_handler = bar_probe_fault;
+  sigemptyset(&sa.sa_mask);
+  sigaction(SIGSEGV, &sa, &old_segv); sigaction(SIGBUS, &sa, &old_bus);
+  bool ok = false;
+  if (!sigsetjmp(g_bar_probe_jmp, 1)) { p[0] = 0x5ca9ull; p[511] = 0x5ca9ull; _mm_sfence(); ok = true; }
+  sigaction(SIGSEGV, &old_segv, nullptr); sigaction(SIGBUS, &old_bus, nullptr);
+  if (ok) {                                       // ... and the device sees what was stored
+    unsigned long long back[2] = {0, 0};
+    // (through the context's own stream: see the note on the NULL stream in capi.hip)
+    ok = hipMemcpyAsync(&back[0], const_cast<unsigned long long*>(p), 8, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+         hipMemcpyAsync(&back[1], const_cast<unsigned long long*>(p) + 511, 8, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+         hipStreamSynchronize(ctx->stream) == hipSuccess && back[0] == 0x5ca9ull && back[1] == 0x5ca9ull;
+    (void)hipGetLastError();
+  }
+  (void)hipFree(const_cast<unsigned long long*>(p));
+  if (ok) known[device] = 1;
+  return ok;
+#else
+  return false;
+#endif
+}
+
 tsd_sensor* tsd_sensor_create(tsd_ctx* ctx, int beams, double ang_res, double phi_min, double max_range,
                               double min_range, double low_refl_range)
 {
@@ -22,7 +70,13 @@ tsd_sensor* tsd_sensor_create(tsd_ctx* ctx, int beams, double ang_res, double ph
   A(hipMalloc(&s->d_state, sizeof(SensorDev)));
   A(hipMalloc(&s->d_rays, nb * 16));
   A(hipMalloc(&s->d_rays_local, nb * 16));
-  for (int i = 0; i < 3; i++) A(hipMalloc(&s->d_scan2[i], nb * 10 + 64));
+  if (host_writes_device_memory(ctx)) {
+    s->scan_bar = true;
+    for (int i = 0; i < 3; i++)
+      if (hipExtMallocWithFlags((void**)&s->d_scan2[i], nb * 10 + 64, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); s->scan_bar = false; }
+    if (!s->scan_bar) for (int i = 0; i < 3; i++) { if (s->d_scan2[i]) hipFree(s->d_scan2[i]); s->d_scan2[i] = nullptr; }
+  }
+  if (!s->scan_bar) for (int i = 0; i < 3; i++) A(hipMalloc(&s->d_scan2[i], nb * 10 + 64));
   for (int i = 0; i < 3; i++) {
     A(hipHostMalloc(&s->h_scan3[i], nb * 10 + 64, hipHostMallocMapped));
     if (ok) A(hipHostGetDevicePointer((void**)&s->hd_scan3[i], s->h_scan3[i], 0));
@@ -148,18 +202,23 @@ static int scan_stage_host(tsd_sensor* s, const double* ranges, const uint8_t* m
   const int sslot = s->stage_slot;
   s->stage_slot = (s->stage_slot + 1) % 3;
   if (s->scan_copy_valid[sslot]) { TSD_HIP_CHECK(ctx, hipEventSynchronize(s->ev_scan_copy[sslot])); s->scan_copy_valid[sslot] = false; }
+  // (the host writes the device buffer itself: with asynchronous mapping the push that last read it has to be SEEN done first)
+  if (s->scan_bar && s->slot_push_valid[sslot]) { TSD_HIP_CHECK(ctx, hipEventSynchronize(s->ev_slot_push[sslot])); s->slot_push_valid[sslot] = false; }
   LAP(0);
-  char* h = s->h_scan3[sslot];
+  char* h = s->scan_bar ? s->d_scan2[sslot] : s->h_scan3[sslot];
   std::memcpy(h, ranges, nb * 8);
   std::memcpy(h + nb * 8, mask, nb);
   std::memcpy(h + nb * 9, mask_push ? mask_push : mask, nb);
+#if defined(__x86_64__)
+  if (s->scan_bar) _mm_sfence();              // (write-combined stores: on their way before any launch that reads them)
+#endif
   LAP(1);
   char* d_scan = s->d_scan2[sslot];
   s->st_ranges = reinterpret_cast<const double*>(d_scan);
   s->st_mask = reinterpret_cast<const uint8_t*>(d_scan + nb * 8);
   s->st_mask_push = reinterpret_cast<const uint8_t*>(d_scan + nb * 9);
-  s->st_h_ranges = reinterpret_cast<const double*>(s->hd_scan3[sslot]);
-  s->st_h_mask = reinterpret_cast<const uint8_t*>(s->hd_scan3[sslot] + nb * 8);
+  s->st_h_ranges = s->scan_bar ? s->st_ranges : reinterpret_cast<const double*>(s->hd_scan3[sslot]);
+  s->st_h_mask = s->scan_bar ? s->st_mask : reinterpret_cast<const uint8_t*>(s->hd_scan3[sslot] + nb * 8);
   s->st_rmq = s->d_rmq2[sslot]; s->st_slot = sslot;
   s->st_device_done = false;
   s->staged = true;
@@ -180,12 +239,14 @@ static int scan_stage_device(tsd_sensor* s)
     if (!host_saw_event(s->ev_slot_push[sslot], 0)) TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream2, s->ev_slot_push[sslot], 0));
     else s->slot_push_valid[sslot] = false;
   }
-  TSD_HIP_CHECK(ctx, hipMemcpyAsync(s->d_scan2[sslot], s->h_scan3[sslot], nb * 10, hipMemcpyHostToDevice, ctx->stream2));
-  LAP(2);
-  TSD_HIP_CHECK(ctx, hipEventRecord(s->ev_scan_copy[sslot], ctx->stream2));
-  s->scan_copy_valid[sslot] = true;
-  TSD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_h2d, ctx->stream2));
-  LAP(3);
+  if (!s->scan_bar) {
+    TSD_HIP_CHECK(ctx, hipMemcpyAsync(s->d_scan2[sslot], s->h_scan3[sslot], nb * 10, hipMemcpyHostToDevice, ctx->stream2));
+    LAP(2);
+    TSD_HIP_CHECK(ctx, hipEventRecord(s->ev_scan_copy[sslot], ctx->stream2));
+    s->scan_copy_valid[sslot] = true;
+    TSD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_h2d, ctx->stream2));
+    LAP(3);
+  }
   LaunchTarget tg;
   tg.rmq = s->st_rmq;
   TargetScope scope(ctx, &tg);
@@ -353,7 +414,7 @@ int tsd_scan_submit(tsd_sensor* s, const double* ranges, const uint8_t* mask, co
     rc = scan_stage_device(s);
     if (rc != TSD_OK) return rc;
   } else {
-    if (!host_saw_event(ctx->ev_h2d, staged_ahead ? 2 : 40)) TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_h2d, 0));
+    if (!s->scan_bar && !host_saw_event(ctx->ev_h2d, staged_ahead ? 2 : 40)) TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_h2d, 0));
     rc = launch_icp(ctx, ia, s->d_state->icpP, s->d_rays_local, d_ranges, d_mask, &sp);
     if (rc != TSD_OK) return rc;
   }

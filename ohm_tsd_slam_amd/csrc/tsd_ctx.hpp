@@ -282,6 +282,10 @@ struct tsd_sensor {
   hipEvent_t ev_scan_copy[3] = {nullptr, nullptr, nullptr};   // "the device copy out of h_scan3[i] is done" (before the host rewrites it)
   bool scan_copy_valid[3] = {false, false, false};
   const double* st_h_ranges = nullptr; const uint8_t* st_h_mask = nullptr;   // the staged scan's ranges / mask in h_scan3 (device addresses)
+  // Where the device's memory is mapped into the host's address space (large PCIe BAR: every MI300-class server), d_scan2[] is
+  // fine-grained device memory and the HOST writes a scan straight into it: no pinned copy, no device copy, and the registration reads
+  // its 10 KB from local memory (1 us) instead of over the host link (3.5-4 us at the top of every registration: tools/exp/bar.hip).
+  bool scan_bar = false;
   bool st_device_done = false;     // the staged scan's device copy and tables are enqueued
   int scan_slot = 0;
   tsd::ScanResultDev* h_result = nullptr;   // the last record that arrived, decoded (ordinary host memory)
