@@ -662,8 +662,13 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
 
   // fused scan: the sensor state the epilogue needs (pose, _lastPose) is requested NOW, ahead of the inputs, and parked in LDS once
   // it is there -- its memory round trip rides along with the inputs' instead of opening the epilogue
-  ScanPostPre pre_regs;
-  if (tid == 0 && post.st && role == 0) scan_post_preload(post, &pre_regs);
+  // (one 8-byte word per lane of wave 0, one load instruction: pose, _lastPose, calcAngle(_lastPose) and the flag are the first 20 words
+  // of SensorDev; thread 0 alone used to carry all of it in registers and store it word by word behind the staging barrier, 1 400
+  // cycles that every other wave waited for at the next one)
+  static_assert(offsetof(SensorDev, last_pose) == 72 && offsetof(SensorDev, have_last_pose) == 144 && offsetof(SensorDev, last_angle) == 152, "SensorDev");
+  static_assert(offsetof(ScanPostPre, last) == 72 && offsetof(ScanPostPre, last_angle) == 144 && offsetof(ScanPostPre, have_last) == 152, "ScanPostPre");
+  unsigned long long pre_word = 0ull;
+  if (post.st && role == 0 && tid < 20) pre_word = reinterpret_cast<const unsigned long long*>(post.st)[tid];
 
   // ---------------------------------------------------------------- inputs
   if (a.beams > 0) {
@@ -728,10 +733,14 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
     }
     __syncthreads();
   }
-  if (tid == 0) {
-    L.tail->out = out; L.tail->trace = trace; L.tail->post = post;
-    if (post.st) L.tail->pre = pre_regs;                      // (fused scan: the sensor state the epilogue starts from, requested at the top)
-    L.ired[IR_CNT] = 0; L.ired[IR_RMAX] = 0; L.ired[IR_CNT2] = 0; L.ired[IR_TIE] = 0;
+  if (role == 0) {       // (a helper searches and leaves: it has no tail)
+    if (tid == 0) {
+      L.tail->out = out; L.tail->trace = trace;
+      L.ired[IR_CNT] = 0; L.ired[IR_RMAX] = 0; L.ired[IR_CNT2] = 0; L.ired[IR_TIE] = 0;
+    }
+    if (tid == 64 % T) L.tail->post = post;                  // (another wave's lane: ~30 stores)
+    // fused scan: the sensor state the epilogue starts from, requested at the top (words 18 / 19 change places: see the assertions)
+    if (post.st && tid < 20) reinterpret_cast<unsigned long long*>(&L.tail->pre)[tid < 18 ? tid : 37 - tid] = pre_word;
   }
 
   // rows 0,1 of _Tfinal4x4: [r00 r01 tx ; r10 r11 ty]; (*_Tfinal4x4) = (*Tinit) * I (Icp.cpp:485)
