@@ -96,12 +96,14 @@ __device__ inline void d_lu3_solve(const double A[9], const double b[3], double 
 // ThreadLocalize::calcAngle (ThreadLocalize.cpp:715-726)
 __device__ __forceinline__ double d_calc_angle(const double T[9])
 {
+  // The reference takes asin(T[3]) and asin(T[1]) and looks at their SIGNS only: asin(x) > 0 <=> 0 < x <= 1, asin(x) < 0 <=> -1 <= x < 0
+  // (NaN beyond +-1 compares false either way).  The two libm calls were two thirds of the pose bookkeeping's chain in the epilogue.
   double angle = 0.0;
-  const double ARCSIN = asin(T[3]);
-  const double ARCSINEG = asin(T[1]);
-  const double ARCOS = acos(T[0]);
-  if ((ARCSIN > 0.0) && (ARCSINEG < 0.0)) angle = ARCOS;
-  else if ((ARCSIN < 0.0) && (ARCSINEG > 0.0)) angle = 2.0 * M_PI - ARCOS;
+  const double t3 = T[3], t1 = T[1];
+  const bool sin_pos = t3 > 0.0 && t3 <= 1.0, sin_neg = t3 < 0.0 && t3 >= -1.0;
+  const bool neg_pos = t1 > 0.0 && t1 <= 1.0, neg_neg = t1 < 0.0 && t1 >= -1.0;
+  if (sin_pos && neg_neg) angle = acos(T[0]);
+  else if (sin_neg && neg_pos) angle = 2.0 * M_PI - acos(T[0]);
   return angle;
 }
 
@@ -185,12 +187,24 @@ __device__ inline void scan_post_body(const ScanPostArgs& sp, const ScanPostPre&
     double* rays = sp.rays;
     const int beams = sp.beams;
     const int nthr = W >= 3 ? (W - 2) * 64 : (int)blockDim.x;
-    for (int i = threadIdx.x; i < beams; i += nthr) {
-      const double x = rays[i], y = rays[beams + i];
-      double nx = 0.0, ny = 0.0;
-      nx += T[0] * x; nx += T[1] * y;
-      ny += T[3] * x; ny += T[4] * y;
-      rays[i] = nx; rays[beams + i] = ny;
+    // (three beams per thread and round with all six reads in flight: one trip to memory where the one-beam loop took three)
+    constexpr int U = 3;
+    for (int i0 = threadIdx.x; i0 < beams; i0 += U * nthr) {
+      double x[U], y[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int i = i0 + u * nthr;
+        x[u] = i < beams ? rays[i] : 0.0; y[u] = i < beams ? rays[beams + i] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int i = i0 + u * nthr;
+        if (i >= beams) continue;
+        double nx = 0.0, ny = 0.0;
+        nx += T[0] * x[u]; nx += T[1] * y[u];
+        ny += T[3] * x[u]; ny += T[4] * y[u];
+        rays[i] = nx; rays[beams + i] = ny;
+      }
     }
   }
   double cur[9];
