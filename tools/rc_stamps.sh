@@ -22,7 +22,7 @@ for rep in range(2):
     cd, nd, md, cnt = dg.raycast(pose, rw, H.MIN_RANGE, H.MAX_RANGE)
     ms, n = dg.profile_get("raycast")
     tr = np.zeros((256, 8)); dg.lib.tsd_icp_trace(dg.h, tr.ctypes.data_as(capi._dp), 256)
-    d = tr.reshape(128, 8)
+    d = tr[:128]
     names = ["clip+coarse", "segments", "cand blocks", "blocks looked at", "march", "normal", "serial", "total"]
     print("kernel us %.1f hits %d" % (1e3 * ms / max(n, 1), cnt), "avg cycles over 128 sampled beams:",
           {nm: "%.0f" % d[:, i].mean() for i, nm in enumerate(names)}, "max total %.0f" % d[:, 7].max())
