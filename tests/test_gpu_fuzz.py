@@ -27,6 +27,18 @@ def test_randomised_facade_closed_loop_short():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tool,args", [("fuzz_slam.py", ["20", "5151"]), ("fuzz_async.py", ["15", "6161"])])
+def test_scan_through_pinned_memory_when_the_bar_is_not_mapped(tool, args):
+    """The fall-back of the scan's way to the device (TSD_SCAN_PINNED=1: pinned host buffer read by the registration over the host link,
+    device copy on the side stream) instead of the host's stores into device memory through the PCIe BAR -- the same closed loops,
+    look-ahead kept / replaced / absent, asynchronous mapping with a lagging push stream."""
+    env = dict(os.environ, TSD_SCAN_PINNED="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool)] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "all %s cases ok" % args[0] in p.stdout
+
+
+@pytest.mark.gpu
 def test_randomised_async_mapping_short():
     """tools/fuzz_async.py: asynchronous mapping through the staged scan with random staging (kept / replaced / absent) and a push stream
     held back by up to 3 ms per push, against the one-push-behind order on the oracle's primitives."""
