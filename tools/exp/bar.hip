@@ -6,6 +6,7 @@
 #include <csignal>
 #include <csetjmp>
 #include <immintrin.h>
+#include <ctime>
 static sigjmp_buf g_jmp;
 static void on_segv(int) { siglongjmp(g_jmp, 1); }
 __global__ void k(const double* __restrict__ src, int n, double* out, long long* cyc)
@@ -46,11 +47,14 @@ int main()
       // the host rewrites the buffer right before the launch, like a scan that has just arrived
       for (int i = 0; i < n; i++) h[i] = i * 0.5 + rep;
       double w = 0; for (int i = 0; i < n; i++) w += h[i];
+      timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0);
       if (x.p == pinned_dev) memcpy(pinned, h, n * 8); else { memcpy((void*)x.p, h, n * 8); _mm_sfence(); }
+      clock_gettime(CLOCK_MONOTONIC, &t1);
+      const double host_us = (t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3;
       (void)hipMemsetAsync(out, 0, 8, 0);
       hipLaunchKernelGGL(k, dim3(1), dim3(512), 0, 0, x.p, n, out, cyc);
       double got; long long c; (void)hipMemcpy(&got, out, 8, hipMemcpyDeviceToHost); (void)hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
-      printf("rep %d  %-36s kernel-side read of 10.8 KB: %6lld cycles; sum %s\n", rep, x.name, c, got == w ? "right" : "WRONG");
+      printf("rep %d  %-36s host-side store of 10.8 KB %6.2f us; kernel-side read: %6lld cycles; sum %s\n", rep, x.name, host_us, c, got == w ? "right" : "WRONG");
     }
   return 0;
 }
