@@ -316,6 +316,8 @@ struct tsd_sensor {
   tsd::PushArgs* d_push_slot = nullptr;          // [2] push arguments by scan parity (asynchronous mapping)
   hipEvent_t ev_pre = nullptr;              // the pre-registration's inputs are on the device (copied on the side stream by tsd_scan_preregister)
   bool pre_copied = false;
+  bool pre_bar = false;       // d_pre is fine-grained device memory (tsd_sensor::scan_bar) ...
+  bool pre_direct = false;    // ... and the armed inputs were stored into it by the host: nothing to copy, nothing to wait for
   bool pre_armed = false, pre_ran = false;
   struct PreLayout {
     size_t off_S, off_ms, off_msp, off_dc, off_dt, in_bytes;             // inputs (host -> device each scan)

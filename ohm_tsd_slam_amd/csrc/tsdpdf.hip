@@ -23,6 +23,9 @@
 // reference does.  With given draws the result is a function of the inputs and is parity-tested against the oracle's
 // restatement (PARITY UNPINNED: the reference's translation unit needs GSL and cannot be compiled in this image).
 #include "tsd_ctx.hpp"
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include <algorithm>
 #include <chrono>
@@ -908,7 +911,10 @@ extern "C" int tsd_scan_preregister(tsd_sensor* s, const tsd_tsdpdf_params* prm,
     if (s->d_pre) hipFree(s->d_pre);
     if (s->h_pre) hipHostFree(s->h_pre);
     s->d_pre = nullptr; s->h_pre = nullptr; s->pre_bytes = 0;
-    TSD_HIP_CHECK(ctx, hipMalloc(&s->d_pre, total));
+    s->pre_bar = false;
+    if (s->scan_bar && hipExtMallocWithFlags((void**)&s->d_pre, total, hipDeviceMallocFinegrained) == hipSuccess) s->pre_bar = true;
+    else { (void)hipGetLastError(); s->d_pre = nullptr; }
+    if (!s->pre_bar) TSD_HIP_CHECK(ctx, hipMalloc(&s->d_pre, total));
     TSD_HIP_CHECK(ctx, hipHostMalloc(&s->h_pre, total, hipHostMallocDefault));
     TSD_HIP_CHECK(ctx, hipHostGetDevicePointer(reinterpret_cast<void**>(&s->h_pre_dev), s->h_pre, 0));
     s->pre_bytes = total;
@@ -936,7 +942,17 @@ extern "C" int tsd_scan_preregister(tsd_sensor* s, const tsd_tsdpdf_params* prm,
   // starts) is off the scan's chain.  The previous scan's kernels that read d_pre ran ahead of its registration, which has ended (the
   // scan was collected).  TSD_PRE_COPY_MAIN=1: the copy at tsd_scan_submit, on the main stream (round 3's first form; A/B).
   static const bool copy_main = [] { const char* e = std::getenv("TSD_PRE_COPY_MAIN"); return e && *e == '1'; }();
-  s->pre_copied = false;
+  s->pre_copied = false; s->pre_direct = false;
+  if (s->pre_bar && !inflight && !copy_main) {
+    // the host stores the inputs into the device buffer itself (the previous scan was collected: nothing on the device reads it)
+    std::memcpy(s->d_pre, s->h_pre, L.in_bytes);
+#if defined(__x86_64__)
+    _mm_sfence();
+#endif
+    s->pre_copied = true; s->pre_direct = true;
+    s->pre_armed = true;
+    return TSD_OK;
+  }
   if (copy_main && inflight) return set_error(ctx, TSD_E_ARG, "tsd_scan_preregister ahead of the collect needs the side-stream copy (TSD_PRE_COPY_MAIN is set)", hipSuccess);
   if (!copy_main) {
     if (inflight && s->pre_done_valid) TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream2, s->ev_pre_done, 0));
@@ -992,6 +1008,7 @@ static PreLaunch pre_launch_args(const tsd_sensor* s, const double* d_coords, co
 // by event) or, where that was switched off, here
 static int pre_inputs_ready(tsd_ctx* ctx, tsd_sensor* s, hipStream_t stream)
 {
+  if (s->pre_direct) return TSD_OK;
   if (!s->pre_copied) TSD_HIP_CHECK(ctx, hipMemcpyAsync(s->d_pre, s->h_pre, s->pre.in_bytes, hipMemcpyHostToDevice, stream));
   else if (hipEventQuery(s->ev_pre) != hipSuccess) {
     (void)hipGetLastError();                 // (hipErrorNotReady is sticky as "last error")
