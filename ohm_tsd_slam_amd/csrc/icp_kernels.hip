@@ -1095,7 +1095,16 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
 #else
             if (!(lk & LIST_PAST_WINDOW)) r = window_search(L, nM, s.x, s.y, lk, thr, sgn);
 #endif
-            if (r.resolved) { L.res_d[e] = r.best; L.res_k[e] = r.bk; L.res_k2[e] = r.bk2; L.res_lb[e] = lb_from_sq(r.lbsq); }
+            if (r.resolved) {
+              L.res_d[e] = r.best; L.res_k[e] = r.bk; L.res_k2[e] = r.bk2; L.res_lb[e] = lb_from_sq(r.lbsq);
+              // DistanceFilter + the reciprocal filter's first half for this entry, by the lane that searched: the slot minima are final
+              // behind the barrier that ends the pass, and the owners only read (they used to issue these atomics themselves behind
+              // the results -- one more LDS round trip and one more barrier in every step that searches)
+              if (r.best <= thr) {
+                const unsigned long long mine = (unsigned long long)__double_as_longlong(r.best);
+                if (atomicMin(&slotD[r.bk], mine) == mine) L.ired[IR_TIE] = 1;
+              }
+            }
             else L.list2[atomicAdd(&L.ired[IR_CNT2], 1)] = e;      // tier 2, shared out over all waves below
           }
         }
@@ -1107,7 +1116,13 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
             const int es = L.list2[i];
             const double2 s = L.list_xy[es];
             const NnResult r = wave_search(L, nM, s.x, s.y, L.list_k[es] & ~LIST_PAST_WINDOW, thr, sgn, lane);
-            if (lane == 0) { L.res_d[es] = r.best; L.res_k[es] = r.bk; L.res_k2[es] = r.bk2; L.res_lb[es] = lb_from_sq(r.lbsq); }
+            if (lane == 0) {
+              L.res_d[es] = r.best; L.res_k[es] = r.bk; L.res_k2[es] = r.bk2; L.res_lb[es] = lb_from_sq(r.lbsq);
+              if (r.bk >= 0 && r.best <= thr) {
+                const unsigned long long mine = (unsigned long long)__double_as_longlong(r.best);
+                if (atomicMin(&slotD[r.bk], mine) == mine) L.ired[IR_TIE] = 1;
+              }
+            }
           }
           __syncthreads();
           if (tid == 0) L.ired[IR_CNT2] = 0;
@@ -1121,18 +1136,15 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
             if (k >= 0) {
               bd[q] = L.res_d[e]; hint[q] = k; hint2[q] = L.res_k2[e]; lb[q] = L.res_lb[e];
               mw[q] = L.mxy[k];
-              keep[q] = bd[q] <= thr;                                  // DistanceFilter::filter
-              if (keep[q]) {
-                const unsigned long long mine = (unsigned long long)__double_as_longlong(bd[q]);
-                tie |= atomicMin(&slotD[k], mine) == mine;
-              }
+              keep[q] = bd[q] <= thr;                                  // DistanceFilter::filter (its slot entry: made by the searching lane)
             } else { bd[q] = __builtin_inf(); lb[q] = -1.0; }          // non-finite input point
           }
         if (base + lcap < n_need) __syncthreads();
       }
-      if (tie) L.ired[IR_TIE] = 1;
-      __syncthreads();
-      tie_any = L.ired[IR_TIE];                                    // the searches' pairs went into the slots: read again
+      // (point-to-line: the pair sums' transpose buffer ALIASES the work list -- the results must have been read before the first wave
+      // gets there; the closed form reduces in registers and needs no barrier here)
+      if constexpr (PTL) __syncthreads();
+      tie_any = L.ired[IR_TIE];                                    // the searches' pairs went into the slots (behind the passes' barriers): read again
 #pragma unroll
       for (int q = 0; q < R; q++) sd[q] = slotD[hint[q]];
     }
