@@ -91,7 +91,8 @@ struct IcpLds {
   int* start;                      // first search position of every compacted scene point
 };
 
-__host__ __device__ inline int icp_list_cap(int cap) { return cap < 1024 ? cap : 1024; }
+// (up to the node's shape -- 1081 beams, capacity 1088 -- the list holds every point: one pass, always)
+__host__ __device__ inline int icp_list_cap(int cap) { return cap <= 1088 ? cap : 1024; }
 // bytes of the region shared by the work list (48 B per entry), the setup staging and the transpose buffer
 __host__ __device__ inline size_t icp_region_bytes(int cap, int threads)
 {
@@ -1052,6 +1053,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
       asm volatile("" : "+v"(nn), "+v"(tie_any));                 // (all five reads issued before the first is waited for)
       n_need = nn;
     }
+    if (lcap == cap) __builtin_assume(n_need <= lcap);           // (no more points than capacity: a list that holds them all needs one pass)
     if (n_need > 0) {
       tie = false;
       for (int base = 0; base < n_need; base += lcap) {       // one pass unless more than lcap points search
