@@ -186,10 +186,11 @@ static bool scan_result_arrived(tsd_sensor* s, unsigned long long seq)
   return true;
 }
 
-// A scan comes in two steps.  scan_stage_host: the caller's arrays into the sensor's pinned buffer (the three scan / table buffers are
-// used in turn).  scan_stage_device: the copy into device memory and the range-query tables of this scan's push on the side stream --
-// they only depend on the scan and run while the main stream is busy.  tsd_scan_stage does both at once (a scan announced ahead);
-// tsd_scan_submit with a scan launches the registration between the two (it reads the pinned buffer itself).
+// A scan comes in two steps.  scan_stage_host: the caller's arrays into the sensor's scan buffer -- device memory that the host stores
+// into through the PCIe BAR (tsd_sensor::scan_bar), or a pinned host buffer where that mapping is missing (the three scan / table
+// buffers are used in turn).  scan_stage_device: the range-query tables of this scan's push on the side stream (and, pinned mode, the
+// copy into device memory ahead of them) -- they only depend on the scan and run while the main stream is busy.  tsd_scan_stage does
+// both at once (a scan announced ahead); tsd_scan_submit with a scan launches the registration between the two.
 static int scan_stage_host(tsd_sensor* s, const double* ranges, const uint8_t* mask, const uint8_t* mask_push)
 {
   tsd_ctx* ctx = s->ctx;
@@ -351,8 +352,9 @@ int tsd_scan_submit(tsd_sensor* s, const double* ranges, const uint8_t* mask, co
     if (rcs != TSD_OK) return rcs;
   }
   s->staged = false;
-  // A scan that came with this call is in the pinned buffer and nowhere else yet: its registration reads it from there, and the device
-  // copy + tables are enqueued BEHIND the registration's launch -- the host's work on them no longer sits between the result of the
+  // A scan that came with this call is in the scan buffer (device memory the host stored into, or the pinned buffer) and its tables are
+  // not built yet: its registration reads it from there, and the tables (pinned mode: the device copy first) are enqueued BEHIND the
+  // registration's launch -- the host's work on them no longer sits between the result of the
   // previous scan and this launch (the main stream ran dry for ~10 us per scan there; the push needs them 100+ us from now).
   const bool icp_from_host = !s->st_device_done;
   const double* d_ranges = s->st_ranges;
