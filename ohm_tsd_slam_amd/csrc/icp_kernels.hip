@@ -832,6 +832,15 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
   const int slot_halves = icp_slot_halves(cap, T, PTL);
   for (int k = tid; k < cap; k += T) { L.slotD[k] = ~0ull; if (slot_halves == 2) L.slotD[cap + k] = ~0ull; L.slotI[k] = INT_MAX; }
   for (int k = tid; k < ICP_MAXW * 16; k += T) L.red[k] = 0.0;    // (block_totals8 reads the rows of absent waves)
+  if (role == 0 && !PTL) {
+    // the waves' sums of the scene coordinates (c0 below), parked in the broadcast rows (scratch until the first step)
+    double cen[2] = {0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < R; q++)       // (a NaN, an infinity or an absurd coordinate never finds a partner: it must not poison the centre either)
+      if (have[q] && fabs(sx[q]) < 1e6 && fabs(sy[q]) < 1e6) { cen[0] += sx[q]; cen[1] += sy[q]; }
+#pragma unroll
+    for (int k = 0; k < 2; k++) { const double t = wave_total(cen[k]); if (lane == 0) L.red[(ICP_MAXW + wave) * 16 + k] = t; }
+  }
   __syncthreads();                     // staging consumed (it aliases the work list); counters zeroed
 #ifdef TSD_ICP_TIMELINE
   tk_s[3] = clock64();
@@ -866,7 +875,17 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
     const double lim = ((slack - 2e-6) / (pnorm * (1.0 + 2e-6)) - scene_rmax) * (1.0 - 1e-6);
     if (lim > 0.0) tcum_lim2 = lim * lim * (1.0 - 1e-6);
   }
-  double c0[4] = {0.0, 0.0, 0.0, 0.0};       // centring point of the pair sums: last step's centroids
+  // centring point of the pair sums: last step's centroids; for the first step the centroid of ALL scene points, for the model side
+  // too (model and scene share the frame, and the pairs' own centroids lie within decimetres of it: the correction term below stays as
+  // well conditioned as in every other step, and the first step no longer runs its pair sums twice -- 3 000 cycles of every
+  // registration).  Not the model's own centroid: the order of the model differs between tsd_icp and the fused calls (a rotation of the
+  // beams), the scene's does not, and the two have to agree to the bit (tests/test_gpu_parity.py)
+  double c0[4] = {0.0, 0.0, 0.0, 0.0};
+  if (!PTL) {
+    double t2[2] = {0.0, 0.0};
+    for (int w = 0; w < W; w++) { t2[0] += L.red[(ICP_MAXW + w) * 16]; t2[1] += L.red[(ICP_MAXW + w) * 16 + 1]; }
+    c0[0] = c0[2] = t2[0] / (double)nS; c0[1] = c0[3] = t2[1] / (double)nS;
+  }
 
 #ifdef TSD_ICP_TIMELINE
   const bool has_trace = trace != nullptr && !post.st;
@@ -1187,13 +1206,13 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
     // -- phase D/F: ClosedFormEstimator2D::setPairs + estimateTransformation in ONE pass over the pairs.
     // The reference centres the pairs on their centroids (two passes).  Centring on the previous
     // step's centroids c0 instead and correcting, sum (a-ca)(b-cb) = sum (a-c0a)(b-c0b) - n (ca-c0a)(cb-c0b),
-    // is the same quantity with the same conditioning (c0 is within millimetres of c); the very first
-    // step has no c0 and runs the pass twice, i.e. the reference's two passes.
+    // is the same quantity with the same conditioning (c0 is within millimetres of c; the very first step
+    // centres on the scene's centroid, see c0).
     constexpr bool ptl = PTL;                           // PointToLine2DEstimator instead of ClosedFormEstimator2D
     constexpr bool RED8 = !PTL;                         // closed form: seven sums + the pair count, reduced in registers (block_totals8)
     constexpr int NSUM = PTL ? NSUM_PTL : (RED8 ? 8 : NSUM_CF);
     double tot[NSUM];
-    for (int pass = ((iter == 0 && !ptl) ? 0 : 1); pass < 2; pass++) {
+    {
       double v[NSUM];
 #pragma unroll
       for (int k = 0; k < NSUM; k++) v[k] = 0.0;
@@ -1241,13 +1260,6 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
       if constexpr (RED8) { block_totals8<MAXT / 64>(L, v, tot, lane, wave, tl_row); pairs = (int)tot[7]; }
       else block_totals<MAXT / 64, NSUM>(L, v, cnt, tot, pairs, tid, lane, wave, W, tl_row);
       TL(10);                                  // totals in registers
-      if (pass == 0) {                     // first step only: centroids first, then the centred pass
-        if (pairs > 0) {
-          const double inv0 = 1.0 / (double)pairs;
-          c0[0] = tot[0] * inv0; c0[1] = tot[1] * inv0; c0[2] = tot[2] * inv0; c0[3] = tot[3] * inv0;
-        }
-        __syncthreads();                   // the wave partials are rewritten by the second pass
-      }
     }
     // everybody is past the winner test: give the touched slots back, clear the work list counter
 #pragma unroll
