@@ -61,7 +61,7 @@ constexpr int IR_CNT = 32, IR_RMAX = 33, IR_CNT2 = 34, IR_TIE = 35;   // words o
 // filling the device) simply search in step 0 as they always did; the results are the same either way, only the time differs.
 constexpr int ICP_HELPER_POINTS = 256;              // scene points per helper workgroup: one per lane of its waves 0-3 (one wave per SIMD)
 constexpr int ICP_MAX_HELPERS = 16;
-constexpr long long ICP_SEED_WAIT_TICKS = 600;      // of the 100 MHz wall clock: 6 us
+constexpr long long ICP_SEED_WAIT_TICKS = 2500;     // of the 100 MHz wall clock: 25 us
 
 // what the kernel needs again only after the last step (and the trace pointer, once per step by one
 // thread): parked in LDS so that it does not sit in scalar registers through the loop
@@ -808,21 +808,43 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
     L.mxy[-1 - i] = L.mxy[nM - 1 - (i % nM)];
   }
   if (role > 0) {
-    // helper: step 0's window search for scene points (role - 1) * ICP_HELPER_POINTS + tid, from the staged scene (the registration's
-    // own list pass reads the same coordinates and the same hint from its registers)
+    // helper: step 0's window search for every seed.helpers-th scene point, from the staged scene (the registration's
+    // own list pass reads the same coordinates and the same hint from its registers); what the window cannot prove -- a point far from
+    // the whole model: the scan turned into space the map does not hold yet -- goes to the whole-wave search right here, shared out
+    // over ALL waves of ALL helpers (the registration's own eight waves had them to themselves: 30 000-80 000 cycles of the slowest scans)
+    if (tid == 0) L.ired[IR_CNT2] = 0;
     __syncthreads();                   // unit directions and padding in place
     const int per = T < ICP_HELPER_POINTS ? T : ICP_HELPER_POINTS;
-    const int i = (role - 1) * per + tid;
+    const int i = tid * seed.helpers + (role - 1);       // interleaved: a sector of far points is every helper's in equal parts
+    const unsigned long long tag = (unsigned long long)seed.seq << 32;
+    int* const far_list = L.slotI;     // (a helper pairs nothing: the slot arrays are free)
     if (tid < per && i < nS) {
       const double2 s = L.stage_s[i];
       int h = L.start[i];
       h = h < 0 ? 0 : (h >= nM ? nM - 1 : h);
       const NnResult r = window_search(L, nM, s.x, s.y, h, a.thr0, a.ccw ? 1.0 : -1.0);
-      const unsigned int root = __float_as_uint(__builtin_amdgcn_sqrtf((float)r.lbsq));       // lb_from_sq's fp32 root
-      const unsigned int kk = r.resolved ? ((unsigned)r.bk | ((unsigned)r.bk2 << 16)) : 0xFFFFu;
-      const unsigned long long tag = (unsigned long long)seed.seq << 32;
-      __hip_atomic_store(seed.g + i, tag | root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(seed.g + seed.stride + i, tag | kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (r.resolved) {
+        const unsigned int root = __float_as_uint(__builtin_amdgcn_sqrtf((float)r.lbsq));       // lb_from_sq's fp32 root
+        __hip_atomic_store(seed.g + i, tag | root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(seed.g + seed.stride + i, tag | ((unsigned)r.bk | ((unsigned)r.bk2 << 16)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        far_list[atomicAdd(&L.ired[IR_CNT2], 1)] = i;
+      }
+    }
+    __syncthreads();
+    const int n_far = L.ired[IR_CNT2];
+    for (int e = wave; e < n_far; e += W) {
+      const int j = far_list[e];
+      const double2 s = L.stage_s[j];
+      int h = L.start[j];
+      h = h < 0 ? 0 : (h >= nM ? nM - 1 : h);
+      const NnResult r = wave_search(L, nM, s.x, s.y, h, a.thr0, a.ccw ? 1.0 : -1.0, lane);
+      if (lane == 0) {
+        const unsigned int root = r.bk >= 0 ? __float_as_uint(__builtin_amdgcn_sqrtf((float)r.lbsq)) : 0u;
+        const unsigned int kk = r.bk >= 0 ? ((unsigned)r.bk | ((unsigned)(r.bk2 >= 0 ? r.bk2 : r.bk) << 16)) : 0xFFFFu;     // (a non-finite point stays the registration's)
+        __hip_atomic_store(seed.g + j, tag | root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(seed.g + seed.stride + j, tag | kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     return;
   }
