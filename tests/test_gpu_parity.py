@@ -721,6 +721,8 @@ def test_icp_helpers_change_nothing(oracle):
         R = np.array([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]])
         S = S @ R.T + rng.uniform(-0.05, 0.05, 2)
         S[:: 7] += rng.uniform(0.3, 0.8, (len(S[:: 7]), 2))    # far from the model: whole-wave searches
+        if n >= 1081:
+            S[n // 3: n // 3 + n // 5] += (1.5, 0.7)           # a whole sector of them (a scan that turns into unseen space): the helpers' sweeps
         cases.append((M, S))
     xs, ys = np.meshgrid(np.arange(-2.0, 2.01, 0.25), np.arange(-1.5, 1.51, 0.25))
     L = np.stack([xs.ravel(), ys.ravel()], axis=1)
