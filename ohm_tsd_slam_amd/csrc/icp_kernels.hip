@@ -1230,7 +1230,6 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
     // step's centroids c0 instead and correcting, sum (a-ca)(b-cb) = sum (a-c0a)(b-c0b) - n (ca-c0a)(cb-c0b),
     // is the same quantity with the same conditioning (c0 is within millimetres of c; the very first step
     // centres on the scene's centroid, see c0).
-    constexpr bool ptl = PTL;                           // PointToLine2DEstimator instead of ClosedFormEstimator2D
     constexpr bool RED8 = !PTL;                         // closed form: seven sums + the pair count, reduced in registers (block_totals8)
     constexpr int NSUM = PTL ? NSUM_PTL : (RED8 ? 8 : NSUM_CF);
     double tot[NSUM];
