@@ -91,6 +91,10 @@ typedef struct {
 
 /* ---- life cycle ------------------------------------------------------------------------------ */
 int      tsd_device_count(void);
+/* Free and total memory of `device` in bytes as the HIP runtime this library is linked against reports it (hipMemGetInfo): what a
+ * caller sizes map_size against -- the node accepts up to 2^15 x 2^15 cells (SlamNode.cpp:71-75), 18.8 GB of fp64 cells here.
+ * TSD_E_NODEVICE without such a device. */
+int      tsd_device_memory(int device, uint64_t* free_bytes, uint64_t* total_bytes);
 /* new TsdGrid(cellSize, LAYOUT_32x32, map_size) + setMaxTruncation(max_trunc)
  * (SlamNode.cpp:77-78, TsdGrid.cpp:112-169, :206-215).  NULL on failure. */
 tsd_ctx* tsd_create(int device, int map_size_log2, double cell_size, double max_trunc);

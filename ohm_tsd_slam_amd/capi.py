@@ -120,6 +120,7 @@ _i8p = C.POINTER(C.c_int8)
 _ip = C.POINTER(C.c_int)
 ABI = {
     "tsd_device_count": (C.c_int, []),
+    "tsd_device_memory": (C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "tsd_create": (C.c_void_p, [C.c_int, C.c_int, C.c_double, C.c_double]),
     "tsd_destroy": (None, [C.c_void_p]),
     "tsd_reset": (C.c_int, [C.c_void_p]),
@@ -226,6 +227,16 @@ def load_library(path: str | None = None):
     if path is None:
         _lib = lib
     return lib
+
+
+def device_memory(device: int = 0):
+    """(free, total) bytes of `device` as the product's own HIP runtime reports them (tsd_device_memory)."""
+    lib = load_library()
+    f, t = C.c_uint64(0), C.c_uint64(0)
+    rc = lib.tsd_device_memory(device, C.byref(f), C.byref(t))
+    if rc != 0:
+        raise TsdError(f"tsd_device_memory({device}) failed ({rc})")
+    return f.value, t.value
 
 
 def _d(a):

@@ -297,6 +297,21 @@ int tsd_device_count(void)
   return n;
 }
 
+int tsd_device_memory(int device, uint64_t* free_bytes, uint64_t* total_bytes)
+{
+  if (!free_bytes || !total_bytes) return TSD_E_ARG;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) { (void)hipGetLastError(); return TSD_E_NODEVICE; }
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  size_t f = 0, t = 0;
+  const bool ok = hipSetDevice(device) == hipSuccess && hipMemGetInfo(&f, &t) == hipSuccess;
+  (void)hipSetDevice(prev);
+  if (!ok) { (void)hipGetLastError(); return TSD_E_HIP; }
+  *free_bytes = (uint64_t)f; *total_bytes = (uint64_t)t;
+  return TSD_OK;
+}
+
 tsd_ctx* tsd_create(int device, int map_size_log2, double cell_size, double max_trunc)
 {
   if (map_size_log2 < 5 || map_size_log2 > 15 || !(cell_size > 0.0)) return nullptr;

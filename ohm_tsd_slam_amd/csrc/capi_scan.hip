@@ -2,8 +2,6 @@
 // stream order, sensor state on the device), its split form for several robots on one grid (tsd_scan_begin / _wait / _finish) and the
 // batched form (tsd_batch_*: one launch of each kernel for the robots of a batch).
 #include "capi_internal.hpp"
-#include <csetjmp>
-#include <csignal>
 #if defined(__x86_64__)
 #include <immintrin.h>
 #endif
@@ -12,10 +10,31 @@ using namespace tsd;
 
 extern "C" {
 // ---------------------------------------------------------------------------------- fused scan path
-// Can this process store into fine-grained device memory of `device` through the PCIe BAR?  Asked once per device: the attribute, an
-// allocation, and ONE guarded store (a fault -- no mapping after all -- is caught and means "no").  TSD_SCAN_PINNED=1 says no.
-static sigjmp_buf g_bar_probe_jmp;
-static void bar_probe_fault(int) { siglongjmp(g_bar_probe_jmp, 1); }
+// Can this process store into fine-grained device memory of `device` through the PCIe BAR, and does a kernel launched right behind the
+// stores read them?  Asked once per device, without provoking a fault: hipDeviceAttributeIsLargeBar is the runtime's own answer to "may
+// the host access this agent's local memory pool" (what HSA's pool-access query says for the CPU agent), and the pointer attributes of
+// the allocation must name it device memory of this device.  What remains is whether the ACCESS PATTERN of the scan path works here --
+// a kernel reads the buffer, the host rewrites it with plain memcpy + sfence, the next kernel (launched at once, nothing drained in
+// between) must read the new contents: a stale L2 line or a write-combined store that lands behind the launch would show as an old
+// word.  That pattern is run for several rounds on the context's own stream (the stream the registrations run on) and on the side
+// stream (the tables'), over a whole buffer of a scan's size.  TSD_SCAN_PINNED=1 says no without asking.
+static __global__ void k_bar_probe(const unsigned long long* __restrict__ buf, unsigned long long* __restrict__ out, int n)
+{
+  for (int i = threadIdx.x + blockIdx.x * blockDim.x; i < n; i += blockDim.x * gridDim.x) out[i] = buf[i];
+}
+// TSD_SCAN_BAR_VERIFY=1 (debug): every scan is ALSO written to the pinned buffer, and ahead of its registration this kernel compares
+// the two copies as the device sees them; a difference is reported by tsd_scan_collect as TSD_E_HIP instead of becoming a wrong pose.
+static __global__ void k_bar_verify(const unsigned char* __restrict__ bar, const unsigned char* __restrict__ pinned, int n, unsigned int* __restrict__ mismatches)
+{
+  unsigned int bad = 0;
+  for (int i = threadIdx.x + blockIdx.x * blockDim.x; i < n; i += blockDim.x * gridDim.x) bad += bar[i] != pinned[i];
+  if (bad) atomicAdd_system(mismatches, bad);
+}
+static bool bar_verify_requested()
+{
+  static const bool on = [] { const char* e = std::getenv("TSD_SCAN_BAR_VERIFY"); return e && *e == '1'; }();
+  return on;
+}
 static bool host_writes_device_memory(tsd_ctx* ctx)
 {
   const int device = ctx->device;
@@ -29,25 +48,29 @@ static bool host_writes_device_memory(tsd_ctx* ctx)
   if (const char* e = std::getenv("TSD_SCAN_PINNED")) if (*e == '1') return false;
   int large_bar = 0;
   if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) != hipSuccess || !large_bar) { (void)hipGetLastError(); return false; }
-  volatile unsigned long long* p = nullptr;
-  if (hipExtMallocWithFlags((void**)&p, 4096, hipDeviceMallocFinegrained) != hipSuccess || !p) { (void)hipGetLastError(); return false; }
-  struct sigaction sa, old_segv, old_bus;
-  std::memset(&sa, 0, sizeof(sa));
-  sa.sa_handler = bar_probe_fault;
-  sigemptyset(&sa.sa_mask);
-  sigaction(SIGSEGV, &sa, &old_segv); sigaction(SIGBUS, &sa, &old_bus);
-  bool ok = false;
-  if (!sigsetjmp(g_bar_probe_jmp, 1)) { p[0] = 0x5ca9ull; p[511] = 0x5ca9ull; _mm_sfence(); ok = true; }
-  sigaction(SIGSEGV, &old_segv, nullptr); sigaction(SIGBUS, &old_bus, nullptr);
-  if (ok) {                                       // ... and the device sees what was stored
-    unsigned long long back[2] = {0, 0};
-    // (through the context's own stream: see the note on the NULL stream in capi.hip)
-    ok = hipMemcpyAsync(&back[0], const_cast<unsigned long long*>(p), 8, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
-         hipMemcpyAsync(&back[1], const_cast<unsigned long long*>(p) + 511, 8, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
-         hipStreamSynchronize(ctx->stream) == hipSuccess && back[0] == 0x5ca9ull && back[1] == 0x5ca9ull;
-    (void)hipGetLastError();
+  constexpr int kWords = (TSD_MAX_BEAMS * 10 + 64 + 7) / 8;      // a scan buffer's size
+  constexpr int kRounds = 6;
+  unsigned long long* p = nullptr;
+  unsigned long long* d_out = nullptr;
+  std::vector<unsigned long long> src(kWords), back(kWords);
+  bool ok = hipExtMallocWithFlags((void**)&p, kWords * 8, hipDeviceMallocFinegrained) == hipSuccess && p;
+  hipPointerAttribute_t at;
+  std::memset(&at, 0, sizeof(at));
+  ok = ok && hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeDevice && at.device == device;
+  ok = ok && hipMalloc((void**)&d_out, kWords * 8) == hipSuccess;
+  for (int r = 0; ok && r < kRounds; r++) {
+    hipStream_t st = (r & 1) && ctx->stream2 ? ctx->stream2 : ctx->stream;
+    for (int i = 0; i < kWords; i++) src[i] = 0x9E3779B97F4A7C15ull * (unsigned long long)(r * kWords + i + 1);
+    std::memcpy(p, src.data(), (size_t)kWords * 8);               // (what scan_stage_host does)
+    _mm_sfence();
+    hipLaunchKernelGGL(k_bar_probe, dim3(4), dim3(256), 0, st, p, d_out, kWords);
+    ok = hipGetLastError() == hipSuccess &&
+         hipMemcpyAsync(back.data(), d_out, (size_t)kWords * 8, hipMemcpyDeviceToHost, st) == hipSuccess &&
+         hipStreamSynchronize(st) == hipSuccess && std::memcmp(back.data(), src.data(), (size_t)kWords * 8) == 0;
   }
-  (void)hipFree(const_cast<unsigned long long*>(p));
+  (void)hipGetLastError();
+  if (p) (void)hipFree(p);
+  if (d_out) (void)hipFree(d_out);
   if (ok) known[device] = 1;
   return ok;
 #else
@@ -75,6 +98,10 @@ tsd_sensor* tsd_sensor_create(tsd_ctx* ctx, int beams, double ang_res, double ph
     for (int i = 0; i < 3; i++)
       if (hipExtMallocWithFlags((void**)&s->d_scan2[i], nb * 10 + 64, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); s->scan_bar = false; }
     if (!s->scan_bar) for (int i = 0; i < 3; i++) { if (s->d_scan2[i]) hipFree(s->d_scan2[i]); s->d_scan2[i] = nullptr; }
+    if (s->scan_bar && bar_verify_requested()) {
+      A(hipHostMalloc((void**)&s->h_bar_mismatch, 64, hipHostMallocMapped | hipHostMallocCoherent));
+      if (ok) { *s->h_bar_mismatch = 0; A(hipHostGetDevicePointer((void**)&s->d_bar_mismatch, s->h_bar_mismatch, 0)); }
+    }
   }
   if (!s->scan_bar) for (int i = 0; i < 3; i++) A(hipMalloc(&s->d_scan2[i], nb * 10 + 64));
   for (int i = 0; i < 3; i++) {
@@ -123,6 +150,7 @@ void tsd_sensor_destroy(tsd_sensor* s)
   if (s->h_stage2[1]) hipHostFree(s->h_stage2[1]);
   hipFree(s->d_state); hipFree(s->d_rays); hipFree(s->d_rays_local); hipFree(s->d_scan2[0]); hipFree(s->d_scan2[1]); hipFree(s->d_scan2[2]);
   hipHostFree(s->h_rwords); delete s->h_result;
+  if (s->h_bar_mismatch) hipHostFree(s->h_bar_mismatch);
   delete s;
 }
 
@@ -213,6 +241,11 @@ static int scan_stage_host(tsd_sensor* s, const double* ranges, const uint8_t* m
 #if defined(__x86_64__)
   if (s->scan_bar) _mm_sfence();              // (write-combined stores: on their way before any launch that reads them)
 #endif
+  if (s->d_bar_mismatch) {                    // (debug: the pinned copy the device compares the scan buffer with, launch_bar_verify)
+    std::memcpy(s->h_scan3[sslot], ranges, nb * 8);
+    std::memcpy(s->h_scan3[sslot] + nb * 8, mask, nb);
+    std::memcpy(s->h_scan3[sslot] + nb * 9, mask_push ? mask_push : mask, nb);
+  }
   LAP(1);
   char* d_scan = s->d_scan2[sslot];
   s->st_ranges = reinterpret_cast<const double*>(d_scan);
@@ -345,8 +378,13 @@ int tsd_scan_submit(tsd_sensor* s, const double* ranges, const uint8_t* mask, co
     // A scan staged ahead that is not the one that came is dropped -- and its buffers are REUSED for the scan that did come: the
     // three-buffer rotation is only safe when it advances once per scan (the buffer two rotations back may still be read by the
     // push of the previous scan, which is ordered behind nothing the host has seen).  The new copy and tables follow the dropped
-    // ones on the side stream, and nothing else ever read the dropped data.
-    if (s->staged) s->stage_slot = s->st_slot;
+    // ones on the side stream (pinned mode), and nothing else ever read the dropped data.
+    if (s->staged) {
+      s->stage_slot = s->st_slot;
+      // (BAR mode: the host is about to store into that buffer itself -- the dropped scan's tables kernel on the side stream, which
+      // reads it, has to be SEEN done first; pinned mode orders the new copy behind it on the side stream)
+      if (s->scan_bar && s->st_device_done) TSD_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev_tables));
+    }
     s->staged = false;
     int rcs = scan_stage_host(s, ranges, mask, mask_push);
     if (rcs != TSD_OK) return rcs;
@@ -410,6 +448,11 @@ int tsd_scan_submit(tsd_sensor* s, const double* ranges, const uint8_t* mask, co
   // host waits for the copy itself (a few microseconds, the device is busy meanwhile) instead of putting a
   // cross-stream barrier between the two kernels; the barrier is the fall-back.  (A scan staged ahead was copied
   // during the previous registration: nothing to wait for.)
+  if (s->d_bar_mismatch) {
+    hipLaunchKernelGGL(k_bar_verify, dim3(4), dim3(256), 0, ctx->stream, reinterpret_cast<const unsigned char*>(s->d_scan2[s->st_slot]),
+                       reinterpret_cast<const unsigned char*>(s->hd_scan3[s->st_slot]), (int)((size_t)s->beams * 10), s->d_bar_mismatch);
+    TSD_HIP_CHECK(ctx, hipGetLastError());
+  }
   if (icp_from_host) {
     rc = launch_icp(ctx, ia, s->d_state->icpP, s->d_rays_local, s->st_h_ranges, s->st_h_mask, &sp);
     if (rc != TSD_OK) return rc;
@@ -516,6 +559,9 @@ int tsd_scan_collect(tsd_sensor* s, tsd_scan_result* result)
     }
   }
   lap.lap(6);
+  if (s->h_bar_mismatch && __atomic_load_n(s->h_bar_mismatch, __ATOMIC_ACQUIRE) != 0)
+    return set_error(ctx, TSD_E_HIP, "tsd_scan: the scan the host stored into device memory through the PCIe BAR is not what the device read "
+                                     "(TSD_SCAN_BAR_VERIFY); run with TSD_SCAN_PINNED=1 on this platform", hipSuccess);
   copy_icp_result(&s->h_result->icp, &result->icp);
   for (int i = 0; i < 9; i++) result->pose[i] = s->h_result->pose[i];
   s->pos[0] = result->pose[2]; s->pos[1] = result->pose[5];
@@ -564,7 +610,8 @@ static int sensor_conc_init(tsd_sensor* s, bool own_stream)
   A(hipMalloc(&s->d_coords, nb * 16)); A(hipMalloc(&s->d_normals, nb * 16)); A(hipMalloc(&s->d_mask_m, nb));
   A(hipMalloc(&s->d_icp_res, sizeof(IcpResultDev))); A(hipMalloc(&s->d_icp_trace, sizeof(double) * TSD_ICP_TRACE_STRIDE * TSD_ICP_TRACE_MAX));
   A(hipMalloc(&s->d_icp_seed, icp_seed_bytes(s->beams)));
-  if (ok) A(hipMemset(s->d_icp_seed, 0, icp_seed_bytes(s->beams)));
+  // (through the context's stream and waited for: a plain hipMemset would bring the NULL stream alive, see capi.hip)
+  if (ok) { A(hipMemsetAsync(s->d_icp_seed, 0, icp_seed_bytes(s->beams), ctx->stream)); A(hipStreamSynchronize(ctx->stream)); }
   for (int i = 0; i < 3; i++) A(hipMalloc(&s->d_rmq2[i], push_rmq_bytes(s->beams)));
   A(hipHostMalloc(&s->h_stage2[0], nb * 10 + 64, hipHostMallocDefault)); A(hipHostMalloc(&s->h_stage2[1], nb * 10 + 64, hipHostMallocDefault));
   if (!ok) return set_error(ctx, TSD_E_HIP, "tsd_scan_begin: per-sensor streams / buffers", hipGetLastError());

@@ -686,7 +686,7 @@ bool ThreadLocalize::isRegistrationError(obvious::Matrix* T, const double trnsMa
 
 // ThreadLocalize.cpp:603-689.  What leaves on tf is map -> odom: the laser pose in the map, taken to base_footprint with the
 // laser -> base_footprint look-up and on to odom with base_footprint -> odom, i.e. pose * T_laser_footprint * T_footprint_odom.
-// A look-up that throws (no such frames yet) is skipped like the reference skips it, and -- also like the reference -- the message's
+// A look-up that fails (no such frames yet: the reference catches tf2::TransformException) is skipped like the reference skips it, and -- also like the reference -- the message's
 // transform is written ONLY where the odom look-up succeeded (:657): without an odom tree the broadcaster repeats whatever _tf.transform
 // held (the identity at start, the last good correction later, NaN after sendNanTransform).  The PoseStamped is always the laser pose.
 void ThreadLocalize::sendTransform(obvious::Matrix* T)
@@ -706,20 +706,28 @@ void ThreadLocalize::sendTransform(obvious::Matrix* T)
   // pose <- pose * lookup(target, source); false when the buffer has no such transform
   auto compose = [&](const std::string& target, const std::string& source, int which) -> bool
   {
+    // (asked first with tf2::BufferCore::canTransform, which answers "no" without throwing: a robot without a tf tree -- the bench's
+    // case -- paid two C++ exceptions per scan on this path for the answer the reference's catch blocks turn into "skip"; the
+    // look-up itself stays guarded, the tree may lose the edge between the two calls)
     int state = 1;
     std::string why;
-    try
-    {
-      const geometry_msgs::msg::TransformStamped st = _tf_buffer->lookupTransform(target, source, tf2::TimePointZero);
-      tf2::Transform step, product;
-      tf2::fromMsg(st.transform, step);
-      product.mult(pose, step);
-      pose = product;
-    }
-    catch(const tf2::TransformException& ex)
-    {
+    if(!_tf_buffer->canTransform(target, source, tf2::TimePointZero, &why))
       state = 0;
-      why = ex.what();
+    else
+    {
+      try
+      {
+        const geometry_msgs::msg::TransformStamped st = _tf_buffer->lookupTransform(target, source, tf2::TimePointZero);
+        tf2::Transform step, product;
+        tf2::fromMsg(st.transform, step);
+        product.mult(pose, step);
+        pose = product;
+      }
+      catch(const tf2::TransformException& ex)
+      {
+        state = 0;
+        why = ex.what();
+      }
     }
     if(state != _tfLookUpState[which])      // (the reference logs this at INFO level on every scan; here: when it changes)
     {

@@ -152,8 +152,8 @@ private:
 }  // namespace tf2_ros
 
 // tf2's linear algebra and the tf buffer, as far as ThreadLocalize::sendTransform uses them (ThreadLocalize.cpp:603-689):
-// Quaternion::setEuler, Transform::mult / setOrigin / setRotation, fromMsg / toMsg, Buffer::lookupTransform throwing
-// tf2::TransformException.  The arithmetic follows tf2's published LinearMath (Quaternion.h setEuler, Matrix3x3.h
+// Quaternion::setEuler, Transform::mult / setOrigin / setRotation, fromMsg / toMsg, Buffer::canTransform and
+// Buffer::lookupTransform throwing tf2::TransformException.  The arithmetic follows tf2's published LinearMath (Quaternion.h setEuler, Matrix3x3.h
 // setRotation / getRotation, Transform.h mult) so that the message the stand-in produces is the one the real library would.
 namespace tf2 {
 class TransformException : public std::runtime_error { public: explicit TransformException(const std::string& m) : std::runtime_error(m) {} };
@@ -276,6 +276,16 @@ public:
     return true;
   }
   void clear() { std::lock_guard<std::mutex> lk(_mx); _edges.clear(); }
+  // tf2::BufferCore::canTransform: the same question without an exception (false + the reason in *error_msg)
+  bool canTransform(const std::string& target, const std::string& source, const tf2::TimePoint&, std::string* error_msg = nullptr) const {
+    std::lock_guard<std::mutex> lk(_mx);
+    if(_edges.count(std::make_pair(target, source)) || _edges.count(std::make_pair(source, target))) return true;
+    if(target == source)
+      for(const auto& e : _edges)
+        if(e.first.first == target || e.first.second == target) return true;
+    if(error_msg) *error_msg = notConnected(target, source);
+    return false;
+  }
   geometry_msgs::msg::TransformStamped lookupTransform(const std::string& target, const std::string& source, const tf2::TimePoint&) const {
     std::lock_guard<std::mutex> lk(_mx);
     auto it = _edges.find(std::make_pair(target, source));
@@ -296,9 +306,12 @@ public:
           r.header.frame_id = target; r.child_frame_id = source;
           return r;
         }
-    throw tf2::LookupException("\"" + target + "\" passed to lookupTransform argument target_frame does not exist or is not connected to \"" + source + "\"");
+    throw tf2::LookupException(notConnected(target, source));
   }
 private:
+  static std::string notConnected(const std::string& target, const std::string& source) {
+    return "\"" + target + "\" passed to lookupTransform argument target_frame does not exist or is not connected to \"" + source + "\"";
+  }
   mutable std::mutex _mx;
   std::map<std::pair<std::string, std::string>, geometry_msgs::msg::TransformStamped> _edges;
 };

@@ -286,6 +286,8 @@ struct tsd_sensor {
   // fine-grained device memory and the HOST writes a scan straight into it: no pinned copy, no device copy, and the registration reads
   // its 10 KB from local memory (1 us) instead of over the host link (3.5-4 us at the top of every registration: tools/exp/bar.hip).
   bool scan_bar = false;
+  unsigned int* h_bar_mismatch = nullptr;   // TSD_SCAN_BAR_VERIFY=1: bytes in which a scan's two copies differed on the device (pinned, coherent)
+  unsigned int* d_bar_mismatch = nullptr;   // ... its device address
   bool st_device_done = false;     // the staged scan's device copy and tables are enqueued
   int scan_slot = 0;
   tsd::ScanResultDev* h_result = nullptr;   // the last record that arrived, decoded (ordinary host memory)

@@ -883,7 +883,10 @@ extern "C" int tsd_scan_preregister(tsd_sensor* s, const tsd_tsdpdf_params* prm,
   const bool inflight = s->submitted;
   if (s->inflight) return set_error(ctx, TSD_E_ARG, "tsd_scan_preregister: the sensor has a batched / split scan in flight (arm it between two scans)", hipSuccess);
   TSD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  if (inflight && s->ev_pre) TSD_HIP_CHECK(ctx, hipEventSynchronize(s->ev_pre));      // (the in-flight scan's own copy has left the pinned buffer)
+  // The last side-stream copy out of the pinned buffer has to have left it before the host rewrites it (and, BAR mode, before the host
+  // stores into d_pre itself).  That copy belongs to the in-flight scan -- or to a pre-registration that was armed ahead while a scan
+  // was in flight and is now being RE-armed without having been submitted: nothing the host has seen is ordered behind that one.
+  if (s->ev_pre && s->pre_copied && !s->pre_direct) TSD_HIP_CHECK(ctx, hipEventSynchronize(s->ev_pre));
   tsd_sensor::PreLayout L{};
   L.n = n; L.trials = prm->trials; L.size_control_set = prm->size_control_set; L.zrand = prm->zrand;
   L.phi_max = std::min(prm->phi_max, M_PI * 0.5);

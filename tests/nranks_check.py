@@ -18,6 +18,9 @@ import json
 import os
 import sys
 
+# (read when HSA initialises: before anything of this process touches HIP -- see the note at the top of bench.py)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

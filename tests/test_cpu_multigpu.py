@@ -138,7 +138,29 @@ def test_bench_gpus2_without_launcher_spawns_two_ranks():
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d == {"launch_check": True, "world_size": 2, "ranks_seen": 2, "processes": 2}
+    assert d == {"launch_check": True, "world_size": 2, "ranks_seen": 2, "processes": 2, "HSA_ENABLE_IPC_MODE_LEGACY": ["0", "0"]}
+
+
+def test_launcher_started_ranks_have_the_ipc_mode_set():
+    """The driver's form -- `python -m torch.distributed.run ... bench.py --gpus 2` with NOTHING about IPC in the environment: every
+    rank must still come up with HSA_ENABLE_IPC_MODE_LEGACY=0 (RCCL's cross-process buffer sharing needs dmabuf handles on this pool;
+    bench.py sets it in-process before anything can initialise HIP).  An explicit setting of the caller's wins."""
+    import socket
+    for given, want in ((None, "0"), ("1", "1")):
+        e = dict(os.environ)
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY"):
+            e.pop(k, None)
+        if given is not None:
+            e["HSA_ENABLE_IPC_MODE_LEGACY"] = given
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                              "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"],
+                             cwd=ROOT, env=e, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+        assert d["launch_check"] is True and d["HSA_ENABLE_IPC_MODE_LEGACY"] == [want, want]
 
 
 def test_bench_never_claims_gpus_it_does_not_have():
