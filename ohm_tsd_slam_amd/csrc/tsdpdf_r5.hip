@@ -384,8 +384,8 @@ k_pdf_normals_batch(PdfNormalsBatch b)
 
 // ---- the list building of TSD_PDFMatching::match on the device (fused scan: nothing returns to the host between the ray cast and the
 // registration).  ONE workgroup: extractSamples of both sets (index order), pickControlSet and the trial picks -- the reference erases
-// the picked element from a vector, i.e. picks the r-th REMAINING element in index order: a Lehmer code, decoded for all picks at once
-// (see the body) -- then the candidates of every trial in one pass over the window's part of the sampled scene list, each
+// the picked element from a vector, i.e. picks the r-th REMAINING element in index order: a bitmap of the remaining positions and a
+// rank-select do the same -- then the candidates of every trial in one pass over the window's part of the sampled scene list, each
 // carrying its place in the reference's serial order (trial-major, scene index ascending) as the key the arg-max breaks ties on.
 struct PdfPrepareArgs {
   const uint8_t* mask_m; const uint8_t* mask_s;       // after the normals (mMp, mSp)
@@ -397,18 +397,39 @@ struct PdfPrepareArgs {
   double phi_max;
 };
 constexpr int PDF_MAX_TRIALS = 512;        // (k_pdf_prepare keeps every per-trial array in LDS)
+__device__ __forceinline__ int select_bit32(unsigned int w, int r)          // position of the r-th (0-based) set bit of w (r < popc(w))
+{
+  int pos = 0;
+#pragma unroll
+  for (int width = 16; width >= 1; width >>= 1) {
+    const int c = __popc(w & (((1u << width) - 1u) << pos));
+    if (r >= c) { r -= c; pos += width; }
+  }
+  return pos;
+}
+// inclusive prefix sum over the 64 lanes of a wave: DPP row shifts inside the 16-lane rows, then the row totals (row_bcast)
+__device__ __forceinline__ int wave_incl_scan(int v)
+{
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);     // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);     // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);     // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);     // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);     // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);     // row_bcast:31 -> rows 2, 3
+  return v;
+}
 __device__ __forceinline__ void pdf_prepare_body(const PdfPrepareArgs& p)
 {
   // everything the picks and the candidate passes read lives in LDS: the two sample lists, the scene's masks and angles
   __shared__ unsigned short s_idx[2][TSD_MAX_BEAMS];          // [0] scene, [1] model: valid indices, ascending
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
   double* s_phi_s = s_dyn;                                    // [n]
-  double* s_phi_m = s_dyn + p.n;                              // [n] (the picked model points' angles are looked up here, not in global memory behind the picks)
-  double* s_pm = s_dyn + 2 * p.n;                             // [trials] the picked model points' angles
+  double* s_pm = s_dyn + p.n;                                 // [trials] the picked model points' angles
   __shared__ unsigned short s_rank[TSD_MAX_BEAMS];            // position in s_idx[0] of the first sampled scene point with index >= i
-  __shared__ int s_wcnt[2][(TSD_MAX_BEAMS + 1023) / 1024][16], s_trial[PDF_MAX_TRIALS];
+  __shared__ int s_wcnt[2][16], s_trial[PDF_MAX_TRIALS];
   __shared__ int s_draw_c[PDF_MAX_CONTROL], s_draw_t[PDF_MAX_TRIALS];      // the draws (a global read per pick would be a round trip per pick)
   __shared__ unsigned short s_ctrl[PDF_MAX_CONTROL];                        // picked control points (scene indices)
+  __shared__ unsigned short s_q[2][64 * 64 + 64];                                // per set and bitmap word: the picks that fell into it (k | rank << 10)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned long long lt = (1ull << lane) - 1ull;
 #ifdef TSD_PDF_STAMPS    // diagnostic build: where the kernel's time goes (thread 0, 100 MHz clock, printed)
@@ -420,130 +441,107 @@ __device__ __forceinline__ void pdf_prepare_body(const PdfPrepareArgs& p)
 #define XSTAMP() do {} while (0)
 #endif
   QSTAMP();
-  // Everything the kernel reads from global memory ahead of the picks is requested HERE, at once: both masks of every 1024-beam round
-  // (unconditional reads of a clamped index), both angle arrays, the draws -- one memory round trip where the rounds of the list
-  // building used to pay one each.
-  constexpr int ROUNDS = (TSD_MAX_BEAMS + 1023) / 1024;
-  uint8_t ms_[ROUNDS], mm_[ROUNDS];
-#pragma unroll
-  for (int r = 0; r < ROUNDS; r++) {
-    const int i = r * 1024 + tid, ic = i < p.n ? i : 0;
-    ms_[r] = ld_pinned(&p.mask_s[ic]); mm_[r] = ld_pinned(&p.mask_m[ic]);
-  }
-  for (int i = tid; i < p.n; i += 1024) { s_phi_s[i] = p.phi_s[i]; s_phi_m[i] = p.phi_m[i]; }
+  for (int i = tid; i < p.n; i += 1024) s_phi_s[i] = p.phi_s[i];
   for (int i = tid; i < p.size_control_set && i < PDF_MAX_CONTROL; i += 1024) s_draw_c[i] = p.draws_control[i];
   for (int i = tid; i < p.trials_cfg && i < PDF_MAX_TRIALS; i += 1024) s_draw_t[i] = p.draws_trials[i];
-  // extractSamples (RandomMatching.cpp:41-50) of both sets at once: i = sr .. n - sr - 1 with the mask set, in index order.
-  // The waves' counts of every round meet in LDS behind ONE barrier; every thread then sums the rounds and waves ahead of it.
+  // extractSamples (RandomMatching.cpp:41-50) of both sets at once: i = sr .. n - sr - 1 with the mask set, in index order
   int nS = 0, nM = 0;
-  unsigned long long bs_[ROUNDS], bm_[ROUNDS];
-#pragma unroll
-  for (int r = 0; r < ROUNDS; r++) {
-    const int i = r * 1024 + tid;
+  for (int c0 = 0; c0 < p.n; c0 += 1024) {
+    const int i = c0 + tid;
     const bool in = i >= p.sr && i < p.n - p.sr;
-    bs_[r] = __ballot(in && ms_[r] != 0); bm_[r] = __ballot(in && mm_[r] != 0);
-    if (lane == 0) { s_wcnt[0][r][wave] = __popcll(bs_[r]); s_wcnt[1][r][wave] = __popcll(bm_[r]); }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < ROUNDS; r++) {
-    if (r * 1024 >= p.n) break;
-    const int i = r * 1024 + tid;
+    const bool fs = in && p.mask_s[i] != 0, fm = in && p.mask_m[i] != 0;
+    const unsigned long long bs = __ballot(fs), bm = __ballot(fm);
+    if (lane == 0) { s_wcnt[0][wave] = __popcll(bs); s_wcnt[1][wave] = __popcll(bm); }
+    __syncthreads();
     int offS = nS, offM = nM, totS = 0, totM = 0;
     for (int w = 0; w < 16; w++) {
-      const int cs = s_wcnt[0][r][w], cm = s_wcnt[1][r][w];
+      const int cs = s_wcnt[0][w], cm = s_wcnt[1][w];
       if (w < wave) { offS += cs; offM += cm; }
       totS += cs; totM += cm;
     }
-    const bool fs = ((bs_[r] >> lane) & 1ull) != 0ull, fm = ((bm_[r] >> lane) & 1ull) != 0ull;
-    if (i < p.n) s_rank[i] = (unsigned short)(offS + __popcll(bs_[r] & lt));      // sampled scene points with an index below i
-    if (fs) s_idx[0][offS + __popcll(bs_[r] & lt)] = (unsigned short)i;
-    if (fm) s_idx[1][offM + __popcll(bm_[r] & lt)] = (unsigned short)i;
+    if (i < p.n) s_rank[i] = (unsigned short)(offS + __popcll(bs & lt));      // sampled scene points with an index below i
+    if (fs) s_idx[0][offS + __popcll(bs & lt)] = (unsigned short)i;
+    if (fm) s_idx[1][offM + __popcll(bm & lt)] = (unsigned short)i;
     nS += totS; nM += totM;
+    __syncthreads();
   }
-  __syncthreads();
   QSTAMP();
   const int nC = p.size_control_set < nS ? p.size_control_set : nS;
   const bool identity = nS < 3 || nM < 3;                                   // "Too less valid points" (:129-139)
   int trials = p.trials_cfg < nM ? p.trials_cfg : nM;
   if (trials > PDF_MAX_TRIALS) trials = PDF_MAX_TRIALS;                     // (the host refuses more)
   if (identity) trials = 0;
-  // pickControlSet (RandomMatching.cpp:52-80) and the trial picks (TSD_PDFMatching.cpp:185-199).  The reference erases the picked element
-  // from a vector, i.e. pick k takes the r_k-th REMAINING element in index order: the picks' positions p_k are the decoding of a Lehmer
-  // code, p_k = r_k + #{j < k : p_j <= p_k}.  Rounds 3-5 decoded it pick by pick (one wave per set, ~140 cycles per pick: 11 us of this
-  // kernel's 20); it decodes by halving instead: a block of picks whose positions are known RELATIVE TO THE ELEMENTS LEFT WHEN THE BLOCK
-  // STARTS (a single pick: its rank) is kept sorted by position; two neighbouring blocks L, R merge into one by moving R's positions
-  // back to L's start -- y -> y + c(y), c(y) = #{i : q_i - i <= y} over L's sorted positions q_0 < q_1 < ... (q_i - i elements lie below
-  // q_i once the i picks below it are gone) -- and y + c(y)'s place in the merged order is its own index + c(y), q_i's is i + #{y < q_i - i}.
-  // One search per pick and level over the sibling block, every pick of both sets at once: ceil(log2(picks)) levels.  A wave holds
-  // 64 consecutive picks of ONE set, so the first six levels (blocks of up to 64 picks) stay inside the wave -- LDS executes a wave's
-  // accesses in order: no barrier -- and only the levels above meet at workgroup barriers (two for the node's 140 / 100 picks).  Both
-  // kinds of search are ONE loop of a fixed number of steps (the block size's bits): "how many of the sibling's entries satisfy a
-  // monotone predicate", L and R lanes side by side (tests/test_cpu_oracle_properties.py: the same decoding against the erase loop).
-  __shared__ unsigned int s_lh[2][PDF_MAX_CONTROL + PDF_MAX_TRIALS];      // ping-pong: position << 16 | pick; the control set at [0, nC), the trials at [PDF_MAX_CONTROL, ..)
-  const int cw = (nC + 63) >> 6, tw = (trials + 63) >> 6;                 // waves' worth of picks per set
-  // one level for pick k of a set of K picks in blocks of B: reads `a`, writes `o` (both the set's own part of a buffer)
-  auto merge_level = [&](const unsigned int* a, unsigned int* o, int k, int K, int B) {
-    if (k >= K) return;
-    const int base = k & ~(2 * B - 1), i = k - base;
-    const int nL = K - base < B ? K - base : B, nR = K - base - B < B ? K - base - B : B;      // (nR <= 0: a lone left block, carried over)
-    const unsigned int v = a[k];
-    if (nR <= 0) { o[k] = v; return; }
-    const int val = (int)(v >> 16);
-    const bool right = i >= B;
-    // L: the picks of R whose position (relative to R's start) is below val - i.  R: the picks of L that lie at or below it once it is
-    // moved back, i.e. those with q_m - m <= val.  Either way a prefix of the sibling's sorted entries.
-    const unsigned int* sib = a + base + (right ? 0 : B);
-    const int n = right ? nL : nR, thresh = right ? val + 1 : val - i;
-    int pos = 0;
-    for (int step = B; step >= 1; step >>= 1) {
-      const int m = pos + step - 1;
-      const int mc = m < n ? m : n - 1;
-      const int sv = (int)(sib[mc] >> 16) - (right ? mc : 0);
-      if (m < n && sv < thresh) pos += step;
-    }
-    if (right) o[base + (i - B) + pos] = ((unsigned)(val + pos) << 16) | (v & 0xFFFFu);
-    else o[base + i + pos] = v;
-  };
-  for (int vw = wave; vw < cw + tw; vw += 16) {
-    const bool tr = vw >= cw;
-    const int k = ((tr ? vw - cw : vw) << 6) + lane, K = tr ? trials : nC, off = tr ? PDF_MAX_CONTROL : 0;
-    // (the ranks: r_k = draw_k mod (remaining before pick k))
-    if (k < K) s_lh[0][off + k] = (((unsigned)(tr ? s_draw_t[k] : s_draw_c[k]) % (unsigned)((tr ? nM : nS) - k)) << 16) | (unsigned)k;
-    int lvl = 0;
-#pragma unroll
-    for (int B = 1; B < 64; B <<= 1, lvl++) {       // (always six levels: both sets end in buffer 0)
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      merge_level(s_lh[lvl & 1] + off, s_lh[(lvl & 1) ^ 1] + off, k, K, B);
-    }
-  }
+  // pickControlSet (RandomMatching.cpp:52-80) by wave 0 and the trial picks (TSD_PDFMatching.cpp:185-199) by wave 1, side by side.
+  // The reference erases the picked element from a vector, i.e. picks the r-th REMAINING element in index order: lane j keeps word j
+  // of the bitmap of remaining positions in a register; prefix sum of the population counts, rank-select inside the word.
+  // (the ranks first, all at once: r_k = draw_k mod (remaining before pick k) -- an integer division per pick off the serial chain)
+  for (int k = tid; k < nC; k += 1024) s_draw_c[k] = (int)((unsigned)s_draw_c[k] % (unsigned)(nS - k));
+  for (int k = tid; k < trials; k += 1024) s_draw_t[k] = (int)((unsigned)s_draw_t[k] % (unsigned)(nM - k));
   __syncthreads();
   XSTAMP();
-  int lvl = 0;
-  for (int B = 64; B < nC || B < trials; B <<= 1, lvl++) {
-    for (int vw = wave; vw < cw + tw; vw += 16) {
-      const bool tr = vw >= cw;
-      const int off = tr ? PDF_MAX_CONTROL : 0;
-      merge_level(s_lh[lvl & 1] + off, s_lh[(lvl & 1) ^ 1] + off, ((tr ? vw - cw : vw) << 6) + lane, tr ? trials : nC, B);
-    }
-    __syncthreads();
-  }
-  XSTAMP();
-  {
-    // POSITIONS in the sample lists (translated below), by pick
-    const unsigned int* fin = s_lh[lvl & 1];
-    unsigned short* out_t = reinterpret_cast<unsigned short*>(s_trial);
-    for (int vw = wave; vw < cw + tw; vw += 16) {
-      const bool tr = vw >= cw;
-      const int k = ((tr ? vw - cw : vw) << 6) + lane;
-      if (k < (tr ? trials : nC)) {
-        const unsigned int v = fin[(tr ? PDF_MAX_CONTROL : 0) + k];
-        (tr ? out_t : s_ctrl)[v & 0xFFFFu] = (unsigned short)(v >> 16);
+  if (wave < 2) {
+    const int count = wave == 0 ? nS : nM, picks = wave == 0 ? nC : trials;
+    const int* ranks = wave == 0 ? s_draw_c : s_draw_t;
+    // lane j holds positions [j * bpl, (j + 1) * bpl) of the bitmap of remaining elements, bpl the smallest power of two that covers
+    // `count` with 64 lanes: the picks spread over as many lanes as possible (pass 2 is serial per lane)
+    int sh = 0;
+    while ((64 << sh) < count) sh++;
+    const int bpl = 1 << sh, lo = lane << sh;
+    const int nbits = count >= lo + bpl ? bpl : (count > lo ? count - lo : 0);
+    const unsigned long long w0 = nbits >= 64 ? ~0ull : ((1ull << nbits) - 1ull);
+    unsigned int wl32 = (unsigned int)w0, wh32 = (unsigned int)(w0 >> 32);   // this lane's word, as two halves
+    const int c0 = nbits;
+    int c = c0;                                                             // elements left in this lane's word ...
+    int incl = wave_incl_scan(c);                                           // ... and in the words up to it: kept up to date per pick
+    int excl = incl - c, qn = 0;                                            // elements in the words before it; picks queued for this word
+    const int picks_u = __builtin_amdgcn_readfirstlane(picks);
+    unsigned short* q = s_q[wave];
+    // pass 1, serial over the picks but a handful of per-lane instructions each, no cross-lane traffic: the counts are monotone over
+    // the lanes, so "the word that holds rank r" is the lane with excl <= r < incl, and the lanes behind it are those with incl > r.
+    // Queued per word: which pick, and its rank inside the word at that moment.
+    // (the ranks wait in registers, 64 per register, and reach the lanes by v_readlane: an LDS read per pick would put an LDS round
+    // trip into every step of this loop)
+    constexpr int RK = (PDF_MAX_CONTROL > PDF_MAX_TRIALS ? PDF_MAX_CONTROL : PDF_MAX_TRIALS) / 64;
+    int rk[RK];
+#pragma unroll
+    for (int j = 0; j < RK; j++) rk[j] = (j * 64 + lane < picks) ? ranks[j * 64 + lane] : 0;
+    // (delivery HERE: left to the compiler, the wait for these LDS reads lands at the head of the pick loop -- which is also its back
+    // edge, so every pick would sit out the round trip of the previous pick's queue write: 160 cycles per pick instead of ~40)
+#pragma unroll
+    for (int j = 0; j < RK; j++) asm volatile("" : "+v"(rk[j]));
+#pragma unroll
+    for (int j = 0; j < RK; j++) {
+      if (j * 64 >= picks_u) break;
+      const int lim = picks_u - j * 64 < 64 ? picks_u - j * 64 : 64;
+      for (int l = 0; l < lim; l++) {      // (~140 cycles per pick, a lone wave's issue rate for these ~18 instructions: unrolling changes nothing)
+        const int k = j * 64 + l;
+        const int r = __builtin_amdgcn_readlane(rk[j], l);
+        // (branch-free: a lane that is not the word writes to a slot of its own beyond the queues.  excl and incl are carried
+        // separately: each is one compare + one subtract per pick, and neither waits for the other)
+        const bool after = excl > r, behind = incl > r, mine = behind && !after;
+        q[mine ? lane * 64 + qn : 64 * 64 + lane] = (unsigned short)(k | ((r - excl) << 10));
+        qn += mine ? 1 : 0;
+        excl -= after ? 1 : 0;
+        incl -= behind ? 1 : 0;
       }
     }
+    c = c0 - qn;
+    XSTAMP();
+    // pass 2, every word on its own lane: its picks in order -- rank-select in the word as it stands, clear the bit, note the position
+    unsigned short* out = wave == 0 ? s_ctrl : reinterpret_cast<unsigned short*>(s_trial);     // POSITIONS (translated below)
+    const int nq = c0 - c;
+    for (int j = 0; j < nq; j++) {
+      const unsigned e = q[lane * 64 + j];
+      int rr = (int)(e >> 10);
+      const int cl = __popc(wl32);
+      const bool hi = rr >= cl;
+      if (hi) rr -= cl;
+      const int bit = select_bit32(hi ? wh32 : wl32, rr);
+      if (hi) wh32 &= ~(1u << bit); else wl32 &= ~(1u << bit);
+      out[e & 1023u] = (unsigned short)(lo + bit + (hi ? 32 : 0));
+    }
+    XSTAMP();
   }
-  XSTAMP();
   __syncthreads();
   XSTAMP();
   // positions -> scene / model indices, all at once (s_trial's picks were parked as 16-bit positions in its own storage: read all, then write)
@@ -558,11 +556,8 @@ __device__ __forceinline__ void pdf_prepare_body(const PdfPrepareArgs& p)
   }
   __syncthreads();
   QSTAMP();
-  // the control points: requested now, stored behind the candidate pass (nothing in this kernel waits for them)
-  static_assert(PDF_MAX_CONTROL <= 1024, "one control point per thread");
-  double2 ctrl_xy = make_double2(0.0, 0.0);
-  if (tid < nC) { const int idx = s_ctrl[tid]; ctrl_xy = make_double2(ld_pinned(&p.S[2 * idx]), ld_pinned(&p.S[2 * idx + 1])); }
-  for (int t = tid; t < trials; t += 1024) s_pm[t] = s_phi_m[s_trial[t]];
+  for (int k = tid; k < nC; k += 1024) { const int idx = s_ctrl[k]; p.control[k] = make_double2(p.S[2 * idx], p.S[2 * idx + 1]); }
+  for (int t = tid; t < trials; t += 1024) s_pm[t] = p.phi_m[s_trial[t]];      // (one round trip for all trials, not one per trial)
   __syncthreads();
   // ---- candidates (:200-215) in ONE pass: wave w takes the trials w, w + 16, ...; the matches of a 64-beam round draw their list places
   // from one LDS counter (one atomic per wave and round).  The list order is whatever order the waves arrive in; the reference's serial
@@ -599,7 +594,6 @@ __device__ __forceinline__ void pdf_prepare_body(const PdfPrepareArgs& p)
       }
     }
   }
-  if (tid < nC) p.control[tid] = ctrl_xy;
   __syncthreads();
   QSTAMP(); QSTAMP(); QSTAMP();
 #ifdef TSD_PDF_STAMPS
@@ -1002,7 +996,7 @@ static PreLaunch pre_launch_args(const tsd_sensor* s, const double* d_coords, co
   pa.hdr = reinterpret_cast<PdfHeader*>(d + L.off_hdr);
   pa.n = n; pa.sr = SR; pa.span = L.span; pa.trials_cfg = L.trials; pa.size_control_set = L.size_control_set; pa.max_cand = L.max_cand;
   pa.phi_max = L.phi_max;
-  pl.prep_lds = (2 * (size_t)n + (size_t)PDF_MAX_TRIALS) * sizeof(double);
+  pl.prep_lds = ((size_t)n + (size_t)PDF_MAX_TRIALS) * sizeof(double);
   pl.score = PdfScoreEntry{d_pose6, d_coords, reinterpret_cast<const double*>(d + L.off_S), reinterpret_cast<const double2*>(d + L.off_C),
                            reinterpret_cast<const PdfCandidate*>(d + L.off_K), reinterpret_cast<double*>(d + L.off_prob),
                            reinterpret_cast<const PdfHeader*>(d + L.off_hdr), L.zrand, L.max_cand, std::max(L.size_control_set, 1)};

@@ -660,3 +660,62 @@ def test_oracle_against_rederivations_on_random_cases():
     p = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_oracle.py"), "60", "4711"], cwd=root, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert "all 60 cases ok" in p.stdout
+
+
+# ------------------------------------------------------------------------------------------------
+# k_pdf_prepare's pick decoding (csrc/tsdpdf.hip): "pick k erases the r_k-th remaining element" (RandomMatching.cpp:52-80,
+# TSD_PDFMatching.cpp:185-199) decoded for all picks at once by merging sorted blocks.  The same index arithmetic, statement by
+# statement, against the erase loop itself.
+def _decode_picks_like_the_kernel(ranks):
+    K = len(ranks)
+    src = [(r << 16) | k for k, r in enumerate(ranks)]
+    B = 1
+    while B < K:
+        dst = [None] * K
+        for k in range(K):
+            base = k & ~(2 * B - 1)
+            i = k - base
+            nL = min(K - base, B)
+            nR = min(K - base - B, B)
+            v = src[k]
+            if nR <= 0:
+                dst[k] = v
+                continue
+            val = v >> 16
+            right = i >= B
+            sib = base + (0 if right else B)
+            n, thresh = (nL, val + 1) if right else (nR, val - i)
+            pos, step = 0, B
+            while step >= 1:
+                m = pos + step - 1
+                mc = min(m, n - 1)
+                sv = (src[sib + mc] >> 16) - (mc if right else 0)
+                if m < n and sv < thresh:
+                    pos += step
+                step >>= 1
+            at = base + (i - B) + pos if right else base + i + pos
+            assert dst[at] is None
+            dst[at] = (((val + pos) << 16) | (v & 0xFFFF)) if right else v
+        src = dst
+        B <<= 1
+    out = [0] * K
+    for v in src:
+        out[v & 0xFFFF] = v >> 16
+    return out
+
+
+def test_pick_decoding_equals_the_erase_loop():
+    rng = np.random.default_rng(7)
+    cases = [(1, 1), (2, 2), (3, 3), (64, 64), (65, 65), (1081, 140), (1081, 100), (180, 180), (4096, 1024), (4096, 512), (257, 129)]
+    cases += [(int(c), int(rng.integers(1, c + 1))) for c in rng.integers(1, 600, size=300)]
+    for count, K in cases:
+        for mode in range(3):
+            if mode == 0:
+                ranks = [int(rng.integers(0, count - k)) for k in range(K)]
+            elif mode == 1:
+                ranks = [0] * K                                   # always the first remaining element
+            else:
+                ranks = [count - k - 1 for k in range(K)]         # always the last
+            remaining = list(range(count))
+            want = [remaining.pop(r) for r in ranks]
+            assert _decode_picks_like_the_kernel(ranks) == want, (count, K, mode)
