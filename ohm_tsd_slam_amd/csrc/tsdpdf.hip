@@ -174,6 +174,25 @@ k_pdf_score_batch(GridDev g, PdfScoreBatch b)
   pdf_score_body(g, e.pose, e.M, e.S, e.control, 0, e.cand, 0, e.zrand, e.prob, e.hdr, e.max_cand, e.control_alloc);
 }
 
+// wave reductions for the arg-max: DPP row shifts inside the 16-lane rows, the four row results through scalar registers
+__device__ __forceinline__ double pdf_wave_max_nonneg(double v)            // v >= 0 in every lane (lanes without a source read 0)
+{
+#define PDF_SHR_F64(CTRL) { const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false), \
+                                      hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false); v = fmax(v, __hiloint2double(hi_, lo_)); }
+  PDF_SHR_F64(0x111) PDF_SHR_F64(0x112) PDF_SHR_F64(0x114) PDF_SHR_F64(0x118)
+#undef PDF_SHR_F64
+  auto rl = [&](int l) { return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l)); };
+  return fmax(fmax(rl(15), rl(31)), fmax(rl(47), rl(63)));
+}
+__device__ __forceinline__ int pdf_wave_min_int(int v)
+{
+  v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x111, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x112, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x114, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x118, 0xf, 0xf, false));
+  return min(min(__builtin_amdgcn_readlane(v, 15), __builtin_amdgcn_readlane(v, 31)), min(__builtin_amdgcn_readlane(v, 47), __builtin_amdgcn_readlane(v, 63)));
+}
+
 // first candidate in the reference's serial trial / i order (the key `ti`) that reaches the maximum; bestProb starts at
 // 0.0 and is replaced on `>` only (TSD_PDFMatching.cpp:188,264)
 __device__ __forceinline__ void
@@ -181,40 +200,49 @@ pdf_argmax_body(const double* __restrict__ prob, const PdfCandidate* __restrict_
                 const double* __restrict__ S, PdfResult* __restrict__ out, const PdfHeader* __restrict__ hdr,
                 PdfHeader* __restrict__ host_hdr, PdfResult* __restrict__ host_res /* fused scan: pinned host memory, or nullptr */)
 {
+  // A chain of dependent memory round trips by nature (header -> probabilities and candidates -> the winner's points); round 6 took one
+  // of them out: a thread keeps its best candidate's model index and angle in registers (the winner used to read its candidate again),
+  // and the reduction is one shuffle tree per wave + one barrier (it was ten barriers).
   if (hdr) n_cand = hdr->identity ? 0 : hdr->n_cand;
-  __shared__ double s_p[1024];
-  __shared__ int s_k[1024], s_o[1024];                      // list position and serial-order key of the thread's best
-  double bp = 0.0; int bk = -1, bo = 0x7fffffff;
-  for (int c = threadIdx.x; c < n_cand; c += 1024) {
+  __shared__ double s_p[16];
+  __shared__ int s_o[16], s_t[16];                          // per wave: serial-order key and thread of its best
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double bp = 0.0, bphi = 0.0; int bk = -1, bo = 0x7fffffff, bidx = 0;
+  for (int c = tid; c < n_cand; c += 1024) {
     const double p = prob[c];
-    const int o = cand[c].ti;
-    if (p > bp || (p == bp && p > 0.0 && o < bo)) { bp = p; bk = c; bo = o; }
+    const PdfCandidate cd = cand[c];
+    if (p > bp || (p == bp && p > 0.0 && cd.ti < bo)) { bp = p; bk = c; bo = cd.ti; bidx = cd.idx; bphi = cd.phi; }
   }
-  s_p[threadIdx.x] = bp; s_k[threadIdx.x] = bk; s_o[threadIdx.x] = bo;
+  const int bci = bk >= 0 ? (bo & PDF_I_MASK) : 0;
+  // the wave's best: the largest probability (DPP row shifts, no LDS), then the earliest serial-order key among the lanes that hold it
+  // (a shuffle tree over the triple cost six dependent LDS-crossbar round trips: 1.1 us of this 5 us kernel)
+  const double wp = pdf_wave_max_nonneg(bp);
+  const bool cont = bk >= 0 && bp == wp;
+  const int wo = pdf_wave_min_int(cont ? bo : 0x7fffffff);
+  const unsigned long long wb = __ballot(cont && bo == wo);
+  const int wt = wb ? wave * 64 + (__ffsll((long long)wb) - 1) : -1;      // (keys are unique: one lane)
+  if (lane == 0) { s_p[wave] = wp; s_o[wave] = wo; s_t[wave] = wt; }
   __syncthreads();
-  for (int h = 512; h > 0; h >>= 1) {
-    if ((int)threadIdx.x < h) {
-      const double p2 = s_p[threadIdx.x + h]; const int k2 = s_k[threadIdx.x + h], o2 = s_o[threadIdx.x + h];
-      const double p1 = s_p[threadIdx.x]; const int k1 = s_k[threadIdx.x], o1 = s_o[threadIdx.x];
-      const bool take = k2 >= 0 && (p2 > p1 || (p2 == p1 && (k1 < 0 || o2 < o1)));
-      if (take) { s_p[threadIdx.x] = p2; s_k[threadIdx.x] = k2; s_o[threadIdx.x] = o2; }
-    }
-    __syncthreads();
+  double gp = s_p[0]; int go = s_o[0], gt = s_t[0];
+#pragma unroll
+  for (int w = 1; w < 16; w++) {
+    const double p2 = s_p[w]; const int o2 = s_o[w], t2 = s_t[w];
+    if (t2 >= 0 && (p2 > gp || (p2 == gp && (gt < 0 || o2 < go)))) { gp = p2; go = o2; gt = t2; }
   }
-  if (threadIdx.x == 0) {
+  const bool found = gt >= 0 && gp > 0.0;
+  if (tid == (found ? gt : 0)) {
     PdfResult r;
     for (int i = 0; i < 9; i++) r.T[i] = (i % 4 == 0) ? 1.0 : 0.0;
     r.prob = 0.0; r.idx = -1; r.i = -1; r.candidates = n_cand; r.pad = 0;
-    const int k = s_k[0];
-    if (k >= 0 && s_p[0] > 0.0) {
-      const PdfCandidate cd = cand[k];
-      const double co = cos(cd.phi), si = sin(cd.phi);
-      const int ci = cd.ti & PDF_I_MASK;
-      const double sx = S[2 * ci], sy = S[2 * ci + 1];
+    if (found) {
+      // (the winner's two points: requested by the winner alone, ahead of the sine and cosine.  Requested by every thread for its own
+      // best ahead of the reduction -- 4 000 scattered 8-byte reads -- the kernel took 6.2 us instead of 5.2)
+      const double msx = ld_pinned(&M[2 * bidx]), msy = ld_pinned(&M[2 * bidx + 1]), ssx = ld_pinned(&S[2 * bci]), ssy = ld_pinned(&S[2 * bci + 1]);
+      const double co = cos(bphi), si = sin(bphi);
       r.T[0] = co; r.T[1] = -si; r.T[3] = si; r.T[4] = co;
-      r.T[2] = M[2 * cd.idx] - (co * sx + (-si) * sy);
-      r.T[5] = M[2 * cd.idx + 1] - (si * sx + co * sy);
-      r.prob = s_p[0]; r.idx = cd.idx; r.i = ci;
+      r.T[2] = msx - (co * ssx + (-si) * ssy);
+      r.T[5] = msy - (si * ssx + co * ssy);
+      r.prob = gp; r.idx = bidx; r.i = bci;
     }
     *out = r;
     // fused scan: header and result go to the host from here (stores into pinned memory, complete when the kernel ends) -- a copy
@@ -271,10 +299,15 @@ __device__ __forceinline__ DD dd_div_d(DD a, double b, double rb)
 }
 struct PdfNormalsSet { const double* xy; const uint8_t* mask_in; const uint8_t* mask_io_init; uint8_t* mask_io; double* phi; };
 
+// TWO lanes per point (round 6): the centroid's two running means -- the longest chain of this kernel, ~45 dependent double-double
+// operations per neighbour and axis -- are independent, so lane 2 i takes the x axis and lane 2 i + 1 the y axis and they swap the
+// results (one DPP quad permute per word); everything else is done by both lanes alike and written by the even one.
 __device__ __forceinline__ void pdf_normals_body(const PdfNormalsSet& st, int points, int sr)
 {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= points) return;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = t >> 1;
+  const bool odd = (t & 1) != 0;
+  if (i >= points) return;                                    // (points in pairs of lanes: a pair is in or out together)
   const double NO_PHI = -1e6;                                 // calcPhi's value for a masked-out point (RandomMatching.cpp:155-174)
   // Everything the thread reads is requested HERE, unconditionally, on clamped indices (pinned reads: the optimiser cannot sink them
   // into the conditions below): its two masks, the masks and coordinates of the ten neighbour slots -- ONE memory round trip.  As
@@ -290,9 +323,9 @@ __device__ __forceinline__ void pdf_normals_body(const PdfNormalsSet& st, int po
     mq[j] = ld_pinned(&st.mask_in[q]);
     ax_[j] = ld_pinned(&st.xy[2 * q]); ay_[j] = ld_pinned(&st.xy[2 * q + 1]);
   }
-  if (i < sr || i >= points - sr) { st.mask_io[i] = 0; st.phi[i] = NO_PHI; return; }
-  if (!m_in || !m_io) { st.mask_io[i] = 0; st.phi[i] = NO_PHI; return; }   // (mask_io <= mask_in on entry)
-  st.mask_io[i] = 1;
+  if (i < sr || i >= points - sr) { if (!odd) { st.mask_io[i] = 0; st.phi[i] = NO_PHI; } return; }
+  if (!m_in || !m_io) { if (!odd) { st.mask_io[i] = 0; st.phi[i] = NO_PHI; } return; }   // (mask_io <= mask_in on entry)
+  if (!odd) st.mask_io[i] = 1;
   // the <= 10 neighbours stay in their slots j = -5 .. 4 (registers, every loop unrolled over the ten slots and skipping the
   // masked-out ones in order): the same sequence of operations as over the compacted list, without an indexed private array
   // (sr <= i < points - sr here, so no slot inside the search radius was clamped)
@@ -304,22 +337,26 @@ __device__ __forceinline__ void pdf_normals_body(const PdfNormalsSet& st, int po
     if (!v_[j]) { ax_[j] = 0.0; ay_[j] = 0.0; }
     cnt += v_[j] ? 1 : 0;
   }
-  if (cnt <= 3) { st.mask_io[i] = 0; st.phi[i] = NO_PHI; return; }
+  if (cnt <= 3) { if (!odd) { st.mask_io[i] = 0; st.phi[i] = NO_PHI; } return; }
   // Matrix::pcaAnalysis (gsl/Matrix.cpp:227-327), see pca2_axes below
   double cent[2];
-#pragma unroll
-  for (int j2 = 0; j2 < 2; j2++) {
+  {
+    // this lane's axis (both lanes of a pair are here: every exit above depends on the point only)
     DD mean = DD{0.0, 0.0};
     int k = 0;
 #pragma unroll
     for (int j = 0; j < NB; j++) {
       if (!v_[j]) continue;
       k++;
-      DD d = dd_two_sum(j2 == 0 ? ax_[j] : ay_[j], -mean.hi);            // x - mean
+      DD d = dd_two_sum(odd ? ay_[j] : ax_[j], -mean.hi);                  // x - mean
       d.lo -= mean.lo; d = dd_quick_two_sum(d.hi, d.lo);
       mean = dd_add(mean, dd_div_d(d, (double)k, __builtin_amdgcn_rcp((double)k)));      // (v_rcp_f64: good to an ulp, which is all dd_div_d asks)
     }
-    cent[j2] = mean.hi;
+    // the partner's mean: quad_perm [1, 0, 3, 2]
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(mean.hi), 0xB1, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(mean.hi), 0xB1, 0xf, 0xf, false);
+    const double other = __hiloint2double(hi, lo);
+    cent[0] = odd ? other : mean.hi; cent[1] = odd ? mean.hi : other;
   }
 #pragma unroll
   for (int j = 0; j < NB; j++) { ax_[j] = ax_[j] + (-cent[0]); ay_[j] = ay_[j] + (-cent[1]); }      // mc (slots of masked-out neighbours: unused)
@@ -361,6 +398,7 @@ __device__ __forceinline__ void pdf_normals_body(const PdfNormalsSet& st, int po
   const double xLong = ax[0][1] - ax[0][0], yLong = ax[0][3] - ax[0][2];
   const double xShort = ax[1][1] - ax[1][0], yShort = ax[1][3] - ax[1][2];
   const double lenLongSqr = xLong * xLong + yLong * yLong, lenShortSqr = xShort * xShort + yShort * yShort;
+  if (odd) return;
   if (lenShortSqr > 1e-6 && (lenLongSqr / lenShortSqr) < 4.0) { st.mask_io[i] = 0; st.phi[i] = NO_PHI; return; }
   const double len = sqrt(lenShortSqr);
   double nx, ny;
@@ -788,7 +826,7 @@ extern "C" int tsd_tsdpdf_match(tsd_ctx* ctx, const double pose33[9], const doub
                      reinterpret_cast<double*>(d + off_phi + bPhi)};
     {
       ScopedKernelTimer t(ctx, "tsdpdf", true);
-      hipLaunchKernelGGL(k_pdf_normals, dim3((n + 255) / 256, 2), dim3(256), 0, ctx->stream, sm, ss, n, SR);
+      hipLaunchKernelGGL(k_pdf_normals, dim3((2 * n + 255) / 256, 2), dim3(256), 0, ctx->stream, sm, ss, n, SR);
     }
     TSD_HIP_CHECK(ctx, hipGetLastError());
     TSD_HIP_CHECK(ctx, hipMemcpyAsync(h + off_mo, d + off_mo, off_C - off_mo, hipMemcpyDeviceToHost, ctx->stream));   // masks + angles
@@ -1046,7 +1084,7 @@ int launch_preregistration(tsd_ctx* ctx, tsd_sensor* s, hipStream_t stream, cons
   if (int rc = pre_configure_lds(ctx, reinterpret_cast<const void*>(k_pdf_prepare), pl.prep_lds)) return rc;
   {
     ScopedKernelTimer t(ctx, "tsdpdf", true);
-    hipLaunchKernelGGL(k_pdf_normals, dim3((L.n + 255) / 256, 2), dim3(256), 0, stream, pl.normals.set0, pl.normals.set1, L.n, pl.normals.sr);
+    hipLaunchKernelGGL(k_pdf_normals, dim3((2 * L.n + 255) / 256, 2), dim3(256), 0, stream, pl.normals.set0, pl.normals.set1, L.n, pl.normals.sr);
     hipLaunchKernelGGL(k_pdf_prepare, dim3(1), dim3(1024), pl.prep_lds, stream, pl.prepare);
     // (asynchronous mapping: the scoring is the first kernel of the chain that reads the grid)
     if (before_score) TSD_HIP_CHECK(ctx, hipStreamWaitEvent(stream, before_score, 0));
@@ -1088,7 +1126,7 @@ int launch_preregistration_batch(tsd_ctx* ctx, hipStream_t stream, tsd_sensor* c
     // batch's workgroups at about that launch's number)
     const int blocks = std::max(64, std::min(max_blocks, PDF_SCORE_GRID / std::max(1, m / 2)));
     ScopedKernelTimer t(ctx, "tsdpdf", true);
-    hipLaunchKernelGGL(k_pdf_normals_batch, dim3((max_points + 255) / 256, 2, m), dim3(256), 0, stream, bn);
+    hipLaunchKernelGGL(k_pdf_normals_batch, dim3((2 * max_points + 255) / 256, 2, m), dim3(256), 0, stream, bn);
     hipLaunchKernelGGL(k_pdf_prepare_batch, dim3(m), dim3(1024), max_lds, stream, bp);
     hipLaunchKernelGGL(k_pdf_score_batch, dim3(blocks, 1, m), dim3(64 * PDF_WAVES), 0, stream, ctx->grid, bs);
     hipLaunchKernelGGL(k_pdf_argmax_batch, dim3(m), dim3(1024), 0, stream, ba);
