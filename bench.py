@@ -769,6 +769,9 @@ def run_slam(args, gc, geo, scene, K, W, every, every_upd, every_icp, device, ra
             "ms_raycast": stages["raycast"],
             "ms_push_kernels": sum(v for k, v in stages.items() if k.startswith("push") and v is not None),
             "stages_ms": stages, "stages_sum_ms_per_scan": stage_sum,
+            # what of a step is NOT inside a kernel of the chain: the host's ingest / launches / result poll where they are not hidden
+            # behind a kernel, and the gaps between the kernels (one robot: the chain is strictly serial, so this is a plain difference)
+            "ms_host_and_gaps_per_scan": (1e3 * elapsed / K - stage_sum) if R == 1 else None,
             "stage_timing": f"HIP events on every {every}th dispatch of each kernel (k_icp: every {every_icp}th; k_push_update: every "
                             f"{'one' if every_upd == 1 else ('second' if every_upd == 2 else str(every_upd) + 'th')}), inside the timed region",
             "pushes_in_timed_region": pushes, "cells_updated_per_push": st["cells_updated"] / max(pushes, 1),

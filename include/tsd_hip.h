@@ -86,7 +86,9 @@ typedef struct {
   int32_t state;                /* EnumIcpState */
   int32_t n_model;              /* valid model points (ray-cast hits)  -- tsd_localize only */
   int32_t n_scene;              /* valid scene points                  -- tsd_localize only */
-  int32_t reserved;
+  int32_t reserved;             /* < 0: a TSD_E_* code (TSD_E_CAPACITY: more points than the registration holds).  >= 0 (diagnostic): the
+                                 * scene points whose first neighbour search was delivered by the helper workgroups of the launch
+                                 * (0 with tsd_debug_set_icp_helpers(ctx, 0)); the results do not depend on it */
 } tsd_icp_result;
 
 /* ---- life cycle ------------------------------------------------------------------------------ */

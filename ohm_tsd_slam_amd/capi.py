@@ -260,6 +260,7 @@ class IcpOut:
     state: int
     n_model: int = 0
     n_scene: int = 0
+    seeded: int = 0         # tsd_icp_result.reserved: scene points whose step-0 search came from the helper workgroups
 
 
 class TsdGridDevice:
@@ -370,7 +371,7 @@ class TsdGridDevice:
             rc = self.lib.tsd_icp_normals(self.h, _d(m), _d(nrm), m.size // 2, _d(s), s.size // 2, _d(pose),
                                           C.byref(params), C.byref(r))
         self._check(rc, "tsd_icp")
-        return IcpOut(np.array(r.T[:]).reshape(3, 3), r.rms, r.pairs, r.iterations, r.state)
+        return IcpOut(np.array(r.T[:]).reshape(3, 3), r.rms, r.pairs, r.iterations, r.state, seeded=r.reserved)
 
     def localize(self, pose, rays_world, rays_local, ranges, mask, min_range, max_range, params: IcpParams) -> IcpOut:
         pose = _f64(pose).reshape(9)
@@ -380,7 +381,7 @@ class TsdGridDevice:
         rc = self.lib.tsd_localize(self.h, _d(pose), _d(rw), _d(rl), _d(rg), _u8(mk), rg.size, min_range,
                                    max_range, C.byref(params), C.byref(r))
         self._check(rc, "tsd_localize")
-        return IcpOut(np.array(r.T[:]).reshape(3, 3), r.rms, r.pairs, r.iterations, r.state, r.n_model, r.n_scene)
+        return IcpOut(np.array(r.T[:]).reshape(3, 3), r.rms, r.pairs, r.iterations, r.state, r.n_model, r.n_scene, seeded=r.reserved)
 
     def set_icp_helpers(self, on: bool):
         """test hook: off = every registration does its first step's searches itself (same results, tsd_debug_set_icp_helpers)"""

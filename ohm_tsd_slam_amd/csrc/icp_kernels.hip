@@ -45,7 +45,7 @@ constexpr int HW = 6;                           // tier-1 window: k-HW .. k+HW (
 constexpr int ICP_PAD = 96;                     // wrapped copies of the model at both ends of its LDS array
 constexpr unsigned REFRESH_A = 6, REFRESH_B = 15;      // steps with a scheduled bound renewal
 constexpr double WEAK_MULT = 36.0;                     // a scheduled renewal takes the bounds with less than sqrt(this) x slack in distance
-constexpr int IR_CNT = 32, IR_RMAX = 33, IR_CNT2 = 34, IR_TIE = 35;   // words of IcpLds::ired
+constexpr int IR_CNT = 32, IR_RMAX = 33, IR_CNT2 = 34, IR_TIE = 35, IR_SEEDED = 36;   // words of IcpLds::ired (SEEDED: points whose step-0 neighbour a helper delivered)
 // Step 0 of a registration is the one step in which EVERY scene point searches (no neighbour is known yet): ~20 000 cycles on the one
 // compute unit that runs the registration.  That search does not depend on anything the loop produces, so it is shared out: the launch
 // brings `helpers` more workgroups, each of which runs the same set-up (model, unit directions, padding in ITS OWN LDS) and then the
@@ -737,7 +737,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
   if (role == 0) {       // (a helper searches and leaves: it has no tail)
     if (tid == 0) {
       L.tail->out = out; L.tail->trace = trace;
-      L.ired[IR_CNT] = 0; L.ired[IR_RMAX] = 0; L.ired[IR_CNT2] = 0; L.ired[IR_TIE] = 0;
+      L.ired[IR_CNT] = 0; L.ired[IR_RMAX] = 0; L.ired[IR_CNT2] = 0; L.ired[IR_TIE] = 0; L.ired[IR_SEEDED] = 0;
     }
     if (tid == 64 % T) L.tail->post = post;                  // (another wave's lane: ~30 stores)
     // fused scan: the sensor state the epilogue starts from, requested at the top (words 18 / 19 change places: see the assertions)
@@ -946,6 +946,14 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
       }
       if (__all(ok) || wall_clock64() - t0 > ICP_SEED_WAIT_TICKS) break;
       __builtin_amdgcn_s_sleep(2);
+    }
+    {
+      // (observability: how many points started from a helper's granules -- tsd_icp_result.reserved; a broken tag or stride, or
+      // helpers that never got a compute unit, would otherwise only cost time, the results being the same either way)
+      int seeded = 0;
+#pragma unroll
+      for (int q = 0; q < R; q++) seeded += __popcll(__ballot(have[q] && got[q]));
+      if (lane == 0 && seeded) atomicAdd(&L.ired[IR_SEEDED], seeded);
     }
 #pragma unroll
     for (int q = 0; q < R; q++) {
@@ -1398,7 +1406,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
     r.T[3] = Tf[3]; r.T[4] = Tf[4]; r.T[5] = Tf[5];
     r.T[6] = 0.0; r.T[7] = 0.0; r.T[8] = 1.0;
     r.rms = rms; r.pairs = pairs; r.iterations = (int)iter; r.state = state;
-    r.n_model = nM; r.n_scene = nS; r.reserved = 0;
+    r.n_model = nM; r.n_scene = nS; r.reserved = L.ired[IR_SEEDED];
     const IcpTail& tl = *L.tail;
     if (tid == 0) *tl.out = r;
     // fused scan: gates, Sensor::transform, push / next-scan arguments, result record for the host

@@ -744,6 +744,9 @@ def test_icp_helpers_change_nothing(oracle):
                 out.append((r, dg.icp_trace(r.iterations)))
             dg.set_icp_helpers(True)
             (ra, ta), (rb, tb) = out
+            # the hand-off DELIVERS: with the helpers on, (nearly) every scene point starts from their granules -- a broken tag or stride,
+            # or helpers that never ran, would fall back to the self-search silently (same results, only slower) -- and none without
+            assert ra.seeded >= 0.9 * len(S) and rb.seeded == 0, (ci, est, ra.seeded, rb.seeded, len(S))
             assert (ra.pairs, ra.iterations, ra.state) == (rb.pairs, rb.iterations, rb.state), (ci, est)
             assert np.array_equal(ra.T, rb.T) and ra.rms == rb.rms, (ci, est, ra.T - rb.T)
             assert np.array_equal(ta, tb, equal_nan=True), (ci, est)
@@ -769,6 +772,7 @@ def test_icp_helpers_change_nothing(oracle):
         out.append((r, dg.icp_trace(r.iterations)))
     dg.set_icp_helpers(True)
     (ra, ta), (rb, tb) = out
+    assert ra.seeded >= 0.9 * ra.n_scene and rb.seeded == 0, (ra.seeded, rb.seeded, ra.n_scene)
     assert ra.pairs > 500 and (ra.pairs, ra.iterations, ra.state, ra.n_model, ra.n_scene) == (rb.pairs, rb.iterations, rb.state, rb.n_model, rb.n_scene)
     assert np.array_equal(ra.T, rb.T) and np.array_equal(ta, tb, equal_nan=True)
 
