@@ -1131,6 +1131,13 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
             if (!(lk & LIST_PAST_WINDOW)) r = window_search(L, nM, s.x, s.y, lk, thr, sgn, &rounds, st);
             asm volatile("" : "+v"(r.best), "+v"(r.lbsq));
             const long long ws2 = clock64();
+            if (L.tail->trace && iter < 16u && !(lk & LIST_PAST_WINDOW)) {
+              // (diagnostic, cumulative over every registration of the run) what the window pass's entries were: rounds 1..7 x {resolved with a
+              // partner within the filter distance, resolved without one, not resolved -> whole-wave search}, by step
+              const int rb = (rounds < 1 ? 1 : (rounds > 7 ? 7 : rounds)) - 1;
+              const int cat = rb + 7 * (r.resolved ? (r.best <= thr ? 0 : 1) : 2);
+              atomicAdd(L.tail->trace + TSD_ICP_TRACE_STRIDE * (TSD_ICP_TRACE_MAX + 202) + 21 * (int)iter + cat, 1.0);
+            }
             {
               // (diagnostic) per list round of wave 0: entries, lanes' largest / mean number of window rounds, cycles of the call
               int mx = rounds;

@@ -71,21 +71,28 @@ pdf_score_body(const GridDev& g, const double* __restrict__ pose /* first two ro
   // candidate and the first batch of control points together; the scene / model points follow the candidate, the look-ups the control
   // points.  As written first -- header field by field, then the candidate, then per batch control point -> wait -> look-ups -- the
   // kernel was a chain of ten memory round trips for 140 control points.
+  // (round 6: the wave's FIRST candidate and the first batch of control points are requested ahead of the header -- which candidate that
+  // is does not depend on the counts, and both arrays are allocated beyond them -- so the header's round trip is theirs too)
+  const int c_first = blockIdx.x * PDF_WAVES + wave;
+  int idx_rd, ti_rd; double phi_rd;
+  double cpx[PDF_BATCH], cpy[PDF_BATCH];
+  auto request = [&](int c) {
+    const int c_rd = c < max_cand_alloc ? c : 0;
+    idx_rd = ld_pinned(&cand[c_rd].idx); ti_rd = ld_pinned(&cand[c_rd].ti); phi_rd = ld_pinned(&cand[c_rd].phi);
+#pragma unroll
+    for (int b = 0; b < PDF_BATCH; b++) {
+      const int s = 64 * b + lane, sc = s < control_alloc ? s : 0;
+      cpx[b] = ld_pinned(&control[sc].x); cpy[b] = ld_pinned(&control[sc].y);
+    }
+  };
+  request(c_first);
   if (hdr) {
     const int4 h0 = reinterpret_cast<const int4*>(hdr)[0];        // n_cand, n_control, n_model_valid, n_scene_valid
     const int ident = hdr->identity;
     n_cand = ident ? 0 : h0.x; n_control = h0.y;
   }
-  for (int c = blockIdx.x * PDF_WAVES + wave; c < n_cand; c += (int)gridDim.x * PDF_WAVES) {       // (whole waves: no barrier below)
-  const int c_rd = c < max_cand_alloc ? c : 0;
-  const int idx_rd = ld_pinned(&cand[c_rd].idx), ti_rd = ld_pinned(&cand[c_rd].ti);
-  const double phi_rd = ld_pinned(&cand[c_rd].phi);
-  double cpx[PDF_BATCH], cpy[PDF_BATCH];
-#pragma unroll
-  for (int b = 0; b < PDF_BATCH; b++) {
-    const int s = 64 * b + lane, sc = s < control_alloc ? s : 0;
-    cpx[b] = ld_pinned(&control[sc].x); cpy[b] = ld_pinned(&control[sc].y);
-  }
+  for (int c = c_first; c < n_cand; c += (int)gridDim.x * PDF_WAVES) {       // (whole waves: no barrier below)
+  if (c != c_first) request(c);
   PdfCandidate cd; cd.idx = idx_rd; cd.ti = ti_rd; cd.phi = phi_rd;
   // T = MatrixFactory::TransformationMatrix33(phi, 0, 0) + translation (TSD_PDFMatching.cpp:217-223)
   const double co = cos(cd.phi), si = sin(cd.phi);
@@ -203,14 +210,21 @@ pdf_argmax_body(const double* __restrict__ prob, const PdfCandidate* __restrict_
   // A chain of dependent memory round trips by nature (header -> probabilities and candidates -> the winner's points); round 6 took one
   // of them out: a thread keeps its best candidate's model index and angle in registers (the winner used to read its candidate again),
   // and the reduction is one shuffle tree per wave + one barrier (it was ten barriers).
+  // (with a header, n_cand arrives as the ALLOCATION's size: the thread's first candidate is requested ahead of the header's counts)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool spec = hdr != nullptr && tid < n_cand;
+  const int c0 = spec ? tid : 0;
+  double p_first = 0.0, phi_first = 0.0; int idx_first = 0, ti_first = 0;
+  if (spec) { p_first = ld_pinned(&prob[c0]); idx_first = ld_pinned(&cand[c0].idx); ti_first = ld_pinned(&cand[c0].ti); phi_first = ld_pinned(&cand[c0].phi); }
   if (hdr) n_cand = hdr->identity ? 0 : hdr->n_cand;
   __shared__ double s_p[16];
   __shared__ int s_o[16], s_t[16];                          // per wave: serial-order key and thread of its best
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double bp = 0.0, bphi = 0.0; int bk = -1, bo = 0x7fffffff, bidx = 0;
   for (int c = tid; c < n_cand; c += 1024) {
-    const double p = prob[c];
-    const PdfCandidate cd = cand[c];
+    const bool first = spec && c == tid;
+    const double p = first ? p_first : prob[c];
+    PdfCandidate cd;
+    if (first) { cd.idx = idx_first; cd.ti = ti_first; cd.phi = phi_first; } else cd = cand[c];
     if (p > bp || (p == bp && p > 0.0 && cd.ti < bo)) { bp = p; bk = c; bo = cd.ti; bidx = cd.idx; bphi = cd.phi; }
   }
   const int bci = bk >= 0 ? (bo & PDF_I_MASK) : 0;
@@ -258,13 +272,13 @@ k_pdf_argmax(const double* __restrict__ prob, const PdfCandidate* __restrict__ c
 {
   pdf_argmax_body(prob, cand, n_cand, M, S, out, hdr, host_hdr, host_res);
 }
-struct PdfArgmaxEntry { const double* prob; const PdfCandidate* cand; const double* M; const double* S; PdfResult* out; const PdfHeader* hdr; PdfHeader* host_hdr; PdfResult* host_res; };
+struct PdfArgmaxEntry { const double* prob; const PdfCandidate* cand; const double* M; const double* S; PdfResult* out; const PdfHeader* hdr; PdfHeader* host_hdr; PdfResult* host_res; int max_cand; };
 struct PdfArgmaxBatch { PdfArgmaxEntry e[PDF_BATCH_BYVAL]; };
 __global__ void __launch_bounds__(1024)
 k_pdf_argmax_batch(PdfArgmaxBatch b)
 {
   const PdfArgmaxEntry& e = b.e[blockIdx.x];
-  pdf_argmax_body(e.prob, e.cand, 0, e.M, e.S, e.out, e.hdr, e.host_hdr, e.host_res);
+  pdf_argmax_body(e.prob, e.cand, e.max_cand, e.M, e.S, e.out, e.hdr, e.host_hdr, e.host_res);
 }
 
 // ---- RandomMatching::calcNormals + calcPhi on the device (second half of round 3) ---------------------------------------------
@@ -1048,7 +1062,7 @@ static PreLaunch pre_launch_args(const tsd_sensor* s, const double* d_coords, co
   pl.argmax = PdfArgmaxEntry{reinterpret_cast<const double*>(d + L.off_prob), reinterpret_cast<const PdfCandidate*>(d + L.off_K), d_coords,
                              reinterpret_cast<const double*>(d + L.off_S), reinterpret_cast<PdfResult*>(d + L.off_res),
                              reinterpret_cast<const PdfHeader*>(d + L.off_hdr), reinterpret_cast<PdfHeader*>(h_dev + L.off_hdr),
-                             reinterpret_cast<PdfResult*>(h_dev + L.off_res)};
+                             reinterpret_cast<PdfResult*>(h_dev + L.off_res), L.max_cand};
   return pl;
 }
 // the inputs of an armed pre-registration must be on the device before its kernels: copied at arm time on the side stream (waited for
@@ -1093,7 +1107,7 @@ int launch_preregistration(tsd_ctx* ctx, tsd_sensor* s, hipStream_t stream, cons
     // (the arg-max's own completion is the event a pre-registration armed AHEAD waits for before it overwrites the inputs: no marker
     // between this kernel and the registration)
     if (!s->ev_pre_done) TSD_HIP_CHECK(ctx, hipEventCreateWithFlags(&s->ev_pre_done, hipEventDisableTiming | hipEventDisableSystemFence));
-    hipExtLaunchKernelGGL(k_pdf_argmax, dim3(1), dim3(1024), 0, stream, nullptr, s->ev_pre_done, 0, pl.argmax.prob, pl.argmax.cand, 0, pl.argmax.M,
+    hipExtLaunchKernelGGL(k_pdf_argmax, dim3(1), dim3(1024), 0, stream, nullptr, s->ev_pre_done, 0, pl.argmax.prob, pl.argmax.cand, pl.argmax.max_cand, pl.argmax.M,
                        pl.argmax.S, pl.argmax.out, pl.argmax.hdr, pl.argmax.host_hdr, pl.argmax.host_res);
     s->pre_done_valid = true;
     s->pre_res_off_hdr = L.off_hdr; s->pre_res_off_res = L.off_res;

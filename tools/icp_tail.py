@@ -83,6 +83,10 @@ late = [(r["lists"][i], r["rounds"][j][1]) for r in rows for j, i in enumerate(r
 if late:
     print(f"search steps after step 15: {len(late)} in {len(rows)} registrations; list length mean {np.mean([l for l, _ in late]):.1f}, "
           f"p90 {np.percentile([l for l, _ in late], 90):.0f}; largest window rounds mean {np.mean([m for _, m in late]):.1f}")
+hist = tr.reshape(-1)[(256 + 202) * 8: (256 + 202) * 8 + 16 * 21].reshape(16, 3, 7)
+print("\nwindow-pass entries of the whole run by step (rows) and number of window rounds (1..7): resolved with a partner | resolved, nothing within the filter distance | unresolved (-> whole-wave search)")
+for it in range(16):
+    print("   step %2d: %s | %s | %s" % (it, hist[it, 0].astype(int).tolist(), hist[it, 1].astype(int).tolist(), hist[it, 2].astype(int).tolist()))
 print("\nthe slowest registrations:")
 for r in sorted(rows, key=lambda r: -r["us"])[:14]:
     print(f"scan {r['k']:3d}: {r['us']:6.1f} us, model {r['nM']}, scene {r['nS']}, pairs {r['pairs']}, search steps {r['srch']}")
