@@ -424,6 +424,10 @@ int tsd_debug_set_icp_helpers(tsd_ctx* ctx, int on);
  * other, ThreadMapping.cpp:43-76), instead of the one pass per tile that applies the robots' updates in that order inside every tile
  * (csrc/push_multi.hip).  The grids are the same cell for cell, halo included (tests/test_gpu_batch.py). */
 int tsd_debug_set_push_multi(tsd_ctx* ctx, int on);
+/* TEST HOOK: how a scan of this sensor reaches the device -- 1: the host stores it into device memory through the PCIe BAR (the default
+ * wherever the device's memory is mapped into the host's address space and the start-up probe's kernel read back what the host wrote),
+ * 0: through a pinned host buffer (no such mapping, or TSD_SCAN_PINNED=1), 2: as 1 with TSD_SCAN_BAR_VERIFY's device-side cross-check. */
+int tsd_debug_sensor_scan_path(const tsd_sensor* s);
 
 /* the pre-registration's outcome for the scan collected last (TBest, probability, winning pair, counts) */
 int tsd_scan_preregistration_result(tsd_sensor* s, tsd_tsdpdf_result* result);

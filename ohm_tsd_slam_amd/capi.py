@@ -175,6 +175,7 @@ ABI = {
     "tsd_sensor_set_async_mapping": (C.c_int, [C.c_void_p, C.c_int]),
     "tsd_debug_stall_push_stream": (C.c_int, [C.c_void_p, C.c_uint]),
     "tsd_debug_set_icp_helpers": (C.c_int, [C.c_void_p, C.c_int]),
+    "tsd_debug_sensor_scan_path": (C.c_int, [C.c_void_p]),
     "tsd_debug_set_push_multi": (C.c_int, [C.c_void_p, C.c_int]),
     "tsd_color_image": (C.c_int, [C.c_void_p, _u8p, C.c_uint, C.c_uint]),
     "tsd_store_grid_text": (C.c_int, [C.c_void_p, C.c_char_p]),

@@ -30,11 +30,13 @@ static __global__ void k_bar_verify(const unsigned char* __restrict__ bar, const
   for (int i = threadIdx.x + blockIdx.x * blockDim.x; i < n; i += blockDim.x * gridDim.x) bad += bar[i] != pinned[i];
   if (bad) atomicAdd_system(mismatches, bad);
 }
-static bool bar_verify_requested()
+// (TSD_SCAN_BAR_VERIFY=2, tests only: the pinned copy of every scan is spoiled in one byte, so the cross-check must fire)
+static int bar_verify_mode()
 {
-  static const bool on = [] { const char* e = std::getenv("TSD_SCAN_BAR_VERIFY"); return e && *e == '1'; }();
-  return on;
+  static const int mode = [] { const char* e = std::getenv("TSD_SCAN_BAR_VERIFY"); return e && (*e == '1' || *e == '2') ? *e - '0' : 0; }();
+  return mode;
 }
+static bool bar_verify_requested() { return bar_verify_mode() != 0; }
 static bool host_writes_device_memory(tsd_ctx* ctx)
 {
   const int device = ctx->device;
@@ -245,6 +247,7 @@ static int scan_stage_host(tsd_sensor* s, const double* ranges, const uint8_t* m
     std::memcpy(s->h_scan3[sslot], ranges, nb * 8);
     std::memcpy(s->h_scan3[sslot] + nb * 8, mask, nb);
     std::memcpy(s->h_scan3[sslot] + nb * 9, mask_push ? mask_push : mask, nb);
+    if (bar_verify_mode() == 2) s->h_scan3[sslot][nb * 4] ^= 0x40;
   }
   LAP(1);
   char* d_scan = s->d_scan2[sslot];
@@ -339,6 +342,12 @@ int tsd_debug_set_icp_helpers(tsd_ctx* ctx, int on)
   if (!ctx) return TSD_E_ARG;
   ctx->icp_helpers = on ? 1 : 0;
   return TSD_OK;
+}
+
+int tsd_debug_sensor_scan_path(const tsd_sensor* s)
+{
+  if (!s) return TSD_E_ARG;
+  return s->scan_bar ? (s->d_bar_mismatch ? 2 : 1) : 0;
 }
 
 int tsd_debug_set_push_multi(tsd_ctx* ctx, int on)

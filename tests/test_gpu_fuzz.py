@@ -39,6 +39,41 @@ def test_scan_through_pinned_memory_when_the_bar_is_not_mapped(tool, args):
 
 
 @pytest.mark.gpu
+def test_scan_through_the_bar_with_the_device_side_cross_check():
+    """TSD_SCAN_BAR_VERIFY=1 (debug): every scan the host stores into device memory through the PCIe BAR is also written to the pinned
+    buffer, and ahead of its registration a kernel compares the two copies as the DEVICE sees them.  The closed loops of the sweep
+    run clean with it (no scan ever differs on this platform); with the pinned copy spoiled on purpose (=2) the very first fused scan
+    is refused with an error instead of producing a pose."""
+    env = dict(os.environ, TSD_SCAN_BAR_VERIFY="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_slam.py"), "12", "7171"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "all 12 cases ok" in p.stdout
+    code = (
+        "import numpy as np\n"
+        "from ohm_tsd_slam_amd import capi, synth\n"
+        "from oracle import pyoracle as O\n"
+        "from tests.slam_driver import HipSlamFused, slam_kwargs\n"
+        "gc = synth.GridConfig(9, 0.05); geo = synth.ScanGeometry.full_circle_360(); world = synth.World('room', gc)\n"
+        "scans = synth.scans_for(world, geo, synth.trajectory(world, 3))\n"
+        "sh = HipSlamFused(O, **slam_kwargs(gc, geo))\n"
+        "sh.process_scan(scans[0])\n"
+        "print('PATH', sh.grid.lib.tsd_debug_sensor_scan_path(sh.sensor.h))\n"
+        "try:\n"
+        "    sh.process_scan(scans[1])\n"
+        "    print('NO ERROR')\n"
+        "except capi.TsdError as e:\n"
+        "    print('REFUSED:', e)\n")
+    for mode, want in (("2", "REFUSED"), ("1", "NO ERROR")):
+        q = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, TSD_SCAN_BAR_VERIFY=mode), capture_output=True, text=True, timeout=300)
+        assert q.returncode == 0, (mode, q.stdout[-1500:], q.stderr[-1500:])
+        if "PATH 0" in q.stdout:
+            pytest.skip("this box does not map the device's memory into the host's address space: scans go through pinned memory")
+        assert "PATH 2" in q.stdout and want in q.stdout, (mode, q.stdout[-1500:], q.stderr[-1500:])
+        if mode == "2":
+            assert "PCIe BAR" in q.stdout
+
+
+@pytest.mark.gpu
 def test_randomised_async_mapping_short():
     """tools/fuzz_async.py: asynchronous mapping through the staged scan with random staging (kept / replaced / absent) and a push stream
     held back by up to 3 ms per push, against the one-push-behind order on the oracle's primitives."""
