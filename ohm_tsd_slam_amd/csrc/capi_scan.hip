@@ -2,6 +2,7 @@
 // stream order, sensor state on the device), its split form for several robots on one grid (tsd_scan_begin / _wait / _finish) and the
 // batched form (tsd_batch_*: one launch of each kernel for the robots of a batch).
 #include "capi_internal.hpp"
+#include "push_device.hpp"
 #if defined(__x86_64__)
 #include <immintrin.h>
 #endif
@@ -477,6 +478,10 @@ int tsd_scan_submit(tsd_sensor* s, const double* ranges, const uint8_t* mask, co
   std::memset(&pa, 0, sizeof(pa));
   pa.beams = s->beams;                                   // LDS size of the launch
   pa.max_range = s->max_range;                           // tile window of the launch (the rest is read on the device)
+  // TSD_HALO_KERNEL=1: the push's halo pass as a kernel of its own even here (the form every other path uses; A/B)
+  static const bool halo_in_raycast = [] { const char* e = std::getenv("TSD_HALO_KERNEL"); return !(e && *e == '1'); }();
+  HaloArgs halo;
+  std::memset(&halo, 0, sizeof(halo));
   if (!async_map) {
     if (int rcd_ = drain_async_push(ctx)) return rcd_;   // (a push left on the push stream by an earlier, asynchronous scan)
     if (!host_saw_event(ctx->ev_tables, staged_ahead ? 2 : 60)) TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_tables, 0));
@@ -485,15 +490,19 @@ int tsd_scan_submit(tsd_sensor* s, const double* ranges, const uint8_t* mask, co
       tg.rmq = s->st_rmq;                                  // this scan's tables (the sensor's own buffers)
       TargetScope scope(ctx, &tg);
       // the registration moves the sensor by at most the gate (a larger step is rejected: pose unchanged)
-      rc = launch_push(ctx, pa, s->pos[0], s->pos[1], gates->reg_trs_max, &s->d_state->push, d_ranges, d_mask_push);
+      // (the push's halo pass is left to the ray cast that follows it at once: k_raycast's prologue, raycast_kernels.hip)
+      rc = launch_push(ctx, pa, s->pos[0], s->pos[1], gates->reg_trs_max, &s->d_state->push, d_ranges, d_mask_push, nullptr, halo_in_raycast ? &halo : nullptr);
     }
     if (rc != TSD_OK) return rc;
     ctx->epoch++;                                          // the grid changes
     lap.lap(4);
     // the next scan's ray cast, right behind the push (see above): the host's work on the next scan no longer sits
     // between this push and that ray cast
-    rc = launch_raycast(ctx, ra, &s->d_state->rc, s->d_rays);
-    if (rc != TSD_OK) return rc;
+    rc = launch_raycast(ctx, ra, &s->d_state->rc, s->d_rays, halo_in_raycast ? &halo : nullptr);
+    if (rc != TSD_OK) {
+      if (halo_in_raycast) (void)launch_push_halo(ctx, halo);      // (the grid's halos must not stay behind the push whatever happened to the ray cast)
+      return rc;
+    }
     s->rc_pending = true; s->rc_epoch = ctx->epoch;
     lap.lap(5);
   } else {

@@ -144,7 +144,7 @@ constexpr int TOT_FIELDS = 8;   // cells updated, range pass, update, new, new f
 // k_push_update's tile queue: TICKET_HEADS counters, each on a 128-byte line of its own (one word shared by every workgroup
 // saturates at ~88 returning atomics per microsecond, MI355X_MICROARCH.md "dequeue": a 10 000-tile push would take 120 us for its
 // tickets alone).  Head h hands out the tiles G + h + TICKET_HEADS * k beyond the G that the G workgroups start with.
-constexpr int CNT_U = 0, CNT_O = 1, CNT_H = 2 /* UPDATE tiles k_push_halo has work for (list_h) */, TICKET_HEADS = 32, TICKET_STRIDE = 32 /* words */, CNT_TICKET = 32;
+constexpr int CNT_U = 0, CNT_O = 1, CNT_H = 2 /* UPDATE tiles k_push_halo has work for (list_h) */, CNT_HDONE = 3 /* halo-list entries done (the ray cast's prologue) */, TICKET_HEADS = 32, TICKET_STRIDE = 32 /* words */, CNT_TICKET = 32;
 constexpr int CNT_WORDS = CNT_TICKET + TICKET_HEADS * TICKET_STRIDE;
 // What k_push_classify leaves for the workgroup of an UPDATE tile: one 128-byte record (a cache line, at the entry's own index),
 // fetched as ONE vector register per wave -- lane i holds word i -- and unpacked with v_readlane.
@@ -335,6 +335,98 @@ __device__ __forceinline__ CellClass classify_cell(const TileA& t, float dxc, fl
     return c;
   } else {
     return classify_angle(FAR ? t.th_c + th_rel : th_rel, t.phi_min, t.inv_res, t.beams);
+  }
+}
+
+// ---- TsdGrid::propagateBorders (TsdGrid.cpp:372-427), incremental form, for ONE listed tile by ONE wave --------------------------------
+// The tile's own halo from R / U / UR and the halos of L / D / DL that mirror its first column / row / cell.  Equal to the reference's
+// full sweep by induction (untouched pairs are already consistent).  Every lane has up to three copy jobs (source cell -> destination
+// cell, value and weight); all loads of a tile are issued before the first store, so a tile costs one memory round trip after its flags.
+// Lanes 0..31: the two column copies; lanes 32..63: the two row copies; lane 0 / lane 32: the corner cells.
+// Shared by k_push_halo (a kernel of its own behind k_push_update) and by k_raycast's prologue (the fused scan: the NEXT scan's ray cast
+// is the kernel behind the push, and its first waves do this before they cast: raycast_kernels.hip).  The destination cells are stored
+// WRITE-THROUGH at agent scope (`sc1`): in the ray cast's prologue they are handed to other waves of the same launch.
+struct HaloArgs {
+  uint8_t* dirty; unsigned long long* pushes; const PushArgs* a_dev;
+  const uint32_t* list; const uint32_t* list_h; const uint32_t* tile_rec;
+  unsigned int* cnt;              // this push's counter words (list_cnt + CNT_WORDS * parity)
+  double cx, cy, slack;           // where the host laid the push's window, and how far the sensor may be from it
+  int on;                         // 0: no push ahead of this launch (nothing to do)
+};
+template <typename T>
+__device__ __forceinline__ void st_agent(T* p, T v)
+{
+  if constexpr (sizeof(T) == 8) __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else __hip_atomic_store(reinterpret_cast<unsigned int*>(p), __builtin_bit_cast(unsigned int, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void halo_tile_job(const GridDev& g, uint8_t* __restrict__ dirty, const uint32_t* __restrict__ tile_rec, uint32_t entry, int lane)
+{
+  const int PX = g.PX;
+  const bool colhalf = lane < TILE_DIM;
+  const int i = lane & 31;
+  const int p = (int)(entry & LIST_TILE_MASK);
+  const int px = p % PX, py = p / PX;
+  const bool hasR = px < PX - 1, hasU = py < PX - 1, hasL = px > 0, hasD = py > 0;
+  // all nine flags, the three records and the dirty mark in flight at once: UNCONDITIONAL reads (a missing neighbour reads the
+  // tile itself and the value is dropped).  As `has ? flags[q] : 0` each read was predicated, and the compiler waits for a
+  // predicated read on the spot -- up to twelve memory round trips in a row per tile (round 3, ISA of rounds 1-2).
+  const int qR = hasR ? p + 1 : p, qU = hasU ? p + PX : p, qUR = (hasR && hasU) ? p + PX + 1 : p;
+  const int qL = hasL ? p - 1 : p, qD = hasD ? p - PX : p, qDL = (hasL && hasD) ? p - PX - 1 : p;
+  const uint8_t f0 = g.flags[p], dty = dirty[p];
+  const uint8_t fR_ = g.flags[qR], fU_ = g.flags[qU], fUR_ = g.flags[qUR], fL_ = g.flags[qL], fD_ = g.flags[qD], fDL_ = g.flags[qDL];
+  const uint32_t rL_ = tile_rec[qL], rD_ = tile_rec[qD], rDL_ = tile_rec[qDL];
+  const uint32_t r0 = tile_rec[p];
+  // ... and the SOURCE cells of the three copy jobs with them (where they are depends on the geometry only; the tile storage exists for
+  // every tile): the pass is a chain of memory round trips -- in the ray cast's prologue every other wave of the launch waits for its
+  // end -- and this is one of them less.  job 0: own halo from the right / upper neighbour; job 1: the left / lower neighbour's halo
+  // from this tile; job 2 (lanes 0 and 32 only): the corner cells
+  const size_t own = (size_t)p * TILE_STRIDE;
+  size_t src[3], dst[3]; bool can[3];
+  if (colhalf) {
+    can[0] = hasR;  src[0] = (size_t)qR * TILE_STRIDE + (size_t)i * TILE_DIM;   dst[0] = own + HALO_COL + i;
+    can[1] = hasL;  src[1] = own + (size_t)i * TILE_DIM;                       dst[1] = (size_t)qL * TILE_STRIDE + HALO_COL + i;
+    can[2] = lane == 0 && hasR && hasU; src[2] = (size_t)qUR * TILE_STRIDE;     dst[2] = own + HALO_ROW + TILE_DIM;
+  } else {
+    can[0] = hasU;  src[0] = (size_t)qU * TILE_STRIDE + i;                      dst[0] = own + HALO_ROW + i;
+    can[1] = hasD;  src[1] = own + i;                                          dst[1] = (size_t)qD * TILE_STRIDE + HALO_ROW + i;
+    can[2] = lane == 32 && hasL && hasD; src[2] = own;                          dst[2] = (size_t)qDL * TILE_STRIDE + HALO_ROW + TILE_DIM;
+  }
+  tsd_cell_t tv[3]; w_cell_t wv_[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) { const size_t sk = can[k] ? src[k] : own; tv[k] = ld_pinned(&g.tsd[sk]); wv_[k] = ld_pinned(&g.weight[sk]); }
+  if (lane == 0 && dty != 0) dirty[p] = 0;
+  const uint8_t fR = hasR ? fR_ : (uint8_t)0, fU = hasU ? fU_ : (uint8_t)0, fUR = (hasR && hasU) ? fUR_ : (uint8_t)0;
+  uint8_t fL = hasL ? fL_ : (uint8_t)0, fD = hasD ? fD_ : (uint8_t)0, fDL = (hasL && hasD) ? fDL_ : (uint8_t)0;
+  // a left / lower / diagonal neighbour that is on this push's list refreshes its own halo from this tile itself
+  // (its job 0 / corner job is the very same copy): skipping the mirror job halves the column gathers where the
+  // listed tiles are dense.  Records outside this push's window are never "listed" (see launch_push).
+  const uint32_t rL = hasL ? rL_ : 0u, rD = hasD ? rD_ : 0u, rDL = (hasL && hasD) ? rDL_ : 0u;
+  if (!f0) return;
+  // An UPDATE tile that held data before this push and was not touched by freeFootprint has nothing to do here: what it changed of
+  // its column 0 / row 0 / corner, its own workgroup wrote into the neighbours' halos (k_push_update's mirror pass), and what its
+  // right / upper neighbours changed arrived the same way or is brought by THEIR jobs below.  Left for this pass: tiles
+  // materialised by this push (everything around them), increaseEmptiness tiles (all 33 x 33 cells changed, own halo included),
+  // tiles freeFootprint wrote to.
+  const bool plain_u = (entry >> KIND_SHIFT) == KIND_UPDATE && !(r0 & REC_NEW) && dty == 0;
+  if (plain_u) return;
+  // (a neighbour that is on the list and surely does its own job 0 -- materialised, emptied or halo-only this push -- needs no
+  // mirror job from here; a plain UPDATE neighbour does nothing in this pass, so it does)
+  auto own_job = [](uint32_t r) { return (r & REC_LISTED) != 0u && !((r & REC_UPDATE) != 0u && !(r & REC_NEW)); };
+  if (own_job(rL)) fL = 0;
+  if (own_job(rD)) fD = 0;
+  if (own_job(rDL)) fDL = 0;
+  const bool on[3] = {can[0] && (colhalf ? fR : fU) != 0, can[1] && (colhalf ? fL : fD) != 0, can[2] && (colhalf ? fUR : fDL) != 0};
+#pragma unroll
+  for (int k = 0; k < 3; k++) if (on[k]) { st_agent(&g.tsd[dst[k]], tv[k]); st_agent(&g.weight[dst[k]], wv_[k]); }
+}
+// the push's bookkeeping that rides with the halo pass (one lane of the launch): the push counter and the check of the window's assumption
+__device__ __forceinline__ void halo_bookkeeping(unsigned long long* __restrict__ pushes, const PushArgs* __restrict__ a_dev, double cx, double cy, double slack)
+{
+  if (a_dev->enabled != 0) {
+    pushes[0] += 1ull;
+    // the window was laid around (cx, cy) +- slack by the host: a sensor outside of that is a host-side bug
+    const double sx = a_dev->trx, sy = a_dev->try_;
+    if (!(fabs(sx - cx) <= slack && fabs(sy - cy) <= slack)) pushes[1] += 1ull;
   }
 }
 

@@ -125,7 +125,7 @@ k_push_classify(GridDev g, const PushArgs* __restrict__ a_dev, const char* __res
   const bool owner = corner == 0;
   const int t = blockIdx.x * (CLASSIFY_BLOCK / 4) + ((int)threadIdx.x >> 2);
   if (t < 16 && owner) {      // the next push's counters (nobody uses them now)
-    if (t < 3) list_cnt[CNT_WORDS * (parity ^ 1) + t] = 0u;
+    if (t < 4) list_cnt[CNT_WORDS * (parity ^ 1) + t] = 0u;        // (U, O, H and HDONE)
     list_cnt[CNT_WORDS * (parity ^ 1) + CNT_TICKET + TICKET_STRIDE * t] = 0u;
     list_cnt[CNT_WORDS * (parity ^ 1) + CNT_TICKET + TICKET_STRIDE * (t + 16)] = 0u;
   }
@@ -755,90 +755,23 @@ k_push_update(GridDev g, const PushArgs* __restrict__ a_dev, const double* __res
 #endif
 }
 
-// TsdGrid::propagateBorders (TsdGrid.cpp:372-427), incremental form.
-// One wave per listed tile: the tile's own halo from R/U/UR and the halos of L/D/DL that mirror its first
-// column/row/cell.  Equal to the reference's full sweep by induction (untouched pairs are already consistent).
-// Every lane has up to three copy jobs (source cell -> destination cell, tsd and weight); all loads of a tile are
-// issued before the first store, so a tile costs one memory round trip after its flags (round 1 ran the six copies
-// one after the other: 40 us of latency chain at cfg3 / comb).  Lanes 0..31: the two column copies; lanes 32..63:
-// the two row copies; lane 0 / lane 32: the corner cells.
+// TsdGrid::propagateBorders (TsdGrid.cpp:372-427), incremental form, as a kernel of its own behind k_push_update: one wave per listed
+// tile (push_device.hpp: halo_tile_job).  The fused scan does not launch it: there the next scan's ray cast follows the push at
+// once and its first waves do this pass (raycast_kernels.hip).
 __global__ void __launch_bounds__(256)
-k_push_halo(GridDev g, uint8_t* __restrict__ dirty, unsigned long long* __restrict__ pushes,
-            const PushArgs* __restrict__ a_dev, const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_h,
-            const uint32_t* __restrict__ tile_rec, const unsigned int* __restrict__ list_cnt, int parity, double cx, double cy, double slack)
+k_push_halo(GridDev g, HaloArgs h)
 {
   const int lane = threadIdx.x & 63;
   const unsigned int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (wv == 0 && lane == 0) {
-    const bool enabled = a_dev->enabled != 0;
-    if (enabled) {
-      pushes[0] += 1ull;
-      // the window was laid around (cx, cy) +- slack by the host: a sensor outside of that is a host-side bug
-      const double sx = a_dev->trx, sy = a_dev->try_;
-      if (!(fabs(sx - cx) <= slack && fabs(sy - cy) <= slack)) pushes[1] += 1ull;
-    }
-  }
+  if (wv == 0 && lane == 0) halo_bookkeeping(h.pushes, h.a_dev, h.cx, h.cy, h.slack);
   // the tiles with work here: UPDATE tiles materialised by this push or written by freeFootprint (list_h), emptied and halo-only tiles
   // (the back of `list`).  A plain UPDATE tile's edge changes were mirrored by its own workgroup.
-  const unsigned int n_u = list_cnt[CNT_WORDS * parity + CNT_H], n_list = n_u + list_cnt[CNT_WORDS * parity + CNT_O];
-  const uint32_t first = list_h[wv];                          // speculative: arrives with the list lengths
-  const int PX = g.PX;
-  const bool colhalf = lane < TILE_DIM;
-  const int i = lane & 31;
+  const unsigned int n_u = h.cnt[CNT_H], n_list = n_u + h.cnt[CNT_O];
+  const uint32_t first = h.list_h[wv];                          // speculative: arrives with the list lengths
   for (unsigned int li = wv; li < n_list; li += gridDim.x * 4) {
     // UPDATE tiles from the halo list, the others (emptied, dirtied) from the back of the work list
-    const uint32_t entry = li < n_u ? ((li == wv) ? first : list_h[li]) : list[(unsigned)g.tiles - 1u - (li - n_u)];
-    const int p = (int)(entry & LIST_TILE_MASK);
-    const int px = p % PX, py = p / PX;
-    const bool hasR = px < PX - 1, hasU = py < PX - 1, hasL = px > 0, hasD = py > 0;
-    // all nine flags, the three records and the dirty mark in flight at once: UNCONDITIONAL reads (a missing neighbour reads the
-    // tile itself and the value is dropped).  As `has ? flags[q] : 0` each read was predicated, and the compiler waits for a
-    // predicated read on the spot -- up to twelve memory round trips in a row per tile (round 3, ISA of rounds 1-2).
-    const int qR = hasR ? p + 1 : p, qU = hasU ? p + PX : p, qUR = (hasR && hasU) ? p + PX + 1 : p;
-    const int qL = hasL ? p - 1 : p, qD = hasD ? p - PX : p, qDL = (hasL && hasD) ? p - PX - 1 : p;
-    const uint8_t f0 = g.flags[p], dty = dirty[p];
-    const uint8_t fR_ = g.flags[qR], fU_ = g.flags[qU], fUR_ = g.flags[qUR], fL_ = g.flags[qL], fD_ = g.flags[qD], fDL_ = g.flags[qDL];
-    const uint32_t rL_ = tile_rec[qL], rD_ = tile_rec[qD], rDL_ = tile_rec[qDL];
-    const uint32_t r0 = tile_rec[p];
-    if (lane == 0 && dty != 0) dirty[p] = 0;
-    const uint8_t fR = hasR ? fR_ : (uint8_t)0, fU = hasU ? fU_ : (uint8_t)0, fUR = (hasR && hasU) ? fUR_ : (uint8_t)0;
-    uint8_t fL = hasL ? fL_ : (uint8_t)0, fD = hasD ? fD_ : (uint8_t)0, fDL = (hasL && hasD) ? fDL_ : (uint8_t)0;
-    // a left / lower / diagonal neighbour that is on this push's list refreshes its own halo from this tile itself
-    // (its job 0 / corner job is the very same copy): skipping the mirror job halves the column gathers where the
-    // listed tiles are dense.  Records outside this push's window are never "listed" (see launch_push).
-    const uint32_t rL = hasL ? rL_ : 0u, rD = hasD ? rD_ : 0u, rDL = (hasL && hasD) ? rDL_ : 0u;
-    if (!f0) continue;
-    // An UPDATE tile that held data before this push and was not touched by freeFootprint has nothing to do here: what it changed of
-    // its column 0 / row 0 / corner, its own workgroup wrote into the neighbours' halos (k_push_update's mirror pass), and what its
-    // right / upper neighbours changed arrived the same way or is brought by THEIR jobs below.  Left for this kernel: tiles
-    // materialised by this push (everything around them), increaseEmptiness tiles (all 33 x 33 cells changed, own halo included),
-    // tiles freeFootprint wrote to.
-    const bool plain_u = (entry >> KIND_SHIFT) == KIND_UPDATE && !(r0 & REC_NEW) && dty == 0;
-    if (plain_u) continue;
-    // (a neighbour that is on the list and surely does its own job 0 -- materialised, emptied or halo-only this push -- needs no
-    // mirror job from here; a plain UPDATE neighbour does nothing in this kernel, so it does)
-    auto own_job = [](uint32_t r) { return (r & REC_LISTED) != 0u && !((r & REC_UPDATE) != 0u && !(r & REC_NEW)); };
-    if (own_job(rL)) fL = 0;
-    if (own_job(rD)) fD = 0;
-    if (own_job(rDL)) fDL = 0;
-    const size_t own = (size_t)p * TILE_STRIDE;
-    // job 0: own halo from the right / upper neighbour; job 1: the left / lower neighbour's halo from this tile;
-    // job 2 (lanes 0 and 32 only): the corner cells
-    size_t src[3], dst[3]; bool on[3];
-    if (colhalf) {
-      on[0] = fR != 0;  src[0] = (size_t)(p + 1) * TILE_STRIDE + (size_t)i * TILE_DIM;  dst[0] = own + HALO_COL + i;
-      on[1] = fL != 0;  src[1] = own + (size_t)i * TILE_DIM;                           dst[1] = (size_t)(p - 1) * TILE_STRIDE + HALO_COL + i;
-      on[2] = lane == 0 && fUR != 0; src[2] = (size_t)(p + PX + 1) * TILE_STRIDE;      dst[2] = own + HALO_ROW + TILE_DIM;
-    } else {
-      on[0] = fU != 0;  src[0] = (size_t)(p + PX) * TILE_STRIDE + i;                   dst[0] = own + HALO_ROW + i;
-      on[1] = fD != 0;  src[1] = own + i;                                              dst[1] = (size_t)(p - PX) * TILE_STRIDE + HALO_ROW + i;
-      on[2] = lane == 32 && fDL != 0; src[2] = own;                                    dst[2] = (size_t)(p - PX - 1) * TILE_STRIDE + HALO_ROW + TILE_DIM;
-    }
-    tsd_cell_t tv[3]; w_cell_t wv_[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) { const size_t sk = on[k] ? src[k] : own; tv[k] = g.tsd[sk]; wv_[k] = g.weight[sk]; }      // (unconditional: see the flags)
-#pragma unroll
-    for (int k = 0; k < 3; k++) if (on[k]) { g.tsd[dst[k]] = tv[k]; g.weight[dst[k]] = wv_[k]; }
+    const uint32_t entry = li < n_u ? ((li == wv) ? first : h.list_h[li]) : h.list[(unsigned)g.tiles - 1u - (li - n_u)];
+    halo_tile_job(g, h.dirty, h.tile_rec, entry, lane);
   }
 }
 
@@ -1083,7 +1016,7 @@ int launch_push_tables_batch(tsd_ctx* ctx, hipStream_t stream, const TablesBatch
 
 // the tables of this scan must already be in ctx->d_rmq (launch_push_tables, ordered before this)
 int launch_push(tsd_ctx* ctx, const PushArgs& a, double cx, double cy, double slack, const PushArgs* a_dev,
-                const double* d_ranges, const uint8_t* d_mask, hipStream_t stream_arg)
+                const double* d_ranges, const uint8_t* d_mask, hipStream_t stream_arg, HaloArgs* defer_halo)
 {
   const hipStream_t stream = stream_arg ? stream_arg : ctx->stream;
   const GridDev& g = ctx->grid;
@@ -1142,15 +1075,28 @@ int launch_push(tsd_ctx* ctx, const PushArgs& a, double cx, double cy, double sl
                        rmq_view(rmq, a.beams).bdir, rmq_view(rmq, a.beams).rot, ctx->d_icp_trace);
   }
   TSD_HIP_CHECK(ctx, hipGetLastError());
+  HaloArgs h;
+  h.dirty = ctx->d_dirty; h.pushes = ctx->d_pushes; h.a_dev = a_dev; h.list = ctx->d_list; h.list_h = ctx->d_list_h; h.tile_rec = ctx->d_tile_rec;
+  h.cnt = ctx->d_list_cnt + CNT_WORDS * parity; h.cx = cx; h.cy = cy; h.slack = slack + g.cs; h.on = 1;
+  if (defer_halo) {
+    // (the caller launches the ray cast that carries this pass -- launch_raycast(.., &halo) -- right behind this push, or, if it cannot,
+    // launch_push_halo(): the grid's halos are not consistent until one of the two has run)
+    *defer_halo = h;
+    return TSD_OK;
+  }
+  return launch_push_halo(ctx, h, n_window, stream);
+}
+
+int launch_push_halo(tsd_ctx* ctx, const HaloArgs& h, int n_window, hipStream_t stream)
+{
   {
     ScopedKernelTimer t(ctx, "push_halo");
     // one wave per tile of the halo list (tiles materialised / emptied / written by freeFootprint: a few dozen per push once the map
     // stands, every tile of the window in the first push); a longer list is looped over.  (Round 4 launched one wave per WINDOW tile:
     // 6 745 waves to move 0.35 MB at cfg 2.)
     constexpr int HALO_WAVES = 2048;
-    const int n_waves = n_window < HALO_WAVES ? n_window : HALO_WAVES;
-    hipExtLaunchKernelGGL(k_push_halo, dim3((n_waves + 3) / 4), dim3(256), 0, stream, t.a, t.b, 0, g, ctx->d_dirty, ctx->d_pushes,
-                       a_dev, ctx->d_list, ctx->d_list_h, ctx->d_tile_rec, ctx->d_list_cnt, parity, cx, cy, slack + g.cs);
+    const int n_waves = n_window < HALO_WAVES ? (n_window < 1 ? 1 : n_window) : HALO_WAVES;
+    hipExtLaunchKernelGGL(k_push_halo, dim3((n_waves + 3) / 4), dim3(256), 0, stream ? stream : ctx->stream, t.a, t.b, 0, ctx->grid, h);
   }
   TSD_HIP_CHECK(ctx, hipGetLastError());
   return TSD_OK;

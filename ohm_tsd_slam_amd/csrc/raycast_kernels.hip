@@ -23,7 +23,7 @@
 // TsdGrid::interpolateNormal (TsdGrid.cpp:517-546) run on 4 lanes.
 //
 // Latency-bound gather (L2 / Infinity-Cache resident tiles): reported as time, not as a roofline.
-#include "tsd_ctx.hpp"
+#include "push_device.hpp"
 #include <cstring>
 
 namespace tsd {
@@ -31,6 +31,7 @@ namespace tsd {
 constexpr int RC_S = 4;            // steps per lane and round (256 steps per round)
 constexpr int RC_MAXSEG = 16;
 constexpr int RC_BLK = 15;         // steps per block of the fine march (one group of 16 lanes; < one tile)
+constexpr int RC_HALO_WAVES = 128; // k_raycast_halo: waves ahead of the beams' that do the preceding push's halo pass (one listed tile at a time each)
 
 struct RcSeg { double anchor, rhat; int n0, pad; };
 
@@ -166,11 +167,81 @@ __device__ __forceinline__ double seg_value(const RcSeg* seg, int nseg, int k)
   return fma((double)(k - seg[s].n0), seg[s].rhat, seg[s].anchor);
 }
 
-// one wave = one beam; shared by k_raycast (one sensor per launch) and k_raycast_batch (block row y = sensor y of a batch)
+// the four cells of a bilinear look-up, read at agent scope (`sc1`: past this compute unit's L1): the halo cells among them may have been
+// written by another wave of the same launch (HALO below)
+__device__ __forceinline__ double ld_tsd_agent(const tsd_cell_t* p)
+{
+#ifdef TSD_STORAGE_Q32
+  const int32_t q = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return q == Q_NAN ? __builtin_nan("") : ldexp((double)q, -30);
+#else
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+template <bool HALO>
+__device__ __forceinline__ Quad load_quad_rc(const tsd_cell_t* __restrict__ tile, int lx, int ly)
+{
+  if constexpr (!HALO) return load_quad(tile, lx, ly);
+#ifdef TSD_RC_HALO_PLAIN      // (A/B only: the cells by plain reads behind the wait)
+  return load_quad(tile, lx, ly);
+#endif
+  Quad q;
+  q.t00 = ld_tsd_agent(tile + cell_off(lx, ly));     q.t01 = ld_tsd_agent(tile + cell_off(lx + 1, ly));
+  q.t10 = ld_tsd_agent(tile + cell_off(lx, ly + 1)); q.t11 = ld_tsd_agent(tile + cell_off(lx + 1, ly + 1));
+  return q;
+}
+
+// interpolate_bilinear (tsd_device.hpp) with the cells read the launch's way (the serial chain's look-ups)
+template <bool HALO>
+__device__ __forceinline__ int interpolate_bilinear_rc(const GridDev& g, double x, double y, double& tsd)
+{
+  if constexpr (!HALO) return interpolate_bilinear(g, x, y, tsd);
+  int p, lx, ly; double dx, dy;
+  if (!coord2cell(g, x, y, p, lx, ly, dx, dy)) return INTERP_INVALIDINDEX;
+  if (!g.flags[p]) return INTERP_EMPTYPARTITION;
+  const double wx = fabs((x - dx) * g.inv_cs), wy = fabs((y - dy) * g.inv_cs);
+  const Quad q = load_quad_rc<true>(g.tsd + (size_t)p * TILE_STRIDE, lx, ly);
+  tsd = q.t00 * (1. - wy) * (1. - wx) + q.t10 * wy * (1. - wx) + q.t01 * (1. - wy) * wx + q.t11 * wy * wx;
+  if (isnan(tsd)) return INTERP_ISNAN;
+  return INTERP_SUCCESS;
+}
+
+// one wave = one beam; shared by k_raycast (one sensor per launch) and k_raycast_batch (block row y = sensor y of a batch).
+// HALO (the fused scan's ray cast, launched right behind a push that left its halo pass to it: launch_push(.., defer_halo)): the first
+// waves of the launch do TsdGrid::propagateBorders for the push's listed tiles before they cast -- one wave per tile, destination cells
+// stored write-through, `s_waitcnt vmcnt(0)`, one agent-scope add of the entries done to the push's counter -- and EVERY wave waits for
+// that counter to reach the list's length before its first read of a cell (the clipping, the coarse traversal over the tiles' flags
+// and the position tables, ~3 us, come first: by then the pass is done as a rule).  No wave of the launch has read a cell before the
+// pass is complete, so no stale line of a halo can sit in any L1 or L2; the cells are read `sc1` all the same (the hand-off's form in
+// MI355X_MICROARCH.md: sc1 stores, drained, a counter add per storing wave, an sc1 poll, sc1 loads).  What it saves: k_push_halo's
+// launch (4.3 us: a chain of three memory round trips for a few dozen tiles) and the kernel boundary in front of it.
+template <bool HALO>
 __device__ __forceinline__ void
 raycast_beam(const GridDev& g, const RaycastArgs& a_val, const RaycastArgs* __restrict__ a_dev, const double* __restrict__ rays,
-             double* __restrict__ coords, double* __restrict__ normals, uint8_t* __restrict__ mask, double* dbg)
+             double* __restrict__ coords, double* __restrict__ normals, uint8_t* __restrict__ mask, double* dbg, const HaloArgs* hp = nullptr)
 {
+  unsigned int halo_n = 0u;
+  if constexpr (HALO) {
+    const HaloArgs& h = *hp;
+    const unsigned int n_u = h.cnt[CNT_H];
+    halo_n = n_u + h.cnt[CNT_O];
+    if (blockIdx.x < (unsigned)RC_HALO_WAVES) {
+      // one of the launch's RC_HALO_WAVES extra waves, at the FRONT of the grid (dispatched first): the pass, no beam
+      const unsigned int wv = blockIdx.x, lane_h = threadIdx.x;
+      const uint32_t first = h.list_h[wv];                      // speculative: arrives with the list lengths
+      if (wv == 0 && lane_h == 0) halo_bookkeeping(h.pushes, h.a_dev, h.cx, h.cy, h.slack);
+      unsigned int mine = 0u;
+      for (unsigned int li = wv; li < halo_n; li += (unsigned)RC_HALO_WAVES) {
+        const uint32_t entry = li < n_u ? ((li == wv) ? first : h.list_h[li]) : h.list[(unsigned)g.tiles - 1u - (li - n_u)];
+        halo_tile_job(g, h.dirty, h.tile_rec, entry, (int)lane_h);
+        mine++;
+      }
+      if (mine) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's halo cells have left for memory ...
+        if (lane_h == 0) __hip_atomic_fetch_add(h.cnt + CNT_HDONE, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // ... before it says so
+      }
+      return;
+    }
+  }
 #ifdef TSD_RC_STAMPS   // diagnostic build: cycles per phase summed over beams into dbg[0..7], max beam total in dbg[8]
   long long st_t = clock64(); const long long st_begin = st_t;
 #define RSTAMP(i) do { const long long now_ = clock64(); if (threadIdx.x == 0 && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 128) dbg[(blockIdx.x >> 3) * 8 + i] = (double)(now_ - st_t); st_t = now_; } while (0)
@@ -178,7 +249,7 @@ raycast_beam(const GridDev& g, const RaycastArgs& a_val, const RaycastArgs* __re
 #define RSTAMP(i) do {} while (0)
 #endif
   const RaycastArgs a = a_dev ? *a_dev : a_val;
-  const int beam = blockIdx.x;
+  const int beam = (int)blockIdx.x - (HALO ? RC_HALO_WAVES : 0);
   const int lane = threadIdx.x;
   if (beam >= a.beams) return;
   __shared__ RcSeg s_segx[RC_MAXSEG], s_segy[RC_MAXSEG];
@@ -274,6 +345,24 @@ raycast_beam(const GridDev& g, const RaycastArgs& a_val, const RaycastArgs* __re
   }
   __syncthreads();
   RSTAMP(1);
+  // HALO: no cell has been read so far (tile flags only), and none is before this has returned: from then on the push's halos stand.
+  // Called right ahead of the wave's first cell read -- behind the position tables and the first chunk's mask culling (negmask words,
+  // not cells), which is where the pass's own chain (list -> flags -> cells -> stores drained -> counter) has usually ended.
+  // (`seen`: a reading of the counter the caller requested earlier, together with reads it had to make anyway -- the wait is then no
+  // memory round trip of its own when the pass has ended, which is the rule)
+  bool halo_waited = !HALO || halo_n == 0u;
+  auto halo_peek = [&]() -> unsigned int {
+    if constexpr (HALO) { if (!halo_waited) return __hip_atomic_load(hp->cnt + CNT_HDONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    return 0u;
+  };
+  auto halo_wait = [&](unsigned int seen) {
+    if constexpr (HALO) {
+      if (!halo_waited) {
+        while (seen < halo_n) { __builtin_amdgcn_s_sleep(4); seen = __hip_atomic_load(hp->cnt + CNT_HDONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        halo_waited = true;
+      }
+    }
+  };
   const int nsteps = closed ? nsteps_i : 0;
 
 
@@ -346,6 +435,7 @@ raycast_beam(const GridDev& g, const RaycastArgs& a_val, const RaycastArgs* __re
     for (int chunk = 0; chunk * 64 < nblk && !found && !ended; chunk++) {
       // which of this chunk's 64 blocks can hold an event
       const int bq = chunk * 64 + lane;
+      const unsigned int halo_seen = halo_peek();              // (requested with the culling's mask reads below)
       bool cand = false;
       if (bq < nblk) {
         const int k0 = bq * RC_BLK, k1 = k0 + RC_BLK < nsteps ? k0 + RC_BLK : nsteps;
@@ -358,6 +448,7 @@ raycast_beam(const GridDev& g, const RaycastArgs& a_val, const RaycastArgs* __re
 #endif
       if (cand) s_blk[__popcll(m_cand & ((1ull << lane) - 1ull))] = bq;
       __syncthreads();
+      if (n_cand) halo_wait(halo_seen);
       for (int r0 = 0; r0 < n_cand && !found && !ended; r0 += 4 * RC_S) {
         double qx[RC_S], qy[RC_S], v[RC_S];
         bool act[RC_S];
@@ -387,7 +478,7 @@ raycast_beam(const GridDev& g, const RaycastArgs& a_val, const RaycastArgs* __re
           fl[j] = 0; qv[j].t00 = qv[j].t01 = qv[j].t10 = qv[j].t11 = 0.0;
           if (r0 + 4 * j >= n_cand) continue;                   // (wave-uniform)
           fl[j] = ld_pinned(&g.flags[tp[j]]);                   // (pinned, like the quad's reads: one memory round trip for the five)
-          qv[j] = load_quad(g.tsd + (size_t)tp[j] * TILE_STRIDE, lxy[j] & 0xFF, lxy[j] >> 8);
+          qv[j] = load_quad_rc<HALO>(g.tsd + (size_t)tp[j] * TILE_STRIDE, lxy[j] & 0xFF, lxy[j] >> 8);
         }
 #pragma unroll
         for (int j = 0; j < RC_S; j++) {
@@ -431,10 +522,11 @@ raycast_beam(const GridDev& g, const RaycastArgs& a_val, const RaycastArgs* __re
 #endif
   } else {
     // serial chain (rare): 64 steps per round, positions by the reference's own additions
+    halo_wait(halo_peek());
     double carry;                                           // sample of the previous step (NaN = none)
     {
       double t0;
-      carry = (interpolate_bilinear(g, px0, py0, t0) == INTERP_SUCCESS) ? t0 : __builtin_nan("");
+      carry = (interpolate_bilinear_rc<HALO>(g, px0, py0, t0) == INTERP_SUCCESS) ? t0 : __builtin_nan("");
     }
     double px = px0, py = py0;
     double i_run = idxMin;
@@ -450,7 +542,7 @@ raycast_beam(const GridDev& g, const RaycastArgs& a_val, const RaycastArgs* __re
       double cur = __builtin_nan("");
       if (my_act) {
         double t;
-        if (interpolate_bilinear(g, mx, my, t) == INTERP_SUCCESS) cur = t;
+        if (interpolate_bilinear_rc<HALO>(g, mx, my, t) == INTERP_SUCCESS) cur = t;
       }
       double prev = __shfl_up(cur, 1, 64);
       if (lane == 0) prev = carry;
@@ -481,6 +573,7 @@ raycast_beam(const GridDev& g, const RaycastArgs& a_val, const RaycastArgs* __re
   if (!found) { if (lane == 0) mask[beam] = 0; return; }
 
   // TsdGrid::interpolateNormal: lanes 0..3 sample (x+cs,y) (x-cs,y) (x,y+cs) (x,y-cs)
+  halo_wait(halo_peek());                                    // (a hit was sampled: long done)
   double sx = hit_x, sy = hit_y;
   if (lane == 0) sx = hit_x + cs;
   else if (lane == 1) sx = hit_x - cs;
@@ -494,7 +587,7 @@ raycast_beam(const GridDev& g, const RaycastArgs& a_val, const RaycastArgs* __re
     okn = coord2cell(g, sx, sy, p, lx, ly, dx, dy);
     if (okn) {
       const uint8_t f = ld_pinned(&g.flags[p]);
-      const Quad q = load_quad(g.tsd + (size_t)p * TILE_STRIDE, lx, ly);
+      const Quad q = load_quad_rc<HALO>(g.tsd + (size_t)p * TILE_STRIDE, lx, ly);
       const double wx = fabs((sx - dx) * g.inv_cs), wy = fabs((sy - dy) * g.inv_cs);
       v = q.t00 * (1. - wy) * (1. - wx) + q.t10 * wy * (1. - wx) + q.t01 * (1. - wy) * wx + q.t11 * wy * wx;
       okn = f != 0 && !isnan(v);
@@ -528,7 +621,14 @@ __global__ void __launch_bounds__(64)
 k_raycast(GridDev g, RaycastArgs a_val, const RaycastArgs* __restrict__ a_dev, const double* __restrict__ rays,
           double* __restrict__ coords, double* __restrict__ normals, uint8_t* __restrict__ mask, double* dbg)
 {
-  raycast_beam(g, a_val, a_dev, rays, coords, normals, mask, dbg);
+  raycast_beam<false>(g, a_val, a_dev, rays, coords, normals, mask, dbg);
+}
+// the ray cast right behind a push of the fused scan: carries that push's halo pass (see raycast_beam<true>)
+__global__ void __launch_bounds__(64)
+k_raycast_halo(GridDev g, RaycastArgs a_val, const RaycastArgs* __restrict__ a_dev, const double* __restrict__ rays,
+               double* __restrict__ coords, double* __restrict__ normals, uint8_t* __restrict__ mask, double* dbg, HaloArgs halo)
+{
+  raycast_beam<true>(g, a_val, a_dev, rays, coords, normals, mask, dbg, &halo);
 }
 
 // the ray casts of a batch of sensors on one grid in ONE launch (tsd_batch_begin): blockIdx.y picks the sensor
@@ -538,7 +638,7 @@ k_raycast_batch(GridDev g, const RaycastBatchEntry* __restrict__ entries, double
   const RaycastBatchEntry e = entries[blockIdx.y];
   RaycastArgs none;
   none.beams = 0;
-  raycast_beam(g, none, e.a_dev, e.rays, e.coords, e.normals, e.mask, dbg);
+  raycast_beam<false>(g, none, e.a_dev, e.rays, e.coords, e.normals, e.mask, dbg);
 }
 
 // the same with the entries as kernel arguments: the launch does not depend on the batch's copy of its argument tables
@@ -548,7 +648,7 @@ k_raycast_batch_args(GridDev g, RaycastBatchArgs args, double* dbg)
   const RaycastBatchEntry e = args.e[blockIdx.y];
   RaycastArgs none;
   none.beams = 0;
-  raycast_beam(g, none, e.a_dev, e.rays, e.coords, e.normals, e.mask, dbg);
+  raycast_beam<false>(g, none, e.a_dev, e.rays, e.coords, e.normals, e.mask, dbg);
 }
 
 int launch_raycast_batch_byval(tsd_ctx* ctx, hipStream_t stream, const RaycastBatchEntry* h_entries, int n, int max_beams)
@@ -570,12 +670,17 @@ int launch_raycast_batch(tsd_ctx* ctx, hipStream_t stream, const RaycastBatchEnt
   return TSD_OK;
 }
 
-int launch_raycast(tsd_ctx* ctx, const RaycastArgs& a, const RaycastArgs* a_dev, const double* d_rays)
+int launch_raycast(tsd_ctx* ctx, const RaycastArgs& a, const RaycastArgs* a_dev, const double* d_rays, const HaloArgs* halo)
 {
   ScopedKernelTimer t(ctx, "raycast");
   const LaunchTarget* tg = launch_target();       // concurrent multi-robot path: the sensor's own stream and output buffers
   hipEvent_t stop = t.b;
   if (tg && tg->rc_done && !t.b) { stop = tg->rc_done; const_cast<LaunchTarget*>(tg)->rc_done_used = true; }
+  if (halo)
+    hipExtLaunchKernelGGL(k_raycast_halo, dim3(a.beams + RC_HALO_WAVES), dim3(64), 0, launch_stream(ctx), t.a, stop, 0, ctx->grid, a, a_dev, d_rays ? d_rays : ctx->d_rays,
+                       tg && tg->coords ? tg->coords : ctx->d_coords, tg && tg->normals ? tg->normals : ctx->d_normals,
+                       tg && tg->mask_m ? tg->mask_m : ctx->d_mask_m, ctx->d_icp_trace, *halo);
+  else
   hipExtLaunchKernelGGL(k_raycast, dim3(a.beams), dim3(64), 0, launch_stream(ctx), t.a, stop, 0, ctx->grid, a, a_dev, d_rays ? d_rays : ctx->d_rays,
                      tg && tg->coords ? tg->coords : ctx->d_coords, tg && tg->normals ? tg->normals : ctx->d_normals,
                      tg && tg->mask_m ? tg->mask_m : ctx->d_mask_m, ctx->d_icp_trace);

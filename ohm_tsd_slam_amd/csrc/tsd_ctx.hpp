@@ -407,8 +407,13 @@ bool kernel_is_timed(const tsd_ctx* ctx, const char* name);
 // per-file launchers.  The *_dev pointers are the fused scan path: the kernels then read their pose
 // dependent arguments from the device-resident sensor state instead of the by-value copy.
 // (cx, cy) is where the host knows the sensor to be and `slack` how far the device-side pose may be from it
+// defer_halo != nullptr: k_push_halo is NOT launched; *defer_halo receives its arguments for the ray cast that follows the push and
+// carries that pass in its prologue (launch_raycast(.., halo)) -- or for launch_push_halo() where no such ray cast follows
+struct HaloArgs;
 int launch_push(tsd_ctx* ctx, const PushArgs& a, double cx, double cy, double slack, const PushArgs* a_dev = nullptr,
-                const double* d_ranges = nullptr, const uint8_t* d_mask = nullptr, hipStream_t stream = nullptr /* nullptr: ctx->stream */);
+                const double* d_ranges = nullptr, const uint8_t* d_mask = nullptr, hipStream_t stream = nullptr /* nullptr: ctx->stream */,
+                HaloArgs* defer_halo = nullptr);
+int launch_push_halo(tsd_ctx* ctx, const HaloArgs& h, int n_window = 2048, hipStream_t stream = nullptr);
 int launch_push_tables(tsd_ctx* ctx, hipStream_t stream, int beams, const double* d_ranges, const uint8_t* d_mask,
                        double phi_min, double ang_res);
 size_t push_rmq_bytes(int beams);
@@ -424,7 +429,8 @@ int launch_neg_scan(tsd_ctx* ctx);
 int launch_export_tiles(tsd_ctx* ctx, int t0, int n, double* d_t, double* d_w);
 int launch_import_tiles(tsd_ctx* ctx, int t0, int n, const double* d_t, const double* d_w);
 int launch_grid_digest(tsd_ctx* ctx, unsigned long long* d_out, double* d_sums);
-int launch_raycast(tsd_ctx* ctx, const RaycastArgs& a, const RaycastArgs* a_dev = nullptr, const double* d_rays = nullptr);
+int launch_raycast(tsd_ctx* ctx, const RaycastArgs& a, const RaycastArgs* a_dev = nullptr, const double* d_rays = nullptr,
+                   const HaloArgs* halo = nullptr /* the push right ahead of this launch left its halo pass to it */);
 int launch_icp(tsd_ctx* ctx, const IcpArgs& a, const double* P_dev = nullptr, const double* d_rays_local = nullptr,
                const double* d_ranges = nullptr, const uint8_t* d_mask = nullptr, const ScanPostArgs* post = nullptr);
 int launch_icp_pairs(tsd_ctx* ctx, const IcpArgs& a, int* d_pairs);
