@@ -3,6 +3,7 @@
 // batched form (tsd_batch_*: one launch of each kernel for the robots of a batch).
 #include "capi_internal.hpp"
 #include "push_device.hpp"
+#include "tsdpdf_device.hpp"
 #if defined(__x86_64__)
 #include <immintrin.h>
 #endif
@@ -146,6 +147,7 @@ void tsd_sensor_destroy(tsd_sensor* s)
       hipEventDestroy(s->ev_slot_push[i]);
     }
   if (s->d_pre) hipFree(s->d_pre);
+  if (s->d_pre_flag) hipFree(s->d_pre_flag);
   if (s->h_pre) hipHostFree(s->h_pre);
   hipFree(s->d_rmq2[0]); hipFree(s->d_rmq2[1]); hipFree(s->d_rmq2[2]);
   for (int i = 0; i < 3; i++) { if (s->h_scan3[i]) hipHostFree(s->h_scan3[i]); if (s->ev_scan_copy[i]) hipEventDestroy(s->ev_scan_copy[i]); }
@@ -431,6 +433,9 @@ int tsd_scan_submit(tsd_sensor* s, const double* ranges, const uint8_t* mask, co
   // registration_mode 3: the pre-registration armed by tsd_scan_preregister runs here, between the ray cast and the registration,
   // whose Tinit it leaves on the device
   s->pre_ran = false;
+  IcpPreLaunch prel;
+  std::memset(&prel, 0, sizeof(prel));
+  bool fold_argmax = false;
   if (s->pre_armed) {
     s->pre_armed = false;
     // (asynchronous mapping: the SCORING reads the grid -- the previous scan's push, still on the push stream, has to land first; the
@@ -439,8 +444,11 @@ int tsd_scan_submit(tsd_sensor* s, const double* ranges, const uint8_t* mask, co
     hipEvent_t before_score = nullptr;
     if (ctx->async_pending) { before_score = ctx->ev_async_push; ctx->async_pending = false; }
     const LaunchTarget* tgp = launch_target();
+    // (the node's registration shape: the arg-max rides with the registration's launch -- TSD_PDF_ARGMAX_KERNEL=1: as a kernel, A/B)
+    static const bool argmax_kernel = [] { const char* e = std::getenv("TSD_PDF_ARGMAX_KERNEL"); return e && *e == '1'; }();
+    fold_argmax = !argmax_kernel && icp_pre_supported(ctx, ia);
     rc = launch_preregistration(ctx, s, launch_stream(ctx), tgp && tgp->coords ? tgp->coords : ctx->d_coords,
-                                tgp && tgp->mask_m ? tgp->mask_m : ctx->d_mask_m, s->d_state->icpP, &ia.Tinit_dev, before_score);
+                                tgp && tgp->mask_m ? tgp->mask_m : ctx->d_mask_m, s->d_state->icpP, &ia.Tinit_dev, before_score, fold_argmax ? &prel : nullptr);
     if (rc != TSD_OK) return rc;
     s->pre_ran = true;
   }
@@ -464,13 +472,13 @@ int tsd_scan_submit(tsd_sensor* s, const double* ranges, const uint8_t* mask, co
     TSD_HIP_CHECK(ctx, hipGetLastError());
   }
   if (icp_from_host) {
-    rc = launch_icp(ctx, ia, s->d_state->icpP, s->d_rays_local, s->st_h_ranges, s->st_h_mask, &sp);
+    rc = launch_icp(ctx, ia, s->d_state->icpP, s->d_rays_local, s->st_h_ranges, s->st_h_mask, &sp, fold_argmax ? &prel : nullptr);
     if (rc != TSD_OK) return rc;
     rc = scan_stage_device(s);
     if (rc != TSD_OK) return rc;
   } else {
     if (!s->scan_bar && !host_saw_event(ctx->ev_h2d, staged_ahead ? 2 : 40)) TSD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_h2d, 0));
-    rc = launch_icp(ctx, ia, s->d_state->icpP, s->d_rays_local, d_ranges, d_mask, &sp);
+    rc = launch_icp(ctx, ia, s->d_state->icpP, s->d_rays_local, d_ranges, d_mask, &sp, fold_argmax ? &prel : nullptr);
     if (rc != TSD_OK) return rc;
   }
   lap.lap(3);

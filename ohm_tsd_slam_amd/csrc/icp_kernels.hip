@@ -33,6 +33,7 @@
 //
 // No dense contraction anywhere => no MFMA; fp64 VALU + LDS.  Latency-bound: reported as ms/iterate.
 #include "scan_device.hpp"
+#include "tsdpdf_device.hpp"
 #include <atomic>
 #include <climits>
 #include <cstring>
@@ -568,7 +569,9 @@ __device__ __forceinline__ void block_totals8(const IcpLds& L, const double (&v)
 // PAIRS (parity / debug instantiation, tsd_icp_pairs): the scene is NOT moved between the steps and every step's surviving pair list
 // is written out -- the repeated PairAssignment::determinePairs calls on a static scene that the compiled reference's chain
 // (PairAssignment.cpp:38-84 -> DistanceFilter -> ReciprocalFilter) is driven with in tests/golden/ref_chain_pairs.npz.
-template <int R, int MAXT, bool PTL, bool PAIRS = false, int FCAP = 0, int FT = 0>
+// PRE (fused registration_mode 3, k_icp_pre): Tinit is not read from memory at the top but taken from the launch's own arg-max workgroup
+// when the set-up first needs it (tsdpdf_device.hpp).
+template <int R, int MAXT, bool PTL, bool PAIRS = false, int FCAP = 0, int FT = 0, bool PRE = false>
 __device__ __forceinline__ void
 icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const double* __restrict__ g_model, const double* __restrict__ g_scene,
       const int* __restrict__ g_morig, const int* __restrict__ g_start,
@@ -578,7 +581,8 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
       double* __restrict__ trace /* [TSD_ICP_TRACE_MAX][TSD_ICP_TRACE_STRIDE] = pairs, rms, thr_before, state, Tlast (co, si, dX, dY) */, const ScanPostArgs& post,
       const double* __restrict__ g_mnormals /* direct mode */, const double* __restrict__ g_normals /* fused: ray cast */,
       const IcpSeedArgs seed = IcpSeedArgs{nullptr, 0u, 0, 0}, const int role = 0 /* 0: the registration; h > 0: helper h of step 0's searches */,
-      int* __restrict__ pairs_out = nullptr /* PAIRS: [steps][cap] winning scene index per model slot, preset to -1 */)
+      int* __restrict__ pairs_out = nullptr /* PAIRS: [steps][cap] winning scene index per model slot, preset to -1 */,
+      const IcpPreArgs* __restrict__ prep = nullptr /* PRE */)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef TSD_ICP_TIMELINE
@@ -641,9 +645,11 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
 #pragma unroll
     for (int i = 0; i < 6; i++) a.P[i] = P_dev[i];
   }
-  if (a.Tinit_dev) {   // fused registration_mode 3: so does Tinit (k_pdf_argmax's result, the kernel right before this one)
+  if constexpr (!PRE) {
+    if (a.Tinit_dev) {   // fused registration_mode 3: so does Tinit (k_pdf_argmax's result, the kernel right before this one)
 #pragma unroll
-    for (int i = 0; i < 6; i++) a.Tinit[i] = a.Tinit_dev[i];
+      for (int i = 0; i < 6; i++) a.Tinit[i] = a.Tinit_dev[i];
+    }
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int T = FT ? FT : (int)blockDim.x, W = T >> 6;
@@ -689,6 +695,26 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
       if (lane == 0) { cnts[(q * W + wave) * 2] = __popcll(bm[q]); cnts[(q * W + wave) * 2 + 1] = __popcll(bs[q]); }
     }
     __syncthreads();
+    if constexpr (PRE) {
+      // Tinit, first needed here (the scene's points below): the launch's arg-max workgroup hands TBest's two rows over as twelve tagged
+      // granules (tsdpdf_device.hpp), re-read at agent scope (sc1) until every one carries this launch's number.  Its chain (scores and
+      // candidates -> reduction -> the winner's two points -> sine and cosine) is about as long as this workgroup's way here, so the wait
+      // is short; bounded all the same (1 ms of the 100 MHz clock: the first workgroup of a grid cannot fail to run).
+      const long long t0w = wall_clock64();
+      const unsigned long long* gr = reinterpret_cast<const unsigned long long*>(prep->flag);
+      unsigned long long gv[12];
+      for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < 12; i++) gv[i] = __hip_atomic_load(gr + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int i = 0; i < 12; i++) ok &= (unsigned int)(gv[i] >> 32) == prep->seq;
+        if (ok || wall_clock64() - t0w > 100000) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+#pragma unroll
+      for (int i = 0; i < 6; i++) a.Tinit[i] = __longlong_as_double((long long)((gv[2 * i] & 0xFFFFFFFFull) | (gv[2 * i + 1] << 32)));
+    }
     const unsigned long long lt = (1ull << lane) - 1ull;
     int runM = 0, runS = 0;
 #pragma unroll
@@ -1453,6 +1479,23 @@ k_icp(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __rest
                               post, g_mnormals, g_normals, seed, (int)blockIdx.x);
 }
 
+// registration_mode 3 inside the fused scan: workgroup 0 is the pre-registration's ARG-MAX (its own kernel, k_pdf_argmax, everywhere else:
+// 5.2 us + a kernel boundary between the scoring and the registration), workgroup 1 registers, workgroups 2 .. are step 0's helpers.
+// The registering workgroup's set-up needs Tinit ~2.5 us in, about when the arg-max has it.
+template <int R, int MAXT, int FCAP, int FT>
+__global__ void __launch_bounds__(MAXT)
+k_icp_pre(IcpArgs a, const double* __restrict__ P_dev, int cap, const double* __restrict__ g_coords, const uint8_t* __restrict__ g_mask_m,
+          const double* __restrict__ g_rays_local, const double* __restrict__ g_ranges, const uint8_t* __restrict__ g_mask,
+          IcpResultDev* __restrict__ out, double* __restrict__ trace, ScanPostArgs post, IcpSeedArgs seed, IcpPreArgs pre)
+{
+  if (blockIdx.x == 0) {
+    pdf_argmax_body<3>(pre.am.prob, pre.am.cand, pre.am.max_cand, pre.am.M, pre.am.S, pre.am.out, pre.am.hdr, pre.am.host_hdr, pre.am.host_res, pre.flag, pre.seq);
+    return;
+  }
+  icp_workgroup<R, MAXT, false, false, FCAP, FT, true>(a, P_dev, cap, nullptr, nullptr, nullptr, nullptr, g_coords, g_mask_m, g_rays_local, g_ranges, g_mask, out, trace,
+                                                     post, nullptr, nullptr, seed, (int)blockIdx.x - 1, nullptr, &pre);
+}
+
 // the same kernel with the per-step pair lists written out and the scene held still (direct mode, closed form): tsd_icp_pairs
 template <int R, int MAXT>
 __global__ void __launch_bounds__(MAXT)
@@ -1551,7 +1594,7 @@ static int icp_threads_for(int n, int R, int maxt)
 template <int R, int MAXT, bool PTL>
 static int launch_icp_shape_est(tsd_ctx* ctx, const IcpArgs& a, int n, int cap, const double* P_dev,
                             const double* d_rays_local, const double* d_ranges, const uint8_t* d_mask,
-                            const ScanPostArgs& post, int force_T = 0)
+                            const ScanPostArgs& post, int force_T = 0, const IcpPreLaunch* pre = nullptr)
 {
   int T = icp_threads_for(n, R, MAXT);
   if (force_T > T) T = force_T;
@@ -1584,6 +1627,28 @@ static int launch_icp_shape_est(tsd_ctx* ctx, const IcpArgs& a, int n, int cap, 
   // The default scanner's shape (1081 beams: capacity 1088, 512 threads, closed form) has an instantiation of its own in which the
   // capacity and the thread count are compile-time constants: the twenty offsets of the LDS layout then cost no scalar registers
   // (spilled scalars of the loop 166 -> 56; -0.7 us per registration, profiles/r5_icp_helpers_ab.txt)
+  if (pre) {
+    // fused registration_mode 3, the node's shape (icp_pre_supported): the arg-max rides as the launch's first workgroup
+    if (!(R == 3 && MAXT == 512 && !PTL && cap == 1088 && T == 512) || !post.st) return set_error(ctx, TSD_E_ARG, "launch_icp: the arg-max can only ride with the node's registration shape", hipSuccess);
+    {
+      std::lock_guard<std::mutex> lk_misc(ctx->misc_mutex);
+      size_t& configured = ctx->lds_configured[reinterpret_cast<const void*>(k_icp_pre<3, 512, 1088, 512>)];
+      if (lds > configured) {
+        TSD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_icp_pre<3, 512, 1088, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = lds;
+      }
+    }
+    // (the launch's own completion is the event a pre-registration armed AHEAD waits for before it overwrites the inputs; a timed
+    // dispatch needs its stop event for the timer: a marker behind it then)
+    hipEvent_t stop = t.b ? t.b : pre->done;
+    hipExtLaunchKernelGGL((k_icp_pre<3, 512, 1088, 512>), dim3(2 + sa.helpers), dim3(T), lds, launch_stream(ctx), t.a, stop, 0, a, P_dev, cap,
+                     tg && tg->coords ? tg->coords : ctx->d_coords, tg && tg->mask_m ? tg->mask_m : ctx->d_mask_m,
+                     d_rays_local ? d_rays_local : ctx->d_rays_local, d_ranges ? d_ranges : ctx->d_ranges,
+                     d_mask ? d_mask : ctx->d_mask, tg && tg->icp_res ? tg->icp_res : ctx->d_icp_res, trace_buf, post, sa, pre->dev);
+    TSD_HIP_CHECK(ctx, hipGetLastError());
+    if (t.b && pre->done) TSD_HIP_CHECK(ctx, hipEventRecord(pre->done, launch_stream(ctx)));
+    return TSD_OK;
+  }
   if (R == 3 && MAXT == 512 && !PTL && cap == 1088 && T == 512) {
     {
       std::lock_guard<std::mutex> lk_misc(ctx->misc_mutex);
@@ -1613,16 +1678,23 @@ static int launch_icp_shape_est(tsd_ctx* ctx, const IcpArgs& a, int n, int cap, 
 template <int R, int MAXT>
 static int launch_icp_shape(tsd_ctx* ctx, const IcpArgs& a, int n, int cap, const double* P_dev,
                             const double* d_rays_local, const double* d_ranges, const uint8_t* d_mask,
-                            const ScanPostArgs& post, int force_T = 0)
+                            const ScanPostArgs& post, int force_T = 0, const IcpPreLaunch* pre = nullptr)
 {
   // the estimator is a compile-time choice: the node's closed form does not pay for the other one's tenth sum
   if (a.estimator == TSD_ESTIMATOR_POINT_TO_LINE)
-    return launch_icp_shape_est<R, MAXT, true>(ctx, a, n, cap, P_dev, d_rays_local, d_ranges, d_mask, post, force_T);
-  return launch_icp_shape_est<R, MAXT, false>(ctx, a, n, cap, P_dev, d_rays_local, d_ranges, d_mask, post, force_T);
+    return launch_icp_shape_est<R, MAXT, true>(ctx, a, n, cap, P_dev, d_rays_local, d_ranges, d_mask, post, force_T, pre);
+  return launch_icp_shape_est<R, MAXT, false>(ctx, a, n, cap, P_dev, d_rays_local, d_ranges, d_mask, post, force_T, pre);
+}
+
+// can the pre-registration's arg-max ride with this registration's launch (k_icp_pre: the node's shape, closed form, fused scan)?
+bool icp_pre_supported(const tsd_ctx* ctx, const IcpArgs& a)
+{
+  if (a.beams < 1 || a.estimator != TSD_ESTIMATOR_CLOSED_FORM || ctx->icp_shape != 0) return false;
+  return icp_cap_for(a.beams) == 1088 && icp_threads_for(a.beams, 3, 512) == 512;
 }
 
 int launch_icp(tsd_ctx* ctx, const IcpArgs& a, const double* P_dev, const double* d_rays_local,
-               const double* d_ranges, const uint8_t* d_mask, const ScanPostArgs* post_in)
+               const double* d_ranges, const uint8_t* d_mask, const ScanPostArgs* post_in, const IcpPreLaunch* pre)
 {
   ScanPostArgs post;
   std::memset(&post, 0, sizeof(post));
@@ -1636,7 +1708,8 @@ int launch_icp(tsd_ctx* ctx, const IcpArgs& a, const double* P_dev, const double
   // (round 3: the experimental shapes <2,576>, <5,512> and <5,256> are gone -- measured no faster in round 2, and the first spilled
   // 21-27 registers per lane; TSD_ICP_SHAPE=8 forces the 8-points-per-thread shape, TSD_ICP_SHAPE >= 64 a thread count of <3,512>)
   if (ctx->icp_shape == 8) return launch_icp_shape<8, 256>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post);
-  if (nthr <= 3 * 512) return launch_icp_shape<3, 512>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post, ctx->icp_shape >= 64 ? ctx->icp_shape : 0);
+  if (pre && !icp_pre_supported(ctx, a)) return set_error(ctx, TSD_E_ARG, "launch_icp: the arg-max can only ride with the node's registration shape", hipSuccess);
+  if (nthr <= 3 * 512) return launch_icp_shape<3, 512>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post, ctx->icp_shape >= 64 ? ctx->icp_shape : 0, pre);
   return launch_icp_shape<8, 256>(ctx, a, nthr, cap, P_dev, d_rays_local, d_ranges, d_mask, post);
 }
 

@@ -321,6 +321,8 @@ struct tsd_sensor {
   bool pre_bar = false;       // d_pre is fine-grained device memory (tsd_sensor::scan_bar) ...
   bool pre_direct = false;    // ... and the armed inputs were stored into it by the host: nothing to copy, nothing to wait for
   bool pre_armed = false, pre_ran = false;
+  unsigned int* d_pre_flag = nullptr;        // k_icp_pre: the launch number of the last arg-max whose TBest stands (its own small allocation)
+  unsigned int pre_seq = 0;
   struct PreLayout {
     size_t off_S, off_ms, off_msp, off_dc, off_dt, in_bytes;             // inputs (host -> device each scan)
     size_t off_mo_m, off_mo_s, off_phi_m, off_phi_s, off_C, off_K, off_prob, off_hdr, off_res;
@@ -420,8 +422,10 @@ size_t push_rmq_bytes(int beams);
 size_t push_list_aux_bytes();
 // fused registration_mode 3: normals -> lists -> scoring -> arg-max on `stream`, model = the ray cast's outputs on the device;
 // *tinit_dev = where the registration kernel finds Tinit (tsdpdf.hip)
+// fold != nullptr: the arg-max is NOT launched; *fold receives what launch_icp(.., pre) needs to carry it
+struct IcpPreLaunch;
 int launch_preregistration(tsd_ctx* ctx, tsd_sensor* s, hipStream_t stream, const double* d_coords, const uint8_t* d_mask_m,
-                           const double* d_pose6, const double** tinit_dev, hipEvent_t before_score = nullptr);
+                           const double* d_pose6, const double** tinit_dev, hipEvent_t before_score = nullptr, IcpPreLaunch* fold = nullptr);
 int launch_preregistration_batch(tsd_ctx* ctx, hipStream_t stream, tsd_sensor* const* sensors, int n);
 size_t push_list_cnt_bytes();
 int launch_free_footprint(tsd_ctx* ctx, unsigned minX, unsigned maxX, unsigned minY, unsigned maxY);
@@ -431,8 +435,11 @@ int launch_import_tiles(tsd_ctx* ctx, int t0, int n, const double* d_t, const do
 int launch_grid_digest(tsd_ctx* ctx, unsigned long long* d_out, double* d_sums);
 int launch_raycast(tsd_ctx* ctx, const RaycastArgs& a, const RaycastArgs* a_dev = nullptr, const double* d_rays = nullptr,
                    const HaloArgs* halo = nullptr /* the push right ahead of this launch left its halo pass to it */);
+// pre: fused registration_mode 3 -- the pre-registration's arg-max rides as the first workgroup of the registration's launch (k_icp_pre;
+// only where icp_pre_supported() says so); pre->done is recorded when the launch has completed
+bool icp_pre_supported(const tsd_ctx* ctx, const IcpArgs& a);
 int launch_icp(tsd_ctx* ctx, const IcpArgs& a, const double* P_dev = nullptr, const double* d_rays_local = nullptr,
-               const double* d_ranges = nullptr, const uint8_t* d_mask = nullptr, const ScanPostArgs* post = nullptr);
+               const double* d_ranges = nullptr, const uint8_t* d_mask = nullptr, const ScanPostArgs* post = nullptr, const IcpPreLaunch* pre = nullptr);
 int launch_icp_pairs(tsd_ctx* ctx, const IcpArgs& a, int* d_pairs);
 int icp_pairs_cap(int n_model, int n_scene);
 int launch_scan_prepare(tsd_ctx* ctx, SensorDev* st);

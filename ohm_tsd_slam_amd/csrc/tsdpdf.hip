@@ -35,18 +35,9 @@
 #include <cstring>
 #include <mutex>
 #include <vector>
+#include "tsdpdf_device.hpp"
 
 namespace tsd {
-
-// a candidate (idx, i) of trial t: `ti` = t << 12 | i -- its place in the reference's serial order (trial-major, scene index ascending),
-// which is what the arg-max breaks ties on; the LIST order is free (k_pdf_prepare writes it in one pass, in whatever order its waves arrive)
-struct PdfCandidate { int idx, ti; double phi; };
-constexpr int PDF_I_BITS = 12, PDF_I_MASK = (1 << PDF_I_BITS) - 1;
-static_assert(TSD_MAX_BEAMS <= (1 << PDF_I_BITS), "scene index field of PdfCandidate::ti");
-struct PdfResult { double T[9]; double prob; int idx, i, candidates, pad; };
-// what k_pdf_prepare (the fused scan's device-side list building) leaves for the scoring and arg-max kernels, which the host then
-// launches without knowing the counts
-struct PdfHeader { int n_cand, n_control, n_model_valid, n_scene_valid, identity, pad[3]; };
 
 constexpr int PDF_MAX_CONTROL = 1024;      // control points held in LDS (16 KB)
 constexpr int PDF_BATCH = 4;               // look-ups per LANE in flight together (64 x 4 control points per round)
@@ -181,90 +172,6 @@ k_pdf_score_batch(GridDev g, PdfScoreBatch b)
   pdf_score_body(g, e.pose, e.M, e.S, e.control, 0, e.cand, 0, e.zrand, e.prob, e.hdr, e.max_cand, e.control_alloc);
 }
 
-// wave reductions for the arg-max: DPP row shifts inside the 16-lane rows, the four row results through scalar registers
-__device__ __forceinline__ double pdf_wave_max_nonneg(double v)            // v >= 0 in every lane (lanes without a source read 0)
-{
-#define PDF_SHR_F64(CTRL) { const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false), \
-                                      hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false); v = fmax(v, __hiloint2double(hi_, lo_)); }
-  PDF_SHR_F64(0x111) PDF_SHR_F64(0x112) PDF_SHR_F64(0x114) PDF_SHR_F64(0x118)
-#undef PDF_SHR_F64
-  auto rl = [&](int l) { return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l)); };
-  return fmax(fmax(rl(15), rl(31)), fmax(rl(47), rl(63)));
-}
-__device__ __forceinline__ int pdf_wave_min_int(int v)
-{
-  v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x111, 0xf, 0xf, false));
-  v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x112, 0xf, 0xf, false));
-  v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x114, 0xf, 0xf, false));
-  v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x118, 0xf, 0xf, false));
-  return min(min(__builtin_amdgcn_readlane(v, 15), __builtin_amdgcn_readlane(v, 31)), min(__builtin_amdgcn_readlane(v, 47), __builtin_amdgcn_readlane(v, 63)));
-}
-
-// first candidate in the reference's serial trial / i order (the key `ti`) that reaches the maximum; bestProb starts at
-// 0.0 and is replaced on `>` only (TSD_PDFMatching.cpp:188,264)
-__device__ __forceinline__ void
-pdf_argmax_body(const double* __restrict__ prob, const PdfCandidate* __restrict__ cand, int n_cand, const double* __restrict__ M,
-                const double* __restrict__ S, PdfResult* __restrict__ out, const PdfHeader* __restrict__ hdr,
-                PdfHeader* __restrict__ host_hdr, PdfResult* __restrict__ host_res /* fused scan: pinned host memory, or nullptr */)
-{
-  // A chain of dependent memory round trips by nature (header -> probabilities and candidates -> the winner's points); round 6 took one
-  // of them out: a thread keeps its best candidate's model index and angle in registers (the winner used to read its candidate again),
-  // and the reduction is one shuffle tree per wave + one barrier (it was ten barriers).
-  // (with a header, n_cand arrives as the ALLOCATION's size: the thread's first candidate is requested ahead of the header's counts)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const bool spec = hdr != nullptr && tid < n_cand;
-  const int c0 = spec ? tid : 0;
-  double p_first = 0.0, phi_first = 0.0; int idx_first = 0, ti_first = 0;
-  if (spec) { p_first = ld_pinned(&prob[c0]); idx_first = ld_pinned(&cand[c0].idx); ti_first = ld_pinned(&cand[c0].ti); phi_first = ld_pinned(&cand[c0].phi); }
-  if (hdr) n_cand = hdr->identity ? 0 : hdr->n_cand;
-  __shared__ double s_p[16];
-  __shared__ int s_o[16], s_t[16];                          // per wave: serial-order key and thread of its best
-  double bp = 0.0, bphi = 0.0; int bk = -1, bo = 0x7fffffff, bidx = 0;
-  for (int c = tid; c < n_cand; c += 1024) {
-    const bool first = spec && c == tid;
-    const double p = first ? p_first : prob[c];
-    PdfCandidate cd;
-    if (first) { cd.idx = idx_first; cd.ti = ti_first; cd.phi = phi_first; } else cd = cand[c];
-    if (p > bp || (p == bp && p > 0.0 && cd.ti < bo)) { bp = p; bk = c; bo = cd.ti; bidx = cd.idx; bphi = cd.phi; }
-  }
-  const int bci = bk >= 0 ? (bo & PDF_I_MASK) : 0;
-  // the wave's best: the largest probability (DPP row shifts, no LDS), then the earliest serial-order key among the lanes that hold it
-  // (a shuffle tree over the triple cost six dependent LDS-crossbar round trips: 1.1 us of this 5 us kernel)
-  const double wp = pdf_wave_max_nonneg(bp);
-  const bool cont = bk >= 0 && bp == wp;
-  const int wo = pdf_wave_min_int(cont ? bo : 0x7fffffff);
-  const unsigned long long wb = __ballot(cont && bo == wo);
-  const int wt = wb ? wave * 64 + (__ffsll((long long)wb) - 1) : -1;      // (keys are unique: one lane)
-  if (lane == 0) { s_p[wave] = wp; s_o[wave] = wo; s_t[wave] = wt; }
-  __syncthreads();
-  double gp = s_p[0]; int go = s_o[0], gt = s_t[0];
-#pragma unroll
-  for (int w = 1; w < 16; w++) {
-    const double p2 = s_p[w]; const int o2 = s_o[w], t2 = s_t[w];
-    if (t2 >= 0 && (p2 > gp || (p2 == gp && (gt < 0 || o2 < go)))) { gp = p2; go = o2; gt = t2; }
-  }
-  const bool found = gt >= 0 && gp > 0.0;
-  if (tid == (found ? gt : 0)) {
-    PdfResult r;
-    for (int i = 0; i < 9; i++) r.T[i] = (i % 4 == 0) ? 1.0 : 0.0;
-    r.prob = 0.0; r.idx = -1; r.i = -1; r.candidates = n_cand; r.pad = 0;
-    if (found) {
-      // (the winner's two points: requested by the winner alone, ahead of the sine and cosine.  Requested by every thread for its own
-      // best ahead of the reduction -- 4 000 scattered 8-byte reads -- the kernel took 6.2 us instead of 5.2)
-      const double msx = ld_pinned(&M[2 * bidx]), msy = ld_pinned(&M[2 * bidx + 1]), ssx = ld_pinned(&S[2 * bci]), ssy = ld_pinned(&S[2 * bci + 1]);
-      const double co = cos(bphi), si = sin(bphi);
-      r.T[0] = co; r.T[1] = -si; r.T[3] = si; r.T[4] = co;
-      r.T[2] = msx - (co * ssx + (-si) * ssy);
-      r.T[5] = msy - (si * ssx + co * ssy);
-      r.prob = gp; r.idx = bidx; r.i = bci;
-    }
-    *out = r;
-    // fused scan: header and result go to the host from here (stores into pinned memory, complete when the kernel ends) -- a copy
-    // behind this kernel would sit between it and the registration (a blit kernel: ~8 us with its hand-offs)
-    if (host_res) { *host_res = r; *host_hdr = *hdr; }
-  }
-}
-
 __global__ void __launch_bounds__(1024)
 k_pdf_argmax(const double* __restrict__ prob, const PdfCandidate* __restrict__ cand, int n_cand, const double* __restrict__ M,
              const double* __restrict__ S, PdfResult* __restrict__ out, const PdfHeader* __restrict__ hdr,
@@ -272,7 +179,6 @@ k_pdf_argmax(const double* __restrict__ prob, const PdfCandidate* __restrict__ c
 {
   pdf_argmax_body(prob, cand, n_cand, M, S, out, hdr, host_hdr, host_res);
 }
-struct PdfArgmaxEntry { const double* prob; const PdfCandidate* cand; const double* M; const double* S; PdfResult* out; const PdfHeader* hdr; PdfHeader* host_hdr; PdfResult* host_res; int max_cand; };
 struct PdfArgmaxBatch { PdfArgmaxEntry e[PDF_BATCH_BYVAL]; };
 __global__ void __launch_bounds__(1024)
 k_pdf_argmax_batch(PdfArgmaxBatch b)
@@ -1090,7 +996,7 @@ static int pre_configure_lds(tsd_ctx* ctx, const void* kernel, size_t prep_lds)
 }
 
 int launch_preregistration(tsd_ctx* ctx, tsd_sensor* s, hipStream_t stream, const double* d_coords, const uint8_t* d_mask_m,
-                           const double* d_pose6, const double** tinit_dev, hipEvent_t before_score)
+                           const double* d_pose6, const double** tinit_dev, hipEvent_t before_score, IcpPreLaunch* fold)
 {
   const tsd_sensor::PreLayout& L = s->pre;
   if (int rc = pre_inputs_ready(ctx, s, stream)) return rc;
@@ -1107,6 +1013,15 @@ int launch_preregistration(tsd_ctx* ctx, tsd_sensor* s, hipStream_t stream, cons
     // (the arg-max's own completion is the event a pre-registration armed AHEAD waits for before it overwrites the inputs: no marker
     // between this kernel and the registration)
     if (!s->ev_pre_done) TSD_HIP_CHECK(ctx, hipEventCreateWithFlags(&s->ev_pre_done, hipEventDisableTiming | hipEventDisableSystemFence));
+    if (fold) {
+      // the arg-max rides as the first workgroup of the registration's launch (k_icp_pre); its outcome is announced through a flag word
+      if (!s->d_pre_flag) {
+        TSD_HIP_CHECK(ctx, hipMalloc(&s->d_pre_flag, 128));
+        TSD_HIP_CHECK(ctx, hipMemsetAsync(s->d_pre_flag, 0, 128, stream));
+      }
+      if (++s->pre_seq == 0u) ++s->pre_seq;
+      fold->dev.am = pl.argmax; fold->dev.flag = s->d_pre_flag; fold->dev.seq = s->pre_seq; fold->done = s->ev_pre_done;
+    } else
     hipExtLaunchKernelGGL(k_pdf_argmax, dim3(1), dim3(1024), 0, stream, nullptr, s->ev_pre_done, 0, pl.argmax.prob, pl.argmax.cand, pl.argmax.max_cand, pl.argmax.M,
                        pl.argmax.S, pl.argmax.out, pl.argmax.hdr, pl.argmax.host_hdr, pl.argmax.host_res);
     s->pre_done_valid = true;
