@@ -1095,6 +1095,7 @@ int launch_push_halo(tsd_ctx* ctx, const HaloArgs& h, int n_window, hipStream_t 
     // stands, every tile of the window in the first push); a longer list is looped over.  (Round 4 launched one wave per WINDOW tile:
     // 6 745 waves to move 0.35 MB at cfg 2.)
     constexpr int HALO_WAVES = 2048;
+    if (n_window > ctx->grid.tiles) n_window = ctx->grid.tiles;        // (every wave reads its first list entry speculatively: stay inside the list)
     const int n_waves = n_window < HALO_WAVES ? (n_window < 1 ? 1 : n_window) : HALO_WAVES;
     hipExtLaunchKernelGGL(k_push_halo, dim3((n_waves + 3) / 4), dim3(256), 0, stream ? stream : ctx->stream, t.a, t.b, 0, ctx->grid, h);
   }

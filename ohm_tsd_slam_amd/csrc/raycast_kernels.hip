@@ -226,12 +226,18 @@ raycast_beam(const GridDev& g, const RaycastArgs& a_val, const RaycastArgs* __re
     halo_n = n_u + h.cnt[CNT_O];
     if (blockIdx.x < (unsigned)RC_HALO_WAVES) {
       // one of the launch's RC_HALO_WAVES extra waves, at the FRONT of the grid (dispatched first): the pass, no beam
+      // (the first half of these waves takes the UPDATE tiles of the halo list, the second half the emptied / halo-only tiles at the back of
+      // the work list: either way a wave's first entry is at an index it knows without the list lengths -- requested with them)
       const unsigned int wv = blockIdx.x, lane_h = threadIdx.x;
-      const uint32_t first = h.list_h[wv];                      // speculative: arrives with the list lengths
+      constexpr unsigned int HALF = (unsigned)RC_HALO_WAVES / 2u;
+      const bool back = wv >= HALF;
+      const unsigned int w2 = back ? wv - HALF : wv, n_mine = back ? halo_n - n_u : n_u;
+      const unsigned int w2c = w2 < (unsigned)g.tiles ? w2 : 0u;                              // (a grid of fewer tiles than waves)
+      const uint32_t first = back ? h.list[(unsigned)g.tiles - 1u - w2c] : h.list_h[w2c];    // speculative: arrives with the list lengths
       if (wv == 0 && lane_h == 0) halo_bookkeeping(h.pushes, h.a_dev, h.cx, h.cy, h.slack);
       unsigned int mine = 0u;
-      for (unsigned int li = wv; li < halo_n; li += (unsigned)RC_HALO_WAVES) {
-        const uint32_t entry = li < n_u ? ((li == wv) ? first : h.list_h[li]) : h.list[(unsigned)g.tiles - 1u - (li - n_u)];
+      for (unsigned int k = w2; k < n_mine; k += HALF) {
+        const uint32_t entry = k == w2 ? first : (back ? h.list[(unsigned)g.tiles - 1u - k] : h.list_h[k]);
         halo_tile_job(g, h.dirty, h.tile_rec, entry, (int)lane_h);
         mine++;
       }
