@@ -74,6 +74,24 @@ def test_scan_through_the_bar_with_the_device_side_cross_check():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 3])
+def test_in_launch_handoffs_under_load_change_nothing(mode):
+    """tools/handoff_stress.py: the fused closed loop with the push's halo pass and (mode 3) the pre-registration's arg-max as kernels
+    of their own on an idle chip, against the same loop with both passes riding inside the launches behind them (the default) while a
+    second context pushes a 16384^2 grid and extracts its map in a loop on another thread: every pose and the grid's digest (halo
+    cells included) must be the same, bit for bit."""
+    tool = os.path.join(ROOT, "tools", "handoff_stress.py")
+    a = subprocess.run([sys.executable, tool, "120", str(mode)], cwd=ROOT, env=dict(os.environ, TSD_HALO_KERNEL="1", TSD_PDF_ARGMAX_KERNEL="1"),
+                       capture_output=True, text=True, timeout=600)
+    b = subprocess.run([sys.executable, tool, "120", str(mode), "--load"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert a.returncode == 0 and b.returncode == 0, a.stderr[-1500:] + b.stderr[-1500:]
+    la = [l for l in a.stdout.splitlines() if l.startswith("poses ")]
+    lb = [l for l in b.stdout.splitlines() if l.startswith("poses ")]
+    assert len(la) == 1 and la == lb, (a.stdout[-600:], b.stdout[-600:])
+    assert "load yes" in b.stdout and "load no" in a.stdout
+
+
+@pytest.mark.gpu
 def test_randomised_async_mapping_short():
     """tools/fuzz_async.py: asynchronous mapping through the staged scan with random staging (kept / replaced / absent) and a push stream
     held back by up to 3 ms per push, against the one-push-behind order on the oracle's primitives."""

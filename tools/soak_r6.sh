@@ -11,5 +11,10 @@ echo "== fuzz_batch 200 (seeds 6000..)"; timeout 900 python3 tools/fuzz_batch.py
 echo "== fuzz_batch 150 mode3 (seeds 7000..)"; timeout 900 python3 tools/fuzz_batch.py 150 7000 mode3 2>&1 | tail -2
 echo "== async_soak"; timeout 900 python3 tools/async_soak.py 2>&1 | tail -3
 echo "== first_flip 600 cfg2"; timeout 1500 python3 tools/first_flip.py 600 cfg2 gpurun_out/first_flip_600.txt 2>&1 | tail -6
+echo "== hand-offs under load (poses + grid digest must be equal line by line)"
+for m in 0 3; do
+  TSD_HALO_KERNEL=1 TSD_PDF_ARGMAX_KERNEL=1 timeout 600 python3 tools/handoff_stress.py 500 $m 2>&1 | tail -2
+  timeout 600 python3 tools/handoff_stress.py 500 $m --load 2>&1 | tail -2
+done
 } > gpurun_out/soak_r6.txt 2>&1
 tail -40 gpurun_out/soak_r6.txt
