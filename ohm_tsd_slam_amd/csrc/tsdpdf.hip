@@ -453,12 +453,24 @@ __device__ __forceinline__ void pdf_prepare_body(const PdfPrepareArgs& p)
     // moved back, i.e. those with q_m - m <= val.  Either way a prefix of the sibling's sorted entries.
     const unsigned int* sib = a + base + (right ? 0 : B);
     const int n = right ? nL : nR, thresh = right ? val + 1 : val - i;
-    int pos = 0;
-    for (int step = B; step >= 1; step >>= 1) {
-      const int m = pos + step - 1;
-      const int mc = m < n ? m : n - 1;
-      const int sv = (int)(sib[mc] >> 16) - (right ? mc : 0);
-      if (m < n && sv < thresh) pos += step;
+    // the count by descent over the steps B, B / 2, .., 1 ("is entry pos + step - 1 still in the prefix?"), TWO steps per LDS round trip:
+    // the second step's probe is one of two positions, both requested with the first step's
+    auto key_at = [&](unsigned int w, int m) { return (int)(w >> 16) - (right ? m : 0); };
+    auto at = [&](int m) { return sib[m < n ? m : n - 1]; };
+    int pos = 0, step = B;
+    while (step >= 2) {
+      const int h = step >> 1;
+      const int m1 = pos + step - 1, m2a = pos + h - 1, m2b = pos + step + h - 1;
+      const unsigned int w1 = at(m1), w2a = at(m2a), w2b = at(m2b);
+      const bool p1 = m1 < n && key_at(w1, m1 < n ? m1 : n - 1) < thresh;
+      const int m2 = p1 ? m2b : m2a;
+      const bool p2 = m2 < n && key_at(p1 ? w2b : w2a, m2 < n ? m2 : n - 1) < thresh;
+      pos += (p1 ? step : 0) + (p2 ? h : 0);
+      step >>= 2;
+    }
+    if (step == 1) {
+      const int m = pos;
+      if (m < n && key_at(at(m), m) < thresh) pos += 1;
     }
     if (right) o[base + (i - B) + pos] = ((unsigned)(val + pos) << 16) | (v & 0xFFFFu);
     else o[base + i + pos] = v;
@@ -531,30 +543,52 @@ __device__ __forceinline__ void pdf_prepare_body(const PdfPrepareArgs& p)
   if (tid == 0) s_ncand = 0;
   __syncthreads();
   QSTAMP();
-  for (int t = wave; t < trials; t += 16) {
+  // (a trial's window into the sampled scene list, for every trial at once: the pass below used to start each trial with three dependent
+  // LDS round trips -- the trial's model index, the two list positions)
+  __shared__ unsigned short s_klo[PDF_MAX_TRIALS], s_khi[PDF_MAX_TRIALS];
+  for (int t = tid; t < trials; t += 1024) {
     const int idx = s_trial[t];
     const int iMin = idx - p.span > p.sr ? idx - p.span : p.sr, iMax = idx + p.span < p.n - p.sr ? idx + p.span : p.n - p.sr;
-    const double pm = s_pm[t];
-    // (the sampled scene points are a sixth of the beams: the window's part of their LIST, one 64-entry round per trial as a rule)
-    const int kLo = iMin < iMax ? (int)s_rank[iMin] : 0, kHi = iMin < iMax ? (int)s_rank[iMax] : 0;
-    for (int k0 = kLo; k0 < kHi; k0 += 64) {
-      const int k = k0 + lane;
-      const int i = k < kHi ? (int)s_idx[0][k] : 0;
-      bool ok = false; double phi = 0.0;
-      if (k < kHi) {
-        phi = pm - s_phi_s[i];
-        if (phi > PI_D) phi -= 2.0 * PI_D;
-        else if (phi < -PI_D) phi += 2.0 * PI_D;
-        ok = fabs(phi) < p.phi_max;
-      }
-      const unsigned long long b = __ballot(ok);
-      if (b) {
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&s_ncand, __popcll(b));
-        base = __builtin_amdgcn_readfirstlane(base);
-        const int at = base + __popcll(b & lt);
-        if (ok && at < p.max_cand) p.cand[at] = PdfCandidate{idx, (t << PDF_I_BITS) | i, phi};
-      }
+    s_klo[t] = iMin < iMax ? s_rank[iMin] : (unsigned short)0;
+    s_khi[t] = iMin < iMax ? s_rank[iMax] : (unsigned short)0;
+  }
+  __syncthreads();
+  // wave w takes the trials w, w + 16, ...: TWO of them per turn, their reads in flight together (the turn is a chain of LDS round
+  // trips: list entry -> angle -> list place; the matches of a 64-entry round draw their places from one LDS counter)
+  auto round_of = [&](int t, int k0, int& i, double& phi, bool& ok) {
+    const int kHi = t < trials ? (int)s_khi[t] : 0;
+    const int k = k0 + lane;
+    const bool in = t < trials && k < kHi;
+    i = in ? (int)s_idx[0][k] : 0;
+    phi = 0.0; ok = false;
+    if (in) {
+      phi = s_pm[t] - s_phi_s[i];
+      if (phi > PI_D) phi -= 2.0 * PI_D;
+      else if (phi < -PI_D) phi += 2.0 * PI_D;
+      ok = fabs(phi) < p.phi_max;
+    }
+  };
+  auto emit = [&](int t, int i, double phi, bool ok) {
+    const unsigned long long b = __ballot(ok);
+    if (b) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&s_ncand, __popcll(b));
+      base = __builtin_amdgcn_readfirstlane(base);
+      const int at = base + __popcll(b & lt);
+      if (ok && at < p.max_cand) p.cand[at] = PdfCandidate{s_trial[t], (t << PDF_I_BITS) | i, phi};
+    }
+  };
+  for (int t = wave; t < trials; t += 32) {
+    const int t2 = t + 16;
+    const int lo1 = (int)s_klo[t], hi1 = (int)s_khi[t];
+    const int lo2 = t2 < trials ? (int)s_klo[t2] : 0, hi2 = t2 < trials ? (int)s_khi[t2] : 0;
+    const int len = (hi1 - lo1) > (hi2 - lo2) ? (hi1 - lo1) : (hi2 - lo2);
+    for (int o = 0; o < len; o += 64) {
+      int i1, i2; double ph1, ph2; bool ok1, ok2;
+      round_of(t, lo1 + o, i1, ph1, ok1);
+      round_of(t2, lo2 + o, i2, ph2, ok2);
+      emit(t, i1, ph1, ok1);
+      emit(t2, i2, ph2, ok2);
     }
   }
   if (tid < nC) p.control[tid] = ctrl_xy;

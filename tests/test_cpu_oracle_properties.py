@@ -685,14 +685,18 @@ def _decode_picks_like_the_kernel(ranks):
             right = i >= B
             sib = base + (0 if right else B)
             n, thresh = (nL, val + 1) if right else (nR, val - i)
-            pos, step = 0, B
-            while step >= 1:
-                m = pos + step - 1
+            def in_prefix(m):
                 mc = min(m, n - 1)
-                sv = (src[sib + mc] >> 16) - (mc if right else 0)
-                if m < n and sv < thresh:
-                    pos += step
-                step >>= 1
+                return m < n and (src[sib + mc] >> 16) - (mc if right else 0) < thresh
+            pos, step = 0, B
+            while step >= 2:                      # two steps of the descent per LDS round trip, like the kernel
+                h = step >> 1
+                p1 = in_prefix(pos + step - 1)
+                p2 = in_prefix(pos + step + h - 1) if p1 else in_prefix(pos + h - 1)
+                pos += (step if p1 else 0) + (h if p2 else 0)
+                step >>= 2
+            if step == 1 and in_prefix(pos):
+                pos += 1
             at = base + (i - B) + pos if right else base + i + pos
             assert dst[at] is None
             dst[at] = (((val + pos) << 16) | (v & 0xFFFF)) if right else v
