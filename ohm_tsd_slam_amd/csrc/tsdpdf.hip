@@ -553,42 +553,40 @@ __device__ __forceinline__ void pdf_prepare_body(const PdfPrepareArgs& p)
     s_khi[t] = iMin < iMax ? s_rank[iMax] : (unsigned short)0;
   }
   __syncthreads();
-  // wave w takes the trials w, w + 16, ...: TWO of them per turn, their reads in flight together (the turn is a chain of LDS round
-  // trips: list entry -> angle -> list place; the matches of a 64-entry round draw their places from one LDS counter)
-  auto round_of = [&](int t, int k0, int& i, double& phi, bool& ok) {
-    const int kHi = t < trials ? (int)s_khi[t] : 0;
-    const int k = k0 + lane;
-    const bool in = t < trials && k < kHi;
-    i = in ? (int)s_idx[0][k] : 0;
-    phi = 0.0; ok = false;
-    if (in) {
-      phi = s_pm[t] - s_phi_s[i];
-      if (phi > PI_D) phi -= 2.0 * PI_D;
-      else if (phi < -PI_D) phi += 2.0 * PI_D;
-      ok = fabs(phi) < p.phi_max;
-    }
-  };
-  auto emit = [&](int t, int i, double phi, bool ok) {
-    const unsigned long long b = __ballot(ok);
-    if (b) {
-      int base = 0;
-      if (lane == 0) base = atomicAdd(&s_ncand, __popcll(b));
-      base = __builtin_amdgcn_readfirstlane(base);
-      const int at = base + __popcll(b & lt);
-      if (ok && at < p.max_cand) p.cand[at] = PdfCandidate{s_trial[t], (t << PDF_I_BITS) | i, phi};
-    }
-  };
+  // wave w takes the trials w, w + 16, ...: TWO of them per turn, their reads in flight together (the turn is a chain of four LDS round
+  // trips: the trials' data -> list entries -> angles -> list places; the matches of both draw their places from one LDS counter at once)
   for (int t = wave; t < trials; t += 32) {
     const int t2 = t + 16;
-    const int lo1 = (int)s_klo[t], hi1 = (int)s_khi[t];
-    const int lo2 = t2 < trials ? (int)s_klo[t2] : 0, hi2 = t2 < trials ? (int)s_khi[t2] : 0;
+    const bool has2 = t2 < trials;
+    const int t2c = has2 ? t2 : t;
+    // everything that depends on the trials alone: one round trip
+    const int lo1 = (int)s_klo[t], hi1 = (int)s_khi[t], lo2 = (int)s_klo[t2c], hi2 = has2 ? (int)s_khi[t2c] : 0;
+    const int idx1 = s_trial[t], idx2 = s_trial[t2c];
+    const double pm1 = s_pm[t], pm2 = s_pm[t2c];
     const int len = (hi1 - lo1) > (hi2 - lo2) ? (hi1 - lo1) : (hi2 - lo2);
     for (int o = 0; o < len; o += 64) {
-      int i1, i2; double ph1, ph2; bool ok1, ok2;
-      round_of(t, lo1 + o, i1, ph1, ok1);
-      round_of(t2, lo2 + o, i2, ph2, ok2);
-      emit(t, i1, ph1, ok1);
-      emit(t2, i2, ph2, ok2);
+      const int k1 = lo1 + o + lane, k2 = lo2 + o + lane;
+      const bool in1 = k1 < hi1, in2 = k2 < hi2;
+      const int i1 = in1 ? (int)s_idx[0][k1] : 0, i2 = in2 ? (int)s_idx[0][k2] : 0;                 // second round trip
+      const double ps1 = s_phi_s[i1], ps2 = s_phi_s[i2];                                               // third
+      auto angle = [&](double pm, double ps, bool in, bool& ok) {
+        double phi = pm - ps;
+        if (phi > PI_D) phi -= 2.0 * PI_D;
+        else if (phi < -PI_D) phi += 2.0 * PI_D;
+        ok = in && fabs(phi) < p.phi_max;
+        return phi;
+      };
+      bool ok1, ok2;
+      const double ph1 = angle(pm1, ps1, in1, ok1), ph2 = angle(pm2, ps2, in2, ok2);
+      const unsigned long long b1 = __ballot(ok1), b2 = __ballot(ok2);
+      if (b1 | b2) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&s_ncand, __popcll(b1) + __popcll(b2));                       // fourth: the places of both trials' matches
+        base = __builtin_amdgcn_readfirstlane(base);
+        const int at1 = base + __popcll(b1 & lt), at2 = base + __popcll(b1) + __popcll(b2 & lt);
+        if (ok1 && at1 < p.max_cand) p.cand[at1] = PdfCandidate{idx1, (t << PDF_I_BITS) | i1, ph1};
+        if (ok2 && at2 < p.max_cand) p.cand[at2] = PdfCandidate{idx2, (t2 << PDF_I_BITS) | i2, ph2};
+      }
     }
   }
   if (tid < nC) p.control[tid] = ctrl_xy;
