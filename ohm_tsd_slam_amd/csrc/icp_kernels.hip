@@ -549,15 +549,18 @@ __device__ __forceinline__ void block_totals8(const IcpLds& L, const double (&v)
   __syncthreads();
   if (tl && lane == 0) tl[8] = clock64();
   double* bc = L.red + (ICP_MAXW + wave) * 16;
-  if (lane < 8) {
+  {
+    // every lane adds the column lane & 7 (eight lanes of a wave used to, inside an exec-masked region with its skip branch: the same
+    // instructions per wave, but one basic block from the barrier to the totals and ~30 cycles of every step less)
+    const int c = lane & 7;
     double x[MAXW];
 #pragma unroll
-    for (int r = 0; r < MAXW; r++) x[r] = L.red[r * 16 + lane];      // (rows of waves the launch does not have were zeroed at the start)
+    for (int r = 0; r < MAXW; r++) x[r] = L.red[r * 16 + c];
 #pragma unroll
     for (int st = 1; st < MAXW; st <<= 1)
 #pragma unroll
       for (int r = 0; r + st < MAXW; r += 2 * st) x[r] += x[r + st];
-    bc[lane] = x[0];
+    bc[c] = x[0];                           // (eight lanes per word, the same value)
   }
   // broadcast through LDS (a wave's LDS accesses execute in order)
 #pragma unroll
@@ -1015,7 +1018,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
     double bd[R]; bool keep[R], need[R];
     int ent[R];
     double2 mw[R];                            // the neighbour's coordinates
-    const bool refresh = (iter == REFRESH_A) || (iter == REFRESH_B);
+    const bool refresh = (iter - REFRESH_A) * (iter - REFRESH_B) == 0u;      // (one scalar compare; `== || ==` compiles to two branches on the steady path)
     // OutOfBoundsFilter2D for one point: S.transform(P): (0 + x*R00) + y*R01, then + t (gsl/Matrix.cpp:403-432)
     auto inside_bounds = [&](double x, double y) {
       double wx = 0.0, wy = 0.0;
@@ -1102,6 +1105,12 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
       for (int q = 0; q < R; q++)
         if (keep[q]) was[q] = atomicMin(&slotD[hint[q]], mine[q]);
       // work list of the points that need a search (an entry beyond the list capacity waits for its pass)
+      // (ONE test per wave and step instead of one per register slot: a conditional branch costs a wave 15-30 cycles even when it is not
+      // taken, an exec-masked region about as much -- tools/exp/ctl.hip -- and here the wait for the atomics above covers it)
+      bool need_any = false;
+#pragma unroll
+      for (int q = 0; q < R; q++) need_any |= need[q];
+      if (__builtin_expect(__ballot(need_any) != 0ull, 0))
 #pragma unroll
       for (int q = 0; q < R; q++)
         if (need[q]) {
@@ -1109,7 +1118,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
           if (ent[q] < lcap) { L.list_xy[ent[q]] = make_double2(sx[q], sy[q]); L.list_k[ent[q]] = hint[q] | (lb[q] == LB_WINDOW_TRIED ? LIST_PAST_WINDOW : 0); }
         }
 #pragma unroll
-      for (int q = 0; q < R; q++) tie |= keep[q] & (was[q] == mine[q]);
+      for (int q = 0; q < R; q++) tie |= keep[q] & (was[q] == (unsigned long long)__double_as_longlong(bd[q]));
     }
     if (tie) L.ired[IR_TIE] = 1;
     TL(3);                                     // the reciprocal filter's atomics are back
@@ -1286,8 +1295,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
           if (win[q]) {
             const double2 m = mw[q];
             v[0] += m.x; v[1] += m.y; v[2] += sx[q]; v[3] += sy[q];
-            const double dx = sx[q] - m.x, dy = sy[q] - m.y;
-            v[4] += dx * dx + dy * dy;
+            v[4] += bd[q];                    // (the pair's squared distance: the same expression on the same operands as tier 0's / the search's)
             const double xF = m.x - c0[0], yF = m.y - c0[1], xS = sx[q] - c0[2], yS = sy[q] - c0[3];
             v[5] += yF * xS - xF * yS; v[6] += xF * xS + yF * yS;
             v[7] += 1.0;
@@ -1324,9 +1332,16 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
       TL(10);                                  // totals in registers
     }
     // everybody is past the winner test: give the touched slots back, clear the work list counter
+    if (slot_halves == 2) {
+      // (the whole half, every thread its share at constant addresses: no per-point test, no address arithmetic; the half is used again
+      // two barriers from here)
 #pragma unroll
-    for (int q = 0; q < R; q++)
-      if (keep[q]) slotD[hint[q]] = ~0ull;
+      for (int k = 0; k < (cap + T - 1) / T; k++) { const int j = tid + k * T; if (j < cap) slotD[j] = ~0ull; }
+    } else {
+#pragma unroll
+      for (int q = 0; q < R; q++)
+        if (keep[q]) slotD[hint[q]] = ~0ull;
+    }
     if (tid == 0) L.ired[IR_CNT] = 0;
 
     double co = __builtin_nan(""), si = __builtin_nan(""), dX = __builtin_nan(""), dY = __builtin_nan("");   // Tlast of this step (trace)
@@ -1373,9 +1388,9 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
       for (int q = 0; q < R; q++) {
         if (q >= Rn || PAIRS) continue;          // (PAIRS: a static scene, determinePairs called again and again)
         const double x = sx[q], y = sy[q];
-        double nx = 0.0, ny = 0.0;
-        nx += x * co; nx += y * (-si);
-        ny += x * si; ny += y * co;
+        // applyTransformation's ((0 + x*co) + y*(-si)) + dX without the leading zero: the same value unless x*co is -0, and then only the
+        // sign of a zero coordinate differs -- which no distance, comparison or sum can see (two instructions per point and step less)
+        double nx = x * co + y * (-si), ny = x * si + y * co;
         nx = nx + dX; ny = ny + dY;
         const double ex = nx - x, ey = ny - y;
         const float disp = __builtin_amdgcn_sqrtf((float)(ex * ex + ey * ey) * 1.000001f) * 1.000001f;
@@ -1384,14 +1399,10 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
       }
       {
         // Tfinal = Tlast * Tfinal (Icp.cpp:452): the 4x4 product restricted to its non-trivial entries
-        // (the dropped terms are exact zeros / ones, so the rounding is the dgemm's)
-        double n00 = 0.0, n01 = 0.0, n02 = 0.0, n10 = 0.0, n11 = 0.0, n12 = 0.0;
-        n00 += co * Tf[0]; n00 += (-si) * Tf[3];
-        n01 += co * Tf[1]; n01 += (-si) * Tf[4];
-        n02 += co * Tf[2]; n02 += (-si) * Tf[5]; n02 += 0.0; n02 += dX * 1.0;
-        n10 += si * Tf[0]; n10 += co * Tf[3];
-        n11 += si * Tf[1]; n11 += co * Tf[4];
-        n12 += si * Tf[2]; n12 += co * Tf[5]; n12 += 0.0; n12 += dY * 1.0;
+        // (the dropped terms are exact zeros / ones, so the rounding is the dgemm's up to the sign of a zero: the leading `0 +` of each
+        // accumulation is left out like in the points' transform above)
+        const double n00 = co * Tf[0] + (-si) * Tf[3], n01 = co * Tf[1] + (-si) * Tf[4], n02 = (co * Tf[2] + (-si) * Tf[5]) + dX;
+        const double n10 = si * Tf[0] + co * Tf[3], n11 = si * Tf[1] + co * Tf[4], n12 = (si * Tf[2] + co * Tf[5]) + dY;
         Tf[0] = n00; Tf[1] = n01; Tf[2] = n02; Tf[3] = n10; Tf[4] = n11; Tf[5] = n12;
       }
       state = TSD_ICP_PROCESSING;
