@@ -38,6 +38,11 @@
 #include <climits>
 #include <cstring>
 
+// Likelihood hints decide the LAYOUT of the step loop: a region the compiler thinks likely loses its skip branch and sits in line, an
+// unlikely one goes out of line -- the steady step then takes one taken branch (the loop's) instead of ten (tools/exp/ctl.hip: 24-38
+// cycles each; profiles/r6_icp_branch_cost_ab.txt).
+#define LIKELY(x) __builtin_expect(!!(x), 1)
+#define UNLIKELY(x) __builtin_expect(!!(x), 0)
 namespace tsd {
 
 constexpr int ICP_MAXW = 16;                    // waves per workgroup at most
@@ -102,10 +107,13 @@ __host__ __device__ inline size_t icp_region_bytes(int cap, int threads)
   if (tr > b) b = tr;
   return (b + 15u) & ~(size_t)15u;
 }
+// a half of the reciprocal filter's slot array: a whole number of entries per thread, so that giving a half back is the same stores in every
+// thread (no bound to test: a test is a branch)
+__host__ __device__ inline int icp_slot_cap(int cap, int threads) { return (cap + threads - 1) / threads * threads; }
 __host__ __device__ inline size_t icp_lds_base_bytes(int cap, int threads, bool normals)      // with ONE half of the slot array
 {
   // the staging (cap double2 + cap int) aliases the list + result arrays: 40 * lc >= 20 * cap
-  return sizeof(double2) * 2 * (size_t)cap + sizeof(double2) * 2 * ICP_PAD + sizeof(unsigned long long) * (size_t)cap + sizeof(int) * 2 * (size_t)cap +
+  return sizeof(double2) * 2 * (size_t)cap + sizeof(double2) * 2 * ICP_PAD + sizeof(unsigned long long) * (size_t)icp_slot_cap(cap, threads) + sizeof(int) * 2 * (size_t)cap +
          icp_region_bytes(cap, threads) + sizeof(double) * (2 * ICP_MAXW * 16 + 16) + ((sizeof(IcpTail) + 15) & ~(size_t)15) +
          sizeof(int) * 64 + 64 + (normals ? sizeof(double2) * (size_t)cap : 0);
 }
@@ -122,11 +130,11 @@ constexpr size_t ICP_TL_BYTES = 0;
 // runs; not the largest point counts of tsd_icp with the point-to-line estimator's normals): see the loop.  Same rule on both sides.
 __host__ __device__ inline int icp_slot_halves(int cap, int threads, bool normals)
 {
-  return icp_lds_base_bytes(cap, threads, normals) + sizeof(unsigned long long) * (size_t)cap + ICP_TL_BYTES <= 160u * 1024u ? 2 : 1;
+  return icp_lds_base_bytes(cap, threads, normals) + sizeof(unsigned long long) * (size_t)icp_slot_cap(cap, threads) + ICP_TL_BYTES <= 160u * 1024u ? 2 : 1;
 }
 __host__ __device__ inline size_t icp_lds_bytes_for(int cap, int threads, bool normals = false)
 {
-  return icp_lds_base_bytes(cap, threads, normals) + sizeof(unsigned long long) * (size_t)cap * (size_t)(icp_slot_halves(cap, threads, normals) - 1);
+  return icp_lds_base_bytes(cap, threads, normals) + sizeof(unsigned long long) * (size_t)icp_slot_cap(cap, threads) * (size_t)(icp_slot_halves(cap, threads, normals) - 1);
 }
 
 // a wave-uniform value the compiler must keep in a vector register
@@ -632,7 +640,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
     p = reinterpret_cast<char*>(L.list_xy) + icp_region_bytes(cap, (FT ? FT : (int)blockDim.x));
     // staging view of the same 40*lcap bytes: cap double2 then cap int (40*lcap >= 20*cap)
     L.start = reinterpret_cast<int*>(reinterpret_cast<char*>(L.stage_s) + sizeof(double2) * (size_t)cap);
-    L.slotD = reinterpret_cast<unsigned long long*>(p); p += sizeof(unsigned long long) * (size_t)icp_slot_halves(cap, (FT ? FT : (int)blockDim.x), PTL) * (size_t)cap;
+    L.slotD = reinterpret_cast<unsigned long long*>(p); p += sizeof(unsigned long long) * (size_t)icp_slot_halves(cap, (FT ? FT : (int)blockDim.x), PTL) * (size_t)icp_slot_cap(cap, (FT ? FT : (int)blockDim.x));
     L.red = reinterpret_cast<double*>(p); p += sizeof(double) * 2 * ICP_MAXW * 16;
     L.cst = reinterpret_cast<double*>(p); p += sizeof(double) * 16;
     L.tail = reinterpret_cast<IcpTail*>(p); p += (sizeof(IcpTail) + 15) & ~(size_t)15;
@@ -881,7 +889,9 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
   tk_s[2] = clock64();                                   // scene in registers, unit directions and padding written
 #endif
   const int slot_halves = icp_slot_halves(cap, T, PTL);
-  for (int k = tid; k < cap; k += T) { L.slotD[k] = ~0ull; if (slot_halves == 2) L.slotD[cap + k] = ~0ull; L.slotI[k] = INT_MAX; }
+  const int scap = icp_slot_cap(cap, T);
+  for (int k = tid; k < scap; k += T) { L.slotD[k] = ~0ull; if (slot_halves == 2) L.slotD[scap + k] = ~0ull; }
+  for (int k = tid; k < cap; k += T) L.slotI[k] = INT_MAX;
   for (int k = tid; k < ICP_MAXW * 16; k += T) L.red[k] = 0.0;    // (block_totals8 reads the rows of absent waves)
   if (role == 0 && !PTL) {
     // the waves' sums of the scene coordinates (c0 below), parked in the broadcast rows (scratch until the first step)
@@ -945,6 +955,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
 #endif
   int Rn = 0;                                // register slots of this wave that hold scene points (wave-uniform)
   for (int q = 0; q < R; q++) Rn += (pid[q] - lane < nS) ? 1 : 0;
+  Rn = __builtin_amdgcn_readfirstlane(Rn);   // (a scalar: "this register slot is empty" is then a scalar branch, which the likelihood hints below do not remove)
 
 #ifdef TSD_ICP_TIMELINE
   tk_seed = clock64();
@@ -1008,7 +1019,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
     // barrier 1: nothing orders the two.  They are a transform and a tier 0 apart (~2 500 cycles) while the waves leave a barrier within
     // tens of cycles of each other, so the hand-back always won -- but only by timing.  Alternate steps use alternate halves of the slot
     // array (where the LDS holds two, icp_slot_halves): a half is given back a whole step (two barriers) before it is used again.
-    unsigned long long* const slotD = L.slotD + (size_t)(iter & (unsigned)(slot_halves - 1)) * (size_t)cap;
+    unsigned long long* const slotD = L.slotD + (size_t)(iter & (unsigned)(slot_halves - 1)) * (size_t)scap;
 
     // -- phase A: pre-filter + exact NN + distance filter (per scene point)
     // OutOfBoundsFilter2D: when even a disc of the largest possible scene radius around the sensor
@@ -1036,13 +1047,20 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
       for (int q = 0; q < R; q++) { asm volatile("" : "+v"(mh[q].x), "+v"(mh2[q].x)); }
       TL(1);                                   // the neighbours' coordinates have arrived
 #endif
+      // (the bounds test of all register slots behind ONE wave-uniform branch: a region per slot was three taken branches per step)
+      bool inb[R];
+#pragma unroll
+      for (int q = 0; q < R; q++) inb[q] = true;
+      if (__builtin_expect(__builtin_amdgcn_readfirstlane((int)all_in) == 0, 0)) {
+#pragma unroll
+        for (int q = 0; q < R; q++) inb[q] = inside_bounds(sx[q], sy[q]);
+      }
 #pragma unroll
       for (int q = 0; q < R; q++) {
         bd[q] = __builtin_inf(); keep[q] = false; need[q] = false; ent[q] = -1; mw[q] = mh[q];
         if (q >= Rn) continue;                  // (wave-uniform) no scene point in this register slot
         const double x = sx[q], y = sy[q];
-        bool pre = have[q];
-        if (!all_in) pre = pre & inside_bounds(x, y);
+        const bool pre = have[q] & inb[q];
         // the nearer of the last neighbour and its runner-up is the exact neighbour as long as it beats
         // the bound on everything else (a point hovering between two model points never searches)
         const double dx1 = x - mh[q].x, dy1 = y - mh[q].y, dx2 = x - mh2[q].x, dy2 = y - mh2[q].y;
@@ -1078,7 +1096,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
       // good pairs at 3 m range whose slack of a few millimetres the scene's remaining motion eats; a third renewal buys nothing).
       // Formed here, in the two steps that renew, from what the loop above left -- bd is +inf for a point outside the bounds or an empty
       // register slot, which makes `drop` true.
-      if (refresh) {
+      if (UNLIKELY(refresh)) {
 #pragma unroll
         for (int q = 0; q < R; q++) {
           if (q >= Rn) continue;
@@ -1120,7 +1138,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
 #pragma unroll
       for (int q = 0; q < R; q++) tie |= keep[q] & (was[q] == (unsigned long long)__double_as_longlong(bd[q]));
     }
-    if (tie) L.ired[IR_TIE] = 1;
+    if (UNLIKELY(tie)) L.ired[IR_TIE] = 1;
     TL(3);                                     // the reciprocal filter's atomics are back
     __syncthreads();
     TL(4);                                     // past barrier 1
@@ -1138,7 +1156,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
       n_need = nn;
     }
     if (lcap == cap) __builtin_assume(n_need <= lcap);           // (no more points than capacity: a list that holds them all needs one pass)
-    if (n_need > 0) {
+    if (UNLIKELY(n_need > 0)) {
       tie = false;
       for (int base = 0; base < n_need; base += lcap) {       // one pass unless more than lcap points search
         const int n = (n_need - base) < lcap ? (n_need - base) : lcap;
@@ -1247,11 +1265,10 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
 
     // -- ReciprocalFilter, second half: the pair whose d2 stands in its slot wins
     bool win[R];
-    int cnt = 0;
 #pragma unroll
     for (int q = 0; q < R; q++) win[q] = keep[q] & (sd[q] == (unsigned long long)__double_as_longlong(bd[q]));
     TL(5);                                     // winners known (work-list counter + slot minima read)
-    if (tie_any) {
+    if (UNLIKELY(tie_any)) {
       // equal d2 somewhere: the lowest scene index of the candidates wins its slot
 #pragma unroll
       for (int q = 0; q < R; q++)
@@ -1267,6 +1284,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
         if (keep[q]) L.slotI[hint[q]] = INT_MAX;
       if (tid == 0) L.ired[IR_TIE] = 0;
     }
+    int cnt = 0;
 #pragma unroll
     for (int q = 0; q < R; q++) cnt += __popcll(__ballot(win[q]));
     if constexpr (PAIRS) {
@@ -1292,7 +1310,8 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
         // is what counts now), the lane's pair count as the eighth value (exact in fp64)
 #pragma unroll
         for (int q = 0; q < R; q++) {
-          if (win[q]) {
+          if (q >= Rn) continue;                // (an empty register slot: skipped by a scalar branch, not run through with no lane active)
+          if (LIKELY(win[q])) {
             const double2 m = mw[q];
             v[0] += m.x; v[1] += m.y; v[2] += sx[q]; v[3] += sy[q];
             v[4] += bd[q];                    // (the pair's squared distance: the same expression on the same operands as tier 0's / the search's)
@@ -1336,7 +1355,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
       // (the whole half, every thread its share at constant addresses: no per-point test, no address arithmetic; the half is used again
       // two barriers from here)
 #pragma unroll
-      for (int k = 0; k < (cap + T - 1) / T; k++) { const int j = tid + k * T; if (j < cap) slotD[j] = ~0ull; }
+      for (int k = 0; k < (cap + T - 1) / T; k++) slotD[tid + k * T] = ~0ull;
     } else {
 #pragma unroll
       for (int q = 0; q < R; q++)
@@ -1346,7 +1365,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
 
     double co = __builtin_nan(""), si = __builtin_nan(""), dX = __builtin_nan(""), dY = __builtin_nan("");   // Tlast of this step (trace)
     pairs = __builtin_amdgcn_readfirstlane(pairs);
-    if (pairs > 2) {
+    if (LIKELY(pairs > 2)) {
       if constexpr (PTL) {
         // PointToLine2DEstimator: Matrix::solve = gsl_linalg_LU_decomp + LU_solve (gsl/Matrix.cpp:343-355);
         // psi = x[0] (cos, sin by libm like the reference), t = (x[1], x[2]); "rms" = mean |n.(p - q)|
@@ -1373,7 +1392,7 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
         // from the reference's atan2 -> cos/sin by rounding only (DESIGN.md "ICP", tolerance 1e-4)
         {
           const double h2 = nom * nom + den * den;
-          if (h2 > 0.0) { const double inv = rsqrt(h2); co = den * inv; si = nom * inv; }
+          if (LIKELY(h2 > 0.0)) { const double inv = rsqrt(h2); co = den * inv; si = nom * inv; }
           else { co = signbit(den) ? -1.0 : 1.0; si = 0.0; }
         }
 #endif
@@ -1401,9 +1420,15 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
         // Tfinal = Tlast * Tfinal (Icp.cpp:452): the 4x4 product restricted to its non-trivial entries
         // (the dropped terms are exact zeros / ones, so the rounding is the dgemm's up to the sign of a zero: the leading `0 +` of each
         // accumulation is left out like in the points' transform above)
-        const double n00 = co * Tf[0] + (-si) * Tf[3], n01 = co * Tf[1] + (-si) * Tf[4], n02 = (co * Tf[2] + (-si) * Tf[5]) + dX;
-        const double n10 = si * Tf[0] + co * Tf[3], n11 = si * Tf[1] + co * Tf[4], n12 = (si * Tf[2] + co * Tf[5]) + dY;
-        Tf[0] = n00; Tf[1] = n01; Tf[2] = n02; Tf[3] = n10; Tf[4] = n11; Tf[5] = n12;
+        // (the translation column in every wave -- the bounds test of the next step reads it --, the rotation block in wave 0 alone: it is
+        // needed behind the loop only, where wave 0 hands it to the others; 16 instructions per step less in seven waves)
+        const double n02 = (co * Tf[2] + (-si) * Tf[5]) + dX, n12 = (si * Tf[2] + co * Tf[5]) + dY;
+        if (wave == 0) {
+          const double n00 = co * Tf[0] + (-si) * Tf[3], n01 = co * Tf[1] + (-si) * Tf[4];
+          const double n10 = si * Tf[0] + co * Tf[3], n11 = si * Tf[1] + co * Tf[4];
+          Tf[0] = n00; Tf[1] = n01; Tf[3] = n10; Tf[4] = n11;
+        }
+        Tf[2] = n02; Tf[5] = n12;
       }
       state = TSD_ICP_PROCESSING;
     } else {
@@ -1415,15 +1440,21 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
     {
       // (every lane holds the same rms: the decisions as wave-uniform scalars, so that the loop is a scalar branch and not an
       // exec-mask loop over a per-lane `state`)
-      const int conv_hit = __builtin_amdgcn_readfirstlane((int)(fabs(rms - rms_prev) < 10e-10));
-      const int rms_done = __builtin_amdgcn_readfirstlane((int)(rms <= 0.0));
+      // (ONE hand-over from the vector to the scalar unit -- ~30 cycles each -- for "converged or exactly matched"; the counters behind it)
+      const bool hit = fabs(rms - rms_prev) < 10e-10, done = rms <= 0.0;
       state = __builtin_amdgcn_readfirstlane(state);
-      conv_cnt = conv_hit ? conv_cnt + 1 : 0;
-      if (rms_done || conv_cnt >= conv_need) state = TSD_ICP_SUCCESS;
-      else if (iter >= max_it) state = TSD_ICP_MAXITERATIONS;
+      if (UNLIKELY(__ballot(hit | done) != 0ull)) {
+        const int conv_hit = __ballot(hit) != 0ull, rms_done = __ballot(done) != 0ull;
+        conv_cnt = conv_hit ? conv_cnt + 1 : 0;
+        if (rms_done || conv_cnt >= conv_need) state = TSD_ICP_SUCCESS;
+        else if (iter >= max_it) state = TSD_ICP_MAXITERATIONS;
+      } else {
+        conv_cnt = 0;
+        if (iter >= max_it) state = TSD_ICP_MAXITERATIONS;
+      }
     }
     rms_prev = rms;
-    if (has_trace && tid == 0 && iter <= TSD_ICP_TRACE_MAX) {
+    if (UNLIKELY(has_trace && tid == 0 && iter <= TSD_ICP_TRACE_MAX)) {
       double* tr = L.tail->trace + TSD_ICP_TRACE_STRIDE * (iter - 1);
       tr[0] = (double)pairs; tr[1] = rms; tr[2] = thr_before; tr[3] = (double)state;
       tr[4] = co; tr[5] = si; tr[6] = dX; tr[7] = dY;          // Tlast = [[co, -si, dX], [si, co, dY]] (NaN: no estimate this step)
@@ -1443,6 +1474,13 @@ icp_workgroup(IcpArgs a, const double* __restrict__ P_dev, int cap_rt, const dou
     }
   }
 #endif
+  if (W > 1) {
+    // the rotation block of Tfinal from wave 0 (see the loop): through the reduction rows, idle by now
+    __syncthreads();
+    if (tid == 0) { L.red[0] = Tf[0]; L.red[1] = Tf[1]; L.red[2] = Tf[3]; L.red[3] = Tf[4]; }
+    __syncthreads();
+    Tf[0] = L.red[0]; Tf[1] = L.red[1]; Tf[3] = L.red[2]; Tf[4] = L.red[3];
+  }
   {
     // Icp::getFinalTransformation (Icp.cpp:528-546)
     IcpResultDev r;
