@@ -46,6 +46,7 @@ for k in range(n):
     ws = tr.reshape(-1)[(256 + 128) * 8: (256 + 128) * 8 + 30 * 8].reshape(30, 8)
     M, S, _ = lh.inputs if not FUSED else (np.zeros((0, 2)), np.zeros((0, 2)), None)
     ws_all[k] = ws.copy(); tl_all[k] = tl.copy()
+    hist_all = globals().setdefault('hist_all', {}); hist_all[k] = tr.reshape(-1)[(256 + 202) * 8: (256 + 202) * 8 + 16 * 21].copy()
     if FUSED:
         ws = np.zeros_like(ws)
     rows.append(dict(k=k, us=1e3 * ms / cnt, nM=len(M), nS=len(S), pairs=int(out["pairs"]), steps=steps, srch=srch,
@@ -87,6 +88,11 @@ hist = tr.reshape(-1)[(256 + 202) * 8: (256 + 202) * 8 + 16 * 21].reshape(16, 3,
 print("\nwindow-pass entries of the whole run by step (rows) and number of window rounds (1..7): resolved with a partner | resolved, nothing within the filter distance | unresolved (-> whole-wave search)")
 for it in range(16):
     print("   step %2d: %s | %s | %s" % (it, hist[it, 0].astype(int).tolist(), hist[it, 1].astype(int).tolist(), hist[it, 2].astype(int).tolist()))
+if 36 in hist_all and 57 in hist_all:
+    hd = (hist_all[57] - hist_all[36]).reshape(16, 3, 7)
+    print("\nthe same for scans 37..57 alone (the robot turns into space the map does not hold: the registration's tail), per registration:")
+    for it in range(16):
+        print("   step %2d: %s | %s | %s" % (it, np.round(hd[it, 0] / 21.0, 1).tolist(), np.round(hd[it, 1] / 21.0, 1).tolist(), np.round(hd[it, 2] / 21.0, 1).tolist()))
 print("\nthe slowest registrations:")
 for r in sorted(rows, key=lambda r: -r["us"])[:14]:
     print(f"scan {r['k']:3d}: {r['us']:6.1f} us, model {r['nM']}, scene {r['nS']}, pairs {r['pairs']}, search steps {r['srch']}")
