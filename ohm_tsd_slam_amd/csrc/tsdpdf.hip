@@ -195,6 +195,8 @@ k_pdf_argmax_batch(PdfArgmaxBatch b)
 // double unless the x87 chain's own rounding error crosses a rounding boundary, ~0.5 % of the means, 1 ulp then), and atan2 / cos / sin
 // are the device library's instead of glibc's.  Discrete outcomes (masks) can differ only for a point whose axis ratio sits within
 // ~1e-15 of its threshold.
+#define PDF_LIKELY(x) __builtin_expect(!!(x), 1)
+#define PDF_UNLIKELY(x) __builtin_expect(!!(x), 0)
 struct DD { double hi, lo; };
 __device__ __forceinline__ DD dd_quick_two_sum(double a, double b) { const double s = a + b; return DD{s, b - (s - a)}; }
 __device__ __forceinline__ DD dd_two_sum(double a, double b) { const double s = a + b, bb = s - a; return DD{s, (a - (s - bb)) + (b - bb)}; }
@@ -266,7 +268,7 @@ __device__ __forceinline__ void pdf_normals_body(const PdfNormalsSet& st, int po
     int k = 0;
 #pragma unroll
     for (int j = 0; j < NB; j++) {
-      if (!v_[j]) continue;
+      if (PDF_UNLIKELY(!v_[j])) continue;        // (most neighbours are there: the region sits in line, without a skip branch -- a branch is 14-30 cycles)
       k++;
       DD d = dd_two_sum(odd ? ay_[j] : ax_[j], -mean.hi);                  // x - mean
       d.lo -= mean.lo; d = dd_quick_two_sum(d.hi, d.lo);
@@ -282,7 +284,7 @@ __device__ __forceinline__ void pdf_normals_body(const PdfNormalsSet& st, int po
   for (int j = 0; j < NB; j++) { ax_[j] = ax_[j] + (-cent[0]); ay_[j] = ay_[j] + (-cent[1]); }      // mc (slots of masked-out neighbours: unused)
   double a = 0.0, b = 0.0, c = 0.0;
 #pragma unroll
-  for (int j = 0; j < NB; j++) if (v_[j]) { a += ax_[j] * ax_[j]; b += ax_[j] * ay_[j]; c += ay_[j] * ay_[j]; }
+  for (int j = 0; j < NB; j++) if (PDF_LIKELY(v_[j])) { a += ax_[j] * ax_[j]; b += ax_[j] * ay_[j]; c += ay_[j] * ay_[j]; }
   const double th = 0.5 * atan2(2.0 * b, a - c);
   const double V[2][2] = {{cos(th), -sin(th)}, {sin(th), cos(th)}};
   double mx[2], mn[2];
@@ -291,7 +293,7 @@ __device__ __forceinline__ void pdf_normals_body(const PdfNormalsSet& st, int po
     mx[q] = -__builtin_inf(); mn[q] = __builtin_inf();
 #pragma unroll
     for (int j = 0; j < NB; j++) {
-      if (!v_[j]) continue;
+      if (PDF_UNLIKELY(!v_[j])) continue;
       double pr = 0.0;
       pr += V[0][q] * ax_[j]; pr += V[1][q] * ay_[j];
       mx[q] = fmax(mx[q], pr); mn[q] = fmin(mn[q], pr);

@@ -14,6 +14,6 @@ for rep in 1 2 3; do for v in 2 1; do
 TSD_LIB_DIR=$GRAFT_REPO_ROOT/ohm_tsd_slam_amd/lib/diag_ab$v python3 bench.py --registration-mode 3 --steps 600 --warmup 20 --no-cpu-baseline --no-second-pass --no-stream 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read()); s=d['stages_ms']
-print('variant $v: %.0f scans/s | %s' % (d['value'], {k: round(1e3*v,2) for k,v in s.items()}))"
+print('variant $v: %.0f scans/s | %s' % (d['value'], {k: (round(1e3*v,2) if v is not None else None) for k,v in s.items()}))"
 done; done
 TSD_LIB_DIR=$GRAFT_REPO_ROOT/ohm_tsd_slam_amd/lib/diag_st python3 bench.py --registration-mode 3 --steps 20 --warmup 2 --no-cpu-baseline --no-second-pass --no-stream 2>/dev/null | grep -v "^{" | tail -12
